@@ -1,0 +1,361 @@
+/*
+ * rnaseqc_amd.h -- C ABI of the MI355X-native RNA-SeQC per-read hot path.
+ *
+ * The reference (getzlab/rnaseqc 2.4.3) has no plugin / FFI interface: its hot
+ * path is five C++ free functions called from the BAM loop of main()
+ * (src/RNASeQC.cpp:242-382, signatures in src/Expression.h:19-37) that mutate
+ * namespace-scope globals (src/Metrics.cpp:20-22, src/GTF.cpp:22-27).  This
+ * header is the batch-oriented C boundary that replaces that seam:
+ *
+ *   reference call site / state                         replaced by
+ *   --------------------------------------------------  -------------------------
+ *   GTF load into features/geneList/exonList/           rsqc_set_annotation()
+ *     exonsForGene/exonLengths  (src/RNASeQC.cpp:108-156,
+ *     src/GTF.cpp:30-131)
+ *   BED load (src/RNASeQC.cpp:172-187, src/BED.cpp:18)  rsqc_set_bed()
+ *   while (bam.next(alignment)) { gate cascade;         rsqc_submit() /
+ *     extractBlocks; trimFeatures;                      rsqc_submit_resident()
+ *     exonAlignmentMetrics; fragmentSizeMetrics }       (one call per SoA batch
+ *     (src/RNASeQC.cpp:242-382)                          of records, file order)
+ *   dropFeatures at EOF -> BaseCoverage::compute ->     rsqc_finalize()
+ *     computeCoverage/computeBias
+ *     (src/RNASeQC.cpp:385-388, src/Metrics.cpp:132-337)
+ *   geneCounts/uniqueGeneCounts/geneFragmentCounts/     rsqc_results
+ *     exonCounts/Metrics/BiasCounter/BaseCoverage
+ *     lists/fragmentSizes/readLength read by the
+ *     report writer (src/RNASeQC.cpp:397-676)
+ *
+ * Conventions: plain C, caller-owned inputs, library-owned outputs (valid
+ * until the next rsqc_finalize()/rsqc_destroy()), 0 = success, negative =
+ * error (no exceptions cross the boundary).  One context drives one GPU (one
+ * shard of contigs); contexts are independent, so a node runs one per GPU.
+ * All coordinates are as in the reference: features 1-based closed
+ * (src/GTF.h:29-37), record pos/mpos 0-based as in BAM (htslib core.pos).
+ */
+#ifndef RNASEQC_AMD_H
+#define RNASEQC_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSQC_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define RSQC_OK              0
+#define RSQC_ERR_ARG        -1   /* bad argument / call order                           */
+#define RSQC_ERR_HIP        -2   /* HIP runtime failure (maps to exit code 10)          */
+#define RSQC_ERR_BAD_CIGAR  -3   /* CIGAR op outside MIDNSHP=X: the reference throws
+                                    std::invalid_argument (src/Expression.cpp:61-63),
+                                    exit code 7                                         */
+#define RSQC_ERR_CAPACITY   -4   /* a fixed device-side capacity was exceeded            */
+#define RSQC_ERR_NO_DEVICE  -5   /* no HIP device: there is NO CPU fallback              */
+#define RSQC_ERR_EMPTY_MEDIAN -6 /* std::range_error of computeMedian (src/Metrics.h:149) */
+
+/* ---- BAM flag bits (SAM spec; accessors used at src/RNASeQC.cpp:254-330) */
+#define RSQC_FPAIRED   0x1
+#define RSQC_FPROPER   0x2
+#define RSQC_FUNMAP    0x4
+#define RSQC_FMUNMAP   0x8
+#define RSQC_FREVERSE  0x10
+#define RSQC_FMREVERSE 0x20
+#define RSQC_FREAD1    0x40
+#define RSQC_FREAD2    0x80
+#define RSQC_FSECONDARY 0x100
+#define RSQC_FQCFAIL   0x200
+#define RSQC_FDUP      0x400
+#define RSQC_FSUPP     0x800
+
+/* ---- tagbits byte of a record ------------------------------------------ */
+#define RSQC_TB_HAS_NM     0x01  /* GetIntTag("NM") succeeded (src/RNASeQC.cpp:295)      */
+#define RSQC_TB_HAS_CH     0x02  /* readStringTag(chimeric_tag): Z tag, or A tag with a
+                                    non-NUL char (src/RNASeQC.cpp:780-800)              */
+#define RSQC_TB_MTID_SAME  0x04  /* ChrID() == MateChrID() (src/RNASeQC.cpp:287)         */
+#define RSQC_TB_FILTER0    0x08  /* --tag k present (GetTag: Z, int or float type,
+                                    src/RNASeQC.cpp:320-327); k = 0..4 -> bits 3..7     */
+#define RSQC_MAX_FILTER_TAGS 5
+
+/* saturating narrow fields: a record whose nm/l_qseq/n_cigar does not fit is
+ * stored with the escape value and listed (index-sorted) in the wide table   */
+#define RSQC_NM_ESCAPE     0xFF
+#define RSQC_LQSEQ_ESCAPE  0xFFFF
+#define RSQC_NCIGAR_ESCAPE 0xFF
+
+/* ---- strandedness (reference enum Strand {Forward, Reverse, Unknown},
+ *      src/Fasta.h:41; --stranded FR -> Forward, RF -> Reverse,
+ *      src/RNASeQC.cpp:78-85) ------------------------------------------------ */
+#define RSQC_STRAND_FORWARD 0
+#define RSQC_STRAND_REVERSE 1
+#define RSQC_STRAND_UNKNOWN 2
+
+/* ---- feature flag byte --------------------------------------------------- */
+#define RSQC_FF_STRAND_MASK 0x03 /* RSQC_STRAND_*                                        */
+#define RSQC_FF_RIBOSOMAL   0x04 /* transcript_type contains "rRNA" (src/GTF.cpp:113)    */
+
+/* ---- scalar counters (Metrics keys, src/Metrics.cpp:344-384 and
+ *      src/RNASeQC.cpp:254-360, src/Expression.cpp:402-455) ------------------ */
+enum rsqc_counter {
+    RSQC_C_ALTERNATIVE_ALIGNMENTS = 0,
+    RSQC_C_SUPPLEMENTARY_ALIGNMENTS,
+    RSQC_C_FAILED_VENDOR_QC,
+    RSQC_C_LOW_MAPPING_QUALITY,
+    RSQC_C_CHIMERIC_AUTO,
+    RSQC_C_CHIMERIC_TAG,
+    RSQC_C_UNIQUE_VENDOR_PASSED,
+    RSQC_C_UNPAIRED_READS,
+    RSQC_C_MAPPED_READS,
+    RSQC_C_MAPPED_DUPLICATE_READS,
+    RSQC_C_MAPPED_UNIQUE_READS,
+    RSQC_C_TOTAL_MAPPED_PAIRS,
+    RSQC_C_END1_MAPPED_READS,
+    RSQC_C_END1_MISMATCHES,
+    RSQC_C_END1_BASES,
+    RSQC_C_DUPLICATE_PAIRS,
+    RSQC_C_UNIQUE_FRAGMENTS,
+    RSQC_C_END2_MAPPED_READS,
+    RSQC_C_END2_MISMATCHES,
+    RSQC_C_END2_BASES,
+    RSQC_C_MISMATCHED_BASES,
+    RSQC_C_TOTAL_BASES,
+    RSQC_C_HIGH_QUALITY_READS,
+    RSQC_C_LOW_QUALITY_READS,
+    RSQC_C_READS_USED,
+    RSQC_C_ALIGNMENT_BLOCKS,
+    RSQC_C_NON_GLOBIN_READS,
+    RSQC_C_NON_GLOBIN_DUPLICATE_READS,
+    RSQC_C_INTRONIC_READS,
+    RSQC_C_INTRAGENIC_READS,
+    RSQC_C_HQ_INTRONIC_READS,
+    RSQC_C_HQ_INTRAGENIC_READS,
+    RSQC_C_INTERGENIC_READS,
+    RSQC_C_HQ_INTERGENIC_READS,
+    RSQC_C_EXONIC_READS,
+    RSQC_C_HQ_EXONIC_READS,
+    RSQC_C_AMBIGUOUS_READS,
+    RSQC_C_HQ_AMBIGUOUS_READS,
+    RSQC_C_RRNA_READS,
+    RSQC_C_END1_SENSE,
+    RSQC_C_END1_ANTISENSE,
+    RSQC_C_END2_SENSE,
+    RSQC_C_END2_ANTISENSE,
+    RSQC_C_TOTAL_ALIGNMENTS,
+    RSQC_C_FILTERED_TAG0,          /* "Filtered by tag: X", one per --tag        */
+    RSQC_C_FILTERED_TAG1,
+    RSQC_C_FILTERED_TAG2,
+    RSQC_C_FILTERED_TAG3,
+    RSQC_C_FILTERED_TAG4,
+    RSQC_N_COUNTERS
+};
+
+/* ---- run parameters (flag table src/RNASeQC.cpp:39-65, defaults :87-100) - */
+typedef struct rsqc_params {
+    uint32_t abi_version;          /* RSQC_ABI_VERSION                                   */
+    int32_t  device;               /* HIP device ordinal                                 */
+    uint32_t mapq_threshold;       /* -q, 255                                            */
+    uint32_t base_mismatch;        /* --base-mismatch, 6                                 */
+    int32_t  chimeric_distance;    /* --chimeric-distance, 2000000                       */
+    uint32_t fragment_samples;     /* --fragment-samples, 1000000 (used iff BED is set)  */
+    int32_t  bias_offset;          /* --offset, 0                                        */
+    int32_t  bias_window;          /* --window-size, 100                                 */
+    uint64_t bias_gene_length;     /* --gene-length, 200                                 */
+    uint32_t coverage_mask;        /* --coverage-mask, 500                               */
+    int32_t  stranded;             /* RSQC_STRAND_*; UNKNOWN = unstranded                */
+    int32_t  unpaired;             /* -u                                                 */
+    int32_t  exclude_chimeric;     /* --exclude-chimeric                                 */
+    int32_t  n_filter_tags;        /* number of --tag filters carried in tagbits (<=5)   */
+    int32_t  reserved[7];
+} rsqc_params;
+
+/* ---- annotation: the flattened form of the reference's GTF state ----------
+ * Contig ids: [0, n_ref) are the BAM @SQ entries in header order (a record's
+ * tid); [n_ref, n_contigs) are contigs that only the GTF names (their genes
+ * still produce coverage rows at EOF, src/RNASeQC.cpp:385-386).
+ * Gene ids: [0, n_genes_listed) = geneList order (GTF order of `gene` rows,
+ * src/GTF.cpp:87); [n_genes_listed, n_genes) = gene_ids that only exon rows
+ * name (they are counted but never reported).  Exon ids = exonList order.
+ * Interval rows are sorted by (contig, start), ties in GTF order -- the
+ * reference's per-contig std::list::sort(compIntervalStart), stable
+ * (src/RNASeQC.cpp:150-152).  start <= end is required.                      */
+typedef struct rsqc_annotation {
+    int32_t n_ref, n_contigs;
+    int32_t n_genes, n_genes_listed, n_exons;
+
+    /* `gene` rows, sorted; n_gene_rows == n_genes_listed                      */
+    const int32_t  *gene_row_contig;   /* [n_genes_listed]                     */
+    const int32_t  *gene_row_start;    /* 1-based                              */
+    const int32_t  *gene_row_end;      /* 1-based closed                       */
+    const uint8_t  *gene_row_flags;    /* RSQC_FF_*                            */
+    const uint32_t *gene_row_id;       /* gene id of the row                   */
+
+    /* `exon` rows, sorted                                                      */
+    const int32_t  *exon_row_contig;   /* [n_exons]                            */
+    const int32_t  *exon_row_start;
+    const int32_t  *exon_row_end;
+    const uint8_t  *exon_row_flags;
+    const uint32_t *exon_row_id;       /* exon id (exonList index)             */
+    const uint32_t *exon_row_gene;     /* gene id named by the row's gene_id   */
+
+    /* per gene id                                                              */
+    const uint8_t  *gene_is_globin;    /* [n_genes] geneNames[gene] in the 12-name
+                                          blacklist (src/Expression.cpp:24,396-398) */
+    /* exonsForGene (src/RNASeQC.cpp:153-154): CSR over gene id -> sorted exon ROW
+       indices, in sorted order                                                 */
+    const uint32_t *gene_exon_off;     /* [n_genes + 1]                        */
+    const uint32_t *gene_exon_row;     /* [n_exons]                            */
+} rsqc_annotation;
+
+/* ---- BED intervals for the fragment-size sampler (src/BED.cpp:18-45):
+ * stored +1/+1 like the reference (start = bed_start+1, end = bed_end+1),
+ * per contig in file order, which must be ascending by start               */
+typedef struct rsqc_bed {
+    int32_t n_intervals;
+    const int32_t *contig;             /* contig id (same id space as above)   */
+    const int32_t *start;
+    const int32_t *end;
+} rsqc_bed;
+
+/* ---- one batch of alignment records, structure-of-arrays, file order ------
+ * 32 bytes per record + 4 bytes per CIGAR op.  Records of
+ * one contig form a segment; tid itself is not stored per record.           */
+typedef struct rsqc_batch {
+    uint64_t n;                        /* records                              */
+    uint64_t file_index_base;          /* index of record 0 in the whole file  */
+    const int32_t  *pos;               /* core.pos (0-based)                   */
+    const int32_t  *mpos;              /* core.mpos                            */
+    const int32_t  *isize;             /* core.isize                           */
+    const uint64_t *qhash;             /* 64-bit hash of QNAME                 */
+    const uint32_t *cigar_off;         /* [n] first op of record i in `cigar`  */
+    const uint16_t *flag;
+    const uint16_t *l_qseq;            /* core.l_qseq, RSQC_LQSEQ_ESCAPE=wide  */
+    const uint8_t  *mapq;
+    const uint8_t  *nm;                /* NM value, RSQC_NM_ESCAPE = wide      */
+    const uint8_t  *tagbits;           /* RSQC_TB_*                            */
+    const uint8_t  *n_cigar;           /* RSQC_NCIGAR_ESCAPE = wide            */
+    const uint32_t *cigar;             /* BAM packed ops: len<<4 | op          */
+    uint64_t n_cigar_total;
+
+    /* contig segments: records [seg_start[s], seg_start[s+1]) have tid seg_tid[s];
+       tid may be -1 (unplaced) or >= n_ref (unrecognised RefID)                */
+    uint32_t n_seg;
+    const int32_t  *seg_tid;           /* [n_seg]                              */
+    const uint64_t *seg_start;         /* [n_seg + 1]                          */
+
+    /* wide table for records carrying an escape value, ascending by index     */
+    uint32_t n_wide;
+    const uint64_t *wide_index;        /* record index within the batch        */
+    const int32_t  *wide_nm;
+    const int32_t  *wide_l_qseq;
+    const uint32_t *wide_n_cigar;
+
+    /* optional (may be NULL): exact QNAMEs, used only by the oracle to check
+       that hashing does not change the fragment de-duplication               */
+    const uint32_t *qname_off;         /* [n + 1]                              */
+    const char     *qname;
+} rsqc_batch;
+
+/* ---- results ---------------------------------------------------------------- */
+typedef struct rsqc_results {
+    int32_t  n_genes_listed, n_exons;
+    /* geneCounts / uniqueGeneCounts / geneFragmentCounts (src/Metrics.cpp:20) */
+    const uint64_t *gene_reads;        /* [n_genes_listed], geneList order     */
+    const uint64_t *gene_unique;
+    const uint64_t *gene_fragments;
+    /* exonCounts: sum of intersection/alignedLength (src/Expression.cpp:345,
+       src/Metrics.cpp:63); exon_hit != 0 iff the exon has a map entry (Q7)    */
+    const double   *exon_reads;        /* [n_exons], exonList order            */
+    const uint8_t  *exon_hit;
+    uint64_t counters[RSQC_N_COUNTERS];
+    int32_t  read_length;              /* "Read Length" (src/RNASeQC.cpp:275-278) */
+
+    /* BaseCoverage::compute per listed gene (src/Metrics.cpp:132-151,265-337):
+       coverage.tsv row (mean, std, cv); cov_valid == 0 -> row "0 0 nan" and the
+       gene is absent from geneMeans/Stds/CVs                                  */
+    const double   *gene_cov_mean;     /* [n_genes_listed]                     */
+    const double   *gene_cov_std;
+    const double   *gene_cov_cv;
+    const uint8_t  *gene_cov_valid;
+    /* per-exon CV (exon_cv.tsv): exon_cv_valid != 0 iff finite CV was stored  */
+    const double   *exon_cv;           /* [n_exons]                            */
+    const uint8_t  *exon_cv_valid;
+    /* BiasCounter accumulators (src/Metrics.h:76-77)                          */
+    const uint64_t *bias_three;        /* [n_genes_listed]                     */
+    const uint64_t *bias_five;
+
+    /* fragment size histogram (map<long long, unsigned long>), ascending size */
+    uint32_t n_fragment_sizes;
+    const int64_t  *fragment_size;
+    const uint64_t *fragment_count;
+    uint32_t fragment_samples_remaining;
+} rsqc_results;
+
+/* ---- timing of the device work (HIP events on the context's own stream) --- */
+typedef struct rsqc_timing {
+    double   classify_ms;              /* sum of K1 classify_count launches since reset */
+    uint64_t classify_launches;
+    uint64_t classify_records;
+    uint64_t classify_bytes;           /* algorithmic bytes: 32*n + 4*n_cigar_total     */
+    double   finalize_ms;              /* de-dup + coverage scan/stats + bias           */
+    double   h2d_ms;                   /* rsqc_submit host->device copies               */
+} rsqc_timing;
+
+typedef struct rsqc_ctx rsqc_ctx;
+
+/* Creates a context on params->device.  Fails with RSQC_ERR_NO_DEVICE when no
+ * HIP device is usable -- the product has no CPU path.                        */
+int rsqc_create(const rsqc_params *params, rsqc_ctx **out);
+void rsqc_destroy(rsqc_ctx *ctx);
+
+/* Copies the annotation into HBM and builds the device index.  `owned_contig`
+ * (n_contigs bytes, may be NULL = all) marks the contigs of this shard: only
+ * their genes get coverage/bias results (multi-GPU by contig).  */
+int rsqc_set_annotation(rsqc_ctx *ctx, const rsqc_annotation *ann,
+                        const uint8_t *owned_contig);
+int rsqc_set_bed(rsqc_ctx *ctx, const rsqc_bed *bed);
+
+/* Asynchronous: copies the batch H2D on the context's stream and launches the
+ * per-read kernels.  The batch memory must stay valid until rsqc_wait().
+ * Batches must be submitted in file order.                                    */
+int rsqc_submit(rsqc_ctx *ctx, const rsqc_batch *batch);
+int rsqc_wait(rsqc_ctx *ctx);
+
+/* Resident variant (what bench.py times): upload once, run many times.       */
+int rsqc_upload(rsqc_ctx *ctx, const rsqc_batch *batch, int *handle_out);
+int rsqc_submit_resident(rsqc_ctx *ctx, int handle);
+int rsqc_release(rsqc_ctx *ctx, int handle);
+
+/* End of file: fragment de-dup, coverage scan, per-gene coverage statistics and
+ * bias windows, fragment-size pairing; fills `out`.                           */
+int rsqc_finalize(rsqc_ctx *ctx, rsqc_results *out);
+
+/* Zeroes every accumulator (keeps annotation/BED and uploaded batches).       */
+int rsqc_reset(rsqc_ctx *ctx);
+
+int rsqc_get_timing(rsqc_ctx *ctx, rsqc_timing *out);
+int rsqc_reset_timing(rsqc_ctx *ctx);
+
+/* Device-resident raw accumulators for an in-place RCCL reduction by the host
+ * (torch.distributed).  Pointers are HIP device pointers owned by the ctx.
+ * Layout: u64 gene_reads[n_genes] | gene_unique[n_genes] | gene_fragments[n_genes]
+ * | counters[RSQC_N_COUNTERS] in one allocation; f64 exon_reads[n_exons] (row
+ * order) in another.  Valid after rsqc_finalize().                            */
+int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *u64_count,
+                             void **f64_base, uint64_t *f64_count);
+/* Re-reads the (reduced) device accumulators into the results struct.         */
+int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
+
+const char *rsqc_strerror(int code);
+const char *rsqc_last_error(rsqc_ctx *ctx);
+const char *rsqc_counter_name(int counter);   /* the reference's Metrics key  */
+const char *rsqc_version(void);               /* "RNASeQC 2.4.3 ..." prefix kept for
+                                                 python/rnaseqc/run.py:25     */
+
+/* QNAME hash used at the boundary (host decoders must use exactly this).     */
+uint64_t rsqc_qname_hash(const char *name, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNASEQC_AMD_H */

@@ -1,0 +1,204 @@
+"""ctypes mirror of include/rnaseqc_amd.h (the C ABI of the hot path).
+
+Nothing here computes: it only describes the structs and turns numpy arrays
+into the plain pointers the boundary takes.  Field order must match the header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+ABI_VERSION = 1
+
+# error codes
+OK, ERR_ARG, ERR_HIP, ERR_BAD_CIGAR, ERR_CAPACITY, ERR_NO_DEVICE, ERR_EMPTY_MEDIAN = 0, -1, -2, -3, -4, -5, -6
+
+# BAM flags
+FPAIRED, FPROPER, FUNMAP, FMUNMAP, FREVERSE, FMREVERSE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+FREAD1, FREAD2, FSECONDARY, FQCFAIL, FDUP, FSUPP = 0x40, 0x80, 0x100, 0x200, 0x400, 0x800
+
+TB_HAS_NM, TB_HAS_CH, TB_MTID_SAME, TB_FILTER0 = 0x01, 0x02, 0x04, 0x08
+MAX_FILTER_TAGS = 5
+NM_ESCAPE, LQSEQ_ESCAPE, NCIGAR_ESCAPE = 0xFF, 0xFFFF, 0xFF
+
+STRAND_FORWARD, STRAND_REVERSE, STRAND_UNKNOWN = 0, 1, 2
+FF_STRAND_MASK, FF_RIBOSOMAL = 0x03, 0x04
+
+# CIGAR op codes (BAM): MIDNSHP=XB
+CIG_M, CIG_I, CIG_D, CIG_N, CIG_S, CIG_H, CIG_P, CIG_EQ, CIG_X, CIG_B = range(10)
+
+COUNTER_NAMES = [
+    "Alternative Alignments", "Supplementary Alignments", "Failed Vendor QC", "Low Mapping Quality",
+    "Chimeric Fragments_auto", "Chimeric Fragments_tag", "Unique Mapping, Vendor QC Passed Reads",
+    "Unpaired Reads", "Mapped Reads", "Mapped Duplicate Reads", "Mapped Unique Reads",
+    "Total Mapped Pairs", "End 1 Mapped Reads", "End 1 Mismatches", "End 1 Bases", "Duplicate Pairs",
+    "Unique Fragments", "End 2 Mapped Reads", "End 2 Mismatches", "End 2 Bases", "Mismatched Bases",
+    "Total Bases", "High Quality Reads", "Low Quality Reads", "Reads used for Intron/Exon counts",
+    "Alignment Blocks", "Non-Globin Reads", "Non-Globin Duplicate Reads", "Intronic Reads",
+    "Intragenic Reads", "HQ Intronic Reads", "HQ Intragenic Reads", "Intergenic Reads",
+    "HQ Intergenic Reads", "Exonic Reads", "HQ Exonic Reads", "Ambiguous Reads", "HQ Ambiguous Reads",
+    "rRNA Reads", "End 1 Sense", "End 1 Antisense", "End 2 Sense", "End 2 Antisense",
+    "Total Alignments", "Filtered by tag: 0", "Filtered by tag: 1", "Filtered by tag: 2",
+    "Filtered by tag: 3", "Filtered by tag: 4",
+]
+N_COUNTERS = len(COUNTER_NAMES)
+COUNTER_INDEX = {n: i for i, n in enumerate(COUNTER_NAMES)}
+
+_P = C.c_void_p
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device", C.c_int32),
+        ("mapq_threshold", C.c_uint32), ("base_mismatch", C.c_uint32),
+        ("chimeric_distance", C.c_int32), ("fragment_samples", C.c_uint32),
+        ("bias_offset", C.c_int32), ("bias_window", C.c_int32),
+        ("bias_gene_length", C.c_uint64), ("coverage_mask", C.c_uint32),
+        ("stranded", C.c_int32), ("unpaired", C.c_int32), ("exclude_chimeric", C.c_int32),
+        ("n_filter_tags", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+def default_params(**kw) -> Params:
+    """Reference defaults, src/RNASeQC.cpp:87-100."""
+    p = Params()
+    p.abi_version = ABI_VERSION
+    p.device = 0
+    p.mapq_threshold = 255
+    p.base_mismatch = 6
+    p.chimeric_distance = 2000000
+    p.fragment_samples = 1000000
+    p.bias_offset = 0
+    p.bias_window = 100
+    p.bias_gene_length = 200
+    p.coverage_mask = 500
+    p.stranded = STRAND_UNKNOWN
+    p.unpaired = 0
+    p.exclude_chimeric = 0
+    p.n_filter_tags = 0
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class AnnotationStruct(C.Structure):
+    _fields_ = [
+        ("n_ref", C.c_int32), ("n_contigs", C.c_int32),
+        ("n_genes", C.c_int32), ("n_genes_listed", C.c_int32), ("n_exons", C.c_int32),
+        ("gene_row_contig", _P), ("gene_row_start", _P), ("gene_row_end", _P),
+        ("gene_row_flags", _P), ("gene_row_id", _P),
+        ("exon_row_contig", _P), ("exon_row_start", _P), ("exon_row_end", _P),
+        ("exon_row_flags", _P), ("exon_row_id", _P), ("exon_row_gene", _P),
+        ("gene_is_globin", _P), ("gene_exon_off", _P), ("gene_exon_row", _P),
+    ]
+
+
+class BedStruct(C.Structure):
+    _fields_ = [("n_intervals", C.c_int32), ("contig", _P), ("start", _P), ("end", _P)]
+
+
+class BatchStruct(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64), ("file_index_base", C.c_uint64),
+        ("pos", _P), ("mpos", _P), ("isize", _P), ("qhash", _P), ("cigar_off", _P),
+        ("flag", _P), ("l_qseq", _P), ("mapq", _P), ("nm", _P), ("tagbits", _P), ("n_cigar", _P),
+        ("cigar", _P), ("n_cigar_total", C.c_uint64),
+        ("n_seg", C.c_uint32), ("seg_tid", _P), ("seg_start", _P),
+        ("n_wide", C.c_uint32), ("wide_index", _P), ("wide_nm", _P), ("wide_l_qseq", _P),
+        ("wide_n_cigar", _P),
+        ("qname_off", _P), ("qname", _P),
+    ]
+
+
+class ResultsStruct(C.Structure):
+    _fields_ = [
+        ("n_genes_listed", C.c_int32), ("n_exons", C.c_int32),
+        ("gene_reads", _P), ("gene_unique", _P), ("gene_fragments", _P),
+        ("exon_reads", _P), ("exon_hit", _P),
+        ("counters", C.c_uint64 * N_COUNTERS),
+        ("read_length", C.c_int32),
+        ("gene_cov_mean", _P), ("gene_cov_std", _P), ("gene_cov_cv", _P), ("gene_cov_valid", _P),
+        ("exon_cv", _P), ("exon_cv_valid", _P),
+        ("bias_three", _P), ("bias_five", _P),
+        ("n_fragment_sizes", C.c_uint32), ("fragment_size", _P), ("fragment_count", _P),
+        ("fragment_samples_remaining", C.c_uint32),
+    ]
+
+
+class TimingStruct(C.Structure):
+    _fields_ = [
+        ("classify_ms", C.c_double), ("classify_launches", C.c_uint64),
+        ("classify_records", C.c_uint64), ("classify_bytes", C.c_uint64),
+        ("finalize_ms", C.c_double), ("h2d_ms", C.c_double),
+    ]
+
+
+def ptr(a: np.ndarray | None):
+    """numpy array -> void* (None -> NULL).  The caller keeps `a` alive."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "boundary arrays must be contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _view(p, n, dtype):
+    if not p or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(p)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Results:
+    """Host copy of an rsqc_results struct (library buffers are copied out)."""
+
+    def __init__(self, rs: ResultsStruct):
+        G, E = rs.n_genes_listed, rs.n_exons
+        self.gene_reads = _view(rs.gene_reads, G, np.uint64)
+        self.gene_unique = _view(rs.gene_unique, G, np.uint64)
+        self.gene_fragments = _view(rs.gene_fragments, G, np.uint64)
+        self.exon_reads = _view(rs.exon_reads, E, np.float64)
+        self.exon_hit = _view(rs.exon_hit, E, np.uint8)
+        self.counters = np.array(list(rs.counters), dtype=np.uint64)
+        self.read_length = int(rs.read_length)
+        self.gene_cov_mean = _view(rs.gene_cov_mean, G, np.float64)
+        self.gene_cov_std = _view(rs.gene_cov_std, G, np.float64)
+        self.gene_cov_cv = _view(rs.gene_cov_cv, G, np.float64)
+        self.gene_cov_valid = _view(rs.gene_cov_valid, G, np.uint8)
+        self.exon_cv = _view(rs.exon_cv, E, np.float64)
+        self.exon_cv_valid = _view(rs.exon_cv_valid, E, np.uint8)
+        self.bias_three = _view(rs.bias_three, G, np.uint64)
+        self.bias_five = _view(rs.bias_five, G, np.uint64)
+        nf = rs.n_fragment_sizes
+        self.fragment_size = _view(rs.fragment_size, nf, np.int64)
+        self.fragment_count = _view(rs.fragment_count, nf, np.uint64)
+        self.fragment_samples_remaining = int(rs.fragment_samples_remaining)
+
+    def counter(self, name: str) -> int:
+        return int(self.counters[COUNTER_INDEX[name]])
+
+    def counter_dict(self) -> dict:
+        return {n: int(self.counters[i]) for i, n in enumerate(COUNTER_NAMES)}
+
+
+def qname_hash_bytes(names: np.ndarray) -> np.ndarray:
+    """rsqc_qname_hash over a [n, width] uint8 matrix of fixed-width names
+    (FNV-1a 64 followed by the murmur3 fmix64 finaliser), vectorised."""
+    names = np.ascontiguousarray(names, dtype=np.uint8)
+    h = np.full(names.shape[0], 0xCBF29CE484222325, dtype=np.uint64)
+    prime = np.uint64(0x100000001B3)
+    with np.errstate(over="ignore"):
+        for j in range(names.shape[1]):
+            h ^= names[:, j].astype(np.uint64)
+            h *= prime
+        h ^= h >> np.uint64(33)
+        h *= np.uint64(0xFF51AFD7ED558CCD)
+        h ^= h >> np.uint64(33)
+        h *= np.uint64(0xC4CEB9FE1A85EC53)
+        h ^= h >> np.uint64(33)
+    return h
+
+
+def qname_hash(name: bytes) -> int:
+    return int(qname_hash_bytes(np.frombuffer(name, dtype=np.uint8)[None, :])[0])

@@ -1,0 +1,109 @@
+"""Hand-built inputs shared by the CPU (oracle) and GPU (HIP) tests.
+
+`quirk_case()` is a 22-record, 2-contig, 5-gene input whose expected outputs
+were derived BY HAND from the reference source (see the comments) -- they are
+not produced by any of our code.
+"""
+import numpy as np
+
+from rnaseqc_amd import abi
+from rnaseqc_amd.model import Annotation, Batch
+
+M, I, D, N, S = abi.CIG_M, abi.CIG_I, abi.CIG_D, abi.CIG_N, abi.CIG_S
+
+
+def quirk_annotation():
+    rows = [
+        dict(contig="chr1", type="gene", start=1000, end=5000, strand="+", gene_id="GA", gene_name="AAA", transcript_type="protein_coding"),
+        dict(contig="chr1", type="exon", start=1000, end=1200, strand="+", gene_id="GA", exon_id="GA_1", gene_name="AAA", transcript_type="protein_coding"),
+        dict(contig="chr1", type="exon", start=2000, end=2300, strand="+", gene_id="GA", exon_id="GA_2", gene_name="AAA", transcript_type="protein_coding"),
+        dict(contig="chr1", type="exon", start=4000, end=5000, strand="+", gene_id="GA", exon_id="GA_3", gene_name="AAA", transcript_type="protein_coding"),
+        dict(contig="chr1", type="gene", start=4500, end=8000, strand="-", gene_id="GB", gene_name="BBB", transcript_type="protein_coding"),
+        dict(contig="chr1", type="exon", start=4500, end=4800, strand="-", gene_id="GB", exon_id="GB_1", gene_name="BBB", transcript_type="protein_coding"),
+        dict(contig="chr1", type="exon", start=7000, end=8000, strand="-", gene_id="GB", exon_id="GB_2", gene_name="BBB", transcript_type="protein_coding"),
+        dict(contig="chr1", type="gene", start=10000, end=10500, strand="+", gene_id="GR", gene_name="RRR", transcript_type="rRNA"),
+        dict(contig="chr1", type="exon", start=10000, end=10500, strand="+", gene_id="GR", exon_id="GR_1", gene_name="RRR", transcript_type="rRNA"),
+        dict(contig="chr1", type="gene", start=12000, end=12600, strand="-", gene_id="GH", gene_name="HBB", transcript_type="protein_coding"),
+        dict(contig="chr1", type="exon", start=12000, end=12600, strand="-", gene_id="GH", exon_id="GH_1", gene_name="HBB", transcript_type="protein_coding"),
+        dict(contig="chr2", type="gene", start=100, end=2100, strand="+", gene_id="GC", gene_name="CCC", transcript_type="protein_coding"),
+        dict(contig="chr2", type="exon", start=100, end=2100, strand="+", gene_id="GC", exon_id="GC_1", gene_name="CCC", transcript_type="protein_coding"),
+    ]
+    return Annotation.from_rows(["chr1", "chr2"], rows)
+
+
+def quirk_records():
+    def rec(q, tid, pos, cigar, flag, mapq=255, nm=0, mpos=None, mtid=None, isize=0, **kw):
+        return dict(qname=q, tid=tid, pos=pos, cigar=cigar, flag=flag, mapq=mapq, nm=nm,
+                    mpos=pos if mpos is None else mpos, mtid=tid if mtid is None else mtid, isize=isize, **kw)
+    R = [
+        rec("p1", 0, 1049, [(M, 100)], 99, mpos=1079, isize=130),
+        rec("p1", 0, 1079, [(M, 100)], 147, mpos=1049, isize=-130),
+        rec("s1", 0, 1150, [(M, 50), (N, 800), (M, 50)], 99),
+        rec("s2", 0, 1150, [(M, 50), (N, 300), (M, 50)], 99),
+        rec("a1", 0, 1899, [(M, 100)], 99),
+        rec("i1", 0, 2999, [(M, 100)], 99),
+        rec("l1", 0, 4099, [(M, 100)], 99, mapq=3),
+        rec("n1", 0, 4199, [(M, 100)], 99, nm=8),
+        rec("d1", 0, 4299, [(M, 100)], 99 | 0x400),
+        rec("x1", 0, 4300, [(M, 100)], 99 | 0x100),
+        rec("x2", 0, 4301, [(M, 100)], 99 | 0x800),
+        rec("x3", 0, 4302, [(M, 100)], 99 | 0x200),
+        rec("k1", 0, 4399, [(S, 10), (M, 40), (I, 2), (M, 48), (D, 5), (M, 10)], 99),
+        rec("t1", 0, 4549, [(M, 100)], 99),
+        rec("g1", 0, 8999, [(M, 100)], 99),
+        rec("r1", 0, 10099, [(M, 100)], 99),
+        rec("h1", 0, 12099, [(M, 100)], 99),
+        rec("c1", 0, 12999, [(M, 100)], 97, mtid=1, mpos=500),
+        rec("u1", 1, 599, [(M, 100)], 99),
+        rec("u2", 1, 699, [(M, 100)], 99),
+        rec("u3", 1, 799, [(M, 100)], 99),
+        rec("um1", -1, -1, [], 77, mapq=0, nm=None, l_qseq=100),
+    ]
+    return R
+
+
+def quirk_case():
+    return quirk_annotation(), Batch.from_records(quirk_records())
+
+
+# ---- expected values, derived by hand from the reference source ----------------
+QUIRK_COUNTERS = {
+    "Total Alignments": 22,                       # src/RNASeQC.cpp:245,397
+    "Alternative Alignments": 1,                  # x1                                   :254
+    "Supplementary Alignments": 1,                # x2                                   :255
+    "Failed Vendor QC": 1,                        # x3                                   :256
+    "Low Mapping Quality": 2,                     # l1 (3 < 255) and the unmapped um1 (0) :257
+    "Chimeric Fragments_auto": 2,                 # x2 (SUP, no ch tag :258-260), c1 (mate on chr2 :287-289)
+    "Chimeric Fragments_tag": 0,
+    "Unique Mapping, Vendor QC Passed Reads": 19,  # 22 - x1 - x2 - x3                    :263-265
+    "Unpaired Reads": 0,
+    "Mapped Reads": 18,                           # - um1                                :268-270
+    "Mapped Duplicate Reads": 1,                  # d1
+    "Mapped Unique Reads": 17,
+    "Total Mapped Pairs": 17,                     # every mapped READ1 (all but p1/2)     :284-286
+    "End 1 Mapped Reads": 17, "End 2 Mapped Reads": 1,
+    "End 1 Mismatches": 8, "End 2 Mismatches": 0, "Mismatched Bases": 8,   # n1 has NM 8  :294-316
+    "End 1 Bases": 1710, "End 2 Bases": 100, "Total Bases": 1810,          # k1 has l_qseq 110
+    "Duplicate Pairs": 1, "Unique Fragments": 16,
+    "High Quality Reads": 15,                     # 18 - l1 (mapq) - n1 (NM>6) - c1 (not proper) :330
+    "Low Quality Reads": 3,
+    "Reads used for Intron/Exon counts": 18,
+    "Alignment Blocks": 22,                       # s1 2 + s2 2 + k1 3 + 15 x 1           :360
+    "Non-Globin Reads": 17,                       # all 18 but h1 (HBB)          Expression.cpp:395-404
+    "Non-Globin Duplicate Reads": 1,
+    "Exonic Reads": 13, "HQ Exonic Reads": 11,    # p1 p1 s1 l1 n1 d1 k1 t1 r1 h1 u1 u2 u3
+    "Ambiguous Reads": 2, "HQ Ambiguous Reads": 2,  # s2 (block in intron), a1 (touches exon start: Q1)
+    "Intronic Reads": 1, "HQ Intronic Reads": 1,  # i1
+    "Intergenic Reads": 2, "HQ Intergenic Reads": 1,  # g1, c1(not HQ)
+    "Intragenic Reads": 14, "HQ Intragenic Reads": 12,
+    "rRNA Reads": 1,
+    "End 1 Sense": 12, "End 1 Antisense": 1,      # h1: forward read on a '-' gene
+    "End 2 Sense": 0, "End 2 Antisense": 1,       # p1/2: reverse read on a '+' gene
+}
+# geneList order: GA GB GR GH GC
+QUIRK_GENE_READS = [6, 1, 1, 1, 3]       # GA: p1 p1 s1 d1 k1 t1; t1 also counts for GB (Q2)
+QUIRK_GENE_UNIQUE = [5, 1, 1, 1, 3]      # d1 is a duplicate
+QUIRK_GENE_FRAGMENTS = [5, 1, 1, 1, 3]   # p1's two mates are one fragment
+# exonList order: GA_1 GA_2 GA_3 GB_1 GB_2 GR_1 GH_1 GC_1
+QUIRK_EXON_READS = [2.5, 0.5, 3.0, 1.0, 0.0, 1.0, 1.0, 3.0]
+QUIRK_READ_LENGTH = 110                  # k1: span 103 > 100 -> l_qseq 110 (Q3)

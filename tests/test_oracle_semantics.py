@@ -1,0 +1,96 @@
+"""The CPU oracle against expectations derived by hand from the reference source."""
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi
+from tests import cases
+
+
+def test_quirk_case_counters(oracle_lib):
+    ann, batch = cases.quirk_case()
+    r = oracle_lib.run_oracle(abi.default_params(), ann, [batch])
+    got = r.counter_dict()
+    for k, v in cases.QUIRK_COUNTERS.items():
+        assert got[k] == v, (k, got[k], v)
+    assert list(r.gene_reads) == cases.QUIRK_GENE_READS
+    assert list(r.gene_unique) == cases.QUIRK_GENE_UNIQUE
+    assert list(r.gene_fragments) == cases.QUIRK_GENE_FRAGMENTS
+    np.testing.assert_allclose(r.exon_reads, cases.QUIRK_EXON_READS, atol=1e-12)
+    assert list(r.exon_hit) == [1, 1, 1, 1, 0, 1, 1, 1]
+    assert r.read_length == cases.QUIRK_READ_LENGTH
+
+
+def test_quirk_case_coverage(oracle_lib):
+    ann, batch = cases.quirk_case()
+    r = oracle_lib.run_oracle(abi.default_params(), ann, [batch])
+    # GA: coding 1503; mask leaves GA_2[299..300] + GA_3[0..500]; ones = d1 100 + k1 88 + k1 8
+    assert list(r.gene_cov_valid) == [1, 1, 0, 0, 1]
+    m = 196 / 503
+    assert r.gene_cov_mean[0] == pytest.approx(m, rel=1e-12)
+    assert r.gene_cov_std[0] == pytest.approx(np.sqrt(m * (1 - m)), rel=1e-12)
+    assert r.gene_cov_cv[0] == pytest.approx(np.sqrt(m * (1 - m)) / m, rel=1e-12)
+    # GB: only GB_1 covered, which the 500-base mask removes -> mean 0, std 0, cv nan
+    assert r.gene_cov_mean[1] == 0 and r.gene_cov_std[1] == 0 and np.isnan(r.gene_cov_cv[1])
+    # GC: 2001 bases, mask leaves [500,1501): three adjacent reads cover [500,800)
+    m = 300 / 1001
+    assert r.gene_cov_mean[4] == pytest.approx(m, rel=1e-12)
+    assert r.gene_cov_cv[4] == pytest.approx(np.sqrt(m * (1 - m)) / m, rel=1e-12)
+    # exon CVs: only GA_3 and GC_1 have a finite CV
+    assert list(r.exon_cv_valid) == [0, 0, 1, 0, 0, 0, 0, 1]
+    m3 = 196 / 501
+    assert r.exon_cv[2] == pytest.approx(np.sqrt(m3 * (1 - m3)) / m3, rel=1e-12)
+    assert not r.bias_three.any() and not r.bias_five.any()
+
+
+def test_quirk_case_batch_split_invariance(oracle_lib):
+    ann, batch = cases.quirk_case()
+    whole = oracle_lib.run_oracle(abi.default_params(), ann, [batch])
+    parts = [batch.slice(0, 5), batch.slice(5, 6), batch.slice(6, 19), batch.slice(19, batch.n)]
+    split = oracle_lib.run_oracle(abi.default_params(), ann, parts)
+    assert (whole.counters == split.counters).all()
+    assert (whole.gene_fragments == split.gene_fragments).all()
+    np.testing.assert_array_equal(whole.exon_reads, split.exon_reads)
+    np.testing.assert_array_equal(whole.gene_cov_mean, split.gene_cov_mean)
+
+
+def test_quirky_median(oracle_lib):
+    # src/Metrics.h:147-160: odd n -> mean of [mid],[mid+1]; even n -> [mid]
+    assert oracle_lib.median([5.0]) == 5.0
+    assert oracle_lib.median([1.0, 2.0]) == 1.0
+    assert oracle_lib.median([1.0, 2.0, 4.0]) == 3.0
+    assert oracle_lib.median([1.0, 2.0, 4.0, 8.0]) == 2.0
+    assert oracle_lib.median([1.0, 2.0, 4.0, 8.0, 16.0]) == 6.0
+    with pytest.raises(oracle_lib.OracleError):
+        oracle_lib.median([])
+
+
+def test_exclude_chimeric_and_tags(oracle_lib):
+    ann, _ = cases.quirk_case()
+    recs = cases.quirk_records()
+    recs[5]["tags"] = [True]           # i1 carries the --tag
+    recs[7]["ch"] = True               # n1 carries the chimeric tag (READ1)
+    from rnaseqc_amd.model import Batch
+    b = Batch.from_records(recs)
+    r = oracle_lib.run_oracle(abi.default_params(n_filter_tags=1, exclude_chimeric=1), ann, [b])
+    c = r.counter_dict()
+    assert c["Filtered by tag: 0"] == 1
+    assert c["Chimeric Fragments_tag"] == 1
+    assert c["Chimeric Fragments_auto"] == 2
+    # i1 filtered by tag, n1 (ch tag) and c1 (mate elsewhere) excluded as chimeric
+    assert c["Reads used for Intron/Exon counts"] == 18 - 3
+    assert c["Intronic Reads"] == 0
+    assert c["Mapped Reads"] == 18     # the exclusions happen after the mapped counters
+    assert c["Total Bases"] == 1810 - 200   # n1 and c1 leave before :317; i1 does not
+
+
+def test_stranded(oracle_lib):
+    ann, batch = cases.quirk_case()
+    # --stranded RF: READ1 forward -> feature strand Reverse (Expression.cpp:119-125)
+    r = oracle_lib.run_oracle(abi.default_params(stranded=abi.STRAND_REVERSE), ann, [batch])
+    c = r.counter_dict()
+    # p1/1 is forward READ1 -> looks only at '-' features: GA is '+', so it is intergenic now;
+    # p1/2 is reverse READ2 -> target = !(rev) .. = '-' as well.  h1 (forward READ1) sees GH ('-').
+    assert list(r.gene_reads) == [0, 1, 0, 1, 0]
+    assert c["End 1 Sense"] == 0 and c["End 1 Antisense"] == 3   # t1 and k1 (last block touches GB_1) on GB, h1 on GH
+    r2 = oracle_lib.run_oracle(abi.default_params(stranded=abi.STRAND_FORWARD), ann, [batch])
+    assert list(r2.gene_reads) == [6, 0, 1, 0, 3]
