@@ -134,3 +134,82 @@ def statistics(values):
 
 def library_complexity(dup, unique, limit=1e9) -> int:
     return int(lib().oracle_library_complexity(float(dup), float(unique), float(limit)))
+
+
+# ---------------------------------------------------------------------------
+# oracle/_ref/libref_metrics.so: the reference's own src/Metrics.cpp (see
+# ref_metrics_harness.cpp).  Present only where /root/reference was available
+# at build time (this container); it travels to the GPU box as a built file.
+_REF_SO = os.path.join(_HERE, "_ref", "libref_metrics.so")
+_ref = None
+
+
+def build_ref() -> bool:
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return os.path.exists(_REF_SO)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        if not os.path.exists(_REF_SO):
+            return None
+        _ref = C.CDLL(_REF_SO)
+        _ref.ref_median.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+        _ref.ref_statistics.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+        _ref.ref_statistics.restype = None
+        _ref.ref_metrics_print.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p]
+        _ref.ref_frac.argtypes = [C.c_uint64, C.c_uint64]
+        _ref.ref_frac.restype = C.c_double
+        _ref.ref_coverage_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int,
+                                          C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+    return _ref
+
+
+def ref_median(values):
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    out = C.c_double()
+    rc = ref_lib().ref_median(abi.ptr(a), len(a), C.byref(out))
+    if rc:
+        raise OracleError(rc, "reference computeMedian threw range_error")
+    return out.value
+
+
+def ref_statistics(values):
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    out = (C.c_double * 4)()
+    ref_lib().ref_statistics(abi.ptr(a), len(a), out)
+    return tuple(out)
+
+
+def ref_metrics_print(counter_dict, path):
+    names = list(counter_dict.keys())
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    vals = np.array([counter_dict[n] for n in names], dtype=np.uint64)
+    rc = ref_lib().ref_metrics_print(len(names), arr, abi.ptr(vals), path.encode())
+    if rc:
+        raise OracleError(rc, "ref_metrics_print")
+
+
+def ref_coverage_run(gene_exon_off, exon_len, gene_strand, commit_exon, commit_off, commit_len, commit_read,
+                     mask=500, bias_offset=0, bias_window=100, bias_gene_length=200, coverage_tsv=None):
+    G = len(gene_exon_off) - 1
+    E = int(gene_exon_off[-1])
+    a = [np.ascontiguousarray(gene_exon_off, np.uint32), np.ascontiguousarray(exon_len, np.int64),
+         np.ascontiguousarray(gene_strand, np.int32), np.ascontiguousarray(commit_exon, np.uint32),
+         np.ascontiguousarray(commit_off, np.int64), np.ascontiguousarray(commit_len, np.uint32),
+         np.ascontiguousarray(commit_read, np.uint32)]
+    out = dict(gene_valid=np.zeros(G, np.uint8), gene_mean=np.zeros(G), gene_std=np.zeros(G), gene_cv=np.zeros(G),
+               exon_cv_valid=np.zeros(E, np.uint8), exon_cv=np.zeros(E), bias_ratio=np.zeros(G))
+    rc = ref_lib().ref_coverage_run(G, abi.ptr(a[0]), abi.ptr(a[1]), abi.ptr(a[2]), len(a[3]), abi.ptr(a[3]),
+                                    abi.ptr(a[4]), abi.ptr(a[5]), abi.ptr(a[6]), mask, bias_offset, bias_window,
+                                    bias_gene_length, abi.ptr(out["gene_valid"]), abi.ptr(out["gene_mean"]),
+                                    abi.ptr(out["gene_std"]), abi.ptr(out["gene_cv"]), abi.ptr(out["exon_cv_valid"]),
+                                    abi.ptr(out["exon_cv"]), abi.ptr(out["bias_ratio"]),
+                                    coverage_tsv.encode() if coverage_tsv else None)
+    if rc < 0:
+        raise OracleError(rc, "reference coverage path threw")
+    out["counted_genes"] = rc
+    return out
