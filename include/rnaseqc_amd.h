@@ -44,6 +44,12 @@ extern "C" {
 
 #define RSQC_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define RSQC_API __attribute__((visibility("default")))
+#else
+#define RSQC_API
+#endif
+
 /* ---- error codes ------------------------------------------------------- */
 #define RSQC_OK              0
 #define RSQC_ERR_ARG        -1   /* bad argument / call order                           */
@@ -305,55 +311,55 @@ typedef struct rsqc_ctx rsqc_ctx;
 
 /* Creates a context on params->device.  Fails with RSQC_ERR_NO_DEVICE when no
  * HIP device is usable -- the product has no CPU path.                        */
-int rsqc_create(const rsqc_params *params, rsqc_ctx **out);
-void rsqc_destroy(rsqc_ctx *ctx);
+RSQC_API int rsqc_create(const rsqc_params *params, rsqc_ctx **out);
+RSQC_API void rsqc_destroy(rsqc_ctx *ctx);
 
 /* Copies the annotation into HBM and builds the device index.  `owned_contig`
  * (n_contigs bytes, may be NULL = all) marks the contigs of this shard: only
  * their genes get coverage/bias results (multi-GPU by contig).  */
-int rsqc_set_annotation(rsqc_ctx *ctx, const rsqc_annotation *ann,
+RSQC_API int rsqc_set_annotation(rsqc_ctx *ctx, const rsqc_annotation *ann,
                         const uint8_t *owned_contig);
-int rsqc_set_bed(rsqc_ctx *ctx, const rsqc_bed *bed);
+RSQC_API int rsqc_set_bed(rsqc_ctx *ctx, const rsqc_bed *bed);
 
 /* Asynchronous: copies the batch H2D on the context's stream and launches the
  * per-read kernels.  The batch memory must stay valid until rsqc_wait().
  * Batches must be submitted in file order.                                    */
-int rsqc_submit(rsqc_ctx *ctx, const rsqc_batch *batch);
-int rsqc_wait(rsqc_ctx *ctx);
+RSQC_API int rsqc_submit(rsqc_ctx *ctx, const rsqc_batch *batch);
+RSQC_API int rsqc_wait(rsqc_ctx *ctx);
 
 /* Resident variant (what bench.py times): upload once, run many times.       */
-int rsqc_upload(rsqc_ctx *ctx, const rsqc_batch *batch, int *handle_out);
-int rsqc_submit_resident(rsqc_ctx *ctx, int handle);
-int rsqc_release(rsqc_ctx *ctx, int handle);
+RSQC_API int rsqc_upload(rsqc_ctx *ctx, const rsqc_batch *batch, int *handle_out);
+RSQC_API int rsqc_submit_resident(rsqc_ctx *ctx, int handle);
+RSQC_API int rsqc_release(rsqc_ctx *ctx, int handle);
 
 /* End of file: fragment de-dup, coverage scan, per-gene coverage statistics and
  * bias windows, fragment-size pairing; fills `out`.                           */
-int rsqc_finalize(rsqc_ctx *ctx, rsqc_results *out);
+RSQC_API int rsqc_finalize(rsqc_ctx *ctx, rsqc_results *out);
 
 /* Zeroes every accumulator (keeps annotation/BED and uploaded batches).       */
-int rsqc_reset(rsqc_ctx *ctx);
+RSQC_API int rsqc_reset(rsqc_ctx *ctx);
 
-int rsqc_get_timing(rsqc_ctx *ctx, rsqc_timing *out);
-int rsqc_reset_timing(rsqc_ctx *ctx);
+RSQC_API int rsqc_get_timing(rsqc_ctx *ctx, rsqc_timing *out);
+RSQC_API int rsqc_reset_timing(rsqc_ctx *ctx);
 
 /* Device-resident raw accumulators for an in-place RCCL reduction by the host
  * (torch.distributed).  Pointers are HIP device pointers owned by the ctx.
  * Layout: u64 gene_reads[n_genes] | gene_unique[n_genes] | gene_fragments[n_genes]
  * | counters[RSQC_N_COUNTERS] in one allocation; f64 exon_reads[n_exons] (row
  * order) in another.  Valid after rsqc_finalize().                            */
-int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *u64_count,
+RSQC_API int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *u64_count,
                              void **f64_base, uint64_t *f64_count);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
-int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
+RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
 
-const char *rsqc_strerror(int code);
-const char *rsqc_last_error(rsqc_ctx *ctx);
-const char *rsqc_counter_name(int counter);   /* the reference's Metrics key  */
-const char *rsqc_version(void);               /* "RNASeQC 2.4.3 ..." prefix kept for
+RSQC_API const char *rsqc_strerror(int code);
+RSQC_API const char *rsqc_last_error(rsqc_ctx *ctx);
+RSQC_API const char *rsqc_counter_name(int counter);   /* the reference's Metrics key  */
+RSQC_API const char *rsqc_version(void);               /* "RNASeQC 2.4.3 ..." prefix kept for
                                                  python/rnaseqc/run.py:25     */
 
 /* QNAME hash used at the boundary (host decoders must use exactly this).     */
-uint64_t rsqc_qname_hash(const char *name, size_t len);
+RSQC_API uint64_t rsqc_qname_hash(const char *name, size_t len);
 
 #ifdef __cplusplus
 }

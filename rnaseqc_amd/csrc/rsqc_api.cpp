@@ -1,0 +1,674 @@
+// rsqc_api.cpp -- the C ABI of include/rnaseqc_amd.h on top of the HIP kernels.
+//
+// One context = one GPU = one shard of contigs.  Everything the per-record path reads
+// (annotation index, uploaded batches) and writes (count vectors, per-base coverage,
+// de-dup tables) stays resident in HBM; the host only builds the index once, enqueues
+// work on the context's stream and reads the small result vectors back at end of file.
+// There is no CPU fallback: without a HIP device rsqc_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rsqc_device.h"
+#include "rsqc_index.h"
+
+using namespace rsqc;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct UploadedBatch {
+    DevBatch d{};
+    std::vector<DevBuf> bufs;
+    uint64_t n = 0, n_cigar_total = 0;
+    bool in_use = false;
+};
+
+struct PairBuf {
+    DevBuf gene, hash, count;
+    uint32_t cap = 0;
+    bool used = false;
+};
+
+}  // namespace
+
+struct rsqc_ctx {
+    rsqc_params params{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int sticky = 0;
+
+    // annotation (host copies needed at finalize)
+    bool have_ann = false;
+    int32_t n_ref = 0, n_contigs = 0, n_genes = 0, n_listed = 0, n_exons = 0;
+    std::vector<uint32_t> exon_row_id;          // row -> exon id
+    std::vector<DevBuf> ann_bufs;
+    DevAnnotation dann{};
+    DevParams dparams{};
+    // K3 inputs
+    const uint32_t *d_ge_off = nullptr, *d_ge_row = nullptr, *d_gene_cov_off = nullptr, *d_gene_coding = nullptr;
+    const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
+    uint64_t cov_entries = 0;
+    bool have_bed = false;
+
+    // accumulators
+    DevBuf d_u64, d_exon_acc, d_cov, d_misc, d_ovf_index, d_tiles;
+    DevAccum acc{};
+    uint64_t tile_cap = 0;
+    std::vector<PairBuf> pair_pool;
+    std::vector<size_t> pairs_in_flight;        // indices into pair_pool, submission order
+    DevBuf d_table, d_tab_off, d_tab_cap;
+    // K3 outputs
+    DevBuf d_gmean, d_gstd, d_gcv, d_gvalid, d_ecv, d_ecv_valid, d_bias3, d_bias5;
+    bool finalized = false;
+
+    // batches
+    std::vector<UploadedBatch *> resident;
+    std::vector<UploadedBatch *> transient;     // owned by submit(), freed at wait()
+    uint64_t next_record_base = 0;
+
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> k1_events;
+    std::vector<hipEvent_t> event_pool;
+    rsqc_timing timing{};
+
+    // host results
+    std::vector<uint64_t> h_reads, h_unique, h_frag, h_bias3, h_bias5, h_fcount;
+    std::vector<double> h_exon, h_gmean, h_gstd, h_gcv, h_ecv;
+    std::vector<uint8_t> h_exon_hit, h_gvalid, h_ecv_valid;
+    std::vector<int64_t> h_fsize;
+    std::vector<uint64_t> h_u64;
+    std::vector<double> h_exon_rows;
+    rsqc_results results{};
+};
+
+namespace {
+
+int fail(rsqc_ctx *c, int code, const std::string &msg) {
+    if (c) { c->last_error = msg; }
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), RSQC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+int dev_alloc(rsqc_ctx *c, DevBuf &b, size_t bytes, bool zero) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes < bytes) {
+        b.release();
+        HIP_TRY(c, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    if (zero) HIP_TRY(c, hipMemsetAsync(b.p, 0, b.bytes, c->stream));
+    return 0;
+}
+
+template <class T>
+int upload(rsqc_ctx *c, std::vector<DevBuf> &owner, const T *host, size_t n, const T **out) {
+    DevBuf b;
+    size_t bytes = n * sizeof(T);
+    HIP_TRY(c, hipMalloc(&b.p, bytes ? bytes : 16));
+    b.bytes = bytes ? bytes : 16;
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    owner.push_back(b);
+    *out = (const T *)b.p;
+    return 0;
+}
+
+hipEvent_t get_event(rsqc_ctx *c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int check_device_error(rsqc_ctx *c) {
+    int err = 0;
+    HIP_TRY(c, hipMemcpy(&err, c->acc.error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        c->sticky = err;
+        return fail(c, err, err == RSQC_ERR_BAD_CIGAR ? "Unrecognized Cigar Op" :
+                            err == RSQC_ERR_CAPACITY ? "a device-side capacity was exceeded" :
+                            err == RSQC_ERR_EMPTY_MEDIAN ? "Cannot compute median of an empty list" : "device error");
+    }
+    return 0;
+}
+
+int resolve_events(rsqc_ctx *c) {
+    for (auto &pr : c->k1_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->timing.classify_ms += ms;
+        c->event_pool.push_back(pr.first); c->event_pool.push_back(pr.second);
+    }
+    c->k1_events.clear();
+    return 0;
+}
+
+int zero_accumulators(rsqc_ctx *c) {
+    HIP_TRY(c, hipMemsetAsync(c->d_u64.p, 0, c->d_u64.bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_exon_acc.p, 0, c->d_exon_acc.bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_cov.p, 0, c->d_cov.bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_misc.p, 0, c->d_misc.bytes, c->stream));
+    for (auto &pb : c->pair_pool) pb.used = false;
+    c->pairs_in_flight.clear();
+    c->finalized = false;
+    c->next_record_base = 0;
+    c->sticky = 0;
+    return 0;
+}
+
+int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u) {
+    if (b->n > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large");
+    DevBatch &d = u->d;
+    d.n = b->n; d.n_seg = b->n_seg; d.n_wide = b->n_wide;
+    u->n = b->n; u->n_cigar_total = b->n_cigar_total;
+    int rc;
+#define UP(field, count) if ((rc = upload(c, u->bufs, b->field, (size_t)(count), &d.field))) return rc
+    UP(pos, b->n); UP(mpos, b->n); UP(isize, b->n); UP(qhash, b->n); UP(cigar_off, b->n);
+    UP(flag, b->n); UP(l_qseq, b->n); UP(mapq, b->n); UP(nm, b->n); UP(tagbits, b->n); UP(n_cigar, b->n);
+    UP(cigar, b->n_cigar_total);
+    UP(seg_tid, b->n_seg); UP(seg_start, (size_t)b->n_seg + 1);
+    UP(wide_index, b->n_wide); UP(wide_nm, b->n_wide); UP(wide_l_qseq, b->n_wide); UP(wide_n_cigar, b->n_wide);
+#undef UP
+    return 0;
+}
+
+void free_batch(UploadedBatch *u) {
+    for (auto &b : u->bufs) b.release();
+    delete u;
+}
+
+PairBuf *acquire_pairs(rsqc_ctx *c, uint32_t cap, size_t *index) {
+    for (size_t i = 0; i < c->pair_pool.size(); ++i)
+        if (!c->pair_pool[i].used && c->pair_pool[i].cap >= cap) { c->pair_pool[i].used = true; *index = i; return &c->pair_pool[i]; }
+    PairBuf pb;
+    if (hipMalloc(&pb.gene.p, (size_t)cap * 4) != hipSuccess) return nullptr;
+    if (hipMalloc(&pb.hash.p, (size_t)cap * 8) != hipSuccess) return nullptr;
+    if (hipMalloc(&pb.count.p, 16) != hipSuccess) return nullptr;
+    pb.cap = cap; pb.used = true;
+    c->pair_pool.push_back(pb);
+    *index = c->pair_pool.size() - 1;
+    return &c->pair_pool.back();
+}
+
+int run_batch(rsqc_ctx *c, UploadedBatch *u) {
+    if (!c->have_ann) return fail(c, RSQC_ERR_ARG, "rsqc_set_annotation must precede rsqc_submit");
+    if (c->finalized) return fail(c, RSQC_ERR_ARG, "rsqc_reset required after rsqc_finalize");
+    if (u->n == 0) return 0;
+    const uint64_t tiles = (u->n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
+    if (tiles > c->tile_cap) {
+        c->tile_cap = tiles + tiles / 4 + 64;
+        int rc = dev_alloc(c, c->d_tiles, c->tile_cap * 3 * sizeof(uint32_t), false);
+        if (rc) return rc;
+        c->acc.tile_span = (uint32_t *)c->d_tiles.p;
+        c->acc.tile_lmin = c->acc.tile_span + c->tile_cap;
+        c->acc.tile_lmax = c->acc.tile_lmin + c->tile_cap;
+    }
+    // (gene, qname-hash) pairs of this batch: at most 2 per record on average
+    const uint64_t want = 2 * u->n + 1024;
+    if (want > 0xFFFFFFFFull) return fail(c, RSQC_ERR_ARG, "batch too large");
+    size_t pidx = 0;
+    PairBuf *pb = acquire_pairs(c, (uint32_t)want, &pidx);
+    if (!pb) return fail(c, RSQC_ERR_HIP, "hipMalloc(pair buffer) failed");
+    c->pairs_in_flight.push_back(pidx);
+    HIP_TRY(c, hipMemsetAsync(pb->count.p, 0, 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->acc.ovf_count, 0, sizeof(uint32_t), c->stream));
+    DevAccum acc = c->acc;
+    acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p;
+    acc.pair_count = (uint32_t *)pb->count.p; acc.pair_cap = pb->cap;
+    DevBatch d = u->d;
+    d.record_base = c->next_record_base;
+    d.tile_base = 0;
+    c->next_record_base += u->n;
+    int grid = (int)std::min<uint64_t>(tiles, 256ull * 8ull);
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    launch_classify(c->stream, grid, c->dann, c->dparams, d, acc);
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    c->k1_events.emplace_back(e0, e1);
+    launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
+    launch_read_length(c->stream, c->dann, c->dparams, d, acc);
+    HIP_TRY(c, hipGetLastError());
+    c->timing.classify_launches += 1;
+    c->timing.classify_records += u->n;
+    c->timing.classify_bytes += 32ull * u->n + 4ull * u->n_cigar_total;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ API
+
+extern "C" {
+
+int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
+    if (!params || !out) return RSQC_ERR_ARG;
+    if (params->abi_version != RSQC_ABI_VERSION) return RSQC_ERR_ARG;
+    if (params->n_filter_tags < 0 || params->n_filter_tags > RSQC_MAX_FILTER_TAGS) return RSQC_ERR_ARG;
+    if (params->bias_offset < 0 || params->bias_window < 1 || params->bias_window > RSQC_MAX_BIAS_WINDOW) return RSQC_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RSQC_ERR_NO_DEVICE;
+    if (params->device < 0 || params->device >= ndev) return RSQC_ERR_NO_DEVICE;
+    rsqc_ctx *c = new rsqc_ctx();
+    c->params = *params;
+    c->device = params->device;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RSQC_ERR_HIP;
+    }
+    c->dparams.mapq_threshold = params->mapq_threshold;
+    c->dparams.base_mismatch = params->base_mismatch;
+    c->dparams.chimeric_distance = params->chimeric_distance;
+    c->dparams.stranded = params->stranded;
+    c->dparams.unpaired = params->unpaired;
+    c->dparams.exclude_chimeric = params->exclude_chimeric;
+    c->dparams.n_filter_tags = params->n_filter_tags;
+    *out = c;
+    return RSQC_OK;
+}
+
+void rsqc_destroy(rsqc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto *u : c->resident) if (u) free_batch(u);
+    for (auto *u : c->transient) free_batch(u);
+    for (auto &b : c->ann_bufs) b.release();
+    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.count.release(); }
+    DevBuf *all[] = {&c->d_u64, &c->d_exon_acc, &c->d_cov, &c->d_misc, &c->d_ovf_index, &c->d_tiles, &c->d_table,
+                     &c->d_tab_off, &c->d_tab_cap, &c->d_gmean, &c->d_gstd, &c->d_gcv, &c->d_gvalid, &c->d_ecv,
+                     &c->d_ecv_valid, &c->d_bias3, &c->d_bias5};
+    for (auto *b : all) b->release();
+    for (auto &pr : c->k1_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *owned_contig) {
+    if (!c || !a) return RSQC_ERR_ARG;
+    if (c->have_ann) return fail(c, RSQC_ERR_ARG, "annotation already set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int nc = a->n_contigs, G = a->n_genes, L = a->n_genes_listed, E = a->n_exons;
+    c->n_ref = a->n_ref; c->n_contigs = nc; c->n_genes = G; c->n_listed = L; c->n_exons = E;
+    HostIndex hx;
+    {
+        std::string err;
+        int brc = hx.build(a, owned_contig, err);
+        if (brc) return fail(c, brc, err);
+    }
+    const int shift = HostIndex::kBinShift;
+    auto &ex_range = hx.ex_range; auto &g_range = hx.g_range; auto &ex_pmax = hx.ex_pmax; auto &g_pmax = hx.g_pmax;
+    auto &ex_bin = hx.ex_bin; auto &g_bin = hx.g_bin; auto &bin_off = hx.bin_off; auto &ex_cov = hx.ex_cov;
+    auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
+    auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
+    const uint64_t run = hx.cov_entries;
+    c->cov_entries = run;
+    c->exon_row_id.assign(a->exon_row_id, a->exon_row_id + E);
+
+    // ---- upload ---------------------------------------------------------------------------------
+    DevAnnotation &d = c->dann;
+    d.n_ref = a->n_ref; d.n_contigs = nc; d.n_genes = G; d.n_listed = L; d.n_exons = E;
+    d.bin_shift = shift;
+    int rc;
+#define UPV(dst, vec) if ((rc = upload(c, c->ann_bufs, (vec).data(), (vec).size(), &(dst)))) return rc
+#define UPA(dst, ptr, n) if ((rc = upload(c, c->ann_bufs, (ptr), (size_t)(n), &(dst)))) return rc
+    UPA(d.ex_start, a->exon_row_start, E); UPA(d.ex_end, a->exon_row_end, E); UPV(d.ex_pmax, ex_pmax);
+    UPA(d.ex_gene, a->exon_row_gene, E); UPA(d.ex_flags, a->exon_row_flags, E); UPV(d.ex_cov, ex_cov);
+    UPV(d.ex_range, ex_range);
+    UPA(d.g_start, a->gene_row_start, L); UPA(d.g_end, a->gene_row_end, L); UPV(d.g_pmax, g_pmax);
+    UPA(d.g_flags, a->gene_row_flags, L); UPV(d.g_range, g_range);
+    UPA(d.gene_globin, a->gene_is_globin, G);
+    UPV(d.ex_bin, ex_bin); UPV(d.g_bin, g_bin); UPV(d.bin_off, bin_off);
+    // empty BED until rsqc_set_bed
+    std::vector<uint32_t> zero_range((size_t)nc + 1, 0);
+    UPV(d.bed_range, zero_range);
+    d.bed_start = d.bed_end = d.bed_pmax = nullptr; d.have_bed = 0;
+    UPA(c->d_ge_off, a->gene_exon_off, (size_t)G + 1);
+    UPA(c->d_ge_row, a->gene_exon_row, E);
+    UPV(c->d_gene_cov_off, gene_cov_off);
+    UPV(c->d_gene_coding, gene_coding);
+    UPV(c->d_gene_flags, gene_flags);
+    UPV(c->d_gene_owned, gene_owned);
+#undef UPV
+#undef UPA
+    // ---- accumulators -----------------------------------------------------------------------------
+    const size_t n_u64 = (size_t)G * 3 + RSQC_N_COUNTERS;
+    if ((rc = dev_alloc(c, c->d_u64, n_u64 * 8, false))) return rc;
+    if ((rc = dev_alloc(c, c->d_exon_acc, (size_t)std::max(E, 1) * 8, false))) return rc;
+    if ((rc = dev_alloc(c, c->d_cov, (size_t)(run + 64) * 4, false))) return rc;
+    if ((rc = dev_alloc(c, c->d_misc, 64, false))) return rc;
+    const uint32_t ovf_cap = 1u << 20;
+    if ((rc = dev_alloc(c, c->d_ovf_index, (size_t)ovf_cap * 8, false))) return rc;
+    DevAccum &acc = c->acc;
+    acc.gene_reads = (unsigned long long *)c->d_u64.p;
+    acc.gene_unique = acc.gene_reads + G;
+    acc.gene_frag = acc.gene_unique + G;
+    acc.counters = acc.gene_frag + G;
+    acc.exon_acc = (double *)c->d_exon_acc.p;
+    acc.cov_diff = (uint32_t *)c->d_cov.p;
+    acc.ovf_count = (uint32_t *)c->d_misc.p;
+    acc.read_length = (int32_t *)((char *)c->d_misc.p + 8);
+    acc.error = (int *)((char *)c->d_misc.p + 16);
+    acc.ovf_index = (uint64_t *)c->d_ovf_index.p; acc.ovf_cap = ovf_cap;
+    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
+    if ((rc = dev_alloc(c, c->d_gmean, Lz * 8, false)) || (rc = dev_alloc(c, c->d_gstd, Lz * 8, false)) ||
+        (rc = dev_alloc(c, c->d_gcv, Lz * 8, false)) || (rc = dev_alloc(c, c->d_gvalid, Lz, false)) ||
+        (rc = dev_alloc(c, c->d_ecv, Ez * 8, false)) || (rc = dev_alloc(c, c->d_ecv_valid, Ez, false)) ||
+        (rc = dev_alloc(c, c->d_bias3, Lz * 8, false)) || (rc = dev_alloc(c, c->d_bias5, Lz * 8, false)))
+        return rc;
+    c->have_ann = true;
+    if ((rc = zero_accumulators(c))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RSQC_OK;
+}
+
+int rsqc_set_bed(rsqc_ctx *c, const rsqc_bed *bed) {
+    if (!c || !bed || !c->have_ann) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int nc = c->n_contigs, n = bed->n_intervals;
+    std::vector<uint32_t> range((size_t)nc + 1, 0);
+    std::vector<int32_t> pmax((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (bed->contig[i] < 0 || bed->contig[i] >= nc) return fail(c, RSQC_ERR_ARG, "BED contig out of range");
+        if (i && (bed->contig[i] < bed->contig[i - 1] ||
+                  (bed->contig[i] == bed->contig[i - 1] && bed->start[i] < bed->start[i - 1])))
+            return fail(c, RSQC_ERR_ARG, "BED intervals must be grouped by contig id and ascending by start");
+        range[(size_t)bed->contig[i] + 1]++;
+    }
+    for (int k = 0; k < nc; ++k) range[(size_t)k + 1] += range[(size_t)k];
+    for (int k = 0; k < nc; ++k) {
+        int32_t m = INT32_MIN;
+        for (uint32_t i = range[(size_t)k]; i < range[(size_t)k + 1]; ++i) { m = std::max(m, bed->end[i]); pmax[i] = m; }
+    }
+    int rc;
+    if ((rc = upload(c, c->ann_bufs, bed->start, (size_t)n, &c->dann.bed_start))) return rc;
+    if ((rc = upload(c, c->ann_bufs, bed->end, (size_t)n, &c->dann.bed_end))) return rc;
+    if ((rc = upload(c, c->ann_bufs, pmax.data(), pmax.size(), &c->dann.bed_pmax))) return rc;
+    if ((rc = upload(c, c->ann_bufs, range.data(), range.size(), &c->dann.bed_range))) return rc;
+    c->dann.have_bed = 1;
+    c->have_bed = true;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RSQC_OK;
+}
+
+int rsqc_submit(rsqc_ctx *c, const rsqc_batch *b) {
+    if (!c || !b) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    HIP_TRY(c, hipSetDevice(c->device));
+    UploadedBatch *u = new UploadedBatch();
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    (void)hipEventRecord(e0, c->stream);
+    int rc = upload_batch(c, b, u);
+    (void)hipEventRecord(e1, c->stream);
+    if (rc) { free_batch(u); return rc; }
+    c->transient.push_back(u);
+    rc = run_batch(c, u);
+    // h2d time resolved lazily together with the K1 events
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.h2d_ms += ms;
+    c->event_pool.push_back(e0); c->event_pool.push_back(e1);
+    return rc;
+}
+
+int rsqc_wait(rsqc_ctx *c) {
+    if (!c) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    resolve_events(c);
+    for (auto *u : c->transient) free_batch(u);
+    c->transient.clear();
+    if (c->have_ann) return check_device_error(c);
+    return RSQC_OK;
+}
+
+int rsqc_upload(rsqc_ctx *c, const rsqc_batch *b, int *handle_out) {
+    if (!c || !b || !handle_out) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    UploadedBatch *u = new UploadedBatch();
+    int rc = upload_batch(c, b, u);
+    if (rc) { free_batch(u); return rc; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->resident.push_back(u);
+    *handle_out = (int)c->resident.size() - 1;
+    return RSQC_OK;
+}
+
+int rsqc_submit_resident(rsqc_ctx *c, int handle) {
+    if (!c || handle < 0 || handle >= (int)c->resident.size() || !c->resident[(size_t)handle]) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_batch(c, c->resident[(size_t)handle]);
+}
+
+int rsqc_release(rsqc_ctx *c, int handle) {
+    if (!c || handle < 0 || handle >= (int)c->resident.size() || !c->resident[(size_t)handle]) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_batch(c->resident[(size_t)handle]);
+    c->resident[(size_t)handle] = nullptr;
+    return RSQC_OK;
+}
+
+int rsqc_reset(rsqc_ctx *c) {
+    if (!c || !c->have_ann) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return zero_accumulators(c);
+}
+
+static int read_back_counts(rsqc_ctx *c) {
+    const int G = c->n_genes, L = c->n_listed, E = c->n_exons;
+    const size_t n_u64 = (size_t)G * 3 + RSQC_N_COUNTERS;
+    c->h_u64.resize(n_u64);
+    HIP_TRY(c, hipMemcpyAsync(c->h_u64.data(), c->d_u64.p, n_u64 * 8, hipMemcpyDeviceToHost, c->stream));
+    c->h_exon_rows.resize((size_t)std::max(E, 1));
+    HIP_TRY(c, hipMemcpyAsync(c->h_exon_rows.data(), c->d_exon_acc.p, (size_t)E * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->h_reads.assign(c->h_u64.begin(), c->h_u64.begin() + L);
+    c->h_unique.assign(c->h_u64.begin() + G, c->h_u64.begin() + G + L);
+    c->h_frag.assign(c->h_u64.begin() + 2 * (size_t)G, c->h_u64.begin() + 2 * (size_t)G + L);
+    c->h_exon.assign((size_t)E, 0.0); c->h_exon_hit.assign((size_t)E, 0);
+    for (int r = 0; r < E; ++r) {
+        const uint32_t id = c->exon_row_id[(size_t)r];
+        c->h_exon[id] = c->h_exon_rows[(size_t)r];
+        c->h_exon_hit[id] = c->h_exon_rows[(size_t)r] > 0.0 ? 1 : 0;
+    }
+    rsqc_results &R = c->results;
+    for (int k = 0; k < RSQC_N_COUNTERS; ++k) R.counters[k] = c->h_u64[3 * (size_t)G + (size_t)k];
+    R.n_genes_listed = L; R.n_exons = E;
+    R.gene_reads = c->h_reads.data(); R.gene_unique = c->h_unique.data(); R.gene_fragments = c->h_frag.data();
+    R.exon_reads = c->h_exon.data(); R.exon_hit = c->h_exon_hit.data();
+    return 0;
+}
+
+int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
+    if (!c || !out || !c->have_ann) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = rsqc_wait(c);
+    if (rc) return rc;
+    const int G = c->n_genes, L = c->n_listed, E = c->n_exons;
+    if (!c->finalized) {
+        hipEvent_t e0 = get_event(c), e1 = get_event(c);
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        // ---- K4: per-gene distinct QNAMEs -------------------------------------------------------
+        std::vector<uint64_t> reads((size_t)std::max(G, 1));
+        HIP_TRY(c, hipMemcpy(reads.data(), c->acc.gene_reads, (size_t)G * 8, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> tab_off((size_t)std::max(G, 1)); std::vector<uint32_t> tab_cap((size_t)std::max(G, 1));
+        uint64_t slots = 0;
+        for (int g = 0; g < G; ++g) {
+            tab_off[(size_t)g] = slots;
+            const uint64_t cap = reads[(size_t)g] ? 2 * reads[(size_t)g] : 0;
+            if (cap > 0xFFFFFFFFull) return fail(c, RSQC_ERR_CAPACITY, "more than 2^31 records on one gene");
+            tab_cap[(size_t)g] = (uint32_t)cap;
+            slots += cap;
+        }
+        if ((rc = dev_alloc(c, c->d_table, slots * 8, true))) return rc;
+        if ((rc = dev_alloc(c, c->d_tab_off, (size_t)std::max(G, 1) * 8, false))) return rc;
+        if ((rc = dev_alloc(c, c->d_tab_cap, (size_t)std::max(G, 1) * 4, false))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_tab_off.p, tab_off.data(), (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_tab_cap.p, tab_cap.data(), (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->acc.gene_frag, 0, (size_t)G * 8, c->stream));
+        for (size_t idx : c->pairs_in_flight) {
+            PairBuf &pb = c->pair_pool[idx];
+            uint32_t n_pairs = 0;
+            HIP_TRY(c, hipMemcpy(&n_pairs, pb.count.p, 4, hipMemcpyDeviceToHost));
+            if (n_pairs > pb.cap) return fail(c, RSQC_ERR_CAPACITY, "pair buffer overflow");
+            launch_dedup(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, n_pairs,
+                         (const uint64_t *)c->d_tab_off.p, (const uint32_t *)c->d_tab_cap.p,
+                         (unsigned long long *)c->d_table.p, c->acc.gene_frag);
+        }
+        // ---- K3: coverage scan + per-gene statistics + bias ----------------------------------------
+        HIP_TRY(c, hipMemsetAsync(c->d_gvalid.p, 0, c->d_gvalid.bytes, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_ecv_valid.p, 0, c->d_ecv_valid.bytes, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_bias3.p, 0, c->d_bias3.bytes, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_bias5.p, 0, c->d_bias5.bytes, c->stream));
+        GeneCovArgs A{};
+        A.ge_off = c->d_ge_off; A.ge_row = c->d_ge_row;
+        A.ex_start = c->dann.ex_start; A.ex_end = c->dann.ex_end; A.ex_cov = c->dann.ex_cov;
+        A.gene_cov_off = c->d_gene_cov_off; A.gene_coding = c->d_gene_coding;
+        A.gene_flags = c->d_gene_flags; A.gene_owned = c->d_gene_owned;
+        A.gene_reads = c->acc.gene_reads; A.cov = c->acc.cov_diff; A.n_listed = L;
+        A.mask = c->params.coverage_mask; A.bias_offset = c->params.bias_offset; A.bias_window = c->params.bias_window;
+        A.bias_gene_length = c->params.bias_gene_length;
+        A.g_mean = (double *)c->d_gmean.p; A.g_std = (double *)c->d_gstd.p; A.g_cv = (double *)c->d_gcv.p;
+        A.g_valid = (uint8_t *)c->d_gvalid.p; A.e_cv = (double *)c->d_ecv.p; A.e_cv_valid = (uint8_t *)c->d_ecv_valid.p;
+        A.bias3 = (unsigned long long *)c->d_bias3.p; A.bias5 = (unsigned long long *)c->d_bias5.p;
+        A.error = c->acc.error;
+        launch_gene_coverage(c->stream, A);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.finalize_ms += ms;
+        c->event_pool.push_back(e0); c->event_pool.push_back(e1);
+        if ((rc = check_device_error(c))) return rc;
+        c->finalized = true;
+    }
+    // ---- read back ---------------------------------------------------------------------------------
+    if ((rc = read_back_counts(c))) return rc;
+    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
+    c->h_gmean.resize(Lz); c->h_gstd.resize(Lz); c->h_gcv.resize(Lz); c->h_gvalid.resize(Lz);
+    c->h_bias3.resize(Lz); c->h_bias5.resize(Lz);
+    std::vector<double> ecv_rows(Ez); std::vector<uint8_t> ecv_valid_rows(Ez);
+    HIP_TRY(c, hipMemcpy(c->h_gmean.data(), c->d_gmean.p, (size_t)L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->h_gstd.data(), c->d_gstd.p, (size_t)L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->h_gcv.data(), c->d_gcv.p, (size_t)L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->h_gvalid.data(), c->d_gvalid.p, (size_t)L, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->h_bias3.data(), c->d_bias3.p, (size_t)L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->h_bias5.data(), c->d_bias5.p, (size_t)L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ecv_rows.data(), c->d_ecv.p, (size_t)E * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ecv_valid_rows.data(), c->d_ecv_valid.p, (size_t)E, hipMemcpyDeviceToHost));
+    c->h_ecv.assign(Ez, 0.0); c->h_ecv_valid.assign(Ez, 0);
+    for (int r = 0; r < E; ++r) if (ecv_valid_rows[(size_t)r]) {
+        c->h_ecv[c->exon_row_id[(size_t)r]] = ecv_rows[(size_t)r];
+        c->h_ecv_valid[c->exon_row_id[(size_t)r]] = 1;
+    }
+    for (int g = 0; g < L; ++g) if (!c->h_gvalid[(size_t)g]) { c->h_gmean[(size_t)g] = c->h_gstd[(size_t)g] = c->h_gcv[(size_t)g] = 0.0; }
+    int32_t rl = 0;
+    HIP_TRY(c, hipMemcpy(&rl, c->acc.read_length, 4, hipMemcpyDeviceToHost));
+    rsqc_results &R = c->results;
+    R.read_length = rl;
+    R.gene_cov_mean = c->h_gmean.data(); R.gene_cov_std = c->h_gstd.data(); R.gene_cov_cv = c->h_gcv.data();
+    R.gene_cov_valid = c->h_gvalid.data(); R.exon_cv = c->h_ecv.data(); R.exon_cv_valid = c->h_ecv_valid.data();
+    R.bias_three = c->h_bias3.data(); R.bias_five = c->h_bias5.data();
+    R.n_fragment_sizes = (uint32_t)c->h_fsize.size();
+    R.fragment_size = c->h_fsize.data(); R.fragment_count = c->h_fcount.data();
+    R.fragment_samples_remaining = c->have_bed ? c->params.fragment_samples : 0;
+    *out = R;
+    return RSQC_OK;
+}
+
+int rsqc_device_accumulators(rsqc_ctx *c, void **u64_base, uint64_t *u64_count, void **f64_base, uint64_t *f64_count) {
+    if (!c || !c->have_ann || !u64_base || !u64_count || !f64_base || !f64_count) return RSQC_ERR_ARG;
+    *u64_base = c->d_u64.p; *u64_count = (uint64_t)c->n_genes * 3 + RSQC_N_COUNTERS;
+    *f64_base = c->d_exon_acc.p; *f64_count = (uint64_t)c->n_exons;
+    return RSQC_OK;
+}
+
+int rsqc_refresh_results(rsqc_ctx *c, rsqc_results *out) {
+    if (!c || !out || !c->have_ann || !c->finalized) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = read_back_counts(c);
+    if (rc) return rc;
+    *out = c->results;
+    return RSQC_OK;
+}
+
+int rsqc_get_timing(rsqc_ctx *c, rsqc_timing *out) {
+    if (!c || !out) return RSQC_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    resolve_events(c);
+    *out = c->timing;
+    return RSQC_OK;
+}
+
+int rsqc_reset_timing(rsqc_ctx *c) {
+    if (!c) return RSQC_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    resolve_events(c);
+    c->timing = rsqc_timing{};
+    return RSQC_OK;
+}
+
+const char *rsqc_strerror(int code) {
+    switch (code) {
+    case RSQC_OK: return "ok";
+    case RSQC_ERR_ARG: return "bad argument or call order";
+    case RSQC_ERR_HIP: return "HIP runtime error";
+    case RSQC_ERR_BAD_CIGAR: return "Unrecognized Cigar Op";
+    case RSQC_ERR_CAPACITY: return "device-side capacity exceeded";
+    case RSQC_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case RSQC_ERR_EMPTY_MEDIAN: return "Cannot compute median of an empty list";
+    default: return "unknown error";
+    }
+}
+
+const char *rsqc_last_error(rsqc_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+static const char *const kCounterNames[RSQC_N_COUNTERS] = {
+    "Alternative Alignments", "Supplementary Alignments", "Failed Vendor QC", "Low Mapping Quality",
+    "Chimeric Fragments_auto", "Chimeric Fragments_tag", "Unique Mapping, Vendor QC Passed Reads",
+    "Unpaired Reads", "Mapped Reads", "Mapped Duplicate Reads", "Mapped Unique Reads",
+    "Total Mapped Pairs", "End 1 Mapped Reads", "End 1 Mismatches", "End 1 Bases", "Duplicate Pairs",
+    "Unique Fragments", "End 2 Mapped Reads", "End 2 Mismatches", "End 2 Bases", "Mismatched Bases",
+    "Total Bases", "High Quality Reads", "Low Quality Reads", "Reads used for Intron/Exon counts",
+    "Alignment Blocks", "Non-Globin Reads", "Non-Globin Duplicate Reads", "Intronic Reads",
+    "Intragenic Reads", "HQ Intronic Reads", "HQ Intragenic Reads", "Intergenic Reads",
+    "HQ Intergenic Reads", "Exonic Reads", "HQ Exonic Reads", "Ambiguous Reads", "HQ Ambiguous Reads",
+    "rRNA Reads", "End 1 Sense", "End 1 Antisense", "End 2 Sense", "End 2 Antisense",
+    "Total Alignments", "Filtered by tag: 0", "Filtered by tag: 1", "Filtered by tag: 2",
+    "Filtered by tag: 3", "Filtered by tag: 4",
+};
+
+const char *rsqc_counter_name(int counter) {
+    return (counter >= 0 && counter < RSQC_N_COUNTERS) ? kCounterNames[counter] : "";
+}
+
+const char *rsqc_version(void) { return "RNASeQC 2.4.3 (rnaseqc_amd 0.1, MI355X/gfx950)"; }
+
+uint64_t rsqc_qname_hash(const char *name, size_t len) {
+    uint64_t h = 0xCBF29CE484222325ull;                    // FNV-1a 64
+    for (size_t i = 0; i < len; ++i) { h ^= (uint8_t)name[i]; h *= 0x100000001B3ull; }
+    h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;   // fmix64
+    return h;
+}
+
+}  // extern "C"

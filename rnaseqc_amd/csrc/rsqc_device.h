@@ -1,0 +1,75 @@
+// rsqc_device.h -- device-side views shared by the kernels and the C-ABI host code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsqc_read.h"
+
+#define RSQC_K1_THREADS 256
+#define RSQC_MAX_BIAS_WINDOW 1024
+
+namespace rsqc {
+
+// one uploaded batch (all pointers are device pointers)
+struct DevBatch {
+    uint64_t n;
+    uint64_t record_base;        // file index of record 0
+    const int32_t *pos, *mpos, *isize;
+    const uint64_t *qhash;
+    const uint32_t *cigar_off;
+    const uint16_t *flag, *l_qseq;
+    const uint8_t *mapq, *nm, *tagbits, *n_cigar;
+    const uint32_t *cigar;
+    uint32_t n_seg;
+    const int32_t *seg_tid;
+    const uint64_t *seg_start;
+    uint32_t n_wide;
+    const uint64_t *wide_index;
+    const int32_t *wide_nm, *wide_l_qseq;
+    const uint32_t *wide_n_cigar;
+    uint64_t tile_base;          // first tile summary slot of this batch
+};
+
+// accumulators (device pointers)
+struct DevAccum {
+    unsigned long long *gene_reads, *gene_unique, *gene_frag, *counters;   // one allocation, in this order
+    double *exon_acc;            // by exon ROW
+    uint32_t *cov_diff;          // per-base difference array / coverage
+    uint32_t *pair_gene; uint64_t *pair_hash; uint32_t *pair_count; uint32_t pair_cap;
+    uint32_t *ovf_count; uint64_t *ovf_index; uint32_t ovf_cap;
+    uint32_t *tile_span, *tile_lmin, *tile_lmax;
+    int32_t *read_length;
+    int *error;
+};
+
+struct GeneCovArgs {
+    const uint32_t *ge_off, *ge_row;        // exonsForGene CSR (gene id -> exon rows)
+    const int32_t *ex_start, *ex_end;
+    const uint32_t *ex_cov;                 // coverage offset of an exon row
+    const uint32_t *gene_cov_off;           // [n_listed]
+    const uint32_t *gene_coding;            // [n_listed]
+    const uint8_t *gene_flags;              // [n_listed] flags of the gene row
+    const uint8_t *gene_owned;              // [n_listed] gene lies on a contig of this shard
+    const unsigned long long *gene_reads;   // touched test
+    uint32_t *cov;
+    int32_t n_listed;
+    uint32_t mask; int32_t bias_offset, bias_window; uint64_t bias_gene_length;
+    double *g_mean, *g_std, *g_cv; uint8_t *g_valid;
+    double *e_cv; uint8_t *e_cv_valid;      // by exon row
+    unsigned long long *bias3, *bias5;
+    int *error;
+};
+void launch_gene_coverage(hipStream_t s, const GeneCovArgs &A);
+
+void launch_classify(hipStream_t s, int grid, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
+                     const DevAccum &acc);
+void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
+                          const DevAccum &acc);
+void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
+                        const DevAccum &acc);
+void launch_dedup(hipStream_t s, const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t n_pairs,
+                  const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
+                  unsigned long long *gene_frag);
+
+}  // namespace rsqc

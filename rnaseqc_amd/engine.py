@@ -1,0 +1,170 @@
+"""Host-side driver of the HIP hot path through the C ABI (include/rnaseqc_amd.h).
+
+This is plumbing: it loads rnaseqc_amd/lib/librnaseqc_amd.so (built by
+__graft_entry__.build() / rnaseqc_amd/csrc/Makefile) and forwards calls.  There is no
+fallback of any kind: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librnaseqc_amd.so")
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("rnaseqc_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(abi.ERR_NO_DEVICE, "HIP library %s is missing; run __graft_entry__.build()" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        lib.rsqc_create.argtypes = [C.POINTER(abi.Params), C.POINTER(vp)]
+        lib.rsqc_destroy.argtypes = [vp]; lib.rsqc_destroy.restype = None
+        lib.rsqc_set_annotation.argtypes = [vp, C.POINTER(abi.AnnotationStruct), vp]
+        lib.rsqc_set_bed.argtypes = [vp, C.POINTER(abi.BedStruct)]
+        lib.rsqc_submit.argtypes = [vp, C.POINTER(abi.BatchStruct)]
+        lib.rsqc_wait.argtypes = [vp]
+        lib.rsqc_upload.argtypes = [vp, C.POINTER(abi.BatchStruct), C.POINTER(C.c_int)]
+        lib.rsqc_submit_resident.argtypes = [vp, C.c_int]
+        lib.rsqc_release.argtypes = [vp, C.c_int]
+        lib.rsqc_finalize.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
+        lib.rsqc_reset.argtypes = [vp]
+        lib.rsqc_get_timing.argtypes = [vp, C.POINTER(abi.TimingStruct)]
+        lib.rsqc_reset_timing.argtypes = [vp]
+        lib.rsqc_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
+        lib.rsqc_strerror.argtypes = [C.c_int]; lib.rsqc_strerror.restype = C.c_char_p
+        lib.rsqc_last_error.argtypes = [vp]; lib.rsqc_last_error.restype = C.c_char_p
+        lib.rsqc_counter_name.argtypes = [C.c_int]; lib.rsqc_counter_name.restype = C.c_char_p
+        lib.rsqc_version.restype = C.c_char_p
+        lib.rsqc_qname_hash.argtypes = [C.c_char_p, C.c_size_t]; lib.rsqc_qname_hash.restype = C.c_uint64
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_submit", "rsqc_wait",
+    "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_strerror",
+    "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
+]
+
+
+class DeviceArray:
+    """A raw HIP device pointer exposed through __cuda_array_interface__ so that
+    torch.as_tensor(..., device='cuda') wraps it zero-copy (used for the RCCL reduction)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class Engine:
+    def __init__(self, params: abi.Params):
+        self._l = load_library()
+        self._h = C.c_void_p()
+        self._keep = []
+        rc = self._l.rsqc_create(C.byref(params), C.byref(self._h))
+        if rc:
+            raise EngineError(rc, self._l.rsqc_strerror(rc).decode())
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError(rc, "%s (%s)" % (self._l.rsqc_strerror(rc).decode(),
+                                               self._l.rsqc_last_error(self._h).decode()))
+
+    def set_annotation(self, ann, owned=None):
+        s = ann.to_struct()
+        o = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
+        self._keep += [ann, s, o]
+        self._check(self._l.rsqc_set_annotation(self._h, C.byref(s), abi.ptr(o)))
+
+    def set_bed(self, bed):
+        s = bed.to_struct()
+        self._keep += [bed, s]
+        self._check(self._l.rsqc_set_bed(self._h, C.byref(s)))
+
+    def submit(self, batch):
+        s = batch.to_struct()
+        self._keep += [batch, s]
+        self._check(self._l.rsqc_submit(self._h, C.byref(s)))
+
+    def wait(self):
+        self._check(self._l.rsqc_wait(self._h))
+
+    def upload(self, batch) -> int:
+        s = batch.to_struct()
+        h = C.c_int()
+        self._check(self._l.rsqc_upload(self._h, C.byref(s), C.byref(h)))
+        return h.value
+
+    def submit_resident(self, handle: int):
+        self._check(self._l.rsqc_submit_resident(self._h, handle))
+
+    def release(self, handle: int):
+        self._check(self._l.rsqc_release(self._h, handle))
+
+    def finalize(self) -> abi.Results:
+        rs = abi.ResultsStruct()
+        self._check(self._l.rsqc_finalize(self._h, C.byref(rs)))
+        return abi.Results(rs)
+
+    def refresh_results(self) -> abi.Results:
+        rs = abi.ResultsStruct()
+        self._check(self._l.rsqc_refresh_results(self._h, C.byref(rs)))
+        return abi.Results(rs)
+
+    def reset(self):
+        self._check(self._l.rsqc_reset(self._h))
+
+    def timing(self) -> dict:
+        t = abi.TimingStruct()
+        self._check(self._l.rsqc_get_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in abi.TimingStruct._fields_}
+
+    def reset_timing(self):
+        self._check(self._l.rsqc_reset_timing(self._h))
+
+    def device_accumulators(self):
+        u, f = C.c_void_p(), C.c_void_p()
+        nu, nf = C.c_uint64(), C.c_uint64()
+        self._check(self._l.rsqc_device_accumulators(self._h, C.byref(u), C.byref(nu), C.byref(f), C.byref(nf)))
+        # int64 view: torch has no uint64 arithmetic; counts are far below 2^63
+        return DeviceArray(u.value, nu.value, "<i8"), DeviceArray(f.value, nf.value, "<f8")
+
+    def close(self):
+        if self._h:
+            self._l.rsqc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_engine(params, ann, batches, bed=None, owned=None) -> abi.Results:
+    e = Engine(params)
+    try:
+        e.set_annotation(ann, owned)
+        if bed is not None:
+            e.set_bed(bed)
+        for b in batches:
+            e.submit(b)
+        return e.finalize()
+    finally:
+        e.close()

@@ -180,7 +180,7 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
                expr_sigma: float = 2.0, low_mapq_frac: float = 0.05, secondary_frac: float = 0.01,
                supplementary_frac: float = 0.005, unmapped_frac: float = 0.01, indel_frac: float = 0.02,
                chimeric_tag_frac: float = 0.0, filter_tag_frac: float = 0.0, expr_genes: int | None = None,
-               contig_lengths=None) -> Batch:
+               contig_lengths=None, only_contig: int | None = None) -> Batch:
     rng = np.random.default_rng(seed)
     rl = read_len
     G = ann.n_genes_listed
@@ -210,6 +210,8 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
     def transcript_mates(n):
         expr = np.exp(rng.normal(0.0, expr_sigma, G))
         ok = coding >= rl
+        if only_contig is not None:
+            ok &= gene_contig == only_contig
         if expr_genes is not None:
             keep = np.zeros(G, bool)
             keep[rng.choice(G, size=min(expr_genes, G), replace=False)] = True
@@ -279,19 +281,28 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
         pB, nB, fB = to_blocks(TB, rl)
         parts.append((gene_contig[g], pA, nA, fA, pB, nB, fB))
     if n_intr:
-        big = np.flatnonzero((gene_e - gene_s) > 3 * rl + 400)
+        big = (gene_e - gene_s) > 3 * rl + 400
+        if only_contig is not None:
+            big &= gene_contig == only_contig
+        big = np.flatnonzero(big)
         g = big[rng.integers(0, len(big), n_intr)]
         s1 = gene_s[g] + (rng.random(n_intr) * (gene_e[g] - gene_s[g] - 2 * rl - 300)).astype(np.int64)
         pA, pB, nc, fl, _ = genomic_mates(gene_contig[g], s1, n_intr)
         parts.append((gene_contig[g], pA, nc, fl, pB, nc.copy(), fl.copy()))
     if n_inter:
-        cw = contig_lengths / contig_lengths.sum()
+        cw = np.asarray(contig_lengths, dtype=np.float64).copy()
+        if only_contig is not None:
+            keep = np.zeros(len(cw), bool); keep[only_contig] = True
+            cw[~keep] = 0
+        cw = cw / cw.sum()
         c = rng.choice(len(contig_lengths), size=n_inter, p=cw)
         s1 = 1 + (rng.random(n_inter) * np.maximum(contig_lengths[c] - 1000, 1)).astype(np.int64)
         pA, pB, nc, fl, _ = genomic_mates(c, s1, n_inter)
         parts.append((c, pA, nc, fl, pB, nc.copy(), fl.copy()))
     if n_edge:
-        r = rng.integers(0, len(ex_s), n_edge)
+        ex_c_all = ann.exon_row_contig.astype(np.int64)[ge_row]
+        cand = np.arange(len(ex_s)) if only_contig is None else np.flatnonzero(ex_c_all == only_contig)
+        r = cand[rng.integers(0, len(cand), n_edge)]
         s1 = np.maximum(ex_s[r] - rng.integers(1, rl, n_edge), 1)
         c = ann.exon_row_contig.astype(np.int64)[ge_row][r]
         pA, pB, nc, fl, _ = genomic_mates(c, s1, n_edge)

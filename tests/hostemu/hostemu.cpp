@@ -1,0 +1,91 @@
+// hostemu.cpp -- TEST HARNESS ONLY (never loaded by the product).
+//
+// Compiles the product's per-record core (rnaseqc_amd/csrc/rsqc_read.h, which is
+// __host__ __device__) and index builder (rsqc_index.h) with g++ and runs them one record
+// at a time, so that the semantics the HIP kernels execute can be diffed against the
+// oracle in the GPU-less build container.  Wave-level code (reductions, de-dup, coverage
+// statistics, read-length scan) is NOT covered here; the -m gpu tests cover it.
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../rnaseqc_amd/csrc/rsqc_read.h"
+#include "../../rnaseqc_amd/csrc/rsqc_index.h"
+
+using namespace rsqc;
+
+namespace {
+struct Acc {
+    std::vector<uint64_t> *reads, *unique;
+    std::vector<double> *exon_rows;
+    std::vector<uint32_t> *cov;
+    const uint32_t *ex_cov;
+    std::vector<std::set<uint64_t>> *names;
+    void gene_hit(uint32_t g, bool nd, uint64_t qh) { (*reads)[g]++; if (nd) (*unique)[g]++; (*names)[g].insert(qh); }
+    void exon_add(uint32_t row, double f) { (*exon_rows)[row] += f; }
+    void cov_range(uint32_t row, uint32_t off, uint32_t len, uint32_t elen) {
+        if (!len) return;
+        (*cov)[ex_cov[row] + off] += 1u;
+        if (off + len < elen) (*cov)[ex_cov[row] + off + len] -= 1u;
+    }
+};
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b,
+                uint64_t *counters /*N_COUNTERS*/, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag,
+                double *exon_reads /*by exon id*/, int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/,
+                uint64_t *n_overflow) {
+    HostIndex hx; std::string err;
+    int rc = hx.build(a, nullptr, err);
+    if (rc) return rc;
+    DevAnnotation d{};
+    d.n_ref = a->n_ref; d.n_contigs = a->n_contigs; d.n_genes = a->n_genes; d.n_listed = a->n_genes_listed; d.n_exons = a->n_exons;
+    d.ex_start = a->exon_row_start; d.ex_end = a->exon_row_end; d.ex_pmax = hx.ex_pmax.data(); d.ex_gene = a->exon_row_gene;
+    d.ex_flags = a->exon_row_flags; d.ex_cov = hx.ex_cov.data(); d.ex_range = hx.ex_range.data();
+    d.g_start = a->gene_row_start; d.g_end = a->gene_row_end; d.g_pmax = hx.g_pmax.data(); d.g_flags = a->gene_row_flags;
+    d.g_range = hx.g_range.data(); d.gene_globin = a->gene_is_globin;
+    d.ex_bin = hx.ex_bin.data(); d.g_bin = hx.g_bin.data(); d.bin_off = hx.bin_off.data(); d.bin_shift = HostIndex::kBinShift;
+    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags};
+    std::vector<uint64_t> reads((size_t)a->n_genes, 0), unique((size_t)a->n_genes, 0);
+    std::vector<double> exon_rows((size_t)a->n_exons, 0.0);
+    std::vector<uint32_t> cov((size_t)hx.cov_entries + 1, 0);
+    std::vector<std::set<uint64_t>> names((size_t)a->n_genes);
+    Acc acc{&reads, &unique, &exon_rows, &cov, hx.ex_cov.data(), &names};
+    memset(counters, 0, sizeof(uint64_t) * RSQC_N_COUNTERS);
+    uint32_t rl = 0; uint32_t w = 0; *n_overflow = 0;
+    for (uint32_t s = 0; s < b->n_seg; ++s) for (uint64_t i = b->seg_start[s]; i < b->seg_start[s + 1]; ++i) {
+        Record r;
+        r.tid = b->seg_tid[s]; r.pos = b->pos[i]; r.mpos = b->mpos[i]; r.isize = b->isize[i]; r.flag = b->flag[i];
+        r.mapq = b->mapq[i]; r.tagbits = b->tagbits[i]; r.l_qseq = b->l_qseq[i]; r.nm = b->nm[i]; r.n_cigar = b->n_cigar[i];
+        if (b->l_qseq[i] == RSQC_LQSEQ_ESCAPE || b->nm[i] == RSQC_NM_ESCAPE || b->n_cigar[i] == RSQC_NCIGAR_ESCAPE) {
+            while (w < b->n_wide && b->wide_index[w] < i) ++w;
+            if (w >= b->n_wide || b->wide_index[w] != i) return RSQC_ERR_ARG;
+            r.l_qseq = b->wide_l_qseq[w]; r.nm = b->wide_nm[w]; r.n_cigar = b->wide_n_cigar[w];
+        }
+        r.cigar = b->cigar + b->cigar_off[i]; r.qhash = b->qhash[i];
+        RecordCounters rc2; bool hq; uint32_t aligned;
+        const bool go = gate_cascade(d, dp, r, rc2, hq, aligned);
+        uint64_t bits = rc2.bits;
+        if (rc2.error) return rc2.error;
+        if (go) {
+            bool over = false;
+            uint64_t fb = exon_metrics<FAST_SET>(d, dp, r, hq, aligned, acc, over);
+            if (over) { ++*n_overflow; fb = exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, acc, over); if (over) return RSQC_ERR_CAPACITY; }
+            bits |= fb;
+        }
+        for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((bits >> c) & 1ull) counters[c]++;
+        counters[RSQC_C_END1_MISMATCHES] += rc2.e1_mm; counters[RSQC_C_END1_BASES] += rc2.e1_bases;
+        counters[RSQC_C_END2_MISMATCHES] += rc2.e2_mm; counters[RSQC_C_END2_BASES] += rc2.e2_bases;
+        counters[RSQC_C_MISMATCHED_BASES] += rc2.mm; counters[RSQC_C_TOTAL_BASES] += rc2.bases;
+        counters[RSQC_C_ALIGNMENT_BLOCKS] += rc2.blocks;
+        if (rc2.rl_eligible && rc2.rl_span > rl) rl = (uint32_t)rc2.rl_lqseq;
+    }
+    for (int g = 0; g < a->n_genes_listed; ++g) { gene_reads[g] = reads[(size_t)g]; gene_unique[g] = unique[(size_t)g]; gene_frag[g] = names[(size_t)g].size(); }
+    for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e];
+    *read_length = (int32_t)rl;
+    if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
+    return 0;
+}

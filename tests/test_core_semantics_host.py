@@ -1,0 +1,58 @@
+"""The product's per-record core (rsqc_read.h + rsqc_index.h), compiled for the host by the
+test harness, against the oracle.  This is the same source the HIP kernels compile; the
+oracle walks a trimmed window, the core queries a static index."""
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, synth
+from tests import cases, hostemu
+
+
+def _compare(o, r):
+    names = abi.COUNTER_NAMES
+    for i, n in enumerate(names):
+        assert int(o.counters[i]) == int(r.counters[i]), n
+    np.testing.assert_array_equal(o.gene_reads, r.gene_reads)
+    np.testing.assert_array_equal(o.gene_unique, r.gene_unique)
+    np.testing.assert_array_equal(o.gene_fragments, r.gene_fragments)
+    np.testing.assert_allclose(o.exon_reads, r.exon_reads, rtol=0, atol=1e-9)
+    assert o.read_length == r.read_length
+
+
+def test_quirk_case(oracle_lib):
+    ann, batch = cases.quirk_case()
+    p = abi.default_params()
+    _compare(hostemu.run(p, ann, batch), oracle_lib.run_oracle(p, ann, [batch]))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stranded=abi.STRAND_REVERSE), dict(stranded=abi.STRAND_FORWARD, unpaired=1),
+                                dict(unpaired=1, mapq_threshold=3, n_filter_tags=1, exclude_chimeric=1),
+                                dict(base_mismatch=1, chimeric_distance=100)])
+def test_synthetic_vs_oracle(oracle_lib, kw):
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 3_000_000, 300), ("chrB", 1_500_000, 150), ("chrC", 400_000, 0)])
+    batch = synth.make_reads(ann, 20000, seed=4, dup_frac=0.1, chimeric_tag_frac=0.01, filter_tag_frac=0.02,
+                             contig_lengths=np.array([3_000_000, 1_500_000, 400_000]))
+    p = abi.default_params(**kw)
+    o = hostemu.run(p, ann, batch)
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    _compare(o, r)
+    assert r.gene_reads.sum() > 1000
+
+
+def test_many_overlapping_genes_take_the_slow_path(oracle_lib):
+    # 12 genes stacked on the same exon: more than FAST_SET genes per block
+    rows = []
+    for g in range(12):
+        rows.append(dict(contig="c", type="gene", start=100, end=2000, strand="+-"[g % 2], gene_id="G%d" % g))
+        rows.append(dict(contig="c", type="exon", start=100 + g, end=1500 + g, strand="+-"[g % 2], gene_id="G%d" % g,
+                         exon_id="E%d" % g))
+    from rnaseqc_amd.model import Annotation, Batch
+    ann = Annotation.from_rows(["c"], rows)
+    recs = [dict(qname="a%d" % i, tid=0, pos=200 + i, cigar=[(abi.CIG_M, 50), (abi.CIG_N, 100), (abi.CIG_M, 50)], flag=99)
+            for i in range(40)]
+    b = Batch.from_records(recs)
+    p = abi.default_params()
+    o = hostemu.run(p, ann, b)
+    assert o.n_overflow == 40
+    _compare(o, oracle_lib.run_oracle(p, ann, [b]))
+    assert list(o.gene_reads) == [40] * 12

@@ -1,0 +1,168 @@
+"""-m gpu: the HIP hot path, called through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, engine, synth
+from rnaseqc_amd.model import Annotation, Batch
+from tests import cases
+from tests.compare import assert_results_match
+
+pytestmark = pytest.mark.gpu
+
+SMALL_CONTIGS = [("chrA", 3_000_000, 300), ("chrB", 1_500_000, 150), ("chrC", 400_000, 0)]
+SMALL_LENGTHS = np.array([3_000_000, 1_500_000, 400_000])
+
+
+def small_inputs(n_pairs=20000, seed=4, **kw):
+    ann = synth.make_annotation(seed=3, contigs=SMALL_CONTIGS)
+    batch = synth.make_reads(ann, n_pairs, seed=seed, contig_lengths=SMALL_LENGTHS, **kw)
+    return ann, batch
+
+
+def test_quirk_case_hand_derived(oracle_lib):
+    ann, batch = cases.quirk_case()
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, [batch])
+    c = got.counter_dict()
+    for k, v in cases.QUIRK_COUNTERS.items():
+        assert c[k] == v, (k, c[k], v)
+    assert list(got.gene_reads) == cases.QUIRK_GENE_READS
+    assert list(got.gene_unique) == cases.QUIRK_GENE_UNIQUE
+    assert list(got.gene_fragments) == cases.QUIRK_GENE_FRAGMENTS
+    np.testing.assert_allclose(got.exon_reads, cases.QUIRK_EXON_READS, atol=1e-12)
+    assert got.read_length == cases.QUIRK_READ_LENGTH
+    assert_results_match(got, oracle_lib.run_oracle(p, ann, [batch]))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stranded=abi.STRAND_REVERSE), dict(stranded=abi.STRAND_FORWARD, unpaired=1),
+                                dict(unpaired=1, mapq_threshold=3, n_filter_tags=1, exclude_chimeric=1),
+                                dict(base_mismatch=1, chimeric_distance=100), dict(coverage_mask=100),
+                                dict(coverage_mask=0, bias_window=50, bias_offset=10)])
+def test_synthetic_vs_oracle(oracle_lib, kw):
+    ann, batch = small_inputs(dup_frac=0.1, chimeric_tag_frac=0.01, filter_tag_frac=0.02)
+    p = abi.default_params(**kw)
+    assert_results_match(engine.run_engine(p, ann, [batch]), oracle_lib.run_oracle(p, ann, [batch]))
+
+
+def test_deep_coverage_bias_path(oracle_lib):
+    # few genes, most reads on them: depth in the hundreds so the bias gate (>=100) opens
+    ann = synth.make_annotation(seed=8, contigs=[("chrA", 400_000, 40)])
+    batch = synth.make_reads(ann, 150000, seed=9, frac=(0.97, 0.01, 0.01, 0.01), expr_sigma=1.0,
+                             contig_lengths=np.array([400_000]))
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert int(((want.bias_three + want.bias_five) > 0).sum()) >= 5
+    assert_results_match(engine.run_engine(p, ann, [batch]), want)
+
+
+def test_batch_split_invariance(oracle_lib):
+    ann, batch = small_inputs(n_pairs=8000)
+    p = abi.default_params()
+    cuts = [0, 1, 257, 4096, 9000, batch.n]
+    parts = [batch.slice(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    whole = engine.run_engine(p, ann, [batch])
+    split = engine.run_engine(p, ann, parts)
+    assert_results_match(split, whole)
+    assert_results_match(split, oracle_lib.run_oracle(p, ann, parts))
+
+
+def test_overlapping_genes_slow_path(oracle_lib):
+    rows = []
+    for g in range(12):
+        rows.append(dict(contig="c", type="gene", start=100, end=2000, strand="+-"[g % 2], gene_id="G%d" % g))
+        rows.append(dict(contig="c", type="exon", start=100 + g, end=1500 + g, strand="+-"[g % 2], gene_id="G%d" % g,
+                         exon_id="E%d" % g))
+    ann = Annotation.from_rows(["c"], rows)
+    recs = [dict(qname="a%d" % (i // 2), tid=0, pos=200 + i, cigar=[(abi.CIG_M, 50), (abi.CIG_N, 100), (abi.CIG_M, 50)],
+                 flag=99 if i % 2 == 0 else 147) for i in range(300)]
+    b = Batch.from_records(recs)
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, [b])
+    assert list(got.gene_reads) == [300] * 12
+    assert list(got.gene_fragments) == [150] * 12
+    assert_results_match(got, oracle_lib.run_oracle(p, ann, [b]))
+
+
+def test_resident_batches_and_reset(oracle_lib):
+    ann, batch = small_inputs(n_pairs=6000)
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    e = engine.Engine(p)
+    e.set_annotation(ann)
+    h = e.upload(batch)
+    for _ in range(3):
+        e.reset()
+        e.submit_resident(h)
+        assert_results_match(e.finalize(), want)
+    t = e.timing()
+    assert t["classify_launches"] == 3 and t["classify_records"] == 3 * batch.n
+    assert t["classify_bytes"] == 3 * batch.algorithmic_bytes and t["classify_ms"] > 0
+    e.close()
+
+
+def test_edge_inputs(oracle_lib):
+    ann, batch = small_inputs(n_pairs=500)
+    p = abi.default_params()
+    # empty batch, one-record batch, records with wide (escaped) fields
+    e = engine.Engine(p)
+    e.set_annotation(ann)
+    e.submit(batch.slice(0, 0))
+    r = e.finalize()
+    assert int(r.counters.sum()) == 0 and r.read_length == 0
+    e.close()
+    one = batch.slice(10, 11)
+    assert_results_match(engine.run_engine(p, ann, [one]), oracle_lib.run_oracle(p, ann, [one]))
+    recs = [dict(qname="w1", tid=0, pos=5000, cigar=[(abi.CIG_M, 70000)], flag=99, nm=300, l_qseq=70000),
+            dict(qname="w2", tid=0, pos=6000, cigar=[(abi.CIG_M, 1), (abi.CIG_I, 1)] * 150, flag=147, nm=3),
+            dict(qname="w3", tid=0, pos=7000, cigar=[(abi.CIG_S, 50)], flag=99, nm=0),          # no reference base
+            dict(qname="w4", tid=5, pos=7000, cigar=[(abi.CIG_M, 50)], flag=99, nm=0),          # unrecognised RefID
+            dict(qname="w5", tid=-1, pos=-1, cigar=[], flag=77, mapq=0, nm=None, l_qseq=50)]
+    wide = Batch.from_records(recs)
+    assert len(wide.wide_index) == 2
+    assert_results_match(engine.run_engine(p, ann, [wide]), oracle_lib.run_oracle(p, ann, [wide]))
+
+
+def test_bad_cigar_is_an_error(oracle_lib):
+    ann, _ = small_inputs(n_pairs=10)
+    b = Batch.from_records([dict(qname="b", tid=0, pos=100, cigar=[(9, 50)], flag=99)])
+    p = abi.default_params()
+    with pytest.raises(oracle_lib.OracleError) as eo:
+        oracle_lib.run_oracle(p, ann, [b])
+    assert eo.value.code == abi.ERR_BAD_CIGAR
+    with pytest.raises(engine.EngineError) as eg:
+        engine.run_engine(p, ann, [b])
+    assert eg.value.code == abi.ERR_BAD_CIGAR
+
+
+def test_contig_ownership_shards(oracle_lib):
+    # multi-GPU by contig: each shard sees only its contigs' records and owns only their genes
+    ann, batch = small_inputs(n_pairs=8000)
+    p = abi.default_params()
+    whole = oracle_lib.run_oracle(p, ann, [batch])
+    tid = batch.tid_per_record()
+    a_end = int(np.searchsorted(tid, 1))
+    shard0, shard1 = batch.slice(0, a_end), batch.slice(a_end, batch.n)
+    r0 = engine.run_engine(p, ann, [shard0], owned=[1, 0, 0])
+    r1 = engine.run_engine(p, ann, [shard1], owned=[0, 1, 1])
+    np.testing.assert_array_equal(r0.gene_reads + r1.gene_reads, whole.gene_reads)
+    np.testing.assert_array_equal(r0.gene_fragments + r1.gene_fragments, whole.gene_fragments)
+    np.testing.assert_array_equal(r0.counters + r1.counters, whole.counters)
+    assert not (r0.gene_cov_valid & r1.gene_cov_valid).any()
+    np.testing.assert_array_equal(r0.gene_cov_valid | r1.gene_cov_valid, whole.gene_cov_valid)
+    np.testing.assert_allclose(r0.gene_cov_mean + r1.gene_cov_mean, whole.gene_cov_mean, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(r0.bias_three + r1.bias_three, whole.bias_three)
+
+
+def test_chr1_scale_million_reads(oracle_lib):
+    ann = synth.make_annotation(seed=1)                       # chr1-like: 5 234 genes
+    batch = synth.make_reads(ann, 500_000, seed=2)
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, [batch])
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert_results_match(got, want)
+    # size-independent invariants of the path: every counted record adds 1 to a
+    # gene and its fractions add 1 to that gene's exons when no record is counted to two genes
+    assert abs(got.exon_reads.sum() - got.gene_reads.sum()) < 1e-3 * max(1, got.gene_reads.sum())
+    assert got.counter("Exonic Reads") + got.counter("Intronic Reads") + got.counter("Intergenic Reads") + \
+        got.counter("Ambiguous Reads") == got.counter("Reads used for Intron/Exon counts")
+    assert (got.gene_fragments <= got.gene_reads).all() and (got.gene_unique <= got.gene_reads).all()
