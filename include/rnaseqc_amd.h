@@ -223,23 +223,33 @@ typedef struct rsqc_bed {
     const int32_t *end;
 } rsqc_bed;
 
-/* ---- one batch of alignment records, structure-of-arrays, file order ------
- * 32 bytes per record + 4 bytes per CIGAR op.  Records of
- * one contig form a segment; tid itself is not stored per record.           */
+/* ---- one batch of alignment records, file order ----------------------------
+ * 32 bytes per record + 4 bytes per CIGAR op, stored as two
+ * arrays of 16-byte half-records so that a wavefront reads each with one
+ * 16-byte-per-lane vector load (1 KiB per wave instruction).  Records of one
+ * contig form a segment; tid itself is not stored per record.               */
+typedef struct rsqc_rec_core {         /* 16 bytes                             */
+    int32_t  pos;                      /* core.pos (0-based)                   */
+    int32_t  mpos;                     /* core.mpos                            */
+    int32_t  isize;                    /* core.isize                           */
+    uint32_t cigar_off;                /* first op of the record in `cigar`    */
+} rsqc_rec_core;
+
+typedef struct rsqc_rec_aux {          /* 16 bytes                             */
+    uint64_t qhash;                    /* rsqc_qname_hash(QNAME)               */
+    uint16_t flag;
+    uint16_t l_qseq;                   /* core.l_qseq, RSQC_LQSEQ_ESCAPE = wide */
+    uint8_t  mapq;
+    uint8_t  nm;                       /* NM value, RSQC_NM_ESCAPE = wide      */
+    uint8_t  tagbits;                  /* RSQC_TB_*                            */
+    uint8_t  n_cigar;                  /* RSQC_NCIGAR_ESCAPE = wide            */
+} rsqc_rec_aux;
+
 typedef struct rsqc_batch {
     uint64_t n;                        /* records                              */
     uint64_t file_index_base;          /* index of record 0 in the whole file  */
-    const int32_t  *pos;               /* core.pos (0-based)                   */
-    const int32_t  *mpos;              /* core.mpos                            */
-    const int32_t  *isize;             /* core.isize                           */
-    const uint64_t *qhash;             /* 64-bit hash of QNAME                 */
-    const uint32_t *cigar_off;         /* [n] first op of record i in `cigar`  */
-    const uint16_t *flag;
-    const uint16_t *l_qseq;            /* core.l_qseq, RSQC_LQSEQ_ESCAPE=wide  */
-    const uint8_t  *mapq;
-    const uint8_t  *nm;                /* NM value, RSQC_NM_ESCAPE = wide      */
-    const uint8_t  *tagbits;           /* RSQC_TB_*                            */
-    const uint8_t  *n_cigar;           /* RSQC_NCIGAR_ESCAPE = wide            */
+    const rsqc_rec_core *core;         /* [n]                                  */
+    const rsqc_rec_aux  *aux;          /* [n]                                  */
     const uint32_t *cigar;             /* BAM packed ops: len<<4 | op          */
     uint64_t n_cigar_total;
 

@@ -785,16 +785,18 @@ ORACLE_API int oracle_submit(oracle_ctx *c, const rsqc_batch *b) {
     for (uint32_t s = 0; s < b->n_seg; ++s) {
         for (uint64_t i = b->seg_start[s]; i < b->seg_start[s + 1]; ++i) {
             rec_t r;
-            r.tid = b->seg_tid[s]; r.pos = b->pos[i]; r.mpos = b->mpos[i]; r.isize = b->isize[i];
-            r.flag = b->flag[i]; r.mapq = b->mapq[i]; r.tagbits = b->tagbits[i];
-            r.l_qseq = b->l_qseq[i]; r.nm = b->nm[i]; r.n_cigar = b->n_cigar[i];
-            if (b->l_qseq[i] == RSQC_LQSEQ_ESCAPE || b->nm[i] == RSQC_NM_ESCAPE || b->n_cigar[i] == RSQC_NCIGAR_ESCAPE) {
+            const rsqc_rec_core *rcore = &b->core[i];
+            const rsqc_rec_aux *ra = &b->aux[i];
+            r.tid = b->seg_tid[s]; r.pos = rcore->pos; r.mpos = rcore->mpos; r.isize = rcore->isize;
+            r.flag = ra->flag; r.mapq = ra->mapq; r.tagbits = ra->tagbits;
+            r.l_qseq = ra->l_qseq; r.nm = ra->nm; r.n_cigar = ra->n_cigar;
+            if (ra->l_qseq == RSQC_LQSEQ_ESCAPE || ra->nm == RSQC_NM_ESCAPE || ra->n_cigar == RSQC_NCIGAR_ESCAPE) {
                 while (w < b->n_wide && b->wide_index[w] < i) ++w;
                 if (w >= b->n_wide || b->wide_index[w] != i) return c->error = RSQC_ERR_ARG;
                 r.l_qseq = b->wide_l_qseq[w]; r.nm = b->wide_nm[w]; r.n_cigar = b->wide_n_cigar[w];
             }
-            r.cigar = b->cigar + b->cigar_off[i];
-            r.qhash = b->qhash[i];
+            r.cigar = b->cigar + rcore->cigar_off;
+            r.qhash = ra->qhash;
             r.qname = NULL; r.qname_len = 0;
             if (b->qname && b->qname_off) { r.qname = b->qname + b->qname_off[i]; r.qname_len = b->qname_off[i + 1] - b->qname_off[i]; }
             int rc = process_record(c, &r);

@@ -46,6 +46,12 @@ COUNTER_INDEX = {n: i for i, n in enumerate(COUNTER_NAMES)}
 
 _P = C.c_void_p
 
+# 16-byte half-records of rsqc_batch (rsqc_rec_core / rsqc_rec_aux)
+REC_CORE = np.dtype([("pos", "<i4"), ("mpos", "<i4"), ("isize", "<i4"), ("cigar_off", "<u4")])
+REC_AUX = np.dtype([("qhash", "<u8"), ("flag", "<u2"), ("l_qseq", "<u2"), ("mapq", "u1"), ("nm", "u1"),
+                    ("tagbits", "u1"), ("n_cigar", "u1")])
+assert REC_CORE.itemsize == 16 and REC_AUX.itemsize == 16
+
 
 class Params(C.Structure):
     _fields_ = [
@@ -102,8 +108,7 @@ class BedStruct(C.Structure):
 class BatchStruct(C.Structure):
     _fields_ = [
         ("n", C.c_uint64), ("file_index_base", C.c_uint64),
-        ("pos", _P), ("mpos", _P), ("isize", _P), ("qhash", _P), ("cigar_off", _P),
-        ("flag", _P), ("l_qseq", _P), ("mapq", _P), ("nm", _P), ("tagbits", _P), ("n_cigar", _P),
+        ("core", _P), ("aux", _P),
         ("cigar", _P), ("n_cigar_total", C.c_uint64),
         ("n_seg", C.c_uint32), ("seg_tid", _P), ("seg_start", _P),
         ("n_wide", C.c_uint32), ("wide_index", _P), ("wide_nm", _P), ("wide_l_qseq", _P),

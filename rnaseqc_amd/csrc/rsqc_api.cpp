@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -48,6 +49,7 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
+    int k1_variant = 4, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
 
     // annotation (host copies needed at finalize)
     bool have_ann = false;
@@ -164,6 +166,7 @@ int zero_accumulators(rsqc_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->d_exon_acc.p, 0, c->d_exon_acc.bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_cov.p, 0, c->d_cov.bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_misc.p, 0, c->d_misc.bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync((char *)c->d_misc.p + 36, 0xFF, 4, c->stream));     // rl_stats[1] = min l_qseq
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
     c->finalized = false;
@@ -179,8 +182,7 @@ int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u) {
     u->n = b->n; u->n_cigar_total = b->n_cigar_total;
     int rc;
 #define UP(field, count) if ((rc = upload(c, u->bufs, b->field, (size_t)(count), &d.field))) return rc
-    UP(pos, b->n); UP(mpos, b->n); UP(isize, b->n); UP(qhash, b->n); UP(cigar_off, b->n);
-    UP(flag, b->n); UP(l_qseq, b->n); UP(mapq, b->n); UP(nm, b->n); UP(tagbits, b->n); UP(n_cigar, b->n);
+    UP(core, b->n); UP(aux, b->n);
     UP(cigar, b->n_cigar_total);
     UP(seg_tid, b->n_seg); UP(seg_start, (size_t)b->n_seg + 1);
     UP(wide_index, b->n_wide); UP(wide_nm, b->n_wide); UP(wide_l_qseq, b->n_wide); UP(wide_n_cigar, b->n_wide);
@@ -211,16 +213,18 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     if (c->finalized) return fail(c, RSQC_ERR_ARG, "rsqc_reset required after rsqc_finalize");
     if (u->n == 0) return 0;
     const uint64_t tiles = (u->n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
-    if (tiles > c->tile_cap) {
-        c->tile_cap = tiles + tiles / 4 + 64;
+    const uint64_t wave_tiles = tiles * (RSQC_K1_THREADS / 64);
+    if (wave_tiles > c->tile_cap) {
+        c->tile_cap = wave_tiles + wave_tiles / 4 + 64;
         int rc = dev_alloc(c, c->d_tiles, c->tile_cap * 3 * sizeof(uint32_t), false);
         if (rc) return rc;
         c->acc.tile_span = (uint32_t *)c->d_tiles.p;
         c->acc.tile_lmin = c->acc.tile_span + c->tile_cap;
         c->acc.tile_lmax = c->acc.tile_lmin + c->tile_cap;
     }
-    // (gene, qname-hash) pairs of this batch: at most 2 per record on average
-    const uint64_t want = 2 * u->n + 1024;
+    // (gene, qname-hash) pairs of this batch: the fast path emits at most FAST_SET per record;
+    // the remainder (>= 1 M pairs) is head-room for the pathological slow path
+    const uint64_t want = (uint64_t)FAST_SET * u->n + (1ull << 20);
     if (want > 0xFFFFFFFFull) return fail(c, RSQC_ERR_ARG, "batch too large");
     size_t pidx = 0;
     PairBuf *pb = acquire_pairs(c, (uint32_t)want, &pidx);
@@ -233,12 +237,11 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     acc.pair_count = (uint32_t *)pb->count.p; acc.pair_cap = pb->cap;
     DevBatch d = u->d;
     d.record_base = c->next_record_base;
-    d.tile_base = 0;
     c->next_record_base += u->n;
-    int grid = (int)std::min<uint64_t>(tiles, 256ull * 8ull);
+    int grid = (int)std::min<uint64_t>(tiles, (uint64_t)c->k1_grid);
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    launch_classify(c->stream, grid, c->dann, c->dparams, d, acc);
+    launch_classify(c->stream, grid, c->k1_variant, c->dann, c->dparams, d, acc);
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->k1_events.emplace_back(e0, e1);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
@@ -278,6 +281,10 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.unpaired = params->unpaired;
     c->dparams.exclude_chimeric = params->exclude_chimeric;
     c->dparams.n_filter_tags = params->n_filter_tags;
+    c->dparams.dbg = 0;
+    if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
+    if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::max(1, atoi(e));
+    if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
     return RSQC_OK;
 }
@@ -312,11 +319,6 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
         int brc = hx.build(a, owned_contig, err);
         if (brc) return fail(c, brc, err);
     }
-    const int shift = HostIndex::kBinShift;
-    auto &ex_range = hx.ex_range; auto &g_range = hx.g_range; auto &ex_pmax = hx.ex_pmax; auto &g_pmax = hx.g_pmax;
-    auto &ex_bin = hx.ex_bin; auto &g_bin = hx.g_bin; auto &bin_off = hx.bin_off; auto &ex_cov = hx.ex_cov;
-    auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
-    auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
     const uint64_t run = hx.cov_entries;
     c->cov_entries = run;
     c->exon_row_id.assign(a->exon_row_id, a->exon_row_id + E);
@@ -324,17 +326,14 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     // ---- upload ---------------------------------------------------------------------------------
     DevAnnotation &d = c->dann;
     d.n_ref = a->n_ref; d.n_contigs = nc; d.n_genes = G; d.n_listed = L; d.n_exons = E;
-    d.bin_shift = shift;
+    d.bin_shift = HostIndex::kBinShift;
     int rc;
 #define UPV(dst, vec) if ((rc = upload(c, c->ann_bufs, (vec).data(), (vec).size(), &(dst)))) return rc
 #define UPA(dst, ptr, n) if ((rc = upload(c, c->ann_bufs, (ptr), (size_t)(n), &(dst)))) return rc
-    UPA(d.ex_start, a->exon_row_start, E); UPA(d.ex_end, a->exon_row_end, E); UPV(d.ex_pmax, ex_pmax);
-    UPA(d.ex_gene, a->exon_row_gene, E); UPA(d.ex_flags, a->exon_row_flags, E); UPV(d.ex_cov, ex_cov);
-    UPV(d.ex_range, ex_range);
-    UPA(d.g_start, a->gene_row_start, L); UPA(d.g_end, a->gene_row_end, L); UPV(d.g_pmax, g_pmax);
-    UPA(d.g_flags, a->gene_row_flags, L); UPV(d.g_range, g_range);
-    UPA(d.gene_globin, a->gene_is_globin, G);
-    UPV(d.ex_bin, ex_bin); UPV(d.g_bin, g_bin); UPV(d.bin_off, bin_off);
+    UPV(d.ex, hx.ex_rows); UPV(d.g, hx.g_rows); UPV(d.contig, hx.contig);
+    UPV(d.ex_binhi, hx.ex_binhi); UPV(d.g_binhi, hx.g_binhi); UPV(d.ex_cov, hx.ex_cov);
+    auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
+    auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
     // empty BED until rsqc_set_bed
     std::vector<uint32_t> zero_range((size_t)nc + 1, 0);
     UPV(d.bed_range, zero_range);
@@ -365,6 +364,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     acc.ovf_count = (uint32_t *)c->d_misc.p;
     acc.read_length = (int32_t *)((char *)c->d_misc.p + 8);
     acc.error = (int *)((char *)c->d_misc.p + 16);
+    acc.rl_stats = (uint32_t *)((char *)c->d_misc.p + 32);
     acc.ovf_index = (uint64_t *)c->d_ovf_index.p; acc.ovf_cap = ovf_cap;
     const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
     if ((rc = dev_alloc(c, c->d_gmean, Lz * 8, false)) || (rc = dev_alloc(c, c->d_gstd, Lz * 8, false)) ||
@@ -540,7 +540,7 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         HIP_TRY(c, hipMemsetAsync(c->d_bias5.p, 0, c->d_bias5.bytes, c->stream));
         GeneCovArgs A{};
         A.ge_off = c->d_ge_off; A.ge_row = c->d_ge_row;
-        A.ex_start = c->dann.ex_start; A.ex_end = c->dann.ex_end; A.ex_cov = c->dann.ex_cov;
+        A.ex = c->dann.ex; A.ex_cov = c->dann.ex_cov;
         A.gene_cov_off = c->d_gene_cov_off; A.gene_coding = c->d_gene_coding;
         A.gene_flags = c->d_gene_flags; A.gene_owned = c->d_gene_owned;
         A.gene_reads = c->acc.gene_reads; A.cov = c->acc.cov_diff; A.n_listed = L;

@@ -15,11 +15,8 @@ namespace rsqc {
 struct DevBatch {
     uint64_t n;
     uint64_t record_base;        // file index of record 0
-    const int32_t *pos, *mpos, *isize;
-    const uint64_t *qhash;
-    const uint32_t *cigar_off;
-    const uint16_t *flag, *l_qseq;
-    const uint8_t *mapq, *nm, *tagbits, *n_cigar;
+    const rsqc_rec_core *core;   // 16-byte half-records: one dwordx4 load per lane each
+    const rsqc_rec_aux *aux;
     const uint32_t *cigar;
     uint32_t n_seg;
     const int32_t *seg_tid;
@@ -28,7 +25,6 @@ struct DevBatch {
     const uint64_t *wide_index;
     const int32_t *wide_nm, *wide_l_qseq;
     const uint32_t *wide_n_cigar;
-    uint64_t tile_base;          // first tile summary slot of this batch
 };
 
 // accumulators (device pointers)
@@ -38,14 +34,15 @@ struct DevAccum {
     uint32_t *cov_diff;          // per-base difference array / coverage
     uint32_t *pair_gene; uint64_t *pair_hash; uint32_t *pair_count; uint32_t pair_cap;
     uint32_t *ovf_count; uint64_t *ovf_index; uint32_t ovf_cap;
-    uint32_t *tile_span, *tile_lmin, *tile_lmax;
+    uint32_t *tile_span, *tile_lmin, *tile_lmax;   // per 64-record wave tile (Read-Length fallback scan)
+    uint32_t *rl_stats;          // [3] batch-level max span, min l_qseq, max l_qseq over eligible records
     int32_t *read_length;
     int *error;
 };
 
 struct GeneCovArgs {
     const uint32_t *ge_off, *ge_row;        // exonsForGene CSR (gene id -> exon rows)
-    const int32_t *ex_start, *ex_end;
+    const ExonRow *ex;
     const uint32_t *ex_cov;                 // coverage offset of an exon row
     const uint32_t *gene_cov_off;           // [n_listed]
     const uint32_t *gene_coding;            // [n_listed]
@@ -62,7 +59,7 @@ struct GeneCovArgs {
 };
 void launch_gene_coverage(hipStream_t s, const GeneCovArgs &A);
 
-void launch_classify(hipStream_t s, int grid, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
+void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc);
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc);

@@ -9,15 +9,18 @@
 #include <vector>
 
 #include "../../include/rnaseqc_amd.h"
+#include "rsqc_read.h"
 
 namespace rsqc {
 
 struct HostIndex {
     static constexpr int kBinShift = 11;
     int32_t n_ref = 0, n_contigs = 0, n_genes = 0, n_listed = 0, n_exons = 0;
-    std::vector<uint32_t> ex_range, g_range, ex_bin, g_bin, ex_cov, gene_cov_off, gene_coding;
+    std::vector<uint32_t> ex_range, g_range, ex_binhi, g_binhi, ex_cov, gene_cov_off, gene_coding;
     std::vector<int32_t> ex_pmax, g_pmax;
-    std::vector<uint64_t> bin_off;
+    std::vector<ExonRow> ex_rows;
+    std::vector<GeneRow> g_rows;
+    std::vector<ContigInfo> contig;
     std::vector<uint8_t> gene_flags, gene_owned;     // by listed gene id
     uint64_t cov_entries = 0;
 
@@ -47,30 +50,47 @@ struct HostIndex {
             err = "annotation rows must be sorted by (contig, start) with start <= end";
             return RSQC_ERR_ARG;
         }
-        bin_off.assign((size_t)nc + 1, 0);
+        if (G > (int)ROW_GENE_MASK) { err = "more than 2^26 genes"; return RSQC_ERR_CAPACITY; }
+        // packed 16-byte rows
+        ex_rows.resize((size_t)E); g_rows.resize((size_t)L);
+        for (int i = 0; i < E; ++i) {
+            if (a->exon_row_gene[i] >= (uint32_t)G) { err = "exon_row_gene out of range"; return RSQC_ERR_ARG; }
+            uint32_t fl = a->exon_row_flags[i] & 0x7u;
+            if (a->gene_is_globin[a->exon_row_gene[i]]) fl |= ROWF_GLOBIN;
+            ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_pmax[(size_t)i],
+                                         a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
+        }
+        for (int i = 0; i < L; ++i)
+            g_rows[(size_t)i] = GeneRow{a->gene_row_start[i], a->gene_row_end[i], g_pmax[(size_t)i],
+                                        (uint32_t)(a->gene_row_flags[i] & 0x7u) << ROW_FLAG_SHIFT};
+        // per-contig info + bin tables: binhi[b] = first row with start >= (b+1) << shift
+        contig.assign((size_t)nc, ContigInfo{0, 0, 0, 0});
         auto max_start = [&](const std::vector<uint32_t> &range, const int32_t *start, int k) -> int64_t {
             return range[(size_t)k + 1] > range[(size_t)k] ? (int64_t)start[range[(size_t)k + 1] - 1] : -1;
         };
+        uint64_t total_bins = 0;
         for (int k = 0; k < nc; ++k) {
             const int64_t ms = std::max(max_start(ex_range, a->exon_row_start, k), max_start(g_range, a->gene_row_start, k));
             const uint64_t nb = ms < 0 ? 0 : (uint64_t)(ms >> kBinShift) + 1;
-            bin_off[(size_t)k + 1] = bin_off[(size_t)k] + nb + 1;          // + sentinel
+            if (total_bins + nb > 0xFFFFFFF0ull) { err = "bin table too large"; return RSQC_ERR_CAPACITY; }
+            contig[(size_t)k] = ContigInfo{ex_range[(size_t)k], g_range[(size_t)k], (uint32_t)total_bins, (uint32_t)nb};
+            total_bins += nb;
         }
         auto build_bins = [&](const std::vector<uint32_t> &range, const int32_t *start, std::vector<uint32_t> &bins) {
-            bins.assign((size_t)bin_off[(size_t)nc], 0);
+            bins.assign((size_t)total_bins + 1, 0);
             for (int k = 0; k < nc; ++k) {
-                const uint64_t nb = bin_off[(size_t)k + 1] - bin_off[(size_t)k] - 1;
+                const ContigInfo &ci = contig[(size_t)k];
                 uint32_t row = range[(size_t)k];
                 const uint32_t hi = range[(size_t)k + 1];
-                for (uint64_t b = 0; b <= nb; ++b) {
-                    const int64_t lo_pos = (int64_t)b << kBinShift;
-                    while (row < hi && (int64_t)start[row] < lo_pos) ++row;
-                    bins[(size_t)(bin_off[(size_t)k] + b)] = (b == nb) ? hi : row;
+                for (uint32_t b = 0; b < ci.n_bins; ++b) {
+                    const int64_t lim = ((int64_t)b + 1) << kBinShift;
+                    while (row < hi && (int64_t)start[row] < lim) ++row;
+                    bins[(size_t)ci.bin_base + b] = row;
                 }
             }
         };
-        build_bins(ex_range, a->exon_row_start, ex_bin);
-        build_bins(g_range, a->gene_row_start, g_bin);
+        build_bins(ex_range, a->exon_row_start, ex_binhi);
+        build_bins(g_range, a->gene_row_start, g_binhi);
         // per-base coverage layout: exons of a gene contiguous, in exonsForGene order
         ex_cov.assign((size_t)E, 0);
         gene_cov_off.assign((size_t)std::max(L, 1), 0);
@@ -106,10 +126,8 @@ struct HostIndex {
             gene_flags[id] = a->gene_row_flags[i];
             gene_owned[id] = owned_contig ? (owned_contig[a->gene_row_contig[i]] ? 1 : 0) : 1;
         }
-        for (int i = 0; i < E; ++i) {
+        for (int i = 0; i < E; ++i)
             if (a->exon_row_id[i] >= (uint32_t)E) { err = "exon_row_id out of range"; return RSQC_ERR_ARG; }
-            if (a->exon_row_gene[i] >= (uint32_t)G) { err = "exon_row_gene out of range"; return RSQC_ERR_ARG; }
-        }
         return 0;
     }
 };

@@ -61,41 +61,38 @@ __device__ __forceinline__ void wave_aggregate(bool valid, uint32_t key, uint64_
     }
 }
 
-// ------------------------------------------------------------------ K1 accumulators
-// Fast-path policy: gene hits and the first exon fractions are kept in registers and
-// flushed with wave-level aggregation at a converged point; coverage goes straight to
-// the difference array (2 atomics per committed block).
-struct FastAcc {
-    uint32_t hit[FAST_SET]; int nhit; bool notdup; uint64_t qhash;
-    uint32_t ex_row[2]; double ex_frac[2]; int nex;
-    double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
-    __device__ __forceinline__ void gene_hit(uint32_t g, bool nd, uint64_t qh) {
-        if (nhit < FAST_SET) hit[nhit++] = g;
-        notdup = nd; qhash = qh;
-    }
-    __device__ __forceinline__ void exon_add(uint32_t row, double frac) {
-        if (nex < 2) { ex_row[nex] = row; ex_frac[nex] = frac; ++nex; }
-        else atomicAdd(&exon_acc[row], frac);
-    }
-    __device__ __forceinline__ void cov_range(uint32_t row, uint32_t off, uint32_t len, uint32_t elen) {
-        if (len == 0) return;
-        const uint32_t base = ex_cov[row];
-        atomicAdd(&cov_diff[base + off], 1u);
-        if (off + len < elen) atomicAdd(&cov_diff[base + off + len], 0xFFFFFFFFu);
-    }
-};
+// Runs of equal keys in lane order.  The input is coordinate-sorted, so records that hit the
+// same exon / gene / coverage slot sit in neighbouring lanes: merging each run into one atomic
+// removes the same-address serialisation on highly expressed genes in O(1) instructions.
+struct Run { bool head; uint32_t count; int end; uint64_t mask; };
+__device__ __forceinline__ Run make_run(bool valid, uint32_t key) {
+    const int l = lane_id();
+    const uint32_t pk = __shfl_up(key, 1, 64);
+    const uint64_t vmask = __ballot(valid);
+    const bool pvalid = l > 0 && ((vmask >> (l - 1)) & 1ull);
+    Run r;
+    r.head = valid && (!pvalid || pk != key);
+    const uint64_t stop = __ballot(r.head) | ~vmask;                 // lanes that end the run before them
+    const uint64_t above = l == 63 ? 0ull : stop & ~((2ull << l) - 1ull);
+    r.end = above ? __ffsll((unsigned long long)above) - 1 : 64;
+    r.count = (uint32_t)(r.end - l);
+    const uint64_t upto = r.end == 64 ? ~0ull : ((1ull << r.end) - 1ull);
+    r.mask = upto & ~((1ull << l) - 1ull);
+    return r;
+}
+// sum of v over the run that starts at this (head) lane
+__device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
+    const int l = lane_id();
+    double sc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(sc, o, 64); if (l >= o) sc += t; }
+    const double at_end = __shfl(sc, r.end - 1, 64);
+    return at_end - (sc - v);
+}
 
-// Slow-path policy: plain atomics.
-struct SlowAcc {
-    unsigned long long *gene_reads, *gene_unique; double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
-    uint32_t *pair_gene; uint64_t *pair_hash; uint32_t *pair_count; uint32_t pair_cap; int *error;
-    __device__ __forceinline__ void gene_hit(uint32_t g, bool nd, uint64_t qh) {
-        atomicAdd(&gene_reads[g], 1ull);
-        if (nd) atomicAdd(&gene_unique[g], 1ull);
-        const uint32_t slot = atomicAdd(pair_count, 1u);
-        if (slot < pair_cap) { pair_gene[slot] = g; pair_hash[slot] = qh; }
-        else atomicExch(error, RSQC_ERR_CAPACITY);
-    }
+// accumulator used only when a record has more contained (block, exon) hits than NSTAGE
+struct DirectAcc {
+    double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
     __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[row], frac); }
     __device__ __forceinline__ void cov_range(uint32_t row, uint32_t off, uint32_t len, uint32_t elen) {
         if (len == 0) return;
@@ -105,102 +102,130 @@ struct SlowAcc {
     }
 };
 
-__device__ __forceinline__ bool load_record(const DevBatch &b, uint64_t i, Record &r) {
-    r.pos = b.pos[i]; r.mpos = b.mpos[i]; r.isize = b.isize[i];
-    r.flag = b.flag[i]; r.mapq = b.mapq[i]; r.tagbits = b.tagbits[i];
-    r.l_qseq = b.l_qseq[i]; r.nm = b.nm[i]; r.n_cigar = b.n_cigar[i];
-    r.qhash = b.qhash[i];
-    r.cigar = b.cigar + b.cigar_off[i];
+// record i of the batch; `seg` is a wave-uniform hint for the contig segment
+__device__ __forceinline__ bool load_record(const DevBatch &b, uint64_t i, uint32_t seg, Record &r) {
+    const int4 cv = *reinterpret_cast<const int4 *>(&b.core[i]);          // global_load_dwordx4
+    const int4 av = *reinterpret_cast<const int4 *>(&b.aux[i]);
+    r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
+    r.cigar = b.cigar + (uint32_t)cv.w;
+    r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+    r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
+    r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
+    r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
+    bool ok = true;
     if (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE) {
         uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
         while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
-        if (lo >= b.n_wide || b.wide_index[lo] != i) return false;
-        r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo];
+        if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
+        else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
     }
-    // contig of the record: segment lookup (few segments; sorted input)
+    while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= i) ++seg;          // rarely iterates
+    r.tid = b.seg_tid[seg];
+    return ok;
+}
+// last segment whose start <= i (wave-uniform i -> scalar loads)
+__device__ __forceinline__ uint32_t find_segment(const DevBatch &b, uint64_t i) {
     uint32_t lo = 0, hi = b.n_seg;
-    while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (b.seg_start[m] <= i) lo = m; else hi = m; }
-    r.tid = b.seg_tid[lo];
-    return true;
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (b.seg_start[m] <= i) lo = m; else hi = m; }
+    return lo;
 }
 
 // ------------------------------------------------------------------ K1
-// grid-stride over tiles of blockDim.x records; one record per lane per iteration.
-__global__ void __launch_bounds__(RSQC_K1_THREADS)
-classify_count_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
-    __shared__ unsigned long long s_cnt[RSQC_N_COUNTERS];
-    __shared__ uint32_t s_span[RSQC_K1_THREADS / 64], s_lmin[RSQC_K1_THREADS / 64], s_lmax[RSQC_K1_THREADS / 64];
+// grid-stride over tiles of RSQC_K1_THREADS records; one record per lane per iteration.
+__device__ __forceinline__ void classify_count_body(const DevAnnotation &a, const DevParams &p, const DevBatch &b,
+                                                    const DevAccum &acc, unsigned long long *s_cnt, uint32_t *s_rl) {
     const int l = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) s_cnt[c] = 0ull;
+    if (threadIdx.x == 0) { s_rl[0] = 0u; s_rl[1] = 0xFFFFFFFFu; s_rl[2] = 0u; }
     __syncthreads();
 
     unsigned long long my_cnt = 0ull;     // lane c of every wave accumulates counter c
-    const uint64_t n_tiles = (b.n + blockDim.x - 1) / blockDim.x;
+    uint32_t w_span = 0u, w_lmin = 0xFFFFFFFFu, w_lmax = 0u;
+    DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
+    const uint64_t n_tiles = (b.n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t i = tile * blockDim.x + threadIdx.x;
+        const uint64_t w0 = tile * RSQC_K1_THREADS + (uint64_t)wave * 64u;     // wave-uniform
+        if (w0 >= b.n) break;                                                 // whole wave past the end
+        const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < b.n;
+        const uint32_t seg0 = find_segment(b, w0);
         RecordCounters rc;
         rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
         rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
-        FastAcc fa;
-        fa.nhit = 0; fa.nex = 0; fa.notdup = false; fa.qhash = 0;
-        fa.exon_acc = acc.exon_acc; fa.cov_diff = acc.cov_diff; fa.ex_cov = a.ex_cov;
-        bool overflow = false;
-        Record r;
+        FeatureOut<FAST_SET> fo;
+        fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0;
+        uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
         if (valid) {
-            if (!load_record(b, i, r)) { atomicExch(acc.error, RSQC_ERR_ARG); }
+            Record r;
+            if (!load_record(b, i, seg0, r)) atomicExch(acc.error, RSQC_ERR_ARG);
             else {
-                bool hq; uint32_t aligned;
-                if (gate_cascade(a, p, r, rc, hq, aligned)) {
-                    const uint64_t fbits = exon_metrics<FAST_SET>(a, p, r, hq, aligned, fa, overflow);
+                bool hq;
+                if (gate_cascade(a, p, r, rc, hq, aligned) && !(p.dbg & 8u)) {
+                    bool overflow = false;
+                    exon_metrics<FAST_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
                     if (overflow) {
+                        fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0;
                         const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
                         if (slot < acc.ovf_cap) acc.ovf_index[slot] = i;
                         else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                    } else rc.bits |= fbits;
+                    }
+                    rc.bits |= fo.bits;
+                    notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                 }
                 if (rc.error) atomicExch(acc.error, rc.error);
             }
         }
-        // ---- converged: wave-aggregated flushes ----------------------------------------
-        const uint64_t nd_mask = __ballot(fa.notdup);
+        // ---- converged: run-merged scatter ---------------------------------------------------
 #pragma unroll
-        for (int k = 0; k < FAST_SET; ++k) {
-            const bool has = fa.nhit > k;
-            const uint64_t m = __ballot(has);
-            if (m == 0) break;
-            // (gene, qname-hash) pairs for the fragment de-dup: one slot reservation per wave
-            uint32_t base = 0;
-            if (l == (int)(__ffsll((unsigned long long)m) - 1)) base = atomicAdd(acc.pair_count, (uint32_t)__popcll(m));
-            base = __shfl(base, __ffsll((unsigned long long)m) - 1, 64);
-            if (has) {
-                const uint32_t slot = base + mask_rank(m);
-                if (slot < acc.pair_cap) { acc.pair_gene[slot] = fa.hit[k]; acc.pair_hash[slot] = fa.qhash; }
-                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+        for (int k = 0; k < NSTAGE; ++k) {
+            const bool has = fo.n_commit > k;
+            if (__ballot(has) == 0ull) break;
+            const Commit cm = fo.commit[k];
+            const uint32_t len = cm.len & COMMIT_LEN_MASK;
+            if (!(p.dbg & 2u)) {            // exonCounts[row] += len / aligned, one f64 atomic per run
+                const bool hv = has && len > 0;
+                const Run run = make_run(hv, cm.row);
+                const double sum = run_sum_f64(hv ? (double)len / (double)aligned : 0.0, run);
+                if (run.head) atomicAdd(&acc.exon_acc[cm.row], sum);
             }
-            wave_aggregate(has, fa.hit[k], nd_mask, [&](uint32_t g, uint32_t cnt, uint32_t cnt_nd) {
-                atomicAdd(&acc.gene_reads[g], (unsigned long long)cnt);
-                if (cnt_nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)cnt_nd);
-            });
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const bool has = fa.nex > k;
-            if (__ballot(has) == 0) break;
-            // exon fractions: sum equal rows inside the wave, one f64 atomic per distinct row
-            uint64_t todo = __ballot(has);
-            while (todo) {
-                const int lead = __ffsll((unsigned long long)todo) - 1;
-                const uint32_t r0 = __shfl(fa.ex_row[k], lead, 64);
-                const bool mine = has && fa.ex_row[k] == r0;
-                const uint64_t same = __ballot(mine);
-                const double s = wave_sum(mine ? fa.ex_frac[k] : 0.0);
-                if (l == lead) atomicAdd(&acc.exon_acc[r0], s);
-                todo &= ~same;
+            if (!(p.dbg & 1u)) {            // per-base coverage as a difference array: +1 at the block start ...
+                const bool hv = has && len > 0;
+                const uint32_t base = hv ? a.ex_cov[cm.row] + cm.off : 0u;
+                const Run up = make_run(hv, base);
+                if (up.head) atomicAdd(&acc.cov_diff[base], up.count);
+                const bool hc = hv && (cm.len & COMMIT_CLOSES);          // ... -1 after its last base
+                const Run dn = make_run(hc, base + len);
+                if (dn.head) atomicAdd(&acc.cov_diff[base + len], 0u - dn.count);
             }
         }
-        // ---- scalar counters: ballot + popcount, lane c keeps counter c ----------------
+        {
+            const uint64_t nd_mask = __ballot(notdup);
+#pragma unroll
+            for (int k = 0; k < FAST_SET; ++k) {
+                const bool has = fo.n_hit > k;
+                const uint64_t m = __ballot(has);
+                if (m == 0ull) break;
+                const uint32_t g = fo.hit[k];
+                // (gene, qname-hash) pairs for the fragment de-dup: one slot reservation per wave
+                const int lead = __ffsll((unsigned long long)m) - 1;
+                uint32_t base = 0;
+                if (l == lead) base = atomicAdd(acc.pair_count, (uint32_t)__popcll(m));
+                base = __shfl(base, lead, 64);
+                if (has) {
+                    const uint32_t slot = base + mask_rank(m);
+                    if (slot < acc.pair_cap) { acc.pair_gene[slot] = g; acc.pair_hash[slot] = qhash; }
+                    else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                }
+                const Run run = make_run(has, g);
+                if (run.head) {
+                    atomicAdd(&acc.gene_reads[g], (unsigned long long)run.count);
+                    const uint32_t nd = (uint32_t)__popcll(run.mask & nd_mask);
+                    if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd);
+                }
+            }
+        }
+        // ---- scalar counters: ballot + popcount, lane c keeps counter c ----------------------
 #pragma unroll
         for (int c = 0; c < RSQC_N_COUNTERS; ++c) {
             const uint64_t m = __ballot((rc.bits >> c) & 1ull);
@@ -218,78 +243,105 @@ classify_count_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
             if (l == RSQC_C_TOTAL_BASES) my_cnt += s5;
             if (l == RSQC_C_ALIGNMENT_BLOCKS) my_cnt += s6;
         }
-        // ---- Read-Length tile summary (max span, min/max l_qseq over eligible records) ---
+        // ---- Read-Length inputs: per-wave tile summary + batch-level extremes -----------------
         {
             const uint32_t sp = wave_max_u32(rc.rl_eligible ? rc.rl_span : 0u);
             const uint32_t mn = wave_min_u32(rc.rl_eligible ? (uint32_t)rc.rl_lqseq : 0xFFFFFFFFu);
             const uint32_t mx = wave_max_u32(rc.rl_eligible ? (uint32_t)rc.rl_lqseq : 0u);
-            if (l == 0) { s_span[wave] = sp; s_lmin[wave] = mn; s_lmax[wave] = mx; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t S = 0, mn2 = 0xFFFFFFFFu, mx2 = 0;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-                    S = s_span[w] > S ? s_span[w] : S;
-                    mn2 = s_lmin[w] < mn2 ? s_lmin[w] : mn2;
-                    mx2 = s_lmax[w] > mx2 ? s_lmax[w] : mx2;
-                }
-                const uint64_t t = b.tile_base + tile;
-                acc.tile_span[t] = S; acc.tile_lmin[t] = mn2; acc.tile_lmax[t] = mx2;
+            if (l == 0) {
+                const uint64_t t = tile * (RSQC_K1_THREADS / 64) + (uint64_t)wave;
+                acc.tile_span[t] = sp; acc.tile_lmin[t] = mn; acc.tile_lmax[t] = mx;
             }
-            __syncthreads();
+            w_span = sp > w_span ? sp : w_span; w_lmin = mn < w_lmin ? mn : w_lmin; w_lmax = mx > w_lmax ? mx : w_lmax;
         }
     }
     if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&s_cnt[l], my_cnt);
+    if (l == 0) { atomicMax(&s_rl[0], w_span); atomicMin(&s_rl[1], w_lmin); atomicMax(&s_rl[2], w_lmax); }
     __syncthreads();
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x)
         if (s_cnt[c]) atomicAdd(&acc.counters[c], s_cnt[c]);
+    if (threadIdx.x == 0) {
+        atomicMax(&acc.rl_stats[0], s_rl[0]); atomicMin(&acc.rl_stats[1], s_rl[1]); atomicMax(&acc.rl_stats[2], s_rl[2]);
+    }
 }
+
+// The same body under three register budgets (occupancy vs. spilling is measured, not guessed):
+// min 4 / 6 / 8 waves per SIMD -> at most 128 / 80 / 64 VGPRs.
+#define RSQC_DEFINE_K1(NAME, MINW)                                                              \
+    __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
+    NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
+        __shared__ unsigned long long s_cnt[RSQC_N_COUNTERS];                                   \
+        __shared__ uint32_t s_rl[3];                                                            \
+        classify_count_body(a, p, b, acc, s_cnt, s_rl);                                         \
+    }
+RSQC_DEFINE_K1(classify_count_kernel, 4)
+RSQC_DEFINE_K1(classify_count_kernel_w6, 6)
+RSQC_DEFINE_K1(classify_count_kernel_w8, 8)
 
 // ------------------------------------------------------------------ K1s
 // Records whose block sits fully inside exons of more than FAST_SET genes (pathological
 // annotations).  The gate cascade already counted them; only the feature stage runs here.
 __global__ void classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     const uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         Record r;
-        if (!load_record(b, acc.ovf_index[k], r)) continue;
+        const uint64_t i = acc.ovf_index[k];
+        if (!load_record(b, i, find_segment(b, i), r)) continue;
         RecordCounters rc; bool hq; uint32_t aligned;
         if (!gate_cascade(a, p, r, rc, hq, aligned)) continue;
-        SlowAcc sa{acc.gene_reads, acc.gene_unique, acc.exon_acc, acc.cov_diff, a.ex_cov,
-                   acc.pair_gene, acc.pair_hash, acc.pair_count, acc.pair_cap, acc.error};
+        FeatureOut<SLOW_SET> fo;
         bool overflow = false;
-        const uint64_t bits = exon_metrics<SLOW_SET>(a, p, r, hq, aligned, sa, overflow);
+        exon_metrics<SLOW_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
         if (overflow) { atomicExch(acc.error, RSQC_ERR_CAPACITY); continue; }
-        for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((bits >> c) & 1ull) atomicAdd(&acc.counters[c], 1ull);
+        for (int j = 0; j < fo.n_commit; ++j) {
+            const Commit cm = fo.commit[j];
+            const uint32_t len = cm.len & COMMIT_LEN_MASK;
+            if (len > 0) dacc.exon_add(cm.row, (double)len / (double)aligned);
+            dacc.cov_range(cm.row, cm.off, len, (cm.len & COMMIT_CLOSES) ? cm.off + len + 1 : cm.off + len);
+        }
+        for (int j = 0; j < fo.n_hit; ++j) {
+            const uint32_t g = fo.hit[j];
+            atomicAdd(&acc.gene_reads[g], 1ull);
+            if (!(r.flag & RSQC_FDUP)) atomicAdd(&acc.gene_unique[g], 1ull);
+            const uint32_t slot = atomicAdd(acc.pair_count, 1u);
+            if (slot < acc.pair_cap) { acc.pair_gene[slot] = g; acc.pair_hash[slot] = r.qhash; }
+            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+        }
+        for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((fo.bits >> c) & 1ull) atomicAdd(&acc.counters[c], 1ull);
     }
 }
 
 // ------------------------------------------------------------------ KR
 // "Read Length" (src/RNASeQC.cpp:275-278): readLength = l_qseq of each record whose span
-// exceeds the current value, in FILE order.  One wavefront walks the tile summaries 64 at a
-// time; a tile is opened only when some record in it could change the state to a new value.
+// exceeds the current value, in FILE order.  When every eligible record of the batch has the
+// same l_qseq L (the normal case) the state after the batch is L if some span exceeds the
+// incoming state, else unchanged -- O(1).  Otherwise one wavefront replays the batch: it walks
+// the 64-record tile summaries 64 at a time and opens only tiles that could change the state.
 __global__ void __launch_bounds__(64)
 read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     const int l = lane_id();
     uint32_t r = (uint32_t)*acc.read_length;
-    const uint64_t n_tiles = (b.n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
-    for (uint64_t t0 = 0; t0 < n_tiles; t0 += 64) {
-        const uint64_t t = t0 + l;
-        uint32_t S = 0, mn = 0xFFFFFFFFu, mx = 0;
-        if (t < n_tiles) { S = acc.tile_span[b.tile_base + t]; mn = acc.tile_lmin[b.tile_base + t]; mx = acc.tile_lmax[b.tile_base + t]; }
-        uint64_t need = __ballot(S > r && !(mn == mx && mn == r));
-        while (need) {
-            const int tl = __ffsll((unsigned long long)need) - 1;
-            need &= need - 1;
-            const uint32_t St = __shfl(S, tl, 64), mnt = __shfl(mn, tl, 64), mxt = __shfl(mx, tl, 64);
-            if (!(St > r && !(mnt == mxt && mnt == r))) continue;      // state moved since the ballot
-            // open tile: replay its records in order, 64 at a time
-            const uint64_t base = (t0 + tl) * RSQC_K1_THREADS;
-            for (uint32_t j0 = 0; j0 < RSQC_K1_THREADS; j0 += 64) {
-                const uint64_t i = base + j0 + l;
+    const uint32_t Smax = acc.rl_stats[0], Lmin = acc.rl_stats[1], Lmax = acc.rl_stats[2];
+    if (Lmin == Lmax || Smax <= r) {
+        if (Smax > r) r = Lmin;
+    } else {
+        const uint64_t n_tiles = (b.n + 63) / 64;
+        for (uint64_t t0 = 0; t0 < n_tiles; t0 += 64) {
+            const uint64_t t = t0 + l;
+            uint32_t S = 0, mn = 0xFFFFFFFFu, mx = 0;
+            if (t < n_tiles) { S = acc.tile_span[t]; mn = acc.tile_lmin[t]; mx = acc.tile_lmax[t]; }
+            uint64_t need = __ballot(S > r && !(mn == mx && mn == r));
+            while (need) {
+                const int tl = __ffsll((unsigned long long)need) - 1;
+                need &= need - 1;
+                const uint32_t St = __shfl(S, tl, 64), mnt = __shfl(mn, tl, 64), mxt = __shfl(mx, tl, 64);
+                if (!(St > r && !(mnt == mxt && mnt == r))) continue;      // state moved since the ballot
+                const uint64_t i = (t0 + tl) * 64 + l;                     // replay the tile's 64 records in order
                 uint32_t span = 0, lq = 0; bool elig = false;
                 if (i < b.n) {
                     Record rec;
-                    if (load_record(b, i, rec)) {
+                    if (load_record(b, i, find_segment(b, (t0 + tl) * 64), rec)) {
                         RecordCounters rc; bool hq; uint32_t aligned;
                         gate_cascade(a, p, rec, rc, hq, aligned);
                         elig = rc.rl_eligible != 0; span = rc.rl_span; lq = (uint32_t)rc.rl_lqseq;
@@ -303,12 +355,14 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                     r = __shfl(lq, w, 64);
                     from = w + 1;
                 }
+                need &= __ballot(S > r && !(mn == mx && mn == r));
             }
-            // re-evaluate the remaining tiles of this group against the new state
-            need &= __ballot(S > r && !(mn == mx && mn == r));
         }
     }
-    if (l == 0) *acc.read_length = (int32_t)r;
+    if (l == 0) {
+        *acc.read_length = (int32_t)r;
+        acc.rl_stats[0] = 0u; acc.rl_stats[1] = 0xFFFFFFFFu; acc.rl_stats[2] = 0u;    // ready for the next batch
+    }
 }
 
 // ------------------------------------------------------------------ K4
@@ -414,7 +468,7 @@ gene_coverage_kernel(GeneCovArgs A) {
     // (1) per-exon inclusive scan: difference array -> coverage, in place
     for (uint32_t k = e0; k < e1; ++k) {
         const uint32_t row = A.ge_row[k];
-        const uint32_t len = (uint32_t)(A.ex_end[row] - A.ex_start[row] + 1);
+        const uint32_t len = (uint32_t)(A.ex[row].end - A.ex[row].start + 1);
         uint32_t *E = A.cov + A.ex_cov[row];
         uint32_t carry = 0;
         for (uint32_t j0 = 0; j0 < len; j0 += 64) {
@@ -433,7 +487,7 @@ gene_coverage_kernel(GeneCovArgs A) {
         const uint64_t lo_t = MASK, hi_t = coding > MASK ? coding - MASK : 0;
         for (uint32_t k = e0; k < e1; ++k) {
             const uint32_t row = A.ge_row[k];
-            const uint32_t len = (uint32_t)(A.ex_end[row] - A.ex_start[row] + 1);
+            const uint32_t len = (uint32_t)(A.ex[row].end - A.ex[row].start + 1);
             const uint64_t a0 = t0 > lo_t ? t0 : lo_t, b0 = (uint64_t)t0 + len < hi_t ? (uint64_t)t0 + len : hi_t;
             if (b0 > a0) {
                 const uint32_t a = (uint32_t)(a0 - t0), bnd = (uint32_t)(b0 - t0);
@@ -561,9 +615,11 @@ gene_coverage_kernel(GeneCovArgs A) {
 }
 
 // ------------------------------------------------------------------ launch wrappers
-void launch_classify(hipStream_t s, int grid, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
+void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
-    hipLaunchKernelGGL(classify_count_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    if (variant == 6) hipLaunchKernelGGL(classify_count_kernel_w6, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 8) hipLaunchKernelGGL(classify_count_kernel_w8, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else hipLaunchKernelGGL(classify_count_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {

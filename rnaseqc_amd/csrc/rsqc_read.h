@@ -26,27 +26,38 @@
 namespace rsqc {
 
 // ---- device-resident annotation index ------------------------------------------
+// One 16-byte row per interval so that a candidate costs one vector load.
+struct ExonRow {
+    int32_t start, end;      // 1-based closed
+    int32_t pmax;            // running max of `end` over the contig's rows up to this one
+    uint32_t gf;             // gene id (low 26 bits) | RowFlags << 26
+};
+struct GeneRow {
+    int32_t start, end, pmax;
+    uint32_t gf;             // RowFlags << 26 (gene id bits unused)
+};
+constexpr uint32_t ROW_GENE_MASK = (1u << 26) - 1u;
+constexpr int ROW_FLAG_SHIFT = 26;     // bits 26-27 strand, 28 ribosomal, 29 the row's gene is a globin
+constexpr uint32_t ROWF_RIBOSOMAL = 4u, ROWF_GLOBIN = 8u;
+
+struct ContigInfo {          // 16 bytes per contig
+    uint32_t ex_lo, g_lo;    // first exon / gene row of the contig
+    uint32_t bin_base;       // first entry of the contig in the two bin tables
+    uint32_t n_bins;         // bins of 2^bin_shift bases covering every row start (0 = no rows)
+};
+
 struct DevAnnotation {
     int32_t n_ref, n_contigs, n_genes, n_listed, n_exons;
-    // exon rows (sorted by contig,start)
-    const int32_t  *ex_start, *ex_end, *ex_pmax;   // pmax = running max of end inside the contig
-    const uint32_t *ex_gene;                       // gene id
-    const uint8_t  *ex_flags;
-    const uint32_t *ex_cov;                        // offset of the row's per-base coverage
-    const uint32_t *ex_range;                      // [n_contigs+1] row range of a contig
-    // gene rows
-    const int32_t  *g_start, *g_end, *g_pmax;
-    const uint8_t  *g_flags;
-    const uint32_t *g_range;
-    // per gene id
-    const uint8_t  *gene_globin;
-    // coarse position bins: first row with start >= bin*2^shift (per contig, concatenated)
-    const uint32_t *ex_bin, *g_bin;                // [bin_off[n_contigs]] + 1 sentinel per contig
-    const uint64_t *bin_off;                       // [n_contigs+1]
     int32_t bin_shift;
+    const ExonRow *ex;                 // sorted by (contig, start)
+    const GeneRow *g;
+    const ContigInfo *contig;          // [n_contigs]
+    // bin tables: first row whose start >= (bin + 1) << bin_shift (rows of later contigs excluded)
+    const uint32_t *ex_binhi, *g_binhi;
+    const uint32_t *ex_cov;            // offset of an exon row's per-base coverage
     // BED rows (sorted by contig,start), optional
     const int32_t  *bed_start, *bed_end, *bed_pmax;
-    const uint32_t *bed_range;                     // [n_contigs+1]
+    const uint32_t *bed_range;         // [n_contigs+1]
     int32_t have_bed;
 };
 
@@ -54,6 +65,7 @@ struct DevParams {
     uint32_t mapq_threshold, base_mismatch;
     int32_t  chimeric_distance;
     int32_t  stranded, unpaired, exclude_chimeric, n_filter_tags;
+    uint32_t dbg;      // profiling ablations (RSQC_DEBUG_MASK); 0 in every real run
 };
 
 // one record, already widened
@@ -81,33 +93,18 @@ struct RecordCounters {
 #define RSQC_BIT(c) (1ull << (c))
 
 constexpr int FAST_SET = 4;    // genes per block handled on the fast path (registers)
-constexpr int SLOW_SET = 128;  // ... on the exact slow path (scratch); more -> RSQC_ERR_CAPACITY
+constexpr int SLOW_SET = 32;   // ... on the exact slow path (scratch); more -> RSQC_ERR_CAPACITY
 
 RSQC_HD bool cigar_is_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 RSQC_HD bool cigar_is_block(uint32_t op) { return op == 0 || op == 7 || op == 8; }
 
-// first row in [lo,hi) with start > x
+// first row in [lo,hi) with start > x  (BED rows only)
 RSQC_HD uint32_t upper_bound_rows(const int32_t *start, uint32_t lo, uint32_t hi, int32_t x) {
     while (lo < hi) {
         uint32_t mid = lo + ((hi - lo) >> 1);
         if (start[mid] <= x) lo = mid + 1; else hi = mid;
     }
     return lo;
-}
-
-// Row range [lo, ub) of contig `tid` whose start <= be, using the coarse bins.
-RSQC_HD uint32_t rows_upto(const int32_t *start, const uint32_t *range, const uint32_t *bins,
-                           const uint64_t *bin_off, int shift, int32_t tid, int32_t be) {
-    uint32_t lo = range[tid], hi = range[tid + 1];
-    if (be < 0) return lo;
-    if (bins) {
-        uint64_t nb = bin_off[tid + 1] - bin_off[tid] - 1;     // bins of this contig (last = sentinel)
-        uint64_t b = (uint64_t)(uint32_t)be >> shift;
-        if (b >= nb) return hi;                                // beyond the last feature start
-        uint32_t l2 = bins[bin_off[tid] + b], h2 = bins[bin_off[tid] + b + 1];
-        return upper_bound_rows(start, l2, h2, be);
-    }
-    return upper_bound_rows(start, lo, hi, be);
 }
 
 // feature_strand, src/Expression.cpp:119-125
@@ -120,47 +117,49 @@ RSQC_HD int read_strand_of(const DevParams &p, uint32_t flag) {
 
 struct ClassFlags { bool intragenic, plus, minus, ribosomal, exonic; };
 
-// Gene rows overlapping [bs, be] (be inclusive: the reference's intersectInterval on a
-// block whose end is exclusive, src/GTF.cpp:171-179, Expression.cpp:111) -> flags only.
-RSQC_HD void scan_gene_rows(const DevAnnotation &a, int32_t tid, int32_t bs, int32_t be, int rstrand,
-                            ClassFlags &f) {
-    const uint32_t lo = a.g_range[tid];
-    uint32_t ub = rows_upto(a.g_start, a.g_range, a.g_bin, a.bin_off, a.bin_shift, tid, be);
-    for (uint32_t i = ub; i > lo;) {
-        --i;
-        if (a.g_pmax[i] < bs) break;
-        if (a.g_end[i] < bs) continue;
-        const uint32_t fl = a.g_flags[i];
-        const int fs = fl & RSQC_FF_STRAND_MASK;
-        if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) continue;     // Expression.cpp:331
-        if (fs == RSQC_STRAND_FORWARD) f.plus = true; else if (fs == RSQC_STRAND_REVERSE) f.minus = true;
-        f.intragenic = true;                                               // :352-354
-        if (fl & RSQC_FF_RIBOSOMAL) f.ribosomal = true;                    // :358
-    }
-}
-
-// Exon rows overlapping the block.  Visit(row, contained) for every strand-compatible hit.
+// The overlap query of one block [bs, be] (be inclusive: the reference's intersectInterval on a
+// block whose end is exclusive, src/GTF.cpp:171-179, and its scan bound `start <= block.end`,
+// src/Expression.cpp:111).  The bin table gives the last row whose start can be <= be; rows are
+// walked downwards until the running max of `end` drops below bs.  Equivalent to the reference's
+// linear scan of the trimmed, start-sorted list on coordinate-sorted input.
+// Gene rows set flags; exon rows call visit(row_index, row, contained).
 template <class Visit>
-RSQC_HD void scan_exon_rows(const DevAnnotation &a, int32_t tid, int32_t bs, int32_t be, int rstrand,
-                            ClassFlags *f, Visit &&visit) {
-    const uint32_t lo = a.ex_range[tid];
-    uint32_t ub = rows_upto(a.ex_start, a.ex_range, a.ex_bin, a.bin_off, a.bin_shift, tid, be);
-    for (uint32_t i = ub; i > lo;) {
+RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be, int rstrand,
+                         ClassFlags *f, Visit &&visit) {
+    if (ci.n_bins == 0 || be < 0) return;
+    uint32_t b = (uint32_t)be >> a.bin_shift;
+    if (b >= ci.n_bins) b = ci.n_bins - 1;
+    const uint32_t ghi = f ? a.g_binhi[ci.bin_base + b] : 0u;
+    const uint32_t ehi = a.ex_binhi[ci.bin_base + b];
+    if (f) {
+        for (uint32_t i = ghi; i > ci.g_lo;) {
+            --i;
+            const GeneRow row = a.g[i];
+            if (row.pmax < bs) break;
+            if (row.start > be || row.end < bs) continue;
+            const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
+            const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
+            if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) continue;     // Expression.cpp:331
+            if (fs == RSQC_STRAND_FORWARD) f->plus = true; else if (fs == RSQC_STRAND_REVERSE) f->minus = true;
+            f->intragenic = true;                                              // :352-354
+            if (fl & ROWF_RIBOSOMAL) f->ribosomal = true;                      // :358
+        }
+    }
+    for (uint32_t i = ehi; i > ci.ex_lo;) {
         --i;
-        if (a.ex_pmax[i] < bs) break;
-        const int32_t fe = a.ex_end[i];
-        if (fe < bs) continue;
-        const uint32_t fl = a.ex_flags[i];
-        const int fs = fl & RSQC_FF_STRAND_MASK;
+        const ExonRow row = a.ex[i];
+        if (row.pmax < bs) break;
+        if (row.start > be || row.end < bs) continue;
+        const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
+        const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
         if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) continue;
         if (f) {
             if (fs == RSQC_STRAND_FORWARD) f->plus = true; else if (fs == RSQC_STRAND_REVERSE) f->minus = true;
-            f->exonic = true;                                              // :337 (even for the phantom base)
-            if (fl & RSQC_FF_RIBOSOMAL) f->ribosomal = true;
+            f->exonic = true;                                                  // :337 (even for the phantom base)
+            if (fl & ROWF_RIBOSOMAL) f->ribosomal = true;
         }
-        // partialIntersect == end - start  <=>  fs <= bs && fe >= be - 1   (src/GTF.cpp:181-186)
-        const bool contained = a.ex_start[i] <= bs && fe >= be - 1;
-        visit(i, contained);
+        // partialIntersect == end - start  <=>  start <= bs && end >= be - 1   (src/GTF.cpp:181-186)
+        visit(i, row, row.start <= bs && row.end >= be - 1);
     }
 }
 
@@ -249,22 +248,53 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
 }
 
 // ---- stage 2: exonAlignmentMetrics, src/Expression.cpp:308-458 ---------------------------
-// Returns the feature-stage counter bits, or sets `overflow` (and scatters nothing) when a
-// block is fully inside exons of more than K distinct genes.  `Acc` provides
-//   void gene_hit(uint32_t gene, bool not_duplicate, uint64_t qhash);  geneCounts/unique + de-dup key
-//   void exon_add(uint32_t row, double frac);                          exonCounts[exon] += frac
-//   void cov_range(uint32_t row, uint32_t offset, uint32_t len, uint32_t exon_len);   BaseCoverage commit
+// Nothing is scattered from inside: the function returns what to count.  Up to NSTAGE
+// (block, exon) commits are staged in registers while the gene set common to all blocks is
+// being built; only records with more contained hits than that re-walk their CIGAR and go
+// through `acc` directly (exon_add / cov_range).
+struct Commit { uint32_t row, off, len; };   // len bit 31 (COMMIT_CLOSES): the block ends before the exon does
+constexpr int NSTAGE = 3;
+constexpr uint32_t COMMIT_CLOSES = 0x80000000u, COMMIT_LEN_MASK = 0x7FFFFFFFu;
+
+// small fixed arrays indexed with unrolled compares so that they stay in registers on the GPU
+template <int K> RSQC_HD bool set_contains(const uint32_t (&s)[K], int n, uint32_t v) {
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) have |= (k < n) & (s[k] == v);
+    return have;
+}
+template <int K> RSQC_HD void set_put(uint32_t (&s)[K], int idx, uint32_t v) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (k == idx) s[k] = v;
+}
+
+template <int K>
+struct FeatureOut {
+    uint64_t bits;              // feature-stage counter bits
+    int n_hit; uint32_t hit[K]; // genes to count: geneCounts++, uniqueGeneCounts, (gene, qname) de-dup
+    int n_commit; Commit commit[NSTAGE];   // exonCounts[row] += len/aligned ; coverage[row][off, off+len) += 1
+};
+
+// `Acc` (used only on the re-walk path) provides
+//   void exon_add(uint32_t row, double frac);                                      Metrics.cpp:59-66
+//   void cov_range(uint32_t row, uint32_t offset, uint32_t len, uint32_t exon_len); Metrics.cpp:96-124
+// Sets `overflow` (and returns nothing to count) when a block lies inside exons of more than K genes.
 template <int K, class Acc>
-RSQC_HD uint64_t exon_metrics(const DevAnnotation &a, const DevParams &p, const Record &r, bool hq,
-                              uint32_t aligned, Acc &acc, bool &overflow) {
+RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Record &r, bool hq,
+                          uint32_t aligned, Acc &acc, FeatureOut<K> &out, bool &overflow) {
     const uint32_t fl = r.flag;
     uint64_t bits = 0;
     overflow = false;
+    out.bits = 0; out.n_hit = 0; out.n_commit = 0;
     const int rstrand = read_strand_of(p, fl);
+    const ContigInfo ci = a.contig[r.tid];
     ClassFlags f = {false, false, false, false, false};
     uint32_t last[K]; int nlast = 0;
     uint32_t cur[K];
+    Commit st[NSTAGE]; uint32_t st_gene[NSTAGE]; int nst = 0; bool st_over = false;
+    static_assert(K <= 32, "the globin bit-set below holds 32 slots");
     bool first = true, over = false;
+    uint32_t last_globin = 0;      // bit k: last[k] is a globin gene
     uint32_t nblocks = 0;
     // pass 1: flags + the gene set common to all blocks (:325-374)
     {
@@ -274,67 +304,88 @@ RSQC_HD uint64_t exon_metrics(const DevAnnotation &a, const DevParams &p, const 
             if (cigar_is_block(op)) {
                 ++nblocks;
                 const int32_t bs = start, be = start + (int32_t)len;
-                scan_gene_rows(a, r.tid, bs, be, rstrand, f);
                 int ncur = 0;
-                scan_exon_rows(a, r.tid, bs, be, rstrand, &f, [&](uint32_t row, bool contained) {
+                query_block(a, ci, bs, be, rstrand, &f, [&](uint32_t row_i, const ExonRow &row, bool contained) {
                     if (!contained) return;
-                    const uint32_t g = a.ex_gene[row];
+                    const uint32_t g = row.gf & ROW_GENE_MASK;
+                    if (nst < NSTAGE) {
+                        const uint32_t off = (uint32_t)(bs - row.start);
+                        const uint32_t elen = (uint32_t)(row.end - row.start + 1);
+                        const uint32_t lenc = len | ((off + len < elen) ? COMMIT_CLOSES : 0u);
+#pragma unroll
+                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = row_i; st[k].off = off; st[k].len = lenc; st_gene[k] = g; }
+                        ++nst;
+                    } else st_over = true;
                     if (first) {                          // genes.front()
-                        bool have = false;
-                        for (int k = 0; k < nlast; ++k) have |= (last[k] == g);
-                        if (!have) { if (nlast < K) last[nlast++] = g; else over = true; }
-                    } else {
-                        bool have = false;
-                        for (int k = 0; k < ncur; ++k) have |= (cur[k] == g);
-                        if (!have) { if (ncur < K) cur[ncur++] = g; else over = true; }
+                        if (!set_contains<K>(last, nlast, g)) {
+                            if (nlast < K) {
+                                if ((row.gf >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) last_globin |= 1u << nlast;
+                                set_put<K>(last, nlast, g); ++nlast;
+                            } else over = true;
+                        }
+                    } else if (!set_contains<K>(cur, ncur, g)) {
+                        if (ncur < K) { set_put<K>(cur, ncur, g); ++ncur; } else over = true;
                     }
                 });
-                if (!first) {                             // set_intersection
-                    int w = 0;
-                    for (int k = 0; k < nlast; ++k) {
-                        bool keep = false;
-                        for (int j = 0; j < ncur; ++j) keep |= (cur[j] == last[k]);
-                        if (keep) last[w++] = last[k];
+                if (!first) {                             // set_intersection, :368-374
+                    int w = 0; uint32_t wg = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (k < nlast && set_contains<K>(cur, ncur, last[k])) {
+                            if ((last_globin >> k) & 1u) wg |= 1u << w;
+                            set_put<K>(last, w, last[k]); ++w;
+                        }
                     }
-                    nlast = w;
+                    nlast = w; last_globin = wg;
                 }
                 first = false;
             }
             if (cigar_is_ref(op)) start += (int32_t)len;
         }
     }
-    if (over) { overflow = true; return 0; }
+    if (over) { overflow = true; return; }
     const bool do_exon = nlast > 0;                                                        // :393
     if (nblocks >= 1) {                                                                    // :363,395-404
-        bool globin = false;
-        for (int k = 0; k < nlast; ++k) globin |= (a.gene_globin[last[k]] != 0);
+        const bool globin = last_globin != 0;       // geneNames[gene] in the globin blacklist, :396-398
         if (!globin) {
             bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_READS);
             if (fl & RSQC_FDUP) bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_DUPLICATE_READS);
         }
     }
-    // pass 2: commit (only HQ records counted to at least one gene, :377-392)
-    if (hq && nlast > 0) {
-        int32_t start = r.pos + 1;
-        for (uint32_t i = 0; i < r.n_cigar; ++i) {
-            const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
-            if (cigar_is_block(op)) {
-                const int32_t bs = start, be = start + (int32_t)len;
-                scan_exon_rows(a, r.tid, bs, be, rstrand, (ClassFlags *)nullptr, [&](uint32_t row, bool contained) {
-                    if (!contained) return;
-                    const uint32_t g = a.ex_gene[row];
-                    bool in_last = false;
-                    for (int k = 0; k < nlast; ++k) in_last |= (last[k] == g);
-                    if (!in_last) return;
-                    if (len > 0) acc.exon_add(row, (double)len / (double)aligned);         // :345, Metrics.cpp:59-66
-                    acc.cov_range(row, (uint32_t)(bs - a.ex_start[row]), len,
-                                  (uint32_t)(a.ex_end[row] - a.ex_start[row] + 1));        // Metrics.cpp:96-124
-                });
+    // commit (only HQ records counted to at least one gene, :377-392)
+    if (hq && nlast > 0 && !(p.dbg & 4u)) {
+        if (!st_over) {
+#pragma unroll
+            for (int k = 0; k < NSTAGE; ++k) {
+                if (k < nst && set_contains<K>(last, nlast, st_gene[k])) {
+#pragma unroll
+                    for (int j = 0; j < NSTAGE; ++j) if (j == out.n_commit) out.commit[j] = st[k];
+                    ++out.n_commit;
+                }
             }
-            if (cigar_is_ref(op)) start += (int32_t)len;
+        } else {
+            // rare: more than NSTAGE contained hits -> pass 2 re-walks the CIGAR
+            int32_t start = r.pos + 1;
+            for (uint32_t i = 0; i < r.n_cigar; ++i) {
+                const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
+                if (cigar_is_block(op)) {
+                    const int32_t bs = start, be = start + (int32_t)len;
+                    query_block(a, ci, bs, be, rstrand, (ClassFlags *)nullptr, [&](uint32_t row_i, const ExonRow &row, bool contained) {
+                        if (!contained) return;
+                        const uint32_t g = row.gf & ROW_GENE_MASK;
+                        if (!set_contains<K>(last, nlast, g)) return;
+                        if (len > 0 && !(p.dbg & 2u)) acc.exon_add(row_i, (double)len / (double)aligned);   // :345
+                        if (!(p.dbg & 1u)) acc.cov_range(row_i, (uint32_t)(bs - row.start), len, (uint32_t)(row.end - row.start + 1));
+                    });
+                }
+                if (cigar_is_ref(op)) start += (int32_t)len;
+            }
         }
-        if (aligned > 0)                                   // Collector::queryGene, :380
-            for (int k = 0; k < nlast; ++k) acc.gene_hit(last[k], !(fl & RSQC_FDUP), r.qhash);
+        if (aligned > 0 && !(p.dbg & 2u)) {                // Collector::queryGene, :380
+#pragma unroll
+            for (int k = 0; k < K; ++k) out.hit[k] = last[k];
+            out.n_hit = nlast;
+        }
     }
     // classification counters, :407-457
     if (!f.exonic) {
@@ -358,7 +409,7 @@ RSQC_HD uint64_t exon_metrics(const DevAnnotation &a, const DevParams &p, const 
         if (p.unpaired || (fl & RSQC_FREAD1)) bits |= sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE);
         else bits |= sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE);
     }
-    return bits;
+    out.bits = bits;
 }
 
 // fragmentSizeMetrics block test (src/Expression.cpp:490-507): every block must hit exactly one

@@ -257,9 +257,16 @@ class Batch:
             setattr(self, f, a)
         s.n = self.n
         s.file_index_base = self.file_index_base
-        for f in ("pos", "mpos", "isize", "qhash", "cigar_off", "flag", "l_qseq", "mapq", "nm",
-                  "tagbits", "n_cigar", "cigar", "seg_tid", "seg_start", "wide_index", "wide_nm",
-                  "wide_l_qseq", "wide_n_cigar"):
+        # pack the two 16-byte half-record arrays of the boundary
+        core = np.empty(self.n, dtype=abi.REC_CORE)
+        aux = np.empty(self.n, dtype=abi.REC_AUX)
+        for f in ("pos", "mpos", "isize", "cigar_off"):
+            core[f] = getattr(self, f)
+        for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
+            aux[f] = getattr(self, f)
+        self._core, self._aux = core, aux
+        s.core, s.aux = abi.ptr(core), abi.ptr(aux)
+        for f in ("cigar", "seg_tid", "seg_start", "wide_index", "wide_nm", "wide_l_qseq", "wide_n_cigar"):
             setattr(s, f, abi.ptr(getattr(self, f)))
         s.n_cigar_total = len(self.cigar)
         s.n_seg = len(self.seg_tid)

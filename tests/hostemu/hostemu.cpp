@@ -5,6 +5,7 @@
 // at a time, so that the semantics the HIP kernels execute can be diffed against the
 // oracle in the GPU-less build container.  Wave-level code (reductions, de-dup, coverage
 // statistics, read-length scan) is NOT covered here; the -m gpu tests cover it.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -31,6 +32,18 @@ struct Acc {
         if (off + len < elen) (*cov)[ex_cov[row] + off + len] -= 1u;
     }
 };
+template <int K>
+void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K> &fo, const Record &r, uint32_t aligned) {
+    for (int k = 0; k < fo.n_commit; ++k) {
+        const Commit &c = fo.commit[k];
+        const uint32_t len = c.len & COMMIT_LEN_MASK;
+        const uint32_t elen = (uint32_t)(d.ex[c.row].end - d.ex[c.row].start + 1);
+        if (((c.len & COMMIT_CLOSES) != 0) != (c.off + len < elen)) abort();
+        if (len > 0) acc.exon_add(c.row, (double)len / (double)aligned);
+        acc.cov_range(c.row, c.off, len, elen);
+    }
+    for (int k = 0; k < fo.n_hit; ++k) acc.gene_hit(fo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
+}
 }  // namespace
 
 extern "C" __attribute__((visibility("default")))
@@ -43,12 +56,10 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     if (rc) return rc;
     DevAnnotation d{};
     d.n_ref = a->n_ref; d.n_contigs = a->n_contigs; d.n_genes = a->n_genes; d.n_listed = a->n_genes_listed; d.n_exons = a->n_exons;
-    d.ex_start = a->exon_row_start; d.ex_end = a->exon_row_end; d.ex_pmax = hx.ex_pmax.data(); d.ex_gene = a->exon_row_gene;
-    d.ex_flags = a->exon_row_flags; d.ex_cov = hx.ex_cov.data(); d.ex_range = hx.ex_range.data();
-    d.g_start = a->gene_row_start; d.g_end = a->gene_row_end; d.g_pmax = hx.g_pmax.data(); d.g_flags = a->gene_row_flags;
-    d.g_range = hx.g_range.data(); d.gene_globin = a->gene_is_globin;
-    d.ex_bin = hx.ex_bin.data(); d.g_bin = hx.g_bin.data(); d.bin_off = hx.bin_off.data(); d.bin_shift = HostIndex::kBinShift;
-    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags};
+    d.bin_shift = HostIndex::kBinShift;
+    d.ex = hx.ex_rows.data(); d.g = hx.g_rows.data(); d.contig = hx.contig.data();
+    d.ex_binhi = hx.ex_binhi.data(); d.g_binhi = hx.g_binhi.data(); d.ex_cov = hx.ex_cov.data();
+    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u};
     std::vector<uint64_t> reads((size_t)a->n_genes, 0), unique((size_t)a->n_genes, 0);
     std::vector<double> exon_rows((size_t)a->n_exons, 0.0);
     std::vector<uint32_t> cov((size_t)hx.cov_entries + 1, 0);
@@ -58,23 +69,31 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     uint32_t rl = 0; uint32_t w = 0; *n_overflow = 0;
     for (uint32_t s = 0; s < b->n_seg; ++s) for (uint64_t i = b->seg_start[s]; i < b->seg_start[s + 1]; ++i) {
         Record r;
-        r.tid = b->seg_tid[s]; r.pos = b->pos[i]; r.mpos = b->mpos[i]; r.isize = b->isize[i]; r.flag = b->flag[i];
-        r.mapq = b->mapq[i]; r.tagbits = b->tagbits[i]; r.l_qseq = b->l_qseq[i]; r.nm = b->nm[i]; r.n_cigar = b->n_cigar[i];
-        if (b->l_qseq[i] == RSQC_LQSEQ_ESCAPE || b->nm[i] == RSQC_NM_ESCAPE || b->n_cigar[i] == RSQC_NCIGAR_ESCAPE) {
+        const rsqc_rec_core &co = b->core[i]; const rsqc_rec_aux &au = b->aux[i];
+        r.tid = b->seg_tid[s]; r.pos = co.pos; r.mpos = co.mpos; r.isize = co.isize; r.flag = au.flag;
+        r.mapq = au.mapq; r.tagbits = au.tagbits; r.l_qseq = au.l_qseq; r.nm = au.nm; r.n_cigar = au.n_cigar;
+        if (au.l_qseq == RSQC_LQSEQ_ESCAPE || au.nm == RSQC_NM_ESCAPE || au.n_cigar == RSQC_NCIGAR_ESCAPE) {
             while (w < b->n_wide && b->wide_index[w] < i) ++w;
             if (w >= b->n_wide || b->wide_index[w] != i) return RSQC_ERR_ARG;
             r.l_qseq = b->wide_l_qseq[w]; r.nm = b->wide_nm[w]; r.n_cigar = b->wide_n_cigar[w];
         }
-        r.cigar = b->cigar + b->cigar_off[i]; r.qhash = b->qhash[i];
+        r.cigar = b->cigar + co.cigar_off; r.qhash = au.qhash;
         RecordCounters rc2; bool hq; uint32_t aligned;
         const bool go = gate_cascade(d, dp, r, rc2, hq, aligned);
         uint64_t bits = rc2.bits;
         if (rc2.error) return rc2.error;
         if (go) {
             bool over = false;
-            uint64_t fb = exon_metrics<FAST_SET>(d, dp, r, hq, aligned, acc, over);
-            if (over) { ++*n_overflow; fb = exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, acc, over); if (over) return RSQC_ERR_CAPACITY; }
-            bits |= fb;
+            FeatureOut<FAST_SET> fo;
+            exon_metrics<FAST_SET>(d, dp, r, hq, aligned, acc, fo, over);
+            if (!over) { bits |= fo.bits; apply(acc, d, fo, r, aligned); }
+            else {
+                ++*n_overflow;
+                FeatureOut<SLOW_SET> so;
+                exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, acc, so, over);
+                if (over) return RSQC_ERR_CAPACITY;
+                bits |= so.bits; apply(acc, d, so, r, aligned);
+            }
         }
         for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((bits >> c) & 1ull) counters[c]++;
         counters[RSQC_C_END1_MISMATCHES] += rc2.e1_mm; counters[RSQC_C_END1_BASES] += rc2.e1_bases;
