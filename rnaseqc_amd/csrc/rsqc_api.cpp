@@ -35,9 +35,11 @@ struct UploadedBatch {
     bool in_use = false;
 };
 
-struct PairBuf {
-    DevBuf gene, hash, count;
-    uint32_t cap = 0;
+struct PairBuf {                // (gene, qname-hash) pairs of one submitted batch
+    DevBuf gene, hash, counts;  // counts: [n_chunks] per K1 block, then [1] slow-path counter
+    uint64_t cap = 0;           // pair slots allocated
+    uint32_t n_chunks = 0, chunk_cap = 0, slow_base = 0, slow_cap = 0;
+    uint32_t counts_cap = 0;
     bool used = false;
 };
 
@@ -195,14 +197,17 @@ void free_batch(UploadedBatch *u) {
     delete u;
 }
 
-PairBuf *acquire_pairs(rsqc_ctx *c, uint32_t cap, size_t *index) {
+PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *index) {
     for (size_t i = 0; i < c->pair_pool.size(); ++i)
-        if (!c->pair_pool[i].used && c->pair_pool[i].cap >= cap) { c->pair_pool[i].used = true; *index = i; return &c->pair_pool[i]; }
+        if (!c->pair_pool[i].used && c->pair_pool[i].cap >= cap && c->pair_pool[i].counts_cap >= n_counts) {
+            c->pair_pool[i].used = true; *index = i; return &c->pair_pool[i];
+        }
     PairBuf pb;
     if (hipMalloc(&pb.gene.p, (size_t)cap * 4) != hipSuccess) return nullptr;
     if (hipMalloc(&pb.hash.p, (size_t)cap * 8) != hipSuccess) return nullptr;
-    if (hipMalloc(&pb.count.p, 16) != hipSuccess) return nullptr;
-    pb.cap = cap; pb.used = true;
+    if (hipMalloc(&pb.counts.p, (size_t)n_counts * 4) != hipSuccess) return nullptr;
+    pb.gene.bytes = (size_t)cap * 4; pb.hash.bytes = (size_t)cap * 8; pb.counts.bytes = (size_t)n_counts * 4;
+    pb.cap = cap; pb.counts_cap = n_counts; pb.used = true;
     c->pair_pool.push_back(pb);
     *index = c->pair_pool.size() - 1;
     return &c->pair_pool.back();
@@ -216,29 +221,34 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     const uint64_t wave_tiles = tiles * (RSQC_K1_THREADS / 64);
     if (wave_tiles > c->tile_cap) {
         c->tile_cap = wave_tiles + wave_tiles / 4 + 64;
-        int rc = dev_alloc(c, c->d_tiles, c->tile_cap * 3 * sizeof(uint32_t), false);
+        int rc = dev_alloc(c, c->d_tiles, c->tile_cap * sizeof(uint32_t), false);
         if (rc) return rc;
         c->acc.tile_span = (uint32_t *)c->d_tiles.p;
-        c->acc.tile_lmin = c->acc.tile_span + c->tile_cap;
-        c->acc.tile_lmax = c->acc.tile_lmin + c->tile_cap;
     }
-    // (gene, qname-hash) pairs of this batch: the fast path emits at most FAST_SET per record;
-    // the remainder (>= 1 M pairs) is head-room for the pathological slow path
-    const uint64_t want = (uint64_t)FAST_SET * u->n + (1ull << 20);
-    if (want > 0xFFFFFFFFull) return fail(c, RSQC_ERR_ARG, "batch too large");
+    // (gene, qname-hash) pairs of this batch: every K1 block owns a private chunk sized for the
+    // worst case of its tiles (FAST_SET pairs per record); 1 M extra slots serve the slow path
+    const int grid = (int)std::min<uint64_t>(tiles, (uint64_t)c->k1_grid);
+    const uint64_t tiles_per_block = (tiles + (uint64_t)grid - 1) / (uint64_t)grid;
+    const uint64_t chunk_cap = tiles_per_block * RSQC_K1_THREADS * FAST_SET;
+    const uint64_t slow_cap = 1ull << 20;
+    const uint64_t want = chunk_cap * (uint64_t)grid + slow_cap;
+    if (want > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
     size_t pidx = 0;
-    PairBuf *pb = acquire_pairs(c, (uint32_t)want, &pidx);
+    PairBuf *pb = acquire_pairs(c, want, (uint32_t)grid + 1, &pidx);
     if (!pb) return fail(c, RSQC_ERR_HIP, "hipMalloc(pair buffer) failed");
+    pb->n_chunks = (uint32_t)grid; pb->chunk_cap = (uint32_t)chunk_cap;
+    pb->slow_base = (uint32_t)(chunk_cap * (uint64_t)grid); pb->slow_cap = (uint32_t)slow_cap;
     c->pairs_in_flight.push_back(pidx);
-    HIP_TRY(c, hipMemsetAsync(pb->count.p, 0, 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(pb->counts.p, 0, ((size_t)grid + 1) * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->acc.ovf_count, 0, sizeof(uint32_t), c->stream));
     DevAccum acc = c->acc;
     acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p;
-    acc.pair_count = (uint32_t *)pb->count.p; acc.pair_cap = pb->cap;
+    acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
+    acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
+    acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
     DevBatch d = u->d;
     d.record_base = c->next_record_base;
     c->next_record_base += u->n;
-    int grid = (int)std::min<uint64_t>(tiles, (uint64_t)c->k1_grid);
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     launch_classify(c->stream, grid, c->k1_variant, c->dann, c->dparams, d, acc);
@@ -296,7 +306,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto *u : c->resident) if (u) free_batch(u);
     for (auto *u : c->transient) free_batch(u);
     for (auto &b : c->ann_bufs) b.release();
-    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.count.release(); }
+    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
     DevBuf *all[] = {&c->d_u64, &c->d_exon_acc, &c->d_cov, &c->d_misc, &c->d_ovf_index, &c->d_tiles, &c->d_table,
                      &c->d_tab_off, &c->d_tab_cap, &c->d_gmean, &c->d_gstd, &c->d_gcv, &c->d_gvalid, &c->d_ecv,
                      &c->d_ecv_valid, &c->d_bias3, &c->d_bias5};
@@ -507,31 +517,26 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         hipEvent_t e0 = get_event(c), e1 = get_event(c);
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         // ---- K4: per-gene distinct QNAMEs -------------------------------------------------------
-        std::vector<uint64_t> reads((size_t)std::max(G, 1));
-        HIP_TRY(c, hipMemcpy(reads.data(), c->acc.gene_reads, (size_t)G * 8, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> tab_off((size_t)std::max(G, 1)); std::vector<uint32_t> tab_cap((size_t)std::max(G, 1));
-        uint64_t slots = 0;
-        for (int g = 0; g < G; ++g) {
-            tab_off[(size_t)g] = slots;
-            const uint64_t cap = reads[(size_t)g] ? 2 * reads[(size_t)g] : 0;
-            if (cap > 0xFFFFFFFFull) return fail(c, RSQC_ERR_CAPACITY, "more than 2^31 records on one gene");
-            tab_cap[(size_t)g] = (uint32_t)cap;
-            slots += cap;
-        }
-        if ((rc = dev_alloc(c, c->d_table, slots * 8, true))) return rc;
-        if ((rc = dev_alloc(c, c->d_tab_off, (size_t)std::max(G, 1) * 8, false))) return rc;
+        if ((rc = dev_alloc(c, c->d_tab_off, ((size_t)std::max(G, 1) + 2) * 8, false))) return rc;
         if ((rc = dev_alloc(c, c->d_tab_cap, (size_t)std::max(G, 1) * 4, false))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->d_tab_off.p, tab_off.data(), (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_tab_cap.p, tab_cap.data(), (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+        unsigned long long *d_total = (unsigned long long *)c->d_tab_off.p + std::max(G, 1);
+        launch_dedup_layout(c->stream, c->acc.gene_reads, (uint32_t)G, (uint64_t *)c->d_tab_off.p,
+                            (uint32_t *)c->d_tab_cap.p, d_total, c->acc.error);
+        unsigned long long slots = 0;
+        HIP_TRY(c, hipMemcpyAsync(&slots, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_table.bytes < (size_t)slots * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slots * 8 + (1u << 20), false))) return rc; }
+        if (slots) HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0, (size_t)slots * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->acc.gene_frag, 0, (size_t)G * 8, c->stream));
         for (size_t idx : c->pairs_in_flight) {
             PairBuf &pb = c->pair_pool[idx];
-            uint32_t n_pairs = 0;
-            HIP_TRY(c, hipMemcpy(&n_pairs, pb.count.p, 4, hipMemcpyDeviceToHost));
-            if (n_pairs > pb.cap) return fail(c, RSQC_ERR_CAPACITY, "pair buffer overflow");
-            launch_dedup(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, n_pairs,
-                         (const uint64_t *)c->d_tab_off.p, (const uint32_t *)c->d_tab_cap.p,
-                         (unsigned long long *)c->d_table.p, c->acc.gene_frag);
+            DevAccum acc = c->acc;
+            acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p;
+            acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
+            acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
+            acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
+            launch_dedup(c->stream, acc, pb.n_chunks, (const uint64_t *)c->d_tab_off.p, (const uint32_t *)c->d_tab_cap.p,
+                         (unsigned long long *)c->d_table.p);
         }
         // ---- K3: coverage scan + per-gene statistics + bias ----------------------------------------
         HIP_TRY(c, hipMemsetAsync(c->d_gvalid.p, 0, c->d_gvalid.bytes, c->stream));

@@ -32,9 +32,13 @@ struct DevAccum {
     unsigned long long *gene_reads, *gene_unique, *gene_frag, *counters;   // one allocation, in this order
     double *exon_acc;            // by exon ROW
     uint32_t *cov_diff;          // per-base difference array / coverage
-    uint32_t *pair_gene; uint64_t *pair_hash; uint32_t *pair_count; uint32_t pair_cap;
+    // (gene, qname-hash) pairs of one batch: K1 block k owns [k*pair_chunk_cap, +pair_chunk_count[k]);
+    // the slow path appends to [pair_slow_base, +*pair_slow_count)
+    uint32_t *pair_gene; uint64_t *pair_hash;
+    uint32_t pair_chunk_cap; uint32_t *pair_chunk_count;
+    uint32_t pair_slow_base, pair_slow_cap; uint32_t *pair_slow_count;
     uint32_t *ovf_count; uint64_t *ovf_index; uint32_t ovf_cap;
-    uint32_t *tile_span, *tile_lmin, *tile_lmax;   // per 64-record wave tile (Read-Length fallback scan)
+    uint32_t *tile_span;         // max span per 64-record wave tile (Read-Length fallback scan)
     uint32_t *rl_stats;          // [3] batch-level max span, min l_qseq, max l_qseq over eligible records
     int32_t *read_length;
     int *error;
@@ -65,8 +69,9 @@ void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams
                           const DevAccum &acc);
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc);
-void launch_dedup(hipStream_t s, const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t n_pairs,
-                  const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
-                  unsigned long long *gene_frag);
+void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
+                  unsigned long long *table);
+void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
+                         uint32_t *tab_cap, unsigned long long *total, int *error);
 
 }  // namespace rsqc

@@ -133,23 +133,58 @@ __device__ __forceinline__ uint32_t find_segment(const DevBatch &b, uint64_t i) 
 // ------------------------------------------------------------------ K1
 // grid-stride over tiles of RSQC_K1_THREADS records; one record per lane per iteration.
 __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                                                    const DevAccum &acc, unsigned long long *s_cnt, uint32_t *s_rl) {
+                                                    const DevAccum &acc, unsigned long long *s_cnt, uint32_t *s_rl,
+                                                    uint32_t *s_pairs) {
     const int l = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) s_cnt[c] = 0ull;
-    if (threadIdx.x == 0) { s_rl[0] = 0u; s_rl[1] = 0xFFFFFFFFu; s_rl[2] = 0u; }
+    if (threadIdx.x == 0) { s_rl[0] = 0u; s_rl[1] = 0xFFFFFFFFu; s_rl[2] = 0u; *s_pairs = 0u; }
     __syncthreads();
 
+    // Scalar counters are kept "vertically": plane j holds bit j of this lane's running count of
+    // every counter, so adding the record's 49 one-bit increments is a 5-step ripple carry on
+    // 64-bit words (~30 VALU ops) instead of 49 ballots.  Decoded every 31 iterations.
+    uint64_t pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl4 = 0;
+    uint32_t sum_e1mm = 0, sum_e1b = 0, sum_e2mm = 0, sum_e2b = 0, sum_mm = 0, sum_b = 0, sum_blk = 0;
+    int pending = 0;
     unsigned long long my_cnt = 0ull;     // lane c of every wave accumulates counter c
-    uint32_t w_span = 0u, w_lmin = 0xFFFFFFFFu, w_lmax = 0u;
+    uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
+    auto flush_counts = [&]() {
+#pragma unroll
+        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {
+            const uint32_t v = (uint32_t)((pl0 >> c) & 1ull) | ((uint32_t)((pl1 >> c) & 1ull) << 1) |
+                               ((uint32_t)((pl2 >> c) & 1ull) << 2) | ((uint32_t)((pl3 >> c) & 1ull) << 3) |
+                               ((uint32_t)((pl4 >> c) & 1ull) << 4);
+            const uint32_t tot = wave_sum(v);
+            if (l == c) my_cnt += tot;
+        }
+        pl0 = pl1 = pl2 = pl3 = pl4 = 0;
+        const uint32_t s0 = wave_sum(sum_e1mm), s1 = wave_sum(sum_e1b), s2 = wave_sum(sum_e2mm), s3 = wave_sum(sum_e2b),
+                       s4 = wave_sum(sum_mm), s5 = wave_sum(sum_b), s6 = wave_sum(sum_blk);
+        if (l == RSQC_C_END1_MISMATCHES) my_cnt += s0;
+        if (l == RSQC_C_END1_BASES) my_cnt += s1;
+        if (l == RSQC_C_END2_MISMATCHES) my_cnt += s2;
+        if (l == RSQC_C_END2_BASES) my_cnt += s3;
+        if (l == RSQC_C_MISMATCHED_BASES) my_cnt += s4;
+        if (l == RSQC_C_TOTAL_BASES) my_cnt += s5;
+        if (l == RSQC_C_ALIGNMENT_BLOCKS) my_cnt += s6;
+        sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
+        pending = 0;
+    };
+
     DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
     const uint64_t n_tiles = (b.n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
+    // this block's private chunk of the (gene, qname-hash) pair buffer: no global slot counter
+    const uint32_t chunk_cap = acc.pair_chunk_cap;
+    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
+    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
+    uint32_t seg = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t w0 = tile * RSQC_K1_THREADS + (uint64_t)wave * 64u;     // wave-uniform
         if (w0 >= b.n) break;                                                 // whole wave past the end
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < b.n;
-        const uint32_t seg0 = find_segment(b, w0);
+        while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;        // tiles only move forward
         RecordCounters rc;
         rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
         rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
@@ -158,7 +193,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
         if (valid) {
             Record r;
-            if (!load_record(b, i, seg0, r)) atomicExch(acc.error, RSQC_ERR_ARG);
+            if (!load_record(b, i, seg, r)) atomicExch(acc.error, RSQC_ERR_ARG);
             else {
                 bool hq;
                 if (gate_cascade(a, p, r, rc, hq, aligned) && !(p.dbg & 8u)) {
@@ -207,14 +242,14 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 const uint64_t m = __ballot(has);
                 if (m == 0ull) break;
                 const uint32_t g = fo.hit[k];
-                // (gene, qname-hash) pairs for the fragment de-dup: one slot reservation per wave
+                // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
                 const int lead = __ffsll((unsigned long long)m) - 1;
                 uint32_t base = 0;
-                if (l == lead) base = atomicAdd(acc.pair_count, (uint32_t)__popcll(m));
+                if (l == lead) base = atomicAdd(s_pairs, (uint32_t)__popcll(m));
                 base = __shfl(base, lead, 64);
                 if (has) {
                     const uint32_t slot = base + mask_rank(m);
-                    if (slot < acc.pair_cap) { acc.pair_gene[slot] = g; acc.pair_hash[slot] = qhash; }
+                    if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
                     else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                 }
                 const Run run = make_run(has, g);
@@ -225,56 +260,60 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 }
             }
         }
-        // ---- scalar counters: ballot + popcount, lane c keeps counter c ----------------------
-#pragma unroll
-        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {
-            const uint64_t m = __ballot((rc.bits >> c) & 1ull);
-            if (l == c) my_cnt += (unsigned long long)__popcll(m);
-        }
+        // ---- scalar counters: vertical add of the record's one-bit increments -----------------
         {
-            const uint32_t s0 = wave_sum(rc.e1_mm), s1 = wave_sum(rc.e1_bases), s2 = wave_sum(rc.e2_mm),
-                           s3 = wave_sum(rc.e2_bases), s4 = wave_sum(rc.mm), s5 = wave_sum(rc.bases),
-                           s6 = wave_sum(rc.blocks);
-            if (l == RSQC_C_END1_MISMATCHES) my_cnt += s0;
-            if (l == RSQC_C_END1_BASES) my_cnt += s1;
-            if (l == RSQC_C_END2_MISMATCHES) my_cnt += s2;
-            if (l == RSQC_C_END2_BASES) my_cnt += s3;
-            if (l == RSQC_C_MISMATCHED_BASES) my_cnt += s4;
-            if (l == RSQC_C_TOTAL_BASES) my_cnt += s5;
-            if (l == RSQC_C_ALIGNMENT_BLOCKS) my_cnt += s6;
+            uint64_t carry = rc.bits, t;
+            t = pl0 & carry; pl0 ^= carry; carry = t;
+            t = pl1 & carry; pl1 ^= carry; carry = t;
+            t = pl2 & carry; pl2 ^= carry; carry = t;
+            t = pl3 & carry; pl3 ^= carry; carry = t;
+            pl4 ^= carry;
+            sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
+            sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
+            // 31 iterations fit the 5 planes; the u32 sums cannot overflow before that unless a record
+            // carries an absurd value, in which case flush right away
+            const bool big = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
+            if (++pending == 31 || __ballot(big) != 0ull) flush_counts();
         }
-        // ---- Read-Length inputs: per-wave tile summary + batch-level extremes -----------------
+        // ---- Read-Length inputs: per-wave max span + batch-level extremes -------------------------
         {
-            const uint32_t sp = wave_max_u32(rc.rl_eligible ? rc.rl_span : 0u);
-            const uint32_t mn = wave_min_u32(rc.rl_eligible ? (uint32_t)rc.rl_lqseq : 0xFFFFFFFFu);
-            const uint32_t mx = wave_max_u32(rc.rl_eligible ? (uint32_t)rc.rl_lqseq : 0u);
-            if (l == 0) {
-                const uint64_t t = tile * (RSQC_K1_THREADS / 64) + (uint64_t)wave;
-                acc.tile_span[t] = sp; acc.tile_lmin[t] = mn; acc.tile_lmax[t] = mx;
+            const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
+            const uint32_t wsp = wave_max_u32(sp);
+            if (l == 0) acc.tile_span[tile * (RSQC_K1_THREADS / 64) + (uint64_t)wave] = wsp;
+            l_span = sp > l_span ? sp : l_span;
+            if (rc.rl_eligible) {
+                const uint32_t lq = (uint32_t)rc.rl_lqseq;
+                l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
             }
-            w_span = sp > w_span ? sp : w_span; w_lmin = mn < w_lmin ? mn : w_lmin; w_lmax = mx > w_lmax ? mx : w_lmax;
         }
     }
+    flush_counts();
     if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&s_cnt[l], my_cnt);
-    if (l == 0) { atomicMax(&s_rl[0], w_span); atomicMin(&s_rl[1], w_lmin); atomicMax(&s_rl[2], w_lmax); }
+    {
+        const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
+        if (l == 0) { atomicMax(&s_rl[0], ws); atomicMin(&s_rl[1], wmn); atomicMax(&s_rl[2], wmx); }
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x)
         if (s_cnt[c]) atomicAdd(&acc.counters[c], s_cnt[c]);
     if (threadIdx.x == 0) {
         atomicMax(&acc.rl_stats[0], s_rl[0]); atomicMin(&acc.rl_stats[1], s_rl[1]); atomicMax(&acc.rl_stats[2], s_rl[2]);
+        acc.pair_chunk_count[blockIdx.x] = *s_pairs < chunk_cap ? *s_pairs : chunk_cap;
     }
 }
 
 // The same body under three register budgets (occupancy vs. spilling is measured, not guessed):
-// min 4 / 6 / 8 waves per SIMD -> at most 128 / 80 / 64 VGPRs.
+// min 3 / 4 / 6 / 8 waves per SIMD -> at most 168 / 128 / 80 / 64 VGPRs.
 #define RSQC_DEFINE_K1(NAME, MINW)                                                              \
     __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
     NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
         __shared__ unsigned long long s_cnt[RSQC_N_COUNTERS];                                   \
         __shared__ uint32_t s_rl[3];                                                            \
-        classify_count_body(a, p, b, acc, s_cnt, s_rl);                                         \
+        __shared__ uint32_t s_pairs;                                                            \
+        classify_count_body(a, p, b, acc, s_cnt, s_rl, &s_pairs);                               \
     }
 RSQC_DEFINE_K1(classify_count_kernel, 4)
+RSQC_DEFINE_K1(classify_count_kernel_w3, 3)
 RSQC_DEFINE_K1(classify_count_kernel_w6, 6)
 RSQC_DEFINE_K1(classify_count_kernel_w8, 8)
 
@@ -304,8 +343,8 @@ __global__ void classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, D
             const uint32_t g = fo.hit[j];
             atomicAdd(&acc.gene_reads[g], 1ull);
             if (!(r.flag & RSQC_FDUP)) atomicAdd(&acc.gene_unique[g], 1ull);
-            const uint32_t slot = atomicAdd(acc.pair_count, 1u);
-            if (slot < acc.pair_cap) { acc.pair_gene[slot] = g; acc.pair_hash[slot] = r.qhash; }
+            const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
+            if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = r.qhash; }
             else atomicExch(acc.error, RSQC_ERR_CAPACITY);
         }
         for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((fo.bits >> c) & 1ull) atomicAdd(&acc.counters[c], 1ull);
@@ -329,14 +368,14 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
         const uint64_t n_tiles = (b.n + 63) / 64;
         for (uint64_t t0 = 0; t0 < n_tiles; t0 += 64) {
             const uint64_t t = t0 + l;
-            uint32_t S = 0, mn = 0xFFFFFFFFu, mx = 0;
-            if (t < n_tiles) { S = acc.tile_span[t]; mn = acc.tile_lmin[t]; mx = acc.tile_lmax[t]; }
-            uint64_t need = __ballot(S > r && !(mn == mx && mn == r));
+            uint32_t S = 0;
+            if (t < n_tiles) S = acc.tile_span[t];
+            uint64_t need = __ballot(S > r);
             while (need) {
                 const int tl = __ffsll((unsigned long long)need) - 1;
                 need &= need - 1;
-                const uint32_t St = __shfl(S, tl, 64), mnt = __shfl(mn, tl, 64), mxt = __shfl(mx, tl, 64);
-                if (!(St > r && !(mnt == mxt && mnt == r))) continue;      // state moved since the ballot
+                const uint32_t St = __shfl(S, tl, 64);
+                if (!(St > r)) continue;                                   // state moved since the ballot
                 const uint64_t i = (t0 + tl) * 64 + l;                     // replay the tile's 64 records in order
                 uint32_t span = 0, lq = 0; bool elig = false;
                 if (i < b.n) {
@@ -355,7 +394,7 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                     r = __shfl(lq, w, 64);
                     from = w + 1;
                 }
-                need &= __ballot(S > r && !(mn == mx && mn == r));
+                need &= __ballot(S > r);
             }
         }
     }
@@ -374,18 +413,23 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// grid = pair chunks (one per K1 block) + 1 slow-path region; block c walks chunk c.
 __global__ void __launch_bounds__(256)
-dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t n_pairs,
-                    const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
+dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
+                    const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, const uint32_t *slow_count,
+                    uint32_t slow_cap, const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
                     unsigned long long *gene_frag) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounds = (n_pairs + stride - 1) / stride;
+    const uint32_t c = blockIdx.x;
+    uint32_t n_pairs, base;
+    if (c < n_chunks) { n_pairs = chunk_count[c]; base = c * chunk_cap; }
+    else { n_pairs = *slow_count < slow_cap ? *slow_count : slow_cap; base = slow_base; }
+    const uint32_t rounds = (n_pairs + blockDim.x - 1) / blockDim.x;
     for (uint32_t it = 0; it < rounds; ++it) {
-        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const uint32_t j = it * blockDim.x + threadIdx.x;
         bool fresh = false; uint32_t g = 0;
-        if (i < n_pairs) {
-            g = pair_gene[i];
-            uint64_t key = pair_hash[i];
+        if (j < n_pairs) {
+            g = pair_gene[base + j];
+            uint64_t key = pair_hash[base + j];
             if (key == 0) key = 0x9e3779b97f4a7c15ull;           // 0 marks an empty slot
             const uint32_t cap = tab_cap[g];
             unsigned long long *tab = table + tab_off[g];
@@ -397,9 +441,38 @@ dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32
                 slot = slot + 1 == cap ? 0 : slot + 1;
             }
         }
-        wave_aggregate(fresh, g, 0ull, [&](uint32_t gg, uint32_t cnt, uint32_t) {
-            atomicAdd(&gene_frag[gg], (unsigned long long)cnt);
-        });
+        const Run run = make_run(fresh, g);
+        if (run.head) atomicAdd(&gene_frag[g], (unsigned long long)run.count);
+    }
+}
+
+// per-gene table layout on the device (no host round trip): cap = 2 * geneCounts, offsets by
+// a single-block exclusive scan.  total slot count is written to *total.
+__global__ void __launch_bounds__(1024)
+dedup_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off, uint32_t *tab_cap,
+                    unsigned long long *total, int *error) {
+    __shared__ unsigned long long s_part[1024];
+    const uint32_t per = (n_genes + 1023) / 1024;
+    const uint32_t g0 = threadIdx.x * per, g1 = g0 + per < n_genes ? g0 + per : n_genes;
+    unsigned long long sum = 0;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const unsigned long long cap = 2ull * gene_reads[g];
+        if (cap > 0xFFFFFFFFull) atomicExch(error, RSQC_ERR_CAPACITY);
+        sum += cap;
+    }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; ++t) { const unsigned long long v = s_part[t]; s_part[t] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long off = s_part[threadIdx.x];
+    for (uint32_t g = g0; g < g1; ++g) {
+        const unsigned long long cap = 2ull * gene_reads[g];
+        tab_off[g] = off; tab_cap[g] = (uint32_t)cap;
+        off += cap;
     }
 }
 
@@ -617,7 +690,8 @@ gene_coverage_kernel(GeneCovArgs A) {
 // ------------------------------------------------------------------ launch wrappers
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
-    if (variant == 6) hipLaunchKernelGGL(classify_count_kernel_w6, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 6) hipLaunchKernelGGL(classify_count_kernel_w6, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else if (variant == 8) hipLaunchKernelGGL(classify_count_kernel_w8, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else hipLaunchKernelGGL(classify_count_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
 }
@@ -629,14 +703,15 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
                         const DevAccum &acc) {
     hipLaunchKernelGGL(read_length_kernel, dim3(1), dim3(64), 0, s, a, p, b, acc);
 }
-void launch_dedup(hipStream_t s, const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t n_pairs,
-                  const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
-                  unsigned long long *gene_frag) {
-    if (!n_pairs) return;
-    int grid = (int)((n_pairs + 255) / 256);
-    if (grid > 256 * 8) grid = 256 * 8;
-    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, pair_gene, pair_hash, n_pairs, tab_off,
-                       tab_cap, table, gene_frag);
+void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
+                  unsigned long long *table) {
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(n_chunks + 1), dim3(256), 0, s, acc.pair_gene, acc.pair_hash,
+                       acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_count,
+                       acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag);
+}
+void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
+                         uint32_t *tab_cap, unsigned long long *total, int *error) {
+    hipLaunchKernelGGL(dedup_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, tab_off, tab_cap, total, error);
 }
 void launch_gene_coverage(hipStream_t s, const GeneCovArgs &A) {
     if (A.n_listed <= 0) return;
