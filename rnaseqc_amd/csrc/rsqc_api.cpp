@@ -63,6 +63,7 @@ struct rsqc_ctx {
     // K3 inputs
     const uint32_t *d_ge_off = nullptr, *d_ge_row = nullptr, *d_gene_cov_off = nullptr, *d_gene_coding = nullptr;
     const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
+    const uint32_t *d_gene_order = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
 
@@ -218,7 +219,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     if (c->finalized) return fail(c, RSQC_ERR_ARG, "rsqc_reset required after rsqc_finalize");
     if (u->n == 0) return 0;
     const uint64_t tiles = (u->n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
-    const uint64_t wave_tiles = tiles * (RSQC_K1_THREADS / 64);
+    const uint64_t wave_tiles = (u->n + 63) / 64 + 64;
     if (wave_tiles > c->tile_cap) {
         c->tile_cap = wave_tiles + wave_tiles / 4 + 64;
         int rc = dev_alloc(c, c->d_tiles, c->tile_cap * sizeof(uint32_t), false);
@@ -228,8 +229,9 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     // (gene, qname-hash) pairs of this batch: every K1 block owns a private chunk sized for the
     // worst case of its tiles (FAST_SET pairs per record); 1 M extra slots serve the slow path
     const int grid = (int)std::min<uint64_t>(tiles, (uint64_t)c->k1_grid);
-    const uint64_t tiles_per_block = (tiles + (uint64_t)grid - 1) / (uint64_t)grid;
-    const uint64_t chunk_cap = tiles_per_block * RSQC_K1_THREADS * FAST_SET;
+    const uint64_t total_waves = (uint64_t)grid * (RSQC_K1_THREADS / 64);
+    const uint64_t per_wave = (((u->n + total_waves - 1) / total_waves) + 63ull) & ~63ull;   // as in the kernel
+    const uint64_t chunk_cap = per_wave * (RSQC_K1_THREADS / 64) * FAST_SET;
     const uint64_t slow_cap = 1ull << 20;
     const uint64_t want = chunk_cap * (uint64_t)grid + slow_cap;
     if (want > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
@@ -354,6 +356,10 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     UPV(c->d_gene_coding, gene_coding);
     UPV(c->d_gene_flags, gene_flags);
     UPV(c->d_gene_owned, gene_owned);
+    std::vector<uint32_t> gene_order((size_t)std::max(L, 1), 0);
+    for (int g = 0; g < L; ++g) gene_order[(size_t)g] = (uint32_t)g;
+    std::stable_sort(gene_order.begin(), gene_order.begin() + L, [&](uint32_t x, uint32_t y) { return gene_coding[x] > gene_coding[y]; });
+    UPV(c->d_gene_order, gene_order);
 #undef UPV
 #undef UPA
     // ---- accumulators -----------------------------------------------------------------------------
@@ -548,6 +554,7 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         A.ex = c->dann.ex; A.ex_cov = c->dann.ex_cov;
         A.gene_cov_off = c->d_gene_cov_off; A.gene_coding = c->d_gene_coding;
         A.gene_flags = c->d_gene_flags; A.gene_owned = c->d_gene_owned;
+        A.gene_order = c->d_gene_order;
         A.gene_reads = c->acc.gene_reads; A.cov = c->acc.cov_diff; A.n_listed = L;
         A.mask = c->params.coverage_mask; A.bias_offset = c->params.bias_offset; A.bias_window = c->params.bias_window;
         A.bias_gene_length = c->params.bias_gene_length;

@@ -8,6 +8,8 @@
 
 #define RSQC_K1_THREADS 256
 #define RSQC_MAX_BIAS_WINDOW 1024
+#define RSQC_K3_THREADS 1024
+#define RSQC_K3_MAX_EXONS 1024
 
 namespace rsqc {
 
@@ -52,6 +54,7 @@ struct GeneCovArgs {
     const uint32_t *gene_coding;            // [n_listed]
     const uint8_t *gene_flags;              // [n_listed] flags of the gene row
     const uint8_t *gene_owned;              // [n_listed] gene lies on a contig of this shard
+    const uint32_t *gene_order;             // [n_listed] gene ids, longest coding length first
     const unsigned long long *gene_reads;   // touched test
     uint32_t *cov;
     int32_t n_listed;

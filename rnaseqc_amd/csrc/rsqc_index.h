@@ -91,7 +91,7 @@ struct HostIndex {
         };
         build_bins(ex_range, a->exon_row_start, ex_binhi);
         build_bins(g_range, a->gene_row_start, g_binhi);
-        // per-base coverage layout: exons of a gene contiguous, in exonsForGene order
+        // per-base coverage layout: exons of a gene contiguous, in exonsForGene order, + 1 pad slot per gene
         ex_cov.assign((size_t)E, 0);
         gene_cov_off.assign((size_t)std::max(L, 1), 0);
         gene_coding.assign((size_t)std::max(L, 1), 0);
@@ -113,6 +113,7 @@ struct HostIndex {
                 const uint64_t len = (uint64_t)(a->exon_row_end[row] - a->exon_row_start[row]) + 1;
                 run += len; coding += len;
             }
+            run += 1;        // pad slot: absorbs the -1 of a block that ends with the gene's last exon
             if (g < L) gene_coding[(size_t)g] = (uint32_t)std::min<uint64_t>(coding, 0xFFFFFFFFull);
             if (run >= 0xFFFFFFF0ull) { err = "annotation exceeds 2^32 exonic bases"; return RSQC_ERR_CAPACITY; }
         }

@@ -94,11 +94,11 @@ __device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
 struct DirectAcc {
     double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
     __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[row], frac); }
-    __device__ __forceinline__ void cov_range(uint32_t row, uint32_t off, uint32_t len, uint32_t elen) {
+    __device__ __forceinline__ void cov_range(uint32_t row, uint32_t off, uint32_t len) {
         if (len == 0) return;
         const uint32_t base = ex_cov[row];
         atomicAdd(&cov_diff[base + off], 1u);
-        if (off + len < elen) atomicAdd(&cov_diff[base + off + len], 0xFFFFFFFFu);
+        atomicAdd(&cov_diff[base + off + len], 0xFFFFFFFFu);      // lands on the next exon / the gene's pad slot
     }
 };
 
@@ -173,18 +173,25 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     };
 
     DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
-    const uint64_t n_tiles = (b.n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
+    // Every WAVE streams its own contiguous range of records (input is coordinate-sorted), so
+    // consecutive iterations keep hitting the same gene / exon and the trailing run of an
+    // iteration can stay in registers until the key changes.
+    constexpr uint32_t WPB = RSQC_K1_THREADS / 64;
+    const uint64_t total_waves = (uint64_t)gridDim.x * WPB;
+    const uint64_t per_wave = (((b.n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
+    const uint64_t wbeg = ((uint64_t)blockIdx.x * WPB + (uint64_t)wave) * per_wave;
+    const uint64_t wend = wbeg + per_wave < b.n ? wbeg + per_wave : b.n;
     // this block's private chunk of the (gene, qname-hash) pair buffer: no global slot counter
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
     uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    uint32_t seg = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t w0 = tile * RSQC_K1_THREADS + (uint64_t)wave * 64u;     // wave-uniform
-        if (w0 >= b.n) break;                                                 // whole wave past the end
+    uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
+    uint32_t cg_key = 0, cg_cnt = 0, cg_nd = 0; bool cg_on = false;      // carried gene run (wave-uniform)
+    uint32_t ce_key = 0; double ce_sum = 0.0; bool ce_on = false;        // carried exon run
+    for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
         const uint64_t i = w0 + (uint64_t)l;
-        const bool valid = i < b.n;
-        while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;        // tiles only move forward
+        const bool valid = i < wend;
+        while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;
         RecordCounters rc;
         rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
         rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
@@ -215,23 +222,33 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k) {
             const bool has = fo.n_commit > k;
-            if (__ballot(has) == 0ull) break;
+            const uint64_t hm = __ballot(has);
+            if (hm == 0ull && !(k == 0 && ce_on)) { if (k == 0) continue; else break; }
             const Commit cm = fo.commit[k];
-            const uint32_t len = cm.len & COMMIT_LEN_MASK;
+            const bool hv = has && cm.len > 0;
             if (!(p.dbg & 2u)) {            // exonCounts[row] += len / aligned, one f64 atomic per run
-                const bool hv = has && len > 0;
                 const Run run = make_run(hv, cm.row);
-                const double sum = run_sum_f64(hv ? (double)len / (double)aligned : 0.0, run);
-                if (run.head) atomicAdd(&acc.exon_acc[cm.row], sum);
+                double sum = run_sum_f64(hv ? (double)cm.len / (double)aligned : 0.0, run);
+                if (k == 0) {
+                    const uint64_t vm = __ballot(hv);
+                    if (ce_on) {                                   // previous iteration's tail run
+                        const bool joins = (vm & 1ull) && __shfl(cm.row, 0, 64) == ce_key;
+                        if (joins) { if (l == 0) sum += ce_sum; }
+                        else if (l == 0) atomicAdd(&acc.exon_acc[ce_key], ce_sum);
+                        ce_on = false;
+                    }
+                    const uint64_t heads = __ballot(run.head);
+                    const int tail = (vm >> 63) ? 63 - __clzll((unsigned long long)heads) : -1;
+                    if (run.head && l != tail) atomicAdd(&acc.exon_acc[cm.row], sum);
+                    if (tail >= 0) { ce_key = __shfl(cm.row, tail, 64); ce_sum = __shfl(sum, tail, 64); ce_on = true; }
+                } else if (run.head) atomicAdd(&acc.exon_acc[cm.row], sum);
             }
-            if (!(p.dbg & 1u)) {            // per-base coverage as a difference array: +1 at the block start ...
-                const bool hv = has && len > 0;
+            if (!(p.dbg & 1u) && hm) {      // per-base coverage as a difference array: +1 at the block start ...
                 const uint32_t base = hv ? a.ex_cov[cm.row] + cm.off : 0u;
                 const Run up = make_run(hv, base);
                 if (up.head) atomicAdd(&acc.cov_diff[base], up.count);
-                const bool hc = hv && (cm.len & COMMIT_CLOSES);          // ... -1 after its last base
-                const Run dn = make_run(hc, base + len);
-                if (dn.head) atomicAdd(&acc.cov_diff[base + len], 0u - dn.count);
+                const Run dn = make_run(hv, base + cm.len);          // ... -1 after its last base
+                if (dn.head) atomicAdd(&acc.cov_diff[base + cm.len], 0u - dn.count);
             }
         }
         {
@@ -240,22 +257,41 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             for (int k = 0; k < FAST_SET; ++k) {
                 const bool has = fo.n_hit > k;
                 const uint64_t m = __ballot(has);
-                if (m == 0ull) break;
+                if (m == 0ull && !(k == 0 && cg_on)) { if (k == 0) continue; else break; }
                 const uint32_t g = fo.hit[k];
-                // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
-                const int lead = __ffsll((unsigned long long)m) - 1;
-                uint32_t base = 0;
-                if (l == lead) base = atomicAdd(s_pairs, (uint32_t)__popcll(m));
-                base = __shfl(base, lead, 64);
-                if (has) {
-                    const uint32_t slot = base + mask_rank(m);
-                    if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
-                    else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                if (m) {
+                    // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
+                    const int lead = __ffsll((unsigned long long)m) - 1;
+                    uint32_t base = 0;
+                    if (l == lead) base = atomicAdd(s_pairs, (uint32_t)__popcll(m));
+                    base = __shfl(base, lead, 64);
+                    if (has) {
+                        const uint32_t slot = base + mask_rank(m);
+                        if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
+                        else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                    }
                 }
                 const Run run = make_run(has, g);
-                if (run.head) {
-                    atomicAdd(&acc.gene_reads[g], (unsigned long long)run.count);
-                    const uint32_t nd = (uint32_t)__popcll(run.mask & nd_mask);
+                uint32_t cnt = run.count, nd = (uint32_t)__popcll(run.mask & nd_mask);
+                if (k == 0) {
+                    if (cg_on) {
+                        const bool joins = (m & 1ull) && __shfl(g, 0, 64) == cg_key;
+                        if (joins) { if (l == 0) { cnt += cg_cnt; nd += cg_nd; } }
+                        else if (l == 0) {
+                            atomicAdd(&acc.gene_reads[cg_key], (unsigned long long)cg_cnt);
+                            if (cg_nd) atomicAdd(&acc.gene_unique[cg_key], (unsigned long long)cg_nd);
+                        }
+                        cg_on = false;
+                    }
+                    const uint64_t heads = __ballot(run.head);
+                    const int tail = (m >> 63) ? 63 - __clzll((unsigned long long)heads) : -1;
+                    if (run.head && l != tail) {
+                        atomicAdd(&acc.gene_reads[g], (unsigned long long)cnt);
+                        if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd);
+                    }
+                    if (tail >= 0) { cg_key = __shfl(g, tail, 64); cg_cnt = __shfl(cnt, tail, 64); cg_nd = __shfl(nd, tail, 64); cg_on = true; }
+                } else if (run.head) {
+                    atomicAdd(&acc.gene_reads[g], (unsigned long long)cnt);
                     if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd);
                 }
             }
@@ -279,12 +315,19 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         {
             const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
             const uint32_t wsp = wave_max_u32(sp);
-            if (l == 0) acc.tile_span[tile * (RSQC_K1_THREADS / 64) + (uint64_t)wave] = wsp;
+            if (l == 0) acc.tile_span[w0 >> 6] = wsp;
             l_span = sp > l_span ? sp : l_span;
             if (rc.rl_eligible) {
                 const uint32_t lq = (uint32_t)rc.rl_lqseq;
                 l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
             }
+        }
+    }
+    if (l == 0) {                                        // carried runs that never met a different key
+        if (ce_on) atomicAdd(&acc.exon_acc[ce_key], ce_sum);
+        if (cg_on) {
+            atomicAdd(&acc.gene_reads[cg_key], (unsigned long long)cg_cnt);
+            if (cg_nd) atomicAdd(&acc.gene_unique[cg_key], (unsigned long long)cg_nd);
         }
     }
     flush_counts();
@@ -335,9 +378,8 @@ __global__ void classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, D
         if (overflow) { atomicExch(acc.error, RSQC_ERR_CAPACITY); continue; }
         for (int j = 0; j < fo.n_commit; ++j) {
             const Commit cm = fo.commit[j];
-            const uint32_t len = cm.len & COMMIT_LEN_MASK;
-            if (len > 0) dacc.exon_add(cm.row, (double)len / (double)aligned);
-            dacc.cov_range(cm.row, cm.off, len, (cm.len & COMMIT_CLOSES) ? cm.off + len + 1 : cm.off + len);
+            if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
+            dacc.cov_range(cm.row, cm.off, cm.len);
         }
         for (int j = 0; j < fo.n_hit; ++j) {
             const uint32_t g = fo.hit[j];
@@ -477,171 +519,254 @@ dedup_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint
 }
 
 // ------------------------------------------------------------------ K3
-// One wavefront per gene.  cov[] holds the per-base DIFFERENCE array of the gene's exons,
-// laid out contiguously in exonsForGene order, so the stitched transcript vector of
-// computeCoverage (src/Metrics.cpp:306-308) is simply cov[gene_cov_off .. +coding).
+// One 1024-thread workgroup per gene, longest genes first.  cov[] holds the per-base DIFFERENCE
+// array of the gene's exons, contiguous in exonsForGene order (+1 pad slot), so a plain prefix
+// sum yields the stitched transcript vector of computeCoverage (src/Metrics.cpp:306-308).
+#define K3T RSQC_K3_THREADS
+#define K3W (RSQC_K3_THREADS / 64)
 
+struct K3Shared {
+    unsigned long long u64[K3W];
+    double f64[K3W];
+    uint32_t u32a[K3W], u32b[K3W];
+    uint32_t hist[256];
+    uint32_t win[2][RSQC_MAX_BIAS_WINDOW];
+    uint32_t toff[RSQC_K3_MAX_EXONS + 1];           // transcript offset of each exon
+    unsigned long long esum[RSQC_K3_MAX_EXONS];
+    double esq[RSQC_K3_MAX_EXONS];
+    uint32_t bc_u32[4]; double bc_f64[2];
+};
 
-__device__ __forceinline__ double wave_sum_f64(double v) { return wave_sum(v); }
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) { return wave_sum(v); }
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, K3Shared &S) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) S.u64[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < K3W; ++w) t += S.u64[w];
+    return t;
+}
+__device__ __forceinline__ double block_sum_f64(double v, K3Shared &S) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) S.f64[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < K3W; ++w) t += S.f64[w];
+    return t;
+}
+__device__ __forceinline__ uint32_t block_min_u32(uint32_t v, K3Shared &S) {
+    v = wave_min_u32(v);
+    __syncthreads();
+    if (lane_id() == 0) S.u32a[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < K3W; ++w) t = S.u32a[w] < t ? S.u32a[w] : t;
+    return t;
+}
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, K3Shared &S) {
+    v = wave_max_u32(v);
+    __syncthreads();
+    if (lane_id() == 0) S.u32a[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < K3W; ++w) t = S.u32a[w] > t ? S.u32a[w] : t;
+    return t;
+}
 
-// quirky computeMedian (src/Metrics.h:147-160) of the k-th order statistics of a window held in
-// LDS (unsorted): select by rank counting.  Returns false for an empty window (range_error).
-__device__ bool window_median(const uint32_t *w, uint32_t n, double *out) {
+// quirky computeMedian (src/Metrics.h:147-160) of a window held in LDS (unsorted): the two middle
+// order statistics are found by rank counting.  Called by the whole block; result broadcast.
+__device__ bool window_median(const uint32_t *w, uint32_t n, double *out, K3Shared &S) {
     if (n == 0) return false;
-    const int l = lane_id();
     if (n == 1) { *out = (double)w[0]; return true; }
     const uint32_t mid = (n - 1) / 2;
-    const bool odd = (n & 1u) != 0;
-    uint32_t va = 0, vb = 0;       // values with rank mid and mid+1
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const uint32_t i = i0 + l;
-        uint32_t rank = 0xFFFFFFFFu, v = 0;
-        if (i < n) {
-            v = w[i]; rank = 0;
-            for (uint32_t j = 0; j < n; ++j) { const uint32_t u = w[j]; rank += (u < v || (u == v && j < i)) ? 1u : 0u; }
-        }
-        const uint64_t ma = __ballot(rank == mid), mb = __ballot(rank == mid + 1);
-        if (ma) va = __shfl(v, __ffsll((unsigned long long)ma) - 1, 64);
-        if (mb) vb = __shfl(v, __ffsll((unsigned long long)mb) - 1, 64);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t v = w[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) { const uint32_t u = w[j]; rank += (u < v || (u == v && j < i)) ? 1u : 0u; }
+        if (rank == mid) S.bc_u32[0] = v;
+        if (rank == mid + 1) S.bc_u32[1] = v;
     }
-    *out = odd ? ((double)va + (double)vb) / 2.0 : (double)va;
+    __syncthreads();
+    *out = (n & 1u) ? ((double)S.bc_u32[0] + (double)S.bc_u32[1]) / 2.0 : (double)S.bc_u32[0];
     return true;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(RSQC_K3_THREADS)
 gene_coverage_kernel(GeneCovArgs A) {
-    __shared__ uint32_t s_hist[4][256];
-    __shared__ uint32_t s_win[4][2][RSQC_MAX_BIAS_WINDOW];
+    __shared__ K3Shared S;
+    const int tid = (int)threadIdx.x;
     const int l = lane_id();
-    const int wv = (int)(threadIdx.x >> 6);
-    const int gene = (int)(blockIdx.x * 4 + wv);
-    if (gene >= A.n_listed) return;
+    const int wv = tid >> 6;
+    const int gene = (int)A.gene_order[blockIdx.x];
     if (!A.gene_owned[gene]) return;
     const uint32_t coding = A.gene_coding[gene];
-    const uint32_t e0 = A.ge_off[gene], e1 = A.ge_off[gene + 1];
+    const uint32_t e0 = A.ge_off[gene], e1 = A.ge_off[gene + 1], n_ex = e1 - e0;
     uint32_t *C = A.cov + A.gene_cov_off[gene];
     const uint32_t MASK = A.mask;
-    const bool touched = A.gene_reads[gene] != 0ull;
     const uint32_t W = (uint32_t)A.bias_window, OFF = (uint32_t)A.bias_offset;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
 
-    if (!touched) {
-        // all-zero coverage: mean 0, std 0, cv NaN; no exon CV; the bias gate reads zeros.
-        if (coding >= A.bias_gene_length) {
-            uint32_t cur = W / 2 < coding ? W / 2 : coding;
-            if ((W < cur ? W : cur) == 0 && l == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN);
-        }
-        if (l == 0) {
-            const bool valid = MASK ? coding > 2 * (uint64_t)MASK : coding > 0;
-            A.g_valid[gene] = valid ? 1 : 0;
-            A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = __longlong_as_double(0x7ff8000000000000ll);
+    if (A.gene_reads[gene] == 0ull) {
+        // never counted: all-zero coverage -> mean 0, std 0, cv NaN; no exon CV; the bias gate reads zeros
+        if (tid == 0) {
+            if (coding >= A.bias_gene_length) {
+                const uint32_t cur = W / 2 < coding ? W / 2 : coding;
+                if ((W < cur ? W : cur) == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN);
+            }
+            A.g_valid[gene] = (MASK ? coding > 2 * (uint64_t)MASK : coding > 0) ? 1 : 0;
+            A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = qnan;
         }
         return;
     }
-    // (1) per-exon inclusive scan: difference array -> coverage, in place
-    for (uint32_t k = e0; k < e1; ++k) {
-        const uint32_t row = A.ge_row[k];
-        const uint32_t len = (uint32_t)(A.ex[row].end - A.ex[row].start + 1);
-        uint32_t *E = A.cov + A.ex_cov[row];
+    // (1) difference array -> coverage: block-wide inclusive scan, 4 bases per thread per round
+    {
         uint32_t carry = 0;
-        for (uint32_t j0 = 0; j0 < len; j0 += 64) {
-            const uint32_t j = j0 + l;
-            uint32_t v = j < len ? E[j] : 0u;
-            v = wave_inclusive_scan_u32(v) + carry;
-            if (j < len) E[j] = v;
-            carry = __shfl(v, 63, 64);
+        for (uint32_t base = 0; base < coding; base += K3T * 4) {
+            const uint32_t j = base + (uint32_t)tid * 4;
+            uint32_t v0 = j < coding ? C[j] : 0u, v1 = j + 1 < coding ? C[j + 1] : 0u,
+                     v2 = j + 2 < coding ? C[j + 2] : 0u, v3 = j + 3 < coding ? C[j + 3] : 0u;
+            v1 += v0; v2 += v1; v3 += v2;
+            const uint32_t inc = wave_inclusive_scan_u32(v3);
+            __syncthreads();
+            if (l == 63) S.u32b[wv] = inc;
+            __syncthreads();
+            uint32_t before = carry, total = 0;
+#pragma unroll
+            for (int w = 0; w < K3W; ++w) { const uint32_t t = S.u32b[w]; if (w < wv) before += t; total += t; }
+            const uint32_t ex = before + inc - v3;
+            if (j < coding) C[j] = v0 + ex;
+            if (j + 1 < coding) C[j + 1] = v1 + ex;
+            if (j + 2 < coding) C[j + 2] = v2 + ex;
+            if (j + 3 < coding) C[j + 3] = v3 + ex;
+            carry += total;
         }
     }
     __threadfence_block();
-    // (2) per-exon CV over the unmasked part (src/Metrics.cpp:267-305): transcript positions
-    //     [MASK, coding-MASK) survive the two mask walks
+    __syncthreads();
+    // (2) per-exon CV over transcript positions [MASK, coding-MASK) (src/Metrics.cpp:267-305)
     {
-        uint32_t t0 = 0;
         const uint64_t lo_t = MASK, hi_t = coding > MASK ? coding - MASK : 0;
-        for (uint32_t k = e0; k < e1; ++k) {
-            const uint32_t row = A.ge_row[k];
-            const uint32_t len = (uint32_t)(A.ex[row].end - A.ex[row].start + 1);
-            const uint64_t a0 = t0 > lo_t ? t0 : lo_t, b0 = (uint64_t)t0 + len < hi_t ? (uint64_t)t0 + len : hi_t;
-            if (b0 > a0) {
-                const uint32_t a = (uint32_t)(a0 - t0), bnd = (uint32_t)(b0 - t0);
-                const double size = (double)(bnd - a);
-                const uint32_t *E = A.cov + A.ex_cov[row];
-                unsigned long long s = 0;
-                for (uint32_t j = a + l; j < bnd; j += 64) s += E[j];
-                s = wave_sum_u64(s);
-                const double mean = (double)s / size;
-                double q = 0.0;
-                for (uint32_t j = a + l; j < bnd; j += 64) { const double d = (double)E[j] - mean; q += d * d; }
-                q = wave_sum_f64(q);
-                const double cv = sqrt(q / size) / mean;
-                if (l == 0 && !(isnan(cv) || isinf(cv))) { A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
+        if (hi_t > lo_t && n_ex <= RSQC_K3_MAX_EXONS) {
+            for (uint32_t k = tid; k < n_ex; k += K3T) {
+                S.toff[k] = A.ex_cov[A.ge_row[e0 + k]] - A.gene_cov_off[gene];
+                S.esum[k] = 0ull; S.esq[k] = 0.0;
             }
-            t0 += len;
+            if (tid == 0) S.toff[n_ex] = coding;
+            __syncthreads();
+            auto exon_of = [&](uint32_t j) { uint32_t lo = 0, hi = n_ex; while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (S.toff[m] <= j) lo = m; else hi = m; } return lo; };
+            for (uint32_t j = (uint32_t)lo_t + tid; j < hi_t; j += K3T) atomicAdd(&S.esum[exon_of(j)], (unsigned long long)C[j]);
+            __syncthreads();
+            for (uint32_t j = (uint32_t)lo_t + tid; j < hi_t; j += K3T) {
+                const uint32_t k = exon_of(j);
+                const uint64_t a0 = S.toff[k] > lo_t ? S.toff[k] : lo_t, b0 = S.toff[k + 1] < hi_t ? S.toff[k + 1] : hi_t;
+                const double mean = (double)S.esum[k] / (double)(b0 - a0);
+                const double d = (double)C[j] - mean;
+                atomicAdd(&S.esq[k], d * d);
+            }
+            __syncthreads();
+            for (uint32_t k = tid; k < n_ex; k += K3T) {
+                const uint64_t a0 = S.toff[k] > lo_t ? S.toff[k] : lo_t, b0 = S.toff[k + 1] < hi_t ? S.toff[k + 1] : hi_t;
+                if (b0 > a0) {
+                    const double size = (double)(b0 - a0), mean = (double)S.esum[k] / size;
+                    const double cv = sqrt(S.esq[k] / size) / mean;
+                    if (!(isnan(cv) || isinf(cv))) { const uint32_t row = A.ge_row[e0 + k]; A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
+                }
+            }
+            __syncthreads();
+        } else if (hi_t > lo_t) {
+            // more exons than the LDS table holds: one exon at a time
+            uint32_t t0 = 0;
+            for (uint32_t k = 0; k < n_ex; ++k) {
+                const uint32_t row = A.ge_row[e0 + k];
+                const uint32_t len = (uint32_t)(A.ex[row].end - A.ex[row].start + 1);
+                const uint64_t a0 = t0 > lo_t ? t0 : lo_t, b0 = (uint64_t)t0 + len < hi_t ? (uint64_t)t0 + len : hi_t;
+                if (b0 > a0) {
+                    const double size = (double)(b0 - a0);
+                    unsigned long long sm = 0;
+                    for (uint32_t j = (uint32_t)a0 + tid; j < b0; j += K3T) sm += C[j];
+                    const double mean = (double)block_sum_u64(sm, S) / size;
+                    double q = 0.0;
+                    for (uint32_t j = (uint32_t)a0 + tid; j < b0; j += K3T) { const double d = (double)C[j] - mean; q += d * d; }
+                    const double cv = sqrt(block_sum_f64(q, S) / size) / mean;
+                    if (tid == 0 && !(isnan(cv) || isinf(cv))) { A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
+                }
+                t0 += len;
+            }
         }
     }
     // (3) bias (src/Metrics.cpp:160-235) on the stitched, unmasked vector C[0..coding)
     uint32_t v0 = 0, v1 = coding;          // the (possibly trimmed) vector the gene stats use (Q14)
     if (coding >= A.bias_gene_length) {
         uint32_t best = 0, best_i = 0xFFFFFFFFu;
-        for (uint32_t j = l; j < coding; j += 64) { const uint32_t v = C[j]; if (v > best) { best = v; best_i = j; } }
+        for (uint32_t j = tid; j < coding; j += K3T) { const uint32_t v = C[j]; if (v > best) { best = v; best_i = j; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const uint32_t ob = __shfl_xor(best, o, 64), oi = __shfl_xor(best_i, o, 64);
             if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         }
+        __syncthreads();
+        if (l == 0) { S.u32a[wv] = best; S.u32b[wv] = best_i; }
+        __syncthreads();
+        best = 0; best_i = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < K3W; ++w) { const uint32_t ob = S.u32a[w], oi = S.u32b[w]; if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; } }
         const uint32_t pp = best == 0 ? 0u : best_i;
         uint32_t cur = pp + W / 2 < coding ? pp + W / 2 : coding;
         const uint32_t n = W < cur ? W : cur;
         cur -= n;
         double gate = 0.0;
-        if (n == 0) { if (l == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN); }
+        if (n == 0) { if (tid == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN); }
         else if (n == 1) gate = (double)C[cur];
         else {
             const uint32_t mid = (n - 1) / 2;
             gate = (n & 1u) ? ((double)C[cur + mid] + (double)C[cur + mid + 1]) / 2.0 : (double)C[cur + mid];
         }
         if (n != 0 && gate >= 100.0) {
-            // 5th percentile of the non-zero coverage: order statistic R of the whole vector
+            // 5th percentile of the non-zero coverage = order statistic R of the whole vector
             unsigned long long nz = 0;
-            for (uint32_t j = l; j < coding; j += 64) nz += C[j] != 0u;
-            nz = wave_sum_u64(nz);
-            const uint32_t nnz = (uint32_t)nz;
+            for (uint32_t j = tid; j < coding; j += K3T) nz += C[j] != 0u;
+            const uint32_t nnz = (uint32_t)block_sum_u64(nz, S);
             uint32_t R = (coding - nnz) + (uint32_t)((double)nnz * 0.05);
             uint32_t prefix = 0, pmask = 0;
             for (int shift = 24; shift >= 0; shift -= 8) {          // MSB-first radix select
-                for (int x = l; x < 256; x += 64) s_hist[wv][x] = 0;
-                __threadfence_block();
-                for (uint32_t j = l; j < coding; j += 64) {
+                __syncthreads();
+                if (tid < 256) S.hist[tid] = 0;
+                __syncthreads();
+                for (uint32_t j = tid; j < coding; j += K3T) {
                     const uint32_t v = C[j];
-                    if ((v & pmask) == prefix) atomicAdd(&s_hist[wv][(v >> shift) & 0xFF], 1u);
+                    if ((v & pmask) == prefix) atomicAdd(&S.hist[(v >> shift) & 0xFF], 1u);
                 }
-                __threadfence_block();
-                // lane x scans 4 bins; find the bin holding rank R
-                uint32_t h0 = s_hist[wv][4 * l], h1 = s_hist[wv][4 * l + 1], h2 = s_hist[wv][4 * l + 2], h3 = s_hist[wv][4 * l + 3];
-                const uint32_t tot = h0 + h1 + h2 + h3;
-                const uint32_t inc = wave_inclusive_scan_u32(tot);
-                const uint32_t exc = inc - tot;
-                const uint64_t here = __ballot(R >= exc && R < inc);
-                const int wl = __ffsll((unsigned long long)here) - 1;
-                uint32_t digit = 0, rbase = 0;
-                if (l == wl) {
-                    uint32_t c0 = exc;
-                    if (R < c0 + h0) { digit = 4 * l; rbase = c0; }
-                    else if (R < c0 + h0 + h1) { digit = 4 * l + 1; rbase = c0 + h0; }
-                    else if (R < c0 + h0 + h1 + h2) { digit = 4 * l + 2; rbase = c0 + h0 + h1; }
-                    else { digit = 4 * l + 3; rbase = c0 + h0 + h1 + h2; }
+                __syncthreads();
+                if (wv == 0) {                                       // wave 0: lane x scans 4 bins
+                    const uint32_t h0 = S.hist[4 * l], h1 = S.hist[4 * l + 1], h2 = S.hist[4 * l + 2], h3 = S.hist[4 * l + 3];
+                    const uint32_t tot = h0 + h1 + h2 + h3;
+                    const uint32_t inc = wave_inclusive_scan_u32(tot);
+                    const uint32_t exc = inc - tot;
+                    if (R >= exc && R < inc) {
+                        uint32_t digit, rbase;
+                        if (R < exc + h0) { digit = 4 * l; rbase = exc; }
+                        else if (R < exc + h0 + h1) { digit = 4 * l + 1; rbase = exc + h0; }
+                        else if (R < exc + h0 + h1 + h2) { digit = 4 * l + 2; rbase = exc + h0 + h1; }
+                        else { digit = 4 * l + 3; rbase = exc + h0 + h1 + h2; }
+                        S.bc_u32[2] = digit; S.bc_u32[3] = rbase;
+                    }
                 }
-                digit = __shfl(digit, wl, 64); rbase = __shfl(rbase, wl, 64);
-                R -= rbase;
-                prefix |= digit << shift; pmask |= 0xFFu << shift;
+                __syncthreads();
+                R -= S.bc_u32[3];
+                prefix |= S.bc_u32[2] << shift; pmask |= 0xFFu << shift;
             }
             const uint32_t lower = prefix;
             // trim leading / trailing entries <= lower (in place in the reference: Q14)
             uint32_t first_gt = 0xFFFFFFFFu, last_gt = 0;
-            bool any = false;
-            for (uint32_t j = l; j < coding; j += 64) if (C[j] > lower) { if (!any) first_gt = j; last_gt = j; any = true; }
-            first_gt = wave_min_u32(first_gt);
-            last_gt = wave_max_u32(any ? last_gt + 1 : 0u);
+            for (uint32_t j = tid; j < coding; j += K3T) if (C[j] > lower) { if (first_gt == 0xFFFFFFFFu) first_gt = j; last_gt = j + 1; }
+            first_gt = block_min_u32(first_gt, S);
+            last_gt = block_max_u32(last_gt, S);
             if (first_gt == 0xFFFFFFFFu) { v0 = coding; v1 = coding; } else { v0 = first_gt; v1 = last_gt; }
             const uint32_t tlen = v1 - v0;
             if (tlen >= A.bias_gene_length) {
@@ -650,14 +775,15 @@ gene_coverage_kernel(GeneCovArgs A) {
                 const uint32_t nl = OFF < lhi ? lhi - OFF : 0u;
                 uint32_t nr = 0, rlo = 0;
                 if ((uint64_t)W + OFF <= tlen) { rlo = tlen - W - OFF; nr = W; }
-                for (uint32_t j = l; j < nl; j += 64) s_win[wv][0][j] = C[v0 + OFF + j];
-                for (uint32_t j = l; j < nr; j += 64) s_win[wv][1][j] = C[v0 + rlo + j];
-                __threadfence_block();
+                __syncthreads();
+                for (uint32_t j = tid; j < nl; j += K3T) S.win[0][j] = C[v0 + OFF + j];
+                for (uint32_t j = tid; j < nr; j += K3T) S.win[1][j] = C[v0 + rlo + j];
+                __syncthreads();
                 double ml = 0.0, mr = 0.0;
-                const bool okl = window_median(s_win[wv][0], nl, &ml);
-                const bool okr = window_median(s_win[wv][1], nr, &mr);
-                if (!(okl && okr)) { if (l == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN); }
-                else if (l == 0) {
+                const bool okl = window_median(S.win[0], nl, &ml, S);
+                const bool okr = window_median(S.win[1], nr, &mr, S);
+                if (!(okl && okr)) { if (tid == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN); }
+                else if (tid == 0) {
                     const bool fwd = (A.gene_flags[gene] & RSQC_FF_STRAND_MASK) == RSQC_STRAND_FORWARD;
                     A.bias3[gene] = (unsigned long long)(fwd ? mr : ml);      // unsigned long += double: truncation
                     A.bias5[gene] = (unsigned long long)(fwd ? ml : mr);
@@ -674,16 +800,14 @@ gene_coverage_kernel(GeneCovArgs A) {
         }
         if (bnd > a) {
             const double size = (double)(bnd - a);
-            unsigned long long s = 0;
-            for (uint32_t j = a + l; j < bnd; j += 64) s += C[j];
-            s = wave_sum_u64(s);
-            const double mean = (double)s / size;
+            unsigned long long sm = 0;
+            for (uint32_t j = a + tid; j < bnd; j += K3T) sm += C[j];
+            const double mean = (double)block_sum_u64(sm, S) / size;
             double q = 0.0;
-            for (uint32_t j = a + l; j < bnd; j += 64) { const double d = (double)C[j] - mean; q += d * d; }
-            q = wave_sum_f64(q);
-            const double sd = sqrt(q / size);
-            if (l == 0) { A.g_valid[gene] = 1; A.g_mean[gene] = mean; A.g_std[gene] = sd; A.g_cv[gene] = sd / mean; }
-        } else if (l == 0) A.g_valid[gene] = 0;
+            for (uint32_t j = a + tid; j < bnd; j += K3T) { const double d = (double)C[j] - mean; q += d * d; }
+            const double sd = sqrt(block_sum_f64(q, S) / size);
+            if (tid == 0) { A.g_valid[gene] = 1; A.g_mean[gene] = mean; A.g_std[gene] = sd; A.g_cv[gene] = sd / mean; }
+        } else if (tid == 0) A.g_valid[gene] = 0;
     }
 }
 
@@ -715,7 +839,7 @@ void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, ui
 }
 void launch_gene_coverage(hipStream_t s, const GeneCovArgs &A) {
     if (A.n_listed <= 0) return;
-    hipLaunchKernelGGL(gene_coverage_kernel, dim3((A.n_listed + 3) / 4), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(gene_coverage_kernel, dim3(A.n_listed), dim3(RSQC_K3_THREADS), 0, s, A);
 }
 
 }  // namespace rsqc

@@ -54,7 +54,10 @@ struct DevAnnotation {
     const ContigInfo *contig;          // [n_contigs]
     // bin tables: first row whose start >= (bin + 1) << bin_shift (rows of later contigs excluded)
     const uint32_t *ex_binhi, *g_binhi;
-    const uint32_t *ex_cov;            // offset of an exon row's per-base coverage
+    // per-base coverage: exons of a gene are contiguous (exonsForGene order) and every gene is
+    // followed by one pad slot, so a block's -1 at offset+len always lands inside the array and a
+    // plain prefix sum over the gene reproduces BaseCoverage's per-exon vectors
+    const uint32_t *ex_cov;            // offset of an exon row's first base
     // BED rows (sorted by contig,start), optional
     const int32_t  *bed_start, *bed_end, *bed_pmax;
     const uint32_t *bed_range;         // [n_contigs+1]
@@ -252,9 +255,8 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
 // (block, exon) commits are staged in registers while the gene set common to all blocks is
 // being built; only records with more contained hits than that re-walk their CIGAR and go
 // through `acc` directly (exon_add / cov_range).
-struct Commit { uint32_t row, off, len; };   // len bit 31 (COMMIT_CLOSES): the block ends before the exon does
+struct Commit { uint32_t row, off, len; };
 constexpr int NSTAGE = 3;
-constexpr uint32_t COMMIT_CLOSES = 0x80000000u, COMMIT_LEN_MASK = 0x7FFFFFFFu;
 
 // small fixed arrays indexed with unrolled compares so that they stay in registers on the GPU
 template <int K> RSQC_HD bool set_contains(const uint32_t (&s)[K], int n, uint32_t v) {
@@ -277,7 +279,7 @@ struct FeatureOut {
 
 // `Acc` (used only on the re-walk path) provides
 //   void exon_add(uint32_t row, double frac);                                      Metrics.cpp:59-66
-//   void cov_range(uint32_t row, uint32_t offset, uint32_t len, uint32_t exon_len); Metrics.cpp:96-124
+//   void cov_range(uint32_t row, uint32_t offset, uint32_t len);                   Metrics.cpp:96-124
 // Sets `overflow` (and returns nothing to count) when a block lies inside exons of more than K genes.
 template <int K, class Acc>
 RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Record &r, bool hq,
@@ -310,10 +312,8 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
                     const uint32_t g = row.gf & ROW_GENE_MASK;
                     if (nst < NSTAGE) {
                         const uint32_t off = (uint32_t)(bs - row.start);
-                        const uint32_t elen = (uint32_t)(row.end - row.start + 1);
-                        const uint32_t lenc = len | ((off + len < elen) ? COMMIT_CLOSES : 0u);
 #pragma unroll
-                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = row_i; st[k].off = off; st[k].len = lenc; st_gene[k] = g; }
+                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = row_i; st[k].off = off; st[k].len = len; st_gene[k] = g; }
                         ++nst;
                     } else st_over = true;
                     if (first) {                          // genes.front()
@@ -375,7 +375,7 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
                         const uint32_t g = row.gf & ROW_GENE_MASK;
                         if (!set_contains<K>(last, nlast, g)) return;
                         if (len > 0 && !(p.dbg & 2u)) acc.exon_add(row_i, (double)len / (double)aligned);   // :345
-                        if (!(p.dbg & 1u)) acc.cov_range(row_i, (uint32_t)(bs - row.start), len, (uint32_t)(row.end - row.start + 1));
+                        if (!(p.dbg & 1u)) acc.cov_range(row_i, (uint32_t)(bs - row.start), len);
                     });
                 }
                 if (cigar_is_ref(op)) start += (int32_t)len;

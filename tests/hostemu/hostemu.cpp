@@ -26,21 +26,18 @@ struct Acc {
     std::vector<std::set<uint64_t>> *names;
     void gene_hit(uint32_t g, bool nd, uint64_t qh) { (*reads)[g]++; if (nd) (*unique)[g]++; (*names)[g].insert(qh); }
     void exon_add(uint32_t row, double f) { (*exon_rows)[row] += f; }
-    void cov_range(uint32_t row, uint32_t off, uint32_t len, uint32_t elen) {
+    void cov_range(uint32_t row, uint32_t off, uint32_t len) {
         if (!len) return;
         (*cov)[ex_cov[row] + off] += 1u;
-        if (off + len < elen) (*cov)[ex_cov[row] + off + len] -= 1u;
+        (*cov)[ex_cov[row] + off + len] -= 1u;
     }
 };
 template <int K>
 void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K> &fo, const Record &r, uint32_t aligned) {
     for (int k = 0; k < fo.n_commit; ++k) {
         const Commit &c = fo.commit[k];
-        const uint32_t len = c.len & COMMIT_LEN_MASK;
-        const uint32_t elen = (uint32_t)(d.ex[c.row].end - d.ex[c.row].start + 1);
-        if (((c.len & COMMIT_CLOSES) != 0) != (c.off + len < elen)) abort();
-        if (len > 0) acc.exon_add(c.row, (double)len / (double)aligned);
-        acc.cov_range(c.row, c.off, len, elen);
+        if (c.len > 0) acc.exon_add(c.row, (double)c.len / (double)aligned);
+        acc.cov_range(c.row, c.off, c.len);
     }
     for (int k = 0; k < fo.n_hit; ++k) acc.gene_hit(fo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
 }
