@@ -477,7 +477,10 @@ dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32
             unsigned long long *tab = table + tab_off[g];
             uint32_t slot = (uint32_t)(mix64(key) % cap);
             for (uint32_t probes = 0; probes < cap; ++probes) {
-                const unsigned long long old = atomicCAS(&tab[slot], 0ull, (unsigned long long)key);
+                // keys are never removed, so a plain (possibly stale) load that already shows the key or
+                // another key is conclusive; only an apparently empty slot needs the device-scope CAS
+                unsigned long long old = __builtin_nontemporal_load(&tab[slot]);
+                if (old == 0ull) old = atomicCAS(&tab[slot], 0ull, (unsigned long long)key);
                 if (old == 0ull) { fresh = true; break; }
                 if (old == key) break;
                 slot = slot + 1 == cap ? 0 : slot + 1;
