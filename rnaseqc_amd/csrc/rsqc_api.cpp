@@ -43,6 +43,12 @@ struct PairBuf {                // (gene, qname-hash) pairs of one submitted bat
     bool used = false;
 };
 
+struct FragBuf {                // fragment-size candidates of one submitted batch (BED runs only)
+    DevBuf file, qhash, name, endpos, fs, count;
+    uint32_t cap = 0;
+    bool used = false;
+};
+
 }  // namespace
 
 struct rsqc_ctx {
@@ -74,6 +80,9 @@ struct rsqc_ctx {
     std::vector<PairBuf> pair_pool;
     std::vector<size_t> pairs_in_flight;        // indices into pair_pool, submission order
     DevBuf d_table, d_tab_off, d_tab_cap;
+    std::vector<FragBuf> frag_pool;
+    std::vector<size_t> frags_in_flight;
+    uint32_t frag_remaining = 0;
     // K3 outputs
     DevBuf d_gmean, d_gstd, d_gcv, d_gvalid, d_ecv, d_ecv_valid, d_bias3, d_bias5;
     bool finalized = false;
@@ -172,6 +181,10 @@ int zero_accumulators(rsqc_ctx *c) {
     HIP_TRY(c, hipMemsetAsync((char *)c->d_misc.p + 36, 0xFF, 4, c->stream));     // rl_stats[1] = min l_qseq
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
+    for (auto &fb : c->frag_pool) fb.used = false;
+    c->frags_in_flight.clear();
+    c->h_fsize.clear(); c->h_fcount.clear();
+    c->frag_remaining = c->have_bed ? c->params.fragment_samples : 0;
     c->finalized = false;
     c->next_record_base = 0;
     c->sticky = 0;
@@ -248,6 +261,25 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
     acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
     acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
+    if (c->have_bed) {
+        size_t fidx = c->frag_pool.size();
+        for (size_t i = 0; i < c->frag_pool.size(); ++i) if (!c->frag_pool[i].used && c->frag_pool[i].cap >= u->n) { fidx = i; break; }
+        if (fidx == c->frag_pool.size()) {
+            FragBuf fb; fb.cap = (uint32_t)u->n;
+            int rc2;
+            if ((rc2 = dev_alloc(c, fb.file, u->n * 8, false)) || (rc2 = dev_alloc(c, fb.qhash, u->n * 8, false)) ||
+                (rc2 = dev_alloc(c, fb.name, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.endpos, u->n * 4, false)) ||
+                (rc2 = dev_alloc(c, fb.fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.count, 16, false))) return rc2;
+            c->frag_pool.push_back(fb);
+        }
+        FragBuf &fb = c->frag_pool[fidx];
+        fb.used = true;
+        c->frags_in_flight.push_back(fidx);
+        HIP_TRY(c, hipMemsetAsync(fb.count.p, 0, 16, c->stream));
+        acc.frag.file_index = (uint64_t *)fb.file.p; acc.frag.qhash = (uint64_t *)fb.qhash.p;
+        acc.frag.name = (int32_t *)fb.name.p; acc.frag.endpos = (int32_t *)fb.endpos.p;
+        acc.frag.flag_size = (uint32_t *)fb.fs.p; acc.frag.count = (uint32_t *)fb.count.p; acc.frag.cap = fb.cap;
+    }
     DevBatch d = u->d;
     d.record_base = c->next_record_base;
     c->next_record_base += u->n;
@@ -309,6 +341,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto *u : c->transient) free_batch(u);
     for (auto &b : c->ann_bufs) b.release();
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
+    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); }
     DevBuf *all[] = {&c->d_u64, &c->d_exon_acc, &c->d_cov, &c->d_misc, &c->d_ovf_index, &c->d_tiles, &c->d_table,
                      &c->d_tab_off, &c->d_tab_cap, &c->d_gmean, &c->d_gstd, &c->d_gcv, &c->d_gvalid, &c->d_ecv,
                      &c->d_ecv_valid, &c->d_bias3, &c->d_bias5};
@@ -419,6 +452,7 @@ int rsqc_set_bed(rsqc_ctx *c, const rsqc_bed *bed) {
     if ((rc = upload(c, c->ann_bufs, range.data(), range.size(), &c->dann.bed_range))) return rc;
     c->dann.have_bed = 1;
     c->have_bed = true;
+    c->frag_remaining = c->params.fragment_samples;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RSQC_OK;
 }
@@ -570,6 +604,40 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.finalize_ms += ms;
         c->event_pool.push_back(e0); c->event_pool.push_back(e1);
         if ((rc = check_device_error(c))) return rc;
+        // ---- K5: fragment-size sampler (BED runs) ---------------------------------------------------
+        if (c->have_bed) {
+            std::vector<uint32_t> counts(c->frags_in_flight.size(), 0);
+            uint64_t total = 0;
+            for (size_t k = 0; k < c->frags_in_flight.size(); ++k) {
+                FragBuf &fb = c->frag_pool[c->frags_in_flight[k]];
+                HIP_TRY(c, hipMemcpy(&counts[k], fb.count.p, 4, hipMemcpyDeviceToHost));
+                if (counts[k] > fb.cap) return fail(c, RSQC_ERR_CAPACITY, "fragment candidate overflow");
+                total += counts[k];
+            }
+            if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment-size candidates");
+            DevBuf m_file, m_q, m_name, m_end, m_fs;
+            if ((rc = dev_alloc(c, m_file, total * 8, false)) || (rc = dev_alloc(c, m_q, total * 8, false)) ||
+                (rc = dev_alloc(c, m_name, total * 4, false)) || (rc = dev_alloc(c, m_end, total * 4, false)) ||
+                (rc = dev_alloc(c, m_fs, total * 4, false))) return rc;
+            uint64_t at = 0;
+            for (size_t k = 0; k < c->frags_in_flight.size(); ++k) {
+                FragBuf &fb = c->frag_pool[c->frags_in_flight[k]];
+                const size_t n = counts[k];
+                if (!n) continue;
+                HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_file.p + at, fb.file.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_q.p + at, fb.qhash.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync((int32_t *)m_name.p + at, fb.name.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync((int32_t *)m_end.p + at, fb.endpos.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync((uint32_t *)m_fs.p + at, fb.fs.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                at += n;
+            }
+            FragCandidates fc{(uint64_t *)m_file.p, (uint64_t *)m_q.p, (int32_t *)m_name.p, (int32_t *)m_end.p,
+                              (uint32_t *)m_fs.p, nullptr, (uint32_t)total};
+            rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
+                                    c->frag_remaining);
+            m_file.release(); m_q.release(); m_name.release(); m_end.release(); m_fs.release();
+            if (rc) return fail(c, rc, "fragment-size stage failed");
+        }
         c->finalized = true;
     }
     // ---- read back ---------------------------------------------------------------------------------
@@ -601,7 +669,7 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
     R.bias_three = c->h_bias3.data(); R.bias_five = c->h_bias5.data();
     R.n_fragment_sizes = (uint32_t)c->h_fsize.size();
     R.fragment_size = c->h_fsize.data(); R.fragment_count = c->h_fcount.data();
-    R.fragment_samples_remaining = c->have_bed ? c->params.fragment_samples : 0;
+    R.fragment_samples_remaining = c->frag_remaining;
     *out = R;
     return RSQC_OK;
 }

@@ -29,6 +29,17 @@ struct DevBatch {
     const uint32_t *wide_n_cigar;
 };
 
+// fragment-size candidates emitted by K1 (only with a BED): one entry per record that passes
+// src/RNASeQC.cpp:372 and the block tests of src/Expression.cpp:490-507
+struct FragCandidates {
+    uint64_t *file_index;        // record index in the whole file
+    uint64_t *qhash;
+    int32_t *name;               // BED row
+    int32_t *endpos;             // PositionEnd()
+    uint32_t *flag_size;         // bit 31: !MateReverse && Reverse && pos != mpos ; low 31 bits |isize|
+    uint32_t *count; uint32_t cap;
+};
+
 // accumulators (device pointers)
 struct DevAccum {
     unsigned long long *gene_reads, *gene_unique, *gene_frag, *counters;   // one allocation, in this order
@@ -41,6 +52,7 @@ struct DevAccum {
     uint32_t pair_slow_base, pair_slow_cap; uint32_t *pair_slow_count;
     uint32_t *ovf_count; uint64_t *ovf_index; uint32_t ovf_cap;
     uint32_t *tile_span;         // max span per 64-record wave tile (Read-Length fallback scan)
+    FragCandidates frag;
     uint32_t *rl_stats;          // [3] batch-level max span, min l_qseq, max l_qseq over eligible records
     int32_t *read_length;
     int *error;
@@ -78,3 +90,9 @@ void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, ui
                          uint32_t *tab_cap, unsigned long long *total, int *error);
 
 }  // namespace rsqc
+
+#include <vector>
+namespace rsqc {
+int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
+                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining);
+}

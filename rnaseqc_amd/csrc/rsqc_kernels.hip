@@ -214,6 +214,19 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                     }
                     rc.bits |= fo.bits;
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
+                    if (a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
+                        const int32_t name = bed_interval_of(a, r);
+                        if (name >= 0) {
+                            const uint32_t slot = atomicAdd(acc.frag.count, 1u);
+                            if (slot < acc.frag.cap) {
+                                acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
+                                acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
+                                const bool ok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
+                                const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
+                                acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (ok ? 0x80000000u : 0u);
+                            } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                        }
+                    }
                 }
                 if (rc.error) atomicExch(acc.error, rc.error);
             }

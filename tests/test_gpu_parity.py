@@ -166,3 +166,52 @@ def test_chr1_scale_million_reads(oracle_lib):
     assert got.counter("Exonic Reads") + got.counter("Intronic Reads") + got.counter("Intergenic Reads") + \
         got.counter("Ambiguous Reads") == got.counter("Reads used for Intron/Exon counts")
     assert (got.gene_fragments <= got.gene_reads).all() and (got.gene_unique <= got.gene_reads).all()
+
+
+@pytest.mark.parametrize("samples", [1000000, 100, 7])
+def test_fragment_sizes_with_bed(oracle_lib, samples):
+    # --bed: pairs whose mates both sit inside one BED interval are sampled in file order (K5)
+    ann = synth.make_annotation(seed=8, contigs=[("chrA", 600_000, 60), ("chrB", 300_000, 30)])
+    bed = synth.make_bed(ann, min_len=250)
+    assert len(bed.contig) >= 10
+    batch = synth.make_reads(ann, 60000, seed=10, frac=(0.9, 0.04, 0.03, 0.03), expr_sigma=1.0,
+                             contig_lengths=np.array([600_000, 300_000]))
+    p = abi.default_params(fragment_samples=samples)
+    want = oracle_lib.run_oracle(p, ann, [batch], bed=bed)
+    assert want.fragment_count.sum() == min(samples, want.fragment_count.sum()) and want.fragment_count.sum() > 0
+    if samples == 1000000:
+        assert want.fragment_count.sum() > 200
+    got = engine.run_engine(p, ann, [batch], bed=bed)
+    assert_results_match(got, want)
+    assert got.fragment_samples_remaining == want.fragment_samples_remaining
+    # split into batches: same result
+    parts = [batch.slice(0, 50000), batch.slice(50000, batch.n)]
+    assert_results_match(engine.run_engine(p, ann, parts, bed=bed), want)
+
+
+def test_fragment_sizes_duplicate_qnames(oracle_lib):
+    # hand-made QNAME groups: a third record after a completed pair starts a new pending entry; a
+    # failing second mate leaves the entry in place (src/Expression.cpp:528)
+    rows = [dict(contig="c", type="gene", start=1000, end=9000, strand="+", gene_id="G"),
+            dict(contig="c", type="exon", start=1000, end=9000, strand="+", gene_id="G", exon_id="E")]
+    ann = Annotation.from_rows(["c"], rows)
+    from rnaseqc_amd.model import Bed
+    bed = Bed.from_intervals([0, 0], [1500, 5000], [4000, 8000])
+    M = abi.CIG_M
+    def rec(q, pos, flag, mpos, isize):
+        return dict(qname=q, tid=0, pos=pos, cigar=[(M, 100)], flag=flag, mpos=mpos, isize=isize)
+    recs = [rec("a", 2000, 99, 2200, 300), rec("b", 2050, 99, 2250, 300), rec("c", 2100, 163, 2300, 310),
+            rec("a", 2200, 147, 2000, -300),          # sample 300
+            rec("b", 2250, 83 | 0x20, 2050, -300),    # mate reverse flag set -> no sample, entry stays
+            rec("b", 2260, 147, 2050, -310),          # same name again: compared with the FIRST b -> sample 310
+            rec("c", 2300, 83, 2100, -310),           # sample 310
+            rec("a", 2400, 147, 2000, -500),          # a was erased: becomes a new pending entry
+            rec("a", 2500, 147, 2000, -600),          # ends after the pending a -> sample 600
+            rec("d", 5100, 99, 2600, 2600), rec("d", 2600, 147, 5100, -2600)]
+    recs.sort(key=lambda r: r["pos"])
+    b = Batch.from_records(recs)
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [b], bed=bed)
+    assert dict(zip(want.fragment_size.tolist(), want.fragment_count.tolist())) == {300: 1, 310: 2, 600: 1}
+    got = engine.run_engine(p, ann, [b], bed=bed)
+    assert_results_match(got, want)
