@@ -1,0 +1,48 @@
+"""Extracts the figures tests/test_golden_reference.py needs from the reference's golden OUTPUT files
+(/root/reference/test_data/*.output/).  Run in the build container; commits data only."""
+import gzip
+import json
+import os
+
+REF = "/root/reference/test_data"
+out = {}
+for name, prefix in [("chr1", "chr1.output/chr1.bam"), ("downsampled", "downsampled.output/downsampled.bam"),
+                     ("single_pair", "single_pair.output/single_pair.bam")]:
+    d = {}
+    m = {}
+    for line in open(os.path.join(REF, prefix + ".metrics.tsv")):
+        k, v = line.rstrip("\n").split("\t")
+        m[k] = v
+    d["metrics"] = m
+    cov = os.path.join(REF, prefix + ".coverage.tsv")
+    if os.path.exists(cov):
+        means, stds, cvs, zero = [], [], [], 0
+        for i, line in enumerate(open(cov)):
+            if i == 0:
+                continue
+            g, a, s, c = line.rstrip("\n").split("\t")
+            if a == "0" and s == "0" and c in ("nan", "-nan"):
+                zero += 1
+                continue
+            means.append(float(a)); stds.append(float(s))
+            if c not in ("nan", "-nan", "inf", "-inf"):
+                cvs.append(float(c))
+        d["coverage_mean_nonzero"], d["coverage_std_nonzero"], d["coverage_cv_finite"], d["n_zero_rows"] = means, stds, cvs, zero
+    fs = os.path.join(REF, prefix + ".fragmentSizes.txt")
+    if os.path.exists(fs):
+        d["fragment_sizes"] = {l.split("\t")[0]: int(l.split("\t")[1]) for i, l in enumerate(open(fs)) if i}
+    ex = os.path.join(REF, prefix + ".exon_reads.gct.gz")
+    if os.path.exists(ex) and name != "single_pair":
+        lines = gzip.open(ex, "rt").read().split("\n")
+        vals = [float(l.split("\t")[2]) for l in lines[3:] if l]
+        d["exon_gct_header_rows"] = int(lines[1].split("\t")[0])
+        d["exon_gct_rows"] = len(vals)
+        d["exon_gct_nonzero_rows"] = sum(1 for v in vals if v > 0)
+        d["exon_reads_sum"] = sum(vals)
+        g = gzip.open(os.path.join(REF, prefix + ".gene_reads.gct.gz"), "rt").read().split("\n")
+        d["gene_reads_sum"] = sum(int(l.split("\t")[2]) for l in g[3:] if l)
+        f = gzip.open(os.path.join(REF, prefix + ".gene_fragments.gct.gz"), "rt").read().split("\n")
+        d["gene_fragments_sum"] = sum(int(l.split("\t")[2]) for l in f[3:] if l)
+    out[name] = d
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json"), "w"))
+print({k: list(v.keys()) for k, v in out.items()})
