@@ -107,3 +107,21 @@ QUIRK_GENE_FRAGMENTS = [5, 1, 1, 1, 3]   # p1's two mates are one fragment
 # exonList order: GA_1 GA_2 GA_3 GB_1 GB_2 GR_1 GH_1 GC_1
 QUIRK_EXON_READS = [2.5, 0.5, 3.0, 1.0, 0.0, 1.0, 1.0, 3.0]
 QUIRK_READ_LENGTH = 110                  # k1: span 103 > 100 -> l_qseq 110 (Q3)
+
+
+def single_pair_case():
+    """A reconstruction of the reference's test_data/single_pair: its inputs are not in the tree, but the
+    golden outputs (single_pair.output/) fix what they must look like: one '-' strand gene with 13 exons
+    (WASH7P), one proper pair of 76-base reads, both inside exon _13, READ1 reverse (End 1 Sense = 1),
+    READ2 forward (End 2 Antisense = 1), within 500 bases of a transcript end (coverage mean 0)."""
+    exons = [(14363, 14829), (14970, 15038), (15796, 15947), (16607, 16765), (16858, 17055), (17233, 17368),
+             (17606, 17742), (17915, 18061), (18268, 18366), (24738, 24891), (29534, 29806), (30000, 30200), (30300, 30500)]
+    rows = [dict(contig="1", type="gene", start=14363, end=30500, strand="-", gene_id="ENSG00000227232.4", gene_name="WASH7P",
+                 transcript_type="pseudogene")]
+    for k, (s, e) in enumerate(exons):
+        rows.append(dict(contig="1", type="exon", start=s, end=e, strand="-", gene_id="ENSG00000227232.4",
+                         exon_id="ENSG00000227232.4_%d" % (13 - k), gene_name="WASH7P", transcript_type="pseudogene"))
+    ann = Annotation.from_rows(["1"], rows)
+    recs = [dict(qname="pair", tid=0, pos=14400, cigar=[(M, 76)], flag=163, mpos=14500, isize=176, nm=0),
+            dict(qname="pair", tid=0, pos=14500, cigar=[(M, 76)], flag=83, mpos=14400, isize=-176, nm=0)]
+    return ann, Batch.from_records(recs)

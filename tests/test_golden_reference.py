@@ -71,3 +71,31 @@ def test_exon_gct_header_counts_nonzero_rows(name):
     # every counted record adds 1 to a gene and fractions summing to 1 to its exons
     assert abs(d["exon_reads_sum"] - d["gene_reads_sum"]) < 1e-3 * d["gene_reads_sum"]
     assert d["gene_fragments_sum"] <= d["gene_reads_sum"]
+
+
+def test_single_pair_golden_reconstruction(oracle_lib):
+    """Every raw counter the reference's single_pair golden metrics.tsv lists must come out of a
+    reconstruction of that input (see tests/cases.py), plus the golden GCT values."""
+    from rnaseqc_amd import abi
+    from tests import cases
+    ann, batch = cases.single_pair_case()
+    r = oracle_lib.run_oracle(abi.default_params(), ann, [batch])
+    m = KA["single_pair"]["metrics"]
+    got = r.counter_dict()
+    checked = 0
+    for k, v in m.items():
+        if k in got:
+            assert got[k] == int(v), (k, got[k], v)
+            checked += 1
+    assert checked >= 30
+    assert r.read_length == int(m["Read Length"])
+    assert list(r.gene_reads) == [2] and list(r.gene_fragments) == [1]
+    # exon_reads.gct: 13 rows, only ..._13 is 2.0 and the header says 1
+    assert r.exon_reads[ann.exon_ids.index("ENSG00000227232.4_13")] == 2.0 and r.exon_reads.sum() == 2.0
+    assert int(r.exon_hit.sum()) == 1
+    # "Median of Avg Transcript Coverage 0", CV list empty -> 0, "Median Exon CV nan"
+    assert list(r.gene_cov_valid) == [1] and r.gene_cov_mean[0] == 0 and np.isnan(r.gene_cov_cv[0])
+    assert int(r.exon_cv_valid.sum()) == 0
+    # Genes Detected 0 (needs 5 unique reads), bias genes 0
+    assert int((r.gene_unique >= 5).sum()) == int(m["Genes Detected"])
+    assert int(((r.bias_three + r.bias_five) > 0).sum()) == int(m["Genes used in 3' bias"])

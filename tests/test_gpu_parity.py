@@ -215,3 +215,17 @@ def test_fragment_sizes_duplicate_qnames(oracle_lib):
     assert dict(zip(want.fragment_size.tolist(), want.fragment_count.tolist())) == {300: 1, 310: 2, 600: 1}
     got = engine.run_engine(p, ann, [b], bed=bed)
     assert_results_match(got, want)
+
+
+def test_single_pair_golden_reconstruction_gpu(oracle_lib):
+    import json, os
+    ka = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_known_answers.json")))
+    ann, batch = cases.single_pair_case()
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, [batch])
+    c = got.counter_dict()
+    for k, v in ka["single_pair"]["metrics"].items():
+        if k in c:
+            assert c[k] == int(v), (k, c[k], v)
+    assert list(got.gene_reads) == [2] and list(got.gene_fragments) == [1] and got.read_length == 76
+    assert_results_match(got, oracle_lib.run_oracle(p, ann, [batch]))
