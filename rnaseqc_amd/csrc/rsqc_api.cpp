@@ -327,7 +327,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.n_filter_tags = params->n_filter_tags;
     c->dparams.dbg = 0;
     if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
-    if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::max(1, atoi(e));
+    if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
     if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
     return RSQC_OK;

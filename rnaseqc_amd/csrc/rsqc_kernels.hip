@@ -468,23 +468,50 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// grid = pair chunks (one per K1 block) + 1 slow-path region; block c walks chunk c.
+// The pairs of a batch live in per-K1-block chunks (+ one slow-path region).  All threads walk
+// them in GLOBAL order (chunk after chunk), i.e. in file order: at any moment the whole grid works
+// on one window of consecutive records, hence on the table slices of the same few genes, which
+// keeps those slices cache-resident.  j -> (chunk, offset) through an exclusive prefix of the
+// chunk fill counts held in LDS.
+#define RSQC_K4_MAX_CHUNKS 4100
 __global__ void __launch_bounds__(256)
 dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
-                    const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, const uint32_t *slow_count,
-                    uint32_t slow_cap, const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
+                    const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
+                    const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
                     unsigned long long *gene_frag) {
-    const uint32_t c = blockIdx.x;
-    uint32_t n_pairs, base;
-    if (c < n_chunks) { n_pairs = chunk_count[c]; base = c * chunk_cap; }
-    else { n_pairs = *slow_count < slow_cap ? *slow_count : slow_cap; base = slow_base; }
-    const uint32_t rounds = (n_pairs + blockDim.x - 1) / blockDim.x;
+    __shared__ uint32_t s_pref[RSQC_K4_MAX_CHUNKS + 2];
+    __shared__ uint32_t s_wave[4];
+    // exclusive prefix over n_chunks + 1 regions (the last one is the slow-path region)
+    const uint32_t n_reg = n_chunks + 1;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_reg; base += 256) {
+        const uint32_t r = base + threadIdx.x;
+        uint32_t v = 0;
+        if (r < n_chunks) v = chunk_count[r] < chunk_cap ? chunk_count[r] : chunk_cap;
+        else if (r == n_chunks) v = chunk_count[r] < slow_cap ? chunk_count[r] : slow_cap;
+        const uint32_t inc = wave_inclusive_scan_u32(v);
+        if (lane_id() == 63) s_wave[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t before = carry, total = 0;
+        for (int w = 0; w < 4; ++w) { if (w < (int)(threadIdx.x >> 6)) before += s_wave[w]; total += s_wave[w]; }
+        if (r < n_reg) s_pref[r] = before + inc - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s_pref[n_reg] = carry;
+    __syncthreads();
+    const uint32_t n_pairs = carry;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n_pairs + stride - 1) / stride;
     for (uint32_t it = 0; it < rounds; ++it) {
-        const uint32_t j = it * blockDim.x + threadIdx.x;
+        const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool fresh = false; uint32_t g = 0;
         if (j < n_pairs) {
-            g = pair_gene[base + j];
-            uint64_t key = pair_hash[base + j];
+            uint32_t lo = 0, hi = n_reg;                         // last region with prefix <= j
+            while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (s_pref[m] <= j) lo = m; else hi = m; }
+            const uint32_t src = (lo < n_chunks ? lo * chunk_cap : slow_base) + (j - s_pref[lo]);
+            g = pair_gene[src];
+            uint64_t key = pair_hash[src];
             if (key == 0) key = 0x9e3779b97f4a7c15ull;           // 0 marks an empty slot
             const uint32_t cap = tab_cap[g];
             unsigned long long *tab = table + tab_off[g];
@@ -845,8 +872,9 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 }
 void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
                   unsigned long long *table) {
-    hipLaunchKernelGGL(dedup_insert_kernel, dim3(n_chunks + 1), dim3(256), 0, s, acc.pair_gene, acc.pair_hash,
-                       acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_count,
+    // pair_chunk_count[n_chunks] is the slow-path counter (same allocation)
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(2048), dim3(256), 0, s, acc.pair_gene, acc.pair_hash,
+                       acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base,
                        acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag);
 }
 void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
