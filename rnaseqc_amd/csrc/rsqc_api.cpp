@@ -57,6 +57,7 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
+    int k4_mode = 0, k4_grid = 2048;
     int k1_variant = 3, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
 
     // annotation (host copies needed at finalize)
@@ -74,7 +75,14 @@ struct rsqc_ctx {
     bool have_bed = false;
 
     // accumulators
-    DevBuf d_u64, d_exon_acc, d_cov, d_misc, d_ovf_index, d_tiles;
+    // one device arena holds every small result vector (single memset at reset, single D2H at finalize):
+    // u64[3G+49] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | u64 bias3,bias5[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | misc[64]
+    DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
+    char *h_arena = nullptr;                      // pinned host mirror
+    size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
+           off_bias5 = 0, off_ecv = 0, off_gvalid = 0, off_ecvv = 0, off_misc = 0;
+    hipStream_t stream2 = nullptr;                // K3 runs beside K4
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevAccum acc{};
     uint64_t tile_cap = 0;
     std::vector<PairBuf> pair_pool;
@@ -84,7 +92,6 @@ struct rsqc_ctx {
     std::vector<size_t> frags_in_flight;
     uint32_t frag_remaining = 0;
     // K3 outputs
-    DevBuf d_gmean, d_gstd, d_gcv, d_gvalid, d_ecv, d_ecv_valid, d_bias3, d_bias5;
     bool finalized = false;
 
     // batches
@@ -102,8 +109,6 @@ struct rsqc_ctx {
     std::vector<double> h_exon, h_gmean, h_gstd, h_gcv, h_ecv;
     std::vector<uint8_t> h_exon_hit, h_gvalid, h_ecv_valid;
     std::vector<int64_t> h_fsize;
-    std::vector<uint64_t> h_u64;
-    std::vector<double> h_exon_rows;
     rsqc_results results{};
 };
 
@@ -153,7 +158,8 @@ hipEvent_t get_event(rsqc_ctx *c) {
 
 int check_device_error(rsqc_ctx *c) {
     int err = 0;
-    HIP_TRY(c, hipMemcpy(&err, c->acc.error, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(&err, c->acc.error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (err) {
         c->sticky = err;
         return fail(c, err, err == RSQC_ERR_BAD_CIGAR ? "Unrecognized Cigar Op" :
@@ -174,11 +180,9 @@ int resolve_events(rsqc_ctx *c) {
 }
 
 int zero_accumulators(rsqc_ctx *c) {
-    HIP_TRY(c, hipMemsetAsync(c->d_u64.p, 0, c->d_u64.bytes, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_exon_acc.p, 0, c->d_exon_acc.bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_arena.p, 0, c->arena_bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync((char *)c->d_arena.p + c->off_misc + 36, 0xFF, 4, c->stream));   // rl_stats[1] = min l_qseq
     HIP_TRY(c, hipMemsetAsync(c->d_cov.p, 0, c->d_cov.bytes, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_misc.p, 0, c->d_misc.bytes, c->stream));
-    HIP_TRY(c, hipMemsetAsync((char *)c->d_misc.p + 36, 0xFF, 4, c->stream));     // rl_stats[1] = min l_qseq
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
     for (auto &fb : c->frag_pool) fb.used = false;
@@ -328,6 +332,8 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.dbg = 0;
     if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
+    if (const char *e = getenv("RSQC_K4_MODE")) c->k4_mode = atoi(e);
+    if (const char *e = getenv("RSQC_K4_GRID")) c->k4_grid = std::max(1, atoi(e));
     if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
     return RSQC_OK;
@@ -342,9 +348,11 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->ann_bufs) b.release();
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); }
-    DevBuf *all[] = {&c->d_u64, &c->d_exon_acc, &c->d_cov, &c->d_misc, &c->d_ovf_index, &c->d_tiles, &c->d_table,
-                     &c->d_tab_off, &c->d_tab_cap, &c->d_gmean, &c->d_gstd, &c->d_gcv, &c->d_gvalid, &c->d_ecv,
-                     &c->d_ecv_valid, &c->d_bias3, &c->d_bias5};
+    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
+    if (c->h_arena) (void)hipHostFree(c->h_arena);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto *b : all) b->release();
     for (auto &pr : c->k1_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -397,30 +405,42 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
 #undef UPA
     // ---- accumulators -----------------------------------------------------------------------------
     const size_t n_u64 = (size_t)G * 3 + RSQC_N_COUNTERS;
-    if ((rc = dev_alloc(c, c->d_u64, n_u64 * 8, false))) return rc;
-    if ((rc = dev_alloc(c, c->d_exon_acc, (size_t)std::max(E, 1) * 8, false))) return rc;
+    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
+    auto pad8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    size_t at = 0;
+    c->off_u64 = at; at += n_u64 * 8;
+    c->off_exon = at; at += Ez * 8;
+    c->off_gmean = at; at += Lz * 8;
+    c->off_gstd = at; at += Lz * 8;
+    c->off_gcv = at; at += Lz * 8;
+    c->off_bias3 = at; at += Lz * 8;
+    c->off_bias5 = at; at += Lz * 8;
+    c->off_ecv = at; at += Ez * 8;
+    c->off_gvalid = at; at += pad8(Lz);
+    c->off_ecvv = at; at += pad8(Ez);
+    c->off_misc = at; at += 64;
+    c->arena_bytes = at;
+    if ((rc = dev_alloc(c, c->d_arena, at, false))) return rc;
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_arena, at, hipHostMallocDefault));
     if ((rc = dev_alloc(c, c->d_cov, (size_t)(run + 64) * 4, false))) return rc;
-    if ((rc = dev_alloc(c, c->d_misc, 64, false))) return rc;
     const uint32_t ovf_cap = 1u << 20;
     if ((rc = dev_alloc(c, c->d_ovf_index, (size_t)ovf_cap * 8, false))) return rc;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    char *A = (char *)c->d_arena.p;
     DevAccum &acc = c->acc;
-    acc.gene_reads = (unsigned long long *)c->d_u64.p;
+    acc.gene_reads = (unsigned long long *)(A + c->off_u64);
     acc.gene_unique = acc.gene_reads + G;
     acc.gene_frag = acc.gene_unique + G;
     acc.counters = acc.gene_frag + G;
-    acc.exon_acc = (double *)c->d_exon_acc.p;
+    acc.exon_acc = (double *)(A + c->off_exon);
     acc.cov_diff = (uint32_t *)c->d_cov.p;
-    acc.ovf_count = (uint32_t *)c->d_misc.p;
-    acc.read_length = (int32_t *)((char *)c->d_misc.p + 8);
-    acc.error = (int *)((char *)c->d_misc.p + 16);
-    acc.rl_stats = (uint32_t *)((char *)c->d_misc.p + 32);
+    acc.ovf_count = (uint32_t *)(A + c->off_misc);
+    acc.read_length = (int32_t *)(A + c->off_misc + 8);
+    acc.error = (int *)(A + c->off_misc + 16);
+    acc.rl_stats = (uint32_t *)(A + c->off_misc + 32);
     acc.ovf_index = (uint64_t *)c->d_ovf_index.p; acc.ovf_cap = ovf_cap;
-    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
-    if ((rc = dev_alloc(c, c->d_gmean, Lz * 8, false)) || (rc = dev_alloc(c, c->d_gstd, Lz * 8, false)) ||
-        (rc = dev_alloc(c, c->d_gcv, Lz * 8, false)) || (rc = dev_alloc(c, c->d_gvalid, Lz, false)) ||
-        (rc = dev_alloc(c, c->d_ecv, Ez * 8, false)) || (rc = dev_alloc(c, c->d_ecv_valid, Ez, false)) ||
-        (rc = dev_alloc(c, c->d_bias3, Lz * 8, false)) || (rc = dev_alloc(c, c->d_bias5, Lz * 8, false)))
-        return rc;
     c->have_ann = true;
     if ((rc = zero_accumulators(c))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -522,52 +542,98 @@ int rsqc_reset(rsqc_ctx *c) {
     return zero_accumulators(c);
 }
 
-static int read_back_counts(rsqc_ctx *c) {
+// one D2H of the whole arena into the pinned mirror, then unpack into the results struct
+static int read_back(rsqc_ctx *c) {
     const int G = c->n_genes, L = c->n_listed, E = c->n_exons;
-    const size_t n_u64 = (size_t)G * 3 + RSQC_N_COUNTERS;
-    c->h_u64.resize(n_u64);
-    HIP_TRY(c, hipMemcpyAsync(c->h_u64.data(), c->d_u64.p, n_u64 * 8, hipMemcpyDeviceToHost, c->stream));
-    c->h_exon_rows.resize((size_t)std::max(E, 1));
-    HIP_TRY(c, hipMemcpyAsync(c->h_exon_rows.data(), c->d_exon_acc.p, (size_t)E * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_arena, c->d_arena.p, c->arena_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->h_reads.assign(c->h_u64.begin(), c->h_u64.begin() + L);
-    c->h_unique.assign(c->h_u64.begin() + G, c->h_u64.begin() + G + L);
-    c->h_frag.assign(c->h_u64.begin() + 2 * (size_t)G, c->h_u64.begin() + 2 * (size_t)G + L);
+    const char *H = c->h_arena;
+    const uint64_t *u = (const uint64_t *)(H + c->off_u64);
+    const double *exon_rows = (const double *)(H + c->off_exon);
+    c->h_reads.assign(u, u + L);
+    c->h_unique.assign(u + G, u + G + L);
+    c->h_frag.assign(u + 2 * (size_t)G, u + 2 * (size_t)G + L);
     c->h_exon.assign((size_t)E, 0.0); c->h_exon_hit.assign((size_t)E, 0);
     for (int r = 0; r < E; ++r) {
         const uint32_t id = c->exon_row_id[(size_t)r];
-        c->h_exon[id] = c->h_exon_rows[(size_t)r];
-        c->h_exon_hit[id] = c->h_exon_rows[(size_t)r] > 0.0 ? 1 : 0;
+        c->h_exon[id] = exon_rows[r];
+        c->h_exon_hit[id] = exon_rows[r] > 0.0 ? 1 : 0;
     }
     rsqc_results &R = c->results;
-    for (int k = 0; k < RSQC_N_COUNTERS; ++k) R.counters[k] = c->h_u64[3 * (size_t)G + (size_t)k];
+    for (int k = 0; k < RSQC_N_COUNTERS; ++k) R.counters[k] = u[3 * (size_t)G + (size_t)k];
     R.n_genes_listed = L; R.n_exons = E;
     R.gene_reads = c->h_reads.data(); R.gene_unique = c->h_unique.data(); R.gene_fragments = c->h_frag.data();
     R.exon_reads = c->h_exon.data(); R.exon_hit = c->h_exon_hit.data();
+    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
+    const double *gm = (const double *)(H + c->off_gmean), *gs = (const double *)(H + c->off_gstd), *gc = (const double *)(H + c->off_gcv);
+    const uint64_t *b3 = (const uint64_t *)(H + c->off_bias3), *b5 = (const uint64_t *)(H + c->off_bias5);
+    const double *ecv = (const double *)(H + c->off_ecv);
+    const uint8_t *gv = (const uint8_t *)(H + c->off_gvalid), *ev = (const uint8_t *)(H + c->off_ecvv);
+    c->h_gmean.assign(gm, gm + Lz); c->h_gstd.assign(gs, gs + Lz); c->h_gcv.assign(gc, gc + Lz);
+    c->h_gvalid.assign(gv, gv + Lz); c->h_bias3.assign(b3, b3 + Lz); c->h_bias5.assign(b5, b5 + Lz);
+    c->h_ecv.assign(Ez, 0.0); c->h_ecv_valid.assign(Ez, 0);
+    for (int r = 0; r < E; ++r) if (ev[r]) {
+        c->h_ecv[c->exon_row_id[(size_t)r]] = ecv[r];
+        c->h_ecv_valid[c->exon_row_id[(size_t)r]] = 1;
+    }
+    for (int g = 0; g < L; ++g) if (!c->h_gvalid[(size_t)g]) { c->h_gmean[(size_t)g] = c->h_gstd[(size_t)g] = c->h_gcv[(size_t)g] = 0.0; }
+    R.read_length = *(const int32_t *)(H + c->off_misc + 8);
+    R.gene_cov_mean = c->h_gmean.data(); R.gene_cov_std = c->h_gstd.data(); R.gene_cov_cv = c->h_gcv.data();
+    R.gene_cov_valid = c->h_gvalid.data(); R.exon_cv = c->h_ecv.data(); R.exon_cv_valid = c->h_ecv_valid.data();
+    R.bias_three = c->h_bias3.data(); R.bias_five = c->h_bias5.data();
+    R.n_fragment_sizes = (uint32_t)c->h_fsize.size();
+    R.fragment_size = c->h_fsize.data(); R.fragment_count = c->h_fcount.data();
+    R.fragment_samples_remaining = c->frag_remaining;
+    const int err = *(const int *)(H + c->off_misc + 16);
+    if (err) {
+        c->sticky = err;
+        return fail(c, err, err == RSQC_ERR_BAD_CIGAR ? "Unrecognized Cigar Op" :
+                            err == RSQC_ERR_CAPACITY ? "a device-side capacity was exceeded" :
+                            err == RSQC_ERR_EMPTY_MEDIAN ? "Cannot compute median of an empty list" : "device error");
+    }
     return 0;
 }
 
 int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
     if (!c || !out || !c->have_ann) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = rsqc_wait(c);
-    if (rc) return rc;
-    const int G = c->n_genes, L = c->n_listed, E = c->n_exons;
+    int rc;
+    const int G = c->n_genes, L = c->n_listed;
+    char *A = (char *)c->d_arena.p;
     if (!c->finalized) {
         hipEvent_t e0 = get_event(c), e1 = get_event(c);
         HIP_TRY(c, hipEventRecord(e0, c->stream));
-        // ---- K4: per-gene distinct QNAMEs -------------------------------------------------------
+        // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        GeneCovArgs Ga{};
+        Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
+        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov;
+        Ga.gene_cov_off = c->d_gene_cov_off; Ga.gene_coding = c->d_gene_coding;
+        Ga.gene_flags = c->d_gene_flags; Ga.gene_owned = c->d_gene_owned;
+        Ga.gene_order = c->d_gene_order;
+        Ga.gene_reads = c->acc.gene_reads; Ga.cov = c->acc.cov_diff; Ga.n_listed = L;
+        Ga.mask = c->params.coverage_mask; Ga.bias_offset = c->params.bias_offset; Ga.bias_window = c->params.bias_window;
+        Ga.bias_gene_length = c->params.bias_gene_length;
+        Ga.g_mean = (double *)(A + c->off_gmean); Ga.g_std = (double *)(A + c->off_gstd); Ga.g_cv = (double *)(A + c->off_gcv);
+        Ga.g_valid = (uint8_t *)(A + c->off_gvalid); Ga.e_cv = (double *)(A + c->off_ecv); Ga.e_cv_valid = (uint8_t *)(A + c->off_ecvv);
+        Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
+        Ga.error = c->acc.error;
+        launch_gene_coverage(c->stream2, Ga);
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+        // ---- K4 on the main stream: per-gene distinct QNAMEs ---------------------------------------------
         if ((rc = dev_alloc(c, c->d_tab_off, ((size_t)std::max(G, 1) + 2) * 8, false))) return rc;
         if ((rc = dev_alloc(c, c->d_tab_cap, (size_t)std::max(G, 1) * 4, false))) return rc;
         unsigned long long *d_total = (unsigned long long *)c->d_tab_off.p + std::max(G, 1);
         launch_dedup_layout(c->stream, c->acc.gene_reads, (uint32_t)G, (uint64_t *)c->d_tab_off.p,
                             (uint32_t *)c->d_tab_cap.p, d_total, c->acc.error);
-        unsigned long long slots = 0;
-        HIP_TRY(c, hipMemcpyAsync(&slots, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long *h_slots = (unsigned long long *)(c->h_arena + c->off_misc + 48);     // pinned scratch
+        HIP_TRY(c, hipMemcpyAsync(h_slots, d_total, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const unsigned long long slots = *h_slots;
         if (c->d_table.bytes < (size_t)slots * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slots * 8 + (1u << 20), false))) return rc; }
         if (slots) HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0, (size_t)slots * 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->acc.gene_frag, 0, (size_t)G * 8, c->stream));
         for (size_t idx : c->pairs_in_flight) {
             PairBuf &pb = c->pair_pool[idx];
             DevAccum acc = c->acc;
@@ -576,36 +642,14 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
             acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
             acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
             launch_dedup(c->stream, acc, pb.n_chunks, (const uint64_t *)c->d_tab_off.p, (const uint32_t *)c->d_tab_cap.p,
-                         (unsigned long long *)c->d_table.p);
+                         (unsigned long long *)c->d_table.p, (uint32_t)c->k4_mode, c->k4_grid);
         }
-        // ---- K3: coverage scan + per-gene statistics + bias ----------------------------------------
-        HIP_TRY(c, hipMemsetAsync(c->d_gvalid.p, 0, c->d_gvalid.bytes, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_ecv_valid.p, 0, c->d_ecv_valid.bytes, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_bias3.p, 0, c->d_bias3.bytes, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_bias5.p, 0, c->d_bias5.bytes, c->stream));
-        GeneCovArgs A{};
-        A.ge_off = c->d_ge_off; A.ge_row = c->d_ge_row;
-        A.ex = c->dann.ex; A.ex_cov = c->dann.ex_cov;
-        A.gene_cov_off = c->d_gene_cov_off; A.gene_coding = c->d_gene_coding;
-        A.gene_flags = c->d_gene_flags; A.gene_owned = c->d_gene_owned;
-        A.gene_order = c->d_gene_order;
-        A.gene_reads = c->acc.gene_reads; A.cov = c->acc.cov_diff; A.n_listed = L;
-        A.mask = c->params.coverage_mask; A.bias_offset = c->params.bias_offset; A.bias_window = c->params.bias_window;
-        A.bias_gene_length = c->params.bias_gene_length;
-        A.g_mean = (double *)c->d_gmean.p; A.g_std = (double *)c->d_gstd.p; A.g_cv = (double *)c->d_gcv.p;
-        A.g_valid = (uint8_t *)c->d_gvalid.p; A.e_cv = (double *)c->d_ecv.p; A.e_cv_valid = (uint8_t *)c->d_ecv_valid.p;
-        A.bias3 = (unsigned long long *)c->d_bias3.p; A.bias5 = (unsigned long long *)c->d_bias5.p;
-        A.error = c->acc.error;
-        launch_gene_coverage(c->stream, A);
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e1, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.finalize_ms += ms;
-        c->event_pool.push_back(e0); c->event_pool.push_back(e1);
-        if ((rc = check_device_error(c))) return rc;
         // ---- K5: fragment-size sampler (BED runs) ---------------------------------------------------
         if (c->have_bed) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
             std::vector<uint32_t> counts(c->frags_in_flight.size(), 0);
             uint64_t total = 0;
             for (size_t k = 0; k < c->frags_in_flight.size(); ++k) {
@@ -638,53 +682,31 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
             m_file.release(); m_q.release(); m_name.release(); m_end.release(); m_fs.release();
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
+        // ---- one read-back of every result vector (also carries the device error flag) ----------------
+        if ((rc = read_back(c))) return rc;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.finalize_ms += ms;
+        c->event_pool.push_back(e0); c->event_pool.push_back(e1);
+        resolve_events(c);
+        for (auto *u : c->transient) free_batch(u);
+        c->transient.clear();
         c->finalized = true;
-    }
-    // ---- read back ---------------------------------------------------------------------------------
-    if ((rc = read_back_counts(c))) return rc;
-    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
-    c->h_gmean.resize(Lz); c->h_gstd.resize(Lz); c->h_gcv.resize(Lz); c->h_gvalid.resize(Lz);
-    c->h_bias3.resize(Lz); c->h_bias5.resize(Lz);
-    std::vector<double> ecv_rows(Ez); std::vector<uint8_t> ecv_valid_rows(Ez);
-    HIP_TRY(c, hipMemcpy(c->h_gmean.data(), c->d_gmean.p, (size_t)L * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(c->h_gstd.data(), c->d_gstd.p, (size_t)L * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(c->h_gcv.data(), c->d_gcv.p, (size_t)L * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(c->h_gvalid.data(), c->d_gvalid.p, (size_t)L, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(c->h_bias3.data(), c->d_bias3.p, (size_t)L * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(c->h_bias5.data(), c->d_bias5.p, (size_t)L * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(ecv_rows.data(), c->d_ecv.p, (size_t)E * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(ecv_valid_rows.data(), c->d_ecv_valid.p, (size_t)E, hipMemcpyDeviceToHost));
-    c->h_ecv.assign(Ez, 0.0); c->h_ecv_valid.assign(Ez, 0);
-    for (int r = 0; r < E; ++r) if (ecv_valid_rows[(size_t)r]) {
-        c->h_ecv[c->exon_row_id[(size_t)r]] = ecv_rows[(size_t)r];
-        c->h_ecv_valid[c->exon_row_id[(size_t)r]] = 1;
-    }
-    for (int g = 0; g < L; ++g) if (!c->h_gvalid[(size_t)g]) { c->h_gmean[(size_t)g] = c->h_gstd[(size_t)g] = c->h_gcv[(size_t)g] = 0.0; }
-    int32_t rl = 0;
-    HIP_TRY(c, hipMemcpy(&rl, c->acc.read_length, 4, hipMemcpyDeviceToHost));
-    rsqc_results &R = c->results;
-    R.read_length = rl;
-    R.gene_cov_mean = c->h_gmean.data(); R.gene_cov_std = c->h_gstd.data(); R.gene_cov_cv = c->h_gcv.data();
-    R.gene_cov_valid = c->h_gvalid.data(); R.exon_cv = c->h_ecv.data(); R.exon_cv_valid = c->h_ecv_valid.data();
-    R.bias_three = c->h_bias3.data(); R.bias_five = c->h_bias5.data();
-    R.n_fragment_sizes = (uint32_t)c->h_fsize.size();
-    R.fragment_size = c->h_fsize.data(); R.fragment_count = c->h_fcount.data();
-    R.fragment_samples_remaining = c->frag_remaining;
-    *out = R;
+    } else if ((rc = read_back(c))) return rc;
+    *out = c->results;
     return RSQC_OK;
 }
 
 int rsqc_device_accumulators(rsqc_ctx *c, void **u64_base, uint64_t *u64_count, void **f64_base, uint64_t *f64_count) {
     if (!c || !c->have_ann || !u64_base || !u64_count || !f64_base || !f64_count) return RSQC_ERR_ARG;
-    *u64_base = c->d_u64.p; *u64_count = (uint64_t)c->n_genes * 3 + RSQC_N_COUNTERS;
-    *f64_base = c->d_exon_acc.p; *f64_count = (uint64_t)c->n_exons;
+    *u64_base = (char *)c->d_arena.p + c->off_u64; *u64_count = (uint64_t)c->n_genes * 3 + RSQC_N_COUNTERS;
+    *f64_base = (char *)c->d_arena.p + c->off_exon; *f64_count = (uint64_t)c->n_exons;
     return RSQC_OK;
 }
 
 int rsqc_refresh_results(rsqc_ctx *c, rsqc_results *out) {
     if (!c || !out || !c->have_ann || !c->finalized) return RSQC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = read_back_counts(c);
+    int rc = read_back(c);
     if (rc) return rc;
     *out = c->results;
     return RSQC_OK;

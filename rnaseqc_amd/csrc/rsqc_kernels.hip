@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256)
 dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
                     const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
                     const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
-                    unsigned long long *gene_frag) {
+                    unsigned long long *gene_frag, uint32_t mode) {
     __shared__ uint32_t s_pref[RSQC_K4_MAX_CHUNKS + 2];
     __shared__ uint32_t s_wave[4];
     // exclusive prefix over n_chunks + 1 regions (the last one is the slow-path region)
@@ -502,11 +502,17 @@ dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32
     __syncthreads();
     const uint32_t n_pairs = carry;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounds = (n_pairs + stride - 1) / stride;
+    const uint32_t rounds = (mode & 1u) ? (n_pairs + stride - 1) / stride
+                                        : ((n_pairs + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x;
     for (uint32_t it = 0; it < rounds; ++it) {
-        const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        // mode bit 0: blocks interleave at 256-pair granularity (global file order); otherwise every block
+        // walks its own contiguous 1/gridDim slice of the pair sequence
+        const uint32_t per_block = (n_pairs + gridDim.x - 1) / gridDim.x;
+        const uint32_t j = (mode & 1u) ? it * stride + blockIdx.x * blockDim.x + threadIdx.x
+                                       : blockIdx.x * per_block + it * blockDim.x + threadIdx.x;
+        const bool in_range = (mode & 1u) ? j < n_pairs : (it * blockDim.x + threadIdx.x < per_block && j < n_pairs);
         bool fresh = false; uint32_t g = 0;
-        if (j < n_pairs) {
+        if (in_range) {
             uint32_t lo = 0, hi = n_reg;                         // last region with prefix <= j
             while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (s_pref[m] <= j) lo = m; else hi = m; }
             const uint32_t src = (lo < n_chunks ? lo * chunk_cap : slow_base) + (j - s_pref[lo]);
@@ -519,7 +525,8 @@ dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32
             for (uint32_t probes = 0; probes < cap; ++probes) {
                 // keys are never removed, so a plain (possibly stale) load that already shows the key or
                 // another key is conclusive; only an apparently empty slot needs the device-scope CAS
-                unsigned long long old = __builtin_nontemporal_load(&tab[slot]);
+                unsigned long long old = 0ull;
+                if (mode & 2u) old = (mode & 4u) ? __builtin_nontemporal_load(&tab[slot]) : tab[slot];
                 if (old == 0ull) old = atomicCAS(&tab[slot], 0ull, (unsigned long long)key);
                 if (old == 0ull) { fresh = true; break; }
                 if (old == key) break;
@@ -871,11 +878,11 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
     hipLaunchKernelGGL(read_length_kernel, dim3(1), dim3(64), 0, s, a, p, b, acc);
 }
 void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
-                  unsigned long long *table) {
+                  unsigned long long *table, uint32_t mode, int grid) {
     // pair_chunk_count[n_chunks] is the slow-path counter (same allocation)
-    hipLaunchKernelGGL(dedup_insert_kernel, dim3(2048), dim3(256), 0, s, acc.pair_gene, acc.pair_hash,
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base,
-                       acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag);
+                       acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag, mode);
 }
 void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
                          uint32_t *tab_cap, unsigned long long *total, int *error) {
