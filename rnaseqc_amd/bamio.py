@@ -1,0 +1,84 @@
+"""Minimal BAM / GTF / BED writers for the synthetic inputs (tests and the CLI benchmark).
+Only what the CLI's decoder reads is written faithfully: header, core fields, CIGAR, NM / chimeric /
+filter tags.  SEQ is all 'A', QUAL 0xff."""
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+from . import abi
+
+
+def _bgzf_block(data: bytes, level: int = 1) -> bytes:
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+    c = comp.compress(data) + comp.flush()
+    bsize = len(c) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + c +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def write_bam(path, contigs, batch, qnames=None, filter_tag="XF", ch_tag="ch", level=1):
+    """contigs: [(name, length)]; batch: model.Batch (file order).  qnames: list of bytes or None (uses batch.qname)."""
+    n = batch.n
+    tid = batch.tid_per_record()
+    hdr_text = ("@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, ln) for nm, ln in contigs)).encode()
+    out = bytearray()
+    out += b"BAM\x01" + struct.pack("<I", len(hdr_text)) + hdr_text + struct.pack("<I", len(contigs))
+    for nm, ln in contigs:
+        out += struct.pack("<I", len(nm) + 1) + nm.encode() + b"\x00" + struct.pack("<I", ln)
+    wide = {int(i): k for k, i in enumerate(batch.wide_index)}
+    cend = np.append(batch.cigar_off, len(batch.cigar)).astype(np.int64)
+    chunks = [bytes(out)]
+    cur = bytearray()
+    for i in range(n):
+        if qnames is not None:
+            name = qnames[i]
+        else:
+            name = bytes(batch.qname[int(batch.qname_off[i]):int(batch.qname_off[i + 1])])
+        lq, nm, nc = int(batch.l_qseq[i]), int(batch.nm[i]), int(batch.n_cigar[i])
+        if i in wide:
+            k = wide[i]
+            lq, nm, nc = int(batch.wide_l_qseq[k]), int(batch.wide_nm[k]), int(batch.wide_n_cigar[k])
+        cig = batch.cigar[int(batch.cigar_off[i]):int(batch.cigar_off[i]) + nc]
+        tb = int(batch.tagbits[i])
+        t = int(tid[i])
+        mtid = t if (tb & abi.TB_MTID_SAME) else (t + 1 if t + 1 < len(contigs) else (0 if t != 0 else -1))
+        tags = b""
+        if tb & abi.TB_HAS_NM:
+            tags += b"NM" + (b"C" + struct.pack("<B", nm) if 0 <= nm < 256 else b"i" + struct.pack("<i", nm))
+        if tb & abi.TB_HAS_CH:
+            tags += ch_tag.encode() + b"Z1\x00"
+        if tb & abi.TB_FILTER0:
+            tags += filter_tag.encode() + b"i" + struct.pack("<i", 1)
+        rec = struct.pack("<iiBBHHHiiii", t, int(batch.pos[i]), len(name) + 1, int(batch.mapq[i]), 4680, nc,
+                          int(batch.flag[i]), lq, mtid, int(batch.mpos[i]), int(batch.isize[i]))
+        rec += name + b"\x00" + cig.astype("<u4").tobytes() + b"\x11" * ((lq + 1) // 2) + b"\xff" * lq + tags
+        cur += struct.pack("<I", len(rec)) + rec
+        if len(cur) > 60000:
+            chunks.append(bytes(cur[:60000])); cur = cur[60000:]
+    if cur:
+        chunks.append(bytes(cur))
+    with open(path, "wb") as f:
+        # the header may exceed one block
+        for c in chunks:
+            for o in range(0, len(c), 60000):
+                f.write(_bgzf_block(c[o:o + 60000], level))
+        f.write(_EOF)
+
+
+def write_gtf(path, ann):
+    with open(path, "w") as f:
+        f.write("##synthetic collapsed annotation\n")
+        for line in ann.to_gtf_lines():
+            f.write(line + "\n")
+
+
+def write_bed(path, ann, bed):
+    with open(path, "w") as f:
+        for c, s, e in zip(bed.contig.tolist(), bed.start.tolist(), bed.end.tolist()):
+            f.write("%s\t%d\t%d\n" % (ann.contig_names[c], s - 1, e - 1))

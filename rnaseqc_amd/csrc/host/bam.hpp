@@ -1,0 +1,53 @@
+// bam.hpp -- BGZF/BAM decode straight into the boundary's record batches (no htslib in this image).
+// Replaces the SeqlibReader adapter (src/BamReader.{h,cpp}) for BAM input; CRAM is out of scope.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../../include/rnaseqc_amd.h"
+
+namespace rsqc_host {
+
+struct HostBatch {                       // owns the arrays an rsqc_batch points to
+    std::vector<rsqc_rec_core> core;
+    std::vector<rsqc_rec_aux> aux;
+    std::vector<uint32_t> cigar;
+    std::vector<int32_t> seg_tid;
+    std::vector<uint64_t> seg_start;
+    std::vector<uint64_t> wide_index;
+    std::vector<int32_t> wide_nm, wide_lq;
+    std::vector<uint32_t> wide_ncig;
+    uint64_t file_index_base = 0;
+    void clear();
+    size_t size() const { return core.size(); }
+    rsqc_batch view();                   // closes the segment table
+};
+
+class BamReader {
+public:
+    bool open(const std::string &path);                 // false: cannot open / not a BAM
+    const std::vector<std::string> &contigs() const { return names_; }
+    // tags: the chimeric tag (2 chars) and up to RSQC_MAX_FILTER_TAGS filter tags
+    void set_tags(const std::string &chimeric, const std::vector<std::string> &filters);
+    // appends up to max_records records to `out`; returns the number appended (0 at EOF)
+    size_t read_batch(HostBatch &out, size_t max_records);
+    uint64_t records_read() const { return n_read_; }
+    ~BamReader();
+private:
+    bool fill(size_t need);              // make at least `need` decompressed bytes available
+    bool inflate_block();
+    FILE *fp_ = nullptr;
+    std::vector<uint8_t> buf_;           // decompressed stream window
+    size_t pos_ = 0;
+    std::vector<uint8_t> cbuf_;
+    bool eof_ = false;
+    std::vector<std::string> names_;
+    std::string ch_tag_ = "ch";
+    std::vector<std::string> filter_tags_;
+    uint64_t n_read_ = 0;
+};
+
+}  // namespace rsqc_host

@@ -1,0 +1,56 @@
+// gtf.hpp -- GTF / BED ingest of the CLI: reproduces the reference's bookkeeping (id assignment,
+// ordering, lengths, name table, parse quirks) and flattens it into the boundary's rsqc_annotation.
+//   reference: src/GTF.cpp:30-148 (operator>>, parseAttributes), src/RNASeQC.cpp:104-164 (load loop,
+//   per-contig stable sort, exonsForGene), src/BED.cpp:18-45, src/Fasta.cpp:17-25 (chromosomeMap)
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rnaseqc_amd.h"
+
+namespace rsqc_host {
+
+struct GtfError : std::runtime_error { using std::runtime_error::runtime_error; };     // exit code 11
+struct BedError : std::runtime_error { using std::runtime_error::runtime_error; };     // exit code 11
+struct FileError : std::runtime_error { using std::runtime_error::runtime_error; };    // exit code 10
+
+struct Annotation {
+    // chromosomeMap: name -> id in first-sight order (GTF, then BED, then BAM header), 1-based like the reference
+    std::map<std::string, int> chrom_id;
+    std::vector<std::string> chrom_name;           // id-1 -> name
+    int chromosome(const std::string &name);
+
+    // GTF state
+    std::vector<std::string> gene_list, exon_list;                  // geneList / exonList (GTF order)
+    std::map<std::string, std::string> gene_names;                  // geneNames[feature_id]
+    std::map<std::string, long long> gene_coding_length;            // geneCodingLengths
+    struct Row { int chrom; long long start, end; int strand; bool is_gene; bool ribosomal; std::string feature_id, gene_id; size_t order; };
+    std::vector<Row> rows;                                          // kept gene/exon rows, GTF order
+    void load_gtf(const std::string &path);
+
+    // BED rows (+1/+1), file order
+    struct BedRow { int chrom; long long start, end; };
+    std::vector<BedRow> bed_rows;
+    void load_bed(const std::string &path);
+
+    // ---- flattened form for the boundary (filled by flatten) -----------------------------------------
+    // contig ids of the boundary: BAM header order first, then contigs only the GTF/BED name
+    std::vector<std::string> contig_names; int n_ref = 0;
+    std::vector<int32_t> g_contig, g_start, g_end, e_contig, e_start, e_end, b_contig, b_start, b_end;
+    std::vector<uint8_t> g_flags, e_flags, globin;
+    std::vector<uint32_t> g_id, e_id, e_gene, ge_off, ge_row;
+    std::vector<std::string> gene_id_of;            // gene id (boundary) -> gene_id string (listed first, then phantom)
+    std::vector<int> chrom_of_contig;               // boundary contig id -> chromosomeMap id
+    int n_genes = 0;
+    rsqc_annotation ann{};
+    rsqc_bed bed{};
+    void flatten(const std::vector<std::string> &bam_contigs);
+    // listed gene ids of a boundary contig in start order (coverage.tsv row order)
+    std::vector<std::vector<uint32_t>> genes_by_contig;
+};
+
+}  // namespace rsqc_host

@@ -1,0 +1,69 @@
+// host_api.cpp -- thin C entry points over the CLI's host-side pieces (GTF/BED ingest, BAM decode,
+// report writers) so that the CPU tests can exercise them without a GPU.  Not part of the product ABI.
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bam.hpp"
+#include "gtf.hpp"
+#include "report.hpp"
+
+using namespace rsqc_host;
+#define HAPI extern "C" __attribute__((visibility("default")))
+
+HAPI void *host_annotation_load(const char *gtf, const char *bed, const char *const *bam_contigs, int n_contigs, int *err) {
+    Annotation *a = new Annotation();
+    *err = 0;
+    try {
+        a->load_gtf(gtf);
+        if (bed && *bed) a->load_bed(bed);
+        std::vector<std::string> c;
+        for (int i = 0; i < n_contigs; ++i) c.emplace_back(bam_contigs[i]);
+        a->flatten(c);
+    } catch (FileError &) { *err = 10; } catch (GtfError &) { *err = 11; } catch (BedError &) { *err = 11; } catch (...) { *err = -1; }
+    if (*err) { delete a; return nullptr; }
+    return a;
+}
+HAPI const rsqc_annotation *host_annotation_struct(void *h) { return &((Annotation *)h)->ann; }
+HAPI const rsqc_bed *host_annotation_bed(void *h) { return &((Annotation *)h)->bed; }
+HAPI const char *host_annotation_gene_name(void *h, int listed_gene) {
+    Annotation *a = (Annotation *)h; return a->gene_names[a->gene_list[(size_t)listed_gene]].c_str();
+}
+HAPI const char *host_annotation_gene_id(void *h, int listed_gene) { return ((Annotation *)h)->gene_list[(size_t)listed_gene].c_str(); }
+HAPI const char *host_annotation_exon_id(void *h, int exon) { return ((Annotation *)h)->exon_list[(size_t)exon].c_str(); }
+HAPI long long host_annotation_coding_length(void *h, int listed_gene) {
+    Annotation *a = (Annotation *)h; return a->gene_coding_length[a->gene_list[(size_t)listed_gene]];
+}
+HAPI void host_annotation_free(void *h) { delete (Annotation *)h; }
+
+HAPI int host_write_reports(void *h, const rsqc_results *r, const char *out_dir, const char *sample, int sample_given,
+                            int use_rpkm, int write_coverage, unsigned detection, const char *const *tags, int n_tags,
+                            const int *visit, int n_visit) {
+    ReportConfig cfg;
+    cfg.output_dir = out_dir; cfg.sample_name = sample; cfg.sample_given = sample_given != 0; cfg.use_rpkm = use_rpkm != 0;
+    cfg.write_coverage = write_coverage != 0; cfg.detection_threshold = detection;
+    for (int i = 0; i < n_tags; ++i) cfg.filter_tags.emplace_back(tags[i]);
+    try { write_reports(cfg, *(Annotation *)h, *r, std::vector<int>(visit, visit + n_visit)); }
+    catch (std::range_error &) { return 2; } catch (...) { return -1; }
+    return 0;
+}
+
+HAPI unsigned host_library_complexity(double dup, double unique, double limit) { return library_complexity(dup, unique, limit); }
+
+struct BamHandle { BamReader reader; HostBatch batch; rsqc_batch view; std::vector<std::string> names; };
+HAPI void *host_bam_read_all(const char *path, const char *ch_tag, const char *const *tags, int n_tags) {
+    BamHandle *b = new BamHandle();
+    if (!b->reader.open(path)) { delete b; return nullptr; }
+    std::vector<std::string> t;
+    for (int i = 0; i < n_tags; ++i) t.emplace_back(tags[i]);
+    b->reader.set_tags(ch_tag, t);
+    try { while (b->reader.read_batch(b->batch, 1u << 20)) {} } catch (...) { delete b; return nullptr; }
+    b->view = b->batch.view();
+    b->names = b->reader.contigs();
+    return b;
+}
+HAPI const rsqc_batch *host_bam_batch(void *h) { return &((BamHandle *)h)->view; }
+HAPI int host_bam_n_contigs(void *h) { return (int)((BamHandle *)h)->names.size(); }
+HAPI const char *host_bam_contig(void *h, int i) { return ((BamHandle *)h)->names[(size_t)i].c_str(); }
+HAPI void host_bam_free(void *h) { delete (BamHandle *)h; }

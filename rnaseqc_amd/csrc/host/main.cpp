@@ -1,0 +1,322 @@
+// main.cpp -- `rnaseqc [OPTIONS] gtf bam output`: the reference's command line (flag table
+// src/RNASeQC.cpp:39-65, defaults :87-100, exit codes :678-766) in front of the HIP hot path.
+// Host side only: GTF/BED ingest, BAM decode into SoA batches, report writers.  Every per-record
+// computation happens on the GPU through the C ABI (include/rnaseqc_amd.h); without a GPU the
+// program exits with code 10.
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bam.hpp"
+#include "gtf.hpp"
+#include "report.hpp"
+
+using namespace rsqc_host;
+
+namespace {
+
+const char *VERSION = "RNASeQC 2.4.3";
+
+struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };          // exit 5
+struct ValidationError : std::runtime_error { using std::runtime_error::runtime_error; };    // exit 6
+struct Help {};
+
+struct Options {
+    std::vector<std::string> positional;
+    std::string sample, bed, fasta, stranded, chimeric_tag = "ch";
+    bool has_sample = false, has_bed = false, has_fasta = false, has_stranded = false;
+    bool legacy = false, exclude_chimeric = false, unpaired = false, rpkm = false, coverage = false, version = false;
+    int verbosity = 0;
+    long chimeric_distance = 2000000; unsigned long fragment_samples = 1000000, mapq = 255, base_mismatch = 6;
+    bool has_mapq = false;
+    long bias_offset = 0, bias_window = 100; unsigned long bias_gene_length = 200, coverage_mask = 500, detection = 5;
+    std::vector<std::string> tags;
+};
+
+void usage(std::ostream &o) {
+    o << "  rnaseqc {OPTIONS} [gtf] [bam] [output]\n\n    " << VERSION << "\n\n  OPTIONS:\n\n"
+         "      -h, --help                        Display this message and quit\n"
+         "      --version                         Display the version and quit\n"
+         "      gtf                               The input GTF file containing features to check the bam against\n"
+         "      bam                               The input SAM/BAM file containing reads to process\n"
+         "      output                            Output directory\n"
+         "      -s[sample], --sample=[sample]     The name of the current sample.  Default: The bam's filename\n"
+         "      --bed=[BEDFILE]                   Optional input BED file containing non-overlapping exons used for fragment size calculations\n"
+         "      --fasta=[fasta]                   (not supported by this build)\n"
+         "      --chimeric-distance=[DISTANCE]    Maximum accepted distance between read mates. Default: 2000000 [bp]\n"
+         "      --fragment-samples=[SAMPLES]      Number of fragment size samples. Default: 1000000\n"
+         "      -q[QUALITY], --mapping-quality=[QUALITY]  Lower bound on read quality for exon coverage counting. Default: 255\n"
+         "      --base-mismatch=[MISMATCHES]      Maximum number of allowed mismatches. Default: 6\n"
+         "      --offset=[OFFSET]                 Offset into the gene for the 3' and 5' windows. Default: 0 [bp]\n"
+         "      --window-size=[SIZE]              Size of the 3' and 5' windows. Default: 100 [bp]\n"
+         "      --gene-length=[LENGTH]            Minimum size of a gene for bias calculation. Default: 200 [bp]\n"
+         "      --legacy                          (not supported by this build)\n"
+         "      --stranded=[stranded]             'RF', 'rf', 'FR', or 'fr'\n"
+         "      -v, --verbose                     Give some feedback; twice for progress updates\n"
+         "      -t[TAG...], --tag=[TAG...]        Filter out reads with the specified tag\n"
+         "      --chimeric-tag=[TAG]              Reads marked with this tag are chimeric. Default: ch\n"
+         "      --exclude-chimeric                Exclude chimeric reads from the read counts\n"
+         "      -u, --unpaired                    Allow unpaired reads to be quantified\n"
+         "      --rpkm                            Output gene RPKM values instead of TPMs\n"
+         "      --coverage                        Write per-transcript coverage statistics to a table\n"
+         "      --coverage-mask=[SIZE]            Bases masked at both transcript ends. Default: 500bp\n"
+         "      -d[threshold], --detection-threshold=[threshold]  Counts to call a gene detected. Default: 5 reads\n";
+}
+
+long to_long(const std::string &flag, const std::string &v) {
+    char *e = nullptr;
+    const long x = strtol(v.c_str(), &e, 10);
+    if (v.empty() || (e && *e)) throw ParseError("Argument '" + flag + "' received invalid value type '" + v + "'");
+    return x;
+}
+unsigned long to_ulong(const std::string &flag, const std::string &v) {
+    char *e = nullptr;
+    if (v.empty() || v[0] == '-') throw ParseError("Argument '" + flag + "' received invalid value type '" + v + "'");
+    const unsigned long x = strtoul(v.c_str(), &e, 10);
+    if (e && *e) throw ParseError("Argument '" + flag + "' received invalid value type '" + v + "'");
+    return x;
+}
+
+Options parse(int argc, char **argv) {
+    Options o;
+    bool only_positional = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (only_positional || a.size() < 2 || a[0] != '-') { o.positional.push_back(a); continue; }
+        if (a == "--") { only_positional = true; continue; }
+        std::string name, value; bool has_value = false;
+        if (a[1] == '-') {
+            const size_t eq = a.find('=');
+            name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            if (eq != std::string::npos) { value = a.substr(eq + 1); has_value = true; }
+        } else {
+            // short flags: -v, -vv, -u, -h may be bundled; -s/-q/-t/-d take the rest of the token or the next one
+            size_t k = 1;
+            bool consumed = false;
+            while (k < a.size() && !consumed) {
+                const char c = a[k];
+                if (c == 'v') { ++o.verbosity; ++k; }
+                else if (c == 'u') { o.unpaired = true; ++k; }
+                else if (c == 'h') throw Help();
+                else if (c == 's' || c == 'q' || c == 't' || c == 'd') {
+                    std::string v = a.substr(k + 1);
+                    if (v.empty()) { if (i + 1 >= argc) throw ParseError(std::string("Flag '") + c + "' requires an argument but received none"); v = argv[++i]; }
+                    const std::string f(1, c);
+                    if (c == 's') { o.sample = v; o.has_sample = true; }
+                    else if (c == 'q') { o.mapq = to_ulong(f, v); o.has_mapq = true; }
+                    else if (c == 't') o.tags.push_back(v);
+                    else o.detection = to_ulong(f, v);
+                    consumed = true;
+                } else throw ParseError(std::string("Flag could not be matched: '") + c + "'");
+            }
+            continue;
+        }
+        auto need = [&]() -> std::string {
+            if (has_value) return value;
+            if (i + 1 >= argc) throw ParseError("Flag '" + name + "' requires an argument but received none");
+            return std::string(argv[++i]);
+        };
+        if (name == "help") throw Help();
+        else if (name == "version") o.version = true;
+        else if (name == "sample") { o.sample = need(); o.has_sample = true; }
+        else if (name == "bed") { o.bed = need(); o.has_bed = true; }
+        else if (name == "fasta") { o.fasta = need(); o.has_fasta = true; }
+        else if (name == "chimeric-distance") o.chimeric_distance = to_long(name, need());
+        else if (name == "fragment-samples") o.fragment_samples = to_ulong(name, need());
+        else if (name == "mapping-quality") { o.mapq = to_ulong(name, need()); o.has_mapq = true; }
+        else if (name == "base-mismatch") o.base_mismatch = to_ulong(name, need());
+        else if (name == "offset") o.bias_offset = to_long(name, need());
+        else if (name == "window-size") o.bias_window = to_long(name, need());
+        else if (name == "gene-length") o.bias_gene_length = to_ulong(name, need());
+        else if (name == "legacy") o.legacy = true;
+        else if (name == "stranded") { o.stranded = need(); o.has_stranded = true; }
+        else if (name == "verbose") ++o.verbosity;
+        else if (name == "tag") o.tags.push_back(need());
+        else if (name == "chimeric-tag") o.chimeric_tag = need();
+        else if (name == "exclude-chimeric") o.exclude_chimeric = true;
+        else if (name == "unpaired") o.unpaired = true;
+        else if (name == "rpkm") o.rpkm = true;
+        else if (name == "coverage") o.coverage = true;
+        else if (name == "coverage-mask") o.coverage_mask = to_ulong(name, need());
+        else if (name == "detection-threshold") o.detection = to_ulong(name, need());
+        else throw ParseError("Flag could not be matched: " + name);
+    }
+    return o;
+}
+
+bool make_dirs(const std::string &path) {          // boost::filesystem::create_directories
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); ++i) {
+        if (i == path.size() || path[i] == '/') {
+            if (!cur.empty() && cur != "/") {
+                struct stat st;
+                if (stat(cur.c_str(), &st) != 0) { if (mkdir(cur.c_str(), 0777) != 0) return false; }
+                else if (!S_ISDIR(st.st_mode)) return false;
+            }
+        }
+        if (i < path.size()) cur += path[i];
+    }
+    return true;
+}
+
+std::string basename_of(const std::string &p) {
+    const size_t s = p.find_last_of('/');
+    return s == std::string::npos ? p : p.substr(s + 1);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    using std::cerr; using std::cout; using std::endl;
+    try {
+        Options o = parse(argc, argv);
+        if (o.version) { cout << VERSION << endl; return 0; }
+        if (o.positional.size() < 1) throw ValidationError("No GTF file provided");
+        if (o.positional.size() < 2) throw ValidationError("No BAM file provided");
+        if (o.positional.size() < 3) throw ValidationError("No output directory provided");
+        if (o.positional.size() > 3) throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + o.positional[3]);
+        const std::string gtf_path = o.positional[0], bam_path = o.positional[1], out_dir = o.positional[2];
+        int strand = RSQC_STRAND_UNKNOWN;
+        if (o.has_stranded) {
+            if (o.stranded == "RF" || o.stranded == "rf") strand = RSQC_STRAND_REVERSE;
+            else if (o.stranded == "FR" || o.stranded == "fr") strand = RSQC_STRAND_FORWARD;
+            else throw ValidationError("--stranded argument must be in {'RF', 'rf', 'FR', 'fr'}");
+        }
+        if (o.legacy) { cerr << "--legacy counting rules are not implemented in this build" << endl; return 7; }
+        if (o.has_fasta) { cerr << "--fasta (CRAM reference / GC statistics) is not implemented in this build" << endl; return 7; }
+        if (o.tags.size() > RSQC_MAX_FILTER_TAGS) { cerr << "at most " << RSQC_MAX_FILTER_TAGS << " --tag filters are supported" << endl; return 7; }
+
+        rsqc_params P{};
+        P.abi_version = RSQC_ABI_VERSION;
+        P.device = getenv("RSQC_DEVICE") ? atoi(getenv("RSQC_DEVICE")) : 0;
+        P.mapq_threshold = (uint32_t)o.mapq; P.base_mismatch = (uint32_t)o.base_mismatch;
+        P.chimeric_distance = (int32_t)o.chimeric_distance; P.fragment_samples = (uint32_t)o.fragment_samples;
+        P.bias_offset = (int32_t)o.bias_offset; P.bias_window = (int32_t)o.bias_window; P.bias_gene_length = o.bias_gene_length;
+        P.coverage_mask = (uint32_t)o.coverage_mask; P.stranded = strand; P.unpaired = o.unpaired; P.exclude_chimeric = o.exclude_chimeric;
+        P.n_filter_tags = (int32_t)o.tags.size();
+        const std::string SAMPLENAME = o.has_sample ? o.sample : basename_of(bam_path);
+
+        const auto t0 = std::chrono::steady_clock::now();
+        Annotation ann;
+        if (o.verbosity) cout << "Reading GTF Features..." << endl;
+        ann.load_gtf(gtf_path);                                               // FileError -> 10, GtfError -> 11
+        if (!(ann.gene_list.size() && ann.exon_list.size())) {
+            cerr << "There were either no genes or no exons in the GTF" << endl;
+            cerr << ann.gene_list.size() << " genes parsed" << endl << ann.exon_list.size() << " exons parsed" << endl;
+            return 11;
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        if (o.verbosity) cout << "Finished processing GTF in " << std::chrono::duration<double>(t1 - t0).count() << " seconds" << endl;
+        std::vector<char> gtf_chrom(ann.chrom_name.size() + 1, 0);
+        for (auto &r : ann.rows) gtf_chrom[(size_t)r.chrom] = 1;
+        if (o.has_bed) {
+            if (o.verbosity) cout << "Parsing BED intervals for fragment size computations..." << endl;
+            ann.load_bed(o.bed);
+        }
+        if (!make_dirs(out_dir)) { cerr << "Filesystem error:  cannot create " << out_dir << endl; return 8; }
+        BamReader bam;
+        if (!bam.open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+        bam.set_tags(o.chimeric_tag, o.tags);
+        // header check: at least one BAM contig must carry GTF features (src/RNASeQC.cpp:216-238)
+        if (o.verbosity > 1) cout << "Checking bam header..." << endl;
+        bool overlap = false;
+        for (auto &n : bam.contigs()) { auto it = ann.chrom_id.find(n); if (it != ann.chrom_id.end() && (size_t)it->second < gtf_chrom.size() && gtf_chrom[(size_t)it->second]) overlap = true; }
+        if (!overlap) { cerr << "BAM file shares no contigs with GTF" << endl; return 11; }
+        ann.flatten(bam.contigs());
+
+        rsqc_ctx *gpu = nullptr;
+        int rc = rsqc_create(&P, &gpu);
+        if (rc != RSQC_OK) { cerr << "Unable to initialise the GPU hot path: " << rsqc_strerror(rc) << endl; return 10; }
+        if ((rc = rsqc_set_annotation(gpu, &ann.ann, nullptr)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
+        if (o.has_bed && (rc = rsqc_set_bed(gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
+
+        if (o.verbosity) cout << "Parsing bam..." << endl;
+        const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
+        HostBatch bufs[2];
+        std::vector<int> visit;
+        unsigned long long alignmentCount = 0;
+        int cur = 0; bool in_flight = false;
+        const auto tb0 = std::chrono::steady_clock::now();
+        for (;;) {
+            HostBatch &hb = bufs[cur];
+            hb.clear();
+            hb.file_index_base = alignmentCount;
+            const size_t n = bam.read_batch(hb, BATCH);              // decode overlaps the previous batch on the GPU
+            if (in_flight) { if ((rc = rsqc_wait(gpu)) != RSQC_OK) break; in_flight = false; }
+            if (n == 0) break;
+            for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t)) visit.push_back(t);
+            alignmentCount += n;
+            rsqc_batch view = hb.view();
+            if ((rc = rsqc_submit(gpu, &view)) != RSQC_OK) break;
+            in_flight = true;
+            cur ^= 1;
+            if (o.verbosity > 1) cout << "Alignments processed: " << alignmentCount << endl;
+        }
+        rsqc_results res{};
+        if (rc == RSQC_OK) rc = rsqc_finalize(gpu, &res);
+        const auto tb1 = std::chrono::steady_clock::now();
+        if (rc == RSQC_ERR_BAD_CIGAR) throw std::invalid_argument("Unrecognized Cigar Op ");
+        if (rc == RSQC_ERR_EMPTY_MEDIAN) throw std::range_error("Cannot compute median of an empty list");
+        if (rc != RSQC_OK) { cerr << rsqc_strerror(rc) << ": " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 10; }
+        if (o.verbosity) {
+            const double secs = std::chrono::duration<double>(tb1 - tb0).count();
+            cout << "Time Elapsed: " << secs << "; Alignments processed: " << alignmentCount << endl;
+            if (o.verbosity > 1) cout << "Average Reads/Sec: " << (double)alignmentCount / secs << endl;
+            cout << "Estimating library complexity..." << endl;
+            cout << "Generating report" << endl;
+        }
+        ReportConfig cfg;
+        cfg.output_dir = out_dir; cfg.sample_name = SAMPLENAME; cfg.sample_given = o.has_sample;
+        cfg.use_rpkm = o.rpkm; cfg.write_coverage = o.coverage; cfg.detection_threshold = (unsigned)o.detection;
+        cfg.filter_tags = o.tags;
+        write_reports(cfg, ann, res, visit);
+        rsqc_destroy(gpu);
+    } catch (Help &) {
+        usage(cout);
+        return 4;
+    } catch (ParseError &e) {
+        usage(cerr); cerr << endl << "Argument parsing error: " << e.what() << endl;
+        return 5;
+    } catch (ValidationError &e) {
+        usage(cerr); cerr << endl << "Argument validation error: " << e.what() << endl;
+        return 6;
+    } catch (std::invalid_argument &e) {
+        cerr << "Invalid argument type provided: " << e.what() << endl;
+        return 7;
+    } catch (FileError &e) {
+        cerr << e.what() << endl;
+        return 10;
+    } catch (GtfError &e) {
+        cerr << "Failed to parse the GTF: " << e.what() << endl;
+        return 11;
+    } catch (BedError &e) {
+        cerr << "Failed to parse the BED: " << e.what() << endl;
+        return 11;
+    } catch (std::length_error &e) {
+        cerr << "Unable to parse the GFT lines" << endl << e.what() << endl;
+        return 1;
+    } catch (std::range_error &e) {
+        cerr << "Invalid range" << endl << e.what() << endl;
+        return 2;
+    } catch (std::domain_error &e) {
+        cerr << "Unable to perform string conversion" << endl << e.what() << endl;
+        return 3;
+    } catch (std::bad_alloc &e) {
+        cerr << "Memory allocation failure. Out of memory" << endl << e.what() << endl;
+        return 10;
+    } catch (std::exception &e) {
+        cerr << "Encountered an IO failure" << endl << e.what() << endl;
+        return 10;
+    } catch (...) {
+        cerr << "Unknown error" << endl;
+        return -1;
+    }
+    return 0;
+}

@@ -1,0 +1,102 @@
+"""The `rnaseqc gtf bam output` command line: exit codes (CPU) and end-to-end outputs (GPU)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, bamio, synth
+from tests import cases
+from tests.test_host_cli_pieces import host, load_annotation, _results_struct, read_table  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "rnaseqc_amd", "bin", "rnaseqc")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rnaseqc_amd", "csrc"), "cli"])
+    return BIN
+
+
+def run(cli, *args):
+    p = subprocess.run([cli, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_cli_exit_codes_without_gpu_work(cli, tmp_path):
+    # reference behaviour: SURVEY.md Appendix B "CLI behaviour", src/RNASeQC.cpp:678-766
+    rc, out, _ = run(cli, "--version")
+    assert rc == 0 and out.strip() == "RNASeQC 2.4.3"                  # python/rnaseqc/run.py:25 needs the prefix
+    assert run(cli, "-h")[0] == 4
+    assert run(cli)[0] == 6 and run(cli, "a.gtf", "b.bam")[0] == 6
+    assert run(cli, "a", "b", "c", "--stranded", "xx")[0] == 6
+    assert run(cli, "a", "b", "c", "--nope")[0] == 5 and run(cli, "a", "b", "c", "-q", "abc")[0] == 5
+    assert run(cli, str(tmp_path / "missing.gtf"), "b.bam", str(tmp_path / "o"))[0] == 10
+    ann, batch = cases.quirk_case()
+    gtf, bam = str(tmp_path / "q.gtf"), str(tmp_path / "q.bam")
+    bamio.write_gtf(gtf, ann)
+    assert run(cli, gtf, str(tmp_path / "missing.bam"), str(tmp_path / "o"))[0] == 10
+    assert os.path.isdir(tmp_path / "o")                               # the output dir is created before the BAM is opened
+    bamio.write_bam(bam, [("other1", 1000), ("other2", 1000)], batch.slice(0, 0))
+    assert run(cli, gtf, bam, str(tmp_path / "o"))[0] == 11            # BAM shares no contigs with the GTF
+    empty = tmp_path / "e.gtf"; empty.write_text('c\tx\ttranscript\t1\t5\t.\t+\t.\tgene_id "A"; transcript_id "T";\n')
+    assert run(cli, str(empty), bam, str(tmp_path / "o"))[0] == 11     # no genes / exons
+
+
+def _compare_tables(a, b, skip, tol=1e-6):
+    """test_data/approx_diff.py semantics: join on the first column, same NaN pattern, |a-b| <= tol."""
+    ta = {r[0]: r[1:] for r in read_table(a, skip)}
+    tb = {r[0]: r[1:] for r in read_table(b, skip)}
+    assert ta.keys() == tb.keys(), (a, set(ta) ^ set(tb))
+    for k in ta:
+        for x, y in zip(ta[k], tb[k]):
+            try:
+                fx, fy = float(x), float(y)
+            except ValueError:
+                assert x == y, (a, k, x, y)
+                continue
+            assert np.isnan(fx) == np.isnan(fy), (a, k, x, y)
+            if not np.isnan(fx):
+                assert abs(fx - fy) <= tol + 1e-9 * abs(fy), (a, k, x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_bed", [False, True])
+def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, with_bed):
+    contigs = [("chrA", 900_000, 70), ("chrB", 500_000, 40)]
+    ann = synth.make_annotation(seed=41, contigs=contigs)
+    batch = synth.make_reads(ann, 40000, seed=42, keep_qnames=True, dup_frac=0.1, frac=(0.85, 0.06, 0.05, 0.04), expr_sigma=1.2,
+                             contig_lengths=np.array([c[1] for c in contigs]))
+    gtf, bam, bedp = str(tmp_path / "s.gtf"), str(tmp_path / "s.bam"), str(tmp_path / "s.bed")
+    bamio.write_gtf(gtf, ann)
+    bamio.write_bam(bam, [(c[0], c[1]) for c in contigs], batch)
+    bed = synth.make_bed(ann, min_len=250) if with_bed else None
+    args = [gtf, bam, str(tmp_path / "cli"), "--coverage", "-vv"]
+    if with_bed:
+        bamio.write_bed(bedp, ann, bed)
+        args += ["--bed", bedp]
+    env = dict(os.environ, RSQC_BATCH="30000")                   # several batches
+    p = subprocess.run([cli, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()
+    assert "Average Reads/Sec" in p.stdout.decode()
+    # expected files: the same C++ report writer fed with the ORACLE's results on the same inputs
+    want = oracle_lib.run_oracle(abi.default_params(), ann, [batch], bed=bed)
+    h, err = load_annotation(host, gtf, [c[0] for c in contigs], bedp if with_bed else None)
+    assert err == 0
+    rs, keep = _results_struct(want)
+    exp = str(tmp_path / "exp"); os.makedirs(exp)
+    visit = (C.c_int * 2)(0, 1)
+    assert host.host_write_reports(h, C.byref(rs), exp.encode(), b"s.bam", 0, 0, 1, 5, None, 0, visit, 2) == 0
+    files = ["metrics.tsv", "gene_reads.gct", "gene_tpm.gct", "gene_fragments.gct", "exon_reads.gct", "coverage.tsv", "exon_cv.tsv"]
+    if with_bed:
+        files.append("fragmentSizes.txt")
+        assert want.fragment_count.sum() > 50
+    for f in files:
+        skip = 3 if f.endswith(".gct") else 1
+        _compare_tables(os.path.join(str(tmp_path / "cli"), "s.bam." + f), os.path.join(exp, "s.bam." + f), skip, tol=1e-5)
+    # integer tables must be byte-identical
+    for f in ["gene_reads.gct", "gene_fragments.gct"] + (["fragmentSizes.txt"] if with_bed else []):
+        assert open(os.path.join(str(tmp_path / "cli"), "s.bam." + f)).read() == open(os.path.join(exp, "s.bam." + f)).read()
+    host.host_annotation_free(h)

@@ -1,0 +1,254 @@
+"""CPU: the CLI's host-side C++ (GTF/BED ingest, BAM decode, report writers, library-complexity search)
+through rnaseqc_amd/lib/librsqc_host.so."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, bamio, synth
+from rnaseqc_amd.model import Annotation, Batch
+from tests import cases, report_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "rnaseqc_amd", "lib", "librsqc_host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rnaseqc_amd", "csrc"), "../lib/librsqc_host.so"])
+    lib = C.CDLL(SO)
+    lib.host_annotation_load.restype = C.c_void_p
+    lib.host_annotation_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+    lib.host_annotation_struct.restype = C.POINTER(abi.AnnotationStruct); lib.host_annotation_struct.argtypes = [C.c_void_p]
+    lib.host_annotation_bed.restype = C.POINTER(abi.BedStruct); lib.host_annotation_bed.argtypes = [C.c_void_p]
+    for f in ("host_annotation_gene_name", "host_annotation_gene_id", "host_annotation_exon_id"):
+        getattr(lib, f).restype = C.c_char_p; getattr(lib, f).argtypes = [C.c_void_p, C.c_int]
+    lib.host_annotation_coding_length.restype = C.c_longlong; lib.host_annotation_coding_length.argtypes = [C.c_void_p, C.c_int]
+    lib.host_annotation_free.argtypes = [C.c_void_p]
+    lib.host_write_reports.argtypes = [C.c_void_p, C.POINTER(abi.ResultsStruct), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_uint, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int), C.c_int]
+    lib.host_library_complexity.restype = C.c_uint; lib.host_library_complexity.argtypes = [C.c_double, C.c_double, C.c_double]
+    lib.host_bam_read_all.restype = C.c_void_p; lib.host_bam_read_all.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+    lib.host_bam_batch.restype = C.POINTER(abi.BatchStruct); lib.host_bam_batch.argtypes = [C.c_void_p]
+    lib.host_bam_n_contigs.argtypes = [C.c_void_p]
+    lib.host_bam_contig.restype = C.c_char_p; lib.host_bam_contig.argtypes = [C.c_void_p, C.c_int]
+    lib.host_bam_free.argtypes = [C.c_void_p]
+    return lib
+
+
+def _arr(p, n, dt):
+    return abi._view(p, n, dt)
+
+
+def load_annotation(host, gtf, contigs, bed=None):
+    names = (C.c_char_p * len(contigs))(*[c.encode() for c in contigs])
+    err = C.c_int()
+    h = host.host_annotation_load(gtf.encode(), (bed or "").encode(), names, len(contigs), C.byref(err))
+    return h, err.value
+
+
+def test_gtf_ingest_matches_python_mirror(host, tmp_path):
+    ann = synth.make_annotation(seed=31, contigs=[("chrA", 2_000_000, 120), ("chrB", 900_000, 60), ("chrC", 500_000, 20)])
+    gtf = str(tmp_path / "a.gtf")
+    bamio.write_gtf(gtf, ann)
+    # BAM header order differs from GTF order and has an extra contig; chrC is GTF-only
+    bam_contigs = ["chrB", "chrZ", "chrA"]
+    h, err = load_annotation(host, gtf, bam_contigs)
+    assert err == 0
+    s = host.host_annotation_struct(h).contents
+    assert (s.n_ref, s.n_contigs, s.n_genes_listed, s.n_exons) == (3, 4, ann.n_genes_listed, ann.n_exons)
+    # python mirror on the same rows with the same BAM contig order
+    rows = []
+    row_of_gene = {int(g): i for i, g in enumerate(ann.gene_row_id)}
+    for g, gid in enumerate(ann.gene_ids):
+        i = row_of_gene[g]
+        strand = {0: "+", 1: "-", 2: "."}[int(ann.gene_row_flags[i]) & 3]
+        tt = "rRNA" if int(ann.gene_row_flags[i]) & abi.FF_RIBOSOMAL else "protein_coding"
+        cname = ann.contig_names[int(ann.gene_row_contig[i])]
+        rows.append(dict(contig=cname, type="gene", start=int(ann.gene_row_start[i]), end=int(ann.gene_row_end[i]), strand=strand,
+                         gene_id=gid, gene_name=ann.gene_names[g], transcript_type=tt))
+        for k in range(int(ann.gene_exon_off[g]), int(ann.gene_exon_off[g + 1])):
+            r = int(ann.gene_exon_row[k])
+            rows.append(dict(contig=cname, type="exon", start=int(ann.exon_row_start[r]), end=int(ann.exon_row_end[r]), strand=strand,
+                             gene_id=gid, exon_id=ann.exon_ids[int(ann.exon_row_id[r])], gene_name=ann.gene_names[g], transcript_type=tt))
+    py = Annotation.from_rows(bam_contigs, rows)
+    L, E = py.n_genes_listed, py.n_exons
+    for f, n, dt in [("gene_row_contig", L, np.int32), ("gene_row_start", L, np.int32), ("gene_row_end", L, np.int32),
+                     ("gene_row_flags", L, np.uint8), ("gene_row_id", L, np.uint32), ("exon_row_contig", E, np.int32),
+                     ("exon_row_start", E, np.int32), ("exon_row_end", E, np.int32), ("exon_row_flags", E, np.uint8),
+                     ("exon_row_id", E, np.uint32), ("exon_row_gene", E, np.uint32), ("gene_is_globin", py.n_genes, np.uint8),
+                     ("gene_exon_off", py.n_genes + 1, np.uint32), ("gene_exon_row", E, np.uint32)]:
+        np.testing.assert_array_equal(_arr(getattr(s, f), n, dt), getattr(py, f), err_msg=f)
+    assert host.host_annotation_gene_name(h, 5).decode() == ann.gene_names[5]
+    assert host.host_annotation_coding_length(h, 7) == int(ann.coding_length[7])
+    host.host_annotation_free(h)
+
+
+def test_gtf_quirks(host, tmp_path):
+    # Q11 exon-id inference, Q16 transcript_type leak, duplicate ids and a blank line are fatal (exit 11)
+    g = tmp_path / "q.gtf"
+    g.write_text("#c\n"
+                 'c1\tx\tgene\t100\t900\t.\t+\t.\tgene_id "G1"; gene_name "HBB"; transcript_type "rRNA";\n'
+                 'c1\tx\texon\t100\t300\t.\t+\t.\tgene_id "G1";\n'
+                 'c1\tx\ttranscript\t100\t900\t.\t+\t.\tgene_id "G1"; transcript_id "T1";\n'
+                 'c1\tx\tgene\t2000\t2500\t.\t-\t.\tgene_id "G2";\n'
+                 'c1\tx\texon\t2000\t2500\t.\t-\t.\tgene_id "G2"; exon_id "E2";\n')
+    h, err = load_annotation(host, str(g), ["c1"])
+    assert err == 0
+    s = host.host_annotation_struct(h).contents
+    assert host.host_annotation_exon_id(h, 0).decode() == "G1_1"
+    # G2 and its exon carry no transcript_type: they inherit "rRNA" from the lines before
+    assert list(_arr(s.gene_row_flags, 2, np.uint8)) == [abi.STRAND_FORWARD | abi.FF_RIBOSOMAL, abi.STRAND_REVERSE | abi.FF_RIBOSOMAL]
+    assert list(_arr(s.gene_is_globin, 2, np.uint8)) == [1, 0]
+    assert host.host_annotation_gene_name(h, 1).decode() == "G2"
+    host.host_annotation_free(h)
+    for bad in ['c1\tx\tgene\t1\t5\t.\t+\t.\tgene_id "A";\nc1\tx\tgene\t7\t9\t.\t+\t.\tgene_id "A";\n',
+                'c1\tx\tgene\t1\t5\t.\t+\t.\tgene_id "A";\n\nc1\tx\texon\t1\t5\t.\t+\t.\tgene_id "A";\n',
+                'c1\tx\texon\t1\t5\t.\t+\t.\ttranscript_id "A";\n']:
+        g.write_text(bad)
+        assert load_annotation(host, str(g), ["c1"]) == (None, 11)
+    assert load_annotation(host, str(tmp_path / "missing.gtf"), ["c1"]) == (None, 10)
+
+
+def test_bam_decode_round_trip(host, tmp_path):
+    ann = synth.make_annotation(seed=33, contigs=[("chrA", 800_000, 50), ("chrB", 400_000, 25)])
+    batch = synth.make_reads(ann, 3000, seed=34, keep_qnames=True, chimeric_tag_frac=0.02, filter_tag_frac=0.03,
+                             contig_lengths=np.array([800_000, 400_000]))
+    # a record with wide fields and an unplaced mate on another contig
+    path = str(tmp_path / "t.bam")
+    bamio.write_bam(path, [("chrA", 800_000), ("chrB", 400_000)], batch)
+    tags = (C.c_char_p * 1)(b"XF")
+    h = host.host_bam_read_all(path.encode(), b"ch", tags, 1)
+    assert h
+    b = host.host_bam_batch(h).contents
+    assert b.n == batch.n and b.n_cigar_total == len(batch.cigar)
+    core = _arr(b.core, b.n, abi.REC_CORE); aux = _arr(b.aux, b.n, abi.REC_AUX)
+    for f in ("pos", "mpos", "isize", "cigar_off"):
+        np.testing.assert_array_equal(core[f], getattr(batch, f), err_msg=f)
+    for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
+        np.testing.assert_array_equal(aux[f], getattr(batch, f), err_msg=f)
+    np.testing.assert_array_equal(_arr(b.cigar, b.n_cigar_total, np.uint32), batch.cigar)
+    np.testing.assert_array_equal(_arr(b.seg_tid, b.n_seg, np.int32), batch.seg_tid)
+    np.testing.assert_array_equal(_arr(b.seg_start, b.n_seg + 1, np.uint64), batch.seg_start)
+    assert [host.host_bam_contig(h, i).decode() for i in range(host.host_bam_n_contigs(h))] == ["chrA", "chrB"]
+    host.host_bam_free(h)
+    assert not host.host_bam_read_all(str(tmp_path / "nope.bam").encode(), b"ch", tags, 0)
+
+
+def test_library_complexity_matches_the_literal_loop(host, oracle_lib):
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        unique = float(rng.integers(10, 40000))
+        dup = float(rng.integers(1, int(unique)))
+        limit = float(unique + rng.integers(1, 300000))
+        assert host.host_library_complexity(dup, unique, limit) == oracle_lib.library_complexity(dup, unique, limit), (dup, unique, limit)
+    assert host.host_library_complexity(0.0, 1000.0, 1e9) == 0
+    # full-size run of the bracketed search (the literal loop needs ~6 s here)
+    assert host.host_library_complexity(3000.0, 30000.0, 1e9) > 30000
+
+
+def _results_struct(r):
+    """abi.Results (numpy) -> ResultsStruct for the C++ report writer."""
+    keep = []
+    rs = abi.ResultsStruct()
+    rs.n_genes_listed, rs.n_exons = len(r.gene_reads), len(r.exon_reads)
+    for f, dt in [("gene_reads", np.uint64), ("gene_unique", np.uint64), ("gene_fragments", np.uint64), ("exon_reads", np.float64),
+                  ("exon_hit", np.uint8), ("gene_cov_mean", np.float64), ("gene_cov_std", np.float64), ("gene_cov_cv", np.float64),
+                  ("gene_cov_valid", np.uint8), ("exon_cv", np.float64), ("exon_cv_valid", np.uint8), ("bias_three", np.uint64),
+                  ("bias_five", np.uint64), ("fragment_size", np.int64), ("fragment_count", np.uint64)]:
+        a = np.ascontiguousarray(getattr(r, f), dtype=dt)
+        keep.append(a)
+        setattr(rs, f, abi.ptr(a))
+    for i, v in enumerate(r.counters):
+        rs.counters[i] = int(v)
+    rs.read_length = r.read_length
+    rs.n_fragment_sizes = len(r.fragment_size)
+    rs.fragment_samples_remaining = r.fragment_samples_remaining
+    return rs, keep
+
+
+def read_table(path, skip=0):
+    rows = [l.rstrip("\n").split("\t") for l in open(path)]
+    return rows[skip:]
+
+
+def test_report_writer_on_the_quirk_case(host, oracle_lib, tmp_path):
+    ann, batch = cases.quirk_case()
+    gtf = str(tmp_path / "q.gtf")
+    bamio.write_gtf(gtf, ann)
+    h, err = load_annotation(host, gtf, ["chr1", "chr2"])
+    assert err == 0
+    p = abi.default_params()
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    rs, keep = _results_struct(r)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    visit = (C.c_int * 2)(0, 1)
+    assert host.host_write_reports(h, C.byref(rs), out.encode(), b"quirk.bam", 0, 0, 1, 5, None, 0, visit, 2) == 0
+    m = dict(read_table(os.path.join(out, "quirk.bam.metrics.tsv")))
+    c = r.counter_dict()
+    # the rate block must equal the Python restatement that reproduces the reference's golden files
+    for key, val in report_ref.metrics_rates(c):
+        assert m[key] == report_ref.fmt(val), key
+    # the counter block against the REFERENCE's own operator<<(ofstream&, Metrics&) when it is built
+    if oracle_lib.ref_lib() is not None:
+        ref_path = str(tmp_path / "ref_counters.tsv")
+        oracle_lib.ref_metrics_print({k: v for k, v in c.items() if not k.startswith("Filtered by tag")}, ref_path)
+        ref_rows = read_table(ref_path)
+        ours = read_table(os.path.join(out, "quirk.bam.metrics.tsv"))
+        start = [i for i, row in enumerate(ours) if row[0] == "Total Alignments"][0]
+        assert ours[start:start + len(ref_rows)] == ref_rows
+    assert m["Read Length"] == "110" and m["Genes Detected"] == "1" and m["Estimated Library Complexity"] != ""
+    assert m["Median of Avg Transcript Coverage"] == report_ref.fmt(oracle_lib.median(sorted(r.gene_cov_mean[r.gene_cov_valid.astype(bool)])))
+    # GCTs
+    g = read_table(os.path.join(out, "quirk.bam.gene_reads.gct"))
+    assert g[0] == ["#1.2"] and g[1] == ["5", "1"] and g[2] == ["Name", "Description", "Counts"]
+    assert [row[2] for row in g[3:]] == ["6", "1", "1", "1", "3"] and g[3][:2] == ["GA", "AAA"]
+    e = read_table(os.path.join(out, "quirk.bam.exon_reads.gct"))
+    assert e[1] == ["7", "1"] and [row[2] for row in e[3:]] == ["2.500000", "0.500000", "3.000000", "1.000000", "0.000000", "1.000000", "1.000000", "3.000000"]
+    t = read_table(os.path.join(out, "quirk.bam.gene_tpm.gct"))
+    tp = np.array([6 / 1503, 1 / 1302, 1 / 501, 1 / 601, 3 / 2001]) * 1000
+    np.testing.assert_allclose([float(row[2]) for row in t[3:]], tp / (tp.sum() / 1e6), rtol=1e-6)
+    f = read_table(os.path.join(out, "quirk.bam.gene_fragments.gct"))
+    assert [row[2] for row in f[3:]] == ["5", "1", "1", "1", "3"]
+    cov = read_table(os.path.join(out, "quirk.bam.coverage.tsv"))
+    assert cov[0] == ["gene_id", "coverage_mean", "coverage_std", "coverage_CV"]
+    assert [row[0] for row in cov[1:]] == ["GA", "GB", "GR", "GH", "GC"]          # exit order: chr1 by start, then chr2
+    assert cov[3][1:] == ["0", "0", "nan"] and cov[1][1] == report_ref.fmt(196 / 503)
+    cv = read_table(os.path.join(out, "quirk.bam.exon_cv.tsv"))
+    assert cv[0] == ["Exon ID", "Exon CV"] and [row[0] for row in cv[1:]] == ["GA_3", "GC_1"]
+    host.host_annotation_free(h)
+
+
+def test_report_writer_reproduces_single_pair_golden(host, oracle_lib, tmp_path):
+    """Every line of the reference's golden single_pair metrics.tsv that the current code still prints must
+    be reproduced verbatim from the reconstructed input (tests/cases.py)."""
+    import json
+    ka = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))["single_pair"]["metrics"]
+    ann, batch = cases.single_pair_case()
+    gtf = str(tmp_path / "s.gtf")
+    bamio.write_gtf(gtf, ann)
+    h, err = load_annotation(host, gtf, ["1"])
+    r = oracle_lib.run_oracle(abi.default_params(), ann, [batch])
+    rs, keep = _results_struct(r)
+    out = str(tmp_path / "out"); os.makedirs(out)
+    visit = (C.c_int * 1)(0)
+    assert host.host_write_reports(h, C.byref(rs), out.encode(), b"single_pair.bam", 0, 0, 0, 5, None, 0, visit, 1) == 0
+    ours = dict(read_table(os.path.join(out, "single_pair.bam.metrics.tsv")))
+    stale = {"Duplicate Reads"}                      # printed by the version that made the golden, not by src/
+    same = 0
+    for k, v in ka.items():
+        if k in stale:
+            continue
+        assert k in ours, k
+        got = ours[k].replace("-nan", "nan")
+        assert got == v, (k, got, v)
+        same += 1
+    assert same >= 75
+    g = read_table(os.path.join(out, "single_pair.bam.gene_tpm.gct"))
+    assert g[3] == ["ENSG00000227232.4", "WASH7P", "1000000.000000"]
+    e = read_table(os.path.join(out, "single_pair.bam.exon_reads.gct"))
+    assert e[1] == ["1", "1"] and len(e) == 16
+    host.host_annotation_free(h)
