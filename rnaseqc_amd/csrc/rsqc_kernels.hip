@@ -90,7 +90,14 @@ __device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
     return at_end - (sc - v);
 }
 
-// accumulator used only when a record has more contained (block, exon) hits than NSTAGE
+// integer variant: sum of v over the run that starts at this (head) lane
+__device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
+    const uint32_t sc = wave_inclusive_scan_u32(v);
+    const uint32_t at_end = __shfl(sc, r.end - 1, 64);
+    return at_end - (sc - v);
+}
+
+// accumulator used by the general (slow-path) code when it re-walks a CIGAR
 struct DirectAcc {
     double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
     __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[row], frac); }
@@ -202,10 +209,10 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             Record r;
             if (!load_record(b, i, seg, r)) atomicExch(acc.error, RSQC_ERR_ARG);
             else {
-                bool hq;
-                if (gate_cascade(a, p, r, rc, hq, aligned) && !(p.dbg & 8u)) {
+                bool hq; Blocks B;
+                if (gate_cascade(a, p, r, rc, hq, aligned, B) && !(p.dbg & 8u)) {
                     bool overflow = false;
-                    exon_metrics<FAST_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
+                    exon_metrics_fast(a, p, r, B, hq, aligned, fo, overflow);
                     if (overflow) {
                         fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0;
                         const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
@@ -239,11 +246,19 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (hm == 0ull && !(k == 0 && ce_on)) { if (k == 0) continue; else break; }
             const Commit cm = fo.commit[k];
             const bool hv = has && cm.len > 0;
-            if (!(p.dbg & 2u)) {            // exonCounts[row] += len / aligned, one f64 atomic per run
-                const Run run = make_run(hv, cm.row);
-                double sum = run_sum_f64(hv ? (double)cm.len / (double)aligned : 0.0, run);
+            if (!(p.dbg & 2u)) {
+                // exonCounts[row] += len / aligned.  Lanes whose aligned size equals the wave's common value
+                // A0 are merged per run with an INTEGER sum of the block lengths and one division; the few
+                // others (soft-clipped / indel records) add their own fraction.
+                const uint64_t vm_all = __ballot(hv);
+                const uint32_t A0 = vm_all ? __shfl(aligned, __ffsll((unsigned long long)vm_all) - 1, 64) : 1u;
+                if (hv && aligned != A0) atomicAdd(&acc.exon_acc[cm.row], (double)cm.len / (double)aligned);
+                const bool hm2 = hv && aligned == A0;
+                const Run run = make_run(hm2, cm.row);
+                const uint32_t isum = run_sum_u32(hm2 ? cm.len : 0u, run);
+                double sum = (double)isum / (double)A0;
                 if (k == 0) {
-                    const uint64_t vm = __ballot(hv);
+                    const uint64_t vm = __ballot(hm2);
                     if (ce_on) {                                   // previous iteration's tail run
                         const bool joins = (vm & 1ull) && __shfl(cm.row, 0, 64) == ce_key;
                         if (joins) { if (l == 0) sum += ce_sum; }
@@ -370,40 +385,59 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     }
 RSQC_DEFINE_K1(classify_count_kernel, 4)
 RSQC_DEFINE_K1(classify_count_kernel_w3, 3)
+RSQC_DEFINE_K1(classify_count_kernel_w2, 2)
 RSQC_DEFINE_K1(classify_count_kernel_w6, 6)
 RSQC_DEFINE_K1(classify_count_kernel_w8, 8)
 
 // ------------------------------------------------------------------ K1s
 // Records whose block sits fully inside exons of more than FAST_SET genes (pathological
 // annotations).  The gate cascade already counted them; only the feature stage runs here.
-__global__ void classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
+__global__ void __launch_bounds__(64)
+classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     const uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    const int l = lane_id();
     DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        Record r;
-        const uint64_t i = acc.ovf_index[k];
-        if (!load_record(b, i, find_segment(b, i), r)) continue;
-        RecordCounters rc; bool hq; uint32_t aligned;
-        if (!gate_cascade(a, p, r, rc, hq, aligned)) continue;
-        FeatureOut<SLOW_SET> fo;
-        bool overflow = false;
-        exon_metrics<SLOW_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
-        if (overflow) { atomicExch(acc.error, RSQC_ERR_CAPACITY); continue; }
-        for (int j = 0; j < fo.n_commit; ++j) {
-            const Commit cm = fo.commit[j];
-            if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
-            dacc.cov_range(cm.row, cm.off, cm.len);
+    unsigned long long my_cnt = 0ull;                 // lane c accumulates counter c
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
+        const uint32_t k = k0 + threadIdx.x;
+        uint64_t bits = 0;
+        if (k < n) {
+            Record r;
+            const uint64_t i = acc.ovf_index[k];
+            if (load_record(b, i, find_segment(b, i), r)) {
+                RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
+                if (gate_cascade(a, p, r, rc, hq, aligned, B)) {
+                    FeatureOut<SLOW_SET> fo;
+                    bool overflow = false;
+                    exon_metrics<SLOW_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
+                    if (overflow) atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                    else {
+                        for (int j = 0; j < fo.n_commit; ++j) {
+                            const Commit cm = fo.commit[j];
+                            if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
+                            dacc.cov_range(cm.row, cm.off, cm.len);
+                        }
+                        for (int j = 0; j < fo.n_hit; ++j) {
+                            const uint32_t g = fo.hit[j];
+                            atomicAdd(&acc.gene_reads[g], 1ull);
+                            if (!(r.flag & RSQC_FDUP)) atomicAdd(&acc.gene_unique[g], 1ull);
+                            const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
+                            if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = r.qhash; }
+                            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                        }
+                        bits = fo.bits;
+                    }
+                }
+            }
         }
-        for (int j = 0; j < fo.n_hit; ++j) {
-            const uint32_t g = fo.hit[j];
-            atomicAdd(&acc.gene_reads[g], 1ull);
-            if (!(r.flag & RSQC_FDUP)) atomicAdd(&acc.gene_unique[g], 1ull);
-            const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
-            if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = r.qhash; }
-            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+#pragma unroll
+        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {       // the gate cascade was counted by K1; only feature-stage bits here
+            const uint64_t m = __ballot((bits >> c) & 1ull);
+            if (l == c) my_cnt += (unsigned long long)__popcll(m);
         }
-        for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((fo.bits >> c) & 1ull) atomicAdd(&acc.counters[c], 1ull);
     }
+    if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&acc.counters[l], my_cnt);
 }
 
 // ------------------------------------------------------------------ KR
@@ -436,8 +470,8 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                 if (i < b.n) {
                     Record rec;
                     if (load_record(b, i, find_segment(b, (t0 + tl) * 64), rec)) {
-                        RecordCounters rc; bool hq; uint32_t aligned;
-                        gate_cascade(a, p, rec, rc, hq, aligned);
+                        RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
+                        gate_cascade(a, p, rec, rc, hq, aligned, B);
                         elig = rc.rl_eligible != 0; span = rc.rl_span; lq = (uint32_t)rc.rl_lqseq;
                     }
                 }
@@ -864,14 +898,15 @@ gene_coverage_kernel(GeneCovArgs A) {
 // ------------------------------------------------------------------ launch wrappers
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
-    if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    if (variant == 2) hipLaunchKernelGGL(classify_count_kernel_w2, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else if (variant == 6) hipLaunchKernelGGL(classify_count_kernel_w6, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else if (variant == 8) hipLaunchKernelGGL(classify_count_kernel_w8, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else hipLaunchKernelGGL(classify_count_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {
-    hipLaunchKernelGGL(classify_slow_kernel, dim3(64), dim3(64), 0, s, a, p, b, acc);
+    hipLaunchKernelGGL(classify_slow_kernel, dim3(512), dim3(64), 0, s, a, p, b, acc);
 }
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc) {

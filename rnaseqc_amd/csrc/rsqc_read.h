@@ -95,7 +95,13 @@ struct RecordCounters {
 
 #define RSQC_BIT(c) (1ull << (c))
 
-constexpr int FAST_SET = 4;    // genes per block handled on the fast path (registers)
+constexpr int FAST_SET = 2;    // genes per block handled on the fast path (registers)
+constexpr int FAST_BLOCKS = 3; // aligned blocks per record on the fast path; more -> slow path
+constexpr int FAST_HITS = 2;   // exons fully containing one block on the fast path
+
+// the first FAST_BLOCKS aligned blocks of a record (extractBlocks, src/Expression.cpp:26-67)
+struct Blocks { int32_t bs[FAST_BLOCKS]; uint32_t len[FAST_BLOCKS]; uint32_t nb; };
+
 constexpr int SLOW_SET = 32;   // ... on the exact slow path (scratch); more -> RSQC_ERR_CAPACITY
 
 RSQC_HD bool cigar_is_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
@@ -169,7 +175,7 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
 // ---- stage 1: the gate cascade and scalar counters, src/RNASeQC.cpp:254-342,359-360 -----
 // Returns true when the record reaches the feature stage; `hq` = highQuality (:330).
 RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, RecordCounters &out,
-                          bool &hq, uint32_t &aligned) {
+                          bool &hq, uint32_t &aligned, Blocks &B) {
     const uint32_t fl = r.flag;
     uint64_t bits = RSQC_BIT(RSQC_C_TOTAL_ALIGNMENTS);                                     // :245,397
     out.e1_mm = out.e1_bases = out.e2_mm = out.e2_bases = out.mm = out.bases = out.blocks = 0;
@@ -195,12 +201,19 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     // one CIGAR walk: reference length (bam_endpos), aligned size, block count
     uint32_t ref_len = 0, nblocks = 0;
     bool bad = false;
+#pragma unroll
+    for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
     for (uint32_t i = 0; i < r.n_cigar; ++i) {
         const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
         if (op > 8) bad = true;                                     // Expression.cpp:61-63
+        if (cigar_is_block(op)) {
+#pragma unroll
+            for (int k = 0; k < FAST_BLOCKS; ++k) if ((uint32_t)k == nblocks) { B.bs[k] = r.pos + 1 + (int32_t)ref_len; B.len[k] = len; }
+            aligned += len; ++nblocks;
+        }
         if (cigar_is_ref(op)) ref_len += len;
-        if (cigar_is_block(op)) { aligned += len; ++nblocks; }
     }
+    B.nb = nblocks;
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
     const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || ref_len == 0) ? 1u : ref_len);
     out.endpos = endpos;
@@ -250,13 +263,89 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
 #undef RSQC_LEAVE
 }
 
-// ---- stage 2: exonAlignmentMetrics, src/Expression.cpp:308-458 ---------------------------
-// Nothing is scattered from inside: the function returns what to count.  Up to NSTAGE
-// (block, exon) commits are staged in registers while the gene set common to all blocks is
-// being built; only records with more contained hits than that re-walk their CIGAR and go
-// through `acc` directly (exon_add / cov_range).
+// ---- fast path of stage 2 ------------------------------------------------------------------
+// Handles the overwhelmingly common records: <= FAST_BLOCKS blocks, every block inside at most
+// FAST_HITS exons, gene sets of at most FAST_SET genes, at most NSTAGE commits.  Anything else
+// sets `overflow` and is recounted by the general code on the slow path.  The overlap query is
+// loop-free in the common case: the two highest candidate rows of each table are loaded up front
+// (independent loads), a loop only runs when both still reach the block.
+struct BlockHits { uint32_t row[FAST_HITS], gf[FAST_HITS]; int32_t start[FAST_HITS]; int n; bool over; };
+
+RSQC_HD void fast_test_gene(const GeneRow &row, int32_t bs, int32_t be, int rstrand, ClassFlags &f) {
+    if (row.start > be || row.end < bs) return;
+    const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
+    const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
+    if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) return;
+    if (fs == RSQC_STRAND_FORWARD) f.plus = true; else if (fs == RSQC_STRAND_REVERSE) f.minus = true;
+    f.intragenic = true;
+    if (fl & ROWF_RIBOSOMAL) f.ribosomal = true;
+}
+RSQC_HD void fast_test_exon(const ExonRow &row, uint32_t i, int32_t bs, int32_t be, int rstrand, ClassFlags &f, BlockHits &h) {
+    if (row.start > be || row.end < bs) return;
+    const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
+    const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
+    if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) return;
+    if (fs == RSQC_STRAND_FORWARD) f.plus = true; else if (fs == RSQC_STRAND_REVERSE) f.minus = true;
+    f.exonic = true;
+    if (fl & ROWF_RIBOSOMAL) f.ribosomal = true;
+    if (row.start <= bs && row.end >= be - 1) {          // fully contained
+        if (h.n < FAST_HITS) {
+#pragma unroll
+            for (int k = 0; k < FAST_HITS; ++k) if (k == h.n) { h.row[k] = i; h.gf[k] = row.gf; h.start[k] = row.start; }
+            ++h.n;
+        } else h.over = true;
+    }
+}
+
+RSQC_HD void query_block_fast(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be, int rstrand,
+                              ClassFlags &f, BlockHits &h) {
+    h.n = 0; h.over = false;
+    if (ci.n_bins == 0 || be < 0) return;
+    uint32_t b = (uint32_t)be >> a.bin_shift;
+    if (b >= ci.n_bins) b = ci.n_bins - 1;
+    const uint32_t ghi = a.g_binhi[ci.bin_base + b], ehi = a.ex_binhi[ci.bin_base + b];
+    const uint32_t gn = ghi - ci.g_lo, en = ehi - ci.ex_lo;            // candidate rows available
+    GeneRow g0{0, 0, INT32_MIN, 0}, g1{0, 0, INT32_MIN, 0};
+    ExonRow e0{0, 0, INT32_MIN, 0}, e1{0, 0, INT32_MIN, 0};
+    if (gn > 0) g0 = a.g[ghi - 1];
+    if (en > 0) e0 = a.ex[ehi - 1];
+    if (gn > 1) g1 = a.g[ghi - 2];
+    if (en > 1) e1 = a.ex[ehi - 2];
+    if (g0.pmax >= bs) {
+        fast_test_gene(g0, bs, be, rstrand, f);
+        if (g1.pmax >= bs) {
+            fast_test_gene(g1, bs, be, rstrand, f);
+            for (uint32_t i = ghi - 2; i > ci.g_lo;) {
+                --i;
+                const GeneRow row = a.g[i];
+                if (row.pmax < bs) break;
+                fast_test_gene(row, bs, be, rstrand, f);
+            }
+        }
+    }
+    if (e0.pmax >= bs) {
+        fast_test_exon(e0, ehi - 1, bs, be, rstrand, f, h);
+        if (e1.pmax >= bs) {
+            fast_test_exon(e1, ehi - 2, bs, be, rstrand, f, h);
+            for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
+                --i;
+                const ExonRow row = a.ex[i];
+                if (row.pmax < bs) break;
+                fast_test_exon(row, i, bs, be, rstrand, f, h);
+            }
+        }
+    }
+}
+
 struct Commit { uint32_t row, off, len; };
 constexpr int NSTAGE = 3;
+
+template <int K>
+struct FeatureOut {
+    uint64_t bits;              // feature-stage counter bits
+    int n_hit; uint32_t hit[K]; // genes to count: geneCounts++, uniqueGeneCounts, (gene, qname) de-dup
+    int n_commit; Commit commit[NSTAGE];   // exonCounts[row] += len/aligned ; coverage[row][off, off+len) += 1
+};
 
 // small fixed arrays indexed with unrolled compares so that they stay in registers on the GPU
 template <int K> RSQC_HD bool set_contains(const uint32_t (&s)[K], int n, uint32_t v) {
@@ -270,13 +359,116 @@ template <int K> RSQC_HD void set_put(uint32_t (&s)[K], int idx, uint32_t v) {
     for (int k = 0; k < K; ++k) if (k == idx) s[k] = v;
 }
 
-template <int K>
-struct FeatureOut {
-    uint64_t bits;              // feature-stage counter bits
-    int n_hit; uint32_t hit[K]; // genes to count: geneCounts++, uniqueGeneCounts, (gene, qname) de-dup
-    int n_commit; Commit commit[NSTAGE];   // exonCounts[row] += len/aligned ; coverage[row][off, off+len) += 1
-};
+// classification counters of exonAlignmentMetrics, src/Expression.cpp:407-457
+RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq) {
+    uint64_t bits = 0;
+    if (!f.exonic) {
+        if (f.intragenic) {
+            bits |= RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS);
+            if (hq) bits |= RSQC_BIT(RSQC_C_HQ_INTRONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS);
+        } else {
+            bits |= RSQC_BIT(RSQC_C_INTERGENIC_READS);
+            if (hq) bits |= RSQC_BIT(RSQC_C_HQ_INTERGENIC_READS);
+        }
+    } else if (do_exon) {
+        bits |= RSQC_BIT(RSQC_C_EXONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS);
+        if (hq) bits |= RSQC_BIT(RSQC_C_HQ_EXONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS);
+    } else {
+        bits |= RSQC_BIT(RSQC_C_AMBIGUOUS_READS);
+        if (hq) bits |= RSQC_BIT(RSQC_C_HQ_AMBIGUOUS_READS);
+    }
+    if (f.ribosomal) bits |= RSQC_BIT(RSQC_C_RRNA_READS);
+    if ((f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED))) {
+        const bool sense = (fl & RSQC_FREVERSE) ? f.minus : f.plus;
+        if (p.unpaired || (fl & RSQC_FREAD1)) bits |= sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE);
+        else bits |= sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE);
+    }
+    return bits;
+}
 
+RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const Record &r, const Blocks &B, bool hq,
+                               uint32_t aligned, FeatureOut<FAST_SET> &out, bool &overflow) {
+    const uint32_t fl = r.flag;
+    out.bits = 0; out.n_hit = 0; out.n_commit = 0;
+    overflow = B.nb > (uint32_t)FAST_BLOCKS;
+    if (overflow) return;
+    const int rstrand = read_strand_of(p, fl);
+    const ContigInfo ci = a.contig[r.tid];
+    ClassFlags f = {false, false, false, false, false};
+    uint32_t last[FAST_SET] = {0, 0}; int nlast = 0; uint32_t last_globin = 0;
+    Commit st[NSTAGE]; uint32_t st_gene[NSTAGE]; int nst = 0;
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < NSTAGE; ++k) { st[k].row = 0; st[k].off = 0; st[k].len = 0; st_gene[k] = 0; }
+#pragma unroll
+    for (int b = 0; b < FAST_BLOCKS; ++b) {
+        if ((uint32_t)b < B.nb) {
+            const int32_t bs = B.bs[b], be = B.bs[b] + (int32_t)B.len[b];
+            BlockHits h;
+            query_block_fast(a, ci, bs, be, rstrand, f, h);
+            over |= h.over;
+            uint32_t cur[FAST_SET] = {0, 0}; int ncur = 0;
+#pragma unroll
+            for (int e = 0; e < FAST_HITS; ++e) {
+                if (e < h.n) {
+                    const uint32_t g = h.gf[e] & ROW_GENE_MASK;
+                    if (nst < NSTAGE) {
+#pragma unroll
+                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = h.row[e]; st[k].off = (uint32_t)(bs - h.start[e]); st[k].len = B.len[b]; st_gene[k] = g; }
+                        ++nst;
+                    } else over = true;
+                    if (b == 0) {
+                        if (!set_contains<FAST_SET>(last, nlast, g)) {
+                            if (nlast < FAST_SET) { if ((h.gf[e] >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) last_globin |= 1u << nlast; set_put<FAST_SET>(last, nlast, g); ++nlast; }
+                            else over = true;
+                        }
+                    } else if (!set_contains<FAST_SET>(cur, ncur, g)) {
+                        if (ncur < FAST_SET) { set_put<FAST_SET>(cur, ncur, g); ++ncur; } else over = true;
+                    }
+                }
+            }
+            if (b > 0) {                                   // set_intersection, :368-374
+                int w = 0; uint32_t wg = 0;
+#pragma unroll
+                for (int k = 0; k < FAST_SET; ++k) {
+                    if (k < nlast && set_contains<FAST_SET>(cur, ncur, last[k])) {
+                        if ((last_globin >> k) & 1u) wg |= 1u << w;
+                        set_put<FAST_SET>(last, w, last[k]); ++w;
+                    }
+                }
+                nlast = w; last_globin = wg;
+            }
+        }
+    }
+    if (over) { overflow = true; return; }
+    uint64_t bits = 0;
+    if (B.nb >= 1 && last_globin == 0) {                                                   // :363,395-404
+        bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_READS);
+        if (fl & RSQC_FDUP) bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_DUPLICATE_READS);
+    }
+    if (hq && nlast > 0 && !(p.dbg & 4u)) {                                                // :377-392
+#pragma unroll
+        for (int k = 0; k < NSTAGE; ++k) {
+            if (k < nst && set_contains<FAST_SET>(last, nlast, st_gene[k])) {
+#pragma unroll
+                for (int j = 0; j < NSTAGE; ++j) if (j == out.n_commit) out.commit[j] = st[k];
+                ++out.n_commit;
+            }
+        }
+        if (aligned > 0 && !(p.dbg & 2u)) {
+#pragma unroll
+            for (int k = 0; k < FAST_SET; ++k) out.hit[k] = last[k];
+            out.n_hit = nlast;
+        }
+    }
+    out.bits = bits | class_bits(p, fl, f, nlast > 0, hq);
+}
+
+// ---- stage 2: exonAlignmentMetrics, src/Expression.cpp:308-458 ---------------------------
+// Nothing is scattered from inside: the function returns what to count.  Up to NSTAGE
+// (block, exon) commits are staged in registers while the gene set common to all blocks is
+// being built; only records with more contained hits than that re-walk their CIGAR and go
+// through `acc` directly (exon_add / cov_range).
 // `Acc` (used only on the re-walk path) provides
 //   void exon_add(uint32_t row, double frac);                                      Metrics.cpp:59-66
 //   void cov_range(uint32_t row, uint32_t offset, uint32_t len);                   Metrics.cpp:96-124
@@ -387,28 +579,7 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
             out.n_hit = nlast;
         }
     }
-    // classification counters, :407-457
-    if (!f.exonic) {
-        if (f.intragenic) {
-            bits |= RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS);
-            if (hq) bits |= RSQC_BIT(RSQC_C_HQ_INTRONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS);
-        } else {
-            bits |= RSQC_BIT(RSQC_C_INTERGENIC_READS);
-            if (hq) bits |= RSQC_BIT(RSQC_C_HQ_INTERGENIC_READS);
-        }
-    } else if (do_exon) {
-        bits |= RSQC_BIT(RSQC_C_EXONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS);
-        if (hq) bits |= RSQC_BIT(RSQC_C_HQ_EXONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS);
-    } else {
-        bits |= RSQC_BIT(RSQC_C_AMBIGUOUS_READS);
-        if (hq) bits |= RSQC_BIT(RSQC_C_HQ_AMBIGUOUS_READS);
-    }
-    if (f.ribosomal) bits |= RSQC_BIT(RSQC_C_RRNA_READS);
-    if ((f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED))) {
-        const bool sense = (fl & RSQC_FREVERSE) ? f.minus : f.plus;
-        if (p.unpaired || (fl & RSQC_FREAD1)) bits |= sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE);
-        else bits |= sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE);
-    }
+    bits |= class_bits(p, fl, f, do_exon, hq);
     out.bits = bits;
 }
 

@@ -75,14 +75,14 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
             r.l_qseq = b->wide_l_qseq[w]; r.nm = b->wide_nm[w]; r.n_cigar = b->wide_n_cigar[w];
         }
         r.cigar = b->cigar + co.cigar_off; r.qhash = au.qhash;
-        RecordCounters rc2; bool hq; uint32_t aligned;
-        const bool go = gate_cascade(d, dp, r, rc2, hq, aligned);
+        RecordCounters rc2; bool hq; uint32_t aligned; Blocks B;
+        const bool go = gate_cascade(d, dp, r, rc2, hq, aligned, B);
         uint64_t bits = rc2.bits;
         if (rc2.error) return rc2.error;
         if (go) {
             bool over = false;
             FeatureOut<FAST_SET> fo;
-            exon_metrics<FAST_SET>(d, dp, r, hq, aligned, acc, fo, over);
+            exon_metrics_fast(d, dp, r, B, hq, aligned, fo, over);
             if (!over) { bits |= fo.bits; apply(acc, d, fo, r, aligned); }
             else {
                 ++*n_overflow;
