@@ -392,6 +392,20 @@ RSQC_DEFINE_K1(classify_count_kernel_w8, 8)
 // ------------------------------------------------------------------ K1s
 // Records whose block sits fully inside exons of more than FAST_SET genes (pathological
 // annotations).  The gate cascade already counted them; only the feature stage runs here.
+// full in-wave aggregation by key (not only neighbouring lanes): the slow-path list is not in file order
+template <class F>
+__device__ __forceinline__ void wave_by_key(bool valid, uint32_t key, F &&leader) {
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+        const int lead = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(key, lead, 64);
+        const bool mine = valid && key == k0;
+        const uint64_t same = __ballot(mine);
+        leader(lead, k0, mine, same);
+        todo &= ~same;
+    }
+}
+
 __global__ void __launch_bounds__(64)
 classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     const uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
@@ -402,33 +416,81 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
         const uint32_t k = k0 + threadIdx.x;
         uint64_t bits = 0;
+        FeatureOut<MID_SET, SLOW_STAGE> fm;
+        fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
+        uint32_t aligned = 1; bool notdup = false; uint64_t qhash = 0;
         if (k < n) {
             Record r;
             const uint64_t i = acc.ovf_index[k];
             if (load_record(b, i, find_segment(b, i), r)) {
-                RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
+                RecordCounters rc; bool hq; Blocks B;
                 if (gate_cascade(a, p, r, rc, hq, aligned, B)) {
-                    FeatureOut<SLOW_SET> fo;
+                    notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                     bool overflow = false;
-                    exon_metrics<SLOW_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
-                    if (overflow) atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                    else {
-                        for (int j = 0; j < fo.n_commit; ++j) {
-                            const Commit cm = fo.commit[j];
-                            if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
-                            dacc.cov_range(cm.row, cm.off, cm.len);
+                    exon_metrics<MID_SET>(a, p, r, hq, aligned, dacc, fm, overflow);
+                    if (overflow) {                  // rare second tier: up to 32 genes, plain atomics
+                        fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
+                        FeatureOut<SLOW_SET, SLOW_STAGE> fo;
+                        exon_metrics<SLOW_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
+                        if (overflow) atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                        else {
+                            for (int j = 0; j < fo.n_commit; ++j) {
+                                const Commit cm = fo.commit[j];
+                                if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
+                                dacc.cov_range(cm.row, cm.off, cm.len);
+                            }
+                            for (int j = 0; j < fo.n_hit; ++j) {
+                                const uint32_t g = fo.hit[j];
+                                atomicAdd(&acc.gene_reads[g], 1ull);
+                                if (notdup) atomicAdd(&acc.gene_unique[g], 1ull);
+                                const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
+                                if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; }
+                                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                            }
+                            bits = fo.bits;
                         }
-                        for (int j = 0; j < fo.n_hit; ++j) {
-                            const uint32_t g = fo.hit[j];
-                            atomicAdd(&acc.gene_reads[g], 1ull);
-                            if (!(r.flag & RSQC_FDUP)) atomicAdd(&acc.gene_unique[g], 1ull);
-                            const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
-                            if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = r.qhash; }
-                            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                        }
-                        bits = fo.bits;
-                    }
+                    } else bits = fm.bits;
                 }
+            }
+        }
+        // ---- converged: aggregated scatter of the first-tier results -----------------------------------
+#pragma unroll
+        for (int j = 0; j < SLOW_STAGE; ++j) {
+            const bool has = fm.n_commit > j;
+            if (__ballot(has) == 0ull) break;
+            const Commit cm = fm.commit[j];
+            const bool hv = has && cm.len > 0;
+            const double frac = hv ? (double)cm.len / (double)aligned : 0.0;
+            wave_by_key(hv, cm.row, [&](int lead, uint32_t row, bool mine, uint64_t) {
+                const double sum = wave_sum(mine ? frac : 0.0);
+                if (l == lead) atomicAdd(&acc.exon_acc[row], sum);
+            });
+            if (hv) dacc.cov_range(cm.row, cm.off, cm.len);
+        }
+        {
+            const uint64_t nd_mask = __ballot(notdup);
+#pragma unroll
+            for (int j = 0; j < MID_SET; ++j) {
+                const bool has = fm.n_hit > j;
+                const uint64_t m = __ballot(has);
+                if (m == 0ull) break;
+                const uint32_t g = fm.hit[j];
+                const int lead0 = __ffsll((unsigned long long)m) - 1;
+                uint32_t base = 0;
+                if (l == lead0) base = atomicAdd(acc.pair_slow_count, (uint32_t)__popcll(m));
+                base = __shfl(base, lead0, 64);
+                if (has) {
+                    const uint32_t slot = base + mask_rank(m);
+                    if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; }
+                    else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                }
+                wave_by_key(has, g, [&](int lead, uint32_t gg, bool, uint64_t same) {
+                    if (l == lead) {
+                        atomicAdd(&acc.gene_reads[gg], (unsigned long long)__popcll(same));
+                        const uint32_t nd = (uint32_t)__popcll(same & nd_mask);
+                        if (nd) atomicAdd(&acc.gene_unique[gg], (unsigned long long)nd);
+                    }
+                });
             }
         }
 #pragma unroll

@@ -102,7 +102,8 @@ constexpr int FAST_HITS = 2;   // exons fully containing one block on the fast p
 // the first FAST_BLOCKS aligned blocks of a record (extractBlocks, src/Expression.cpp:26-67)
 struct Blocks { int32_t bs[FAST_BLOCKS]; uint32_t len[FAST_BLOCKS]; uint32_t nb; };
 
-constexpr int SLOW_SET = 32;   // ... on the exact slow path (scratch); more -> RSQC_ERR_CAPACITY
+constexpr int MID_SET = 4;     // ... first tier of the slow path (records with many blocks)
+constexpr int SLOW_SET = 32;   // ... second tier (scratch); more -> RSQC_ERR_CAPACITY
 
 RSQC_HD bool cigar_is_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
 RSQC_HD bool cigar_is_block(uint32_t op) { return op == 0 || op == 7 || op == 8; }
@@ -340,11 +341,12 @@ RSQC_HD void query_block_fast(const DevAnnotation &a, const ContigInfo &ci, int3
 struct Commit { uint32_t row, off, len; };
 constexpr int NSTAGE = 3;
 
-template <int K>
+constexpr int SLOW_STAGE = 8;  // staged commits on the slow path (records with many blocks)
+template <int K, int NST = NSTAGE>
 struct FeatureOut {
     uint64_t bits;              // feature-stage counter bits
     int n_hit; uint32_t hit[K]; // genes to count: geneCounts++, uniqueGeneCounts, (gene, qname) de-dup
-    int n_commit; Commit commit[NSTAGE];   // exonCounts[row] += len/aligned ; coverage[row][off, off+len) += 1
+    int n_commit; Commit commit[NST];      // exonCounts[row] += len/aligned ; coverage[row][off, off+len) += 1
 };
 
 // small fixed arrays indexed with unrolled compares so that they stay in registers on the GPU
@@ -475,7 +477,8 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
 // Sets `overflow` (and returns nothing to count) when a block lies inside exons of more than K genes.
 template <int K, class Acc>
 RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Record &r, bool hq,
-                          uint32_t aligned, Acc &acc, FeatureOut<K> &out, bool &overflow) {
+                          uint32_t aligned, Acc &acc, FeatureOut<K, SLOW_STAGE> &out, bool &overflow) {
+    constexpr int NSTAGE = SLOW_STAGE;      // shadows the fast path's capacity inside this function
     const uint32_t fl = r.flag;
     uint64_t bits = 0;
     overflow = false;

@@ -32,8 +32,8 @@ struct Acc {
         (*cov)[ex_cov[row] + off + len] -= 1u;
     }
 };
-template <int K>
-void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K> &fo, const Record &r, uint32_t aligned) {
+template <int K, int NST>
+void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K, NST> &fo, const Record &r, uint32_t aligned) {
     for (int k = 0; k < fo.n_commit; ++k) {
         const Commit &c = fo.commit[k];
         if (c.len > 0) acc.exon_add(c.row, (double)c.len / (double)aligned);
@@ -86,7 +86,7 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
             if (!over) { bits |= fo.bits; apply(acc, d, fo, r, aligned); }
             else {
                 ++*n_overflow;
-                FeatureOut<SLOW_SET> so;
+                FeatureOut<SLOW_SET, SLOW_STAGE> so;
                 exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, acc, so, over);
                 if (over) return RSQC_ERR_CAPACITY;
                 bits |= so.bits; apply(acc, d, so, r, aligned);
