@@ -96,7 +96,7 @@ struct RecordCounters {
 #define RSQC_BIT(c) (1ull << (c))
 
 constexpr int FAST_SET = 2;    // genes per block handled on the fast path (registers)
-constexpr int FAST_BLOCKS = 3; // aligned blocks per record on the fast path; more -> slow path
+constexpr int FAST_BLOCKS = 4; // aligned blocks per record on the fast path; more -> slow path
 constexpr int FAST_HITS = 2;   // exons fully containing one block on the fast path
 
 // the first FAST_BLOCKS aligned blocks of a record (extractBlocks, src/Expression.cpp:26-67)
@@ -339,7 +339,7 @@ RSQC_HD void query_block_fast(const DevAnnotation &a, const ContigInfo &ci, int3
 }
 
 struct Commit { uint32_t row, off, len; };
-constexpr int NSTAGE = 3;
+constexpr int NSTAGE = 4;
 
 constexpr int SLOW_STAGE = 8;  // staged commits on the slow path (records with many blocks)
 template <int K, int NST = NSTAGE>
