@@ -383,8 +383,8 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     int rc;
 #define UPV(dst, vec) if ((rc = upload(c, c->ann_bufs, (vec).data(), (vec).size(), &(dst)))) return rc
 #define UPA(dst, ptr, n) if ((rc = upload(c, c->ann_bufs, (ptr), (size_t)(n), &(dst)))) return rc
-    UPV(d.ex, hx.ex_rows); UPV(d.g, hx.g_rows); UPV(d.contig, hx.contig);
-    UPV(d.ex_binhi, hx.ex_binhi); UPV(d.g_binhi, hx.g_binhi); UPV(d.ex_cov, hx.ex_cov);
+    UPV(d.ex, hx.ex_rows); UPV(d.gb, hx.gb); UPV(d.contig, hx.contig);
+    UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov);
     auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
     auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
     // empty BED until rsqc_set_bed

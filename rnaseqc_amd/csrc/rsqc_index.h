@@ -16,10 +16,10 @@ namespace rsqc {
 struct HostIndex {
     static constexpr int kBinShift = 11;
     int32_t n_ref = 0, n_contigs = 0, n_genes = 0, n_listed = 0, n_exons = 0;
-    std::vector<uint32_t> ex_range, g_range, ex_binhi, g_binhi, ex_cov, gene_cov_off, gene_coding;
+    std::vector<uint32_t> ex_range, g_range, ex_binhi, gb_bin, ex_cov, gene_cov_off, gene_coding;
+    std::vector<GeneBreak> gb;
     std::vector<int32_t> ex_pmax, g_pmax;
     std::vector<ExonRow> ex_rows;
-    std::vector<GeneRow> g_rows;
     std::vector<ContigInfo> contig;
     std::vector<uint8_t> gene_flags, gene_owned;     // by listed gene id
     uint64_t cov_entries = 0;
@@ -52,7 +52,7 @@ struct HostIndex {
         }
         if (G > (int)ROW_GENE_MASK) { err = "more than 2^26 genes"; return RSQC_ERR_CAPACITY; }
         // packed 16-byte rows
-        ex_rows.resize((size_t)E); g_rows.resize((size_t)L);
+        ex_rows.resize((size_t)E);
         for (int i = 0; i < E; ++i) {
             if (a->exon_row_gene[i] >= (uint32_t)G) { err = "exon_row_gene out of range"; return RSQC_ERR_ARG; }
             uint32_t fl = a->exon_row_flags[i] & 0x7u;
@@ -60,37 +60,59 @@ struct HostIndex {
             ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_pmax[(size_t)i],
                                          a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
         }
-        for (int i = 0; i < L; ++i)
-            g_rows[(size_t)i] = GeneRow{a->gene_row_start[i], a->gene_row_end[i], g_pmax[(size_t)i],
-                                        (uint32_t)(a->gene_row_flags[i] & 0x7u) << ROW_FLAG_SHIFT};
-        // per-contig info + bin tables: binhi[b] = first row with start >= (b+1) << shift
-        contig.assign((size_t)nc, ContigInfo{0, 0, 0, 0});
-        auto max_start = [&](const std::vector<uint32_t> &range, const int32_t *start, int k) -> int64_t {
-            return range[(size_t)k + 1] > range[(size_t)k] ? (int64_t)start[range[(size_t)k + 1] - 1] : -1;
-        };
+        // gene breakpoints per contig: sweep over gene starts (+) and ends+1 (-) with per-class counters
+        gb.clear();
+        std::vector<uint32_t> gb_range((size_t)nc + 1, 0);
+        for (int k = 0; k < nc; ++k) {
+            std::vector<std::pair<int64_t, int>> ev;     // (position, +/-(1 + class + 3*ribo))
+            for (uint32_t i = g_range[(size_t)k]; i < g_range[(size_t)k + 1]; ++i) {
+                const int cls = a->gene_row_flags[i] & RSQC_FF_STRAND_MASK, ribo = (a->gene_row_flags[i] & RSQC_FF_RIBOSOMAL) ? 1 : 0;
+                if (cls > 2) { err = "bad strand class"; return RSQC_ERR_ARG; }
+                const int code = 1 + cls + 3 * ribo;
+                ev.emplace_back((int64_t)a->gene_row_start[i], code);
+                ev.emplace_back((int64_t)a->gene_row_end[i] + 1, -code);
+            }
+            std::sort(ev.begin(), ev.end());
+            int cnt[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t e = 0; e < ev.size();) {
+                const int64_t pos = ev[e].first;
+                while (e < ev.size() && ev[e].first == pos) { const int c2 = ev[e].second; if (c2 > 0) cnt[c2 - 1]++; else cnt[-c2 - 1]--; ++e; }
+                uint32_t mask = 0;
+                for (int cls = 0; cls < 3; ++cls) {
+                    if (cnt[cls] + cnt[3 + cls] > 0) mask |= 1u << cls;
+                    if (cnt[3 + cls] > 0) mask |= 1u << (3 + cls);
+                }
+                if (pos > 0x7FFFFFFFll) break;
+                if (gb.size() > gb_range[(size_t)k] && gb.back().mask == mask) continue;   // no change
+                gb.push_back(GeneBreak{(int32_t)pos, mask});
+            }
+            gb_range[(size_t)k + 1] = (uint32_t)gb.size();
+        }
+        // per-contig info + bin tables
+        contig.assign((size_t)nc, ContigInfo{0, 0, 0, 0, 0, 0, 0, 0});
         uint64_t total_bins = 0;
         for (int k = 0; k < nc; ++k) {
-            const int64_t ms = std::max(max_start(ex_range, a->exon_row_start, k), max_start(g_range, a->gene_row_start, k));
+            int64_t ms = -1;
+            if (ex_range[(size_t)k + 1] > ex_range[(size_t)k]) ms = std::max<int64_t>(ms, a->exon_row_start[ex_range[(size_t)k + 1] - 1]);
+            if (gb_range[(size_t)k + 1] > gb_range[(size_t)k]) ms = std::max<int64_t>(ms, gb[gb_range[(size_t)k + 1] - 1].pos);
             const uint64_t nb = ms < 0 ? 0 : (uint64_t)(ms >> kBinShift) + 1;
             if (total_bins + nb > 0xFFFFFFF0ull) { err = "bin table too large"; return RSQC_ERR_CAPACITY; }
-            contig[(size_t)k] = ContigInfo{ex_range[(size_t)k], g_range[(size_t)k], (uint32_t)total_bins, (uint32_t)nb};
+            contig[(size_t)k] = ContigInfo{ex_range[(size_t)k], ex_range[(size_t)k + 1], gb_range[(size_t)k], gb_range[(size_t)k + 1],
+                                           (uint32_t)total_bins, (uint32_t)nb, 0, 0};
             total_bins += nb;
         }
-        auto build_bins = [&](const std::vector<uint32_t> &range, const int32_t *start, std::vector<uint32_t> &bins) {
-            bins.assign((size_t)total_bins + 1, 0);
-            for (int k = 0; k < nc; ++k) {
-                const ContigInfo &ci = contig[(size_t)k];
-                uint32_t row = range[(size_t)k];
-                const uint32_t hi = range[(size_t)k + 1];
-                for (uint32_t b = 0; b < ci.n_bins; ++b) {
-                    const int64_t lim = ((int64_t)b + 1) << kBinShift;
-                    while (row < hi && (int64_t)start[row] < lim) ++row;
-                    bins[(size_t)ci.bin_base + b] = row;
-                }
+        ex_binhi.assign((size_t)total_bins + 1, 0); gb_bin.assign((size_t)total_bins + 1, 0);
+        for (int k = 0; k < nc; ++k) {
+            const ContigInfo &ci = contig[(size_t)k];
+            uint32_t row = ci.ex_lo, bp = ci.gb_lo;
+            for (uint32_t b = 0; b < ci.n_bins; ++b) {
+                const int64_t lim = ((int64_t)b + 1) << kBinShift, lo_pos = (int64_t)b << kBinShift;
+                while (row < ci.ex_hi && (int64_t)a->exon_row_start[row] < lim) ++row;
+                ex_binhi[(size_t)ci.bin_base + b] = row;                 // first exon row with start >= (b+1) << shift
+                while (bp < ci.gb_hi && (int64_t)gb[bp].pos <= lo_pos) ++bp;
+                gb_bin[(size_t)ci.bin_base + b] = bp;                    // first breakpoint with pos > b << shift
             }
-        };
-        build_bins(ex_range, a->exon_row_start, ex_binhi);
-        build_bins(g_range, a->gene_row_start, g_binhi);
+        }
         // per-base coverage layout: exons of a gene contiguous, in exonsForGene order, + 1 pad slot per gene
         ex_cov.assign((size_t)E, 0);
         gene_cov_off.assign((size_t)std::max(L, 1), 0);

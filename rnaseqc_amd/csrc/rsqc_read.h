@@ -32,28 +32,35 @@ struct ExonRow {
     int32_t pmax;            // running max of `end` over the contig's rows up to this one
     uint32_t gf;             // gene id (low 26 bits) | RowFlags << 26
 };
-struct GeneRow {
-    int32_t start, end, pmax;
-    uint32_t gf;             // RowFlags << 26 (gene id bits unused)
+// Gene rows only contribute flags (intragenic, strand, rRNA; src/Expression.cpp:331-333,352-358), so they are
+// stored as BREAKPOINTS: between two consecutive gene boundaries the set of covering genes is constant
+// and so is the union of their flags per strand class.  A block query ORs the masks of the (1-2)
+// elementary intervals it touches -- independent of how deeply genes nest.
+struct GeneBreak {
+    int32_t pos;             // first position of the elementary interval
+    uint32_t mask;           // bit s (s = RSQC_STRAND_*): a gene of strand class s covers it; bit 3+s: ... a ribosomal one
 };
 constexpr uint32_t ROW_GENE_MASK = (1u << 26) - 1u;
 constexpr int ROW_FLAG_SHIFT = 26;     // bits 26-27 strand, 28 ribosomal, 29 the row's gene is a globin
 constexpr uint32_t ROWF_RIBOSOMAL = 4u, ROWF_GLOBIN = 8u;
 
-struct ContigInfo {          // 16 bytes per contig
-    uint32_t ex_lo, g_lo;    // first exon / gene row of the contig
+struct ContigInfo {          // 32 bytes per contig
+    uint32_t ex_lo, ex_hi;   // exon rows of the contig
+    uint32_t gb_lo, gb_hi;   // gene breakpoints of the contig
     uint32_t bin_base;       // first entry of the contig in the two bin tables
-    uint32_t n_bins;         // bins of 2^bin_shift bases covering every row start (0 = no rows)
+    uint32_t n_bins;         // bins of 2^bin_shift bases (0 = contig without features)
+    uint32_t pad0, pad1;
 };
 
 struct DevAnnotation {
     int32_t n_ref, n_contigs, n_genes, n_listed, n_exons;
     int32_t bin_shift;
     const ExonRow *ex;                 // sorted by (contig, start)
-    const GeneRow *g;
+    const GeneBreak *gb;               // sorted by (contig, pos)
     const ContigInfo *contig;          // [n_contigs]
-    // bin tables: first row whose start >= (bin + 1) << bin_shift (rows of later contigs excluded)
-    const uint32_t *ex_binhi, *g_binhi;
+    // bin tables: ex_binhi = first exon row whose start >= (bin + 1) << bin_shift;
+    //             gb_bin   = first breakpoint whose pos > bin << bin_shift
+    const uint32_t *ex_binhi, *gb_bin;
     // per-base coverage: exons of a gene are contiguous (exonsForGene order) and every gene is
     // followed by one pad slot, so a block's -1 at offset+len always lands inside the array and a
     // plain prefix sum over the gene reproduces BaseCoverage's per-exon vectors
@@ -127,6 +134,32 @@ RSQC_HD int read_strand_of(const DevParams &p, uint32_t flag) {
 
 struct ClassFlags { bool intragenic, plus, minus, ribosomal, exonic; };
 
+// union of the gene masks over positions [bs, be] of a contig
+RSQC_HD uint32_t gene_mask(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be) {
+    if (ci.gb_hi == ci.gb_lo || ci.n_bins == 0 || be < 0) return 0u;
+    if (bs < 0) bs = 0;
+    uint32_t b = (uint32_t)bs >> a.bin_shift;
+    if (b >= ci.n_bins) b = ci.n_bins - 1;
+    uint32_t nxt = a.gb_bin[ci.bin_base + b];                // first breakpoint with pos > bin start
+    while (nxt < ci.gb_hi && a.gb[nxt].pos <= bs) ++nxt;     // ... with pos > bs
+    uint32_t mask = nxt > ci.gb_lo ? a.gb[nxt - 1].mask : 0u;
+    while (nxt < ci.gb_hi) {
+        const GeneBreak g = a.gb[nxt];
+        if (g.pos > be) break;
+        mask |= g.mask; ++nxt;
+    }
+    return mask;
+}
+// gene-row part of the feature loop (src/Expression.cpp:331-333,352-358) from a mask
+RSQC_HD void apply_gene_mask(uint32_t mask, int rstrand, ClassFlags &f) {
+    uint32_t present = mask & 7u, ribo = (mask >> 3) & 7u;
+    if (rstrand != RSQC_STRAND_UNKNOWN) { present &= 1u << rstrand; ribo &= 1u << rstrand; }   // :331
+    if (present) f.intragenic = true;
+    if (present & (1u << RSQC_STRAND_FORWARD)) f.plus = true;
+    if (present & (1u << RSQC_STRAND_REVERSE)) f.minus = true;
+    if (ribo) f.ribosomal = true;
+}
+
 // The overlap query of one block [bs, be] (be inclusive: the reference's intersectInterval on a
 // block whose end is exclusive, src/GTF.cpp:171-179, and its scan bound `start <= block.end`,
 // src/Expression.cpp:111).  The bin table gives the last row whose start can be <= be; rows are
@@ -139,22 +172,8 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
     if (ci.n_bins == 0 || be < 0) return;
     uint32_t b = (uint32_t)be >> a.bin_shift;
     if (b >= ci.n_bins) b = ci.n_bins - 1;
-    const uint32_t ghi = f ? a.g_binhi[ci.bin_base + b] : 0u;
     const uint32_t ehi = a.ex_binhi[ci.bin_base + b];
-    if (f) {
-        for (uint32_t i = ghi; i > ci.g_lo;) {
-            --i;
-            const GeneRow row = a.g[i];
-            if (row.pmax < bs) break;
-            if (row.start > be || row.end < bs) continue;
-            const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
-            const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
-            if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) continue;     // Expression.cpp:331
-            if (fs == RSQC_STRAND_FORWARD) f->plus = true; else if (fs == RSQC_STRAND_REVERSE) f->minus = true;
-            f->intragenic = true;                                              // :352-354
-            if (fl & ROWF_RIBOSOMAL) f->ribosomal = true;                      // :358
-        }
-    }
+    if (f) apply_gene_mask(gene_mask(a, ci, bs, be), rstrand, *f);
     for (uint32_t i = ehi; i > ci.ex_lo;) {
         --i;
         const ExonRow row = a.ex[i];
@@ -272,15 +291,6 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
 // (independent loads), a loop only runs when both still reach the block.
 struct BlockHits { uint32_t row[FAST_HITS], gf[FAST_HITS]; int32_t start[FAST_HITS]; int n; bool over; };
 
-RSQC_HD void fast_test_gene(const GeneRow &row, int32_t bs, int32_t be, int rstrand, ClassFlags &f) {
-    if (row.start > be || row.end < bs) return;
-    const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
-    const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
-    if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) return;
-    if (fs == RSQC_STRAND_FORWARD) f.plus = true; else if (fs == RSQC_STRAND_REVERSE) f.minus = true;
-    f.intragenic = true;
-    if (fl & ROWF_RIBOSOMAL) f.ribosomal = true;
-}
 RSQC_HD void fast_test_exon(const ExonRow &row, uint32_t i, int32_t bs, int32_t be, int rstrand, ClassFlags &f, BlockHits &h) {
     if (row.start > be || row.end < bs) return;
     const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
@@ -304,26 +314,12 @@ RSQC_HD void query_block_fast(const DevAnnotation &a, const ContigInfo &ci, int3
     if (ci.n_bins == 0 || be < 0) return;
     uint32_t b = (uint32_t)be >> a.bin_shift;
     if (b >= ci.n_bins) b = ci.n_bins - 1;
-    const uint32_t ghi = a.g_binhi[ci.bin_base + b], ehi = a.ex_binhi[ci.bin_base + b];
-    const uint32_t gn = ghi - ci.g_lo, en = ehi - ci.ex_lo;            // candidate rows available
-    GeneRow g0{0, 0, INT32_MIN, 0}, g1{0, 0, INT32_MIN, 0};
+    const uint32_t ehi = a.ex_binhi[ci.bin_base + b];
+    const uint32_t en = ehi - ci.ex_lo;                                // candidate rows available
     ExonRow e0{0, 0, INT32_MIN, 0}, e1{0, 0, INT32_MIN, 0};
-    if (gn > 0) g0 = a.g[ghi - 1];
     if (en > 0) e0 = a.ex[ehi - 1];
-    if (gn > 1) g1 = a.g[ghi - 2];
     if (en > 1) e1 = a.ex[ehi - 2];
-    if (g0.pmax >= bs) {
-        fast_test_gene(g0, bs, be, rstrand, f);
-        if (g1.pmax >= bs) {
-            fast_test_gene(g1, bs, be, rstrand, f);
-            for (uint32_t i = ghi - 2; i > ci.g_lo;) {
-                --i;
-                const GeneRow row = a.g[i];
-                if (row.pmax < bs) break;
-                fast_test_gene(row, bs, be, rstrand, f);
-            }
-        }
-    }
+    apply_gene_mask(gene_mask(a, ci, bs, be), rstrand, f);
     if (e0.pmax >= bs) {
         fast_test_exon(e0, ehi - 1, bs, be, rstrand, f, h);
         if (e1.pmax >= bs) {

@@ -54,8 +54,8 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     DevAnnotation d{};
     d.n_ref = a->n_ref; d.n_contigs = a->n_contigs; d.n_genes = a->n_genes; d.n_listed = a->n_genes_listed; d.n_exons = a->n_exons;
     d.bin_shift = HostIndex::kBinShift;
-    d.ex = hx.ex_rows.data(); d.g = hx.g_rows.data(); d.contig = hx.contig.data();
-    d.ex_binhi = hx.ex_binhi.data(); d.g_binhi = hx.g_binhi.data(); d.ex_cov = hx.ex_cov.data();
+    d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.contig = hx.contig.data();
+    d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
     DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u};
     std::vector<uint64_t> reads((size_t)a->n_genes, 0), unique((size_t)a->n_genes, 0);
     std::vector<double> exon_rows((size_t)a->n_exons, 0.0);
