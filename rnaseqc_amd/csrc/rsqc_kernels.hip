@@ -406,11 +406,45 @@ __device__ __forceinline__ void wave_by_key(bool valid, uint32_t key, F &&leader
     }
 }
 
-__global__ void __launch_bounds__(64)
+#define RSQC_SLOW_THREADS 256
+#define RSQC_SLOW_SLOTS 1024
+#define RSQC_SLOW_CSLOTS 8192
+__global__ void __launch_bounds__(RSQC_SLOW_THREADS)
 classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
-    const uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    // A single hot address sustains only ~90 M atomics/s on this chip (tools/atomic_bench.hip), and the
+    // slow-path records concentrate on a few genes: exon fractions are summed per workgroup in an LDS
+    // hash (row -> f64) and flushed with one global atomic per distinct row.
+    // Atomics into one cache line serialise at ~5-10 ns each as well, and the coverage slots these records
+    // touch are few (short exons of a few genes): the +1/-1 events go through an LDS hash too.
+    __shared__ uint32_t s_key[RSQC_SLOW_SLOTS];
+    __shared__ double s_val[RSQC_SLOW_SLOTS];
+    __shared__ uint32_t s_ckey[RSQC_SLOW_CSLOTS];
+    __shared__ uint32_t s_cval[RSQC_SLOW_CSLOTS];
+    for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x) { s_key[i] = 0xFFFFFFFFu; s_val[i] = 0.0; }
+    for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x) { s_ckey[i] = 0xFFFFFFFFu; s_cval[i] = 0u; }
+    __syncthreads();
+    uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    if (p.dbg & 64u) n = 0;
     const int l = lane_id();
     DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
+    auto exon_add_lds = [&](uint32_t row, double frac) {
+        uint32_t slot = (row * 2654435761u) >> 22;                      // 10 bits
+        for (int probe = 0; probe < 16; ++probe) {
+            const uint32_t old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, row);
+            if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&s_val[slot], frac); return; }
+            slot = (slot + 1) & (RSQC_SLOW_SLOTS - 1);
+        }
+        atomicAdd(&acc.exon_acc[row], frac);                            // table crowded: straight to memory
+    };
+    auto cov_add_lds = [&](uint32_t idx, uint32_t delta) {
+        uint32_t slot = (idx * 2654435761u) >> 19;                      // 13 bits
+        for (int probe = 0; probe < 16; ++probe) {
+            const uint32_t old = atomicCAS(&s_ckey[slot], 0xFFFFFFFFu, idx);
+            if (old == 0xFFFFFFFFu || old == idx) { atomicAdd(&s_cval[slot], delta); return; }
+            slot = (slot + 1) & (RSQC_SLOW_CSLOTS - 1);
+        }
+        atomicAdd(&acc.cov_diff[idx], delta);
+    };
     unsigned long long my_cnt = 0ull;                 // lane c accumulates counter c
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
@@ -424,7 +458,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
             const uint64_t i = acc.ovf_index[k];
             if (load_record(b, i, find_segment(b, i), r)) {
                 RecordCounters rc; bool hq; Blocks B;
-                if (gate_cascade(a, p, r, rc, hq, aligned, B)) {
+                if (gate_cascade(a, p, r, rc, hq, aligned, B) && !(p.dbg & 16u)) {
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                     bool overflow = false;
                     exon_metrics<MID_SET>(a, p, r, hq, aligned, dacc, fm, overflow);
@@ -453,20 +487,18 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                 }
             }
         }
-        // ---- converged: aggregated scatter of the first-tier results -----------------------------------
-#pragma unroll
-        for (int j = 0; j < SLOW_STAGE; ++j) {
-            const bool has = fm.n_commit > j;
-            if (__ballot(has) == 0ull) break;
+        // ---- scatter of the first-tier results: few records, so exon fractions and coverage go out as
+        //      plain atomics; gene counts and pair slots are aggregated per wave (same-address traffic)
+        if (p.dbg & 32u) { fm.n_commit = 0; fm.n_hit = 0; }
+        for (int j = 0; j < fm.n_commit; ++j) {
             const Commit cm = fm.commit[j];
-            const bool hv = has && cm.len > 0;
-            const double frac = hv ? (double)cm.len / (double)aligned : 0.0;
-            wave_by_key(hv, cm.row, [&](int lead, uint32_t row, bool mine, uint64_t) {
-                const double sum = wave_sum(mine ? frac : 0.0);
-                if (l == lead) atomicAdd(&acc.exon_acc[row], sum);
-            });
-            if (hv) dacc.cov_range(cm.row, cm.off, cm.len);
+            if (cm.len > 0 && !(p.dbg & 128u)) exon_add_lds(cm.row, (double)cm.len / (double)aligned);
+            if (!(p.dbg & 256u) && cm.len > 0) {
+                const uint32_t base = a.ex_cov[cm.row] + cm.off;
+                cov_add_lds(base, 1u); cov_add_lds(base + cm.len, 0xFFFFFFFFu);
+            }
         }
+        if (p.dbg & 512u) fm.n_hit = 0;
         {
             const uint64_t nd_mask = __ballot(notdup);
 #pragma unroll
@@ -500,6 +532,11 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
         }
     }
     if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&acc.counters[l], my_cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x)
+        if (s_key[i] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[s_key[i]], s_val[i]);
+    for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x)
+        if (s_ckey[i] != 0xFFFFFFFFu && s_cval[i] != 0u) atomicAdd(&acc.cov_diff[s_ckey[i]], s_cval[i]);
 }
 
 // ------------------------------------------------------------------ KR
@@ -968,7 +1005,7 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {
-    hipLaunchKernelGGL(classify_slow_kernel, dim3(512), dim3(64), 0, s, a, p, b, acc);
+    hipLaunchKernelGGL(classify_slow_kernel, dim3(64), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
 }
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc) {
