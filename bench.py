@@ -120,6 +120,13 @@ def main():
     tm = e.timing()
 
     if rank == 0:
+        # HBM traffic of K1 per launch comes from separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE and WRITE_SIZE cannot share a pass); tools_pmc.sh stores them in profiles/k1_traffic.json
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tpath) and world == 1 and args.pairs == 5_000_000:
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
         k1_ms = tm["classify_ms"] / max(tm["classify_launches"], 1)
         bytes_per_launch = tm["classify_bytes"] / max(tm["classify_launches"], 1)
         achieved = bytes_per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
@@ -154,7 +161,7 @@ def main():
                        "records_per_gpu": int(batch.n), "contigs": world, "sharding": "by contig",
                        "collective": "RCCL all_reduce(sum) of u64[3G+49] + f64[E] per step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "classify_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": k1_ms},
             "cpu_baseline": cpu,
             "stage_ms": {"classify_k1": k1_ms, "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1)},

@@ -141,8 +141,9 @@ template <class T>
 int upload(rsqc_ctx *c, std::vector<DevBuf> &owner, const T *host, size_t n, const T **out) {
     DevBuf b;
     size_t bytes = n * sizeof(T);
-    HIP_TRY(c, hipMalloc(&b.p, bytes ? bytes : 16));
-    b.bytes = bytes ? bytes : 16;
+    // 32 bytes of slack: kernels load a few entries past the end with unconditional, ignored loads
+    HIP_TRY(c, hipMalloc(&b.p, bytes + 32));
+    b.bytes = bytes + 32;
     if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, c->stream));
     owner.push_back(b);
     *out = (const T *)b.p;
@@ -384,7 +385,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
 #define UPV(dst, vec) if ((rc = upload(c, c->ann_bufs, (vec).data(), (vec).size(), &(dst)))) return rc
 #define UPA(dst, ptr, n) if ((rc = upload(c, c->ann_bufs, (ptr), (size_t)(n), &(dst)))) return rc
     UPV(d.ex, hx.ex_rows); UPV(d.gb, hx.gb); UPV(d.contig, hx.contig);
-    UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov);
+    UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov); UPV(d.ex_pmax, hx.ex_pmax);
     auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
     auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
     // empty BED until rsqc_set_bed

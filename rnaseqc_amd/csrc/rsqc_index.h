@@ -51,15 +51,8 @@ struct HostIndex {
             return RSQC_ERR_ARG;
         }
         if (G > (int)ROW_GENE_MASK) { err = "more than 2^26 genes"; return RSQC_ERR_CAPACITY; }
-        // packed 16-byte rows
-        ex_rows.resize((size_t)E);
-        for (int i = 0; i < E; ++i) {
+        for (int i = 0; i < E; ++i)
             if (a->exon_row_gene[i] >= (uint32_t)G) { err = "exon_row_gene out of range"; return RSQC_ERR_ARG; }
-            uint32_t fl = a->exon_row_flags[i] & 0x7u;
-            if (a->gene_is_globin[a->exon_row_gene[i]]) fl |= ROWF_GLOBIN;
-            ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_pmax[(size_t)i],
-                                         a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
-        }
         // gene breakpoints per contig: sweep over gene starts (+) and ends+1 (-) with per-class counters
         gb.clear();
         std::vector<uint32_t> gb_range((size_t)nc + 1, 0);
@@ -141,6 +134,15 @@ struct HostIndex {
         }
         if ((int)a->gene_exon_off[G] != E) { err = "gene_exon_off[n_genes] != n_exons"; return RSQC_ERR_ARG; }
         cov_entries = run;
+        // packed 16-byte rows (after the coverage layout: a row carries its coverage offset)
+        ex_rows.resize((size_t)E);
+        for (int i = 0; i < E; ++i) {
+            uint32_t fl = a->exon_row_flags[i] & 0x7u;
+            if (a->gene_is_globin[a->exon_row_gene[i]]) fl |= ROWF_GLOBIN;
+            if (ex_pmax[(size_t)i] != a->exon_row_end[i]) fl |= ROWF_PMAX_EXT;
+            ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_cov[(size_t)i],
+                                         a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
+        }
         gene_flags.assign((size_t)std::max(L, 1), 0);
         gene_owned.assign((size_t)std::max(L, 1), 0);
         for (int i = 0; i < L; ++i) {

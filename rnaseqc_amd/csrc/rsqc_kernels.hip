@@ -101,11 +101,10 @@ __device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
 struct DirectAcc {
     double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
     __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[row], frac); }
-    __device__ __forceinline__ void cov_range(uint32_t row, uint32_t off, uint32_t len) {
+    __device__ __forceinline__ void cov_range(uint32_t cidx, uint32_t len) {
         if (len == 0) return;
-        const uint32_t base = ex_cov[row];
-        atomicAdd(&cov_diff[base + off], 1u);
-        atomicAdd(&cov_diff[base + off + len], 0xFFFFFFFFu);      // lands on the next exon / the gene's pad slot
+        atomicAdd(&cov_diff[cidx], 1u);
+        atomicAdd(&cov_diff[cidx + len], 0xFFFFFFFFu);            // lands on the next exon / the gene's pad slot
     }
 };
 
@@ -139,13 +138,51 @@ __device__ __forceinline__ uint32_t find_segment(const DevBatch &b, uint64_t i) 
 
 // ------------------------------------------------------------------ K1
 // grid-stride over tiles of RSQC_K1_THREADS records; one record per lane per iteration.
+// Workgroup-local accumulators.  A workgroup streams a short genomic window (a few thousand
+// coordinate-sorted records), so it touches a handful of neighbouring exon rows and genes: direct-mapped
+// LDS tables indexed by the low bits of the row / gene id take every update, and each distinct key
+// costs ONE global atomic when the workgroup retires.  (A single hot address sustains only ~90 M global
+// atomics/s on this chip -- tools/atomic_bench.hip.)  A key that finds its slot taken by another key
+// probes a few neighbours and otherwise falls through to memory.
+constexpr int K1_ESLOTS = 512, K1_GSLOTS = 256;
+struct K1Shared {
+    unsigned long long cnt[RSQC_N_COUNTERS];
+    double eval[K1_ESLOTS];
+    uint32_t ekey[K1_ESLOTS];
+    uint32_t gkey[K1_GSLOTS], gcnt[K1_GSLOTS], gnd[K1_GSLOTS];
+    uint32_t rl[3];
+    uint32_t pairs;
+    __device__ __forceinline__ void exon_add(const DevAccum &acc, uint32_t row, double frac) {
+        uint32_t slot = row & (K1_ESLOTS - 1);
+#pragma unroll 1
+        for (int probe = 0; probe < 4; ++probe) {
+            const uint32_t old = atomicCAS(&ekey[slot], 0xFFFFFFFFu, row);
+            if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&eval[slot], frac); return; }
+            slot = (slot + 1) & (K1_ESLOTS - 1);
+        }
+        atomicAdd(&acc.exon_acc[row], frac);
+    }
+    __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, bool notdup) {
+        uint32_t slot = g & (K1_GSLOTS - 1);
+#pragma unroll 1
+        for (int probe = 0; probe < 4; ++probe) {
+            const uint32_t old = atomicCAS(&gkey[slot], 0xFFFFFFFFu, g);
+            if (old == 0xFFFFFFFFu || old == g) { atomicAdd(&gcnt[slot], 1u); if (notdup) atomicAdd(&gnd[slot], 1u); return; }
+            slot = (slot + 1) & (K1_GSLOTS - 1);
+        }
+        atomicAdd(&acc.gene_reads[g], 1ull);
+        if (notdup) atomicAdd(&acc.gene_unique[g], 1ull);
+    }
+};
+
 __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                                                    const DevAccum &acc, unsigned long long *s_cnt, uint32_t *s_rl,
-                                                    uint32_t *s_pairs) {
+                                                    const DevAccum &acc, K1Shared &S) {
     const int l = lane_id();
-    const int wave = (int)(threadIdx.x >> 6);
-    for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) s_cnt[c] = 0ull;
-    if (threadIdx.x == 0) { s_rl[0] = 0u; s_rl[1] = 0xFFFFFFFFu; s_rl[2] = 0u; *s_pairs = 0u; }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) S.cnt[c] = 0ull;
+    for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x) { S.ekey[c] = 0xFFFFFFFFu; S.eval[c] = 0.0; }
+    for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x) { S.gkey[c] = 0xFFFFFFFFu; S.gcnt[c] = 0u; S.gnd[c] = 0u; }
+    if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; S.pairs = 0u; }
     __syncthreads();
 
     // Scalar counters are kept "vertically": plane j holds bit j of this lane's running count of
@@ -179,7 +216,6 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         pending = 0;
     };
 
-    DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
     // Every WAVE streams its own contiguous range of records (input is coordinate-sorted), so
     // consecutive iterations keep hitting the same gene / exon and the trailing run of an
     // iteration can stay in registers until the key changes.
@@ -192,13 +228,40 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
     uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
+    // contig of the tile: wave-uniform (scalar loads), refreshed when the stream crosses a segment
     uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
-    uint32_t cg_key = 0, cg_cnt = 0, cg_nd = 0; bool cg_on = false;      // carried gene run (wave-uniform)
-    uint32_t ce_key = 0; double ce_sum = 0.0; bool ce_on = false;        // carried exon run
+    int32_t u_tid = -1;
+    ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_contig = [&]() {
+        u_tid = b.n_seg ? b.seg_tid[seg] : -1;
+        if (u_tid >= 0 && u_tid < a.n_contigs) u_ci = a.contig[u_tid];
+        else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    load_contig();
+    // Record words are staged one tile ahead (core words two tiles ahead, because the CIGAR address
+    // comes from them): the loads of tile t+1 are issued after the last dependent load of tile t and
+    // land while tile t is being scattered, so the HBM-cold round trips leave the critical chain.
+    const int4 zero4 = {0, 0, 0, 0};
+    int4 cur_cv = zero4, cur_av = zero4, nx_cv = zero4;
+    uint32_t cur_cg[4] = {0, 0, 0, 0};
+    if (wbeg + (uint64_t)l < wend) {
+        cur_cv = *reinterpret_cast<const int4 *>(&b.core[wbeg + (uint64_t)l]);
+        cur_av = *reinterpret_cast<const int4 *>(&b.aux[wbeg + (uint64_t)l]);
+    }
+    if (wbeg + 64ull + (uint64_t)l < wend) nx_cv = *reinterpret_cast<const int4 *>(&b.core[wbeg + 64ull + (uint64_t)l]);
+    {
+        const uint32_t *cg = b.cigar + (uint32_t)cur_cv.w;               // buffers carry 32 bytes of slack
+        cur_cg[0] = cg[0]; cur_cg[1] = cg[1]; cur_cg[2] = cg[2]; cur_cg[3] = cg[3];
+    }
     for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
-        while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;
+        {
+            bool moved = false;
+            while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) { ++seg; moved = true; }
+            if (moved) load_contig();
+        }
+        const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
         RecordCounters rc;
         rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
         rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
@@ -207,12 +270,30 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
         if (valid) {
             Record r;
-            if (!load_record(b, i, seg, r)) atomicExch(acc.error, RSQC_ERR_ARG);
+            const int4 cv = cur_cv, av = cur_av;
+            r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
+            r.cigar = b.cigar + (uint32_t)cv.w;
+            r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+            r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
+            r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
+            r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
+            bool ok = true;
+            if (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE) {
+                uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
+                while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
+                if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
+                else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
+            }
+            r.tid = u_tid;
+            if (mixed) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
+            if (!ok) atomicExch(acc.error, RSQC_ERR_ARG);
             else {
-                bool hq; Blocks B;
-                if (gate_cascade(a, p, r, rc, hq, aligned, B) && !(p.dbg & 8u)) {
-                    bool overflow = false;
-                    exon_metrics_fast(a, p, r, B, hq, aligned, fo, overflow);
+                bool hq; Blocks B; CigarWalk cw;
+                walk_cigar(r, cur_cg, cw, B);
+                aligned = cw.aligned;
+                if (gate_cascade(a, p, r, cw, rc, hq) && !(p.dbg & 8u)) {
+                    bool overflow = r.tid != u_tid;          // stragglers of a boundary tile: general code
+                    if (!overflow) exon_metrics_fast(a, p, u_ci, r.flag, B, hq, aligned, fo, overflow);
                     if (overflow) {
                         fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0;
                         const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
@@ -228,9 +309,9 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                             if (slot < acc.frag.cap) {
                                 acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
                                 acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
-                                const bool ok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
+                                const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
                                 const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
-                                acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (ok ? 0x80000000u : 0u);
+                                acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
                             } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                         }
                     }
@@ -238,91 +319,57 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 if (rc.error) atomicExch(acc.error, rc.error);
             }
         }
-        // ---- converged: run-merged scatter ---------------------------------------------------
+        // ---- stage the next tile (see above) ------------------------------------------------
+        {
+            const uint64_t i1 = i + 64ull, i2 = i + 128ull;
+            const int4 t_cv = nx_cv;
+            int4 t_av = zero4;
+            if (i1 < wend) t_av = *reinterpret_cast<const int4 *>(&b.aux[i1]);
+            const uint32_t *cg = b.cigar + (uint32_t)t_cv.w;
+            cur_cg[0] = cg[0]; cur_cg[1] = cg[1]; cur_cg[2] = cg[2]; cur_cg[3] = cg[3];
+            nx_cv = zero4;
+            if (i2 < wend) nx_cv = *reinterpret_cast<const int4 *>(&b.core[i2]);
+            cur_cv = t_cv; cur_av = t_av;
+        }
+        // ---- scatter -----------------------------------------------------------------------------
+        // exonCounts[row] += len / aligned and the per-gene counters go to the workgroup's LDS tables
+        // (no wave-wide merging, no carried state); per-base coverage goes to memory as a difference
+        // array, identical neighbouring slots merged into one atomic.
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k) {
             const bool has = fo.n_commit > k;
             const uint64_t hm = __ballot(has);
-            if (hm == 0ull && !(k == 0 && ce_on)) { if (k == 0) continue; else break; }
+            if (hm == 0ull) break;
             const Commit cm = fo.commit[k];
             const bool hv = has && cm.len > 0;
-            if (!(p.dbg & 2u)) {
-                // exonCounts[row] += len / aligned.  Lanes whose aligned size equals the wave's common value
-                // A0 are merged per run with an INTEGER sum of the block lengths and one division; the few
-                // others (soft-clipped / indel records) add their own fraction.
-                const uint64_t vm_all = __ballot(hv);
-                const uint32_t A0 = vm_all ? __shfl(aligned, __ffsll((unsigned long long)vm_all) - 1, 64) : 1u;
-                if (hv && aligned != A0) atomicAdd(&acc.exon_acc[cm.row], (double)cm.len / (double)aligned);
-                const bool hm2 = hv && aligned == A0;
-                const Run run = make_run(hm2, cm.row);
-                const uint32_t isum = run_sum_u32(hm2 ? cm.len : 0u, run);
-                double sum = (double)isum / (double)A0;
-                if (k == 0) {
-                    const uint64_t vm = __ballot(hm2);
-                    if (ce_on) {                                   // previous iteration's tail run
-                        const bool joins = (vm & 1ull) && __shfl(cm.row, 0, 64) == ce_key;
-                        if (joins) { if (l == 0) sum += ce_sum; }
-                        else if (l == 0) atomicAdd(&acc.exon_acc[ce_key], ce_sum);
-                        ce_on = false;
-                    }
-                    const uint64_t heads = __ballot(run.head);
-                    const int tail = (vm >> 63) ? 63 - __clzll((unsigned long long)heads) : -1;
-                    if (run.head && l != tail) atomicAdd(&acc.exon_acc[cm.row], sum);
-                    if (tail >= 0) { ce_key = __shfl(cm.row, tail, 64); ce_sum = __shfl(sum, tail, 64); ce_on = true; }
-                } else if (run.head) atomicAdd(&acc.exon_acc[cm.row], sum);
-            }
-            if (!(p.dbg & 1u) && hm) {      // per-base coverage as a difference array: +1 at the block start ...
-                const uint32_t base = hv ? a.ex_cov[cm.row] + cm.off : 0u;
+            if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, cm.row, (double)cm.len / (double)aligned);
+            if (!(p.dbg & 1u)) {                 // +1 at the block start, -1 after its last base
+                const uint32_t base = hv ? cm.cidx : 0u;
                 const Run up = make_run(hv, base);
                 if (up.head) atomicAdd(&acc.cov_diff[base], up.count);
-                const Run dn = make_run(hv, base + cm.len);          // ... -1 after its last base
+                const Run dn = make_run(hv, base + cm.len);
                 if (dn.head) atomicAdd(&acc.cov_diff[base + cm.len], 0u - dn.count);
             }
         }
-        {
-            const uint64_t nd_mask = __ballot(notdup);
 #pragma unroll
-            for (int k = 0; k < FAST_SET; ++k) {
-                const bool has = fo.n_hit > k;
-                const uint64_t m = __ballot(has);
-                if (m == 0ull && !(k == 0 && cg_on)) { if (k == 0) continue; else break; }
-                const uint32_t g = fo.hit[k];
-                if (m) {
-                    // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
-                    const int lead = __ffsll((unsigned long long)m) - 1;
-                    uint32_t base = 0;
-                    if (l == lead) base = atomicAdd(s_pairs, (uint32_t)__popcll(m));
-                    base = __shfl(base, lead, 64);
-                    if (has) {
-                        const uint32_t slot = base + mask_rank(m);
-                        if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
-                        else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                    }
-                }
-                const Run run = make_run(has, g);
-                uint32_t cnt = run.count, nd = (uint32_t)__popcll(run.mask & nd_mask);
-                if (k == 0) {
-                    if (cg_on) {
-                        const bool joins = (m & 1ull) && __shfl(g, 0, 64) == cg_key;
-                        if (joins) { if (l == 0) { cnt += cg_cnt; nd += cg_nd; } }
-                        else if (l == 0) {
-                            atomicAdd(&acc.gene_reads[cg_key], (unsigned long long)cg_cnt);
-                            if (cg_nd) atomicAdd(&acc.gene_unique[cg_key], (unsigned long long)cg_nd);
-                        }
-                        cg_on = false;
-                    }
-                    const uint64_t heads = __ballot(run.head);
-                    const int tail = (m >> 63) ? 63 - __clzll((unsigned long long)heads) : -1;
-                    if (run.head && l != tail) {
-                        atomicAdd(&acc.gene_reads[g], (unsigned long long)cnt);
-                        if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd);
-                    }
-                    if (tail >= 0) { cg_key = __shfl(g, tail, 64); cg_cnt = __shfl(cnt, tail, 64); cg_nd = __shfl(nd, tail, 64); cg_on = true; }
-                } else if (run.head) {
-                    atomicAdd(&acc.gene_reads[g], (unsigned long long)cnt);
-                    if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd);
+        for (int k = 0; k < FAST_SET; ++k) {
+            const bool has = fo.n_hit > k;
+            const uint64_t m = __ballot(has);
+            if (m == 0ull) break;
+            const uint32_t g = fo.hit[k];
+            if (!(p.dbg & 2048u)) {
+                // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
+                const int lead = __ffsll((unsigned long long)m) - 1;
+                uint32_t base = 0;
+                if (l == lead) base = atomicAdd(&S.pairs, (uint32_t)__popcll(m));
+                base = __shfl(base, lead, 64);
+                if (has) {
+                    const uint32_t slot = base + mask_rank(m);
+                    if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
+                    else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                 }
             }
+            if (has && !(p.dbg & 4096u)) S.gene_add(acc, g, notdup);
         }
         // ---- scalar counters: vertical add of the record's one-bit increments -----------------
         {
@@ -351,25 +398,25 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             }
         }
     }
-    if (l == 0) {                                        // carried runs that never met a different key
-        if (ce_on) atomicAdd(&acc.exon_acc[ce_key], ce_sum);
-        if (cg_on) {
-            atomicAdd(&acc.gene_reads[cg_key], (unsigned long long)cg_cnt);
-            if (cg_nd) atomicAdd(&acc.gene_unique[cg_key], (unsigned long long)cg_nd);
-        }
-    }
     flush_counts();
-    if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&s_cnt[l], my_cnt);
+    if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&S.cnt[l], my_cnt);
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
-        if (l == 0) { atomicMax(&s_rl[0], ws); atomicMin(&s_rl[1], wmn); atomicMax(&s_rl[2], wmx); }
+        if (l == 0) { atomicMax(&S.rl[0], ws); atomicMin(&S.rl[1], wmn); atomicMax(&S.rl[2], wmx); }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x)
-        if (s_cnt[c]) atomicAdd(&acc.counters[c], s_cnt[c]);
+        if (S.cnt[c]) atomicAdd(&acc.counters[c], S.cnt[c]);
+    for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x)
+        if (S.ekey[c] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[S.ekey[c]], S.eval[c]);
+    for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x)
+        if (S.gkey[c] != 0xFFFFFFFFu) {
+            atomicAdd(&acc.gene_reads[S.gkey[c]], (unsigned long long)S.gcnt[c]);
+            if (S.gnd[c]) atomicAdd(&acc.gene_unique[S.gkey[c]], (unsigned long long)S.gnd[c]);
+        }
     if (threadIdx.x == 0) {
-        atomicMax(&acc.rl_stats[0], s_rl[0]); atomicMin(&acc.rl_stats[1], s_rl[1]); atomicMax(&acc.rl_stats[2], s_rl[2]);
-        acc.pair_chunk_count[blockIdx.x] = *s_pairs < chunk_cap ? *s_pairs : chunk_cap;
+        atomicMax(&acc.rl_stats[0], S.rl[0]); atomicMin(&acc.rl_stats[1], S.rl[1]); atomicMax(&acc.rl_stats[2], S.rl[2]);
+        acc.pair_chunk_count[blockIdx.x] = S.pairs < chunk_cap ? S.pairs : chunk_cap;
     }
 }
 
@@ -378,10 +425,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #define RSQC_DEFINE_K1(NAME, MINW)                                                              \
     __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
     NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
-        __shared__ unsigned long long s_cnt[RSQC_N_COUNTERS];                                   \
-        __shared__ uint32_t s_rl[3];                                                            \
-        __shared__ uint32_t s_pairs;                                                            \
-        classify_count_body(a, p, b, acc, s_cnt, s_rl, &s_pairs);                               \
+        __shared__ K1Shared S;                                                                  \
+        classify_count_body(a, p, b, acc, S);                                                   \
     }
 RSQC_DEFINE_K1(classify_count_kernel, 4)
 RSQC_DEFINE_K1(classify_count_kernel_w3, 3)
@@ -471,7 +516,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                             for (int j = 0; j < fo.n_commit; ++j) {
                                 const Commit cm = fo.commit[j];
                                 if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
-                                dacc.cov_range(cm.row, cm.off, cm.len);
+                                dacc.cov_range(cm.cidx, cm.len);
                             }
                             for (int j = 0; j < fo.n_hit; ++j) {
                                 const uint32_t g = fo.hit[j];
@@ -494,7 +539,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
             const Commit cm = fm.commit[j];
             if (cm.len > 0 && !(p.dbg & 128u)) exon_add_lds(cm.row, (double)cm.len / (double)aligned);
             if (!(p.dbg & 256u) && cm.len > 0) {
-                const uint32_t base = a.ex_cov[cm.row] + cm.off;
+                const uint32_t base = cm.cidx;
                 cov_add_lds(base, 1u); cov_add_lds(base + cm.len, 0xFFFFFFFFu);
             }
         }

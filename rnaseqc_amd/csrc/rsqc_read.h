@@ -29,9 +29,12 @@ namespace rsqc {
 // One 16-byte row per interval so that a candidate costs one vector load.
 struct ExonRow {
     int32_t start, end;      // 1-based closed
-    int32_t pmax;            // running max of `end` over the contig's rows up to this one
+    uint32_t cov;            // index of the exon's first base in the per-base coverage array
     uint32_t gf;             // gene id (low 26 bits) | RowFlags << 26
 };
+// The running max of `end` over the contig's rows up to row i (what bounds the downward walk of a
+// query) lives in a separate column, DevAnnotation::ex_pmax: for most rows it equals the row's own
+// end, and ROWF_PMAX_EXT in `gf` says when it does not, so the common case never loads it.
 // Gene rows only contribute flags (intragenic, strand, rRNA; src/Expression.cpp:331-333,352-358), so they are
 // stored as BREAKPOINTS: between two consecutive gene boundaries the set of covering genes is constant
 // and so is the union of their flags per strand class.  A block query ORs the masks of the (1-2)
@@ -41,8 +44,8 @@ struct GeneBreak {
     uint32_t mask;           // bit s (s = RSQC_STRAND_*): a gene of strand class s covers it; bit 3+s: ... a ribosomal one
 };
 constexpr uint32_t ROW_GENE_MASK = (1u << 26) - 1u;
-constexpr int ROW_FLAG_SHIFT = 26;     // bits 26-27 strand, 28 ribosomal, 29 the row's gene is a globin
-constexpr uint32_t ROWF_RIBOSOMAL = 4u, ROWF_GLOBIN = 8u;
+constexpr int ROW_FLAG_SHIFT = 26;     // bits 26-27 strand, 28 ribosomal, 29 the row's gene is a globin, 30 pmax > end
+constexpr uint32_t ROWF_RIBOSOMAL = 4u, ROWF_GLOBIN = 8u, ROWF_PMAX_EXT = 16u;
 
 struct ContigInfo {          // 32 bytes per contig
     uint32_t ex_lo, ex_hi;   // exon rows of the contig
@@ -56,6 +59,7 @@ struct DevAnnotation {
     int32_t n_ref, n_contigs, n_genes, n_listed, n_exons;
     int32_t bin_shift;
     const ExonRow *ex;                 // sorted by (contig, start)
+    const int32_t *ex_pmax;            // running max of end, per row (see ExonRow)
     const GeneBreak *gb;               // sorted by (contig, pos)
     const ContigInfo *contig;          // [n_contigs]
     // bin tables: ex_binhi = first exon row whose start >= (bin + 1) << bin_shift;
@@ -64,7 +68,7 @@ struct DevAnnotation {
     // per-base coverage: exons of a gene are contiguous (exonsForGene order) and every gene is
     // followed by one pad slot, so a block's -1 at offset+len always lands inside the array and a
     // plain prefix sum over the gene reproduces BaseCoverage's per-exon vectors
-    const uint32_t *ex_cov;            // offset of an exon row's first base
+    const uint32_t *ex_cov;            // offset of an exon row's first base (== ExonRow::cov; used by the end-of-file stage)
     // BED rows (sorted by contig,start), optional
     const int32_t  *bed_start, *bed_end, *bed_pmax;
     const uint32_t *bed_range;         // [n_contigs+1]
@@ -177,7 +181,7 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
     for (uint32_t i = ehi; i > ci.ex_lo;) {
         --i;
         const ExonRow row = a.ex[i];
-        if (row.pmax < bs) break;
+        if (a.ex_pmax[i] < bs) break;
         if (row.start > be || row.end < bs) continue;
         const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
         const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
@@ -192,15 +196,40 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
     }
 }
 
+// ---- CIGAR walk: extractBlocks (src/Expression.cpp:26-67) and bam_endpos in one pass ----
+struct CigarWalk { uint32_t ref_len, nblocks, aligned; bool bad; };
+RSQC_HD void cigar_op(uint32_t c, int32_t pos, CigarWalk &w, Blocks &B) {
+    const uint32_t op = c & 0xf, len = c >> 4;
+    if (op > 8) w.bad = true;                                       // Expression.cpp:61-63
+    if (cigar_is_block(op)) {
+#pragma unroll
+        for (int k = 0; k < FAST_BLOCKS; ++k) if ((uint32_t)k == w.nblocks) { B.bs[k] = pos + 1 + (int32_t)w.ref_len; B.len[k] = len; }
+        w.aligned += len; ++w.nblocks;
+    }
+    if (cigar_is_ref(op)) w.ref_len += len;
+}
+// `first` holds the record's first 4 CIGAR words, loaded by the caller in one go (words past
+// n_cigar are ignored); longer CIGARs continue from memory.
+RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &w, Blocks &B) {
+    w.ref_len = 0; w.nblocks = 0; w.aligned = 0; w.bad = false;
+#pragma unroll
+    for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((uint32_t)k < r.n_cigar) cigar_op(first[k], r.pos, w, B);
+    for (uint32_t i = 4; i < r.n_cigar; ++i) cigar_op(r.cigar[i], r.pos, w, B);
+    B.nb = w.nblocks;
+}
+
 // ---- stage 1: the gate cascade and scalar counters, src/RNASeQC.cpp:254-342,359-360 -----
-// Returns true when the record reaches the feature stage; `hq` = highQuality (:330).
-RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, RecordCounters &out,
-                          bool &hq, uint32_t &aligned, Blocks &B) {
+// Pure register arithmetic on the record and its CIGAR summary.  Returns true when the record
+// reaches the feature stage; `hq` = highQuality (:330).
+RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
+                          RecordCounters &out, bool &hq) {
     const uint32_t fl = r.flag;
     uint64_t bits = RSQC_BIT(RSQC_C_TOTAL_ALIGNMENTS);                                     // :245,397
     out.e1_mm = out.e1_bases = out.e2_mm = out.e2_bases = out.mm = out.bases = out.blocks = 0;
     out.rl_eligible = 0; out.rl_span = 0; out.rl_lqseq = 0; out.error = 0; out.frag_candidate = 0; out.endpos = 0;
-    hq = false; aligned = 0;
+    hq = false;
 #define RSQC_LEAVE() do { out.bits = bits; return false; } while (0)
     if (fl & RSQC_FSECONDARY) bits |= RSQC_BIT(RSQC_C_ALTERNATIVE_ALIGNMENTS);             // :254
     if (fl & RSQC_FSUPP) bits |= RSQC_BIT(RSQC_C_SUPPLEMENTARY_ALIGNMENTS);                // :255
@@ -217,25 +246,8 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     if (fl & RSQC_FUNMAP) RSQC_LEAVE();                                                    // :268
     bits |= RSQC_BIT(RSQC_C_MAPPED_READS);
     bits |= (fl & RSQC_FDUP) ? RSQC_BIT(RSQC_C_MAPPED_DUPLICATE_READS) : RSQC_BIT(RSQC_C_MAPPED_UNIQUE_READS);
-
-    // one CIGAR walk: reference length (bam_endpos), aligned size, block count
-    uint32_t ref_len = 0, nblocks = 0;
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
-    for (uint32_t i = 0; i < r.n_cigar; ++i) {
-        const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
-        if (op > 8) bad = true;                                     // Expression.cpp:61-63
-        if (cigar_is_block(op)) {
-#pragma unroll
-            for (int k = 0; k < FAST_BLOCKS; ++k) if ((uint32_t)k == nblocks) { B.bs[k] = r.pos + 1 + (int32_t)ref_len; B.len[k] = len; }
-            aligned += len; ++nblocks;
-        }
-        if (cigar_is_ref(op)) ref_len += len;
-    }
-    B.nb = nblocks;
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
-    const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || ref_len == 0) ? 1u : ref_len);
+    const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || w.ref_len == 0) ? 1u : w.ref_len);
     out.endpos = endpos;
     out.rl_eligible = 1; out.rl_span = (uint32_t)(endpos - r.pos); out.rl_lqseq = r.l_qseq;   // :275-278
     if (has_ch) {                                                                          // :279-283
@@ -275,21 +287,39 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     if (r.tid < 0 || r.tid >= a.n_ref) RSQC_LEAVE();                                       // :333-337
     bits |= hq ? RSQC_BIT(RSQC_C_HIGH_QUALITY_READS) : RSQC_BIT(RSQC_C_LOW_QUALITY_READS);
     bits |= RSQC_BIT(RSQC_C_READS_USED);
-    if (bad) { out.error = RSQC_ERR_BAD_CIGAR; RSQC_LEAVE(); }
-    out.blocks = nblocks;                                                                  // :360
+    if (w.bad) { out.error = RSQC_ERR_BAD_CIGAR; RSQC_LEAVE(); }
+    out.blocks = w.nblocks;                                                                // :360
     out.frag_candidate = (hq && (fl & RSQC_FPAIRED)) ? 1u : 0u;                            // :372
     out.bits = bits;
     return true;
 #undef RSQC_LEAVE
 }
+// convenience form for callers that did not stage the CIGAR words themselves
+RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, RecordCounters &out,
+                          bool &hq, uint32_t &aligned, Blocks &B) {
+    uint32_t first[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 4 && k < r.n_cigar; ++k) first[k] = r.cigar[k];
+    CigarWalk w;
+    walk_cigar(r, first, w, B);
+    aligned = w.aligned;
+    return gate_cascade(a, p, r, w, out, hq);
+}
 
 // ---- fast path of stage 2 ------------------------------------------------------------------
 // Handles the overwhelmingly common records: <= FAST_BLOCKS blocks, every block inside at most
 // FAST_HITS exons, gene sets of at most FAST_SET genes, at most NSTAGE commits.  Anything else
-// sets `overflow` and is recounted by the general code on the slow path.  The overlap query is
-// loop-free in the common case: the two highest candidate rows of each table are loaded up front
-// (independent loads), a loop only runs when both still reach the block.
-struct BlockHits { uint32_t row[FAST_HITS], gf[FAST_HITS]; int32_t start[FAST_HITS]; int n; bool over; };
+// sets `overflow` and is recounted by the general code on the slow path.
+//
+// The kernel is bound by the LATENCY of dependent loads (a wave waits for the slowest lane of every
+// round trip), so the query is organised as two rounds of independent, unconditional loads:
+//   round 1  the two bin-table entries of every block                       (fast_load_bins)
+//   round 2  per block: the two highest candidate exon rows and the three gene breakpoints
+//            around the block start                                         (fast_load_rows)
+// and everything else is arithmetic on registers (fast_resolve_block).  Only rows whose running
+// max differs from their own end, blocks that still reach a third row, or blocks that span more
+// than two gene boundaries go back to memory.  Lanes without a given block load entry 0 of each
+// table (one shared line) and ignore it.
+struct BlockHits { uint32_t row[FAST_HITS], gf[FAST_HITS], cidx[FAST_HITS]; int n; bool over; };
 
 RSQC_HD void fast_test_exon(const ExonRow &row, uint32_t i, int32_t bs, int32_t be, int rstrand, ClassFlags &f, BlockHits &h) {
     if (row.start > be || row.end < bs) return;
@@ -302,39 +332,92 @@ RSQC_HD void fast_test_exon(const ExonRow &row, uint32_t i, int32_t bs, int32_t 
     if (row.start <= bs && row.end >= be - 1) {          // fully contained
         if (h.n < FAST_HITS) {
 #pragma unroll
-            for (int k = 0; k < FAST_HITS; ++k) if (k == h.n) { h.row[k] = i; h.gf[k] = row.gf; h.start[k] = row.start; }
+            for (int k = 0; k < FAST_HITS; ++k) if (k == h.n) { h.row[k] = i; h.gf[k] = row.gf; h.cidx[k] = row.cov + (uint32_t)(bs - row.start); }
             ++h.n;
         } else h.over = true;
     }
 }
 
-RSQC_HD void query_block_fast(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be, int rstrand,
-                              ClassFlags &f, BlockHits &h) {
+struct FastBins { uint32_t ehi[FAST_BLOCKS], nxt[FAST_BLOCKS]; uint32_t have; };   // bit k: block k exists and its contig has features
+struct FastRows { ExonRow e0, e1; GeneBreak g0, g1, g2; };
+
+RSQC_HD void fast_load_bins(const DevAnnotation &a, const ContigInfo &ci, const Blocks &B, FastBins &fb) {
+    fb.have = 0;
+#pragma unroll
+    for (int k = 0; k < FAST_BLOCKS; ++k) {
+        const int32_t bs = B.bs[k], be = B.bs[k] + (int32_t)B.len[k];
+        const bool have = (uint32_t)k < B.nb && ci.n_bins != 0 && be >= 0;
+        uint32_t bE = (uint32_t)(be < 0 ? 0 : be) >> a.bin_shift, bG = (uint32_t)(bs < 0 ? 0 : bs) >> a.bin_shift;
+        const uint32_t last = ci.n_bins ? ci.n_bins - 1 : 0;
+        if (bE > last) bE = last;
+        if (bG > last) bG = last;
+        const uint32_t vE = a.ex_binhi[have ? ci.bin_base + bE : 0u];
+        const uint32_t vG = a.gb_bin[have ? ci.bin_base + bG : 0u];
+        fb.ehi[k] = have ? vE : ci.ex_lo;
+        fb.nxt[k] = have ? vG : ci.gb_hi;
+        if (have) fb.have |= 1u << k;
+    }
+}
+RSQC_HD void fast_load_rows(const DevAnnotation &a, const ContigInfo &ci, uint32_t ehi, uint32_t nxt, bool have, FastRows &fr) {
+    const uint32_t en = ehi - ci.ex_lo;
+    const bool hg = have && ci.gb_hi != ci.gb_lo;
+    fr.e0 = a.ex[en > 0 ? ehi - 1 : 0u];
+    fr.e1 = a.ex[en > 1 ? ehi - 2 : 0u];
+    fr.g0 = a.gb[(hg && nxt > ci.gb_lo) ? nxt - 1 : 0u];
+    fr.g1 = a.gb[(hg && nxt < ci.gb_hi) ? nxt : 0u];
+    fr.g2 = a.gb[(hg && nxt + 1 < ci.gb_hi) ? nxt + 1 : 0u];
+}
+RSQC_HD int32_t row_pmax(const DevAnnotation &a, const ExonRow &row, uint32_t i) {
+    return ((row.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) ? a.ex_pmax[i] : row.end;
+}
+RSQC_HD void fast_resolve_block(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be, int rstrand,
+                                uint32_t ehi, uint32_t nxt, bool have, const FastRows &fr, ClassFlags &f, BlockHits &h) {
     h.n = 0; h.over = false;
-    if (ci.n_bins == 0 || be < 0) return;
-    uint32_t b = (uint32_t)be >> a.bin_shift;
-    if (b >= ci.n_bins) b = ci.n_bins - 1;
-    const uint32_t ehi = a.ex_binhi[ci.bin_base + b];
-    const uint32_t en = ehi - ci.ex_lo;                                // candidate rows available
-    ExonRow e0{0, 0, INT32_MIN, 0}, e1{0, 0, INT32_MIN, 0};
-    if (en > 0) e0 = a.ex[ehi - 1];
-    if (en > 1) e1 = a.ex[ehi - 2];
-    apply_gene_mask(gene_mask(a, ci, bs, be), rstrand, f);
-    if (e0.pmax >= bs) {
-        fast_test_exon(e0, ehi - 1, bs, be, rstrand, f, h);
-        if (e1.pmax >= bs) {
-            fast_test_exon(e1, ehi - 2, bs, be, rstrand, f, h);
-            for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
-                --i;
-                const ExonRow row = a.ex[i];
-                if (row.pmax < bs) break;
-                fast_test_exon(row, i, bs, be, rstrand, f, h);
+    if (!have) return;
+    if (ci.gb_hi != ci.gb_lo) {                                 // gene_mask() on the three staged breakpoints
+        const int32_t bsc = bs < 0 ? 0 : bs;
+        const bool v0 = nxt > ci.gb_lo, v1 = nxt < ci.gb_hi, v2 = nxt + 1 < ci.gb_hi, more = nxt + 2 < ci.gb_hi;
+        uint32_t mask; bool deeper = false;
+        if (v1 && fr.g1.pos <= bsc) {
+            if (v2 && fr.g2.pos <= bsc) deeper = true;
+            mask = fr.g1.mask;
+            if (v2 && fr.g2.pos <= be) { mask |= fr.g2.mask; if (more) deeper = true; }
+        } else {
+            mask = v0 ? fr.g0.mask : 0u;
+            if (v1 && fr.g1.pos <= be) {
+                mask |= fr.g1.mask;
+                if (v2 && fr.g2.pos <= be) { mask |= fr.g2.mask; if (more) deeper = true; }
+            }
+        }
+        if (deeper) mask = gene_mask(a, ci, bs, be);
+        apply_gene_mask(mask, rstrand, f);
+    }
+    const uint32_t en = ehi - ci.ex_lo;
+    if (en > 0) {
+        int32_t pm0 = fr.e0.end, pm1 = fr.e1.end;
+        const bool x0 = ((fr.e0.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
+        const bool x1 = en > 1 && ((fr.e1.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
+        if (x0 || x1) {                                        // both from memory in one round trip
+            const int32_t q0 = a.ex_pmax[ehi - 1], q1 = a.ex_pmax[en > 1 ? ehi - 2 : ehi - 1];
+            if (x0) pm0 = q0;
+            if (x1) pm1 = q1;
+        }
+        if (pm0 >= bs) {
+            fast_test_exon(fr.e0, ehi - 1, bs, be, rstrand, f, h);
+            if (en > 1 && pm1 >= bs) {
+                fast_test_exon(fr.e1, ehi - 2, bs, be, rstrand, f, h);
+                for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
+                    --i;
+                    const ExonRow row = a.ex[i];
+                    if (row_pmax(a, row, i) < bs) break;
+                    fast_test_exon(row, i, bs, be, rstrand, f, h);
+                }
             }
         }
     }
 }
 
-struct Commit { uint32_t row, off, len; };
+struct Commit { uint32_t row, cidx, len; };    // exon row, coverage index of the block's first base, block length
 constexpr int NSTAGE = 4;
 
 constexpr int SLOW_STAGE = 8;  // staged commits on the slow path (records with many blocks)
@@ -342,7 +425,7 @@ template <int K, int NST = NSTAGE>
 struct FeatureOut {
     uint64_t bits;              // feature-stage counter bits
     int n_hit; uint32_t hit[K]; // genes to count: geneCounts++, uniqueGeneCounts, (gene, qname) de-dup
-    int n_commit; Commit commit[NST];      // exonCounts[row] += len/aligned ; coverage[row][off, off+len) += 1
+    int n_commit; Commit commit[NST];      // exonCounts[row] += len/aligned ; coverage[cidx, cidx+len) += 1
 };
 
 // small fixed arrays indexed with unrolled compares so that they stay in registers on the GPU
@@ -384,57 +467,66 @@ RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f
     return bits;
 }
 
-RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const Record &r, const Blocks &B, bool hq,
-                               uint32_t aligned, FeatureOut<FAST_SET> &out, bool &overflow) {
-    const uint32_t fl = r.flag;
+// `ci` is the ContigInfo of the record's contig (wave-uniform in the kernel).
+RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl,
+                               const Blocks &B, bool hq, uint32_t aligned, FeatureOut<FAST_SET> &out, bool &overflow) {
     out.bits = 0; out.n_hit = 0; out.n_commit = 0;
     overflow = B.nb > (uint32_t)FAST_BLOCKS;
     if (overflow) return;
     const int rstrand = read_strand_of(p, fl);
-    const ContigInfo ci = a.contig[r.tid];
     ClassFlags f = {false, false, false, false, false};
     uint32_t last[FAST_SET] = {0, 0}; int nlast = 0; uint32_t last_globin = 0;
     Commit st[NSTAGE]; uint32_t st_gene[NSTAGE]; int nst = 0;
     bool over = false;
 #pragma unroll
-    for (int k = 0; k < NSTAGE; ++k) { st[k].row = 0; st[k].off = 0; st[k].len = 0; st_gene[k] = 0; }
+    for (int k = 0; k < NSTAGE; ++k) { st[k].row = 0; st[k].cidx = 0; st[k].len = 0; st_gene[k] = 0; }
+    FastBins fb;
+    fast_load_bins(a, ci, B, fb);
 #pragma unroll
-    for (int b = 0; b < FAST_BLOCKS; ++b) {
-        if ((uint32_t)b < B.nb) {
-            const int32_t bs = B.bs[b], be = B.bs[b] + (int32_t)B.len[b];
-            BlockHits h;
-            query_block_fast(a, ci, bs, be, rstrand, f, h);
-            over |= h.over;
-            uint32_t cur[FAST_SET] = {0, 0}; int ncur = 0;
+    for (int b0 = 0; b0 < FAST_BLOCKS; b0 += 2) {
+        if (b0 > 0 && B.nb <= (uint32_t)b0) break;
+        FastRows fr[2];
 #pragma unroll
-            for (int e = 0; e < FAST_HITS; ++e) {
-                if (e < h.n) {
-                    const uint32_t g = h.gf[e] & ROW_GENE_MASK;
-                    if (nst < NSTAGE) {
+        for (int j = 0; j < 2; ++j) fast_load_rows(a, ci, fb.ehi[b0 + j], fb.nxt[b0 + j], ((fb.have >> (b0 + j)) & 1u) != 0, fr[j]);
 #pragma unroll
-                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = h.row[e]; st[k].off = (uint32_t)(bs - h.start[e]); st[k].len = B.len[b]; st_gene[k] = g; }
-                        ++nst;
-                    } else over = true;
-                    if (b == 0) {
-                        if (!set_contains<FAST_SET>(last, nlast, g)) {
-                            if (nlast < FAST_SET) { if ((h.gf[e] >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) last_globin |= 1u << nlast; set_put<FAST_SET>(last, nlast, g); ++nlast; }
-                            else over = true;
+        for (int j = 0; j < 2; ++j) {
+            const int b = b0 + j;
+            if ((uint32_t)b < B.nb) {
+                const int32_t bs = B.bs[b], be = B.bs[b] + (int32_t)B.len[b];
+                BlockHits h;
+                fast_resolve_block(a, ci, bs, be, rstrand, fb.ehi[b], fb.nxt[b], ((fb.have >> b) & 1u) != 0, fr[j], f, h);
+                over |= h.over;
+                uint32_t cur[FAST_SET] = {0, 0}; int ncur = 0;
+#pragma unroll
+                for (int e = 0; e < FAST_HITS; ++e) {
+                    if (e < h.n) {
+                        const uint32_t g = h.gf[e] & ROW_GENE_MASK;
+                        if (nst < NSTAGE) {
+#pragma unroll
+                            for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = h.row[e]; st[k].cidx = h.cidx[e]; st[k].len = B.len[b]; st_gene[k] = g; }
+                            ++nst;
+                        } else over = true;
+                        if (b == 0) {
+                            if (!set_contains<FAST_SET>(last, nlast, g)) {
+                                if (nlast < FAST_SET) { if ((h.gf[e] >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) last_globin |= 1u << nlast; set_put<FAST_SET>(last, nlast, g); ++nlast; }
+                                else over = true;
+                            }
+                        } else if (!set_contains<FAST_SET>(cur, ncur, g)) {
+                            if (ncur < FAST_SET) { set_put<FAST_SET>(cur, ncur, g); ++ncur; } else over = true;
                         }
-                    } else if (!set_contains<FAST_SET>(cur, ncur, g)) {
-                        if (ncur < FAST_SET) { set_put<FAST_SET>(cur, ncur, g); ++ncur; } else over = true;
                     }
                 }
-            }
-            if (b > 0) {                                   // set_intersection, :368-374
-                int w = 0; uint32_t wg = 0;
+                if (b > 0) {                                   // set_intersection, :368-374
+                    int w = 0; uint32_t wg = 0;
 #pragma unroll
-                for (int k = 0; k < FAST_SET; ++k) {
-                    if (k < nlast && set_contains<FAST_SET>(cur, ncur, last[k])) {
-                        if ((last_globin >> k) & 1u) wg |= 1u << w;
-                        set_put<FAST_SET>(last, w, last[k]); ++w;
+                    for (int k = 0; k < FAST_SET; ++k) {
+                        if (k < nlast && set_contains<FAST_SET>(cur, ncur, last[k])) {
+                            if ((last_globin >> k) & 1u) wg |= 1u << w;
+                            set_put<FAST_SET>(last, w, last[k]); ++w;
+                        }
                     }
+                    nlast = w; last_globin = wg;
                 }
-                nlast = w; last_globin = wg;
             }
         }
     }
@@ -469,7 +561,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
 // through `acc` directly (exon_add / cov_range).
 // `Acc` (used only on the re-walk path) provides
 //   void exon_add(uint32_t row, double frac);                                      Metrics.cpp:59-66
-//   void cov_range(uint32_t row, uint32_t offset, uint32_t len);                   Metrics.cpp:96-124
+//   void cov_range(uint32_t cidx, uint32_t len);       (coverage index of the first base)  Metrics.cpp:96-124
 // Sets `overflow` (and returns nothing to count) when a block lies inside exons of more than K genes.
 template <int K, class Acc>
 RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Record &r, bool hq,
@@ -502,9 +594,9 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
                     if (!contained) return;
                     const uint32_t g = row.gf & ROW_GENE_MASK;
                     if (nst < NSTAGE) {
-                        const uint32_t off = (uint32_t)(bs - row.start);
+                        const uint32_t cidx = row.cov + (uint32_t)(bs - row.start);
 #pragma unroll
-                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = row_i; st[k].off = off; st[k].len = len; st_gene[k] = g; }
+                        for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = row_i; st[k].cidx = cidx; st[k].len = len; st_gene[k] = g; }
                         ++nst;
                     } else st_over = true;
                     if (first) {                          // genes.front()
@@ -566,7 +658,7 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
                         const uint32_t g = row.gf & ROW_GENE_MASK;
                         if (!set_contains<K>(last, nlast, g)) return;
                         if (len > 0 && !(p.dbg & 2u)) acc.exon_add(row_i, (double)len / (double)aligned);   // :345
-                        if (!(p.dbg & 1u)) acc.cov_range(row_i, (uint32_t)(bs - row.start), len);
+                        if (!(p.dbg & 1u)) acc.cov_range(row.cov + (uint32_t)(bs - row.start), len);
                     });
                 }
                 if (cigar_is_ref(op)) start += (int32_t)len;

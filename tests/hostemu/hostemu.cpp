@@ -26,10 +26,10 @@ struct Acc {
     std::vector<std::set<uint64_t>> *names;
     void gene_hit(uint32_t g, bool nd, uint64_t qh) { (*reads)[g]++; if (nd) (*unique)[g]++; (*names)[g].insert(qh); }
     void exon_add(uint32_t row, double f) { (*exon_rows)[row] += f; }
-    void cov_range(uint32_t row, uint32_t off, uint32_t len) {
+    void cov_range(uint32_t cidx, uint32_t len) {
         if (!len) return;
-        (*cov)[ex_cov[row] + off] += 1u;
-        (*cov)[ex_cov[row] + off + len] -= 1u;
+        (*cov)[cidx] += 1u;
+        (*cov)[cidx + len] -= 1u;
     }
 };
 template <int K, int NST>
@@ -37,7 +37,7 @@ void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K, NST> &fo, const
     for (int k = 0; k < fo.n_commit; ++k) {
         const Commit &c = fo.commit[k];
         if (c.len > 0) acc.exon_add(c.row, (double)c.len / (double)aligned);
-        acc.cov_range(c.row, c.off, c.len);
+        acc.cov_range(c.cidx, c.len);
     }
     for (int k = 0; k < fo.n_hit; ++k) acc.gene_hit(fo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
 }
@@ -54,7 +54,12 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     DevAnnotation d{};
     d.n_ref = a->n_ref; d.n_contigs = a->n_contigs; d.n_genes = a->n_genes; d.n_listed = a->n_genes_listed; d.n_exons = a->n_exons;
     d.bin_shift = HostIndex::kBinShift;
-    d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.contig = hx.contig.data();
+    d.contig = hx.contig.data();
+    // the kernels' unconditional loads read entry 0 of a table for lanes that have nothing to look up
+    if (hx.ex_rows.empty()) hx.ex_rows.push_back(ExonRow{0, 0, 0, 0});
+    if (hx.gb.empty()) hx.gb.push_back(GeneBreak{0, 0});
+    if (hx.ex_pmax.empty()) hx.ex_pmax.push_back(0);
+    d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.ex_pmax = hx.ex_pmax.data();
     d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
     DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u};
     std::vector<uint64_t> reads((size_t)a->n_genes, 0), unique((size_t)a->n_genes, 0);
@@ -82,7 +87,7 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
         if (go) {
             bool over = false;
             FeatureOut<FAST_SET> fo;
-            exon_metrics_fast(d, dp, r, B, hq, aligned, fo, over);
+            exon_metrics_fast(d, dp, d.contig[r.tid], r.flag, B, hq, aligned, fo, over);
             if (!over) { bits |= fo.bits; apply(acc, d, fo, r, aligned); }
             else {
                 ++*n_overflow;

@@ -1,28 +1,40 @@
 #!/bin/bash
-# PMC passes (each its own rocprofv3 run, counters only -- never combined with trace flags)
+# PMC passes for the default bench command (each its own rocprofv3 run, counters only).
+# Writes gpurun_out/prof/$TAG/summary.txt and profiles-ready k1_traffic.json.
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof/${TAG:-pmc}
 mkdir -p $OUT
 cd /tmp
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
-           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS" \
-           "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum"; do
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum GRBM_GUI_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/p$i.log 2>&1
 done
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r.get("Kernel_Name", "")[:40]
+        k = r.get("Kernel_Name", "").split("(")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
-    for k, d in agg.items():
+    o.write("# rocprofv3 --pmc (separate passes) -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 ; mean per launch\n")
+    for k, d in sorted(agg.items()):
         o.write(k + "\n")
         for c, v in sorted(d.items()):
-            o.write("   %-24s n=%d mean=%.4g\n" % (c, len(v), sum(v) / len(v)))
-print(open("$OUT/summary.txt").read())
+            o.write("   %-24s n=%d mean=%.5g\n" % (c, len(v), sum(v) / len(v)))
+k1 = [k for k in agg if "classify_count" in k]
+if k1:
+    d = agg[k1[0]]
+    fetch_kb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); write_kb = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+    # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE uncalibrated, taken as is
+    out = {"kernel": k1[0], "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
+           "hbm_bytes_per_launch": fetch_kb * 1024 * 2.0 + write_kb * 1024,
+           "note": "FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; separate --pmc passes"}
+    json.dump(out, open("$OUT/k1_traffic.json", "w"), indent=1)
+    print(out)
+print(open("$OUT/summary.txt").read()[:3000])
 PY
