@@ -197,7 +197,7 @@ int zero_accumulators(rsqc_ctx *c) {
 }
 
 int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u) {
-    if (b->n > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large");
+    if (b->n > 0xFFFFFFF0ull || b->n_cigar_total >= (1ull << 30)) return fail(c, RSQC_ERR_ARG, "batch too large");
     DevBatch &d = u->d;
     d.n = b->n; d.n_seg = b->n_seg; d.n_wide = b->n_wide;
     u->n = b->n; u->n_cigar_total = b->n_cigar_total;

@@ -51,6 +51,7 @@ struct HostIndex {
             return RSQC_ERR_ARG;
         }
         if (G > (int)ROW_GENE_MASK) { err = "more than 2^26 genes"; return RSQC_ERR_CAPACITY; }
+        if (E >= (1 << 27)) { err = "more than 2^27 exons"; return RSQC_ERR_CAPACITY; }        // 16-byte rows, 32-bit offsets
         for (int i = 0; i < E; ++i)
             if (a->exon_row_gene[i] >= (uint32_t)G) { err = "exon_row_gene out of range"; return RSQC_ERR_ARG; }
         // gene breakpoints per contig: sweep over gene starts (+) and ends+1 (-) with per-class counters
@@ -89,7 +90,7 @@ struct HostIndex {
             if (ex_range[(size_t)k + 1] > ex_range[(size_t)k]) ms = std::max<int64_t>(ms, a->exon_row_start[ex_range[(size_t)k + 1] - 1]);
             if (gb_range[(size_t)k + 1] > gb_range[(size_t)k]) ms = std::max<int64_t>(ms, gb[gb_range[(size_t)k + 1] - 1].pos);
             const uint64_t nb = ms < 0 ? 0 : (uint64_t)(ms >> kBinShift) + 1;
-            if (total_bins + nb > 0xFFFFFFF0ull) { err = "bin table too large"; return RSQC_ERR_CAPACITY; }
+            if (total_bins + nb > 0x3FFFFFF0ull) { err = "bin table too large"; return RSQC_ERR_CAPACITY; }
             contig[(size_t)k] = ContigInfo{ex_range[(size_t)k], ex_range[(size_t)k + 1], gb_range[(size_t)k], gb_range[(size_t)k + 1],
                                            (uint32_t)total_bins, (uint32_t)nb, 0, 0};
             total_bins += nb;

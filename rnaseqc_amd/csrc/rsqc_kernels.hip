@@ -175,6 +175,7 @@ struct K1Shared {
     }
 };
 
+template <int ROUND>
 __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                                                     const DevAccum &acc, K1Shared &S) {
     const int l = lane_id();
@@ -193,9 +194,21 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     int pending = 0;
     unsigned long long my_cnt = 0ull;     // lane c of every wave accumulates counter c
     uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
+    bool big_any = false;
+    auto vertical_add = [&](uint64_t bits) {
+#ifdef EXP_NOCNT
+        return;
+#endif
+        uint64_t carry = bits, t;
+        t = pl0 & carry; pl0 ^= carry; carry = t;
+        t = pl1 & carry; pl1 ^= carry; carry = t;
+        t = pl2 & carry; pl2 ^= carry; carry = t;
+        t = pl3 & carry; pl3 ^= carry; carry = t;
+        pl4 ^= carry;
+    };
     auto flush_counts = [&]() {
-#pragma unroll
-        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {
+#pragma unroll 1
+        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {      // rare (once per 31 tiles): keep it rolled, it must not set the register budget
             const uint32_t v = (uint32_t)((pl0 >> c) & 1ull) | ((uint32_t)((pl1 >> c) & 1ull) << 1) |
                                ((uint32_t)((pl2 >> c) & 1ull) << 2) | ((uint32_t)((pl3 >> c) & 1ull) << 3) |
                                ((uint32_t)((pl4 >> c) & 1ull) << 4);
@@ -244,14 +257,12 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     const int4 zero4 = {0, 0, 0, 0};
     int4 cur_cv = zero4, cur_av = zero4, nx_cv = zero4;
     uint32_t cur_cg[4] = {0, 0, 0, 0};
-    if (wbeg + (uint64_t)l < wend) {
-        cur_cv = *reinterpret_cast<const int4 *>(&b.core[wbeg + (uint64_t)l]);
-        cur_av = *reinterpret_cast<const int4 *>(&b.aux[wbeg + (uint64_t)l]);
-    }
-    if (wbeg + 64ull + (uint64_t)l < wend) nx_cv = *reinterpret_cast<const int4 *>(&b.core[wbeg + 64ull + (uint64_t)l]);
+    const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
+    if (wbeg + (uint64_t)l < wend) { cur_cv = ld32(core4 + wbeg, (uint32_t)l); cur_av = ld32(aux4 + wbeg, (uint32_t)l); }
+    if (wbeg + 64ull + (uint64_t)l < wend) nx_cv = ld32(core4 + wbeg + 64, (uint32_t)l);
     {
-        const uint32_t *cg = b.cigar + (uint32_t)cur_cv.w;               // buffers carry 32 bytes of slack
-        cur_cg[0] = cg[0]; cur_cg[1] = cg[1]; cur_cg[2] = cg[2]; cur_cg[3] = cg[3];
+        const uint32_t co = (uint32_t)cur_cv.w;                          // buffers carry 32 bytes of slack
+        cur_cg[0] = ld32(b.cigar, co); cur_cg[1] = ld32(b.cigar, co + 1); cur_cg[2] = ld32(b.cigar, co + 2); cur_cg[3] = ld32(b.cigar, co + 3);
     }
     for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
         const uint64_t i = w0 + (uint64_t)l;
@@ -262,47 +273,49 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (moved) load_contig();
         }
         const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
-        RecordCounters rc;
-        rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
-        rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
         FeatureOut<FAST_SET> fo;
-        fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0;
+        fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0; fo.cmask = 0;
         uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
-        if (valid) {
-            Record r;
-            const int4 cv = cur_cv, av = cur_av;
-            r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
-            r.cigar = b.cigar + (uint32_t)cv.w;
-            r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
-            r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
-            r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
-            r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
-            bool ok = true;
-            if (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE) {
-                uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
-                while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
-                if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
-                else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
-            }
-            r.tid = u_tid;
-            if (mixed) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
-            if (!ok) atomicExch(acc.error, RSQC_ERR_ARG);
-            else {
-                bool hq; Blocks B; CigarWalk cw;
-                walk_cigar(r, cur_cg, cw, B);
-                aligned = cw.aligned;
-                if (gate_cascade(a, p, r, cw, rc, hq) && !(p.dbg & 8u)) {
-                    bool overflow = r.tid != u_tid;          // stragglers of a boundary tile: general code
-                    if (!overflow) exon_metrics_fast(a, p, u_ci, r.flag, B, hq, aligned, fo, overflow);
-                    if (overflow) {
-                        fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0;
-                        const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
-                        if (slot < acc.ovf_cap) acc.ovf_index[slot] = i;
-                        else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                    }
-                    rc.bits |= fo.bits;
+        // Everything that depends only on the gate cascade (scalar counters, Read-Length inputs, the
+        // fragment-size candidate) is retired BEFORE the feature stage, so that the record and its counters
+        // are dead while the index loads of the feature stage are in flight (register pressure).
+        bool go = false, hq = false; Blocks B; uint32_t fl = 0; int32_t tid = u_tid;
+        {
+            RecordCounters rc;
+            rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
+            rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
+            B.nb = 0;
+            if (valid) {
+                Record r;
+                const int4 cv = cur_cv, av = cur_av;
+                r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
+                r.cigar = b.cigar + (uint32_t)cv.w;
+                r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+                r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
+                r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
+                r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
+                bool ok = true;
+                if (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE) {
+                    uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
+                    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
+                    if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
+                    else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
+                }
+                r.tid = u_tid;
+                if (mixed) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
+                if (!ok) atomicExch(acc.error, RSQC_ERR_ARG);
+                else {
+                    CigarWalk cw;
+                    walk_cigar(r, cur_cg, cw, B);
+                    aligned = cw.aligned;
+                    go = gate_cascade(a, p, r, cw, rc, hq) && !(p.dbg & 8u);
+                    fl = r.flag; tid = r.tid;
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
-                    if (a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
+#ifdef EXP_NOBED
+                    if (false) {
+#else
+                    if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
+#endif
                         const int32_t name = bed_interval_of(a, r);
                         if (name >= 0) {
                             const uint32_t slot = atomicAdd(acc.frag.count, 1u);
@@ -315,8 +328,35 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                             } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                         }
                     }
+                    if (rc.error) atomicExch(acc.error, rc.error);
                 }
-                if (rc.error) atomicExch(acc.error, rc.error);
+            }
+            // scalar counters of the gate cascade: vertical add of the record's one-bit increments
+            vertical_add(rc.bits);
+#ifndef EXP_NOCNT
+            sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
+            sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
+#endif
+            big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
+            // Read-Length inputs: per-wave max span + batch-level extremes
+            const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
+            const uint32_t wsp = wave_max_u32(sp);
+            if (l == 0) acc.tile_span[w0 >> 6] = wsp;
+            l_span = sp > l_span ? sp : l_span;
+            if (rc.rl_eligible) {
+                const uint32_t lq = (uint32_t)rc.rl_lqseq;
+                l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
+            }
+        }
+        // ---- feature stage ------------------------------------------------------------------------
+        if (go) {
+            bool overflow = tid != u_tid;          // stragglers of a boundary tile: general code
+            if (!overflow) exon_metrics_fast<ROUND>(a, p, u_ci, fl, B, hq, aligned, fo, overflow);
+            if (overflow) {
+                fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0; fo.cmask = 0;
+                const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
+                if (slot < acc.ovf_cap) acc.ovf_index[slot] = i;
+                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
             }
         }
         // ---- stage the next tile (see above) ------------------------------------------------
@@ -324,11 +364,11 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             const uint64_t i1 = i + 64ull, i2 = i + 128ull;
             const int4 t_cv = nx_cv;
             int4 t_av = zero4;
-            if (i1 < wend) t_av = *reinterpret_cast<const int4 *>(&b.aux[i1]);
-            const uint32_t *cg = b.cigar + (uint32_t)t_cv.w;
-            cur_cg[0] = cg[0]; cur_cg[1] = cg[1]; cur_cg[2] = cg[2]; cur_cg[3] = cg[3];
+            if (i1 < wend) t_av = ld32(aux4 + w0 + 64, (uint32_t)l);
+            const uint32_t co = (uint32_t)t_cv.w;
+            cur_cg[0] = ld32(b.cigar, co); cur_cg[1] = ld32(b.cigar, co + 1); cur_cg[2] = ld32(b.cigar, co + 2); cur_cg[3] = ld32(b.cigar, co + 3);
             nx_cv = zero4;
-            if (i2 < wend) nx_cv = *reinterpret_cast<const int4 *>(&b.core[i2]);
+            if (i2 < wend) nx_cv = ld32(core4 + w0 + 128, (uint32_t)l);
             cur_cv = t_cv; cur_av = t_av;
         }
         // ---- scatter -----------------------------------------------------------------------------
@@ -337,12 +377,15 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         // array, identical neighbouring slots merged into one atomic.
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k) {
-            const bool has = fo.n_commit > k;
+            const bool has = (fo.cmask >> k) & 1u;
             const uint64_t hm = __ballot(has);
-            if (hm == 0ull) break;
+            if (hm == 0ull) continue;
             const Commit cm = fo.commit[k];
             const bool hv = has && cm.len > 0;
             if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, cm.row, (double)cm.len / (double)aligned);
+#ifdef EXP_NOCOVRUN
+            if (hv) { atomicAdd(&acc.cov_diff[cm.cidx], 1u); atomicAdd(&acc.cov_diff[cm.cidx + cm.len], 0xFFFFFFFFu); }
+#else
             if (!(p.dbg & 1u)) {                 // +1 at the block start, -1 after its last base
                 const uint32_t base = hv ? cm.cidx : 0u;
                 const Run up = make_run(hv, base);
@@ -350,6 +393,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 const Run dn = make_run(hv, base + cm.len);
                 if (dn.head) atomicAdd(&acc.cov_diff[base + cm.len], 0u - dn.count);
             }
+#endif
         }
 #pragma unroll
         for (int k = 0; k < FAST_SET; ++k) {
@@ -371,32 +415,11 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             }
             if (has && !(p.dbg & 4096u)) S.gene_add(acc, g, notdup);
         }
-        // ---- scalar counters: vertical add of the record's one-bit increments -----------------
-        {
-            uint64_t carry = rc.bits, t;
-            t = pl0 & carry; pl0 ^= carry; carry = t;
-            t = pl1 & carry; pl1 ^= carry; carry = t;
-            t = pl2 & carry; pl2 ^= carry; carry = t;
-            t = pl3 & carry; pl3 ^= carry; carry = t;
-            pl4 ^= carry;
-            sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
-            sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
-            // 31 iterations fit the 5 planes; the u32 sums cannot overflow before that unless a record
-            // carries an absurd value, in which case flush right away
-            const bool big = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
-            if (++pending == 31 || __ballot(big) != 0ull) flush_counts();
-        }
-        // ---- Read-Length inputs: per-wave max span + batch-level extremes -------------------------
-        {
-            const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
-            const uint32_t wsp = wave_max_u32(sp);
-            if (l == 0) acc.tile_span[w0 >> 6] = wsp;
-            l_span = sp > l_span ? sp : l_span;
-            if (rc.rl_eligible) {
-                const uint32_t lq = (uint32_t)rc.rl_lqseq;
-                l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
-            }
-        }
+        // ---- feature-stage counter bits (disjoint from the gate's, so a second vertical add is exact) ----
+        vertical_add(fo.bits);
+        // 31 iterations fit the 5 planes (two adds of disjoint bit sets count once per counter); the u32
+        // sums cannot overflow before that unless a record carries an absurd value: flush right away then
+        if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
     }
     flush_counts();
     if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&S.cnt[l], my_cnt);
@@ -422,17 +445,18 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 
 // The same body under three register budgets (occupancy vs. spilling is measured, not guessed):
 // min 3 / 4 / 6 / 8 waves per SIMD -> at most 168 / 128 / 80 / 64 VGPRs.
-#define RSQC_DEFINE_K1(NAME, MINW)                                                              \
+#define RSQC_DEFINE_K1(NAME, MINW, ROUND)                                                       \
     __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
     NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
         __shared__ K1Shared S;                                                                  \
-        classify_count_body(a, p, b, acc, S);                                                   \
+        classify_count_body<ROUND>(a, p, b, acc, S);                                            \
     }
-RSQC_DEFINE_K1(classify_count_kernel, 4)
-RSQC_DEFINE_K1(classify_count_kernel_w3, 3)
-RSQC_DEFINE_K1(classify_count_kernel_w2, 2)
-RSQC_DEFINE_K1(classify_count_kernel_w6, 6)
-RSQC_DEFINE_K1(classify_count_kernel_w8, 8)
+RSQC_DEFINE_K1(classify_count_kernel, 4, 2)
+RSQC_DEFINE_K1(classify_count_kernel_w3, 3, 2)
+RSQC_DEFINE_K1(classify_count_kernel_w2, 2, 2)
+RSQC_DEFINE_K1(classify_count_kernel_w3r1, 3, 1)
+RSQC_DEFINE_K1(classify_count_kernel_w4r1, 4, 1)
+RSQC_DEFINE_K1(classify_count_kernel_w3r4, 3, 4)
 
 // ------------------------------------------------------------------ K1s
 // Records whose block sits fully inside exons of more than FAST_SET genes (pathological
@@ -1044,8 +1068,9 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
                      const DevAccum &acc) {
     if (variant == 2) hipLaunchKernelGGL(classify_count_kernel_w2, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 6) hipLaunchKernelGGL(classify_count_kernel_w6, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 8) hipLaunchKernelGGL(classify_count_kernel_w8, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 31) hipLaunchKernelGGL(classify_count_kernel_w3r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 41) hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 34) hipLaunchKernelGGL(classify_count_kernel_w3r4, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else hipLaunchKernelGGL(classify_count_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,

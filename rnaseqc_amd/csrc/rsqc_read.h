@@ -25,6 +25,13 @@
 
 namespace rsqc {
 
+// base[idx] with the byte offset formed in 32 bits: the device code then addresses the table as
+// (scalar base) + (one 32-bit lane offset) instead of a 64-bit address per lane.  Every table loaded
+// through this is smaller than 4 GiB by construction (HostIndex::build checks).
+template <class T> RSQC_HD T ld32(const T *base, uint32_t idx) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+}
+
 // ---- device-resident annotation index ------------------------------------------
 // One 16-byte row per interval so that a candidate costs one vector load.
 struct ExonRow {
@@ -144,11 +151,11 @@ RSQC_HD uint32_t gene_mask(const DevAnnotation &a, const ContigInfo &ci, int32_t
     if (bs < 0) bs = 0;
     uint32_t b = (uint32_t)bs >> a.bin_shift;
     if (b >= ci.n_bins) b = ci.n_bins - 1;
-    uint32_t nxt = a.gb_bin[ci.bin_base + b];                // first breakpoint with pos > bin start
-    while (nxt < ci.gb_hi && a.gb[nxt].pos <= bs) ++nxt;     // ... with pos > bs
-    uint32_t mask = nxt > ci.gb_lo ? a.gb[nxt - 1].mask : 0u;
+    uint32_t nxt = ld32(a.gb_bin, ci.bin_base + b);         // first breakpoint with pos > bin start
+    while (nxt < ci.gb_hi && ld32(a.gb, nxt).pos <= bs) ++nxt;   // ... with pos > bs
+    uint32_t mask = nxt > ci.gb_lo ? ld32(a.gb, nxt - 1).mask : 0u;
     while (nxt < ci.gb_hi) {
-        const GeneBreak g = a.gb[nxt];
+        const GeneBreak g = ld32(a.gb, nxt);
         if (g.pos > be) break;
         mask |= g.mask; ++nxt;
     }
@@ -351,8 +358,8 @@ RSQC_HD void fast_load_bins(const DevAnnotation &a, const ContigInfo &ci, const 
         const uint32_t last = ci.n_bins ? ci.n_bins - 1 : 0;
         if (bE > last) bE = last;
         if (bG > last) bG = last;
-        const uint32_t vE = a.ex_binhi[have ? ci.bin_base + bE : 0u];
-        const uint32_t vG = a.gb_bin[have ? ci.bin_base + bG : 0u];
+        const uint32_t vE = ld32(a.ex_binhi, have ? ci.bin_base + bE : 0u);
+        const uint32_t vG = ld32(a.gb_bin, have ? ci.bin_base + bG : 0u);
         fb.ehi[k] = have ? vE : ci.ex_lo;
         fb.nxt[k] = have ? vG : ci.gb_hi;
         if (have) fb.have |= 1u << k;
@@ -361,14 +368,14 @@ RSQC_HD void fast_load_bins(const DevAnnotation &a, const ContigInfo &ci, const 
 RSQC_HD void fast_load_rows(const DevAnnotation &a, const ContigInfo &ci, uint32_t ehi, uint32_t nxt, bool have, FastRows &fr) {
     const uint32_t en = ehi - ci.ex_lo;
     const bool hg = have && ci.gb_hi != ci.gb_lo;
-    fr.e0 = a.ex[en > 0 ? ehi - 1 : 0u];
-    fr.e1 = a.ex[en > 1 ? ehi - 2 : 0u];
-    fr.g0 = a.gb[(hg && nxt > ci.gb_lo) ? nxt - 1 : 0u];
-    fr.g1 = a.gb[(hg && nxt < ci.gb_hi) ? nxt : 0u];
-    fr.g2 = a.gb[(hg && nxt + 1 < ci.gb_hi) ? nxt + 1 : 0u];
+    fr.e0 = ld32(a.ex, en > 0 ? ehi - 1 : 0u);
+    fr.e1 = ld32(a.ex, en > 1 ? ehi - 2 : 0u);
+    fr.g0 = ld32(a.gb, (hg && nxt > ci.gb_lo) ? nxt - 1 : 0u);
+    fr.g1 = ld32(a.gb, (hg && nxt < ci.gb_hi) ? nxt : 0u);
+    fr.g2 = ld32(a.gb, (hg && nxt + 1 < ci.gb_hi) ? nxt + 1 : 0u);
 }
 RSQC_HD int32_t row_pmax(const DevAnnotation &a, const ExonRow &row, uint32_t i) {
-    return ((row.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) ? a.ex_pmax[i] : row.end;
+    return ((row.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) ? ld32(a.ex_pmax, i) : row.end;
 }
 RSQC_HD void fast_resolve_block(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be, int rstrand,
                                 uint32_t ehi, uint32_t nxt, bool have, const FastRows &fr, ClassFlags &f, BlockHits &h) {
@@ -398,7 +405,7 @@ RSQC_HD void fast_resolve_block(const DevAnnotation &a, const ContigInfo &ci, in
         const bool x0 = ((fr.e0.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
         const bool x1 = en > 1 && ((fr.e1.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
         if (x0 || x1) {                                        // both from memory in one round trip
-            const int32_t q0 = a.ex_pmax[ehi - 1], q1 = a.ex_pmax[en > 1 ? ehi - 2 : ehi - 1];
+            const int32_t q0 = ld32(a.ex_pmax, ehi - 1), q1 = ld32(a.ex_pmax, en > 1 ? ehi - 2 : ehi - 1);
             if (x0) pm0 = q0;
             if (x1) pm1 = q1;
         }
@@ -408,7 +415,7 @@ RSQC_HD void fast_resolve_block(const DevAnnotation &a, const ContigInfo &ci, in
                 fast_test_exon(fr.e1, ehi - 2, bs, be, rstrand, f, h);
                 for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
                     --i;
-                    const ExonRow row = a.ex[i];
+                    const ExonRow row = ld32(a.ex, i);
                     if (row_pmax(a, row, i) < bs) break;
                     fast_test_exon(row, i, bs, be, rstrand, f, h);
                 }
@@ -425,7 +432,9 @@ template <int K, int NST = NSTAGE>
 struct FeatureOut {
     uint64_t bits;              // feature-stage counter bits
     int n_hit; uint32_t hit[K]; // genes to count: geneCounts++, uniqueGeneCounts, (gene, qname) de-dup
-    int n_commit; Commit commit[NST];      // exonCounts[row] += len/aligned ; coverage[cidx, cidx+len) += 1
+    // exonCounts[row] += len/aligned ; coverage[cidx, cidx+len) += 1 for every k with bit k of cmask set
+    // (the general code fills commit[0..n_commit) densely; the fast path marks its staged hits in place)
+    int n_commit; uint32_t cmask; Commit commit[NST];
 };
 
 // small fixed arrays indexed with unrolled compares so that they stay in registers on the GPU
@@ -467,29 +476,32 @@ RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f
     return bits;
 }
 
-// `ci` is the ContigInfo of the record's contig (wave-uniform in the kernel).
+// `ci` is the ContigInfo of the record's contig (wave-uniform in the kernel).  ROUND = blocks whose row
+// loads are in flight together (registers vs. round trips).
+template <int ROUND = 2>
 RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl,
                                const Blocks &B, bool hq, uint32_t aligned, FeatureOut<FAST_SET> &out, bool &overflow) {
-    out.bits = 0; out.n_hit = 0; out.n_commit = 0;
+    out.bits = 0; out.n_hit = 0; out.n_commit = 0; out.cmask = 0;
     overflow = B.nb > (uint32_t)FAST_BLOCKS;
     if (overflow) return;
     const int rstrand = read_strand_of(p, fl);
     ClassFlags f = {false, false, false, false, false};
     uint32_t last[FAST_SET] = {0, 0}; int nlast = 0; uint32_t last_globin = 0;
-    Commit st[NSTAGE]; uint32_t st_gene[NSTAGE]; int nst = 0;
+    uint32_t st_gene[NSTAGE]; int nst = 0;       // staged hits live in out.commit[]; cmask selects the counted ones
     bool over = false;
 #pragma unroll
-    for (int k = 0; k < NSTAGE; ++k) { st[k].row = 0; st[k].cidx = 0; st[k].len = 0; st_gene[k] = 0; }
+    for (int k = 0; k < NSTAGE; ++k) { out.commit[k].row = 0; out.commit[k].cidx = 0; out.commit[k].len = 0; st_gene[k] = 0; }
+    out.cmask = 0;
     FastBins fb;
     fast_load_bins(a, ci, B, fb);
 #pragma unroll
-    for (int b0 = 0; b0 < FAST_BLOCKS; b0 += 2) {
+    for (int b0 = 0; b0 < FAST_BLOCKS; b0 += ROUND) {
         if (b0 > 0 && B.nb <= (uint32_t)b0) break;
-        FastRows fr[2];
+        FastRows fr[ROUND];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fast_load_rows(a, ci, fb.ehi[b0 + j], fb.nxt[b0 + j], ((fb.have >> (b0 + j)) & 1u) != 0, fr[j]);
+        for (int j = 0; j < ROUND; ++j) fast_load_rows(a, ci, fb.ehi[b0 + j], fb.nxt[b0 + j], ((fb.have >> (b0 + j)) & 1u) != 0, fr[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < ROUND; ++j) {
             const int b = b0 + j;
             if ((uint32_t)b < B.nb) {
                 const int32_t bs = B.bs[b], be = B.bs[b] + (int32_t)B.len[b];
@@ -503,7 +515,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
                         const uint32_t g = h.gf[e] & ROW_GENE_MASK;
                         if (nst < NSTAGE) {
 #pragma unroll
-                            for (int k = 0; k < NSTAGE; ++k) if (k == nst) { st[k].row = h.row[e]; st[k].cidx = h.cidx[e]; st[k].len = B.len[b]; st_gene[k] = g; }
+                            for (int k = 0; k < NSTAGE; ++k) if (k == nst) { out.commit[k].row = h.row[e]; out.commit[k].cidx = h.cidx[e]; out.commit[k].len = B.len[b]; st_gene[k] = g; }
                             ++nst;
                         } else over = true;
                         if (b == 0) {
@@ -538,13 +550,8 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
     }
     if (hq && nlast > 0 && !(p.dbg & 4u)) {                                                // :377-392
 #pragma unroll
-        for (int k = 0; k < NSTAGE; ++k) {
-            if (k < nst && set_contains<FAST_SET>(last, nlast, st_gene[k])) {
-#pragma unroll
-                for (int j = 0; j < NSTAGE; ++j) if (j == out.n_commit) out.commit[j] = st[k];
-                ++out.n_commit;
-            }
-        }
+        for (int k = 0; k < NSTAGE; ++k)
+            if (k < nst && set_contains<FAST_SET>(last, nlast, st_gene[k])) { out.cmask |= 1u << k; ++out.n_commit; }
         if (aligned > 0 && !(p.dbg & 2u)) {
 #pragma unroll
             for (int k = 0; k < FAST_SET; ++k) out.hit[k] = last[k];
@@ -570,7 +577,7 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
     const uint32_t fl = r.flag;
     uint64_t bits = 0;
     overflow = false;
-    out.bits = 0; out.n_hit = 0; out.n_commit = 0;
+    out.bits = 0; out.n_hit = 0; out.n_commit = 0; out.cmask = 0;
     const int rstrand = read_strand_of(p, fl);
     const ContigInfo ci = a.contig[r.tid];
     ClassFlags f = {false, false, false, false, false};
@@ -643,6 +650,7 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
                 if (k < nst && set_contains<K>(last, nlast, st_gene[k])) {
 #pragma unroll
                     for (int j = 0; j < NSTAGE; ++j) if (j == out.n_commit) out.commit[j] = st[k];
+                    out.cmask |= 1u << out.n_commit;
                     ++out.n_commit;
                 }
             }

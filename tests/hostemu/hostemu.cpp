@@ -34,7 +34,8 @@ struct Acc {
 };
 template <int K, int NST>
 void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K, NST> &fo, const Record &r, uint32_t aligned) {
-    for (int k = 0; k < fo.n_commit; ++k) {
+    for (int k = 0; k < NST; ++k) {
+        if (!((fo.cmask >> k) & 1u)) continue;
         const Commit &c = fo.commit[k];
         if (c.len > 0) acc.exon_add(c.row, (double)c.len / (double)aligned);
         acc.cov_range(c.cidx, c.len);
