@@ -40,6 +40,7 @@ struct PairBuf {                // (gene, qname-hash) pairs of one submitted bat
     uint64_t cap = 0;           // pair slots allocated
     uint32_t n_chunks = 0, chunk_cap = 0, slow_base = 0, slow_cap = 0;
     uint32_t counts_cap = 0;
+    uint64_t pairs_bound = 0;   // most pairs the batch can have emitted
     bool used = false;
 };
 
@@ -257,6 +258,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     PairBuf *pb = acquire_pairs(c, want, (uint32_t)grid + 1, &pidx);
     if (!pb) return fail(c, RSQC_ERR_HIP, "hipMalloc(pair buffer) failed");
     pb->n_chunks = (uint32_t)grid; pb->chunk_cap = (uint32_t)chunk_cap;
+    pb->pairs_bound = std::min<uint64_t>(want, u->n * (uint64_t)FAST_SET + slow_cap);
     pb->slow_base = (uint32_t)(chunk_cap * (uint64_t)grid); pb->slow_cap = (uint32_t)slow_cap;
     c->pairs_in_flight.push_back(pidx);
     HIP_TRY(c, hipMemsetAsync(pb->counts.p, 0, ((size_t)grid + 1) * 4, c->stream));
@@ -629,12 +631,13 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         unsigned long long *d_total = (unsigned long long *)c->d_tab_off.p + std::max(G, 1);
         launch_dedup_layout(c->stream, c->acc.gene_reads, (uint32_t)G, (uint64_t *)c->d_tab_off.p,
                             (uint32_t *)c->d_tab_cap.p, d_total, c->acc.error);
-        unsigned long long *h_slots = (unsigned long long *)(c->h_arena + c->off_misc + 48);     // pinned scratch
-        HIP_TRY(c, hipMemcpyAsync(h_slots, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const unsigned long long slots = *h_slots;
-        if (c->d_table.bytes < (size_t)slots * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slots * 8 + (1u << 20), false))) return rc; }
-        if (slots) HIP_TRY(c, hipMemsetAsync(c->d_table.p, 0, (size_t)slots * 8, c->stream));
+        // table slots = 2 x sum(geneCounts) <= 2 x (pairs emitted); the host only knows the bound, the exact
+        // count stays on the device (no synchronisation here)
+        uint64_t pair_bound = 0;
+        for (size_t idx : c->pairs_in_flight) pair_bound += c->pair_pool[idx].pairs_bound;
+        const uint64_t slot_bound = 2 * pair_bound + 16;
+        if (c->d_table.bytes < (size_t)slot_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slot_bound * 8 + (1u << 20), false))) return rc; }
+        launch_dedup_clear(c->stream, (unsigned long long *)c->d_table.p, d_total);
         for (size_t idx : c->pairs_in_flight) {
             PairBuf &pb = c->pair_pool[idx];
             DevAccum acc = c->acc;

@@ -86,6 +86,7 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
                         const DevAccum &acc);
 void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
                   unsigned long long *table, uint32_t mode, int grid);
+void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total);
 void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
                          uint32_t *tab_cap, unsigned long long *total, int *error);
 

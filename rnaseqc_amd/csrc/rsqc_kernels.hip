@@ -670,74 +670,112 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// The pairs of a batch live in per-K1-block chunks (+ one slow-path region).  All threads walk
-// them in GLOBAL order (chunk after chunk), i.e. in file order: at any moment the whole grid works
-// on one window of consecutive records, hence on the table slices of the same few genes, which
-// keeps those slices cache-resident.  j -> (chunk, offset) through an exclusive prefix of the
-// chunk fill counts held in LDS.
-#define RSQC_K4_MAX_CHUNKS 4100
-__global__ void __launch_bounds__(256)
-dedup_insert_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
-                    const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-                    const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
-                    unsigned long long *gene_frag, uint32_t mode) {
-    __shared__ uint32_t s_pref[RSQC_K4_MAX_CHUNKS + 2];
-    __shared__ uint32_t s_wave[4];
-    // exclusive prefix over n_chunks + 1 regions (the last one is the slow-path region)
-    const uint32_t n_reg = n_chunks + 1;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_reg; base += 256) {
-        const uint32_t r = base + threadIdx.x;
-        uint32_t v = 0;
-        if (r < n_chunks) v = chunk_count[r] < chunk_cap ? chunk_count[r] : chunk_cap;
-        else if (r == n_chunks) v = chunk_count[r] < slow_cap ? chunk_count[r] : slow_cap;
-        const uint32_t inc = wave_inclusive_scan_u32(v);
-        if (lane_id() == 63) s_wave[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t before = carry, total = 0;
-        for (int w = 0; w < 4; ++w) { if (w < (int)(threadIdx.x >> 6)) before += s_wave[w]; total += s_wave[w]; }
-        if (r < n_reg) s_pref[r] = before + inc - v;
-        carry += total;
-        __syncthreads();
+// The pairs of a batch live in per-K1-block chunks (+ one slow-path region), each chunk in file order.
+// Both mates of a fragment usually fall into the same chunk (a chunk spans ~100 kb of the genome), so a
+// workgroup first removes duplicates among the pairs of its chunk in an LDS table and only the survivors
+// (about half) go to the global per-gene tables, whose random memory-side CAS traffic is what bounds this
+// stage.  The LDS pass is an optimisation only: whenever it cannot decide (table crowded, gene word of a
+// freshly claimed slot not yet visible) the pair is sent on, and the global table is exact.
+#define RSQC_K4_THREADS 512
+#define RSQC_K4_LSLOTS 4096
+#define RSQC_K4_PIECE 3072                      /* pairs per LDS pass (75 % load) */
+#define RSQC_K4_GSLOTS 256
+#define RSQC_K4_SLOW_BLOCKS 32
+struct K4Shared {
+    unsigned long long lkey[RSQC_K4_LSLOTS];
+    uint32_t lgene[RSQC_K4_LSLOTS];
+    uint32_t gkey[RSQC_K4_GSLOTS], gcnt[RSQC_K4_GSLOTS];
+};
+
+__global__ void __launch_bounds__(RSQC_K4_THREADS)
+dedup_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
+             const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
+             const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
+             unsigned long long *gene_frag, uint32_t mode) {
+    __shared__ K4Shared S;
+    // the pairs this workgroup owns: chunk blockIdx.x, or pieces of the slow-path region
+    uint32_t base, count, piece0 = 0, piece_step = 1;
+    if (blockIdx.x < n_chunks) {
+        base = blockIdx.x * chunk_cap;
+        count = chunk_count[blockIdx.x] < chunk_cap ? chunk_count[blockIdx.x] : chunk_cap;
+    } else {
+        base = slow_base;
+        count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
+        piece0 = blockIdx.x - n_chunks; piece_step = gridDim.x - n_chunks;
     }
-    if (threadIdx.x == 0) s_pref[n_reg] = carry;
-    __syncthreads();
-    const uint32_t n_pairs = carry;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounds = (mode & 1u) ? (n_pairs + stride - 1) / stride
-                                        : ((n_pairs + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x;
-    for (uint32_t it = 0; it < rounds; ++it) {
-        // mode bit 0: blocks interleave at 256-pair granularity (global file order); otherwise every block
-        // walks its own contiguous 1/gridDim slice of the pair sequence
-        const uint32_t per_block = (n_pairs + gridDim.x - 1) / gridDim.x;
-        const uint32_t j = (mode & 1u) ? it * stride + blockIdx.x * blockDim.x + threadIdx.x
-                                       : blockIdx.x * per_block + it * blockDim.x + threadIdx.x;
-        const bool in_range = (mode & 1u) ? j < n_pairs : (it * blockDim.x + threadIdx.x < per_block && j < n_pairs);
-        bool fresh = false; uint32_t g = 0;
-        if (in_range) {
-            uint32_t lo = 0, hi = n_reg;                         // last region with prefix <= j
-            while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (s_pref[m] <= j) lo = m; else hi = m; }
-            const uint32_t src = (lo < n_chunks ? lo * chunk_cap : slow_base) + (j - s_pref[lo]);
-            g = pair_gene[src];
-            uint64_t key = pair_hash[src];
-            if (key == 0) key = 0x9e3779b97f4a7c15ull;           // 0 marks an empty slot
-            const uint32_t cap = tab_cap[g];
-            unsigned long long *tab = table + tab_off[g];
-            uint32_t slot = (uint32_t)(mix64(key) % cap);
-            for (uint32_t probes = 0; probes < cap; ++probes) {
-                // keys are never removed, so a plain (possibly stale) load that already shows the key or
-                // another key is conclusive; only an apparently empty slot needs the device-scope CAS
-                unsigned long long old = 0ull;
-                if (mode & 2u) old = (mode & 4u) ? __builtin_nontemporal_load(&tab[slot]) : tab[slot];
-                if (old == 0ull) old = atomicCAS(&tab[slot], 0ull, (unsigned long long)key);
-                if (old == 0ull) { fresh = true; break; }
-                if (old == key) break;
-                slot = slot + 1 == cap ? 0 : slot + 1;
+    for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x) { S.gkey[i] = 0xFFFFFFFFu; S.gcnt[i] = 0u; }
+    const uint32_t n_pieces = (count + RSQC_K4_PIECE - 1) / RSQC_K4_PIECE;
+    for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < RSQC_K4_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
+        __syncthreads();
+        const uint32_t p0 = piece * RSQC_K4_PIECE, p1 = p0 + RSQC_K4_PIECE < count ? p0 + RSQC_K4_PIECE : count;
+        for (uint32_t j0 = p0; j0 < p1; j0 += blockDim.x) {
+            const uint32_t j = j0 + threadIdx.x;
+            bool survivor = false, fresh = false; uint32_t g = 0; uint64_t key = 0;
+            if (j < p1) {
+                g = pair_gene[base + j];
+                key = pair_hash[base + j];
+                if (key == 0) key = 0x9e3779b97f4a7c15ull;               // 0 marks an empty slot
+                survivor = true;
+                if (!(mode & 8u)) {
+                    // LDS key: the name hash made gene-specific by a per-gene bijection (for one gene, equal
+                    // LDS keys <=> equal hashes); the gene word settles the rest
+                    unsigned long long lk = key ^ ((unsigned long long)g * 0x9E3779B97F4A7C15ull);
+                    if (lk == 0ull) lk = 1ull;
+                    uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4_LSLOTS - 1);
+                    bool done = false;
+#pragma unroll 1
+                    for (int probe = 0; probe < 8 && !done; ++probe) {
+                        const unsigned long long old = atomicCAS(&S.lkey[slot], 0ull, lk);
+                        if (old == 0ull) { S.lgene[slot] = g; done = true; }                 // first of its kind here
+                        // (reconverged: a claimer in this wave has written its gene word by now)
+                        if (!done && old == lk) { if (S.lgene[slot] == g) survivor = false; done = true; }
+                        slot = (slot + 1) & (RSQC_K4_LSLOTS - 1);
+                    }
+                }
+            }
+            if (survivor) {
+                const uint32_t cap = tab_cap[g];
+                unsigned long long *tab = table + tab_off[g];
+                uint32_t slot = (uint32_t)(((mix64(key) >> 32) * (unsigned long long)cap) >> 32);
+                for (uint32_t probes = 0; probes < cap; ++probes) {
+                    // keys are never removed, so a plain (possibly stale) load that already shows the key or
+                    // another key is conclusive; only an apparently empty slot needs the device-scope CAS
+                    unsigned long long old = tab[slot];
+                    if (old == 0ull) old = atomicCAS(&tab[slot], 0ull, (unsigned long long)key);
+                    if (old == 0ull) { fresh = true; break; }
+                    if (old == key) break;
+                    slot = slot + 1 == cap ? 0 : slot + 1;
+                }
+            }
+            if (fresh) {                                                  // geneFragmentCounts[g]++ via the LDS table
+                uint32_t slot = g & (RSQC_K4_GSLOTS - 1);
+                bool placed = false;
+#pragma unroll 1
+                for (int probe = 0; probe < 4 && !placed; ++probe) {
+                    const uint32_t old = atomicCAS(&S.gkey[slot], 0xFFFFFFFFu, g);
+                    if (old == 0xFFFFFFFFu || old == g) { atomicAdd(&S.gcnt[slot], 1u); placed = true; }
+                    slot = (slot + 1) & (RSQC_K4_GSLOTS - 1);
+                }
+                if (!placed) atomicAdd(&gene_frag[g], 1ull);
             }
         }
-        const Run run = make_run(fresh, g);
-        if (run.head) atomicAdd(&gene_frag[g], (unsigned long long)run.count);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x)
+        if (S.gkey[i] != 0xFFFFFFFFu && S.gcnt[i]) atomicAdd(&gene_frag[S.gkey[i]], (unsigned long long)S.gcnt[i]);
+}
+
+// clears the first *total slots of the table (the count lives on the device: no host round trip)
+__global__ void __launch_bounds__(256)
+dedup_clear_kernel(unsigned long long *table, const unsigned long long *total) {
+    const unsigned long long n = *total;
+    ulonglong2 *t2 = reinterpret_cast<ulonglong2 *>(table);
+    const unsigned long long n2 = n / 2;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * blockDim.x)
+        t2[i] = make_ulonglong2(0ull, 0ull);
+    if ((n & 1ull) && blockIdx.x == 0 && threadIdx.x == 0) table[n - 1] = 0ull;
 }
 
 // per-gene table layout on the device (no host round trip): cap = 2 * geneCounts, offsets by
@@ -1084,9 +1122,13 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
                   unsigned long long *table, uint32_t mode, int grid) {
     // pair_chunk_count[n_chunks] is the slow-path counter (same allocation)
-    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, acc.pair_gene, acc.pair_hash,
+    (void)grid;
+    hipLaunchKernelGGL(dedup_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base,
                        acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag, mode);
+}
+void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total) {
+    hipLaunchKernelGGL(dedup_clear_kernel, dim3(2048), dim3(256), 0, s, table, total);
 }
 void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
                          uint32_t *tab_cap, unsigned long long *total, int *error) {
