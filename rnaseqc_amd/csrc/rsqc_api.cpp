@@ -72,6 +72,7 @@ struct rsqc_ctx {
     const uint32_t *d_ge_off = nullptr, *d_ge_row = nullptr, *d_gene_cov_off = nullptr, *d_gene_coding = nullptr;
     const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
     const uint32_t *d_gene_order = nullptr;
+    uint32_t k3_large = 0, k3_medium = 0;
     uint64_t cov_entries = 0;
     bool have_bed = false;
 
@@ -82,8 +83,8 @@ struct rsqc_ctx {
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
            off_bias5 = 0, off_ecv = 0, off_gvalid = 0, off_ecvv = 0, off_misc = 0;
-    hipStream_t stream2 = nullptr;                // K3 runs beside K4
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;   // K3 (three size classes) runs beside K4
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
     DevAccum acc{};
     uint64_t tile_cap = 0;
     std::vector<PairBuf> pair_pool;
@@ -354,6 +355,10 @@ void rsqc_destroy(rsqc_ctx *c) {
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+    if (c->ev_join4) (void)hipEventDestroy(c->ev_join4);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto *b : all) b->release();
@@ -404,6 +409,12 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     for (int g = 0; g < L; ++g) gene_order[(size_t)g] = (uint32_t)g;
     std::stable_sort(gene_order.begin(), gene_order.begin() + L, [&](uint32_t x, uint32_t y) { return gene_coding[x] > gene_coding[y]; });
     UPV(c->d_gene_order, gene_order);
+    // workgroup size classes of the end-of-file coverage stage (rsqc_kernels.hip, K3)
+    c->k3_large = c->k3_medium = 0;
+    for (int k = 0; k < L; ++k) {
+        const uint32_t len = gene_coding[gene_order[(size_t)k]];
+        if (len > (uint32_t)RSQC_K3_MEDIUM_MAX) c->k3_large++; else if (len > (uint32_t)RSQC_K3_SMALL_MAX) c->k3_medium++;
+    }
 #undef UPV
 #undef UPA
     // ---- accumulators -----------------------------------------------------------------------------
@@ -429,6 +440,10 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     const uint32_t ovf_cap = 1u << 20;
     if ((rc = dev_alloc(c, c->d_ovf_index, (size_t)ovf_cap * 8, false))) return rc;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     char *A = (char *)c->d_arena.p;
@@ -610,6 +625,8 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
         GeneCovArgs Ga{};
         Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
         Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov;
@@ -623,8 +640,17 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         Ga.g_valid = (uint8_t *)(A + c->off_gvalid); Ga.e_cv = (double *)(A + c->off_ecv); Ga.e_cv_valid = (uint8_t *)(A + c->off_ecvv);
         Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
         Ga.error = c->acc.error;
-        launch_gene_coverage(c->stream2, Ga);
+        {
+            uint32_t nl = c->k3_large, nm = c->k3_medium;
+            if (const char *e = getenv("RSQC_K3_FORCE")) {           // diagnostic: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
+                const int f = atoi(e);
+                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; } else if (f == 3) { nl = 0; nm = 0; }
+            }
+            launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm);
+        }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+        HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
+        HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
         // ---- K4 on the main stream: per-gene distinct QNAMEs ---------------------------------------------
         if ((rc = dev_alloc(c, c->d_tab_off, ((size_t)std::max(G, 1) + 2) * 8, false))) return rc;
         if ((rc = dev_alloc(c, c->d_tab_cap, (size_t)std::max(G, 1) * 4, false))) return rc;
@@ -649,6 +675,8 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
                          (unsigned long long *)c->d_table.p, (uint32_t)c->k4_mode, c->k4_grid);
         }
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         // ---- K5: fragment-size sampler (BED runs) ---------------------------------------------------

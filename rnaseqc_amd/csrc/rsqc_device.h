@@ -9,6 +9,9 @@
 #define RSQC_K1_THREADS 256
 #define RSQC_MAX_BIAS_WINDOW 1024
 #define RSQC_K3_THREADS 1024
+// coding-length classes of the end-of-file coverage stage: one wave / 256 threads with the vector in LDS, 1024 threads in memory
+#define RSQC_K3_SMALL_MAX 4096
+#define RSQC_K3_MEDIUM_MAX 12288
 #define RSQC_K3_MAX_EXONS 1024
 
 namespace rsqc {
@@ -76,7 +79,7 @@ struct GeneCovArgs {
     unsigned long long *bias3, *bias5;
     int *error;
 };
-void launch_gene_coverage(hipStream_t s, const GeneCovArgs &A);
+void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium);
 
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc);

@@ -809,95 +809,111 @@ dedup_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint
 }
 
 // ------------------------------------------------------------------ K3
-// One 1024-thread workgroup per gene, longest genes first.  cov[] holds the per-base DIFFERENCE
-// array of the gene's exons, contiguous in exonsForGene order (+1 pad slot), so a plain prefix
-// sum yields the stitched transcript vector of computeCoverage (src/Metrics.cpp:306-308).
-#define K3T RSQC_K3_THREADS
-#define K3W (RSQC_K3_THREADS / 64)
-
+// One workgroup per gene, longest genes first.  cov[] holds the per-base DIFFERENCE array of the
+// gene's exons, contiguous in exonsForGene order (+1 pad slot), so a plain prefix sum yields the
+// stitched transcript vector of computeCoverage (src/Metrics.cpp:306-308).
+// The stage is a chain of ~40 short data-parallel passes separated by workgroup barriers, so its
+// time is (genes / genes in flight) x (barriers x barrier cost): the workgroup is sized to the gene.
+// Most genes have a few thousand coding bases and run as ONE WAVE each (T = 64: barriers degenerate
+// to in-order LDS traffic and thousands of genes are in flight); longer ones get 256 or 1024 threads.
+template <int T> __device__ __forceinline__ void k3_sync() {
+    if constexpr (T > 64) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+}
+template <int T_, int WIN_, int LDSCAP_>
 struct K3Shared {
-    unsigned long long u64[K3W];
-    double f64[K3W];
-    uint32_t u32a[K3W], u32b[K3W];
+    static constexpr int T = T_, WIN = WIN_, W = T_ / 64, LDSCAP = LDSCAP_;
+    uint32_t covbuf[LDSCAP_ > 0 ? LDSCAP_ : 1];      // the gene's coverage vector when it fits (see the kernel)
+    unsigned long long u64[W];
+    double f64[W];
+    uint32_t u32a[W], u32b[W];
     uint32_t hist[256];
-    uint32_t win[2][RSQC_MAX_BIAS_WINDOW];
-    uint32_t toff[RSQC_K3_MAX_EXONS + 1];           // transcript offset of each exon
-    unsigned long long esum[RSQC_K3_MAX_EXONS];
-    double esq[RSQC_K3_MAX_EXONS];
+    uint32_t win[2][WIN];
     uint32_t bc_u32[4]; double bc_f64[2];
 };
 
-__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, K3Shared &S) {
+template <class SH> __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, SH &S) {
+    constexpr int T = SH::T;
     v = wave_sum(v);
-    __syncthreads();
+    k3_sync<T>();
     if (lane_id() == 0) S.u64[threadIdx.x >> 6] = v;
-    __syncthreads();
+    k3_sync<T>();
     unsigned long long t = 0;
 #pragma unroll
-    for (int w = 0; w < K3W; ++w) t += S.u64[w];
+    for (int w = 0; w < (T / 64); ++w) t += S.u64[w];
     return t;
 }
-__device__ __forceinline__ double block_sum_f64(double v, K3Shared &S) {
+template <class SH> __device__ __forceinline__ double block_sum_f64(double v, SH &S) {
+    constexpr int T = SH::T;
     v = wave_sum(v);
-    __syncthreads();
+    k3_sync<T>();
     if (lane_id() == 0) S.f64[threadIdx.x >> 6] = v;
-    __syncthreads();
+    k3_sync<T>();
     double t = 0;
 #pragma unroll
-    for (int w = 0; w < K3W; ++w) t += S.f64[w];
+    for (int w = 0; w < (T / 64); ++w) t += S.f64[w];
     return t;
 }
-__device__ __forceinline__ uint32_t block_min_u32(uint32_t v, K3Shared &S) {
+template <class SH> __device__ __forceinline__ uint32_t block_min_u32(uint32_t v, SH &S) {
+    constexpr int T = SH::T;
     v = wave_min_u32(v);
-    __syncthreads();
+    k3_sync<T>();
     if (lane_id() == 0) S.u32a[threadIdx.x >> 6] = v;
-    __syncthreads();
+    k3_sync<T>();
     uint32_t t = 0xFFFFFFFFu;
 #pragma unroll
-    for (int w = 0; w < K3W; ++w) t = S.u32a[w] < t ? S.u32a[w] : t;
+    for (int w = 0; w < (T / 64); ++w) t = S.u32a[w] < t ? S.u32a[w] : t;
     return t;
 }
-__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, K3Shared &S) {
+template <class SH> __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, SH &S) {
+    constexpr int T = SH::T;
     v = wave_max_u32(v);
-    __syncthreads();
+    k3_sync<T>();
     if (lane_id() == 0) S.u32a[threadIdx.x >> 6] = v;
-    __syncthreads();
+    k3_sync<T>();
     uint32_t t = 0;
 #pragma unroll
-    for (int w = 0; w < K3W; ++w) t = S.u32a[w] > t ? S.u32a[w] : t;
+    for (int w = 0; w < (T / 64); ++w) t = S.u32a[w] > t ? S.u32a[w] : t;
     return t;
 }
 
 // quirky computeMedian (src/Metrics.h:147-160) of a window held in LDS (unsorted): the two middle
 // order statistics are found by rank counting.  Called by the whole block; result broadcast.
-__device__ bool window_median(const uint32_t *w, uint32_t n, double *out, K3Shared &S) {
+template <class SH> __device__ bool window_median(const uint32_t *w, uint32_t n, double *out, SH &S) {
+    constexpr int T = SH::T;
     if (n == 0) return false;
     if (n == 1) { *out = (double)w[0]; return true; }
     const uint32_t mid = (n - 1) / 2;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    k3_sync<T>();
+    for (uint32_t i = threadIdx.x; i < n; i += T) {
         const uint32_t v = w[i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; ++j) { const uint32_t u = w[j]; rank += (u < v || (u == v && j < i)) ? 1u : 0u; }
         if (rank == mid) S.bc_u32[0] = v;
         if (rank == mid + 1) S.bc_u32[1] = v;
     }
-    __syncthreads();
+    k3_sync<T>();
     *out = (n & 1u) ? ((double)S.bc_u32[0] + (double)S.bc_u32[1]) / 2.0 : (double)S.bc_u32[0];
     return true;
 }
 
-__global__ void __launch_bounds__(RSQC_K3_THREADS)
-gene_coverage_kernel(GeneCovArgs A) {
-    __shared__ K3Shared S;
+template <int T, int WIN, int LDSCAP>
+__global__ void __launch_bounds__(T)
+gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
+    __shared__ K3Shared<T, WIN, LDSCAP> S;
     const int tid = (int)threadIdx.x;
     const int l = lane_id();
     const int wv = tid >> 6;
-    const int gene = (int)A.gene_order[blockIdx.x];
+    const int gene = (int)A.gene_order[first + blockIdx.x];
     if (!A.gene_owned[gene]) return;
     const uint32_t coding = A.gene_coding[gene];
     const uint32_t e0 = A.ge_off[gene], e1 = A.ge_off[gene + 1], n_ex = e1 - e0;
-    uint32_t *C = A.cov + A.gene_cov_off[gene];
+    // Every later pass re-reads the coverage vector; a gene that fits keeps it in LDS (the difference array is
+    // read from memory once and never written back: nothing downstream needs it), longer genes scan in place
+    // in memory and rely on unrolled, independent loads.
+    uint32_t *const D = A.cov + A.gene_cov_off[gene];
+    uint32_t *C;
+    if constexpr (LDSCAP > 0) C = coding <= (uint32_t)LDSCAP ? S.covbuf : D; else C = D;    // (mis-classified gene: still correct)
     const uint32_t MASK = A.mask;
     const uint32_t W = (uint32_t)A.bias_window, OFF = (uint32_t)A.bias_offset;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
@@ -917,18 +933,18 @@ gene_coverage_kernel(GeneCovArgs A) {
     // (1) difference array -> coverage: block-wide inclusive scan, 4 bases per thread per round
     {
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < coding; base += K3T * 4) {
+        for (uint32_t base = 0; base < coding; base += T * 4) {
             const uint32_t j = base + (uint32_t)tid * 4;
-            uint32_t v0 = j < coding ? C[j] : 0u, v1 = j + 1 < coding ? C[j + 1] : 0u,
-                     v2 = j + 2 < coding ? C[j + 2] : 0u, v3 = j + 3 < coding ? C[j + 3] : 0u;
+            uint32_t v0 = j < coding ? D[j] : 0u, v1 = j + 1 < coding ? D[j + 1] : 0u,
+                     v2 = j + 2 < coding ? D[j + 2] : 0u, v3 = j + 3 < coding ? D[j + 3] : 0u;
             v1 += v0; v2 += v1; v3 += v2;
             const uint32_t inc = wave_inclusive_scan_u32(v3);
-            __syncthreads();
+            k3_sync<T>();
             if (l == 63) S.u32b[wv] = inc;
-            __syncthreads();
+            k3_sync<T>();
             uint32_t before = carry, total = 0;
 #pragma unroll
-            for (int w = 0; w < K3W; ++w) { const uint32_t t = S.u32b[w]; if (w < wv) before += t; total += t; }
+            for (int w = 0; w < (T / 64); ++w) { const uint32_t t = S.u32b[w]; if (w < wv) before += t; total += t; }
             const uint32_t ex = before + inc - v3;
             if (j < coding) C[j] = v0 + ex;
             if (j + 1 < coding) C[j + 1] = v1 + ex;
@@ -938,55 +954,29 @@ gene_coverage_kernel(GeneCovArgs A) {
         }
     }
     __threadfence_block();
-    __syncthreads();
-    // (2) per-exon CV over transcript positions [MASK, coding-MASK) (src/Metrics.cpp:267-305)
+    k3_sync<T>();
+    // (2) per-exon CV over transcript positions [MASK, coding-MASK) (src/Metrics.cpp:267-305): one wave per
+    //     exon at a time (an exon's bases are contiguous in C): register sums, no shared accumulators
     {
         const uint64_t lo_t = MASK, hi_t = coding > MASK ? coding - MASK : 0;
-        if (hi_t > lo_t && n_ex <= RSQC_K3_MAX_EXONS) {
-            for (uint32_t k = tid; k < n_ex; k += K3T) {
-                S.toff[k] = A.ex_cov[A.ge_row[e0 + k]] - A.gene_cov_off[gene];
-                S.esum[k] = 0ull; S.esq[k] = 0.0;
-            }
-            if (tid == 0) S.toff[n_ex] = coding;
-            __syncthreads();
-            auto exon_of = [&](uint32_t j) { uint32_t lo = 0, hi = n_ex; while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (S.toff[m] <= j) lo = m; else hi = m; } return lo; };
-            for (uint32_t j = (uint32_t)lo_t + tid; j < hi_t; j += K3T) atomicAdd(&S.esum[exon_of(j)], (unsigned long long)C[j]);
-            __syncthreads();
-            for (uint32_t j = (uint32_t)lo_t + tid; j < hi_t; j += K3T) {
-                const uint32_t k = exon_of(j);
-                const uint64_t a0 = S.toff[k] > lo_t ? S.toff[k] : lo_t, b0 = S.toff[k + 1] < hi_t ? S.toff[k + 1] : hi_t;
-                const double mean = (double)S.esum[k] / (double)(b0 - a0);
-                const double d = (double)C[j] - mean;
-                atomicAdd(&S.esq[k], d * d);
-            }
-            __syncthreads();
-            for (uint32_t k = tid; k < n_ex; k += K3T) {
-                const uint64_t a0 = S.toff[k] > lo_t ? S.toff[k] : lo_t, b0 = S.toff[k + 1] < hi_t ? S.toff[k + 1] : hi_t;
-                if (b0 > a0) {
-                    const double size = (double)(b0 - a0), mean = (double)S.esum[k] / size;
-                    const double cv = sqrt(S.esq[k] / size) / mean;
-                    if (!(isnan(cv) || isinf(cv))) { const uint32_t row = A.ge_row[e0 + k]; A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
-                }
-            }
-            __syncthreads();
-        } else if (hi_t > lo_t) {
-            // more exons than the LDS table holds: one exon at a time
-            uint32_t t0 = 0;
-            for (uint32_t k = 0; k < n_ex; ++k) {
+        if (hi_t > lo_t) {
+            for (uint32_t k = (uint32_t)wv; k < n_ex; k += (uint32_t)(T / 64)) {
                 const uint32_t row = A.ge_row[e0 + k];
-                const uint32_t len = (uint32_t)(A.ex[row].end - A.ex[row].start + 1);
+                const ExonRow er = A.ex[row];
+                const uint32_t t0 = er.cov - A.gene_cov_off[gene], len = (uint32_t)(er.end - er.start + 1);
                 const uint64_t a0 = t0 > lo_t ? t0 : lo_t, b0 = (uint64_t)t0 + len < hi_t ? (uint64_t)t0 + len : hi_t;
                 if (b0 > a0) {
                     const double size = (double)(b0 - a0);
                     unsigned long long sm = 0;
-                    for (uint32_t j = (uint32_t)a0 + tid; j < b0; j += K3T) sm += C[j];
-                    const double mean = (double)block_sum_u64(sm, S) / size;
+#pragma unroll 4
+                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) sm += C[j];
+                    const double mean = (double)wave_sum(sm) / size;
                     double q = 0.0;
-                    for (uint32_t j = (uint32_t)a0 + tid; j < b0; j += K3T) { const double d = (double)C[j] - mean; q += d * d; }
-                    const double cv = sqrt(block_sum_f64(q, S) / size) / mean;
-                    if (tid == 0 && !(isnan(cv) || isinf(cv))) { A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
+#pragma unroll 4
+                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) { const double d = (double)C[j] - mean; q += d * d; }
+                    const double cv = sqrt(wave_sum(q) / size) / mean;
+                    if (l == 0 && !(isnan(cv) || isinf(cv))) { A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
                 }
-                t0 += len;
             }
         }
     }
@@ -994,18 +984,20 @@ gene_coverage_kernel(GeneCovArgs A) {
     uint32_t v0 = 0, v1 = coding;          // the (possibly trimmed) vector the gene stats use (Q14)
     if (coding >= A.bias_gene_length) {
         uint32_t best = 0, best_i = 0xFFFFFFFFu;
-        for (uint32_t j = tid; j < coding; j += K3T) { const uint32_t v = C[j]; if (v > best) { best = v; best_i = j; } }
+        unsigned long long nz = 0;
+#pragma unroll 8
+        for (uint32_t j = tid; j < coding; j += T) { const uint32_t v = C[j]; nz += v != 0u; if (v > best) { best = v; best_i = j; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const uint32_t ob = __shfl_xor(best, o, 64), oi = __shfl_xor(best_i, o, 64);
             if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
         }
-        __syncthreads();
+        k3_sync<T>();
         if (l == 0) { S.u32a[wv] = best; S.u32b[wv] = best_i; }
-        __syncthreads();
+        k3_sync<T>();
         best = 0; best_i = 0xFFFFFFFFu;
 #pragma unroll
-        for (int w = 0; w < K3W; ++w) { const uint32_t ob = S.u32a[w], oi = S.u32b[w]; if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; } }
+        for (int w = 0; w < (T / 64); ++w) { const uint32_t ob = S.u32a[w], oi = S.u32b[w]; if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; } }
         const uint32_t pp = best == 0 ? 0u : best_i;
         uint32_t cur = pp + W / 2 < coding ? pp + W / 2 : coding;
         const uint32_t n = W < cur ? W : cur;
@@ -1019,20 +1011,26 @@ gene_coverage_kernel(GeneCovArgs A) {
         }
         if (n != 0 && gate >= 100.0) {
             // 5th percentile of the non-zero coverage = order statistic R of the whole vector
-            unsigned long long nz = 0;
-            for (uint32_t j = tid; j < coding; j += K3T) nz += C[j] != 0u;
             const uint32_t nnz = (uint32_t)block_sum_u64(nz, S);
             uint32_t R = (coding - nnz) + (uint32_t)((double)nnz * 0.05);
             uint32_t prefix = 0, pmask = 0;
-            for (int shift = 24; shift >= 0; shift -= 8) {          // MSB-first radix select
-                __syncthreads();
-                if (tid < 256) S.hist[tid] = 0;
-                __syncthreads();
-                for (uint32_t j = tid; j < coding; j += K3T) {
-                    const uint32_t v = C[j];
-                    if ((v & pmask) == prefix) atomicAdd(&S.hist[(v >> shift) & 0xFF], 1u);
+            // MSB-first radix select; bytes above the top non-zero byte of the maximum are zero for every entry
+            const int top = best >> 24 ? 24 : best >> 16 ? 16 : best >> 8 ? 8 : 0;
+            pmask = top == 24 ? 0u : 0xFFFFFFFFu << (top + 8);
+            for (int shift = top; shift >= 0; shift -= 8) {
+                k3_sync<T>();
+                for (int h = tid; h < 256; h += T) S.hist[h] = 0;
+                k3_sync<T>();
+                for (uint32_t j0 = 0; j0 < coding; j0 += T) {          // neighbouring bases have similar depth: one LDS
+                    const uint32_t j = j0 + (uint32_t)tid;                 // atomic per distinct digit of the wave
+                    const uint32_t v = j < coding ? C[j] : 0u;
+                    const bool in = j < coding && (v & pmask) == prefix;
+                    const uint32_t dg = (v >> shift) & 0xFF;
+                    wave_by_key(in, dg, [&](int lead, uint32_t d0, bool, uint64_t same) {
+                        if (l == lead) atomicAdd(&S.hist[d0], (uint32_t)__popcll(same));
+                    });
                 }
-                __syncthreads();
+                k3_sync<T>();
                 if (wv == 0) {                                       // wave 0: lane x scans 4 bins
                     const uint32_t h0 = S.hist[4 * l], h1 = S.hist[4 * l + 1], h2 = S.hist[4 * l + 2], h3 = S.hist[4 * l + 3];
                     const uint32_t tot = h0 + h1 + h2 + h3;
@@ -1047,14 +1045,15 @@ gene_coverage_kernel(GeneCovArgs A) {
                         S.bc_u32[2] = digit; S.bc_u32[3] = rbase;
                     }
                 }
-                __syncthreads();
+                k3_sync<T>();
                 R -= S.bc_u32[3];
                 prefix |= S.bc_u32[2] << shift; pmask |= 0xFFu << shift;
             }
             const uint32_t lower = prefix;
             // trim leading / trailing entries <= lower (in place in the reference: Q14)
             uint32_t first_gt = 0xFFFFFFFFu, last_gt = 0;
-            for (uint32_t j = tid; j < coding; j += K3T) if (C[j] > lower) { if (first_gt == 0xFFFFFFFFu) first_gt = j; last_gt = j + 1; }
+#pragma unroll 8
+            for (uint32_t j = tid; j < coding; j += T) if (C[j] > lower) { if (first_gt == 0xFFFFFFFFu) first_gt = j; last_gt = j + 1; }
             first_gt = block_min_u32(first_gt, S);
             last_gt = block_max_u32(last_gt, S);
             if (first_gt == 0xFFFFFFFFu) { v0 = coding; v1 = coding; } else { v0 = first_gt; v1 = last_gt; }
@@ -1065,10 +1064,10 @@ gene_coverage_kernel(GeneCovArgs A) {
                 const uint32_t nl = OFF < lhi ? lhi - OFF : 0u;
                 uint32_t nr = 0, rlo = 0;
                 if ((uint64_t)W + OFF <= tlen) { rlo = tlen - W - OFF; nr = W; }
-                __syncthreads();
-                for (uint32_t j = tid; j < nl; j += K3T) S.win[0][j] = C[v0 + OFF + j];
-                for (uint32_t j = tid; j < nr; j += K3T) S.win[1][j] = C[v0 + rlo + j];
-                __syncthreads();
+                k3_sync<T>();
+                for (uint32_t j = tid; j < nl; j += T) S.win[0][j] = C[v0 + OFF + j];
+                for (uint32_t j = tid; j < nr; j += T) S.win[1][j] = C[v0 + rlo + j];
+                k3_sync<T>();
                 double ml = 0.0, mr = 0.0;
                 const bool okl = window_median(S.win[0], nl, &ml, S);
                 const bool okr = window_median(S.win[1], nr, &mr, S);
@@ -1091,10 +1090,12 @@ gene_coverage_kernel(GeneCovArgs A) {
         if (bnd > a) {
             const double size = (double)(bnd - a);
             unsigned long long sm = 0;
-            for (uint32_t j = a + tid; j < bnd; j += K3T) sm += C[j];
+#pragma unroll 8
+            for (uint32_t j = a + tid; j < bnd; j += T) sm += C[j];
             const double mean = (double)block_sum_u64(sm, S) / size;
             double q = 0.0;
-            for (uint32_t j = a + tid; j < bnd; j += K3T) { const double d = (double)C[j] - mean; q += d * d; }
+#pragma unroll 8
+            for (uint32_t j = a + tid; j < bnd; j += T) { const double d = (double)C[j] - mean; q += d * d; }
             const double sd = sqrt(block_sum_f64(q, S) / size);
             if (tid == 0) { A.g_valid[gene] = 1; A.g_mean[gene] = mean; A.g_std[gene] = sd; A.g_cv[gene] = sd / mean; }
         } else if (tid == 0) A.g_valid[gene] = 0;
@@ -1134,9 +1135,22 @@ void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, ui
                          uint32_t *tab_cap, unsigned long long *total, int *error) {
     hipLaunchKernelGGL(dedup_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, tab_off, tab_cap, total, error);
 }
-void launch_gene_coverage(hipStream_t s, const GeneCovArgs &A) {
+void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium) {
     if (A.n_listed <= 0) return;
-    hipLaunchKernelGGL(gene_coverage_kernel, dim3(A.n_listed), dim3(RSQC_K3_THREADS), 0, s, A);
+    // gene_order is sorted by coding length, longest first: [0, n_large) x 1024 threads,
+    // [n_large, n_large + n_medium) x 256 threads, the rest one wave each; the three launches are independent
+    // (disjoint genes) and go to three streams so that they overlap
+    const uint32_t n = (uint32_t)A.n_listed, n_small = n - n_large - n_medium;
+    const bool wide = A.bias_window > 128;
+#define RSQC_K3_LAUNCH(T, CAP, COUNT, FIRST, STREAM)                                                                         \
+    if (COUNT) {                                                                                                        \
+        if (wide) hipLaunchKernelGGL((gene_coverage_kernel<T, RSQC_MAX_BIAS_WINDOW, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST); \
+        else hipLaunchKernelGGL((gene_coverage_kernel<T, 128, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST);        \
+    }
+    RSQC_K3_LAUNCH(1024, 0, n_large, 0u, s)
+    RSQC_K3_LAUNCH(256, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
+    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
+#undef RSQC_K3_LAUNCH
 }
 
 }  // namespace rsqc
