@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/p$i.log 2>&1
+  timeout 100 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, json
