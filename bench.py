@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=5_000_000, help="read pairs per GPU (2 records each)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-finalize", action="store_true", help="(diagnostic) time K1 only; output marked invalid")
+    ap.add_argument("--genome", action="store_true",
+                    help="BASELINE.json configs[2] shape on ONE GPU: GENCODE-sized annotation (25 contigs, 56 202 genes); "
+                         "not the default bench line")
     args = ap.parse_args()
 
     import torch
@@ -62,6 +65,10 @@ def main():
     # ---- synthetic inputs: N chr1-like contigs, rank k owns contig k -----------------------------
     chr1 = synth.HUMAN_CONTIGS[0]
     contigs = [("chr1_%d" % k, chr1[1], chr1[2]) for k in range(world)] if world > 1 else [chr1]
+    if args.genome:
+        if world > 1:
+            raise SystemExit("--genome is a single-GPU diagnostic")
+        contigs = synth.human_contigs()
     ann = synth.make_annotation(seed=1, contigs=contigs)
     # every rank generates the records of ITS contig only (same annotation everywhere)
     t_gen = time.time()
@@ -124,7 +131,7 @@ def main():
         # (FETCH_SIZE and WRITE_SIZE cannot share a pass); tools_pmc.sh stores them in profiles/k1_traffic.json
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.pairs == 5_000_000:
+        if os.path.exists(tpath) and world == 1 and args.pairs == 5_000_000 and not args.genome:
             tj = json.load(open(tpath))
             traffic = tj.get("hbm_bytes_per_launch")
         k1_ms = tm["classify_ms"] / max(tm["classify_launches"], 1)
@@ -155,7 +162,10 @@ def main():
             "vs_baseline": None,
             "dtype": "i32/u64 counters, f64 exon fractions",
             "data": "synthetic (seeded generator rnaseqc_amd/synth.py; no real GENCODE/BAM offline)",
-            "config": {"workload": "configs[1]: chr1-like collapsed GTF (%d genes, %d exons per contig) + %d records/GPU, "
+            "config": {"workload": ("configs[2] shape: GENCODE-sized collapsed GTF (%d genes, %d exons, 25 contigs) + %d records, "
+                                    "device-resident SoA, full pass incl. end-of-file stage" % (ann.n_genes, ann.n_exons, batch.n))
+                                   if args.genome else
+                                   "configs[1]: chr1-like collapsed GTF (%d genes, %d exons per contig) + %d records/GPU, "
                                    "device-resident SoA, full pass incl. end-of-file stage" %
                                    (chr1[2], ann.n_exons // max(world, 1), batch.n),
                        "records_per_gpu": int(batch.n), "contigs": world, "sharding": "by contig",

@@ -59,7 +59,7 @@ struct rsqc_ctx {
     std::string last_error;
     int sticky = 0;
     int k4_mode = 2, k4_grid = 2048;
-    int k1_variant = 3, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
+    int k1_variant = 41, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
 
     // annotation (host copies needed at finalize)
     bool have_ann = false;

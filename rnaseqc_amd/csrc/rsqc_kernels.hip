@@ -273,7 +273,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (moved) load_contig();
         }
         const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
-        FeatureOut<FAST_SET> fo;
+        FeatureOut<FAST_SET, NSLOT> fo;
         fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0; fo.cmask = 0;
         uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
         // Everything that depends only on the gate cascade (scalar counters, Read-Length inputs, the
@@ -376,7 +376,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         // (no wave-wide merging, no carried state); per-base coverage goes to memory as a difference
         // array, identical neighbouring slots merged into one atomic.
 #pragma unroll
-        for (int k = 0; k < NSTAGE; ++k) {
+        for (int k = 0; k < NSLOT; ++k) {
             const bool has = (fo.cmask >> k) & 1u;
             const uint64_t hm = __ballot(has);
             if (hm == 0ull) continue;

@@ -326,25 +326,6 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
 // max differs from their own end, blocks that still reach a third row, or blocks that span more
 // than two gene boundaries go back to memory.  Lanes without a given block load entry 0 of each
 // table (one shared line) and ignore it.
-struct BlockHits { uint32_t row[FAST_HITS], gf[FAST_HITS], cidx[FAST_HITS]; int n; bool over; };
-
-RSQC_HD void fast_test_exon(const ExonRow &row, uint32_t i, int32_t bs, int32_t be, int rstrand, ClassFlags &f, BlockHits &h) {
-    if (row.start > be || row.end < bs) return;
-    const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
-    const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
-    if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) return;
-    if (fs == RSQC_STRAND_FORWARD) f.plus = true; else if (fs == RSQC_STRAND_REVERSE) f.minus = true;
-    f.exonic = true;
-    if (fl & ROWF_RIBOSOMAL) f.ribosomal = true;
-    if (row.start <= bs && row.end >= be - 1) {          // fully contained
-        if (h.n < FAST_HITS) {
-#pragma unroll
-            for (int k = 0; k < FAST_HITS; ++k) if (k == h.n) { h.row[k] = i; h.gf[k] = row.gf; h.cidx[k] = row.cov + (uint32_t)(bs - row.start); }
-            ++h.n;
-        } else h.over = true;
-    }
-}
-
 struct FastBins { uint32_t ehi[FAST_BLOCKS], nxt[FAST_BLOCKS]; uint32_t have; };   // bit k: block k exists and its contig has features
 struct FastRows { ExonRow e0, e1; GeneBreak g0, g1, g2; };
 
@@ -377,53 +358,6 @@ RSQC_HD void fast_load_rows(const DevAnnotation &a, const ContigInfo &ci, uint32
 RSQC_HD int32_t row_pmax(const DevAnnotation &a, const ExonRow &row, uint32_t i) {
     return ((row.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) ? ld32(a.ex_pmax, i) : row.end;
 }
-RSQC_HD void fast_resolve_block(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, int32_t be, int rstrand,
-                                uint32_t ehi, uint32_t nxt, bool have, const FastRows &fr, ClassFlags &f, BlockHits &h) {
-    h.n = 0; h.over = false;
-    if (!have) return;
-    if (ci.gb_hi != ci.gb_lo) {                                 // gene_mask() on the three staged breakpoints
-        const int32_t bsc = bs < 0 ? 0 : bs;
-        const bool v0 = nxt > ci.gb_lo, v1 = nxt < ci.gb_hi, v2 = nxt + 1 < ci.gb_hi, more = nxt + 2 < ci.gb_hi;
-        uint32_t mask; bool deeper = false;
-        if (v1 && fr.g1.pos <= bsc) {
-            if (v2 && fr.g2.pos <= bsc) deeper = true;
-            mask = fr.g1.mask;
-            if (v2 && fr.g2.pos <= be) { mask |= fr.g2.mask; if (more) deeper = true; }
-        } else {
-            mask = v0 ? fr.g0.mask : 0u;
-            if (v1 && fr.g1.pos <= be) {
-                mask |= fr.g1.mask;
-                if (v2 && fr.g2.pos <= be) { mask |= fr.g2.mask; if (more) deeper = true; }
-            }
-        }
-        if (deeper) mask = gene_mask(a, ci, bs, be);
-        apply_gene_mask(mask, rstrand, f);
-    }
-    const uint32_t en = ehi - ci.ex_lo;
-    if (en > 0) {
-        int32_t pm0 = fr.e0.end, pm1 = fr.e1.end;
-        const bool x0 = ((fr.e0.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
-        const bool x1 = en > 1 && ((fr.e1.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
-        if (x0 || x1) {                                        // both from memory in one round trip
-            const int32_t q0 = ld32(a.ex_pmax, ehi - 1), q1 = ld32(a.ex_pmax, en > 1 ? ehi - 2 : ehi - 1);
-            if (x0) pm0 = q0;
-            if (x1) pm1 = q1;
-        }
-        if (pm0 >= bs) {
-            fast_test_exon(fr.e0, ehi - 1, bs, be, rstrand, f, h);
-            if (en > 1 && pm1 >= bs) {
-                fast_test_exon(fr.e1, ehi - 2, bs, be, rstrand, f, h);
-                for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
-                    --i;
-                    const ExonRow row = ld32(a.ex, i);
-                    if (row_pmax(a, row, i) < bs) break;
-                    fast_test_exon(row, i, bs, be, rstrand, f, h);
-                }
-            }
-        }
-    }
-}
-
 struct Commit { uint32_t row, cidx, len; };    // exon row, coverage index of the block's first base, block length
 constexpr int NSTAGE = 4;
 
@@ -476,88 +410,160 @@ RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f
     return bits;
 }
 
+// ---- the fast feature stage ------------------------------------------------------------------
+// Written as straight-line predicated arithmetic: in a 64-lane wave every branch of a per-record
+// decision tree is taken by some lane, so divergent control flow only adds exec-mask bookkeeping.
+// Branches remain only where a lane must go back to memory (rows beyond the two staged ones, a
+// running-max column entry, more than two gene boundaries) and around the second round of loads
+// (wave-uniform: skipped when no lane has a third block).
+//
+// Commit slots are positional: slots 2b and 2b + 1 hold the (at most two) exons that contain block b.
+// `cmask` selects the slots whose gene survived the intersection over all blocks.
+constexpr int NSLOT = 2 * FAST_BLOCKS;
+constexpr uint32_t CF_INTRAGENIC = 1u, CF_PLUS = 2u, CF_MINUS = 4u, CF_RIBOSOMAL = 8u, CF_EXONIC = 16u;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQC_ANY_LANE(x) (__ballot(x) != 0ull)
+#else
+#define RSQC_ANY_LANE(x) (x)
+#endif
+
+// gene-row part of the feature loop (apply_gene_mask) as flag bits
+RSQC_HD uint32_t gene_class_flags(uint32_t mask, int rstrand) {
+    uint32_t present = mask & 7u, ribo = (mask >> 3) & 7u;
+    const uint32_t sel = rstrand == RSQC_STRAND_UNKNOWN ? 7u : 1u << rstrand;                  // :331
+    present &= sel; ribo &= sel;
+    return (present ? CF_INTRAGENIC : 0u) | ((present & (1u << RSQC_STRAND_FORWARD)) ? CF_PLUS : 0u) |
+           ((present & (1u << RSQC_STRAND_REVERSE)) ? CF_MINUS : 0u) | (ribo ? CF_RIBOSOMAL : 0u);
+}
+// one exon row against one block: bit 0 = overlaps (strand-compatible), bit 1 = contains the block;
+// the class flags of an overlapping row are OR-ed into cf
+RSQC_HD uint32_t exon_row_test(const ExonRow &row, bool reach, int32_t bs, int32_t be, int rstrand, uint32_t &cf) {
+    const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
+    const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
+    const bool ov = reach && row.start <= be && row.end >= bs && (rstrand == RSQC_STRAND_UNKNOWN || rstrand == fs);
+    const uint32_t add = CF_EXONIC | (fs == RSQC_STRAND_FORWARD ? CF_PLUS : fs == RSQC_STRAND_REVERSE ? CF_MINUS : 0u) |
+                         ((fl & ROWF_RIBOSOMAL) ? CF_RIBOSOMAL : 0u);
+    cf |= ov ? add : 0u;
+    // partialIntersect == end - start  <=>  start <= bs && end >= be - 1   (src/GTF.cpp:181-186)
+    const bool con = ov && row.start <= bs && row.end >= be - 1;
+    return (ov ? 1u : 0u) | (con ? 2u : 0u);
+}
+
 // `ci` is the ContigInfo of the record's contig (wave-uniform in the kernel).  ROUND = blocks whose row
 // loads are in flight together (registers vs. round trips).
 template <int ROUND = 2>
 RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl,
-                               const Blocks &B, bool hq, uint32_t aligned, FeatureOut<FAST_SET> &out, bool &overflow) {
+                               const Blocks &B, bool hq, uint32_t aligned, FeatureOut<FAST_SET, NSLOT> &out, bool &overflow) {
     out.bits = 0; out.n_hit = 0; out.n_commit = 0; out.cmask = 0;
-    overflow = B.nb > (uint32_t)FAST_BLOCKS;
-    if (overflow) return;
     const int rstrand = read_strand_of(p, fl);
-    ClassFlags f = {false, false, false, false, false};
-    uint32_t last[FAST_SET] = {0, 0}; int nlast = 0; uint32_t last_globin = 0;
-    uint32_t st_gene[NSTAGE]; int nst = 0;       // staged hits live in out.commit[]; cmask selects the counted ones
-    bool over = false;
+    uint32_t cf = 0;                                          // CF_* class flags of the whole record
+    uint32_t la = 0, lb = 0; bool va = false, vb = false, ga = false, gb = false;   // gene set common to all blocks so far
+    uint32_t sgene[NSLOT]; uint32_t con = 0;                  // gene of each slot; bit s: slot s holds a containing exon
+    bool over = B.nb > (uint32_t)FAST_BLOCKS;
 #pragma unroll
-    for (int k = 0; k < NSTAGE; ++k) { out.commit[k].row = 0; out.commit[k].cidx = 0; out.commit[k].len = 0; st_gene[k] = 0; }
-    out.cmask = 0;
+    for (int k = 0; k < NSLOT; ++k) { out.commit[k].row = 0; out.commit[k].cidx = 0; out.commit[k].len = 0; sgene[k] = 0; }
     FastBins fb;
     fast_load_bins(a, ci, B, fb);
 #pragma unroll
     for (int b0 = 0; b0 < FAST_BLOCKS; b0 += ROUND) {
-        if (b0 > 0 && B.nb <= (uint32_t)b0) break;
+        if (b0 > 0 && !RSQC_ANY_LANE(B.nb > (uint32_t)b0)) break;
         FastRows fr[ROUND];
 #pragma unroll
         for (int j = 0; j < ROUND; ++j) fast_load_rows(a, ci, fb.ehi[b0 + j], fb.nxt[b0 + j], ((fb.have >> (b0 + j)) & 1u) != 0, fr[j]);
 #pragma unroll
         for (int j = 0; j < ROUND; ++j) {
             const int b = b0 + j;
-            if ((uint32_t)b < B.nb) {
-                const int32_t bs = B.bs[b], be = B.bs[b] + (int32_t)B.len[b];
-                BlockHits h;
-                fast_resolve_block(a, ci, bs, be, rstrand, fb.ehi[b], fb.nxt[b], ((fb.have >> b) & 1u) != 0, fr[j], f, h);
-                over |= h.over;
-                uint32_t cur[FAST_SET] = {0, 0}; int ncur = 0;
-#pragma unroll
-                for (int e = 0; e < FAST_HITS; ++e) {
-                    if (e < h.n) {
-                        const uint32_t g = h.gf[e] & ROW_GENE_MASK;
-                        if (nst < NSTAGE) {
-#pragma unroll
-                            for (int k = 0; k < NSTAGE; ++k) if (k == nst) { out.commit[k].row = h.row[e]; out.commit[k].cidx = h.cidx[e]; out.commit[k].len = B.len[b]; st_gene[k] = g; }
-                            ++nst;
-                        } else over = true;
-                        if (b == 0) {
-                            if (!set_contains<FAST_SET>(last, nlast, g)) {
-                                if (nlast < FAST_SET) { if ((h.gf[e] >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) last_globin |= 1u << nlast; set_put<FAST_SET>(last, nlast, g); ++nlast; }
-                                else over = true;
-                            }
-                        } else if (!set_contains<FAST_SET>(cur, ncur, g)) {
-                            if (ncur < FAST_SET) { set_put<FAST_SET>(cur, ncur, g); ++ncur; } else over = true;
-                        }
+            const bool act = (uint32_t)b < B.nb && ((fb.have >> b) & 1u) != 0;
+            const int32_t bs = B.bs[b], be = B.bs[b] + (int32_t)B.len[b];
+            const uint32_t ehi = fb.ehi[b], nxt = fb.nxt[b];
+            const FastRows &r = fr[j];
+            // -- genes: gene_mask() on the three staged breakpoints
+            {
+                const bool hg = act && ci.gb_hi != ci.gb_lo;
+                const int32_t bsc = bs < 0 ? 0 : bs;
+                const bool v0 = nxt > ci.gb_lo, v1 = nxt < ci.gb_hi, v2 = nxt + 1 < ci.gb_hi, more = nxt + 2 < ci.gb_hi;
+                const bool adv = v1 && r.g1.pos <= bsc;                       // the block starts at or after g1
+                const bool in1 = v1 && r.g1.pos <= be, in2 = v2 && r.g2.pos <= be;
+                uint32_t mask = adv ? r.g1.mask : ((v0 ? r.g0.mask : 0u) | (in1 ? r.g1.mask : 0u));
+                mask |= (in2 && (adv || in1)) ? r.g2.mask : 0u;
+                const bool deeper = (adv && v2 && r.g2.pos <= bsc) || (in2 && (adv || in1) && more);
+                if (hg && deeper) mask = gene_mask(a, ci, bs, be);
+                cf |= hg ? gene_class_flags(mask, rstrand) : 0u;
+            }
+            // -- exons: the two staged rows; further rows only while the running max still reaches the block
+            const uint32_t en = ehi - ci.ex_lo;
+            int32_t pm0 = r.e0.end, pm1 = r.e1.end;
+            {
+                const bool x0 = act && en > 0 && ((r.e0.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
+                const bool x1 = act && en > 1 && ((r.e1.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
+                if (x0 || x1) {                                              // both from memory in one round trip
+                    const int32_t q0 = ld32(a.ex_pmax, ehi - 1), q1 = ld32(a.ex_pmax, en > 1 ? ehi - 2 : ehi - 1);
+                    if (x0) pm0 = q0;
+                    if (x1) pm1 = q1;
+                }
+            }
+            const bool reach0 = act && en > 0 && pm0 >= bs, reach1 = reach0 && en > 1 && pm1 >= bs;
+            const uint32_t t0 = exon_row_test(r.e0, reach0, bs, be, rstrand, cf);
+            const uint32_t t1 = exon_row_test(r.e1, reach1, bs, be, rstrand, cf);
+            const bool k0 = (t0 & 2u) != 0, k1 = (t1 & 2u) != 0;
+            // the block's (at most two) containing exons, in row order: A then B
+            bool c0 = k0 || k1, c1 = k0 && k1;
+            uint32_t rowA = k0 ? ehi - 1 : ehi - 2, gfA = k0 ? r.e0.gf : r.e1.gf, rowB = ehi - 2, gfB = r.e1.gf;
+            uint32_t cidxA = k0 ? r.e0.cov + (uint32_t)(bs - r.e0.start) : r.e1.cov + (uint32_t)(bs - r.e1.start);
+            uint32_t cidxB = r.e1.cov + (uint32_t)(bs - r.e1.start);
+            if (reach1) {
+                for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
+                    --i;
+                    const ExonRow row = ld32(a.ex, i);
+                    if (row_pmax(a, row, i) < bs) break;
+                    if (exon_row_test(row, true, bs, be, rstrand, cf) & 2u) {
+                        const uint32_t cx = row.cov + (uint32_t)(bs - row.start);
+                        if (!c0) { c0 = true; rowA = i; gfA = row.gf; cidxA = cx; }
+                        else if (!c1) { c1 = true; rowB = i; gfB = row.gf; cidxB = cx; }
+                        else over = true;                                                   // a third containing exon
                     }
                 }
-                if (b > 0) {                                   // set_intersection, :368-374
-                    int w = 0; uint32_t wg = 0;
-#pragma unroll
-                    for (int k = 0; k < FAST_SET; ++k) {
-                        if (k < nlast && set_contains<FAST_SET>(cur, ncur, last[k])) {
-                            if ((last_globin >> k) & 1u) wg |= 1u << w;
-                            set_put<FAST_SET>(last, w, last[k]); ++w;
-                        }
-                    }
-                    nlast = w; last_globin = wg;
-                }
+            }
+            const uint32_t g0 = gfA & ROW_GENE_MASK, g1 = gfB & ROW_GENE_MASK;
+            out.commit[2 * b].row = rowA; out.commit[2 * b].cidx = cidxA; out.commit[2 * b].len = B.len[b];
+            out.commit[2 * b + 1].row = rowB; out.commit[2 * b + 1].cidx = cidxB; out.commit[2 * b + 1].len = B.len[b];
+            sgene[2 * b] = g0; sgene[2 * b + 1] = g1;
+            con |= (c0 ? 1u : 0u) << (2 * b) | (c1 ? 1u : 0u) << (2 * b + 1);
+            // -- gene set: genes.front() for the first block, set_intersection afterwards (:363-374)
+            if (b == 0) {
+                la = g0; va = c0; ga = c0 && ((gfA >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+                lb = g1; vb = c1 && !(c0 && g1 == g0); gb = vb && ((gfB >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+            } else {
+                const bool live = (uint32_t)b < B.nb;            // a block on a feature-less contig intersects with the empty set
+                const bool a_in = (c0 && la == g0) || (c1 && la == g1), b_in = (c0 && lb == g0) || (c1 && lb == g1);
+                va = live ? (va && a_in) : va; vb = live ? (vb && b_in) : vb;
             }
         }
     }
-    if (over) { overflow = true; return; }
+    overflow = over;
+    ga = ga && va; gb = gb && vb;
+    const int nlast = (va ? 1 : 0) + (vb ? 1 : 0);
     uint64_t bits = 0;
-    if (B.nb >= 1 && last_globin == 0) {                                                   // :363,395-404
+    if (B.nb >= 1 && !(ga || gb)) {                                                        // :363,395-404
         bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_READS);
         if (fl & RSQC_FDUP) bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_DUPLICATE_READS);
     }
     if (hq && nlast > 0 && !(p.dbg & 4u)) {                                                // :377-392
 #pragma unroll
-        for (int k = 0; k < NSTAGE; ++k)
-            if (k < nst && set_contains<FAST_SET>(last, nlast, st_gene[k])) { out.cmask |= 1u << k; ++out.n_commit; }
+        for (int k = 0; k < NSLOT; ++k) {
+            const bool keep = ((con >> k) & 1u) && ((va && sgene[k] == la) || (vb && sgene[k] == lb));
+            out.cmask |= keep ? 1u << k : 0u;
+            out.n_commit += keep ? 1 : 0;
+        }
         if (aligned > 0 && !(p.dbg & 2u)) {
-#pragma unroll
-            for (int k = 0; k < FAST_SET; ++k) out.hit[k] = last[k];
+            out.hit[0] = va ? la : lb; out.hit[1] = lb;
             out.n_hit = nlast;
         }
     }
+    ClassFlags f;
+    f.intragenic = (cf & CF_INTRAGENIC) != 0; f.plus = (cf & CF_PLUS) != 0; f.minus = (cf & CF_MINUS) != 0;
+    f.ribosomal = (cf & CF_RIBOSOMAL) != 0; f.exonic = (cf & CF_EXONIC) != 0;
     out.bits = bits | class_bits(p, fl, f, nlast > 0, hq);
 }
 

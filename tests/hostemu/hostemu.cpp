@@ -87,7 +87,7 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
         if (rc2.error) return rc2.error;
         if (go) {
             bool over = false;
-            FeatureOut<FAST_SET> fo;
+            FeatureOut<FAST_SET, NSLOT> fo;
             exon_metrics_fast(d, dp, d.contig[r.tid], r.flag, B, hq, aligned, fo, over);
             if (!over) { bits |= fo.bits; apply(acc, d, fo, r, aligned); }
             else {

@@ -168,6 +168,20 @@ def test_chr1_scale_million_reads(oracle_lib):
     assert (got.gene_fragments <= got.gene_reads).all() and (got.gene_unique <= got.gene_reads).all()
 
 
+def test_genome_scale_annotation(oracle_lib):
+    """GENCODE-shaped annotation (25 contigs, 56 202 genes) in two batches: contig segments, the
+    per-contig bin tables and boundary tiles at full annotation size (BASELINE.json configs[2] shape)."""
+    ann = synth.make_annotation(seed=3, contigs=synth.human_contigs())
+    batch = synth.make_reads(ann, 1_000_000, seed=4)
+    half = batch.n // 2 + 17                                   # not a multiple of the tile size
+    parts = [batch.slice(0, half), batch.slice(half, batch.n)]
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, parts)
+    want = oracle_lib.run_oracle(p, ann, parts)
+    assert_results_match(got, want)
+    assert got.counter("Total Alignments") == batch.n
+
+
 @pytest.mark.parametrize("samples", [1000000, 100, 7])
 def test_fragment_sizes_with_bed(oracle_lib, samples):
     # --bed: pairs whose mates both sit inside one BED interval are sampled in file order (K5)
