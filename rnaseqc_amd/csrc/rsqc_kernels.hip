@@ -192,7 +192,6 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     uint64_t pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl4 = 0;
     uint32_t sum_e1mm = 0, sum_e1b = 0, sum_e2mm = 0, sum_e2b = 0, sum_mm = 0, sum_b = 0, sum_blk = 0;
     int pending = 0;
-    unsigned long long my_cnt = 0ull;     // lane c of every wave accumulates counter c
     uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
     bool big_any = false;
     auto vertical_add = [&](uint64_t bits) {
@@ -213,18 +212,18 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                                ((uint32_t)((pl2 >> c) & 1ull) << 2) | ((uint32_t)((pl3 >> c) & 1ull) << 3) |
                                ((uint32_t)((pl4 >> c) & 1ull) << 4);
             const uint32_t tot = wave_sum(v);
-            if (l == c) my_cnt += tot;
+            if (l == 0 && tot) atomicAdd(&S.cnt[c], (unsigned long long)tot);
         }
         pl0 = pl1 = pl2 = pl3 = pl4 = 0;
         const uint32_t s0 = wave_sum(sum_e1mm), s1 = wave_sum(sum_e1b), s2 = wave_sum(sum_e2mm), s3 = wave_sum(sum_e2b),
                        s4 = wave_sum(sum_mm), s5 = wave_sum(sum_b), s6 = wave_sum(sum_blk);
-        if (l == RSQC_C_END1_MISMATCHES) my_cnt += s0;
-        if (l == RSQC_C_END1_BASES) my_cnt += s1;
-        if (l == RSQC_C_END2_MISMATCHES) my_cnt += s2;
-        if (l == RSQC_C_END2_BASES) my_cnt += s3;
-        if (l == RSQC_C_MISMATCHED_BASES) my_cnt += s4;
-        if (l == RSQC_C_TOTAL_BASES) my_cnt += s5;
-        if (l == RSQC_C_ALIGNMENT_BLOCKS) my_cnt += s6;
+        if (l == 0 && s0) atomicAdd(&S.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
+        if (l == 0 && s1) atomicAdd(&S.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
+        if (l == 0 && s2) atomicAdd(&S.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
+        if (l == 0 && s3) atomicAdd(&S.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
+        if (l == 0 && s4) atomicAdd(&S.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
+        if (l == 0 && s5) atomicAdd(&S.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
+        if (l == 0 && s6) atomicAdd(&S.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
         sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
         pending = 0;
     };
@@ -273,8 +272,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (moved) load_contig();
         }
         const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
-        FeatureOut<FAST_SET, NSLOT> fo;
-        fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0; fo.cmask = 0;
+        FastOut fo;
+        fo.bits = 0; fo.n_hit = 0; fo.cmask = 0;
         uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
         // Everything that depends only on the gate cascade (scalar counters, Read-Length inputs, the
         // fragment-size candidate) is retired BEFORE the feature stage, so that the record and its counters
@@ -353,7 +352,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             bool overflow = tid != u_tid;          // stragglers of a boundary tile: general code
             if (!overflow) exon_metrics_fast<ROUND>(a, p, u_ci, fl, B, hq, aligned, fo, overflow);
             if (overflow) {
-                fo.bits = 0; fo.n_hit = 0; fo.n_commit = 0; fo.cmask = 0;
+                fo.bits = 0; fo.n_hit = 0; fo.cmask = 0;
                 const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
                 if (slot < acc.ovf_cap) acc.ovf_index[slot] = i;
                 else atomicExch(acc.error, RSQC_ERR_CAPACITY);
@@ -375,14 +374,17 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         // exonCounts[row] += len / aligned and the per-gene counters go to the workgroup's LDS tables
         // (no wave-wide merging, no carried state); per-base coverage goes to memory as a difference
         // array, identical neighbouring slots merged into one atomic.
+        // one f64 division per record (the expansion is long and would otherwise be repeated per slot); a slot adds
+        // len * (1 / aligned), within 1 ulp of the reference's len / aligned
+        const double inv_aligned = 1.0 / (double)(aligned ? aligned : 1u);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
             const bool has = (fo.cmask >> k) & 1u;
             const uint64_t hm = __ballot(has);
             if (hm == 0ull) continue;
-            const Commit cm = fo.commit[k];
+            struct { uint32_t row, cidx, len; } cm = {fo.row[k], fo.cidx[k], B.len[k >> 1]};
             const bool hv = has && cm.len > 0;
-            if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, cm.row, (double)cm.len / (double)aligned);
+            if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, cm.row, (double)cm.len * inv_aligned);
 #ifdef EXP_NOCOVRUN
             if (hv) { atomicAdd(&acc.cov_diff[cm.cidx], 1u); atomicAdd(&acc.cov_diff[cm.cidx + cm.len], 0xFFFFFFFFu); }
 #else
@@ -422,7 +424,6 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
     }
     flush_counts();
-    if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&S.cnt[l], my_cnt);
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
         if (l == 0) { atomicMax(&S.rl[0], ws); atomicMin(&S.rl[1], wmn); atomicMax(&S.rl[2], wmx); }

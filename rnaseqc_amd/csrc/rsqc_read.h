@@ -450,19 +450,30 @@ RSQC_HD uint32_t exon_row_test(const ExonRow &row, bool reach, int32_t bs, int32
     return (ov ? 1u : 0u) | (con ? 2u : 0u);
 }
 
+// What the fast feature stage returns: slot s = 2b + j commits block b (length B.len[b]) to exon `row[s]` at
+// coverage index `cidx[s]` when bit s of cmask is set.
+struct FastOut {
+    uint64_t bits;
+    int n_hit; uint32_t hit[FAST_SET];
+    uint32_t cmask;
+    uint32_t row[NSLOT], cidx[NSLOT];
+};
+
 // `ci` is the ContigInfo of the record's contig (wave-uniform in the kernel).  ROUND = blocks whose row
 // loads are in flight together (registers vs. round trips).
 template <int ROUND = 2>
 RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl,
-                               const Blocks &B, bool hq, uint32_t aligned, FeatureOut<FAST_SET, NSLOT> &out, bool &overflow) {
-    out.bits = 0; out.n_hit = 0; out.n_commit = 0; out.cmask = 0;
+                               const Blocks &B, bool hq, uint32_t aligned, FastOut &out, bool &overflow) {
+    out.bits = 0; out.n_hit = 0; out.cmask = 0;
     const int rstrand = read_strand_of(p, fl);
     uint32_t cf = 0;                                          // CF_* class flags of the whole record
     uint32_t la = 0, lb = 0; bool va = false, vb = false, ga = false, gb = false;   // gene set common to all blocks so far
-    uint32_t sgene[NSLOT]; uint32_t con = 0;                  // gene of each slot; bit s: slot s holds a containing exon
+    // bit s of con: slot s holds a containing exon; of ma / mb: its gene is the first / second gene of block 0's
+    // set (the final set can only be a subset of that one, so these two bits decide the slot at the end)
+    uint32_t con = 0, ma = 0, mb = 0;
     bool over = B.nb > (uint32_t)FAST_BLOCKS;
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k) { out.commit[k].row = 0; out.commit[k].cidx = 0; out.commit[k].len = 0; sgene[k] = 0; }
+    for (int k = 0; k < NSLOT; ++k) { out.row[k] = 0; out.cidx[k] = 0; }
     FastBins fb;
     fast_load_bins(a, ci, B, fb);
 #pragma unroll
@@ -526,18 +537,20 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
                 }
             }
             const uint32_t g0 = gfA & ROW_GENE_MASK, g1 = gfB & ROW_GENE_MASK;
-            out.commit[2 * b].row = rowA; out.commit[2 * b].cidx = cidxA; out.commit[2 * b].len = B.len[b];
-            out.commit[2 * b + 1].row = rowB; out.commit[2 * b + 1].cidx = cidxB; out.commit[2 * b + 1].len = B.len[b];
-            sgene[2 * b] = g0; sgene[2 * b + 1] = g1;
+            out.row[2 * b] = rowA; out.cidx[2 * b] = cidxA;
+            out.row[2 * b + 1] = rowB; out.cidx[2 * b + 1] = cidxB;
             con |= (c0 ? 1u : 0u) << (2 * b) | (c1 ? 1u : 0u) << (2 * b + 1);
             // -- gene set: genes.front() for the first block, set_intersection afterwards (:363-374)
             if (b == 0) {
                 la = g0; va = c0; ga = c0 && ((gfA >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
                 lb = g1; vb = c1 && !(c0 && g1 == g0); gb = vb && ((gfB >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+                ma = (c0 ? 1u : 0u) | ((c1 && g1 == g0) ? 2u : 0u); mb = vb ? 2u : 0u;
             } else {
                 const bool live = (uint32_t)b < B.nb;            // a block on a feature-less contig intersects with the empty set
                 const bool a_in = (c0 && la == g0) || (c1 && la == g1), b_in = (c0 && lb == g0) || (c1 && lb == g1);
                 va = live ? (va && a_in) : va; vb = live ? (vb && b_in) : vb;
+                ma |= ((c0 && la == g0) ? 1u : 0u) << (2 * b) | ((c1 && la == g1) ? 1u : 0u) << (2 * b + 1);
+                mb |= ((c0 && lb == g0) ? 1u : 0u) << (2 * b) | ((c1 && lb == g1) ? 1u : 0u) << (2 * b + 1);
             }
         }
     }
@@ -550,12 +563,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
         if (fl & RSQC_FDUP) bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_DUPLICATE_READS);
     }
     if (hq && nlast > 0 && !(p.dbg & 4u)) {                                                // :377-392
-#pragma unroll
-        for (int k = 0; k < NSLOT; ++k) {
-            const bool keep = ((con >> k) & 1u) && ((va && sgene[k] == la) || (vb && sgene[k] == lb));
-            out.cmask |= keep ? 1u << k : 0u;
-            out.n_commit += keep ? 1 : 0;
-        }
+        out.cmask = con & ((va ? ma : 0u) | (vb ? mb : 0u));
         if (aligned > 0 && !(p.dbg & 2u)) {
             out.hit[0] = va ? la : lb; out.hit[1] = lb;
             out.n_hit = nlast;

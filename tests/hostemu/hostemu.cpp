@@ -87,9 +87,18 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
         if (rc2.error) return rc2.error;
         if (go) {
             bool over = false;
-            FeatureOut<FAST_SET, NSLOT> fo;
+            FastOut fo;
             exon_metrics_fast(d, dp, d.contig[r.tid], r.flag, B, hq, aligned, fo, over);
-            if (!over) { bits |= fo.bits; apply(acc, d, fo, r, aligned); }
+            if (!over) {
+                bits |= fo.bits;
+                for (int k = 0; k < NSLOT; ++k) {
+                    if (!((fo.cmask >> k) & 1u)) continue;
+                    const uint32_t len = B.len[k >> 1];
+                    if (len > 0) acc.exon_add(fo.row[k], (double)len / (double)aligned);
+                    acc.cov_range(fo.cidx[k], len);
+                }
+                for (int k = 0; k < fo.n_hit; ++k) acc.gene_hit(fo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
+            }
             else {
                 ++*n_overflow;
                 FeatureOut<SLOW_SET, SLOW_STAGE> so;
