@@ -82,3 +82,19 @@ def write_bed(path, ann, bed):
     with open(path, "w") as f:
         for c, s, e in zip(bed.contig.tolist(), bed.start.tolist(), bed.end.tolist()):
             f.write("%s\t%d\t%d\n" % (ann.contig_names[c], s - 1, e - 1))
+
+
+def write_bam_fast(path, contigs, batch, ch_tag="ch", filter_tag="XF", threads=16):
+    """Same file as write_bam through the C++ host library's writer (rnaseqc_amd/lib/librsqc_host.so,
+    host_bam_write): used for multi-million-record CLI benchmarks.  Records without names get 16 hex digits of
+    their qhash as QNAME (mates keep sharing a name)."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsqc_host.so"))
+    names = (C.c_char_p * len(contigs))(*[c[0].encode() for c in contigs])
+    lens = (C.c_uint * len(contigs))(*[int(c[1]) for c in contigs])
+    st = batch.to_struct()
+    lib.host_bam_write.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    rc = lib.host_bam_write(str(path).encode(), names, lens, len(contigs), C.byref(st), ch_tag.encode(), filter_tag.encode(), threads)
+    if rc:
+        raise OSError("host_bam_write failed: %d" % rc)

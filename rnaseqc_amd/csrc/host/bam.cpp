@@ -3,10 +3,18 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
+#include <chrono>
+
 namespace rsqc_host {
+
+namespace {
+double g_t_read = 0, g_t_frame_blocks = 0, g_t_inflate = 0, g_t_frame_rec = 0, g_t_parse = 0, g_t_merge = 0, g_t_move = 0;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
 
 void HostBatch::clear() {
     core.clear(); aux.clear(); cigar.clear(); seg_tid.clear(); seg_start.clear();
@@ -25,7 +33,13 @@ rsqc_batch HostBatch::view() {
     return b;
 }
 
-BamReader::~BamReader() { if (fp_) fclose(fp_); }
+BamReader::~BamReader() {
+    if (fp_) fclose(fp_);
+    delete pool_;
+    if (getenv("RSQC_HOST_PROFILE"))
+        fprintf(stderr, "[bam] read %.3f  frame-blocks %.3f  inflate %.3f  move %.3f  frame-records %.3f  parse %.3f  merge %.3f s\n",
+                g_t_read, g_t_frame_blocks, g_t_inflate, g_t_move, g_t_frame_rec, g_t_parse, g_t_merge);
+}
 
 void BamReader::set_tags(const std::string &chimeric, const std::vector<std::string> &filters) {
     ch_tag_ = chimeric; filter_tags_ = filters;
@@ -34,45 +48,155 @@ void BamReader::set_tags(const std::string &chimeric, const std::vector<std::str
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-bool BamReader::inflate_block() {
-    uint8_t hdr[18];
-    const size_t got = fread(hdr, 1, 18, fp_);
-    if (got == 0) { eof_ = true; return false; }
-    if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) throw std::runtime_error("not a BGZF block");
-    const uint16_t xlen = le16(hdr + 10);
-    // the BC subfield is the first (and normally only) extra field
-    uint32_t bsize = 0;
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp_) != (size_t)(xlen - 6)) throw std::runtime_error("truncated BGZF block");
-    for (size_t o = 0; o + 4 <= xlen;) {
-        const uint16_t slen = le16(extra.data() + o + 2);
-        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = (uint32_t)le16(extra.data() + o + 4) + 1;
-        o += 4 + slen;
+// ------------------------------------------------------------------ fork-join pool
+WorkPool::WorkPool(int threads) {
+    for (int i = 1; i < threads; ++i) workers_.emplace_back([this] { worker(); });
+}
+WorkPool::~WorkPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_work_.notify_all();
+    for (auto &t : workers_) t.join();
+}
+void WorkPool::worker() {
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<void(size_t)> *fn;
+        size_t n;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_work_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+            if (stop_) return;
+            seen = epoch_; fn = fn_; n = n_tasks_;
+        }
+        std::string err;
+        for (;;) {
+            const size_t t = next_.fetch_add(1);
+            if (t >= n) break;
+            try { (*fn)(t); } catch (std::exception &e) { err = e.what(); }
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!err.empty() && error_.empty()) error_ = err;
+            if (--running_ == 0) cv_done_.notify_all();
+        }
     }
-    if (!bsize) throw std::runtime_error("BGZF block without BC field");
-    const size_t clen = bsize - xlen - 12 - 8;
-    cbuf_.resize(clen + 8);
-    if (fread(cbuf_.data(), 1, clen + 8, fp_) != clen + 8) throw std::runtime_error("truncated BGZF block");
-    const uint32_t isize = le32(cbuf_.data() + clen + 4);
-    const size_t old = buf_.size();
-    buf_.resize(old + isize);
-    if (isize) {
+}
+void WorkPool::run(size_t n_tasks, const std::function<void(size_t)> &fn) {
+    if (n_tasks == 0) return;
+    if (workers_.empty() || n_tasks == 1) { for (size_t t = 0; t < n_tasks; ++t) fn(t); return; }
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); running_ = workers_.size(); error_.clear(); ++epoch_;
+    }
+    cv_work_.notify_all();
+    std::string err;
+    for (;;) {
+        const size_t t = next_.fetch_add(1);
+        if (t >= n_tasks) break;
+        try { fn(t); } catch (std::exception &e) { err = e.what(); }
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return running_ == 0; });
+    if (err.empty()) err = error_;
+    if (!err.empty()) throw std::runtime_error(err);
+}
+
+void BamReader::set_threads(int n) {
+    if (n < 1) n = 1;
+    if (n == n_threads_ && pool_) return;
+    delete pool_;
+    n_threads_ = n;
+    pool_ = new WorkPool(n);
+}
+
+// BGZF blocks are independent deflate streams whose uncompressed size sits in the trailer, so a group of
+// blocks is framed sequentially (headers only) and inflated in parallel straight into place.
+bool BamReader::fill_group() {
+    if (eof_) return false;
+    if (!pool_) {
+        int n = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+        if (const char *e = getenv("RSQC_HOST_THREADS")) n = atoi(e);
+        set_threads(n);
+    }
+    const size_t GROUP_BYTES = (size_t)64 << 20;        // uncompressed bytes per group
+    const size_t READ_CHUNK = (size_t)16 << 20;
+    struct Blk { size_t coff, clen, out; uint32_t isize; };
+    std::vector<Blk> blks;
+    size_t total = 0;
+    for (;;) {
+        // frame complete blocks of the compressed window
+        while (total < GROUP_BYTES) {
+            const size_t avail = cbuf_.size() - cpos_;
+            if (avail < 18) break;
+            const uint8_t *h = cbuf_.data() + cpos_;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
+            const uint16_t xlen = le16(h + 10);
+            if (avail < 12 + (size_t)xlen) break;
+            uint32_t bsize = 0;
+            for (size_t o = 0; o + 4 <= xlen;) {
+                const uint8_t *x = h + 12 + o;
+                const uint16_t slen = le16(x + 2);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = (uint32_t)le16(x + 4) + 1;
+                o += 4 + (size_t)slen;
+            }
+            if (!bsize) throw std::runtime_error("BGZF block without BC field");
+            if (bsize < 12u + xlen + 8u) throw std::runtime_error("bad BGZF block size");
+            if (avail < bsize) break;
+            const size_t clen = bsize - xlen - 12 - 8;
+            const uint32_t isize = le32(h + bsize - 4);
+            blks.push_back(Blk{cpos_ + 12 + xlen, clen, total, isize});
+            total += isize;
+            cpos_ += bsize;
+        }
+        if (total >= GROUP_BYTES || file_eof_) break;
+        // need more compressed bytes: drop the consumed prefix only when no framed block still points into it
+        if (blks.empty() && cpos_ > 0) { cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (long)cpos_); cpos_ = 0; }
+        const double tr = now_s();
+        const size_t old = cbuf_.size();
+        cbuf_.resize(old + READ_CHUNK);
+        const size_t got = fread(cbuf_.data() + old, 1, READ_CHUNK, fp_);
+        cbuf_.resize(old + got);
+        g_t_read += now_s() - tr;
+        if (got == 0) file_eof_ = true;
+    }
+    if (blks.empty()) {
+        if (cbuf_.size() - cpos_ != 0) throw std::runtime_error("truncated BGZF block");
+        eof_ = true;
+        return false;
+    }
+    const double tm = now_s();
+    // unread tail to the front, then the group behind it
+    if (pos_ > 0) { buf_.erase(buf_.begin(), buf_.begin() + (long)pos_); pos_ = 0; }
+    const size_t base = buf_.size();
+    buf_.resize(base + total);
+    const uint8_t *cdata = cbuf_.data();
+    uint8_t *odata = buf_.data() + base;
+    g_t_move += now_s() - tm;
+    const double ti = now_s();
+    // tasks of ~16 consecutive blocks: one z_stream per task
+    const size_t per = 16, n_tasks = (blks.size() + per - 1) / per;
+    pool_->run(n_tasks, [&](size_t t) {
         z_stream zs{};
         if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
-        zs.next_in = cbuf_.data(); zs.avail_in = (uInt)clen;
-        zs.next_out = buf_.data() + old; zs.avail_out = isize;
-        const int rc = inflate(&zs, Z_FINISH);
+        const size_t b0 = t * per, b1 = std::min(blks.size(), b0 + per);
+        for (size_t k = b0; k < b1; ++k) {
+            const Blk &bk = blks[k];
+            if (!bk.isize) continue;
+            if (k != b0) inflateReset(&zs);
+            zs.next_in = const_cast<uint8_t *>(cdata + bk.coff); zs.avail_in = (uInt)bk.clen;
+            zs.next_out = odata + bk.out; zs.avail_out = bk.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw std::runtime_error("BGZF inflate failed"); }
+        }
         inflateEnd(&zs);
-        if (rc != Z_STREAM_END) throw std::runtime_error("BGZF inflate failed");
-    }
+    });
+    g_t_inflate += now_s() - ti;
+
     return true;
 }
 
 bool BamReader::fill(size_t need) {
-    if (buf_.size() - pos_ >= need) return true;
-    if (pos_ > (1u << 22)) { buf_.erase(buf_.begin(), buf_.begin() + (long)pos_); pos_ = 0; }
-    while (buf_.size() - pos_ < need) { if (eof_ || !inflate_block()) break; }
+    while (buf_.size() - pos_ < need) { if (!fill_group()) break; }
     return buf_.size() - pos_ >= need;
 }
 
@@ -109,64 +233,126 @@ static bool aux_int(const uint8_t *v, char type, int32_t &out) {
     }
 }
 
+// Records are framed sequentially (one hop per record: block_size, n_cigar) and parsed in parallel into
+// pre-sized arrays; contig segments and the wide table are collected per task and merged in order.
 size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
     size_t n = 0;
+    std::vector<size_t> offs;
+    std::vector<uint32_t> cigoff;
     while (n < max_records) {
-        if (!fill(4)) break;
-        const uint32_t block_size = le32(buf_.data() + pos_);
-        if (!fill(4 + (size_t)block_size)) throw std::runtime_error("truncated BAM record");
-        const uint8_t *r = buf_.data() + pos_ + 4;
-        const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
-        const uint8_t l_read_name = r[8], mapq = r[9];
-        const uint16_t n_cigar = le16(r + 12), flag = le16(r + 14);
-        const int32_t l_seq = (int32_t)le32(r + 16), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24), isize = (int32_t)le32(r + 28);
-        const char *qname = (const char *)r + 32;
-        const uint8_t *cig = r + 32 + l_read_name;
-        const uint8_t *auxp = cig + 4 * (size_t)n_cigar + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
-        const uint8_t *end = r + block_size;
-        if (out.seg_tid.empty() || out.seg_tid.back() != tid) { out.seg_tid.push_back(tid); out.seg_start.push_back(out.core.size()); }
-        rsqc_rec_core co{pos, mpos, isize, (uint32_t)out.cigar.size()};
-        rsqc_rec_aux au{};
-        const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
-        au.qhash = rsqc_qname_hash(qname, qlen);
-        au.flag = flag; au.mapq = mapq;
-        uint8_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
-        int32_t nm = 0;
-        // aux fields
-        for (const uint8_t *p = auxp; p + 3 <= end;) {
-            const char t0 = (char)p[0], t1 = (char)p[1], type = (char)p[2];
-            const uint8_t *v = p + 3;
-            size_t vlen = 0;
-            switch (type) {
-            case 'A': case 'c': case 'C': vlen = 1; break;
-            case 's': case 'S': vlen = 2; break;
-            case 'i': case 'I': case 'f': vlen = 4; break;
-            case 'Z': case 'H': vlen = strnlen((const char *)v, (size_t)(end - v)) + 1; break;
-            case 'B': { const char st = (char)v[0]; const uint32_t cnt = le32(v + 1);
-                        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; vlen = 5 + es * (size_t)cnt; break; }
-            default: vlen = (size_t)(end - v); break;
-            }
-            if (t0 == 'N' && t1 == 'M') { int32_t x; if (aux_int(v, type, x)) { nm = x; tagbits |= RSQC_TB_HAS_NM; } }
-            if (ch_tag_.size() == 2 && t0 == ch_tag_[0] && t1 == ch_tag_[1]) {         // readStringTag, src/RNASeQC.cpp:780-800
-                if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
-            }
-            for (size_t k = 0; k < filter_tags_.size() && k < RSQC_MAX_FILTER_TAGS; ++k)   // GetTag: Z, integer or float
-                if (filter_tags_[k].size() == 2 && t0 == filter_tags_[k][0] && t1 == filter_tags_[k][1]) {
-                    int32_t x;
-                    if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << k);
-                }
-            p = v + vlen;
+        if (buf_.size() - pos_ < 4 && !fill(4)) {
+            if (buf_.size() - pos_ != 0) throw std::runtime_error("truncated BAM record");
+            break;
         }
-        const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_cigar >= RSQC_NCIGAR_ESCAPE;
-        au.l_qseq = wide && (l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0) ? RSQC_LQSEQ_ESCAPE : (uint16_t)l_seq;
-        au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
-        au.n_cigar = n_cigar >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_cigar;
-        au.tagbits = tagbits;
-        if (wide) { out.wide_index.push_back(out.core.size()); out.wide_nm.push_back(nm); out.wide_lq.push_back(l_seq); out.wide_ncig.push_back(n_cigar); }
-        for (uint16_t k = 0; k < n_cigar; ++k) out.cigar.push_back(le32(cig + 4 * (size_t)k));
-        out.core.push_back(co); out.aux.push_back(au);
-        pos_ += 4 + (size_t)block_size;
-        ++n; ++n_read_;
+        // ---- framing
+        const double tf = now_s();
+        offs.clear(); cigoff.clear();
+        size_t p = pos_;
+        const size_t end = buf_.size();
+        uint64_t cig_total = 0;
+        size_t need_more = 0;
+        while (n + offs.size() < max_records && p + 4 <= end) {
+            const uint32_t block_size = le32(buf_.data() + p);
+            if (block_size < 32) throw std::runtime_error("bad BAM record");
+            if (p + 4 + (size_t)block_size > end) { need_more = 4 + (size_t)block_size; break; }
+            offs.push_back(p);
+            cigoff.push_back((uint32_t)cig_total);
+            cig_total += le16(buf_.data() + p + 4 + 12);
+            p += 4 + (size_t)block_size;
+        }
+        if (offs.empty()) {
+            const size_t need = need_more ? need_more : 4;
+            if (!fill(need)) throw std::runtime_error("truncated BAM record");
+            continue;
+        }
+        g_t_frame_rec += now_s() - tf;
+        // ---- parallel parse
+        const double tp = now_s();
+        const size_t K = offs.size(), base = out.core.size(), cig_base = out.cigar.size();
+        if (cig_base + cig_total > 0xFFFFFFF0ull) throw std::runtime_error("batch too large");
+        out.core.resize(base + K); out.aux.resize(base + K); out.cigar.resize(cig_base + (size_t)cig_total);
+        const int32_t prev_tid_valid = out.seg_tid.empty() ? 0 : 1;
+        const int32_t prev_tid = out.seg_tid.empty() ? 0 : out.seg_tid.back();
+        const size_t per = 8192, n_tasks = (K + per - 1) / per;
+        struct Local { std::vector<std::pair<uint64_t, int32_t>> segs; std::vector<uint64_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc; };
+        std::vector<Local> locals(n_tasks);
+        const uint8_t *bufp = buf_.data();
+        if (!pool_) set_threads(1);
+        pool_->run(n_tasks, [&](size_t t) {
+            Local &L = locals[t];
+            const size_t k0 = t * per, k1 = std::min(K, k0 + per);
+            for (size_t k = k0; k < k1; ++k) {
+                const uint8_t *r = bufp + offs[k] + 4;
+                const uint32_t block_size = le32(bufp + offs[k]);
+                const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
+                const uint8_t l_read_name = r[8], mapq = r[9];
+                const uint16_t n_cigar = le16(r + 12), flag = le16(r + 14);
+                const int32_t l_seq = (int32_t)le32(r + 16), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24), isize = (int32_t)le32(r + 28);
+                const char *qname = (const char *)r + 32;
+                const uint8_t *cig = r + 32 + l_read_name;
+                const uint8_t *end_r = r + block_size;
+                const uint8_t *auxp = cig + 4 * (size_t)n_cigar + (size_t)((l_seq < 0 ? 0 : l_seq + 1) / 2) + (size_t)(l_seq < 0 ? 0 : l_seq);
+                if (cig + 4 * (size_t)n_cigar > end_r) throw std::runtime_error("bad BAM record");
+                bool new_seg;
+                if (k == 0) new_seg = !prev_tid_valid || prev_tid != tid;
+                else new_seg = (int32_t)le32(bufp + offs[k - 1] + 4) != tid;
+                if (new_seg) L.segs.emplace_back((uint64_t)(base + k), tid);
+                rsqc_rec_core co{pos, mpos, isize, (uint32_t)(cig_base + cigoff[k])};
+                rsqc_rec_aux au{};
+                const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
+                au.qhash = rsqc_qname_hash(qname, qlen);
+                au.flag = flag; au.mapq = mapq;
+                uint8_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
+                int32_t nm = 0;
+                for (const uint8_t *q = auxp; q + 3 <= end_r;) {
+                    const char t0 = (char)q[0], t1 = (char)q[1], type = (char)q[2];
+                    const uint8_t *v = q + 3;
+                    size_t vlen = 0;
+                    switch (type) {
+                    case 'A': case 'c': case 'C': vlen = 1; break;
+                    case 's': case 'S': vlen = 2; break;
+                    case 'i': case 'I': case 'f': vlen = 4; break;
+                    case 'Z': case 'H': vlen = strnlen((const char *)v, (size_t)(end_r - v)) + 1; break;
+                    case 'B': { if (v + 5 > end_r) { vlen = (size_t)(end_r - v); break; }
+                                const char st = (char)v[0]; const uint32_t cnt = le32(v + 1);
+                                const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; vlen = 5 + es * (size_t)cnt; break; }
+                    default: vlen = (size_t)(end_r - v); break;
+                    }
+                    if (v + vlen > end_r) break;                                            // malformed tail: stop scanning
+                    if (t0 == 'N' && t1 == 'M') { int32_t x; if (aux_int(v, type, x)) { nm = x; tagbits |= RSQC_TB_HAS_NM; } }
+                    if (ch_tag_.size() == 2 && t0 == ch_tag_[0] && t1 == ch_tag_[1]) {         // readStringTag, src/RNASeQC.cpp:780-800
+                        if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
+                    }
+                    for (size_t f = 0; f < filter_tags_.size() && f < RSQC_MAX_FILTER_TAGS; ++f)   // GetTag: Z, integer or float
+                        if (filter_tags_[f].size() == 2 && t0 == filter_tags_[f][0] && t1 == filter_tags_[f][1]) {
+                            int32_t x;
+                            if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << f);
+                        }
+                    q = v + vlen;
+                }
+                const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_cigar >= RSQC_NCIGAR_ESCAPE;
+                au.l_qseq = wide && (l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0) ? RSQC_LQSEQ_ESCAPE : (uint16_t)l_seq;
+                au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
+                au.n_cigar = n_cigar >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_cigar;
+                au.tagbits = tagbits;
+                if (wide) { L.widx.push_back(base + k); L.wnm.push_back(nm); L.wlq.push_back(l_seq); L.wnc.push_back(n_cigar); }
+                uint32_t *cdst = out.cigar.data() + cig_base + cigoff[k];
+                for (uint16_t c = 0; c < n_cigar; ++c) cdst[c] = le32(cig + 4 * (size_t)c);
+                out.core[base + k] = co; out.aux[base + k] = au;
+            }
+        });
+        g_t_parse += now_s() - tp;
+        const double tg = now_s();
+        for (const Local &L : locals) {
+            for (const auto &sg : L.segs) { out.seg_tid.push_back(sg.second); out.seg_start.push_back(sg.first); }
+            out.wide_index.insert(out.wide_index.end(), L.widx.begin(), L.widx.end());
+            out.wide_nm.insert(out.wide_nm.end(), L.wnm.begin(), L.wnm.end());
+            out.wide_lq.insert(out.wide_lq.end(), L.wlq.begin(), L.wlq.end());
+            out.wide_ncig.insert(out.wide_ncig.end(), L.wnc.begin(), L.wnc.end());
+        }
+        g_t_merge += now_s() - tg;
+        pos_ = p;
+        n += K; n_read_ += K;
     }
     return n;
 }

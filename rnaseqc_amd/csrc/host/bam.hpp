@@ -2,9 +2,14 @@
 // Replaces the SeqlibReader adapter (src/BamReader.{h,cpp}) for BAM input; CRAM is out of scope.
 #pragma once
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/rnaseqc_amd.h"
@@ -26,6 +31,27 @@ struct HostBatch {                       // owns the arrays an rsqc_batch points
     rsqc_batch view();                   // closes the segment table
 };
 
+// fork-join helper: run(n, fn) calls fn(task) for task in [0, n) on the pool's threads and the caller
+class WorkPool {
+public:
+    explicit WorkPool(int threads);
+    ~WorkPool();
+    int size() const { return (int)workers_.size() + 1; }
+    void run(size_t n_tasks, const std::function<void(size_t)> &fn);
+private:
+    void worker();
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_tasks_ = 0;
+    std::atomic<size_t> next_{0};
+    size_t running_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+    std::string error_;
+};
+
 class BamReader {
 public:
     bool open(const std::string &path);                 // false: cannot open / not a BAM
@@ -35,15 +61,21 @@ public:
     // appends up to max_records records to `out`; returns the number appended (0 at EOF)
     size_t read_batch(HostBatch &out, size_t max_records);
     uint64_t records_read() const { return n_read_; }
+    // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 64)
+    void set_threads(int n);
     ~BamReader();
 private:
     bool fill(size_t need);              // make at least `need` decompressed bytes available
-    bool inflate_block();
+    bool fill_group();                   // inflate the next group of BGZF blocks (in parallel) behind the unread tail
     FILE *fp_ = nullptr;
     std::vector<uint8_t> buf_;           // decompressed stream window
     size_t pos_ = 0;
-    std::vector<uint8_t> cbuf_;
+    std::vector<uint8_t> cbuf_;          // compressed window: [cpos_, cbuf_.size()) is unread
+    size_t cpos_ = 0;
+    bool file_eof_ = false;
     bool eof_ = false;
+    WorkPool *pool_ = nullptr;
+    int n_threads_ = 0;
     std::vector<std::string> names_;
     std::string ch_tag_ = "ch";
     std::vector<std::string> filter_tags_;

@@ -137,6 +137,33 @@ def test_bam_decode_round_trip(host, tmp_path):
     assert not host.host_bam_read_all(str(tmp_path / "nope.bam").encode(), b"ch", tags, 0)
 
 
+@pytest.mark.parametrize("threads,batch_records", [(1, 1 << 20), (8, 1 << 20), (5, 7777), (16, 100)])
+def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_records):
+    """Parallel BGZF inflate + parallel record parsing: many blocks, records spanning block borders,
+    read_batch calls that end in the middle of an inflated group."""
+    ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40), ("chrC", 500_000, 10)])
+    batch = synth.make_reads(ann, 30_000, seed=36, keep_qnames=True, chimeric_tag_frac=0.02, filter_tag_frac=0.03,
+                             contig_lengths=np.array([3_000_000, 1_000_000, 500_000]))
+    path = str(tmp_path / "p.bam")
+    bamio.write_bam(path, [("chrA", 3_000_000), ("chrB", 1_000_000), ("chrC", 500_000)], batch)
+    tags = (C.c_char_p * 1)(b"XF")
+    host.host_bam_read_all_ex.restype = C.c_void_p
+    h = host.host_bam_read_all_ex(path.encode(), b"ch", tags, 1, threads, C.c_ulonglong(batch_records))
+    assert h
+    b = host.host_bam_batch(C.c_void_p(h)).contents
+    assert b.n == batch.n and b.n_cigar_total == len(batch.cigar)
+    core = _arr(b.core, b.n, abi.REC_CORE); aux = _arr(b.aux, b.n, abi.REC_AUX)
+    for f in ("pos", "mpos", "isize", "cigar_off"):
+        np.testing.assert_array_equal(core[f], getattr(batch, f), err_msg=f)
+    for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
+        np.testing.assert_array_equal(aux[f], getattr(batch, f), err_msg=f)
+    np.testing.assert_array_equal(_arr(b.cigar, b.n_cigar_total, np.uint32), batch.cigar)
+    np.testing.assert_array_equal(_arr(b.seg_tid, b.n_seg, np.int32), batch.seg_tid)
+    np.testing.assert_array_equal(_arr(b.seg_start, b.n_seg + 1, np.uint64), batch.seg_start)
+    np.testing.assert_array_equal(_arr(b.wide_index, b.n_wide, np.uint64), batch.wide_index)
+    host.host_bam_free(C.c_void_p(h))
+
+
 def test_library_complexity_matches_the_literal_loop(host, oracle_lib):
     rng = np.random.default_rng(7)
     for _ in range(40):
