@@ -1,5 +1,7 @@
 #include "bam.hpp"
 
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -34,6 +36,7 @@ rsqc_batch HostBatch::view() {
 }
 
 BamReader::~BamReader() {
+    if (map_) munmap(const_cast<uint8_t *>(map_), map_size_);
     if (fp_) fclose(fp_);
     delete pool_;
     if (getenv("RSQC_HOST_PROFILE"))
@@ -126,9 +129,9 @@ bool BamReader::fill_group() {
     for (;;) {
         // frame complete blocks of the compressed window
         while (total < GROUP_BYTES) {
-            const size_t avail = cbuf_.size() - cpos_;
+            const size_t avail = (map_ ? map_size_ : cbuf_.size()) - cpos_;
             if (avail < 18) break;
-            const uint8_t *h = cbuf_.data() + cpos_;
+            const uint8_t *h = (map_ ? map_ : cbuf_.data()) + cpos_;
             if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
             const uint16_t xlen = le16(h + 10);
             if (avail < 12 + (size_t)xlen) break;
@@ -148,9 +151,9 @@ bool BamReader::fill_group() {
             total += isize;
             cpos_ += bsize;
         }
-        if (total >= GROUP_BYTES || file_eof_) break;
+        if (total >= GROUP_BYTES || file_eof_ || map_) break;
         // need more compressed bytes: drop the consumed prefix only when no framed block still points into it
-        if (blks.empty() && cpos_ > 0) { cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (long)cpos_); cpos_ = 0; }
+        if (blks.empty() && cpos_ > 0) { cbuf_.erase_front(cpos_); cpos_ = 0; }
         const double tr = now_s();
         const size_t old = cbuf_.size();
         cbuf_.resize(old + READ_CHUNK);
@@ -160,16 +163,16 @@ bool BamReader::fill_group() {
         if (got == 0) file_eof_ = true;
     }
     if (blks.empty()) {
-        if (cbuf_.size() - cpos_ != 0) throw std::runtime_error("truncated BGZF block");
+        if ((map_ ? map_size_ : cbuf_.size()) - cpos_ != 0) throw std::runtime_error("truncated BGZF block");
         eof_ = true;
         return false;
     }
     const double tm = now_s();
     // unread tail to the front, then the group behind it
-    if (pos_ > 0) { buf_.erase(buf_.begin(), buf_.begin() + (long)pos_); pos_ = 0; }
+    if (pos_ > 0) { buf_.erase_front(pos_); pos_ = 0; }
     const size_t base = buf_.size();
     buf_.resize(base + total);
-    const uint8_t *cdata = cbuf_.data();
+    const uint8_t *cdata = map_ ? map_ : cbuf_.data();
     uint8_t *odata = buf_.data() + base;
     g_t_move += now_s() - tm;
     const double ti = now_s();
@@ -203,6 +206,16 @@ bool BamReader::fill(size_t need) {
 bool BamReader::open(const std::string &path) {
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) return false;
+    {
+        struct stat st;
+        if (fstat(fileno(fp_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && !getenv("RSQC_HOST_NO_MMAP")) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp_), 0);
+            if (m != MAP_FAILED) {
+                map_ = (const uint8_t *)m; map_size_ = (size_t)st.st_size;
+                (void)madvise(m, map_size_, MADV_SEQUENTIAL);
+            }
+        }
+    }
     try {
         if (!fill(12) || memcmp(buf_.data() + pos_, "BAM\1", 4) != 0) return false;
         const uint32_t l_text = le32(buf_.data() + pos_ + 4);
@@ -233,57 +246,136 @@ static bool aux_int(const uint8_t *v, char type, int32_t &out) {
     }
 }
 
-// Records are framed sequentially (one hop per record: block_size, n_cigar) and parsed in parallel into
-// pre-sized arrays; contig segments and the wide table are collected per task and merged in order.
+// ---- record framing ---------------------------------------------------------------------------------
+// A BAM record can only be located by hopping from the previous one (block_size), one dependent cache miss per
+// record.  The window is therefore cut into chunks that are framed IN PARALLEL from a guessed record start
+// (the first offset where two consecutive records pass a structural check), and the guesses are then verified
+// sequentially: chunk c's guess is accepted only if the TRUE chain of chunk c-1 (which starts at a verified
+// boundary) ends exactly on it; otherwise chunk c is re-framed from the true position.  The result is exact --
+// a wrong guess costs time, never correctness.
+namespace {
+struct Framed { std::vector<uint32_t> off; std::vector<uint32_t> ncig; size_t start = 0, end = 0; bool guessed = false; };
+
+inline bool plausible_record(const uint8_t *buf, size_t p, size_t end, int32_t n_ref) {
+    if (p + 36 > end) return false;
+    const uint32_t bs = le32(buf + p);
+    if (bs < 32 || bs > (1u << 26)) return false;
+    const uint8_t *r = buf + p + 4;
+    const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24);
+    if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1) return false;
+    const uint32_t l_name = r[8], n_cig = le16(r + 12);
+    const int32_t l_seq = (int32_t)le32(r + 16);
+    if (l_name == 0 || l_seq < 0) return false;
+    const uint64_t fixed = 32ull + l_name + 4ull * n_cig + (uint64_t)(l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (fixed > bs) return false;
+    if (p + 4 + 32 + l_name <= end && r[32 + l_name - 1] != 0) return false;     // QNAME is NUL-terminated
+    return true;
+}
+// hop from `p` while records are complete and start before `limit`; returns the first start >= limit (or the
+// start of the first incomplete record)
+inline size_t frame_from(const uint8_t *buf, size_t p, size_t limit, size_t end, size_t base, Framed &f, size_t max_records) {
+    while (p < limit && p + 4 <= end && f.off.size() < max_records) {
+        const uint32_t bs = le32(buf + p);
+        if (bs < 32) throw std::runtime_error("bad BAM record");
+        if (p + 4 + (size_t)bs > end) break;
+        f.off.push_back((uint32_t)(p - base));
+        f.ncig.push_back(le16(buf + p + 4 + 12));
+        p += 4 + (size_t)bs;
+    }
+    return p;
+}
+}  // namespace
+
+// Records are framed and parsed in parallel into pre-sized arrays; contig segments and the wide table are
+// collected per chunk and merged in order.
 size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
     size_t n = 0;
-    std::vector<size_t> offs;
-    std::vector<uint32_t> cigoff;
+    if (!pool_) set_threads(1);
+    const int32_t n_ref = (int32_t)names_.size();
     while (n < max_records) {
         if (buf_.size() - pos_ < 4 && !fill(4)) {
             if (buf_.size() - pos_ != 0) throw std::runtime_error("truncated BAM record");
             break;
         }
-        // ---- framing
         const double tf = now_s();
-        offs.clear(); cigoff.clear();
-        size_t p = pos_;
-        const size_t end = buf_.size();
-        uint64_t cig_total = 0;
-        size_t need_more = 0;
-        while (n + offs.size() < max_records && p + 4 <= end) {
-            const uint32_t block_size = le32(buf_.data() + p);
-            if (block_size < 32) throw std::runtime_error("bad BAM record");
-            if (p + 4 + (size_t)block_size > end) { need_more = 4 + (size_t)block_size; break; }
-            offs.push_back(p);
-            cigoff.push_back((uint32_t)cig_total);
-            cig_total += le16(buf_.data() + p + 4 + 12);
-            p += 4 + (size_t)block_size;
+        const uint8_t *bufp = buf_.data();
+        const size_t end = buf_.size(), want = max_records - n;
+        // ---- parallel speculative framing of [pos_, end)
+        const size_t CH = (size_t)1 << 20;
+        const size_t n_ch = std::max<size_t>(1, (end - pos_ + CH - 1) / CH);
+        std::vector<Framed> fr(n_ch);
+        pool_->run(n_ch, [&](size_t c) {
+            Framed &f = fr[c];
+            const size_t lo = pos_ + c * CH, hi = std::min(end, lo + CH);
+            size_t p = lo;
+            if (c > 0) {
+                f.guessed = false;
+                for (; p < hi; ++p) {
+                    if (!plausible_record(bufp, p, end, n_ref)) continue;
+                    const size_t q = p + 4 + le32(bufp + p);
+                    if (q + 36 <= end ? plausible_record(bufp, q, end, n_ref) : true) { f.guessed = true; break; }
+                }
+                if (!f.guessed) { f.start = f.end = hi; return; }
+            } else f.guessed = true;
+            f.start = p;
+            f.off.reserve(8192); f.ncig.reserve(8192);
+            f.end = frame_from(bufp, p, hi, end, pos_, f, (size_t)-1);
+        });
+        // ---- sequential verification (exact)
+        size_t truth = pos_;
+        size_t total = 0;
+        bool stop = false;
+        for (size_t c = 0; c < n_ch && !stop; ++c) {
+            Framed &f = fr[c];
+            const size_t lo = pos_ + c * CH, hi = std::min(end, lo + CH);
+            if (truth >= hi) { f.off.clear(); f.ncig.clear(); f.start = f.end = truth; continue; }     // a long record spans the chunk
+            if (!(f.guessed && f.start == truth)) {
+                f.off.clear(); f.ncig.clear(); f.start = truth;
+                f.end = frame_from(bufp, truth, hi, end, pos_, f, (size_t)-1);
+            }
+            if (total + f.off.size() >= want) {                                    // the batch ends inside this chunk
+                const size_t keep = want - total;
+                if (keep < f.off.size()) { f.end = pos_ + f.off[keep]; f.off.resize(keep); f.ncig.resize(keep); }
+                stop = true;
+                for (size_t d = c + 1; d < n_ch; ++d) { fr[d].off.clear(); fr[d].ncig.clear(); }
+            }
+            total += f.off.size();
+            truth = f.end;
+            if (f.end < hi && !stop) {                                             // incomplete record: the window ends here
+                for (size_t d = c + 1; d < n_ch; ++d) { fr[d].off.clear(); fr[d].ncig.clear(); }
+                break;
+            }
         }
-        if (offs.empty()) {
-            const size_t need = need_more ? need_more : 4;
+        g_t_frame_rec += now_s() - tf;
+        if (total == 0) {
+            size_t need = 4;
+            if (truth + 4 <= end) need = 4 + (size_t)le32(bufp + truth);
+            if (truth != pos_) throw std::runtime_error("internal framing error");
             if (!fill(need)) throw std::runtime_error("truncated BAM record");
             continue;
         }
-        g_t_frame_rec += now_s() - tf;
-        // ---- parallel parse
+        // ---- prefix sums over chunks, then parallel parse
         const double tp = now_s();
-        const size_t K = offs.size(), base = out.core.size(), cig_base = out.cigar.size();
-        if (cig_base + cig_total > 0xFFFFFFF0ull) throw std::runtime_error("batch too large");
-        out.core.resize(base + K); out.aux.resize(base + K); out.cigar.resize(cig_base + (size_t)cig_total);
-        const int32_t prev_tid_valid = out.seg_tid.empty() ? 0 : 1;
+        std::vector<size_t> rec0(n_ch + 1, 0), cig0(n_ch + 1, 0);
+        pool_->run(n_ch, [&](size_t c) { uint64_t s = 0; for (uint32_t v : fr[c].ncig) s += v; cig0[c + 1] = (size_t)s; rec0[c + 1] = fr[c].off.size(); });
+        for (size_t c = 0; c < n_ch; ++c) { rec0[c + 1] += rec0[c]; cig0[c + 1] += cig0[c]; }
+        const size_t K = rec0[n_ch], base = out.core.size(), cig_base = out.cigar.size();
+        if (cig_base + cig0[n_ch] > 0x3FFFFFF0ull) throw std::runtime_error("batch too large");
+        out.core.resize(base + K); out.aux.resize(base + K); out.cigar.resize(cig_base + cig0[n_ch]);
+        const bool prev_tid_valid = !out.seg_tid.empty();
         const int32_t prev_tid = out.seg_tid.empty() ? 0 : out.seg_tid.back();
-        const size_t per = 8192, n_tasks = (K + per - 1) / per;
-        struct Local { std::vector<std::pair<uint64_t, int32_t>> segs; std::vector<uint64_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc; };
-        std::vector<Local> locals(n_tasks);
-        const uint8_t *bufp = buf_.data();
-        if (!pool_) set_threads(1);
-        pool_->run(n_tasks, [&](size_t t) {
-            Local &L = locals[t];
-            const size_t k0 = t * per, k1 = std::min(K, k0 + per);
-            for (size_t k = k0; k < k1; ++k) {
-                const uint8_t *r = bufp + offs[k] + 4;
-                const uint32_t block_size = le32(bufp + offs[k]);
+        struct Local { std::vector<std::pair<uint64_t, int32_t>> segs; std::vector<uint64_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc; int32_t last_tid = 0; bool any = false; };
+        std::vector<Local> locals(n_ch);
+        rsqc_rec_core *ocore = out.core.data(); rsqc_rec_aux *oaux = out.aux.data(); uint32_t *ocig = out.cigar.data();
+        pool_->run(n_ch, [&](size_t c) {
+            Local &L = locals[c];
+            const Framed &f = fr[c];
+            size_t cigo = cig_base + cig0[c];
+            int32_t last_tid = 0; bool have_last = false;
+            for (size_t k = 0; k < f.off.size(); ++k) {
+                const size_t gi = base + rec0[c] + k;
+                const uint8_t *r = bufp + pos_ + f.off[k] + 4;
+                const uint32_t block_size = le32(r - 4);
                 const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
                 const uint8_t l_read_name = r[8], mapq = r[9];
                 const uint16_t n_cigar = le16(r + 12), flag = le16(r + 14);
@@ -293,11 +385,11 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
                 const uint8_t *end_r = r + block_size;
                 const uint8_t *auxp = cig + 4 * (size_t)n_cigar + (size_t)((l_seq < 0 ? 0 : l_seq + 1) / 2) + (size_t)(l_seq < 0 ? 0 : l_seq);
                 if (cig + 4 * (size_t)n_cigar > end_r) throw std::runtime_error("bad BAM record");
-                bool new_seg;
-                if (k == 0) new_seg = !prev_tid_valid || prev_tid != tid;
-                else new_seg = (int32_t)le32(bufp + offs[k - 1] + 4) != tid;
-                if (new_seg) L.segs.emplace_back((uint64_t)(base + k), tid);
-                rsqc_rec_core co{pos, mpos, isize, (uint32_t)(cig_base + cigoff[k])};
+                // segment starts inside a chunk are decided here; a chunk's first record is compared at merge time
+                if (have_last && last_tid != tid) L.segs.emplace_back((uint64_t)gi, tid);
+                if (!have_last) { L.segs.emplace_back((uint64_t)gi, tid); have_last = true; }       // provisional
+                last_tid = tid;
+                rsqc_rec_core co{pos, mpos, isize, (uint32_t)cigo};
                 rsqc_rec_aux au{};
                 const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
                 au.qhash = rsqc_qname_hash(qname, qlen);
@@ -323,10 +415,10 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
                     if (ch_tag_.size() == 2 && t0 == ch_tag_[0] && t1 == ch_tag_[1]) {         // readStringTag, src/RNASeQC.cpp:780-800
                         if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
                     }
-                    for (size_t f = 0; f < filter_tags_.size() && f < RSQC_MAX_FILTER_TAGS; ++f)   // GetTag: Z, integer or float
-                        if (filter_tags_[f].size() == 2 && t0 == filter_tags_[f][0] && t1 == filter_tags_[f][1]) {
+                    for (size_t fi = 0; fi < filter_tags_.size() && fi < RSQC_MAX_FILTER_TAGS; ++fi)   // GetTag: Z, integer or float
+                        if (filter_tags_[fi].size() == 2 && t0 == filter_tags_[fi][0] && t1 == filter_tags_[fi][1]) {
                             int32_t x;
-                            if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << f);
+                            if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << fi);
                         }
                     q = v + vlen;
                 }
@@ -335,23 +427,30 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
                 au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
                 au.n_cigar = n_cigar >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_cigar;
                 au.tagbits = tagbits;
-                if (wide) { L.widx.push_back(base + k); L.wnm.push_back(nm); L.wlq.push_back(l_seq); L.wnc.push_back(n_cigar); }
-                uint32_t *cdst = out.cigar.data() + cig_base + cigoff[k];
-                for (uint16_t c = 0; c < n_cigar; ++c) cdst[c] = le32(cig + 4 * (size_t)c);
-                out.core[base + k] = co; out.aux[base + k] = au;
+                if (wide) { L.widx.push_back(gi); L.wnm.push_back(nm); L.wlq.push_back(l_seq); L.wnc.push_back(n_cigar); }
+                for (uint16_t ci = 0; ci < n_cigar; ++ci) ocig[cigo + ci] = le32(cig + 4 * (size_t)ci);
+                cigo += n_cigar;
+                ocore[gi] = co; oaux[gi] = au;
             }
+            L.last_tid = last_tid; L.any = have_last;
         });
         g_t_parse += now_s() - tp;
         const double tg = now_s();
+        bool have_prev = prev_tid_valid; int32_t ptid = prev_tid;
         for (const Local &L : locals) {
-            for (const auto &sg : L.segs) { out.seg_tid.push_back(sg.second); out.seg_start.push_back(sg.first); }
+            for (size_t si = 0; si < L.segs.size(); ++si) {
+                const auto &sg = L.segs[si];
+                if (si == 0 && have_prev && ptid == sg.second) continue;            // the chunk continues the previous contig
+                out.seg_tid.push_back(sg.second); out.seg_start.push_back(sg.first);
+            }
+            if (L.any) { have_prev = true; ptid = L.last_tid; }
             out.wide_index.insert(out.wide_index.end(), L.widx.begin(), L.widx.end());
             out.wide_nm.insert(out.wide_nm.end(), L.wnm.begin(), L.wnm.end());
             out.wide_lq.insert(out.wide_lq.end(), L.wlq.begin(), L.wlq.end());
             out.wide_ncig.insert(out.wide_ncig.end(), L.wnc.begin(), L.wnc.end());
         }
         g_t_merge += now_s() - tg;
-        pos_ = p;
+        pos_ = truth;
         n += K; n_read_ += K;
     }
     return n;

@@ -6,6 +6,9 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -16,10 +19,44 @@
 
 namespace rsqc_host {
 
+// growable array of trivially copyable T whose new elements are NOT value-initialised (the decode threads
+// write every element; a zero-fill of hundreds of MB on one thread would be the bottleneck)
+template <class T>
+class RawVec {
+public:
+    RawVec() = default;
+    RawVec(const RawVec &) = delete;
+    RawVec &operator=(const RawVec &) = delete;
+    ~RawVec() { free(p_); }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+    void resize(size_t n) {
+        if (n > cap_) {
+            size_t c = cap_ ? cap_ : 1024;
+            while (c < n) c += c / 2 + 1024;
+            T *q = (T *)realloc(p_, c * sizeof(T));
+            if (!q) throw std::bad_alloc();
+            p_ = q; cap_ = c;
+        }
+        n_ = n;
+    }
+    void push_back(const T &v) { resize(n_ + 1); p_[n_ - 1] = v; }
+    // drop the first k elements
+    void erase_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, (n_ - k) * sizeof(T)); n_ -= k; }
+private:
+    T *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 struct HostBatch {                       // owns the arrays an rsqc_batch points to
-    std::vector<rsqc_rec_core> core;
-    std::vector<rsqc_rec_aux> aux;
-    std::vector<uint32_t> cigar;
+    RawVec<rsqc_rec_core> core;
+    RawVec<rsqc_rec_aux> aux;
+    RawVec<uint32_t> cigar;
     std::vector<int32_t> seg_tid;
     std::vector<uint64_t> seg_start;
     std::vector<uint64_t> wide_index;
@@ -68,9 +105,11 @@ private:
     bool fill(size_t need);              // make at least `need` decompressed bytes available
     bool fill_group();                   // inflate the next group of BGZF blocks (in parallel) behind the unread tail
     FILE *fp_ = nullptr;
-    std::vector<uint8_t> buf_;           // decompressed stream window
+    RawVec<uint8_t> buf_;                // decompressed stream window
     size_t pos_ = 0;
-    std::vector<uint8_t> cbuf_;          // compressed window: [cpos_, cbuf_.size()) is unread
+    RawVec<uint8_t> cbuf_;               // compressed window: [cpos_, cbuf_.size()) is unread (streams that cannot be mapped)
+    const uint8_t *map_ = nullptr;       // the whole compressed file, memory-mapped (regular files): inflate reads the page cache directly
+    size_t map_size_ = 0;
     size_t cpos_ = 0;
     bool file_eof_ = false;
     bool eof_ = false;

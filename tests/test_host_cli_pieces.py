@@ -164,6 +164,36 @@ def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_record
     host.host_bam_free(C.c_void_p(h))
 
 
+def test_bam_decode_long_record_spans_framing_chunks(host, tmp_path):
+    """A 2.6 MB record (long read) between short ones: the parallel framer's chunks inside it have no record
+    start to guess, and its SEQ/QUAL bytes (0x11 / 0xff runs) must not be taken for records."""
+    recs = []
+    for i in range(3000):
+        recs.append(dict(tid=0, pos=100 + i, mpos=100 + i, isize=0, flag=0, cigar=[(abi.CIG_M, 100)], qname="s%d" % i))
+    recs.append(dict(tid=0, pos=5000, mpos=5000, isize=0, flag=0, cigar=[(abi.CIG_M, 1_700_000)], qname="long"))
+    for i in range(3000):
+        recs.append(dict(tid=1 if i > 1500 else 0, pos=6000 + i, mpos=6000 + i, isize=0, flag=0, cigar=[(abi.CIG_M, 90), (abi.CIG_S, 10)], qname="t%d" % i))
+    batch = Batch.from_records(recs)
+    path = str(tmp_path / "l.bam")
+    bamio.write_bam(path, [("chrA", 3_000_000), ("chrB", 1_000_000)], batch)
+    host.host_bam_read_all_ex.restype = C.c_void_p
+    for threads, per in ((1, 1 << 20), (8, 1 << 20), (4, 1000)):
+        h = host.host_bam_read_all_ex(path.encode(), b"ch", None, 0, threads, C.c_ulonglong(per))
+        assert h
+        b = host.host_bam_batch(C.c_void_p(h)).contents
+        assert b.n == batch.n
+        core = _arr(b.core, b.n, abi.REC_CORE); aux = _arr(b.aux, b.n, abi.REC_AUX)
+        np.testing.assert_array_equal(core["pos"], batch.pos)
+        np.testing.assert_array_equal(aux["qhash"], batch.qhash)
+        np.testing.assert_array_equal(aux["l_qseq"], batch.l_qseq)
+        np.testing.assert_array_equal(_arr(b.cigar, b.n_cigar_total, np.uint32), batch.cigar)
+        np.testing.assert_array_equal(_arr(b.wide_index, b.n_wide, np.uint64), batch.wide_index)
+        np.testing.assert_array_equal(_arr(b.wide_l_qseq, b.n_wide, np.int32), batch.wide_l_qseq)
+        np.testing.assert_array_equal(_arr(b.seg_tid, b.n_seg, np.int32), batch.seg_tid)
+        np.testing.assert_array_equal(_arr(b.seg_start, b.n_seg + 1, np.uint64), batch.seg_start)
+        host.host_bam_free(C.c_void_p(h))
+
+
 def test_library_complexity_matches_the_literal_loop(host, oracle_lib):
     rng = np.random.default_rng(7)
     for _ in range(40):
