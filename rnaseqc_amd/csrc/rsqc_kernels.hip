@@ -97,6 +97,22 @@ __device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
     return at_end - (sc - v);
 }
 
+// cov[idx] += sign * (number of lanes of the run) with identical neighbouring slots merged into one atomic.
+// Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
+// then is the run structure built.
+__device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {
+    const uint32_t pidx = __shfl_up(idx, 1, 64);
+    const uint64_t vmask = __ballot(valid);
+    const int l = lane_id();
+    const bool dup = valid && l > 0 && ((vmask >> (l - 1)) & 1ull) && pidx == idx;
+    if (__ballot(dup) == 0ull) {
+        if (valid) atomicAdd(&cov[idx], sign);
+    } else {
+        const Run r = make_run(valid, idx);
+        if (r.head) atomicAdd(&cov[idx], sign * r.count);
+    }
+}
+
 // accumulator used by the general (slow-path) code when it re-walks a CIGAR
 struct DirectAcc {
     double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
@@ -390,10 +406,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #else
             if (!(p.dbg & 1u)) {                 // +1 at the block start, -1 after its last base
                 const uint32_t base = hv ? cm.cidx : 0u;
-                const Run up = make_run(hv, base);
-                if (up.head) atomicAdd(&acc.cov_diff[base], up.count);
-                const Run dn = make_run(hv, base + cm.len);
-                if (dn.head) atomicAdd(&acc.cov_diff[base + cm.len], 0u - dn.count);
+                cov_add_merged(acc.cov_diff, hv, base, 1u);
+                cov_add_merged(acc.cov_diff, hv, base + cm.len, 0xFFFFFFFFu);
             }
 #endif
         }
