@@ -646,7 +646,7 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
                 const int f = atoi(e);
                 if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; } else if (f == 3) { nl = 0; nm = 0; }
             }
-            launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm);
+            if (!getenv("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm);   // (diagnostic knob: results incomplete)
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
@@ -665,6 +665,7 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
         if (c->d_table.bytes < (size_t)slot_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slot_bound * 8 + (1u << 20), false))) return rc; }
         launch_dedup_clear(c->stream, (unsigned long long *)c->d_table.p, d_total);
         for (size_t idx : c->pairs_in_flight) {
+            if (getenv("RSQC_DIAG_SKIP_K4")) break;                       // (diagnostic knob: results incomplete)
             PairBuf &pb = c->pair_pool[idx];
             DevAccum acc = c->acc;
             acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p;

@@ -725,55 +725,81 @@ dedup_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chun
         for (int i = threadIdx.x; i < RSQC_K4_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
         __syncthreads();
         const uint32_t p0 = piece * RSQC_K4_PIECE, p1 = p0 + RSQC_K4_PIECE < count ? p0 + RSQC_K4_PIECE : count;
-        for (uint32_t j0 = p0; j0 < p1; j0 += blockDim.x) {
-            const uint32_t j = j0 + threadIdx.x;
-            bool survivor = false, fresh = false; uint32_t g = 0; uint64_t key = 0;
-            if (j < p1) {
-                g = pair_gene[base + j];
-                key = pair_hash[base + j];
-                if (key == 0) key = 0x9e3779b97f4a7c15ull;               // 0 marks an empty slot
-                survivor = true;
-                if (!(mode & 8u)) {
+        // Every pair is a chain of dependent memory operations (pair -> slice descriptor -> slot -> CAS); a thread
+        // keeps U of them in flight and each phase issues its U independent accesses back to back.
+        constexpr int U = 4;
+        for (uint32_t j0 = p0; j0 < p1; j0 += U * RSQC_K4_THREADS) {
+            bool live[U], fresh[U]; uint32_t g[U]; uint64_t key[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // A: the pairs
+                const uint32_t j = j0 + (uint32_t)u * RSQC_K4_THREADS + threadIdx.x;
+                live[u] = j < p1; fresh[u] = false;
+                g[u] = live[u] ? pair_gene[base + j] : 0u;
+                key[u] = live[u] ? pair_hash[base + j] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // B: the chunk's own LDS table
+                if (key[u] == 0) key[u] = 0x9e3779b97f4a7c15ull;           // 0 marks an empty slot
+                if (live[u] && !(mode & (8u | 64u))) {
                     // LDS key: the name hash made gene-specific by a per-gene bijection (for one gene, equal
                     // LDS keys <=> equal hashes); the gene word settles the rest
-                    unsigned long long lk = key ^ ((unsigned long long)g * 0x9E3779B97F4A7C15ull);
+                    unsigned long long lk = key[u] ^ ((unsigned long long)g[u] * 0x9E3779B97F4A7C15ull);
                     if (lk == 0ull) lk = 1ull;
                     uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4_LSLOTS - 1);
                     bool done = false;
 #pragma unroll 1
                     for (int probe = 0; probe < 8 && !done; ++probe) {
                         const unsigned long long old = atomicCAS(&S.lkey[slot], 0ull, lk);
-                        if (old == 0ull) { S.lgene[slot] = g; done = true; }                 // first of its kind here
+                        if (old == 0ull) { S.lgene[slot] = g[u]; done = true; }              // first of its kind here
                         // (reconverged: a claimer in this wave has written its gene word by now)
-                        if (!done && old == lk) { if (S.lgene[slot] == g) survivor = false; done = true; }
+                        if (!done && old == lk) { if (S.lgene[slot] == g[u]) live[u] = false; done = true; }
                         slot = (slot + 1) & (RSQC_K4_LSLOTS - 1);
                     }
                 }
             }
-            if (survivor) {
-                const uint32_t cap = tab_cap[g];
-                unsigned long long *tab = table + tab_off[g];
-                uint32_t slot = (uint32_t)(((mix64(key) >> 32) * (unsigned long long)cap) >> 32);
-                for (uint32_t probes = 0; probes < cap; ++probes) {
+            if (mode & 32u) { for (int u = 0; u < U; ++u) live[u] = false; }     // (ablation: no global phase)
+            uint32_t cap[U], slot[U]; unsigned long long *tab[U]; unsigned long long old[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // C: slice descriptors of the survivors
+                cap[u] = tab_cap[g[u]];
+                tab[u] = table + tab_off[g[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // D: first probe (plain load)
+                slot[u] = (uint32_t)(((mix64(key[u]) >> 32) * (unsigned long long)cap[u]) >> 32);
+                old[u] = live[u] ? ((mode & 16u) ? 0ull : tab[u][slot[u]]) : 1ull;     // mode 16: CAS straight away
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)                                    // E: claim apparently empty slots
+                if (live[u] && old[u] == 0ull) old[u] = atomicCAS(&tab[u][slot[u]], 0ull, (unsigned long long)key[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // F: resolve; collisions probe on (rare)
+                if (!live[u]) continue;
+                if (old[u] == 0ull) { fresh[u] = true; continue; }
+                if (old[u] == key[u]) continue;
+                uint32_t sl = slot[u] + 1 == cap[u] ? 0 : slot[u] + 1;
+                for (uint32_t probes = 1; probes < cap[u]; ++probes) {
                     // keys are never removed, so a plain (possibly stale) load that already shows the key or
                     // another key is conclusive; only an apparently empty slot needs the device-scope CAS
-                    unsigned long long old = tab[slot];
-                    if (old == 0ull) old = atomicCAS(&tab[slot], 0ull, (unsigned long long)key);
-                    if (old == 0ull) { fresh = true; break; }
-                    if (old == key) break;
-                    slot = slot + 1 == cap ? 0 : slot + 1;
+                    unsigned long long o = tab[u][sl];
+                    if (o == 0ull) o = atomicCAS(&tab[u][sl], 0ull, (unsigned long long)key[u]);
+                    if (o == 0ull) { fresh[u] = true; break; }
+                    if (o == key[u]) break;
+                    sl = sl + 1 == cap[u] ? 0 : sl + 1;
                 }
             }
-            if (fresh) {                                                  // geneFragmentCounts[g]++ via the LDS table
-                uint32_t slot = g & (RSQC_K4_GSLOTS - 1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // G: geneFragmentCounts[g]++ via the LDS table
+                if (!fresh[u]) continue;
+                uint32_t sl = g[u] & (RSQC_K4_GSLOTS - 1);
                 bool placed = false;
 #pragma unroll 1
                 for (int probe = 0; probe < 4 && !placed; ++probe) {
-                    const uint32_t old = atomicCAS(&S.gkey[slot], 0xFFFFFFFFu, g);
-                    if (old == 0xFFFFFFFFu || old == g) { atomicAdd(&S.gcnt[slot], 1u); placed = true; }
-                    slot = (slot + 1) & (RSQC_K4_GSLOTS - 1);
+                    const uint32_t o = atomicCAS(&S.gkey[sl], 0xFFFFFFFFu, g[u]);
+                    if (o == 0xFFFFFFFFu || o == g[u]) { atomicAdd(&S.gcnt[sl], 1u); placed = true; }
+                    sl = (sl + 1) & (RSQC_K4_GSLOTS - 1);
                 }
-                if (!placed) atomicAdd(&gene_frag[g], 1ull);
+                if (!placed) atomicAdd(&gene_frag[g[u]], 1ull);
             }
         }
     }
@@ -945,26 +971,27 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
         }
         return;
     }
-    // (1) difference array -> coverage: block-wide inclusive scan, 4 bases per thread per round
+    // (1) difference array -> coverage: block-wide inclusive scan, 16 consecutive bases per thread per round
     {
+        constexpr int PER = 16;
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < coding; base += T * 4) {
-            const uint32_t j = base + (uint32_t)tid * 4;
-            uint32_t v0 = j < coding ? D[j] : 0u, v1 = j + 1 < coding ? D[j + 1] : 0u,
-                     v2 = j + 2 < coding ? D[j + 2] : 0u, v3 = j + 3 < coding ? D[j + 3] : 0u;
-            v1 += v0; v2 += v1; v3 += v2;
-            const uint32_t inc = wave_inclusive_scan_u32(v3);
+        for (uint32_t base = 0; base < coding; base += T * PER) {
+            const uint32_t j = base + (uint32_t)tid * PER;
+            uint32_t v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = j + k < coding ? D[j + k] : 0u;
+#pragma unroll
+            for (int k = 1; k < PER; ++k) v[k] += v[k - 1];
+            const uint32_t inc = wave_inclusive_scan_u32(v[PER - 1]);
             k3_sync<T>();
             if (l == 63) S.u32b[wv] = inc;
             k3_sync<T>();
             uint32_t before = carry, total = 0;
 #pragma unroll
             for (int w = 0; w < (T / 64); ++w) { const uint32_t t = S.u32b[w]; if (w < wv) before += t; total += t; }
-            const uint32_t ex = before + inc - v3;
-            if (j < coding) C[j] = v0 + ex;
-            if (j + 1 < coding) C[j + 1] = v1 + ex;
-            if (j + 2 < coding) C[j + 2] = v2 + ex;
-            if (j + 3 < coding) C[j + 3] = v3 + ex;
+            const uint32_t ex = before + inc - v[PER - 1];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) if (j + k < coding) C[j + k] = v[k] + ex;
             carry += total;
         }
     }
@@ -1036,14 +1063,10 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
                 k3_sync<T>();
                 for (int h = tid; h < 256; h += T) S.hist[h] = 0;
                 k3_sync<T>();
-                for (uint32_t j0 = 0; j0 < coding; j0 += T) {          // neighbouring bases have similar depth: one LDS
-                    const uint32_t j = j0 + (uint32_t)tid;                 // atomic per distinct digit of the wave
-                    const uint32_t v = j < coding ? C[j] : 0u;
-                    const bool in = j < coding && (v & pmask) == prefix;
-                    const uint32_t dg = (v >> shift) & 0xFF;
-                    wave_by_key(in, dg, [&](int lead, uint32_t d0, bool, uint64_t same) {
-                        if (l == lead) atomicAdd(&S.hist[d0], (uint32_t)__popcll(same));
-                    });
+#pragma unroll 8
+                for (uint32_t j = tid; j < coding; j += T) {            // (same-bin LDS atomics of a wave serialise inside ONE
+                    const uint32_t v = C[j];                            //  instruction, ~1 cycle per lane: cheaper than merging them)
+                    if ((v & pmask) == prefix) atomicAdd(&S.hist[(v >> shift) & 0xFF], 1u);
                 }
                 k3_sync<T>();
                 if (wv == 0) {                                       // wave 0: lane x scans 4 bins
