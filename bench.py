@@ -95,12 +95,12 @@ def main():
         if args.no_finalize:
             e.wait()
             return None
-        r = e.finalize()
+        r = e.finalize(lazy=True)        # the vectors are on the host (library buffers); Python copies are made on access
         if world > 1:
             dist.all_reduce(u64_t)           # RCCL over xGMI: gene reads/unique/fragments + scalar counters
             dist.all_reduce(f64_t)           # exon fractions
             torch.cuda.synchronize()
-            r = e.refresh_results()
+            r = e.refresh_results(lazy=True)
         return r
 
     for _ in range(args.warmup):

@@ -85,7 +85,7 @@ class Oracle:
     def finalize(self) -> abi.Results:
         rs = abi.ResultsStruct()
         self._check(self._l.oracle_finalize(self._h, C.byref(rs)))
-        return abi.Results(rs)
+        return abi.Results(rs).materialise()
 
     def exit_order(self) -> np.ndarray:
         p, n = C.c_void_p(), C.c_uint32()

@@ -156,29 +156,44 @@ def _view(p, n, dtype):
 
 
 class Results:
-    """Host copy of an rsqc_results struct (library buffers are copied out)."""
+    """Host view of an rsqc_results struct.  The vectors live in the library's host buffers (already on the
+    host after rsqc_finalize); each is copied out the first time it is read, so holding a Results costs nothing
+    until it is inspected.  Call materialise() to detach everything before the next finalize/reset of the context
+    (Engine.finalize does that unless lazy=True)."""
+
+    _VEC = {  # name -> (struct field, length selector, dtype)
+        "gene_reads": ("gene_reads", "G", np.uint64), "gene_unique": ("gene_unique", "G", np.uint64),
+        "gene_fragments": ("gene_fragments", "G", np.uint64), "exon_reads": ("exon_reads", "E", np.float64),
+        "exon_hit": ("exon_hit", "E", np.uint8), "gene_cov_mean": ("gene_cov_mean", "G", np.float64),
+        "gene_cov_std": ("gene_cov_std", "G", np.float64), "gene_cov_cv": ("gene_cov_cv", "G", np.float64),
+        "gene_cov_valid": ("gene_cov_valid", "G", np.uint8), "exon_cv": ("exon_cv", "E", np.float64),
+        "exon_cv_valid": ("exon_cv_valid", "E", np.uint8), "bias_three": ("bias_three", "G", np.uint64),
+        "bias_five": ("bias_five", "G", np.uint64), "fragment_size": ("fragment_size", "F", np.int64),
+        "fragment_count": ("fragment_count", "F", np.uint64),
+    }
 
     def __init__(self, rs: ResultsStruct):
-        G, E = rs.n_genes_listed, rs.n_exons
-        self.gene_reads = _view(rs.gene_reads, G, np.uint64)
-        self.gene_unique = _view(rs.gene_unique, G, np.uint64)
-        self.gene_fragments = _view(rs.gene_fragments, G, np.uint64)
-        self.exon_reads = _view(rs.exon_reads, E, np.float64)
-        self.exon_hit = _view(rs.exon_hit, E, np.uint8)
-        self.counters = np.array(list(rs.counters), dtype=np.uint64)
+        self._rs = rs
+        self._n = {"G": rs.n_genes_listed, "E": rs.n_exons, "F": rs.n_fragment_sizes}
         self.read_length = int(rs.read_length)
-        self.gene_cov_mean = _view(rs.gene_cov_mean, G, np.float64)
-        self.gene_cov_std = _view(rs.gene_cov_std, G, np.float64)
-        self.gene_cov_cv = _view(rs.gene_cov_cv, G, np.float64)
-        self.gene_cov_valid = _view(rs.gene_cov_valid, G, np.uint8)
-        self.exon_cv = _view(rs.exon_cv, E, np.float64)
-        self.exon_cv_valid = _view(rs.exon_cv_valid, E, np.uint8)
-        self.bias_three = _view(rs.bias_three, G, np.uint64)
-        self.bias_five = _view(rs.bias_five, G, np.uint64)
-        nf = rs.n_fragment_sizes
-        self.fragment_size = _view(rs.fragment_size, nf, np.int64)
-        self.fragment_count = _view(rs.fragment_count, nf, np.uint64)
         self.fragment_samples_remaining = int(rs.fragment_samples_remaining)
+
+    def __getattr__(self, name):
+        # only called for attributes not materialised yet
+        if name == "counters":
+            v = np.frombuffer(self._rs.counters, dtype=np.uint64, count=N_COUNTERS).copy()
+        elif name in Results._VEC:
+            field, sel, dt = Results._VEC[name]
+            v = _view(getattr(self._rs, field), self._n[sel], dt)
+        else:
+            raise AttributeError(name)
+        self.__dict__[name] = v
+        return v
+
+    def materialise(self) -> "Results":
+        for name in list(Results._VEC) + ["counters"]:
+            getattr(self, name)
+        return self
 
     def counter(self, name: str) -> int:
         return int(self.counters[COUNTER_INDEX[name]])

@@ -130,6 +130,7 @@ int fail(rsqc_ctx *c, int code, const std::string &msg) {
 
 int dev_alloc(rsqc_ctx *c, DevBuf &b, size_t bytes, bool zero) {
     if (bytes == 0) bytes = 16;
+    bytes = (bytes + 15) & ~(size_t)15;          // whole 16-byte vectors (the reset kernel clears uint4s)
     if (b.bytes < bytes) {
         b.release();
         HIP_TRY(c, hipMalloc(&b.p, bytes));
@@ -183,9 +184,9 @@ int resolve_events(rsqc_ctx *c) {
 }
 
 int zero_accumulators(rsqc_ctx *c) {
-    HIP_TRY(c, hipMemsetAsync(c->d_arena.p, 0, c->arena_bytes, c->stream));
-    HIP_TRY(c, hipMemsetAsync((char *)c->d_arena.p + c->off_misc + 36, 0xFF, 4, c->stream));   // rl_stats[1] = min l_qseq
-    HIP_TRY(c, hipMemsetAsync(c->d_cov.p, 0, c->d_cov.bytes, c->stream));
+    // one zeroing kernel + one store (rl_stats[1] = min l_qseq starts at UINT_MAX) instead of several memsets
+    launch_reset(c->stream, c->d_arena.p, c->arena_bytes, c->d_cov.p, c->d_cov.bytes, (uint32_t *)((char *)c->d_arena.p + c->off_misc + 36));
+    HIP_TRY(c, hipGetLastError());
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
     for (auto &fb : c->frag_pool) fb.used = false;
@@ -262,8 +263,8 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     pb->pairs_bound = std::min<uint64_t>(want, u->n * (uint64_t)FAST_SET + slow_cap);
     pb->slow_base = (uint32_t)(chunk_cap * (uint64_t)grid); pb->slow_cap = (uint32_t)slow_cap;
     c->pairs_in_flight.push_back(pidx);
-    HIP_TRY(c, hipMemsetAsync(pb->counts.p, 0, ((size_t)grid + 1) * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->acc.ovf_count, 0, sizeof(uint32_t), c->stream));
+    // (no per-batch memsets: every K1 workgroup writes its own chunk count, workgroup 0 zeroes the slow-path pair
+    //  counter, and the overflow counter is re-armed by the last kernel of the previous batch / the reset kernel)
     DevAccum acc = c->acc;
     acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p;
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;

@@ -81,6 +81,7 @@ struct GeneCovArgs {
 };
 void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium);
 
+void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min);
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc);
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,

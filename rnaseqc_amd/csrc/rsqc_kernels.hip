@@ -200,6 +200,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x) { S.ekey[c] = 0xFFFFFFFFu; S.eval[c] = 0.0; }
     for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x) { S.gkey[c] = 0xFFFFFFFFu; S.gcnt[c] = 0u; S.gnd[c] = 0u; }
     if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; S.pairs = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
     __syncthreads();
 
     // Scalar counters are kept "vertically": plane j holds bit j of this lane's running count of
@@ -504,11 +505,12 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     __shared__ double s_val[RSQC_SLOW_SLOTS];
     __shared__ uint32_t s_ckey[RSQC_SLOW_CSLOTS];
     __shared__ uint32_t s_cval[RSQC_SLOW_CSLOTS];
+    uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    if (p.dbg & 64u) n = 0;
+    if (blockIdx.x * blockDim.x >= n) return;            // nothing for this workgroup (the usual case for most of the grid)
     for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x) { s_key[i] = 0xFFFFFFFFu; s_val[i] = 0.0; }
     for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x) { s_ckey[i] = 0xFFFFFFFFu; s_cval[i] = 0u; }
     __syncthreads();
-    uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
-    if (p.dbg & 64u) n = 0;
     const int l = lane_id();
     DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
     auto exon_add_lds = [&](uint32_t row, double frac) {
@@ -673,6 +675,7 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     if (l == 0) {
         *acc.read_length = (int32_t)r;
         acc.rl_stats[0] = 0u; acc.rl_stats[1] = 0xFFFFFFFFu; acc.rl_stats[2] = 0u;    // ready for the next batch
+        *acc.ovf_count = 0u;                  // (the slow kernel, this batch's only reader, ran before this kernel)
     }
 }
 
@@ -1140,7 +1143,24 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
     }
 }
 
+// ------------------------------------------------------------------ reset
+// one launch instead of a handful of memsets: zero the accumulator arena and the coverage array, arm rl_stats
+__global__ void __launch_bounds__(256)
+reset_kernel(uint4 *arena, size_t arena_vec, uint4 *cov, size_t cov_vec, uint32_t *rl_min) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cov_vec; i += stride) cov[i] = z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < arena_vec; i += stride) arena[i] = z;
+    (void)rl_min;                                  // armed by reset_arm_kernel, launched right behind this one
+}
+__global__ void reset_arm_kernel(uint32_t *rl_min) { *rl_min = 0xFFFFFFFFu; }
+
 // ------------------------------------------------------------------ launch wrappers
+void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min) {
+    // both allocations are 16-byte multiples with slack (rsqc_api.cpp: dev_alloc)
+    hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_min);
+    hipLaunchKernelGGL(reset_arm_kernel, dim3(1), dim3(1), 0, s, rl_min);
+}
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
     if (variant == 2) hipLaunchKernelGGL(classify_count_kernel_w2, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);

@@ -117,15 +117,20 @@ class Engine:
     def release(self, handle: int):
         self._check(self._l.rsqc_release(self._h, handle))
 
-    def finalize(self) -> abi.Results:
+    def finalize(self, lazy: bool = False) -> abi.Results:
+        """Runs the end-of-file stage and reads every result vector back to the host (inside the library).
+        lazy=True returns views that are copied out of the library's host buffers on first access and are only
+        valid until the next finalize/reset of this engine."""
         rs = abi.ResultsStruct()
         self._check(self._l.rsqc_finalize(self._h, C.byref(rs)))
-        return abi.Results(rs)
+        r = abi.Results(rs)
+        return r if lazy else r.materialise()
 
-    def refresh_results(self) -> abi.Results:
+    def refresh_results(self, lazy: bool = False) -> abi.Results:
         rs = abi.ResultsStruct()
         self._check(self._l.rsqc_refresh_results(self._h, C.byref(rs)))
-        return abi.Results(rs)
+        r = abi.Results(rs)
+        return r if lazy else r.materialise()
 
     def reset(self):
         self._check(self._l.rsqc_reset(self._h))
