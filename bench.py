@@ -95,7 +95,10 @@ def main():
         if args.no_finalize:
             e.wait()
             return None
-        r = e.finalize(lazy=True)        # the vectors are on the host (library buffers); Python copies are made on access
+        if world == 1:
+            return e.finalize(lazy=True)     # the vectors are on the host (library buffers); Python copies are made on access
+        e.finalize_device()                  # results stay on the device until the counts are reduced
+        r = None
         if world > 1:
             dist.all_reduce(u64_t)           # RCCL over xGMI: gene reads/unique/fragments + scalar counters
             dist.all_reduce(f64_t)           # exon fractions

@@ -361,6 +361,9 @@ RSQC_API int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *
                              void **f64_base, uint64_t *f64_count);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
+/* rsqc_finalize without the read-back: runs the end-of-file stage and leaves every result on the device
+ * (multi-GPU runs reduce the accumulators first and read back once with rsqc_refresh_results).            */
+RSQC_API int rsqc_finalize_device(rsqc_ctx *ctx);
 
 RSQC_API const char *rsqc_strerror(int code);
 RSQC_API const char *rsqc_last_error(rsqc_ctx *ctx);

@@ -73,6 +73,7 @@ struct rsqc_ctx {
     const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
     const uint32_t *d_gene_order = nullptr;
     uint32_t k3_large = 0, k3_medium = 0;
+    hipEvent_t fin_e0 = nullptr, fin_e1 = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
 
@@ -613,15 +614,12 @@ static int read_back(rsqc_ctx *c) {
     return 0;
 }
 
-int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
-    if (!c || !out || !c->have_ann) return RSQC_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    HIP_TRY(c, hipSetDevice(c->device));
+// end-of-file kernels (K3 beside K4, K5 for BED runs); results stay on the device
+static int run_finalize_kernels(rsqc_ctx *c) {
     int rc;
     const int G = c->n_genes, L = c->n_listed;
     char *A = (char *)c->d_arena.p;
-    if (!c->finalized) {
-        hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
@@ -716,17 +714,43 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
             m_file.release(); m_q.release(); m_name.release(); m_end.release(); m_fs.release();
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
+    c->fin_e0 = e0; c->fin_e1 = e1;
+    return 0;
+}
+static void finish_finalize_bookkeeping(rsqc_ctx *c) {
+    float ms = 0.f;
+    if (c->fin_e0 && hipEventElapsedTime(&ms, c->fin_e0, c->fin_e1) == hipSuccess) c->timing.finalize_ms += ms;
+    if (c->fin_e0) { c->event_pool.push_back(c->fin_e0); c->event_pool.push_back(c->fin_e1); c->fin_e0 = c->fin_e1 = nullptr; }
+    resolve_events(c);
+    for (auto *u : c->transient) free_batch(u);
+    c->transient.clear();
+    c->finalized = true;
+}
+
+int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
+    if (!c || !out || !c->have_ann) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if (!c->finalized) {
+        if ((rc = run_finalize_kernels(c))) return rc;
         // ---- one read-back of every result vector (also carries the device error flag) ----------------
         if ((rc = read_back(c))) return rc;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.finalize_ms += ms;
-        c->event_pool.push_back(e0); c->event_pool.push_back(e1);
-        resolve_events(c);
-        for (auto *u : c->transient) free_batch(u);
-        c->transient.clear();
-        c->finalized = true;
+        finish_finalize_bookkeeping(c);
     } else if ((rc = read_back(c))) return rc;
     *out = c->results;
+    return RSQC_OK;
+}
+
+int rsqc_finalize_device(rsqc_ctx *c) {
+    if (!c || !c->have_ann) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->finalized) return RSQC_OK;
+    int rc;
+    if ((rc = run_finalize_kernels(c))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    finish_finalize_bookkeeping(c);
     return RSQC_OK;
 }
 

@@ -46,6 +46,7 @@ def load_library():
         lib.rsqc_reset_timing.argtypes = [vp]
         lib.rsqc_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
+        lib.rsqc_finalize_device.argtypes = [vp]
         lib.rsqc_strerror.argtypes = [C.c_int]; lib.rsqc_strerror.restype = C.c_char_p
         lib.rsqc_last_error.argtypes = [vp]; lib.rsqc_last_error.restype = C.c_char_p
         lib.rsqc_counter_name.argtypes = [C.c_int]; lib.rsqc_counter_name.restype = C.c_char_p
@@ -58,7 +59,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
 ]
 
@@ -125,6 +126,10 @@ class Engine:
         self._check(self._l.rsqc_finalize(self._h, C.byref(rs)))
         r = abi.Results(rs)
         return r if lazy else r.materialise()
+
+    def finalize_device(self):
+        """End-of-file stage without the read-back (the distributed path reduces first, then refresh_results())."""
+        self._check(self._l.rsqc_finalize_device(self._h))
 
     def refresh_results(self, lazy: bool = False) -> abi.Results:
         rs = abi.ResultsStruct()

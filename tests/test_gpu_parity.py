@@ -168,6 +168,25 @@ def test_chr1_scale_million_reads(oracle_lib):
     assert (got.gene_fragments <= got.gene_reads).all() and (got.gene_unique <= got.gene_reads).all()
 
 
+def test_finalize_device_then_refresh_matches_finalize(oracle_lib):
+    """The distributed flow: end-of-file stage without read-back, then one read-back after the reduction."""
+    ann = synth.make_annotation(seed=11, contigs=[("c1", 2_000_000, 80), ("c2", 1_000_000, 40)])
+    batch = synth.make_reads(ann, 40_000, seed=12)
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    e = engine.Engine(p)
+    try:
+        e.set_annotation(ann)
+        e.submit(batch); e.wait()
+        e.finalize_device()
+        got = e.refresh_results()
+        assert_results_match(got, want)
+        again = e.finalize()                 # already finalized: plain read-back
+        assert_results_match(again, want)
+    finally:
+        e.close()
+
+
 def test_genome_scale_annotation(oracle_lib):
     """GENCODE-shaped annotation (25 contigs, 56 202 genes) in two batches: contig segments, the
     per-contig bin tables and boundary tiles at full annotation size (BASELINE.json configs[2] shape)."""
