@@ -361,6 +361,11 @@ RSQC_API int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *
                              void **f64_base, uint64_t *f64_count);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
+/* Page-locked host memory for the arrays of an rsqc_batch: rsqc_submit then copies by DMA and returns without
+ * waiting for the transfer (arrays from ordinary memory work too, through the driver's staging copy).
+ * NULL when no device is available.                                                                       */
+RSQC_API void *rsqc_host_alloc(size_t bytes);
+RSQC_API void rsqc_host_free(void *p);
 /* rsqc_finalize without the read-back: runs the end-of-file stage and leaves every result on the device
  * (multi-GPU runs reduce the accumulators first and read back once with rsqc_refresh_results).            */
 RSQC_API int rsqc_finalize_device(rsqc_ctx *ctx);

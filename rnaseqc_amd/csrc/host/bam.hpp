@@ -27,7 +27,11 @@ public:
     RawVec() = default;
     RawVec(const RawVec &) = delete;
     RawVec &operator=(const RawVec &) = delete;
-    ~RawVec() { free(p_); }
+    ~RawVec() { release(p_, pinned_now_); }
+    // page-locked storage (rsqc_host_alloc): rsqc_submit then copies by DMA without a staging pass.  Falls back to
+    // ordinary memory when no device is present.  Call before the first growth.
+    void use_pinned(bool on) { want_pinned_ = on; }
+    void reserve(size_t n) { if (n > cap_) grow(n); }
     T *data() { return p_; }
     const T *data() const { return p_; }
     size_t size() const { return n_; }
@@ -39,9 +43,7 @@ public:
         if (n > cap_) {
             size_t c = cap_ ? cap_ : 1024;
             while (c < n) c += c / 2 + 1024;
-            T *q = (T *)realloc(p_, c * sizeof(T));
-            if (!q) throw std::bad_alloc();
-            p_ = q; cap_ = c;
+            grow(c);
         }
         n_ = n;
     }
@@ -49,8 +51,22 @@ public:
     // drop the first k elements
     void erase_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, (n_ - k) * sizeof(T)); n_ -= k; }
 private:
+    static void release(T *p, bool pinned) { if (pinned) rsqc_host_free(p); else free(p); }
+    void grow(size_t c) {
+        T *q = nullptr; bool pin = false;
+        if (want_pinned_) { q = (T *)rsqc_host_alloc(c * sizeof(T)); pin = q != nullptr; }
+        if (!q) {
+            if (!pinned_now_) { q = (T *)realloc(p_, c * sizeof(T)); if (!q) throw std::bad_alloc(); p_ = q; cap_ = c; return; }
+            q = (T *)malloc(c * sizeof(T));
+            if (!q) throw std::bad_alloc();
+        }
+        if (n_) memcpy(q, p_, n_ * sizeof(T));
+        release(p_, pinned_now_);
+        p_ = q; cap_ = c; pinned_now_ = pin;
+    }
     T *p_ = nullptr;
     size_t n_ = 0, cap_ = 0;
+    bool want_pinned_ = false, pinned_now_ = false;
 };
 
 struct HostBatch {                       // owns the arrays an rsqc_batch points to

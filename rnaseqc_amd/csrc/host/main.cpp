@@ -240,6 +240,10 @@ int main(int argc, char **argv) {
         if (o.verbosity) cout << "Parsing bam..." << endl;
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
         HostBatch bufs[2];
+        for (auto &hb : bufs) {                                  // page-locked staging, sized once
+            hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.cigar.use_pinned(true);
+            hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.cigar.reserve(BATCH * 2);
+        }
         std::vector<int> visit;
         unsigned long long alignmentCount = 0;
         int cur = 0; bool in_flight = false;

@@ -33,6 +33,7 @@ struct UploadedBatch {
     std::vector<DevBuf> bufs;
     uint64_t n = 0, n_cigar_total = 0;
     bool in_use = false;
+    bool pooled = false;           // transient upload: its buffers go back to the context's pool
 };
 
 struct PairBuf {                // (gene, qname-hash) pairs of one submitted batch
@@ -103,7 +104,8 @@ struct rsqc_ctx {
     uint64_t next_record_base = 0;
 
     // timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> k1_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> k1_events, h2d_events;
+    std::vector<DevBuf> upload_pool;            // device buffers of retired transient uploads
     std::vector<hipEvent_t> event_pool;
     rsqc_timing timing{};
 
@@ -141,10 +143,22 @@ int dev_alloc(rsqc_ctx *c, DevBuf &b, size_t bytes, bool zero) {
     return 0;
 }
 
+// device buffer of at least `bytes` from the context's pool of retired upload buffers (smallest that fits), or empty
+DevBuf take_pooled(rsqc_ctx *c, size_t bytes);
+
 template <class T>
-int upload(rsqc_ctx *c, std::vector<DevBuf> &owner, const T *host, size_t n, const T **out) {
+int upload(rsqc_ctx *c, std::vector<DevBuf> &owner, const T *host, size_t n, const T **out, bool from_pool = false) {
     DevBuf b;
     size_t bytes = n * sizeof(T);
+    if (from_pool) {
+        b = take_pooled(c, bytes + 32);
+        if (b.p) {
+            if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+            owner.push_back(b);
+            *out = (const T *)b.p;
+            return 0;
+        }
+    }
     // 32 bytes of slack: kernels load a few entries past the end with unconditional, ignored loads
     HIP_TRY(c, hipMalloc(&b.p, bytes + 32));
     b.bytes = bytes + 32;
@@ -181,7 +195,32 @@ int resolve_events(rsqc_ctx *c) {
         c->event_pool.push_back(pr.first); c->event_pool.push_back(pr.second);
     }
     c->k1_events.clear();
+    for (auto &pr : c->h2d_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->timing.h2d_ms += ms;
+        c->event_pool.push_back(pr.first); c->event_pool.push_back(pr.second);
+    }
+    c->h2d_events.clear();
     return 0;
+}
+
+void free_batch(UploadedBatch *u);
+
+DevBuf take_pooled(rsqc_ctx *c, size_t bytes) {
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < c->upload_pool.size(); ++i)
+        if (c->upload_pool[i].bytes >= bytes && (best == (size_t)-1 || c->upload_pool[i].bytes < c->upload_pool[best].bytes)) best = i;
+    DevBuf b;
+    if (best != (size_t)-1) { b = c->upload_pool[best]; c->upload_pool.erase(c->upload_pool.begin() + (long)best); }
+    return b;
+}
+void retire_batch(rsqc_ctx *c, UploadedBatch *u) {
+    if (!u->pooled) { free_batch(u); return; }
+    for (auto &b : u->bufs) {
+        if (c->upload_pool.size() < 64) c->upload_pool.push_back(b); else b.release();
+    }
+    u->bufs.clear();
+    delete u;
 }
 
 int zero_accumulators(rsqc_ctx *c) {
@@ -200,13 +239,14 @@ int zero_accumulators(rsqc_ctx *c) {
     return 0;
 }
 
-int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u) {
+int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u, bool pooled = false) {
+    u->pooled = pooled;
     if (b->n > 0xFFFFFFF0ull || b->n_cigar_total >= (1ull << 30)) return fail(c, RSQC_ERR_ARG, "batch too large");
     DevBatch &d = u->d;
     d.n = b->n; d.n_seg = b->n_seg; d.n_wide = b->n_wide;
     u->n = b->n; u->n_cigar_total = b->n_cigar_total;
     int rc;
-#define UP(field, count) if ((rc = upload(c, u->bufs, b->field, (size_t)(count), &d.field))) return rc
+#define UP(field, count) if ((rc = upload(c, u->bufs, b->field, (size_t)(count), &d.field, pooled))) return rc
     UP(core, b->n); UP(aux, b->n);
     UP(cigar, b->n_cigar_total);
     UP(seg_tid, b->n_seg); UP(seg_start, (size_t)b->n_seg + 1);
@@ -219,6 +259,8 @@ void free_batch(UploadedBatch *u) {
     for (auto &b : u->bufs) b.release();
     delete u;
 }
+// a transient batch whose kernels have completed: keep its device buffers for the next rsqc_submit
+void retire_batch(rsqc_ctx *c, UploadedBatch *u);
 
 PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *index) {
     for (size_t i = 0; i < c->pair_pool.size(); ++i)
@@ -351,6 +393,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto *u : c->resident) if (u) free_batch(u);
     for (auto *u : c->transient) free_batch(u);
+    for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); }
@@ -504,17 +547,14 @@ int rsqc_submit(rsqc_ctx *c, const rsqc_batch *b) {
     UploadedBatch *u = new UploadedBatch();
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     (void)hipEventRecord(e0, c->stream);
-    int rc = upload_batch(c, b, u);
+    int rc = upload_batch(c, b, u, /*pooled=*/true);
     (void)hipEventRecord(e1, c->stream);
+    c->h2d_events.emplace_back(e0, e1);           // resolved at rsqc_wait / rsqc_finalize
     if (rc) { free_batch(u); return rc; }
     c->transient.push_back(u);
-    rc = run_batch(c, u);
-    // h2d time resolved lazily together with the K1 events
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.h2d_ms += ms;
-    c->event_pool.push_back(e0); c->event_pool.push_back(e1);
-    return rc;
+    // asynchronous from here on: with pinned source arrays (rsqc_host_alloc) the copies are DMA transfers the
+    // call does not wait for; the caller keeps the arrays alive and unmodified until rsqc_wait
+    return run_batch(c, u);
 }
 
 int rsqc_wait(rsqc_ctx *c) {
@@ -522,7 +562,7 @@ int rsqc_wait(rsqc_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     resolve_events(c);
-    for (auto *u : c->transient) free_batch(u);
+    for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
     if (c->have_ann) return check_device_error(c);
     return RSQC_OK;
@@ -722,7 +762,7 @@ static void finish_finalize_bookkeeping(rsqc_ctx *c) {
     if (c->fin_e0 && hipEventElapsedTime(&ms, c->fin_e0, c->fin_e1) == hipSuccess) c->timing.finalize_ms += ms;
     if (c->fin_e0) { c->event_pool.push_back(c->fin_e0); c->event_pool.push_back(c->fin_e1); c->fin_e0 = c->fin_e1 = nullptr; }
     resolve_events(c);
-    for (auto *u : c->transient) free_batch(u);
+    for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
     c->finalized = true;
 }
@@ -753,6 +793,13 @@ int rsqc_finalize_device(rsqc_ctx *c) {
     finish_finalize_bookkeeping(c);
     return RSQC_OK;
 }
+
+void *rsqc_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void rsqc_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int rsqc_device_accumulators(rsqc_ctx *c, void **u64_base, uint64_t *u64_count, void **f64_base, uint64_t *f64_count) {
     if (!c || !c->have_ann || !u64_base || !u64_count || !f64_base || !f64_count) return RSQC_ERR_ARG;

@@ -47,6 +47,8 @@ def load_library():
         lib.rsqc_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
         lib.rsqc_finalize_device.argtypes = [vp]
+        lib.rsqc_host_alloc.argtypes = [C.c_size_t]; lib.rsqc_host_alloc.restype = vp
+        lib.rsqc_host_free.argtypes = [vp]; lib.rsqc_host_free.restype = None
         lib.rsqc_strerror.argtypes = [C.c_int]; lib.rsqc_strerror.restype = C.c_char_p
         lib.rsqc_last_error.argtypes = [vp]; lib.rsqc_last_error.restype = C.c_char_p
         lib.rsqc_counter_name.argtypes = [C.c_int]; lib.rsqc_counter_name.restype = C.c_char_p
@@ -59,7 +61,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
 ]
 
@@ -78,6 +80,7 @@ class Engine:
         self._l = load_library()
         self._h = C.c_void_p()
         self._keep = []
+        self._pinned = []
         rc = self._l.rsqc_create(C.byref(params), C.byref(self._h))
         if rc:
             raise EngineError(rc, self._l.rsqc_strerror(rc).decode())
@@ -102,6 +105,22 @@ class Engine:
         s = batch.to_struct()
         self._keep += [batch, s]
         self._check(self._l.rsqc_submit(self._h, C.byref(s)))
+
+    def submit_struct(self, s):
+        """rsqc_submit of an already packed abi.BatchStruct (the caller keeps its arrays alive until wait())."""
+        self._check(self._l.rsqc_submit(self._h, C.byref(s)))
+
+    def pinned_copy(self, a: np.ndarray) -> np.ndarray:
+        """A copy of `a` in page-locked host memory (rsqc_host_alloc); freed with the engine."""
+        a = np.ascontiguousarray(a)
+        nbytes = max(a.nbytes, 16)
+        p = self._l.rsqc_host_alloc(nbytes)
+        if not p:
+            raise EngineError(abi.ERR_HIP, "rsqc_host_alloc failed")
+        self._pinned.append(p)
+        out = np.frombuffer((C.c_char * nbytes).from_address(p), dtype=a.dtype, count=a.size).reshape(a.shape)
+        out[...] = a
+        return out
 
     def wait(self):
         self._check(self._l.rsqc_wait(self._h))
@@ -159,6 +178,9 @@ class Engine:
         if self._h:
             self._l.rsqc_destroy(self._h)
             self._h = C.c_void_p()
+            for p in self._pinned:
+                self._l.rsqc_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
