@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_M
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=5_000_000, help="read pairs per GPU (2 records each)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-finalize", action="store_true", help="(diagnostic) time K1 only; output marked invalid")
