@@ -145,7 +145,7 @@ def main():
 
     if rank == 0:
         # HBM traffic of K1 per launch comes from separate rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE and WRITE_SIZE cannot share a pass); tools_pmc.sh stores them in profiles/k1_traffic.json
+        # (FETCH_SIZE and WRITE_SIZE cannot share a pass); tools/pmc.sh stores them in profiles/k1_traffic.json
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.pairs == 5_000_000 and not args.genome:

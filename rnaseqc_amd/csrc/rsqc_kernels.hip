@@ -212,9 +212,6 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
     bool big_any = false;
     auto vertical_add = [&](uint64_t bits) {
-#ifdef EXP_NOCNT
-        return;
-#endif
         uint64_t carry = bits, t;
         t = pl0 & carry; pl0 ^= carry; carry = t;
         t = pl1 & carry; pl1 ^= carry; carry = t;
@@ -327,11 +324,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                     go = gate_cascade(a, p, r, cw, rc, hq) && !(p.dbg & 8u);
                     fl = r.flag; tid = r.tid;
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
-#ifdef EXP_NOBED
-                    if (false) {
-#else
                     if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
-#endif
                         const int32_t name = bed_interval_of(a, r);
                         if (name >= 0) {
                             const uint32_t slot = atomicAdd(acc.frag.count, 1u);
@@ -349,10 +342,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             }
             // scalar counters of the gate cascade: vertical add of the record's one-bit increments
             vertical_add(rc.bits);
-#ifndef EXP_NOCNT
             sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
             sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
-#endif
             big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
             // Read-Length inputs: per-wave max span + batch-level extremes
             const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
@@ -402,15 +393,11 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             struct { uint32_t row, cidx, len; } cm = {fo.row[k], fo.cidx[k], B.len[k >> 1]};
             const bool hv = has && cm.len > 0;
             if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, cm.row, (double)cm.len * inv_aligned);
-#ifdef EXP_NOCOVRUN
-            if (hv) { atomicAdd(&acc.cov_diff[cm.cidx], 1u); atomicAdd(&acc.cov_diff[cm.cidx + cm.len], 0xFFFFFFFFu); }
-#else
             if (!(p.dbg & 1u)) {                 // +1 at the block start, -1 after its last base
                 const uint32_t base = hv ? cm.cidx : 0u;
                 cov_add_merged(acc.cov_diff, hv, base, 1u);
                 cov_add_merged(acc.cov_diff, hv, base + cm.len, 0xFFFFFFFFu);
             }
-#endif
         }
 #pragma unroll
         for (int k = 0; k < FAST_SET; ++k) {
