@@ -84,7 +84,7 @@ struct rsqc_ctx {
     DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
-           off_bias5 = 0, off_ecv = 0, off_gvalid = 0, off_ecvv = 0, off_misc = 0;
+           off_bias5 = 0, off_ecv = 0, off_gvalid = 0, off_ecvv = 0, off_ehit = 0, off_misc = 0;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;   // K3 (three size classes) runs beside K4
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
     DevAccum acc{};
@@ -110,9 +110,7 @@ struct rsqc_ctx {
     rsqc_timing timing{};
 
     // host results
-    std::vector<uint64_t> h_reads, h_unique, h_frag, h_bias3, h_bias5, h_fcount;
-    std::vector<double> h_exon, h_gmean, h_gstd, h_gcv, h_ecv;
-    std::vector<uint8_t> h_exon_hit, h_gvalid, h_ecv_valid;
+    std::vector<uint64_t> h_fcount;
     std::vector<int64_t> h_fsize;
     rsqc_results results{};
 };
@@ -438,6 +436,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
 #define UPA(dst, ptr, n) if ((rc = upload(c, c->ann_bufs, (ptr), (size_t)(n), &(dst)))) return rc
     UPV(d.ex, hx.ex_rows); UPV(d.gb, hx.gb); UPV(d.contig, hx.contig);
     UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov); UPV(d.ex_pmax, hx.ex_pmax);
+    UPV(d.ex_id, c->exon_row_id);
     auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
     auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
     // empty BED until rsqc_set_bed
@@ -477,6 +476,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     c->off_ecv = at; at += Ez * 8;
     c->off_gvalid = at; at += pad8(Lz);
     c->off_ecvv = at; at += pad8(Ez);
+    c->off_ehit = at; at += pad8(Ez);
     c->off_misc = at; at += 64;
     c->arena_bytes = at;
     if ((rc = dev_alloc(c, c->d_arena, at, false))) return rc;
@@ -603,44 +603,25 @@ int rsqc_reset(rsqc_ctx *c) {
 }
 
 // one D2H of the whole arena into the pinned mirror, then unpack into the results struct
+// The device holds every result vector in its final order (genes by listed id, exons by exon id), so the read-back
+// is ONE D2H of the arena into the page-locked mirror; the results struct points straight into the mirror.
 static int read_back(rsqc_ctx *c) {
     const int G = c->n_genes, L = c->n_listed, E = c->n_exons;
+    char *A = (char *)c->d_arena.p;
+    launch_pack_results(c->stream, (const double *)(A + c->off_exon), (uint8_t *)(A + c->off_ehit), (uint32_t)E);
     HIP_TRY(c, hipMemcpyAsync(c->h_arena, c->d_arena.p, c->arena_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const char *H = c->h_arena;
-    const uint64_t *u = (const uint64_t *)(H + c->off_u64);
-    const double *exon_rows = (const double *)(H + c->off_exon);
-    c->h_reads.assign(u, u + L);
-    c->h_unique.assign(u + G, u + G + L);
-    c->h_frag.assign(u + 2 * (size_t)G, u + 2 * (size_t)G + L);
-    c->h_exon.assign((size_t)E, 0.0); c->h_exon_hit.assign((size_t)E, 0);
-    for (int r = 0; r < E; ++r) {
-        const uint32_t id = c->exon_row_id[(size_t)r];
-        c->h_exon[id] = exon_rows[r];
-        c->h_exon_hit[id] = exon_rows[r] > 0.0 ? 1 : 0;
-    }
+    char *H = c->h_arena;
+    uint64_t *u = (uint64_t *)(H + c->off_u64);
     rsqc_results &R = c->results;
     for (int k = 0; k < RSQC_N_COUNTERS; ++k) R.counters[k] = u[3 * (size_t)G + (size_t)k];
     R.n_genes_listed = L; R.n_exons = E;
-    R.gene_reads = c->h_reads.data(); R.gene_unique = c->h_unique.data(); R.gene_fragments = c->h_frag.data();
-    R.exon_reads = c->h_exon.data(); R.exon_hit = c->h_exon_hit.data();
-    const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
-    const double *gm = (const double *)(H + c->off_gmean), *gs = (const double *)(H + c->off_gstd), *gc = (const double *)(H + c->off_gcv);
-    const uint64_t *b3 = (const uint64_t *)(H + c->off_bias3), *b5 = (const uint64_t *)(H + c->off_bias5);
-    const double *ecv = (const double *)(H + c->off_ecv);
-    const uint8_t *gv = (const uint8_t *)(H + c->off_gvalid), *ev = (const uint8_t *)(H + c->off_ecvv);
-    c->h_gmean.assign(gm, gm + Lz); c->h_gstd.assign(gs, gs + Lz); c->h_gcv.assign(gc, gc + Lz);
-    c->h_gvalid.assign(gv, gv + Lz); c->h_bias3.assign(b3, b3 + Lz); c->h_bias5.assign(b5, b5 + Lz);
-    c->h_ecv.assign(Ez, 0.0); c->h_ecv_valid.assign(Ez, 0);
-    for (int r = 0; r < E; ++r) if (ev[r]) {
-        c->h_ecv[c->exon_row_id[(size_t)r]] = ecv[r];
-        c->h_ecv_valid[c->exon_row_id[(size_t)r]] = 1;
-    }
-    for (int g = 0; g < L; ++g) if (!c->h_gvalid[(size_t)g]) { c->h_gmean[(size_t)g] = c->h_gstd[(size_t)g] = c->h_gcv[(size_t)g] = 0.0; }
+    R.gene_reads = u; R.gene_unique = u + G; R.gene_fragments = u + 2 * (size_t)G;
+    R.exon_reads = (double *)(H + c->off_exon); R.exon_hit = (uint8_t *)(H + c->off_ehit);
     R.read_length = *(const int32_t *)(H + c->off_misc + 8);
-    R.gene_cov_mean = c->h_gmean.data(); R.gene_cov_std = c->h_gstd.data(); R.gene_cov_cv = c->h_gcv.data();
-    R.gene_cov_valid = c->h_gvalid.data(); R.exon_cv = c->h_ecv.data(); R.exon_cv_valid = c->h_ecv_valid.data();
-    R.bias_three = c->h_bias3.data(); R.bias_five = c->h_bias5.data();
+    R.gene_cov_mean = (double *)(H + c->off_gmean); R.gene_cov_std = (double *)(H + c->off_gstd); R.gene_cov_cv = (double *)(H + c->off_gcv);
+    R.gene_cov_valid = (uint8_t *)(H + c->off_gvalid); R.exon_cv = (double *)(H + c->off_ecv); R.exon_cv_valid = (uint8_t *)(H + c->off_ecvv);
+    R.bias_three = (uint64_t *)(H + c->off_bias3); R.bias_five = (uint64_t *)(H + c->off_bias5);
     R.n_fragment_sizes = (uint32_t)c->h_fsize.size();
     R.fragment_size = c->h_fsize.data(); R.fragment_count = c->h_fcount.data();
     R.fragment_samples_remaining = c->frag_remaining;
@@ -668,7 +649,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
         GeneCovArgs Ga{};
         Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
-        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov;
+        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov; Ga.ex_id = c->dann.ex_id;
         Ga.gene_cov_off = c->d_gene_cov_off; Ga.gene_coding = c->d_gene_coding;
         Ga.gene_flags = c->d_gene_flags; Ga.gene_owned = c->d_gene_owned;
         Ga.gene_order = c->d_gene_order;

@@ -65,6 +65,7 @@ struct GeneCovArgs {
     const uint32_t *ge_off, *ge_row;        // exonsForGene CSR (gene id -> exon rows)
     const ExonRow *ex;
     const uint32_t *ex_cov;                 // coverage offset of an exon row
+    const uint32_t *ex_id;                  // exon row -> exon id
     const uint32_t *gene_cov_off;           // [n_listed]
     const uint32_t *gene_coding;            // [n_listed]
     const uint8_t *gene_flags;              // [n_listed] flags of the gene row
@@ -81,6 +82,7 @@ struct GeneCovArgs {
 };
 void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium);
 
+void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons);
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min);
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc);

@@ -115,8 +115,8 @@ __device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32
 
 // accumulator used by the general (slow-path) code when it re-walks a CIGAR
 struct DirectAcc {
-    double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_cov;
-    __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[row], frac); }
+    double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_id;
+    __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[ex_id[row]], frac); }
     __device__ __forceinline__ void cov_range(uint32_t cidx, uint32_t len) {
         if (len == 0) return;
         atomicAdd(&cov_diff[cidx], 1u);
@@ -168,7 +168,7 @@ struct K1Shared {
     uint32_t gkey[K1_GSLOTS], gcnt[K1_GSLOTS], gnd[K1_GSLOTS];
     uint32_t rl[3];
     uint32_t pairs;
-    __device__ __forceinline__ void exon_add(const DevAccum &acc, uint32_t row, double frac) {
+    __device__ __forceinline__ void exon_add(const DevAccum &acc, const uint32_t *ex_id, uint32_t row, double frac) {
         uint32_t slot = row & (K1_ESLOTS - 1);
 #pragma unroll 1
         for (int probe = 0; probe < 4; ++probe) {
@@ -176,7 +176,7 @@ struct K1Shared {
             if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&eval[slot], frac); return; }
             slot = (slot + 1) & (K1_ESLOTS - 1);
         }
-        atomicAdd(&acc.exon_acc[row], frac);
+        atomicAdd(&acc.exon_acc[ex_id[row]], frac);
     }
     __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, bool notdup) {
         uint32_t slot = g & (K1_GSLOTS - 1);
@@ -392,7 +392,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (hm == 0ull) continue;
             struct { uint32_t row, cidx, len; } cm = {fo.row[k], fo.cidx[k], B.len[k >> 1]};
             const bool hv = has && cm.len > 0;
-            if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, cm.row, (double)cm.len * inv_aligned);
+            if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, a.ex_id, cm.row, (double)cm.len * inv_aligned);
             if (!(p.dbg & 1u)) {                 // +1 at the block start, -1 after its last base
                 const uint32_t base = hv ? cm.cidx : 0u;
                 cov_add_merged(acc.cov_diff, hv, base, 1u);
@@ -434,7 +434,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x)
         if (S.cnt[c]) atomicAdd(&acc.counters[c], S.cnt[c]);
     for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x)
-        if (S.ekey[c] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[S.ekey[c]], S.eval[c]);
+        if (S.ekey[c] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[a.ex_id[S.ekey[c]]], S.eval[c]);      // accumulators are indexed by exon id
     for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x)
         if (S.gkey[c] != 0xFFFFFFFFu) {
             atomicAdd(&acc.gene_reads[S.gkey[c]], (unsigned long long)S.gcnt[c]);
@@ -499,7 +499,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x) { s_ckey[i] = 0xFFFFFFFFu; s_cval[i] = 0u; }
     __syncthreads();
     const int l = lane_id();
-    DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_cov};
+    DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_id};
     auto exon_add_lds = [&](uint32_t row, double frac) {
         uint32_t slot = (row * 2654435761u) >> 22;                      // 10 bits
         for (int probe = 0; probe < 16; ++probe) {
@@ -507,7 +507,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
             if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&s_val[slot], frac); return; }
             slot = (slot + 1) & (RSQC_SLOW_SLOTS - 1);
         }
-        atomicAdd(&acc.exon_acc[row], frac);                            // table crowded: straight to memory
+        atomicAdd(&acc.exon_acc[a.ex_id[row]], frac);                   // table crowded: straight to memory
     };
     auto cov_add_lds = [&](uint32_t idx, uint32_t delta) {
         uint32_t slot = (idx * 2654435761u) >> 19;                      // 13 bits
@@ -607,7 +607,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&acc.counters[l], my_cnt);
     __syncthreads();
     for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x)
-        if (s_key[i] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[s_key[i]], s_val[i]);
+        if (s_key[i] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[a.ex_id[s_key[i]]], s_val[i]);
     for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x)
         if (s_ckey[i] != 0xFFFFFFFFu && s_cval[i] != 0u) atomicAdd(&acc.cov_diff[s_ckey[i]], s_cval[i]);
 }
@@ -956,8 +956,9 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
                 const uint32_t cur = W / 2 < coding ? W / 2 : coding;
                 if ((W < cur ? W : cur) == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN);
             }
-            A.g_valid[gene] = (MASK ? coding > 2 * (uint64_t)MASK : coding > 0) ? 1 : 0;
-            A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = qnan;
+            const bool pushed = MASK ? coding > 2 * (uint64_t)MASK : coding > 0;
+            A.g_valid[gene] = pushed ? 1 : 0;
+            A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = pushed ? qnan : 0.0;
         }
         return;
     }
@@ -1007,7 +1008,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
 #pragma unroll 4
                     for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) { const double d = (double)C[j] - mean; q += d * d; }
                     const double cv = sqrt(wave_sum(q) / size) / mean;
-                    if (l == 0 && !(isnan(cv) || isinf(cv))) { A.e_cv[row] = cv; A.e_cv_valid[row] = 1; }
+                    if (l == 0 && !(isnan(cv) || isinf(cv))) { const uint32_t id = A.ex_id[row]; A.e_cv[id] = cv; A.e_cv_valid[id] = 1; }
                 }
             }
         }
@@ -1126,8 +1127,16 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             for (uint32_t j = a + tid; j < bnd; j += T) { const double d = (double)C[j] - mean; q += d * d; }
             const double sd = sqrt(block_sum_f64(q, S) / size);
             if (tid == 0) { A.g_valid[gene] = 1; A.g_mean[gene] = mean; A.g_std[gene] = sd; A.g_cv[gene] = sd / mean; }
-        } else if (tid == 0) A.g_valid[gene] = 0;
+        } else if (tid == 0) { A.g_valid[gene] = 0; A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = 0.0; }
     }
+}
+
+// ------------------------------------------------------------------ result packing
+// exon_hit[id] = the exon has a map entry in the reference's exonCounts (a non-zero sum; src/RNASeQC.cpp:513).
+// Runs right before the read-back, i.e. after a multi-GPU reduction of the sums.
+__global__ void __launch_bounds__(256)
+pack_results_kernel(const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_exons; i += gridDim.x * blockDim.x) exon_hit[i] = exon_acc[i] > 0.0 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ reset
@@ -1143,6 +1152,9 @@ reset_kernel(uint4 *arena, size_t arena_vec, uint4 *cov, size_t cov_vec, uint32_
 __global__ void reset_arm_kernel(uint32_t *rl_min) { *rl_min = 0xFFFFFFFFu; }
 
 // ------------------------------------------------------------------ launch wrappers
+void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons) {
+    if (n_exons) hipLaunchKernelGGL(pack_results_kernel, dim3((n_exons + 255) / 256 < 1024 ? (n_exons + 255) / 256 : 1024), dim3(256), 0, s, exon_acc, exon_hit, n_exons);
+}
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min) {
     // both allocations are 16-byte multiples with slack (rsqc_api.cpp: dev_alloc)
     hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_min);

@@ -76,6 +76,7 @@ struct DevAnnotation {
     // followed by one pad slot, so a block's -1 at offset+len always lands inside the array and a
     // plain prefix sum over the gene reproduces BaseCoverage's per-exon vectors
     const uint32_t *ex_cov;            // offset of an exon row's first base (== ExonRow::cov; used by the end-of-file stage)
+    const uint32_t *ex_id;             // exon row -> exon id (exonList order): accumulators are indexed by id
     // BED rows (sorted by contig,start), optional
     const int32_t  *bed_start, *bed_end, *bed_pmax;
     const uint32_t *bed_range;         // [n_contigs+1]
