@@ -59,7 +59,7 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
-    int k4_mode = 2, k4_grid = 2048;
+    int k4_mode = 2, k4_grid = 2048, k4_impl = 2;     // k4_impl: 1 = open-addressing table (memory-side CAS), 2 = per-gene lists + LDS partitions
     int k1_variant = 41, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
 
     // annotation (host copies needed at finalize)
@@ -379,6 +379,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
     if (const char *e = getenv("RSQC_K4_MODE")) c->k4_mode = atoi(e);
+    if (const char *e = getenv("RSQC_K4_IMPL")) c->k4_impl = atoi(e);
     if (const char *e = getenv("RSQC_K4_GRID")) c->k4_grid = std::max(1, atoi(e));
     if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
@@ -672,6 +673,36 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
         HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
         // ---- K4 on the main stream: per-gene distinct QNAMEs ---------------------------------------------
+        uint64_t pair_bound = 0;
+        for (size_t idx : c->pairs_in_flight) pair_bound += c->pair_pool[idx].pairs_bound;
+        if (c->k4_impl == 2) {
+            // streaming form: survivors appended to per-partition key lists, then counted per partition in LDS.
+            // bounds from the host's pair bound: partitions <= pairs / PART_READS + G, keys <= 2 x pairs + SUB_CAP x parts
+            const uint64_t Gz = (uint64_t)std::max(G, 1);
+            const uint64_t parts_bound = pair_bound / 1024 + Gz + 1;
+            const uint64_t keys_bound = 2 * pair_bound + 2048 * std::min<uint64_t>(parts_bound, pair_bound / 1024 + 1) + 16;
+            if (parts_bound > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment partitions");
+            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 12 + 64, false))) return rc;                      // gene_base | part_first
+            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 4 + 64, false))) return rc;                    // cursor
+            if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
+            FragPlan P;
+            P.gene_base = (uint64_t *)c->d_tab_off.p;
+            P.part_first = (uint32_t *)((uint64_t *)c->d_tab_off.p + Gz + 1);
+            P.cursor = (uint32_t *)c->d_tab_cap.p;
+            P.list = (unsigned long long *)c->d_table.p;
+            launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
+            for (size_t idx : c->pairs_in_flight) {
+                if (getenv("RSQC_DIAG_SKIP_K4")) break;                   // (diagnostic knob: results incomplete)
+                PairBuf &pb = c->pair_pool[idx];
+                DevAccum acc = c->acc;
+                acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p;
+                acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
+                acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
+                acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
+                launch_frag_local(c->stream, acc, pb.n_chunks, P);
+            }
+            if (!getenv("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, c->acc.gene_reads, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
+        } else {
         if ((rc = dev_alloc(c, c->d_tab_off, ((size_t)std::max(G, 1) + 2) * 8, false))) return rc;
         if ((rc = dev_alloc(c, c->d_tab_cap, (size_t)std::max(G, 1) * 4, false))) return rc;
         unsigned long long *d_total = (unsigned long long *)c->d_tab_off.p + std::max(G, 1);
@@ -679,8 +710,6 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                             (uint32_t *)c->d_tab_cap.p, d_total, c->acc.error);
         // table slots = 2 x sum(geneCounts) <= 2 x (pairs emitted); the host only knows the bound, the exact
         // count stays on the device (no synchronisation here)
-        uint64_t pair_bound = 0;
-        for (size_t idx : c->pairs_in_flight) pair_bound += c->pair_pool[idx].pairs_bound;
         const uint64_t slot_bound = 2 * pair_bound + 16;
         if (c->d_table.bytes < (size_t)slot_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slot_bound * 8 + (1u << 20), false))) return rc; }
         launch_dedup_clear(c->stream, (unsigned long long *)c->d_table.p, d_total);
@@ -694,6 +723,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
             launch_dedup(c->stream, acc, pb.n_chunks, (const uint64_t *)c->d_tab_off.p, (const uint32_t *)c->d_tab_cap.p,
                          (unsigned long long *)c->d_table.p, (uint32_t)c->k4_mode, c->k4_grid);
+        }
         }
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));

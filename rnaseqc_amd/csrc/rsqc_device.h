@@ -92,6 +92,17 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
                         const DevAccum &acc);
 void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
                   unsigned long long *table, uint32_t mode, int grid);
+// K4, streaming form (rsqc_kernels.hip): partition tables laid out on the device from the final geneCounts
+struct FragPlan {
+    uint32_t *part_first;          // [G + 1] first partition of a gene
+    uint64_t *gene_base;           // [G] offset of the gene's key lists
+    uint32_t *cursor;              // [parts] keys appended so far
+    unsigned long long *list;      // key lists
+};
+void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error);
+void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P);
+void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound,
+                       unsigned long long *gene_frag, int *error);
 void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total);
 void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
                          uint32_t *tab_cap, unsigned long long *total, int *error);

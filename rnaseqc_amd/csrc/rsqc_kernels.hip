@@ -839,6 +839,193 @@ dedup_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint
     }
 }
 
+// ------------------------------------------------------------------ K4, second form: no memory-side atomics
+// The open-addressing table above is bound by the chip's rate of random memory-side CAS operations (one per
+// distinct fragment).  This form replaces it by two streaming passes over PARTITIONS: a gene with n counted
+// records owns ceil(n / RSQC_K4_PART_READS) partitions (by high bits of the name hash), each with a key list of
+// fixed capacity laid out by frag_layout_kernel from the final geneCounts:
+//   frag_local_kernel   per pair chunk: LDS de-dup as before; the survivors' name hashes are APPENDED to their
+//                       partition's list (space for one piece's survivors of a partition is reserved with ONE
+//                       global atomicAdd; positions inside the reservation come from an LDS counter)
+//   frag_count_kernel   one workgroup per partition: its keys go through an LDS hash set; the number of distinct
+//                       keys is added to geneFragmentCounts
+// A partition expects <= RSQC_K4_PART_READS / 2 .. RSQC_K4_PART_READS keys and has room for RSQC_K4_SUB_CAP; one
+// that overflows (never with random hashes) reports RSQC_ERR_CAPACITY instead of miscounting.
+#define RSQC_K4_PART_READS 1024
+#define RSQC_K4_SUB_CAP 2048
+#define RSQC_K4_PART_SLOTS 4096
+#define RSQC_K4_COUNT_THREADS 256
+#define RSQC_K4_PIECE2 2048                     /* pairs per LDS pass of frag_local_kernel: 4 per thread */
+
+__device__ __forceinline__ uint32_t frag_parts_of(unsigned long long reads) {
+    return (uint32_t)((reads + RSQC_K4_PART_READS - 1) / RSQC_K4_PART_READS);
+}
+// per gene: part_first[g] = its first partition (part_first[n_genes] = partition count) and gene_base[g] = offset of
+// its key lists; partition k of the gene has capacity frag_cap_of(reads) and starts at gene_base + k * capacity
+__device__ __forceinline__ uint32_t frag_cap_of(unsigned long long reads) {
+    return frag_parts_of(reads) == 1 ? (uint32_t)reads : (uint32_t)RSQC_K4_SUB_CAP;
+}
+__global__ void __launch_bounds__(1024)
+frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint32_t *part_first, uint64_t *gene_base, int *error) {
+    __shared__ unsigned long long s_space[1024];
+    __shared__ uint32_t s_parts[1024];
+    const uint32_t per = (n_genes + 1023) / 1024;
+    const uint32_t g0 = threadIdx.x * per, g1 = g0 + per < n_genes ? g0 + per : n_genes;
+    unsigned long long space = 0; uint32_t parts = 0;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const unsigned long long n = gene_reads[g];
+        if (n > 0xFFFFFFF0ull) atomicExch(error, RSQC_ERR_CAPACITY);
+        const uint32_t p = frag_parts_of(n);
+        parts += p;
+        space += (unsigned long long)p * frag_cap_of(n);
+    }
+    s_space[threadIdx.x] = space; s_parts[threadIdx.x] = parts;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long rs = 0; uint32_t rp = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const unsigned long long v = s_space[t]; const uint32_t q = s_parts[t];
+            s_space[t] = rs; s_parts[t] = rp; rs += v; rp += q;
+        }
+        part_first[n_genes] = rp;
+    }
+    __syncthreads();
+    unsigned long long off = s_space[threadIdx.x]; uint32_t pp = s_parts[threadIdx.x];
+    for (uint32_t g = g0; g < g1; ++g) {
+        const unsigned long long n = gene_reads[g];
+        const uint32_t p = frag_parts_of(n);
+        part_first[g] = pp; gene_base[g] = off;
+        pp += p; off += (unsigned long long)p * frag_cap_of(n);
+    }
+}
+__global__ void __launch_bounds__(256)
+frag_zero_kernel(uint32_t *cursor, const uint32_t *part_first, uint32_t n_genes) {
+    const uint32_t n = part_first[n_genes];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cursor[i] = 0u;
+}
+
+struct K4LocalShared {
+    unsigned long long lkey[RSQC_K4_LSLOTS];
+    uint32_t lgene[RSQC_K4_LSLOTS];
+    uint32_t gkey[RSQC_K4_GSLOTS], gcnt[RSQC_K4_GSLOTS], gbase[RSQC_K4_GSLOTS];      // keyed by partition id
+};
+
+__global__ void __launch_bounds__(RSQC_K4_THREADS)
+frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
+                  const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
+                  const unsigned long long *gene_reads, const uint32_t *part_first, const uint64_t *gene_base, uint32_t *cursor,
+                  unsigned long long *list, int *error) {
+    __shared__ K4LocalShared S;
+    uint32_t base, count, piece0 = 0, piece_step = 1;
+    if (blockIdx.x < n_chunks) {
+        base = blockIdx.x * chunk_cap;
+        count = chunk_count[blockIdx.x] < chunk_cap ? chunk_count[blockIdx.x] : chunk_cap;
+    } else {
+        base = slow_base;
+        count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
+        piece0 = blockIdx.x - n_chunks; piece_step = gridDim.x - n_chunks;
+    }
+    constexpr int U = RSQC_K4_PIECE2 / RSQC_K4_THREADS;
+    const uint32_t n_pieces = (count + RSQC_K4_PIECE2 - 1) / RSQC_K4_PIECE2;
+    for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < RSQC_K4_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
+        for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x) { S.gkey[i] = 0xFFFFFFFFu; S.gcnt[i] = 0u; }
+        __syncthreads();
+        const uint32_t p0 = piece * RSQC_K4_PIECE2, p1 = p0 + RSQC_K4_PIECE2 < count ? p0 + RSQC_K4_PIECE2 : count;
+        bool live[U]; uint32_t g[U], gp[U], gslot[U], rank[U]; uint64_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                      // the pairs of the piece
+            const uint32_t j = p0 + (uint32_t)u * RSQC_K4_THREADS + threadIdx.x;
+            live[u] = j < p1;
+            g[u] = live[u] ? pair_gene[base + j] : 0u;
+            key[u] = live[u] ? pair_hash[base + j] : 0ull;
+            gslot[u] = 0xFFFFFFFFu; rank[u] = 0; gp[u] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                      // de-dup inside the piece (see dedup_kernel)
+            if (key[u] == 0) key[u] = 0x9e3779b97f4a7c15ull;
+            if (live[u]) {
+                unsigned long long lk = key[u] ^ ((unsigned long long)g[u] * 0x9E3779B97F4A7C15ull);
+                if (lk == 0ull) lk = 1ull;
+                uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4_LSLOTS - 1);
+                bool done = false;
+#pragma unroll 1
+                for (int probe = 0; probe < 8 && !done; ++probe) {
+                    const unsigned long long old = atomicCAS(&S.lkey[slot], 0ull, lk);
+                    if (old == 0ull) { S.lgene[slot] = g[u]; done = true; }
+                    if (!done && old == lk) { if (S.lgene[slot] == g[u]) live[u] = false; done = true; }
+                    slot = (slot + 1) & (RSQC_K4_LSLOTS - 1);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                      // survivors per partition: rank inside the piece
+            if (!live[u]) continue;
+            const uint32_t first = part_first[g[u]], n_part = part_first[g[u] + 1] - first;
+            gp[u] = first + (n_part > 1 ? (uint32_t)(((mix64(key[u]) >> 32) * (unsigned long long)n_part) >> 32) : 0u);
+            uint32_t sl = gp[u] & (RSQC_K4_GSLOTS - 1);
+#pragma unroll 1
+            for (int probe = 0; probe < 8; ++probe) {
+                const uint32_t o = atomicCAS(&S.gkey[sl], 0xFFFFFFFFu, gp[u]);
+                if (o == 0xFFFFFFFFu || o == gp[u]) { gslot[u] = sl; rank[u] = atomicAdd(&S.gcnt[sl], 1u); break; }
+                sl = (sl + 1) & (RSQC_K4_GSLOTS - 1);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x)     // one reservation per partition of the piece
+            if (S.gkey[i] != 0xFFFFFFFFu) S.gbase[i] = atomicAdd(&cursor[S.gkey[i]], S.gcnt[i]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            const uint32_t at = gslot[u] != 0xFFFFFFFFu ? S.gbase[gslot[u]] + rank[u] : atomicAdd(&cursor[gp[u]], 1u);   // (crowded table)
+            const uint32_t cap = frag_cap_of(gene_reads[g[u]]);
+            if (at < cap) list[gene_base[g[u]] + (unsigned long long)(gp[u] - part_first[g[u]]) * cap + at] = key[u];
+            else atomicExch(error, RSQC_ERR_CAPACITY);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
+frag_count_kernel(const unsigned long long *gene_reads, const uint32_t *part_first, uint32_t n_genes, const uint64_t *gene_base,
+                  const uint32_t *cursor, const unsigned long long *list, unsigned long long *gene_frag, int *error) {
+    __shared__ unsigned long long s_keys[RSQC_K4_PART_SLOTS];
+    __shared__ uint32_t s_fresh;
+    const uint32_t n_parts = part_first[n_genes];
+    for (uint32_t w = blockIdx.x; w < n_parts; w += gridDim.x) {
+        if (cursor[w] == 0) continue;                                  // (uniform)
+        uint32_t lo = 0, hi = n_genes;                                 // owning gene: last g with part_first[g] <= w
+        while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (part_first[m] <= w) lo = m; else hi = m; }
+        const uint32_t gene = lo;                                      // (genes without partitions share part_first with their successor: the last such index owns w)
+        const uint32_t cap = frag_cap_of(gene_reads[gene]);
+        const uint32_t n = cursor[w] < cap ? cursor[w] : cap;
+        const unsigned long long *keys = list + gene_base[gene] + (unsigned long long)(w - part_first[gene]) * cap;
+        __syncthreads();
+        for (int i = threadIdx.x; i < RSQC_K4_PART_SLOTS; i += blockDim.x) s_keys[i] = 0ull;
+        if (threadIdx.x == 0) s_fresh = 0u;
+        __syncthreads();
+        uint32_t fresh = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long k = keys[i];
+            uint32_t slot = (uint32_t)mix64(k) & (RSQC_K4_PART_SLOTS - 1);
+            bool placed = false;
+#pragma unroll 1
+            for (int probe = 0; probe < RSQC_K4_PART_SLOTS; ++probe) {
+                const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
+                if (old == 0ull) { ++fresh; placed = true; break; }
+                if (old == k) { placed = true; break; }
+                slot = (slot + 1) & (RSQC_K4_PART_SLOTS - 1);
+            }
+            if (!placed) atomicExch(error, RSQC_ERR_CAPACITY);
+        }
+        fresh = wave_sum(fresh);
+        if (lane_id() == 0 && fresh) atomicAdd(&s_fresh, fresh);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_fresh) atomicAdd(&gene_frag[gene], (unsigned long long)s_fresh);
+    }
+}
+
 // ------------------------------------------------------------------ K3
 // One workgroup per gene, longest genes first.  cov[] holds the per-base DIFFERENCE array of the
 // gene's exons, contiguous in exonsForGene order (+1 pad slot), so a plain prefix sum yields the
@@ -1184,6 +1371,21 @@ void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const u
     hipLaunchKernelGGL(dedup_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base,
                        acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag, mode);
+}
+void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error) {
+    hipLaunchKernelGGL(frag_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, P.part_first, P.gene_base, error);
+    hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_first, n_genes);
+}
+void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P) {
+    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
+                       acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
+                       acc.gene_reads, P.part_first, P.gene_base, P.cursor, P.list, acc.error);
+}
+void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound,
+                       unsigned long long *gene_frag, int *error) {
+    const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
+    hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, gene_reads, P.part_first, n_genes, P.gene_base,
+                       P.cursor, P.list, gene_frag, error);
 }
 void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total) {
     hipLaunchKernelGGL(dedup_clear_kernel, dim3(2048), dim3(256), 0, s, table, total);
