@@ -12,6 +12,7 @@
 // coding-length classes of the end-of-file coverage stage: one wave / 256 threads with the vector in LDS, 1024 threads in memory
 #define RSQC_K3_SMALL_MAX 4096
 #define RSQC_K3_MEDIUM_MAX 12288
+#define RSQC_K3_LARGE_LDS16 73000      /* bases a 1024-thread workgroup keeps in LDS as 16-bit depths (146 KB of the CU's 160 KB) */
 #define RSQC_K3_MAX_EXONS 1024
 
 namespace rsqc {

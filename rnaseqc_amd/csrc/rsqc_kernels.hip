@@ -1038,10 +1038,10 @@ template <int T> __device__ __forceinline__ void k3_sync() {
     if constexpr (T > 64) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 }
-template <int T_, int WIN_, int LDSCAP_>
+template <int T_, int WIN_, class CovT_, int LDSCAP_>
 struct K3Shared {
     static constexpr int T = T_, WIN = WIN_, W = T_ / 64, LDSCAP = LDSCAP_;
-    uint32_t covbuf[LDSCAP_ > 0 ? LDSCAP_ : 1];      // the gene's coverage vector when it fits (see the kernel)
+    CovT_ covbuf[LDSCAP_ > 0 ? LDSCAP_ : 1];         // the gene's coverage vector when it fits (see the kernel)
     unsigned long long u64[W];
     double f64[W];
     uint32_t u32a[W], u32b[W];
@@ -1115,10 +1115,10 @@ template <class SH> __device__ bool window_median(const uint32_t *w, uint32_t n,
     return true;
 }
 
-template <int T, int WIN, int LDSCAP>
+template <int T, int WIN, class CovT, int LDSCAP>
 __global__ void __launch_bounds__(T)
 gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
-    __shared__ K3Shared<T, WIN, LDSCAP> S;
+    __shared__ K3Shared<T, WIN, CovT, LDSCAP> S;
     const int tid = (int)threadIdx.x;
     const int l = lane_id();
     const int wv = tid >> 6;
@@ -1127,11 +1127,12 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
     const uint32_t coding = A.gene_coding[gene];
     const uint32_t e0 = A.ge_off[gene], e1 = A.ge_off[gene + 1], n_ex = e1 - e0;
     // Every later pass re-reads the coverage vector; a gene that fits keeps it in LDS (the difference array is
-    // read from memory once and never written back: nothing downstream needs it), longer genes scan in place
-    // in memory and rely on unrolled, independent loads.
+    // read from memory once and never written back: nothing downstream needs it) -- as 32-bit values, or as
+    // 16-bit values for the longest genes (160 KB of LDS hold 73 k bases) as long as no base is covered 65 536
+    // times or more.  Otherwise the scan runs in place in memory and the passes rely on unrolled, independent loads.
     uint32_t *const D = A.cov + A.gene_cov_off[gene];
-    uint32_t *C;
-    if constexpr (LDSCAP > 0) C = coding <= (uint32_t)LDSCAP ? S.covbuf : D; else C = D;    // (mis-classified gene: still correct)
+    bool in_lds = LDSCAP > 0 && coding <= (uint32_t)LDSCAP;
+    auto Cget = [&](uint32_t j) -> uint32_t { return in_lds ? (uint32_t)S.covbuf[j] : D[j]; };
     const uint32_t MASK = A.mask;
     const uint32_t W = (uint32_t)A.bias_window, OFF = (uint32_t)A.bias_offset;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
@@ -1150,9 +1151,9 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
         return;
     }
     // (1) difference array -> coverage: block-wide inclusive scan, 16 consecutive bases per thread per round
-    {
+    auto scan = [&]() -> bool {                        // returns false when a value does not fit the LDS cell type
         constexpr int PER = 16;
-        uint32_t carry = 0;
+        uint32_t carry = 0, vmax = 0;
         for (uint32_t base = 0; base < coding; base += T * PER) {
             const uint32_t j = base + (uint32_t)tid * PER;
             uint32_t v[PER];
@@ -1169,10 +1170,17 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             for (int w = 0; w < (T / 64); ++w) { const uint32_t t = S.u32b[w]; if (w < wv) before += t; total += t; }
             const uint32_t ex = before + inc - v[PER - 1];
 #pragma unroll
-            for (int k = 0; k < PER; ++k) if (j + k < coding) C[j + k] = v[k] + ex;
+            for (int k = 0; k < PER; ++k) if (j + k < coding) {
+                const uint32_t x = v[k] + ex;
+                vmax = x > vmax ? x : vmax;
+                if (in_lds) S.covbuf[j + k] = (CovT)x; else D[j + k] = x;
+            }
             carry += total;
         }
-    }
+        if constexpr (sizeof(CovT) < 4) { if (in_lds) return block_max_u32(vmax, S) <= (uint32_t)(CovT)~(CovT)0; }
+        return true;
+    };
+    if (!scan()) { in_lds = false; scan(); }           // (uniform: block_max_u32 broadcasts) too deep for 16 bits: in memory
     __threadfence_block();
     k3_sync<T>();
     // (2) per-exon CV over transcript positions [MASK, coding-MASK) (src/Metrics.cpp:267-305): one wave per
@@ -1189,24 +1197,24 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
                     const double size = (double)(b0 - a0);
                     unsigned long long sm = 0;
 #pragma unroll 4
-                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) sm += C[j];
+                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) sm += Cget(j);
                     const double mean = (double)wave_sum(sm) / size;
                     double q = 0.0;
 #pragma unroll 4
-                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) { const double d = (double)C[j] - mean; q += d * d; }
+                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) { const double d = (double)Cget(j) - mean; q += d * d; }
                     const double cv = sqrt(wave_sum(q) / size) / mean;
                     if (l == 0 && !(isnan(cv) || isinf(cv))) { const uint32_t id = A.ex_id[row]; A.e_cv[id] = cv; A.e_cv_valid[id] = 1; }
                 }
             }
         }
     }
-    // (3) bias (src/Metrics.cpp:160-235) on the stitched, unmasked vector C[0..coding)
+    // (3) bias (src/Metrics.cpp:160-235) on the stitched, unmasked coverage vector [0, coding)
     uint32_t v0 = 0, v1 = coding;          // the (possibly trimmed) vector the gene stats use (Q14)
     if (coding >= A.bias_gene_length) {
         uint32_t best = 0, best_i = 0xFFFFFFFFu;
         unsigned long long nz = 0;
 #pragma unroll 8
-        for (uint32_t j = tid; j < coding; j += T) { const uint32_t v = C[j]; nz += v != 0u; if (v > best) { best = v; best_i = j; } }
+        for (uint32_t j = tid; j < coding; j += T) { const uint32_t v = Cget(j); nz += v != 0u; if (v > best) { best = v; best_i = j; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const uint32_t ob = __shfl_xor(best, o, 64), oi = __shfl_xor(best_i, o, 64);
@@ -1224,10 +1232,10 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
         cur -= n;
         double gate = 0.0;
         if (n == 0) { if (tid == 0) atomicExch(A.error, RSQC_ERR_EMPTY_MEDIAN); }
-        else if (n == 1) gate = (double)C[cur];
+        else if (n == 1) gate = (double)Cget(cur);
         else {
             const uint32_t mid = (n - 1) / 2;
-            gate = (n & 1u) ? ((double)C[cur + mid] + (double)C[cur + mid + 1]) / 2.0 : (double)C[cur + mid];
+            gate = (n & 1u) ? ((double)Cget(cur + mid) + (double)Cget(cur + mid + 1)) / 2.0 : (double)Cget(cur + mid);
         }
         if (n != 0 && gate >= 100.0) {
             // 5th percentile of the non-zero coverage = order statistic R of the whole vector
@@ -1243,7 +1251,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
                 k3_sync<T>();
 #pragma unroll 8
                 for (uint32_t j = tid; j < coding; j += T) {            // (same-bin LDS atomics of a wave serialise inside ONE
-                    const uint32_t v = C[j];                            //  instruction, ~1 cycle per lane: cheaper than merging them)
+                    const uint32_t v = Cget(j);                            //  instruction, ~1 cycle per lane: cheaper than merging them)
                     if ((v & pmask) == prefix) atomicAdd(&S.hist[(v >> shift) & 0xFF], 1u);
                 }
                 k3_sync<T>();
@@ -1269,7 +1277,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             // trim leading / trailing entries <= lower (in place in the reference: Q14)
             uint32_t first_gt = 0xFFFFFFFFu, last_gt = 0;
 #pragma unroll 8
-            for (uint32_t j = tid; j < coding; j += T) if (C[j] > lower) { if (first_gt == 0xFFFFFFFFu) first_gt = j; last_gt = j + 1; }
+            for (uint32_t j = tid; j < coding; j += T) if (Cget(j) > lower) { if (first_gt == 0xFFFFFFFFu) first_gt = j; last_gt = j + 1; }
             first_gt = block_min_u32(first_gt, S);
             last_gt = block_max_u32(last_gt, S);
             if (first_gt == 0xFFFFFFFFu) { v0 = coding; v1 = coding; } else { v0 = first_gt; v1 = last_gt; }
@@ -1281,8 +1289,8 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
                 uint32_t nr = 0, rlo = 0;
                 if ((uint64_t)W + OFF <= tlen) { rlo = tlen - W - OFF; nr = W; }
                 k3_sync<T>();
-                for (uint32_t j = tid; j < nl; j += T) S.win[0][j] = C[v0 + OFF + j];
-                for (uint32_t j = tid; j < nr; j += T) S.win[1][j] = C[v0 + rlo + j];
+                for (uint32_t j = tid; j < nl; j += T) S.win[0][j] = Cget(v0 + OFF + j);
+                for (uint32_t j = tid; j < nr; j += T) S.win[1][j] = Cget(v0 + rlo + j);
                 k3_sync<T>();
                 double ml = 0.0, mr = 0.0;
                 const bool okl = window_median(S.win[0], nl, &ml, S);
@@ -1296,7 +1304,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             }
         }
     }
-    // (4) gene mean / std / CV on V = C[v0..v1) with MASK bases removed at both ends
+    // (4) gene mean / std / CV on positions [v0, v1) with MASK bases removed at both ends
     {
         const uint32_t len = v1 - v0;
         uint32_t a = v0, bnd = v1;
@@ -1307,11 +1315,11 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             const double size = (double)(bnd - a);
             unsigned long long sm = 0;
 #pragma unroll 8
-            for (uint32_t j = a + tid; j < bnd; j += T) sm += C[j];
+            for (uint32_t j = a + tid; j < bnd; j += T) sm += Cget(j);
             const double mean = (double)block_sum_u64(sm, S) / size;
             double q = 0.0;
 #pragma unroll 8
-            for (uint32_t j = a + tid; j < bnd; j += T) { const double d = (double)C[j] - mean; q += d * d; }
+            for (uint32_t j = a + tid; j < bnd; j += T) { const double d = (double)Cget(j) - mean; q += d * d; }
             const double sd = sqrt(block_sum_f64(q, S) / size);
             if (tid == 0) { A.g_valid[gene] = 1; A.g_mean[gene] = mean; A.g_std[gene] = sd; A.g_cv[gene] = sd / mean; }
         } else if (tid == 0) { A.g_valid[gene] = 0; A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = 0.0; }
@@ -1401,14 +1409,14 @@ void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const G
     // (disjoint genes) and go to three streams so that they overlap
     const uint32_t n = (uint32_t)A.n_listed, n_small = n - n_large - n_medium;
     const bool wide = A.bias_window > 128;
-#define RSQC_K3_LAUNCH(T, CAP, COUNT, FIRST, STREAM)                                                                         \
+#define RSQC_K3_LAUNCH(T, COVT, CAP, COUNT, FIRST, STREAM)                                                                   \
     if (COUNT) {                                                                                                        \
-        if (wide) hipLaunchKernelGGL((gene_coverage_kernel<T, RSQC_MAX_BIAS_WINDOW, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST); \
-        else hipLaunchKernelGGL((gene_coverage_kernel<T, 128, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST);        \
+        if (wide) hipLaunchKernelGGL((gene_coverage_kernel<T, RSQC_MAX_BIAS_WINDOW, COVT, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST); \
+        else hipLaunchKernelGGL((gene_coverage_kernel<T, 128, COVT, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST);  \
     }
-    RSQC_K3_LAUNCH(1024, 0, n_large, 0u, s)
-    RSQC_K3_LAUNCH(256, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
-    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
+    RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE_LDS16, n_large, 0u, s)
+    RSQC_K3_LAUNCH(256, uint32_t, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
+    RSQC_K3_LAUNCH(64, uint32_t, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
 #undef RSQC_K3_LAUNCH
 }
 
