@@ -643,36 +643,9 @@ static int run_finalize_kernels(rsqc_ctx *c) {
     char *A = (char *)c->d_arena.p;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
         HIP_TRY(c, hipEventRecord(e0, c->stream));
-        // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
+        // the side streams start from here (recorded BEFORE the K4 kernels are enqueued on the main stream)
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
-        GeneCovArgs Ga{};
-        Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
-        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov; Ga.ex_id = c->dann.ex_id;
-        Ga.gene_cov_off = c->d_gene_cov_off; Ga.gene_coding = c->d_gene_coding;
-        Ga.gene_flags = c->d_gene_flags; Ga.gene_owned = c->d_gene_owned;
-        Ga.gene_order = c->d_gene_order;
-        Ga.gene_reads = c->acc.gene_reads; Ga.cov = c->acc.cov_diff; Ga.n_listed = L;
-        Ga.mask = c->params.coverage_mask; Ga.bias_offset = c->params.bias_offset; Ga.bias_window = c->params.bias_window;
-        Ga.bias_gene_length = c->params.bias_gene_length;
-        Ga.g_mean = (double *)(A + c->off_gmean); Ga.g_std = (double *)(A + c->off_gstd); Ga.g_cv = (double *)(A + c->off_gcv);
-        Ga.g_valid = (uint8_t *)(A + c->off_gvalid); Ga.e_cv = (double *)(A + c->off_ecv); Ga.e_cv_valid = (uint8_t *)(A + c->off_ecvv);
-        Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
-        Ga.error = c->acc.error;
-        {
-            uint32_t nl = c->k3_large, nm = c->k3_medium;
-            if (const char *e = getenv("RSQC_K3_FORCE")) {           // diagnostic: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
-                const int f = atoi(e);
-                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; } else if (f == 3) { nl = 0; nm = 0; }
-            }
-            if (!getenv("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm);   // (diagnostic knob: results incomplete)
-        }
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
-        HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
-        HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
-        // ---- K4 on the main stream: per-gene distinct QNAMEs ---------------------------------------------
+        // ---- K4 on the main stream: per-gene distinct QNAMEs (the longer chain: enqueued first) ---------------
         uint64_t pair_bound = 0;
         for (size_t idx : c->pairs_in_flight) pair_bound += c->pair_pool[idx].pairs_bound;
         if (c->k4_impl == 2) {
@@ -683,12 +656,12 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             const uint64_t keys_bound = 2 * pair_bound + 2048 * std::min<uint64_t>(parts_bound, pair_bound / 1024 + 1) + 16;
             if (parts_bound > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment partitions");
             if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 12 + 64, false))) return rc;                      // gene_base | part_first
-            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 4 + 64, false))) return rc;                    // cursor
+            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 8 + 64, false))) return rc;                    // cursor | part_gene
             if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
             FragPlan P;
             P.gene_base = (uint64_t *)c->d_tab_off.p;
             P.part_first = (uint32_t *)((uint64_t *)c->d_tab_off.p + Gz + 1);
-            P.cursor = (uint32_t *)c->d_tab_cap.p;
+            P.cursor = (uint32_t *)c->d_tab_cap.p; P.part_gene = P.cursor + parts_bound;
             P.list = (unsigned long long *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
             for (size_t idx : c->pairs_in_flight) {
@@ -725,6 +698,34 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                          (unsigned long long *)c->d_table.p, (uint32_t)c->k4_mode, c->k4_grid);
         }
         }
+        // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
+        GeneCovArgs Ga{};
+        Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
+        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov; Ga.ex_id = c->dann.ex_id;
+        Ga.gene_cov_off = c->d_gene_cov_off; Ga.gene_coding = c->d_gene_coding;
+        Ga.gene_flags = c->d_gene_flags; Ga.gene_owned = c->d_gene_owned;
+        Ga.gene_order = c->d_gene_order;
+        Ga.gene_reads = c->acc.gene_reads; Ga.cov = c->acc.cov_diff; Ga.n_listed = L;
+        Ga.mask = c->params.coverage_mask; Ga.bias_offset = c->params.bias_offset; Ga.bias_window = c->params.bias_window;
+        Ga.bias_gene_length = c->params.bias_gene_length;
+        Ga.g_mean = (double *)(A + c->off_gmean); Ga.g_std = (double *)(A + c->off_gstd); Ga.g_cv = (double *)(A + c->off_gcv);
+        Ga.g_valid = (uint8_t *)(A + c->off_gvalid); Ga.e_cv = (double *)(A + c->off_ecv); Ga.e_cv_valid = (uint8_t *)(A + c->off_ecvv);
+        Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
+        Ga.error = c->acc.error;
+        {
+            uint32_t nl = c->k3_large, nm = c->k3_medium;
+            if (const char *e = getenv("RSQC_K3_FORCE")) {           // diagnostic: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
+                const int f = atoi(e);
+                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; } else if (f == 3) { nl = 0; nm = 0; }
+            }
+            if (!getenv("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm);   // (diagnostic knob: results incomplete)
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+        HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
+        HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0));

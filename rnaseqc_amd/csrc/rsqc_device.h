@@ -98,6 +98,7 @@ struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
     uint64_t *gene_base;           // [G] offset of the gene's key lists
     uint32_t *cursor;              // [parts] keys appended so far
+    uint32_t *part_gene;           // [parts] owning gene
     unsigned long long *list;      // key lists
 };
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error);

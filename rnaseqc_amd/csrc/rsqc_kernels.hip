@@ -898,10 +898,17 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint3
         pp += p; off += (unsigned long long)p * frag_cap_of(n);
     }
 }
+// per partition: fill cursor = 0 and its owning gene (one binary search per partition, all in parallel, so that
+// the counting kernel starts from a single load)
 __global__ void __launch_bounds__(256)
-frag_zero_kernel(uint32_t *cursor, const uint32_t *part_first, uint32_t n_genes) {
+frag_zero_kernel(uint32_t *cursor, uint32_t *part_gene, const uint32_t *part_first, uint32_t n_genes) {
     const uint32_t n = part_first[n_genes];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cursor[i] = 0u;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        cursor[w] = 0u;
+        uint32_t lo = 0, hi = n_genes;                                 // last g with part_first[g] <= w (genes without
+        while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (part_first[m] <= w) lo = m; else hi = m; }   // partitions share their value with the owner)
+        part_gene[w] = lo;
+    }
 }
 
 struct K4LocalShared {
@@ -989,33 +996,35 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
 
 __global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
 frag_count_kernel(const unsigned long long *gene_reads, const uint32_t *part_first, uint32_t n_genes, const uint64_t *gene_base,
-                  const uint32_t *cursor, const unsigned long long *list, unsigned long long *gene_frag, int *error) {
+                  const uint32_t *cursor, const uint32_t *part_gene, const unsigned long long *list, unsigned long long *gene_frag, int *error) {
     __shared__ unsigned long long s_keys[RSQC_K4_PART_SLOTS];
     __shared__ uint32_t s_fresh;
     const uint32_t n_parts = part_first[n_genes];
     for (uint32_t w = blockIdx.x; w < n_parts; w += gridDim.x) {
         if (cursor[w] == 0) continue;                                  // (uniform)
-        uint32_t lo = 0, hi = n_genes;                                 // owning gene: last g with part_first[g] <= w
-        while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (part_first[m] <= w) lo = m; else hi = m; }
-        const uint32_t gene = lo;                                      // (genes without partitions share part_first with their successor: the last such index owns w)
+        const uint32_t gene = part_gene[w];
         const uint32_t cap = frag_cap_of(gene_reads[gene]);
         const uint32_t n = cursor[w] < cap ? cursor[w] : cap;
         const unsigned long long *keys = list + gene_base[gene] + (unsigned long long)(w - part_first[gene]) * cap;
+        // the set is sized to the partition: the smallest power of two >= 2 n (most partitions hold a few dozen keys)
+        uint32_t slots = 64;
+        while (slots < 2 * n && slots < RSQC_K4_PART_SLOTS) slots <<= 1;
+        const uint32_t smask = slots - 1;
         __syncthreads();
-        for (int i = threadIdx.x; i < RSQC_K4_PART_SLOTS; i += blockDim.x) s_keys[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) s_keys[i] = 0ull;
         if (threadIdx.x == 0) s_fresh = 0u;
         __syncthreads();
         uint32_t fresh = 0;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             const unsigned long long k = keys[i];
-            uint32_t slot = (uint32_t)mix64(k) & (RSQC_K4_PART_SLOTS - 1);
+            uint32_t slot = (uint32_t)mix64(k) & smask;
             bool placed = false;
 #pragma unroll 1
-            for (int probe = 0; probe < RSQC_K4_PART_SLOTS; ++probe) {
+            for (uint32_t probe = 0; probe < slots; ++probe) {
                 const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
                 if (old == 0ull) { ++fresh; placed = true; break; }
                 if (old == k) { placed = true; break; }
-                slot = (slot + 1) & (RSQC_K4_PART_SLOTS - 1);
+                slot = (slot + 1) & smask;
             }
             if (!placed) atomicExch(error, RSQC_ERR_CAPACITY);
         }
@@ -1382,7 +1391,7 @@ void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const u
 }
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error) {
     hipLaunchKernelGGL(frag_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, P.part_first, P.gene_base, error);
-    hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_first, n_genes);
+    hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_gene, P.part_first, n_genes);
 }
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P) {
     hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
@@ -1393,7 +1402,7 @@ void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint
                        unsigned long long *gene_frag, int *error) {
     const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
     hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, gene_reads, P.part_first, n_genes, P.gene_base,
-                       P.cursor, P.list, gene_frag, error);
+                       P.cursor, P.part_gene, P.list, gene_frag, error);
 }
 void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total) {
     hipLaunchKernelGGL(dedup_clear_kernel, dim3(2048), dim3(256), 0, s, table, total);
