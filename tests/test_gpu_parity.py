@@ -55,6 +55,36 @@ def test_deep_coverage_bias_path(oracle_lib):
     assert_results_match(engine.run_engine(p, ann, [batch]), want)
 
 
+def test_depth_beyond_16_bits_on_a_long_gene(oracle_lib):
+    """The longest genes keep 16-bit depths in LDS; a base covered >= 65 536 times must send the gene through the
+    in-memory path with identical results (two long genes here: one deep, one shallow)."""
+    rows = []
+    for gid, base in (("deep", 10_000), ("shallow", 200_000)):
+        rows.append(dict(contig="c", type="gene", start=base, end=base + 60_000, strand="+", gene_id=gid, gene_name=gid))
+        for k in range(5):                                     # 5 exons x 4 kb = 20 kb of coding length (1024-thread class)
+            rows.append(dict(contig="c", type="exon", start=base + k * 10_000, end=base + k * 10_000 + 3_999, strand="+",
+                             gene_id=gid, exon_id="%s_e%d" % (gid, k)))
+    from rnaseqc_amd.model import Annotation, Batch
+    ann = Annotation.from_rows(["c"], rows)
+    n_deep = 70_000
+    n = n_deep + 3_000
+    pos = np.concatenate([np.full(n_deep, 10_000 + 10_100, np.int32) - 1,          # all on the same 100 bases of exon 1
+                          (200_000 + np.sort(np.random.default_rng(5).integers(0, 3_900, 3_000))).astype(np.int32) - 1])
+    qh = abi.qname_hash_bytes(np.frombuffer(b"".join(b"%015d" % i for i in range(n)), np.uint8).reshape(n, 15))
+    batch = Batch(pos=pos, mpos=pos.copy(), isize=np.zeros(n, np.int32), qhash=qh, cigar_off=np.arange(n, dtype=np.uint32),
+                  flag=np.zeros(n, np.uint16), l_qseq=np.full(n, 100, np.uint16), mapq=np.full(n, 255, np.uint8),
+                  nm=np.zeros(n, np.uint8), tagbits=np.full(n, abi.TB_HAS_NM | abi.TB_MTID_SAME, np.uint8),
+                  n_cigar=np.ones(n, np.uint8), cigar=np.full(n, (100 << 4) | abi.CIG_M, np.uint32),
+                  seg_tid=np.array([0], np.int32), seg_start=np.array([0, n], np.uint64),
+                  wide_index=np.zeros(0, np.uint64), wide_nm=np.zeros(0, np.int32), wide_l_qseq=np.zeros(0, np.int32),
+                  wide_n_cigar=np.zeros(0, np.uint32))
+    p = abi.default_params(unpaired=1)
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    got = engine.run_engine(p, ann, [batch])
+    assert_results_match(got, want)
+    assert got.gene_reads[0] == n_deep and got.gene_cov_valid[0] == 1 and got.gene_cov_mean[0] > 300
+
+
 def test_batch_split_invariance(oracle_lib):
     ann, batch = small_inputs(n_pairs=8000)
     p = abi.default_params()
