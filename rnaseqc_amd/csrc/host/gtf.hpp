@@ -8,6 +8,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/rnaseqc_amd.h"
@@ -26,9 +27,24 @@ struct Annotation {
 
     // GTF state
     std::vector<std::string> gene_list, exon_list;                  // geneList / exonList (GTF order)
-    std::map<std::string, std::string> gene_names;                  // geneNames[feature_id]
-    std::map<std::string, long long> gene_coding_length;            // geneCodingLengths
-    struct Row { int chrom; long long start, end; int strand; bool is_gene; bool ribosomal; std::string feature_id, gene_id; size_t order; };
+    // ids (gene, transcript and exon ids share one table) are interned while parsing: a row carries two small
+    // integers, and the per-id tables of the reference (geneNames, geneCodingLengths, uniqueness sets) are vectors
+    // indexed by them.  The table is open addressing over one character arena: no allocation per line.
+    std::vector<uint32_t> id_slots;                 // hash slots -> key + 1 (0 = empty)
+    std::vector<uint64_t> id_hash;                  // per key
+    std::vector<uint32_t> id_off;                   // per key: [id_off[k], id_off[k + 1]) in id_chars
+    std::vector<char> id_chars;
+    uint32_t intern(const char *p, size_t n);
+    uint32_t intern(const std::string &s) { return intern(s.data(), s.size()); }
+    bool lookup(const std::string &s, uint32_t &key) const;
+    std::string id_text(uint32_t key) const { return std::string(id_chars.data() + id_off[key], id_chars.data() + id_off[key + 1]); }
+    size_t n_ids() const { return id_hash.size(); }
+    std::vector<std::string> name_of_key;           // geneNames[feature_id] by key ("" + has flag below)
+    std::vector<uint8_t> has_name, seen_gene, seen_exon;
+    std::vector<long long> coding_of_key;           // geneCodingLengths by key
+    std::string gene_name(const std::string &feature_id) const;          // geneNames[feature_id] ("" when absent)
+    long long coding_length(const std::string &gene_id) const;          // geneCodingLengths[gene_id] (0 when absent)
+    struct Row { int chrom; long long start, end; int strand; bool is_gene; bool ribosomal; uint32_t feature_key, gene_key; size_t order; };
     std::vector<Row> rows;                                          // kept gene/exon rows, GTF order
     void load_gtf(const std::string &path);
 

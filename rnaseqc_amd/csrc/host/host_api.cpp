@@ -31,12 +31,12 @@ HAPI void *host_annotation_load(const char *gtf, const char *bed, const char *co
 HAPI const rsqc_annotation *host_annotation_struct(void *h) { return &((Annotation *)h)->ann; }
 HAPI const rsqc_bed *host_annotation_bed(void *h) { return &((Annotation *)h)->bed; }
 HAPI const char *host_annotation_gene_name(void *h, int listed_gene) {
-    Annotation *a = (Annotation *)h; return a->gene_names[a->gene_list[(size_t)listed_gene]].c_str();
+    Annotation *a = (Annotation *)h; static thread_local std::string tmp; tmp = a->gene_name(a->gene_list[(size_t)listed_gene]); return tmp.c_str();
 }
 HAPI const char *host_annotation_gene_id(void *h, int listed_gene) { return ((Annotation *)h)->gene_list[(size_t)listed_gene].c_str(); }
 HAPI const char *host_annotation_exon_id(void *h, int exon) { return ((Annotation *)h)->exon_list[(size_t)exon].c_str(); }
 HAPI long long host_annotation_coding_length(void *h, int listed_gene) {
-    Annotation *a = (Annotation *)h; return a->gene_coding_length[a->gene_list[(size_t)listed_gene]];
+    Annotation *a = (Annotation *)h; return a->coding_length(a->gene_list[(size_t)listed_gene]);
 }
 HAPI void host_annotation_free(void *h) { delete (Annotation *)h; }
 

@@ -63,7 +63,7 @@ unsigned library_complexity(double duplicates, double unique, double limit) {
     return minReads;
 }
 
-static std::string gene_name_of(Annotation &ann, const std::string &id) { return ann.gene_names[id]; }
+static std::string gene_name_of(Annotation &ann, const std::string &id) { return ann.gene_name(id); }
 
 void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results &r,
                    const std::vector<int> &contig_visit_order) {
@@ -117,7 +117,7 @@ void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results 
         for (size_t g = 0; g < ann.gene_list.size(); ++g) {
             const std::string &gene = ann.gene_list[g];
             const double geneCount = (double)r.gene_reads[g];
-            const double codingLength = static_cast<double>(ann.gene_coding_length[gene]);
+            const double codingLength = static_cast<double>(ann.coding_length(gene));
             geneReport << gene << "\t" << gene_name_of(ann, gene) << "\t" << static_cast<long>(geneCount) << endl;
             fragmentReport << gene << "\t" << gene_name_of(ann, gene) << "\t" << static_cast<long>((double)r.gene_fragments[g]) << endl;
             if (cfg.use_rpkm) {
