@@ -36,6 +36,12 @@ rsqc_batch HostBatch::view() {
 }
 
 BamReader::~BamReader() {
+    if (producer_started_) {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        producer_.join();
+    }
+    delete pool_inflate_;
     if (map_) munmap(const_cast<uint8_t *>(map_), map_size_);
     if (fp_) fclose(fp_);
     delete pool_;
@@ -107,21 +113,18 @@ void WorkPool::run(size_t n_tasks, const std::function<void(size_t)> &fn) {
 void BamReader::set_threads(int n) {
     if (n < 1) n = 1;
     if (n == n_threads_ && pool_) return;
-    delete pool_;
+    if (producer_started_) return;                 // fixed once decoding has begun
+    delete pool_; delete pool_inflate_;
     n_threads_ = n;
     pool_ = new WorkPool(n);
+    pool_inflate_ = new WorkPool(n);
 }
 
 // BGZF blocks are independent deflate streams whose uncompressed size sits in the trailer, so a group of
 // blocks is framed sequentially (headers only) and inflated in parallel straight into place.
-bool BamReader::fill_group() {
-    if (eof_) return false;
-    if (!pool_) {
-        int n = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
-        if (const char *e = getenv("RSQC_HOST_THREADS")) n = atoi(e);
-        set_threads(n);
-    }
-    const size_t GROUP_BYTES = (size_t)64 << 20;        // uncompressed bytes per group
+bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
+    size_t GROUP_BYTES = (size_t)64 << 20;              // uncompressed bytes per group
+    if (const char *e = getenv("RSQC_HOST_GROUP_BYTES")) GROUP_BYTES = std::max<size_t>(1, (size_t)atoll(e));   // (tests: many small groups)
     const size_t READ_CHUNK = (size_t)16 << 20;
     struct Blk { size_t coff, clen, out; uint32_t isize; };
     std::vector<Blk> blks;
@@ -164,21 +167,16 @@ bool BamReader::fill_group() {
     }
     if (blks.empty()) {
         if ((map_ ? map_size_ : cbuf_.size()) - cpos_ != 0) throw std::runtime_error("truncated BGZF block");
-        eof_ = true;
         return false;
     }
-    const double tm = now_s();
-    // unread tail to the front, then the group behind it
-    if (pos_ > 0) { buf_.erase_front(pos_); pos_ = 0; }
-    const size_t base = buf_.size();
-    buf_.resize(base + total);
+    dst.resize(head + total);
+    stage_bytes_ = total;
     const uint8_t *cdata = map_ ? map_ : cbuf_.data();
-    uint8_t *odata = buf_.data() + base;
-    g_t_move += now_s() - tm;
+    uint8_t *odata = dst.data() + head;
     const double ti = now_s();
-    // tasks of ~16 consecutive blocks: one z_stream per task
-    const size_t per = 16, n_tasks = (blks.size() + per - 1) / per;
-    pool_->run(n_tasks, [&](size_t t) {
+    // tasks of 4 consecutive blocks (fine enough to balance across ~100 threads): one z_stream per task
+    const size_t per = 4, n_tasks = (blks.size() + per - 1) / per;
+    pool_inflate_->run(n_tasks, [&](size_t t) {
         z_stream zs{};
         if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
         const size_t b0 = t * per, b1 = std::min(blks.size(), b0 + per);
@@ -195,6 +193,69 @@ bool BamReader::fill_group() {
     });
     g_t_inflate += now_s() - ti;
 
+    return true;
+}
+
+// ---- producer thread: keeps ONE inflated group ahead of the parser
+void BamReader::producer_main() {
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || stage_state_ == kEmpty; });
+            if (stop_) return;
+        }
+        StageState next = kReady;
+        std::string err;
+        try { if (!produce_group(stage_, kHead)) next = kEof; }
+        catch (std::exception &e) { next = kError; err = e.what(); }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stage_state_ = next; stage_error_ = err;
+        }
+        cv_.notify_all();
+        if (next != kReady) return;
+    }
+}
+void BamReader::start_producer() {
+    if (producer_started_) return;
+    if (!pool_) {
+        int n = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+        if (const char *e = getenv("RSQC_HOST_THREADS")) n = atoi(e);
+        set_threads(n);
+    }
+    producer_started_ = true;
+    producer_ = std::thread([this] { producer_main(); });
+}
+
+// consumer side: take the group the producer prepared, put the unread tail in front of it, let the producer go on
+bool BamReader::fill_group() {
+    if (eof_) return false;
+    start_producer();
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stage_state_ != kEmpty; });
+        if (stage_state_ == kError) throw std::runtime_error(stage_error_);
+        if (stage_state_ == kEof) { eof_ = true; return false; }
+    }
+    const double tm = now_s();
+    const size_t tail = buf_.size() - pos_, got = stage_bytes_;
+    if (tail <= kHead) {
+        if (tail) memcpy(stage_.data() + kHead - tail, buf_.data() + pos_, tail);
+        buf_.swap(stage_);                                        // (pointer swap)
+        buf_.resize(kHead + got);
+        pos_ = kHead - tail;
+    } else {                                                     // a record larger than the head room: grow in place
+        if (pos_ > 0) { buf_.erase_front(pos_); pos_ = 0; }
+        const size_t base = buf_.size();
+        buf_.resize(base + got);
+        memcpy(buf_.data() + base, stage_.data() + kHead, got);
+    }
+    g_t_move += now_s() - tm;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stage_state_ = kEmpty;
+    }
+    cv_.notify_all();
     return true;
 }
 
@@ -301,7 +362,7 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
         const uint8_t *bufp = buf_.data();
         const size_t end = buf_.size(), want = max_records - n;
         // ---- parallel speculative framing of [pos_, end)
-        const size_t CH = (size_t)1 << 20;
+        const size_t CH = (size_t)1 << 18;                       // 256 KB chunks: a few hundred per inflated group
         const size_t n_ch = std::max<size_t>(1, (end - pos_ + CH - 1) / CH);
         std::vector<Framed> fr(n_ch);
         pool_->run(n_ch, [&](size_t c) {

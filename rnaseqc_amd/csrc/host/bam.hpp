@@ -13,6 +13,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../../include/rnaseqc_amd.h"
@@ -48,6 +49,7 @@ public:
         n_ = n;
     }
     void push_back(const T &v) { resize(n_ + 1); p_[n_ - 1] = v; }
+    void swap(RawVec &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); std::swap(want_pinned_, o.want_pinned_); std::swap(pinned_now_, o.pinned_now_); }
     // drop the first k elements
     void erase_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, (n_ - k) * sizeof(T)); n_ -= k; }
 private:
@@ -119,7 +121,10 @@ public:
     ~BamReader();
 private:
     bool fill(size_t need);              // make at least `need` decompressed bytes available
-    bool fill_group();                   // inflate the next group of BGZF blocks (in parallel) behind the unread tail
+    bool fill_group();                   // swap in the next inflated group (prepared by the producer thread) behind the unread tail
+    bool produce_group(RawVec<uint8_t> &dst, size_t head);   // producer side: frame + inflate one group at dst[head..)
+    void producer_main();
+    void start_producer();
     FILE *fp_ = nullptr;
     RawVec<uint8_t> buf_;                // decompressed stream window
     size_t pos_ = 0;
@@ -129,8 +134,20 @@ private:
     size_t cpos_ = 0;
     bool file_eof_ = false;
     bool eof_ = false;
-    WorkPool *pool_ = nullptr;
+    WorkPool *pool_ = nullptr;           // record framing + parsing (consumer side)
+    WorkPool *pool_inflate_ = nullptr;   // BGZF inflate (producer thread): the next group is inflated while this one is parsed
     int n_threads_ = 0;
+    // hand-over of one inflated group: the producer fills stage_[kHead, kHead + stage_bytes_), the consumer copies its
+    // unread tail in front of it (into the head room) and swaps the buffers
+    static constexpr size_t kHead = (size_t)4 << 20;
+    RawVec<uint8_t> stage_;
+    size_t stage_bytes_ = 0;
+    enum StageState { kEmpty, kReady, kEof, kError } stage_state_ = kEmpty;
+    std::string stage_error_;
+    bool stop_ = false, producer_started_ = false;
+    std::thread producer_;
+    std::mutex mu_;
+    std::condition_variable cv_;
     std::vector<std::string> names_;
     std::string ch_tag_ = "ch";
     std::vector<std::string> filter_tags_;

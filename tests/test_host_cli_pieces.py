@@ -137,8 +137,9 @@ def test_bam_decode_round_trip(host, tmp_path):
     assert not host.host_bam_read_all(str(tmp_path / "nope.bam").encode(), b"ch", tags, 0)
 
 
-@pytest.mark.parametrize("threads,batch_records", [(1, 1 << 20), (8, 1 << 20), (5, 7777), (16, 100)])
-def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_records):
+@pytest.mark.parametrize("threads,batch_records,group_bytes", [(1, 1 << 20, 0), (8, 1 << 20, 0), (5, 7777, 0), (16, 100, 0),
+                                                               (8, 1 << 20, 200_000), (3, 5000, 70_000)])
+def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_records, group_bytes, monkeypatch):
     """Parallel BGZF inflate + parallel record parsing: many blocks, records spanning block borders,
     read_batch calls that end in the middle of an inflated group."""
     ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40), ("chrC", 500_000, 10)])
@@ -146,6 +147,8 @@ def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_record
                              contig_lengths=np.array([3_000_000, 1_000_000, 500_000]))
     path = str(tmp_path / "p.bam")
     bamio.write_bam(path, [("chrA", 3_000_000), ("chrB", 1_000_000), ("chrC", 500_000)], batch)
+    if group_bytes:                       # many small inflated groups: every hand-over between producer and parser
+        monkeypatch.setenv("RSQC_HOST_GROUP_BYTES", str(group_bytes))
     tags = (C.c_char_p * 1)(b"XF")
     host.host_bam_read_all_ex.restype = C.c_void_p
     h = host.host_bam_read_all_ex(path.encode(), b"ch", tags, 1, threads, C.c_ulonglong(batch_records))
@@ -165,19 +168,23 @@ def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_record
 
 
 def test_bam_decode_long_record_spans_framing_chunks(host, tmp_path):
-    """A 2.6 MB record (long read) between short ones: the parallel framer's chunks inside it have no record
+    """A 4.5 MB record (long read, larger than the reader's 4 MB head room) between short ones: the parallel framer's chunks inside it have no record
     start to guess, and its SEQ/QUAL bytes (0x11 / 0xff runs) must not be taken for records."""
     recs = []
     for i in range(3000):
         recs.append(dict(tid=0, pos=100 + i, mpos=100 + i, isize=0, flag=0, cigar=[(abi.CIG_M, 100)], qname="s%d" % i))
-    recs.append(dict(tid=0, pos=5000, mpos=5000, isize=0, flag=0, cigar=[(abi.CIG_M, 1_700_000)], qname="long"))
+    recs.append(dict(tid=0, pos=5000, mpos=5000, isize=0, flag=0, cigar=[(abi.CIG_M, 3_000_000)], qname="long"))
     for i in range(3000):
         recs.append(dict(tid=1 if i > 1500 else 0, pos=6000 + i, mpos=6000 + i, isize=0, flag=0, cigar=[(abi.CIG_M, 90), (abi.CIG_S, 10)], qname="t%d" % i))
     batch = Batch.from_records(recs)
     path = str(tmp_path / "l.bam")
     bamio.write_bam(path, [("chrA", 3_000_000), ("chrB", 1_000_000)], batch)
     host.host_bam_read_all_ex.restype = C.c_void_p
-    for threads, per in ((1, 1 << 20), (8, 1 << 20), (4, 1000)):
+    for threads, per, group in ((1, 1 << 20, 0), (8, 1 << 20, 0), (4, 1000, 0), (8, 1 << 20, 1_000_000), (2, 300, 400_000)):
+        if group:                         # the record then spans several groups and outgrows the head room
+            os.environ["RSQC_HOST_GROUP_BYTES"] = str(group)
+        else:
+            os.environ.pop("RSQC_HOST_GROUP_BYTES", None)
         h = host.host_bam_read_all_ex(path.encode(), b"ch", None, 0, threads, C.c_ulonglong(per))
         assert h
         b = host.host_bam_batch(C.c_void_p(h)).contents
@@ -192,6 +199,7 @@ def test_bam_decode_long_record_spans_framing_chunks(host, tmp_path):
         np.testing.assert_array_equal(_arr(b.seg_tid, b.n_seg, np.int32), batch.seg_tid)
         np.testing.assert_array_equal(_arr(b.seg_start, b.n_seg + 1, np.uint64), batch.seg_start)
         host.host_bam_free(C.c_void_p(h))
+    os.environ.pop("RSQC_HOST_GROUP_BYTES", None)
 
 
 def test_library_complexity_matches_the_literal_loop(host, oracle_lib):
