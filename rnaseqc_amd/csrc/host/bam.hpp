@@ -116,7 +116,7 @@ public:
     // appends up to max_records records to `out`; returns the number appended (0 at EOF)
     size_t read_batch(HostBatch &out, size_t max_records);
     uint64_t records_read() const { return n_read_; }
-    // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 64)
+    // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 16), per pool
     void set_threads(int n);
     ~BamReader();
 private:
