@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--host-fed", action="store_true",
                     help="(diagnostic) every step uploads the batch from host memory through rsqc_submit: the "
                          "PCIe-inclusive rate noted in DESIGN.md; not the bench line")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="(diagnostic) single process, but through the N > 1 code path: 1-rank RCCL group, finalize_device, "
+                         "all_reduce of the device accumulators, refresh_results")
     ap.add_argument("--genome", action="store_true",
                     help="BASELINE.json configs[2] shape on ONE GPU: GENCODE-sized annotation (25 contigs, 56 202 genes); "
                          "not the default bench line")
@@ -60,9 +63,13 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    reduce_path = world > 1 or args.dist_selftest
+    if reduce_path:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic inputs: N chr1-like contigs, rank k owns contig k -----------------------------
@@ -95,7 +102,7 @@ def main():
             setattr(host_struct, f, pin.ctypes.data)
 
     u64_t = f64_t = None
-    if world > 1:
+    if reduce_path:
         u64_d, f64_d = e.device_accumulators()
         u64_t = torch.as_tensor(u64_d, device="cuda")
         f64_t = torch.as_tensor(f64_d, device="cuda")
@@ -109,16 +116,13 @@ def main():
         if args.no_finalize:
             e.wait()
             return None
-        if world == 1:
+        if not reduce_path:
             return e.finalize(lazy=True)     # the vectors are on the host (library buffers); Python copies are made on access
         e.finalize_device()                  # results stay on the device until the counts are reduced
-        r = None
-        if world > 1:
-            dist.all_reduce(u64_t)           # RCCL over xGMI: gene reads/unique/fragments + scalar counters
-            dist.all_reduce(f64_t)           # exon fractions
-            torch.cuda.synchronize()
-            r = e.refresh_results(lazy=True)
-        return r
+        dist.all_reduce(u64_t)               # RCCL over xGMI: gene reads/unique/fragments + scalar counters
+        dist.all_reduce(f64_t)               # exon fractions
+        torch.cuda.synchronize()
+        return e.refresh_results(lazy=True)
 
     for _ in range(args.warmup):
         step()
@@ -198,6 +202,8 @@ def main():
         }
         if args.no_finalize:
             out["invalid"] = "diagnostic run: end-of-file stage skipped"
+        if args.dist_selftest:
+            out["invalid"] = "diagnostic run: the N > 1 code path on one rank"
         if args.host_fed:
             out["invalid"] = "diagnostic run: PCIe-inclusive (inputs uploaded from host memory inside the timed region)"
             out["h2d_ms_per_step"] = tm["h2d_ms"] / max(args.steps, 1)
