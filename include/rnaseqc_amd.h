@@ -245,6 +245,8 @@ typedef struct rsqc_rec_aux {          /* 16 bytes                             *
     uint8_t  n_cigar;                  /* RSQC_NCIGAR_ESCAPE = wide            */
 } rsqc_rec_aux;
 
+/* Limits of one batch: n < 2^32 - 16 records, n_cigar_total < 2^30 ops (split larger inputs into several
+ * batches; 1-4 M records per batch is the intended granularity).                                          */
 typedef struct rsqc_batch {
     uint64_t n;                        /* records                              */
     uint64_t file_index_base;          /* index of record 0 in the whole file  */
@@ -332,8 +334,9 @@ RSQC_API int rsqc_set_annotation(rsqc_ctx *ctx, const rsqc_annotation *ann,
 RSQC_API int rsqc_set_bed(rsqc_ctx *ctx, const rsqc_bed *bed);
 
 /* Asynchronous: copies the batch H2D on the context's stream and launches the
- * per-read kernels.  The batch memory must stay valid until rsqc_wait().
- * Batches must be submitted in file order.                                    */
+ * per-read kernels; returns without waiting for either.  The batch memory must
+ * stay valid and unmodified until rsqc_wait() (page-locked arrays from
+ * rsqc_host_alloc are copied by DMA).  Batches must be submitted in file order. */
 RSQC_API int rsqc_submit(rsqc_ctx *ctx, const rsqc_batch *batch);
 RSQC_API int rsqc_wait(rsqc_ctx *ctx);
 
@@ -343,7 +346,9 @@ RSQC_API int rsqc_submit_resident(rsqc_ctx *ctx, int handle);
 RSQC_API int rsqc_release(rsqc_ctx *ctx, int handle);
 
 /* End of file: fragment de-dup, coverage scan, per-gene coverage statistics and
- * bias windows, fragment-size pairing; fills `out`.                           */
+ * bias windows, fragment-size pairing; fills `out`, whose vectors point into a
+ * page-locked host mirror owned by the context (valid until the next
+ * rsqc_finalize / rsqc_refresh_results / rsqc_destroy).                       */
 RSQC_API int rsqc_finalize(rsqc_ctx *ctx, rsqc_results *out);
 
 /* Zeroes every accumulator (keeps annotation/BED and uploaded batches).       */

@@ -1,15 +1,18 @@
 // rsqc_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, wave64).
 //
-//   K1  classify_count_kernel   per-record path: gate cascade, CIGAR blocks, overlap query,
-//                               gene/exon/coverage scatter, scalar counters (wave-reduced)
-//   K1s classify_slow_kernel    exact slow path for records whose block hits > FAST_SET genes
+//   K1  classify_count_kernel   per-record path: gate cascade, CIGAR blocks, overlap query (staged, batched
+//                               loads), exon / gene counters in workgroup LDS tables, coverage as a
+//                               difference array, (gene, name-hash) pairs, vertical scalar counters
+//   K1s classify_slow_kernel    general code for the records the fast path hands over
 //   KR  read_length_kernel      order-dependent "Read Length" state machine over tile summaries
-//   K4  dedup_insert_kernel     per-gene distinct QNAME count (geneFragmentCounts)
-//   K3  gene_coverage_kernel    per-gene: diff->coverage scan, per-exon CV, bias windows,
-//                               masked gene mean/std/CV  (one wavefront per gene)
+//   K4  frag_layout / frag_local / frag_count   per-gene distinct QNAME count (geneFragmentCounts) by
+//                               partitioned key lists + LDS sets; dedup_* = the earlier open-addressing form
+//   K3  gene_coverage_kernel    per gene: diff->coverage scan into LDS, per-exon CV, bias windows, masked
+//                               gene mean/std/CV; workgroup sized to the gene (1 wave / 256 / 1024 threads)
+//   reset_kernel, pack_results_kernel   accumulator reset and result packing around a pass
 //
-// This is integer / byte indexing work bound by HBM and atomics, not a contraction:
-// no MFMA.  All wave-level idioms are written for 64-lane wavefronts.
+// This is integer / byte indexing work bound by instruction issue, load latency and atomics, not a
+// contraction: no MFMA.  All wave-level idioms are written for 64-lane wavefronts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
