@@ -44,14 +44,17 @@ def test_synthetic_vs_oracle(oracle_lib, kw):
     assert_results_match(engine.run_engine(p, ann, [batch]), oracle_lib.run_oracle(p, ann, [batch]))
 
 
-def test_deep_coverage_bias_path(oracle_lib):
-    # few genes, most reads on them: depth in the hundreds so the bias gate (>=100) opens
+@pytest.mark.parametrize("kw", [dict(), dict(bias_window=300, bias_offset=25, bias_gene_length=700),
+                                dict(bias_window=700, bias_offset=5, bias_gene_length=1500, coverage_mask=50)])
+def test_deep_coverage_bias_path(oracle_lib, kw):
+    # few genes, most reads on them: depth in the hundreds so the bias gate (>=100) opens; windows beyond 128 bases use
+    # the wide-window instantiation of the coverage kernel
     ann = synth.make_annotation(seed=8, contigs=[("chrA", 400_000, 40)])
     batch = synth.make_reads(ann, 150000, seed=9, frac=(0.97, 0.01, 0.01, 0.01), expr_sigma=1.0,
                              contig_lengths=np.array([400_000]))
-    p = abi.default_params()
+    p = abi.default_params(**kw)
     want = oracle_lib.run_oracle(p, ann, [batch])
-    assert int(((want.bias_three + want.bias_five) > 0).sum()) >= 5
+    assert int(((want.bias_three + want.bias_five) > 0).sum()) >= (5 if not kw else 1)
     assert_results_match(engine.run_engine(p, ann, [batch]), want)
 
 
