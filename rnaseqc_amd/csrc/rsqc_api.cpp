@@ -478,6 +478,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     c->off_gvalid = at; at += pad8(Lz);
     c->off_ecvv = at; at += pad8(Ez);
     c->off_ehit = at; at += pad8(Ez);
+    at = (at + 15) & ~(size_t)15;                 // rl_stats (off_misc + 32) starts a 16-byte vector: the reset kernel arms it
     c->off_misc = at; at += 64;
     c->arena_bytes = at;
     if ((rc = dev_alloc(c, c->d_arena, at, false))) return rc;

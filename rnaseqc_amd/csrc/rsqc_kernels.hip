@@ -1347,16 +1347,15 @@ pack_results_kernel(const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons)
 }
 
 // ------------------------------------------------------------------ reset
-// one launch instead of a handful of memsets: zero the accumulator arena and the coverage array, arm rl_stats
+// one launch instead of a handful of memsets: zero the accumulator arena and the coverage array; the vector that
+// holds rl_stats is written armed ({max span 0, min l_qseq UINT_MAX, max l_qseq 0, -})
 __global__ void __launch_bounds__(256)
-reset_kernel(uint4 *arena, size_t arena_vec, uint4 *cov, size_t cov_vec, uint32_t *rl_min) {
+reset_kernel(uint4 *arena, size_t arena_vec, uint4 *cov, size_t cov_vec, size_t rl_vec) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const uint4 z = {0u, 0u, 0u, 0u};
+    const uint4 z = {0u, 0u, 0u, 0u}, armed = {0u, 0xFFFFFFFFu, 0u, 0u};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cov_vec; i += stride) cov[i] = z;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < arena_vec; i += stride) arena[i] = z;
-    (void)rl_min;                                  // armed by reset_arm_kernel, launched right behind this one
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < arena_vec; i += stride) arena[i] = i == rl_vec ? armed : z;
 }
-__global__ void reset_arm_kernel(uint32_t *rl_min) { *rl_min = 0xFFFFFFFFu; }
 
 // ------------------------------------------------------------------ launch wrappers
 void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons) {
@@ -1364,8 +1363,9 @@ void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hi
 }
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min) {
     // both allocations are 16-byte multiples with slack (rsqc_api.cpp: dev_alloc)
-    hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_min);
-    hipLaunchKernelGGL(reset_arm_kernel, dim3(1), dim3(1), 0, s, rl_min);
+    // rl_min = &rl_stats[1]; rl_stats starts a 16-byte vector of the arena (off_misc + 32)
+    const size_t rl_vec = (size_t)((char *)rl_min - 4 - (char *)arena) / 16;
+    hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_vec);
 }
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
