@@ -50,6 +50,12 @@ def main():
                          "not the default bench line")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on stdout when the communicator comes up; the contract is ONE JSON line there,
+    # so everything else this process (and the libraries it loads) writes to fd 1 is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from rnaseqc_amd import abi, engine, synth
 
@@ -119,8 +125,8 @@ def main():
         if not reduce_path:
             return e.finalize(lazy=True)     # the vectors are on the host (library buffers); Python copies are made on access
         e.finalize_device()                  # results stay on the device until the counts are reduced
-        dist.all_reduce(u64_t)               # RCCL over xGMI: gene reads/unique/fragments + scalar counters
-        dist.all_reduce(f64_t)               # exon fractions
+        dist.all_reduce(u64_t)               # RCCL over xGMI: gene reads/unique/fragments + scalar counters (as i64)
+        dist.all_reduce(f64_t)               # exon fractions (torch's coalescing context needs one dtype: two launches)
         torch.cuda.synchronize()
         return e.refresh_results(lazy=True)
 
@@ -207,7 +213,7 @@ def main():
         if args.host_fed:
             out["invalid"] = "diagnostic run: PCIe-inclusive (inputs uploaded from host memory inside the timed region)"
             out["h2d_ms_per_step"] = tm["h2d_ms"] / max(args.steps, 1)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     e.close()
     if dist:
         dist.destroy_process_group()
