@@ -165,7 +165,7 @@ def main():
         bytes_per_launch = tm["classify_bytes"] / max(tm["classify_launches"], 1)
         achieved = bytes_per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:          # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             from oracle import binding
             ns = min(args.cpu_sample, batch.n)
             sample = batch.slice(0, ns) if ns < batch.n else batch
