@@ -197,7 +197,7 @@ def main():
                                    (chr1[2], ann.n_exons // max(world, 1), batch.n),
                        "records_per_gpu": int(batch.n), "contigs": world, "sharding": "by contig",
                        "collective": "RCCL all_reduce(sum) of u64[3G+49] + f64[E] per step" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "classify_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "classify_count_kernel_w4r1", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": k1_ms},
             "cpu_baseline": cpu,

@@ -449,20 +449,18 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     }
 }
 
-// The same body under three register budgets (occupancy vs. spilling is measured, not guessed):
-// min 3 / 4 / 6 / 8 waves per SIMD -> at most 168 / 128 / 80 / 64 VGPRs.
+// The same body under two register budgets and two load-batching depths (occupancy vs. spilling vs. round trips
+// is measured, not guessed): min 3 / 4 waves per SIMD -> at most 168 / 128 VGPRs; ROUND = blocks whose row loads
+// are in flight together.  RSQC_K1_VARIANT picks one; 41 (4 waves, ROUND 1) is the default.
 #define RSQC_DEFINE_K1(NAME, MINW, ROUND)                                                       \
     __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
     NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
         __shared__ K1Shared S;                                                                  \
         classify_count_body<ROUND>(a, p, b, acc, S);                                            \
     }
-RSQC_DEFINE_K1(classify_count_kernel, 4, 2)
 RSQC_DEFINE_K1(classify_count_kernel_w3, 3, 2)
-RSQC_DEFINE_K1(classify_count_kernel_w2, 2, 2)
 RSQC_DEFINE_K1(classify_count_kernel_w3r1, 3, 1)
 RSQC_DEFINE_K1(classify_count_kernel_w4r1, 4, 1)
-RSQC_DEFINE_K1(classify_count_kernel_w3r4, 3, 4)
 
 // ------------------------------------------------------------------ K1s
 // Records whose block sits fully inside exons of more than FAST_SET genes (pathological
@@ -1369,12 +1367,9 @@ void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, siz
 }
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
-    if (variant == 2) hipLaunchKernelGGL(classify_count_kernel_w2, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else if (variant == 31) hipLaunchKernelGGL(classify_count_kernel_w3r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 41) hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 34) hipLaunchKernelGGL(classify_count_kernel_w3r4, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else hipLaunchKernelGGL(classify_count_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {
