@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -203,6 +204,10 @@ int main(int argc, char **argv) {
         P.n_filter_tags = (int32_t)o.tags.size();
         const std::string SAMPLENAME = o.has_sample ? o.sample : basename_of(bam_path);
 
+        // the HIP context comes up (~0.3 s) while the GTF is being parsed; its status is looked at where the
+        // reference would first need it, so input errors keep their precedence and exit codes
+        rsqc_ctx *gpu = nullptr;
+        std::future<int> gpu_ready = std::async(std::launch::async, [&P, &gpu] { return rsqc_create(&P, &gpu); });
         const auto t0 = std::chrono::steady_clock::now();
         Annotation ann;
         if (o.verbosity) cout << "Reading GTF Features..." << endl;
@@ -231,8 +236,7 @@ int main(int argc, char **argv) {
         if (!overlap) { cerr << "BAM file shares no contigs with GTF" << endl; return 11; }
         ann.flatten(bam.contigs());
 
-        rsqc_ctx *gpu = nullptr;
-        int rc = rsqc_create(&P, &gpu);
+        int rc = gpu_ready.get();
         if (rc != RSQC_OK) { cerr << "Unable to initialise the GPU hot path: " << rsqc_strerror(rc) << endl; return 10; }
         if ((rc = rsqc_set_annotation(gpu, &ann.ann, nullptr)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
         if (o.has_bed && (rc = rsqc_set_bed(gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
