@@ -856,7 +856,6 @@ dedup_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint
 #define RSQC_K4_SUB_CAP 2048
 #define RSQC_K4_PART_SLOTS 4096
 #define RSQC_K4_COUNT_THREADS 256
-#define RSQC_K4_PIECE2 2048                     /* pairs per LDS pass of frag_local_kernel: 4 per thread */
 
 __device__ __forceinline__ uint32_t frag_parts_of(unsigned long long reads) {
     return (uint32_t)((reads + RSQC_K4_PART_READS - 1) / RSQC_K4_PART_READS);
@@ -912,13 +911,18 @@ frag_zero_kernel(uint32_t *cursor, uint32_t *part_gene, const uint32_t *part_fir
     }
 }
 
+// frag_local_kernel: 256 threads take 1024 pairs per LDS pass (4 per thread) through a 2048-slot table: 25 KB of LDS,
+// six workgroups per CU (measured against 512 / 2048 / 4096 and 128 / 512 / 1024)
+#define RSQC_K4L_THREADS 256
+#define RSQC_K4L_LSLOTS 2048
+#define RSQC_K4L_PIECE 1024
 struct K4LocalShared {
-    unsigned long long lkey[RSQC_K4_LSLOTS];
-    uint32_t lgene[RSQC_K4_LSLOTS];
+    unsigned long long lkey[RSQC_K4L_LSLOTS];
+    uint32_t lgene[RSQC_K4L_LSLOTS];
     uint32_t gkey[RSQC_K4_GSLOTS], gcnt[RSQC_K4_GSLOTS], gbase[RSQC_K4_GSLOTS];      // keyed by partition id
 };
 
-__global__ void __launch_bounds__(RSQC_K4_THREADS)
+__global__ void __launch_bounds__(RSQC_K4L_THREADS)
 frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
                   const unsigned long long *gene_reads, const uint32_t *part_first, const uint64_t *gene_base, uint32_t *cursor,
@@ -933,18 +937,18 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
         count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
         piece0 = blockIdx.x - n_chunks; piece_step = gridDim.x - n_chunks;
     }
-    constexpr int U = RSQC_K4_PIECE2 / RSQC_K4_THREADS;
-    const uint32_t n_pieces = (count + RSQC_K4_PIECE2 - 1) / RSQC_K4_PIECE2;
+    constexpr int U = RSQC_K4L_PIECE / RSQC_K4L_THREADS;
+    const uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;
     for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
         __syncthreads();
-        for (int i = threadIdx.x; i < RSQC_K4_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
+        for (int i = threadIdx.x; i < RSQC_K4L_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
         for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x) { S.gkey[i] = 0xFFFFFFFFu; S.gcnt[i] = 0u; }
         __syncthreads();
-        const uint32_t p0 = piece * RSQC_K4_PIECE2, p1 = p0 + RSQC_K4_PIECE2 < count ? p0 + RSQC_K4_PIECE2 : count;
+        const uint32_t p0 = piece * RSQC_K4L_PIECE, p1 = p0 + RSQC_K4L_PIECE < count ? p0 + RSQC_K4L_PIECE : count;
         bool live[U]; uint32_t g[U], gp[U], gslot[U], rank[U]; uint64_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {                                      // the pairs of the piece
-            const uint32_t j = p0 + (uint32_t)u * RSQC_K4_THREADS + threadIdx.x;
+            const uint32_t j = p0 + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
             live[u] = j < p1;
             g[u] = live[u] ? pair_gene[base + j] : 0u;
             key[u] = live[u] ? pair_hash[base + j] : 0ull;
@@ -956,14 +960,14 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
             if (live[u]) {
                 unsigned long long lk = key[u] ^ ((unsigned long long)g[u] * 0x9E3779B97F4A7C15ull);
                 if (lk == 0ull) lk = 1ull;
-                uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4_LSLOTS - 1);
+                uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4L_LSLOTS - 1);
                 bool done = false;
 #pragma unroll 1
                 for (int probe = 0; probe < 8 && !done; ++probe) {
                     const unsigned long long old = atomicCAS(&S.lkey[slot], 0ull, lk);
                     if (old == 0ull) { S.lgene[slot] = g[u]; done = true; }
                     if (!done && old == lk) { if (S.lgene[slot] == g[u]) live[u] = false; done = true; }
-                    slot = (slot + 1) & (RSQC_K4_LSLOTS - 1);
+                    slot = (slot + 1) & (RSQC_K4L_LSLOTS - 1);
                 }
             }
         }
@@ -1392,7 +1396,7 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
     hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_gene, P.part_first, n_genes);
 }
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P) {
-    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
+    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
                        acc.gene_reads, P.part_first, P.gene_base, P.cursor, P.list, acc.error);
 }
