@@ -879,15 +879,23 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint3
         parts += p;
         space += (unsigned long long)p * frag_cap_of(n);
     }
-    s_space[threadIdx.x] = space; s_parts[threadIdx.x] = parts;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long rs = 0; uint32_t rp = 0;
-        for (int t = 0; t < 1024; ++t) {
-            const unsigned long long v = s_space[t]; const uint32_t q = s_parts[t];
-            s_space[t] = rs; s_parts[t] = rp; rs += v; rp += q;
+    // exclusive prefix over the 1024 threads: wave scans + one pass over the 16 wave totals
+    {
+        unsigned long long isp = space; uint32_t ipt = parts;
+        const int l = lane_id(), wv = (int)(threadIdx.x >> 6);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long ts = __shfl_up(isp, o, 64); const uint32_t tp = __shfl_up(ipt, o, 64);
+            if (l >= o) { isp += ts; ipt += tp; }
         }
-        part_first[n_genes] = rp;
+        __shared__ unsigned long long w_space[16];
+        __shared__ uint32_t w_parts[16];
+        if (l == 63) { w_space[wv] = isp; w_parts[wv] = ipt; }
+        __syncthreads();
+        unsigned long long bs = 0; uint32_t bp = 0;
+        for (int w = 0; w < wv; ++w) { bs += w_space[w]; bp += w_parts[w]; }
+        s_space[threadIdx.x] = bs + isp - space; s_parts[threadIdx.x] = bp + ipt - parts;
+        if (threadIdx.x == 1023) part_first[n_genes] = bp + ipt;
     }
     __syncthreads();
     unsigned long long off = s_space[threadIdx.x]; uint32_t pp = s_parts[threadIdx.x];
