@@ -86,6 +86,28 @@ def test_gtf_ingest_matches_python_mirror(host, tmp_path):
     host.host_annotation_free(h)
 
 
+def test_gtf_ingest_genome_scale(host, tmp_path):
+    """332 k lines (56 202 genes, 25 contigs): the interned-id table grows several times; the flattened annotation must
+    equal the generator's, which was flattened by the Python mirror of the same rules."""
+    ann = synth.make_annotation(seed=3, contigs=synth.human_contigs())
+    gtf = str(tmp_path / "g.gtf")
+    bamio.write_gtf(gtf, ann)
+    h, err = load_annotation(host, gtf, list(ann.contig_names))
+    assert err == 0
+    s = host.host_annotation_struct(h).contents
+    L, E = ann.n_genes_listed, ann.n_exons
+    assert (s.n_genes_listed, s.n_exons, s.n_genes) == (L, E, ann.n_genes)
+    for f, n, dt in [("gene_row_contig", L, np.int32), ("gene_row_start", L, np.int32), ("gene_row_end", L, np.int32),
+                     ("gene_row_flags", L, np.uint8), ("gene_row_id", L, np.uint32), ("exon_row_contig", E, np.int32),
+                     ("exon_row_start", E, np.int32), ("exon_row_end", E, np.int32), ("exon_row_flags", E, np.uint8),
+                     ("exon_row_id", E, np.uint32), ("exon_row_gene", E, np.uint32), ("gene_is_globin", ann.n_genes, np.uint8),
+                     ("gene_exon_off", ann.n_genes + 1, np.uint32), ("gene_exon_row", E, np.uint32)]:
+        np.testing.assert_array_equal(_arr(getattr(s, f), n, dt), np.asarray(getattr(ann, f)), err_msg=f)
+    assert host.host_annotation_gene_name(h, L - 1).decode() == ann.gene_names[L - 1]
+    assert host.host_annotation_coding_length(h, L // 2) == int(ann.coding_length[L // 2])
+    host.host_annotation_free(h)
+
+
 def test_gtf_quirks(host, tmp_path):
     # Q11 exon-id inference, Q16 transcript_type leak, duplicate ids and a blank line are fatal (exit 11)
     g = tmp_path / "q.gtf"
