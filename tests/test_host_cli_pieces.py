@@ -189,6 +189,28 @@ def test_bam_decode_parallel_matches_input(host, tmp_path, threads, batch_record
     host.host_bam_free(C.c_void_p(h))
 
 
+def test_bam_decode_many_default_groups(host, tmp_path):
+    """1.2 M records (~300 MB inflated): several 64 MB groups handed from the producer thread to the parser at the
+    default settings, batches of 2^20 records ending inside a group."""
+    ann = synth.make_annotation(seed=37, contigs=[("chrA", 30_000_000, 600), ("chrB", 10_000_000, 200)])
+    batch = synth.make_reads(ann, 600_000, seed=38, keep_qnames=True, contig_lengths=np.array([30_000_000, 10_000_000]))
+    path = str(tmp_path / "big.bam")
+    bamio.write_bam_fast(path, [("chrA", 30_000_000), ("chrB", 10_000_000)], batch, threads=4)
+    host.host_bam_read_all_ex.restype = C.c_void_p
+    h = host.host_bam_read_all_ex(path.encode(), b"ch", None, 0, 4, C.c_ulonglong(1 << 20))
+    assert h
+    b = host.host_bam_batch(C.c_void_p(h)).contents
+    assert b.n == batch.n and b.n_cigar_total == len(batch.cigar)
+    core = _arr(b.core, b.n, abi.REC_CORE); aux = _arr(b.aux, b.n, abi.REC_AUX)
+    for f in ("pos", "mpos", "isize", "cigar_off"):
+        np.testing.assert_array_equal(core[f], getattr(batch, f), err_msg=f)
+    for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
+        np.testing.assert_array_equal(aux[f], getattr(batch, f), err_msg=f)
+    np.testing.assert_array_equal(_arr(b.cigar, b.n_cigar_total, np.uint32), batch.cigar)
+    np.testing.assert_array_equal(_arr(b.seg_start, b.n_seg + 1, np.uint64), batch.seg_start)
+    host.host_bam_free(C.c_void_p(h))
+
+
 def test_bam_decode_long_record_spans_framing_chunks(host, tmp_path):
     """A 4.5 MB record (long read, larger than the reader's 4 MB head room) between short ones: the parallel framer's chunks inside it have no record
     start to guess, and its SEQ/QUAL bytes (0x11 / 0xff runs) must not be taken for records."""
