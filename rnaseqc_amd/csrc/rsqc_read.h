@@ -233,74 +233,64 @@ RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &
 // reaches the feature stage; `hq` = highQuality (:330).
 RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
                           RecordCounters &out, bool &hq) {
+    // Straight-line form of the cascade: `alive` stays true while the reference's loop body has not hit a
+    // `continue`; every counter is added under the conjunction of `alive` and its own condition.  (In a 64-lane
+    // wave every early exit is taken by some lane, so branching only adds exec-mask bookkeeping.)
     const uint32_t fl = r.flag;
+    const bool excl = p.exclude_chimeric != 0;
+    const bool paired = (fl & RSQC_FPAIRED) != 0, read1 = (fl & RSQC_FREAD1) != 0, dup = (fl & RSQC_FDUP) != 0;
     uint64_t bits = RSQC_BIT(RSQC_C_TOTAL_ALIGNMENTS);                                     // :245,397
-    out.e1_mm = out.e1_bases = out.e2_mm = out.e2_bases = out.mm = out.bases = out.blocks = 0;
-    out.rl_eligible = 0; out.rl_span = 0; out.rl_lqseq = 0; out.error = 0; out.frag_candidate = 0; out.endpos = 0;
-    hq = false;
-#define RSQC_LEAVE() do { out.bits = bits; return false; } while (0)
     if (fl & RSQC_FSECONDARY) bits |= RSQC_BIT(RSQC_C_ALTERNATIVE_ALIGNMENTS);             // :254
     if (fl & RSQC_FSUPP) bits |= RSQC_BIT(RSQC_C_SUPPLEMENTARY_ALIGNMENTS);                // :255
     else if (fl & RSQC_FQCFAIL) bits |= RSQC_BIT(RSQC_C_FAILED_VENDOR_QC);                 // :256
     else if (r.mapq < p.mapq_threshold) bits |= RSQC_BIT(RSQC_C_LOW_MAPPING_QUALITY);      // :257
     const bool has_ch = (r.tagbits & RSQC_TB_HAS_CH) != 0;
-    if ((fl & RSQC_FSUPP) && !has_ch) {                                                    // :258-262
-        bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
-        if (p.exclude_chimeric) RSQC_LEAVE();
-    }
-    if (fl & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP)) RSQC_LEAVE();                  // :263
-    bits |= RSQC_BIT(RSQC_C_UNIQUE_VENDOR_PASSED);
-    if (!(fl & RSQC_FPAIRED)) bits |= RSQC_BIT(RSQC_C_UNPAIRED_READS);
-    if (fl & RSQC_FUNMAP) RSQC_LEAVE();                                                    // :268
-    bits |= RSQC_BIT(RSQC_C_MAPPED_READS);
-    bits |= (fl & RSQC_FDUP) ? RSQC_BIT(RSQC_C_MAPPED_DUPLICATE_READS) : RSQC_BIT(RSQC_C_MAPPED_UNIQUE_READS);
+    const bool supp_auto = (fl & RSQC_FSUPP) && !has_ch;                                   // :258-262
+    if (supp_auto) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
+    bool alive = !(supp_auto && excl);
+    alive = alive && !(fl & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP));               // :263
+    if (alive) bits |= RSQC_BIT(RSQC_C_UNIQUE_VENDOR_PASSED);
+    if (alive && !paired) bits |= RSQC_BIT(RSQC_C_UNPAIRED_READS);
+    alive = alive && !(fl & RSQC_FUNMAP);                                                  // :268
+    if (alive) bits |= RSQC_BIT(RSQC_C_MAPPED_READS) | (dup ? RSQC_BIT(RSQC_C_MAPPED_DUPLICATE_READS) : RSQC_BIT(RSQC_C_MAPPED_UNIQUE_READS));
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
     const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || w.ref_len == 0) ? 1u : w.ref_len);
-    out.endpos = endpos;
-    out.rl_eligible = 1; out.rl_span = (uint32_t)(endpos - r.pos); out.rl_lqseq = r.l_qseq;   // :275-278
-    if (has_ch) {                                                                          // :279-283
-        if (fl & RSQC_FREAD1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_TAG);
-        if (p.exclude_chimeric) RSQC_LEAVE();
-    }
-    if ((fl & RSQC_FPAIRED) && !(fl & RSQC_FMUNMAP)) {                                     // :284-292
-        if (fl & RSQC_FREAD1) bits |= RSQC_BIT(RSQC_C_TOTAL_MAPPED_PAIRS);
-        int32_t d = r.pos - r.mpos; if (d < 0) d = -d;
-        if (!(r.tagbits & RSQC_TB_MTID_SAME) || d > p.chimeric_distance) {
-            if (fl & RSQC_FREAD1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
-            if (p.exclude_chimeric) RSQC_LEAVE();
-        }
-    }
-    int32_t mismatches = 0;
-    if (r.tagbits & RSQC_TB_HAS_NM) {                                                      // :295-316
-        mismatches = r.nm;
-        if (fl & RSQC_FPAIRED) {
-            if (fl & RSQC_FREAD1) {
-                bits |= RSQC_BIT(RSQC_C_END1_MAPPED_READS);
-                out.e1_mm = (uint32_t)mismatches; out.e1_bases = (uint32_t)r.l_qseq;
-                bits |= (fl & RSQC_FDUP) ? RSQC_BIT(RSQC_C_DUPLICATE_PAIRS) : RSQC_BIT(RSQC_C_UNIQUE_FRAGMENTS);
-            } else {
-                bits |= RSQC_BIT(RSQC_C_END2_MAPPED_READS);
-                out.e2_mm = (uint32_t)mismatches; out.e2_bases = (uint32_t)r.l_qseq;
-            }
-        }
-        out.mm = (uint32_t)mismatches;
-    }
-    out.bases = (uint32_t)r.l_qseq;                                                        // :317
+    out.endpos = alive ? endpos : 0;
+    out.rl_eligible = alive ? 1u : 0u;                                                     // :275-278
+    out.rl_span = alive ? (uint32_t)(endpos - r.pos) : 0u; out.rl_lqseq = alive ? r.l_qseq : 0;
+    const bool ch_here = alive && has_ch;                                                  // :279-283
+    if (ch_here && read1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_TAG);
+    alive = alive && !(ch_here && excl);
+    const bool mate_mapped = alive && paired && !(fl & RSQC_FMUNMAP);                      // :284-292
+    if (mate_mapped && read1) bits |= RSQC_BIT(RSQC_C_TOTAL_MAPPED_PAIRS);
+    int32_t d = r.pos - r.mpos; if (d < 0) d = -d;
+    const bool far = mate_mapped && (!(r.tagbits & RSQC_TB_MTID_SAME) || d > p.chimeric_distance);
+    if (far && read1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
+    alive = alive && !(far && excl);
+    const bool has_nm = alive && (r.tagbits & RSQC_TB_HAS_NM) != 0;                        // :295-316
+    const int32_t mismatches = (r.tagbits & RSQC_TB_HAS_NM) ? r.nm : 0;
+    const bool nm1 = has_nm && paired && read1, nm2 = has_nm && paired && !read1;
+    if (nm1) bits |= RSQC_BIT(RSQC_C_END1_MAPPED_READS) | (dup ? RSQC_BIT(RSQC_C_DUPLICATE_PAIRS) : RSQC_BIT(RSQC_C_UNIQUE_FRAGMENTS));
+    if (nm2) bits |= RSQC_BIT(RSQC_C_END2_MAPPED_READS);
+    out.e1_mm = nm1 ? (uint32_t)mismatches : 0u; out.e1_bases = nm1 ? (uint32_t)r.l_qseq : 0u;
+    out.e2_mm = nm2 ? (uint32_t)mismatches : 0u; out.e2_bases = nm2 ? (uint32_t)r.l_qseq : 0u;
+    out.mm = has_nm ? (uint32_t)mismatches : 0u;
+    out.bases = alive ? (uint32_t)r.l_qseq : 0u;                                           // :317
     bool discard = false;                                                                  // :319-328
     for (int t = 0; t < p.n_filter_tags; ++t)
-        if (r.tagbits & (RSQC_TB_FILTER0 << t)) { discard = true; bits |= RSQC_BIT(RSQC_C_FILTERED_TAG0 + t); }
-    if (discard) RSQC_LEAVE();
-    hq = ((uint32_t)mismatches <= p.base_mismatch) && (p.unpaired || (fl & RSQC_FPROPER)) &&
+        if (alive && (r.tagbits & (RSQC_TB_FILTER0 << t))) { discard = true; bits |= RSQC_BIT(RSQC_C_FILTERED_TAG0 + t); }
+    alive = alive && !discard;
+    hq = alive && ((uint32_t)mismatches <= p.base_mismatch) && (p.unpaired || (fl & RSQC_FPROPER)) &&
          (r.mapq >= p.mapq_threshold);                                                     // :330
-    if (r.tid < 0 || r.tid >= a.n_ref) RSQC_LEAVE();                                       // :333-337
-    bits |= hq ? RSQC_BIT(RSQC_C_HIGH_QUALITY_READS) : RSQC_BIT(RSQC_C_LOW_QUALITY_READS);
-    bits |= RSQC_BIT(RSQC_C_READS_USED);
-    if (w.bad) { out.error = RSQC_ERR_BAD_CIGAR; RSQC_LEAVE(); }
-    out.blocks = w.nblocks;                                                                // :360
-    out.frag_candidate = (hq && (fl & RSQC_FPAIRED)) ? 1u : 0u;                            // :372
+    alive = alive && !(r.tid < 0 || r.tid >= a.n_ref);                                     // :333-337
+    hq = hq && alive;
+    if (alive) bits |= (hq ? RSQC_BIT(RSQC_C_HIGH_QUALITY_READS) : RSQC_BIT(RSQC_C_LOW_QUALITY_READS)) | RSQC_BIT(RSQC_C_READS_USED);
+    out.error = (alive && w.bad) ? RSQC_ERR_BAD_CIGAR : 0;
+    alive = alive && !w.bad;
+    out.blocks = alive ? w.nblocks : 0u;                                                   // :360
+    out.frag_candidate = (alive && hq && paired) ? 1u : 0u;                                // :372
     out.bits = bits;
-    return true;
-#undef RSQC_LEAVE
+    return alive;
 }
 // convenience form for callers that did not stage the CIGAR words themselves
 RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, RecordCounters &out,
