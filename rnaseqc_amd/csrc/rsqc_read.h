@@ -206,15 +206,20 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
 
 // ---- CIGAR walk: extractBlocks (src/Expression.cpp:26-67) and bam_endpos in one pass ----
 struct CigarWalk { uint32_t ref_len, nblocks, aligned; bool bad; };
-RSQC_HD void cigar_op(uint32_t c, int32_t pos, CigarWalk &w, Blocks &B) {
+// op classes as bit sets over the BAM op codes MIDNSHP=XB (0..9): aligned block = M,=,X; consumes reference = M,D,N,=,X
+constexpr uint32_t CIG_BLOCK_SET = 0x181u, CIG_REF_SET = 0x18Du;
+RSQC_HD void cigar_op(uint32_t c, int32_t pos, CigarWalk &w, Blocks &B, bool active = true) {
     const uint32_t op = c & 0xf, len = c >> 4;
-    if (op > 8) w.bad = true;                                       // Expression.cpp:61-63
-    if (cigar_is_block(op)) {
+    const bool blk = active && ((CIG_BLOCK_SET >> op) & 1u), ref = active && ((CIG_REF_SET >> op) & 1u);
+    w.bad = w.bad || (active && op > 8);                            // Expression.cpp:61-63
 #pragma unroll
-        for (int k = 0; k < FAST_BLOCKS; ++k) if ((uint32_t)k == w.nblocks) { B.bs[k] = pos + 1 + (int32_t)w.ref_len; B.len[k] = len; }
-        w.aligned += len; ++w.nblocks;
+    for (int k = 0; k < FAST_BLOCKS; ++k) {
+        const bool here = blk && (uint32_t)k == w.nblocks;
+        B.bs[k] = here ? pos + 1 + (int32_t)w.ref_len : B.bs[k];
+        B.len[k] = here ? len : B.len[k];
     }
-    if (cigar_is_ref(op)) w.ref_len += len;
+    w.aligned += blk ? len : 0u; w.nblocks += blk ? 1u : 0u;
+    w.ref_len += ref ? len : 0u;
 }
 // `first` holds the record's first 4 CIGAR words, loaded by the caller in one go (words past
 // n_cigar are ignored); longer CIGARs continue from memory.
@@ -223,7 +228,7 @@ RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &
 #pragma unroll
     for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if ((uint32_t)k < r.n_cigar) cigar_op(first[k], r.pos, w, B);
+    for (int k = 0; k < 4; ++k) cigar_op(first[k], r.pos, w, B, (uint32_t)k < r.n_cigar);
     for (uint32_t i = 4; i < r.n_cigar; ++i) cigar_op(r.cigar[i], r.pos, w, B);
     B.nb = w.nblocks;
 }
@@ -376,28 +381,24 @@ template <int K> RSQC_HD void set_put(uint32_t (&s)[K], int idx, uint32_t v) {
 
 // classification counters of exonAlignmentMetrics, src/Expression.cpp:407-457
 RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq) {
+    const bool intronic = !f.exonic && f.intragenic, intergenic = !f.exonic && !f.intragenic;
+    const bool exonic = f.exonic && do_exon, ambiguous = f.exonic && !do_exon;
     uint64_t bits = 0;
-    if (!f.exonic) {
-        if (f.intragenic) {
-            bits |= RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS);
-            if (hq) bits |= RSQC_BIT(RSQC_C_HQ_INTRONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS);
-        } else {
-            bits |= RSQC_BIT(RSQC_C_INTERGENIC_READS);
-            if (hq) bits |= RSQC_BIT(RSQC_C_HQ_INTERGENIC_READS);
-        }
-    } else if (do_exon) {
-        bits |= RSQC_BIT(RSQC_C_EXONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS);
-        if (hq) bits |= RSQC_BIT(RSQC_C_HQ_EXONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS);
-    } else {
-        bits |= RSQC_BIT(RSQC_C_AMBIGUOUS_READS);
-        if (hq) bits |= RSQC_BIT(RSQC_C_HQ_AMBIGUOUS_READS);
-    }
-    if (f.ribosomal) bits |= RSQC_BIT(RSQC_C_RRNA_READS);
-    if ((f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED))) {
-        const bool sense = (fl & RSQC_FREVERSE) ? f.minus : f.plus;
-        if (p.unpaired || (fl & RSQC_FREAD1)) bits |= sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE);
-        else bits |= sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE);
-    }
+    bits |= intronic ? RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
+    bits |= (intronic && hq) ? RSQC_BIT(RSQC_C_HQ_INTRONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS) : 0ull;
+    bits |= intergenic ? RSQC_BIT(RSQC_C_INTERGENIC_READS) : 0ull;
+    bits |= (intergenic && hq) ? RSQC_BIT(RSQC_C_HQ_INTERGENIC_READS) : 0ull;
+    bits |= exonic ? RSQC_BIT(RSQC_C_EXONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
+    bits |= (exonic && hq) ? RSQC_BIT(RSQC_C_HQ_EXONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS) : 0ull;
+    bits |= ambiguous ? RSQC_BIT(RSQC_C_AMBIGUOUS_READS) : 0ull;
+    bits |= (ambiguous && hq) ? RSQC_BIT(RSQC_C_HQ_AMBIGUOUS_READS) : 0ull;
+    bits |= f.ribosomal ? RSQC_BIT(RSQC_C_RRNA_READS) : 0ull;
+    const bool one_strand = (f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED));
+    const bool sense = (fl & RSQC_FREVERSE) ? f.minus : f.plus;
+    const bool end1 = p.unpaired || (fl & RSQC_FREAD1);
+    const uint64_t sbit = end1 ? (sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE))
+                               : (sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE));
+    bits |= one_strand ? sbit : 0ull;
     return bits;
 }
 
