@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--dist-selftest", action="store_true",
                     help="(diagnostic) single process, but through the N > 1 code path: 1-rank RCCL group, finalize_device, "
                          "all_reduce of the device accumulators, refresh_results")
+    ap.add_argument("--legacy", action="store_true", help="(diagnostic) the --legacy counting rules; output marked invalid")
     ap.add_argument("--genome", action="store_true",
                     help="BASELINE.json configs[2] shape on ONE GPU: GENCODE-sized annotation (25 contigs, 56 202 genes); "
                          "not the default bench line")
@@ -91,7 +92,7 @@ def main():
     batch = synth.make_reads(ann, args.pairs, seed=2 + rank, only_contig=rank if world > 1 else None)
     t_gen = time.time() - t_gen
 
-    p = abi.default_params(device=local_rank)
+    p = abi.default_params(device=local_rank, **(dict(legacy=1, mapq_threshold=4) if args.legacy else {}))
     e = engine.Engine(p)
     owned = None
     if world > 1:
@@ -169,7 +170,7 @@ def main():
             from oracle import binding
             ns = min(args.cpu_sample, batch.n)
             sample = batch.slice(0, ns) if ns < batch.n else batch
-            o = binding.Oracle(abi.default_params())
+            o = binding.Oracle(abi.default_params(**(dict(legacy=1, mapq_threshold=4) if args.legacy else {})))
             o.set_annotation(ann)
             tc = time.perf_counter()
             o.submit(sample)
@@ -196,7 +197,7 @@ def main():
                                    "device-resident SoA, full pass incl. end-of-file stage" %
                                    (chr1[2], ann.n_exons // max(world, 1), batch.n),
                        "records_per_gpu": int(batch.n), "contigs": world, "sharding": "by contig",
-                       "collective": "RCCL all_reduce(sum) of u64[3G+49] + f64[E] per step" if world > 1 else "none"},
+                       "collective": "RCCL all_reduce(sum) of u64[3G+%d] + f64[E] per step" % abi.N_COUNTERS if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "classify_count_kernel_w4r1", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": k1_ms},
@@ -206,6 +207,8 @@ def main():
                                                 "total_alignments": res.counter("Total Alignments")},
             "input_generation_s": round(t_gen, 1),
         }
+        if args.legacy:
+            out["invalid"] = "diagnostic run: --legacy counting rules (general per-record kernel, not the headline path)"
         if args.no_finalize:
             out["invalid"] = "diagnostic run: end-of-file stage skipped"
         if args.dist_selftest:

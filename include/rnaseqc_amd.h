@@ -153,6 +153,8 @@ enum rsqc_counter {
     RSQC_C_FILTERED_TAG2,
     RSQC_C_FILTERED_TAG3,
     RSQC_C_FILTERED_TAG4,
+    RSQC_C_SPLIT_READS,            /* --legacy only (src/Expression.cpp:274); printed when non-zero
+                                      (src/Metrics.cpp:398)                                          */
     RSQC_N_COUNTERS
 };
 
@@ -172,7 +174,12 @@ typedef struct rsqc_params {
     int32_t  unpaired;             /* -u                                                 */
     int32_t  exclude_chimeric;     /* --exclude-chimeric                                 */
     int32_t  n_filter_tags;        /* number of --tag filters carried in tagbits (<=5)   */
-    int32_t  reserved[7];
+    int32_t  legacy;               /* --legacy: RNA-SeQC 1.1.9 counting rules
+                                      (legacyExonAlignmentMetrics, src/Expression.cpp:129-304, and the
+                                      LegacyMode tests of src/RNASeQC.cpp:258-287).  The caller applies
+                                      the two host-side parts: -q defaults to 4 (src/RNASeQC.cpp:90) and
+                                      1-base features are left out of the annotation (:129-135)        */
+    int32_t  reserved[6];
 } rsqc_params;
 
 /* ---- annotation: the flattened form of the reference's GTF state ----------
@@ -211,6 +218,14 @@ typedef struct rsqc_annotation {
        indices, in sorted order                                                 */
     const uint32_t *gene_exon_off;     /* [n_genes + 1]                        */
     const uint32_t *gene_exon_row;     /* [n_exons]                            */
+
+    /* optional (may both be NULL), read only under rsqc_params.legacy: the position of each kept row in the
+       GTF (any strictly increasing key, e.g. the line number).  The legacy rules depend on the order of the
+       reference's ONE start-sorted list of genes and exons (stable sort, src/RNASeQC.cpp:150-152), i.e. on how
+       a gene row and an exon row with the same start are ordered.  When NULL, gene rows are taken to precede
+       exon rows of the same start (a GTF whose gene lines precede their exon lines).                        */
+    const uint32_t *gene_row_order;    /* [n_genes_listed]                     */
+    const uint32_t *exon_row_order;    /* [n_exons]                            */
 } rsqc_annotation;
 
 /* ---- BED intervals for the fragment-size sampler (src/BED.cpp:18-45):

@@ -2,7 +2,7 @@
  * rsqc_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * A single-threaded CPU restatement, in plain C, of the per-read hot path of
- * getzlab/rnaseqc 2.4.3 (non-legacy, no --fasta).  It deliberately keeps the
+ * getzlab/rnaseqc 2.4.3 (default and --legacy rules, no --fasta).  It deliberately keeps the
  * reference's *streaming* algorithm -- one start-sorted feature list per
  * contig, destructively front-trimmed as the coordinate-sorted input advances,
  * linearly scanned per CIGAR block -- whereas the HIP product queries a static
@@ -44,6 +44,7 @@ typedef struct {
     uint32_t id;              /* gene id (gene row) / exon id (exon row)     */
     uint32_t gene;            /* gene id named by the row's gene_id          */
     uint32_t row;             /* index in the sorted gene/exon row arrays    */
+    uint32_t order;           /* position in the GTF (rsqc_annotation.*_row_order), when given */
 } feat_t;
 
 typedef struct {
@@ -603,6 +604,131 @@ static void exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_t 
     free(gset); free(gn); free(st);
 }
 
+
+/* legacyExonAlignmentMetrics, src/Expression.cpp:129-304 (--legacy).  `length` (extractBlocks' return value) is
+ * not used by the reference here: the split dosage divides by alignment.Length() = l_qseq (:201).               */
+static void legacy_exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_t *blocks, size_t nb, int hq) {
+    flist_t *fl = &c->feat[r->tid];
+    const int64_t SPLIT_DISTANCE = 100;                                     /* LEGACY_SPLIT_DISTANCE, src/RNASeQC.cpp:28 */
+    int split = 0; int64_t last_end = -1;                                   /* :135-141 */
+    for (size_t b = 0; b < nb; ++b) {
+        if (last_end > 0 && !split) split = (blocks[b].start - last_end) > SPLIT_DISTANCE - 1;
+        last_end = blocks[b].end;
+    }
+    const int64_t cs = (int64_t)r->pos + 1, ce = end_position(r);           /* :145-146 (1-based closed span) */
+    /* intersectBlock(current, features[chr]) :148, src/Expression.cpp:106-117 */
+    size_t nres = 0, cres = 0; const feat_t **res = NULL;
+    for (size_t i = fl->head; i < fl->n && fl->f[i].start <= ce; ++i)
+        if (intersects(cs, ce, &fl->f[i])) {
+            if (nres == cres) { cres = cres ? cres * 2 : 16; res = xrealloc(res, cres * sizeof(*res)); }
+            res[nres++] = &fl->f[i];
+        }
+    int intragenic = 0, plus = 0, minus = 0, ribosomal = 0, do_exon = 0, exonic = 0, junction = 0, not_exonic = 0; /* :151 */
+    int not_split = 0;                                                      /* :152 */
+    int read_strand = RSQC_STRAND_UNKNOWN;                                  /* :153, feature_strand :119-125 */
+    if (c->p.stranded != RSQC_STRAND_UNKNOWN) {
+        int target = (r->flag & RSQC_FREVERSE) != 0;
+        if ((c->p.stranded == RSQC_STRAND_FORWARD) ^ ((r->flag & RSQC_FREAD1) != 0)) target = !target;
+        read_strand = target ? RSQC_STRAND_REVERSE : RSQC_STRAND_FORWARD;
+    }
+    staged_t *st = NULL; size_t cst = 0;                                    /* BaseCoverage cache of this read */
+    uint32_t *dose_row = xcalloc(nb + 1, sizeof(uint32_t)); float *dose = xcalloc(nb + 1, sizeof(float));
+    for (size_t ri = 0; ri < nres; ++ri) {                                  /* :154 */
+        const feat_t *g = res[ri];
+        const feat_t *exon = NULL;                                          /* :156 */
+        int found_exon = 0, t_intron = 0, t_exon = 0;                       /* :157 */
+        size_t ndose = 0;                                                   /* legacySplitDosage :158 */
+        size_t nst = 0;                                                     /* cache[gene] (one gene row per gene id) */
+        not_split = 0;                                                      /* :159 */
+        if (!g->is_gene) continue;                                          /* :160 */
+        const int gstrand = g->flags & RSQC_FF_STRAND_MASK;
+        if (gstrand == RSQC_STRAND_FORWARD) plus = 1;                       /* :163-164 */
+        else if (gstrand == RSQC_STRAND_REVERSE) minus = 1;
+        for (size_t b = 0; b < nb; ++b) {                                   /* :165 */
+            const int64_t bs = blocks[b].start, be = blocks[b].end;
+            if (read_strand != RSQC_STRAND_UNKNOWN && read_strand != gstrand) continue; /* :167 */
+            intragenic = 1;                                                 /* :168 */
+            if (bs > g->end) not_exonic = 1;                                /* :170 */
+            int first_exon = 0;                                             /* :172 */
+            found_exon = 0;                                                 /* :173 */
+            for (size_t ei = 0; ei < nres && !first_exon; ++ei) {           /* :178 */
+                const feat_t *ex = res[ei];
+                if (ex->is_gene || ex->gene != g->id || !intersects(bs, be, ex)) continue; /* :180 */
+                if (g->flags & RSQC_FF_RIBOSOMAL) ribosomal = 1;            /* :182 */
+                const int64_t pi = partial_intersect(ex, bs, be);
+                if (pi == be - bs) {                                        /* :183-190 */
+                    exon = ex; t_exon = 1; first_exon = 1; found_exon = 1;
+                    if (nst == cst) { cst = cst ? cst * 2 : 8; st = xrealloc(st, cst * sizeof(staged_t)); }
+                    st[nst].gene = ex->gene; st[nst].exon_row = ex->row;    /* baseCoverage.add, Metrics.cpp:96-103 */
+                    st[nst].offset = bs - ex->start; st[nst].length = (uint32_t)(be - bs); st[nst].frac = 0;
+                    nst++;
+                } else if (pi > 0) t_intron = 1;                            /* :191-194 */
+            }
+            if (split && !not_split) {                                      /* :197-204 */
+                if (found_exon) {
+                    size_t k = 0; while (k < ndose && dose_row[k] != exon->row) ++k;
+                    if (k == ndose) { dose_row[k] = exon->row; dose[k] = 0.0f; ndose++; }
+                    dose[k] += (float)(be - bs) / (float)r->l_qseq;        /* :201 */
+                } else not_split = 1;
+            }
+        }
+        if (found_exon) {                                                   /* :210 */
+            if (hq) {
+                if (split && !not_split) {                                  /* :214-221 */
+                    for (size_t k = 0; k < ndose; ++k) {
+                        const uint32_t eid = c->ex_id[dose_row[k]];
+                        c->exon_reads[eid] += dose[k]; c->exon_hit[eid] = 1;
+                    }
+                } else {                                                    /* :222-227 */
+                    const uint32_t eid = c->ex_id[exon->row];
+                    c->exon_reads[eid] += 1.0; c->exon_hit[eid] = 1;
+                }
+                const uint32_t gene = exon->gene;
+                c->gene_reads[gene] += 1.0;                                 /* :228 */
+                if (nameset_insert(&c->tracker[gene], r->qhash, r->qname, r->qname_len))
+                    c->gene_frag[gene] += 1.0;                              /* :229-233 */
+                if (!(r->flag & RSQC_FDUP)) c->gene_unique[gene] += 1.0;    /* :234 */
+                if (c->seen[gene]) {                                        /* commit :235, Metrics.cpp:106-124 */
+                    fprintf(stderr, "Gene encountered after computing coverage %u\n", gene);
+                } else for (size_t k = 0; k < nst; ++k) {
+                    const uint32_t row = st[k].exon_row;
+                    const size_t elen = (size_t)(c->ex_end[row] - c->ex_start[row] + 1);
+                    if (!c->cov[row]) c->cov[row] = xcalloc(elen, sizeof(uint64_t));
+                    for (int64_t j = st[k].offset; j < st[k].offset + (int64_t)st[k].length && (size_t)j < elen; ++j)
+                        c->cov[row][j] += 1;
+                }
+            }
+            do_exon = 1;                                                    /* :237 */
+        }
+        if (t_intron && t_exon) junction = 1;                               /* :239 */
+        if (t_exon) exonic = 1;                                             /* :240 */
+    }
+    free(res); free(st); free(dose_row); free(dose);
+    if (not_exonic || junction || !exonic) {                                /* :246-262 */
+        if (intragenic) {
+            INC(RSQC_C_INTRONIC_READS); INC(RSQC_C_INTRAGENIC_READS);
+            if (hq) { INC(RSQC_C_HQ_INTRONIC_READS); INC(RSQC_C_HQ_INTRAGENIC_READS); }
+        } else {
+            INC(RSQC_C_INTERGENIC_READS);
+            if (hq) INC(RSQC_C_HQ_INTERGENIC_READS);
+        }
+    } else if (do_exon && !junction && !not_exonic) {                       /* :264-275 */
+        INC(RSQC_C_EXONIC_READS); INC(RSQC_C_INTRAGENIC_READS);
+        if (hq) { INC(RSQC_C_HQ_EXONIC_READS); INC(RSQC_C_HQ_INTRAGENIC_READS); }
+        if (split && !not_split) INC(RSQC_C_SPLIT_READS);
+    } else if (intragenic) {                                                /* :276-287 */
+        INC(RSQC_C_EXONIC_READS); INC(RSQC_C_INTRAGENIC_READS);
+        if (hq) { INC(RSQC_C_HQ_EXONIC_READS); INC(RSQC_C_HQ_INTRAGENIC_READS); }
+    }
+    if (ribosomal) INC(RSQC_C_RRNA_READS);                                  /* :288 */
+    if ((minus ^ plus) && (c->p.unpaired || (r->flag & RSQC_FPAIRED))) {    /* :290-302 */
+        int rev = (r->flag & RSQC_FREVERSE) != 0;
+        int sense = rev ? minus : plus;
+        if (c->p.unpaired || (r->flag & RSQC_FREAD1)) INC(sense ? RSQC_C_END1_SENSE : RSQC_C_END1_ANTISENSE);
+        else INC(sense ? RSQC_C_END2_SENSE : RSQC_C_END2_ANTISENSE);
+    }
+}
+
 /* The body of `while (bam.next(alignment))`, src/RNASeQC.cpp:242-382 */
 static int process_record(oracle_ctx *c, const rec_t *r) {
     const uint32_t fl = r->flag;
@@ -611,8 +737,9 @@ static int process_record(oracle_ctx *c, const rec_t *r) {
     if (fl & RSQC_FSUPP) INC(RSQC_C_SUPPLEMENTARY_ALIGNMENTS);              /* :255 */
     else if (fl & RSQC_FQCFAIL) INC(RSQC_C_FAILED_VENDOR_QC);               /* :256 */
     else if (r->mapq < c->p.mapq_threshold) INC(RSQC_C_LOW_MAPPING_QUALITY);/* :257 */
+    const int legacy = c->p.legacy != 0;
     const int has_ch = (r->tagbits & RSQC_TB_HAS_CH) != 0;
-    if ((fl & RSQC_FSUPP) && !has_ch) {                                     /* :258-262 */
+    if ((fl & RSQC_FSUPP) && !(legacy || has_ch)) {                         /* :258-262 */
         INC(RSQC_C_CHIMERIC_AUTO);
         if (c->p.exclude_chimeric) return 0;
     }
@@ -624,14 +751,16 @@ static int process_record(oracle_ctx *c, const rec_t *r) {
     if (fl & RSQC_FDUP) INC(RSQC_C_MAPPED_DUPLICATE_READS); else INC(RSQC_C_MAPPED_UNIQUE_READS); /* :272-273 */
     const int32_t endpos = end_position(r);
     unsigned int alignment_size = (unsigned int)(endpos - r->pos);          /* :275 */
+    if (legacy && alignment_size > 100000u) return 0;                       /* :276, LEGACY_MAX_READ_LENGTH :27 */
     if (alignment_size > (unsigned int)c->read_length) c->read_length = r->l_qseq; /* :278 */
-    if (has_ch) {                                                           /* :279-283 */
+    if (!legacy && has_ch) {                                                /* :279-283 */
         if (fl & RSQC_FREAD1) INC(RSQC_C_CHIMERIC_TAG);
         if (c->p.exclude_chimeric) return 0;
     }
     if ((fl & RSQC_FPAIRED) && !(fl & RSQC_FMUNMAP)) {                      /* :284-292 */
         if (fl & RSQC_FREAD1) INC(RSQC_C_TOTAL_MAPPED_PAIRS);
-        if (!(r->tagbits & RSQC_TB_MTID_SAME) || abs(r->pos - r->mpos) > c->p.chimeric_distance) {
+        if (!(r->tagbits & RSQC_TB_MTID_SAME) || abs(r->pos - r->mpos) > c->p.chimeric_distance ||
+            (legacy && r->tid > 127)) {                                     /* :287 */
             if (fl & RSQC_FREAD1) INC(RSQC_C_CHIMERIC_AUTO);
             if (c->p.exclude_chimeric) return 0;
         }
@@ -690,7 +819,8 @@ static int process_record(oracle_ctx *c, const rec_t *r) {
     c->counters[RSQC_C_ALIGNMENT_BLOCKS] += nb;                             /* :360 */
     int rc = trim_features(c, &c->feat[r->tid], r->pos);                    /* :361 */
     if (rc) { free(blocks); return rc; }
-    exon_alignment_metrics(c, r, blocks, nb, aligned, hq);                  /* :366 */
+    if (legacy) legacy_exon_alignment_metrics(c, r, blocks, nb, hq);        /* :364 */
+    else exon_alignment_metrics(c, r, blocks, nb, aligned, hq);             /* :366 */
     if (hq && c->frag_remaining && (fl & RSQC_FPAIRED) && c->have_bed &&
         c->bed[r->tid].n)                                                   /* :372 */
         fragment_size(c, r, blocks, nb);
@@ -709,9 +839,11 @@ ORACLE_API int oracle_create(const rsqc_params *p, oracle_ctx **out) {
     return 0;
 }
 
+static int cmp_use_order;                               /* the annotation carries GTF positions */
 static int cmp_feat(const void *a, const void *b) {     /* compIntervalStart + stable order */
     const feat_t *x = a, *y = b;
     if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    if (cmp_use_order && x->order != y->order) return x->order < y->order ? -1 : 1;
     if (x->is_gene != y->is_gene) return x->is_gene ? -1 : 1;   /* gene row before its exons */
     return x->row < y->row ? -1 : x->row > y->row;
 }
@@ -734,6 +866,7 @@ ORACLE_API int oracle_set_annotation(oracle_ctx *c, const rsqc_annotation *a, co
         feat_t *f = &fl->f[fl->n++];
         f->start = a->gene_row_start[i]; f->end = a->gene_row_end[i]; f->flags = a->gene_row_flags[i];
         f->is_gene = 1; f->id = a->gene_row_id[i]; f->gene = f->id; f->row = (uint32_t)i;
+        f->order = a->gene_row_order ? a->gene_row_order[i] : 0;
         if (f->id < (uint32_t)L) c->g_row_flags[f->id] = f->flags;
     }
     for (int i = 0; i < E; ++i) {
@@ -741,7 +874,9 @@ ORACLE_API int oracle_set_annotation(oracle_ctx *c, const rsqc_annotation *a, co
         feat_t *f = &fl->f[fl->n++];
         f->start = a->exon_row_start[i]; f->end = a->exon_row_end[i]; f->flags = a->exon_row_flags[i];
         f->is_gene = 0; f->id = a->exon_row_id[i]; f->gene = a->exon_row_gene[i]; f->row = (uint32_t)i;
+        f->order = a->exon_row_order ? a->exon_row_order[i] : 0;
     }
+    cmp_use_order = a->gene_row_order && a->exon_row_order;
     for (int i = 0; i < nc; ++i) qsort(c->feat[i].f, c->feat[i].n, sizeof(feat_t), cmp_feat);
     free(cnt);
     c->ex_start = dup_array(a->exon_row_start, E, 4); c->ex_end = dup_array(a->exon_row_end, E, 4);

@@ -39,7 +39,7 @@ COUNTER_NAMES = [
     "HQ Intergenic Reads", "Exonic Reads", "HQ Exonic Reads", "Ambiguous Reads", "HQ Ambiguous Reads",
     "rRNA Reads", "End 1 Sense", "End 1 Antisense", "End 2 Sense", "End 2 Antisense",
     "Total Alignments", "Filtered by tag: 0", "Filtered by tag: 1", "Filtered by tag: 2",
-    "Filtered by tag: 3", "Filtered by tag: 4",
+    "Filtered by tag: 3", "Filtered by tag: 4", "Split Reads",
 ]
 N_COUNTERS = len(COUNTER_NAMES)
 COUNTER_INDEX = {n: i for i, n in enumerate(COUNTER_NAMES)}
@@ -61,7 +61,7 @@ class Params(C.Structure):
         ("bias_offset", C.c_int32), ("bias_window", C.c_int32),
         ("bias_gene_length", C.c_uint64), ("coverage_mask", C.c_uint32),
         ("stranded", C.c_int32), ("unpaired", C.c_int32), ("exclude_chimeric", C.c_int32),
-        ("n_filter_tags", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("n_filter_tags", C.c_int32), ("legacy", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -82,6 +82,7 @@ def default_params(**kw) -> Params:
     p.unpaired = 0
     p.exclude_chimeric = 0
     p.n_filter_tags = 0
+    p.legacy = 0
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -98,6 +99,7 @@ class AnnotationStruct(C.Structure):
         ("exon_row_contig", _P), ("exon_row_start", _P), ("exon_row_end", _P),
         ("exon_row_flags", _P), ("exon_row_id", _P), ("exon_row_gene", _P),
         ("gene_is_globin", _P), ("gene_exon_off", _P), ("gene_exon_row", _P),
+        ("gene_row_order", _P), ("exon_row_order", _P),      # optional, legacy rules only
     ]
 
 

@@ -171,7 +171,9 @@ void Annotation::load_gtf(const std::string &path) {
             const bool ribosomal = transcript_type.find("rRNA") != std::string::npos;     // regex_search "rRNA"
             if (type == 0 || type == 2) {                                                // src/RNASeQC.cpp:137-139
                 if (endp < start) throw GtfError("feature with end < start is not supported: " + line);
-                rows.push_back(Row{chrom, start, endp, strand, type == 0, ribosomal, feature_key, gene_key, order});
+                const bool excluded = legacy && endp == start;                           // src/RNASeQC.cpp:129-135
+                if (excluded && type == 2) coding_of_key[gene_key] -= 1;
+                rows.push_back(Row{chrom, start, endp, strand, type == 0, ribosomal, feature_key, gene_key, order, excluded});
             }
             ++order;
         }
@@ -217,52 +219,62 @@ void Annotation::flatten(const std::vector<std::string> &bam_contigs) {
         const int id = (int)k + 1;
         if (!contig_of_chrom.count(id)) { contig_of_chrom[id] = (int)contig_names.size(); contig_names.push_back(chrom_name[k]); }
     }
+    // rows --legacy excludes live on one extra contig behind all others (chromosomeMap id 0 = none)
+    bool any_excluded = false;
+    for (auto &r : rows) any_excluded = any_excluded || r.excluded;
+    const int parked = any_excluded ? (int)contig_names.size() : -1;
+    if (any_excluded) contig_names.push_back("(legacy: excluded 1-base features)");
     chrom_of_contig.assign(contig_names.size(), 0);
     for (auto &kv : contig_of_chrom) chrom_of_contig[(size_t)kv.second] = kv.first;
+    auto contig_of = [&](const Row *r) { return r->excluded ? parked : contig_of_chrom[r->chrom]; };
     // gene ids: listed genes in geneList order, then gene_ids only exon rows name
     const uint32_t NONE = 0xFFFFFFFFu;
     std::vector<uint32_t> gene_index(n_ids() + 1, NONE), exon_index(n_ids() + 1, NONE);   // by interned key (every listed id is interned)
     for (size_t g = 0; g < gene_list.size(); ++g) gene_index[intern(gene_list[g])] = (uint32_t)g;        // (already interned)
     gene_id_of = gene_list;
     for (auto &r : rows) if (!r.is_gene && gene_index[r.gene_key] == NONE) { gene_index[r.gene_key] = (uint32_t)gene_id_of.size(); gene_id_of.push_back(id_text(r.gene_key)); }
+    // excluded exon rows belong to one extra unlisted gene: they must not lengthen the transcript of their own gene
+    // (exonsForGene never sees them, src/RNASeQC.cpp:150-154)
+    uint32_t parked_gene = NONE;
+    for (auto &r : rows) if (r.excluded && !r.is_gene && parked_gene == NONE) { parked_gene = (uint32_t)gene_id_of.size(); gene_id_of.push_back("(legacy: excluded)"); }
     n_genes = (int)gene_id_of.size();
     for (size_t e = 0; e < exon_list.size(); ++e) exon_index[intern(exon_list[e])] = (uint32_t)e;
     // stable sort by (contig, start): std::list::sort(compIntervalStart) per contig (src/RNASeQC.cpp:150-152)
     std::vector<const Row *> gr, er;
     for (auto &r : rows) (r.is_gene ? gr : er).push_back(&r);
     auto cmp = [&](const Row *a, const Row *b) {
-        const int ca = contig_of_chrom[a->chrom], cb = contig_of_chrom[b->chrom];
+        const int ca = contig_of(a), cb = contig_of(b);
         if (ca != cb) return ca < cb;
         return a->start < b->start;
     };
     std::stable_sort(gr.begin(), gr.end(), cmp);
     std::stable_sort(er.begin(), er.end(), cmp);
     auto flags_of = [](const Row *r) { return (uint8_t)(r->strand | (r->ribosomal ? RSQC_FF_RIBOSOMAL : 0)); };
-    g_contig.clear(); g_start.clear(); g_end.clear(); g_flags.clear(); g_id.clear();
+    g_contig.clear(); g_start.clear(); g_end.clear(); g_flags.clear(); g_id.clear(); g_order.clear(); e_order.clear();
     genes_by_contig.assign(contig_names.size(), {});
     for (auto *r : gr) {
-        g_contig.push_back(contig_of_chrom[r->chrom]); g_start.push_back((int32_t)r->start); g_end.push_back((int32_t)r->end);
-        g_flags.push_back(flags_of(r)); g_id.push_back(gene_index[r->feature_key]);
-        genes_by_contig[(size_t)contig_of_chrom[r->chrom]].push_back(gene_index[r->feature_key]);
+        g_contig.push_back(contig_of(r)); g_start.push_back((int32_t)r->start); g_end.push_back((int32_t)r->end);
+        g_flags.push_back(flags_of(r)); g_id.push_back(gene_index[r->feature_key]); g_order.push_back((uint32_t)r->order);
+        if (!r->excluded) genes_by_contig[(size_t)contig_of(r)].push_back(gene_index[r->feature_key]);   // (an excluded gene never reaches BaseCoverage::compute: no coverage.tsv row)
     }
     e_contig.clear(); e_start.clear(); e_end.clear(); e_flags.clear(); e_id.clear(); e_gene.clear();
     std::vector<std::vector<uint32_t>> per_gene((size_t)n_genes);
     for (size_t i = 0; i < er.size(); ++i) {
         const Row *r = er[i];
-        e_contig.push_back(contig_of_chrom[r->chrom]); e_start.push_back((int32_t)r->start); e_end.push_back((int32_t)r->end);
-        e_flags.push_back(flags_of(r)); e_id.push_back(exon_index[r->feature_key]);
-        const uint32_t g = gene_index[r->gene_key];
+        e_contig.push_back(contig_of(r)); e_start.push_back((int32_t)r->start); e_end.push_back((int32_t)r->end);
+        e_flags.push_back(flags_of(r)); e_id.push_back(exon_index[r->feature_key]); e_order.push_back((uint32_t)r->order);
+        const uint32_t g = r->excluded ? parked_gene : gene_index[r->gene_key];
         e_gene.push_back(g);
         per_gene[g].push_back((uint32_t)i);                 // exonsForGene: sorted order (src/RNASeQC.cpp:153-154)
     }
     ge_off.assign((size_t)n_genes + 1, 0); ge_row.clear();
     for (int g = 0; g < n_genes; ++g) { ge_off[(size_t)g + 1] = ge_off[(size_t)g] + (uint32_t)per_gene[(size_t)g].size(); ge_row.insert(ge_row.end(), per_gene[(size_t)g].begin(), per_gene[(size_t)g].end()); }
     globin.assign((size_t)n_genes, 0);
-    for (int g = 0; g < n_genes; ++g) if (kGlobins.count(gene_name(gene_id_of[(size_t)g]))) globin[(size_t)g] = 1;
+    for (int g = 0; g < n_genes; ++g) if ((uint32_t)g != parked_gene && kGlobins.count(gene_name(gene_id_of[(size_t)g]))) globin[(size_t)g] = 1;
     ann = rsqc_annotation{n_ref, (int32_t)contig_names.size(), n_genes, (int32_t)gene_list.size(), (int32_t)exon_list.size(),
                           g_contig.data(), g_start.data(), g_end.data(), g_flags.data(), g_id.data(),
                           e_contig.data(), e_start.data(), e_end.data(), e_flags.data(), e_id.data(), e_gene.data(),
-                          globin.data(), ge_off.data(), ge_row.data()};
+                          globin.data(), ge_off.data(), ge_row.data(), g_order.data(), e_order.data()};
     // BED: grouped by contig, file order inside (must ascend by start)
     std::vector<const BedRow *> br;
     for (auto &b : bed_rows) br.push_back(&b);

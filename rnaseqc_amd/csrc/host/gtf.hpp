@@ -44,7 +44,11 @@ struct Annotation {
     std::vector<long long> coding_of_key;           // geneCodingLengths by key
     std::string gene_name(const std::string &feature_id) const;          // geneNames[feature_id] ("" when absent)
     long long coding_length(const std::string &gene_id) const;          // geneCodingLengths[gene_id] (0 when absent)
-    struct Row { int chrom; long long start, end; int strand; bool is_gene; bool ribosomal; uint32_t feature_key, gene_key; size_t order; };
+    // excluded: --legacy leaves 1-base features out of the feature lists (src/RNASeQC.cpp:129-135) but they are already
+    // in geneList / exonList; flatten() parks such rows on a contig no record can name, so that the boundary's id
+    // spaces (and the report rows) stay those of the lists
+    struct Row { int chrom; long long start, end; int strand; bool is_gene; bool ribosomal; uint32_t feature_key, gene_key; size_t order; bool excluded; };
+    bool legacy = false;                                            // --legacy (set before load_gtf)
     std::vector<Row> rows;                                          // kept gene/exon rows, GTF order
     void load_gtf(const std::string &path);
 
@@ -58,7 +62,7 @@ struct Annotation {
     std::vector<std::string> contig_names; int n_ref = 0;
     std::vector<int32_t> g_contig, g_start, g_end, e_contig, e_start, e_end, b_contig, b_start, b_end;
     std::vector<uint8_t> g_flags, e_flags, globin;
-    std::vector<uint32_t> g_id, e_id, e_gene, ge_off, ge_row;
+    std::vector<uint32_t> g_id, e_id, e_gene, ge_off, ge_row, g_order, e_order;
     std::vector<std::string> gene_id_of;            // gene id (boundary) -> gene_id string (listed first, then phantom)
     std::vector<int> chrom_of_contig;               // boundary contig id -> chromosomeMap id
     int n_genes = 0;

@@ -15,8 +15,9 @@
 using namespace rsqc_host;
 #define HAPI extern "C" __attribute__((visibility("default")))
 
-HAPI void *host_annotation_load(const char *gtf, const char *bed, const char *const *bam_contigs, int n_contigs, int *err) {
+HAPI void *host_annotation_load_ex(const char *gtf, const char *bed, const char *const *bam_contigs, int n_contigs, int legacy, int *err) {
     Annotation *a = new Annotation();
+    a->legacy = legacy != 0;
     *err = 0;
     try {
         a->load_gtf(gtf);
@@ -27,6 +28,9 @@ HAPI void *host_annotation_load(const char *gtf, const char *bed, const char *co
     } catch (FileError &) { *err = 10; } catch (GtfError &) { *err = 11; } catch (BedError &) { *err = 11; } catch (...) { *err = -1; }
     if (*err) { delete a; return nullptr; }
     return a;
+}
+HAPI void *host_annotation_load(const char *gtf, const char *bed, const char *const *bam_contigs, int n_contigs, int *err) {
+    return host_annotation_load_ex(gtf, bed, bam_contigs, n_contigs, 0, err);
 }
 HAPI const rsqc_annotation *host_annotation_struct(void *h) { return &((Annotation *)h)->ann; }
 HAPI const rsqc_bed *host_annotation_bed(void *h) { return &((Annotation *)h)->bed; }

@@ -58,7 +58,7 @@ void usage(std::ostream &o) {
          "      --offset=[OFFSET]                 Offset into the gene for the 3' and 5' windows. Default: 0 [bp]\n"
          "      --window-size=[SIZE]              Size of the 3' and 5' windows. Default: 100 [bp]\n"
          "      --gene-length=[LENGTH]            Minimum size of a gene for bias calculation. Default: 200 [bp]\n"
-         "      --legacy                          (not supported by this build)\n"
+         "      --legacy                          Use legacy counting rules.  Gene and exon counts match output of RNA-SeQC 1.1.9\n"
          "      --stranded=[stranded]             'RF', 'rf', 'FR', or 'fr'\n"
          "      -v, --verbose                     Give some feedback; twice for progress updates\n"
          "      -t[TAG...], --tag=[TAG...]        Filter out reads with the specified tag\n"
@@ -190,14 +190,15 @@ int main(int argc, char **argv) {
             else if (o.stranded == "FR" || o.stranded == "fr") strand = RSQC_STRAND_FORWARD;
             else throw ValidationError("--stranded argument must be in {'RF', 'rf', 'FR', 'fr'}");
         }
-        if (o.legacy) { cerr << "--legacy counting rules are not implemented in this build" << endl; return 7; }
         if (o.has_fasta) { cerr << "--fasta (CRAM reference / GC statistics) is not implemented in this build" << endl; return 7; }
         if (o.tags.size() > RSQC_MAX_FILTER_TAGS) { cerr << "at most " << RSQC_MAX_FILTER_TAGS << " --tag filters are supported" << endl; return 7; }
 
         rsqc_params P{};
         P.abi_version = RSQC_ABI_VERSION;
         P.device = getenv("RSQC_DEVICE") ? atoi(getenv("RSQC_DEVICE")) : 0;
-        P.mapq_threshold = (uint32_t)o.mapq; P.base_mismatch = (uint32_t)o.base_mismatch;
+        P.mapq_threshold = o.has_mapq ? (uint32_t)o.mapq : (o.legacy ? 4u : 255u);     // src/RNASeQC.cpp:90
+        P.legacy = o.legacy ? 1 : 0;
+        P.base_mismatch = (uint32_t)o.base_mismatch;
         P.chimeric_distance = (int32_t)o.chimeric_distance; P.fragment_samples = (uint32_t)o.fragment_samples;
         P.bias_offset = (int32_t)o.bias_offset; P.bias_window = (int32_t)o.bias_window; P.bias_gene_length = o.bias_gene_length;
         P.coverage_mask = (uint32_t)o.coverage_mask; P.stranded = strand; P.unpaired = o.unpaired; P.exclude_chimeric = o.exclude_chimeric;
@@ -210,6 +211,7 @@ int main(int argc, char **argv) {
         std::future<int> gpu_ready = std::async(std::launch::async, [&P, &gpu] { return rsqc_create(&P, &gpu); });
         const auto t0 = std::chrono::steady_clock::now();
         Annotation ann;
+        ann.legacy = o.legacy;
         if (o.verbosity) cout << "Reading GTF Features..." << endl;
         ann.load_gtf(gtf_path);                                               // FileError -> 10, GtfError -> 11
         if (!(ann.gene_list.size() && ann.exon_list.size())) {
@@ -220,7 +222,7 @@ int main(int argc, char **argv) {
         const auto t1 = std::chrono::steady_clock::now();
         if (o.verbosity) cout << "Finished processing GTF in " << std::chrono::duration<double>(t1 - t0).count() << " seconds" << endl;
         std::vector<char> gtf_chrom(ann.chrom_name.size() + 1, 0);
-        for (auto &r : ann.rows) gtf_chrom[(size_t)r.chrom] = 1;
+        for (auto &r : ann.rows) if (!r.excluded) gtf_chrom[(size_t)r.chrom] = 1;
         if (o.has_bed) {
             if (o.verbosity) cout << "Parsing BED intervals for fragment size computations..." << endl;
             ann.load_bed(o.bed);

@@ -202,7 +202,7 @@ void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results 
                                    RSQC_C_INTRONIC_READS, RSQC_C_LOW_MAPPING_QUALITY, RSQC_C_LOW_QUALITY_READS,
                                    RSQC_C_MAPPED_DUPLICATE_READS, RSQC_C_MAPPED_READS, RSQC_C_MAPPED_UNIQUE_READS,
                                    RSQC_C_MISMATCHED_BASES, RSQC_C_NON_GLOBIN_READS, RSQC_C_NON_GLOBIN_DUPLICATE_READS,
-                                   RSQC_C_READS_USED, RSQC_C_RRNA_READS, /* "Split Reads": legacy only, never printed when 0 */
+                                   RSQC_C_READS_USED, RSQC_C_RRNA_READS, RSQC_C_SPLIT_READS /* printed only when non-zero, src/Metrics.cpp:398 */,
                                    RSQC_C_TOTAL_BASES, RSQC_C_TOTAL_MAPPED_PAIRS, RSQC_C_UNIQUE_VENDOR_PASSED, RSQC_C_UNPAIRED_READS};
         output << "Total Alignments\t" << cnt(RSQC_C_TOTAL_ALIGNMENTS) << endl;
         output << "Alternative Alignments\t" << cnt(RSQC_C_ALTERNATIVE_ALIGNMENTS) << endl;
@@ -216,7 +216,7 @@ void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results 
             output << cnt(RSQC_C_CHIMERIC_AUTO) << endl;
             output << "Chimeric Alignment Rate\t" << frac(RSQC_C_CHIMERIC_AUTO, RSQC_C_TOTAL_MAPPED_PAIRS) << endl;
         }
-        for (int k : keys) output << rsqc_counter_name(k) << "\t" << cnt(k) << endl;
+        for (int k : keys) if (k != RSQC_C_SPLIT_READS || cnt(k)) output << rsqc_counter_name(k) << "\t" << cnt(k) << endl;
         // "Filtered by tag: X" entries exist only for tags that fired, in std::map (string) order
         std::map<std::string, unsigned long> filtered;
         for (size_t t = 0; t < cfg.filter_tags.size() && t < RSQC_MAX_FILTER_TAGS; ++t)

@@ -294,7 +294,9 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     const uint64_t total_waves = (uint64_t)grid * (RSQC_K1_THREADS / 64);
     const uint64_t per_wave = (((u->n + total_waves - 1) / total_waves) + 63ull) & ~63ull;   // as in the kernel
     const uint64_t chunk_cap = per_wave * (RSQC_K1_THREADS / 64) * FAST_SET;
-    const uint64_t slow_cap = 1ull << 20;
+    // --legacy: every pair comes from the general kernel (one per gene a record is counted to; 4 per record is far
+    // above what annotations produce -- beyond it the run fails with RSQC_ERR_CAPACITY)
+    const uint64_t slow_cap = c->dparams.legacy ? std::max<uint64_t>(1ull << 20, 4ull * u->n) : 1ull << 20;
     const uint64_t want = chunk_cap * (uint64_t)grid + slow_cap;
     if (want > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
     size_t pidx = 0;
@@ -335,7 +337,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     c->next_record_base += u->n;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    launch_classify(c->stream, grid, c->k1_variant, c->dann, c->dparams, d, acc);
+    launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc);
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->k1_events.emplace_back(e0, e1);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
@@ -376,6 +378,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.exclude_chimeric = params->exclude_chimeric;
     c->dparams.n_filter_tags = params->n_filter_tags;
     c->dparams.dbg = 0;
+    c->dparams.legacy = params->legacy ? 1 : 0;
     if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
     if (const char *e = getenv("RSQC_K4_MODE")) c->k4_mode = atoi(e);
@@ -438,6 +441,13 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     UPV(d.ex, hx.ex_rows); UPV(d.gb, hx.gb); UPV(d.contig, hx.contig);
     UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov); UPV(d.ex_pmax, hx.ex_pmax);
     UPV(d.ex_id, c->exon_row_id);
+    d.legacy = nullptr;
+    if (c->params.legacy) {                       // tables of the --legacy rules (rsqc_read.h: LegacyTables)
+        LegacyTables lt{};
+        UPV(lt.gr, hx.gr_rows); UPV(lt.gr_pmax, hx.g_pmax); UPV(lt.gr_range, hx.g_range); UPV(lt.ex_ord, hx.ex_ord);
+        std::vector<LegacyTables> one(1, lt);
+        UPV(d.legacy, one);
+    }
     auto &gene_cov_off = hx.gene_cov_off; auto &gene_coding = hx.gene_coding;
     auto &gene_flags = hx.gene_flags; auto &gene_owned = hx.gene_owned;
     // empty BED until rsqc_set_bed
@@ -875,8 +885,9 @@ static const char *const kCounterNames[RSQC_N_COUNTERS] = {
     "HQ Intergenic Reads", "Exonic Reads", "HQ Exonic Reads", "Ambiguous Reads", "HQ Ambiguous Reads",
     "rRNA Reads", "End 1 Sense", "End 1 Antisense", "End 2 Sense", "End 2 Antisense",
     "Total Alignments", "Filtered by tag: 0", "Filtered by tag: 1", "Filtered by tag: 2",
-    "Filtered by tag: 3", "Filtered by tag: 4",
+    "Filtered by tag: 3", "Filtered by tag: 4", "Split Reads",
 };
+static_assert(sizeof(kCounterNames) / sizeof(kCounterNames[0]) == RSQC_N_COUNTERS, "one name per counter");
 
 const char *rsqc_counter_name(int counter) {
     return (counter >= 0 && counter < RSQC_N_COUNTERS) ? kCounterNames[counter] : "";

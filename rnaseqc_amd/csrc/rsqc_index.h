@@ -20,6 +20,8 @@ struct HostIndex {
     std::vector<GeneBreak> gb;
     std::vector<int32_t> ex_pmax, g_pmax;
     std::vector<ExonRow> ex_rows;
+    std::vector<GeneRow> gr_rows;                     // --legacy tables (LegacyTables)
+    std::vector<uint32_t> ex_ord;
     std::vector<ContigInfo> contig;
     std::vector<uint8_t> gene_flags, gene_owned;     // by listed gene id
     uint64_t cov_entries = 0;
@@ -154,6 +156,29 @@ struct HostIndex {
         }
         for (int i = 0; i < E; ++i)
             if (a->exon_row_id[i] >= (uint32_t)E) { err = "exon_row_id out of range"; return RSQC_ERR_ARG; }
+        // --legacy: gene rows as rows, and the rank of every row in the contig's one start-sorted list of genes and
+        // exons (std::list::sort by start, stable: ties keep GTF order, src/RNASeQC.cpp:150-152).  Both row sets are
+        // already in that order among themselves, so the list is their merge; without GTF positions a gene row goes
+        // before the exon rows of the same start.
+        gr_rows.resize((size_t)L); ex_ord.assign((size_t)E, 0);
+        const bool have_order = a->gene_row_order && a->exon_row_order;
+        for (int k = 0; k < nc; ++k) {
+            uint32_t gi = g_range[(size_t)k], ei = ex_range[(size_t)k], rank = 0;
+            const uint32_t gN = g_range[(size_t)k + 1], eN = ex_range[(size_t)k + 1];
+            while (gi < gN || ei < eN) {
+                bool take_gene;
+                if (gi == gN) take_gene = false;
+                else if (ei == eN) take_gene = true;
+                else if (a->gene_row_start[gi] != a->exon_row_start[ei]) take_gene = a->gene_row_start[gi] < a->exon_row_start[ei];
+                else take_gene = have_order ? a->gene_row_order[gi] < a->exon_row_order[ei] : true;
+                if (take_gene) {
+                    gr_rows[gi] = GeneRow{a->gene_row_start[gi], a->gene_row_end[gi],
+                                          a->gene_row_id[gi] | ((uint32_t)(a->gene_row_flags[gi] & 0x7u) << ROW_FLAG_SHIFT), rank};
+                    ++gi;
+                } else ex_ord[ei++] = rank;
+                ++rank;
+            }
+        }
         return 0;
     }
 };

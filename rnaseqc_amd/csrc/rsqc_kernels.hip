@@ -15,6 +15,7 @@
 // contraction: no MFMA.  All wave-level idioms are written for 64-lane wavefronts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "rsqc_device.h"
 
@@ -194,7 +195,9 @@ struct K1Shared {
     }
 };
 
-template <int ROUND>
+// LEGACY (--legacy): only the gate cascade, its counters and the fragment-size candidates are produced here; the
+// legacy feature stage runs as general code in classify_slow_kernel<true> over every record.
+template <int ROUND, bool LEGACY = false>
 __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                                                     const DevAccum &acc, K1Shared &S) {
     const int l = lane_id();
@@ -324,7 +327,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                     CigarWalk cw;
                     walk_cigar(r, cur_cg, cw, B);
                     aligned = cw.aligned;
-                    go = gate_cascade(a, p, r, cw, rc, hq) && !(p.dbg & 8u);
+                    go = gate_cascade<LEGACY>(a, p, r, cw, rc, hq) && !(p.dbg & 8u);
                     fl = r.flag; tid = r.tid;
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                     if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
@@ -359,7 +362,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             }
         }
         // ---- feature stage ------------------------------------------------------------------------
-        if (go) {
+        if (!LEGACY && go) {
             bool overflow = tid != u_tid;          // stragglers of a boundary tile: general code
             if (!overflow) exon_metrics_fast<ROUND>(a, p, u_ci, fl, B, hq, aligned, fo, overflow);
             if (overflow) {
@@ -461,6 +464,11 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 RSQC_DEFINE_K1(classify_count_kernel_w3, 3, 2)
 RSQC_DEFINE_K1(classify_count_kernel_w3r1, 3, 1)
 RSQC_DEFINE_K1(classify_count_kernel_w4r1, 4, 1)
+__global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
+classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
+    __shared__ K1Shared S;
+    classify_count_body<1, true>(a, p, b, acc, S);
+}
 
 // ------------------------------------------------------------------ K1s
 // Records whose block sits fully inside exons of more than FAST_SET genes (pathological
@@ -482,59 +490,93 @@ __device__ __forceinline__ void wave_by_key(bool valid, uint32_t key, F &&leader
 #define RSQC_SLOW_THREADS 256
 #define RSQC_SLOW_SLOTS 1024
 #define RSQC_SLOW_CSLOTS 8192
+// A single hot address sustains only ~90 M atomics/s on this chip (tools/atomic_bench.hip), and the
+// slow-path records concentrate on a few genes: exon fractions are summed per workgroup in an LDS
+// hash (row -> f64) and flushed with one global atomic per distinct row.
+// Atomics into one cache line serialise at ~5-10 ns each as well, and the coverage slots these records
+// touch are few (short exons of a few genes): the +1/-1 events go through an LDS hash too.
+struct SlowShared {
+    uint32_t key[RSQC_SLOW_SLOTS];
+    double val[RSQC_SLOW_SLOTS];
+    uint32_t ckey[RSQC_SLOW_CSLOTS];
+    uint32_t cval[RSQC_SLOW_CSLOTS];
+};
+// accumulator of the general code inside classify_slow_kernel (the `Acc` of legacy_metrics)
+struct SlowAcc {
+    SlowShared *S; const DevAccum *acc; const uint32_t *ex_id;
+    __device__ __forceinline__ void exon_add(uint32_t row, double frac) {
+        uint32_t slot = (row * 2654435761u) >> 22;                      // 10 bits
+        for (int probe = 0; probe < 16; ++probe) {
+            const uint32_t old = atomicCAS(&S->key[slot], 0xFFFFFFFFu, row);
+            if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&S->val[slot], frac); return; }
+            slot = (slot + 1) & (RSQC_SLOW_SLOTS - 1);
+        }
+        atomicAdd(&acc->exon_acc[ex_id[row]], frac);                    // table crowded: straight to memory
+    }
+    __device__ __forceinline__ void cov_add(uint32_t idx, uint32_t delta) {
+        uint32_t slot = (idx * 2654435761u) >> 19;                      // 13 bits
+        for (int probe = 0; probe < 16; ++probe) {
+            const uint32_t old = atomicCAS(&S->ckey[slot], 0xFFFFFFFFu, idx);
+            if (old == 0xFFFFFFFFu || old == idx) { atomicAdd(&S->cval[slot], delta); return; }
+            slot = (slot + 1) & (RSQC_SLOW_CSLOTS - 1);
+        }
+        atomicAdd(&acc->cov_diff[idx], delta);
+    }
+    __device__ __forceinline__ void cov_range(uint32_t cidx, uint32_t len) {
+        if (len == 0) return;
+        cov_add(cidx, 1u); cov_add(cidx + len, 0xFFFFFFFFu);
+    }
+    __device__ __forceinline__ void gene_hit(uint32_t g, bool notdup, uint64_t qhash) {   // genes beyond the wave-aggregated ones
+        atomicAdd(&acc->gene_reads[g], 1ull);
+        if (notdup) atomicAdd(&acc->gene_unique[g], 1ull);
+        const uint32_t slot = atomicAdd(acc->pair_slow_count, 1u);
+        if (slot < acc->pair_slow_cap) { acc->pair_gene[acc->pair_slow_base + slot] = g; acc->pair_hash[acc->pair_slow_base + slot] = qhash; }
+        else atomicExch(acc->error, RSQC_ERR_CAPACITY);
+    }
+};
+
+// LEGACY = false: the records K1 listed in ovf_index.  LEGACY = true (--legacy): every record of the batch, in file
+// order, through legacy_metrics (rsqc_read.h).
+template <bool LEGACY>
 __global__ void __launch_bounds__(RSQC_SLOW_THREADS)
 classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
-    // A single hot address sustains only ~90 M atomics/s on this chip (tools/atomic_bench.hip), and the
-    // slow-path records concentrate on a few genes: exon fractions are summed per workgroup in an LDS
-    // hash (row -> f64) and flushed with one global atomic per distinct row.
-    // Atomics into one cache line serialise at ~5-10 ns each as well, and the coverage slots these records
-    // touch are few (short exons of a few genes): the +1/-1 events go through an LDS hash too.
-    __shared__ uint32_t s_key[RSQC_SLOW_SLOTS];
-    __shared__ double s_val[RSQC_SLOW_SLOTS];
-    __shared__ uint32_t s_ckey[RSQC_SLOW_CSLOTS];
-    __shared__ uint32_t s_cval[RSQC_SLOW_CSLOTS];
-    uint32_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    __shared__ SlowShared SH;
+    uint32_t *const s_key = SH.key; double *const s_val = SH.val; uint32_t *const s_ckey = SH.ckey, *const s_cval = SH.cval;
+    uint64_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
+    if (LEGACY) n = b.n;
     if (p.dbg & 64u) n = 0;
-    if (blockIdx.x * blockDim.x >= n) return;            // nothing for this workgroup (the usual case for most of the grid)
+    if ((uint64_t)blockIdx.x * blockDim.x >= n) return;  // nothing for this workgroup (the usual case for most of the grid)
     for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x) { s_key[i] = 0xFFFFFFFFu; s_val[i] = 0.0; }
     for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x) { s_ckey[i] = 0xFFFFFFFFu; s_cval[i] = 0u; }
     __syncthreads();
     const int l = lane_id();
     DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_id};
-    auto exon_add_lds = [&](uint32_t row, double frac) {
-        uint32_t slot = (row * 2654435761u) >> 22;                      // 10 bits
-        for (int probe = 0; probe < 16; ++probe) {
-            const uint32_t old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, row);
-            if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&s_val[slot], frac); return; }
-            slot = (slot + 1) & (RSQC_SLOW_SLOTS - 1);
-        }
-        atomicAdd(&acc.exon_acc[a.ex_id[row]], frac);                   // table crowded: straight to memory
-    };
-    auto cov_add_lds = [&](uint32_t idx, uint32_t delta) {
-        uint32_t slot = (idx * 2654435761u) >> 19;                      // 13 bits
-        for (int probe = 0; probe < 16; ++probe) {
-            const uint32_t old = atomicCAS(&s_ckey[slot], 0xFFFFFFFFu, idx);
-            if (old == 0xFFFFFFFFu || old == idx) { atomicAdd(&s_cval[slot], delta); return; }
-            slot = (slot + 1) & (RSQC_SLOW_CSLOTS - 1);
-        }
-        atomicAdd(&acc.cov_diff[idx], delta);
-    };
+    SlowAcc sacc{&SH, &acc, a.ex_id};
+    auto exon_add_lds = [&](uint32_t row, double frac) { sacc.exon_add(row, frac); };
+    auto cov_add_lds = [&](uint32_t idx, uint32_t delta) { sacc.cov_add(idx, delta); };
     unsigned long long my_cnt = 0ull;                 // lane c accumulates counter c
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
-        const uint32_t k = k0 + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k0 = (uint64_t)blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
+        const uint64_t k = k0 + threadIdx.x;
         uint64_t bits = 0;
         FeatureOut<MID_SET, SLOW_STAGE> fm;
         fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
         uint32_t aligned = 1; bool notdup = false; uint64_t qhash = 0;
         if (k < n) {
             Record r;
-            const uint64_t i = acc.ovf_index[k];
+            const uint64_t i = LEGACY ? k : acc.ovf_index[k];
             if (load_record(b, i, find_segment(b, i), r)) {
                 RecordCounters rc; bool hq; Blocks B;
                 if (gate_cascade(a, p, r, rc, hq, aligned, B) && !(p.dbg & 16u)) {
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                     bool overflow = false;
+                    if (LEGACY) {
+                        LegacyOut<MID_SET> lo;
+                        legacy_metrics<MID_SET>(a, p, r, hq, sacc, lo);
+                        bits = lo.bits; fm.n_hit = lo.n_hit;
+#pragma unroll
+                        for (int j = 0; j < MID_SET; ++j) fm.hit[j] = lo.hit[j];
+                    } else {
                     exon_metrics<MID_SET>(a, p, r, hq, aligned, dacc, fm, overflow);
                     if (overflow) {                  // rare second tier: up to 32 genes, plain atomics
                         fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
@@ -558,6 +600,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                             bits = fo.bits;
                         }
                     } else bits = fm.bits;
+                    }
                 }
             }
         }
@@ -1379,13 +1422,17 @@ void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, siz
 }
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
-    if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else if (variant == 31) hipLaunchKernelGGL(classify_count_kernel_w3r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {
-    hipLaunchKernelGGL(classify_slow_kernel, dim3(64), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
+    if (p.legacy) {
+        const uint64_t blocks = (b.n + RSQC_SLOW_THREADS - 1) / RSQC_SLOW_THREADS;
+        hipLaunchKernelGGL(classify_slow_kernel<true>, dim3((unsigned)std::min<uint64_t>(blocks ? blocks : 1, 4096)), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
+    } else hipLaunchKernelGGL(classify_slow_kernel<false>, dim3(64), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
 }
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc) {

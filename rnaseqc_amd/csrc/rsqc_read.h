@@ -62,6 +62,20 @@ struct ContigInfo {          // 32 bytes per contig
     uint32_t pad0, pad1;
 };
 
+// Tables read only by the --legacy rules (legacy_metrics below): the gene ROWS themselves (the default rules need
+// only the breakpoint masks) and the rank of every row in the reference's one start-sorted list of genes and exons.
+struct GeneRow {
+    int32_t start, end;      // 1-based closed
+    uint32_t gf;             // gene id (low 26 bits) | feature flags << 26
+    uint32_t ord;            // rank in the contig's combined (gene + exon) list, src/RNASeQC.cpp:150-152
+};
+struct LegacyTables {
+    const GeneRow *gr;                 // sorted by (contig, start)
+    const int32_t *gr_pmax;            // running max of end per contig
+    const uint32_t *gr_range;          // [n_contigs + 1]
+    const uint32_t *ex_ord;            // per exon row: rank in the combined list
+};
+
 struct DevAnnotation {
     int32_t n_ref, n_contigs, n_genes, n_listed, n_exons;
     int32_t bin_shift;
@@ -81,6 +95,7 @@ struct DevAnnotation {
     const int32_t  *bed_start, *bed_end, *bed_pmax;
     const uint32_t *bed_range;         // [n_contigs+1]
     int32_t have_bed;
+    const LegacyTables *legacy;        // device copy of the struct above (always built; read under DevParams::legacy)
 };
 
 struct DevParams {
@@ -88,6 +103,7 @@ struct DevParams {
     int32_t  chimeric_distance;
     int32_t  stranded, unpaired, exclude_chimeric, n_filter_tags;
     uint32_t dbg;      // profiling ablations (RSQC_DEBUG_MASK); 0 in every real run
+    int32_t  legacy;   // --legacy rules (rsqc_params.legacy)
 };
 
 // one record, already widened
@@ -236,6 +252,9 @@ RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &
 // ---- stage 1: the gate cascade and scalar counters, src/RNASeQC.cpp:254-342,359-360 -----
 // Pure register arithmetic on the record and its CIGAR summary.  Returns true when the record
 // reaches the feature stage; `hq` = highQuality (:330).
+// LEGACY: the LegacyMode tests of the loop body (src/RNASeQC.cpp:258,276,279,287) as a compile-time switch, so
+// that the default kernel carries none of them.
+template <bool LEGACY = false>
 RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
                           RecordCounters &out, bool &hq) {
     // Straight-line form of the cascade: `alive` stays true while the reference's loop body has not hit a
@@ -250,7 +269,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     else if (fl & RSQC_FQCFAIL) bits |= RSQC_BIT(RSQC_C_FAILED_VENDOR_QC);                 // :256
     else if (r.mapq < p.mapq_threshold) bits |= RSQC_BIT(RSQC_C_LOW_MAPPING_QUALITY);      // :257
     const bool has_ch = (r.tagbits & RSQC_TB_HAS_CH) != 0;
-    const bool supp_auto = (fl & RSQC_FSUPP) && !has_ch;                                   // :258-262
+    const bool supp_auto = !LEGACY && (fl & RSQC_FSUPP) && !has_ch;                        // :258-262
     if (supp_auto) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
     bool alive = !(supp_auto && excl);
     alive = alive && !(fl & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP));               // :263
@@ -260,16 +279,17 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     if (alive) bits |= RSQC_BIT(RSQC_C_MAPPED_READS) | (dup ? RSQC_BIT(RSQC_C_MAPPED_DUPLICATE_READS) : RSQC_BIT(RSQC_C_MAPPED_UNIQUE_READS));
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
     const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || w.ref_len == 0) ? 1u : w.ref_len);
+    if (LEGACY) alive = alive && !((uint32_t)(endpos - r.pos) > 100000u);                  // :276, LEGACY_MAX_READ_LENGTH
     out.endpos = alive ? endpos : 0;
     out.rl_eligible = alive ? 1u : 0u;                                                     // :275-278
     out.rl_span = alive ? (uint32_t)(endpos - r.pos) : 0u; out.rl_lqseq = alive ? r.l_qseq : 0;
-    const bool ch_here = alive && has_ch;                                                  // :279-283
+    const bool ch_here = !LEGACY && alive && has_ch;                                       // :279-283
     if (ch_here && read1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_TAG);
     alive = alive && !(ch_here && excl);
     const bool mate_mapped = alive && paired && !(fl & RSQC_FMUNMAP);                      // :284-292
     if (mate_mapped && read1) bits |= RSQC_BIT(RSQC_C_TOTAL_MAPPED_PAIRS);
     int32_t d = r.pos - r.mpos; if (d < 0) d = -d;
-    const bool far = mate_mapped && (!(r.tagbits & RSQC_TB_MTID_SAME) || d > p.chimeric_distance);
+    const bool far = mate_mapped && (!(r.tagbits & RSQC_TB_MTID_SAME) || d > p.chimeric_distance || (LEGACY && r.tid > 127));
     if (far && read1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
     alive = alive && !(far && excl);
     const bool has_nm = alive && (r.tagbits & RSQC_TB_HAS_NM) != 0;                        // :295-316
@@ -305,7 +325,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     CigarWalk w;
     walk_cigar(r, first, w, B);
     aligned = w.aligned;
-    return gate_cascade(a, p, r, w, out, hq);
+    return p.legacy ? gate_cascade<true>(a, p, r, w, out, hq) : gate_cascade<false>(a, p, r, w, out, hq);
 }
 
 // ---- fast path of stage 2 ------------------------------------------------------------------
@@ -685,6 +705,169 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
         }
     }
     bits |= class_bits(p, fl, f, do_exon, hq);
+    out.bits = bits;
+}
+
+
+// ---- --legacy: legacyExonAlignmentMetrics, src/Expression.cpp:129-304 --------------------------------------
+// The reference intersects the read's whole span [pos + 1, endpos] with its start-sorted feature list once
+// (:145-148) and then runs, for every GENE row of that result list, a loop over the read's blocks in which the
+// exon rows of the same result list are scanned in list order up to the first exon that contains the block
+// (:154-241).  Here the result list is never materialised: gene rows come from LegacyTables (a start-sorted
+// table with a running max of end), and "the first containing exon of gene g in list order, and whether a
+// partially overlapping exon of g precedes it" is one downward walk of the exon rows (legacy_find).  The CIGAR is
+// re-walked per gene instead of being staged, so a lane keeps no per-block state.
+struct LegacyFind { uint32_t cmin; bool partial_before, any; };
+RSQC_HD LegacyFind legacy_find(const DevAnnotation &a, const ContigInfo &ci, uint32_t g, int32_t bs, int32_t be, int32_t se) {
+    LegacyFind f = {0xFFFFFFFFu, false, false};
+    // a row of the result list starts at or before the span's end; one that intersects the block starts at or before
+    // the block's (exclusive, but compared inclusively: src/GTF.cpp:171-179) end
+    const int32_t hi = be < se ? be : se;
+    if (ci.n_bins == 0 || hi < 0) return f;
+    uint32_t b = (uint32_t)hi >> a.bin_shift;
+    if (b >= ci.n_bins) b = ci.n_bins - 1;
+    uint32_t pmin = 0xFFFFFFFFu;
+    for (uint32_t i = a.ex_binhi[ci.bin_base + b]; i > ci.ex_lo;) {
+        --i;
+        const ExonRow row = a.ex[i];
+        if (a.ex_pmax[i] < bs) break;
+        if (row.start > hi || row.end < bs) continue;
+        if ((row.gf & ROW_GENE_MASK) != g) continue;                                   // ex->gene_id == result->gene_id, :180
+        f.any = true;
+        const int32_t lo_e = row.end < be - 1 ? row.end : be - 1, hi_s = row.start > bs ? row.start : bs;
+        const int32_t pi = 1 + lo_e - hi_s;                                            // partialIntersect, src/GTF.cpp:181-186
+        if (pi == be - bs) f.cmin = i;               // walking down: the last one seen is the first in list order
+        else if (pi > 0) pmin = i;
+    }
+    f.partial_before = pmin < f.cmin;                // :191-194 is reached only before the scan stops at the first container
+    return f;
+}
+
+template <int K> struct LegacyOut { uint64_t bits; int n_hit; uint32_t hit[K]; };
+
+// `Acc` provides exon_add(row, double), cov_range(cidx, len) and gene_hit(gene, notdup, qhash) (genes beyond the K
+// returned in `out`).
+template <int K, class Acc>
+RSQC_HD void legacy_metrics(const DevAnnotation &a, const DevParams &p, const Record &r, bool hq, Acc &acc, LegacyOut<K> &out) {
+    const LegacyTables &T = *a.legacy;
+    const uint32_t fl = r.flag;
+    out.bits = 0; out.n_hit = 0;
+    const int rstrand = read_strand_of(p, fl);
+    const ContigInfo ci = a.contig[r.tid];
+    // split detection (:135-141, LEGACY_SPLIT_DISTANCE = 100) and the span
+    bool split = false; uint32_t nblocks = 0, ref_len = 0;
+    {
+        int64_t last_end = -1; int32_t start = r.pos + 1;
+        for (uint32_t i = 0; i < r.n_cigar; ++i) {
+            const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
+            if (cigar_is_block(op)) {
+                if (last_end > 0 && !split) split = ((int64_t)start - last_end) > 99;
+                last_end = (int64_t)start + (int64_t)len; ++nblocks;
+            }
+            if (cigar_is_ref(op)) { start += (int32_t)len; ref_len += len; }
+        }
+    }
+    const int32_t ss = r.pos + 1;                                                          // :145
+    const int32_t se = r.pos + (int32_t)((r.n_cigar == 0 || ref_len == 0) ? 1u : ref_len); // :146 PositionEnd(), 1-based closed
+    bool intragenic = false, plus = false, minus = false, ribosomal = false, do_exon = false, exonic = false,
+         junction = false, not_exonic = false;
+    uint32_t last_ord = 0; bool have_last = false, last_not_split = false;   // the final value of legacyNotSplit (:159) is
+                                                                             // the one of the LAST row of the result list
+    const uint32_t glo = T.gr_range[r.tid], ghi = T.gr_range[r.tid + 1];
+    uint32_t lo = glo, hi = ghi;                                             // first gene row with start > se
+    while (lo < hi) { const uint32_t m = lo + ((hi - lo) >> 1); if (T.gr[m].start <= se) lo = m + 1; else hi = m; }
+    for (uint32_t gi = lo; gi > glo;) {
+        --gi;
+        if (T.gr_pmax[gi] < ss) break;
+        const GeneRow G = T.gr[gi];
+        if (G.end < ss) continue;
+        const uint32_t g = G.gf & ROW_GENE_MASK, gfl = G.gf >> ROW_FLAG_SHIFT;
+        const int gs = (int)(gfl & RSQC_FF_STRAND_MASK);
+        if (gs == RSQC_STRAND_FORWARD) plus = true; else if (gs == RSQC_STRAND_REVERSE) minus = true;   // :163-164
+        bool not_split = false, found = false, t_intron = false, t_exon = false;
+        uint32_t last_row = 0;
+        if (rstrand == RSQC_STRAND_UNKNOWN || rstrand == gs) {                             // :167
+            int32_t start = r.pos + 1;
+            for (uint32_t i = 0; i < r.n_cigar; ++i) {
+                const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
+                if (cigar_is_block(op)) {
+                    const int32_t bs = start, be = start + (int32_t)len;
+                    intragenic = true;                                                     // :168
+                    if (bs > G.end) not_exonic = true;                                     // :170
+                    const LegacyFind f = legacy_find(a, ci, g, bs, be, se);
+                    if (f.any && (gfl & RSQC_FF_RIBOSOMAL)) ribosomal = true;              // :182
+                    found = f.cmin != 0xFFFFFFFFu; last_row = f.cmin;                      // :173,186-189
+                    if (found) t_exon = true;
+                    if (f.partial_before) t_intron = true;
+                    if (split && !not_split && !found) not_split = true;                   // :197-204
+                }
+                if (cigar_is_ref(op)) start += (int32_t)len;
+            }
+        }
+        if (!have_last || G.ord > last_ord) { have_last = true; last_ord = G.ord; last_not_split = not_split; }
+        if (found) {                                                                       // :210
+            if (hq) {
+                const bool dose = split && !not_split;
+                if (!dose) acc.exon_add(last_row, 1.0);                                    // :222-227
+                uint32_t cur = 0xFFFFFFFFu; float dsum = 0.0f;
+                int32_t start = r.pos + 1;
+                for (uint32_t i = 0; i < r.n_cigar; ++i) {
+                    const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
+                    if (cigar_is_block(op)) {
+                        const int32_t bs = start, be = start + (int32_t)len;
+                        const LegacyFind f = legacy_find(a, ci, g, bs, be, se);
+                        if (f.cmin != 0xFFFFFFFFu) {
+                            const ExonRow row = a.ex[f.cmin];
+                            acc.cov_range(row.cov + (uint32_t)(bs - row.start), len);      // baseCoverage.add + commit, :190,235
+                            if (dose) {                                                    // legacySplitDosage: float sums per exon, :201,216-219
+                                if (f.cmin != cur) { if (cur != 0xFFFFFFFFu) acc.exon_add(cur, (double)dsum); cur = f.cmin; dsum = 0.0f; }
+                                dsum += (float)len / (float)r.l_qseq;
+                            }
+                        }
+                    }
+                    if (cigar_is_ref(op)) start += (int32_t)len;
+                }
+                if (cur != 0xFFFFFFFFu) acc.exon_add(cur, (double)dsum);
+                if (out.n_hit < K) { set_put<K>(out.hit, out.n_hit, g); ++out.n_hit; }    // :228-234
+                else acc.gene_hit(g, !(fl & RSQC_FDUP), r.qhash);
+            }
+            do_exon = true;                                                                // :237
+        }
+        if (t_intron && t_exon) junction = true;                                           // :239
+        if (t_exon) exonic = true;                                                         // :240
+    }
+    // the last row of the result list may be an exon row: legacyNotSplit was reset for it (:159) and nothing set it
+    if (ci.n_bins != 0 && se >= 0) {
+        uint32_t b = (uint32_t)se >> a.bin_shift;
+        if (b >= ci.n_bins) b = ci.n_bins - 1;
+        for (uint32_t i = a.ex_binhi[ci.bin_base + b]; i > ci.ex_lo;) {
+            --i;
+            if (a.ex_pmax[i] < ss) break;
+            const ExonRow row = a.ex[i];
+            if (row.start > se || row.end < ss) continue;
+            if (!have_last || T.ex_ord[i] > last_ord) last_not_split = false;
+            break;                                   // rows further down rank lower
+        }
+    }
+    const bool outside = not_exonic || junction || !exonic;                                // :246
+    const bool as_exonic = !outside && (do_exon || intragenic);                            // :264,276
+    const bool intronic = outside && intragenic, intergenic = outside && !intragenic;
+    uint64_t bits = 0;
+    bits |= intronic ? RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
+    bits |= (intronic && hq) ? RSQC_BIT(RSQC_C_HQ_INTRONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS) : 0ull;
+    bits |= intergenic ? RSQC_BIT(RSQC_C_INTERGENIC_READS) : 0ull;
+    bits |= (intergenic && hq) ? RSQC_BIT(RSQC_C_HQ_INTERGENIC_READS) : 0ull;
+    bits |= as_exonic ? RSQC_BIT(RSQC_C_EXONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
+    bits |= (as_exonic && hq) ? RSQC_BIT(RSQC_C_HQ_EXONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS) : 0ull;
+    bits |= (!outside && do_exon && split && !last_not_split) ? RSQC_BIT(RSQC_C_SPLIT_READS) : 0ull;   // :274
+    bits |= ribosomal ? RSQC_BIT(RSQC_C_RRNA_READS) : 0ull;                                // :288
+    const bool one_strand = (minus != plus) && (p.unpaired || (fl & RSQC_FPAIRED));        // :290-302
+    const bool sense = (fl & RSQC_FREVERSE) ? minus : plus;
+    const bool end1 = p.unpaired || (fl & RSQC_FREAD1);
+    const uint64_t sbit = end1 ? (sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE))
+                               : (sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE));
+    bits |= one_strand ? sbit : 0ull;
+    (void)nblocks;
     out.bits = bits;
 }
 

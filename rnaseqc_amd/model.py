@@ -45,6 +45,8 @@ class Annotation:
     gene_exon_off: np.ndarray
     gene_exon_row: np.ndarray
     coding_length: np.ndarray = field(default=None)   # geneCodingLengths by gene id
+    gene_row_order: np.ndarray = field(default=None)  # optional GTF positions of the rows (legacy rules only)
+    exon_row_order: np.ndarray = field(default=None)
 
     @property
     def n_genes_listed(self) -> int:
@@ -146,6 +148,8 @@ class Annotation:
             exon_row_end=er[:, 2].astype(np.int32), exon_row_flags=er[:, 3].astype(np.uint8),
             exon_row_id=er[:, 4].astype(np.uint32), exon_row_gene=er[:, 5].astype(np.uint32),
             gene_is_globin=globin, gene_exon_off=off, gene_exon_row=ge_row, coding_length=coding,
+            gene_row_order=np.array([t[2] for t in g_rows], dtype=np.uint32),
+            exon_row_order=np.array([t[2] for t in e_rows], dtype=np.uint32),
         )
 
     # ------------------------------------------------------------------ ABI
@@ -159,6 +163,11 @@ class Annotation:
             a = np.ascontiguousarray(getattr(self, f))
             setattr(self, f, a)
             setattr(s, f, abi.ptr(a))
+        for f in ("gene_row_order", "exon_row_order"):
+            if getattr(self, f) is not None:
+                a = np.ascontiguousarray(getattr(self, f), dtype=np.uint32)
+                setattr(self, f, a)
+                setattr(s, f, abi.ptr(a))
         return s
 
     def to_gtf_lines(self):

@@ -62,7 +62,13 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     if (hx.ex_pmax.empty()) hx.ex_pmax.push_back(0);
     d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.ex_pmax = hx.ex_pmax.data();
     d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
-    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u};
+    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u,
+                 p->legacy ? 1 : 0};
+    if (hx.gr_rows.empty()) hx.gr_rows.push_back(GeneRow{0, 0, 0, 0});
+    if (hx.g_pmax.empty()) hx.g_pmax.push_back(0);
+    if (hx.ex_ord.empty()) hx.ex_ord.push_back(0);
+    const LegacyTables lt{hx.gr_rows.data(), hx.g_pmax.data(), hx.g_range.data(), hx.ex_ord.data()};
+    d.legacy = &lt;
     std::vector<uint64_t> reads((size_t)a->n_genes, 0), unique((size_t)a->n_genes, 0);
     std::vector<double> exon_rows((size_t)a->n_exons, 0.0);
     std::vector<uint32_t> cov((size_t)hx.cov_entries + 1, 0);
@@ -85,7 +91,12 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
         const bool go = gate_cascade(d, dp, r, rc2, hq, aligned, B);
         uint64_t bits = rc2.bits;
         if (rc2.error) return rc2.error;
-        if (go) {
+        if (go && dp.legacy) {
+            LegacyOut<MID_SET> lo;
+            legacy_metrics<MID_SET>(d, dp, r, hq, acc, lo);
+            bits |= lo.bits;
+            for (int k = 0; k < lo.n_hit; ++k) acc.gene_hit(lo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
+        } else if (go) {
             bool over = false;
             FastOut fo;
             exon_metrics_fast(d, dp, d.contig[r.tid], r.flag, B, hq, aligned, fo, over);

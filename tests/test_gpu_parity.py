@@ -295,3 +295,38 @@ def test_single_pair_golden_reconstruction_gpu(oracle_lib):
             assert c[k] == int(v), (k, c[k], v)
     assert list(got.gene_reads) == [2] and list(got.gene_fragments) == [1] and got.read_length == 76
     assert_results_match(got, oracle_lib.run_oracle(p, ann, [batch]))
+
+
+# ---- --legacy counting rules (src/Expression.cpp:129-304, src/RNASeQC.cpp:258-287) -------------------------------
+@pytest.mark.parametrize("kw", [dict(), dict(stranded=abi.STRAND_REVERSE), dict(unpaired=1, n_filter_tags=1, exclude_chimeric=1),
+                                dict(coverage_mask=100, stranded=abi.STRAND_FORWARD)])
+def test_legacy_rules_vs_oracle(oracle_lib, kw):
+    ann, batch = small_inputs(dup_frac=0.1, chimeric_tag_frac=0.01, filter_tag_frac=0.02)
+    p = abi.default_params(legacy=1, mapq_threshold=4, **kw)
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert int(want.counters[abi.COUNTER_INDEX["Split Reads"]]) > 100 and int(want.gene_reads.sum()) > 1000
+    assert_results_match(engine.run_engine(p, ann, [batch]), want)
+
+
+def test_legacy_hand_derived_and_hostile_cases(oracle_lib):
+    from tests import test_legacy_rules as tl
+    ann = cases.quirk_annotation()
+    got = engine.run_engine(tl._legacy_params(), ann, [Batch.from_records(tl._records())])
+    tl._check(got, ann)
+    for seed in range(4):
+        ann, batch = tl.hostile_case(seed)
+        for kw in (dict(), dict(stranded=abi.STRAND_FORWARD)):
+            p = tl._legacy_params(coverage_mask=20, **kw)
+            assert_results_match(engine.run_engine(p, ann, [batch]), oracle_lib.run_oracle(p, ann, [batch]))
+
+
+def test_legacy_deep_coverage_and_batches(oracle_lib):
+    # the same records in one batch and in three: coverage / bias of the end-of-file stage under the legacy commits
+    ann = synth.make_annotation(seed=8, contigs=[("chrA", 400_000, 40)])
+    batch = synth.make_reads(ann, 60000, seed=9, frac=(0.97, 0.01, 0.01, 0.01), expr_sigma=1.0, contig_lengths=np.array([400_000]))
+    p = abi.default_params(legacy=1, mapq_threshold=4)
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert_results_match(engine.run_engine(p, ann, [batch]), want)
+    n = batch.n
+    parts = [batch.slice(0, n // 3), batch.slice(n // 3, 2 * n // 3), batch.slice(2 * n // 3, n)]
+    assert_results_match(engine.run_engine(p, ann, parts), want)

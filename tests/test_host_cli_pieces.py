@@ -21,6 +21,8 @@ def host():
     lib = C.CDLL(SO)
     lib.host_annotation_load.restype = C.c_void_p
     lib.host_annotation_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+    lib.host_annotation_load_ex.restype = C.c_void_p
+    lib.host_annotation_load_ex.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.host_annotation_struct.restype = C.POINTER(abi.AnnotationStruct); lib.host_annotation_struct.argtypes = [C.c_void_p]
     lib.host_annotation_bed.restype = C.POINTER(abi.BedStruct); lib.host_annotation_bed.argtypes = [C.c_void_p]
     for f in ("host_annotation_gene_name", "host_annotation_gene_id", "host_annotation_exon_id"):
@@ -83,6 +85,38 @@ def test_gtf_ingest_matches_python_mirror(host, tmp_path):
         np.testing.assert_array_equal(_arr(getattr(s, f), n, dt), getattr(py, f), err_msg=f)
     assert host.host_annotation_gene_name(h, 5).decode() == ann.gene_names[5]
     assert host.host_annotation_coding_length(h, 7) == int(ann.coding_length[7])
+    host.host_annotation_free(h)
+
+
+def test_gtf_ingest_legacy_leaves_out_one_base_features(host, tmp_path):
+    # src/RNASeQC.cpp:129-135: under --legacy a feature with end == start is not added to the feature lists (and a
+    # 1-base exon takes 1 off its gene's coding length), but operator>> has already entered it in geneList / exonList
+    lines = ['c1\tx\tgene\t100\t900\t.\t+\t.\tgene_id "A"; gene_name "A";',
+             'c1\tx\texon\t100\t300\t.\t+\t.\tgene_id "A"; exon_id "A1";',
+             'c1\tx\texon\t500\t500\t.\t+\t.\tgene_id "A"; exon_id "A2";',          # 1-base exon
+             'c1\tx\texon\t700\t900\t.\t+\t.\tgene_id "A"; exon_id "A3";',
+             'c1\tx\tgene\t950\t950\t.\t-\t.\tgene_id "B"; gene_name "B";',          # 1-base gene
+             'c1\tx\texon\t950\t950\t.\t-\t.\tgene_id "B"; exon_id "B1";']
+    gtf = str(tmp_path / "l.gtf")
+    open(gtf, "w").write("\n".join(lines) + "\n")
+    names = (C.c_char_p * 1)(b"c1")
+    err = C.c_int()
+    h = host.host_annotation_load_ex(gtf.encode(), b"", names, 1, 1, C.byref(err))
+    assert err.value == 0
+    s = host.host_annotation_struct(h).contents
+    assert (s.n_ref, s.n_contigs, s.n_genes_listed, s.n_genes, s.n_exons) == (1, 2, 2, 3, 4)      # + the parking contig and gene
+    assert list(_arr(s.gene_row_contig, 2, np.int32)) == [0, 1] and list(_arr(s.gene_row_id, 2, np.uint32)) == [0, 1]
+    assert list(_arr(s.exon_row_contig, 4, np.int32)) == [0, 0, 1, 1]
+    assert list(_arr(s.exon_row_id, 4, np.uint32)) == [0, 2, 1, 3]                                 # exonList order kept as ids
+    assert list(_arr(s.exon_row_gene, 4, np.uint32)) == [0, 0, 2, 2]
+    assert list(_arr(s.gene_exon_off, 4, np.uint32)) == [0, 2, 2, 4]
+    assert list(_arr(s.gene_row_order, 2, np.uint32)) == [0, 4] and list(_arr(s.exon_row_order, 4, np.uint32)) == [1, 3, 2, 5]
+    assert host.host_annotation_coding_length(h, 0) == 201 + 1 + 201 - 1 and host.host_annotation_coding_length(h, 1) == 0
+    host.host_annotation_free(h)
+    # without --legacy the same file keeps every row
+    h = host.host_annotation_load_ex(gtf.encode(), b"", names, 1, 0, C.byref(err))
+    s = host.host_annotation_struct(h).contents
+    assert (s.n_contigs, s.n_genes, s.n_exons) == (1, 2, 4) and host.host_annotation_coding_length(h, 0) == 403
     host.host_annotation_free(h)
 
 

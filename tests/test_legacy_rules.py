@@ -1,0 +1,197 @@
+"""--legacy counting rules (legacyExonAlignmentMetrics, src/Expression.cpp:129-304, and the LegacyMode tests of
+src/RNASeQC.cpp:258-287): expectations derived BY HAND from the reference source for a small input, then the
+oracle's literal restatement against the product's per-record code (compiled for the host) on randomized
+annotations that are hostile to the index-based formulation (overlapping exons, nested genes, shared starts,
+exon lines that precede their gene line)."""
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, synth
+from rnaseqc_amd.model import Annotation, Batch
+from tests import cases, hostemu
+
+M, I, D, N, S = abi.CIG_M, abi.CIG_I, abi.CIG_D, abi.CIG_N, abi.CIG_S
+
+
+def _legacy_params(**kw):
+    kw.setdefault("mapq_threshold", 4)            # src/RNASeQC.cpp:90
+    return abi.default_params(legacy=1, **kw)
+
+
+def _records():
+    def rec(q, pos, cigar, flag=99, tid=0, **kw):
+        return dict(qname=q, tid=tid, pos=pos, cigar=cigar, flag=flag, mapq=255, nm=0, mpos=pos, mtid=tid, **kw)
+    return [
+        rec("e1", 1049, [(M, 100)]),                         # inside GA_1
+        rec("s1", 1150, [(M, 50), (N, 800), (M, 50)]),       # GA_1 -> GA_2, gap 850 > 99: split, dosage 0.5 + 0.5
+        rec("s2", 1150, [(M, 50), (N, 300), (M, 50)]),       # second block intronic: legacyNotSplit, nothing counted, still "Exonic"
+        rec("j1", 1180, [(M, 50)]),                          # hangs over the end of GA_1: no containing exon -> Intronic
+        rec("t1", 4549, [(M, 100)]),                         # GA_3 (+) and GB_1 (-): both genes counted, no sense call
+        rec("n1", 10449, [(M, 50), (N, 100), (M, 50)]),      # second block starts past the end of GR: legacyNotExonic -> Intronic, rRNA
+        rec("x2", 10460, [(M, 40)], flag=99 | 0x800),        # supplementary: never chimeric under --legacy (:258)
+        rec("c1", 10470, [(M, 30)], ch=True),                # ch tag ignored under --legacy (:279)
+        rec("L1", 12000, [(M, 50), (N, 100001), (M, 50)]),   # span 100101 > LEGACY_MAX_READ_LENGTH: dropped after "Mapped Reads" (:276)
+    ]
+
+
+def _expected():
+    c = {n: 0 for n in abi.COUNTER_NAMES}
+    c["Total Alignments"] = 9
+    c["Supplementary Alignments"] = 1
+    c["Unique Mapping, Vendor QC Passed Reads"] = 8          # all but x2
+    c["Mapped Reads"] = 8
+    c["Mapped Unique Reads"] = 8
+    c["Total Mapped Pairs"] = 7                              # L1 left the loop before :284
+    c["End 1 Mapped Reads"] = 7
+    c["Unique Fragments"] = 7
+    c["End 1 Bases"] = 100 + 100 + 100 + 50 + 100 + 100 + 30
+    c["Total Bases"] = c["End 1 Bases"]
+    c["High Quality Reads"] = 7
+    c["Reads used for Intron/Exon counts"] = 7
+    c["Alignment Blocks"] = 1 + 2 + 2 + 1 + 1 + 2 + 1
+    # e1, s1, t1, c1 (inside GR_1) exonic; s2 falls back to exonic (:276-287); j1, n1 intronic
+    c["Exonic Reads"] = c["HQ Exonic Reads"] = 5
+    c["Intronic Reads"] = c["HQ Intronic Reads"] = 2
+    c["Intragenic Reads"] = c["HQ Intragenic Reads"] = 7
+    c["Split Reads"] = 1                                     # s1 only (s2: legacyNotSplit; n1: not in the exonic branch)
+    c["rRNA Reads"] = 2                                      # n1, c1 (GR is rRNA)
+    c["End 1 Sense"] = 6                                     # forward read1 on + genes: e1 s1 s2 j1 n1 c1; t1 sees both strands
+    genes = {"GA": 3, "GB": 1, "GR": 1, "GH": 0, "GC": 0}    # GA: e1 s1 t1; GB: t1; GR: c1
+    exons = {"GA_1": 1.0 + 0.5, "GA_2": 0.5, "GA_3": 1.0, "GB_1": 1.0, "GR_1": 1.0}
+    return c, genes, exons
+
+
+def _check(r, ann):
+    c, genes, exons = _expected()
+    for n, v in c.items():
+        assert int(r.counters[abi.COUNTER_INDEX[n]]) == v, n
+    for g, v in genes.items():
+        assert int(r.gene_reads[ann.gene_ids.index(g)]) == v, g
+        assert int(r.gene_fragments[ann.gene_ids.index(g)]) == v, g
+    for i, e in enumerate(ann.exon_ids):
+        assert r.exon_reads[i] == pytest.approx(exons.get(e, 0.0), abs=1e-7), e
+
+
+def test_hand_derived_legacy_case_oracle(oracle_lib):
+    ann = cases.quirk_annotation()
+    _check(oracle_lib.run_oracle(_legacy_params(), ann, [Batch.from_records(_records())]), ann)
+
+
+def test_hand_derived_legacy_case_core():
+    ann = cases.quirk_annotation()
+    _check(hostemu.run(_legacy_params(), ann, Batch.from_records(_records())), ann)
+
+
+def test_contig_beyond_127_is_chimeric(oracle_lib):
+    # src/RNASeQC.cpp:287: `|| (LegacyMode.Get() && alignment.ChrID() > 127)`
+    names = ["c%d" % i for i in range(130)]
+    rows = [dict(contig="c129", type="gene", start=100, end=900, strand="+", gene_id="G"),
+            dict(contig="c129", type="exon", start=100, end=900, strand="+", gene_id="G", exon_id="E")]
+    ann = Annotation.from_rows(names, rows)
+    recs = [dict(qname="a", tid=127, pos=10, cigar=[(M, 50)], flag=99, mapq=255, nm=0, mpos=60, mtid=127),
+            dict(qname="b", tid=129, pos=200, cigar=[(M, 50)], flag=99, mapq=255, nm=0, mpos=260, mtid=129)]
+    b = Batch.from_records(recs)
+    for p, want in ((_legacy_params(), 1), (abi.default_params(), 0), (_legacy_params(exclude_chimeric=1), 1)):
+        r = oracle_lib.run_oracle(p, ann, [b]); o = hostemu.run(p, ann, b)
+        for x in (r, o):
+            assert int(x.counters[abi.COUNTER_INDEX["Chimeric Fragments_auto"]]) == want
+            assert int(x.gene_reads[0]) == (0 if p.exclude_chimeric else 1)
+
+
+def _compare(o, r):
+    for i, n in enumerate(abi.COUNTER_NAMES):
+        assert int(o.counters[i]) == int(r.counters[i]), n
+    np.testing.assert_array_equal(o.gene_reads, r.gene_reads)
+    np.testing.assert_array_equal(o.gene_unique, r.gene_unique)
+    np.testing.assert_array_equal(o.gene_fragments, r.gene_fragments)
+    np.testing.assert_allclose(o.exon_reads, r.exon_reads, rtol=0, atol=1e-6)
+    assert o.read_length == r.read_length
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stranded=abi.STRAND_REVERSE), dict(stranded=abi.STRAND_FORWARD, unpaired=1),
+                                dict(unpaired=1, n_filter_tags=1, exclude_chimeric=1), dict(base_mismatch=1, chimeric_distance=100)])
+def test_synthetic_vs_oracle(oracle_lib, kw):
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 3_000_000, 300), ("chrB", 1_500_000, 150), ("chrC", 400_000, 0)])
+    batch = synth.make_reads(ann, 20000, seed=4, dup_frac=0.1, chimeric_tag_frac=0.01, filter_tag_frac=0.02,
+                             contig_lengths=np.array([3_000_000, 1_500_000, 400_000]))
+    p = _legacy_params(**kw)
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    _compare(hostemu.run(p, ann, batch), r)
+    assert r.gene_reads.sum() > 1000 and int(r.counters[abi.COUNTER_INDEX["Split Reads"]]) > 100
+
+
+def hostile_case(seed, n_genes=40, n_reads=3000, span=6000, shuffle_lines=True):
+    """Genes and exons on a short contig: overlapping and nested genes on both strands, exons that overlap each other
+    or share starts with other rows, 1-base exons; reads with 1-4 blocks whose gaps straddle
+    the split distance, dropped on and around the features."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for g in range(n_genes):
+        gs = int(rng.integers(1, span - 600)); ge = gs + int(rng.integers(1, 900))
+        strand = "+-."[int(rng.integers(0, 3))]
+        ttype = "rRNA" if rng.random() < 0.1 else "protein_coding"
+        block = [dict(contig="c", type="gene", start=gs, end=ge, strand=strand, gene_id="G%d" % g, transcript_type=ttype)]
+        for e in range(int(rng.integers(0, 5))):
+            # (exons stay inside their gene row: one that sticks out keeps matching reads after the reference has
+            #  retired the gene, an input on which the reference itself only prints "Gene encountered after computing
+            #  coverage" -- outside the parity contract)
+            es = int(rng.integers(gs, ge + 1)) if rng.random() < 0.8 else gs
+            ee = min(ge, es + int(rng.integers(0, 260)))
+            block.append(dict(contig="c", type="exon", start=es, end=ee, strand=strand, gene_id="G%d" % g,
+                              exon_id="G%d_e%d" % (g, e), transcript_type=ttype))
+        if shuffle_lines and rng.random() < 0.3:
+            block = [block[i] for i in rng.permutation(len(block))]      # exon lines before their gene line
+        rows += block
+    ann = Annotation.from_rows(["c"], rows)
+    recs = []
+    starts = np.sort(rng.integers(0, span, n_reads))
+    for i, pos in enumerate(starts):
+        cig = []
+        for b in range(int(rng.integers(1, 5))):
+            if b:
+                cig.append((N if rng.random() < 0.7 else D, int(rng.choice([1, 50, 98, 99, 100, 101, 150, 400]))))
+            if rng.random() < 0.15:
+                cig.append((I, int(rng.integers(1, 4))))
+            cig.append((M, int(rng.integers(1, 120))))
+        if rng.random() < 0.2:
+            cig = [(S, 5)] + cig
+        flag = 0x1 | (0x2 if rng.random() < 0.9 else 0) | (0x10 if rng.random() < 0.5 else 0) | (0x40 if rng.random() < 0.5 else 0x80)
+        if rng.random() < 0.05:
+            flag |= 0x400
+        recs.append(dict(qname="q%d" % int(rng.integers(0, n_reads // 2)), tid=0, pos=int(pos), cigar=cig, flag=flag,
+                         mapq=int(rng.choice([0, 3, 4, 60, 255])), nm=int(rng.integers(0, 9)) if rng.random() < 0.9 else None,
+                         mpos=int(pos) + int(rng.integers(0, 300)), mtid=0))
+    return ann, Batch.from_records(recs)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("legacy", [1, 0])
+def test_hostile_annotations_vs_oracle(oracle_lib, seed, legacy):
+    ann, batch = hostile_case(seed)
+    for kw in (dict(), dict(stranded=abi.STRAND_FORWARD), dict(stranded=abi.STRAND_REVERSE, unpaired=1)):
+        p = _legacy_params(**kw) if legacy else abi.default_params(mapq_threshold=4, **kw)
+        r = oracle_lib.run_oracle(p, ann, [batch])
+        _compare(hostemu.run(p, ann, batch), r)
+    assert r.gene_reads.sum() > 50
+
+
+def test_row_order_decides_split_reads(oracle_lib):
+    # legacyNotSplit is reset at every row of the read's result list (:159), so "Split Reads" (:274) sees the value left
+    # by the LAST row.  The read is counted to gene H (both blocks inside H_1); in gene G its second block is intronic
+    # (-> legacyNotSplit).  G's rows come last in the list; whether the list ends with G's gene row (flag stays set) or
+    # with G's exon row (flag reset) depends only on the GTF order of two lines with the same start.
+    def build(exon_first):
+        g = dict(contig="c", type="gene", start=500, end=2000, strand="+", gene_id="G")
+        e = dict(contig="c", type="exon", start=500, end=700, strand="+", gene_id="G", exon_id="G_1")
+        rows = [dict(contig="c", type="gene", start=100, end=3000, strand="+", gene_id="H"),
+                dict(contig="c", type="exon", start=100, end=3000, strand="+", gene_id="H", exon_id="H_1")]
+        rows += [e, g] if exon_first else [g, e]
+        return Annotation.from_rows(["c"], rows)
+    recs = [dict(qname="r", tid=0, pos=599, cigar=[(M, 50), (N, 300), (M, 50)], flag=99, mapq=255, nm=0, mpos=599, mtid=0)]
+    b = Batch.from_records(recs)
+    for exon_first, want in ((False, 1), (True, 0)):
+        ann = build(exon_first)
+        for x in (oracle_lib.run_oracle(_legacy_params(), ann, [b]), hostemu.run(_legacy_params(), ann, b)):
+            assert int(x.counters[abi.COUNTER_INDEX["Split Reads"]]) == want
+            assert int(x.counters[abi.COUNTER_INDEX["Exonic Reads"]]) == 1
+            assert int(x.gene_reads[ann.gene_ids.index("H")]) == 1 and int(x.gene_reads[ann.gene_ids.index("G")]) == 0
