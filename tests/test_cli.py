@@ -63,8 +63,9 @@ def _compare_tables(a, b, skip, tol=1e-6):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_bed", [False, True])
-def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, with_bed):
+@pytest.mark.parametrize("mode", ["plain", "bed", "legacy"])
+def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, mode):
+    with_bed, legacy = mode == "bed", mode == "legacy"
     contigs = [("chrA", 900_000, 70), ("chrB", 500_000, 40)]
     ann = synth.make_annotation(seed=41, contigs=contigs)
     batch = synth.make_reads(ann, 40000, seed=42, keep_qnames=True, dup_frac=0.1, frac=(0.85, 0.06, 0.05, 0.04), expr_sigma=1.2,
@@ -77,14 +78,18 @@ def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, 
     if with_bed:
         bamio.write_bed(bedp, ann, bed)
         args += ["--bed", bedp]
+    if legacy:
+        args.append("--legacy")                                  # counting rules + the -q 4 default (src/RNASeQC.cpp:90)
     env = dict(os.environ, RSQC_BATCH="30000")                   # several batches
     p = subprocess.run([cli, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()
     assert "Average Reads/Sec" in p.stdout.decode()
     # expected files: the same C++ report writer fed with the ORACLE's results on the same inputs
-    want = oracle_lib.run_oracle(abi.default_params(), ann, [batch], bed=bed)
+    want = oracle_lib.run_oracle(abi.default_params(**(dict(legacy=1, mapq_threshold=4) if legacy else {})), ann, [batch], bed=bed)
     h, err = load_annotation(host, gtf, [c[0] for c in contigs], bedp if with_bed else None)
     assert err == 0
+    if legacy:
+        assert want.counter("Split Reads") > 100 and "Split Reads\t" in open(os.path.join(str(tmp_path / "cli"), "s.bam.metrics.tsv")).read()
     rs, keep = _results_struct(want)
     exp = str(tmp_path / "exp"); os.makedirs(exp)
     visit = (C.c_int * 2)(0, 1)
