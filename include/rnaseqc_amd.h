@@ -13,6 +13,8 @@
  *     exonsForGene/exonLengths  (src/RNASeQC.cpp:108-156,
  *     src/GTF.cpp:30-131)
  *   BED load (src/RNASeQC.cpp:172-187, src/BED.cpp:18)  rsqc_set_bed()
+ *   Fasta::open / getSeq (src/Fasta.cpp:77-140,          rsqc_set_reference()
+ *     src/RNASeQC.cpp:118-121)
  *   while (bam.next(alignment)) { gate cascade;         rsqc_submit() /
  *     extractBlocks; trimFeatures;                      rsqc_submit_resident()
  *     exonAlignmentMetrics; fragmentSizeMetrics }       (one call per SoA batch
@@ -238,6 +240,18 @@ typedef struct rsqc_bed {
     const int32_t *end;
 } rsqc_bed;
 
+/* ---- reference sequence for the GC statistics of --fasta (src/Fasta.cpp, bioio.hpp): what the reference reads
+ * through its .fai index, handed over as plain per-contig base strings (FASTA text without line ends, any case;
+ * G/g/C/c count, everything else does not -- gc(), src/Fasta.cpp:67-74).  Contigs the FASTA index does not name
+ * are simply absent (Fasta::hasContig).  The library keeps one bit per base in HBM.                             */
+typedef struct rsqc_reference {
+    int32_t n;                         /* contigs named by the FASTA index     */
+    const int32_t  *contig;            /* [n] boundary contig id               */
+    const uint64_t *length;            /* [n] bases                            */
+    const uint8_t *const *sequence;    /* [n] `length[i]` ASCII bases each     */
+} rsqc_reference;
+#define RSQC_GC_BINS 100               /* unsigned long gcBins[100], src/RNASeQC.cpp:106 */
+
 /* ---- one batch of alignment records, file order ----------------------------
  * 32 bytes per record + 4 bytes per CIGAR op, stored as two
  * arrays of 16-byte half-records so that a wavefront reads each with one
@@ -322,6 +336,15 @@ typedef struct rsqc_results {
     const int64_t  *fragment_size;
     const uint64_t *fragment_count;
     uint32_t fragment_samples_remaining;
+
+    /* --fasta (valid when have_reference != 0): fragment GC histogram gcBins (src/RNASeQC.cpp:366-369, bin =
+       unsigned(gc * 100)); a fragment of 100 % GC indexes past the reference's array (undefined there) and is
+       counted in gc_out_of_range instead.  exon_gc = gc() of the exon's sequence as fetched at
+       src/Metrics.cpp:301 (-1 when the FASTA lacks the contig); meaningful where exon_cv_valid != 0.              */
+    int32_t  have_reference;
+    const uint64_t *gc_bins;           /* [RSQC_GC_BINS]                       */
+    uint64_t gc_out_of_range;
+    const double   *exon_gc;           /* [n_exons], exonList order            */
 } rsqc_results;
 
 /* ---- timing of the device work (HIP events on the context's own stream) --- */
@@ -347,6 +370,9 @@ RSQC_API void rsqc_destroy(rsqc_ctx *ctx);
 RSQC_API int rsqc_set_annotation(rsqc_ctx *ctx, const rsqc_annotation *ann,
                         const uint8_t *owned_contig);
 RSQC_API int rsqc_set_bed(rsqc_ctx *ctx, const rsqc_bed *bed);
+/* --fasta: after rsqc_set_annotation.  Copies the bases to the device, packs them to one G/C bit per base and
+ * computes the per-exon GC values; the caller's strings are not referenced afterwards.                          */
+RSQC_API int rsqc_set_reference(rsqc_ctx *ctx, const rsqc_reference *ref);
 
 /* Asynchronous: copies the batch H2D on the context's stream and launches the
  * per-read kernels; returns without waiting for either.  The batch memory must

@@ -33,6 +33,7 @@ def lib():
         _lib.oracle_create.argtypes = [C.POINTER(abi.Params), C.POINTER(C.c_void_p)]
         _lib.oracle_set_annotation.argtypes = [C.c_void_p, C.POINTER(abi.AnnotationStruct), C.c_void_p]
         _lib.oracle_set_bed.argtypes = [C.c_void_p, C.POINTER(abi.BedStruct)]
+        _lib.oracle_set_reference.argtypes = [C.c_void_p, C.POINTER(abi.ReferenceStruct)]
         _lib.oracle_submit.argtypes = [C.c_void_p, C.POINTER(abi.BatchStruct)]
         _lib.oracle_finalize.argtypes = [C.c_void_p, C.POINTER(abi.ResultsStruct)]
         _lib.oracle_destroy.argtypes = [C.c_void_p]
@@ -78,6 +79,11 @@ class Oracle:
         self._keep += [bed, s]
         self._check(self._l.oracle_set_bed(self._h, C.byref(s)))
 
+    def set_reference(self, ref):
+        s = ref.to_struct()
+        self._keep += [ref, s]
+        self._check(self._l.oracle_set_reference(self._h, C.byref(s)))
+
     def submit(self, batch):
         s = batch.to_struct()
         self._check(self._l.oracle_submit(self._h, C.byref(s)))
@@ -104,11 +110,13 @@ class Oracle:
             pass
 
 
-def run_oracle(params, ann, batches, bed=None, owned=None) -> abi.Results:
+def run_oracle(params, ann, batches, bed=None, owned=None, reference=None) -> abi.Results:
     o = Oracle(params)
     o.set_annotation(ann, owned)
     if bed is not None:
         o.set_bed(bed)
+    if reference is not None:
+        o.set_reference(reference)
     for b in batches:
         o.submit(b)
     r = o.finalize()

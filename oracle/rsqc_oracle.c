@@ -2,7 +2,7 @@
  * rsqc_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * A single-threaded CPU restatement, in plain C, of the per-read hot path of
- * getzlab/rnaseqc 2.4.3 (default and --legacy rules, no --fasta).  It deliberately keeps the
+ * getzlab/rnaseqc 2.4.3 (default and --legacy rules, --fasta GC statistics).  It deliberately keeps the
  * reference's *streaming* algorithm -- one start-sorted feature list per
  * contig, destructively front-trimmed as the coordinate-sorted input advances,
  * linearly scanned per CIGAR block -- whereas the HIP product queries a static
@@ -85,6 +85,12 @@ typedef struct oracle_ctx {
     uint32_t frag_remaining;
     pending_t *pend; size_t pend_cap, pend_n;
     int64_t *fs_size; uint64_t *fs_count; size_t fs_n, fs_cap;
+    /* --fasta */
+    int have_ref;
+    uint8_t **ref_seq; uint64_t *ref_len;     /* [n_contigs], NULL = the FASTA index lacks the contig */
+    pending_t *gcp; size_t gcp_cap, gcp_n;    /* gcContentFragmentTracker, src/RNASeQC.cpp:169 */
+    uint64_t gc_bins[RSQC_GC_BINS]; uint64_t gc_oob;
+    double *exon_gc;                          /* by exon id */
     /* streaming state */
     int32_t current_contig;   /* current_chrom (src/RNASeQC.cpp:210), -1 = none */
     int32_t read_length;      /* readLength (src/RNASeQC.cpp:205)             */
@@ -216,6 +222,28 @@ ORACLE_API void oracle_statistics(double *d, uint64_t n, double out[4]) {
     out[0] = avg; out[1] = median; out[2] = sd; out[3] = mad;
 }
 
+/* Fasta::getSeq(contig, start, end) for 0-based half-open [start, end), src/Fasta.cpp:104-140: whole 1e6-base pages
+ * are fetched with bioio::read_fasta_contig (bioio.hpp:298-331, which clips a page at the contig's length) and the
+ * requested range is cut out with substr -- i.e. the range clipped at the contig end.  Ranges that start before 0 or
+ * at/after the contig end leave the reference in error paths (page of another contig / std::out_of_range) and are not
+ * defined here: *len = 0.                                                                                            */
+static const uint8_t *get_seq(const oracle_ctx *c, int contig, int64_t start, int64_t end, size_t *len) {
+    *len = 0;
+    if (!c->ref_seq[contig] || start < 0 || (uint64_t)start >= c->ref_len[contig] || end <= start) return NULL;
+    if ((uint64_t)end > c->ref_len[contig]) end = (int64_t)c->ref_len[contig];
+    *len = (size_t)(end - start);
+    return c->ref_seq[contig] + start;
+}
+/* gc(), src/Fasta.cpp:67-74: adds 1.0/size once per G/g/C/c base, in sequence order */
+static double gc_content(const uint8_t *seq, size_t len) {
+    if (len == 0) return -1;
+    double content = 0.0, size = (double)len;
+    for (size_t i = 0; i < len; ++i)
+        if (seq[i] == 'G' || seq[i] == 'g' || seq[i] == 'C' || seq[i] == 'c') content += 1.0 / size;
+    return content;
+}
+
+
 /* ---------------------------------------------------- coverage and bias */
 
 /* BiasCounter::computeBias, src/Metrics.cpp:160-235.  Mutates cov/len (the
@@ -320,6 +348,12 @@ static int gene_exit(oracle_ctx *c, const feat_t *g, int contig) {
             sd /= mean;
             if (!(isnan(sd) || isinf(sd))) {
                 c->exon_cv[c->ex_id[row]] = sd; c->exon_cv_valid[c->ex_id[row]] = 1;
+                if (c->have_ref) {                                          /* :299-303: getSeq(chr, start, start + length) with the
+                                                                               1-BASED start used as a 0-based offset */
+                    size_t slen = 0; const uint8_t *sq = NULL;
+                    if (c->ref_seq[contig]) sq = get_seq(c, contig, c->ex_start[row], (int64_t)c->ex_start[row] + (int64_t)elen, &slen);
+                    c->exon_gc[c->ex_id[row]] = c->ref_seq[contig] ? gc_content(sq, slen) : -1.0;
+                }
             }
         }
         memcpy(gc + glen, ec, elen * sizeof(uint64_t));
@@ -484,12 +518,59 @@ static void fragment_size(oracle_ctx *c, const rec_t *r, const block_t *blocks, 
     }
 }
 
+
+/* ------------------------------------------------------------- --fasta */
+
+/* The GC branch of exonAlignmentMetrics, src/Expression.cpp:459-477, reached with `exon_row` = the single element of
+ * alignedExons.  Returns the fragment's GC content or -1.                                                            */
+static double fragment_gc(oracle_ctx *c, const rec_t *r, uint32_t exon_row) {
+    pending_t *found = NULL;
+    uint64_t h = r->qhash ? r->qhash : 0x9e3779b97f4a7c15ull;
+    if (c->gcp_cap) {                                                       /* fragments.find(Qname) :461 */
+        size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (c->gcp_cap - 1);
+        while (c->gcp[j].used) {
+            if (c->gcp[j].used == 1 && c->gcp[j].h == h &&
+                (!r->qname || (c->gcp[j].s && strlen(c->gcp[j].s) == r->qname_len &&
+                               memcmp(c->gcp[j].s, r->qname, r->qname_len) == 0))) { found = &c->gcp[j]; break; }
+            j = (j + 1) & (c->gcp_cap - 1);
+        }
+    }
+    const int32_t endpos = end_position(r);
+    if (!found) {                                                           /* :462-466 */
+        if ((c->gcp_n + 1) * 2 > c->gcp_cap) {
+            size_t ncap = c->gcp_cap ? c->gcp_cap * 2 : 1024;
+            pending_t *np = xcalloc(ncap, sizeof(pending_t));
+            for (size_t i = 0; i < c->gcp_cap; ++i) if (c->gcp[i].used == 1) {
+                size_t j = (size_t)(c->gcp[i].h * 0x9e3779b97f4a7c15ull >> 17) & (ncap - 1);
+                while (np[j].used) j = (j + 1) & (ncap - 1);
+                np[j] = c->gcp[i];
+            }
+            free(c->gcp); c->gcp = np; c->gcp_cap = ncap;
+        }
+        size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (c->gcp_cap - 1);
+        while (c->gcp[j].used == 1) j = (j + 1) & (c->gcp_cap - 1);
+        int was_tomb = c->gcp[j].used == 2;
+        c->gcp[j].used = 1; c->gcp[j].h = h; c->gcp[j].bed = (int32_t)exon_row; c->gcp[j].endpos = endpos;
+        c->gcp[j].s = NULL;
+        if (r->qname) { c->gcp[j].s = xcalloc(r->qname_len + 1, 1); memcpy(c->gcp[j].s, r->qname, r->qname_len); }
+        if (!was_tomb) c->gcp_n++;
+        return -1;
+    }
+    if (found->bed != (int32_t)exon_row) return -1;                         /* :467 */
+    if (endpos <= found->endpos || r->pos == r->mpos) return -1;            /* :471 */
+    size_t len;
+    const uint8_t *seq = get_seq(c, r->tid, found->endpos - (int64_t)r->l_qseq, endpos, &len);   /* :473 */
+    free(found->s); found->s = NULL; found->used = 2;                       /* erase :474 */
+    return len > 0 ? gc_content(seq, len) : -1;                             /* :475 */
+}
+
 #define INC(k) (c->counters[(k)]++)
 
 /* exonAlignmentMetrics, src/Expression.cpp:308-458 (GC branch :459-477 is
  * --fasta only and out of scope)                                           */
-static void exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_t *blocks,
-                                   size_t nb, unsigned length, int hq) {
+static double exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_t *blocks,
+                                     size_t nb, unsigned length, int hq) {
+    uint32_t aligned_exon = 0; size_t n_aligned_exons = 0;                  /* set<string> alignedExons :318 */
     flist_t *fl = &c->feat[r->tid];
     int intragenic = 0, plus = 0, minus = 0, ribosomal = 0, do_exon = 0, exonic = 0; /* :321 */
     /* feature_strand, src/Expression.cpp:119-125 */
@@ -527,6 +608,11 @@ static void exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_t 
                     st[nst].frac = (double)isz / length;                    /* :345 */
                     st[nst].offset = bs - f->start;                         /* Metrics.cpp:99-100 */
                     st[nst].length = (uint32_t)(be - bs);
+                    {                                                       /* alignedExons.insert(feature_id) :348 */
+                        int seen_exon = 0;
+                        for (size_t k2 = 0; k2 < nst; ++k2) if (st[k2].exon_row == f->row) seen_exon = 1;
+                        if (!seen_exon) { aligned_exon = f->row; n_aligned_exons++; }
+                    }
                     nst++;
                 }
             } else intragenic = 1;                                          /* :352-354 */
@@ -602,6 +688,11 @@ static void exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_t 
     }
     for (size_t b = 0; b < nb; ++b) free(gset[b]);
     free(gset); free(gn); free(st);
+    /* :459 (the |InsertSize| window is open on both sides) */
+    const double isz = fabs((double)r->isize);
+    if (c->have_ref && c->ref_seq[r->tid] && hq && exonic && do_exon && n_aligned_exons == 1 && nb == 1 && isz > 100 && isz < 1000)
+        return fragment_gc(c, r, aligned_exon);
+    return -1;
 }
 
 
@@ -820,7 +911,13 @@ static int process_record(oracle_ctx *c, const rec_t *r) {
     int rc = trim_features(c, &c->feat[r->tid], r->pos);                    /* :361 */
     if (rc) { free(blocks); return rc; }
     if (legacy) legacy_exon_alignment_metrics(c, r, blocks, nb, hq);        /* :364 */
-    else exon_alignment_metrics(c, r, blocks, nb, aligned, hq);             /* :366 */
+    else {
+        const double gcv = exon_alignment_metrics(c, r, blocks, nb, aligned, hq);   /* :366 */
+        if (gcv != -1) {                                                    /* :368 (gcBins has 100 slots: 100 % GC is out of range) */
+            const unsigned int bin = (unsigned int)(gcv * 100.0);
+            if (bin < RSQC_GC_BINS) c->gc_bins[bin]++; else c->gc_oob++;
+        }
+    }
     if (hq && c->frag_remaining && (fl & RSQC_FPAIRED) && c->have_bed &&
         c->bed[r->tid].n)                                                   /* :372 */
         fragment_size(c, r, blocks, nb);
@@ -913,6 +1010,20 @@ ORACLE_API int oracle_set_bed(oracle_ctx *c, const rsqc_bed *b) {
     return 0;
 }
 
+/* Fasta::open, src/Fasta.cpp:77-98 (the index decides which contigs exist) */
+ORACLE_API int oracle_set_reference(oracle_ctx *c, const rsqc_reference *ref) {
+    if (!c || !ref || !c->feat) return RSQC_ERR_ARG;
+    c->ref_seq = xcalloc(c->n_contigs, sizeof(uint8_t *)); c->ref_len = xcalloc(c->n_contigs, sizeof(uint64_t));
+    for (int i = 0; i < ref->n; ++i) {
+        const int k = ref->contig[i];
+        if (k < 0 || k >= c->n_contigs) return RSQC_ERR_ARG;
+        c->ref_seq[k] = dup_array(ref->sequence[i], ref->length[i], 1); c->ref_len[k] = ref->length[i];
+    }
+    c->exon_gc = xcalloc(c->n_exons, 8);
+    c->have_ref = 1;
+    return 0;
+}
+
 ORACLE_API int oracle_submit(oracle_ctx *c, const rsqc_batch *b) {
     if (!c || !b || !c->feat) return RSQC_ERR_ARG;
     if (c->error) return c->error;
@@ -968,6 +1079,7 @@ ORACLE_API int oracle_finalize(oracle_ctx *c, rsqc_results *out) {
     out->bias_three = c->bias3; out->bias_five = c->bias5;
     out->n_fragment_sizes = (uint32_t)c->fs_n; out->fragment_size = c->fs_size; out->fragment_count = c->fs_count;
     out->fragment_samples_remaining = c->frag_remaining;
+    out->have_reference = c->have_ref; out->gc_bins = c->gc_bins; out->gc_out_of_range = c->gc_oob; out->exon_gc = c->exon_gc;
     return 0;
 }
 
@@ -985,6 +1097,9 @@ ORACLE_API void oracle_destroy(oracle_ctx *c) {
     if (c->tracker) for (int g = 0; g < c->n_genes; ++g) nameset_clear(&c->tracker[g]);
     if (c->cov) for (int e = 0; e < c->n_exons; ++e) free(c->cov[e]);
     for (size_t i = 0; i < c->pend_cap; ++i) free(c->pend[i].s);
+    for (size_t i = 0; i < c->gcp_cap; ++i) free(c->gcp[i].s);
+    if (c->ref_seq) for (int i = 0; i < c->n_contigs; ++i) free(c->ref_seq[i]);
+    free(c->gcp); free(c->ref_seq); free(c->ref_len); free(c->exon_gc);
     free(c->pend); free(c->fs_size); free(c->fs_count);
     free(c->feat); free(c->bed); free(c->owned); free(c->ex_start); free(c->ex_end); free(c->ex_id);
     free(c->ex_gene); free(c->ex_flags); free(c->g_globin); free(c->g_row_flags); free(c->ge_off); free(c->ge_row);

@@ -131,7 +131,15 @@ class ResultsStruct(C.Structure):
         ("bias_three", _P), ("bias_five", _P),
         ("n_fragment_sizes", C.c_uint32), ("fragment_size", _P), ("fragment_count", _P),
         ("fragment_samples_remaining", C.c_uint32),
+        ("have_reference", C.c_int32), ("gc_bins", _P), ("gc_out_of_range", C.c_uint64), ("exon_gc", _P),
     ]
+
+
+class ReferenceStruct(C.Structure):
+    _fields_ = [("n", C.c_int32), ("contig", _P), ("length", _P), ("sequence", _P)]
+
+
+GC_BINS = 100
 
 
 class TimingStruct(C.Structure):
@@ -172,11 +180,15 @@ class Results:
         "exon_cv_valid": ("exon_cv_valid", "E", np.uint8), "bias_three": ("bias_three", "G", np.uint64),
         "bias_five": ("bias_five", "G", np.uint64), "fragment_size": ("fragment_size", "F", np.int64),
         "fragment_count": ("fragment_count", "F", np.uint64),
+        "gc_bins": ("gc_bins", "B", np.uint64), "exon_gc": ("exon_gc", "R", np.float64),
     }
 
     def __init__(self, rs: ResultsStruct):
         self._rs = rs
-        self._n = {"G": rs.n_genes_listed, "E": rs.n_exons, "F": rs.n_fragment_sizes}
+        self.have_reference = int(rs.have_reference)
+        self.gc_out_of_range = int(rs.gc_out_of_range)
+        self._n = {"G": rs.n_genes_listed, "E": rs.n_exons, "F": rs.n_fragment_sizes,
+                   "B": GC_BINS if rs.have_reference else 0, "R": rs.n_exons if rs.have_reference else 0}
         self.read_length = int(rs.read_length)
         self.fragment_samples_remaining = int(rs.fragment_samples_remaining)
 

@@ -50,6 +50,11 @@ struct FragBuf {                // fragment-size candidates of one submitted bat
     uint32_t cap = 0;
     bool used = false;
 };
+struct GcBuf {                  // fragment GC candidates of one submitted batch (--fasta runs only)
+    DevBuf file, qhash, row, endpos, flag_lq, tid, count;
+    uint32_t cap = 0;
+    bool used = false;
+};
 
 }  // namespace
 
@@ -95,6 +100,14 @@ struct rsqc_ctx {
     std::vector<FragBuf> frag_pool;
     std::vector<size_t> frags_in_flight;
     uint32_t frag_remaining = 0;
+    // --fasta
+    bool have_ref = false;
+    DevBuf d_ref_bits, d_ref_off, d_ref_len, d_gc_bins, d_exon_gc;
+    DevReference dref{};
+    std::vector<GcBuf> gc_pool;
+    std::vector<size_t> gcs_in_flight;
+    std::vector<uint64_t> h_gc;                 // [RSQC_GC_BINS + 1]
+    std::vector<double> h_exon_gc;              // by exon id
     // K3 outputs
     bool finalized = false;
 
@@ -231,6 +244,12 @@ int zero_accumulators(rsqc_ctx *c) {
     c->frags_in_flight.clear();
     c->h_fsize.clear(); c->h_fcount.clear();
     c->frag_remaining = c->have_bed ? c->params.fragment_samples : 0;
+    for (auto &gb : c->gc_pool) gb.used = false;
+    c->gcs_in_flight.clear();
+    if (c->have_ref) {
+        HIP_TRY(c, hipMemsetAsync(c->d_gc_bins.p, 0, (RSQC_GC_BINS + 1) * 8, c->stream));
+        c->h_gc.assign(RSQC_GC_BINS + 1, 0);
+    }
     c->finalized = false;
     c->next_record_base = 0;
     c->sticky = 0;
@@ -342,6 +361,26 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     c->k1_events.emplace_back(e0, e1);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
     launch_read_length(c->stream, c->dann, c->dparams, d, acc);
+    if (c->have_ref && !c->dparams.legacy) {          // --fasta: fragment GC candidates, a separate pass over the batch
+        size_t gidx = c->gc_pool.size();
+        for (size_t i = 0; i < c->gc_pool.size(); ++i) if (!c->gc_pool[i].used && c->gc_pool[i].cap >= u->n) { gidx = i; break; }
+        if (gidx == c->gc_pool.size()) {
+            GcBuf gb; gb.cap = (uint32_t)u->n;
+            int rc2;
+            if ((rc2 = dev_alloc(c, gb.file, u->n * 8, false)) || (rc2 = dev_alloc(c, gb.qhash, u->n * 8, false)) ||
+                (rc2 = dev_alloc(c, gb.row, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.endpos, u->n * 4, false)) ||
+                (rc2 = dev_alloc(c, gb.flag_lq, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.tid, u->n * 4, false)) ||
+                (rc2 = dev_alloc(c, gb.count, 16, false))) return rc2;
+            c->gc_pool.push_back(gb);
+        }
+        GcBuf &gb = c->gc_pool[gidx];
+        gb.used = true;
+        c->gcs_in_flight.push_back(gidx);
+        HIP_TRY(c, hipMemsetAsync(gb.count.p, 0, 16, c->stream));
+        GcCandidates gc{(uint64_t *)gb.file.p, (uint64_t *)gb.qhash.p, (uint32_t *)gb.row.p, (int32_t *)gb.endpos.p,
+                        (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, (uint32_t *)gb.count.p, gb.cap};
+        launch_gc_candidates(c->stream, c->dann, c->dparams, d, c->dref, gc, acc.error);
+    }
     HIP_TRY(c, hipGetLastError());
     c->timing.classify_launches += 1;
     c->timing.classify_records += u->n;
@@ -399,6 +438,8 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->ann_bufs) b.release();
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); }
+    for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); }
+    c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -522,6 +563,50 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     return RSQC_OK;
 }
 
+int rsqc_set_reference(rsqc_ctx *c, const rsqc_reference *ref) {
+    if (!c || !ref || !c->have_ann) return RSQC_ERR_ARG;
+    if (c->have_ref) return fail(c, RSQC_ERR_ARG, "reference already set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int nc = c->n_contigs;
+    std::vector<unsigned long long> off((size_t)nc, ~0ull), len((size_t)nc, 0ull);
+    unsigned long long words = 0, longest = 0;
+    for (int i = 0; i < ref->n; ++i) {
+        const int k = ref->contig[i];
+        if (k < 0 || k >= nc || off[(size_t)k] != ~0ull) return fail(c, RSQC_ERR_ARG, "reference contig out of range or repeated");
+        if (ref->length[i] && !ref->sequence[i]) return fail(c, RSQC_ERR_ARG, "reference contig without bases");
+        off[(size_t)k] = words; len[(size_t)k] = ref->length[i];
+        words += (ref->length[i] + 63) / 64;
+        longest = std::max<unsigned long long>(longest, ref->length[i]);
+    }
+    int rc;
+    if ((rc = dev_alloc(c, c->d_ref_bits, (size_t)(words + 2) * 8, false)) || (rc = dev_alloc(c, c->d_ref_off, (size_t)std::max(nc, 1) * 8, false)) ||
+        (rc = dev_alloc(c, c->d_ref_len, (size_t)std::max(nc, 1) * 8, false)) || (rc = dev_alloc(c, c->d_gc_bins, (RSQC_GC_BINS + 1) * 8, false)) ||
+        (rc = dev_alloc(c, c->d_exon_gc, (size_t)std::max(c->n_exons, 1) * 8, false))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_ref_off.p, off.data(), (size_t)nc * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_ref_len.p, len.data(), (size_t)nc * 8, hipMemcpyHostToDevice, c->stream));
+    // the bases pass through one staging buffer sized for the longest contig and are packed to one bit each
+    DevBuf stage;
+    if ((rc = dev_alloc(c, stage, (size_t)longest + 64, false))) return rc;
+    for (int i = 0; i < ref->n; ++i) {
+        if (!ref->length[i]) continue;
+        HIP_TRY(c, hipMemcpyAsync(stage.p, ref->sequence[i], (size_t)ref->length[i], hipMemcpyHostToDevice, c->stream));
+        launch_gc_pack(c->stream, (const uint8_t *)stage.p, ref->length[i], (unsigned long long *)c->d_ref_bits.p + off[(size_t)ref->contig[i]]);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the caller's string and the staging buffer are reused
+    }
+    stage.release();
+    c->dref = DevReference{(const unsigned long long *)c->d_ref_bits.p, (const unsigned long long *)c->d_ref_off.p,
+                           (const unsigned long long *)c->d_ref_len.p};
+    launch_exon_gc(c->stream, c->dann, c->dref, (double *)c->d_exon_gc.p);
+    c->h_exon_gc.assign((size_t)std::max(c->n_exons, 1), -1.0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_exon_gc.data(), c->d_exon_gc.p, (size_t)c->n_exons * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_gc_bins.p, 0, (RSQC_GC_BINS + 1) * 8, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    c->h_gc.assign(RSQC_GC_BINS + 1, 0);
+    c->have_ref = true;
+    return RSQC_OK;
+}
+
 int rsqc_set_bed(rsqc_ctx *c, const rsqc_bed *bed) {
     if (!c || !bed || !c->have_ann) return RSQC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -637,6 +722,10 @@ static int read_back(rsqc_ctx *c) {
     R.n_fragment_sizes = (uint32_t)c->h_fsize.size();
     R.fragment_size = c->h_fsize.data(); R.fragment_count = c->h_fcount.data();
     R.fragment_samples_remaining = c->frag_remaining;
+    R.have_reference = c->have_ref ? 1 : 0;
+    R.gc_bins = c->have_ref ? c->h_gc.data() : nullptr;
+    R.gc_out_of_range = c->have_ref ? c->h_gc[RSQC_GC_BINS] : 0;
+    R.exon_gc = c->have_ref ? c->h_exon_gc.data() : nullptr;
     const int err = *(const int *)(H + c->off_misc + 16);
     if (err) {
         c->sticky = err;
@@ -776,6 +865,46 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                                     c->frag_remaining);
             m_file.release(); m_q.release(); m_name.release(); m_end.release(); m_fs.release();
             if (rc) return fail(c, rc, "fragment-size stage failed");
+        }
+        // ---- fragment GC content (--fasta runs): the same mate pairing, no cut-off --------------------------
+        if (c->have_ref && !c->gcs_in_flight.empty()) {
+            std::vector<uint32_t> counts(c->gcs_in_flight.size(), 0);
+            uint64_t total = 0;
+            for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
+                GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
+                HIP_TRY(c, hipMemcpyAsync(&counts[k], gb.count.p, 4, hipMemcpyDeviceToHost, c->stream));
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (size_t k = 0; k < counts.size(); ++k) {
+                if (counts[k] > c->gc_pool[c->gcs_in_flight[k]].cap) return fail(c, RSQC_ERR_CAPACITY, "GC candidate overflow");
+                total += counts[k];
+            }
+            if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many GC candidates");
+            if (total) {
+                DevBuf m_file, m_q, m_row, m_end, m_fl, m_tid;
+                if ((rc = dev_alloc(c, m_file, total * 8, false)) || (rc = dev_alloc(c, m_q, total * 8, false)) ||
+                    (rc = dev_alloc(c, m_row, total * 4, false)) || (rc = dev_alloc(c, m_end, total * 4, false)) ||
+                    (rc = dev_alloc(c, m_fl, total * 4, false)) || (rc = dev_alloc(c, m_tid, total * 4, false))) return rc;
+                uint64_t at = 0;
+                for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
+                    GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
+                    const size_t n = counts[k];
+                    if (!n) continue;
+                    HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_file.p + at, gb.file.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_q.p + at, gb.qhash.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync((uint32_t *)m_row.p + at, gb.row.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync((int32_t *)m_end.p + at, gb.endpos.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync((uint32_t *)m_fl.p + at, gb.flag_lq.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync((int32_t *)m_tid.p + at, gb.tid.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
+                    at += n;
+                }
+                GcCandidates gc{(uint64_t *)m_file.p, (uint64_t *)m_q.p, (uint32_t *)m_row.p, (int32_t *)m_end.p,
+                                (uint32_t *)m_fl.p, (int32_t *)m_tid.p, nullptr, (uint32_t)total};
+                rc = run_gc_content(c->stream, gc, (uint32_t)total, c->dref, (unsigned long long *)c->d_gc_bins.p);
+                m_file.release(); m_q.release(); m_row.release(); m_end.release(); m_fl.release(); m_tid.release();
+                if (rc) return fail(c, rc, "GC content stage failed");
+            }
+            HIP_TRY(c, hipMemcpy(c->h_gc.data(), c->d_gc_bins.p, (RSQC_GC_BINS + 1) * 8, hipMemcpyDeviceToHost));
         }
     c->fin_e0 = e0; c->fin_e1 = e1;
     return 0;

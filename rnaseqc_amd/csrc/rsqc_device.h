@@ -44,6 +44,46 @@ struct FragCandidates {
     uint32_t *count; uint32_t cap;
 };
 
+// --fasta: one G/C bit per base (gc(), src/Fasta.cpp:67-74, counts G g C c only); every contig starts on a word
+struct DevReference {
+    const unsigned long long *bits;
+    const unsigned long long *word_off;   // [n_contigs] first word of the contig; ~0 = the FASTA index lacks the contig
+    const unsigned long long *length;     // [n_contigs] bases
+};
+// fragment GC candidates (src/Expression.cpp:459): records that reach the fragments map of the GC branch
+struct GcCandidates {
+    uint64_t *file_index;        // record index in the whole file
+    uint64_t *qhash;
+    uint32_t *row;               // the single aligned exon (row index)
+    int32_t *endpos;             // PositionEnd()
+    uint32_t *flag_lq;           // bit 31: pos != mpos ; low 31 bits alignment.Length()
+    int32_t *tid;
+    uint32_t *count; uint32_t cap;
+};
+#if defined(__HIPCC__)
+// bases of [s, e) (0-based, inside the contig) that are G/C
+__device__ __forceinline__ uint32_t gc_count(const DevReference &R, int contig, int64_t s, int64_t e) {
+    if (e <= s) return 0u;
+    const unsigned long long *w = R.bits + R.word_off[contig];
+    const int64_t w0 = s >> 6, w1 = (e - 1) >> 6;
+    uint32_t n = 0;
+    for (int64_t i = w0; i <= w1; ++i) {
+        unsigned long long x = w[i];
+        if (i == w0) x &= ~0ull << (s & 63);
+        if (i == w1) x &= ~0ull >> (63 - ((e - 1) & 63));
+        n += (uint32_t)__popcll(x);
+    }
+    return n;
+}
+// gc(): 1.0/size added once per G/C base -- k sequential additions, not k/size
+__device__ __forceinline__ double gc_value(uint32_t k, uint64_t size) {
+    const double inc = 1.0 / (double)size;
+    double c = 0.0;
+    for (uint32_t i = 0; i < k; ++i) c += inc;
+    return c;
+}
+#endif
+
 // accumulators (device pointers)
 struct DevAccum {
     unsigned long long *gene_reads, *gene_unique, *gene_frag, *counters;   // one allocation, in this order
@@ -115,4 +155,11 @@ void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, ui
 namespace rsqc {
 int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
                        std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining);
+// --fasta (rsqc_kernels.hip / rsqc_fragsize.hip)
+void launch_gc_pack(hipStream_t s, const uint8_t *ascii, uint64_t len, unsigned long long *words);
+void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R, double *exon_gc);
+void launch_gc_candidates(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevReference &R,
+                          const GcCandidates &out, int *error);
+// pairs the candidates by QNAME in file order and adds every usable fragment to bins[0..100] (slot 100 = 100 % GC)
+int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins);
 }

@@ -12,6 +12,11 @@
 //      a library primitive -- the state machine and everything else is ours);
 //   one thread per QNAME group replays the reference's state machine;
 //   samples are ordered by file index and the first N are kept.
+//
+// The fragment GC statistics of --fasta runs (src/Expression.cpp:459-477) pair mates the same way -- a map
+// QNAME -> (exon, end position), first record stored, a later one in the same exon either yields a fragment or leaves
+// the entry -- without a cut-off: run_gc_content below shares the ordering steps and replays the groups with the
+// G/C bit mask of the reference.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
@@ -114,6 +119,60 @@ int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, 
     cleanup();
 #undef FS_TRY
     return rc;
+}
+
+
+// One thread per candidate in (qhash, file index) order; group starts replay src/Expression.cpp:461-476.
+__global__ void gc_groups_kernel(const uint64_t *sorted_q, const uint32_t *order, const GcCandidates c, uint32_t n,
+                                 const DevReference R, unsigned long long *bins) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t q = sorted_q[j];
+    if (j > 0 && sorted_q[j - 1] == q) return;           // not a group start
+    bool pending = false; uint32_t p_row = 0; int32_t p_end = 0;
+    for (uint32_t k = j; k < n && sorted_q[k] == q; ++k) {
+        const uint32_t e = order[k];
+        const uint32_t row = c.row[e]; const int32_t endpos = c.endpos[e];
+        if (!pending) { pending = true; p_row = row; p_end = endpos; }              // :462-466
+        else if (row == p_row) {                                                    // :467
+            const uint32_t fl = c.flag_lq[e];
+            if (endpos <= p_end || !(fl >> 31)) continue;                            // :471 (the entry stays)
+            pending = false;                                                        // erase, :474
+            const int tid = c.tid[e];
+            const int64_t L = (int64_t)R.length[tid];
+            int64_t s = (int64_t)p_end - (int64_t)(fl & 0x7FFFFFFFu), en = endpos;  // getSeq(chr, stored end - Length(), PositionEnd()) :473
+            if (s < 0 || s >= L) continue;               // outside the contig: error paths of the reference, no fragment here
+            if (en > L) en = L;                          // a page is clipped at the contig end (bioio.hpp:306)
+            if (en <= s) continue;
+            const double v = gc_value(gc_count(R, tid, s, en), (uint64_t)(en - s));
+            const unsigned int bin = (unsigned int)(v * 100.0);                     // src/RNASeQC.cpp:368
+            atomicAdd(&bins[bin < RSQC_GC_BINS ? bin : RSQC_GC_BINS], 1ull);
+        }
+    }
+}
+
+int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins) {
+    if (n == 0) return 0;
+    uint64_t *k0 = nullptr, *k1 = nullptr;
+    uint32_t *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
+    void *tmp = nullptr;
+    auto cleanup = [&]() { for (void *p : {(void *)k0, (void *)k1, (void *)v0, (void *)v1, (void *)v2, tmp}) if (p) (void)hipFree(p); };
+#define GC_TRY(e) do { if ((e) != hipSuccess) { cleanup(); return RSQC_ERR_HIP; } } while (0)
+    GC_TRY(hipMalloc(&k0, (size_t)n * 8)); GC_TRY(hipMalloc(&k1, (size_t)n * 8));
+    GC_TRY(hipMalloc(&v0, (size_t)n * 4)); GC_TRY(hipMalloc(&v1, (size_t)n * 4)); GC_TRY(hipMalloc(&v2, (size_t)n * 4));
+    size_t tmp_bytes = 0;
+    GC_TRY(sort_pairs_u64(nullptr, tmp_bytes, c.file_index, k0, v0, v1, n, stream));
+    GC_TRY(hipMalloc(&tmp, tmp_bytes + 256));
+    const int T = 256, B = (int)((n + T - 1) / T);
+    hipLaunchKernelGGL(frag_iota_kernel, dim3(B), dim3(T), 0, stream, v0, n);
+    GC_TRY(sort_pairs_u64(tmp, tmp_bytes, c.file_index, k0, v0, v1, n, stream));                 // file order
+    hipLaunchKernelGGL(frag_gather_u64_kernel, dim3(B), dim3(T), 0, stream, c.qhash, v1, k0, n);
+    GC_TRY(sort_pairs_u64(tmp, tmp_bytes, k0, k1, v1, v2, n, stream));                           // stable by QNAME hash
+    hipLaunchKernelGGL(gc_groups_kernel, dim3(B), dim3(T), 0, stream, k1, v2, c, n, R, bins);
+    GC_TRY(hipStreamSynchronize(stream));
+    cleanup();
+#undef GC_TRY
+    return 0;
 }
 
 }  // namespace rsqc

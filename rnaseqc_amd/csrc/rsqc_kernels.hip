@@ -10,6 +10,7 @@
 //   K3  gene_coverage_kernel    per gene: diff->coverage scan into LDS, per-exon CV, bias windows, masked
 //                               gene mean/std/CV; workgroup sized to the gene (1 wave / 256 / 1024 threads)
 //   reset_kernel, pack_results_kernel   accumulator reset and result packing around a pass
+//   gc_pack / exon_gc / gc_candidates   --fasta: G/C bit mask of the reference, per-exon GC, fragment GC candidates
 //
 // This is integer / byte indexing work bound by instruction issue, load latency and atomics, not a
 // contraction: no MFMA.  All wave-level idioms are written for 64-lane wavefronts.
@@ -1390,6 +1391,107 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
         } else if (tid == 0) { A.g_valid[gene] = 0; A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = 0.0; }
     }
 }
+// ------------------------------------------------------------------ --fasta
+// One G/C bit per base from the FASTA text of a contig (64 bases per thread).
+__global__ void __launch_bounds__(256)
+gc_pack_kernel(const uint8_t *ascii, uint64_t len, unsigned long long *words) {
+    const uint64_t n_words = (len + 63) / 64;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long x = 0ull;
+        const uint64_t b0 = w * 64, b1 = b0 + 64 < len ? b0 + 64 : len;
+        for (uint64_t i = b0; i < b1; ++i) {
+            const uint8_t ch = ascii[i] | 0x20u;                       // G g C c, src/Fasta.cpp:72
+            if (ch == 'g' || ch == 'c') x |= 1ull << (i - b0);
+        }
+        words[w] = x;
+    }
+}
+void launch_gc_pack(hipStream_t s, const uint8_t *ascii, uint64_t len, unsigned long long *words) {
+    const uint64_t n_words = (len + 63) / 64;
+    if (!n_words) return;
+    hipLaunchKernelGGL(gc_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_words + 255) / 256, 65536)), dim3(256), 0, s, ascii, len, words);
+}
+
+// Per-exon GC as fetched by computeCoverage (src/Metrics.cpp:299-303): getSeq(chr, start, start + length) -- the
+// 1-based start used as a 0-based offset -- clipped at the contig end (bioio.hpp:306); -1 when the FASTA lacks the contig.
+__global__ void __launch_bounds__(256)
+exon_gc_kernel(DevAnnotation a, DevReference R, double *exon_gc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)a.n_exons) return;
+    int lo = 0, hi = a.n_contigs;                                      // contig of the row: last one with ex_lo <= i
+    while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (a.contig[m].ex_lo <= i) lo = m; else hi = m; }
+    while (lo + 1 < a.n_contigs && a.contig[lo].ex_hi <= i) ++lo;      // (contigs without exons share ex_lo)
+    const ExonRow row = a.ex[i];
+    double v = -1.0;
+    if (R.word_off[lo] != ~0ull) {
+        const int64_t L = (int64_t)R.length[lo];
+        int64_t s = row.start, e = (int64_t)row.start + ((int64_t)row.end - row.start + 1);
+        if (s >= 0 && s < L) {
+            if (e > L) e = L;
+            v = gc_value(gc_count(R, lo, s, e), (uint64_t)(e - s));
+        }
+    }
+    exon_gc[a.ex_id[i]] = v;
+}
+void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R, double *exon_gc) {
+    if (a.n_exons <= 0) return;
+    hipLaunchKernelGGL(exon_gc_kernel, dim3((a.n_exons + 255) / 256), dim3(256), 0, s, a, R, exon_gc);
+}
+
+// Candidates of the fragment GC branch (src/Expression.cpp:459): contig in the FASTA, high quality, ONE aligned block
+// that lies inside exactly ONE exon row (then exonic, alignedExons.size() == 1 and doExonMetrics hold), and
+// 100 < |InsertSize| < 1000.  A separate pass over the batch, launched only when a reference is set: the per-read
+// kernel of runs without --fasta is untouched.
+__global__ void __launch_bounds__(256)
+gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, GcCandidates out, int *error) {
+    __shared__ uint32_t s_base, s_count;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < b.n; i0 += stride) {
+        const uint64_t i = i0 + threadIdx.x;
+        if (threadIdx.x == 0) s_count = 0u;
+        __syncthreads();
+        bool emit = false; uint32_t row_hit = 0; int32_t endpos = 0, tid = 0; uint32_t flag_lq = 0; uint64_t qhash = 0;
+        if (i < b.n) {
+            Record r;
+            if (load_record(b, i, find_segment(b, i), r)) {
+                RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
+                const bool go = gate_cascade(a, p, r, rc, hq, aligned, B);
+                const int64_t isz = r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize;
+                if (go && hq && !p.legacy && B.nb == 1 && isz > 100 && isz < 1000 && R.word_off[r.tid] != ~0ull) {   // (--legacy never reaches the GC branch, src/RNASeQC.cpp:364)
+                    const int32_t bs = B.bs[0], be = B.bs[0] + (int32_t)B.len[0];
+                    uint32_t n_in = 0;
+                    query_block(a, a.contig[r.tid], bs, be, read_strand_of(p, r.flag), (ClassFlags *)nullptr,
+                                [&](uint32_t row_i, const ExonRow &, bool contained) { if (contained) { ++n_in; row_hit = row_i; } });
+                    if (n_in == 1) {
+                        emit = true; endpos = rc.endpos; tid = r.tid; qhash = r.qhash;
+                        flag_lq = ((uint32_t)r.l_qseq & 0x7FFFFFFFu) | (r.pos != r.mpos ? 0x80000000u : 0u);
+                    }
+                }
+            }
+        }
+        uint32_t my = 0;
+        if (emit) my = atomicAdd(&s_count, 1u);                        // LDS: one global reservation per workgroup
+        __syncthreads();
+        if (threadIdx.x == 0 && s_count) s_base = atomicAdd(out.count, s_count);
+        __syncthreads();
+        if (emit) {
+            const uint32_t slot = s_base + my;
+            if (slot < out.cap) {
+                out.file_index[slot] = b.record_base + i; out.qhash[slot] = qhash; out.row[slot] = row_hit;
+                out.endpos[slot] = endpos; out.flag_lq[slot] = flag_lq; out.tid[slot] = tid;
+            } else atomicExch(error, RSQC_ERR_CAPACITY);
+        }
+        __syncthreads();
+    }
+}
+void launch_gc_candidates(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevReference &R,
+                          const GcCandidates &out, int *error) {
+    if (!b.n) return;
+    const uint64_t blocks = (b.n + 255) / 256;
+    hipLaunchKernelGGL(gc_candidates_kernel, dim3((unsigned)std::min<uint64_t>(blocks, 8192)), dim3(256), 0, s, a, p, b, R, out, error);
+}
+
+
 
 // ------------------------------------------------------------------ result packing
 // exon_hit[id] = the exon has a map entry in the reference's exonCounts (a non-zero sum; src/RNASeQC.cpp:513).

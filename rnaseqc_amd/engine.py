@@ -35,6 +35,7 @@ def load_library():
         lib.rsqc_destroy.argtypes = [vp]; lib.rsqc_destroy.restype = None
         lib.rsqc_set_annotation.argtypes = [vp, C.POINTER(abi.AnnotationStruct), vp]
         lib.rsqc_set_bed.argtypes = [vp, C.POINTER(abi.BedStruct)]
+        lib.rsqc_set_reference.argtypes = [vp, C.POINTER(abi.ReferenceStruct)]
         lib.rsqc_submit.argtypes = [vp, C.POINTER(abi.BatchStruct)]
         lib.rsqc_wait.argtypes = [vp]
         lib.rsqc_upload.argtypes = [vp, C.POINTER(abi.BatchStruct), C.POINTER(C.c_int)]
@@ -59,7 +60,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_submit", "rsqc_wait",
+    "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_set_reference", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
     "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
@@ -100,6 +101,10 @@ class Engine:
         s = bed.to_struct()
         self._keep += [bed, s]
         self._check(self._l.rsqc_set_bed(self._h, C.byref(s)))
+
+    def set_reference(self, ref):
+        s = ref.to_struct()
+        self._check(self._l.rsqc_set_reference(self._h, C.byref(s)))     # (copied: nothing of `ref` is kept)
 
     def submit(self, batch):
         s = batch.to_struct()
@@ -189,12 +194,14 @@ class Engine:
             pass
 
 
-def run_engine(params, ann, batches, bed=None, owned=None) -> abi.Results:
+def run_engine(params, ann, batches, bed=None, owned=None, reference=None) -> abi.Results:
     e = Engine(params)
     try:
         e.set_annotation(ann, owned)
         if bed is not None:
             e.set_bed(bed)
+        if reference is not None:
+            e.set_reference(reference)
         for b in batches:
             e.submit(b)
         return e.finalize()

@@ -215,6 +215,25 @@ class Bed:
 
 
 @dataclass
+class Reference:
+    """--fasta: base strings of the contigs the FASTA index names (rsqc_reference)."""
+    contig: list                 # boundary contig ids
+    sequence: list               # one uint8 array (ASCII) per contig
+
+    def to_struct(self) -> abi.ReferenceStruct:
+        import ctypes as C
+        s = abi.ReferenceStruct()
+        s.n = len(self.contig)
+        self._contig = np.ascontiguousarray(self.contig, dtype=np.int32)
+        self._length = np.array([len(x) for x in self.sequence], dtype=np.uint64)
+        self.sequence = [np.ascontiguousarray(x, dtype=np.uint8) for x in self.sequence]
+        self._ptrs = (C.c_void_p * max(s.n, 1))(*[x.ctypes.data for x in self.sequence])
+        s.contig, s.length = abi.ptr(self._contig), abi.ptr(self._length)
+        s.sequence = C.cast(self._ptrs, C.c_void_p)
+        return s
+
+
+@dataclass
 class Batch:
     """Structure-of-arrays batch of alignment records in file order."""
     pos: np.ndarray

@@ -472,3 +472,26 @@ def make_bed(ann: Annotation, min_len: int = 1000) -> Bed:
     ok = (prev_end < me_s) & (next_start > me_e) & ((e - s + 1) >= min_len)
     idx = np.flatnonzero(ok)
     return Bed.from_intervals(c[idx], s[idx] - 1, e[idx])
+
+
+def make_reference(contig_lengths, seed: int = 0, contigs=None, gc_wave: int = 50_000):
+    """Random base strings for the given contigs (ids default to 0..n-1): GC fraction drifting between 0.3 and 0.7
+    along the contig, a few lower-case stretches and N runs (only G/g/C/c count, src/Fasta.cpp:67-74)."""
+    from .model import Reference
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for L in contig_lengths:
+        L = int(L)
+        x = np.arange(L, dtype=np.float64)
+        pgc = 0.5 + 0.2 * np.sin(x / gc_wave * 2 * np.pi + rng.random() * 6.28)
+        is_gc = rng.random(L) < pgc
+        pick = rng.random(L) < 0.5
+        b = np.where(is_gc, np.where(pick, ord("G"), ord("C")), np.where(pick, ord("A"), ord("T"))).astype(np.uint8)
+        for _ in range(max(1, L // 200_000)):                       # soft-masked stretches and N runs
+            a = int(rng.integers(0, max(1, L - 2000))); n = int(rng.integers(50, 2000))
+            b[a:a + n] |= 0x20
+            a = int(rng.integers(0, max(1, L - 500))); n = int(rng.integers(10, 500))
+            b[a:a + n] = ord("N")
+        seqs.append(b)
+    ids = list(range(len(seqs))) if contigs is None else list(contigs)
+    return Reference(contig=ids, sequence=seqs)

@@ -37,3 +37,10 @@ def assert_results_match(got, want, check_coverage=True, check_fragments=True):
     if check_fragments:
         np.testing.assert_array_equal(got.fragment_size, want.fragment_size)
         np.testing.assert_array_equal(got.fragment_count, want.fragment_count)
+    # --fasta: the histogram is integer work; exon GC values come out of the same sequence of additions (bit-exact)
+    assert got.have_reference == want.have_reference
+    if want.have_reference:
+        np.testing.assert_array_equal(got.gc_bins, want.gc_bins)
+        assert got.gc_out_of_range == want.gc_out_of_range
+        ev = want.exon_cv_valid.astype(bool)
+        np.testing.assert_array_equal(got.exon_gc[ev], want.exon_gc[ev])

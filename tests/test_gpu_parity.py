@@ -330,3 +330,26 @@ def test_legacy_deep_coverage_and_batches(oracle_lib):
     n = batch.n
     parts = [batch.slice(0, n // 3), batch.slice(n // 3, 2 * n // 3), batch.slice(2 * n // 3, n)]
     assert_results_match(engine.run_engine(p, ann, parts), want)
+
+
+# ---- --fasta GC statistics (src/Expression.cpp:459-477, src/Metrics.cpp:299-303) -----------------------------------
+def test_fasta_hand_derived_case(oracle_lib):
+    from tests import test_fasta_gc as tg
+    ann, batch, ref = tg.gc_case()
+    p = abi.default_params(coverage_mask=0)
+    got = engine.run_engine(p, ann, [batch], reference=ref)
+    tg.check_gc_case(got, ann)
+    assert_results_match(got, oracle_lib.run_oracle(p, ann, [batch], reference=ref))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stranded=abi.STRAND_REVERSE), dict(coverage_mask=50, unpaired=1)])
+def test_fasta_gc_vs_oracle(oracle_lib, kw):
+    ann, batch = small_inputs(n_pairs=40000, dup_frac=0.05)
+    ref = synth.make_reference(SMALL_LENGTHS[:2], seed=11)            # chrC is not in the FASTA index
+    p = abi.default_params(**kw)
+    want = oracle_lib.run_oracle(p, ann, [batch], reference=ref)
+    assert int(want.gc_bins.sum()) > 1000 and int((want.gc_bins > 0).sum()) > 20
+    got = engine.run_engine(p, ann, [batch], reference=ref)
+    assert_results_match(got, want)
+    n = batch.n                                                      # mates of a fragment in different batches
+    assert_results_match(engine.run_engine(p, ann, [batch.slice(0, n // 2), batch.slice(n // 2, n)], reference=ref), want)
