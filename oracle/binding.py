@@ -166,6 +166,9 @@ def ref_lib():
         _ref.ref_median.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         _ref.ref_statistics.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         _ref.ref_statistics.restype = None
+        if hasattr(_ref, "ref_advanced_statistics"):
+            _ref.ref_advanced_statistics.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+            _ref.ref_advanced_statistics.restype = None
         _ref.ref_metrics_print.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p]
         _ref.ref_frac.argtypes = [C.c_uint64, C.c_uint64]
         _ref.ref_frac.restype = C.c_double
@@ -190,6 +193,13 @@ def ref_statistics(values):
     out = (C.c_double * 4)()
     ref_lib().ref_statistics(abi.ptr(a), len(a), out)
     return tuple(out)
+
+
+def ref_advanced_statistics(values):
+    a = np.ascontiguousarray(values, dtype=np.uint32)
+    out = (C.c_double * 4)()
+    ref_lib().ref_advanced_statistics(abi.ptr(a), len(a), out)
+    return list(out)
 
 
 def ref_metrics_print(counter_dict, path):

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <list>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,15 @@ int ref_median(const double *v, uint64_t n, double *out) {
         *out = computeMedian(d.size(), d.begin());
         return 0;
     } catch (std::range_error &) { return -6; }
+}
+
+// getAdvancedStatistics (src/Metrics.h:188-206) over a list of unsigned values: avg, skewness, std, kurtosis
+__attribute__((visibility("default")))
+void ref_advanced_statistics(const unsigned int *v, uint64_t n, double out[4]) {
+    std::list<unsigned int> d(v, v + n);
+    statsTuple t = getAdvancedStatistics(d);
+    out[0] = std::get<StatIdx::avg>(t); out[1] = std::get<StatIdx::skew>(t);
+    out[2] = std::get<StatIdx::std>(t); out[3] = std::get<StatIdx::kurt>(t);
 }
 
 // getStatistics (src/Metrics.h:166-186): avg, median, std, MAD

@@ -98,3 +98,19 @@ def write_bam_fast(path, contigs, batch, ch_tag="ch", filter_tag="XF", threads=1
     rc = lib.host_bam_write(str(path).encode(), names, lens, len(contigs), C.byref(st), ch_tag.encode(), filter_tag.encode(), threads)
     if rc:
         raise OSError("host_bam_write failed: %d" % rc)
+
+
+def write_fasta(path, names, reference, line_bases=60, index_path=None):
+    """FASTA + .fai for the contigs of a model.Reference (test input for --fasta)."""
+    idx = []
+    with open(path, "wb") as f:
+        for name, seq in zip(names, reference.sequence):
+            f.write(b">" + name.encode() + b"\n")
+            off = f.tell()
+            b = bytes(bytearray(seq))
+            for i in range(0, len(b), line_bases):
+                f.write(b[i:i + line_bases] + b"\n")
+            idx.append((name, len(b), off, line_bases, line_bases + 1))
+    with open(index_path or path + ".fai", "w") as f:
+        for rec in idx:
+            f.write("%s\t%d\t%d\t%d\t%d\n" % rec)

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <future>
 #include <iostream>
 #include <stdexcept>
@@ -16,6 +17,7 @@
 #include <vector>
 
 #include "bam.hpp"
+#include "fasta.hpp"
 #include "gtf.hpp"
 #include "report.hpp"
 
@@ -50,7 +52,7 @@ void usage(std::ostream &o) {
          "      output                            Output directory\n"
          "      -s[sample], --sample=[sample]     The name of the current sample.  Default: The bam's filename\n"
          "      --bed=[BEDFILE]                   Optional input BED file containing non-overlapping exons used for fragment size calculations\n"
-         "      --fasta=[fasta]                   (not supported by this build)\n"
+         "      --fasta=[fasta]                   Optional input FASTA (with .fai index): enables the GC-content statistics (CRAM input is not supported)\n"
          "      --chimeric-distance=[DISTANCE]    Maximum accepted distance between read mates. Default: 2000000 [bp]\n"
          "      --fragment-samples=[SAMPLES]      Number of fragment size samples. Default: 1000000\n"
          "      -q[QUALITY], --mapping-quality=[QUALITY]  Lower bound on read quality for exon coverage counting. Default: 255\n"
@@ -190,7 +192,6 @@ int main(int argc, char **argv) {
             else if (o.stranded == "FR" || o.stranded == "fr") strand = RSQC_STRAND_FORWARD;
             else throw ValidationError("--stranded argument must be in {'RF', 'rf', 'FR', 'fr'}");
         }
-        if (o.has_fasta) { cerr << "--fasta (CRAM reference / GC statistics) is not implemented in this build" << endl; return 7; }
         if (o.tags.size() > RSQC_MAX_FILTER_TAGS) { cerr << "at most " << RSQC_MAX_FILTER_TAGS << " --tag filters are supported" << endl; return 7; }
 
         rsqc_params P{};
@@ -212,6 +213,16 @@ int main(int argc, char **argv) {
         const auto t0 = std::chrono::steady_clock::now();
         Annotation ann;
         ann.legacy = o.legacy;
+        FastaFile fasta;
+        std::vector<std::vector<uint8_t>> fasta_seq;
+        std::future<void> fasta_loaded;                                       // (declared last: its destructor joins the reader before the buffers go)
+        if (o.has_fasta) {                                                    // src/RNASeQC.cpp:111-121: GTF openable, then Fasta::open
+            { std::ifstream probe(gtf_path); if (!probe.is_open()) { cerr << "Unable to open GTF file: " << gtf_path << endl; return 10; } }
+            fasta.open(o.fasta);                                              // FileError -> 10
+            for (auto &e : fasta.index) ann.chromosome(e.name);               // the index names join chromosomeMap first (src/Fasta.cpp:93-94)
+            if (o.verbosity > 1) cout << "A FASTA has been provided. This will enable GC-content statistics but adds additional runtime and memory costs" << endl;
+            fasta_loaded = std::async(std::launch::async, [&fasta, &fasta_seq] { fasta.load(fasta_seq); });   // read beside the GTF parse
+        }
         if (o.verbosity) cout << "Reading GTF Features..." << endl;
         ann.load_gtf(gtf_path);                                               // FileError -> 10, GtfError -> 11
         if (!(ann.gene_list.size() && ann.exon_list.size())) {
@@ -242,6 +253,19 @@ int main(int argc, char **argv) {
         if (rc != RSQC_OK) { cerr << "Unable to initialise the GPU hot path: " << rsqc_strerror(rc) << endl; return 10; }
         if ((rc = rsqc_set_annotation(gpu, &ann.ann, nullptr)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
         if (o.has_bed && (rc = rsqc_set_bed(gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
+        if (o.has_fasta) {
+            fasta_loaded.get();                                               // FileError -> 10
+            std::vector<int32_t> r_contig; std::vector<uint64_t> r_len; std::vector<const uint8_t *> r_seq;
+            for (size_t i = 0; i < fasta.index.size(); ++i) {
+                int cid = -1;
+                for (size_t k = 0; k < ann.contig_names.size(); ++k) if (ann.contig_names[k] == fasta.index[i].name) { cid = (int)k; break; }
+                if (cid < 0) continue;                                        // a contig neither the BAM nor the GTF/BED names
+                r_contig.push_back(cid); r_len.push_back(fasta_seq[i].size()); r_seq.push_back(fasta_seq[i].data());
+            }
+            rsqc_reference ref{(int32_t)r_contig.size(), r_contig.data(), r_len.data(), r_seq.data()};
+            if ((rc = rsqc_set_reference(gpu, &ref)) != RSQC_OK) { cerr << "Failed to load the reference: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 10; }
+            std::vector<std::vector<uint8_t>>().swap(fasta_seq);              // the bases live on the device now
+        }
 
         if (o.verbosity) cout << "Parsing bam..." << endl;
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;

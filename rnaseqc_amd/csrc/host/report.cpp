@@ -275,13 +275,49 @@ void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results 
         std::map<std::string, double> exonCoverage;                               // std::map<string, ExonCoverage>: id order
         for (size_t e = 0; e < ann.exon_list.size(); ++e) if (r.exon_cv_valid[e]) exonCoverage[ann.exon_list[e]] = r.exon_cv[e];
         std::ofstream cvReport(base + ".exon_cv.tsv");
-        cvReport << "Exon ID\tExon CV" << endl;
+        cvReport << "Exon ID\tExon CV";
+        if (r.have_reference) cvReport << "\tGC Content";                          // :633-634
+        cvReport << endl;
         std::vector<double> totalExonCV;
+        if (r.have_reference) {                                                   // :636-640 (ExonCoverage{cv, gc})
+            std::map<std::string, double> exonGC;
+            for (size_t e = 0; e < ann.exon_list.size(); ++e) if (r.exon_cv_valid[e]) exonGC[ann.exon_list[e]] = r.exon_gc[e];
+            for (auto &kv : exonCoverage) { cvReport << kv.first << "\t" << kv.second << "\t" << exonGC[kv.first] << endl; totalExonCV.push_back(kv.second); }
+        } else
         for (auto &kv : exonCoverage) { cvReport << kv.first << "\t" << kv.second << endl; totalExonCV.push_back(kv.second); }
         double a, m, s, d;
         get_statistics(totalExonCV, a, m, s, d);
         output << "Median Exon CV\t" << m << endl;
         output << "Exon CV MAD\t" << d << endl;
+    }
+    if (r.have_reference) {                                                       // :660-674
+        std::ofstream gcReport(base + ".gc_content.tsv");
+        gcReport << "Content Bin\tCount" << endl;
+        // getAdvancedStatistics (src/Metrics.h:188-206) over the bin index repeated gcBins[i] times, ascending
+        double avg = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, count = 0.0;
+        bool any = false;
+        for (unsigned int i = 0; i < RSQC_GC_BINS; ++i) {
+            gcReport << (double)i / 100.0 << "\t" << r.gc_bins[i] << endl;
+            for (uint64_t j = 0; j < r.gc_bins[i]; ++j) {
+                any = true;
+                const double prev_count = count++;
+                const double delta = static_cast<double>(i) - avg;
+                const double delta_n = delta / count;
+                const double delta_n2 = delta_n * delta_n;
+                const double t = delta * delta_n * prev_count;
+                avg += delta_n;
+                m4 += t * delta_n2 * (count * count - 3 * count + 3) + 6 * delta_n2 * m2 - 4 * delta_n * m3;
+                m3 += t * delta_n * (count - 2) - 3 * delta_n * m2;
+                m2 += t;
+            }
+        }
+        double sd = NAN, skew = NAN, kurt = NAN;
+        if (any) { sd = pow(m2 / count, 0.5); skew = m3 / count / pow(sd, 3.0); kurt = (count * m4) / (m2 * m2) - 3; }
+        else avg = NAN;
+        output << "Fragment GC Content Mean\t" << (double)avg / 100.0 << endl;
+        output << "Fragment GC Content Std\t" << (double)sd / 100.0 << endl;
+        output << "Fragment GC Content Skewness\t" << skew << endl;
+        output << "Fragment GC Content Kurtosis\t" << kurt << endl;
     }
     output.close();
 }

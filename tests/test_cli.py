@@ -41,6 +41,9 @@ def test_cli_exit_codes_without_gpu_work(cli, tmp_path):
     assert os.path.isdir(tmp_path / "o")                               # the output dir is created before the BAM is opened
     bamio.write_bam(bam, [("other1", 1000), ("other2", 1000)], batch.slice(0, 0))
     assert run(cli, gtf, bam, str(tmp_path / "o"))[0] == 11            # BAM shares no contigs with the GTF
+    fa = tmp_path / "r.fa"; fa.write_text(">chr1\nACGT\n")
+    assert run(cli, gtf, bam, str(tmp_path / "o"), "--fasta", str(tmp_path / "missing.fa"))[0] == 10   # fileException
+    assert run(cli, gtf, bam, str(tmp_path / "o"), "--fasta", str(fa))[0] == 10                        # no .fai beside it
     empty = tmp_path / "e.gtf"; empty.write_text('c\tx\ttranscript\t1\t5\t.\t+\t.\tgene_id "A"; transcript_id "T";\n')
     assert run(cli, str(empty), bam, str(tmp_path / "o"))[0] == 11     # no genes / exons
 
@@ -63,9 +66,9 @@ def _compare_tables(a, b, skip, tol=1e-6):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["plain", "bed", "legacy"])
+@pytest.mark.parametrize("mode", ["plain", "bed", "legacy", "fasta"])
 def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, mode):
-    with_bed, legacy = mode == "bed", mode == "legacy"
+    with_bed, legacy, with_fasta = mode == "bed", mode == "legacy", mode == "fasta"
     contigs = [("chrA", 900_000, 70), ("chrB", 500_000, 40)]
     ann = synth.make_annotation(seed=41, contigs=contigs)
     batch = synth.make_reads(ann, 40000, seed=42, keep_qnames=True, dup_frac=0.1, frac=(0.85, 0.06, 0.05, 0.04), expr_sigma=1.2,
@@ -78,6 +81,11 @@ def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, 
     if with_bed:
         bamio.write_bed(bedp, ann, bed)
         args += ["--bed", bedp]
+    ref = None
+    if with_fasta:                                               # chrA only: chrB is not in the FASTA index
+        ref = synth.make_reference([contigs[0][1]], seed=43)
+        bamio.write_fasta(str(tmp_path / "ref.fa"), ["chrA"], ref, index_path=str(tmp_path / "ref.fai"))   # <stem>.fai is looked up first
+        args += ["--fasta", str(tmp_path / "ref.fa")]
     if legacy:
         args.append("--legacy")                                  # counting rules + the -q 4 default (src/RNASeQC.cpp:90)
     env = dict(os.environ, RSQC_BATCH="30000")                   # several batches
@@ -85,7 +93,7 @@ def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, 
     assert p.returncode == 0, p.stderr.decode()
     assert "Average Reads/Sec" in p.stdout.decode()
     # expected files: the same C++ report writer fed with the ORACLE's results on the same inputs
-    want = oracle_lib.run_oracle(abi.default_params(**(dict(legacy=1, mapq_threshold=4) if legacy else {})), ann, [batch], bed=bed)
+    want = oracle_lib.run_oracle(abi.default_params(**(dict(legacy=1, mapq_threshold=4) if legacy else {})), ann, [batch], bed=bed, reference=ref)
     h, err = load_annotation(host, gtf, [c[0] for c in contigs], bedp if with_bed else None)
     assert err == 0
     if legacy:
@@ -98,10 +106,15 @@ def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, 
     if with_bed:
         files.append("fragmentSizes.txt")
         assert want.fragment_count.sum() > 50
+    if with_fasta:
+        files.append("gc_content.tsv")
+        assert int(want.gc_bins.sum()) > 500
+        assert "Fragment GC Content Kurtosis" in open(os.path.join(str(tmp_path / "cli"), "s.bam.metrics.tsv")).read()
+        assert open(os.path.join(str(tmp_path / "cli"), "s.bam.exon_cv.tsv")).readline() == "Exon ID\tExon CV\tGC Content\n"
     for f in files:
         skip = 3 if f.endswith(".gct") else 1
         _compare_tables(os.path.join(str(tmp_path / "cli"), "s.bam." + f), os.path.join(exp, "s.bam." + f), skip, tol=1e-5)
     # integer tables must be byte-identical
-    for f in ["gene_reads.gct", "gene_fragments.gct"] + (["fragmentSizes.txt"] if with_bed else []):
+    for f in ["gene_reads.gct", "gene_fragments.gct"] + (["fragmentSizes.txt"] if with_bed else []) + (["gc_content.tsv"] if with_fasta else []):
         assert open(os.path.join(str(tmp_path / "cli"), "s.bam." + f)).read() == open(os.path.join(exp, "s.bam." + f)).read()
     host.host_annotation_free(h)

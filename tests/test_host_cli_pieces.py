@@ -309,6 +309,13 @@ def _results_struct(r):
     rs.read_length = r.read_length
     rs.n_fragment_sizes = len(r.fragment_size)
     rs.fragment_samples_remaining = r.fragment_samples_remaining
+    if getattr(r, "have_reference", 0):
+        rs.have_reference = 1
+        rs.gc_out_of_range = int(r.gc_out_of_range)
+        for f, dt in [("gc_bins", np.uint64), ("exon_gc", np.float64)]:
+            a = np.ascontiguousarray(getattr(r, f), dtype=dt)
+            keep.append(a)
+            setattr(rs, f, abi.ptr(a))
     return rs, keep
 
 
@@ -394,4 +401,40 @@ def test_report_writer_reproduces_single_pair_golden(host, oracle_lib, tmp_path)
     assert g[3] == ["ENSG00000227232.4", "WASH7P", "1000000.000000"]
     e = read_table(os.path.join(out, "single_pair.bam.exon_reads.gct"))
     assert e[1] == ["1", "1"] and len(e) == 16
+    host.host_annotation_free(h)
+
+
+def test_report_writer_gc_outputs(host, oracle_lib, tmp_path):
+    """--fasta outputs of the report tail (src/RNASeQC.cpp:628-674): gc_content.tsv, the GC column of exon_cv.tsv and the
+    four moment lines, the latter against the reference's own getAdvancedStatistics when oracle/_ref is built."""
+    from tests import test_fasta_gc as tg
+    ann, batch, ref = tg.gc_case()
+    r = oracle_lib.run_oracle(abi.default_params(coverage_mask=0), ann, [batch], reference=ref)
+    r.gc_bins[40] += 7; r.gc_bins[41] += 2; r.gc_bins[77] += 5              # a less degenerate histogram
+    gtf = str(tmp_path / "q.gtf")
+    bamio.write_gtf(gtf, ann)
+    h, err = load_annotation(host, gtf, ["chr1", "chr2"])
+    assert err == 0
+    rs, keep = _results_struct(r)
+    out = str(tmp_path / "out"); os.makedirs(out)
+    visit = (C.c_int * 2)(0, 1)
+    assert host.host_write_reports(h, C.byref(rs), out.encode(), b"g.bam", 0, 0, 1, 5, None, 0, visit, 2) == 0
+    gc = read_table(os.path.join(out, "g.bam.gc_content.tsv"))
+    assert gc[0] == ["Content Bin", "Count"] and len(gc) == 101
+    assert gc[1] == ["0", str(int(r.gc_bins[0]))] and gc[34] == ["0.33", str(int(r.gc_bins[33]))] and gc[100][0] == "0.99"
+    cv = read_table(os.path.join(out, "g.bam.exon_cv.tsv"))
+    assert cv[0] == ["Exon ID", "Exon CV", "GC Content"]
+    rows = {row[0]: row for row in cv[1:]}
+    assert rows["GA_1"][2] == "-1" and rows["GC_1"][2] == report_ref.fmt(tg.ref_gc(100, 2001))
+    m = dict(read_table(os.path.join(out, "g.bam.metrics.tsv")))
+    values = np.repeat(np.arange(100), r.gc_bins.astype(np.int64))
+    if oracle_lib.ref_lib() is not None and hasattr(oracle_lib.ref_lib(), "ref_advanced_statistics"):
+        avg, skew, sd, kurt = oracle_lib.ref_advanced_statistics(values)
+    else:                                                                  # moments by definition (looser)
+        avg, sd = values.mean(), values.std()
+        skew = ((values - avg) ** 3).mean() / sd ** 3; kurt = ((values - avg) ** 4).mean() / sd ** 4 - 3
+    for key, val in (("Fragment GC Content Mean", avg / 100.0), ("Fragment GC Content Std", sd / 100.0),
+                     ("Fragment GC Content Skewness", skew), ("Fragment GC Content Kurtosis", kurt)):
+        assert abs(float(m[key]) - val) <= 1e-5 * max(1.0, abs(val)), key
+    assert list(m)[-4:] == ["Fragment GC Content Mean", "Fragment GC Content Std", "Fragment GC Content Skewness", "Fragment GC Content Kurtosis"]
     host.host_annotation_free(h)
