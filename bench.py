@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--dist-selftest", action="store_true",
                     help="(diagnostic) single process, but through the N > 1 code path: 1-rank RCCL group, finalize_device, "
                          "all_reduce of the device accumulators, refresh_results")
+    ap.add_argument("--fasta", action="store_true", help="(diagnostic) with a reference sequence: GC statistics on; output marked invalid")
     ap.add_argument("--legacy", action="store_true", help="(diagnostic) the --legacy counting rules; output marked invalid")
     ap.add_argument("--genome", action="store_true",
                     help="BASELINE.json configs[2] shape on ONE GPU: GENCODE-sized annotation (25 contigs, 56 202 genes); "
@@ -98,6 +99,10 @@ def main():
     if world > 1:
         owned = np.zeros(ann.n_contigs, np.uint8); owned[rank] = 1
     e.set_annotation(ann, owned)
+    if args.fasta:
+        t_ref = time.time()
+        e.set_reference(synth.make_reference([c[1] for c in contigs], seed=7, uniform=True))
+        t_ref = time.time() - t_ref
     h = e.upload(batch)                      # inputs resident in HBM before the timed region
     host_struct = None
     if args.host_fed:                        # the same batch, packed once, in page-locked host memory
@@ -207,6 +212,10 @@ def main():
                                                 "total_alignments": res.counter("Total Alignments")},
             "input_generation_s": round(t_gen, 1),
         }
+        if args.fasta:
+            out["invalid"] = "diagnostic run: --fasta GC statistics on (extra candidate pass + mate pairing per step)"
+            out["gc_fragments"] = None if res is None else int(res.gc_bins.sum())
+            out["reference_setup_s"] = round(t_ref, 2)
         if args.legacy:
             out["invalid"] = "diagnostic run: --legacy counting rules (general per-record kernel, not the headline path)"
         if args.no_finalize:

@@ -108,6 +108,8 @@ struct rsqc_ctx {
     std::vector<size_t> gcs_in_flight;
     std::vector<uint64_t> h_gc;                 // [RSQC_GC_BINS + 1]
     std::vector<double> h_exon_gc;              // by exon id
+    SortScratch gc_scratch;
+    DevBuf gc_merged[6];                        // candidates of several batches side by side (kept between passes)
     // K3 outputs
     bool finalized = false;
 
@@ -439,6 +441,8 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); }
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); }
+    free_sort_scratch(c->gc_scratch);
+    for (auto &b : c->gc_merged) b.release();
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
@@ -881,30 +885,33 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             }
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many GC candidates");
             if (total) {
-                DevBuf m_file, m_q, m_row, m_end, m_fl, m_tid;
-                if ((rc = dev_alloc(c, m_file, total * 8, false)) || (rc = dev_alloc(c, m_q, total * 8, false)) ||
-                    (rc = dev_alloc(c, m_row, total * 4, false)) || (rc = dev_alloc(c, m_end, total * 4, false)) ||
-                    (rc = dev_alloc(c, m_fl, total * 4, false)) || (rc = dev_alloc(c, m_tid, total * 4, false))) return rc;
-                uint64_t at = 0;
-                for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
-                    GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
-                    const size_t n = counts[k];
-                    if (!n) continue;
-                    HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_file.p + at, gb.file.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_q.p + at, gb.qhash.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync((uint32_t *)m_row.p + at, gb.row.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync((int32_t *)m_end.p + at, gb.endpos.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync((uint32_t *)m_fl.p + at, gb.flag_lq.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync((int32_t *)m_tid.p + at, gb.tid.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                    at += n;
+                GcCandidates gc{};
+                if (c->gcs_in_flight.size() == 1) {          // one batch: its candidate arrays are used in place
+                    GcBuf &gb = c->gc_pool[c->gcs_in_flight[0]];
+                    gc = GcCandidates{(uint64_t *)gb.file.p, (uint64_t *)gb.qhash.p, (uint32_t *)gb.row.p, (int32_t *)gb.endpos.p,
+                                      (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, nullptr, (uint32_t)total};
+                } else {
+                    static const size_t width[6] = {8, 8, 4, 4, 4, 4};
+                    for (int f = 0; f < 6; ++f)
+                        if (c->gc_merged[f].bytes < total * width[f] && (rc = dev_alloc(c, c->gc_merged[f], (total + total / 4) * width[f], false))) return rc;
+                    uint64_t at = 0;
+                    for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
+                        GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
+                        const size_t n = counts[k];
+                        if (!n) continue;
+                        const void *src[6] = {gb.file.p, gb.qhash.p, gb.row.p, gb.endpos.p, gb.flag_lq.p, gb.tid.p};
+                        for (int f = 0; f < 6; ++f)
+                            HIP_TRY(c, hipMemcpyAsync((char *)c->gc_merged[f].p + at * width[f], src[f], n * width[f], hipMemcpyDeviceToDevice, c->stream));
+                        at += n;
+                    }
+                    gc = GcCandidates{(uint64_t *)c->gc_merged[0].p, (uint64_t *)c->gc_merged[1].p, (uint32_t *)c->gc_merged[2].p,
+                                      (int32_t *)c->gc_merged[3].p, (uint32_t *)c->gc_merged[4].p, (int32_t *)c->gc_merged[5].p, nullptr, (uint32_t)total};
                 }
-                GcCandidates gc{(uint64_t *)m_file.p, (uint64_t *)m_q.p, (uint32_t *)m_row.p, (int32_t *)m_end.p,
-                                (uint32_t *)m_fl.p, (int32_t *)m_tid.p, nullptr, (uint32_t)total};
-                rc = run_gc_content(c->stream, gc, (uint32_t)total, c->dref, (unsigned long long *)c->d_gc_bins.p);
-                m_file.release(); m_q.release(); m_row.release(); m_end.release(); m_fl.release(); m_tid.release();
+                rc = run_gc_content(c->stream, gc, (uint32_t)total, c->dref, (unsigned long long *)c->d_gc_bins.p, c->gc_scratch);
                 if (rc) return fail(c, rc, "GC content stage failed");
             }
-            HIP_TRY(c, hipMemcpy(c->h_gc.data(), c->d_gc_bins.p, (RSQC_GC_BINS + 1) * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpyAsync(c->h_gc.data(), c->d_gc_bins.p, (RSQC_GC_BINS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     c->fin_e0 = e0; c->fin_e1 = e1;
     return 0;

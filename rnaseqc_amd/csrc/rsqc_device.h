@@ -160,6 +160,10 @@ void launch_gc_pack(hipStream_t s, const uint8_t *ascii, uint64_t len, unsigned 
 void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R, double *exon_gc);
 void launch_gc_candidates(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevReference &R,
                           const GcCandidates &out, int *error);
-// pairs the candidates by QNAME in file order and adds every usable fragment to bins[0..100] (slot 100 = 100 % GC)
-int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins);
+// device scratch of the pairing step, kept by the context between passes (allocation and release synchronise the device)
+struct SortScratch { void *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *tmp = nullptr; size_t cap_n = 0, tmp_bytes = 0; };
+void free_sort_scratch(SortScratch &s);
+// pairs the candidates by QNAME in file order and adds every usable fragment to bins[0..100] (slot 100 = 100 % GC);
+// asynchronous on `stream`
+int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins, SortScratch &scratch);
 }

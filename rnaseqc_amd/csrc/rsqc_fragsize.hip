@@ -123,54 +123,78 @@ int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, 
 
 
 // One thread per candidate in (qhash, file index) order; group starts replay src/Expression.cpp:461-476.
-__global__ void gc_groups_kernel(const uint64_t *sorted_q, const uint32_t *order, const GcCandidates c, uint32_t n,
-                                 const DevReference R, unsigned long long *bins) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint64_t q = sorted_q[j];
-    if (j > 0 && sorted_q[j - 1] == q) return;           // not a group start
-    bool pending = false; uint32_t p_row = 0; int32_t p_end = 0;
-    for (uint32_t k = j; k < n && sorted_q[k] == q; ++k) {
-        const uint32_t e = order[k];
-        const uint32_t row = c.row[e]; const int32_t endpos = c.endpos[e];
-        if (!pending) { pending = true; p_row = row; p_end = endpos; }              // :462-466
-        else if (row == p_row) {                                                    // :467
-            const uint32_t fl = c.flag_lq[e];
-            if (endpos <= p_end || !(fl >> 31)) continue;                            // :471 (the entry stays)
-            pending = false;                                                        // erase, :474
-            const int tid = c.tid[e];
-            const int64_t L = (int64_t)R.length[tid];
-            int64_t s = (int64_t)p_end - (int64_t)(fl & 0x7FFFFFFFu), en = endpos;  // getSeq(chr, stored end - Length(), PositionEnd()) :473
-            if (s < 0 || s >= L) continue;               // outside the contig: error paths of the reference, no fragment here
-            if (en > L) en = L;                          // a page is clipped at the contig end (bioio.hpp:306)
-            if (en <= s) continue;
-            const double v = gc_value(gc_count(R, tid, s, en), (uint64_t)(en - s));
-            const unsigned int bin = (unsigned int)(v * 100.0);                     // src/RNASeQC.cpp:368
-            atomicAdd(&bins[bin < RSQC_GC_BINS ? bin : RSQC_GC_BINS], 1ull);
+// Real fragments pile up in a dozen neighbouring bins, i.e. in two cache lines: memory-side atomics on them serialise
+// (~3 ns each, 3.4 ms per million fragments when every fragment went to memory).  The histogram is therefore kept per
+// workgroup in LDS over a grid-stride loop and flushed once: a few thousand global atomics per launch.
+#define RSQC_GC_GROUP_BLOCKS 512
+__global__ void __launch_bounds__(256)
+gc_groups_kernel(const uint64_t *sorted_q, const uint32_t *order, const GcCandidates c, uint32_t n,
+                 const DevReference R, unsigned long long *bins) {
+    __shared__ uint32_t hist[RSQC_GC_BINS + 1];
+    for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = sorted_q[j];
+        if (j > 0 && sorted_q[j - 1] == q) continue;         // not a group start
+        bool pending = false; uint32_t p_row = 0; int32_t p_end = 0;
+        for (uint64_t k = j; k < n && sorted_q[k] == q; ++k) {
+            const uint32_t e = order[k];
+            const uint32_t row = c.row[e]; const int32_t endpos = c.endpos[e];
+            if (!pending) { pending = true; p_row = row; p_end = endpos; }              // :462-466
+            else if (row == p_row) {                                                    // :467
+                const uint32_t fl = c.flag_lq[e];
+                if (endpos <= p_end || !(fl >> 31)) continue;                            // :471 (the entry stays)
+                pending = false;                                                        // erase, :474
+                const int tid = c.tid[e];
+                const int64_t L = (int64_t)R.length[tid];
+                int64_t s = (int64_t)p_end - (int64_t)(fl & 0x7FFFFFFFu), en = endpos;  // getSeq(chr, stored end - Length(), PositionEnd()) :473
+                if (s < 0 || s >= L) continue;               // outside the contig: error paths of the reference, no fragment here
+                if (en > L) en = L;                          // a page is clipped at the contig end (bioio.hpp:306)
+                if (en <= s) continue;
+                const double v = gc_value(gc_count(R, tid, s, en), (uint64_t)(en - s));
+                const unsigned int bin = (unsigned int)(v * 100.0);                     // src/RNASeQC.cpp:368
+                atomicAdd(&hist[bin < RSQC_GC_BINS ? bin : RSQC_GC_BINS], 1u);
+            }
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += blockDim.x) if (hist[i]) atomicAdd(&bins[i], (unsigned long long)hist[i]);
 }
 
-int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins) {
+void free_sort_scratch(SortScratch &s) {
+    for (void *p : {s.k0, s.k1, s.v0, s.v1, s.v2, s.tmp}) if (p) (void)hipFree(p);
+    s = SortScratch{};
+}
+
+int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins, SortScratch &S) {
     if (n == 0) return 0;
-    uint64_t *k0 = nullptr, *k1 = nullptr;
-    uint32_t *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
-    void *tmp = nullptr;
-    auto cleanup = [&]() { for (void *p : {(void *)k0, (void *)k1, (void *)v0, (void *)v1, (void *)v2, tmp}) if (p) (void)hipFree(p); };
-#define GC_TRY(e) do { if ((e) != hipSuccess) { cleanup(); return RSQC_ERR_HIP; } } while (0)
-    GC_TRY(hipMalloc(&k0, (size_t)n * 8)); GC_TRY(hipMalloc(&k1, (size_t)n * 8));
-    GC_TRY(hipMalloc(&v0, (size_t)n * 4)); GC_TRY(hipMalloc(&v1, (size_t)n * 4)); GC_TRY(hipMalloc(&v2, (size_t)n * 4));
+#define GC_TRY(e) do { if ((e) != hipSuccess) return RSQC_ERR_HIP; } while (0)
+    if (n > S.cap_n) {
+        void *tmp_keep = S.tmp; size_t tmp_bytes_keep = S.tmp_bytes;
+        S.tmp = nullptr;
+        free_sort_scratch(S);
+        S.tmp = tmp_keep; S.tmp_bytes = tmp_bytes_keep;
+        const size_t cap = (size_t)n + n / 4 + 1024;
+        GC_TRY(hipMalloc(&S.k0, cap * 8)); GC_TRY(hipMalloc(&S.k1, cap * 8));
+        GC_TRY(hipMalloc(&S.v0, cap * 4)); GC_TRY(hipMalloc(&S.v1, cap * 4)); GC_TRY(hipMalloc(&S.v2, cap * 4));
+        S.cap_n = cap;
+    }
+    uint64_t *k0 = (uint64_t *)S.k0, *k1 = (uint64_t *)S.k1;
+    uint32_t *v0 = (uint32_t *)S.v0, *v1 = (uint32_t *)S.v1, *v2 = (uint32_t *)S.v2;
     size_t tmp_bytes = 0;
     GC_TRY(sort_pairs_u64(nullptr, tmp_bytes, c.file_index, k0, v0, v1, n, stream));
-    GC_TRY(hipMalloc(&tmp, tmp_bytes + 256));
+    if (tmp_bytes + 256 > S.tmp_bytes) {
+        if (S.tmp) (void)hipFree(S.tmp);
+        S.tmp = nullptr; S.tmp_bytes = tmp_bytes + tmp_bytes / 4 + 4096;
+        GC_TRY(hipMalloc(&S.tmp, S.tmp_bytes));
+    }
     const int T = 256, B = (int)((n + T - 1) / T);
     hipLaunchKernelGGL(frag_iota_kernel, dim3(B), dim3(T), 0, stream, v0, n);
-    GC_TRY(sort_pairs_u64(tmp, tmp_bytes, c.file_index, k0, v0, v1, n, stream));                 // file order
+    GC_TRY(sort_pairs_u64(S.tmp, tmp_bytes, c.file_index, k0, v0, v1, n, stream));               // file order
     hipLaunchKernelGGL(frag_gather_u64_kernel, dim3(B), dim3(T), 0, stream, c.qhash, v1, k0, n);
-    GC_TRY(sort_pairs_u64(tmp, tmp_bytes, k0, k1, v1, v2, n, stream));                           // stable by QNAME hash
-    hipLaunchKernelGGL(gc_groups_kernel, dim3(B), dim3(T), 0, stream, k1, v2, c, n, R, bins);
-    GC_TRY(hipStreamSynchronize(stream));
-    cleanup();
+    GC_TRY(sort_pairs_u64(S.tmp, tmp_bytes, k0, k1, v1, v2, n, stream));                         // stable by QNAME hash
+    hipLaunchKernelGGL(gc_groups_kernel, dim3(B < RSQC_GC_GROUP_BLOCKS ? B : RSQC_GC_GROUP_BLOCKS), dim3(T), 0, stream, k1, v2, c, n, R, bins);
+    GC_TRY(hipGetLastError());
 #undef GC_TRY
     return 0;
 }

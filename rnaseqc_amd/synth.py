@@ -474,7 +474,7 @@ def make_bed(ann: Annotation, min_len: int = 1000) -> Bed:
     return Bed.from_intervals(c[idx], s[idx] - 1, e[idx])
 
 
-def make_reference(contig_lengths, seed: int = 0, contigs=None, gc_wave: int = 50_000):
+def make_reference(contig_lengths, seed: int = 0, contigs=None, gc_wave: int = 50_000, uniform: bool = False):
     """Random base strings for the given contigs (ids default to 0..n-1): GC fraction drifting between 0.3 and 0.7
     along the contig, a few lower-case stretches and N runs (only G/g/C/c count, src/Fasta.cpp:67-74)."""
     from .model import Reference
@@ -482,6 +482,9 @@ def make_reference(contig_lengths, seed: int = 0, contigs=None, gc_wave: int = 5
     seqs = []
     for L in contig_lengths:
         L = int(L)
+        if uniform:                                                 # large contigs (bench): uniform ACGT, no drift
+            seqs.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L, dtype=np.uint8)])
+            continue
         x = np.arange(L, dtype=np.float64)
         pgc = 0.5 + 0.2 * np.sin(x / gc_wave * 2 * np.pi + rng.random() * 6.28)
         is_gc = rng.random(L) < pgc
