@@ -38,7 +38,7 @@ def merge_results(local, dist=None, device=None):
     `dist` is torch.distributed (initialised) or None for a single rank.  Additive: gene reads /
     unique / fragments, exon fractions, scalar counters, fragment-size histogram.  Owner-only
     (zero on non-owners, so a sum is a merge): per-gene coverage mean/std/CV/valid, exon CV,
-    bias accumulators.  Read Length: exact when every shard's eligible records share one l_qseq
+    bias accumulators.  --fasta: the fragment GC histogram is additive.  Read Length: exact when every shard's eligible records share one l_qseq
     (see DESIGN.md); shards are combined in contig order.
     """
     import torch
@@ -80,4 +80,11 @@ def merge_results(local, dist=None, device=None):
     nz = np.flatnonzero(rl)
     m.read_length = int(rl[nz[-1]]) if len(nz) else 0
     m.read_length_per_rank = rl
+    # --fasta: both mates of a GC fragment lie in one exon, hence on one contig -> the histogram is additive; exon GC
+    # values depend on the annotation and the reference only (identical on every rank)
+    m.have_reference = int(getattr(local, "have_reference", 0))
+    if m.have_reference:
+        m.gc_bins = allsum(local.gc_bins, np.int64).astype(np.uint64)
+        m.gc_out_of_range = int(allsum(np.array([local.gc_out_of_range]), np.int64)[0])
+        m.exon_gc = np.array(local.exon_gc)
     return m

@@ -41,10 +41,13 @@ def _worker(rank, world, port, out_dir):
     runs = np.split(idx, np.flatnonzero(np.diff(idx) != 1) + 1) if len(idx) else []
     parts = [batch.slice(int(r[0]), int(r[-1]) + 1) for r in runs]
     p = abi.default_params()
-    local = binding.run_oracle(p, ann, parts, owned=distributed.owned_mask(rank_of, rank))
+    ref = synth.make_reference([c[1] for c in contigs], seed=23)
+    local = binding.run_oracle(p, ann, parts, owned=distributed.owned_mask(rank_of, rank), reference=ref)
     merged = distributed.merge_results(local, dist)
     if rank == 0:
-        whole = binding.run_oracle(p, ann, [batch])
+        whole = binding.run_oracle(p, ann, [batch], reference=ref)
+        np.testing.assert_array_equal(merged.gc_bins, whole.gc_bins)
+        assert int(whole.gc_bins.sum()) > 300 and merged.gc_out_of_range == whole.gc_out_of_range
         np.testing.assert_array_equal(merged.gene_reads, whole.gene_reads)
         np.testing.assert_array_equal(merged.gene_unique, whole.gene_unique)
         np.testing.assert_array_equal(merged.gene_fragments, whole.gene_fragments)
