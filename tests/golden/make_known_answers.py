@@ -44,5 +44,19 @@ for name, prefix in [("chr1", "chr1.output/chr1.bam"), ("downsampled", "downsamp
         f = gzip.open(os.path.join(REF, prefix + ".gene_fragments.gct.gz"), "rt").read().split("\n")
         d["gene_fragments_sum"] = sum(int(l.split("\t")[2]) for l in f[3:] if l)
     out[name] = d
+# --fasta run of the chr1 case (CRAM input): the GC histogram and the metrics.tsv it belongs to
+d = {"metrics_keys": [], "metrics": {}}
+for line in open(os.path.join(REF, "chr1.output/chr1.cram.metrics.tsv")):
+    k, v = line.rstrip("\n").split("\t")
+    d["metrics"][k] = v; d["metrics_keys"].append(k)
+d["gc_bins"] = [int(l.split("\t")[1]) for i, l in enumerate(open(os.path.join(REF, "chr1.output/chr1.cram.gc_content.tsv"))) if i]
+d["gc_bin_labels"] = [l.split("\t")[0] for i, l in enumerate(open(os.path.join(REF, "chr1.output/chr1.cram.gc_content.tsv"))) if i]
+out["chr1_cram"] = d
+# --legacy run of the downsampled case
+d = {"metrics_keys": [], "metrics": {}}
+for line in open(os.path.join(REF, "legacy.output/downsampled.bam.metrics.tsv")):
+    k, v = line.rstrip("\n").split("\t")
+    d["metrics"][k] = v; d["metrics_keys"].append(k)
+out["legacy"] = d
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json"), "w"))
 print({k: list(v.keys()) for k, v in out.items()})

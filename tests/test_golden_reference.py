@@ -99,3 +99,64 @@ def test_single_pair_golden_reconstruction(oracle_lib):
     # Genes Detected 0 (needs 5 unique reads), bias genes 0
     assert int((r.gene_unique >= 5).sum()) == int(m["Genes Detected"])
     assert int(((r.bias_three + r.bias_five) > 0).sum()) == int(m["Genes used in 3' bias"])
+
+
+def test_gc_moment_lines_reproduce_golden(oracle_lib, tmp_path):
+    """chr1.cram golden (--fasta run): the four "Fragment GC Content" lines of metrics.tsv must come out of the golden
+    gc_content.tsv histogram through OUR report tail, digit for digit, and gc_content.tsv itself must be re-emitted
+    byte for byte (labels i/100 in default ostream format)."""
+    import ctypes as C
+    from rnaseqc_amd import abi, bamio
+    from tests import test_fasta_gc as tg
+    from tests.test_host_cli_pieces import _results_struct, load_annotation, read_table
+    import subprocess
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "rnaseqc_amd", "csrc"), "../lib/librsqc_host.so"])
+    host = C.CDLL(os.path.join(root, "rnaseqc_amd", "lib", "librsqc_host.so"))
+    host.host_annotation_load.restype = C.c_void_p
+    host.host_annotation_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+    host.host_write_reports.argtypes = [C.c_void_p, C.POINTER(abi.ResultsStruct), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_uint, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int), C.c_int]
+    host.host_annotation_free.argtypes = [C.c_void_p]
+    ann, batch, ref = tg.gc_case()
+    r = oracle_lib.run_oracle(abi.default_params(coverage_mask=0), ann, [batch], reference=ref)
+    g = KA["chr1_cram"]
+    r.gc_bins[:] = np.array(g["gc_bins"], dtype=np.uint64)
+    gtf = str(tmp_path / "q.gtf"); bamio.write_gtf(gtf, ann)
+    h, err = load_annotation(host, gtf, ["chr1", "chr2"])
+    assert err == 0
+    rs, keep = _results_struct(r)
+    out = str(tmp_path / "out"); os.makedirs(out)
+    visit = (C.c_int * 2)(0, 1)
+    assert host.host_write_reports(h, C.byref(rs), out.encode(), b"g.bam", 0, 0, 1, 5, None, 0, visit, 2) == 0
+    m = dict(read_table(os.path.join(out, "g.bam.metrics.tsv")))
+    for k in ("Fragment GC Content Mean", "Fragment GC Content Std", "Fragment GC Content Skewness", "Fragment GC Content Kurtosis"):
+        assert m[k] == g["metrics"][k], (k, m[k], g["metrics"][k])
+    rows = read_table(os.path.join(out, "g.bam.gc_content.tsv"), 1)
+    assert [x[0] for x in rows] == g["gc_bin_labels"] and [int(x[1]) for x in rows] == g["gc_bins"]
+    assert list(m)[-4:] == g["metrics_keys"][-4:]
+    host.host_annotation_free(h)
+
+
+def test_legacy_golden_invariants(oracle_lib):
+    """legacy.output golden (--legacy run of the downsampled case): properties of the rule set that do not depend on the
+    missing input, checked on the golden AND on our restatement: no globin and no "Ambiguous" counters, every counted
+    read in exactly one of exonic / intronic / intergenic, intragenic = exonic + intronic, "Split Reads" printed between
+    "rRNA Reads" and "Total Bases"."""
+    from rnaseqc_amd import abi, synth
+    g = KA["legacy"]["metrics"]
+    our = None
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 3_000_000, 300), ("chrB", 1_500_000, 150)])
+    batch = synth.make_reads(ann, 20000, seed=4, dup_frac=0.1, contig_lengths=np.array([3_000_000, 1_500_000]))
+    r = oracle_lib.run_oracle(abi.default_params(legacy=1, mapq_threshold=4), ann, [batch])
+    our = {k: str(v) for k, v in r.counter_dict().items()}
+    for m in (g, our):
+        i = {k: int(m[k]) for k in ("Exonic Reads", "Intronic Reads", "Intergenic Reads", "Intragenic Reads",
+                                    "Reads used for Intron/Exon counts", "Non-Globin Reads", "Non-Globin Duplicate Reads",
+                                    "Ambiguous Reads", "Split Reads")}
+        assert i["Non-Globin Reads"] == 0 and i["Non-Globin Duplicate Reads"] == 0 and i["Ambiguous Reads"] == 0
+        assert i["Exonic Reads"] + i["Intronic Reads"] + i["Intergenic Reads"] == i["Reads used for Intron/Exon counts"]
+        assert i["Intragenic Reads"] == i["Exonic Reads"] + i["Intronic Reads"]
+        assert 0 < i["Split Reads"] <= i["Exonic Reads"]
+    keys = KA["legacy"]["metrics_keys"]
+    assert keys.index("rRNA Reads") + 1 == keys.index("Split Reads") == keys.index("Total Bases") - 1
