@@ -2,6 +2,7 @@
 
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -120,13 +121,37 @@ void BamReader::set_threads(int n) {
     pool_inflate_ = new WorkPool(n);
 }
 
+// libdeflate (whole-buffer inflate, 2-3x zlib on BGZF-sized blocks) when the shared library is on the system: it ships
+// without headers in this image, so its three entry points are bound at run time; zlib otherwise (RSQC_HOST_ZLIB=1 forces it).
+namespace {
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;   // 0 = LIBDEFLATE_SUCCESS
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;                              // libdeflate_crc32 (carry-less multiply)
+    bool ok = false;
+    LibDeflate() {
+        if (const char *e = getenv("RSQC_HOST_ZLIB")) if (atoi(e)) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc && decompress && release && crc;
+    }
+};
+const LibDeflate &libdeflate() { static const LibDeflate d; return d; }
+}  // namespace
+
 // BGZF blocks are independent deflate streams whose uncompressed size sits in the trailer, so a group of
 // blocks is framed sequentially (headers only) and inflated in parallel straight into place.
 bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
     size_t GROUP_BYTES = (size_t)64 << 20;              // uncompressed bytes per group
     if (const char *e = getenv("RSQC_HOST_GROUP_BYTES")) GROUP_BYTES = std::max<size_t>(1, (size_t)atoll(e));   // (tests: many small groups)
     const size_t READ_CHUNK = (size_t)16 << 20;
-    struct Blk { size_t coff, clen, out; uint32_t isize; };
+    struct Blk { size_t coff, clen, out; uint32_t isize, crc; };
     std::vector<Blk> blks;
     size_t total = 0;
     for (;;) {
@@ -150,7 +175,7 @@ bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
             if (avail < bsize) break;
             const size_t clen = bsize - xlen - 12 - 8;
             const uint32_t isize = le32(h + bsize - 4);
-            blks.push_back(Blk{cpos_ + 12 + xlen, clen, total, isize});
+            blks.push_back(Blk{cpos_ + 12 + xlen, clen, total, isize, le32(h + bsize - 8)});
             total += isize;
             cpos_ += bsize;
         }
@@ -176,10 +201,27 @@ bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
     const double ti = now_s();
     // tasks of 4 consecutive blocks (fine enough to balance across ~100 threads): one z_stream per task
     const size_t per = 4, n_tasks = (blks.size() + per - 1) / per;
+    const LibDeflate &ld = libdeflate();
     pool_inflate_->run(n_tasks, [&](size_t t) {
+        const size_t b0 = t * per, b1 = std::min(blks.size(), b0 + per);
+        if (ld.ok) {
+            void *d = ld.alloc();
+            if (!d) throw std::runtime_error("libdeflate: out of memory");
+            for (size_t k = b0; k < b1; ++k) {
+                const Blk &bk = blks[k];
+                if (!bk.isize) continue;
+                // exact fill required; the block's CRC-32 is checked like htslib's bgzf reader does
+                if (ld.decompress(d, cdata + bk.coff, bk.clen, odata + bk.out, bk.isize, nullptr) != 0 ||
+                    ld.crc(0, odata + bk.out, bk.isize) != bk.crc) {
+                    ld.release(d);
+                    throw std::runtime_error("BGZF inflate failed (corrupt block)");
+                }
+            }
+            ld.release(d);
+            return;
+        }
         z_stream zs{};
         if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
-        const size_t b0 = t * per, b1 = std::min(blks.size(), b0 + per);
         for (size_t k = b0; k < b1; ++k) {
             const Blk &bk = blks[k];
             if (!bk.isize) continue;
@@ -187,7 +229,9 @@ bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
             zs.next_in = const_cast<uint8_t *>(cdata + bk.coff); zs.avail_in = (uInt)bk.clen;
             zs.next_out = odata + bk.out; zs.avail_out = bk.isize;
             const int rc = inflate(&zs, Z_FINISH);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw std::runtime_error("BGZF inflate failed"); }
+            if (rc != Z_STREAM_END || zs.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), odata + bk.out, bk.isize) != bk.crc) {
+                inflateEnd(&zs); throw std::runtime_error("BGZF inflate failed (corrupt block)");
+            }
         }
         inflateEnd(&zs);
     });

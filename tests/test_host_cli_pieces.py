@@ -438,3 +438,39 @@ def test_report_writer_gc_outputs(host, oracle_lib, tmp_path):
         assert abs(float(m[key]) - val) <= 1e-5 * max(1.0, abs(val)), key
     assert list(m)[-4:] == ["Fragment GC Content Mean", "Fragment GC Content Std", "Fragment GC Content Skewness", "Fragment GC Content Kurtosis"]
     host.host_annotation_free(h)
+
+
+def test_bam_decode_inflate_backends_agree(host, tmp_path):
+    """BGZF inflate goes through libdeflate when the shared library is present and through zlib otherwise
+    (RSQC_HOST_ZLIB=1 forces zlib): same records either way, and a damaged block is an error in both."""
+    import sys
+    ann = synth.make_annotation(seed=37, contigs=[("chrA", 2_000_000, 100)])
+    batch = synth.make_reads(ann, 20_000, seed=38, keep_qnames=True, contig_lengths=np.array([2_000_000]))
+    path = str(tmp_path / "b.bam")
+    bamio.write_bam(path, [("chrA", 2_000_000)], batch)
+    bad = str(tmp_path / "bad.bam")
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0x5A; raw[len(raw) // 2 + 1] ^= 0xA5          # inside some block's deflate stream
+    open(bad, "wb").write(bytes(raw))
+    code = (
+        "import ctypes as C, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from rnaseqc_amd import abi\n"
+        "lib = C.CDLL(%r)\n"
+        "lib.host_bam_read_all_ex.restype = C.c_void_p\n"
+        "lib.host_bam_read_all_ex.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_ulonglong]\n"
+        "lib.host_bam_batch.restype = C.POINTER(abi.BatchStruct); lib.host_bam_batch.argtypes = [C.c_void_p]\n"
+        "h = lib.host_bam_read_all_ex(sys.argv[1].encode(), b'ch', None, 0, 4, 1 << 20)\n"
+        "if not h: print('ERR'); sys.exit(0)\n"
+        "b = lib.host_bam_batch(h).contents\n"
+        "core = abi._view(b.core, b.n, abi.REC_CORE); aux = abi._view(b.aux, b.n, abi.REC_AUX)\n"
+        "print(b.n, int(core['pos'].astype(np.int64).sum()), int(aux['qhash'].sum() & np.uint64(0xFFFFFFFF)), b.n_cigar_total)\n"
+    ) % (ROOT, SO)
+    outs = {}
+    for name, env in (("libdeflate", {}), ("zlib", {"RSQC_HOST_ZLIB": "1"})):
+        for f in (path, bad):
+            p = subprocess.run([sys.executable, "-c", code, f], stdout=subprocess.PIPE, env=dict(os.environ, **env))
+            outs[(name, f)] = p.stdout.decode().strip()
+    assert outs[("libdeflate", path)] == outs[("zlib", path)] and outs[("zlib", path)].split()[0] == str(batch.n)
+    assert int(outs[("zlib", path)].split()[1]) == int(batch.pos.astype(np.int64).sum())
+    assert outs[("libdeflate", bad)] == "ERR" and outs[("zlib", bad)] == "ERR"
