@@ -42,6 +42,11 @@ for rep in range(2):                       # second run: page cache warm, GPU dr
     e = re.search(r"Time Elapsed: ([0-9.e+-]+)", p.stdout)
     runs.append({"rc": p.returncode, "wall_s": round(wall, 3), "bam_loop_s": float(e.group(1)) if e else None,
                  "bam_loop_reads_per_s": float(m.group(1)) if m else None})
+# the same file with zlib forced for the BGZF inflate (default: libdeflate when the shared library is present)
+t = time.time()
+p = subprocess.run([os.path.join(ROOT, "rnaseqc_amd", "bin", "rnaseqc"), gtf, bam, out, "-vv"], env=dict(env, RSQC_HOST_ZLIB="1"), capture_output=True, text=True)
+m = re.search(r"Average Reads/Sec: ([0-9.e+]+)", p.stdout)
+zlib_run = {"rc": p.returncode, "wall_s": round(time.time() - t, 3), "bam_loop_reads_per_s": float(m.group(1)) if m else None}
 print(json.dumps({"records": int(batch.n), "bam_bytes": os.path.getsize(bam), "genes": int(ann.n_genes),
                   "decode_only_s": round(t_dec, 3), "decode_only_reads_per_s": batch.n / t_dec,
-                  "threads": args.threads or "default", "cli_runs": runs, "gen_s": round(t_gen, 1), "bam_write_s": round(t_bam, 1)}))
+                  "threads": args.threads or "default", "cli_runs": runs, "cli_run_zlib": zlib_run, "gen_s": round(t_gen, 1), "bam_write_s": round(t_bam, 1)}))
