@@ -253,14 +253,17 @@ int main(int argc, char **argv) {
         if (rc != RSQC_OK) { cerr << "Unable to initialise the GPU hot path: " << rsqc_strerror(rc) << endl; return 10; }
         if ((rc = rsqc_set_annotation(gpu, &ann.ann, nullptr)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
         if (o.has_bed && (rc = rsqc_set_bed(gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
+        std::vector<char> in_fasta;
         if (o.has_fasta) {
             fasta_loaded.get();                                               // FileError -> 10
+            in_fasta.assign(ann.contig_names.size(), 0);
             std::vector<int32_t> r_contig; std::vector<uint64_t> r_len; std::vector<const uint8_t *> r_seq;
             for (size_t i = 0; i < fasta.index.size(); ++i) {
                 int cid = -1;
                 for (size_t k = 0; k < ann.contig_names.size(); ++k) if (ann.contig_names[k] == fasta.index[i].name) { cid = (int)k; break; }
                 if (cid < 0) continue;                                        // a contig neither the BAM nor the GTF/BED names
                 r_contig.push_back(cid); r_len.push_back(fasta_seq[i].size()); r_seq.push_back(fasta_seq[i].data());
+                in_fasta[(size_t)cid] = 1;
             }
             rsqc_reference ref{(int32_t)r_contig.size(), r_contig.data(), r_len.data(), r_seq.data()};
             if ((rc = rsqc_set_reference(gpu, &ref)) != RSQC_OK) { cerr << "Failed to load the reference: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 10; }
@@ -285,7 +288,12 @@ int main(int argc, char **argv) {
             const size_t n = bam.read_batch(hb, BATCH);              // decode overlaps the previous batch on the GPU
             if (in_flight) { if ((rc = rsqc_wait(gpu)) != RSQC_OK) break; in_flight = false; }
             if (n == 0) break;
-            for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t)) visit.push_back(t);
+            for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t)) {
+                visit.push_back(t);
+                if (o.has_fasta && (size_t)t < in_fasta.size() && !in_fasta[(size_t)t])      // src/RNASeQC.cpp:350-352
+                    cerr << "Warning: Provided Fasta does not contain chromosome " << ann.contig_names[(size_t)t]
+                         << ". No GC statistics will be collected for this chromosome" << endl;
+            }
             alignmentCount += n;
             rsqc_batch view = hb.view();
             if ((rc = rsqc_submit(gpu, &view)) != RSQC_OK) break;
