@@ -11,6 +11,7 @@ from rnaseqc_amd.model import Annotation, Batch
 from tests import cases, hostemu
 
 M, I, D, N, S = abi.CIG_M, abi.CIG_I, abi.CIG_D, abi.CIG_N, abi.CIG_S
+H, P, EQ, X = abi.CIG_H, abi.CIG_P, abi.CIG_EQ, abi.CIG_X
 
 
 def _legacy_params(**kw):
@@ -195,3 +196,50 @@ def test_row_order_decides_split_reads(oracle_lib):
             assert int(x.counters[abi.COUNTER_INDEX["Split Reads"]]) == want
             assert int(x.counters[abi.COUNTER_INDEX["Exonic Reads"]]) == 1
             assert int(x.gene_reads[ann.gene_ids.index("H")]) == 1 and int(x.gene_reads[ann.gene_ids.index("G")]) == 0
+
+
+def stacked_case(seed):
+    rng=np.random.default_rng(seed)
+    rows=[]; span=4000
+    # stacks of genes sharing coordinates (more than FAST_SET per block), plus ordinary ones
+    for g in range(int(rng.integers(5,30))):
+        if rng.random()<0.4 and rows:
+            base=rows[int(rng.integers(0,len(rows)))]
+            gs,ge=base['start'],base['end']
+        else:
+            gs=int(rng.integers(1,span-500)); ge=gs+int(rng.integers(50,1200))
+        strand="+-."[int(rng.integers(0,3))]
+        rows.append(dict(contig="c",type="gene",start=gs,end=ge,strand=strand,gene_id="G%d"%g,transcript_type="rRNA" if rng.random()<0.1 else "x"))
+        ne=int(rng.integers(0,6))
+        cuts=np.sort(rng.integers(gs,ge+1,2*ne))
+        for e in range(ne):
+            rows.append(dict(contig="c",type="exon",start=int(cuts[2*e]),end=int(cuts[2*e+1]),strand=strand,gene_id="G%d"%g,exon_id="G%d_%d"%(g,e)))
+    ann=Annotation.from_rows(["c","d"],rows)
+    recs=[]
+    starts=np.sort(rng.integers(0,span,1200)); starts[:5]=0
+    for i,pos in enumerate(starts):
+        cig=[]
+        nb=int(rng.choice([1,1,1,2,2,3,4,5,6,8]))
+        if rng.random()<0.1: cig.append((H,3))
+        if rng.random()<0.2: cig.append((S,int(rng.integers(1,9))))
+        for b in range(nb):
+            if b: cig.append((int(rng.choice([N,N,D,P])), int(rng.choice([0,1,30,99,100,101,300]))))
+            if rng.random()<0.1: cig.append((I,2))
+            cig.append((int(rng.choice([M,M,M,EQ,X])), int(rng.integers(0 if rng.random()<0.05 else 1,90))))
+        if rng.random()<0.1: cig.append((S,4))
+        flag=0x1|(0x2 if rng.random()<0.9 else 0)|(0x10 if rng.random()<0.5 else 0)|(0x40 if rng.random()<0.5 else 0x80)|(0x400 if rng.random()<0.05 else 0)|(0x800 if rng.random()<0.02 else 0)|(0x100 if rng.random()<0.02 else 0)
+        if rng.random()<0.03: flag&=~1
+        recs.append(dict(qname="q%d"%int(rng.integers(0,700)),tid=0,pos=int(pos),cigar=cig,flag=flag,mapq=int(rng.choice([0,4,60,255])),nm=int(rng.integers(0,9)) if rng.random()<0.9 else None,mpos=int(pos)+int(rng.integers(-50,300)),mtid=0 if rng.random()<0.95 else 1, ch=bool(rng.random()<0.03), isize=int(rng.integers(-1200,1200))))
+    return ann,Batch.from_records(recs)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stacked_genes_and_long_cigars_vs_oracle(oracle_lib, seed):
+    """Genes stacked on identical coordinates (more genes per block than the fast path holds), up to 8 blocks per read,
+    zero-length and padding operations, supplementary / secondary / unpaired / chimeric-tagged records, reads at
+    position 0 -- both rule sets (a 720-comparison sweep of this generator ran clean when it was added)."""
+    ann, batch = stacked_case(seed)
+    for legacy in (0, 1):
+        for kw in (dict(), dict(stranded=abi.STRAND_FORWARD, exclude_chimeric=1), dict(stranded=abi.STRAND_REVERSE, unpaired=1, base_mismatch=3)):
+            p = _legacy_params(**kw) if legacy else abi.default_params(mapq_threshold=4, **kw)
+            _compare(hostemu.run(p, ann, batch), oracle_lib.run_oracle(p, ann, [batch]))
