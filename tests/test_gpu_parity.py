@@ -318,6 +318,10 @@ def test_legacy_hand_derived_and_hostile_cases(oracle_lib):
         for kw in (dict(), dict(stranded=abi.STRAND_FORWARD)):
             p = tl._legacy_params(coverage_mask=20, **kw)
             assert_results_match(engine.run_engine(p, ann, [batch]), oracle_lib.run_oracle(p, ann, [batch]))
+    for seed in range(2):                         # stacked genes: more genes per read than the kernel returns in registers
+        ann, batch = tl.stacked_case(seed)
+        for p in (tl._legacy_params(coverage_mask=20), abi.default_params(mapq_threshold=4, coverage_mask=20)):
+            assert_results_match(engine.run_engine(p, ann, [batch]), oracle_lib.run_oracle(p, ann, [batch]))
 
 
 def test_legacy_deep_coverage_and_batches(oracle_lib):
