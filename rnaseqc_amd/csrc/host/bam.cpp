@@ -355,14 +355,12 @@ static bool aux_int(const uint8_t *v, char type, int32_t &out) {
 
 // ---- record framing ---------------------------------------------------------------------------------
 // A BAM record can only be located by hopping from the previous one (block_size), one dependent cache miss per
-// record.  The window is therefore cut into chunks that are framed IN PARALLEL from a guessed record start
-// (the first offset where two consecutive records pass a structural check), and the guesses are then verified
+// record.  The window is therefore cut into chunks that are framed (and parsed) IN PARALLEL from a guessed record
+// start (the first offset where two consecutive records pass a structural check), and the guesses are then verified
 // sequentially: chunk c's guess is accepted only if the TRUE chain of chunk c-1 (which starts at a verified
-// boundary) ends exactly on it; otherwise chunk c is re-framed from the true position.  The result is exact --
+// boundary) ends exactly on it; otherwise chunk c is redone from the true position.  The result is exact --
 // a wrong guess costs time, never correctness.
 namespace {
-struct Framed { std::vector<uint32_t> off; std::vector<uint32_t> ncig; size_t start = 0, end = 0; bool guessed = false; };
-
 inline bool plausible_record(const uint8_t *buf, size_t p, size_t end, int32_t n_ref) {
     if (p + 36 > end) return false;
     const uint32_t bs = le32(buf + p);
@@ -378,27 +376,124 @@ inline bool plausible_record(const uint8_t *buf, size_t p, size_t end, int32_t n
     if (p + 4 + 32 + l_name <= end && r[32 + l_name - 1] != 0) return false;     // QNAME is NUL-terminated
     return true;
 }
-// hop from `p` while records are complete and start before `limit`; returns the first start >= limit (or the
-// start of the first incomplete record)
-inline size_t frame_from(const uint8_t *buf, size_t p, size_t limit, size_t end, size_t base, Framed &f, size_t max_records) {
-    while (p < limit && p + 4 <= end && f.off.size() < max_records) {
-        const uint32_t bs = le32(buf + p);
-        if (bs < 32) throw std::runtime_error("bad BAM record");
-        if (p + 4 + (size_t)bs > end) break;
-        f.off.push_back((uint32_t)(p - base));
-        f.ncig.push_back(le16(buf + p + 4 + 12));
-        p += 4 + (size_t)bs;
+}  // namespace
+
+// One pass per chunk: a worker hops through the records of its chunk from the guessed start AND parses each one while
+// it is in cache, into chunk-local arrays (a record is ~190 bytes of which framing needs 6 and parsing ~100: framing
+// first and parsing later read every record's lines from memory twice).  After the sequential verification of the
+// guesses the chunk-local arrays are copied to their final place in parallel (40 bytes per record).
+namespace {
+struct ChunkOut {
+    size_t start = 0, end = 0; bool guessed = false;
+    std::vector<uint32_t> cig_end;                       // per record: CIGAR words of the chunk up to and including it
+    std::vector<rsqc_rec_core> core;                     // cigar_off relative to the chunk
+    std::vector<rsqc_rec_aux> aux;
+    std::vector<uint32_t> cig;
+    std::vector<std::pair<uint32_t, int32_t>> segs;      // (local record index, tid): contig changes inside the chunk (+ its first record)
+    std::vector<uint32_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc;
+    int32_t last_tid = 0;
+    void clear() { core.clear(); aux.clear(); cig.clear(); cig_end.clear(); segs.clear(); widx.clear(); wnm.clear(); wlq.clear(); wnc.clear(); last_tid = 0; }
+    size_t size() const { return core.size(); }
+    // keep the first k records
+    void truncate(size_t k) {
+        if (k >= core.size()) return;
+        const uint32_t nc = k ? cig_end[k - 1] : 0u;
+        core.resize(k); aux.resize(k); cig_end.resize(k); cig.resize(nc);
+        while (!segs.empty() && segs.back().first >= k) segs.pop_back();
+        while (!widx.empty() && widx.back() >= k) { widx.pop_back(); wnm.pop_back(); wlq.pop_back(); wnc.pop_back(); }
+        last_tid = segs.empty() ? 0 : segs.back().second;
     }
+};
+struct TagSpec { char ch0 = 0, ch1 = 0; bool have_ch = false; int n_filter = 0; char f0[RSQC_MAX_FILTER_TAGS], f1[RSQC_MAX_FILTER_TAGS]; };
+
+// hop from `p` while records are complete and start before `limit`, parsing each into `o`; returns the first start
+// >= limit (or the start of the first incomplete record)
+size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, const TagSpec &tags, ChunkOut &o) {
+    bool have_last = false; int32_t last_tid = 0;
+    while (p < limit && p + 4 <= end) {
+        const uint32_t block_size = le32(buf + p);
+        if (block_size < 32) throw std::runtime_error("bad BAM record");
+        if (p + 4 + (size_t)block_size > end) break;
+        const uint8_t *r = buf + p + 4;
+        const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
+        const uint8_t l_read_name = r[8], mapq = r[9];
+        const uint16_t n_cigar = le16(r + 12), flag = le16(r + 14);
+        const int32_t l_seq = (int32_t)le32(r + 16), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24), isize = (int32_t)le32(r + 28);
+        const char *qname = (const char *)r + 32;
+        const uint8_t *cig = r + 32 + l_read_name;
+        const uint8_t *end_r = r + block_size;
+        const uint8_t *auxp = cig + 4 * (size_t)n_cigar + (size_t)((l_seq < 0 ? 0 : l_seq + 1) / 2) + (size_t)(l_seq < 0 ? 0 : l_seq);
+        if (cig + 4 * (size_t)n_cigar > end_r) throw std::runtime_error("bad BAM record");
+        const uint32_t k = (uint32_t)o.core.size();
+        // a chunk's first record always opens a provisional segment; whether it continues the previous chunk's contig
+        // is decided at merge time
+        if (!have_last || last_tid != tid) o.segs.emplace_back(k, tid);
+        have_last = true; last_tid = tid;
+        rsqc_rec_core co{pos, mpos, isize, (uint32_t)o.cig.size()};
+        rsqc_rec_aux au{};
+        const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
+        au.qhash = rsqc_qname_hash(qname, qlen);
+        au.flag = flag; au.mapq = mapq;
+        uint8_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
+        int32_t nm = 0;
+        for (const uint8_t *q = auxp; q + 3 <= end_r;) {
+            const char t0 = (char)q[0], t1 = (char)q[1], type = (char)q[2];
+            const uint8_t *v = q + 3;
+            size_t vlen = 0;
+            switch (type) {
+            case 'A': case 'c': case 'C': vlen = 1; break;
+            case 's': case 'S': vlen = 2; break;
+            case 'i': case 'I': case 'f': vlen = 4; break;
+            case 'Z': case 'H': vlen = strnlen((const char *)v, (size_t)(end_r - v)) + 1; break;
+            case 'B': { if (v + 5 > end_r) { vlen = (size_t)(end_r - v); break; }
+                        const char st = (char)v[0]; const uint32_t cnt = le32(v + 1);
+                        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; vlen = 5 + es * (size_t)cnt; break; }
+            default: vlen = (size_t)(end_r - v); break;
+            }
+            if (v + vlen > end_r) break;                                            // malformed tail: stop scanning
+            if (t0 == 'N' && t1 == 'M') { int32_t x; if (aux_int(v, type, x)) { nm = x; tagbits |= RSQC_TB_HAS_NM; } }
+            if (tags.have_ch && t0 == tags.ch0 && t1 == tags.ch1) {                     // readStringTag, src/RNASeQC.cpp:780-800
+                if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
+            }
+            for (int fi = 0; fi < tags.n_filter; ++fi)                                  // GetTag: Z, integer or float
+                if (t0 == tags.f0[fi] && t1 == tags.f1[fi]) {
+                    int32_t x;
+                    if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << fi);
+                }
+            q = v + vlen;
+        }
+        const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_cigar >= RSQC_NCIGAR_ESCAPE;
+        au.l_qseq = wide && (l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0) ? RSQC_LQSEQ_ESCAPE : (uint16_t)l_seq;
+        au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
+        au.n_cigar = n_cigar >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_cigar;
+        au.tagbits = tagbits;
+        if (wide) { o.widx.push_back(k); o.wnm.push_back(nm); o.wlq.push_back(l_seq); o.wnc.push_back(n_cigar); }
+        const size_t c0 = o.cig.size();
+        o.cig.resize(c0 + n_cigar);
+        for (uint16_t ci = 0; ci < n_cigar; ++ci) o.cig[c0 + ci] = le32(cig + 4 * (size_t)ci);
+        o.cig_end.push_back((uint32_t)o.cig.size());
+        o.core.push_back(co); o.aux.push_back(au);
+        p += 4 + (size_t)block_size;
+    }
+    o.last_tid = last_tid;
     return p;
 }
 }  // namespace
 
-// Records are framed and parsed in parallel into pre-sized arrays; contig segments and the wide table are
-// collected per chunk and merged in order.
 size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
     size_t n = 0;
     if (!pool_) set_threads(1);
     const int32_t n_ref = (int32_t)names_.size();
+    TagSpec tags;
+    if (ch_tag_.size() == 2) { tags.have_ch = true; tags.ch0 = ch_tag_[0]; tags.ch1 = ch_tag_[1]; }
+    for (size_t fi = 0; fi < filter_tags_.size() && fi < RSQC_MAX_FILTER_TAGS; ++fi) {
+        // a tag name that is not two characters long can never match; keep its bit position
+        tags.f0[tags.n_filter] = filter_tags_[fi].size() == 2 ? filter_tags_[fi][0] : '\0';
+        tags.f1[tags.n_filter] = filter_tags_[fi].size() == 2 ? filter_tags_[fi][1] : '\0';
+        ++tags.n_filter;
+    }
+    static thread_local std::vector<ChunkOut> tl_chunks;         // capacity is reused from group to group
+    std::vector<ChunkOut> &chunks = tl_chunks;                   // (the workers must see THIS thread's instance)
     while (n < max_records) {
         if (buf_.size() - pos_ < 4 && !fill(4)) {
             if (buf_.size() - pos_ != 0) throw std::runtime_error("truncated BAM record");
@@ -407,52 +502,65 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
         const double tf = now_s();
         const uint8_t *bufp = buf_.data();
         const size_t end = buf_.size(), want = max_records - n;
-        // ---- parallel speculative framing of [pos_, end)
+        // ---- parallel speculative framing + parsing of [pos_, end): a BAM record can only be located by hopping from the
+        //      previous one, so every chunk starts from a GUESSED record start (the first offset where two consecutive
+        //      records pass a structural check)
         const size_t CH = (size_t)1 << 18;                       // 256 KB chunks: a few hundred per inflated group
         const size_t n_ch = std::max<size_t>(1, (end - pos_ + CH - 1) / CH);
-        std::vector<Framed> fr(n_ch);
+        if (chunks.size() < n_ch) chunks.resize(n_ch);
         pool_->run(n_ch, [&](size_t c) {
-            Framed &f = fr[c];
+            ChunkOut &o = chunks[c];
+            o.clear();
             const size_t lo = pos_ + c * CH, hi = std::min(end, lo + CH);
             size_t p = lo;
             if (c > 0) {
-                f.guessed = false;
+                o.guessed = false;
                 for (; p < hi; ++p) {
                     if (!plausible_record(bufp, p, end, n_ref)) continue;
                     const size_t q = p + 4 + le32(bufp + p);
-                    if (q + 36 <= end ? plausible_record(bufp, q, end, n_ref) : true) { f.guessed = true; break; }
+                    if (q + 36 <= end ? plausible_record(bufp, q, end, n_ref) : true) { o.guessed = true; break; }
                 }
-                if (!f.guessed) { f.start = f.end = hi; return; }
-            } else f.guessed = true;
-            f.start = p;
-            f.off.reserve(8192); f.ncig.reserve(8192);
-            f.end = frame_from(bufp, p, hi, end, pos_, f, (size_t)-1);
+                if (!o.guessed) { o.start = o.end = hi; return; }
+            } else o.guessed = true;
+            o.start = p;
+            try { o.end = frame_and_parse(bufp, p, hi, end, tags, o); }
+            catch (std::exception &) {
+                if (c == 0) throw;                               // the first chunk starts at a true boundary: a real error
+                o.clear(); o.guessed = false; o.start = o.end = hi;   // a wrong guess ran into garbage: re-done below from the true position
+            }
         });
-        // ---- sequential verification (exact)
+        // ---- sequential verification (exact): chunk c's guess is accepted only if the TRUE chain of chunk c-1 ends
+        //      exactly on it; otherwise the chunk is redone from the true position.  A wrong guess costs time, never correctness.
         size_t truth = pos_;
         size_t total = 0;
         bool stop = false;
+        size_t used = 0;                                         // chunks [0, used) carry records of this round
         for (size_t c = 0; c < n_ch && !stop; ++c) {
-            Framed &f = fr[c];
+            ChunkOut &o = chunks[c];
             const size_t lo = pos_ + c * CH, hi = std::min(end, lo + CH);
-            if (truth >= hi) { f.off.clear(); f.ncig.clear(); f.start = f.end = truth; continue; }     // a long record spans the chunk
-            if (!(f.guessed && f.start == truth)) {
-                f.off.clear(); f.ncig.clear(); f.start = truth;
-                f.end = frame_from(bufp, truth, hi, end, pos_, f, (size_t)-1);
+            used = c + 1;
+            if (truth >= hi) { o.clear(); o.start = o.end = truth; continue; }     // a long record spans the chunk
+            if (!(o.guessed && o.start == truth)) {
+                o.clear(); o.start = truth;
+                o.end = frame_and_parse(bufp, truth, hi, end, tags, o);
             }
-            if (total + f.off.size() >= want) {                                    // the batch ends inside this chunk
+            (void)lo;
+            if (total + o.size() >= want) {                                        // the batch ends inside this chunk
                 const size_t keep = want - total;
-                if (keep < f.off.size()) { f.end = pos_ + f.off[keep]; f.off.resize(keep); f.ncig.resize(keep); }
+                if (keep < o.size()) {
+                    // the kept records end where record `keep` starts: hop there from the chunk's start
+                    size_t q = o.start;
+                    for (size_t k = 0; k < keep; ++k) q += 4 + (size_t)le32(bufp + q);
+                    o.end = q;
+                    o.truncate(keep);
+                }
                 stop = true;
-                for (size_t d = c + 1; d < n_ch; ++d) { fr[d].off.clear(); fr[d].ncig.clear(); }
             }
-            total += f.off.size();
-            truth = f.end;
-            if (f.end < hi && !stop) {                                             // incomplete record: the window ends here
-                for (size_t d = c + 1; d < n_ch; ++d) { fr[d].off.clear(); fr[d].ncig.clear(); }
-                break;
-            }
+            total += o.size();
+            truth = o.end;
+            if (o.end < hi && !stop) break;                                        // incomplete record: the window ends here
         }
+        for (size_t d = used; d < n_ch; ++d) chunks[d].clear();
         g_t_frame_rec += now_s() - tf;
         if (total == 0) {
             size_t need = 4;
@@ -461,100 +569,39 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
             if (!fill(need)) throw std::runtime_error("truncated BAM record");
             continue;
         }
-        // ---- prefix sums over chunks, then parallel parse
+        // ---- prefix sums over chunks, then parallel copy to the final place
         const double tp = now_s();
-        std::vector<size_t> rec0(n_ch + 1, 0), cig0(n_ch + 1, 0);
-        pool_->run(n_ch, [&](size_t c) { uint64_t s = 0; for (uint32_t v : fr[c].ncig) s += v; cig0[c + 1] = (size_t)s; rec0[c + 1] = fr[c].off.size(); });
-        for (size_t c = 0; c < n_ch; ++c) { rec0[c + 1] += rec0[c]; cig0[c + 1] += cig0[c]; }
-        const size_t K = rec0[n_ch], base = out.core.size(), cig_base = out.cigar.size();
-        if (cig_base + cig0[n_ch] > 0x3FFFFFF0ull) throw std::runtime_error("batch too large");
-        out.core.resize(base + K); out.aux.resize(base + K); out.cigar.resize(cig_base + cig0[n_ch]);
-        const bool prev_tid_valid = !out.seg_tid.empty();
-        const int32_t prev_tid = out.seg_tid.empty() ? 0 : out.seg_tid.back();
-        struct Local { std::vector<std::pair<uint64_t, int32_t>> segs; std::vector<uint64_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc; int32_t last_tid = 0; bool any = false; };
-        std::vector<Local> locals(n_ch);
+        std::vector<size_t> rec0(used + 1, 0), cig0(used + 1, 0);
+        for (size_t c = 0; c < used; ++c) { rec0[c + 1] = rec0[c] + chunks[c].size(); cig0[c + 1] = cig0[c] + chunks[c].cig.size(); }
+        const size_t K = rec0[used], base = out.core.size(), cig_base = out.cigar.size();
+        if (cig_base + cig0[used] > 0x3FFFFFF0ull) throw std::runtime_error("batch too large");
+        out.core.resize(base + K); out.aux.resize(base + K); out.cigar.resize(cig_base + cig0[used]);
         rsqc_rec_core *ocore = out.core.data(); rsqc_rec_aux *oaux = out.aux.data(); uint32_t *ocig = out.cigar.data();
-        pool_->run(n_ch, [&](size_t c) {
-            Local &L = locals[c];
-            const Framed &f = fr[c];
-            size_t cigo = cig_base + cig0[c];
-            int32_t last_tid = 0; bool have_last = false;
-            for (size_t k = 0; k < f.off.size(); ++k) {
-                const size_t gi = base + rec0[c] + k;
-                const uint8_t *r = bufp + pos_ + f.off[k] + 4;
-                const uint32_t block_size = le32(r - 4);
-                const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
-                const uint8_t l_read_name = r[8], mapq = r[9];
-                const uint16_t n_cigar = le16(r + 12), flag = le16(r + 14);
-                const int32_t l_seq = (int32_t)le32(r + 16), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24), isize = (int32_t)le32(r + 28);
-                const char *qname = (const char *)r + 32;
-                const uint8_t *cig = r + 32 + l_read_name;
-                const uint8_t *end_r = r + block_size;
-                const uint8_t *auxp = cig + 4 * (size_t)n_cigar + (size_t)((l_seq < 0 ? 0 : l_seq + 1) / 2) + (size_t)(l_seq < 0 ? 0 : l_seq);
-                if (cig + 4 * (size_t)n_cigar > end_r) throw std::runtime_error("bad BAM record");
-                // segment starts inside a chunk are decided here; a chunk's first record is compared at merge time
-                if (have_last && last_tid != tid) L.segs.emplace_back((uint64_t)gi, tid);
-                if (!have_last) { L.segs.emplace_back((uint64_t)gi, tid); have_last = true; }       // provisional
-                last_tid = tid;
-                rsqc_rec_core co{pos, mpos, isize, (uint32_t)cigo};
-                rsqc_rec_aux au{};
-                const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
-                au.qhash = rsqc_qname_hash(qname, qlen);
-                au.flag = flag; au.mapq = mapq;
-                uint8_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
-                int32_t nm = 0;
-                for (const uint8_t *q = auxp; q + 3 <= end_r;) {
-                    const char t0 = (char)q[0], t1 = (char)q[1], type = (char)q[2];
-                    const uint8_t *v = q + 3;
-                    size_t vlen = 0;
-                    switch (type) {
-                    case 'A': case 'c': case 'C': vlen = 1; break;
-                    case 's': case 'S': vlen = 2; break;
-                    case 'i': case 'I': case 'f': vlen = 4; break;
-                    case 'Z': case 'H': vlen = strnlen((const char *)v, (size_t)(end_r - v)) + 1; break;
-                    case 'B': { if (v + 5 > end_r) { vlen = (size_t)(end_r - v); break; }
-                                const char st = (char)v[0]; const uint32_t cnt = le32(v + 1);
-                                const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; vlen = 5 + es * (size_t)cnt; break; }
-                    default: vlen = (size_t)(end_r - v); break;
-                    }
-                    if (v + vlen > end_r) break;                                            // malformed tail: stop scanning
-                    if (t0 == 'N' && t1 == 'M') { int32_t x; if (aux_int(v, type, x)) { nm = x; tagbits |= RSQC_TB_HAS_NM; } }
-                    if (ch_tag_.size() == 2 && t0 == ch_tag_[0] && t1 == ch_tag_[1]) {         // readStringTag, src/RNASeQC.cpp:780-800
-                        if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
-                    }
-                    for (size_t fi = 0; fi < filter_tags_.size() && fi < RSQC_MAX_FILTER_TAGS; ++fi)   // GetTag: Z, integer or float
-                        if (filter_tags_[fi].size() == 2 && t0 == filter_tags_[fi][0] && t1 == filter_tags_[fi][1]) {
-                            int32_t x;
-                            if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << fi);
-                        }
-                    q = v + vlen;
-                }
-                const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_cigar >= RSQC_NCIGAR_ESCAPE;
-                au.l_qseq = wide && (l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0) ? RSQC_LQSEQ_ESCAPE : (uint16_t)l_seq;
-                au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
-                au.n_cigar = n_cigar >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_cigar;
-                au.tagbits = tagbits;
-                if (wide) { L.widx.push_back(gi); L.wnm.push_back(nm); L.wlq.push_back(l_seq); L.wnc.push_back(n_cigar); }
-                for (uint16_t ci = 0; ci < n_cigar; ++ci) ocig[cigo + ci] = le32(cig + 4 * (size_t)ci);
-                cigo += n_cigar;
-                ocore[gi] = co; oaux[gi] = au;
-            }
-            L.last_tid = last_tid; L.any = have_last;
+        pool_->run(used, [&](size_t c) {
+            const ChunkOut &o = chunks[c];
+            const size_t m = o.size();
+            if (!m) return;
+            const uint32_t shift = (uint32_t)(cig_base + cig0[c]);
+            rsqc_rec_core *dc = ocore + base + rec0[c];
+            for (size_t k = 0; k < m; ++k) { rsqc_rec_core v = o.core[k]; v.cigar_off += shift; dc[k] = v; }
+            memcpy(oaux + base + rec0[c], o.aux.data(), m * sizeof(rsqc_rec_aux));
+            if (!o.cig.empty()) memcpy(ocig + cig_base + cig0[c], o.cig.data(), o.cig.size() * sizeof(uint32_t));
         });
         g_t_parse += now_s() - tp;
         const double tg = now_s();
-        bool have_prev = prev_tid_valid; int32_t ptid = prev_tid;
-        for (const Local &L : locals) {
-            for (size_t si = 0; si < L.segs.size(); ++si) {
-                const auto &sg = L.segs[si];
+        bool have_prev = !out.seg_tid.empty(); int32_t ptid = out.seg_tid.empty() ? 0 : out.seg_tid.back();
+        for (size_t c = 0; c < used; ++c) {
+            const ChunkOut &o = chunks[c];
+            const uint64_t g0 = (uint64_t)(base + rec0[c]);
+            for (size_t si = 0; si < o.segs.size(); ++si) {
+                const auto &sg = o.segs[si];
                 if (si == 0 && have_prev && ptid == sg.second) continue;            // the chunk continues the previous contig
-                out.seg_tid.push_back(sg.second); out.seg_start.push_back(sg.first);
+                out.seg_tid.push_back(sg.second); out.seg_start.push_back(g0 + sg.first);
             }
-            if (L.any) { have_prev = true; ptid = L.last_tid; }
-            out.wide_index.insert(out.wide_index.end(), L.widx.begin(), L.widx.end());
-            out.wide_nm.insert(out.wide_nm.end(), L.wnm.begin(), L.wnm.end());
-            out.wide_lq.insert(out.wide_lq.end(), L.wlq.begin(), L.wlq.end());
-            out.wide_ncig.insert(out.wide_ncig.end(), L.wnc.begin(), L.wnc.end());
+            if (o.size()) { have_prev = true; ptid = o.last_tid; }
+            for (size_t w = 0; w < o.widx.size(); ++w) {
+                out.wide_index.push_back(g0 + o.widx[w]); out.wide_nm.push_back(o.wnm[w]); out.wide_lq.push_back(o.wlq[w]); out.wide_ncig.push_back(o.wnc[w]);
+            }
         }
         g_t_merge += now_s() - tg;
         pos_ = truth;
