@@ -117,8 +117,14 @@ void BamReader::set_threads(int n) {
     if (producer_started_) return;                 // fixed once decoding has begun
     delete pool_; delete pool_inflate_;
     n_threads_ = n;
-    pool_ = new WorkPool(n);
-    pool_inflate_ = new WorkPool(n);
+    // 2n threads in two pools.  With libdeflate and the one-pass parser, inflating a group costs ~1.5x what framing +
+    // parsing + copying it costs (measured per thread), so the producer side gets 60 % of them
+    // (RSQC_HOST_INFLATE_THREADS overrides: the parser keeps the rest, at least one).
+    int n_inflate = n == 1 ? 1 : (2 * n * 3 + 2) / 5;
+    if (const char *e = getenv("RSQC_HOST_INFLATE_THREADS")) n_inflate = atoi(e);
+    n_inflate = std::max(1, std::min(n_inflate, 2 * n - 1));
+    pool_ = new WorkPool(std::max(1, 2 * n - n_inflate));
+    pool_inflate_ = new WorkPool(n_inflate);
 }
 
 // libdeflate (whole-buffer inflate, 2-3x zlib on BGZF-sized blocks) when the shared library is on the system: it ships
@@ -263,7 +269,7 @@ void BamReader::producer_main() {
 void BamReader::start_producer() {
     if (producer_started_) return;
     if (!pool_) {
-        // two pools of n threads (inflate ahead, frame + parse): 16 each measured best on a 2 x 64-core host (54 M reads/s;
+        // two pools, 2n threads (inflate ahead, frame + parse; split in set_threads): n = 16 measured best on a 2 x 64-core host (54 M reads/s;
         // 64 each: 35 M reads/s -- the fork-join phases are short and wake-ups dominate)
         int n = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
         if (const char *e = getenv("RSQC_HOST_THREADS")) n = atoi(e);
