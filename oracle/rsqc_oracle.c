@@ -755,7 +755,7 @@ static void legacy_exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const b
                     nst++;
                 } else if (pi > 0) t_intron = 1;                            /* :191-194 */
             }
-            if (split && !not_split) {                                      /* :197-204 */
+            if (split && !not_split) {                                      /* :198-205 */
                 if (found_exon) {
                     size_t k = 0; while (k < ndose && dose_row[k] != exon->row) ++k;
                     if (k == ndose) { dose_row[k] = exon->row; dose[k] = 0.0f; ndose++; }
@@ -763,23 +763,23 @@ static void legacy_exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const b
                 } else not_split = 1;
             }
         }
-        if (found_exon) {                                                   /* :210 */
+        if (found_exon) {                                                   /* :211 */
             if (hq) {
-                if (split && !not_split) {                                  /* :214-221 */
+                if (split && !not_split) {                                  /* :215-222 */
                     for (size_t k = 0; k < ndose; ++k) {
                         const uint32_t eid = c->ex_id[dose_row[k]];
                         c->exon_reads[eid] += dose[k]; c->exon_hit[eid] = 1;
                     }
-                } else {                                                    /* :222-227 */
+                } else {                                                    /* :223-227 */
                     const uint32_t eid = c->ex_id[exon->row];
                     c->exon_reads[eid] += 1.0; c->exon_hit[eid] = 1;
                 }
                 const uint32_t gene = exon->gene;
-                c->gene_reads[gene] += 1.0;                                 /* :228 */
+                c->gene_reads[gene] += 1.0;                                 /* :229 */
                 if (nameset_insert(&c->tracker[gene], r->qhash, r->qname, r->qname_len))
-                    c->gene_frag[gene] += 1.0;                              /* :229-233 */
-                if (!(r->flag & RSQC_FDUP)) c->gene_unique[gene] += 1.0;    /* :234 */
-                if (c->seen[gene]) {                                        /* commit :235, Metrics.cpp:106-124 */
+                    c->gene_frag[gene] += 1.0;                              /* :230-234 */
+                if (!(r->flag & RSQC_FDUP)) c->gene_unique[gene] += 1.0;    /* :235 */
+                if (c->seen[gene]) {                                        /* commit :236, Metrics.cpp:106-124 */
                     fprintf(stderr, "Gene encountered after computing coverage %u\n", gene);
                 } else for (size_t k = 0; k < nst; ++k) {
                     const uint32_t row = st[k].exon_row;
@@ -789,13 +789,13 @@ static void legacy_exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const b
                         c->cov[row][j] += 1;
                 }
             }
-            do_exon = 1;                                                    /* :237 */
+            do_exon = 1;                                                    /* :238 */
         }
-        if (t_intron && t_exon) junction = 1;                               /* :239 */
-        if (t_exon) exonic = 1;                                             /* :240 */
+        if (t_intron && t_exon) junction = 1;                               /* :240 */
+        if (t_exon) exonic = 1;                                             /* :241 */
     }
     free(res); free(st); free(dose_row); free(dose);
-    if (not_exonic || junction || !exonic) {                                /* :246-262 */
+    if (not_exonic || junction || !exonic) {                                /* :248-263 */
         if (intragenic) {
             INC(RSQC_C_INTRONIC_READS); INC(RSQC_C_INTRAGENIC_READS);
             if (hq) { INC(RSQC_C_HQ_INTRONIC_READS); INC(RSQC_C_HQ_INTRAGENIC_READS); }
@@ -803,7 +803,7 @@ static void legacy_exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const b
             INC(RSQC_C_INTERGENIC_READS);
             if (hq) INC(RSQC_C_HQ_INTERGENIC_READS);
         }
-    } else if (do_exon && !junction && !not_exonic) {                       /* :264-275 */
+    } else if (do_exon && !junction && !not_exonic) {                       /* :265-275 */
         INC(RSQC_C_EXONIC_READS); INC(RSQC_C_INTRAGENIC_READS);
         if (hq) { INC(RSQC_C_HQ_EXONIC_READS); INC(RSQC_C_HQ_INTRAGENIC_READS); }
         if (split && !not_split) INC(RSQC_C_SPLIT_READS);

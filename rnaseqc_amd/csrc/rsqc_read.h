@@ -799,16 +799,16 @@ RSQC_HD void legacy_metrics(const DevAnnotation &a, const DevParams &p, const Re
                     found = f.cmin != 0xFFFFFFFFu; last_row = f.cmin;                      // :173,186-189
                     if (found) t_exon = true;
                     if (f.partial_before) t_intron = true;
-                    if (split && !not_split && !found) not_split = true;                   // :197-204
+                    if (split && !not_split && !found) not_split = true;                   // :198-205
                 }
                 if (cigar_is_ref(op)) start += (int32_t)len;
             }
         }
         if (!have_last || G.ord > last_ord) { have_last = true; last_ord = G.ord; last_not_split = not_split; }
-        if (found) {                                                                       // :210
+        if (found) {                                                                       // :211
             if (hq) {
                 const bool dose = split && !not_split;
-                if (!dose) acc.exon_add(last_row, 1.0);                                    // :222-227
+                if (!dose) acc.exon_add(last_row, 1.0);                                    // :223-227
                 uint32_t cur = 0xFFFFFFFFu; float dsum = 0.0f;
                 int32_t start = r.pos + 1;
                 for (uint32_t i = 0; i < r.n_cigar; ++i) {
@@ -818,8 +818,8 @@ RSQC_HD void legacy_metrics(const DevAnnotation &a, const DevParams &p, const Re
                         const LegacyFind f = legacy_find(a, ci, g, bs, be, se);
                         if (f.cmin != 0xFFFFFFFFu) {
                             const ExonRow row = a.ex[f.cmin];
-                            acc.cov_range(row.cov + (uint32_t)(bs - row.start), len);      // baseCoverage.add + commit, :190,235
-                            if (dose) {                                                    // legacySplitDosage: float sums per exon, :201,216-219
+                            acc.cov_range(row.cov + (uint32_t)(bs - row.start), len);      // baseCoverage.add + commit, :190,236
+                            if (dose) {                                                    // legacySplitDosage: float sums per exon, :201,217-220
                                 if (f.cmin != cur) { if (cur != 0xFFFFFFFFu) acc.exon_add(cur, (double)dsum); cur = f.cmin; dsum = 0.0f; }
                                 dsum += (float)len / (float)r.l_qseq;
                             }
@@ -828,13 +828,13 @@ RSQC_HD void legacy_metrics(const DevAnnotation &a, const DevParams &p, const Re
                     if (cigar_is_ref(op)) start += (int32_t)len;
                 }
                 if (cur != 0xFFFFFFFFu) acc.exon_add(cur, (double)dsum);
-                if (out.n_hit < K) { set_put<K>(out.hit, out.n_hit, g); ++out.n_hit; }    // :228-234
+                if (out.n_hit < K) { set_put<K>(out.hit, out.n_hit, g); ++out.n_hit; }    // :229-235
                 else acc.gene_hit(g, !(fl & RSQC_FDUP), r.qhash);
             }
-            do_exon = true;                                                                // :237
+            do_exon = true;                                                                // :238
         }
-        if (t_intron && t_exon) junction = true;                                           // :239
-        if (t_exon) exonic = true;                                                         // :240
+        if (t_intron && t_exon) junction = true;                                           // :240
+        if (t_exon) exonic = true;                                                         // :241
     }
     // the last row of the result list may be an exon row: legacyNotSplit was reset for it (:159) and nothing set it
     if (ci.n_bins != 0 && se >= 0) {
@@ -849,8 +849,8 @@ RSQC_HD void legacy_metrics(const DevAnnotation &a, const DevParams &p, const Re
             break;                                   // rows further down rank lower
         }
     }
-    const bool outside = not_exonic || junction || !exonic;                                // :246
-    const bool as_exonic = !outside && (do_exon || intragenic);                            // :264,276
+    const bool outside = not_exonic || junction || !exonic;                                // :248
+    const bool as_exonic = !outside && (do_exon || intragenic);                            // :265,276
     const bool intronic = outside && intragenic, intergenic = outside && !intragenic;
     uint64_t bits = 0;
     bits |= intronic ? RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
