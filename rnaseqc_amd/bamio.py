@@ -22,8 +22,9 @@ def _bgzf_block(data: bytes, level: int = 1) -> bytes:
 _EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def write_bam(path, contigs, batch, qnames=None, filter_tag="XF", ch_tag="ch", level=1):
-    """contigs: [(name, length)]; batch: model.Batch (file order).  qnames: list of bytes or None (uses batch.qname)."""
+def write_bam(path, contigs, batch, qnames=None, filter_tag="XF", ch_tag="ch", level=1, extra_aux=None):
+    """contigs: [(name, length)]; batch: model.Batch (file order).  qnames: list of bytes or None (uses batch.qname).
+    extra_aux: optional callable i -> (bytes before, bytes after) of further aux fields around the standard ones."""
     n = batch.n
     tid = batch.tid_per_record()
     hdr_text = ("@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, ln) for nm, ln in contigs)).encode()
@@ -55,6 +56,9 @@ def write_bam(path, contigs, batch, qnames=None, filter_tag="XF", ch_tag="ch", l
             tags += ch_tag.encode() + b"Z1\x00"
         if tb & abi.TB_FILTER0:
             tags += filter_tag.encode() + b"i" + struct.pack("<i", 1)
+        if extra_aux is not None:
+            before, after = extra_aux(i)
+            tags = before + tags + after
         rec = struct.pack("<iiBBHHHiiii", t, int(batch.pos[i]), len(name) + 1, int(batch.mapq[i]), 4680, nc,
                           int(batch.flag[i]), lq, mtid, int(batch.mpos[i]), int(batch.isize[i]))
         rec += name + b"\x00" + cig.astype("<u4").tobytes() + b"\x11" * ((lq + 1) // 2) + b"\xff" * lq + tags

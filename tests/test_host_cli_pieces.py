@@ -474,3 +474,49 @@ def test_bam_decode_inflate_backends_agree(host, tmp_path):
     assert outs[("libdeflate", path)] == outs[("zlib", path)] and outs[("zlib", path)].split()[0] == str(batch.n)
     assert int(outs[("zlib", path)].split()[1]) == int(batch.pos.astype(np.int64).sum())
     assert outs[("libdeflate", bad)] == "ERR" and outs[("zlib", bad)] == "ERR"
+
+
+def test_bam_decode_walks_every_aux_type(host, tmp_path):
+    """Records carry random extra aux fields of every BAM type (A c C s S i I f Z H and B arrays of each element type)
+    around NM / the chimeric tag / the filter tag, including look-alike tag names: the decoded tag bits and NM must not
+    change (SeqLib GetIntTag / GetZTag / GetTag semantics at src/RNASeQC.cpp:295,320-327,780-800)."""
+    import struct
+    rng = np.random.default_rng(5)
+    ann = synth.make_annotation(seed=39, contigs=[("chrA", 1_000_000, 60)])
+    batch = synth.make_reads(ann, 4000, seed=40, keep_qnames=True, chimeric_tag_frac=0.05, filter_tag_frac=0.05,
+                             contig_lengths=np.array([1_000_000]))
+
+    def field():
+        name = bytes(rng.choice(list(b"ABXYZabmn"), 2).tolist())
+        if name in (b"NM", b"ch", b"XF"):
+            name = b"Zz"
+        t = rng.choice(list("AcCsSiIfZHB"))
+        if t == "A": v = bytes([int(rng.integers(33, 126))])
+        elif t in "cC": v = bytes([int(rng.integers(0, 256))])
+        elif t in "sS": v = struct.pack("<H", int(rng.integers(0, 65536)))
+        elif t in "iI": v = struct.pack("<I", int(rng.integers(0, 2 ** 32)))
+        elif t == "f": v = struct.pack("<f", float(rng.random()))
+        elif t == "Z": v = bytes(rng.integers(33, 126, int(rng.integers(0, 40))).tolist()) + b"\x00"
+        elif t == "H": v = b"".join(b"%02X" % int(x) for x in rng.integers(0, 256, int(rng.integers(0, 8)))) + b"\x00"
+        else:
+            st = rng.choice(list("cCsSiIf")); cnt = int(rng.integers(0, 20))
+            es = {"c": 1, "C": 1, "s": 2, "S": 2}.get(st, 4)
+            v = st.encode() + struct.pack("<I", cnt) + bytes(rng.integers(0, 256, es * cnt).tolist())
+        return name + t.encode() + v
+
+    def extra(i):
+        return b"".join(field() for _ in range(int(rng.integers(0, 4)))), b"".join(field() for _ in range(int(rng.integers(0, 4))))
+    path = str(tmp_path / "x.bam")
+    bamio.write_bam(path, [("chrA", 1_000_000)], batch, extra_aux=extra)
+    tags = (C.c_char_p * 1)(b"XF")
+    host.host_bam_read_all_ex.restype = C.c_void_p
+    h = host.host_bam_read_all_ex(path.encode(), b"ch", tags, 1, 4, C.c_ulonglong(1 << 20))
+    assert h
+    b = host.host_bam_batch(C.c_void_p(h)).contents
+    assert b.n == batch.n
+    aux = _arr(b.aux, b.n, abi.REC_AUX); core = _arr(b.core, b.n, abi.REC_CORE)
+    for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
+        np.testing.assert_array_equal(aux[f], getattr(batch, f), err_msg=f)
+    np.testing.assert_array_equal(core["pos"], batch.pos)
+    np.testing.assert_array_equal(_arr(b.cigar, b.n_cigar_total, np.uint32), batch.cigar)
+    host.host_bam_free(C.c_void_p(h))
