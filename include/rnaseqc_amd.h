@@ -405,6 +405,17 @@ RSQC_API int rsqc_reset_timing(rsqc_ctx *ctx);
  * order) in another.  Valid after rsqc_finalize().                            */
 RSQC_API int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *u64_count,
                              void **f64_base, uint64_t *f64_count);
+/* Everything a contig-sharded run exchanges, as three device ranges of one element type each, to
+ * be sum-reduced in place across the ranks (RCCL all_reduce, SUM) between rsqc_finalize_device and
+ * rsqc_refresh_results:
+ *   [0] u64: gene_reads | gene_unique | gene_fragments | counters | bias_three | bias_five
+ *   [1] f64: exon_reads | gene_cov_mean | gene_cov_std | gene_cov_cv | exon_cv
+ *   [2] u8 : gene_cov_valid | exon_cv_valid (padded to 8 bytes each)
+ * Counts and exon sums are additive; the per-gene / per-exon statistics are written by the owner of the gene's
+ * contig only and stay zero elsewhere, so the same sum is their merge (a NaN CV stays NaN).  rsqc_device_accumulators
+ * exposes the additive prefixes of [0] and [1] only.                                                              */
+typedef struct rsqc_device_range { void *base; uint64_t count; } rsqc_device_range;
+RSQC_API int rsqc_device_vectors(rsqc_ctx *ctx, rsqc_device_range out[3]);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
 /* Page-locked host memory for the arrays of an rsqc_batch: rsqc_submit then copies by DMA and returns without

@@ -53,6 +53,10 @@ REC_AUX = np.dtype([("qhash", "<u8"), ("flag", "<u2"), ("l_qseq", "<u2"), ("mapq
 assert REC_CORE.itemsize == 16 and REC_AUX.itemsize == 16
 
 
+class DeviceRange(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("count", C.c_uint64)]
+
+
 class Params(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device", C.c_int32),

@@ -88,20 +88,27 @@ def write_bed(path, ann, bed):
             f.write("%s\t%d\t%d\n" % (ann.contig_names[c], s - 1, e - 1))
 
 
-def write_bam_fast(path, contigs, batch, ch_tag="ch", filter_tag="XF", threads=16):
+def write_bam_fast(path, contigs, batch, ch_tag="ch", filter_tag="XF", threads=16, seq_mode=0, bai=False, struct=None):
     """Same file as write_bam through the C++ host library's writer (rnaseqc_amd/lib/librsqc_host.so,
-    host_bam_write): used for multi-million-record CLI benchmarks.  Records without names get 16 hex digits of
-    their qhash as QNAME (mates keep sharing a name)."""
+    host_bam_write_ex): used for multi-million-record CLI benchmarks.  Records without names get 16 hex digits of
+    their qhash as QNAME (mates keep sharing a name).  seq_mode 0: SEQ all 'A', QUAL 0xff (SURVEY.md 8(d));
+    1: random bases and binned Phred-like qualities (the compressibility of a real file).  bai: also write
+    <path>.bai with the per-contig virtual offsets.  Returns the BGZF virtual offsets of the batch's segments
+    (+ the end of the records)."""
     import ctypes as C
     import os
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsqc_host.so"))
     names = (C.c_char_p * len(contigs))(*[c[0].encode() for c in contigs])
     lens = (C.c_uint * len(contigs))(*[int(c[1]) for c in contigs])
-    st = batch.to_struct()
-    lib.host_bam_write.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
-    rc = lib.host_bam_write(str(path).encode(), names, lens, len(contigs), C.byref(st), ch_tag.encode(), filter_tag.encode(), threads)
+    st = struct if struct is not None else batch.to_struct()
+    voff = np.zeros(int(st.n_seg) + 1, np.uint64)
+    lib.host_bam_write_ex.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.c_int, C.c_void_p, C.c_char_p,
+                                      C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = lib.host_bam_write_ex(str(path).encode(), names, lens, len(contigs), C.byref(st), ch_tag.encode(), filter_tag.encode(),
+                               threads, seq_mode, 1 if bai else 0, voff.ctypes.data)
     if rc:
-        raise OSError("host_bam_write failed: %d" % rc)
+        raise OSError("host_bam_write_ex failed: %d" % rc)
+    return voff
 
 
 def write_fasta(path, names, reference, line_bases=60, index_path=None):

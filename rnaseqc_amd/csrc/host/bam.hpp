@@ -118,6 +118,8 @@ public:
     uint64_t records_read() const { return n_read_; }
     // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 16), per pool
     void set_threads(int n);
+    int inflate_threads() const { return pool_inflate_ ? pool_inflate_->size() : 0; }
+    int parse_threads() const { return pool_ ? pool_->size() : 0; }
     ~BamReader();
 private:
     bool fill(size_t need);              // make at least `need` decompressed bytes available

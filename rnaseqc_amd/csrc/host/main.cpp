@@ -311,6 +311,7 @@ int main(int argc, char **argv) {
             const double secs = std::chrono::duration<double>(tb1 - tb0).count();
             cout << "Time Elapsed: " << secs << "; Alignments processed: " << alignmentCount << endl;
             if (o.verbosity > 1) cout << "Average Reads/Sec: " << (double)alignmentCount / secs << endl;
+            if (o.verbosity > 1) cout << "(decode threads: " << bam.inflate_threads() << " inflate + " << bam.parse_threads() << " parse)" << endl;
             cout << "Estimating library complexity..." << endl;
             cout << "Generating report" << endl;
         }

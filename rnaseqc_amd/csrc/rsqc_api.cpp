@@ -85,7 +85,7 @@ struct rsqc_ctx {
 
     // accumulators
     // one device arena holds every small result vector (single memset at reset, single D2H at finalize):
-    // u64[3G+49] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | u64 bias3,bias5[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | misc[64]
+    // u64[3G+K] | u64 bias3,bias5[L] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | u8 exon_hit[E] | misc[64]
     DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
@@ -522,13 +522,15 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     const size_t Lz = (size_t)std::max(L, 1), Ez = (size_t)std::max(E, 1);
     auto pad8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
     size_t at = 0;
+    // three runs of one element type each, so that a sharded run sum-reduces everything with three collectives
+    // (rsqc_device_vectors): u64 counts | f64 sums and owner-only statistics | u8 validity flags
     c->off_u64 = at; at += n_u64 * 8;
+    c->off_bias3 = at; at += Lz * 8;
+    c->off_bias5 = at; at += Lz * 8;
     c->off_exon = at; at += Ez * 8;
     c->off_gmean = at; at += Lz * 8;
     c->off_gstd = at; at += Lz * 8;
     c->off_gcv = at; at += Lz * 8;
-    c->off_bias3 = at; at += Lz * 8;
-    c->off_bias5 = at; at += Lz * 8;
     c->off_ecv = at; at += Ez * 8;
     c->off_gvalid = at; at += pad8(Lz);
     c->off_ecvv = at; at += pad8(Ez);
@@ -964,6 +966,15 @@ int rsqc_device_accumulators(rsqc_ctx *c, void **u64_base, uint64_t *u64_count, 
     if (!c || !c->have_ann || !u64_base || !u64_count || !f64_base || !f64_count) return RSQC_ERR_ARG;
     *u64_base = (char *)c->d_arena.p + c->off_u64; *u64_count = (uint64_t)c->n_genes * 3 + RSQC_N_COUNTERS;
     *f64_base = (char *)c->d_arena.p + c->off_exon; *f64_count = (uint64_t)c->n_exons;
+    return RSQC_OK;
+}
+
+int rsqc_device_vectors(rsqc_ctx *c, rsqc_device_range out[3]) {
+    if (!c || !c->have_ann || !out) return RSQC_ERR_ARG;
+    char *A = (char *)c->d_arena.p;
+    out[0].base = A + c->off_u64;    out[0].count = (c->off_exon - c->off_u64) / 8;
+    out[1].base = A + c->off_exon;   out[1].count = (c->off_gvalid - c->off_exon) / 8;
+    out[2].base = A + c->off_gvalid; out[2].count = c->off_ehit - c->off_gvalid;
     return RSQC_OK;
 }
 

@@ -46,6 +46,7 @@ def load_library():
         lib.rsqc_get_timing.argtypes = [vp, C.POINTER(abi.TimingStruct)]
         lib.rsqc_reset_timing.argtypes = [vp]
         lib.rsqc_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        lib.rsqc_device_vectors.argtypes = [vp, C.POINTER(abi.DeviceRange * 3)]
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
         lib.rsqc_finalize_device.argtypes = [vp]
         lib.rsqc_host_alloc.argtypes = [C.c_size_t]; lib.rsqc_host_alloc.restype = vp
@@ -62,7 +63,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_set_reference", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
 ]
 
@@ -136,6 +137,12 @@ class Engine:
         self._check(self._l.rsqc_upload(self._h, C.byref(s), C.byref(h)))
         return h.value
 
+    def upload_struct(self, s) -> int:
+        """rsqc_upload of an already packed abi.BatchStruct."""
+        h = C.c_int()
+        self._check(self._l.rsqc_upload(self._h, C.byref(s), C.byref(h)))
+        return h.value
+
     def submit_resident(self, handle: int):
         self._check(self._l.rsqc_submit_resident(self._h, handle))
 
@@ -178,6 +185,14 @@ class Engine:
         self._check(self._l.rsqc_device_accumulators(self._h, C.byref(u), C.byref(nu), C.byref(f), C.byref(nf)))
         # int64 view: torch has no uint64 arithmetic; counts are far below 2^63
         return DeviceArray(u.value, nu.value, "<i8"), DeviceArray(f.value, nf.value, "<f8")
+
+    def device_vectors(self):
+        """The three device ranges a sharded run sum-reduces (rsqc_device_vectors): int64 counts, f64 sums and
+        owner-only statistics, u8 validity flags."""
+        r = (abi.DeviceRange * 3)()
+        self._check(self._l.rsqc_device_vectors(self._h, C.byref(r)))
+        return (DeviceArray(r[0].base, r[0].count, "<i8"), DeviceArray(r[1].base, r[1].count, "<f8"),
+                DeviceArray(r[2].base, r[2].count, "|u1"))
 
     def close(self):
         if self._h:

@@ -367,6 +367,44 @@ class Batch:
                      qname_off=np.array(noff, np.uint32), qname=np.frombuffer(bytes(names), dtype=np.uint8).copy(),
                      **b)
 
+    @staticmethod
+    def concat(parts: Sequence["Batch"]) -> "Batch":
+        """The batches one after the other as ONE batch (cigar pool, segment table and wide table re-based).
+        Adjacent segments of the same contig are merged."""
+        parts = [p for p in parts if p.n]
+        if not parts:
+            return Batch.from_records([])
+        if len(parts) == 1:
+            return parts[0]
+        n_at = np.concatenate([[0], np.cumsum([p.n for p in parts])]).astype(np.int64)
+        c_at = np.concatenate([[0], np.cumsum([len(p.cigar) for p in parts])]).astype(np.int64)
+        if c_at[-1] >= (1 << 32):
+            raise ValueError("CIGAR pool of the concatenation exceeds 32-bit offsets")
+        cat = lambda f: np.concatenate([getattr(p, f) for p in parts])
+        seg_tid, seg_start = [], []
+        for k, p in enumerate(parts):
+            for s in range(len(p.seg_tid)):
+                if int(p.seg_start[s + 1]) == int(p.seg_start[s]):
+                    continue
+                if seg_tid and seg_tid[-1] == int(p.seg_tid[s]):
+                    continue
+                seg_tid.append(int(p.seg_tid[s])); seg_start.append(int(p.seg_start[s]) + int(n_at[k]))
+        seg_start.append(int(n_at[-1]))
+        kw = {}
+        if all(p.qname is not None for p in parts):
+            q_at = np.concatenate([[0], np.cumsum([len(p.qname) for p in parts])]).astype(np.int64)
+            kw = dict(qname=cat("qname"),
+                      qname_off=np.concatenate([(p.qname_off[:-1].astype(np.int64) + q_at[k]) for k, p in enumerate(parts)] +
+                                               [q_at[-1:]]).astype(np.uint32))
+        return Batch(pos=cat("pos"), mpos=cat("mpos"), isize=cat("isize"), qhash=cat("qhash"),
+                     cigar_off=np.concatenate([(p.cigar_off.astype(np.int64) + c_at[k]) for k, p in enumerate(parts)]).astype(np.uint32),
+                     flag=cat("flag"), l_qseq=cat("l_qseq"), mapq=cat("mapq"), nm=cat("nm"), tagbits=cat("tagbits"),
+                     n_cigar=cat("n_cigar"), cigar=cat("cigar"), seg_tid=np.asarray(seg_tid, np.int32),
+                     seg_start=np.asarray(seg_start, np.uint64),
+                     wide_index=np.concatenate([(p.wide_index.astype(np.int64) + n_at[k]) for k, p in enumerate(parts)]).astype(np.uint64),
+                     wide_nm=cat("wide_nm"), wide_l_qseq=cat("wide_l_qseq"), wide_n_cigar=cat("wide_n_cigar"),
+                     file_index_base=parts[0].file_index_base, **kw)
+
     def slice(self, lo: int, hi: int) -> "Batch":
         """Records [lo, hi) as an independent batch (cigar pool re-based)."""
         lo, hi = int(lo), int(hi)

@@ -3,7 +3,7 @@
 No real GENCODE GTF or BAM exists offline, so both are generated:
   * make_annotation: GENCODE-like collapsed gene models (exons of a gene disjoint
     and sorted, ~10 % opposite-strand overlaps, ~1 % rRNA, the 12 globin names),
-    56 202 genes / ~323 k exons at full scale, 5 234 / ~31 k for the chr1 subset.
+    56 202 genes / 323 826 exons at full scale (reference model: 323 418), 5 234 / 29 190 for the chr1 subset.
   * make_reads: coordinate-sorted paired 2x150 records: ~78 % from transcripts
     (spliced CIGARs), ~11 % intronic, ~7 % intergenic, ~4 % straddling exon edges,
     plus S/I/D CIGARs, low-MAPQ, NM>6, secondary/supplementary/unmapped records.
@@ -30,6 +30,7 @@ HUMAN_CONTIGS = [
     ("chrM", 16569, 37),
 ]
 # sums to 56 202 genes after the fix-up in human_contigs()
+NEX_SMALL_FRAC = 0.592     # tuned so that human_contigs() yields ~323 k exons (the reference's GENCODE v19 collapsed model: 323 418)
 
 
 def human_contigs(total_genes: int = 56202):
@@ -58,7 +59,13 @@ def make_annotation(seed: int = 1, contigs=None, bam_contigs=None, shuffle_rows:
         cid = contig_id[cname]
         if ng == 0:
             continue
-        nex = np.clip(np.rint(np.exp(rng.normal(np.log(2.2), 1.25, ng))), 1, 359).astype(np.int64)
+        # exons per gene: the collapsed GENCODE shape recoverable from the reference's golden exon_reads.gct
+        # (mean 5.75, median 2, p90 16, p99 39, max 359) = a mixture of 1-3-exon genes (lncRNA,
+        # pseudogenes) and protein-coding-like genes, plus a handful of very long ones
+        nex = np.where(rng.random(ng) < NEX_SMALL_FRAC, 1 + rng.poisson(0.5, ng),
+                       np.clip(np.rint(np.exp(rng.normal(np.log(9.0), 0.72, ng))), 1, 359)).astype(np.int64)
+        giant = rng.random(ng) < 0.0004
+        nex[giant] = rng.integers(150, 360, int(giant.sum()))
         E = int(nex.sum())
         elen = np.clip(np.rint(np.exp(rng.normal(np.log(150.0), 0.8, E))), 20, 12000).astype(np.int64)
         ilen = np.clip(np.rint(np.exp(rng.normal(np.log(1500.0), 1.2, E))), 50, 150000).astype(np.int64)
@@ -180,7 +187,9 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
                expr_sigma: float = 2.0, low_mapq_frac: float = 0.05, secondary_frac: float = 0.01,
                supplementary_frac: float = 0.005, unmapped_frac: float = 0.01, indel_frac: float = 0.02,
                chimeric_tag_frac: float = 0.0, filter_tag_frac: float = 0.0, expr_genes: int | None = None,
-               contig_lengths=None, only_contig: int | None = None) -> Batch:
+               contig_lengths=None, only_contig: int | None = None, fid_base: int = 0) -> Batch:
+    """fid_base: first fragment number (QNAMEs are "SYN:%012d" of the fragment number), so that batches made
+    contig by contig (make_reads_sharded) never share a name."""
     rng = np.random.default_rng(seed)
     rl = read_len
     G = ann.n_genes_listed
@@ -204,6 +213,16 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
         np.maximum.at(contig_lengths, gene_contig, gene_e + 5000)
     n_tx, n_intr, n_inter, n_edge = [int(round(f * n_pairs)) for f in frac]
     n_tx = n_pairs - n_intr - n_inter - n_edge
+    if only_contig is not None:
+        # a contig without a usable gene (chrM-like: every transcript shorter than a read, no gene long enough for an
+        # intronic pair) sends those pairs to the intergenic class instead
+        on = gene_contig == only_contig
+        if not (on & (coding >= rl)).any():
+            n_inter += n_tx; n_tx = 0
+        if not (on & ((gene_e - gene_s) > 3 * rl + 400)).any():
+            n_inter += n_intr; n_intr = 0
+        if not (ann.exon_row_contig == only_contig).any():
+            n_inter += n_edge; n_edge = 0
 
     # ---- fragment-level: genomic block lists for both mates -----------------------
     # every mate is described by (contig, list of (gstart1, len)); we build flat op arrays
@@ -327,7 +346,7 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
     flagA = np.where(a_is_r1, 99, 163).astype(np.uint16)
     flagB = np.where(a_is_r1, 147, 83).astype(np.uint16)
     isz = (np.maximum(endA, endB) - np.minimum(posA, posB)).astype(np.int32)
-    frag_id = np.arange(nf, dtype=np.int64)
+    frag_id = np.arange(nf, dtype=np.int64) + int(fid_base)
 
     # ---- record-level arrays (2 per fragment) --------------------------------------
     tid = np.concatenate([contig, contig]).astype(np.int32)
@@ -409,7 +428,7 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
     # unmapped tail (pairs)
     nu = int(unmapped_frac * n) // 2 * 2
     if nu:
-        uf = nf + np.arange(nu // 2, dtype=np.int64)
+        uf = int(fid_base) + nf + np.arange(nu // 2, dtype=np.int64)
         tid = np.concatenate([tid, np.full(nu, -1, np.int32)])
         pos = np.concatenate([pos, np.full(nu, -1, np.int64)]); mpos = np.concatenate([mpos, np.full(nu, -1, np.int64)])
         isize = np.concatenate([isize, np.zeros(nu, np.int32)])
@@ -454,6 +473,82 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
         b.qname = digits.reshape(-1).copy()
         b.qname_off = (np.arange(N + 1, dtype=np.uint32) * 16).astype(np.uint32)
     return b
+
+
+def contig_pair_shares(ann: Annotation, n_pairs: int) -> np.ndarray:
+    """Read pairs per BAM contig for make_reads_sharded: proportional to the contig's gene count (largest
+    remainder), so the split is known before anything is generated -- the LPT assignment of contigs to GPUs
+    (distributed.assign_contigs) works from these numbers."""
+    G = ann.n_genes_listed
+    per = np.bincount(ann.gene_row_contig.astype(np.int64), minlength=ann.n_ref)[:ann.n_ref].astype(np.float64)
+    if per.sum() == 0:
+        per[:] = 1.0
+    exact = per / per.sum() * n_pairs
+    share = np.floor(exact).astype(np.int64)
+    rest = int(n_pairs - share.sum())
+    if rest:
+        share[np.argsort(-(exact - share), kind="stable")[:rest]] += 1
+    return share
+
+
+_SHARD_CTX = {}
+
+
+def _shard_job(c):
+    a = _SHARD_CTX
+    return c, make_reads(a["ann"], int(a["share"][c]), seed=a["seed"] * 100003 + c, only_contig=c, unmapped_frac=0.0,
+                         fid_base=int(a["fid_base"][c]), contig_lengths=a["contig_lengths"], **a["kw"])
+
+
+def make_reads_sharded(ann: Annotation, n_pairs: int, seed: int = 2, contigs=None, workers: int = 0,
+                       unmapped_frac: float = 0.01, with_unmapped: bool = True, contig_lengths=None, **kw):
+    """The BASELINE-scale input (100 M records): every contig is generated on its own (own seed, own fragment
+    numbers) and the pieces are concatenated in contig order, which IS coordinate order; the unmapped tail comes
+    last.  `contigs` restricts the output to a subset (a GPU's shard): the union over a partition of the contigs
+    equals the full input record for record.  workers > 1 forks that many generator processes (call this
+    before the HIP runtime is initialised).  Returns (batch, records_per_contig[n_ref])."""
+    share = contig_pair_shares(ann, n_pairs)
+    fid_base = np.concatenate([[0], np.cumsum(share)])[:-1]
+    if contig_lengths is None:
+        contig_lengths = np.zeros(ann.n_ref, np.int64)
+        np.maximum.at(contig_lengths, ann.gene_row_contig.astype(np.int64), ann.gene_row_end.astype(np.int64) + 5000)
+    want = [c for c in (range(ann.n_ref) if contigs is None else contigs) if share[c] > 0]
+    _SHARD_CTX.clear()
+    _SHARD_CTX.update(ann=ann, share=share, seed=seed, fid_base=fid_base, kw=kw, contig_lengths=np.asarray(contig_lengths, np.int64))
+    order = sorted(want, key=lambda c: -int(share[c]))              # longest first
+    pieces = {}
+    if workers > 1 and len(order) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(order))) as pool:
+            for c, b in pool.imap_unordered(_shard_job, order, chunksize=1):
+                pieces[c] = b
+    else:
+        for c in order:
+            pieces[c] = _shard_job(c)[1]
+    _SHARD_CTX.clear()
+    per_contig = np.zeros(ann.n_ref, np.int64)
+    for c, b in pieces.items():
+        per_contig[c] = b.n
+    parts = [pieces[c] for c in sorted(pieces)]
+    if with_unmapped and unmapped_frac:
+        nu = int(unmapped_frac * 2 * n_pairs) // 2 * 2
+        if nu:
+            rl = int(kw.get("read_len", 150))
+            fid = int(share.sum()) + np.repeat(np.arange(nu // 2, dtype=np.int64), 2)
+            digits = np.zeros((nu, 16), np.uint8)
+            digits[:, :4] = np.frombuffer(b"SYN:", np.uint8)
+            v = fid.copy()
+            for j in range(15, 3, -1):
+                digits[:, j] = 48 + (v % 10)
+                v //= 10
+            parts.append(Batch(pos=np.full(nu, -1, np.int32), mpos=np.full(nu, -1, np.int32), isize=np.zeros(nu, np.int32),
+                               qhash=abi.qname_hash_bytes(digits), cigar_off=np.zeros(nu, np.uint32),
+                               flag=np.tile(np.array([77, 141], np.uint16), nu // 2), l_qseq=np.full(nu, rl, np.uint16),
+                               mapq=np.zeros(nu, np.uint8), nm=np.zeros(nu, np.uint8),
+                               tagbits=np.full(nu, abi.TB_MTID_SAME, np.uint8), n_cigar=np.zeros(nu, np.uint8),
+                               cigar=np.zeros(0, np.uint32), seg_tid=np.array([-1], np.int32),
+                               seg_start=np.array([0, nu], np.uint64)))
+    return Batch.concat(parts), per_contig
 
 
 def make_bed(ann: Annotation, min_len: int = 1000) -> Bed:

@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 100 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/p$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e $BENCH_ARGS > $OUT/p$i.log 2>$OUT/p$i.err
 done
 python - <<PY
 import csv, glob, collections, json
@@ -21,7 +21,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
         k = r.get("Kernel_Name", "").split("(")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
-    o.write("# rocprofv3 --pmc (separate passes) -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 ; mean per launch\n")
+    o.write("# rocprofv3 --pmc (separate passes) -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e ; mean per launch\n")
     for k, d in sorted(agg.items()):
         o.write(k + "\n")
         for c, v in sorted(d.items()):
@@ -31,7 +31,12 @@ if k1:
     d = agg[k1[0]]
     fetch_kb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); write_kb = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
     # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE uncalibrated, taken as is
-    out = {"kernel": k1[0], "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
+    cfg = {}
+    try:
+        for line in open("$OUT/p1.log"):
+            if line.startswith("{"): cfg = json.loads(line).get("config", {})
+    except Exception: pass
+    out = {"kernel": k1[0], "records": cfg.get("records"), "genes": cfg.get("genes"), "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
            "hbm_bytes_per_launch": fetch_kb * 1024 * 2.0 + write_kb * 1024,
            "note": "FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; separate --pmc passes"}
     json.dump(out, open("$OUT/k1_traffic.json", "w"), indent=1)
