@@ -309,7 +309,8 @@ def main():
                          "timer": "hipEvents around the launch on the context's stream (rsqc_get_timing), rank 0"},
             "cpu_baseline": cpu,
             "end_to_end": e2e,
-            "stage_ms": {"classify_k1": k1_ms, "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1)},
+            "stage_ms": {"classify_k1": k1_ms, "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
+                         "slow_path_records": int(tm["slow_records"])},
             "checks": None if res is None else {"gene_reads_sum": int(res.gene_reads.sum()),
                                                 "total_alignments": res.counter("Total Alignments")},
             "input_generation_s": round(t_gen, 1),

@@ -355,6 +355,7 @@ typedef struct rsqc_timing {
     uint64_t classify_bytes;           /* algorithmic bytes: 32*n + 4*n_cigar_total     */
     double   finalize_ms;              /* de-dup + coverage scan/stats + bias           */
     double   h2d_ms;                   /* rsqc_submit host->device copies               */
+    uint64_t slow_records;             /* records the general (slow-path) kernel took in the last finalized pass */
 } rsqc_timing;
 
 typedef struct rsqc_ctx rsqc_ctx;

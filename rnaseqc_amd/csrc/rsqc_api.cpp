@@ -732,6 +732,7 @@ static int read_back(rsqc_ctx *c) {
     R.gc_bins = c->have_ref ? c->h_gc.data() : nullptr;
     R.gc_out_of_range = c->have_ref ? c->h_gc[RSQC_GC_BINS] : 0;
     R.exon_gc = c->have_ref ? c->h_exon_gc.data() : nullptr;
+    c->timing.slow_records = *(const uint32_t *)(H + c->off_misc + 4);
     const int err = *(const int *)(H + c->off_misc + 16);
     if (err) {
         c->sticky = err;

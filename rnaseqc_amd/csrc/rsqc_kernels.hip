@@ -18,12 +18,40 @@
 #include <stdint.h>
 #include <algorithm>
 
+// Profiling build (make prof -> lib/librnaseqc_amd_prof.so, loaded with RSQC_LIB): K1 reads the shader clock at section
+// marks and accumulates, per section, the cycles its waves spent since their previous mark (stalls included).
+// Diagnostic only; the product library is compiled without it.
+#ifdef RSQC_K1_PROF
+namespace rsqc { __device__ __forceinline__ void k1_mark(int sec); }
+#define RSQC_MARK(sec) ::rsqc::k1_mark(sec)
+#endif
+
 #include "rsqc_device.h"
 
 namespace rsqc {
 
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+#ifdef RSQC_K1_PROF
+__device__ unsigned long long g_k1_prof[32];          // [sec] cycles, [16 + sec] marks
+__shared__ unsigned long long s_prof_acc[32];
+__shared__ unsigned long long s_prof_last[RSQC_K1_THREADS / 64];
+__device__ __forceinline__ void k1_mark(int sec) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (lane_id() == 0) {
+        const int w = (int)(threadIdx.x >> 6);
+        atomicAdd(&s_prof_acc[sec], t - s_prof_last[w]);
+        atomicAdd(&s_prof_acc[16 + sec], 1ull);
+        s_prof_last[w] = t;
+    }
+}
+extern "C" __attribute__((visibility("default"))) int rsqc_debug_k1_prof(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1_prof), sizeof(g_k1_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_k1_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 __device__ __forceinline__ uint32_t mask_rank(uint64_t m) {      // #set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -208,6 +236,10 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x) { S.gkey[c] = 0xFFFFFFFFu; S.gcnt[c] = 0u; S.gnd[c] = 0u; }
     if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; S.pairs = 0u; }
     if (blockIdx.x == 0 && threadIdx.x == 0) *acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
+#ifdef RSQC_K1_PROF
+    if (threadIdx.x < 32) s_prof_acc[threadIdx.x] = 0ull;
+    if (l == 0) s_prof_last[wave] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
 
     // Scalar counters are kept "vertically": plane j holds bit j of this lane's running count of
@@ -285,6 +317,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         cur_cg[0] = ld32(b.cigar, co); cur_cg[1] = ld32(b.cigar, co + 1); cur_cg[2] = ld32(b.cigar, co + 2); cur_cg[3] = ld32(b.cigar, co + 3);
     }
     for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
+        RSQC_MARK(0);                              // [0] loop overhead + counter flush of the previous tile
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
         {
@@ -347,6 +380,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                     if (rc.error) atomicExch(acc.error, rc.error);
                 }
             }
+            RSQC_MARK(1);                          // [1] wait for the staged record words, unpack, CIGAR walk, gate cascade
             // scalar counters of the gate cascade: vertical add of the record's one-bit increments
             vertical_add(rc.bits);
             sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
@@ -362,7 +396,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
             }
         }
-        // ---- feature stage ------------------------------------------------------------------------
+        RSQC_MARK(2);                              // [2] gate counters + Read-Length inputs
+        // ---- feature stage ------------------------------------------------------------------------ [3] bins, [4..7] block rounds, [8] epilogue
         if (!LEGACY && go) {
             bool overflow = tid != u_tid;          // stragglers of a boundary tile: general code
             if (!overflow) exon_metrics_fast<ROUND>(a, p, u_ci, fl, B, hq, aligned, fo, overflow);
@@ -373,6 +408,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 else atomicExch(acc.error, RSQC_ERR_CAPACITY);
             }
         }
+        RSQC_MARK(9);                              // [9] class bits + overflow hand-over
         // ---- stage the next tile (see above) ------------------------------------------------
         {
             const uint64_t i1 = i + 64ull, i2 = i + 128ull;
@@ -391,6 +427,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         // array, identical neighbouring slots merged into one atomic.
         // one f64 division per record (the expansion is long and would otherwise be repeated per slot); a slot adds
         // len * (1 / aligned), within 1 ulp of the reference's len / aligned
+        RSQC_MARK(10);                             // [10] issue of the next tile's loads
         const double inv_aligned = 1.0 / (double)(aligned ? aligned : 1u);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
@@ -406,6 +443,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 cov_add_merged(acc.cov_diff, hv, base + cm.len, 0xFFFFFFFFu);
             }
         }
+        RSQC_MARK(11);                             // [11] commit slots: exon fractions (LDS) + coverage atomics
 #pragma unroll
         for (int k = 0; k < FAST_SET; ++k) {
             const bool has = fo.n_hit > k;
@@ -426,6 +464,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             }
             if (has && !(p.dbg & 4096u)) S.gene_add(acc, g, notdup);
         }
+        RSQC_MARK(12);                             // [12] gene hits: pairs + gene counters
         // ---- feature-stage counter bits (disjoint from the gate's, so a second vertical add is exact) ----
         vertical_add(fo.bits);
         // 31 iterations fit the 5 planes (two adds of disjoint bit sets count once per counter); the u32
@@ -433,6 +472,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
     }
     flush_counts();
+    RSQC_MARK(13);
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
         if (l == 0) { atomicMax(&S.rl[0], ws); atomicMin(&S.rl[1], wmn); atomicMax(&S.rl[2], wmx); }
@@ -451,6 +491,11 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         atomicMax(&acc.rl_stats[0], S.rl[0]); atomicMin(&acc.rl_stats[1], S.rl[1]); atomicMax(&acc.rl_stats[2], S.rl[2]);
         acc.pair_chunk_count[blockIdx.x] = S.pairs < chunk_cap ? S.pairs : chunk_cap;
     }
+#ifdef RSQC_K1_PROF
+    RSQC_MARK(14);                                 // [14] workgroup epilogue (barrier + flush of the LDS tables)
+    __syncthreads();
+    if (threadIdx.x < 32 && s_prof_acc[threadIdx.x]) atomicAdd(&g_k1_prof[threadIdx.x], s_prof_acc[threadIdx.x]);
+#endif
 }
 
 // The same body under two register budgets and two load-batching depths (occupancy vs. spilling vs. round trips
@@ -707,6 +752,7 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     if (l == 0) {
         *acc.read_length = (int32_t)r;
         acc.rl_stats[0] = 0u; acc.rl_stats[1] = 0xFFFFFFFFu; acc.rl_stats[2] = 0u;    // ready for the next batch
+        acc.ovf_count[1] += *acc.ovf_count;   // records the general kernel took since the last reset (rsqc_timing.slow_records)
         *acc.ovf_count = 0u;                  // (the slow kernel, this batch's only reader, ran before this kernel)
     }
 }
@@ -1534,7 +1580,12 @@ void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams
     if (p.legacy) {
         const uint64_t blocks = (b.n + RSQC_SLOW_THREADS - 1) / RSQC_SLOW_THREADS;
         hipLaunchKernelGGL(classify_slow_kernel<true>, dim3((unsigned)std::min<uint64_t>(blocks ? blocks : 1, 4096)), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
-    } else hipLaunchKernelGGL(classify_slow_kernel<false>, dim3(64), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
+    } else {
+        // the number of listed records is only known on the device: enough workgroups for 1 record in 200 to take ONE record per
+        // thread (the code is a chain of dependent loads: parallelism, not iterations); workgroups beyond the list leave at once
+        const uint64_t blocks = std::max<uint64_t>(64, std::min<uint64_t>(2048, b.n / 200 / RSQC_SLOW_THREADS + 1));
+        hipLaunchKernelGGL(classify_slow_kernel<false>, dim3((unsigned)blocks), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
+    }
 }
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc) {

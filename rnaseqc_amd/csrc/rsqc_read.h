@@ -23,6 +23,11 @@
 #define RSQC_HD inline
 #endif
 
+// section marks of the profiling build of K1 (rsqc_kernels.hip, -DRSQC_K1_PROF); nothing otherwise
+#ifndef RSQC_MARK
+#define RSQC_MARK(sec)
+#endif
+
 namespace rsqc {
 
 // base[idx] with the byte offset formed in 32 bits: the device code then addresses the table as
@@ -488,9 +493,11 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
     for (int k = 0; k < NSLOT; ++k) { out.row[k] = 0; out.cidx[k] = 0; }
     FastBins fb;
     fast_load_bins(a, ci, B, fb);
+    RSQC_MARK(3);
 #pragma unroll
     for (int b0 = 0; b0 < FAST_BLOCKS; b0 += ROUND) {
         if (b0 > 0 && !RSQC_ANY_LANE(B.nb > (uint32_t)b0)) break;
+        RSQC_MARK(4 + b0);
         FastRows fr[ROUND];
 #pragma unroll
         for (int j = 0; j < ROUND; ++j) fast_load_rows(a, ci, fb.ehi[b0 + j], fb.nxt[b0 + j], ((fb.have >> (b0 + j)) & 1u) != 0, fr[j]);
@@ -566,6 +573,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
             }
         }
     }
+    RSQC_MARK(8);
     overflow = over;
     ga = ga && va; gb = gb && vb;
     const int nlast = (va ? 1 : 0) + (vb ? 1 : 0);

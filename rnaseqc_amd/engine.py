@@ -14,7 +14,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librnaseqc_amd.so")
+LIB_PATH = os.environ.get("RSQC_LIB") or os.path.join(_HERE, "lib", "librnaseqc_amd.so")   # RSQC_LIB: a diagnostic build (make prof)
 _lib = None
 
 

@@ -66,32 +66,29 @@ def make_annotation(seed: int = 1, contigs=None, bam_contigs=None, shuffle_rows:
                        np.clip(np.rint(np.exp(rng.normal(np.log(9.0), 0.72, ng))), 1, 359)).astype(np.int64)
         giant = rng.random(ng) < 0.0004
         nex[giant] = rng.integers(150, 360, int(giant.sum()))
+        budget = max(clen - 1000, 1000)
         E = int(nex.sum())
         elen = np.clip(np.rint(np.exp(rng.normal(np.log(150.0), 0.8, E))), 20, 12000).astype(np.int64)
         ilen = np.clip(np.rint(np.exp(rng.normal(np.log(1500.0), 1.2, E))), 50, 150000).astype(np.int64)
         first = np.cumsum(nex) - nex                     # index of each gene's first exon
-        gidx = np.repeat(np.arange(ng), nex)
         ilen[first] = 0                                  # no intron before the first exon
+        if elen.sum() + ilen.sum() > 0.6 * budget:
+            if elen.sum() < 0.45 * budget:               # gene-dense contig (chr19-like): shorter introns, same exons
+                ilen = np.maximum((ilen * ((0.6 * budget - elen.sum()) / ilen.sum())).astype(np.int64), 30)
+                ilen[first] = 0
+            else:                                        # too small for spliced models (chrM: 37 genes in 16.5 kb):
+                nex = np.ones(ng, np.int64); E = ng      # single-exon genes sized to the contig, like the real one
+                elen = np.maximum((0.85 * budget / ng * (0.4 + 1.2 * rng.random(ng))).astype(np.int64), 30)
+                ilen = np.zeros(ng, np.int64)
+                first = np.arange(ng)
+        gidx = np.repeat(np.arange(ng), nex)
         step = elen + ilen
         cum = np.cumsum(step)
         rel_end = cum - (cum[first] - step[first])[gidx]  # exon end offset within gene (exclusive)
         rel_start = rel_end - elen
         span = rel_end[first + nex - 1]
-        # tiny contigs (chrM): shrink to fit
-        budget = max(clen - 1000, 1000)
-        if span.sum() > 0.6 * budget:
-            scale = 0.6 * budget / span.sum()
-            rel_start = np.floor(rel_start * scale).astype(np.int64)
-            rel_end = np.maximum(rel_start + 20, np.floor(rel_end * scale).astype(np.int64))
-            # keep exons disjoint after scaling
-            for _ in range(3):
-                nxt = np.roll(rel_start, -1)
-                last = np.zeros(E, bool)
-                last[first + nex - 1] = True
-                bad = (~last) & (rel_end > nxt - 1)
-                rel_end[bad] = nxt[bad] - 1
-                rel_end = np.maximum(rel_end, rel_start + 1)
-            span = rel_end[first + nex - 1]
+        if span.sum() > 0.9 * budget:
+            raise ValueError("contig %s is too small for %d genes" % (cname, ng))
         free = budget - span.sum()
         overlap = rng.random(ng) < 0.10
         overlap[0] = False

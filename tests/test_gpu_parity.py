@@ -352,7 +352,7 @@ def test_fasta_gc_vs_oracle(oracle_lib, kw):
     ref = synth.make_reference(SMALL_LENGTHS[:2], seed=11)            # chrC is not in the FASTA index
     p = abi.default_params(**kw)
     want = oracle_lib.run_oracle(p, ann, [batch], reference=ref)
-    assert int(want.gc_bins.sum()) > 1000 and int((want.gc_bins > 0).sum()) > 20
+    assert int(want.gc_bins.sum()) > 500 and int((want.gc_bins > 0).sum()) > 20
     got = engine.run_engine(p, ann, [batch], reference=ref)
     assert_results_match(got, want)
     n = batch.n                                                      # mates of a fragment in different batches

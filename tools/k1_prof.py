@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Section timers of K1 (diagnostic build `make -C rnaseqc_amd/csrc prof`): where the waves' cycles go, stalls included.
+Usage: RSQC_LIB=rnaseqc_amd/lib/librnaseqc_amd_prof.so python tools/k1_prof.py [--pairs N] [--chr1]"""
+import argparse, ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RSQC_LIB", os.path.join(ROOT, "rnaseqc_amd", "lib", "librnaseqc_amd_prof.so"))
+import numpy as np
+from rnaseqc_amd import abi, engine, synth
+ap = argparse.ArgumentParser(); ap.add_argument("--pairs", type=int, default=10_000_000); ap.add_argument("--chr1", action="store_true")
+args = ap.parse_args()
+contigs = [synth.HUMAN_CONTIGS[0]] if args.chr1 else synth.human_contigs()
+ann = synth.make_annotation(seed=1, contigs=contigs)
+batch = synth.make_reads(ann, args.pairs, seed=2) if args.chr1 else synth.make_reads_sharded(ann, args.pairs, seed=2, workers=24)[0]
+e = engine.Engine(abi.default_params()); e.set_annotation(ann); h = e.upload(batch)
+lib = engine.load_library()
+names = ["loop+flush", "load-wait+unpack+cigar+gate", "gate counters+RL", "bins load", "round0", "round1", "round2", "round3",
+         "feature epilogue", "class bits/ovf", "stage next tile", "commit slots", "gene hits", "tail flush", "wg epilogue", ""]
+for rep in range(2):
+    e.reset(); lib.rsqc_debug_k1_prof(None, 1); e.submit_resident(h); e.wait()
+out = (C.c_ulonglong * 32)(); lib.rsqc_debug_k1_prof(out, 0)
+cyc = np.array(out[:16], dtype=np.float64); cnt = np.array(out[16:], dtype=np.float64)
+tiles = (batch.n + 63) // 64
+tm = e.timing()
+print("records %d  tiles %d  K1 %.3f ms" % (batch.n, tiles, tm["classify_ms"] / max(tm["classify_launches"], 1)))
+for k in range(15):
+    if cnt[k]: print("  [%2d] %-30s %5.1f %%   %8.0f cycles/tile   (%.2f marks/tile)" % (k, names[k], 100 * cyc[k] / cyc.sum(), cyc[k] / tiles, cnt[k] / tiles))
+print("  total %.0f cycles/tile/wave (s_memtime ticks)" % (cyc.sum() / tiles))
+e.close()
