@@ -163,11 +163,20 @@ def main():
     workers = args.workers or max(1, min(cores // max(world, 1), 24))
     if args.chr1:
         batch = synth.make_reads(ann, args.pairs, seed=2)
+        parts = [batch]
+    elif world > 1 or args.dist_selftest:
+        # sharded runs submit one batch per owned contig: a batch is a contiguous range of the file, and the
+        # order-dependent outputs are composed per batch in file order (rsqc_shard_info)
+        parts, _ = synth.make_reads_sharded(ann, args.pairs, seed=2, contigs=mine, workers=workers, with_unmapped=(rank == tail_rank), as_parts=True)
+        batch = None
     else:
         batch, _ = synth.make_reads_sharded(ann, args.pairs, seed=2, contigs=mine, workers=workers, with_unmapped=(rank == tail_rank))
-    st = batch.to_struct()
+        parts = [batch]
+    structs = [b.to_struct() for b in parts]
+    st = structs[0] if len(structs) == 1 else None
+    n_local = sum(b.n for b in parts)
     t_gen = time.time() - t_gen
-    log("inputs: %d genes, %d exons, %d records on this rank, %.1f s (%d generator processes)" % (ann.n_genes, ann.n_exons, batch.n, t_gen, workers))
+    log("inputs: %d genes, %d exons, %d records in %d batch(es) on this rank, %.1f s (%d generator processes)" % (ann.n_genes, ann.n_exons, n_local, len(parts), t_gen, workers))
 
     import torch
     from rnaseqc_amd import engine
@@ -197,8 +206,10 @@ def main():
         t_ref = time.time()
         e.set_reference(synth.make_reference([c[1] for c in contigs], seed=7, uniform=True))
         t_ref = time.time() - t_ref
-    h = e.upload_struct(st)                  # inputs resident in HBM before the timed region
+    handles = [e.upload_struct(x) for x in structs]      # inputs resident in HBM before the timed region
     if args.host_fed:                        # the same batch in page-locked host memory
+        if st is None:
+            raise SystemExit("--host-fed is a single-batch diagnostic")
         import ctypes
         keep = []
         for f, n_items, dt in (("core", batch.n, abi.REC_CORE), ("aux", batch.n, abi.REC_AUX), ("cigar", len(batch.cigar), np.uint32)):
@@ -207,6 +218,7 @@ def main():
             setattr(st, f, pin.ctypes.data)
 
     vec = None
+    order_dep = [None]
     if reduce_path:
         vec = [torch.as_tensor(v, device="cuda") for v in e.device_vectors()]
 
@@ -215,7 +227,8 @@ def main():
         if args.host_fed:
             e.submit_struct(st)              # H2D (DMA from page-locked memory) + K1, as the CLI does per batch
         else:
-            e.submit_resident(h)
+            for h in handles:
+                e.submit_resident(h)
         if args.no_finalize:
             e.wait()
             return None
@@ -224,6 +237,9 @@ def main():
         e.finalize_device()                  # results stay on the device until they are reduced
         for t in vec:                        # RCCL over xGMI: u64 counts | f64 sums + owner-only statistics | u8 validity flags
             dist.all_reduce(t)
+        # the order-dependent outputs (Read Length; the fragment-size cut-off with --bed): per-batch transfer functions
+        # and kept samples of every rank, composed in file order on the host
+        order_dep[0] = distributed.merge_order_dependent(e.shard_summary(), dist, torch.device("cuda", local_rank), p.fragment_samples)
         torch.cuda.synchronize()
         return e.refresh_results(lazy=True)
 
@@ -239,13 +255,13 @@ def main():
     torch.cuda.synchronize()
     if dist: dist.barrier()
     elapsed = time.perf_counter() - t0
-    per_rank = [int(batch.n)]
+    per_rank = [int(n_local)]
     if dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         nrec = torch.zeros(world, device="cuda", dtype=torch.int64)
-        nrec[rank] = batch.n
+        nrec[rank] = n_local
         dist.all_reduce(nrec)
         per_rank = [int(x) for x in nrec.tolist()]
     total_records = sum(per_rank)
@@ -261,10 +277,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
-            if int(tj.get("records", 0)) == int(batch.n) and int(tj.get("genes", 0)) == int(ann.n_genes):
+            if int(tj.get("records") or 0) == int(n_local) and int(tj.get("genes") or 0) == int(ann.n_genes):
                 traffic = tj.get("hbm_bytes_per_launch")
         cpu = None
-        if args.cpu_sample > 0 and world == 1:          # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
+        if args.cpu_sample > 0 and world == 1 and batch is not None:          # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             from oracle import binding
             ns = min(args.cpu_sample, batch.n)
             sample = batch.slice(0, ns) if ns < batch.n else batch
@@ -309,10 +325,11 @@ def main():
                          "timer": "hipEvents around the launch on the context's stream (rsqc_get_timing), rank 0"},
             "cpu_baseline": cpu,
             "end_to_end": e2e,
-            "stage_ms": {"classify_k1": k1_ms, "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
+            "stage_ms": {"classify_k1": k1_ms * len(handles), "classify_launches_per_step": len(handles), "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
                          "slow_path_records": int(tm["slow_records"])},
             "checks": None if res is None else {"gene_reads_sum": int(res.gene_reads.sum()),
-                                                "total_alignments": res.counter("Total Alignments")},
+                                                "total_alignments": res.counter("Total Alignments"),
+                                                "read_length": int(order_dep[0][0]) if order_dep[0] else int(res.read_length)},
             "input_generation_s": round(t_gen, 1),
         }
         for flag, why in (("chr1", "diagnostic run: configs[1] (chr1), not the workload the metric is quoted on"),

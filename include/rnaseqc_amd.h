@@ -278,7 +278,9 @@ typedef struct rsqc_rec_aux {          /* 16 bytes                             *
  * batches; 1-4 M records per batch is the intended granularity).                                          */
 typedef struct rsqc_batch {
     uint64_t n;                        /* records                              */
-    uint64_t file_index_base;          /* index of record 0 in the whole file  */
+    uint64_t file_index_base;          /* index of record 0 in the whole file: a batch is a contiguous range of the
+                                          file, batches are submitted in ascending order (gaps allowed: the records
+                                          of other shards); decides the fragment-size cut-off and the shard merge */
     const rsqc_rec_core *core;         /* [n]                                  */
     const rsqc_rec_aux  *aux;          /* [n]                                  */
     const uint32_t *cigar;             /* BAM packed ops: len<<4 | op          */
@@ -417,6 +419,27 @@ RSQC_API int rsqc_device_accumulators(rsqc_ctx *ctx, void **u64_base, uint64_t *
  * exposes the additive prefixes of [0] and [1] only.                                                              */
 typedef struct rsqc_device_range { void *base; uint64_t count; } rsqc_device_range;
 RSQC_API int rsqc_device_vectors(rsqc_ctx *ctx, rsqc_device_range out[3]);
+/* The order-dependent outputs of a shard, for the host-side merge of a contig-sharded run; valid
+ * after rsqc_finalize / rsqc_finalize_device until the next reset.  Pointers are owned by the context.
+ *   Read Length (src/RNASeQC.cpp:275-278) is a state machine over the file.  Per submitted batch the library keeps
+ *   the batch's transfer function as a short table: entered with state r, the batch leaves rl_state[k] for the first k
+ *   in [rl_offset[b], rl_offset[b+1]) with rl_span[k] > r, and r itself when no entry qualifies.  Composing the
+ *   batches of ALL shards in ascending batch_file_index from state 0 gives the reference's value.
+ *   Fragment sizes (src/Expression.cpp:482-540): mates pair inside one BED interval, hence inside one shard; the
+ *   cut-off --fragment-samples applies in FILE order.  The shard hands over the samples it kept (its first N by the file
+ *   index of the completing record, ascending); the merged histogram holds the N smallest file indices of the union.  */
+typedef struct rsqc_shard_info {
+    uint32_t n_batches;
+    const uint64_t *batch_file_index;  /* [n_batches] file_index_base of the batch  */
+    const uint64_t *batch_records;     /* [n_batches]                               */
+    const uint32_t *rl_offset;         /* [n_batches + 1]                           */
+    const uint32_t *rl_span;           /* ascending inside a batch                  */
+    const int32_t  *rl_state;
+    uint32_t n_samples;
+    const uint64_t *sample_file_index; /* [n_samples] ascending                     */
+    const uint32_t *sample_size;       /* [n_samples] abs(InsertSize)               */
+} rsqc_shard_info;
+RSQC_API int rsqc_shard_summary(rsqc_ctx *ctx, rsqc_shard_info *out);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
 /* Page-locked host memory for the arrays of an rsqc_batch: rsqc_submit then copies by DMA and returns without

@@ -40,6 +40,8 @@ def lib():
         _lib.oracle_destroy.restype = None
         _lib.oracle_last_error.argtypes = [C.c_void_p]
         _lib.oracle_last_error.restype = C.c_char_p
+        _lib.oracle_enable_trace.argtypes = [C.c_void_p]
+        _lib.oracle_get_trace.argtypes = [C.c_void_p, C.POINTER(OracleTrace)]
         _lib.oracle_exit_order.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         _lib.oracle_median_f64.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         _lib.oracle_statistics.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
@@ -47,6 +49,12 @@ def lib():
         _lib.oracle_library_complexity.argtypes = [C.c_double, C.c_double, C.c_double]
         _lib.oracle_library_complexity.restype = C.c_uint
     return _lib
+
+
+class OracleTrace(C.Structure):
+    _fields_ = [("n_eligible", C.c_uint64), ("span", C.c_void_p), ("l_qseq", C.c_void_p),
+                ("n_batches", C.c_uint64), ("batch_end", C.c_void_p), ("batch_file_index", C.c_void_p),
+                ("n_samples", C.c_uint64), ("sample_file_index", C.c_void_p), ("sample_size", C.c_void_p)]
 
 
 class OracleError(RuntimeError):
@@ -92,6 +100,29 @@ class Oracle:
         rs = abi.ResultsStruct()
         self._check(self._l.oracle_finalize(self._h, C.byref(rs)))
         return abi.Results(rs).materialise()
+
+    def enable_trace(self):
+        self._check(self._l.oracle_enable_trace(self._h))
+
+    def shard_info(self):
+        """distributed.ShardInfo of what this oracle instance processed (needs enable_trace() before the first submit;
+        run with fragment_samples = 2^32 - 1 so that the shard's sampler is not cut off before the merge)."""
+        from rnaseqc_amd import distributed
+        t = OracleTrace()
+        self._check(self._l.oracle_get_trace(self._h, C.byref(t)))
+        span = abi._view(t.span, t.n_eligible, np.uint32); lq = abi._view(t.l_qseq, t.n_eligible, np.int32)
+        ends = abi._view(t.batch_end, t.n_batches, np.uint64).astype(np.int64)
+        off, keys, vals = [0], [], []
+        lo = 0
+        for hi in ends:
+            k, v = distributed.read_length_transfer(span[lo:hi], lq[lo:hi])
+            keys.append(k); vals.append(v); off.append(off[-1] + len(k)); lo = int(hi)
+        return distributed.ShardInfo(
+            batch_file_index=abi._view(t.batch_file_index, t.n_batches, np.uint64), batch_records=np.zeros(t.n_batches, np.uint64),
+            rl_offset=np.array(off, np.uint32), rl_span=np.concatenate(keys) if keys else np.zeros(0, np.uint32),
+            rl_state=np.concatenate(vals) if vals else np.zeros(0, np.int32),
+            sample_file_index=abi._view(t.sample_file_index, t.n_samples, np.uint64),
+            sample_size=abi._view(t.sample_size, t.n_samples, np.uint32))
 
     def exit_order(self) -> np.ndarray:
         p, n = C.c_void_p(), C.c_uint32()

@@ -108,6 +108,14 @@ typedef struct oracle_ctx {
     uint32_t *exit_order; uint32_t n_exit;         /* coverage.tsv row order  */
     /* results mirrors */
     uint64_t *r_reads, *r_unique, *r_frag;
+    /* test trace (oracle_enable_trace): what a contig-sharded run needs from a shard for the host-side merge -- the
+     * (span, l_qseq) of every record that reaches src/RNASeQC.cpp:275, the record counts at the end of every submit,
+     * and every fragment-size sample with the file index of the record that completed it                          */
+    int trace;
+    uint64_t cur_file_index;
+    uint32_t *tr_span; int32_t *tr_lq; size_t tr_n, tr_cap;
+    uint64_t *tr_batch_end, *tr_batch_file; size_t tr_nb, tr_bcap;
+    uint64_t *tr_sample_file; uint32_t *tr_sample_size; size_t tr_ns, tr_scap;
     int error;
     char errmsg[256];
 } oracle_ctx;
@@ -513,6 +521,13 @@ static void fragment_size(oracle_ctx *c, const rec_t *r, const block_t *blocks, 
             c->fs_size[k] = key; c->fs_count[k] = 0; c->fs_n++;
         }
         c->fs_count[k]++;
+        if (c->trace) {
+            if (c->tr_ns == c->tr_scap) {
+                c->tr_scap = c->tr_scap ? c->tr_scap * 2 : 4096;
+                c->tr_sample_file = xrealloc(c->tr_sample_file, c->tr_scap * 8); c->tr_sample_size = xrealloc(c->tr_sample_size, c->tr_scap * 4);
+            }
+            c->tr_sample_file[c->tr_ns] = c->cur_file_index; c->tr_sample_size[c->tr_ns] = (uint32_t)key; c->tr_ns++;
+        }
         free(found->s); found->s = NULL; found->used = 2;                   /* erase :531 (tombstone) */
         --c->frag_remaining;                                                /* :532 */
     }
@@ -844,6 +859,13 @@ static int process_record(oracle_ctx *c, const rec_t *r) {
     unsigned int alignment_size = (unsigned int)(endpos - r->pos);          /* :275 */
     if (legacy && alignment_size > 100000u) return 0;                       /* :276, LEGACY_MAX_READ_LENGTH :27 */
     if (alignment_size > (unsigned int)c->read_length) c->read_length = r->l_qseq; /* :278 */
+    if (c->trace) {
+        if (c->tr_n == c->tr_cap) {
+            c->tr_cap = c->tr_cap ? c->tr_cap * 2 : 4096;
+            c->tr_span = xrealloc(c->tr_span, c->tr_cap * 4); c->tr_lq = xrealloc(c->tr_lq, c->tr_cap * 4);
+        }
+        c->tr_span[c->tr_n] = alignment_size; c->tr_lq[c->tr_n] = r->l_qseq; c->tr_n++;
+    }
     if (!legacy && has_ch) {                                                /* :279-283 */
         if (fl & RSQC_FREAD1) INC(RSQC_C_CHIMERIC_TAG);
         if (c->p.exclude_chimeric) return 0;
@@ -1045,10 +1067,33 @@ ORACLE_API int oracle_submit(oracle_ctx *c, const rsqc_batch *b) {
             r.qhash = ra->qhash;
             r.qname = NULL; r.qname_len = 0;
             if (b->qname && b->qname_off) { r.qname = b->qname + b->qname_off[i]; r.qname_len = b->qname_off[i + 1] - b->qname_off[i]; }
+            c->cur_file_index = b->file_index_base + i;
             int rc = process_record(c, &r);
             if (rc) return c->error = rc;
         }
     }
+    if (c->trace) {
+        if (c->tr_nb == c->tr_bcap) {
+            c->tr_bcap = c->tr_bcap ? c->tr_bcap * 2 : 64;
+            c->tr_batch_end = xrealloc(c->tr_batch_end, c->tr_bcap * 8); c->tr_batch_file = xrealloc(c->tr_batch_file, c->tr_bcap * 8);
+        }
+        c->tr_batch_end[c->tr_nb] = c->tr_n; c->tr_batch_file[c->tr_nb] = b->file_index_base; c->tr_nb++;
+    }
+    return 0;
+}
+
+/* test trace: see oracle_ctx.trace */
+typedef struct oracle_trace {
+    uint64_t n_eligible; const uint32_t *span; const int32_t *l_qseq;
+    uint64_t n_batches; const uint64_t *batch_end, *batch_file_index;
+    uint64_t n_samples; const uint64_t *sample_file_index; const uint32_t *sample_size;
+} oracle_trace;
+ORACLE_API int oracle_enable_trace(oracle_ctx *c) { if (!c) return RSQC_ERR_ARG; c->trace = 1; return 0; }
+ORACLE_API int oracle_get_trace(oracle_ctx *c, oracle_trace *t) {
+    if (!c || !t) return RSQC_ERR_ARG;
+    t->n_eligible = c->tr_n; t->span = c->tr_span; t->l_qseq = c->tr_lq;
+    t->n_batches = c->tr_nb; t->batch_end = c->tr_batch_end; t->batch_file_index = c->tr_batch_file;
+    t->n_samples = c->tr_ns; t->sample_file_index = c->tr_sample_file; t->sample_size = c->tr_sample_size;
     return 0;
 }
 
@@ -1107,6 +1152,7 @@ ORACLE_API void oracle_destroy(oracle_ctx *c) {
     free(c->tracker); free(c->cov); free(c->seen); free(c->cov_mean); free(c->cov_std); free(c->cov_cv);
     free(c->cov_valid); free(c->exon_cv); free(c->exon_cv_valid); free(c->bias3); free(c->bias5);
     free(c->exit_order); free(c->r_reads); free(c->r_unique); free(c->r_frag);
+    free(c->tr_span); free(c->tr_lq); free(c->tr_batch_end); free(c->tr_batch_file); free(c->tr_sample_file); free(c->tr_sample_size);
     free(c);
 }
 

@@ -53,6 +53,12 @@ REC_AUX = np.dtype([("qhash", "<u8"), ("flag", "<u2"), ("l_qseq", "<u2"), ("mapq
 assert REC_CORE.itemsize == 16 and REC_AUX.itemsize == 16
 
 
+class ShardInfoStruct(C.Structure):
+    _fields_ = [("n_batches", C.c_uint32), ("batch_file_index", C.c_void_p), ("batch_records", C.c_void_p),
+                ("rl_offset", C.c_void_p), ("rl_span", C.c_void_p), ("rl_state", C.c_void_p),
+                ("n_samples", C.c_uint32), ("sample_file_index", C.c_void_p), ("sample_size", C.c_void_p)]
+
+
 class DeviceRange(C.Structure):
     _fields_ = [("base", C.c_void_p), ("count", C.c_uint64)]
 

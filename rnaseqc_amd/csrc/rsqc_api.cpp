@@ -31,7 +31,7 @@ struct DevBuf {
 struct UploadedBatch {
     DevBatch d{};
     std::vector<DevBuf> bufs;
-    uint64_t n = 0, n_cigar_total = 0;
+    uint64_t n = 0, n_cigar_total = 0, file_index_base = 0;
     bool in_use = false;
     bool pooled = false;           // transient upload: its buffers go back to the context's pool
 };
@@ -117,6 +117,14 @@ struct rsqc_ctx {
     std::vector<UploadedBatch *> resident;
     std::vector<UploadedBatch *> transient;     // owned by submit(), freed at wait()
     uint64_t next_record_base = 0;
+    // per submitted batch: file index of its first record and the Read-Length transfer function the KR kernel leaves
+    // on the device (rsqc_shard_info)
+    std::vector<uint64_t> batch_file_index, batch_records;
+    DevBuf d_rl_summary;
+    std::vector<uint32_t> h_rl_raw, h_rl_offset, h_rl_span;
+    std::vector<int32_t> h_rl_state;
+    std::vector<uint64_t> h_sample_file;        // fragment-size samples kept by this shard (first N by file index), ascending
+    std::vector<uint32_t> h_sample_size;
 
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> k1_events, h2d_events;
@@ -254,6 +262,9 @@ int zero_accumulators(rsqc_ctx *c) {
     }
     c->finalized = false;
     c->next_record_base = 0;
+    c->batch_file_index.clear(); c->batch_records.clear();
+    c->h_rl_offset.clear(); c->h_rl_span.clear(); c->h_rl_state.clear();
+    c->h_sample_file.clear(); c->h_sample_size.clear();
     c->sticky = 0;
     return 0;
 }
@@ -263,7 +274,7 @@ int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u, bool pooled
     if (b->n > 0xFFFFFFF0ull || b->n_cigar_total >= (1ull << 30)) return fail(c, RSQC_ERR_ARG, "batch too large");
     DevBatch &d = u->d;
     d.n = b->n; d.n_seg = b->n_seg; d.n_wide = b->n_wide;
-    u->n = b->n; u->n_cigar_total = b->n_cigar_total;
+    u->n = b->n; u->n_cigar_total = b->n_cigar_total; u->file_index_base = b->file_index_base;
     int rc;
 #define UP(field, count) if ((rc = upload(c, u->bufs, b->field, (size_t)(count), &d.field, pooled))) return rc
     UP(core, b->n); UP(aux, b->n);
@@ -353,16 +364,25 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
         acc.frag.name = (int32_t *)fb.name.p; acc.frag.endpos = (int32_t *)fb.endpos.p;
         acc.frag.flag_size = (uint32_t *)fb.fs.p; acc.frag.count = (uint32_t *)fb.count.p; acc.frag.cap = fb.cap;
     }
+    // file order is part of the boundary: the index of record 0 in the whole file comes from the caller (it decides the
+    // first-N cut-off of the fragment-size sampler and the order in which shards are composed); batches arrive in file order
+    if (u->file_index_base < c->next_record_base)
+        return fail(c, RSQC_ERR_ARG, "batches must be submitted in file order (file_index_base below the end of the previous batch)");
+    constexpr size_t kMaxBatches = 1u << 14;
+    if (c->batch_file_index.size() >= kMaxBatches) return fail(c, RSQC_ERR_CAPACITY, "more than 16384 batches in one pass");
+    if (!c->d_rl_summary.p) { int rc3 = dev_alloc(c, c->d_rl_summary, kMaxBatches * RSQC_RL_SUMMARY_WORDS * 4, false); if (rc3) return rc3; }
+    uint32_t *rl_slot = (uint32_t *)c->d_rl_summary.p + c->batch_file_index.size() * RSQC_RL_SUMMARY_WORDS;
+    c->batch_file_index.push_back(u->file_index_base); c->batch_records.push_back(u->n);
     DevBatch d = u->d;
-    d.record_base = c->next_record_base;
-    c->next_record_base += u->n;
+    d.record_base = u->file_index_base;
+    c->next_record_base = u->file_index_base + u->n;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc);
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->k1_events.emplace_back(e0, e1);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
-    launch_read_length(c->stream, c->dann, c->dparams, d, acc);
+    launch_read_length(c->stream, c->dann, c->dparams, d, acc, rl_slot);
     if (c->have_ref && !c->dparams.legacy) {          // --fasta: fragment GC candidates, a separate pass over the batch
         size_t gidx = c->gc_pool.size();
         for (size_t i = 0; i < c->gc_pool.size(); ++i) if (!c->gc_pool[i].used && c->gc_pool[i].cap >= u->n) { gidx = i; break; }
@@ -869,7 +889,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             FragCandidates fc{(uint64_t *)m_file.p, (uint64_t *)m_q.p, (int32_t *)m_name.p, (int32_t *)m_end.p,
                               (uint32_t *)m_fs.p, nullptr, (uint32_t)total};
             rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
-                                    c->frag_remaining);
+                                    c->frag_remaining, &c->h_sample_file, &c->h_sample_size);
             m_file.release(); m_q.release(); m_name.release(); m_end.release(); m_fs.release();
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
@@ -916,8 +936,24 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             HIP_TRY(c, hipMemcpyAsync(c->h_gc.data(), c->d_gc_bins.p, (RSQC_GC_BINS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
+    // ---- per-batch Read-Length transfer functions (rsqc_shard_info) -----------------------------------------------
+    {
+        const size_t nb = c->batch_file_index.size();
+        c->h_rl_raw.resize(nb * RSQC_RL_SUMMARY_WORDS);
+        if (nb) HIP_TRY(c, hipMemcpyAsync(c->h_rl_raw.data(), c->d_rl_summary.p, nb * RSQC_RL_SUMMARY_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     c->fin_e0 = e0; c->fin_e1 = e1;
     return 0;
+}
+static void unpack_rl_summaries(rsqc_ctx *c) {           // after the stream has been synchronised
+    const size_t nb = c->batch_file_index.size();
+    c->h_rl_offset.assign(nb + 1, 0); c->h_rl_span.clear(); c->h_rl_state.clear();
+    for (size_t k = 0; k < nb; ++k) {
+        const uint32_t *w = c->h_rl_raw.data() + k * RSQC_RL_SUMMARY_WORDS;
+        const uint32_t P = std::min<uint32_t>(w[0], 128u);
+        for (uint32_t j = 0; j < P; ++j) { c->h_rl_span.push_back(w[2 + 2 * j]); c->h_rl_state.push_back((int32_t)w[3 + 2 * j]); }
+        c->h_rl_offset[k + 1] = (uint32_t)c->h_rl_span.size();
+    }
 }
 static void finish_finalize_bookkeeping(rsqc_ctx *c) {
     float ms = 0.f;
@@ -926,6 +962,7 @@ static void finish_finalize_bookkeeping(rsqc_ctx *c) {
     resolve_events(c);
     for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
+    unpack_rl_summaries(c);
     c->finalized = true;
 }
 
@@ -967,6 +1004,16 @@ int rsqc_device_accumulators(rsqc_ctx *c, void **u64_base, uint64_t *u64_count, 
     if (!c || !c->have_ann || !u64_base || !u64_count || !f64_base || !f64_count) return RSQC_ERR_ARG;
     *u64_base = (char *)c->d_arena.p + c->off_u64; *u64_count = (uint64_t)c->n_genes * 3 + RSQC_N_COUNTERS;
     *f64_base = (char *)c->d_arena.p + c->off_exon; *f64_count = (uint64_t)c->n_exons;
+    return RSQC_OK;
+}
+
+int rsqc_shard_summary(rsqc_ctx *c, rsqc_shard_info *out) {
+    if (!c || !out || !c->have_ann || !c->finalized) return RSQC_ERR_ARG;
+    out->n_batches = (uint32_t)c->batch_file_index.size();
+    out->batch_file_index = c->batch_file_index.data(); out->batch_records = c->batch_records.data();
+    out->rl_offset = c->h_rl_offset.data(); out->rl_span = c->h_rl_span.data(); out->rl_state = c->h_rl_state.data();
+    out->n_samples = (uint32_t)c->h_sample_file.size();
+    out->sample_file_index = c->h_sample_file.data(); out->sample_size = c->h_sample_size.data();
     return RSQC_OK;
 }
 

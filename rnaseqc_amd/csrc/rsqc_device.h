@@ -129,8 +129,10 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
                      const DevAccum &acc);
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc);
+// summary (may be NULL): RSQC_RL_SUMMARY_WORDS words of the batch's Read-Length transfer function (rsqc_kernels.hip, KR)
+#define RSQC_RL_SUMMARY_WORDS (2 + 2 * 128)
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                        const DevAccum &acc);
+                        const DevAccum &acc, uint32_t *summary);
 void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
                   unsigned long long *table, uint32_t mode, int grid);
 // K4, streaming form (rsqc_kernels.hip): partition tables laid out on the device from the final geneCounts
@@ -153,8 +155,10 @@ void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, ui
 
 #include <vector>
 namespace rsqc {
+// keep_file / keep_size (may be NULL): the kept samples themselves (first max_samples by file index, ascending)
 int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
-                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining);
+                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining,
+                       std::vector<uint64_t> *keep_file = nullptr, std::vector<uint32_t> *keep_size = nullptr);
 // --fasta (rsqc_kernels.hip / rsqc_fragsize.hip)
 void launch_gc_pack(hipStream_t s, const uint8_t *ascii, uint64_t len, unsigned long long *words);
 void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R, double *exon_gc);

@@ -71,8 +71,11 @@ static hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *k
 // Runs K5 over `n` candidates (device arrays in `c`).  Returns 0 or an RSQC_ERR_* code; fills the
 // histogram (ascending size) and the number of samples left.
 int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
-                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining) {
+                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining,
+                       std::vector<uint64_t> *keep_file, std::vector<uint32_t> *keep_size) {
     sizes.clear(); counts.clear(); remaining = max_samples;
+    if (keep_file) keep_file->clear();
+    if (keep_size) keep_size->clear();
     if (n == 0) return 0;
     uint64_t *k0 = nullptr, *k1 = nullptr, *sf = nullptr, *sf2 = nullptr;
     uint32_t *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *ss = nullptr, *d_ns = nullptr, *sidx = nullptr, *sidx2 = nullptr;
@@ -115,6 +118,11 @@ int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, 
         for (uint32_t i = 0; i < keep; ++i) hist[(int64_t)h_size[ord[i]]]++;
         for (auto &kv : hist) { sizes.push_back(kv.first); counts.push_back(kv.second); }
         remaining = max_samples - keep;
+        if (keep_file && keep_size) {                     // the kept samples in file order: what a sharded run merges
+            std::sort(ord.begin(), ord.begin() + keep, [&](uint32_t x, uint32_t y) { return h_file[x] < h_file[y]; });
+            keep_file->reserve(keep); keep_size->reserve(keep);
+            for (uint32_t i = 0; i < keep; ++i) { keep_file->push_back(h_file[ord[i]]); keep_size->push_back(h_size[ord[i]]); }
+        }
     }
     cleanup();
 #undef FS_TRY

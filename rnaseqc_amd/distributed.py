@@ -28,12 +28,112 @@ def owned_mask(rank_of, rank: int) -> np.ndarray:
     return (np.asarray(rank_of) == rank).astype(np.uint8)
 
 
+from dataclasses import dataclass
+
+
+@dataclass
+class ShardInfo:
+    """The order-dependent outputs of one shard (include/rnaseqc_amd.h, rsqc_shard_info)."""
+    batch_file_index: np.ndarray       # [B] file index of the first record of every submitted batch
+    batch_records: np.ndarray          # [B]
+    rl_offset: np.ndarray              # [B + 1] into rl_span / rl_state
+    rl_span: np.ndarray                # Read-Length transfer function of the batch: ascending span keys ...
+    rl_state: np.ndarray               # ... and the state the batch leaves when entered with a state below the key
+    sample_file_index: np.ndarray      # fragment-size samples kept by the shard, ascending file index
+    sample_size: np.ndarray
+
+
+def read_length_transfer(span, lq):
+    """The Read-Length transfer function (src/RNASeQC.cpp:275-278) of a run of eligible records, as the table
+    rsqc_shard_info describes: keys = the prefix maxima of span, value k = the final state of the walk that starts by
+    firing prefix maximum k.  Literal restatement for the tests (the device kernel runs all the walks at once)."""
+    span = np.asarray(span, dtype=np.int64); lq = np.asarray(lq, dtype=np.int64)
+    keys, vals = [], []
+    cur = 0
+    starts = []
+    for i in range(len(span)):
+        if span[i] > cur:
+            cur = int(span[i]); starts.append(i)
+    for i in starts:
+        r = int(lq[i])
+        for j in range(i + 1, len(span)):
+            if span[j] > r:
+                r = int(lq[j])
+        keys.append(int(span[i])); vals.append(r)
+    return np.array(keys, np.uint32), np.array(vals, np.int32)
+
+
+def compose_read_length(infos):
+    """Read Length of the whole file from the shards' per-batch transfer functions: batches of all shards in
+    ascending file index, from state 0."""
+    items = []
+    for si in infos:
+        for b in range(len(si.batch_file_index)):
+            lo, hi = int(si.rl_offset[b]), int(si.rl_offset[b + 1])
+            items.append((int(si.batch_file_index[b]), si.rl_span[lo:hi], si.rl_state[lo:hi]))
+    items.sort(key=lambda t: t[0])
+    r = 0
+    for _, keys, vals in items:
+        k = int(np.searchsorted(keys, r, side="right"))          # first key > r (keys ascend)
+        if k < len(keys):
+            r = int(vals[k])
+    return r
+
+
+def merge_fragment_samples(infos, max_samples: int):
+    """First `max_samples` samples of the union in file order -> (sizes ascending, counts), remaining."""
+    f = np.concatenate([np.asarray(si.sample_file_index, np.uint64) for si in infos]) if infos else np.zeros(0, np.uint64)
+    z = np.concatenate([np.asarray(si.sample_size, np.uint32) for si in infos]) if infos else np.zeros(0, np.uint32)
+    keep = min(len(f), int(max_samples))
+    if keep < len(f):
+        idx = np.argpartition(f, keep - 1)[:keep] if keep else np.zeros(0, np.int64)
+        z = z[idx]
+    sizes, counts = np.unique(z.astype(np.int64), return_counts=True)
+    return sizes.astype(np.int64), counts.astype(np.uint64), int(max_samples) - keep
+
+
+def merge_order_dependent(shard: ShardInfo, dist=None, device=None, fragment_samples: int = 1000000):
+    """Gathers every rank's ShardInfo (a handful of small all_gathers) and returns
+    (read_length, fragment sizes, fragment counts, samples remaining, [ShardInfo per rank])."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+
+    def gather_var(a):
+        """Every rank's 1-D array (different lengths) -> list of int64 arrays, by padding to the longest.
+        (uint32 / uint64 travel as int64: gloo and RCCL both carry it, values are far below 2^63.)"""
+        a = np.ascontiguousarray(a).astype(np.int64)
+        if dist is None:
+            return [a]
+        n = torch.zeros(world, dtype=torch.int64, device=device); n[rank] = len(a)
+        dist.all_reduce(n)
+        n = n.cpu().numpy()
+        buf = torch.zeros(max(int(n.max()), 1), dtype=torch.int64, device=device)
+        if len(a):
+            buf[:len(a)] = torch.from_numpy(a).to(buf.device)
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        return [o.cpu().numpy()[:int(n[k])] for k, o in enumerate(out)]
+
+    cols = [gather_var(x) for x in (shard.batch_file_index, shard.batch_records, shard.rl_offset, shard.rl_span,
+                                    shard.rl_state, shard.sample_file_index, shard.sample_size)]
+    infos = [ShardInfo(*(c[k] for c in cols)) for k in range(world)]
+    sizes, counts, remaining = merge_fragment_samples(infos, fragment_samples)
+    return compose_read_length(infos), sizes, counts, remaining, infos
+
+
 class MergedResults:
     pass
 
 
-def merge_results(local, dist=None, device=None):
+def merge_results(local, dist=None, device=None, shard: ShardInfo | None = None, fragment_samples: int = 1000000):
     """All-reduce the additive parts of a rank's abi.Results and merge the owner-only parts.
+
+    `shard` (this rank's ShardInfo: Engine.shard_summary(), or built from the oracle's trace in the CPU tests) carries
+    the two order-dependent outputs: with it, Read Length is composed exactly from the per-batch transfer functions of
+    all ranks in file order, and the fragment-size histogram is rebuilt from the ranks' samples with the
+    --fragment-samples cut-off applied in file order (src/Expression.cpp:482-540).  Without it those two fields are
+    left unset (a consumer that needs them fails loudly).
 
     `dist` is torch.distributed (initialised) or None for a single rank.  Additive: gene reads /
     unique / fragments, exon fractions, scalar counters, fragment-size histogram.  Owner-only
@@ -70,16 +170,9 @@ def merge_results(local, dist=None, device=None):
     m.exon_cv = allsum(np.where(ev, local.exon_cv, 0.0), np.float64)
     m.bias_three = allsum(local.bias_three, np.int64).astype(np.uint64)
     m.bias_five = allsum(local.bias_five, np.int64).astype(np.uint64)
-    # Read Length: (rank, value) -- the last shard (highest rank with mapped records) decides when all
-    # shards are uniform; ranks hold contigs in increasing order in the benchmarks and the CLI
-    world = dist.get_world_size() if dist is not None else 1
-    rank = dist.get_rank() if dist is not None else 0
-    rl = np.zeros(world, dtype=np.int64)
-    rl[rank] = local.read_length
-    rl = allsum(rl, np.int64)
-    nz = np.flatnonzero(rl)
-    m.read_length = int(rl[nz[-1]]) if len(nz) else 0
-    m.read_length_per_rank = rl
+    if shard is not None:
+        m.read_length, m.fragment_size, m.fragment_count, m.fragment_samples_remaining, m.shard_infos = \
+            merge_order_dependent(shard, dist, device, fragment_samples)
     # --fasta: both mates of a GC fragment lie in one exon, hence on one contig -> the histogram is additive; exon GC
     # values depend on the annotation and the reference only (identical on every rank)
     m.have_reference = int(getattr(local, "have_reference", 0))

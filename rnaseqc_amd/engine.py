@@ -47,6 +47,7 @@ def load_library():
         lib.rsqc_reset_timing.argtypes = [vp]
         lib.rsqc_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
         lib.rsqc_device_vectors.argtypes = [vp, C.POINTER(abi.DeviceRange * 3)]
+        lib.rsqc_shard_summary.argtypes = [vp, C.POINTER(abi.ShardInfoStruct)]
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
         lib.rsqc_finalize_device.argtypes = [vp]
         lib.rsqc_host_alloc.argtypes = [C.c_size_t]; lib.rsqc_host_alloc.restype = vp
@@ -63,7 +64,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_set_reference", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
 ]
 
@@ -193,6 +194,20 @@ class Engine:
         self._check(self._l.rsqc_device_vectors(self._h, C.byref(r)))
         return (DeviceArray(r[0].base, r[0].count, "<i8"), DeviceArray(r[1].base, r[1].count, "<f8"),
                 DeviceArray(r[2].base, r[2].count, "|u1"))
+
+    def shard_summary(self):
+        """The order-dependent outputs of this shard (rsqc_shard_summary) as a distributed.ShardInfo (copies)."""
+        from .distributed import ShardInfo
+        si = abi.ShardInfoStruct()
+        self._check(self._l.rsqc_shard_summary(self._h, C.byref(si)))
+        nb, ns = si.n_batches, si.n_samples
+        off = abi._view(si.rl_offset, nb + 1, np.uint32).copy() if nb else np.zeros(1, np.uint32)
+        ne = int(off[-1])
+        return ShardInfo(batch_file_index=abi._view(si.batch_file_index, nb, np.uint64).copy(),
+                         batch_records=abi._view(si.batch_records, nb, np.uint64).copy(), rl_offset=off,
+                         rl_span=abi._view(si.rl_span, ne, np.uint32).copy(), rl_state=abi._view(si.rl_state, ne, np.int32).copy(),
+                         sample_file_index=abi._view(si.sample_file_index, ns, np.uint64).copy(),
+                         sample_size=abi._view(si.sample_size, ns, np.uint32).copy())
 
     def close(self):
         if self._h:

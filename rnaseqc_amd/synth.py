@@ -498,12 +498,13 @@ def _shard_job(c):
 
 
 def make_reads_sharded(ann: Annotation, n_pairs: int, seed: int = 2, contigs=None, workers: int = 0,
-                       unmapped_frac: float = 0.01, with_unmapped: bool = True, contig_lengths=None, **kw):
+                       unmapped_frac: float = 0.01, with_unmapped: bool = True, contig_lengths=None, as_parts: bool = False, **kw):
     """The BASELINE-scale input (100 M records): every contig is generated on its own (own seed, own fragment
     numbers) and the pieces are concatenated in contig order, which IS coordinate order; the unmapped tail comes
     last.  `contigs` restricts the output to a subset (a GPU's shard): the union over a partition of the contigs
     equals the full input record for record.  workers > 1 forks that many generator processes (call this
-    before the HIP runtime is initialised).  Returns (batch, records_per_contig[n_ref])."""
+    before the HIP runtime is initialised).  Returns (batch, records_per_contig[n_ref]); with as_parts, the list of
+    per-contig batches instead of their concatenation."""
     share = contig_pair_shares(ann, n_pairs)
     fid_base = np.concatenate([[0], np.cumsum(share)])[:-1]
     if contig_lengths is None:
@@ -545,6 +546,14 @@ def make_reads_sharded(ann: Annotation, n_pairs: int, seed: int = 2, contigs=Non
                                tagbits=np.full(nu, abi.TB_MTID_SAME, np.uint8), n_cigar=np.zeros(nu, np.uint8),
                                cigar=np.zeros(0, np.uint32), seg_tid=np.array([-1], np.int32),
                                seg_start=np.array([0, nu], np.uint64)))
+    if as_parts:
+        # one batch per contig (+ the unmapped tail), each a contiguous range of the file.  file_index_base is a VIRTUAL
+        # file index, contig << 32: monotone in file order, which is all the boundary asks for (gaps are allowed), and
+        # computable by a rank that generated only its own contigs
+        keys = sorted(pieces)
+        for c, b in zip(keys + [ann.n_ref], parts):
+            b.file_index_base = int(c) << 32
+        return parts, per_contig
     return Batch.concat(parts), per_contig
 
 

@@ -1,0 +1,66 @@
+"""-m gpu: the workload BASELINE.json's metric is quoted on, at its own size -- GENCODE-sized annotation + ~100 M
+records on ONE GPU (configs[2]), and the same records with BED intervals through several host-fed batches
+(configs[4]'s flags on one GPU) -- against the oracle record for record, plus size-independent identities of the
+reference's counters."""
+import os
+
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, engine, synth
+from tests.compare import assert_results_match
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = int(os.environ.get("RSQC_TEST_CONTRACT_PAIRS", "50000000"))
+
+
+@pytest.fixture(scope="module")
+def contract_inputs():
+    ann = synth.make_annotation(seed=1, contigs=synth.human_contigs())
+    batch, per_contig = synth.make_reads_sharded(ann, PAIRS, seed=2, workers=min(os.cpu_count() or 1, 24))
+    return ann, batch, per_contig
+
+
+def check_identities(r, n):
+    c = r.counter_dict()
+    assert c["Total Alignments"] == n
+    assert c["Mapped Reads"] == c["Mapped Duplicate Reads"] + c["Mapped Unique Reads"]
+    assert c["Reads used for Intron/Exon counts"] == c["High Quality Reads"] + c["Low Quality Reads"]
+    assert c["Intragenic Reads"] == c["Exonic Reads"] + c["Intronic Reads"]
+    assert c["HQ Intragenic Reads"] == c["HQ Exonic Reads"] + c["HQ Intronic Reads"]
+    # every record that reaches the feature stage with at least one block lands in exactly one class (src/Expression.cpp:407-441)
+    classes = c["Exonic Reads"] + c["Intronic Reads"] + c["Intergenic Reads"] + c["Ambiguous Reads"]
+    assert classes <= c["Reads used for Intron/Exon counts"] and classes >= c["Reads used for Intron/Exon counts"] - c["Total Alignments"] // 1000
+    assert c["End 1 Mapped Reads"] == c["Duplicate Pairs"] + c["Unique Fragments"]
+    # a gene's distinct fragments lie between half its counted records and all of them
+    assert (r.gene_fragments <= r.gene_reads).all() and (2 * r.gene_fragments >= r.gene_reads).all()
+    assert (r.gene_unique <= r.gene_reads).all()
+    # exonCounts sum: every counted record adds (sum of its committed block lengths) / aligned <= 1 per gene it is counted to
+    assert r.exon_reads.sum() <= float(r.gene_reads.sum()) + 1e-3
+    assert int(r.exon_hit.sum()) == int((r.exon_reads > 0).sum())
+
+
+def test_contract_workload_one_batch(oracle_lib, contract_inputs):
+    ann, batch, per_contig = contract_inputs
+    assert ann.n_genes == 56202 and abs(ann.n_exons - 323418) < 3500 and batch.n > 2 * PAIRS
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, [batch])
+    check_identities(got, batch.n)
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert_results_match(got, want)
+    assert int(got.gene_reads.sum()) > batch.n // 2
+
+
+def test_contract_workload_bed_host_batches(oracle_lib, contract_inputs):
+    ann, batch, per_contig = contract_inputs
+    bed = synth.make_bed(ann)
+    n = batch.n
+    cuts = [0] + [int(n * f) + 7 * k for k, f in enumerate((0.11, 0.23, 0.38, 0.52, 0.61, 0.77, 0.9), 1)] + [n]
+    parts = [batch.slice(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1)]
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, parts, bed=bed)
+    check_identities(got, n)
+    want = oracle_lib.run_oracle(p, ann, parts, bed=bed)
+    assert_results_match(got, want)
+    assert int(np.asarray(got.fragment_count).sum()) == p.fragment_samples      # the first-N cut-off is reached and honoured
