@@ -20,6 +20,7 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 }
 
 void HostBatch::clear() {
+    unsorted = false; bad_refid.clear();
     core.clear(); aux.clear(); cigar.clear(); seg_tid.clear(); seg_start.clear();
     wide_index.clear(); wide_nm.clear(); wide_lq.clear(); wide_ncig.clear();
 }
@@ -111,10 +112,10 @@ void WorkPool::run(size_t n_tasks, const std::function<void(size_t)> &fn) {
     if (!err.empty()) throw std::runtime_error(err);
 }
 
-void BamReader::set_threads(int n) {
+bool BamReader::set_threads(int n) {
     if (n < 1) n = 1;
-    if (n == n_threads_ && pool_) return;
-    if (producer_started_) return;                 // fixed once decoding has begun
+    if (n == n_threads_ && pool_) return true;
+    if (producer_started_) return false;           // fixed once decoding has begun (open() starts it): call before open()
     delete pool_; delete pool_inflate_;
     n_threads_ = n;
     // 2n threads in two pools.  With libdeflate and the one-pass parser, inflating a group costs ~1.5x what framing +
@@ -125,6 +126,68 @@ void BamReader::set_threads(int n) {
     n_inflate = std::max(1, std::min(n_inflate, 2 * n - 1));
     pool_ = new WorkPool(std::max(1, 2 * n - n_inflate));
     pool_inflate_ = new WorkPool(n_inflate);
+    return true;
+}
+
+// ---- by-contig reading (counterpart of an index-driven region reader) -------------------------------
+// <bam>.bai: per reference, the metadata pseudo-bin 37450 {ref_beg, ref_end, n_mapped, n_unmapped} when the indexer wrote
+// it (samtools does), else the smallest chunk begin / largest chunk end over its bins; n_records is 0 when unknown.
+bool BamReader::load_index(const std::string &bai_path) {
+    FILE *f = fopen(bai_path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> d;
+    { uint8_t tmp[1 << 16]; size_t g; while ((g = fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + g); }
+    fclose(f);
+    size_t p = 0;
+    auto need = [&](size_t k) { return p + k <= d.size(); };
+    auto u32 = [&]() { const uint32_t v = le32(d.data() + p); p += 4; return v; };
+    auto u64 = [&]() { const uint64_t v = (uint64_t)le32(d.data() + p) | ((uint64_t)le32(d.data() + p + 4) << 32); p += 8; return v; };
+    if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    p = 4;
+    const uint32_t n_ref = u32();
+    std::vector<ContigRange> idx(n_ref);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (!need(4)) return false;
+        const uint32_t n_bin = u32();
+        uint64_t lo = ~0ull, hi = 0; bool meta = false;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            if (!need(8)) return false;
+            const uint32_t bin = u32(), n_chunk = u32();
+            if (!need(16 * (size_t)n_chunk)) return false;
+            if (bin == 37450 && n_chunk == 2) {
+                idx[r].beg = u64(); idx[r].end = u64(); idx[r].n_records = u64(); idx[r].n_records += u64(); meta = true;
+            } else for (uint32_t c = 0; c < n_chunk; ++c) { const uint64_t cb = u64(), ce = u64(); lo = std::min(lo, cb); hi = std::max(hi, ce); }
+        }
+        if (!meta && lo != ~0ull) { idx[r].beg = lo; idx[r].end = hi; idx[r].n_records = 0; }
+        idx[r].present = meta || lo != ~0ull;
+        if (!need(4)) return false;
+        const uint32_t n_intv = u32();
+        if (!need(8 * (size_t)n_intv)) return false;
+        p += 8 * (size_t)n_intv;
+    }
+    index_ = std::move(idx);
+    n_no_coor_ = need(8) ? u64() : 0;
+    return true;
+}
+
+// Restarts the stream at a BGZF virtual offset and stops inflating behind `voff_end` (0 = end of file).  Memory-mapped
+// files only; must follow open().  The caller reads the records it wants (e.g. ContigRange::n_records, or until the
+// segment table shows another contig).
+bool BamReader::seek(uint64_t voff, uint64_t voff_end) {
+    if (!map_) return false;
+    if (producer_started_) {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        producer_.join();
+        stop_ = false; producer_started_ = false;
+    }
+    stage_state_ = kEmpty; stage_bytes_ = 0; stage_error_.clear();
+    buf_.clear(); pos_ = 0; eof_ = false; file_eof_ = false;
+    cpos_ = (size_t)(voff >> 16);
+    skip_ = (size_t)(voff & 0xFFFF);
+    climit_ = voff_end ? (size_t)(voff_end >> 16) + 1 : 0;          // the block that holds the end is still inflated
+    if (cpos_ > map_size_) return false;
+    return true;
 }
 
 // libdeflate (whole-buffer inflate, 2-3x zlib on BGZF-sized blocks) when the shared library is on the system: it ships
@@ -181,6 +244,8 @@ bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
             if (avail < bsize) break;
             const size_t clen = bsize - xlen - 12 - 8;
             const uint32_t isize = le32(h + bsize - 4);
+            if (isize > 65536u) throw std::runtime_error("BGZF block with ISIZE above 64 KiB (corrupt trailer)");   // before any buffer is sized from it
+            if (climit_ && cpos_ >= climit_) break;                   // by-contig reading: nothing to inflate past the range
             blks.push_back(Blk{cpos_ + 12 + xlen, clen, total, isize, le32(h + bsize - 8)});
             total += isize;
             cpos_ += bsize;
@@ -197,6 +262,7 @@ bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {
         if (got == 0) file_eof_ = true;
     }
     if (blks.empty()) {
+        if (climit_ && cpos_ >= climit_) return false;            // the end of a seek() range is an end of stream
         if ((map_ ? map_size_ : cbuf_.size()) - cpos_ != 0) throw std::runtime_error("truncated BGZF block");
         return false;
     }
@@ -296,6 +362,7 @@ bool BamReader::fill_group() {
         buf_.swap(stage_);                                        // (pointer swap)
         buf_.resize(kHead + got);
         pos_ = kHead - tail;
+        if (skip_) { pos_ += std::min(skip_, got); skip_ = 0; }   // seek(): the first block starts before the wanted record
     } else {                                                     // a record larger than the head room: grow in place
         if (pos_ > 0) { buf_.erase_front(pos_); pos_ = 0; }
         const size_t base = buf_.size();
@@ -398,7 +465,12 @@ struct ChunkOut {
     std::vector<std::pair<uint32_t, int32_t>> segs;      // (local record index, tid): contig changes inside the chunk (+ its first record)
     std::vector<uint32_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc;
     int32_t last_tid = 0;
-    void clear() { core.clear(); aux.clear(); cig.clear(); cig_end.clear(); segs.clear(); widx.clear(); wnm.clear(); wlq.clear(); wnc.clear(); last_tid = 0; }
+    // what the reference's loop reports on stderr: records that reach src/RNASeQC.cpp:333 with a RefID outside the header
+    // (their names), and positions that go backwards inside a contig (:354); judged on primary, mapped, QC-passed records
+    std::vector<std::pair<uint32_t, std::string>> bad_ref;   // (local record index, QNAME)
+    bool unsorted = false, have_q = false; int32_t first_tid = 0, first_pos = 0, q_tid = 0, q_pos = 0;
+    void clear() { core.clear(); aux.clear(); cig.clear(); cig_end.clear(); segs.clear(); widx.clear(); wnm.clear(); wlq.clear(); wnc.clear(); last_tid = 0;
+                   bad_ref.clear(); unsorted = false; have_q = false; }
     size_t size() const { return core.size(); }
     // keep the first k records
     void truncate(size_t k) {
@@ -408,14 +480,30 @@ struct ChunkOut {
         while (!segs.empty() && segs.back().first >= k) segs.pop_back();
         while (!widx.empty() && widx.back() >= k) { widx.pop_back(); wnm.pop_back(); wlq.pop_back(); wnc.pop_back(); }
         last_tid = segs.empty() ? 0 : segs.back().second;
+        // the order / RefID diagnostics describe parsed records: redo them for the kept ones (the dropped records come
+        // back with the next batch)
+        while (!bad_ref.empty() && bad_ref.back().first >= k) bad_ref.pop_back();
+        unsorted = false; have_q = false;
+        size_t sg = 0;
+        for (size_t r = 0; r < k; ++r) {
+            while (sg + 1 < segs.size() && segs[sg + 1].first <= r) ++sg;
+            const int32_t tid = segs.empty() ? -1 : segs[sg].second;
+            if (aux[r].flag & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP | RSQC_FUNMAP)) continue;
+            if (tid < 0 || tid >= n_ref) continue;                 // (names of undefined RefIDs are reported when their batch is read)
+            if (!have_q) { first_tid = tid; first_pos = core[r].pos; }
+            else if (q_tid == tid && q_pos > core[r].pos) unsorted = true;
+            have_q = true; q_tid = tid; q_pos = core[r].pos;
+        }
     }
+    int32_t n_ref = 0;
 };
-struct TagSpec { char ch0 = 0, ch1 = 0; bool have_ch = false; int n_filter = 0; char f0[RSQC_MAX_FILTER_TAGS], f1[RSQC_MAX_FILTER_TAGS]; };
+struct TagSpec { char ch0 = 0, ch1 = 0; bool have_ch = false; int n_filter = 0; char f0[RSQC_MAX_FILTER_TAGS], f1[RSQC_MAX_FILTER_TAGS]; int32_t n_ref = 0; };
 
 // hop from `p` while records are complete and start before `limit`, parsing each into `o`; returns the first start
 // >= limit (or the start of the first incomplete record)
 size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, const TagSpec &tags, ChunkOut &o) {
     bool have_last = false; int32_t last_tid = 0;
+    o.n_ref = tags.n_ref;
     while (p < limit && p + 4 <= end) {
         const uint32_t block_size = le32(buf + p);
         if (block_size < 32) throw std::runtime_error("bad BAM record");
@@ -440,8 +528,17 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
         const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
         au.qhash = rsqc_qname_hash(qname, qlen);
         au.flag = flag; au.mapq = mapq;
+        if (!(flag & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP | RSQC_FUNMAP))) {
+            if (tid < 0 || tid >= tags.n_ref) { if (o.bad_ref.size() < 64) o.bad_ref.emplace_back(k, std::string(qname, qlen)); }
+            else {
+                if (!o.have_q) { o.first_tid = tid; o.first_pos = pos; }
+                else if (o.q_tid == tid && o.q_pos > pos) o.unsorted = true;
+                o.have_q = true; o.q_tid = tid; o.q_pos = pos;
+            }
+        }
         uint8_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
         int32_t nm = 0;
+        const uint8_t *cg_ops = nullptr; uint32_t cg_n = 0;                             // CG:B,I -- the real CIGAR of a record with more than 65535 ops
         for (const uint8_t *q = auxp; q + 3 <= end_r;) {
             const char t0 = (char)q[0], t1 = (char)q[1], type = (char)q[2];
             const uint8_t *v = q + 3;
@@ -450,6 +547,7 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
             case 'A': case 'c': case 'C': vlen = 1; break;
             case 's': case 'S': vlen = 2; break;
             case 'i': case 'I': case 'f': vlen = 4; break;
+            case 'd': vlen = 8; break;                                                  // (htslib skips 8 bytes)
             case 'Z': case 'H': vlen = strnlen((const char *)v, (size_t)(end_r - v)) + 1; break;
             case 'B': { if (v + 5 > end_r) { vlen = (size_t)(end_r - v); break; }
                         const char st = (char)v[0]; const uint32_t cnt = le32(v + 1);
@@ -458,6 +556,7 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
             }
             if (v + vlen > end_r) break;                                            // malformed tail: stop scanning
             if (t0 == 'N' && t1 == 'M') { int32_t x; if (aux_int(v, type, x)) { nm = x; tagbits |= RSQC_TB_HAS_NM; } }
+            if (t0 == 'C' && t1 == 'G' && type == 'B' && v[0] == 'I' && vlen >= 5) { cg_ops = v + 5; cg_n = le32(v + 1); }
             if (tags.have_ch && t0 == tags.ch0 && t1 == tags.ch1) {                     // readStringTag, src/RNASeQC.cpp:780-800
                 if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
             }
@@ -468,15 +567,21 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
                 }
             q = v + vlen;
         }
-        const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_cigar >= RSQC_NCIGAR_ESCAPE;
+        // A CIGAR of more than 65535 operations is stored in the CG tag behind the placeholder <l_seq>S<ref_len>N
+        // (SAM spec 4.2.2); htslib puts it back when it reads the record (bam_tag2cigar), so the reference sees the real one
+        uint32_t n_ops = n_cigar; const uint8_t *ops = cig;
+        if (cg_ops && cg_n > 0 && n_cigar == 2 && (le32(cig) & 0xf) == 4 && (int64_t)(le32(cig) >> 4) == (int64_t)l_seq && (le32(cig + 4) & 0xf) == 3) {
+            n_ops = cg_n; ops = cg_ops;
+        }
+        const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_ops >= RSQC_NCIGAR_ESCAPE;
         au.l_qseq = wide && (l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0) ? RSQC_LQSEQ_ESCAPE : (uint16_t)l_seq;
         au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
-        au.n_cigar = n_cigar >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_cigar;
+        au.n_cigar = n_ops >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_ops;
         au.tagbits = tagbits;
-        if (wide) { o.widx.push_back(k); o.wnm.push_back(nm); o.wlq.push_back(l_seq); o.wnc.push_back(n_cigar); }
+        if (wide) { o.widx.push_back(k); o.wnm.push_back(nm); o.wlq.push_back(l_seq); o.wnc.push_back(n_ops); }
         const size_t c0 = o.cig.size();
-        o.cig.resize(c0 + n_cigar);
-        for (uint16_t ci = 0; ci < n_cigar; ++ci) o.cig[c0 + ci] = le32(cig + 4 * (size_t)ci);
+        o.cig.resize(c0 + n_ops);
+        for (uint32_t ci = 0; ci < n_ops; ++ci) o.cig[c0 + ci] = le32(ops + 4 * (size_t)ci);
         o.cig_end.push_back((uint32_t)o.cig.size());
         o.core.push_back(co); o.aux.push_back(au);
         p += 4 + (size_t)block_size;
@@ -491,6 +596,7 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
     if (!pool_) set_threads(1);
     const int32_t n_ref = (int32_t)names_.size();
     TagSpec tags;
+    tags.n_ref = n_ref;
     if (ch_tag_.size() == 2) { tags.have_ch = true; tags.ch0 = ch_tag_[0]; tags.ch1 = ch_tag_[1]; }
     for (size_t fi = 0; fi < filter_tags_.size() && fi < RSQC_MAX_FILTER_TAGS; ++fi) {
         // a tag name that is not two characters long can never match; keep its bit position
@@ -605,6 +711,11 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
                 out.seg_tid.push_back(sg.second); out.seg_start.push_back(g0 + sg.first);
             }
             if (o.size()) { have_prev = true; ptid = o.last_tid; }
+            for (auto &nm_ : o.bad_ref) if (out.bad_refid.size() < 64) out.bad_refid.push_back(nm_.second);
+            if (o.have_q) {
+                if (o.unsorted || (have_q_ && q_tid_ == o.first_tid && q_pos_ > o.first_pos)) out.unsorted = true;
+                have_q_ = true; q_tid_ = o.q_tid; q_pos_ = o.q_pos;
+            }
             for (size_t w = 0; w < o.widx.size(); ++w) {
                 out.wide_index.push_back(g0 + o.widx[w]); out.wide_nm.push_back(o.wnm[w]); out.wide_lq.push_back(o.wlq[w]); out.wide_ncig.push_back(o.wnc[w]);
             }

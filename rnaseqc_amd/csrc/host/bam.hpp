@@ -81,6 +81,10 @@ struct HostBatch {                       // owns the arrays an rsqc_batch points
     std::vector<int32_t> wide_nm, wide_lq;
     std::vector<uint32_t> wide_ncig;
     uint64_t file_index_base = 0;
+    // diagnostics of the decode (what the reference's loop prints on stderr): positions going backwards inside a contig
+    // (src/RNASeQC.cpp:354-355) and names of records whose RefID the header does not define (:333-337)
+    bool unsorted = false;
+    std::vector<std::string> bad_refid;
     void clear();
     size_t size() const { return core.size(); }
     rsqc_batch view();                   // closes the segment table
@@ -116,8 +120,16 @@ public:
     // appends up to max_records records to `out`; returns the number appended (0 at EOF)
     size_t read_batch(HostBatch &out, size_t max_records);
     uint64_t records_read() const { return n_read_; }
-    // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 16), per pool
-    void set_threads(int n);
+    // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 16), per pool.
+    // Call BEFORE open(): open() starts the decode pipeline to read the header and the pools are fixed from then on
+    // (returns false, and changes nothing, afterwards).
+    bool set_threads(int n);
+    // by-contig reading: the BAM index's per-reference ranges and a restart of the stream at a virtual offset
+    struct ContigRange { uint64_t beg = 0, end = 0, n_records = 0; bool present = false; };
+    bool load_index(const std::string &bai_path);
+    const std::vector<ContigRange> &index() const { return index_; }
+    uint64_t unplaced_records() const { return n_no_coor_; }
+    bool seek(uint64_t voff, uint64_t voff_end);
     int inflate_threads() const { return pool_inflate_ ? pool_inflate_->size() : 0; }
     int parse_threads() const { return pool_ ? pool_->size() : 0; }
     ~BamReader();
@@ -134,6 +146,10 @@ private:
     const uint8_t *map_ = nullptr;       // the whole compressed file, memory-mapped (regular files): inflate reads the page cache directly
     size_t map_size_ = 0;
     size_t cpos_ = 0;
+    size_t climit_ = 0;                  // seek(): compressed offset behind which nothing is framed (0 = none)
+    size_t skip_ = 0;                    // seek(): bytes of the first inflated block that precede the wanted record
+    std::vector<ContigRange> index_;
+    uint64_t n_no_coor_ = 0;
     bool file_eof_ = false;
     bool eof_ = false;
     WorkPool *pool_ = nullptr;           // record framing + parsing (consumer side)
@@ -154,6 +170,7 @@ private:
     std::string ch_tag_ = "ch";
     std::vector<std::string> filter_tags_;
     uint64_t n_read_ = 0;
+    bool have_q_ = false; int32_t q_tid_ = 0, q_pos_ = 0;      // last primary mapped record seen (sort check across batches)
 };
 
 }  // namespace rsqc_host

@@ -84,6 +84,29 @@ HAPI void *host_bam_read_all_ex(const char *path, const char *ch_tag, const char
     b->names = b->reader.contigs();
     return b;
 }
+// the records of ONE reference sequence through the BAM index (<path>.bai): BamReader::load_index + seek
+HAPI void *host_bam_read_contig(const char *path, const char *ch_tag, const char *const *tags, int n_tags, int threads, int contig) {
+    BamHandle *b = new BamHandle();
+    b->reader.set_threads(threads);
+    if (!b->reader.open(path) || !b->reader.load_index(std::string(path) + ".bai")) { delete b; return nullptr; }
+    const auto &idx = b->reader.index();
+    if (contig < 0 || (size_t)contig >= idx.size()) { delete b; return nullptr; }
+    std::vector<std::string> t;
+    for (int i = 0; i < n_tags; ++i) t.emplace_back(tags[i]);
+    b->reader.set_tags(ch_tag, t);
+    b->names = b->reader.contigs();
+    if (idx[(size_t)contig].present) {
+        if (!b->reader.seek(idx[(size_t)contig].beg, idx[(size_t)contig].end)) { delete b; return nullptr; }
+        uint64_t left = idx[(size_t)contig].n_records;
+        try { while (left) { const size_t got = b->reader.read_batch(b->batch, (size_t)std::min<uint64_t>(left, 1u << 20)); if (!got) break; left -= got; } }
+        catch (...) { delete b; return nullptr; }
+    }
+    b->view = b->batch.view();
+    return b;
+}
+HAPI int host_bam_unsorted(void *h) { return ((BamHandle *)h)->batch.unsorted ? 1 : 0; }
+HAPI int host_bam_bad_refid_count(void *h) { return (int)((BamHandle *)h)->batch.bad_refid.size(); }
+HAPI const char *host_bam_bad_refid(void *h, int i) { return ((BamHandle *)h)->batch.bad_refid[(size_t)i].c_str(); }
 HAPI const rsqc_batch *host_bam_batch(void *h) { return &((BamHandle *)h)->view; }
 HAPI int host_bam_n_contigs(void *h) { return (int)((BamHandle *)h)->names.size(); }
 HAPI const char *host_bam_contig(void *h, int i) { return ((BamHandle *)h)->names[(size_t)i].c_str(); }

@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -279,7 +280,7 @@ int main(int argc, char **argv) {
         }
         std::vector<int> visit;
         unsigned long long alignmentCount = 0;
-        int cur = 0; bool in_flight = false;
+        int cur = 0; bool in_flight = false, warned_unsorted = false;
         const auto tb0 = std::chrono::steady_clock::now();
         for (;;) {
             HostBatch &hb = bufs[cur];
@@ -288,6 +289,17 @@ int main(int argc, char **argv) {
             const size_t n = bam.read_batch(hb, BATCH);              // decode overlaps the previous batch on the GPU
             if (in_flight) { if ((rc = rsqc_wait(gpu)) != RSQC_OK) break; in_flight = false; }
             if (n == 0) break;
+            // stderr of the reference's loop: the names of records with a RefID the header lacks (src/RNASeQC.cpp:333-337, under -v)
+            // and the sort warning (:354-355).  The reference repeats the warning for every offending record; it is given
+            // once here -- an unsorted file voids the results either way (the static index does not reproduce what the
+            // reference's destructively trimmed window would count).
+            if (o.verbosity) for (auto &nm : hb.bad_refid) cerr << "Unrecognized RefID on alignment: " << nm << endl;
+            bool revisit = false;
+            for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t) && std::find(visit.begin(), visit.end(), t) != visit.end()) revisit = true;
+            if ((hb.unsorted || revisit) && !warned_unsorted) {
+                cerr << "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results" << endl;
+                warned_unsorted = true;
+            }
             for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t)) {
                 visit.push_back(t);
                 if (o.has_fasta && (size_t)t < in_fasta.size() && !in_fasta[(size_t)t])      // src/RNASeQC.cpp:350-352

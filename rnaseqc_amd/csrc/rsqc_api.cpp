@@ -36,24 +36,38 @@ struct UploadedBatch {
     bool pooled = false;           // transient upload: its buffers go back to the context's pool
 };
 
+// What a submitted batch leaves behind for the end-of-file stage is written into WORST-CASE sized buffers (the counts
+// are only known on the device).  A batch that has completed is RETIRED at the next rsqc_submit / rsqc_wait: its
+// counts are read from a page-locked mirror, what it actually emitted is appended to a growing arena, and the
+// worst-case buffers go back to the pool -- so the memory held until rsqc_finalize is what was emitted (12 B per
+// (gene, name) pair, 28 B per fragment-size candidate, 32 B per GC candidate) plus the buffers of the batches in flight.
 struct PairBuf {                // (gene, qname-hash) pairs of one submitted batch
     DevBuf gene, hash, counts;  // counts: [n_chunks] per K1 block, then [1] slow-path counter
     uint64_t cap = 0;           // pair slots allocated
     uint32_t n_chunks = 0, chunk_cap = 0, slow_base = 0, slow_cap = 0;
     uint32_t counts_cap = 0;
     uint64_t pairs_bound = 0;   // most pairs the batch can have emitted
+    uint32_t *h_counts = nullptr;   // page-locked mirror of `counts` (copied when the batch's kernels are done)
+    hipEvent_t done = nullptr;
     bool used = false;
 };
 
 struct FragBuf {                // fragment-size candidates of one submitted batch (BED runs only)
     DevBuf file, qhash, name, endpos, fs, count;
     uint32_t cap = 0;
+    uint32_t *h_count = nullptr;
     bool used = false;
 };
 struct GcBuf {                  // fragment GC candidates of one submitted batch (--fasta runs only)
     DevBuf file, qhash, row, endpos, flag_lq, tid, count;
     uint32_t cap = 0;
+    uint32_t *h_count = nullptr;
     bool used = false;
+};
+// growing device arrays of the retired batches: a few parallel columns with one fill level
+struct Arena {
+    DevBuf col[6]; size_t width[6] = {0, 0, 0, 0, 0, 0}; int n_col = 0;
+    uint64_t used = 0, cap = 0;
 };
 
 }  // namespace
@@ -64,7 +78,6 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
-    int k4_mode = 2, k4_grid = 2048, k4_impl = 2;     // k4_impl: 1 = open-addressing table (memory-side CAS), 2 = per-gene lists + LDS partitions
     int k1_variant = 41, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
 
     // annotation (host copies needed at finalize)
@@ -95,7 +108,9 @@ struct rsqc_ctx {
     DevAccum acc{};
     uint64_t tile_cap = 0;
     std::vector<PairBuf> pair_pool;
-    std::vector<size_t> pairs_in_flight;        // indices into pair_pool, submission order
+    std::vector<size_t> pairs_in_flight;        // indices into pair_pool, submission order (batches not retired yet)
+    Arena pair_arena, frag_arena, gc_arena;     // what the retired batches emitted
+    DevBuf d_arena_count;                       // u32: pair_arena.used for the K4 launch over the arena
     DevBuf d_table, d_tab_off, d_tab_cap;
     std::vector<FragBuf> frag_pool;
     std::vector<size_t> frags_in_flight;
@@ -109,7 +124,6 @@ struct rsqc_ctx {
     std::vector<uint64_t> h_gc;                 // [RSQC_GC_BINS + 1]
     std::vector<double> h_exon_gc;              // by exon id
     SortScratch gc_scratch;
-    DevBuf gc_merged[6];                        // candidates of several batches side by side (kept between passes)
     // K3 outputs
     bool finalized = false;
 
@@ -250,6 +264,7 @@ int zero_accumulators(rsqc_ctx *c) {
     HIP_TRY(c, hipGetLastError());
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
+    c->pair_arena.used = c->frag_arena.used = c->gc_arena.used = 0;
     for (auto &fb : c->frag_pool) fb.used = false;
     c->frags_in_flight.clear();
     c->h_fsize.clear(); c->h_fcount.clear();
@@ -292,6 +307,74 @@ void free_batch(UploadedBatch *u) {
 // a transient batch whose kernels have completed: keep its device buffers for the next rsqc_submit
 void retire_batch(rsqc_ctx *c, UploadedBatch *u);
 
+int arena_reserve(rsqc_ctx *c, Arena &a, uint64_t extra) {
+    if (a.used + extra <= a.cap) return 0;
+    const uint64_t ncap = std::max<uint64_t>(a.used + extra, a.cap + a.cap / 2 + (1u << 16));
+    for (int k = 0; k < a.n_col; ++k) {
+        DevBuf nb;
+        HIP_TRY(c, hipMalloc(&nb.p, ncap * a.width[k] + 64));
+        nb.bytes = ncap * a.width[k] + 64;
+        if (a.used) HIP_TRY(c, hipMemcpyAsync(nb.p, a.col[k].p, a.used * a.width[k], hipMemcpyDeviceToDevice, c->stream));
+        if (a.col[k].p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); a.col[k].release(); }
+        a.col[k] = nb;
+    }
+    a.cap = ncap;
+    return 0;
+}
+
+// Retires every in-flight batch whose kernels have completed (all of them when `all` -- the caller has synchronised).
+int retire_completed(rsqc_ctx *c, bool all) {
+    size_t keep = 0;
+    for (size_t k = 0; k < c->pairs_in_flight.size(); ++k) {
+        const size_t idx = c->pairs_in_flight[k];
+        PairBuf &pb = c->pair_pool[idx];
+        // in submission order only: the arena keeps file order, which the fragment de-dup's LDS pass relies on for locality
+        const bool done = keep == k && (all || hipEventQuery(pb.done) == hipSuccess);
+        if (!done) { c->pairs_in_flight[keep++] = idx; continue; }
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < pb.n_chunks; ++j) total += std::min(pb.h_counts[j], pb.chunk_cap);
+        total += std::min(pb.h_counts[pb.n_chunks], pb.slow_cap);
+        if (c->pair_arena.used + total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "more than 2^32 (gene, name) pairs in one pass");
+        int rc = arena_reserve(c, c->pair_arena, total);
+        if (rc) return rc;
+        if (total) launch_pairs_append(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, pb.chunk_cap, (const uint32_t *)pb.counts.p,
+                                       pb.n_chunks, pb.slow_base, pb.slow_cap, (uint32_t *)c->pair_arena.col[0].p + c->pair_arena.used,
+                                       (uint64_t *)c->pair_arena.col[1].p + c->pair_arena.used);
+        c->pair_arena.used += total;
+        pb.used = false;                       // (stream order: the append reads the buffer before a later batch writes it)
+    }
+    c->pairs_in_flight.resize(keep);
+    // candidate lists are dense [0, count): plain device-to-device copies.  They are retired together with their batch's
+    // pairs: a candidate buffer is in flight exactly as long as the pair buffer submitted with it.
+    auto retire_list = [&](std::vector<size_t> &in_flight, size_t n_keep, Arena &arena, auto &&buf_of) -> int {
+        const size_t n_retire = in_flight.size() > n_keep ? in_flight.size() - n_keep : 0;
+        for (size_t k = 0; k < n_retire; ++k) {
+            uint32_t count = 0; uint32_t cap = 0; const void *src[6]; bool *used = nullptr;
+            buf_of(in_flight[k], count, cap, src, used);
+            if (count > cap) return fail(c, RSQC_ERR_CAPACITY, "candidate overflow");
+            int rc = arena_reserve(c, arena, count);
+            if (rc) return rc;
+            for (int f = 0; f < arena.n_col && count; ++f)
+                HIP_TRY(c, hipMemcpyAsync((char *)arena.col[f].p + arena.used * arena.width[f], src[f], (size_t)count * arena.width[f], hipMemcpyDeviceToDevice, c->stream));
+            arena.used += count;
+            *used = false;
+        }
+        in_flight.erase(in_flight.begin(), in_flight.begin() + (long)n_retire);
+        return 0;
+    };
+    int rc = retire_list(c->frags_in_flight, c->have_bed ? keep : c->frags_in_flight.size(), c->frag_arena,
+                         [&](size_t i, uint32_t &count, uint32_t &cap, const void **src, bool *&used) {
+                             FragBuf &fb = c->frag_pool[i]; count = *fb.h_count; cap = fb.cap; used = &fb.used;
+                             src[0] = fb.file.p; src[1] = fb.qhash.p; src[2] = fb.name.p; src[3] = fb.endpos.p; src[4] = fb.fs.p; src[5] = nullptr;
+                         });
+    if (rc) return rc;
+    return retire_list(c->gcs_in_flight, (c->have_ref && !c->dparams.legacy) ? keep : c->gcs_in_flight.size(), c->gc_arena,
+                       [&](size_t i, uint32_t &count, uint32_t &cap, const void **src, bool *&used) {
+                           GcBuf &gb = c->gc_pool[i]; count = *gb.h_count; cap = gb.cap; used = &gb.used;
+                           src[0] = gb.file.p; src[1] = gb.qhash.p; src[2] = gb.row.p; src[3] = gb.endpos.p; src[4] = gb.flag_lq.p; src[5] = gb.tid.p;
+                       });
+}
+
 PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *index) {
     for (size_t i = 0; i < c->pair_pool.size(); ++i)
         if (!c->pair_pool[i].used && c->pair_pool[i].cap >= cap && c->pair_pool[i].counts_cap >= n_counts) {
@@ -302,6 +385,8 @@ PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *ind
     if (hipMalloc(&pb.hash.p, (size_t)cap * 8) != hipSuccess) return nullptr;
     if (hipMalloc(&pb.counts.p, (size_t)n_counts * 4) != hipSuccess) return nullptr;
     pb.gene.bytes = (size_t)cap * 4; pb.hash.bytes = (size_t)cap * 8; pb.counts.bytes = (size_t)n_counts * 4;
+    if (hipHostMalloc((void **)&pb.h_counts, (size_t)n_counts * 4, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&pb.done, hipEventDisableTiming) != hipSuccess) return nullptr;
     pb.cap = cap; pb.counts_cap = n_counts; pb.used = true;
     c->pair_pool.push_back(pb);
     *index = c->pair_pool.size() - 1;
@@ -331,6 +416,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     const uint64_t slow_cap = c->dparams.legacy ? std::max<uint64_t>(1ull << 20, 4ull * u->n) : 1ull << 20;
     const uint64_t want = chunk_cap * (uint64_t)grid + slow_cap;
     if (want > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
+    { int rcr = retire_completed(c, false); if (rcr) return rcr; }     // completed batches hand their buffers back first
     size_t pidx = 0;
     PairBuf *pb = acquire_pairs(c, want, (uint32_t)grid + 1, &pidx);
     if (!pb) return fail(c, RSQC_ERR_HIP, "hipMalloc(pair buffer) failed");
@@ -354,6 +440,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
             if ((rc2 = dev_alloc(c, fb.file, u->n * 8, false)) || (rc2 = dev_alloc(c, fb.qhash, u->n * 8, false)) ||
                 (rc2 = dev_alloc(c, fb.name, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.endpos, u->n * 4, false)) ||
                 (rc2 = dev_alloc(c, fb.fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.count, 16, false))) return rc2;
+            HIP_TRY(c, hipHostMalloc((void **)&fb.h_count, 16, hipHostMallocDefault));
             c->frag_pool.push_back(fb);
         }
         FragBuf &fb = c->frag_pool[fidx];
@@ -393,6 +480,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
                 (rc2 = dev_alloc(c, gb.row, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.endpos, u->n * 4, false)) ||
                 (rc2 = dev_alloc(c, gb.flag_lq, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.tid, u->n * 4, false)) ||
                 (rc2 = dev_alloc(c, gb.count, 16, false))) return rc2;
+            HIP_TRY(c, hipHostMalloc((void **)&gb.h_count, 16, hipHostMallocDefault));
             c->gc_pool.push_back(gb);
         }
         GcBuf &gb = c->gc_pool[gidx];
@@ -403,6 +491,11 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
                         (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, (uint32_t *)gb.count.p, gb.cap};
         launch_gc_candidates(c->stream, c->dann, c->dparams, d, c->dref, gc, acc.error);
     }
+    // the batch's counts, for its retirement: page-locked mirrors + an event that tells when they are valid
+    HIP_TRY(c, hipMemcpyAsync(pb->h_counts, pb->counts.p, ((size_t)grid + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->have_bed) { FragBuf &fb = c->frag_pool[c->frags_in_flight.back()]; HIP_TRY(c, hipMemcpyAsync(fb.h_count, fb.count.p, 4, hipMemcpyDeviceToHost, c->stream)); }
+    if (c->have_ref && !c->dparams.legacy) { GcBuf &gb = c->gc_pool[c->gcs_in_flight.back()]; HIP_TRY(c, hipMemcpyAsync(gb.h_count, gb.count.p, 4, hipMemcpyDeviceToHost, c->stream)); }
+    HIP_TRY(c, hipEventRecord(pb->done, c->stream));
     HIP_TRY(c, hipGetLastError());
     c->timing.classify_launches += 1;
     c->timing.classify_records += u->n;
@@ -440,11 +533,11 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.n_filter_tags = params->n_filter_tags;
     c->dparams.dbg = 0;
     c->dparams.legacy = params->legacy ? 1 : 0;
+    c->pair_arena.n_col = 2; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8;                       // gene, name hash
+    c->frag_arena.n_col = 5; { const size_t w[5] = {8, 8, 4, 4, 4}; for (int k = 0; k < 5; ++k) c->frag_arena.width[k] = w[k]; }
+    c->gc_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->gc_arena.width[k] = w[k]; }
     if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
-    if (const char *e = getenv("RSQC_K4_MODE")) c->k4_mode = atoi(e);
-    if (const char *e = getenv("RSQC_K4_IMPL")) c->k4_impl = atoi(e);
-    if (const char *e = getenv("RSQC_K4_GRID")) c->k4_grid = std::max(1, atoi(e));
     if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
     return RSQC_OK;
@@ -458,11 +551,12 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto *u : c->transient) free_batch(u);
     for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
-    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); }
-    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); }
-    for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); }
+    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); }
+    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
+    for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
+    for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
+    c->d_arena_count.release(); c->d_rl_summary.release();
     free_sort_scratch(c->gc_scratch);
-    for (auto &b : c->gc_merged) b.release();
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
@@ -687,7 +781,11 @@ int rsqc_wait(rsqc_ctx *c) {
     resolve_events(c);
     for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
-    if (c->have_ann) return check_device_error(c);
+    if (c->have_ann) {
+        int rc = retire_completed(c, true);      // everything submitted so far has completed
+        if (rc) return rc;
+        return check_device_error(c);
+    }
     return RSQC_OK;
 }
 
@@ -773,9 +871,9 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         // the side streams start from here (recorded BEFORE the K4 kernels are enqueued on the main stream)
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         // ---- K4 on the main stream: per-gene distinct QNAMEs (the longer chain: enqueued first) ---------------
-        uint64_t pair_bound = 0;
+        uint64_t pair_bound = c->pair_arena.used;
         for (size_t idx : c->pairs_in_flight) pair_bound += c->pair_pool[idx].pairs_bound;
-        if (c->k4_impl == 2) {
+        {
             // streaming form: survivors appended to per-partition key lists, then counted per partition in LDS.
             // bounds from the host's pair bound: partitions <= pairs / PART_READS + G, keys <= 2 x pairs + SUB_CAP x parts
             const uint64_t Gz = (uint64_t)std::max(G, 1);
@@ -791,6 +889,16 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             P.cursor = (uint32_t *)c->d_tab_cap.p; P.part_gene = P.cursor + parts_bound;
             P.list = (unsigned long long *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
+            if (c->pair_arena.used && !getenv("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces
+                if ((rc = dev_alloc(c, c->d_arena_count, 16, false))) return rc;
+                const uint32_t used32 = (uint32_t)c->pair_arena.used;
+                HIP_TRY(c, hipMemcpyAsync(c->d_arena_count.p, &used32, 4, hipMemcpyHostToDevice, c->stream));
+                DevAccum acc = c->acc;
+                acc.pair_gene = (uint32_t *)c->pair_arena.col[0].p; acc.pair_hash = (uint64_t *)c->pair_arena.col[1].p;
+                acc.pair_chunk_cap = 0; acc.pair_chunk_count = (uint32_t *)c->d_arena_count.p;
+                acc.pair_slow_base = 0; acc.pair_slow_cap = used32;
+                launch_frag_local(c->stream, acc, 0, P, (uint32_t)std::min<uint64_t>(4096, c->pair_arena.used / 1024 + 1));
+            }
             for (size_t idx : c->pairs_in_flight) {
                 if (getenv("RSQC_DIAG_SKIP_K4")) break;                   // (diagnostic knob: results incomplete)
                 PairBuf &pb = c->pair_pool[idx];
@@ -799,31 +907,9 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
                 acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
-                launch_frag_local(c->stream, acc, pb.n_chunks, P);
+                launch_frag_local(c->stream, acc, pb.n_chunks, P, 0);
             }
             if (!getenv("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, c->acc.gene_reads, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
-        } else {
-        if ((rc = dev_alloc(c, c->d_tab_off, ((size_t)std::max(G, 1) + 2) * 8, false))) return rc;
-        if ((rc = dev_alloc(c, c->d_tab_cap, (size_t)std::max(G, 1) * 4, false))) return rc;
-        unsigned long long *d_total = (unsigned long long *)c->d_tab_off.p + std::max(G, 1);
-        launch_dedup_layout(c->stream, c->acc.gene_reads, (uint32_t)G, (uint64_t *)c->d_tab_off.p,
-                            (uint32_t *)c->d_tab_cap.p, d_total, c->acc.error);
-        // table slots = 2 x sum(geneCounts) <= 2 x (pairs emitted); the host only knows the bound, the exact
-        // count stays on the device (no synchronisation here)
-        const uint64_t slot_bound = 2 * pair_bound + 16;
-        if (c->d_table.bytes < (size_t)slot_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)slot_bound * 8 + (1u << 20), false))) return rc; }
-        launch_dedup_clear(c->stream, (unsigned long long *)c->d_table.p, d_total);
-        for (size_t idx : c->pairs_in_flight) {
-            if (getenv("RSQC_DIAG_SKIP_K4")) break;                       // (diagnostic knob: results incomplete)
-            PairBuf &pb = c->pair_pool[idx];
-            DevAccum acc = c->acc;
-            acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p;
-            acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
-            acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
-            acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
-            launch_dedup(c->stream, acc, pb.n_chunks, (const uint64_t *)c->d_tab_off.p, (const uint32_t *)c->d_tab_cap.p,
-                         (unsigned long long *)c->d_table.p, (uint32_t)c->k4_mode, c->k4_grid);
-        }
         }
         // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -860,76 +946,60 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         // ---- K5: fragment-size sampler (BED runs) ---------------------------------------------------
         if (c->have_bed) {
+            // the batches still in flight join the retired ones in the candidate arena (file order), then one pairing pass
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            std::vector<uint32_t> counts(c->frags_in_flight.size(), 0);
-            uint64_t total = 0;
             for (size_t k = 0; k < c->frags_in_flight.size(); ++k) {
                 FragBuf &fb = c->frag_pool[c->frags_in_flight[k]];
-                HIP_TRY(c, hipMemcpy(&counts[k], fb.count.p, 4, hipMemcpyDeviceToHost));
-                if (counts[k] > fb.cap) return fail(c, RSQC_ERR_CAPACITY, "fragment candidate overflow");
-                total += counts[k];
+                const uint32_t n = *fb.h_count;               // (copied when the batch was submitted; the stream has been synchronised)
+                if (n > fb.cap) return fail(c, RSQC_ERR_CAPACITY, "fragment candidate overflow");
+                if ((rc = arena_reserve(c, c->frag_arena, n))) return rc;
+                const void *src[5] = {fb.file.p, fb.qhash.p, fb.name.p, fb.endpos.p, fb.fs.p};
+                for (int f = 0; f < 5 && n; ++f)
+                    HIP_TRY(c, hipMemcpyAsync((char *)c->frag_arena.col[f].p + c->frag_arena.used * c->frag_arena.width[f], src[f],
+                                              (size_t)n * c->frag_arena.width[f], hipMemcpyDeviceToDevice, c->stream));
+                c->frag_arena.used += n;
+                fb.used = false;
             }
+            c->frags_in_flight.clear();
+            const uint64_t total = c->frag_arena.used;
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment-size candidates");
-            DevBuf m_file, m_q, m_name, m_end, m_fs;
-            if ((rc = dev_alloc(c, m_file, total * 8, false)) || (rc = dev_alloc(c, m_q, total * 8, false)) ||
-                (rc = dev_alloc(c, m_name, total * 4, false)) || (rc = dev_alloc(c, m_end, total * 4, false)) ||
-                (rc = dev_alloc(c, m_fs, total * 4, false))) return rc;
-            uint64_t at = 0;
-            for (size_t k = 0; k < c->frags_in_flight.size(); ++k) {
-                FragBuf &fb = c->frag_pool[c->frags_in_flight[k]];
-                const size_t n = counts[k];
-                if (!n) continue;
-                HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_file.p + at, fb.file.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync((uint64_t *)m_q.p + at, fb.qhash.p, n * 8, hipMemcpyDeviceToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync((int32_t *)m_name.p + at, fb.name.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync((int32_t *)m_end.p + at, fb.endpos.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync((uint32_t *)m_fs.p + at, fb.fs.p, n * 4, hipMemcpyDeviceToDevice, c->stream));
-                at += n;
-            }
-            FragCandidates fc{(uint64_t *)m_file.p, (uint64_t *)m_q.p, (int32_t *)m_name.p, (int32_t *)m_end.p,
-                              (uint32_t *)m_fs.p, nullptr, (uint32_t)total};
+            FragCandidates fc{(uint64_t *)c->frag_arena.col[0].p, (uint64_t *)c->frag_arena.col[1].p, (int32_t *)c->frag_arena.col[2].p,
+                              (int32_t *)c->frag_arena.col[3].p, (uint32_t *)c->frag_arena.col[4].p, nullptr, (uint32_t)total};
             rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
                                     c->frag_remaining, &c->h_sample_file, &c->h_sample_size);
-            m_file.release(); m_q.release(); m_name.release(); m_end.release(); m_fs.release();
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
         // ---- fragment GC content (--fasta runs): the same mate pairing, no cut-off --------------------------
-        if (c->have_ref && !c->gcs_in_flight.empty()) {
-            std::vector<uint32_t> counts(c->gcs_in_flight.size(), 0);
-            uint64_t total = 0;
-            for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
-                GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
-                HIP_TRY(c, hipMemcpyAsync(&counts[k], gb.count.p, 4, hipMemcpyDeviceToHost, c->stream));
-            }
+        if (c->have_ref && (!c->gcs_in_flight.empty() || c->gc_arena.used)) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            for (size_t k = 0; k < counts.size(); ++k) {
-                if (counts[k] > c->gc_pool[c->gcs_in_flight[k]].cap) return fail(c, RSQC_ERR_CAPACITY, "GC candidate overflow");
-                total += counts[k];
+            GcCandidates gc{};
+            uint64_t total = 0;
+            if (c->gc_arena.used == 0 && c->gcs_in_flight.size() == 1) {          // one batch: its candidate arrays are used in place
+                GcBuf &gb = c->gc_pool[c->gcs_in_flight[0]];
+                total = *gb.h_count;
+                if (total > gb.cap) return fail(c, RSQC_ERR_CAPACITY, "GC candidate overflow");
+                gc = GcCandidates{(uint64_t *)gb.file.p, (uint64_t *)gb.qhash.p, (uint32_t *)gb.row.p, (int32_t *)gb.endpos.p,
+                                  (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, nullptr, (uint32_t)total};
+            } else {
+                for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
+                    GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
+                    const uint32_t n = *gb.h_count;
+                    if (n > gb.cap) return fail(c, RSQC_ERR_CAPACITY, "GC candidate overflow");
+                    if ((rc = arena_reserve(c, c->gc_arena, n))) return rc;
+                    const void *src[6] = {gb.file.p, gb.qhash.p, gb.row.p, gb.endpos.p, gb.flag_lq.p, gb.tid.p};
+                    for (int f = 0; f < 6 && n; ++f)
+                        HIP_TRY(c, hipMemcpyAsync((char *)c->gc_arena.col[f].p + c->gc_arena.used * c->gc_arena.width[f], src[f],
+                                                  (size_t)n * c->gc_arena.width[f], hipMemcpyDeviceToDevice, c->stream));
+                    c->gc_arena.used += n;
+                    gb.used = false;
+                }
+                c->gcs_in_flight.clear();
+                total = c->gc_arena.used;
+                gc = GcCandidates{(uint64_t *)c->gc_arena.col[0].p, (uint64_t *)c->gc_arena.col[1].p, (uint32_t *)c->gc_arena.col[2].p,
+                                  (int32_t *)c->gc_arena.col[3].p, (uint32_t *)c->gc_arena.col[4].p, (int32_t *)c->gc_arena.col[5].p, nullptr, (uint32_t)total};
             }
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many GC candidates");
             if (total) {
-                GcCandidates gc{};
-                if (c->gcs_in_flight.size() == 1) {          // one batch: its candidate arrays are used in place
-                    GcBuf &gb = c->gc_pool[c->gcs_in_flight[0]];
-                    gc = GcCandidates{(uint64_t *)gb.file.p, (uint64_t *)gb.qhash.p, (uint32_t *)gb.row.p, (int32_t *)gb.endpos.p,
-                                      (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, nullptr, (uint32_t)total};
-                } else {
-                    static const size_t width[6] = {8, 8, 4, 4, 4, 4};
-                    for (int f = 0; f < 6; ++f)
-                        if (c->gc_merged[f].bytes < total * width[f] && (rc = dev_alloc(c, c->gc_merged[f], (total + total / 4) * width[f], false))) return rc;
-                    uint64_t at = 0;
-                    for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
-                        GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
-                        const size_t n = counts[k];
-                        if (!n) continue;
-                        const void *src[6] = {gb.file.p, gb.qhash.p, gb.row.p, gb.endpos.p, gb.flag_lq.p, gb.tid.p};
-                        for (int f = 0; f < 6; ++f)
-                            HIP_TRY(c, hipMemcpyAsync((char *)c->gc_merged[f].p + at * width[f], src[f], n * width[f], hipMemcpyDeviceToDevice, c->stream));
-                        at += n;
-                    }
-                    gc = GcCandidates{(uint64_t *)c->gc_merged[0].p, (uint64_t *)c->gc_merged[1].p, (uint32_t *)c->gc_merged[2].p,
-                                      (int32_t *)c->gc_merged[3].p, (uint32_t *)c->gc_merged[4].p, (int32_t *)c->gc_merged[5].p, nullptr, (uint32_t)total};
-                }
                 rc = run_gc_content(c->stream, gc, (uint32_t)total, c->dref, (unsigned long long *)c->d_gc_bins.p, c->gc_scratch);
                 if (rc) return fail(c, rc, "GC content stage failed");
             }

@@ -133,8 +133,6 @@ void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams
 #define RSQC_RL_SUMMARY_WORDS (2 + 2 * 128)
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc, uint32_t *summary);
-void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
-                  unsigned long long *table, uint32_t mode, int grid);
 // K4, streaming form (rsqc_kernels.hip): partition tables laid out on the device from the final geneCounts
 struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
@@ -144,12 +142,11 @@ struct FragPlan {
     unsigned long long *list;      // key lists
 };
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error);
-void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P);
+void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks);
+void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, uint32_t chunk_cap, const uint32_t *counts,
+                         uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash);
 void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound,
                        unsigned long long *gene_frag, int *error);
-void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total);
-void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
-                         uint32_t *tab_cap, unsigned long long *total, int *error);
 
 }  // namespace rsqc
 

@@ -806,173 +806,40 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// The pairs of a batch live in per-K1-block chunks (+ one slow-path region), each chunk in file order.
-// Both mates of a fragment usually fall into the same chunk (a chunk spans ~100 kb of the genome), so a
-// workgroup first removes duplicates among the pairs of its chunk in an LDS table and only the survivors
-// (about half) go to the global per-gene tables, whose random memory-side CAS traffic is what bounds this
-// stage.  The LDS pass is an optimisation only: whenever it cannot decide (table crowded, gene word of a
-// freshly claimed slot not yet visible) the pair is sent on, and the global table is exact.
-#define RSQC_K4_THREADS 512
-#define RSQC_K4_LSLOTS 4096
-#define RSQC_K4_PIECE 3072                      /* pairs per LDS pass (75 % load) */
+// The pairs of a batch live in per-K1-block chunks (+ one slow-path region), each chunk in file order; the pairs of
+// batches that have been retired (rsqc_api.cpp) sit in one dense arena in file order.
 #define RSQC_K4_GSLOTS 256
 #define RSQC_K4_SLOW_BLOCKS 32
-struct K4Shared {
-    unsigned long long lkey[RSQC_K4_LSLOTS];
-    uint32_t lgene[RSQC_K4_LSLOTS];
-    uint32_t gkey[RSQC_K4_GSLOTS], gcnt[RSQC_K4_GSLOTS];
-};
 
-__global__ void __launch_bounds__(RSQC_K4_THREADS)
-dedup_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
-             const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-             const uint64_t *tab_off, const uint32_t *tab_cap, unsigned long long *table,
-             unsigned long long *gene_frag, uint32_t mode) {
-    __shared__ K4Shared S;
-    // the pairs this workgroup owns: chunk blockIdx.x, or pieces of the slow-path region
-    uint32_t base, count, piece0 = 0, piece_step = 1;
-    if (blockIdx.x < n_chunks) {
-        base = blockIdx.x * chunk_cap;
-        count = chunk_count[blockIdx.x] < chunk_cap ? chunk_count[blockIdx.x] : chunk_cap;
-    } else {
-        base = slow_base;
-        count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
-        piece0 = blockIdx.x - n_chunks; piece_step = gridDim.x - n_chunks;
-    }
-    for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x) { S.gkey[i] = 0xFFFFFFFFu; S.gcnt[i] = 0u; }
-    const uint32_t n_pieces = (count + RSQC_K4_PIECE - 1) / RSQC_K4_PIECE;
-    for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < RSQC_K4_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
-        __syncthreads();
-        const uint32_t p0 = piece * RSQC_K4_PIECE, p1 = p0 + RSQC_K4_PIECE < count ? p0 + RSQC_K4_PIECE : count;
-        // Every pair is a chain of dependent memory operations (pair -> slice descriptor -> slot -> CAS); a thread
-        // keeps U of them in flight and each phase issues its U independent accesses back to back.
-        constexpr int U = 4;
-        for (uint32_t j0 = p0; j0 < p1; j0 += U * RSQC_K4_THREADS) {
-            bool live[U], fresh[U]; uint32_t g[U]; uint64_t key[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                  // A: the pairs
-                const uint32_t j = j0 + (uint32_t)u * RSQC_K4_THREADS + threadIdx.x;
-                live[u] = j < p1; fresh[u] = false;
-                g[u] = live[u] ? pair_gene[base + j] : 0u;
-                key[u] = live[u] ? pair_hash[base + j] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                  // B: the chunk's own LDS table
-                if (key[u] == 0) key[u] = 0x9e3779b97f4a7c15ull;           // 0 marks an empty slot
-                if (live[u] && !(mode & (8u | 64u))) {
-                    // LDS key: the name hash made gene-specific by a per-gene bijection (for one gene, equal
-                    // LDS keys <=> equal hashes); the gene word settles the rest
-                    unsigned long long lk = key[u] ^ ((unsigned long long)g[u] * 0x9E3779B97F4A7C15ull);
-                    if (lk == 0ull) lk = 1ull;
-                    uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4_LSLOTS - 1);
-                    bool done = false;
-#pragma unroll 1
-                    for (int probe = 0; probe < 8 && !done; ++probe) {
-                        const unsigned long long old = atomicCAS(&S.lkey[slot], 0ull, lk);
-                        if (old == 0ull) { S.lgene[slot] = g[u]; done = true; }              // first of its kind here
-                        // (reconverged: a claimer in this wave has written its gene word by now)
-                        if (!done && old == lk) { if (S.lgene[slot] == g[u]) live[u] = false; done = true; }
-                        slot = (slot + 1) & (RSQC_K4_LSLOTS - 1);
-                    }
-                }
-            }
-            if (mode & 32u) { for (int u = 0; u < U; ++u) live[u] = false; }     // (ablation: no global phase)
-            uint32_t cap[U], slot[U]; unsigned long long *tab[U]; unsigned long long old[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                  // C: slice descriptors of the survivors
-                cap[u] = tab_cap[g[u]];
-                tab[u] = table + tab_off[g[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                  // D: first probe (plain load)
-                slot[u] = (uint32_t)(((mix64(key[u]) >> 32) * (unsigned long long)cap[u]) >> 32);
-                old[u] = live[u] ? ((mode & 16u) ? 0ull : tab[u][slot[u]]) : 1ull;     // mode 16: CAS straight away
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)                                    // E: claim apparently empty slots
-                if (live[u] && old[u] == 0ull) old[u] = atomicCAS(&tab[u][slot[u]], 0ull, (unsigned long long)key[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                  // F: resolve; collisions probe on (rare)
-                if (!live[u]) continue;
-                if (old[u] == 0ull) { fresh[u] = true; continue; }
-                if (old[u] == key[u]) continue;
-                uint32_t sl = slot[u] + 1 == cap[u] ? 0 : slot[u] + 1;
-                for (uint32_t probes = 1; probes < cap[u]; ++probes) {
-                    // keys are never removed, so a plain (possibly stale) load that already shows the key or
-                    // another key is conclusive; only an apparently empty slot needs the device-scope CAS
-                    unsigned long long o = tab[u][sl];
-                    if (o == 0ull) o = atomicCAS(&tab[u][sl], 0ull, (unsigned long long)key[u]);
-                    if (o == 0ull) { fresh[u] = true; break; }
-                    if (o == key[u]) break;
-                    sl = sl + 1 == cap[u] ? 0 : sl + 1;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                  // G: geneFragmentCounts[g]++ via the LDS table
-                if (!fresh[u]) continue;
-                uint32_t sl = g[u] & (RSQC_K4_GSLOTS - 1);
-                bool placed = false;
-#pragma unroll 1
-                for (int probe = 0; probe < 4 && !placed; ++probe) {
-                    const uint32_t o = atomicCAS(&S.gkey[sl], 0xFFFFFFFFu, g[u]);
-                    if (o == 0xFFFFFFFFu || o == g[u]) { atomicAdd(&S.gcnt[sl], 1u); placed = true; }
-                    sl = (sl + 1) & (RSQC_K4_GSLOTS - 1);
-                }
-                if (!placed) atomicAdd(&gene_frag[g[u]], 1ull);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x)
-        if (S.gkey[i] != 0xFFFFFFFFu && S.gcnt[i]) atomicAdd(&gene_frag[S.gkey[i]], (unsigned long long)S.gcnt[i]);
-}
-
-// clears the first *total slots of the table (the count lives on the device: no host round trip)
+// Retirement of a batch: its chunks, one after the other, appended to the arena.  Workgroup k < n_chunks copies chunk k
+// (its destination = the sum of the counts before it); the last RSQC_K4_SLOW_BLOCKS workgroups share the slow-path region.
 __global__ void __launch_bounds__(256)
-dedup_clear_kernel(unsigned long long *table, const unsigned long long *total) {
-    const unsigned long long n = *total;
-    ulonglong2 *t2 = reinterpret_cast<ulonglong2 *>(table);
-    const unsigned long long n2 = n / 2;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * blockDim.x)
-        t2[i] = make_ulonglong2(0ull, 0ull);
-    if ((n & 1ull) && blockIdx.x == 0 && threadIdx.x == 0) table[n - 1] = 0ull;
-}
-
-// per-gene table layout on the device (no host round trip): cap = 2 * geneCounts, offsets by
-// a single-block exclusive scan.  total slot count is written to *total.
-__global__ void __launch_bounds__(1024)
-dedup_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off, uint32_t *tab_cap,
-                    unsigned long long *total, int *error) {
-    __shared__ unsigned long long s_part[1024];
-    const uint32_t per = (n_genes + 1023) / 1024;
-    const uint32_t g0 = threadIdx.x * per, g1 = g0 + per < n_genes ? g0 + per : n_genes;
-    unsigned long long sum = 0;
-    for (uint32_t g = g0; g < g1; ++g) {
-        const unsigned long long cap = 2ull * gene_reads[g];
-        if (cap > 0xFFFFFFFFull) atomicExch(error, RSQC_ERR_CAPACITY);
-        sum += cap;
-    }
-    s_part[threadIdx.x] = sum;
+pairs_append_kernel(const uint32_t *src_gene, const uint64_t *src_hash, uint32_t chunk_cap, const uint32_t *counts, uint32_t n_chunks,
+                    uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash) {
+    __shared__ unsigned long long s_part[256];
+    const uint32_t k = blockIdx.x < n_chunks ? blockIdx.x : n_chunks;
+    unsigned long long before = 0;
+    for (uint32_t j = threadIdx.x; j < k; j += blockDim.x) before += counts[j] < chunk_cap ? counts[j] : chunk_cap;
+    s_part[threadIdx.x] = before;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int t = 0; t < 1024; ++t) { const unsigned long long v = s_part[t]; s_part[t] = run; run += v; }
-        *total = run;
-    }
-    __syncthreads();
-    unsigned long long off = s_part[threadIdx.x];
-    for (uint32_t g = g0; g < g1; ++g) {
-        const unsigned long long cap = 2ull * gene_reads[g];
-        tab_off[g] = off; tab_cap[g] = (uint32_t)cap;
-        off += cap;
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
+    const unsigned long long dst = s_part[0];
+    uint32_t base, count, lo = 0, step = 1;
+    if (blockIdx.x < n_chunks) { base = blockIdx.x * chunk_cap; count = counts[k] < chunk_cap ? counts[k] : chunk_cap; }
+    else { base = slow_base; count = counts[n_chunks] < slow_cap ? counts[n_chunks] : slow_cap; lo = blockIdx.x - n_chunks; step = gridDim.x - n_chunks; }
+    for (uint32_t i = lo * blockDim.x + threadIdx.x; i < count; i += step * blockDim.x) {
+        dst_gene[dst + i] = src_gene[base + i]; dst_hash[dst + i] = src_hash[base + i];
     }
 }
+void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, uint32_t chunk_cap, const uint32_t *counts,
+                         uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash) {
+    hipLaunchKernelGGL(pairs_append_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(256), 0, s, src_gene, src_hash, chunk_cap, counts,
+                       n_chunks, slow_base, slow_cap, dst_gene, dst_hash);
+}
 
-// ------------------------------------------------------------------ K4, second form: no memory-side atomics
-// The open-addressing table above is bound by the chip's rate of random memory-side CAS operations (one per
-// distinct fragment).  This form replaces it by two streaming passes over PARTITIONS: a gene with n counted
+// ------------------------------------------------------------------ K4: no memory-side atomics
+// An open-addressing table per gene (round 1's first form) is bound by the chip's rate of random memory-side CAS
+// operations (one per distinct fragment).  Two streaming passes over PARTITIONS instead: a gene with n counted
 // records owns ceil(n / RSQC_K4_PART_READS) partitions (by high bits of the name hash), each with a key list of
 // fixed capacity laid out by frag_layout_kernel from the final geneCounts:
 //   frag_local_kernel   per pair chunk: LDS de-dup as before; the survivors' name hashes are APPENDED to their
@@ -1631,20 +1498,13 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
                         const DevAccum &acc, uint32_t *summary) {
     hipLaunchKernelGGL(read_length_kernel, dim3(1), dim3(64), 0, s, a, p, b, acc, summary);
 }
-void launch_dedup(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const uint64_t *tab_off, const uint32_t *tab_cap,
-                  unsigned long long *table, uint32_t mode, int grid) {
-    // pair_chunk_count[n_chunks] is the slow-path counter (same allocation)
-    (void)grid;
-    hipLaunchKernelGGL(dedup_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
-                       acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base,
-                       acc.pair_slow_cap, tab_off, tab_cap, table, acc.gene_frag, mode);
-}
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error) {
     hipLaunchKernelGGL(frag_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, P.part_first, P.gene_base, error);
     hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_gene, P.part_first, n_genes);
 }
-void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P) {
-    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
+// list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
+void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
+    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
                        acc.gene_reads, P.part_first, P.gene_base, P.cursor, P.list, acc.error);
 }
@@ -1653,13 +1513,6 @@ void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint
     const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
     hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, gene_reads, P.part_first, n_genes, P.gene_base,
                        P.cursor, P.part_gene, P.list, gene_frag, error);
-}
-void launch_dedup_clear(hipStream_t s, unsigned long long *table, const unsigned long long *total) {
-    hipLaunchKernelGGL(dedup_clear_kernel, dim3(2048), dim3(256), 0, s, table, total);
-}
-void launch_dedup_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, uint64_t *tab_off,
-                         uint32_t *tab_cap, unsigned long long *total, int *error) {
-    hipLaunchKernelGGL(dedup_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, tab_off, tab_cap, total, error);
 }
 void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium) {
     if (A.n_listed <= 0) return;

@@ -118,3 +118,43 @@ def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, 
     for f in ["gene_reads.gct", "gene_fragments.gct"] + (["fragmentSizes.txt"] if with_bed else []) + (["gc_content.tsv"] if with_fasta else []):
         assert open(os.path.join(str(tmp_path / "cli"), "s.bam." + f)).read() == open(os.path.join(exp, "s.bam." + f)).read()
     host.host_annotation_free(h)
+
+
+@pytest.mark.gpu
+def test_cli_stderr_of_the_reference_loop(cli, tmp_path):
+    """src/RNASeQC.cpp:354-355: the sort warning (positions going backwards inside a contig, or a contig visited twice);
+    :333-337: under -v, the names of primary mapped records whose RefID the header does not define.  A sorted file with
+    a complete header prints neither."""
+    contigs = [("chrA", 900_000, 70), ("chrB", 500_000, 40)]
+    ann = synth.make_annotation(seed=41, contigs=contigs)
+    batch = synth.make_reads(ann, 6000, seed=42, keep_qnames=True, contig_lengths=np.array([c[1] for c in contigs]))
+    gtf = str(tmp_path / "s.gtf")
+    bamio.write_gtf(gtf, ann)
+    WARN = "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results"
+
+    def go(b, hdr, *flags):
+        bam = str(tmp_path / "t.bam")
+        bamio.write_bam(bam, hdr, b)
+        p = subprocess.run([cli, gtf, bam, str(tmp_path / "o"), *flags], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, RSQC_BATCH="2500"))
+        assert p.returncode == 0, p.stderr.decode()
+        return p.stderr.decode()
+
+    hdr = [(c[0], c[1]) for c in contigs]
+    err = go(batch, hdr, "-v")
+    assert WARN not in err and "Unrecognized RefID" not in err
+    tid = batch.tid_per_record()
+    ok = np.flatnonzero((tid == 1) & ((batch.flag & 0x904) == 0))
+    sw = batch.slice(0, batch.n)
+    i, j = int(ok[5]), int(ok[900])
+    sw.pos[i], sw.pos[j] = batch.pos[j], batch.pos[i]
+    assert go(sw, hdr).count(WARN) == 1
+    # the second contig's records come first: chrB, chrA, then the unmapped tail -> still sorted per contig, no warning;
+    # a contig that comes back after another one is a revisit -> warning
+    a_lo, a_hi = int(batch.seg_start[0]), int(batch.seg_start[1])
+    from rnaseqc_amd.model import Batch
+    back = Batch.concat([batch.slice(a_lo, a_lo + 1000), batch.slice(a_hi, int(batch.seg_start[2])), batch.slice(a_lo + 1000, a_hi)])
+    assert go(back, hdr).count(WARN) == 1
+    err = go(batch, hdr[:1], "-v")                                # chrB's records now carry a RefID the header lacks
+    assert err.count("Unrecognized RefID on alignment: SYN:") >= 10 and WARN not in err
+    assert "Unrecognized RefID" not in go(batch, hdr[:1])         # only under -v, like the reference

@@ -477,7 +477,7 @@ def test_bam_decode_inflate_backends_agree(host, tmp_path):
 
 
 def test_bam_decode_walks_every_aux_type(host, tmp_path):
-    """Records carry random extra aux fields of every BAM type (A c C s S i I f Z H and B arrays of each element type)
+    """Records carry random extra aux fields of every BAM type (A c C s S i I f d Z H and B arrays of each element type)
     around NM / the chimeric tag / the filter tag, including look-alike tag names: the decoded tag bits and NM must not
     change (SeqLib GetIntTag / GetZTag / GetTag semantics at src/RNASeQC.cpp:295,320-327,780-800)."""
     import struct
@@ -490,12 +490,13 @@ def test_bam_decode_walks_every_aux_type(host, tmp_path):
         name = bytes(rng.choice(list(b"ABXYZabmn"), 2).tolist())
         if name in (b"NM", b"ch", b"XF"):
             name = b"Zz"
-        t = rng.choice(list("AcCsSiIfZHB"))
+        t = rng.choice(list("AcCsSiIfdZHB"))
         if t == "A": v = bytes([int(rng.integers(33, 126))])
         elif t in "cC": v = bytes([int(rng.integers(0, 256))])
         elif t in "sS": v = struct.pack("<H", int(rng.integers(0, 65536)))
         elif t in "iI": v = struct.pack("<I", int(rng.integers(0, 2 ** 32)))
         elif t == "f": v = struct.pack("<f", float(rng.random()))
+        elif t == "d": v = struct.pack("<d", float(rng.random()))               # 8 bytes: htslib skips it, so do we
         elif t == "Z": v = bytes(rng.integers(33, 126, int(rng.integers(0, 40))).tolist()) + b"\x00"
         elif t == "H": v = b"".join(b"%02X" % int(x) for x in rng.integers(0, 256, int(rng.integers(0, 8)))) + b"\x00"
         else:
@@ -520,3 +521,119 @@ def test_bam_decode_walks_every_aux_type(host, tmp_path):
     np.testing.assert_array_equal(core["pos"], batch.pos)
     np.testing.assert_array_equal(_arr(b.cigar, b.n_cigar_total, np.uint32), batch.cigar)
     host.host_bam_free(C.c_void_p(h))
+
+
+def test_bam_decode_long_cigar_from_cg_tag(host, tmp_path):
+    """A CIGAR of more than 65535 operations is stored in the CG:B,I tag behind the placeholder <l_seq>S<ref_len>N
+    (SAM spec 4.2.2); htslib restores it on read (bam_tag2cigar), so the reference's extractBlocks sees the real
+    operations -- and so must the boundary's batch."""
+    import struct, zlib
+    n_ops = 70001                                                   # 35001 x 1M interleaved with 35000 x 1D
+    ops = [(1 << 4) | (0 if k % 2 == 0 else 2) for k in range(n_ops)]
+    l_seq = (n_ops + 1) // 2
+    ref_len = n_ops
+    name = b"long1\x00"
+    cg = b"CGBI" + struct.pack("<I", n_ops) + struct.pack("<%dI" % n_ops, *ops)
+    tags = b"NMC" + bytes([3]) + cg + b"XYd" + struct.pack("<d", 1.5) + b"chZx\x00"      # a 'd' field before the chimeric tag
+    placeholder = struct.pack("<II", (l_seq << 4) | 4, (ref_len << 4) | 3)
+    rec = struct.pack("<iiBBHHHiiii", 0, 100, len(name), 255, 4680, 2, 0, l_seq, -1, -1, 0) + name + placeholder + \
+        b"\x11" * ((l_seq + 1) // 2) + b"\xff" * l_seq + tags
+    plain = struct.pack("<iiBBHHHiiii", 0, 200, len(name), 255, 4680, 1, 0, 50, -1, -1, 0) + name + struct.pack("<I", (50 << 4)) + \
+        b"\x11" * 25 + b"\xff" * 50
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrA\tLN:1000000\n"
+    raw = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 5) + b"chrA\x00" + struct.pack("<I", 1000000)
+    raw += struct.pack("<I", len(rec)) + rec + struct.pack("<I", len(plain)) + plain
+    path = str(tmp_path / "cg.bam")
+    with open(path, "wb") as f:
+        for o in range(0, len(raw), 60000):
+            f.write(bamio._bgzf_block(raw[o:o + 60000]))
+        f.write(bamio._EOF)
+    h = host.host_bam_read_all(path.encode(), b"ch", None, 0)
+    assert h
+    b = host.host_bam_batch(h).contents
+    assert b.n == 2 and b.n_wide == 1
+    aux = _arr(b.aux, 2, abi.REC_AUX); core = _arr(b.core, 2, abi.REC_CORE)
+    assert aux["n_cigar"][0] == abi.NCIGAR_ESCAPE and _arr(b.wide_n_cigar, 1, np.uint32)[0] == n_ops
+    cig = _arr(b.cigar, b.n_cigar_total, np.uint32)
+    assert b.n_cigar_total == n_ops + 1 and list(cig[:n_ops]) == ops and cig[n_ops] == (50 << 4)
+    assert core["cigar_off"][1] == n_ops
+    assert aux["tagbits"][0] & abi.TB_HAS_NM and aux["nm"][0] == 3 and aux["tagbits"][0] & abi.TB_HAS_CH   # found behind CG and the 'd' field
+    host.host_bam_free(h)
+
+
+def test_bam_decode_rejects_oversized_isize(host, tmp_path):
+    """A BGZF trailer that claims more than 64 KiB is refused before any buffer is sized from it."""
+    import struct
+    ann, batch = cases.quirk_case()
+    path = str(tmp_path / "q.bam")
+    bamio.write_bam(path, [("chr1", 100000), ("chr2", 100000)], batch)
+    d = bytearray(open(path, "rb").read())
+    bsize = struct.unpack_from("<H", d, 16)[0] + 1
+    struct.pack_into("<I", d, bsize - 4, 0x7FFFFFF0)                 # ISIZE of the first block
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(d))
+    assert not host.host_bam_read_all(bad.encode(), b"ch", None, 0)
+    h = host.host_bam_read_all(path.encode(), b"ch", None, 0)
+    assert h
+    host.host_bam_free(h)
+
+
+def test_bam_decode_reports_unsorted_input_and_unknown_refids(host, tmp_path):
+    """What the reference prints on stderr from its loop: positions going backwards inside a contig
+    (src/RNASeQC.cpp:354-355) and records whose RefID the header does not define (:333-337)."""
+    ann = synth.make_annotation(seed=39, contigs=[("chrA", 1_000_000, 60), ("chrB", 500_000, 20)])
+    batch = synth.make_reads(ann, 3000, seed=41, keep_qnames=True, contig_lengths=np.array([1_000_000, 500_000]))
+    contigs = [("chrA", 1_000_000), ("chrB", 500_000)]
+    host.host_bam_unsorted.argtypes = [C.c_void_p]; host.host_bam_bad_refid_count.argtypes = [C.c_void_p]
+    host.host_bam_bad_refid.argtypes = [C.c_void_p, C.c_int]; host.host_bam_bad_refid.restype = C.c_char_p
+    host.host_bam_read_all_ex.restype = C.c_void_p
+
+    def decode(b, contigs_):
+        path = str(tmp_path / "t.bam")
+        bamio.write_bam(path, contigs_, b)
+        out = []
+        for threads, per in ((1, 1 << 20), (3, 700)):
+            h = host.host_bam_read_all_ex(path.encode(), b"ch", None, 0, threads, C.c_ulonglong(per))
+            assert h
+            out.append((host.host_bam_unsorted(C.c_void_p(h)), [host.host_bam_bad_refid(C.c_void_p(h), i).decode()
+                                                                  for i in range(host.host_bam_bad_refid_count(C.c_void_p(h)))]))
+            host.host_bam_free(C.c_void_p(h))
+        assert out[0] == out[1]
+        return out[0]
+
+    assert decode(batch, contigs) == (0, [])
+    # two mapped primary records of one contig swapped
+    tid = batch.tid_per_record()
+    ok = np.flatnonzero((tid == 0) & ((batch.flag & 0x904) == 0))
+    i, j = int(ok[10]), int(ok[400])
+    assert batch.pos[i] < batch.pos[j]
+    sw = batch.slice(0, batch.n)
+    sw.pos[i], sw.pos[j] = batch.pos[j], batch.pos[i]
+    assert decode(sw, contigs)[0] == 1
+    # a header that names only the first contig: the records of the second one carry an undefined RefID
+    u, names = decode(batch, contigs[:1])
+    assert u == 0 and len(names) > 0 and all(n.startswith("SYN:") for n in names)
+
+
+def test_bam_by_contig_reading_through_the_index(host, tmp_path):
+    """BamReader::load_index + seek: the records of one reference sequence, located by the .bai's per-reference
+    virtual offsets (the counterpart of an index-driven region reader; what a contig-sharded run reads)."""
+    contigs = [("cA", 2_000_000, 150), ("cB", 1_500_000, 120), ("cC", 900_000, 0), ("cD", 700_000, 50)]
+    ann = synth.make_annotation(seed=21, contigs=contigs)
+    batch = synth.make_reads(ann, 20000, seed=22, contig_lengths=np.array([c[1] for c in contigs]))
+    path = str(tmp_path / "i.bam")
+    voff = bamio.write_bam_fast(path, [(c[0], c[1]) for c in contigs], batch, threads=3, bai=True)
+    assert len(voff) == len(batch.seg_tid) + 1 and (np.diff(voff.astype(np.int64)) > 0).all()
+    host.host_bam_read_contig.restype = C.c_void_p
+    tid = batch.tid_per_record()
+    for c in range(len(contigs)):
+        for threads in (1, 3):
+            h = host.host_bam_read_contig(path.encode(), b"ch", None, 0, threads, c)
+            assert h
+            b = host.host_bam_batch(C.c_void_p(h)).contents
+            m = tid == c
+            assert b.n == int(m.sum())
+            core = _arr(b.core, b.n, abi.REC_CORE); aux = _arr(b.aux, b.n, abi.REC_AUX)
+            np.testing.assert_array_equal(core["pos"], batch.pos[m]); np.testing.assert_array_equal(aux["flag"], batch.flag[m])
+            assert b.n_seg == 1 and _arr(b.seg_tid, 1, np.int32)[0] == c
+            host.host_bam_free(C.c_void_p(h))
