@@ -21,6 +21,7 @@
 #include "Metrics.h"
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <list>
@@ -40,6 +41,32 @@ namespace rnaseqc {
 using namespace rnaseqc;
 
 extern "C" {
+
+// Collector (src/Metrics.h:43-59, src/Metrics.cpp:48-93) driven with a recorded call sequence: kind 0 = add(gene, exon,
+// frac), 1 = queryGene(gene), 2 = collect(gene); a new Collector is constructed whenever `read` changes, like the one
+// exonAlignmentMetrics constructs per alignment (src/Expression.cpp:320).  The target map plays exonCounts.
+// Outputs: the map's value per exon id and whether the exon has a map ENTRY (src/RNASeQC.cpp:513 counts entries), the
+// answer of every queryGene, and Collector::sum() after the last call of each read that collected something.
+__attribute__((visibility("default")))
+int ref_collector_replay(uint64_t n, const uint8_t *kind, const uint32_t *read, const uint32_t *gene, const uint32_t *exon, const double *frac,
+                         uint32_t n_exons, double *exon_value, uint8_t *exon_entry, uint8_t *query_out, double *max_sum) {
+    std::map<std::string, double> target;
+    Collector *col = nullptr; uint32_t cur = 0; bool have = false;
+    *max_sum = 0.0;
+    auto name = [](char p, uint32_t v) { char b[16]; snprintf(b, sizeof b, "%c%09u", p, v); return std::string(b); };
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!have || read[i] != cur) { if (col) { if (col->sum() > *max_sum) *max_sum = col->sum(); delete col; } col = new Collector(&target); cur = read[i]; have = true; }
+        if (kind[i] == 0) col->add(name('G', gene[i]), name('E', exon[i]), frac[i]);
+        else if (kind[i] == 1) query_out[i] = col->queryGene(name('G', gene[i])) ? 1 : 0;
+        else col->collect(name('G', gene[i]));
+    }
+    if (col) { if (col->sum() > *max_sum) *max_sum = col->sum(); delete col; }
+    for (uint32_t e = 0; e < n_exons; ++e) {
+        auto it = target.find(name('E', e));
+        exon_entry[e] = it != target.end(); exon_value[e] = it != target.end() ? it->second : 0.0;
+    }
+    return 0;
+}
 
 // computeMedian on an already ordered list (src/Metrics.h:147-160)
 __attribute__((visibility("default")))

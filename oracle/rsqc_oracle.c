@@ -112,6 +112,10 @@ typedef struct oracle_ctx {
      * (span, l_qseq) of every record that reaches src/RNASeQC.cpp:275, the record counts at the end of every submit,
      * and every fragment-size sample with the file index of the record that completed it                          */
     int trace;
+    /* Collector trace (oracle_enable_collector_trace): every Collector::add / queryGene / collect this restatement
+     * performs, in order, so that the REFERENCE's own class (compiled in oracle/_ref) can be driven with the same calls */
+    int ctrace; uint32_t ctr_read;
+    uint8_t *ct_kind; uint32_t *ct_read, *ct_gene, *ct_exon; double *ct_frac; uint8_t *ct_query; size_t ct_n, ct_cap;
     uint64_t cur_file_index;
     uint32_t *tr_span; int32_t *tr_lq; size_t tr_n, tr_cap;
     uint64_t *tr_batch_end, *tr_batch_file; size_t tr_nb, tr_bcap;
@@ -121,6 +125,17 @@ typedef struct oracle_ctx {
 } oracle_ctx;
 
 /* ------------------------------------------------------------ small utils */
+static void *xrealloc(void *q, size_t sz);
+static void ct_push(struct oracle_ctx *c, int kind, uint32_t gene, uint32_t exon, double frac, int query) {
+    if (c->ct_n == c->ct_cap) {
+        c->ct_cap = c->ct_cap ? c->ct_cap * 2 : 4096;
+        c->ct_kind = xrealloc(c->ct_kind, c->ct_cap); c->ct_read = xrealloc(c->ct_read, c->ct_cap * 4);
+        c->ct_gene = xrealloc(c->ct_gene, c->ct_cap * 4); c->ct_exon = xrealloc(c->ct_exon, c->ct_cap * 4);
+        c->ct_frac = xrealloc(c->ct_frac, c->ct_cap * 8); c->ct_query = xrealloc(c->ct_query, c->ct_cap);
+    }
+    c->ct_kind[c->ct_n] = (uint8_t)kind; c->ct_read[c->ct_n] = c->ctr_read; c->ct_gene[c->ct_n] = gene; c->ct_exon[c->ct_n] = exon;
+    c->ct_frac[c->ct_n] = frac; c->ct_query[c->ct_n] = (uint8_t)query; c->ct_n++;
+}
 
 static void *xcalloc(size_t n, size_t sz) {
     void *p = calloc(n ? n : 1, sz ? sz : 1);
@@ -621,6 +636,7 @@ static double exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_
                     if (nst == cst) { cst = cst ? cst * 2 : 8; st = xrealloc(st, cst * sizeof(staged_t)); }
                     st[nst].gene = f->gene; st[nst].exon_row = f->row;
                     st[nst].frac = (double)isz / length;                    /* :345 */
+                    if (c->ctrace) ct_push(c, 0, f->gene, c->ex_id[f->row], st[nst].frac, 0);   /* Collector::add :346 */
                     st[nst].offset = bs - f->start;                         /* Metrics.cpp:99-100 */
                     st[nst].length = (uint32_t)(be - bs);
                     {                                                       /* alignedExons.insert(feature_id) :348 */
@@ -650,6 +666,7 @@ static double exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_
             if (hq) {
                 int query = 0;                                              /* Collector::queryGene: entries with coverage > 0 */
                 for (size_t k = 0; k < nst; ++k) if (st[k].gene == gene && st[k].frac > 0) query = 1;
+                if (c->ctrace) { ct_push(c, 1, gene, 0, 0.0, query); ct_push(c, 2, gene, 0, 0.0, 0); }  /* queryGene :380, collect :390 */
                 if (query) {
                     c->gene_reads[gene] += 1.0;                             /* :382 */
                     if (nameset_insert(&c->tracker[gene], r->qhash, r->qname, r->qname_len))
@@ -1068,6 +1085,7 @@ ORACLE_API int oracle_submit(oracle_ctx *c, const rsqc_batch *b) {
             r.qname = NULL; r.qname_len = 0;
             if (b->qname && b->qname_off) { r.qname = b->qname + b->qname_off[i]; r.qname_len = b->qname_off[i + 1] - b->qname_off[i]; }
             c->cur_file_index = b->file_index_base + i;
+            c->ctr_read++;
             int rc = process_record(c, &r);
             if (rc) return c->error = rc;
         }
@@ -1089,6 +1107,16 @@ typedef struct oracle_trace {
     uint64_t n_samples; const uint64_t *sample_file_index; const uint32_t *sample_size;
 } oracle_trace;
 ORACLE_API int oracle_enable_trace(oracle_ctx *c) { if (!c) return RSQC_ERR_ARG; c->trace = 1; return 0; }
+typedef struct oracle_collector_trace {
+    uint64_t n; const uint8_t *kind;        /* 0 add, 1 queryGene, 2 collect */
+    const uint32_t *read, *gene, *exon; const double *frac; const uint8_t *query;
+} oracle_collector_trace;
+ORACLE_API int oracle_enable_collector_trace(oracle_ctx *c) { if (!c) return RSQC_ERR_ARG; c->ctrace = 1; return 0; }
+ORACLE_API int oracle_get_collector_trace(oracle_ctx *c, oracle_collector_trace *t) {
+    if (!c || !t) return RSQC_ERR_ARG;
+    t->n = c->ct_n; t->kind = c->ct_kind; t->read = c->ct_read; t->gene = c->ct_gene; t->exon = c->ct_exon; t->frac = c->ct_frac; t->query = c->ct_query;
+    return 0;
+}
 ORACLE_API int oracle_get_trace(oracle_ctx *c, oracle_trace *t) {
     if (!c || !t) return RSQC_ERR_ARG;
     t->n_eligible = c->tr_n; t->span = c->tr_span; t->l_qseq = c->tr_lq;
@@ -1152,6 +1180,7 @@ ORACLE_API void oracle_destroy(oracle_ctx *c) {
     free(c->tracker); free(c->cov); free(c->seen); free(c->cov_mean); free(c->cov_std); free(c->cov_cv);
     free(c->cov_valid); free(c->exon_cv); free(c->exon_cv_valid); free(c->bias3); free(c->bias5);
     free(c->exit_order); free(c->r_reads); free(c->r_unique); free(c->r_frag);
+    free(c->ct_kind); free(c->ct_read); free(c->ct_gene); free(c->ct_exon); free(c->ct_frac); free(c->ct_query);
     free(c->tr_span); free(c->tr_lq); free(c->tr_batch_end); free(c->tr_batch_file); free(c->tr_sample_file); free(c->tr_sample_size);
     free(c);
 }

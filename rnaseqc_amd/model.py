@@ -405,6 +405,50 @@ class Batch:
                      wide_nm=cat("wide_nm"), wide_l_qseq=cat("wide_l_qseq"), wide_n_cigar=cat("wide_n_cigar"),
                      file_index_base=parts[0].file_index_base, **kw)
 
+    def take(self, idx) -> "Batch":
+        """The records idx[0], idx[1], ... as a new batch (any order, e.g. a coordinate sort of a concatenation)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = self.n
+        cend = np.empty(n + 1, dtype=np.int64); cend[:n] = self.cigar_off; cend[n] = len(self.cigar)
+        # CIGAR length of a record = distance to the next record's offset IN STORAGE ORDER
+        order = np.argsort(self.cigar_off, kind="stable")
+        clen = np.zeros(n, np.int64)
+        nxt = np.append(self.cigar_off[order][1:].astype(np.int64), len(self.cigar))
+        clen[order] = nxt - self.cigar_off[order].astype(np.int64)
+        counts = clen[idx]
+        total = int(counts.sum())
+        out_off = np.cumsum(counts) - counts
+        flat = self.cigar[(np.arange(total) - np.repeat(out_off, counts) + np.repeat(self.cigar_off[idx].astype(np.int64), counts))] if total else self.cigar[:0]
+        tid = self.tid_per_record()[idx]
+        m = len(idx)
+        if m:
+            change = np.flatnonzero(np.diff(tid)) + 1
+            starts = np.concatenate([[0], change])
+            seg_tid, seg_start = tid[starts], np.concatenate([starts, [m]])
+        else:
+            seg_tid, seg_start = np.zeros(0, np.int32), np.zeros(1, np.uint64)
+        pos_of = {int(w): k for k, w in enumerate(self.wide_index)}
+        wsel = [(j, pos_of[int(i)]) for j, i in enumerate(idx) if int(i) in pos_of] if len(pos_of) else []
+        kw = {}
+        if self.qname is not None:
+            qlen = (self.qname_off[1:].astype(np.int64) - self.qname_off[:-1].astype(np.int64))[idx]
+            qo = np.concatenate([[0], np.cumsum(qlen)])
+            qflat = self.qname[(np.arange(int(qlen.sum())) - np.repeat(qo[:-1], qlen) + np.repeat(self.qname_off[:-1].astype(np.int64)[idx], qlen))]
+            kw = dict(qname=qflat, qname_off=qo.astype(np.uint32))
+        return Batch(pos=self.pos[idx], mpos=self.mpos[idx], isize=self.isize[idx], qhash=self.qhash[idx],
+                     cigar_off=out_off.astype(np.uint32), flag=self.flag[idx], l_qseq=self.l_qseq[idx], mapq=self.mapq[idx],
+                     nm=self.nm[idx], tagbits=self.tagbits[idx], n_cigar=self.n_cigar[idx], cigar=flat,
+                     seg_tid=np.asarray(seg_tid, np.int32), seg_start=np.asarray(seg_start, np.uint64),
+                     wide_index=np.array([w[0] for w in wsel], np.uint64), wide_nm=self.wide_nm[[w[1] for w in wsel]] if wsel else np.zeros(0, np.int32),
+                     wide_l_qseq=self.wide_l_qseq[[w[1] for w in wsel]] if wsel else np.zeros(0, np.int32),
+                     wide_n_cigar=self.wide_n_cigar[[w[1] for w in wsel]] if wsel else np.zeros(0, np.uint32), **kw)
+
+    def coordinate_sorted(self) -> "Batch":
+        """Stable sort by (contig, position), unplaced records last: what a coordinate-sorted BAM holds."""
+        tid = self.tid_per_record().astype(np.int64)
+        key = np.where(tid < 0, np.int64(1) << 40, tid)
+        return self.take(np.lexsort((self.pos.astype(np.int64), key)))
+
     def slice(self, lo: int, hi: int) -> "Batch":
         """Records [lo, hi) as an independent batch (cigar pool re-based)."""
         lo, hi = int(lo), int(hi)

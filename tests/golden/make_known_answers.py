@@ -60,3 +60,13 @@ for line in open(os.path.join(REF, "legacy.output/downsampled.bam.metrics.tsv"))
 out["legacy"] = d
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json"), "w"))
 print({k: list(v.keys()) for k, v in out.items()})
+
+# The chr1 golden GCT tables themselves (ids, descriptions, values as printed): data for the byte-for-byte check of the GCT
+# writers and of "Genes Detected" (tests/test_golden_reference.py::test_gct_writers_reproduce_chr1_golden).  ~120 KB gzipped.
+tables = {}
+for f in ("gene_reads", "gene_fragments", "exon_reads", "gene_tpm"):
+    t = gzip.open(os.path.join(REF, "chr1.output/chr1.bam.%s.gct.gz" % f), "rt").read().split("\n")
+    rows = [l.split("\t") for l in t[3:] if l]
+    tables[f] = {"header": t[:3], "id": [r[0] for r in rows], "desc": [r[1] for r in rows], "value": [r[2] for r in rows]}
+with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "chr1_gct_tables.json.gz"), "wt") as fh:
+    json.dump(tables, fh)

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from tests import report_ref
+from tests.test_host_cli_pieces import host  # noqa: F401  (fixture: the C++ host library)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KA = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
@@ -160,3 +161,74 @@ def test_legacy_golden_invariants(oracle_lib):
         assert 0 < i["Split Reads"] <= i["Exonic Reads"]
     keys = KA["legacy"]["metrics_keys"]
     assert keys.index("rRNA Reads") + 1 == keys.index("Split Reads") == keys.index("Total Bases") - 1
+
+
+def test_gct_writers_reproduce_chr1_golden(host, tmp_path):
+    """The reference's chr1 golden GCT files, re-emitted BYTE FOR BYTE by our report writer from the values they hold:
+    gene_reads / gene_fragments (cast to long, src/RNASeQC.cpp:441-442), exon_reads (std::fixed 6 decimals, header
+    count = exons with a map entry while every exon gets a row, :510-521), the `#1.2` / `rows\\t1` / column header
+    lines (:427-436), and "Genes Detected" = genes with uniqueGeneCounts >= 5 (:461; the golden run has no duplicate
+    reads, so unique == reads).  The annotation is rebuilt from the ids in the tables (coordinates are irrelevant here)."""
+    import ctypes as C
+    import gzip
+    import json
+    from rnaseqc_amd import abi
+    from tests.test_host_cli_pieces import load_annotation, _results_struct, read_table
+    T = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chr1_gct_tables.json.gz"), "rt"))
+    gids, gdesc = T["gene_reads"]["id"], T["gene_reads"]["desc"]
+    eids = T["exon_reads"]["id"]
+    exons_of = {}
+    for e in eids:
+        exons_of.setdefault(e.rsplit("_", 1)[0], []).append(e)
+    gtf = str(tmp_path / "g.gtf")
+    with open(gtf, "w") as f:
+        pos = 1000
+        for g, nm in zip(gids, gdesc):
+            ex = exons_of.get(g, [])
+            span = 300 * max(len(ex), 1)
+            attr = 'gene_id "%s"; transcript_id "%s"; gene_name "%s"; transcript_type "protein_coding";' % (g, g, nm)
+            f.write("chr1\tx\tgene\t%d\t%d\t.\t+\t.\t%s\n" % (pos, pos + span, attr))
+            for k, e in enumerate(ex):
+                f.write("chr1\tx\texon\t%d\t%d\t.\t+\t.\t%s exon_id \"%s\";\n" % (pos + 300 * k, pos + 300 * k + 99, attr, e))
+            pos += span + 500
+    h, err = load_annotation(host, gtf, ["chr1"])
+    assert err == 0
+    G, E = len(gids), len(eids)
+
+    class R:            # the fields _results_struct reads
+        pass
+    r = R()
+    r.gene_reads = np.array([int(v) for v in T["gene_reads"]["value"]], np.uint64)
+    r.gene_unique = r.gene_reads.copy()
+    r.gene_fragments = np.array([int(v) for v in T["gene_fragments"]["value"]], np.uint64)
+    r.exon_reads = np.array([float(v) for v in T["exon_reads"]["value"]], np.float64)
+    r.exon_hit = (r.exon_reads > 0).astype(np.uint8)
+    m = KA["chr1"]["metrics"]
+    r.counters = np.zeros(abi.N_COUNTERS, np.uint64)
+    for k, name in enumerate(abi.COUNTER_NAMES):
+        if name in m and m[name].isdigit():
+            r.counters[k] = int(m[name])
+    r.read_length = int(m["Read Length"])
+    r.gene_cov_mean = np.zeros(G); r.gene_cov_std = np.zeros(G); r.gene_cov_cv = np.zeros(G); r.gene_cov_valid = np.zeros(G, np.uint8)
+    r.gene_cov_valid[0] = 1                                        # (one gene with coverage: the median lines need a non-empty list)
+    r.exon_cv = np.zeros(E); r.exon_cv_valid = np.zeros(E, np.uint8)
+    r.bias_three = np.zeros(G, np.uint64); r.bias_five = np.zeros(G, np.uint64)
+    r.fragment_size = np.zeros(0, np.int64); r.fragment_count = np.zeros(0, np.uint64); r.fragment_samples_remaining = 0
+    r.have_reference = 0
+    rs, keep = _results_struct(r)
+    out = str(tmp_path / "out"); os.makedirs(out)
+    visit = (C.c_int * 1)(0)
+    assert host.host_write_reports(h, C.byref(rs), out.encode(), b"chr1.bam", 0, 0, 0, 5, None, 0, visit, 1) == 0
+    for f in ("gene_reads", "gene_fragments", "exon_reads"):
+        t = T[f]
+        want = "\n".join(t["header"]) + "\n" + "".join("%s\t%s\t%s\n" % x for x in zip(t["id"], t["desc"], t["value"]))
+        assert open(os.path.join(out, "chr1.bam.%s.gct" % f)).read() == want, f
+    assert int(T["exon_reads"]["header"][1].split("\t")[0]) == int(r.exon_hit.sum()) < E
+    ours = dict(read_table(os.path.join(out, "chr1.bam.metrics.tsv")))
+    assert ours["Genes Detected"] == m["Genes Detected"] == str(int((r.gene_reads >= 5).sum()))
+    # TPM needs the coding lengths of the missing GTF; what the golden table does pin: zero exactly where the count is zero, sum 1e6
+    tpm = np.array([float(v) for v in T["gene_tpm"]["value"]])
+    assert ((tpm > 0) == (r.gene_reads > 0)).all() and abs(tpm.sum() - 1e6) < 1e-3
+    t_ours = read_table(os.path.join(out, "chr1.bam.gene_tpm.gct"), 3)
+    assert abs(sum(float(x[2]) for x in t_ours) - 1e6) < 1e-2 and all((float(x[2]) > 0) == (c > 0) for x, c in zip(t_ours, r.gene_reads))
+    host.host_annotation_free(h)

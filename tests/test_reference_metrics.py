@@ -130,3 +130,58 @@ def test_median_and_statistics_vs_reference(ref):
         assert ref.statistics(d.copy()) == ref.ref_statistics(d)
     with pytest.raises(ref.OracleError):
         ref.ref_median([])
+
+
+def test_collector_vs_reference_class(ref):
+    """Collector::{add, queryGene, collect} (src/Metrics.h:43-59, src/Metrics.cpp:48-81) -- the per-read staging of exon
+    fractions behind exonCounts -- is driven with exactly the calls the oracle's restatement of exonAlignmentMetrics makes
+    (recorded call by call) and must leave bit-identical sums, the same set of map entries (the `exon_reads.gct` header
+    count, src/RNASeQC.cpp:513) and the same queryGene answers; incl. zero-length blocks, whose fraction 0 (or 0/0) the
+    `coverage > 0` test drops (src/Metrics.cpp:51)."""
+    import ctypes as C
+    from rnaseqc_amd import synth
+    contigs = [("chrA", 600_000, 80), ("chrB", 300_000, 30)]
+    ann = synth.make_annotation(seed=51, contigs=contigs)
+    base = synth.make_reads(ann, 12000, seed=52, dup_frac=0.1, contig_lengths=np.array([c[1] for c in contigs]))
+    # hand-made additions on the first contig: zero-length aligned blocks inside exons
+    rows = np.flatnonzero((ann.exon_row_contig == 0) & ((ann.exon_row_end - ann.exon_row_start) > 120))
+    extra = []
+    for k, row in enumerate(rows[:6]):
+        s = int(ann.exon_row_start[row])
+        extra.append(dict(tid=0, pos=s + 4, mpos=s + 4, flag=99, mapq=255, qname="zero%d" % k, nm=0, l_qseq=50,
+                          cigar=[(M, 0)] if k % 2 == 0 else [(M, 50), (abi.CIG_I, 3), (M, 0), (M, 20)]))
+    zb = Batch.from_records(extra)
+    base.qname = base.qname_off = None
+    zb.qname = zb.qname_off = None
+    recs = Batch.concat([base, zb]).coordinate_sorted()
+    assert recs.n == base.n + 6
+    o = ref.Oracle(abi.default_params())
+    o.set_annotation(ann)
+    o._check(o._l.oracle_enable_collector_trace(o._h))
+    o.submit(recs)
+    want = o.finalize()
+
+    class T(C.Structure):
+        _fields_ = [("n", C.c_uint64), ("kind", C.c_void_p), ("read", C.c_void_p), ("gene", C.c_void_p), ("exon", C.c_void_p),
+                    ("frac", C.c_void_p), ("query", C.c_void_p)]
+    t = T()
+    o._check(o._l.oracle_get_collector_trace(o._h, C.byref(t)))
+    n = int(t.n)
+    kind = abi._view(t.kind, n, np.uint8); read = abi._view(t.read, n, np.uint32); gene = abi._view(t.gene, n, np.uint32)
+    exon = abi._view(t.exon, n, np.uint32); frac = abi._view(t.frac, n, np.float64); query = abi._view(t.query, n, np.uint8)
+    o.close()
+    assert (kind == 0).sum() > 5000 and (kind == 2).sum() > 3000
+    adds = kind == 0
+    assert (adds & ~(frac > 0)).sum() >= 3                      # the zero-length blocks: fraction 0 or NaN, dropped by add()
+    E = ann.n_exons
+    val = np.zeros(E); entry = np.zeros(E, np.uint8); q = np.zeros(n, np.uint8); mx = C.c_double()
+    rl = ref.ref_lib()
+    rl.ref_collector_replay.argtypes = [C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint32] + [C.c_void_p] * 3 + [C.POINTER(C.c_double)]
+    assert rl.ref_collector_replay(n, abi.ptr(kind), abi.ptr(read), abi.ptr(gene), abi.ptr(exon), abi.ptr(frac), E,
+                                   abi.ptr(val), abi.ptr(entry), abi.ptr(q), C.byref(mx)) == 0
+    np.testing.assert_array_equal(val, want.exon_reads)         # same additions in the same order: bit-identical
+    np.testing.assert_array_equal(entry, want.exon_hit)
+    np.testing.assert_array_equal(q[kind == 1], query[kind == 1])
+    assert 0.99 < mx.value <= 2.0 + 1e-9                        # Collector::sum(): a read counted to two overlapping genes adds up twice
+    # geneCounts only moves when queryGene says so (src/Expression.cpp:380-382)
+    assert int(want.gene_reads.sum()) == int(query[kind == 1].sum())
