@@ -295,16 +295,16 @@ int main(int argc, char **argv) {
             // reference's destructively trimmed window would count).
             if (o.verbosity) for (auto &nm : hb.bad_refid) cerr << "Unrecognized RefID on alignment: " << nm << endl;
             bool revisit = false;
-            for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t) && std::find(visit.begin(), visit.end(), t) != visit.end()) revisit = true;
-            if ((hb.unsorted || revisit) && !warned_unsorted) {
-                cerr << "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results" << endl;
-                warned_unsorted = true;
-            }
             for (int32_t t : hb.seg_tid) if (t >= 0 && (visit.empty() || visit.back() != t)) {
+                if (std::find(visit.begin(), visit.end(), t) != visit.end()) revisit = true;     // a contig that comes back
                 visit.push_back(t);
                 if (o.has_fasta && (size_t)t < in_fasta.size() && !in_fasta[(size_t)t])      // src/RNASeQC.cpp:350-352
                     cerr << "Warning: Provided Fasta does not contain chromosome " << ann.contig_names[(size_t)t]
                          << ". No GC statistics will be collected for this chromosome" << endl;
+            }
+            if ((hb.unsorted || revisit) && !warned_unsorted) {
+                cerr << "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results" << endl;
+                warned_unsorted = true;
             }
             alignmentCount += n;
             rsqc_batch view = hb.view();
