@@ -47,10 +47,11 @@ def end_to_end(args, ann, contigs, batch, st, log):
     """The whole-node tier: `rnaseqc gtf bam out -vv` on a BAM of the bench records.  Driver-timed here; the
     reads/s is the CLI's own `Average Reads/Sec` line (BAM loop + end-of-file stage, GTF load and report writing
     excluded, exactly the reference's window)."""
-    from rnaseqc_amd import bamio
-    cores = os.cpu_count() or 1
+    from rnaseqc_amd import bamio, hostinfo
+    cores = hostinfo.effective_cpus()
     d = tempfile.mkdtemp(prefix="rsqc_e2e_", dir=args.tmp or None)
-    out = {"cores": cores}
+    out = {"cores": cores, "hardware_threads": os.cpu_count(),
+           "cores_note": "CPUs the process may use = affinity mask capped by the cgroup CPU quota (cpu.max); the decode pools are sized to it"}
     try:
         bam, gtf, odir = os.path.join(d, "s.bam"), os.path.join(d, "s.gtf"), os.path.join(d, "out")
         t = time.time()
@@ -107,7 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=50_000_000, help="read pairs of the whole job (2 records each + 1.5 %% copies + 1 %% unmapped)")
     ap.add_argument("--cpu-sample", type=int, default=60_000_000, help="records timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--workers", type=int, default=0, help="generator processes (0 = min(cores, 24))")
+    ap.add_argument("--workers", type=int, default=0, help="generator processes (0 = min(usable CPUs, 24))")
     ap.add_argument("--chr1", action="store_true", help="(diagnostic) BASELINE.json configs[1]: chr1-like GTF + --pairs pairs "
                                                          "(default 5 M) on one GPU; output marked invalid")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end tier (CLI on a BAM of the same records)")
@@ -159,7 +160,8 @@ def main():
     load = np.array([int(share[rank_of == r].sum()) for r in range(world)])
     mine = [int(c) for c in np.flatnonzero(rank_of == rank)]
     tail_rank = int(np.argmin(load))                     # the unmapped tail goes to the lightest shard
-    cores = os.cpu_count() or 1
+    from rnaseqc_amd import hostinfo
+    cores = hostinfo.effective_cpus()
     workers = args.workers or max(1, min(cores // max(world, 1), 24))
     if args.chr1:
         batch = synth.make_reads(ann, args.pairs, seed=2)

@@ -427,7 +427,8 @@ RSQC_API int rsqc_device_vectors(rsqc_ctx *ctx, rsqc_device_range out[3]);
  *   batches of ALL shards in ascending batch_file_index from state 0 gives the reference's value.
  *   Fragment sizes (src/Expression.cpp:482-540): mates pair inside one BED interval, hence inside one shard; the
  *   cut-off --fragment-samples applies in FILE order.  The shard hands over the samples it kept (its first N by the file
- *   index of the completing record, ascending); the merged histogram holds the N smallest file indices of the union.  */
+ *   index of the completing record, in no particular order); the merged histogram holds the N smallest file indices
+ *   of the union.                                                                                                   */
 typedef struct rsqc_shard_info {
     uint32_t n_batches;
     const uint64_t *batch_file_index;  /* [n_batches] file_index_base of the batch  */
@@ -436,7 +437,7 @@ typedef struct rsqc_shard_info {
     const uint32_t *rl_span;           /* ascending inside a batch                  */
     const int32_t  *rl_state;
     uint32_t n_samples;
-    const uint64_t *sample_file_index; /* [n_samples] ascending                     */
+    const uint64_t *sample_file_index; /* [n_samples] unordered                     */
     const uint32_t *sample_size;       /* [n_samples] abs(InsertSize)               */
 } rsqc_shard_info;
 RSQC_API int rsqc_shard_summary(rsqc_ctx *ctx, rsqc_shard_info *out);

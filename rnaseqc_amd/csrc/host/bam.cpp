@@ -1,5 +1,6 @@
 #include "bam.hpp"
 
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <dlfcn.h>
@@ -112,19 +113,47 @@ void WorkPool::run(size_t n_tasks, const std::function<void(size_t)> &fn) {
     if (!err.empty()) throw std::runtime_error(err);
 }
 
+// CPUs this process may actually use: the affinity mask, capped by the cgroup's CFS quota (cpu.max of cgroup v2,
+// cpu.cfs_quota_us / cpu.cfs_period_us of v1).  More runnable threads than that are not faster, they are throttled:
+// the whole group is frozen for the rest of every period once the quota is spent.
+int effective_cpus() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    auto quota_of = [](const char *path, const char *path2) -> double {
+        FILE *f = fopen(path, "r");
+        if (!f) return 0.0;
+        char a[64] = {0}; long long period = 0, quota = -1;
+        if (path2 == nullptr) {                                   // "max 100000" | "1600000 100000"
+            if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0) quota = atoll(a);
+            fclose(f);
+        } else {
+            if (fscanf(f, "%lld", &quota) != 1) quota = -1;
+            fclose(f);
+            FILE *g = fopen(path2, "r");
+            if (g) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+        }
+        return (quota > 0 && period > 0) ? (double)quota / (double)period : 0.0;
+    };
+    double q = quota_of("/sys/fs/cgroup/cpu.max", nullptr);
+    if (q <= 0.0) q = quota_of("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (q > 0.0) n = std::min(n, std::max(1, (int)(q + 0.5)));
+    return n;
+}
+
 bool BamReader::set_threads(int n) {
     if (n < 1) n = 1;
     if (n == n_threads_ && pool_) return true;
     if (producer_started_) return false;           // fixed once decoding has begun (open() starts it): call before open()
     delete pool_; delete pool_inflate_;
     n_threads_ = n;
-    // 2n threads in two pools.  With libdeflate and the one-pass parser, inflating a group costs ~1.5x what framing +
-    // parsing + copying it costs (measured per thread), so the producer side gets 60 % of them
+    // n threads in two pools (n = 1: one thread each).  With libdeflate and the one-pass parser, inflating a group costs
+    // ~1.5x what framing + parsing + copying it costs (measured per thread), so the producer side gets 60 % of them
     // (RSQC_HOST_INFLATE_THREADS overrides: the parser keeps the rest, at least one).
-    int n_inflate = n == 1 ? 1 : (2 * n * 3 + 2) / 5;
+    int n_inflate = n <= 2 ? 1 : (n * 3 + 2) / 5;
     if (const char *e = getenv("RSQC_HOST_INFLATE_THREADS")) n_inflate = atoi(e);
-    n_inflate = std::max(1, std::min(n_inflate, 2 * n - 1));
-    pool_ = new WorkPool(std::max(1, 2 * n - n_inflate));
+    n_inflate = std::max(1, std::min(n_inflate, std::max(1, n - 1)));
+    pool_ = new WorkPool(std::max(1, n - n_inflate));
     pool_inflate_ = new WorkPool(n_inflate);
     return true;
 }
@@ -335,9 +364,11 @@ void BamReader::producer_main() {
 void BamReader::start_producer() {
     if (producer_started_) return;
     if (!pool_) {
-        // two pools, 2n threads (inflate ahead, frame + parse; split in set_threads): n = 16 measured best on a 2 x 64-core host (54 M reads/s;
-        // 64 each: 35 M reads/s -- the fork-join phases are short and wake-ups dominate)
-        int n = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        // two pools (inflate ahead, frame + parse; split in set_threads) with TWICE as many threads as CPUs the process
+        // may use: the pools take turns blocking on each other, so about half of the threads are runnable at a time.  The
+        // count follows the cgroup quota, not the hardware thread count -- measured on the 256-thread GPU box under its
+        // 16-CPU quota (tools/decode_sweep.py, 100 M records): 32 threads 79 M reads/s, 16: 64-72 M, 64: 54 M, 128: 31 M
+        int n = std::min(2 * effective_cpus(), 96);
         if (const char *e = getenv("RSQC_HOST_THREADS")) n = atoi(e);
         set_threads(n);
     }

@@ -90,6 +90,9 @@ struct HostBatch {                       // owns the arrays an rsqc_batch points
     rsqc_batch view();                   // closes the segment table
 };
 
+// CPUs the process may use: affinity mask capped by the cgroup CPU quota
+int effective_cpus();
+
 // fork-join helper: run(n, fn) calls fn(task) for task in [0, n) on the pool's threads and the caller
 class WorkPool {
 public:
@@ -120,7 +123,8 @@ public:
     // appends up to max_records records to `out`; returns the number appended (0 at EOF)
     size_t read_batch(HostBatch &out, size_t max_records);
     uint64_t records_read() const { return n_read_; }
-    // decode threads (BGZF inflate and record parsing); default: RSQC_HOST_THREADS or min(cores, 16), per pool.
+    // decode threads in total (BGZF inflate + record parsing, split 60 / 40); default: RSQC_HOST_THREADS or twice the CPUs
+    // the process may use (effective_cpus(): affinity capped by the cgroup quota).
     // Call BEFORE open(): open() starts the decode pipeline to read the header and the pools are fixed from then on
     // (returns false, and changes nothing, afterwards).
     bool set_threads(int n);

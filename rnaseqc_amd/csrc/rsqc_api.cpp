@@ -123,7 +123,8 @@ struct rsqc_ctx {
     std::vector<size_t> gcs_in_flight;
     std::vector<uint64_t> h_gc;                 // [RSQC_GC_BINS + 1]
     std::vector<double> h_exon_gc;              // by exon id
-    SortScratch gc_scratch;
+    SortScratch gc_scratch, frag_scratch;
+    uint32_t frag_kept = 0;                     // samples run_fragment_sizes left in frag_scratch (k1 / v1)
     // K3 outputs
     bool finalized = false;
 
@@ -279,7 +280,7 @@ int zero_accumulators(rsqc_ctx *c) {
     c->next_record_base = 0;
     c->batch_file_index.clear(); c->batch_records.clear();
     c->h_rl_offset.clear(); c->h_rl_span.clear(); c->h_rl_state.clear();
-    c->h_sample_file.clear(); c->h_sample_size.clear();
+    c->h_sample_file.clear(); c->h_sample_size.clear(); c->frag_kept = 0;
     c->sticky = 0;
     return 0;
 }
@@ -556,7 +557,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
     c->d_arena_count.release(); c->d_rl_summary.release();
-    free_sort_scratch(c->gc_scratch);
+    free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
@@ -966,7 +967,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             FragCandidates fc{(uint64_t *)c->frag_arena.col[0].p, (uint64_t *)c->frag_arena.col[1].p, (int32_t *)c->frag_arena.col[2].p,
                               (int32_t *)c->frag_arena.col[3].p, (uint32_t *)c->frag_arena.col[4].p, nullptr, (uint32_t)total};
             rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
-                                    c->frag_remaining, &c->h_sample_file, &c->h_sample_size);
+                                    c->frag_remaining, c->frag_scratch, c->frag_kept);
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
         // ---- fragment GC content (--fasta runs): the same mate pairing, no cut-off --------------------------
@@ -1082,6 +1083,12 @@ int rsqc_shard_summary(rsqc_ctx *c, rsqc_shard_info *out) {
     out->n_batches = (uint32_t)c->batch_file_index.size();
     out->batch_file_index = c->batch_file_index.data(); out->batch_records = c->batch_records.data();
     out->rl_offset = c->h_rl_offset.data(); out->rl_span = c->h_rl_span.data(); out->rl_state = c->h_rl_state.data();
+    if (c->frag_kept && c->h_sample_file.size() != c->frag_kept) {      // fetched on demand: only sharded runs look at the samples
+        HIP_TRY(c, hipSetDevice(c->device));
+        c->h_sample_file.resize(c->frag_kept); c->h_sample_size.resize(c->frag_kept);
+        HIP_TRY(c, hipMemcpy(c->h_sample_file.data(), c->frag_scratch.k1, (size_t)c->frag_kept * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_sample_size.data(), c->frag_scratch.v1, (size_t)c->frag_kept * 4, hipMemcpyDeviceToHost));
+    }
     out->n_samples = (uint32_t)c->h_sample_file.size();
     out->sample_file_index = c->h_sample_file.data(); out->sample_size = c->h_sample_size.data();
     return RSQC_OK;

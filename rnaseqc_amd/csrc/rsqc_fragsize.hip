@@ -68,65 +68,78 @@ static hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *k
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 64, s);
 }
 
-// Runs K5 over `n` candidates (device arrays in `c`).  Returns 0 or an RSQC_ERR_* code; fills the
-// histogram (ascending size) and the number of samples left.
+static int grow_scratch(SortScratch &S, uint32_t n) {
+    if (n <= S.cap_n) return 0;
+    for (void **q : {&S.k0, &S.k1, &S.v0, &S.v1, &S.v2}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    S.cap_n = 0;
+    const size_t cap = (size_t)n + n / 4 + 1024;
+    if (hipMalloc(&S.k0, cap * 8) != hipSuccess || hipMalloc(&S.k1, cap * 8) != hipSuccess || hipMalloc(&S.v0, cap * 4) != hipSuccess ||
+        hipMalloc(&S.v1, cap * 4) != hipSuccess || hipMalloc(&S.v2, cap * 4) != hipSuccess) return RSQC_ERR_HIP;
+    S.cap_n = cap;
+    return 0;
+}
+static int grow_tmp(SortScratch &S, size_t tmp_bytes) {
+    if (tmp_bytes + 256 <= S.tmp_bytes) return 0;
+    if (S.tmp) (void)hipFree(S.tmp);
+    S.tmp = nullptr; S.tmp_bytes = tmp_bytes + tmp_bytes / 4 + 4096;
+    return hipMalloc(&S.tmp, S.tmp_bytes) == hipSuccess ? 0 : RSQC_ERR_HIP;
+}
+
+// Runs K5 over `n` candidates (device arrays in `c`): fills the histogram (ascending size) and the number of samples
+// left, and leaves the kept samples (the first max_samples by file index, in no particular order) on the device in
+// S.k1 (file index) / S.v1 (size), `n_kept` of them, for rsqc_shard_summary.  Everything but the final run-length pass over
+// the sorted sizes happens on the device; the scratch arrays are kept by the context between passes.
 int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
-                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining,
-                       std::vector<uint64_t> *keep_file, std::vector<uint32_t> *keep_size) {
-    sizes.clear(); counts.clear(); remaining = max_samples;
-    if (keep_file) keep_file->clear();
-    if (keep_size) keep_size->clear();
+                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining, SortScratch &S, uint32_t &n_kept) {
+    sizes.clear(); counts.clear(); remaining = max_samples; n_kept = 0;
     if (n == 0) return 0;
-    uint64_t *k0 = nullptr, *k1 = nullptr, *sf = nullptr, *sf2 = nullptr;
-    uint32_t *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *ss = nullptr, *d_ns = nullptr, *sidx = nullptr, *sidx2 = nullptr;
-    void *tmp = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        for (void *p : {(void *)k0, (void *)k1, (void *)sf, (void *)sf2, (void *)v0, (void *)v1, (void *)v2, (void *)ss,
-                        (void *)d_ns, (void *)sidx, (void *)sidx2, tmp}) if (p) (void)hipFree(p);
-    };
-#define FS_TRY(e) do { if ((e) != hipSuccess) { cleanup(); return RSQC_ERR_HIP; } } while (0)
-    FS_TRY(hipMalloc(&k0, (size_t)n * 8)); FS_TRY(hipMalloc(&k1, (size_t)n * 8));
-    FS_TRY(hipMalloc(&v0, (size_t)n * 4)); FS_TRY(hipMalloc(&v1, (size_t)n * 4)); FS_TRY(hipMalloc(&v2, (size_t)n * 4));
-    FS_TRY(hipMalloc(&sf, (size_t)n * 8)); FS_TRY(hipMalloc(&ss, (size_t)n * 4)); FS_TRY(hipMalloc(&d_ns, 4));
+#define FS_TRY(e) do { if ((e) != hipSuccess) return RSQC_ERR_HIP; } while (0)
+    if (grow_scratch(S, n)) return RSQC_ERR_HIP;
+    if (!S.count) FS_TRY(hipMalloc(&S.count, 16));
+    uint64_t *k0 = (uint64_t *)S.k0, *k1 = (uint64_t *)S.k1;
+    uint32_t *v0 = (uint32_t *)S.v0, *v1 = (uint32_t *)S.v1, *v2 = (uint32_t *)S.v2, *d_ns = (uint32_t *)S.count;
     size_t tmp_bytes = 0;
     FS_TRY(sort_pairs_u64(nullptr, tmp_bytes, c.file_index, k0, v0, v1, n, stream));
-    FS_TRY(hipMalloc(&tmp, tmp_bytes + 256));
+    if (grow_tmp(S, tmp_bytes)) return RSQC_ERR_HIP;
     const int T = 256, B = (int)((n + T - 1) / T);
     hipLaunchKernelGGL(frag_iota_kernel, dim3(B), dim3(T), 0, stream, v0, n);
     // (1) file order
-    FS_TRY(sort_pairs_u64(tmp, tmp_bytes, c.file_index, k0, v0, v1, n, stream));
+    FS_TRY(sort_pairs_u64(S.tmp, tmp_bytes, c.file_index, k0, v0, v1, n, stream));
     // (2) stable sort by QNAME hash: groups, file order inside
     hipLaunchKernelGGL(frag_gather_u64_kernel, dim3(B), dim3(T), 0, stream, c.qhash, v1, k0, n);
-    FS_TRY(sort_pairs_u64(tmp, tmp_bytes, k0, k1, v1, v2, n, stream));
-    // (3) replay every group
+    FS_TRY(sort_pairs_u64(S.tmp, tmp_bytes, k0, k1, v1, v2, n, stream));
+    // (3) replay every group: samples (file index of the completing record, |isize|) -> k0 / v0 (free again by now)
     FS_TRY(hipMemsetAsync(d_ns, 0, 4, stream));
-    hipLaunchKernelGGL(frag_groups_kernel, dim3(B), dim3(T), 0, stream, k1, v2, c, n, sf, ss, d_ns);
+    hipLaunchKernelGGL(frag_groups_kernel, dim3(B), dim3(T), 0, stream, k1, v2, c, n, k0, v0, d_ns);
     uint32_t ns = 0;
     FS_TRY(hipMemcpyAsync(&ns, d_ns, 4, hipMemcpyDeviceToHost, stream));
     FS_TRY(hipStreamSynchronize(stream));
-    if (ns) {
-        // (4) the first max_samples samples in file order
-        std::vector<uint64_t> h_file(ns); std::vector<uint32_t> h_size(ns);
-        FS_TRY(hipMemcpy(h_file.data(), sf, (size_t)ns * 8, hipMemcpyDeviceToHost));
-        FS_TRY(hipMemcpy(h_size.data(), ss, (size_t)ns * 4, hipMemcpyDeviceToHost));
-        std::vector<uint32_t> ord(ns);
-        for (uint32_t i = 0; i < ns; ++i) ord[i] = i;
-        const uint32_t keep = std::min(ns, max_samples);
-        if (keep < ns) std::nth_element(ord.begin(), ord.begin() + keep, ord.end(), [&](uint32_t x, uint32_t y) { return h_file[x] < h_file[y]; });
-        std::map<int64_t, uint64_t> hist;                 // map<long long, unsigned long>, src/RNASeQC.cpp:171
-        for (uint32_t i = 0; i < keep; ++i) hist[(int64_t)h_size[ord[i]]]++;
-        for (auto &kv : hist) { sizes.push_back(kv.first); counts.push_back(kv.second); }
-        remaining = max_samples - keep;
-        if (keep_file && keep_size) {                     // the kept samples in file order: what a sharded run merges
-            std::sort(ord.begin(), ord.begin() + keep, [&](uint32_t x, uint32_t y) { return h_file[x] < h_file[y]; });
-            keep_file->reserve(keep); keep_size->reserve(keep);
-            for (uint32_t i = 0; i < keep; ++i) { keep_file->push_back(h_file[ord[i]]); keep_size->push_back(h_size[ord[i]]); }
-        }
+    if (!ns) return 0;
+    // (4) the first max_samples samples in file order: only when there are more than that
+    const uint32_t keep = std::min(ns, max_samples);
+    if (keep < ns) FS_TRY(sort_pairs_u64(S.tmp, tmp_bytes, k0, k1, v0, v1, ns, stream));
+    else { FS_TRY(hipMemcpyAsync(k1, k0, (size_t)ns * 8, hipMemcpyDeviceToDevice, stream)); FS_TRY(hipMemcpyAsync(v1, v0, (size_t)ns * 4, hipMemcpyDeviceToDevice, stream)); }
+    n_kept = keep; remaining = max_samples - keep;
+    // (5) histogram: the kept sizes sorted on the device, run lengths on the host (map<long long, unsigned long>, src/RNASeQC.cpp:171)
+    size_t tb2 = 0;
+    FS_TRY(rocprim::radix_sort_keys(nullptr, tb2, v1, v2, keep, 0, 32, stream));
+    if (grow_tmp(S, tb2)) return RSQC_ERR_HIP;
+    FS_TRY(rocprim::radix_sort_keys(S.tmp, tb2, v1, v2, keep, 0, 32, stream));
+    if (keep > S.h_cap) {
+        if (S.h_sizes) (void)hipHostFree(S.h_sizes);
+        S.h_cap = keep + keep / 4 + 1024;
+        FS_TRY(hipHostMalloc((void **)&S.h_sizes, (size_t)S.h_cap * 4, hipHostMallocDefault));
     }
-    cleanup();
+    FS_TRY(hipMemcpyAsync(S.h_sizes, v2, (size_t)keep * 4, hipMemcpyDeviceToHost, stream));
+    FS_TRY(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < keep;) {
+        uint32_t j = i + 1;
+        while (j < keep && S.h_sizes[j] == S.h_sizes[i]) ++j;
+        sizes.push_back((int64_t)S.h_sizes[i]); counts.push_back((uint64_t)(j - i));
+        i = j;
+    }
 #undef FS_TRY
-    return rc;
+    return 0;
 }
 
 
@@ -170,32 +183,20 @@ gc_groups_kernel(const uint64_t *sorted_q, const uint32_t *order, const GcCandid
 }
 
 void free_sort_scratch(SortScratch &s) {
-    for (void *p : {s.k0, s.k1, s.v0, s.v1, s.v2, s.tmp}) if (p) (void)hipFree(p);
+    for (void *p : {s.k0, s.k1, s.v0, s.v1, s.v2, s.tmp, s.count}) if (p) (void)hipFree(p);
+    if (s.h_sizes) (void)hipHostFree(s.h_sizes);
     s = SortScratch{};
 }
 
 int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins, SortScratch &S) {
     if (n == 0) return 0;
 #define GC_TRY(e) do { if ((e) != hipSuccess) return RSQC_ERR_HIP; } while (0)
-    if (n > S.cap_n) {
-        void *tmp_keep = S.tmp; size_t tmp_bytes_keep = S.tmp_bytes;
-        S.tmp = nullptr;
-        free_sort_scratch(S);
-        S.tmp = tmp_keep; S.tmp_bytes = tmp_bytes_keep;
-        const size_t cap = (size_t)n + n / 4 + 1024;
-        GC_TRY(hipMalloc(&S.k0, cap * 8)); GC_TRY(hipMalloc(&S.k1, cap * 8));
-        GC_TRY(hipMalloc(&S.v0, cap * 4)); GC_TRY(hipMalloc(&S.v1, cap * 4)); GC_TRY(hipMalloc(&S.v2, cap * 4));
-        S.cap_n = cap;
-    }
+    if (grow_scratch(S, n)) return RSQC_ERR_HIP;
     uint64_t *k0 = (uint64_t *)S.k0, *k1 = (uint64_t *)S.k1;
     uint32_t *v0 = (uint32_t *)S.v0, *v1 = (uint32_t *)S.v1, *v2 = (uint32_t *)S.v2;
     size_t tmp_bytes = 0;
     GC_TRY(sort_pairs_u64(nullptr, tmp_bytes, c.file_index, k0, v0, v1, n, stream));
-    if (tmp_bytes + 256 > S.tmp_bytes) {
-        if (S.tmp) (void)hipFree(S.tmp);
-        S.tmp = nullptr; S.tmp_bytes = tmp_bytes + tmp_bytes / 4 + 4096;
-        GC_TRY(hipMalloc(&S.tmp, S.tmp_bytes));
-    }
+    if (grow_tmp(S, tmp_bytes)) return RSQC_ERR_HIP;
     const int T = 256, B = (int)((n + T - 1) / T);
     hipLaunchKernelGGL(frag_iota_kernel, dim3(B), dim3(T), 0, stream, v0, n);
     GC_TRY(sort_pairs_u64(S.tmp, tmp_bytes, c.file_index, k0, v0, v1, n, stream));               // file order

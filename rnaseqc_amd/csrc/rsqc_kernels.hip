@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdlib>
 
 // Profiling build (make prof -> lib/librnaseqc_amd_prof.so, loaded with RSQC_LIB): K1 reads the shader clock at section
 // marks and accumulates, per section, the cycles its waves spent since their previous mark (stalls included).
@@ -510,6 +511,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 RSQC_DEFINE_K1(classify_count_kernel_w3, 3, 2)
 RSQC_DEFINE_K1(classify_count_kernel_w3r1, 3, 1)
 RSQC_DEFINE_K1(classify_count_kernel_w4r1, 4, 1)
+RSQC_DEFINE_K1(classify_count_kernel_w5r1, 5, 1)
 __global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
 classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     __shared__ K1Shared S;
@@ -1477,10 +1479,13 @@ void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, siz
 }
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
+    // (diagnostic) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
+    static const unsigned pad = getenv("RSQC_K1_LDS_PAD") ? (unsigned)atoi(getenv("RSQC_K1_LDS_PAD")) : 0u;
     if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 31) hipLaunchKernelGGL(classify_count_kernel_w3r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
+    else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
+    else if (variant == 31) hipLaunchKernelGGL(classify_count_kernel_w3r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
+    else if (variant == 51) hipLaunchKernelGGL(classify_count_kernel_w5r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
+    else hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {

@@ -39,7 +39,7 @@ class ShardInfo:
     rl_offset: np.ndarray              # [B + 1] into rl_span / rl_state
     rl_span: np.ndarray                # Read-Length transfer function of the batch: ascending span keys ...
     rl_state: np.ndarray               # ... and the state the batch leaves when entered with a state below the key
-    sample_file_index: np.ndarray      # fragment-size samples kept by the shard, ascending file index
+    sample_file_index: np.ndarray      # fragment-size samples kept by the shard (its first N by file index, any order)
     sample_size: np.ndarray
 
 

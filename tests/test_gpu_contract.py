@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from rnaseqc_amd import abi, engine, synth
+from rnaseqc_amd import abi, engine, hostinfo, synth
 from tests.compare import assert_results_match
 
 pytestmark = pytest.mark.gpu
@@ -18,7 +18,7 @@ PAIRS = int(os.environ.get("RSQC_TEST_CONTRACT_PAIRS", "50000000"))
 @pytest.fixture(scope="module")
 def contract_inputs():
     ann = synth.make_annotation(seed=1, contigs=synth.human_contigs())
-    batch, per_contig = synth.make_reads_sharded(ann, PAIRS, seed=2, workers=min(os.cpu_count() or 1, 24))
+    batch, per_contig = synth.make_reads_sharded(ann, PAIRS, seed=2, workers=min(hostinfo.effective_cpus(), 24))
     return ann, batch, per_contig
 
 
