@@ -78,7 +78,7 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
-    int k1_variant = 41, k1_grid = 256 * 8;   // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
+    int k1_variant = 41, k1_grid = 256 * 16;  // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
 
     // annotation (host copies needed at finalize)
     bool have_ann = false;
@@ -881,12 +881,15 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             const uint64_t parts_bound = pair_bound / 1024 + Gz + 1;
             const uint64_t keys_bound = 2 * pair_bound + 2048 * std::min<uint64_t>(parts_bound, pair_bound / 1024 + 1) + 16;
             if (parts_bound > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment partitions");
-            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 12 + 64, false))) return rc;                      // gene_base | part_first
+            const uint64_t lay_blocks = (Gz + 1023) / 1024;
+            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 12 + 64 + lay_blocks * 12 + 64, false))) return rc;  // gene_base | part_first | layout totals
             if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 8 + 64, false))) return rc;                    // cursor | part_gene
             if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
             FragPlan P;
             P.gene_base = (uint64_t *)c->d_tab_off.p;
             P.part_first = (uint32_t *)((uint64_t *)c->d_tab_off.p + Gz + 1);
+            P.blk_space = (unsigned long long *)(((uintptr_t)(P.part_first + Gz + 2) + 15) & ~(uintptr_t)15);
+            P.blk_parts = (uint32_t *)(P.blk_space + lay_blocks);
             P.cursor = (uint32_t *)c->d_tab_cap.p; P.part_gene = P.cursor + parts_bound;
             P.list = (unsigned long long *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);

@@ -140,6 +140,7 @@ struct FragPlan {
     uint32_t *cursor;              // [parts] keys appended so far
     uint32_t *part_gene;           // [parts] owning gene
     unsigned long long *list;      // key lists
+    unsigned long long *blk_space; uint32_t *blk_parts;   // [ceil(G / 1024)] per-workgroup totals of the layout scan
 };
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error);
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks);

@@ -196,7 +196,8 @@ __device__ __forceinline__ uint32_t find_segment(const DevBatch &b, uint64_t i) 
 // probes a few neighbours and otherwise falls through to memory.
 constexpr int K1_ESLOTS = 512, K1_GSLOTS = 256;
 struct K1Shared {
-    unsigned long long cnt[RSQC_N_COUNTERS];
+    unsigned long long cnt[RSQC_N_COUNTERS];     // sum-type counters
+    uint32_t cnt32[64];                          // one-per-record counters of the workgroup (a workgroup sees < 2^32 records)
     double eval[K1_ESLOTS];
     uint32_t ekey[K1_ESLOTS];
     uint32_t gkey[K1_GSLOTS], gcnt[K1_GSLOTS], gnd[K1_GSLOTS];
@@ -233,6 +234,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) S.cnt[c] = 0ull;
+    if (threadIdx.x < 64) S.cnt32[threadIdx.x] = 0u;
     for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x) { S.ekey[c] = 0xFFFFFFFFu; S.eval[c] = 0.0; }
     for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x) { S.gkey[c] = 0xFFFFFFFFu; S.gcnt[c] = 0u; S.gnd[c] = 0u; }
     if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; S.pairs = 0u; }
@@ -243,32 +245,14 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #endif
     __syncthreads();
 
-    // Scalar counters are kept "vertically": plane j holds bit j of this lane's running count of
-    // every counter, so adding the record's 49 one-bit increments is a 5-step ripple carry on
-    // 64-bit words (~30 VALU ops) instead of 49 ballots.  Decoded every 31 iterations.
-    uint64_t pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl4 = 0;
+    // One-per-record counters: a WaveSink (rsqc_read.h) -- per tile, lane c of one register receives the number of records
+    // that increment counter c (scalar popcounts of the condition masks), and ONE LDS instruction adds the register to
+    // the workgroup's table.  The seven sum-type counters stay per-lane sums, reduced every 31 tiles.
     uint32_t sum_e1mm = 0, sum_e1b = 0, sum_e2mm = 0, sum_e2b = 0, sum_mm = 0, sum_b = 0, sum_blk = 0;
     int pending = 0;
     uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
     bool big_any = false;
-    auto vertical_add = [&](uint64_t bits) {
-        uint64_t carry = bits, t;
-        t = pl0 & carry; pl0 ^= carry; carry = t;
-        t = pl1 & carry; pl1 ^= carry; carry = t;
-        t = pl2 & carry; pl2 ^= carry; carry = t;
-        t = pl3 & carry; pl3 ^= carry; carry = t;
-        pl4 ^= carry;
-    };
     auto flush_counts = [&]() {
-#pragma unroll 1
-        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {      // rare (once per 31 tiles): keep it rolled, it must not set the register budget
-            const uint32_t v = (uint32_t)((pl0 >> c) & 1ull) | ((uint32_t)((pl1 >> c) & 1ull) << 1) |
-                               ((uint32_t)((pl2 >> c) & 1ull) << 2) | ((uint32_t)((pl3 >> c) & 1ull) << 3) |
-                               ((uint32_t)((pl4 >> c) & 1ull) << 4);
-            const uint32_t tot = wave_sum(v);
-            if (l == 0 && tot) atomicAdd(&S.cnt[c], (unsigned long long)tot);
-        }
-        pl0 = pl1 = pl2 = pl3 = pl4 = 0;
         const uint32_t s0 = wave_sum(sum_e1mm), s1 = wave_sum(sum_e1b), s2 = wave_sum(sum_e2mm), s3 = wave_sum(sum_e2b),
                        s4 = wave_sum(sum_mm), s5 = wave_sum(sum_b), s6 = wave_sum(sum_blk);
         if (l == 0 && s0) atomicAdd(&S.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
@@ -328,62 +312,59 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         }
         const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
         FastOut fo;
-        fo.bits = 0; fo.n_hit = 0; fo.cmask = 0;
+        fo.n_hit = 0; fo.cmask = 0;
         uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
+        WaveSink cnt;
         // Everything that depends only on the gate cascade (scalar counters, Read-Length inputs, the
         // fragment-size candidate) is retired BEFORE the feature stage, so that the record and its counters
         // are dead while the index loads of the feature stage are in flight (register pressure).
+        // The cascade and the feature stage run CONVERGED (lanes without a record are predicated off by `lane_on`): the
+        // counter sink works on whole-wave ballots.
         bool go = false, hq = false; Blocks B; uint32_t fl = 0; int32_t tid = u_tid;
         {
             RecordCounters rc;
-            rc.bits = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0;
-            rc.rl_eligible = 0; rc.rl_span = 0; rc.rl_lqseq = 0; rc.error = 0; rc.frag_candidate = 0; rc.endpos = 0;
-            B.nb = 0;
-            if (valid) {
-                Record r;
-                const int4 cv = cur_cv, av = cur_av;
-                r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
-                r.cigar = b.cigar + (uint32_t)cv.w;
-                r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
-                r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
-                r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
-                r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
-                bool ok = true;
-                if (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE) {
-                    uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
-                    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
-                    if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
-                    else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
-                }
-                r.tid = u_tid;
-                if (mixed) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
-                if (!ok) atomicExch(acc.error, RSQC_ERR_ARG);
-                else {
-                    CigarWalk cw;
-                    walk_cigar(r, cur_cg, cw, B);
-                    aligned = cw.aligned;
-                    go = gate_cascade<LEGACY>(a, p, r, cw, rc, hq) && !(p.dbg & 8u);
-                    fl = r.flag; tid = r.tid;
-                    notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
-                    if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
-                        const int32_t name = bed_interval_of(a, r);
-                        if (name >= 0) {
-                            const uint32_t slot = atomicAdd(acc.frag.count, 1u);
-                            if (slot < acc.frag.cap) {
-                                acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
-                                acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
-                                const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
-                                const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
-                                acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
-                            } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                        }
-                    }
-                    if (rc.error) atomicExch(acc.error, rc.error);
+            Record r;
+            const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
+            r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
+            r.cigar = b.cigar + (uint32_t)cv.w;
+            r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+            r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
+            r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
+            r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
+            bool ok = true;
+            if (valid && (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE)) {
+                uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
+                while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
+                if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
+                else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
+            }
+            r.tid = u_tid;
+            if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
+            if (valid && !ok) atomicExch(acc.error, RSQC_ERR_ARG);
+            const bool lane_on = valid && ok;
+            if (!lane_on) r.n_cigar = 0;
+            CigarWalk cw;
+            walk_cigar(r, cur_cg, cw, B);
+            aligned = cw.aligned;
+            go = gate_cascade<LEGACY, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on) && !(p.dbg & 8u);
+            fl = r.flag; tid = r.tid;
+            notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
+            if (!lane_on) { B.nb = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
+            if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
+                const int32_t name = bed_interval_of(a, r);
+                if (name >= 0) {
+                    const uint32_t slot = atomicAdd(acc.frag.count, 1u);
+                    if (slot < acc.frag.cap) {
+                        acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
+                        acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
+                        const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
+                        const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
+                        acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
+                    } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                 }
             }
+            if (rc.error) atomicExch(acc.error, rc.error);
             RSQC_MARK(1);                          // [1] wait for the staged record words, unpack, CIGAR walk, gate cascade
-            // scalar counters of the gate cascade: vertical add of the record's one-bit increments
-            vertical_add(rc.bits);
             sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
             sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
             big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
@@ -399,15 +380,17 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         }
         RSQC_MARK(2);                              // [2] gate counters + Read-Length inputs
         // ---- feature stage ------------------------------------------------------------------------ [3] bins, [4..7] block rounds, [8] epilogue
-        if (!LEGACY && go) {
-            bool overflow = tid != u_tid;          // stragglers of a boundary tile: general code
-            if (!overflow) exon_metrics_fast<ROUND>(a, p, u_ci, fl, B, hq, aligned, fo, overflow);
-            if (overflow) {
-                fo.bits = 0; fo.n_hit = 0; fo.cmask = 0;
+        if (!LEGACY) {
+            const bool fast_on = go && tid == u_tid;           // stragglers of a boundary tile: general code
+            bool overflow = false;
+            exon_metrics_fast<ROUND, WaveSink>(a, p, u_ci, fl, B, hq, aligned, fo, overflow, cnt, fast_on);
+            if (go && overflow) {
+                fo.n_hit = 0; fo.cmask = 0;
                 const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
                 if (slot < acc.ovf_cap) acc.ovf_index[slot] = i;
                 else atomicExch(acc.error, RSQC_ERR_CAPACITY);
             }
+            if (!go) { fo.n_hit = 0; fo.cmask = 0; }
         }
         RSQC_MARK(9);                              // [9] class bits + overflow hand-over
         // ---- stage the next tile (see above) ------------------------------------------------
@@ -466,10 +449,9 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (has && !(p.dbg & 4096u)) S.gene_add(acc, g, notdup);
         }
         RSQC_MARK(12);                             // [12] gene hits: pairs + gene counters
-        // ---- feature-stage counter bits (disjoint from the gate's, so a second vertical add is exact) ----
-        vertical_add(fo.bits);
-        // 31 iterations fit the 5 planes (two adds of disjoint bit sets count once per counter); the u32
-        // sums cannot overflow before that unless a record carries an absurd value: flush right away then
+        // ---- the tile's one-per-record counters: lane c holds counter c's increment (one LDS instruction) ----
+        if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.cnt32[l], cnt.vec);
+        // the u32 sums cannot overflow within 31 tiles unless a record carries an absurd value: flush right away then
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
     }
     flush_counts();
@@ -479,8 +461,10 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         if (l == 0) { atomicMax(&S.rl[0], ws); atomicMin(&S.rl[1], wmn); atomicMax(&S.rl[2], wmx); }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x)
-        if (S.cnt[c]) atomicAdd(&acc.counters[c], S.cnt[c]);
+    for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) {
+        const unsigned long long v = S.cnt[c] + (unsigned long long)S.cnt32[c];
+        if (v) atomicAdd(&acc.counters[c], v);
+    }
     for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x)
         if (S.ekey[c] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[a.ex_id[S.ekey[c]]], S.eval[c]);      // accumulators are indexed by exon id
     for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x)
@@ -864,46 +848,57 @@ __device__ __forceinline__ uint32_t frag_parts_of(unsigned long long reads) {
 __device__ __forceinline__ uint32_t frag_cap_of(unsigned long long reads) {
     return frag_parts_of(reads) == 1 ? (uint32_t)reads : (uint32_t)RSQC_K4_SUB_CAP;
 }
+// Two launches of 1024-thread workgroups, 1024 genes each (coalesced loads): (1) per-workgroup totals, (2) every workgroup
+// adds the totals before it (a few dozen values) to its own scan.  (One workgroup walking all the genes serially took
+// 0.24 ms at 56 202 genes: 55 dependent loads per thread, twice.)
 __global__ void __launch_bounds__(1024)
-frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, uint32_t *part_first, uint64_t *gene_base, int *error) {
-    __shared__ unsigned long long s_space[1024];
-    __shared__ uint32_t s_parts[1024];
-    const uint32_t per = (n_genes + 1023) / 1024;
-    const uint32_t g0 = threadIdx.x * per, g1 = g0 + per < n_genes ? g0 + per : n_genes;
+frag_layout_totals_kernel(const unsigned long long *gene_reads, uint32_t n_genes, unsigned long long *blk_space, uint32_t *blk_parts, int *error) {
+    __shared__ unsigned long long w_space[16];
+    __shared__ uint32_t w_parts[16];
+    const uint32_t g = blockIdx.x * 1024u + threadIdx.x;
     unsigned long long space = 0; uint32_t parts = 0;
-    for (uint32_t g = g0; g < g1; ++g) {
+    if (g < n_genes) {
         const unsigned long long n = gene_reads[g];
         if (n > 0xFFFFFFF0ull) atomicExch(error, RSQC_ERR_CAPACITY);
-        const uint32_t p = frag_parts_of(n);
-        parts += p;
-        space += (unsigned long long)p * frag_cap_of(n);
+        parts = frag_parts_of(n); space = (unsigned long long)parts * frag_cap_of(n);
     }
-    // exclusive prefix over the 1024 threads: wave scans + one pass over the 16 wave totals
-    {
-        unsigned long long isp = space; uint32_t ipt = parts;
-        const int l = lane_id(), wv = (int)(threadIdx.x >> 6);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long ts = __shfl_up(isp, o, 64); const uint32_t tp = __shfl_up(ipt, o, 64);
-            if (l >= o) { isp += ts; ipt += tp; }
-        }
-        __shared__ unsigned long long w_space[16];
-        __shared__ uint32_t w_parts[16];
-        if (l == 63) { w_space[wv] = isp; w_parts[wv] = ipt; }
-        __syncthreads();
-        unsigned long long bs = 0; uint32_t bp = 0;
-        for (int w = 0; w < wv; ++w) { bs += w_space[w]; bp += w_parts[w]; }
-        s_space[threadIdx.x] = bs + isp - space; s_parts[threadIdx.x] = bp + ipt - parts;
-        if (threadIdx.x == 1023) part_first[n_genes] = bp + ipt;
-    }
+    space = wave_sum(space); parts = wave_sum(parts);
+    if (lane_id() == 0) { w_space[threadIdx.x >> 6] = space; w_parts[threadIdx.x >> 6] = parts; }
     __syncthreads();
-    unsigned long long off = s_space[threadIdx.x]; uint32_t pp = s_parts[threadIdx.x];
-    for (uint32_t g = g0; g < g1; ++g) {
-        const unsigned long long n = gene_reads[g];
-        const uint32_t p = frag_parts_of(n);
-        part_first[g] = pp; gene_base[g] = off;
-        pp += p; off += (unsigned long long)p * frag_cap_of(n);
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0; uint32_t p = 0;
+        for (int w = 0; w < 16; ++w) { s += w_space[w]; p += w_parts[w]; }
+        blk_space[blockIdx.x] = s; blk_parts[blockIdx.x] = p;
     }
+}
+__global__ void __launch_bounds__(1024)
+frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const unsigned long long *blk_space, const uint32_t *blk_parts,
+                   uint32_t *part_first, uint64_t *gene_base) {
+    __shared__ unsigned long long w_space[16];
+    __shared__ uint32_t w_parts[16];
+    __shared__ unsigned long long s_base; __shared__ uint32_t p_base;
+    const int l = lane_id(), wv = (int)(threadIdx.x >> 6);
+    if (wv == 0) {                                                     // offsets of this workgroup: totals of the ones before it
+        unsigned long long s = 0; uint32_t p = 0;
+        for (uint32_t k = (uint32_t)l; k < blockIdx.x; k += 64) { s += blk_space[k]; p += blk_parts[k]; }
+        s = wave_sum(s); p = wave_sum(p);
+        if (l == 0) { s_base = s; p_base = p; }
+    }
+    const uint32_t g = blockIdx.x * 1024u + threadIdx.x;
+    unsigned long long space = 0; uint32_t parts = 0;
+    if (g < n_genes) { const unsigned long long n = gene_reads[g]; parts = frag_parts_of(n); space = (unsigned long long)parts * frag_cap_of(n); }
+    unsigned long long isp = space; uint32_t ipt = parts;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long ts = __shfl_up(isp, o, 64); const uint32_t tp = __shfl_up(ipt, o, 64);
+        if (l >= o) { isp += ts; ipt += tp; }
+    }
+    if (l == 63) { w_space[wv] = isp; w_parts[wv] = ipt; }
+    __syncthreads();
+    unsigned long long bs = s_base; uint32_t bp = p_base;
+    for (int w = 0; w < wv; ++w) { bs += w_space[w]; bp += w_parts[w]; }
+    if (g < n_genes) { part_first[g] = bp + ipt - parts; gene_base[g] = bs + isp - space; }
+    if (g == n_genes - 1) part_first[n_genes] = bp + ipt;
 }
 // per partition: fill cursor = 0 and its owning gene (one binary search per partition, all in parallel, so that
 // the counting kernel starts from a single load)
@@ -1504,7 +1499,10 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
     hipLaunchKernelGGL(read_length_kernel, dim3(1), dim3(64), 0, s, a, p, b, acc, summary);
 }
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error) {
-    hipLaunchKernelGGL(frag_layout_kernel, dim3(1), dim3(1024), 0, s, gene_reads, n_genes, P.part_first, P.gene_base, error);
+    const uint32_t blocks = (n_genes + 1023u) / 1024u;
+    if (!blocks) return;
+    hipLaunchKernelGGL(frag_layout_totals_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, error);
+    hipLaunchKernelGGL(frag_layout_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, P.part_first, P.gene_base);
     hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_gene, P.part_first, n_genes);
 }
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)

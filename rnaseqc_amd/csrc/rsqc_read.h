@@ -135,6 +135,31 @@ struct RecordCounters {
 
 #define RSQC_BIT(c) (1ull << (c))
 
+// Where the one-per-record counter increments go.  BitSink keeps them as a 64-bit set for one record (general code, host
+// emulation).  The per-record kernel uses WaveSink instead: a condition is a lane mask already, so the count of a tile is
+// one scalar popcount of the ballot, dropped into lane `c` of ONE vector register (v_writelane) -- the scalar unit does
+// the counting and the vector pipe sees one instruction per counter instead of the select / or / carry chains a
+// per-lane bit set costs.
+struct BitSink {
+    uint64_t bits = 0;
+    template <int C> RSQC_HD void add(bool cond) { bits |= cond ? RSQC_BIT(C) : 0ull; }
+};
+#if defined(__HIPCC__)
+struct WaveSink {
+    uint32_t vec = 0;                          // lane c: records of this tile that increment counter c
+    template <int C> __device__ __forceinline__ void add(bool cond) {
+        static_assert(C >= 0 && C < 64, "one lane per counter");
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t n = (uint32_t)__popcll(__ballot(cond));          // s_bcnt1_i32_b64 of the condition mask
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(n), "n"(C));  // (no clang builtin for v_writelane in this toolchain)
+#else
+        (void)cond;
+#endif
+    }
+};
+#endif
+#define RSQC_COUNT(sink, c, cond) (sink).template add<(c)>(cond)
+
 constexpr int FAST_SET = 2;    // genes per block handled on the fast path (registers)
 constexpr int FAST_BLOCKS = 4; // aligned blocks per record on the fast path; more -> slow path
 constexpr int FAST_HITS = 2;   // exons fully containing one block on the fast path
@@ -259,29 +284,31 @@ RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &
 // reaches the feature stage; `hq` = highQuality (:330).
 // LEGACY: the LegacyMode tests of the loop body (src/RNASeQC.cpp:258,276,279,287) as a compile-time switch, so
 // that the default kernel carries none of them.
-template <bool LEGACY = false>
+template <bool LEGACY = false, class Sink = BitSink>
 RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
-                          RecordCounters &out, bool &hq) {
+                          RecordCounters &out, bool &hq, Sink &cnt, bool on = true) {
+    // `on` = the caller's lane holds a record at all (a whole wave runs the cascade converged; see WaveSink)
     // Straight-line form of the cascade: `alive` stays true while the reference's loop body has not hit a
     // `continue`; every counter is added under the conjunction of `alive` and its own condition.  (In a 64-lane
     // wave every early exit is taken by some lane, so branching only adds exec-mask bookkeeping.)
     const uint32_t fl = r.flag;
     const bool excl = p.exclude_chimeric != 0;
     const bool paired = (fl & RSQC_FPAIRED) != 0, read1 = (fl & RSQC_FREAD1) != 0, dup = (fl & RSQC_FDUP) != 0;
-    uint64_t bits = RSQC_BIT(RSQC_C_TOTAL_ALIGNMENTS);                                     // :245,397
-    if (fl & RSQC_FSECONDARY) bits |= RSQC_BIT(RSQC_C_ALTERNATIVE_ALIGNMENTS);             // :254
-    if (fl & RSQC_FSUPP) bits |= RSQC_BIT(RSQC_C_SUPPLEMENTARY_ALIGNMENTS);                // :255
-    else if (fl & RSQC_FQCFAIL) bits |= RSQC_BIT(RSQC_C_FAILED_VENDOR_QC);                 // :256
-    else if (r.mapq < p.mapq_threshold) bits |= RSQC_BIT(RSQC_C_LOW_MAPPING_QUALITY);      // :257
+    const bool sec = (fl & RSQC_FSECONDARY) != 0, supp = (fl & RSQC_FSUPP) != 0, qcf = (fl & RSQC_FQCFAIL) != 0;
+    RSQC_COUNT(cnt, RSQC_C_TOTAL_ALIGNMENTS, on);                                                  // :245,397
+    RSQC_COUNT(cnt, RSQC_C_ALTERNATIVE_ALIGNMENTS, on && sec);                                     // :254
+    RSQC_COUNT(cnt, RSQC_C_SUPPLEMENTARY_ALIGNMENTS, on && supp);                                  // :255
+    RSQC_COUNT(cnt, RSQC_C_FAILED_VENDOR_QC, on && !supp && qcf);                                  // :256
+    RSQC_COUNT(cnt, RSQC_C_LOW_MAPPING_QUALITY, on && !supp && !qcf && r.mapq < p.mapq_threshold); // :257
     const bool has_ch = (r.tagbits & RSQC_TB_HAS_CH) != 0;
-    const bool supp_auto = !LEGACY && (fl & RSQC_FSUPP) && !has_ch;                        // :258-262
-    if (supp_auto) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
-    bool alive = !(supp_auto && excl);
-    alive = alive && !(fl & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP));               // :263
-    if (alive) bits |= RSQC_BIT(RSQC_C_UNIQUE_VENDOR_PASSED);
-    if (alive && !paired) bits |= RSQC_BIT(RSQC_C_UNPAIRED_READS);
+    const bool supp_auto = on && !LEGACY && supp && !has_ch;                               // :258-262
+    bool alive = on && !(supp_auto && excl);
+    alive = alive && !(sec || qcf || supp);                                                // :263
+    RSQC_COUNT(cnt, RSQC_C_UNIQUE_VENDOR_PASSED, alive);
+    RSQC_COUNT(cnt, RSQC_C_UNPAIRED_READS, alive && !paired);
     alive = alive && !(fl & RSQC_FUNMAP);                                                  // :268
-    if (alive) bits |= RSQC_BIT(RSQC_C_MAPPED_READS) | (dup ? RSQC_BIT(RSQC_C_MAPPED_DUPLICATE_READS) : RSQC_BIT(RSQC_C_MAPPED_UNIQUE_READS));
+    RSQC_COUNT(cnt, RSQC_C_MAPPED_READS, alive);
+    RSQC_COUNT(cnt, RSQC_C_MAPPED_DUPLICATE_READS, alive && dup); RSQC_COUNT(cnt, RSQC_C_MAPPED_UNIQUE_READS, alive && !dup);
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
     const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || w.ref_len == 0) ? 1u : w.ref_len);
     if (LEGACY) alive = alive && !((uint32_t)(endpos - r.pos) > 100000u);                  // :276, LEGACY_MAX_READ_LENGTH
@@ -289,37 +316,48 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     out.rl_eligible = alive ? 1u : 0u;                                                     // :275-278
     out.rl_span = alive ? (uint32_t)(endpos - r.pos) : 0u; out.rl_lqseq = alive ? r.l_qseq : 0;
     const bool ch_here = !LEGACY && alive && has_ch;                                       // :279-283
-    if (ch_here && read1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_TAG);
+    RSQC_COUNT(cnt, RSQC_C_CHIMERIC_TAG, ch_here && read1);
     alive = alive && !(ch_here && excl);
     const bool mate_mapped = alive && paired && !(fl & RSQC_FMUNMAP);                      // :284-292
-    if (mate_mapped && read1) bits |= RSQC_BIT(RSQC_C_TOTAL_MAPPED_PAIRS);
+    RSQC_COUNT(cnt, RSQC_C_TOTAL_MAPPED_PAIRS, mate_mapped && read1);
     int32_t d = r.pos - r.mpos; if (d < 0) d = -d;
     const bool far = mate_mapped && (!(r.tagbits & RSQC_TB_MTID_SAME) || d > p.chimeric_distance || (LEGACY && r.tid > 127));
-    if (far && read1) bits |= RSQC_BIT(RSQC_C_CHIMERIC_AUTO);
+    RSQC_COUNT(cnt, RSQC_C_CHIMERIC_AUTO, supp_auto || (far && read1));                            // (:258 and :289 exclude each other: :263)
     alive = alive && !(far && excl);
     const bool has_nm = alive && (r.tagbits & RSQC_TB_HAS_NM) != 0;                        // :295-316
     const int32_t mismatches = (r.tagbits & RSQC_TB_HAS_NM) ? r.nm : 0;
     const bool nm1 = has_nm && paired && read1, nm2 = has_nm && paired && !read1;
-    if (nm1) bits |= RSQC_BIT(RSQC_C_END1_MAPPED_READS) | (dup ? RSQC_BIT(RSQC_C_DUPLICATE_PAIRS) : RSQC_BIT(RSQC_C_UNIQUE_FRAGMENTS));
-    if (nm2) bits |= RSQC_BIT(RSQC_C_END2_MAPPED_READS);
+    RSQC_COUNT(cnt, RSQC_C_END1_MAPPED_READS, nm1); RSQC_COUNT(cnt, RSQC_C_DUPLICATE_PAIRS, nm1 && dup); RSQC_COUNT(cnt, RSQC_C_UNIQUE_FRAGMENTS, nm1 && !dup);
+    RSQC_COUNT(cnt, RSQC_C_END2_MAPPED_READS, nm2);
     out.e1_mm = nm1 ? (uint32_t)mismatches : 0u; out.e1_bases = nm1 ? (uint32_t)r.l_qseq : 0u;
     out.e2_mm = nm2 ? (uint32_t)mismatches : 0u; out.e2_bases = nm2 ? (uint32_t)r.l_qseq : 0u;
     out.mm = has_nm ? (uint32_t)mismatches : 0u;
     out.bases = alive ? (uint32_t)r.l_qseq : 0u;                                           // :317
     bool discard = false;                                                                  // :319-328
-    for (int t = 0; t < p.n_filter_tags; ++t)
-        if (alive && (r.tagbits & (RSQC_TB_FILTER0 << t))) { discard = true; bits |= RSQC_BIT(RSQC_C_FILTERED_TAG0 + t); }
+#define RSQC_FILTER_TAG(t) { const bool hit = (t) < p.n_filter_tags && alive && (r.tagbits & (RSQC_TB_FILTER0 << (t))) != 0; \
+                             RSQC_COUNT(cnt, RSQC_C_FILTERED_TAG0 + (t), hit); discard = discard || hit; }
+    RSQC_FILTER_TAG(0) RSQC_FILTER_TAG(1) RSQC_FILTER_TAG(2) RSQC_FILTER_TAG(3) RSQC_FILTER_TAG(4)
+#undef RSQC_FILTER_TAG
+    static_assert(RSQC_MAX_FILTER_TAGS == 5, "one line per filter tag above");
     alive = alive && !discard;
     hq = alive && ((uint32_t)mismatches <= p.base_mismatch) && (p.unpaired || (fl & RSQC_FPROPER)) &&
          (r.mapq >= p.mapq_threshold);                                                     // :330
     alive = alive && !(r.tid < 0 || r.tid >= a.n_ref);                                     // :333-337
     hq = hq && alive;
-    if (alive) bits |= (hq ? RSQC_BIT(RSQC_C_HIGH_QUALITY_READS) : RSQC_BIT(RSQC_C_LOW_QUALITY_READS)) | RSQC_BIT(RSQC_C_READS_USED);
+    RSQC_COUNT(cnt, RSQC_C_HIGH_QUALITY_READS, hq); RSQC_COUNT(cnt, RSQC_C_LOW_QUALITY_READS, alive && !hq); RSQC_COUNT(cnt, RSQC_C_READS_USED, alive);
     out.error = (alive && w.bad) ? RSQC_ERR_BAD_CIGAR : 0;
     alive = alive && !w.bad;
     out.blocks = alive ? w.nblocks : 0u;                                                   // :360
     out.frag_candidate = (alive && hq && paired) ? 1u : 0u;                                // :372
-    out.bits = bits;
+    return alive;
+}
+// the same with the counters as a bit set in out.bits
+template <bool LEGACY = false>
+RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
+                          RecordCounters &out, bool &hq) {
+    BitSink sink;
+    const bool alive = gate_cascade<LEGACY, BitSink>(a, p, r, w, out, hq, sink);
+    out.bits = sink.bits;
     return alive;
 }
 // convenience form for callers that did not stage the CIGAR words themselves
@@ -404,27 +442,28 @@ template <int K> RSQC_HD void set_put(uint32_t (&s)[K], int idx, uint32_t v) {
     for (int k = 0; k < K; ++k) if (k == idx) s[k] = v;
 }
 
-// classification counters of exonAlignmentMetrics, src/Expression.cpp:407-457
-RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq) {
-    const bool intronic = !f.exonic && f.intragenic, intergenic = !f.exonic && !f.intragenic;
-    const bool exonic = f.exonic && do_exon, ambiguous = f.exonic && !do_exon;
-    uint64_t bits = 0;
-    bits |= intronic ? RSQC_BIT(RSQC_C_INTRONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
-    bits |= (intronic && hq) ? RSQC_BIT(RSQC_C_HQ_INTRONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS) : 0ull;
-    bits |= intergenic ? RSQC_BIT(RSQC_C_INTERGENIC_READS) : 0ull;
-    bits |= (intergenic && hq) ? RSQC_BIT(RSQC_C_HQ_INTERGENIC_READS) : 0ull;
-    bits |= exonic ? RSQC_BIT(RSQC_C_EXONIC_READS) | RSQC_BIT(RSQC_C_INTRAGENIC_READS) : 0ull;
-    bits |= (exonic && hq) ? RSQC_BIT(RSQC_C_HQ_EXONIC_READS) | RSQC_BIT(RSQC_C_HQ_INTRAGENIC_READS) : 0ull;
-    bits |= ambiguous ? RSQC_BIT(RSQC_C_AMBIGUOUS_READS) : 0ull;
-    bits |= (ambiguous && hq) ? RSQC_BIT(RSQC_C_HQ_AMBIGUOUS_READS) : 0ull;
-    bits |= f.ribosomal ? RSQC_BIT(RSQC_C_RRNA_READS) : 0ull;
-    const bool one_strand = (f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED));
+// classification counters of exonAlignmentMetrics, src/Expression.cpp:407-457; `keep` = the record is counted here
+// (a record handed to the general code is counted there)
+template <class Sink>
+RSQC_HD void class_counts(Sink &cnt, const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq, bool keep) {
+    const bool intronic = keep && !f.exonic && f.intragenic, intergenic = keep && !f.exonic && !f.intragenic;
+    const bool exonic = keep && f.exonic && do_exon, ambiguous = keep && f.exonic && !do_exon;
+    RSQC_COUNT(cnt, RSQC_C_INTRONIC_READS, intronic); RSQC_COUNT(cnt, RSQC_C_HQ_INTRONIC_READS, intronic && hq);
+    RSQC_COUNT(cnt, RSQC_C_INTRAGENIC_READS, intronic || exonic); RSQC_COUNT(cnt, RSQC_C_HQ_INTRAGENIC_READS, (intronic || exonic) && hq);
+    RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, intergenic); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, intergenic && hq);
+    RSQC_COUNT(cnt, RSQC_C_EXONIC_READS, exonic); RSQC_COUNT(cnt, RSQC_C_HQ_EXONIC_READS, exonic && hq);
+    RSQC_COUNT(cnt, RSQC_C_AMBIGUOUS_READS, ambiguous); RSQC_COUNT(cnt, RSQC_C_HQ_AMBIGUOUS_READS, ambiguous && hq);
+    RSQC_COUNT(cnt, RSQC_C_RRNA_READS, keep && f.ribosomal);
+    const bool one_strand = keep && (f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED));
     const bool sense = (fl & RSQC_FREVERSE) ? f.minus : f.plus;
     const bool end1 = p.unpaired || (fl & RSQC_FREAD1);
-    const uint64_t sbit = end1 ? (sense ? RSQC_BIT(RSQC_C_END1_SENSE) : RSQC_BIT(RSQC_C_END1_ANTISENSE))
-                               : (sense ? RSQC_BIT(RSQC_C_END2_SENSE) : RSQC_BIT(RSQC_C_END2_ANTISENSE));
-    bits |= one_strand ? sbit : 0ull;
-    return bits;
+    RSQC_COUNT(cnt, RSQC_C_END1_SENSE, one_strand && end1 && sense); RSQC_COUNT(cnt, RSQC_C_END1_ANTISENSE, one_strand && end1 && !sense);
+    RSQC_COUNT(cnt, RSQC_C_END2_SENSE, one_strand && !end1 && sense); RSQC_COUNT(cnt, RSQC_C_END2_ANTISENSE, one_strand && !end1 && !sense);
+}
+RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq) {
+    BitSink s;
+    class_counts(s, p, fl, f, do_exon, hq, true);
+    return s.bits;
 }
 
 // ---- the fast feature stage ------------------------------------------------------------------
@@ -470,7 +509,6 @@ RSQC_HD uint32_t exon_row_test(const ExonRow &row, bool reach, int32_t bs, int32
 // What the fast feature stage returns: slot s = 2b + j commits block b (length B.len[b]) to exon `row[s]` at
 // coverage index `cidx[s]` when bit s of cmask is set.
 struct FastOut {
-    uint64_t bits;
     int n_hit; uint32_t hit[FAST_SET];
     uint32_t cmask;
     uint32_t row[NSLOT], cidx[NSLOT];
@@ -478,10 +516,12 @@ struct FastOut {
 
 // `ci` is the ContigInfo of the record's contig (wave-uniform in the kernel).  ROUND = blocks whose row
 // loads are in flight together (registers vs. round trips).
-template <int ROUND = 2>
+// `cnt` takes the feature-stage counters of the records handled here (`lane_on` = this lane holds such a record; with a
+// WaveSink the function is called by the whole wave); a record that sets `overflow` is counted by the general code instead.
+template <int ROUND = 2, class Sink = BitSink>
 RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl,
-                               const Blocks &B, bool hq, uint32_t aligned, FastOut &out, bool &overflow) {
-    out.bits = 0; out.n_hit = 0; out.cmask = 0;
+                               const Blocks &B, bool hq, uint32_t aligned, FastOut &out, bool &overflow, Sink &cnt, bool lane_on = true) {
+    out.n_hit = 0; out.cmask = 0;
     const int rstrand = read_strand_of(p, fl);
     uint32_t cf = 0;                                          // CF_* class flags of the whole record
     uint32_t la = 0, lb = 0; bool va = false, vb = false, ga = false, gb = false;   // gene set common to all blocks so far
@@ -574,14 +614,13 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
         }
     }
     RSQC_MARK(8);
+    over = over || !lane_on;
     overflow = over;
     ga = ga && va; gb = gb && vb;
     const int nlast = (va ? 1 : 0) + (vb ? 1 : 0);
-    uint64_t bits = 0;
-    if (B.nb >= 1 && !(ga || gb)) {                                                        // :363,395-404
-        bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_READS);
-        if (fl & RSQC_FDUP) bits |= RSQC_BIT(RSQC_C_NON_GLOBIN_DUPLICATE_READS);
-    }
+    const bool nonglobin = !over && B.nb >= 1 && !(ga || gb);                              // :363,395-404
+    RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, nonglobin);
+    RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, nonglobin && (fl & RSQC_FDUP) != 0);
     if (hq && nlast > 0 && !(p.dbg & 4u)) {                                                // :377-392
         out.cmask = con & ((va ? ma : 0u) | (vb ? mb : 0u));
         if (aligned > 0 && !(p.dbg & 2u)) {
@@ -592,7 +631,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
     ClassFlags f;
     f.intragenic = (cf & CF_INTRAGENIC) != 0; f.plus = (cf & CF_PLUS) != 0; f.minus = (cf & CF_MINUS) != 0;
     f.ribosomal = (cf & CF_RIBOSOMAL) != 0; f.exonic = (cf & CF_EXONIC) != 0;
-    out.bits = bits | class_bits(p, fl, f, nlast > 0, hq);
+    class_counts(cnt, p, fl, f, nlast > 0, hq, !over);
 }
 
 // ---- stage 2: exonAlignmentMetrics, src/Expression.cpp:308-458 ---------------------------

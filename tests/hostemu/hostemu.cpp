@@ -99,9 +99,10 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
         } else if (go) {
             bool over = false;
             FastOut fo;
-            exon_metrics_fast(d, dp, d.contig[r.tid], r.flag, B, hq, aligned, fo, over);
+            BitSink fsink;
+            exon_metrics_fast<2, BitSink>(d, dp, d.contig[r.tid], r.flag, B, hq, aligned, fo, over, fsink);
             if (!over) {
-                bits |= fo.bits;
+                bits |= fsink.bits;
                 for (int k = 0; k < NSLOT; ++k) {
                     if (!((fo.cmask >> k) & 1u)) continue;
                     const uint32_t len = B.len[k >> 1];
