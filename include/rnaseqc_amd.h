@@ -441,6 +441,10 @@ typedef struct rsqc_shard_info {
     const uint32_t *sample_size;       /* [n_samples] abs(InsertSize)               */
 } rsqc_shard_info;
 RSQC_API int rsqc_shard_summary(rsqc_ctx *ctx, rsqc_shard_info *out);
+/* dst += src over those three ranges, for ONE process that drives several GPUs (the command line with --gpus): the
+ * peer's ranges cross xGMI by hipMemcpyPeerAsync and are added on dst's device.  Both contexts must hold the same
+ * annotation and be past rsqc_finalize_device.  A process-per-GPU host uses an RCCL all_reduce on the ranges instead.  */
+RSQC_API int rsqc_reduce_peer(rsqc_ctx *dst, rsqc_ctx *src);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
 /* Page-locked host memory for the arrays of an rsqc_batch: rsqc_submit then copies by DMA and returns without

@@ -26,6 +26,20 @@ void HostBatch::clear() {
     wide_index.clear(); wide_nm.clear(); wide_lq.clear(); wide_ncig.clear();
 }
 
+bool HostBatch::keep_leading_contig(int32_t tid) {
+    if (seg_tid.empty()) return false;
+    const size_t total = core.size();
+    size_t k = 0;                                                  // records of the leading segment(s) with this tid
+    if (seg_tid[0] == tid) k = seg_tid.size() > 1 ? (size_t)seg_start[1] : total;
+    if (k >= total) return false;
+    const size_t c_end = core[k].cigar_off;
+    core.resize(k); aux.resize(k); cigar.resize(c_end);
+    if (k == 0) { seg_tid.clear(); seg_start.clear(); }
+    else { seg_tid.resize(1); seg_start.resize(1); }
+    while (!wide_index.empty() && wide_index.back() >= k) { wide_index.pop_back(); wide_nm.pop_back(); wide_lq.pop_back(); wide_ncig.pop_back(); }
+    return true;
+}
+
 rsqc_batch HostBatch::view() {
     if (seg_start.size() == seg_tid.size()) seg_start.push_back(core.size());
     else seg_start.back() = core.size();

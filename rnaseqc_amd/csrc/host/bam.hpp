@@ -86,6 +86,9 @@ struct HostBatch {                       // owns the arrays an rsqc_batch points
     bool unsorted = false;
     std::vector<std::string> bad_refid;
     void clear();
+    // keep only the leading records of contig `tid` (by-contig reading: the block that ends a contig's range may also
+    // hold the first records of the next one); returns true when something was cut off
+    bool keep_leading_contig(int32_t tid);
     size_t size() const { return core.size(); }
     rsqc_batch view();                   // closes the segment table
 };

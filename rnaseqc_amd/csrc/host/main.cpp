@@ -15,6 +15,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bam.hpp"
@@ -42,6 +43,7 @@ struct Options {
     bool has_mapq = false;
     long bias_offset = 0, bias_window = 100; unsigned long bias_gene_length = 200, coverage_mask = 500, detection = 5;
     std::vector<std::string> tags;
+    int gpus = 0;                      // --gpus (extension): GPUs to shard the BAM over by contig; 0 = RSQC_GPUS or 1
 };
 
 void usage(std::ostream &o) {
@@ -71,7 +73,8 @@ void usage(std::ostream &o) {
          "      --rpkm                            Output gene RPKM values instead of TPMs\n"
          "      --coverage                        Write per-transcript coverage statistics to a table\n"
          "      --coverage-mask=[SIZE]            Bases masked at both transcript ends. Default: 500bp\n"
-         "      -d[threshold], --detection-threshold=[threshold]  Counts to call a gene detected. Default: 5 reads\n";
+         "      -d[threshold], --detection-threshold=[threshold]  Counts to call a gene detected. Default: 5 reads\n"
+         "      --gpus=[N]                        (extension) Shard the BAM by contig over N GPUs of this node; needs [bam].bai. Default: 1\n";
 }
 
 long to_long(const std::string &flag, const std::string &v) {
@@ -148,6 +151,7 @@ Options parse(int argc, char **argv) {
         else if (name == "unpaired") o.unpaired = true;
         else if (name == "rpkm") o.rpkm = true;
         else if (name == "coverage") o.coverage = true;
+        else if (name == "gpus") o.gpus = (int)to_ulong(name, need());
         else if (name == "coverage-mask") o.coverage_mask = to_ulong(name, need());
         else if (name == "detection-threshold") o.detection = to_ulong(name, need());
         else throw ParseError("Flag could not be matched: " + name);
@@ -176,6 +180,95 @@ std::string basename_of(const std::string &p) {
 }
 
 }  // namespace
+
+// ---- one process, several GPUs: the BAM sharded by contig ------------------------------------------
+// Every GPU holds the whole annotation and owns a set of contigs (longest-processing-time packing on the index's record
+// counts); a host thread per GPU reads ITS contigs through the BAM index (BamReader::seek) and feeds its context; at
+// end of file the contexts' result ranges are summed onto the first GPU (rsqc_reduce_peer: peer copies over xGMI), and the
+// two order-dependent outputs are composed on the host from the shards' summaries (rsqc_shard_summary).
+struct Shard {
+    rsqc_ctx *gpu = nullptr; int device = 0;
+    std::vector<int> contigs; bool tail = false;
+    uint64_t load = 0, n_records = 0;
+    int rc = RSQC_OK; std::string error; bool unsorted = false; std::vector<std::string> bad_refid;
+};
+
+constexpr int kFileIndexShift = 36;      // virtual file index of a batch: (contig << 36) + records of the contig before it
+
+void shard_worker(Shard &sh, const std::string &bam_path, const Options &o, int threads, const std::vector<BamReader::ContigRange> &index,
+                  int n_ref, uint64_t tail_voff, size_t BATCH) {
+    try {
+        HostBatch bufs[2];
+        for (auto &hb : bufs) { hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.cigar.use_pinned(true); hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.cigar.reserve(BATCH * 2); }
+        int cur = 0; bool in_flight = false;
+        std::vector<int> ranges = sh.contigs;
+        if (sh.tail) ranges.push_back(n_ref);                          // the unplaced records behind the last contig
+        for (int c : ranges) {
+            BamReader bam;
+            bam.set_threads(threads);
+            if (!bam.open(bam_path)) { sh.rc = RSQC_ERR_ARG; sh.error = "Unable to open BAM file: " + bam_path; return; }
+            bam.set_tags(o.chimeric_tag, o.tags);
+            const bool is_tail = c == n_ref;
+            if (!bam.seek(is_tail ? tail_voff : index[(size_t)c].beg, is_tail ? 0 : index[(size_t)c].end)) { sh.rc = RSQC_ERR_ARG; sh.error = "cannot seek in " + bam_path; return; }
+            uint64_t left = is_tail ? ~0ull : (index[(size_t)c].n_records ? index[(size_t)c].n_records : ~0ull), done = 0;
+            while (left) {
+                HostBatch &hb = bufs[cur];
+                hb.clear();
+                hb.file_index_base = ((uint64_t)c << kFileIndexShift) + done;
+                size_t n = bam.read_batch(hb, (size_t)std::min<uint64_t>(left, BATCH));
+                bool last = false;
+                if (n && !is_tail && hb.keep_leading_contig(c)) { n = hb.size(); last = true; }   // ran into the next contig
+                if (is_tail && n) {                                    // (the tail holds unplaced records only: tid -1)
+                    for (int32_t t : hb.seg_tid) if (t >= 0) { sh.rc = RSQC_ERR_ARG; sh.error = "placed records behind the last indexed contig: stale index?"; return; }
+                }
+                if (in_flight) { if ((sh.rc = rsqc_wait(sh.gpu)) != RSQC_OK) { sh.error = rsqc_last_error(sh.gpu); return; } in_flight = false; }
+                if (n == 0) break;
+                if (hb.unsorted) sh.unsorted = true;
+                for (auto &nm : hb.bad_refid) if (sh.bad_refid.size() < 64) sh.bad_refid.push_back(nm);
+                rsqc_batch view = hb.view();
+                if ((sh.rc = rsqc_submit(sh.gpu, &view)) != RSQC_OK) { sh.error = rsqc_last_error(sh.gpu); return; }
+                in_flight = true; cur ^= 1;
+                done += n; sh.n_records += n;
+                if (left != ~0ull) left -= std::min<uint64_t>(left, n);
+                if (last) break;
+            }
+            if (in_flight) { if ((sh.rc = rsqc_wait(sh.gpu)) != RSQC_OK) { sh.error = rsqc_last_error(sh.gpu); return; } in_flight = false; }
+        }
+        sh.rc = rsqc_finalize_device(sh.gpu);
+        if (sh.rc != RSQC_OK) sh.error = rsqc_last_error(sh.gpu);
+    } catch (std::exception &e) { sh.rc = RSQC_ERR_ARG; sh.error = e.what(); }
+}
+
+// merged outputs that do not come out of the reduction
+struct ShardMerge { int32_t read_length = 0; std::vector<int64_t> fsize; std::vector<uint64_t> fcount; uint32_t remaining = 0; };
+
+int merge_shards(std::vector<Shard> &shards, uint32_t fragment_samples, ShardMerge &m, std::string &err) {
+    struct Item { uint64_t file; const uint32_t *span; const int32_t *state; uint32_t n; };
+    std::vector<Item> items;
+    std::vector<std::pair<uint64_t, uint32_t>> samples;
+    for (auto &sh : shards) {
+        rsqc_shard_info si{};
+        const int rc = rsqc_shard_summary(sh.gpu, &si);
+        if (rc != RSQC_OK) { err = rsqc_last_error(sh.gpu); return rc; }
+        for (uint32_t b = 0; b < si.n_batches; ++b)
+            items.push_back(Item{si.batch_file_index[b], si.rl_span + si.rl_offset[b], si.rl_state + si.rl_offset[b], si.rl_offset[b + 1] - si.rl_offset[b]});
+        for (uint32_t k = 0; k < si.n_samples; ++k) samples.emplace_back(si.sample_file_index[k], si.sample_size[k]);
+    }
+    // Read Length (src/RNASeQC.cpp:275-278): the batches of all shards in file order, each applied as its transfer function
+    std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.file < b.file; });
+    uint32_t r = 0;
+    for (auto &it : items) for (uint32_t k = 0; k < it.n; ++k) if (it.span[k] > r) { r = (uint32_t)it.state[k]; break; }
+    m.read_length = (int32_t)r;
+    // fragment sizes (src/Expression.cpp:482-540): the --fragment-samples first samples of the union, in file order
+    const size_t keep = std::min<size_t>(samples.size(), fragment_samples);
+    if (keep < samples.size()) std::nth_element(samples.begin(), samples.begin() + (long)keep, samples.end());
+    std::vector<uint32_t> sz(keep);
+    for (size_t k = 0; k < keep; ++k) sz[k] = samples[k].second;
+    std::sort(sz.begin(), sz.end());
+    for (size_t i = 0; i < keep;) { size_t j = i + 1; while (j < keep && sz[j] == sz[i]) ++j; m.fsize.push_back((int64_t)sz[i]); m.fcount.push_back((uint64_t)(j - i)); i = j; }
+    m.remaining = fragment_samples - (uint32_t)keep;
+    return RSQC_OK;
+}
 
 int main(int argc, char **argv) {
     using std::cerr; using std::cout; using std::endl;
@@ -250,10 +343,59 @@ int main(int argc, char **argv) {
         if (!overlap) { cerr << "BAM file shares no contigs with GTF" << endl; return 11; }
         ann.flatten(bam.contigs());
 
+        // ---- GPUs: one by default; --gpus N (or RSQC_GPUS) shards the file by contig, which needs the BAM index
+        std::vector<int> devices;
+        {
+            int want = o.gpus > 0 ? o.gpus : (getenv("RSQC_GPUS") ? atoi(getenv("RSQC_GPUS")) : 1);
+            if (const char *e = getenv("RSQC_GPU_LIST")) { for (const char *q = e; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+            else for (int k = 0; k < std::max(1, want); ++k) devices.push_back(P.device + k);
+            if (devices.size() > 1 && !bam.load_index(bam_path + ".bai")) {
+                cerr << "Warning: sharding over " << devices.size() << " GPUs needs the BAM index " << bam_path << ".bai; running on one GPU" << endl;
+                devices.resize(1);
+            }
+        }
+        const int n_ref_bam = (int)bam.contigs().size();
+        std::vector<Shard> shards(devices.size());
+        uint64_t tail_voff = 0;
+        if (devices.size() > 1) {
+            // longest-processing-time packing of the contigs on the index's record counts (compressed bytes when an index
+            // carries no counts); the unplaced tail goes to the lightest shard
+            const auto &idx = bam.index();
+            std::vector<std::pair<uint64_t, int>> byload;
+            for (int c2 = 0; c2 < n_ref_bam && (size_t)c2 < idx.size(); ++c2) if (idx[(size_t)c2].present) {
+                const uint64_t load = idx[(size_t)c2].n_records ? idx[(size_t)c2].n_records : ((idx[(size_t)c2].end >> 16) - (idx[(size_t)c2].beg >> 16)) / 24 + 1;
+                byload.emplace_back(load, c2);
+                tail_voff = std::max(tail_voff, idx[(size_t)c2].end);
+            }
+            std::sort(byload.begin(), byload.end(), [](const std::pair<uint64_t, int> &x, const std::pair<uint64_t, int> &y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+            for (auto &bl : byload) {
+                size_t best = 0;
+                for (size_t g = 1; g < shards.size(); ++g) if (shards[g].load < shards[best].load) best = g;
+                shards[best].contigs.push_back(bl.second); shards[best].load += bl.first;
+            }
+            size_t lightest = 0;
+            for (size_t g = 1; g < shards.size(); ++g) if (shards[g].load < shards[lightest].load) lightest = g;
+            shards[lightest].tail = true;
+            for (auto &sh : shards) std::sort(sh.contigs.begin(), sh.contigs.end());
+        }
+
         int rc = gpu_ready.get();
         if (rc != RSQC_OK) { cerr << "Unable to initialise the GPU hot path: " << rsqc_strerror(rc) << endl; return 10; }
-        if ((rc = rsqc_set_annotation(gpu, &ann.ann, nullptr)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
-        if (o.has_bed && (rc = rsqc_set_bed(gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 11; }
+        std::vector<std::vector<uint8_t>> owned_masks(shards.size());
+        for (size_t g = 0; g < shards.size(); ++g) {
+            Shard &sh = shards[g];
+            sh.device = devices[g];
+            if (g == 0) sh.gpu = gpu;
+            else { rsqc_params Pg = P; Pg.device = sh.device; if ((rc = rsqc_create(&Pg, &sh.gpu)) != RSQC_OK) { cerr << "Unable to initialise GPU " << sh.device << ": " << rsqc_strerror(rc) << endl; return 10; } }
+            const uint8_t *owned = nullptr;
+            if (shards.size() > 1) {
+                owned_masks[g].assign(ann.contig_names.size(), 0);
+                for (int c2 : sh.contigs) owned_masks[g][(size_t)c2] = 1;
+                owned = owned_masks[g].data();
+            }
+            if ((rc = rsqc_set_annotation(sh.gpu, &ann.ann, owned)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(sh.gpu) << endl; return 11; }
+            if (o.has_bed && (rc = rsqc_set_bed(sh.gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(sh.gpu) << endl; return 11; }
+        }
         std::vector<char> in_fasta;
         if (o.has_fasta) {
             fasta_loaded.get();                                               // FileError -> 10
@@ -267,7 +409,8 @@ int main(int argc, char **argv) {
                 in_fasta[(size_t)cid] = 1;
             }
             rsqc_reference ref{(int32_t)r_contig.size(), r_contig.data(), r_len.data(), r_seq.data()};
-            if ((rc = rsqc_set_reference(gpu, &ref)) != RSQC_OK) { cerr << "Failed to load the reference: " << rsqc_last_error(gpu) << endl; rsqc_destroy(gpu); return 10; }
+            for (auto &sh : shards)
+                if ((rc = rsqc_set_reference(sh.gpu, &ref)) != RSQC_OK) { cerr << "Failed to load the reference: " << rsqc_last_error(sh.gpu) << endl; return 10; }
             std::vector<std::vector<uint8_t>>().swap(fasta_seq);              // the bases live on the device now
         }
 
@@ -281,7 +424,38 @@ int main(int argc, char **argv) {
         std::vector<int> visit;
         unsigned long long alignmentCount = 0;
         int cur = 0; bool in_flight = false, warned_unsorted = false;
+        ShardMerge merged;
         const auto tb0 = std::chrono::steady_clock::now();
+        if (shards.size() > 1) {
+            // one reader thread per GPU; the decode threads of the process are shared out between them
+            int budget = 2 * effective_cpus();
+            if (const char *e = getenv("RSQC_HOST_THREADS")) budget = atoi(e);
+            const int per = std::max(2, budget / (int)shards.size());
+            std::vector<std::thread> th;
+            for (auto &sh : shards) th.emplace_back(shard_worker, std::ref(sh), std::cref(bam_path), std::cref(o), per, std::cref(bam.index()), n_ref_bam, tail_voff, BATCH);
+            for (auto &t : th) t.join();
+            rc = RSQC_OK;
+            for (auto &sh : shards) {
+                alignmentCount += sh.n_records;
+                if (sh.rc != RSQC_OK && rc == RSQC_OK) { rc = sh.rc; if (rc != RSQC_ERR_BAD_CIGAR && rc != RSQC_ERR_EMPTY_MEDIAN) cerr << "GPU " << sh.device << ": " << sh.error << endl; }
+                if (o.verbosity) for (auto &nm : sh.bad_refid) cerr << "Unrecognized RefID on alignment: " << nm << endl;
+                if (sh.unsorted && !warned_unsorted) { cerr << "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results" << endl; warned_unsorted = true; }
+            }
+            for (int c2 = 0; c2 < n_ref_bam && (size_t)c2 < bam.index().size(); ++c2) if (bam.index()[(size_t)c2].present) {
+                visit.push_back(c2);
+                if (o.has_fasta && (size_t)c2 < in_fasta.size() && !in_fasta[(size_t)c2])
+                    cerr << "Warning: Provided Fasta does not contain chromosome " << ann.contig_names[(size_t)c2]
+                         << ". No GC statistics will be collected for this chromosome" << endl;
+            }
+            // the exchange step: result ranges summed onto the first GPU, order-dependent outputs composed from the summaries
+            for (size_t g = 1; g < shards.size() && rc == RSQC_OK; ++g) rc = rsqc_reduce_peer(shards[0].gpu, shards[g].gpu);
+            if (rc == RSQC_OK) { std::string merr; rc = merge_shards(shards, P.fragment_samples, merged, merr); if (rc != RSQC_OK) cerr << merr << endl; }
+            if (o.verbosity > 1) {
+                cout << "Alignments processed: " << alignmentCount << " on " << shards.size() << " GPUs (";
+                for (size_t g = 0; g < shards.size(); ++g) cout << (g ? ", " : "") << shards[g].n_records;
+                cout << " records)" << endl;
+            }
+        } else
         for (;;) {
             HostBatch &hb = bufs[cur];
             hb.clear();
@@ -314,6 +488,12 @@ int main(int argc, char **argv) {
             if (o.verbosity > 1) cout << "Alignments processed: " << alignmentCount << endl;
         }
         rsqc_results res{};
+        if (rc == RSQC_OK && shards.size() > 1) {
+            rc = rsqc_refresh_results(gpu, &res);
+            res.read_length = merged.read_length;
+            res.n_fragment_sizes = (uint32_t)merged.fsize.size(); res.fragment_size = merged.fsize.data(); res.fragment_count = merged.fcount.data();
+            res.fragment_samples_remaining = merged.remaining;
+        } else
         if (rc == RSQC_OK) rc = rsqc_finalize(gpu, &res);
         const auto tb1 = std::chrono::steady_clock::now();
         if (rc == RSQC_ERR_BAD_CIGAR) throw std::invalid_argument("Unrecognized Cigar Op ");
@@ -323,7 +503,7 @@ int main(int argc, char **argv) {
             const double secs = std::chrono::duration<double>(tb1 - tb0).count();
             cout << "Time Elapsed: " << secs << "; Alignments processed: " << alignmentCount << endl;
             if (o.verbosity > 1) cout << "Average Reads/Sec: " << (double)alignmentCount / secs << endl;
-            if (o.verbosity > 1) cout << "(decode threads: " << bam.inflate_threads() << " inflate + " << bam.parse_threads() << " parse)" << endl;
+            if (o.verbosity > 1 && shards.size() == 1) cout << "(decode threads: " << bam.inflate_threads() << " inflate + " << bam.parse_threads() << " parse)" << endl;
             cout << "Estimating library complexity..." << endl;
             cout << "Generating report" << endl;
         }
@@ -332,7 +512,7 @@ int main(int argc, char **argv) {
         cfg.use_rpkm = o.rpkm; cfg.write_coverage = o.coverage; cfg.detection_threshold = (unsigned)o.detection;
         cfg.filter_tags = o.tags;
         write_reports(cfg, ann, res, visit);
-        rsqc_destroy(gpu);
+        for (auto &sh : shards) rsqc_destroy(sh.gpu);
     } catch (Help &) {
         usage(cout);
         return 4;

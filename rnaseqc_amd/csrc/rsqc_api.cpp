@@ -1106,6 +1106,34 @@ int rsqc_device_vectors(rsqc_ctx *c, rsqc_device_range out[3]) {
     return RSQC_OK;
 }
 
+int rsqc_reduce_peer(rsqc_ctx *dst, rsqc_ctx *src) {
+    if (!dst || !src || dst == src || !dst->have_ann || !src->have_ann || !dst->finalized || !src->finalized) return RSQC_ERR_ARG;
+    if (dst->arena_bytes != src->arena_bytes || dst->n_genes != src->n_genes || dst->n_exons != src->n_exons)
+        return fail(dst, RSQC_ERR_ARG, "rsqc_reduce_peer: the two contexts hold different annotations");
+    HIP_TRY(src, hipSetDevice(src->device));
+    HIP_TRY(src, hipStreamSynchronize(src->stream));
+    HIP_TRY(dst, hipSetDevice(dst->device));
+    // the peer's three ranges are contiguous in its arena: [off_u64, off_ehit)
+    const size_t lo = dst->off_u64, hi = dst->off_ehit, bytes = hi - lo;
+    DevBuf tmp;
+    int rc = dev_alloc(dst, tmp, bytes, false);
+    if (rc) return rc;
+    HIP_TRY(dst, hipMemcpyPeerAsync(tmp.p, dst->device, (const char *)src->d_arena.p + lo, src->device, bytes, dst->stream));
+    char *D = (char *)dst->d_arena.p, *T = (char *)tmp.p - lo;
+    launch_reduce_add(dst->stream, (unsigned long long *)(D + dst->off_u64), (const unsigned long long *)(T + dst->off_u64), (dst->off_exon - dst->off_u64) / 8,
+                      (double *)(D + dst->off_exon), (const double *)(T + dst->off_exon), (dst->off_gvalid - dst->off_exon) / 8,
+                      (uint8_t *)(D + dst->off_gvalid), (const uint8_t *)(T + dst->off_gvalid), dst->off_ehit - dst->off_gvalid);
+    HIP_TRY(dst, hipGetLastError());
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    tmp.release();
+    // the device error flags travel too: a shard's failure is the run's failure
+    int err = 0;
+    HIP_TRY(src, hipSetDevice(src->device));
+    HIP_TRY(src, hipMemcpy(&err, src->acc.error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) { dst->sticky = err; return fail(dst, err, "a shard reported a device-side error"); }
+    return RSQC_OK;
+}
+
 int rsqc_refresh_results(rsqc_ctx *c, rsqc_results *out) {
     if (!c || !out || !c->have_ann || !c->finalized) return RSQC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

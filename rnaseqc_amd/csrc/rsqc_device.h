@@ -123,6 +123,8 @@ struct GeneCovArgs {
 };
 void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium);
 
+void launch_reduce_add(hipStream_t s, unsigned long long *du, const unsigned long long *su, size_t nu, double *df, const double *sf, size_t nf,
+                       uint8_t *db, const uint8_t *sb, size_t nb);
 void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons);
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min);
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,

@@ -1462,6 +1462,23 @@ reset_kernel(uint4 *arena, size_t arena_vec, uint4 *cov, size_t cov_vec, size_t 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < arena_vec; i += stride) arena[i] = i == rl_vec ? armed : z;
 }
 
+// ------------------------------------------------------------------ shard reduction (single-process multi-GPU)
+// dst += src over the three reducible ranges of a context's result arena (rsqc_device_vectors): what the RCCL all_reduce of
+// a one-process-per-GPU run does, for a process that drives several GPUs itself: the peer's ranges arrive by
+// hipMemcpyPeerAsync (xGMI) and are added here.
+__global__ void __launch_bounds__(256)
+reduce_add_kernel(unsigned long long *du, const unsigned long long *su, size_t nu, double *df, const double *sf, size_t nf,
+                  uint8_t *db, const uint8_t *sb, size_t nb) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t; i < nu; i += stride) du[i] += su[i];
+    for (size_t i = t; i < nf; i += stride) df[i] += sf[i];
+    for (size_t i = t; i < nb; i += stride) db[i] = (uint8_t)(db[i] + sb[i]);
+}
+void launch_reduce_add(hipStream_t s, unsigned long long *du, const unsigned long long *su, size_t nu, double *df, const double *sf, size_t nf,
+                       uint8_t *db, const uint8_t *sb, size_t nb) {
+    hipLaunchKernelGGL(reduce_add_kernel, dim3(512), dim3(256), 0, s, du, su, nu, df, sf, nf, db, sb, nb);
+}
+
 // ------------------------------------------------------------------ launch wrappers
 void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons) {
     if (n_exons) hipLaunchKernelGGL(pack_results_kernel, dim3((n_exons + 255) / 256 < 1024 ? (n_exons + 255) / 256 : 1024), dim3(256), 0, s, exon_acc, exon_hit, n_exons);

@@ -48,6 +48,7 @@ def load_library():
         lib.rsqc_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
         lib.rsqc_device_vectors.argtypes = [vp, C.POINTER(abi.DeviceRange * 3)]
         lib.rsqc_shard_summary.argtypes = [vp, C.POINTER(abi.ShardInfoStruct)]
+        lib.rsqc_reduce_peer.argtypes = [vp, vp]
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
         lib.rsqc_finalize_device.argtypes = [vp]
         lib.rsqc_host_alloc.argtypes = [C.c_size_t]; lib.rsqc_host_alloc.restype = vp
@@ -64,7 +65,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_set_reference", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
 ]
 

@@ -158,3 +158,43 @@ def test_cli_stderr_of_the_reference_loop(cli, tmp_path):
     err = go(batch, hdr[:1], "-v")                                # chrB's records now carry a RefID the header lacks
     assert err.count("Unrecognized RefID on alignment: SYN:") >= 10 and WARN not in err
     assert "Unrecognized RefID" not in go(batch, hdr[:1])         # only under -v, like the reference
+
+
+@pytest.mark.gpu
+def test_cli_sharded_by_contig_matches_single_gpu(cli, tmp_path):
+    """`--gpus N`: the BAM sharded by contig through its index, one context per GPU (here both on the box's one GPU,
+    RSQC_GPU_LIST=0,0), results summed with rsqc_reduce_peer and the order-dependent outputs composed from the shard
+    summaries -- every output file must equal the single-GPU run's, incl. fragmentSizes.txt under a tight --fragment-samples
+    cut-off and Read Length on input with mixed read lengths."""
+    contigs = [("cA", 2_000_000, 150), ("cB", 1_500_000, 120), ("cC", 900_000, 60), ("cD", 700_000, 50)]
+    ann = synth.make_annotation(seed=21, contigs=contigs)
+    batch = synth.make_reads(ann, 30000, seed=22, dup_frac=0.05, contig_lengths=np.array([c[1] for c in contigs]))
+    rng = np.random.default_rng(5)
+    batch.l_qseq = rng.choice(np.array([36, 50, 76, 101, 150], np.uint16), size=batch.n).astype(np.uint16)
+    bed = synth.make_bed(ann, min_len=300)
+    gtf, bam, bedp = str(tmp_path / "s.gtf"), str(tmp_path / "s.bam"), str(tmp_path / "s.bed")
+    bamio.write_gtf(gtf, ann)
+    bamio.write_bam_fast(bam, [(c[0], c[1]) for c in contigs], batch, threads=4, bai=True)
+    bamio.write_bed(bedp, ann, bed)
+    common = [gtf, bam, "--coverage", "--bed", bedp, "--fragment-samples", "300", "-vv"]
+    env = dict(os.environ, RSQC_BATCH="9000")
+    one = subprocess.run([cli, *common[:2], str(tmp_path / "one"), *common[2:]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert one.returncode == 0, one.stderr.decode()
+    two = subprocess.run([cli, *common[:2], str(tmp_path / "two"), *common[2:], "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env=dict(env, RSQC_GPU_LIST="0,0"))
+    assert two.returncode == 0, two.stderr.decode()
+    assert "on 2 GPUs" in two.stdout.decode()
+    m1 = dict(read_table(str(tmp_path / "one" / "s.bam.metrics.tsv"))); m2 = dict(read_table(str(tmp_path / "two" / "s.bam.metrics.tsv")))
+    assert m1.keys() == m2.keys()
+    assert m1["Read Length"] == m2["Read Length"] and m1["Total Alignments"] == m2["Total Alignments"] == str(batch.n)
+    for f in ("gene_reads.gct", "gene_fragments.gct", "fragmentSizes.txt"):
+        assert open(str(tmp_path / "one" / ("s.bam." + f))).read() == open(str(tmp_path / "two" / ("s.bam." + f))).read(), f
+    assert sum(int(r[1]) for r in read_table(str(tmp_path / "two" / "s.bam.fragmentSizes.txt"), 1)) == 300
+    for f in ("metrics.tsv", "gene_tpm.gct", "exon_reads.gct", "coverage.tsv", "exon_cv.tsv"):
+        _compare_tables(str(tmp_path / "one" / ("s.bam." + f)), str(tmp_path / "two" / ("s.bam." + f)), 3 if f.endswith(".gct") else 1, tol=1e-6)
+    # without the index the run falls back to one GPU with a notice
+    os.remove(bam + ".bai")
+    three = subprocess.run([cli, *common[:2], str(tmp_path / "three"), *common[2:], "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(env, RSQC_GPU_LIST="0,0"))
+    assert three.returncode == 0 and "needs the BAM index" in three.stderr.decode()
+    assert open(str(tmp_path / "three" / "s.bam.gene_reads.gct")).read() == open(str(tmp_path / "one" / "s.bam.gene_reads.gct")).read()
