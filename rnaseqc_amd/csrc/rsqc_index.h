@@ -140,9 +140,12 @@ struct HostIndex {
         // packed 16-byte rows (after the coverage layout: a row carries its coverage offset)
         ex_rows.resize((size_t)E);
         for (int i = 0; i < E; ++i) {
-            uint32_t fl = a->exon_row_flags[i] & 0x7u;
+            uint32_t fl = a->exon_row_flags[i] & 0x7u;   // strand + ribosomal
             if (a->gene_is_globin[a->exon_row_gene[i]]) fl |= ROWF_GLOBIN;
             if (ex_pmax[(size_t)i] != a->exon_row_end[i]) fl |= ROWF_PMAX_EXT;
+            // closed to the left: first row of its contig, or every earlier row of the contig ends before this one starts
+            const bool first_of_contig = i == 0 || a->exon_row_contig[i - 1] != a->exon_row_contig[i];
+            if (first_of_contig || ex_pmax[(size_t)i - 1] < a->exon_row_start[i]) fl |= ROWF_LEFT_CLOSED;
             ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_cov[(size_t)i],
                                          a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
         }

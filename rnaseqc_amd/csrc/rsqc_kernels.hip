@@ -23,8 +23,9 @@
 // marks and accumulates, per section, the cycles its waves spent since their previous mark (stalls included).
 // Diagnostic only; the product library is compiled without it.
 #ifdef RSQC_K1_PROF
-namespace rsqc { __device__ __forceinline__ void k1_mark(int sec); }
+namespace rsqc { __device__ __forceinline__ void k1_mark(int sec); __device__ __forceinline__ void k1_event(int id, bool cond); }
 #define RSQC_MARK(sec) ::rsqc::k1_mark(sec)
+#define RSQC_EVENT(id, cond) ::rsqc::k1_event(id, cond)
 #endif
 
 #include "rsqc_device.h"
@@ -35,8 +36,8 @@ namespace rsqc {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 #ifdef RSQC_K1_PROF
-__device__ unsigned long long g_k1_prof[32];          // [sec] cycles, [16 + sec] marks
-__shared__ unsigned long long s_prof_acc[32];
+__device__ unsigned long long g_k1_prof[48];          // [sec] cycles, [16 + sec] marks, [32 + id] / [36 + id] slow-branch events
+__shared__ unsigned long long s_prof_acc[48];
 __shared__ unsigned long long s_prof_last[RSQC_K1_THREADS / 64];
 __device__ __forceinline__ void k1_mark(int sec) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -47,9 +48,14 @@ __device__ __forceinline__ void k1_mark(int sec) {
         s_prof_last[w] = t;
     }
 }
+// [32 + id]: tiles (block rounds) in which at least one lane takes slow branch `id`; [36 + id]: lanes that take it
+__device__ __forceinline__ void k1_event(int id, bool cond) {
+    const unsigned long long m = __ballot(cond);
+    if (m && lane_id() == 0) { atomicAdd(&s_prof_acc[32 + id], 1ull); atomicAdd(&s_prof_acc[36 + id], (unsigned long long)__popcll(m)); }
+}
 extern "C" __attribute__((visibility("default"))) int rsqc_debug_k1_prof(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1_prof), sizeof(g_k1_prof)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_k1_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_k1_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -240,7 +246,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
     if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; S.pairs = 0u; }
     if (blockIdx.x == 0 && threadIdx.x == 0) *acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
 #ifdef RSQC_K1_PROF
-    if (threadIdx.x < 32) s_prof_acc[threadIdx.x] = 0ull;
+    if (threadIdx.x < 48) s_prof_acc[threadIdx.x] = 0ull;
     if (l == 0) s_prof_last[wave] = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
@@ -479,7 +485,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #ifdef RSQC_K1_PROF
     RSQC_MARK(14);                                 // [14] workgroup epilogue (barrier + flush of the LDS tables)
     __syncthreads();
-    if (threadIdx.x < 32 && s_prof_acc[threadIdx.x]) atomicAdd(&g_k1_prof[threadIdx.x], s_prof_acc[threadIdx.x]);
+    if (threadIdx.x < 48 && s_prof_acc[threadIdx.x]) atomicAdd(&g_k1_prof[threadIdx.x], s_prof_acc[threadIdx.x]);
 #endif
 }
 

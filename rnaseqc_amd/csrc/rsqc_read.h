@@ -27,6 +27,9 @@
 #ifndef RSQC_MARK
 #define RSQC_MARK(sec)
 #endif
+#ifndef RSQC_EVENT
+#define RSQC_EVENT(id, cond)          // profiling build: counts the tiles in which some lane takes a slow branch
+#endif
 
 namespace rsqc {
 
@@ -56,8 +59,13 @@ struct GeneBreak {
     uint32_t mask;           // bit s (s = RSQC_STRAND_*): a gene of strand class s covers it; bit 3+s: ... a ribosomal one
 };
 constexpr uint32_t ROW_GENE_MASK = (1u << 26) - 1u;
-constexpr int ROW_FLAG_SHIFT = 26;     // bits 26-27 strand, 28 ribosomal, 29 the row's gene is a globin, 30 pmax > end
+constexpr int ROW_FLAG_SHIFT = 26;     // bits 26-27 strand, 28 ribosomal, 29 the row's gene is a globin, 30 pmax > end, 31 closed to the left
 constexpr uint32_t ROWF_RIBOSOMAL = 4u, ROWF_GLOBIN = 8u, ROWF_PMAX_EXT = 16u;
+// ROWF_LEFT_CLOSED: every row before this one (same contig) ends before this row starts, i.e. running max of end over the
+// earlier rows < start.  A query block that starts at or after such a row cannot overlap anything below it: the downward
+// walk stops there without looking at the next row (which in a bin with several exon starts is usually the only reason
+// to look further down -- measured: 41 % of the lanes of a tile went back to memory for that before the flag existed).
+constexpr uint32_t ROWF_LEFT_CLOSED = 32u;
 
 struct ContigInfo {          // 32 bytes per contig
     uint32_t ex_lo, ex_hi;   // exon rows of the contig
@@ -236,10 +244,11 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
         --i;
         const ExonRow row = a.ex[i];
         if (a.ex_pmax[i] < bs) break;
-        if (row.start > be || row.end < bs) continue;
+        const bool last = ((row.gf >> ROW_FLAG_SHIFT) & ROWF_LEFT_CLOSED) && row.start <= bs;   // nothing below can reach the block
+        if (row.start > be || row.end < bs) { if (last) break; continue; }
         const uint32_t fl = row.gf >> ROW_FLAG_SHIFT;
         const int fs = (int)(fl & RSQC_FF_STRAND_MASK);
-        if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) continue;
+        if (rstrand != RSQC_STRAND_UNKNOWN && rstrand != fs) { if (last) break; continue; }
         if (f) {
             if (fs == RSQC_STRAND_FORWARD) f->plus = true; else if (fs == RSQC_STRAND_REVERSE) f->minus = true;
             f->exonic = true;                                                  // :337 (even for the phantom base)
@@ -247,6 +256,7 @@ RSQC_HD void query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t b
         }
         // partialIntersect == end - start  <=>  start <= bs && end >= be - 1   (src/GTF.cpp:181-186)
         visit(i, row, row.start <= bs && row.end >= be - 1);
+        if (last) break;
     }
 }
 
@@ -558,6 +568,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
                 uint32_t mask = adv ? r.g1.mask : ((v0 ? r.g0.mask : 0u) | (in1 ? r.g1.mask : 0u));
                 mask |= (in2 && (adv || in1)) ? r.g2.mask : 0u;
                 const bool deeper = (adv && v2 && r.g2.pos <= bsc) || (in2 && (adv || in1) && more);
+                RSQC_EVENT(0, hg && deeper);
                 if (hg && deeper) mask = gene_mask(a, ci, bs, be);
                 cf |= hg ? gene_class_flags(mask, rstrand) : 0u;
             }
@@ -567,13 +578,18 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
             {
                 const bool x0 = act && en > 0 && ((r.e0.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
                 const bool x1 = act && en > 1 && ((r.e1.gf >> ROW_FLAG_SHIFT) & ROWF_PMAX_EXT) != 0;
+                RSQC_EVENT(1, x0 || x1);
                 if (x0 || x1) {                                              // both from memory in one round trip
                     const int32_t q0 = ld32(a.ex_pmax, ehi - 1), q1 = ld32(a.ex_pmax, en > 1 ? ehi - 2 : ehi - 1);
                     if (x0) pm0 = q0;
                     if (x1) pm1 = q1;
                 }
             }
-            const bool reach0 = act && en > 0 && pm0 >= bs, reach1 = reach0 && en > 1 && pm1 >= bs;
+            // a staged row that is closed to the left and starts at or before the block ends the walk (ROWF_LEFT_CLOSED)
+            const bool stop0 = ((r.e0.gf >> ROW_FLAG_SHIFT) & ROWF_LEFT_CLOSED) != 0 && r.e0.start <= bs;
+            const bool stop1 = ((r.e1.gf >> ROW_FLAG_SHIFT) & ROWF_LEFT_CLOSED) != 0 && r.e1.start <= bs;
+            const bool reach0 = act && en > 0 && pm0 >= bs, reach1 = reach0 && !stop0 && en > 1 && pm1 >= bs;
+            const bool reach2 = reach1 && !stop1;
             const uint32_t t0 = exon_row_test(r.e0, reach0, bs, be, rstrand, cf);
             const uint32_t t1 = exon_row_test(r.e1, reach1, bs, be, rstrand, cf);
             const bool k0 = (t0 & 2u) != 0, k1 = (t1 & 2u) != 0;
@@ -582,7 +598,8 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
             uint32_t rowA = k0 ? ehi - 1 : ehi - 2, gfA = k0 ? r.e0.gf : r.e1.gf, rowB = ehi - 2, gfB = r.e1.gf;
             uint32_t cidxA = k0 ? r.e0.cov + (uint32_t)(bs - r.e0.start) : r.e1.cov + (uint32_t)(bs - r.e1.start);
             uint32_t cidxB = r.e1.cov + (uint32_t)(bs - r.e1.start);
-            if (reach1) {
+            RSQC_EVENT(2, reach2);
+            if (reach2) {
                 for (uint32_t i = ehi - 2; i > ci.ex_lo;) {
                     --i;
                     const ExonRow row = ld32(a.ex, i);
@@ -593,6 +610,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
                         else if (!c1) { c1 = true; rowB = i; gfB = row.gf; cidxB = cx; }
                         else over = true;                                                   // a third containing exon
                     }
+                    if (((row.gf >> ROW_FLAG_SHIFT) & ROWF_LEFT_CLOSED) && row.start <= bs) break;
                 }
             }
             const uint32_t g0 = gfA & ROW_GENE_MASK, g1 = gfB & ROW_GENE_MASK;

@@ -4,4 +4,4 @@
 #       1024 no exon LDS add | 2048 no pair store | 4096 no gene LDS add
 PAIRS=${PAIRS:-10000000}
 run() { python bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-e2e --no-finalize --pairs $PAIRS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-40s k1 %.3f ms  (%d records)' % ('$1', d['stage_ms']['classify_k1'], d['config']['records']))"; }
-for m in ${MASKS:-0 8 4 1 2 1024 2048 4096 7}; do RSQC_DEBUG_MASK=$m run "variant${RSQC_K1_VARIANT:-41} dbg=$m"; done
+for m in ${MASKS:-0 8 4 1 7}; do RSQC_DEBUG_MASK=$m run "variant${RSQC_K1_VARIANT:-41} dbg=$m"; done

@@ -18,12 +18,15 @@ names = ["loop+flush", "load-wait+unpack+cigar+gate", "gate counters+RL", "bins 
          "feature epilogue", "class bits/ovf", "stage next tile", "commit slots", "gene hits", "tail flush", "wg epilogue", ""]
 for rep in range(2):
     e.reset(); lib.rsqc_debug_k1_prof(None, 1); e.submit_resident(h); e.wait()
-out = (C.c_ulonglong * 32)(); lib.rsqc_debug_k1_prof(out, 0)
-cyc = np.array(out[:16], dtype=np.float64); cnt = np.array(out[16:], dtype=np.float64)
+out = (C.c_ulonglong * 48)(); lib.rsqc_debug_k1_prof(out, 0)
+cyc = np.array(out[:16], dtype=np.float64); cnt = np.array(out[16:32], dtype=np.float64)
 tiles = (batch.n + 63) // 64
 tm = e.timing()
 print("records %d  tiles %d  K1 %.3f ms" % (batch.n, tiles, tm["classify_ms"] / max(tm["classify_launches"], 1)))
 for k in range(15):
     if cnt[k]: print("  [%2d] %-30s %5.1f %%   %8.0f cycles/tile   (%.2f marks/tile)" % (k, names[k], 100 * cyc[k] / cyc.sum(), cyc[k] / tiles, cnt[k] / tiles))
-print("  total %.0f cycles/tile/wave (s_memtime ticks)" % (cyc.sum() / tiles))
+print("  total %.0f cycles/tile/wave (s_memtime ticks)" % (cyc[:16].sum() / tiles))
+ev = np.array(out[32:40], dtype=np.float64)
+for k, nm in enumerate(["gene mask beyond 3 breakpoints", "running-max column load", "walk beyond the two staged rows"]):
+    print("  slow branch %-34s taken in %.3f block rounds per tile, %.3f lanes per tile" % (nm, ev[k] / tiles, ev[4 + k] / tiles))
 e.close()
