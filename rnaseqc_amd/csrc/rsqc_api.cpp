@@ -111,6 +111,7 @@ struct rsqc_ctx {
     std::vector<size_t> pairs_in_flight;        // indices into pair_pool, submission order (batches not retired yet)
     Arena pair_arena, frag_arena, gc_arena;     // what the retired batches emitted
     DevBuf d_arena_count;                       // u32: pair_arena.used for the K4 launch over the arena
+    std::vector<DevBuf> parked;                 // outgrown arena columns, freed at the next synchronisation point
     DevBuf d_table, d_tab_off, d_tab_cap;
     std::vector<FragBuf> frag_pool;
     std::vector<size_t> frags_in_flight;
@@ -310,17 +311,24 @@ void retire_batch(rsqc_ctx *c, UploadedBatch *u);
 
 int arena_reserve(rsqc_ctx *c, Arena &a, uint64_t extra) {
     if (a.used + extra <= a.cap) return 0;
-    const uint64_t ncap = std::max<uint64_t>(a.used + extra, a.cap + a.cap / 2 + (1u << 16));
+    // doubling, from a floor of 16 M entries: a handful of growth steps for any input.  The old columns are not freed here
+    // (hipFree synchronises the device, in the middle of the decode / kernel pipeline): they are parked until the next
+    // point where the stream has been synchronised anyway.
+    const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(a.used + extra, 2 * a.cap), 1ull << 24);
     for (int k = 0; k < a.n_col; ++k) {
         DevBuf nb;
         HIP_TRY(c, hipMalloc(&nb.p, ncap * a.width[k] + 64));
         nb.bytes = ncap * a.width[k] + 64;
         if (a.used) HIP_TRY(c, hipMemcpyAsync(nb.p, a.col[k].p, a.used * a.width[k], hipMemcpyDeviceToDevice, c->stream));
-        if (a.col[k].p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); a.col[k].release(); }
+        if (a.col[k].p) c->parked.push_back(a.col[k]);
         a.col[k] = nb;
     }
     a.cap = ncap;
     return 0;
+}
+void free_parked(rsqc_ctx *c) {                 // caller: the stream has been synchronised
+    for (auto &b : c->parked) b.release();
+    c->parked.clear();
 }
 
 // Retires every in-flight batch whose kernels have completed (all of them when `all` -- the caller has synchronised).
@@ -557,6 +565,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
     c->d_arena_count.release(); c->d_rl_summary.release();
+    for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
@@ -782,6 +791,7 @@ int rsqc_wait(rsqc_ctx *c) {
     resolve_events(c);
     for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
+    free_parked(c);
     if (c->have_ann) {
         int rc = retire_completed(c, true);      // everything submitted so far has completed
         if (rc) return rc;
@@ -1037,6 +1047,7 @@ static void finish_finalize_bookkeeping(rsqc_ctx *c) {
     for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
     unpack_rl_summaries(c);
+    free_parked(c);
     c->finalized = true;
 }
 
