@@ -78,7 +78,7 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
-    int k1_variant = 41, k1_grid = 256 * 16;  // tuning knobs (RSQC_K1_VARIANT / RSQC_K1_GRID), set once at create
+    int k1_variant = 41, k1_grid = 256 * 16;  // workgroups of the per-read kernel (RSQC_K1_GRID overrides), set once at create
 
     // annotation (host copies needed at finalize)
     bool have_ann = false;
@@ -91,7 +91,7 @@ struct rsqc_ctx {
     const uint32_t *d_ge_off = nullptr, *d_ge_row = nullptr, *d_gene_cov_off = nullptr, *d_gene_coding = nullptr;
     const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
     const uint32_t *d_gene_order = nullptr;
-    uint32_t k3_large = 0, k3_medium = 0;
+    uint32_t k3_large = 0, k3_medium = 0, k3_xlarge = 0;
     hipEvent_t fin_e0 = nullptr, fin_e1 = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
@@ -545,7 +545,6 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->pair_arena.n_col = 2; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8;                       // gene, name hash
     c->frag_arena.n_col = 5; { const size_t w[5] = {8, 8, 4, 4, 4}; for (int k = 0; k < 5; ++k) c->frag_arena.width[k] = w[k]; }
     c->gc_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->gc_arena.width[k] = w[k]; }
-    if (const char *e = getenv("RSQC_K1_VARIANT")) c->k1_variant = atoi(e);
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
     if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
@@ -634,10 +633,11 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     std::stable_sort(gene_order.begin(), gene_order.begin() + L, [&](uint32_t x, uint32_t y) { return gene_coding[x] > gene_coding[y]; });
     UPV(c->d_gene_order, gene_order);
     // workgroup size classes of the end-of-file coverage stage (rsqc_kernels.hip, K3)
-    c->k3_large = c->k3_medium = 0;
+    c->k3_large = c->k3_medium = c->k3_xlarge = 0;
     for (int k = 0; k < L; ++k) {
         const uint32_t len = gene_coding[gene_order[(size_t)k]];
         if (len > (uint32_t)RSQC_K3_MEDIUM_MAX) c->k3_large++; else if (len > (uint32_t)RSQC_K3_SMALL_MAX) c->k3_medium++;
+        if (len > (uint32_t)RSQC_K3_LARGE2_LDS16) c->k3_xlarge++;
     }
 #undef UPV
 #undef UPA
@@ -943,12 +943,12 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
         Ga.error = c->acc.error;
         {
-            uint32_t nl = c->k3_large, nm = c->k3_medium;
+            uint32_t nl = c->k3_large, nm = c->k3_medium, nx = c->k3_xlarge;
             if (const char *e = getenv("RSQC_K3_FORCE")) {           // diagnostic: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
                 const int f = atoi(e);
-                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; } else if (f == 3) { nl = 0; nm = 0; }
+                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; nx = 0; } else if (f == 3) { nl = 0; nm = 0; nx = 0; } else if (f == 4) { nl = (uint32_t)L; nm = 0; nx = (uint32_t)L; }
             }
-            if (!getenv("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm);   // (diagnostic knob: results incomplete)
+            if (!getenv("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm, nx);   // (diagnostic knob: results incomplete)
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));

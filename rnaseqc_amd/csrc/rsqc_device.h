@@ -13,6 +13,7 @@
 #define RSQC_K3_SMALL_MAX 4096
 #define RSQC_K3_MEDIUM_MAX 12288
 #define RSQC_K3_LARGE_LDS16 73000      /* bases a 1024-thread workgroup keeps in LDS as 16-bit depths (146 KB of the CU's 160 KB) */
+#define RSQC_K3_LARGE2_LDS16 32768     /* ... the shorter genes of that class: 64 KB */
 #define RSQC_K3_MAX_EXONS 1024
 
 namespace rsqc {
@@ -121,7 +122,7 @@ struct GeneCovArgs {
     unsigned long long *bias3, *bias5;
     int *error;
 };
-void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium);
+void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge);
 
 void launch_reduce_add(hipStream_t s, unsigned long long *du, const unsigned long long *su, size_t nu, double *df, const double *sf, size_t nf,
                        uint8_t *db, const uint8_t *sb, size_t nb);

@@ -489,19 +489,15 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #endif
 }
 
-// The same body under two register budgets and two load-batching depths (occupancy vs. spilling vs. round trips
-// is measured, not guessed): min 3 / 4 waves per SIMD -> at most 168 / 128 VGPRs; ROUND = blocks whose row loads
-// are in flight together.  RSQC_K1_VARIANT picks one; 41 (4 waves, ROUND 1) is the default.
+// 4 waves per SIMD (at most 128 VGPRs), one block's row loads in flight at a time (ROUND = 1): measured against 3 waves
+// (168 VGPRs, no spills: +14 %), 5 waves (96 VGPRs, spills in the loop: 2.2x) and ROUND = 2 (profiles/r2_k1_occupancy_v1.txt).
 #define RSQC_DEFINE_K1(NAME, MINW, ROUND)                                                       \
     __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
     NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
         __shared__ K1Shared S;                                                                  \
         classify_count_body<ROUND>(a, p, b, acc, S);                                            \
     }
-RSQC_DEFINE_K1(classify_count_kernel_w3, 3, 2)
-RSQC_DEFINE_K1(classify_count_kernel_w3r1, 3, 1)
 RSQC_DEFINE_K1(classify_count_kernel_w4r1, 4, 1)
-RSQC_DEFINE_K1(classify_count_kernel_w5r1, 5, 1)
 __global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
 classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     __shared__ K1Shared S;
@@ -1500,9 +1496,6 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
     // (diagnostic) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
     static const unsigned pad = getenv("RSQC_K1_LDS_PAD") ? (unsigned)atoi(getenv("RSQC_K1_LDS_PAD")) : 0u;
     if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else if (variant == 3) hipLaunchKernelGGL(classify_count_kernel_w3, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
-    else if (variant == 31) hipLaunchKernelGGL(classify_count_kernel_w3r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
-    else if (variant == 51) hipLaunchKernelGGL(classify_count_kernel_w5r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
     else hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
@@ -1540,7 +1533,7 @@ void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint
     hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, gene_reads, P.part_first, n_genes, P.gene_base,
                        P.cursor, P.part_gene, P.list, gene_frag, error);
 }
-void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium) {
+void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge) {
     if (A.n_listed <= 0) return;
     // gene_order is sorted by coding length, longest first: [0, n_large) x 1024 threads,
     // [n_large, n_large + n_medium) x 256 threads, the rest one wave each; the three launches are independent
@@ -1552,7 +1545,10 @@ void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const G
         if (wide) hipLaunchKernelGGL((gene_coverage_kernel<T, RSQC_MAX_BIAS_WINDOW, COVT, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST); \
         else hipLaunchKernelGGL((gene_coverage_kernel<T, 128, COVT, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST);  \
     }
-    RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE_LDS16, n_large, 0u, s)
+    // the 1024-thread class in two LDS sizes: a workgroup that holds 146 KB keeps its CU to itself, one that holds 64 KB leaves
+    // room for the fragment de-dup workgroups running beside it (the longest genes go first on the same stream)
+    RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE_LDS16, n_xlarge, 0u, s)
+    RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE2_LDS16, n_large - n_xlarge, n_xlarge, s)
     RSQC_K3_LAUNCH(256, uint32_t, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
     RSQC_K3_LAUNCH(64, uint32_t, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
 #undef RSQC_K3_LAUNCH

@@ -58,13 +58,15 @@ def test_deep_coverage_bias_path(oracle_lib, kw):
     assert_results_match(engine.run_engine(p, ann, [batch]), want)
 
 
-def test_depth_beyond_16_bits_on_a_long_gene(oracle_lib):
+@pytest.mark.parametrize("n_exons", [5, 10])
+def test_depth_beyond_16_bits_on_a_long_gene(oracle_lib, n_exons):
     """The longest genes keep 16-bit depths in LDS; a base covered >= 65 536 times must send the gene through the
-    in-memory path with identical results (two long genes here: one deep, one shallow)."""
+    in-memory path with identical results (two long genes here: one deep, one shallow).  5 exons x 4 kb = 20 kb of coding
+    length: the 64 KB instantiation of the 1024-thread class; 10 exons = 40 kb: the 146 KB one."""
     rows = []
     for gid, base in (("deep", 10_000), ("shallow", 200_000)):
-        rows.append(dict(contig="c", type="gene", start=base, end=base + 60_000, strand="+", gene_id=gid, gene_name=gid))
-        for k in range(5):                                     # 5 exons x 4 kb = 20 kb of coding length (1024-thread class)
+        rows.append(dict(contig="c", type="gene", start=base, end=base + 10_000 * n_exons + 10_000, strand="+", gene_id=gid, gene_name=gid))
+        for k in range(n_exons):
             rows.append(dict(contig="c", type="exon", start=base + k * 10_000, end=base + k * 10_000 + 3_999, strand="+",
                              gene_id=gid, exon_id="%s_e%d" % (gid, k)))
     from rnaseqc_amd.model import Annotation, Batch
@@ -85,7 +87,7 @@ def test_depth_beyond_16_bits_on_a_long_gene(oracle_lib):
     want = oracle_lib.run_oracle(p, ann, [batch])
     got = engine.run_engine(p, ann, [batch])
     assert_results_match(got, want)
-    assert got.gene_reads[0] == n_deep and got.gene_cov_valid[0] == 1 and got.gene_cov_mean[0] > 300
+    assert got.gene_reads[0] == n_deep and got.gene_cov_valid[0] == 1 and got.gene_cov_mean[0] > 100
 
 
 def test_batch_split_invariance(oracle_lib):
