@@ -553,6 +553,12 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
         const uint32_t block_size = le32(buf + p);
         if (block_size < 32) throw std::runtime_error("bad BAM record");
         if (p + 4 + (size_t)block_size > end) break;
+        // Records are found by hopping, one dependent cache miss after the other, in data another core has just inflated.
+        // The record after the next one most likely has this record's size: fetch its first two lines and its tail (aux)
+        {
+            const uint8_t *guess = buf + p + 2 * (4 + (size_t)block_size);
+            __builtin_prefetch(guess, 0, 1); __builtin_prefetch(guess + 64, 0, 1); __builtin_prefetch(guess + block_size - 32, 0, 1);
+        }
         const uint8_t *r = buf + p + 4;
         const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
         const uint8_t l_read_name = r[8], mapq = r[9];
