@@ -327,6 +327,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         // The cascade and the feature stage run CONVERGED (lanes without a record are predicated off by `lane_on`): the
         // counter sink works on whole-wave ballots.
         bool go = false, hq = false; Blocks B; uint32_t fl = 0; int32_t tid = u_tid;
+        FastBins fb_early;
+        fb_early.have = 0;
         {
             RecordCounters rc;
             Record r;
@@ -352,6 +354,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             CigarWalk cw;
             walk_cigar(r, cur_cg, cw, B);
             aligned = cw.aligned;
+            if (!lane_on || r.tid != u_tid) B.nb = 0;          // (stragglers of a boundary tile go to the general code: no look-up here)
+            if (!LEGACY) fast_load_bins(a, u_ci, B, fb_early);  // round 1 of the overlap query: in flight during the gate cascade
             go = gate_cascade<LEGACY, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on) && !(p.dbg & 8u);
             fl = r.flag; tid = r.tid;
             notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
@@ -389,7 +393,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         if (!LEGACY) {
             const bool fast_on = go && tid == u_tid;           // stragglers of a boundary tile: general code
             bool overflow = false;
-            exon_metrics_fast<ROUND, WaveSink>(a, p, u_ci, fl, B, hq, aligned, fo, overflow, cnt, fast_on);
+            exon_metrics_fast<ROUND, WaveSink>(a, p, u_ci, fl, B, hq, aligned, fo, overflow, cnt, fast_on, &fb_early);
             if (go && overflow) {
                 fo.n_hit = 0; fo.cmask = 0;
                 const uint32_t slot = atomicAdd(acc.ovf_count, 1u);

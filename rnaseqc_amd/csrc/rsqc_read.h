@@ -530,7 +530,10 @@ struct FastOut {
 // WaveSink the function is called by the whole wave); a record that sets `overflow` is counted by the general code instead.
 template <int ROUND = 2, class Sink = BitSink>
 RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl,
-                               const Blocks &B, bool hq, uint32_t aligned, FastOut &out, bool &overflow, Sink &cnt, bool lane_on = true) {
+                               const Blocks &B, bool hq, uint32_t aligned, FastOut &out, bool &overflow, Sink &cnt, bool lane_on = true,
+                               const FastBins *staged_bins = nullptr) {
+    // staged_bins: round 1 (fast_load_bins) already issued by the caller -- the per-record kernel starts it right after the
+    // CIGAR walk, so that the bin entries travel while the gate cascade computes
     out.n_hit = 0; out.cmask = 0;
     const int rstrand = read_strand_of(p, fl);
     uint32_t cf = 0;                                          // CF_* class flags of the whole record
@@ -542,7 +545,7 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) { out.row[k] = 0; out.cidx[k] = 0; }
     FastBins fb;
-    fast_load_bins(a, ci, B, fb);
+    if (staged_bins) fb = *staged_bins; else fast_load_bins(a, ci, B, fb);
     RSQC_MARK(3);
 #pragma unroll
     for (int b0 = 0; b0 < FAST_BLOCKS; b0 += ROUND) {
