@@ -1,4 +1,5 @@
 #include "bam.hpp"
+#include "../rsqc_bamrec.h"
 
 #include <sched.h>
 #include <sys/mman.h>
@@ -458,19 +459,6 @@ bool BamReader::open(const std::string &path) {
     return true;
 }
 
-// SeqLib::BamRecord::GetIntTag: an integer-typed aux field (htslib bam_aux2i)
-static bool aux_int(const uint8_t *v, char type, int32_t &out) {
-    switch (type) {
-    case 'c': out = (int8_t)v[0]; return true;
-    case 'C': out = v[0]; return true;
-    case 's': out = (int16_t)le16(v); return true;
-    case 'S': out = le16(v); return true;
-    case 'i': out = (int32_t)le32(v); return true;
-    case 'I': out = (int32_t)le32(v); return true;
-    default: return false;
-    }
-}
-
 // ---- record framing ---------------------------------------------------------------------------------
 // A BAM record can only be located by hopping from the previous one (block_size), one dependent cache miss per
 // record.  The window is therefore cut into chunks that are framed (and parsed) IN PARALLEL from a guessed record
@@ -479,21 +467,7 @@ static bool aux_int(const uint8_t *v, char type, int32_t &out) {
 // boundary) ends exactly on it; otherwise chunk c is redone from the true position.  The result is exact --
 // a wrong guess costs time, never correctness.
 namespace {
-inline bool plausible_record(const uint8_t *buf, size_t p, size_t end, int32_t n_ref) {
-    if (p + 36 > end) return false;
-    const uint32_t bs = le32(buf + p);
-    if (bs < 32 || bs > (1u << 26)) return false;
-    const uint8_t *r = buf + p + 4;
-    const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24);
-    if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1) return false;
-    const uint32_t l_name = r[8], n_cig = le16(r + 12);
-    const int32_t l_seq = (int32_t)le32(r + 16);
-    if (l_name == 0 || l_seq < 0) return false;
-    const uint64_t fixed = 32ull + l_name + 4ull * n_cig + (uint64_t)(l_seq + 1) / 2 + (uint64_t)l_seq;
-    if (fixed > bs) return false;
-    if (p + 4 + 32 + l_name <= end && r[32 + l_name - 1] != 0) return false;     // QNAME is NUL-terminated
-    return true;
-}
+inline bool plausible_record(const uint8_t *buf, size_t p, size_t end, int32_t n_ref) { return rsqc::bam_plausible(buf, p, end, n_ref); }
 }  // namespace
 
 // One pass per chunk: a worker hops through the records of its chunk from the guessed start AND parses each one while
@@ -542,7 +516,7 @@ struct ChunkOut {
     }
     int32_t n_ref = 0;
 };
-struct TagSpec { char ch0 = 0, ch1 = 0; bool have_ch = false; int n_filter = 0; char f0[RSQC_MAX_FILTER_TAGS], f1[RSQC_MAX_FILTER_TAGS]; int32_t n_ref = 0; };
+using TagSpec = rsqc::BamTagSpec;
 
 // hop from `p` while records are complete and start before `limit`, parsing each into `o`; returns the first start
 // >= limit (or the start of the first incomplete record)
@@ -559,82 +533,31 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
             const uint8_t *guess = buf + p + 2 * (4 + (size_t)block_size);
             __builtin_prefetch(guess, 0, 1); __builtin_prefetch(guess + 64, 0, 1); __builtin_prefetch(guess + block_size - 32, 0, 1);
         }
-        const uint8_t *r = buf + p + 4;
-        const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
-        const uint8_t l_read_name = r[8], mapq = r[9];
-        const uint16_t n_cigar = le16(r + 12), flag = le16(r + 14);
-        const int32_t l_seq = (int32_t)le32(r + 16), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24), isize = (int32_t)le32(r + 28);
-        const char *qname = (const char *)r + 32;
-        const uint8_t *cig = r + 32 + l_read_name;
-        const uint8_t *end_r = r + block_size;
-        const uint8_t *auxp = cig + 4 * (size_t)n_cigar + (size_t)((l_seq < 0 ? 0 : l_seq + 1) / 2) + (size_t)(l_seq < 0 ? 0 : l_seq);
-        if (cig + 4 * (size_t)n_cigar > end_r) throw std::runtime_error("bad BAM record");
+        // (the record itself: rsqc_bamrec.h, the code the device decode runs as well)
+        rsqc::BamRecOut ro;
+        if (!rsqc::bam_parse_record(buf + p, block_size, tags, ro)) throw std::runtime_error("bad BAM record");
+        const int32_t tid = ro.tid, pos = ro.core.pos;
         const uint32_t k = (uint32_t)o.core.size();
         // a chunk's first record always opens a provisional segment; whether it continues the previous chunk's contig
         // is decided at merge time
         if (!have_last || last_tid != tid) o.segs.emplace_back(k, tid);
         have_last = true; last_tid = tid;
-        rsqc_rec_core co{pos, mpos, isize, (uint32_t)o.cig.size()};
-        rsqc_rec_aux au{};
-        const size_t qlen = l_read_name ? strnlen(qname, l_read_name) : 0;
-        au.qhash = rsqc_qname_hash(qname, qlen);
-        au.flag = flag; au.mapq = mapq;
-        if (!(flag & (RSQC_FSECONDARY | RSQC_FQCFAIL | RSQC_FSUPP | RSQC_FUNMAP))) {
-            if (tid < 0 || tid >= tags.n_ref) { if (o.bad_ref.size() < 64) o.bad_ref.emplace_back(k, std::string(qname, qlen)); }
+        if (rsqc::bam_flag_judged(ro.aux.flag)) {
+            if (tid < 0 || tid >= tags.n_ref) { if (o.bad_ref.size() < 64) o.bad_ref.emplace_back(k, std::string((const char *)buf + p + 36, ro.qname_len)); }
             else {
                 if (!o.have_q) { o.first_tid = tid; o.first_pos = pos; }
                 else if (o.q_tid == tid && o.q_pos > pos) o.unsorted = true;
                 o.have_q = true; o.q_tid = tid; o.q_pos = pos;
             }
         }
-        uint8_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
-        int32_t nm = 0;
-        const uint8_t *cg_ops = nullptr; uint32_t cg_n = 0;                             // CG:B,I -- the real CIGAR of a record with more than 65535 ops
-        for (const uint8_t *q = auxp; q + 3 <= end_r;) {
-            const char t0 = (char)q[0], t1 = (char)q[1], type = (char)q[2];
-            const uint8_t *v = q + 3;
-            size_t vlen = 0;
-            switch (type) {
-            case 'A': case 'c': case 'C': vlen = 1; break;
-            case 's': case 'S': vlen = 2; break;
-            case 'i': case 'I': case 'f': vlen = 4; break;
-            case 'd': vlen = 8; break;                                                  // (htslib skips 8 bytes)
-            case 'Z': case 'H': vlen = strnlen((const char *)v, (size_t)(end_r - v)) + 1; break;
-            case 'B': { if (v + 5 > end_r) { vlen = (size_t)(end_r - v); break; }
-                        const char st = (char)v[0]; const uint32_t cnt = le32(v + 1);
-                        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; vlen = 5 + es * (size_t)cnt; break; }
-            default: vlen = (size_t)(end_r - v); break;
-            }
-            if (v + vlen > end_r) break;                                            // malformed tail: stop scanning
-            if (t0 == 'N' && t1 == 'M') { int32_t x; if (aux_int(v, type, x)) { nm = x; tagbits |= RSQC_TB_HAS_NM; } }
-            if (t0 == 'C' && t1 == 'G' && type == 'B' && v[0] == 'I' && vlen >= 5) { cg_ops = v + 5; cg_n = le32(v + 1); }
-            if (tags.have_ch && t0 == tags.ch0 && t1 == tags.ch1) {                     // readStringTag, src/RNASeQC.cpp:780-800
-                if (type == 'Z' || (type == 'A' && v[0] != 0)) tagbits |= RSQC_TB_HAS_CH;
-            }
-            for (int fi = 0; fi < tags.n_filter; ++fi)                                  // GetTag: Z, integer or float
-                if (t0 == tags.f0[fi] && t1 == tags.f1[fi]) {
-                    int32_t x;
-                    if (type == 'Z' || type == 'f' || aux_int(v, type, x)) tagbits |= (uint8_t)(RSQC_TB_FILTER0 << fi);
-                }
-            q = v + vlen;
-        }
-        // A CIGAR of more than 65535 operations is stored in the CG tag behind the placeholder <l_seq>S<ref_len>N
-        // (SAM spec 4.2.2); htslib puts it back when it reads the record (bam_tag2cigar), so the reference sees the real one
-        uint32_t n_ops = n_cigar; const uint8_t *ops = cig;
-        if (cg_ops && cg_n > 0 && n_cigar == 2 && (le32(cig) & 0xf) == 4 && (int64_t)(le32(cig) >> 4) == (int64_t)l_seq && (le32(cig + 4) & 0xf) == 3) {
-            n_ops = cg_n; ops = cg_ops;
-        }
-        const bool wide = l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0 || nm >= RSQC_NM_ESCAPE || nm < 0 || n_ops >= RSQC_NCIGAR_ESCAPE;
-        au.l_qseq = wide && (l_seq >= RSQC_LQSEQ_ESCAPE || l_seq < 0) ? RSQC_LQSEQ_ESCAPE : (uint16_t)l_seq;
-        au.nm = wide && (nm >= RSQC_NM_ESCAPE || nm < 0) ? RSQC_NM_ESCAPE : (uint8_t)nm;
-        au.n_cigar = n_ops >= RSQC_NCIGAR_ESCAPE ? RSQC_NCIGAR_ESCAPE : (uint8_t)n_ops;
-        au.tagbits = tagbits;
-        if (wide) { o.widx.push_back(k); o.wnm.push_back(nm); o.wlq.push_back(l_seq); o.wnc.push_back(n_ops); }
+        ro.core.cigar_off = (uint32_t)o.cig.size();
+        if (ro.wide) { o.widx.push_back(k); o.wnm.push_back(ro.nm); o.wlq.push_back(ro.l_seq); o.wnc.push_back(ro.n_ops); }
         const size_t c0 = o.cig.size();
-        o.cig.resize(c0 + n_ops);
-        for (uint32_t ci = 0; ci < n_ops; ++ci) o.cig[c0 + ci] = le32(ops + 4 * (size_t)ci);
+        o.cig.resize(c0 + ro.n_ops);
+        const uint8_t *ops = buf + p + ro.ops_off;
+        for (uint32_t ci = 0; ci < ro.n_ops; ++ci) o.cig[c0 + ci] = le32(ops + 4 * (size_t)ci);
         o.cig_end.push_back((uint32_t)o.cig.size());
-        o.core.push_back(co); o.aux.push_back(au);
+        o.core.push_back(ro.core); o.aux.push_back(ro.aux);
         p += 4 + (size_t)block_size;
     }
     o.last_tid = last_tid;
@@ -646,15 +569,18 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
     size_t n = 0;
     if (!pool_) set_threads(1);
     const int32_t n_ref = (int32_t)names_.size();
-    TagSpec tags;
+    TagSpec tags{};
     tags.n_ref = n_ref;
-    if (ch_tag_.size() == 2) { tags.have_ch = true; tags.ch0 = ch_tag_[0]; tags.ch1 = ch_tag_[1]; }
+    if (ch_tag_.size() == 2) { tags.have_ch = 1; tags.ch0 = (uint8_t)ch_tag_[0]; tags.ch1 = (uint8_t)ch_tag_[1]; }
     for (size_t fi = 0; fi < filter_tags_.size() && fi < RSQC_MAX_FILTER_TAGS; ++fi) {
         // a tag name that is not two characters long can never match; keep its bit position
         tags.f0[tags.n_filter] = filter_tags_[fi].size() == 2 ? filter_tags_[fi][0] : '\0';
         tags.f1[tags.n_filter] = filter_tags_[fi].size() == 2 ? filter_tags_[fi][1] : '\0';
         ++tags.n_filter;
     }
+    // diagnostic (tools/decode_sweep.py --inflate-only): consume the inflated stream without framing or parsing it
+    static const bool drain_only = getenv("RSQC_HOST_INFLATE_ONLY") != nullptr;
+    if (drain_only) { while (fill_group()) pos_ = buf_.size(); return 0; }
     static thread_local std::vector<ChunkOut> tl_chunks;         // capacity is reused from group to group
     std::vector<ChunkOut> &chunks = tl_chunks;                   // (the workers must see THIS thread's instance)
     while (n < max_records) {
