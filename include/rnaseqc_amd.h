@@ -62,6 +62,8 @@ extern "C" {
 #define RSQC_ERR_CAPACITY   -4   /* a fixed device-side capacity was exceeded            */
 #define RSQC_ERR_NO_DEVICE  -5   /* no HIP device: there is NO CPU fallback              */
 #define RSQC_ERR_EMPTY_MEDIAN -6 /* std::range_error of computeMedian (src/Metrics.h:149) */
+#define RSQC_ERR_INPUT      -7   /* rsqc_decode_*: corrupt BGZF block / malformed or truncated BAM record (the reference
+                                    ends with htslib's read error)                       */
 
 /* ---- BAM flag bits (SAM spec; accessors used at src/RNASeQC.cpp:254-330) */
 #define RSQC_FPAIRED   0x1
@@ -455,6 +457,54 @@ RSQC_API void rsqc_host_free(void *p);
 /* rsqc_finalize without the read-back: runs the end-of-file stage and leaves every result on the device
  * (multi-GPU runs reduce the accumulators first and read back once with rsqc_refresh_results).            */
 RSQC_API int rsqc_finalize_device(rsqc_ctx *ctx);
+
+/* ---- device-side BAM decode --------------------------------------------------------------
+ * The input side of the per-read path, moved to the GPU: the caller reads the file and hops over the BGZF block
+ * headers (src/BamReader.cpp:12-20 does this through htslib's bgzf.c, one thread, inflate included); inflating
+ * (one wavefront per block), finding the records and parsing them into an rsqc_batch run on the device, and the
+ * batch is submitted as by rsqc_submit.  One stream of consecutive blocks between rsqc_decode_begin and
+ * rsqc_decode_end; a record that straddles two calls is carried over on the device.                              */
+typedef struct rsqc_bgzf_block {
+    uint64_t in_offset;                /* first DEFLATE byte of the block, from `compressed`                   */
+    uint32_t in_bytes;                 /* DEFLATE bytes (BSIZE + 1 - XLEN - 20)                                */
+    uint32_t out_bytes;                /* ISIZE (<= 65536)                                                     */
+    uint32_t crc32;                    /* of the inflated bytes (the gzip trailer)                             */
+    uint32_t reserved;
+} rsqc_bgzf_block;
+typedef struct rsqc_decode_params {
+    int32_t n_ref;                     /* reference sequences in the BAM header                                */
+    int32_t has_chimeric_tag;          /* --chimeric-tag (readStringTag, src/RNASeQC.cpp:780-800)              */
+    char    chimeric_tag[2];
+    char    filter_tag[RSQC_MAX_FILTER_TAGS][2];   /* params.n_filter_tags names; {0,0} never matches          */
+    uint64_t file_index_base;          /* index of the stream's first record in the whole file                 */
+} rsqc_decode_params;
+typedef struct rsqc_decode_info {
+    uint64_t records;                  /* records decoded and submitted since rsqc_decode_begin                */
+    int32_t  unsorted;                 /* a record starts before its predecessor on the same contig, judged on primary,
+                                          mapped, QC-passed records: the reference's sort warning (src/RNASeQC.cpp:354) */
+    int32_t  n_bad_refid;              /* records whose RefID the header does not define (:333-337) ...        */
+    const char *const *bad_refid;      /* ... and the first 64 of their names (owned by the context)           */
+} rsqc_decode_info;
+typedef struct rsqc_decode_window {    /* what one rsqc_decode_submit decoded (arrays owned by the context, valid until its next call) */
+    uint64_t n_records;
+    uint32_t n_runs;                   /* runs of consecutive records on one reference sequence ...            */
+    const int32_t *run_tid;            /* ... their RefIDs, in file order (the batch's contig segments)        */
+} rsqc_decode_window;
+RSQC_API int rsqc_decode_begin(rsqc_ctx *ctx, const rsqc_decode_params *p);
+/* Inflates n_blocks consecutive blocks behind what the stream already holds, decodes every complete record and submits
+ * them as one batch (asynchronous like rsqc_submit; `compressed` may be reused when the call returns).
+ * skip_bytes: inflated bytes at the start of the first block that precede the first record (the BAM header, or the
+ * in-block part of a virtual file offset) -- only in a call that starts on a record boundary.
+ * limit_bytes: 0, or the inflated offset (counted from the first block of THIS call) at which the wanted range ends:
+ * records that start there or later are left out.  out (may be NULL): what the call decoded.
+ * Limits per call: 1 GiB of inflated data.                                                                        */
+RSQC_API int rsqc_decode_submit(rsqc_ctx *ctx, const void *compressed, uint64_t compressed_bytes,
+                                const rsqc_bgzf_block *blocks, uint32_t n_blocks,
+                                uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out);
+/* Test hook: the batch the last rsqc_decode_submit produced, as DEVICE pointers (valid until the next decode call). */
+RSQC_API int rsqc_debug_last_decoded(rsqc_ctx *ctx, rsqc_batch *out);
+/* End of the stream: RSQC_ERR_INPUT if an incomplete record is left over ("truncated BAM record").             */
+RSQC_API int rsqc_decode_end(rsqc_ctx *ctx, rsqc_decode_info *out);
 
 RSQC_API const char *rsqc_strerror(int code);
 RSQC_API const char *rsqc_last_error(rsqc_ctx *ctx);

@@ -1,0 +1,205 @@
+#include "bgzf_feed.hpp"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace rsqc_host {
+
+namespace {
+inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// BSIZE of the block whose header starts at h (avail bytes readable): 0 = not enough bytes yet; throws on a bad header
+uint32_t block_size(const uint8_t *h, size_t avail) {
+    if (avail < 18) return 0;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF block (bad gzip header)");
+    const uint32_t xlen = le16(h + 10);
+    if (avail < 12u + xlen) return 0;
+    uint32_t bsize = 0;
+    for (size_t o = 0; o + 4 <= xlen;) {
+        const uint8_t *x = h + 12 + o;
+        const uint32_t slen = le16(x + 2);
+        if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = le16(x + 4) + 1;
+        o += 4 + (size_t)slen;
+    }
+    if (!bsize) throw std::runtime_error("BGZF block without BC field");
+    if (bsize < 12u + xlen + 8u) throw std::runtime_error("bad BGZF block size");
+    return bsize;
+}
+}  // namespace
+
+BgzfFeeder::~BgzfFeeder() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+    for (auto &c : ring_) if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
+    if (fd_ >= 0) close(fd_);
+}
+
+bool BgzfFeeder::open(const std::string &path) {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) return false;
+    struct stat st;
+    if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    file_size_ = (uint64_t)st.st_size;
+    return true;
+}
+
+uint64_t BgzfFeeder::first_record_voffset() {
+    std::vector<uint8_t> raw, text;
+    std::vector<std::pair<uint64_t, uint64_t>> blocks;                 // (file offset, inflated bytes before the block)
+    uint64_t fpos = 0;
+    auto need = [&](size_t n) {                                         // inflate blocks until `text` holds n bytes
+        while (text.size() < n) {
+            uint8_t head[18 + 65536];
+            const ssize_t got = pread(fd_, head, sizeof head, (off_t)fpos);
+            if (got < 18) throw std::runtime_error("truncated BAM header");
+            const uint32_t bs = block_size(head, (size_t)got);
+            if (!bs || bs > (uint32_t)got) throw std::runtime_error("truncated BAM header");
+            const uint32_t xlen = le16(head + 10), isize = le32(head + bs - 4);
+            if (isize > 65536u) throw std::runtime_error("BGZF block with ISIZE above 64 KiB (corrupt trailer)");
+            blocks.emplace_back(fpos, (uint64_t)text.size());
+            const size_t at = text.size();
+            text.resize(at + isize);
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
+            zs.next_in = head + 12 + xlen; zs.avail_in = bs - xlen - 20;
+            zs.next_out = text.data() + at; zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) throw std::runtime_error("BGZF inflate failed (corrupt block)");
+            fpos += bs;
+        }
+    };
+    need(12);
+    if (memcmp(text.data(), "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file");
+    const uint32_t l_text = le32(text.data() + 4);
+    need(12 + (size_t)l_text);
+    const uint32_t n_ref = le32(text.data() + 8 + l_text);
+    size_t p = 12 + (size_t)l_text;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        need(p + 4);
+        const uint32_t l_name = le32(text.data() + p);
+        need(p + 8 + (size_t)l_name);
+        p += 8 + (size_t)l_name;
+    }
+    // the block that holds inflated offset p (the next block when the header ends with its block)
+    for (size_t b = blocks.size(); b-- > 0;)
+        if (blocks[b].second <= p) {
+            const uint64_t in_block = p - blocks[b].second;
+            const uint64_t block_len = (b + 1 < blocks.size() ? blocks[b + 1].second : (uint64_t)text.size()) - blocks[b].second;
+            if (in_block == block_len) return fpos << 16;                // (b is the last block inflated)
+            return (blocks[b].first << 16) | in_block;
+        }
+    return 0;
+}
+
+void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes, uint64_t max_out) {
+    cpos_ = voff_beg >> 16; skip_ = (uint32_t)(voff_beg & 0xffff);
+    cend_ = voff_end >> 16; uend_ = (uint32_t)(voff_end & 0xffff);
+    has_end_ = voff_end != 0;
+    chunk_bytes_ = std::max<size_t>(chunk_bytes, (size_t)1 << 17); max_out_ = max_out;      // (a chunk holds at least one whole block)
+    done_ = cpos_ >= file_size_;
+    for (auto &c : ring_) if (!c.data || c.cap < chunk_bytes_) {
+        if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
+        c.data = (uint8_t *)rsqc_host_alloc(chunk_bytes_ + 64); c.pinned = c.data != nullptr;
+        if (!c.data) c.data = (uint8_t *)malloc(chunk_bytes_ + 64);       // (no device: the tests of the feeder alone)
+        if (!c.data) throw std::bad_alloc();
+        c.cap = chunk_bytes_;
+    }
+    head_ = tail_ = count_ = 0; lent_ = nullptr; eof_ = false; stop_ = false; error_.clear();
+    if (th_.joinable()) th_.join();
+    th_ = std::thread([this] { producer(); });
+}
+
+bool BgzfFeeder::fill(Chunk &c) {
+    c.blocks.clear(); c.bytes = 0; c.skip = 0; c.limit = 0; c.last = false;
+    if (done_) return false;
+    const size_t want = (size_t)std::min<uint64_t>(chunk_bytes_, file_size_ - cpos_);
+    // the slices of one chunk are read side by side (a single pread stream from the page cache is ~3-5 GB/s)
+    const int T = std::max(1, std::min(read_threads, (int)(want >> 22) + 1));
+    std::vector<std::thread> th;
+    std::vector<ssize_t> got((size_t)T, 0);
+    const size_t per = (want + (size_t)T - 1) / (size_t)T;
+    auto job = [&](int t) {
+        size_t off = (size_t)t * per; const size_t end = std::min(want, off + per);
+        while (off < end) {
+            const ssize_t g = pread(fd_, c.data + off, end - off, (off_t)(cpos_ + off));
+            if (g <= 0) { got[(size_t)t] = -1; return; }
+            off += (size_t)g;
+        }
+        got[(size_t)t] = 1;
+    };
+    for (int t = 1; t < T; ++t) th.emplace_back(job, t);
+    job(0);
+    for (auto &x : th) x.join();
+    for (ssize_t g : got) if (g < 0) throw std::runtime_error("read error on the BAM file");
+    size_t p = 0; uint64_t total_out = 0;
+    while (p < want) {
+        const uint32_t bs = block_size(c.data + p, want - p);
+        if (!bs || p + bs > want) break;                               // the chunk ends inside this block
+        const uint64_t coff = cpos_ + p;
+        if (has_end_ && (coff > cend_ || (coff == cend_ && uend_ == 0))) { done_ = true; break; }
+        const uint32_t xlen = le16(c.data + p + 10), isize = le32(c.data + p + bs - 4);
+        if (isize > 65536u) throw std::runtime_error("BGZF block with ISIZE above 64 KiB (corrupt trailer)");
+        if (total_out + isize > max_out_ && !c.blocks.empty()) break;
+        c.blocks.push_back(rsqc_bgzf_block{(uint64_t)p + 12 + xlen, bs - xlen - 20, isize, le32(c.data + p + bs - 8), 0});
+        total_out += isize; p += bs;
+        if (has_end_ && coff == cend_) { c.limit = total_out - isize + uend_; done_ = true; break; }
+    }
+    if (c.blocks.empty() && !done_) {
+        if (cpos_ + want >= file_size_) throw std::runtime_error("truncated BGZF block");
+        throw std::runtime_error("BGZF block larger than the read chunk");
+    }
+    c.bytes = p; cpos_ += p;
+    c.skip = skip_; skip_ = 0;
+    if (cpos_ >= file_size_) done_ = true;
+    c.last = done_;
+    return !c.blocks.empty() || c.last;
+}
+
+void BgzfFeeder::producer() {
+    for (;;) {
+        Chunk *slot;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || count_ + (lent_ ? 1 : 0) < 3; });
+            if (stop_) return;
+            slot = &ring_[head_];
+        }
+        bool ok = false; std::string err;
+        try { ok = fill(*slot); } catch (std::exception &e) { err = e.what(); }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!err.empty()) { error_ = err; eof_ = true; }
+            else if (!ok) eof_ = true;
+            else { head_ = (head_ + 1) % 3; ++count_; if (slot->last) eof_ = true; }
+        }
+        cv_.notify_all();
+        if (eof_) return;
+    }
+}
+
+BgzfFeeder::Chunk *BgzfFeeder::next() {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (lent_) { lent_ = nullptr; cv_.notify_all(); }
+    cv_.wait(lk, [&] { return count_ > 0 || eof_; });
+    if (count_ == 0) {
+        if (!error_.empty()) throw std::runtime_error(error_);
+        return nullptr;
+    }
+    Chunk *c = &ring_[tail_];
+    tail_ = (tail_ + 1) % 3; --count_;
+    lent_ = c;
+    cv_.notify_all();
+    return c;
+}
+
+}  // namespace rsqc_host

@@ -1,0 +1,54 @@
+// bgzf_feed.hpp -- host side of the device BAM decode (rsqc_decode_*): reads the file in large page-locked chunks and
+// hops over the BGZF block headers (18 bytes per block); inflating, record framing and parsing happen on the GPU.
+// Replaces, together with the device kernels, the reference's SeqlibReader loop (src/BamReader.{h,cpp}) for BAM input.
+#pragma once
+
+#include <cstdint>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/rnaseqc_amd.h"
+
+namespace rsqc_host {
+
+class BgzfFeeder {
+public:
+    struct Chunk {
+        uint8_t *data = nullptr; size_t cap = 0, bytes = 0; bool pinned = false;   // page-locked when a device is present
+        std::vector<rsqc_bgzf_block> blocks;
+        uint32_t skip = 0;                                         // inflated bytes of the first block that precede the first record
+        uint64_t limit = 0;                                        // 0, or the inflated offset (from the chunk's first block) where the range ends
+        bool last = false;                                         // the range / file ends with this chunk
+    };
+    BgzfFeeder() = default;
+    ~BgzfFeeder();
+    BgzfFeeder(const BgzfFeeder &) = delete;
+    BgzfFeeder &operator=(const BgzfFeeder &) = delete;
+
+    bool open(const std::string &path);
+    // Virtual offset (coffset << 16 | uoffset) of the first alignment record: inflates the header's blocks on the host.
+    // Throws std::runtime_error on a file that is not a BAM.
+    uint64_t first_record_voffset();
+    // the blocks from virtual offset `beg` to `end` (0 = end of file); starts the read-ahead thread
+    void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)48 << 20, uint64_t max_out = (uint64_t)768 << 20);
+    // next chunk, or nullptr at the end; the previous chunk becomes reusable.  Throws on a malformed block header.
+    Chunk *next();
+    int read_threads = 4;
+
+private:
+    void producer();
+    bool fill(Chunk &c);
+    int fd_ = -1; uint64_t file_size_ = 0;
+    uint64_t cpos_ = 0, cend_ = 0; uint32_t skip_ = 0, uend_ = 0; bool done_ = false, has_end_ = false;
+    size_t chunk_bytes_ = 0; uint64_t max_out_ = 0;
+    Chunk ring_[3];
+    int head_ = 0, tail_ = 0, count_ = 0; Chunk *lent_ = nullptr;
+    bool eof_ = false, stop_ = false; std::string error_;
+    std::mutex mu_; std::condition_variable cv_;
+    std::thread th_;
+};
+
+}  // namespace rsqc_host

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "bam.hpp"
+#include "bgzf_feed.hpp"
 #include "gtf.hpp"
 #include "report.hpp"
 
@@ -113,3 +114,33 @@ HAPI const char *host_bam_contig(void *h, int i) { return ((BamHandle *)h)->name
 HAPI void host_bam_free(void *h) { delete (BamHandle *)h; }
 
 // (the synthetic BAM writer lives in bam_write.cpp)
+
+// ---- the device decode's host side (bgzf_feed.hpp) for the tests: chunks of framed BGZF blocks
+namespace { struct FeedHandle { rsqc_host::BgzfFeeder feed; std::string error; }; }
+HAPI void *host_feed_open(const char *path) {
+    FeedHandle *h = new FeedHandle();
+    if (!h->feed.open(path)) { delete h; return nullptr; }
+    return h;
+}
+HAPI unsigned long long host_feed_first_voffset(void *hv) {
+    FeedHandle *h = (FeedHandle *)hv;
+    try { return h->feed.first_record_voffset(); } catch (std::exception &e) { h->error = e.what(); return ~0ull; }
+}
+HAPI int host_feed_start(void *hv, unsigned long long voff_beg, unsigned long long voff_end, unsigned long long chunk_bytes, unsigned long long max_out, int read_threads) {
+    FeedHandle *h = (FeedHandle *)hv;
+    try { h->feed.read_threads = read_threads; h->feed.start(voff_beg, voff_end, (size_t)chunk_bytes, max_out); return 0; }
+    catch (std::exception &e) { h->error = e.what(); return -1; }
+}
+// 1 = a chunk, 0 = end of the range, -1 = error (host_feed_error)
+HAPI int host_feed_next(void *hv, const uint8_t **data, unsigned long long *bytes, const rsqc_bgzf_block **blocks, uint32_t *n_blocks,
+                        uint32_t *skip, unsigned long long *limit, int *last) {
+    FeedHandle *h = (FeedHandle *)hv;
+    try {
+        rsqc_host::BgzfFeeder::Chunk *c = h->feed.next();
+        if (!c) return 0;
+        *data = c->data; *bytes = c->bytes; *blocks = c->blocks.data(); *n_blocks = (uint32_t)c->blocks.size(); *skip = c->skip; *limit = c->limit; *last = c->last ? 1 : 0;
+        return 1;
+    } catch (std::exception &e) { h->error = e.what(); return -1; }
+}
+HAPI const char *host_feed_error(void *hv) { return ((FeedHandle *)hv)->error.c_str(); }
+HAPI void host_feed_free(void *hv) { delete (FeedHandle *)hv; }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "bam.hpp"
+#include "bgzf_feed.hpp"
 #include "fasta.hpp"
 #include "gtf.hpp"
 #include "report.hpp"
@@ -195,9 +196,64 @@ struct Shard {
 
 constexpr int kFileIndexShift = 36;      // virtual file index of a batch: (contig << 36) + records of the contig before it
 
+// ---- device decode (rsqc_decode_*): the default.  RSQC_DECODE=host keeps inflate + record parsing on the CPU threads.
+bool device_decode_wanted() {
+    const char *e = getenv("RSQC_DECODE");
+    return !(e && (!strcmp(e, "host") || !strcmp(e, "cpu")));
+}
+rsqc_decode_params decode_params(const Options &o, int n_ref, uint64_t file_index_base) {
+    rsqc_decode_params dp{};
+    dp.n_ref = n_ref;
+    if (o.chimeric_tag.size() == 2) { dp.has_chimeric_tag = 1; dp.chimeric_tag[0] = o.chimeric_tag[0]; dp.chimeric_tag[1] = o.chimeric_tag[1]; }
+    for (size_t k = 0; k < o.tags.size() && k < RSQC_MAX_FILTER_TAGS; ++k)
+        if (o.tags[k].size() == 2) { dp.filter_tag[k][0] = o.tags[k][0]; dp.filter_tag[k][1] = o.tags[k][1]; }   // (other lengths never match)
+    dp.file_index_base = file_index_base;
+    return dp;
+}
+// One stream of BGZF blocks [voff_beg, voff_end) through the GPU: the feeder reads and frames the blocks, every chunk is one
+// rsqc_decode_submit.  on_window sees what each call decoded.  Returns an RSQC_* code; info describes the whole stream.
+template <class F>
+int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, uint64_t voff_beg, uint64_t voff_end, rsqc_decode_info &info, F &&on_window) {
+    int rc = rsqc_decode_begin(gpu, &dp);
+    if (rc != RSQC_OK) return rc;
+    feed.start(voff_beg, voff_end);
+    while (BgzfFeeder::Chunk *ch = feed.next()) {
+        if (ch->blocks.empty()) continue;
+        rsqc_decode_window w{};
+        rc = rsqc_decode_submit(gpu, ch->data, ch->bytes, ch->blocks.data(), (uint32_t)ch->blocks.size(), ch->skip, ch->limit, &w);
+        if (rc != RSQC_OK) { rsqc_decode_info dropped{}; (void)rsqc_decode_end(gpu, &dropped); return rc; }
+        on_window(w);
+    }
+    return rsqc_decode_end(gpu, &info);
+}
+
 void shard_worker(Shard &sh, const std::string &bam_path, const Options &o, int threads, const std::vector<BamReader::ContigRange> &index,
-                  int n_ref, uint64_t tail_voff, size_t BATCH) {
+                  int n_ref, uint64_t tail_voff, size_t BATCH, bool device_decode) {
     try {
+        if (device_decode) {
+            BgzfFeeder feed;
+            if (!feed.open(bam_path)) { sh.rc = RSQC_ERR_ARG; sh.error = "Unable to open BAM file: " + bam_path; return; }
+            feed.read_threads = std::max(1, threads / 4);
+            std::vector<int> ranges = sh.contigs;
+            if (sh.tail) ranges.push_back(n_ref);
+            for (int c : ranges) {
+                const bool is_tail = c == n_ref;
+                rsqc_decode_info di{};
+                bool stale = false;
+                sh.rc = decode_range(sh.gpu, feed, decode_params(o, n_ref, (uint64_t)c << kFileIndexShift), is_tail ? tail_voff : index[(size_t)c].beg,
+                                     is_tail ? 0 : index[(size_t)c].end, di, [&](const rsqc_decode_window &w) {
+                                         sh.n_records += w.n_records;
+                                         for (uint32_t k = 0; k < w.n_runs; ++k) if (is_tail ? w.run_tid[k] >= 0 : w.run_tid[k] != c) stale = true;
+                                     });
+                if (sh.rc != RSQC_OK) { sh.error = rsqc_last_error(sh.gpu); return; }
+                if (stale) { sh.rc = RSQC_ERR_ARG; sh.error = is_tail ? "placed records behind the last indexed contig: stale index?" : "records of another contig inside an indexed range: stale index?"; return; }
+                if (di.unsorted) sh.unsorted = true;
+                for (int k = 0; k < di.n_bad_refid && k < 64; ++k) if (sh.bad_refid.size() < 64) sh.bad_refid.push_back(di.bad_refid[k]);
+            }
+            sh.rc = rsqc_finalize_device(sh.gpu);
+            if (sh.rc != RSQC_OK) sh.error = rsqc_last_error(sh.gpu);
+            return;
+        }
         HostBatch bufs[2];
         for (auto &hb : bufs) { hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.cigar.use_pinned(true); hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.cigar.reserve(BATCH * 2); }
         int cur = 0; bool in_flight = false;
@@ -414,6 +470,10 @@ int main(int argc, char **argv) {
             std::vector<std::vector<uint8_t>>().swap(fasta_seq);              // the bases live on the device now
         }
 
+        // device decode needs exact range ends from the index when the file is sharded
+        bool device_decode = device_decode_wanted();
+        if (device_decode && shards.size() > 1)
+            for (auto &r : bam.index()) if (r.present && !r.end) device_decode = false;
         if (o.verbosity) cout << "Parsing bam..." << endl;
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
         HostBatch bufs[2];
@@ -432,7 +492,7 @@ int main(int argc, char **argv) {
             if (const char *e = getenv("RSQC_HOST_THREADS")) budget = atoi(e);
             const int per = std::max(2, budget / (int)shards.size());
             std::vector<std::thread> th;
-            for (auto &sh : shards) th.emplace_back(shard_worker, std::ref(sh), std::cref(bam_path), std::cref(o), per, std::cref(bam.index()), n_ref_bam, tail_voff, BATCH);
+            for (auto &sh : shards) th.emplace_back(shard_worker, std::ref(sh), std::cref(bam_path), std::cref(o), per, std::cref(bam.index()), n_ref_bam, tail_voff, BATCH, device_decode);
             for (auto &t : th) t.join();
             rc = RSQC_OK;
             for (auto &sh : shards) {
@@ -454,6 +514,38 @@ int main(int argc, char **argv) {
                 cout << "Alignments processed: " << alignmentCount << " on " << shards.size() << " GPUs (";
                 for (size_t g = 0; g < shards.size(); ++g) cout << (g ? ", " : "") << shards[g].n_records;
                 cout << " records)" << endl;
+            }
+        } else if (device_decode) {
+            // ---- one GPU, device decode: the host reads the file and frames the BGZF blocks, nothing else
+            BgzfFeeder feed;
+            if (!feed.open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+            feed.read_threads = std::max(1, std::min(8, effective_cpus() / 2));
+            rsqc_decode_info di{};
+            rc = decode_range(gpu, feed, decode_params(o, n_ref_bam, 0), feed.first_record_voffset(), 0, di, [&](const rsqc_decode_window &w) {
+                bool revisit = false;
+                for (uint32_t k = 0; k < w.n_runs; ++k) {
+                    const int32_t t = w.run_tid[k];
+                    if (t < 0 || (!visit.empty() && visit.back() == t)) continue;
+                    if (std::find(visit.begin(), visit.end(), t) != visit.end()) revisit = true;     // a contig that comes back
+                    visit.push_back(t);
+                    if (o.has_fasta && (size_t)t < in_fasta.size() && !in_fasta[(size_t)t])      // src/RNASeQC.cpp:350-352
+                        cerr << "Warning: Provided Fasta does not contain chromosome " << ann.contig_names[(size_t)t]
+                             << ". No GC statistics will be collected for this chromosome" << endl;
+                }
+                if (revisit && !warned_unsorted) {
+                    cerr << "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results" << endl;
+                    warned_unsorted = true;
+                }
+                alignmentCount += w.n_records;
+                if (o.verbosity > 1) cout << "Alignments processed: " << alignmentCount << endl;
+            });
+            if (rc == RSQC_ERR_INPUT) throw std::runtime_error(rsqc_last_error(gpu));
+            if (rc == RSQC_OK) {
+                if (o.verbosity) for (int k = 0; k < di.n_bad_refid && k < 64; ++k) cerr << "Unrecognized RefID on alignment: " << di.bad_refid[k] << endl;
+                if (di.unsorted && !warned_unsorted) {
+                    cerr << "Warning: The input bam does not appear to be sorted. An unsorted bam will yield incorrect results" << endl;
+                    warned_unsorted = true;
+                }
             }
         } else
         for (;;) {
@@ -503,7 +595,8 @@ int main(int argc, char **argv) {
             const double secs = std::chrono::duration<double>(tb1 - tb0).count();
             cout << "Time Elapsed: " << secs << "; Alignments processed: " << alignmentCount << endl;
             if (o.verbosity > 1) cout << "Average Reads/Sec: " << (double)alignmentCount / secs << endl;
-            if (o.verbosity > 1 && shards.size() == 1) cout << "(decode threads: " << bam.inflate_threads() << " inflate + " << bam.parse_threads() << " parse)" << endl;
+            if (o.verbosity > 1 && device_decode) cout << "(decode: BGZF inflate and record parsing on the GPU)" << endl;
+            else if (o.verbosity > 1 && shards.size() == 1) cout << "(decode threads: " << bam.inflate_threads() << " inflate + " << bam.parse_threads() << " parse)" << endl;
             cout << "Estimating library complexity..." << endl;
             cout << "Generating report" << endl;
         }

@@ -18,6 +18,7 @@
 
 #include "rsqc_device.h"
 #include "rsqc_index.h"
+#include "rsqc_decode.h"
 
 using namespace rsqc;
 
@@ -68,6 +69,28 @@ struct GcBuf {                  // fragment GC candidates of one submitted batch
 struct Arena {
     DevBuf col[6]; size_t width[6] = {0, 0, 0, 0, 0, 0}; int n_col = 0;
     uint64_t used = 0, cap = 0;
+};
+
+// device-side BAM decode (rsqc_decode_*): the window buffers are sized once for the largest call and reused; the batch
+// columns a window is parsed into are read by the per-read kernels of that window before the next window's kernels
+// (same stream) overwrite them
+struct DecodeState {
+    bool active = false;
+    BamTagSpec tags{};
+    uint64_t next_file_index = 0, records = 0;
+    uint32_t head = 1u << 22;          // room in front of the window for the carried-over part of a record
+    uint32_t tail = 0;                 // bytes carried over, parked at [head - tail, head)
+    size_t out_cap = 0, comp_cap = 0, blk_cap = 0;
+    DevBuf comp, blocks, ubuf, seg, seg_rec0, seg_ops0, rec_off, ops_at, mark, core, aux, cigar, seg_tid, seg_start,
+           wide_index, wide_nm, wide_lq, wide_nc, sum, carry, tailtmp;
+    DecodeSummary *h_sum = nullptr;    // page-locked
+    DevBgzfBlock *h_blocks = nullptr;  // page-locked, blk_cap entries
+    bool unsorted = false;
+    uint64_t n_bad = 0;
+    std::vector<std::string> bad_names;
+    std::vector<const char *> bad_ptrs;
+    std::vector<int32_t> run_tid;      // contig segments of the last window
+    rsqc_batch last{};                 // the last window's batch (device pointers), for rsqc_debug_last_decoded
 };
 
 }  // namespace
@@ -147,6 +170,8 @@ struct rsqc_ctx {
     std::vector<DevBuf> upload_pool;            // device buffers of retired transient uploads
     std::vector<hipEvent_t> event_pool;
     rsqc_timing timing{};
+
+    DecodeState dec;
 
     // host results
     std::vector<uint64_t> h_fcount;
@@ -564,6 +589,13 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
     c->d_arena_count.release(); c->d_rl_summary.release();
+    {
+        DecodeState &D = c->dec;
+        for (DevBuf *b : {&D.comp, &D.blocks, &D.ubuf, &D.seg, &D.seg_rec0, &D.seg_ops0, &D.rec_off, &D.ops_at, &D.mark, &D.core, &D.aux, &D.cigar,
+                          &D.seg_tid, &D.seg_start, &D.wide_index, &D.wide_nm, &D.wide_lq, &D.wide_nc, &D.sum, &D.carry, &D.tailtmp}) b->release();
+        if (D.h_sum) (void)hipHostFree(D.h_sum);
+        if (D.h_blocks) (void)hipHostFree(D.h_blocks);
+    }
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
@@ -1172,6 +1204,186 @@ int rsqc_reset_timing(rsqc_ctx *c) {
     return RSQC_OK;
 }
 
+// ---- device-side BAM decode ---------------------------------------------------------------------------------------
+int rsqc_decode_begin(rsqc_ctx *c, const rsqc_decode_params *p) {
+    if (!c || !p || p->n_ref < 0) return RSQC_ERR_ARG;
+    if (!c->have_ann) return fail(c, RSQC_ERR_ARG, "rsqc_set_annotation must precede rsqc_decode_begin");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DecodeState &D = c->dec;
+    D.tags = BamTagSpec{};
+    D.tags.n_ref = p->n_ref;
+    if (p->has_chimeric_tag) { D.tags.have_ch = 1; D.tags.ch0 = (uint8_t)p->chimeric_tag[0]; D.tags.ch1 = (uint8_t)p->chimeric_tag[1]; }
+    D.tags.n_filter = (uint8_t)c->params.n_filter_tags;
+    for (int k = 0; k < c->params.n_filter_tags; ++k) { D.tags.f0[k] = (uint8_t)p->filter_tag[k][0]; D.tags.f1[k] = (uint8_t)p->filter_tag[k][1]; }
+    D.next_file_index = p->file_index_base; D.records = 0; D.tail = 0;
+    D.unsorted = false; D.n_bad = 0; D.bad_names.clear();
+    int rc;
+    if ((rc = dev_alloc(c, D.sum, sizeof(DecodeSummary), false)) || (rc = dev_alloc(c, D.carry, sizeof(DecodeCarry), true))) return rc;
+    if (!D.h_sum) HIP_TRY(c, hipHostMalloc((void **)&D.h_sum, sizeof(DecodeSummary), hipHostMallocDefault));
+    D.active = true;
+    return RSQC_OK;
+}
+
+namespace {
+// buffers for a window of `out_bytes` inflated bytes behind the head room
+int decode_reserve(rsqc_ctx *c, size_t out_bytes, size_t comp_bytes, size_t n_blocks) {
+    DecodeState &D = c->dec;
+    int rc;
+    if (comp_bytes + 64 > D.comp_cap) {
+        D.comp_cap = comp_bytes + comp_bytes / 4 + 64;
+        if ((rc = dev_alloc(c, D.comp, D.comp_cap, false))) return rc;
+    }
+    if (n_blocks > D.blk_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        D.blk_cap = n_blocks + n_blocks / 4 + 64;
+        if ((rc = dev_alloc(c, D.blocks, D.blk_cap * sizeof(DevBgzfBlock), false))) return rc;
+        if (D.h_blocks) (void)hipHostFree(D.h_blocks);
+        HIP_TRY(c, hipHostMalloc((void **)&D.h_blocks, D.blk_cap * sizeof(DevBgzfBlock), hipHostMallocDefault));
+    }
+    if (out_bytes <= D.out_cap) return 0;
+    const size_t cap = std::max<size_t>(out_bytes + out_bytes / 8, 64u << 20);
+    const size_t W = (size_t)D.head + cap;
+    // the window buffer keeps the carried-over bytes
+    DevBuf nu;
+    HIP_TRY(c, hipMalloc(&nu.p, W + 256)); nu.bytes = W + 256;
+    if (D.tail) HIP_TRY(c, hipMemcpyAsync((char *)nu.p + D.head - D.tail, (char *)D.ubuf.p + D.head - D.tail, D.tail, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    D.ubuf.release(); D.ubuf = nu;
+    const size_t n_seg = W / DEC_SEG_BYTES + 4, n_rec = W / 36 + 4;
+    if ((rc = dev_alloc(c, D.seg, n_seg * sizeof(BamSegment), false)) || (rc = dev_alloc(c, D.seg_rec0, n_seg * 4, false)) ||
+        (rc = dev_alloc(c, D.seg_ops0, n_seg * 4, false)) || (rc = dev_alloc(c, D.rec_off, n_rec * 4, false)) ||
+        (rc = dev_alloc(c, D.ops_at, n_rec * 4, false)) || (rc = dev_alloc(c, D.mark, n_rec, false)) ||
+        (rc = dev_alloc(c, D.core, n_rec * 16 + 64, false)) || (rc = dev_alloc(c, D.aux, n_rec * 16 + 64, false)) ||
+        (rc = dev_alloc(c, D.cigar, W + 256, false)) || (rc = dev_alloc(c, D.seg_tid, n_rec * 4 + 64, false)) ||
+        (rc = dev_alloc(c, D.seg_start, (n_rec + 1) * 8 + 64, false)) || (rc = dev_alloc(c, D.wide_index, n_rec * 8 + 64, false)) ||
+        (rc = dev_alloc(c, D.wide_nm, n_rec * 4 + 64, false)) || (rc = dev_alloc(c, D.wide_lq, n_rec * 4 + 64, false)) ||
+        (rc = dev_alloc(c, D.wide_nc, n_rec * 4 + 64, false))) return rc;
+    D.out_cap = cap;
+    return 0;
+}
+}  // namespace
+
+int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_bytes, const rsqc_bgzf_block *blocks, uint32_t n_blocks,
+                       uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out) {
+    if (!c || (!compressed && compressed_bytes) || (!blocks && n_blocks)) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    DecodeState &D = c->dec;
+    if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_submit");
+    if (out) { out->n_records = 0; out->n_runs = 0; out->run_tid = nullptr; }
+    D.last = rsqc_batch{};
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_blocks; ++k) {
+        const rsqc_bgzf_block &b = blocks[k];
+        if (b.out_bytes > 65536u || b.in_offset > compressed_bytes || b.in_bytes > compressed_bytes - b.in_offset)
+            return fail(c, RSQC_ERR_ARG, "BGZF block outside the compressed buffer or with ISIZE above 64 KiB");
+        total += b.out_bytes;
+    }
+    if (total > (1ull << 30)) return fail(c, RSQC_ERR_ARG, "more than 1 GiB of inflated data in one rsqc_decode_submit");
+    if (skip_bytes && D.tail) return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record");
+    if (skip_bytes > total) return fail(c, RSQC_ERR_ARG, "skip_bytes beyond the inflated data");
+    int rc;
+    if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
+    { uint32_t at = D.head;
+      for (uint32_t k = 0; k < n_blocks; ++k) { D.h_blocks[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; } }
+    if (compressed_bytes) HIP_TRY(c, hipMemcpyAsync(D.comp.p, compressed, (size_t)compressed_bytes, hipMemcpyHostToDevice, c->stream));
+    if (n_blocks) HIP_TRY(c, hipMemcpyAsync(D.blocks.p, D.h_blocks, (size_t)n_blocks * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(D.sum.p, 0, sizeof(DecodeSummary), c->stream));
+    launch_bgzf_inflate(c->stream, (const uint8_t *)D.comp.p, (const DevBgzfBlock *)D.blocks.p, n_blocks, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
+    const bool limited = limit_bytes && limit_bytes < total;
+    DecodeWindow W{};
+    W.buf = (const uint8_t *)D.ubuf.p;
+    W.start = D.head - D.tail + skip_bytes;
+    W.end = D.head + (uint32_t)(limited ? limit_bytes : total);
+    if (W.start > W.end) W.start = W.end;
+    W.n_seg = (W.end - W.start + DEC_SEG_BYTES - 1) / DEC_SEG_BYTES;
+    W.seg = (BamSegment *)D.seg.p; W.seg_rec0 = (uint32_t *)D.seg_rec0.p; W.seg_ops0 = (uint32_t *)D.seg_ops0.p;
+    W.rec_off = (uint32_t *)D.rec_off.p; W.ops_at = (uint32_t *)D.ops_at.p; W.mark = (uint8_t *)D.mark.p;
+    W.core = (rsqc_rec_core *)D.core.p; W.aux = (rsqc_rec_aux *)D.aux.p; W.cigar = (uint32_t *)D.cigar.p;
+    W.seg_tid = (int32_t *)D.seg_tid.p; W.seg_start = (uint64_t *)D.seg_start.p;
+    W.wide_index = (uint64_t *)D.wide_index.p; W.wide_nm = (int32_t *)D.wide_nm.p; W.wide_lq = (int32_t *)D.wide_lq.p; W.wide_nc = (uint32_t *)D.wide_nc.p;
+    W.sum = (DecodeSummary *)D.sum.p; W.carry = (DecodeCarry *)D.carry.p; W.tags = D.tags;
+    launch_decode_window(c->stream, W);
+    HIP_TRY(c, hipMemcpyAsync(D.h_sum, D.sum.p, sizeof(DecodeSummary), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    const DecodeSummary &S = *D.h_sum;
+    if (S.status & DEC_ST_INFLATE) {
+        c->sticky = RSQC_ERR_INPUT;
+        return fail(c, RSQC_ERR_INPUT, "BGZF inflate failed (corrupt block " + std::to_string((S.inflate_fail >> 4) - 1) + " of the call, code " + std::to_string(S.inflate_fail & 15u) + ")");
+    }
+    if (S.status & DEC_ST_BAD_RECORD) { c->sticky = RSQC_ERR_INPUT; return fail(c, RSQC_ERR_INPUT, "bad BAM record"); }
+    // the reference's stderr diagnostics
+    if (S.unsorted) D.unsorted = true;
+    for (uint32_t k = 0; k < S.n_bad && k < DEC_MAX_BAD && D.bad_names.size() < DEC_MAX_BAD; ++k) {
+        uint8_t raw[36 + 256] = {0};
+        const size_t room = std::min<size_t>(sizeof raw, (size_t)W.end - S.bad_off[k]);
+        HIP_TRY(c, hipMemcpy(raw, (const char *)D.ubuf.p + S.bad_off[k], room, hipMemcpyDeviceToHost));
+        const size_t l_name = raw[12];
+        D.bad_names.emplace_back((const char *)raw + 36, strnlen((const char *)raw + 36, std::min(l_name, room > 36 ? room - 36 : 0)));
+    }
+    D.n_bad += S.n_bad;
+    // what is left of the window: an incomplete record stays in front of the next one
+    const uint32_t left = limited ? 0u : W.end - S.consumed_end;
+    if (left) {
+        if ((rc = dev_alloc(c, D.tailtmp, left, false))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(D.tailtmp.p, (const char *)D.ubuf.p + S.consumed_end, left, hipMemcpyDeviceToDevice, c->stream));
+        if (left <= D.head) HIP_TRY(c, hipMemcpyAsync((char *)D.ubuf.p + D.head - left, D.tailtmp.p, left, hipMemcpyDeviceToDevice, c->stream));
+    }
+    D.run_tid.assign(S.n_seg, 0);
+    if (S.n_seg) HIP_TRY(c, hipMemcpy(D.run_tid.data(), D.seg_tid.p, (size_t)S.n_seg * 4, hipMemcpyDeviceToHost));
+    if (out) { out->n_records = S.n_rec; out->n_runs = S.n_seg; out->run_tid = D.run_tid.data(); }
+    if (S.n_rec) {
+        D.last.n = S.n_rec; D.last.file_index_base = D.next_file_index; D.last.core = W.core; D.last.aux = W.aux; D.last.cigar = W.cigar;
+        D.last.n_cigar_total = S.n_ops; D.last.n_seg = S.n_seg; D.last.seg_tid = W.seg_tid; D.last.seg_start = W.seg_start;
+        D.last.n_wide = S.n_wide; D.last.wide_index = W.wide_index; D.last.wide_nm = W.wide_nm; D.last.wide_l_qseq = W.wide_lq; D.last.wide_n_cigar = W.wide_nc;
+        UploadedBatch *u = new UploadedBatch();
+        u->pooled = false;
+        u->n = S.n_rec; u->n_cigar_total = S.n_ops; u->file_index_base = D.next_file_index;
+        DevBatch &d = u->d;
+        d.n = S.n_rec; d.core = W.core; d.aux = W.aux; d.cigar = W.cigar;
+        d.n_seg = S.n_seg; d.seg_tid = W.seg_tid; d.seg_start = W.seg_start;
+        d.n_wide = S.n_wide; d.wide_index = W.wide_index; d.wide_nm = W.wide_nm; d.wide_l_qseq = W.wide_lq; d.wide_n_cigar = W.wide_nc;
+        c->transient.push_back(u);
+        D.next_file_index += S.n_rec; D.records += S.n_rec;
+        if ((rc = run_batch(c, u))) return rc;
+    }
+    if (left > D.head) {
+        // a record larger than the head room: every window buffer is rebuilt around a larger one (the per-read kernels of
+        // this window finish first: releasing device memory waits for them)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t nh = D.head; while (nh < left) nh <<= 1;
+        const size_t keep = D.out_cap;
+        D.head = nh; D.out_cap = 0; D.tail = 0;
+        if ((rc = decode_reserve(c, keep, 0, 0))) return rc;
+        HIP_TRY(c, hipMemcpyAsync((char *)D.ubuf.p + D.head - left, D.tailtmp.p, left, hipMemcpyDeviceToDevice, c->stream));
+    }
+    D.tail = left;
+    return RSQC_OK;
+}
+
+int rsqc_debug_last_decoded(rsqc_ctx *c, rsqc_batch *out) {
+    if (!c || !out) return RSQC_ERR_ARG;
+    *out = c->dec.last;
+    return RSQC_OK;
+}
+
+int rsqc_decode_end(rsqc_ctx *c, rsqc_decode_info *out) {
+    if (!c) return RSQC_ERR_ARG;
+    DecodeState &D = c->dec;
+    if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_end");
+    D.active = false;
+    if (out) {
+        D.bad_ptrs.clear();
+        for (auto &n : D.bad_names) D.bad_ptrs.push_back(n.c_str());
+        out->records = D.records; out->unsorted = D.unsorted ? 1 : 0;
+        out->n_bad_refid = (int32_t)std::min<uint64_t>(D.n_bad, 0x7fffffff);
+        out->bad_refid = D.bad_ptrs.data();
+    }
+    if (D.tail) { D.tail = 0; return fail(c, RSQC_ERR_INPUT, "truncated BAM record"); }
+    return RSQC_OK;
+}
+
 const char *rsqc_strerror(int code) {
     switch (code) {
     case RSQC_OK: return "ok";
@@ -1181,6 +1393,7 @@ const char *rsqc_strerror(int code) {
     case RSQC_ERR_CAPACITY: return "device-side capacity exceeded";
     case RSQC_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
     case RSQC_ERR_EMPTY_MEDIAN: return "Cannot compute median of an empty list";
+    case RSQC_ERR_INPUT: return "corrupt or truncated BAM input";
     default: return "unknown error";
     }
 }

@@ -5,6 +5,7 @@
 // kernels execute can be diffed against zlib and against the host BAM reader in the GPU-less build container.
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../rnaseqc_amd/csrc/rsqc_inflate.h"
@@ -45,4 +46,56 @@ uint32_t emu_crc_wave64(const uint8_t *data, uint32_t n, uint32_t crc_before) {
         m = crc_mulmod(m, m);
     }
     return crc_mulmod(crc_before, crc_xpow(8ull * n)) ^ r[0];
+}
+
+// ---- one window of inflated data through frame / chain / offsets / parse / lists, the kernels' per-thread bodies run
+// serially.  `threads` = how many threads the lists step pretends to have (chunk boundaries, exclusive sums);
+// perturb != 0 moves some guesses, which the chain step has to repair.
+#include "../../rnaseqc_amd/csrc/rsqc_decode.h"
+
+extern "C" __attribute__((visibility("default")))
+int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const BamTagSpec *tags, int threads, int32_t *carry3, int perturb,
+                      rsqc_rec_core *core, rsqc_rec_aux *aux, uint32_t *cigar, int32_t *seg_tid, uint64_t *seg_start,
+                      uint64_t *wide_index, int32_t *wide_nm, int32_t *wide_lq, uint32_t *wide_nc, uint32_t *summary /* 8 + 64 */) {
+    DecodeWindow W{};
+    W.buf = buf; W.start = start; W.end = end;
+    W.n_seg = end > start ? (end - start + DEC_SEG_BYTES - 1) / DEC_SEG_BYTES : 0;
+    std::vector<BamSegment> seg(W.n_seg + 1);
+    std::vector<uint32_t> rec0(W.n_seg + 1), ops0(W.n_seg + 1);
+    W.seg = seg.data(); W.seg_rec0 = rec0.data(); W.seg_ops0 = ops0.data();
+    DecodeSummary sum{}; DecodeCarry carry{carry3[0], carry3[1], carry3[2]};
+    W.sum = &sum; W.carry = &carry; W.tags = *tags;
+    W.core = core; W.aux = aux; W.cigar = cigar; W.seg_tid = seg_tid; W.seg_start = seg_start;
+    W.wide_index = wide_index; W.wide_nm = wide_nm; W.wide_lq = wide_lq; W.wide_nc = wide_nc;
+    for (uint32_t s = 0; s < W.n_seg; ++s) decode_frame_one(W, s);
+    if (perturb) for (uint32_t s = 1; s < W.n_seg; s += 3) { seg[s].start += (s % 2) ? 1 : 40; seg[s].n_rec += 1; }
+    bool all = true;
+    for (uint32_t s = 0; s < W.n_seg; ++s) all = all && decode_guess_confirmed(W, s);
+    uint32_t consumed = start, bad = 0;
+    if (W.n_seg) consumed = all ? seg[W.n_seg - 1].land : bam_verify_chain(buf, seg.data(), W.n_seg, start, DEC_SEG_BYTES, end, bad);
+    uint32_t n = 0, ops = 0;
+    for (uint32_t s = 0; s < W.n_seg; ++s) { rec0[s] = n; ops0[s] = ops; n += seg[s].n_rec; ops += seg[s].n_ops; }
+    sum.n_rec = n; sum.n_ops = ops; sum.consumed_end = consumed; sum.status = bad ? DEC_ST_BAD_RECORD : 0;
+    std::vector<uint32_t> rec_off(n + 1), ops_at(n + 1); std::vector<uint8_t> mark(n + 1);
+    W.rec_off = rec_off.data(); W.ops_at = ops_at.data(); W.mark = mark.data();
+    if (!bad) {
+        for (uint32_t s = 0; s < W.n_seg; ++s) decode_offsets_one(W, s);
+        for (uint32_t i = 0; i < n; ++i) { bool u = false; sum.status |= decode_parse_one(W, i, u); if (u) sum.unsorted = 1; }
+        const uint32_t T = (uint32_t)threads, per = (n + T - 1) / T;
+        std::vector<DecodeListCounts> cnt(T), base(T);
+        DecodeListCounts run{0, 0, 0, -1};
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t lo = std::min(n, t * per), hi = std::min(n, lo + per);
+            decode_lists_count(W, lo, hi, cnt[t]);
+            base[t] = run;
+            run.seg += cnt[t].seg; run.wide += cnt[t].wide; run.bad += cnt[t].bad;
+            if (cnt[t].last_judged >= 0) run.last_judged = cnt[t].last_judged;
+        }
+        for (uint32_t t = 0; t < T; ++t) { const uint32_t lo = std::min(n, t * per), hi = std::min(n, lo + per); decode_lists_write(W, lo, hi, base[t]); }
+        decode_lists_finish(W, n, run);
+    }
+    memcpy(summary, &sum, 8 * 4);
+    memcpy(summary + 8, sum.bad_off, sizeof sum.bad_off);
+    carry3[0] = carry.have_q; carry3[1] = carry.q_tid; carry3[2] = carry.q_pos;
+    return 0;
 }
