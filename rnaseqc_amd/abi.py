@@ -11,7 +11,7 @@ import numpy as np
 ABI_VERSION = 1
 
 # error codes
-OK, ERR_ARG, ERR_HIP, ERR_BAD_CIGAR, ERR_CAPACITY, ERR_NO_DEVICE, ERR_EMPTY_MEDIAN = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_ARG, ERR_HIP, ERR_BAD_CIGAR, ERR_CAPACITY, ERR_NO_DEVICE, ERR_EMPTY_MEDIAN, ERR_INPUT = 0, -1, -2, -3, -4, -5, -6, -7
 
 # BAM flags
 FPAIRED, FPROPER, FUNMAP, FMUNMAP, FREVERSE, FMREVERSE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -127,6 +127,23 @@ class BatchStruct(C.Structure):
         ("wide_n_cigar", _P),
         ("qname_off", _P), ("qname", _P),
     ]
+
+
+class BgzfBlock(C.Structure):
+    _fields_ = [("in_offset", C.c_uint64), ("in_bytes", C.c_uint32), ("out_bytes", C.c_uint32), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [("n_ref", C.c_int32), ("has_chimeric_tag", C.c_int32), ("chimeric_tag", C.c_char * 2),
+                ("filter_tag", (C.c_char * 2) * MAX_FILTER_TAGS), ("file_index_base", C.c_uint64)]
+
+
+class DecodeWindow(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_runs", C.c_uint32), ("run_tid", _P)]
+
+
+class DecodeInfo(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("unsorted", C.c_int32), ("n_bad_refid", C.c_int32), ("bad_refid", _P)]
 
 
 class ResultsStruct(C.Structure):

@@ -216,7 +216,11 @@ template <class F>
 int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, uint64_t voff_beg, uint64_t voff_end, rsqc_decode_info &info, F &&on_window) {
     int rc = rsqc_decode_begin(gpu, &dp);
     if (rc != RSQC_OK) return rc;
-    feed.start(voff_beg, voff_end);
+    // (RSQC_DECODE_CHUNK / RSQC_DECODE_MAX_OUT: compressed bytes read per call / inflated bytes per call -- the tests use
+    //  small values so that records straddle many calls)
+    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)48 << 20;
+    const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)768 << 20;
+    feed.start(voff_beg, voff_end, chunk, max_out);
     while (BgzfFeeder::Chunk *ch = feed.next()) {
         if (ch->blocks.empty()) continue;
         rsqc_decode_window w{};

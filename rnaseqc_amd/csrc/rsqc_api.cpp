@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +90,9 @@ struct DecodeState {
     uint64_t n_bad = 0;
     std::vector<std::string> bad_names;
     std::vector<const char *> bad_ptrs;
+    // RSQC_DECODE_PROFILE: stage times of the stream, printed at rsqc_decode_end
+    bool profile = false; hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+    double ms_copy = 0, ms_inflate = 0, ms_parse = 0, ms_call = 0; uint64_t prof_in = 0, prof_out = 0, prof_calls = 0;
     std::vector<int32_t> run_tid;      // contig segments of the last window
     rsqc_batch last{};                 // the last window's batch (device pointers), for rsqc_debug_last_decoded
 };
@@ -1217,6 +1221,9 @@ int rsqc_decode_begin(rsqc_ctx *c, const rsqc_decode_params *p) {
     for (int k = 0; k < c->params.n_filter_tags; ++k) { D.tags.f0[k] = (uint8_t)p->filter_tag[k][0]; D.tags.f1[k] = (uint8_t)p->filter_tag[k][1]; }
     D.next_file_index = p->file_index_base; D.records = 0; D.tail = 0;
     D.unsorted = false; D.n_bad = 0; D.bad_names.clear();
+    D.profile = getenv("RSQC_DECODE_PROFILE") != nullptr;
+    D.ms_copy = D.ms_inflate = D.ms_parse = D.ms_call = 0; D.prof_in = D.prof_out = D.prof_calls = 0;
+    if (D.profile && !D.pe[0]) for (auto &e : D.pe) HIP_TRY(c, hipEventCreate(&e));
     int rc;
     if ((rc = dev_alloc(c, D.sum, sizeof(DecodeSummary), false)) || (rc = dev_alloc(c, D.carry, sizeof(DecodeCarry), true))) return rc;
     if (!D.h_sum) HIP_TRY(c, hipHostMalloc((void **)&D.h_sum, sizeof(DecodeSummary), hipHostMallocDefault));
@@ -1286,9 +1293,12 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
     { uint32_t at = D.head;
       for (uint32_t k = 0; k < n_blocks; ++k) { D.h_blocks[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; } }
+    const auto wall0 = std::chrono::steady_clock::now();
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[0], c->stream));
     if (compressed_bytes) HIP_TRY(c, hipMemcpyAsync(D.comp.p, compressed, (size_t)compressed_bytes, hipMemcpyHostToDevice, c->stream));
     if (n_blocks) HIP_TRY(c, hipMemcpyAsync(D.blocks.p, D.h_blocks, (size_t)n_blocks * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(D.sum.p, 0, sizeof(DecodeSummary), c->stream));
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[1], c->stream));
     launch_bgzf_inflate(c->stream, (const uint8_t *)D.comp.p, (const DevBgzfBlock *)D.blocks.p, n_blocks, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
     const bool limited = limit_bytes && limit_bytes < total;
     DecodeWindow W{};
@@ -1303,9 +1313,18 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     W.seg_tid = (int32_t *)D.seg_tid.p; W.seg_start = (uint64_t *)D.seg_start.p;
     W.wide_index = (uint64_t *)D.wide_index.p; W.wide_nm = (int32_t *)D.wide_nm.p; W.wide_lq = (int32_t *)D.wide_lq.p; W.wide_nc = (uint32_t *)D.wide_nc.p;
     W.sum = (DecodeSummary *)D.sum.p; W.carry = (DecodeCarry *)D.carry.p; W.tags = D.tags;
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[2], c->stream));
     launch_decode_window(c->stream, W);
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[3], c->stream));
     HIP_TRY(c, hipMemcpyAsync(D.h_sum, D.sum.p, sizeof(DecodeSummary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (D.profile) {
+        float a = 0, b = 0, d = 0;
+        (void)hipEventElapsedTime(&a, D.pe[0], D.pe[1]); (void)hipEventElapsedTime(&b, D.pe[1], D.pe[2]); (void)hipEventElapsedTime(&d, D.pe[2], D.pe[3]);
+        D.ms_copy += a; D.ms_inflate += b; D.ms_parse += d;
+        D.ms_call += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        D.prof_in += compressed_bytes; D.prof_out += total; D.prof_calls++;
+    }
     HIP_TRY(c, hipGetLastError());
     const DecodeSummary &S = *D.h_sum;
     if (S.status & DEC_ST_INFLATE) {
@@ -1373,6 +1392,10 @@ int rsqc_decode_end(rsqc_ctx *c, rsqc_decode_info *out) {
     DecodeState &D = c->dec;
     if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_end");
     D.active = false;
+    if (D.profile)
+        fprintf(stderr, "[decode] %llu calls, %.1f MB in, %.1f MB inflated: copy %.1f ms, inflate %.1f ms (%.2f GB/s out), frame+parse %.1f ms, host wait per call %.2f ms\n",
+                (unsigned long long)D.prof_calls, D.prof_in / 1e6, D.prof_out / 1e6, D.ms_copy, D.ms_inflate, D.ms_inflate > 0 ? D.prof_out / D.ms_inflate / 1e6 : 0.0,
+                D.ms_parse, D.prof_calls ? D.ms_call / (double)D.prof_calls : 0.0);
     if (out) {
         D.bad_ptrs.clear();
         for (auto &n : D.bad_names) D.bad_ptrs.push_back(n.c_str());

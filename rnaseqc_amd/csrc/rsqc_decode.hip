@@ -6,6 +6,9 @@
 // thread).  What the host still does: read the file and hop over the BGZF block headers.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "rsqc_inflate.h"
 #include "rsqc_decode.h"
 #include "rsqc_device.h"
@@ -13,10 +16,13 @@
 namespace rsqc {
 
 // ---- K0: one wave per BGZF block (work handed out by an atomic counter: block decode times differ) -----------------
-// LDS: 37.4 KB per wave, so four single-wave workgroups share a CU, one per SIMD.
-__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restrict__ in, const DevBgzfBlock *__restrict__ blk, uint32_t n_blk,
-                                                           uint8_t *__restrict__ out, DecodeSummary *sum) {
-    __shared__ InflateScratch S;
+// LDS: 8.7 KB per wave, registers capped for four waves per SIMD (sixteen per CU): the decoder is a chain of dependent scalar
+// instructions, so the waves of a SIMD take turns in its issue slots.  WPW waves share a workgroup, each with its own scratch.
+template <int WPW>
+__global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_inflate_kernel(const uint8_t *__restrict__ in, const DevBgzfBlock *__restrict__ blk, uint32_t n_blk,
+                                                                uint8_t *__restrict__ out, DecodeSummary *sum) {
+    __shared__ InflateScratch SS[WPW];
+    InflateScratch &S = SS[WPW == 1 ? 0 : (threadIdx.x >> 6)];
     inflate_crc_init(S);
     for (;;) {
         uint32_t b = 0;
@@ -115,8 +121,23 @@ __global__ __launch_bounds__(1024) void bam_lists_kernel(DecodeWindow W) {
 // ---- launches ----------------------------------------------------------------------------------------------------
 void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *blk, uint32_t n_blk, uint8_t *out, DecodeSummary *sum) {
     if (!n_blk) return;
-    const uint32_t grid = n_blk < 256u * 4u ? n_blk : 256u * 4u;          // one wave per SIMD of the chip; the counter feeds them
-    bgzf_inflate_kernel<<<grid, 64, 0, s>>>(in, blk, n_blk, out, sum);
+    // four waves per SIMD of the chip; the counter feeds them
+    static const int wpw = getenv("RSQC_INFLATE_WPW") ? atoi(getenv("RSQC_INFLATE_WPW")) : 4;
+    static bool told = false;
+    if (!told && getenv("RSQC_DECODE_PROFILE")) {
+        int a = 0, b = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bgzf_inflate_kernel<1>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bgzf_inflate_kernel<4>, 256, 0);
+        fprintf(stderr, "[decode] inflate kernel: %d workgroups of 1 wave or %d of 4 waves per CU; running %d waves per workgroup\n", a, b, wpw);
+        told = true;
+    }
+    if (wpw == 1) {
+        const uint32_t grid = n_blk < 256u * 16u ? n_blk : 256u * 16u;
+        bgzf_inflate_kernel<1><<<grid, 64, 0, s>>>(in, blk, n_blk, out, sum);
+    } else {
+        const uint32_t need = (n_blk + 3u) / 4u, grid = need < 256u * 4u ? need : 256u * 4u;
+        bgzf_inflate_kernel<4><<<grid, 256, 0, s>>>(in, blk, n_blk, out, sum);
+    }
 }
 void launch_decode_window(hipStream_t s, const DecodeWindow &W) {
     if (W.n_seg) bam_frame_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);

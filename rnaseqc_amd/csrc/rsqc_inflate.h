@@ -7,13 +7,17 @@
 //
 // Shape of the decoder on CDNA4:
 //  * the bit reader, the Huffman walk and the output position are WAVE-UNIFORM values (every lane computes the same
-//    thing; table entries come back from LDS through readfirstlane), so the compiler keeps them in SGPRs and the loop
-//    runs on the scalar unit;
+//    thing), so the compiler keeps them in SGPRs and the walk runs on the scalar unit;
+//  * the table look-ups are NOT serial: every lane looks both Huffman tables up at its own bit offset of the buffered
+//    input, and the walk hops from symbol to symbol with v_readlane; literals are gathered one per lane and stored
+//    together;
 //  * the compressed bytes arrive as one coalesced 256-byte vector load per 64 dwords (lane l holds dword l of the
 //    window, the next window is already in flight) and are handed to the bit reader with v_readlane;
-//  * the last 32 KiB of output -- the whole DEFLATE history -- live in an LDS ring, so a match is an LDS-to-LDS copy done
-//    by all lanes at once and never reads global memory back; the ring is written out to HBM 16 KiB at a time;
-//  * LDS per wave: 32 KiB ring + 3.5 KiB of decoding tables = one wave per SIMD (4 per CU, 160 KiB).
+//  * the last 4 KiB of output live in an LDS ring, so a match is an LDS-to-LDS copy done by all lanes at once; the ring goes
+//    out to HBM (and through the block's CRC-32) 1 KiB at a time, and the few matches that reach further back than the
+//    ring read the flushed bytes from HBM;
+//  * LDS per wave: 4 KiB ring + 4.6 KiB of tables, so four waves share a SIMD (the decoder is a chain of dependent
+//    scalar instructions: more waves is what fills the issue slots).
 //
 // The same source compiles for the host with a wave of ONE lane (tests/hostemu/decode_emu.cpp), which is how it is
 // checked against zlib in the GPU-less container.
@@ -41,6 +45,22 @@
 // a store done once per wave
 #define INF_ST(stmt) do { if (INF_LANE == 0u) { stmt; } } while (0)
 
+// One value per lane of the wave.  On the device that is a VGPR; the host build keeps an array of 64, so the tests run the
+// same 64-lane logic (speculative table look-ups at 64 bit offsets, literals gathered one per lane) on the CPU.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t InfVec;
+#define INF_FOREACH(k) for (uint32_t k = INF_LANE, once_ = 1u; once_; once_ = 0u)              /* the body runs once: k = this lane */
+#define INF_AT(vec, k) (vec)
+#define INF_GET(vec, k) ((uint32_t)__builtin_amdgcn_readlane((int)(vec), (int)(k)))           /* k wave-uniform */
+#define INF_SET(vec, k, x) ((vec) = (INF_LANE == (k)) ? (x) : (vec))
+#else
+struct InfVec { uint32_t v[64]; };
+#define INF_FOREACH(k) for (uint32_t k = 0; k < 64u; ++k)
+#define INF_AT(vec, k) ((vec).v[k])
+#define INF_GET(vec, k) ((vec).v[k])
+#define INF_SET(vec, k, x) ((vec).v[k] = (x))
+#endif
+
 namespace rsqc {
 
 enum InflateStatus {
@@ -55,9 +75,18 @@ enum InflateStatus {
     INF_ERR_CRC = 8
 };
 
-constexpr uint32_t INF_RING_BITS = 15, INF_RING = 1u << INF_RING_BITS, INF_RMASK = INF_RING - 1u;
+// The LDS ring holds the most recent INF_RING bytes of output; a match that reaches further back than INF_NEAR reads the
+// bytes from the stream in HBM, where they were flushed long before (INF_RING >= INF_FLUSH + 774 guarantees that, see
+// inflate_copy).  A small ring is what lets several waves share a SIMD: the decoder is a chain of dependent scalar
+// instructions, and the only way to fill the issue slots is more waves.
+#ifndef INF_RING_BITS_CFG
+#define INF_RING_BITS_CFG 12
+#endif
+constexpr uint32_t INF_RING_BITS = INF_RING_BITS_CFG, INF_RING = 1u << INF_RING_BITS, INF_RMASK = INF_RING - 1u;
+constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this are served from the ring
 constexpr uint32_t INF_LBITS = 10, INF_DBITS = 8;
-constexpr uint32_t INF_FLUSH = 16384;
+constexpr uint32_t INF_FLUSH = 1024;                   // the ring goes out to HBM (and through the CRC) in pieces of this size
+static_assert(INF_RING >= INF_FLUSH + 774u + 258u, "the far-match argument needs this");
 
 // decoding tables + output history of one wave (LDS on the device)
 struct InflateScratch {
@@ -104,7 +133,7 @@ struct InflateIn {
     const uint32_t *base;    // dword-aligned address at or before the first payload byte
     uint32_t n_words;        // dwords that may be read
     uint32_t next;           // next dword index
-    uint64_t buf; uint32_t cnt;
+    uint64_t lo, hi; uint32_t cnt;      // the next cnt bits of the stream, bit 0 of lo first (up to 128)
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t win, win_next;  // lane l: base[win_base + l] and base[win_base + 64 + l]
     uint32_t win_base;
@@ -134,14 +163,28 @@ struct InflateIn {
         open_window(next);
         const uint32_t lead = byte_pos & 3u;
         const uint32_t w = next32();
-        buf = (uint64_t)(w >> (8u * lead));
+        lo = (uint64_t)(w >> (8u * lead)); hi = 0;
         cnt = 32u - 8u * lead;
     }
-    RSQC_INF_FN void refill() { if (cnt < 32u) { buf |= (uint64_t)next32() << cnt; cnt += 32u; } }   // afterwards cnt >= 32
-    RSQC_INF_FN uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
-    RSQC_INF_FN void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    RSQC_INF_FN void insert32(uint32_t w) {
+        if (cnt < 64u) { lo |= (uint64_t)w << cnt; if (cnt > 32u) hi |= (uint64_t)w >> (64u - cnt); }
+        else hi |= (uint64_t)w << (cnt - 64u);
+        cnt += 32u;
+    }
+    RSQC_INF_FN void refill() { while (cnt <= 96u) insert32(next32()); }                 // afterwards 97 <= cnt <= 128
+    // the stream from bit `off` on (off < 128); only the first cnt - off bits are meaningful
+    RSQC_INF_FN uint64_t bits_at(uint32_t off) const {
+        if (off >= 64u) return hi >> (off - 64u);
+        return off ? (lo >> off) | (hi << (64u - off)) : lo;
+    }
+    RSQC_INF_FN uint32_t peek(uint32_t n) const { return (uint32_t)lo & ((1u << n) - 1u); }      // n < 32
+    RSQC_INF_FN void drop(uint32_t n) {                                                           // n <= cnt
+        if (n >= 64u) { lo = (n == 64u) ? hi : hi >> (n - 64u); hi = 0; }
+        else if (n) { lo = (lo >> n) | (hi << (64u - n)); hi >>= n; }
+        cnt -= n;
+    }
     RSQC_INF_FN uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
-    RSQC_INF_FN uint32_t byte_pos() const { return next * 4u - cnt / 8u; }    // first byte not consumed yet (whole bytes left in buf)
+    RSQC_INF_FN uint32_t byte_pos() const { return next * 4u - cnt / 8u; }    // first byte not consumed yet (whole bytes left in the buffer)
 };
 
 // ---- Huffman tables ------------------------------------------------------------------------------------------
@@ -183,19 +226,26 @@ RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count,
     return true;
 }
 
-// one symbol: the fast table, or bit by bit for a code longer than the table's index
+// a code longer than the fast table's index (or one nobody owns), bit by bit from `bits`: the symbol and its length, or 0xFFFF
+RSQC_INF_FN uint32_t inflate_symbol_slow(uint64_t bits, const uint16_t *count, const uint16_t *sym, uint32_t &len) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        code |= (uint32_t)bits & 1u; bits >>= 1;
+        const uint32_t c = INF_UNI(count[l]);
+        if (code - first < c) { len = l; return INF_UNI(sym[index + (code - first)]); }
+        index += c; first = (first + c) << 1; code <<= 1;
+    }
+    len = 0;
+    return 0xFFFFu;
+}
+// one symbol at the head of the reader (the block headers' code-length code)
 RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint16_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *sym) {
     const uint32_t e = INF_UNI(fast[in.peek(fbits)]);
     if (e) { in.drop(e & 15u); return e >> 4; }
-    uint32_t code = 0, first = 0, index = 0;
-    uint64_t b = in.buf;
-    for (uint32_t l = 1; l <= 15u; ++l) {
-        code |= (uint32_t)b & 1u; b >>= 1;
-        const uint32_t c = INF_UNI(count[l]);
-        if (code - first < c) { in.drop(l); return INF_UNI(sym[index + (code - first)]); }
-        index += c; first = (first + c) << 1; code <<= 1;
-    }
-    return 0xFFFFu;                                                 // no symbol owns this code
+    uint32_t len;
+    const uint32_t s = inflate_symbol_slow(in.lo, count, sym, len);
+    in.drop(len);
+    return s;
 }
 
 struct InflateOut {
@@ -236,6 +286,48 @@ RSQC_INF_FN void inflate_flush(InflateScratch &S, InflateOut &o, uint32_t n) {
     o.flushed += n;
 }
 
+// the literals gathered in a round (lane j: the j-th) go into the ring with one store
+RSQC_INF_FN bool inflate_put_literals(InflateScratch &S, InflateOut &o, const InfVec &L, uint32_t n) {
+    if (o.pos + n > o.out_len) return false;
+    INF_FOREACH(j) { if (j < n) S.ring[(o.pos + j) & INF_RMASK] = (uint8_t)INF_AT(L, j); }
+    o.pos += n;
+    while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+    return true;
+}
+// out[pos + j] = out[pos + j - dist], j < len.
+// Near (dist <= INF_NEAR): ring to ring.  A match that overlaps its own output (dist < len) repeats the dist bytes before
+// pos: every lane reads byte (j mod dist) of that period, so all of it is ONE round of independent LDS reads -- a run of a
+// single byte (dist 1, the bulk of SEQ/QUAL in low-entropy files) costs the same as any other match.  No write of the copy
+// can land on a slot that a later pass still has to read: that needs dist >= INF_RING - 257.
+// Far: the source left the ring; it is read back from the stream.  Those bytes have been flushed: unflushed output stays
+// below INF_FLUSH + 258 bytes, and the source ends before pos - dist + 258 < pos - INF_RING + 516 <= pos - INF_FLUSH - 258.
+// The loads follow the flush's stores of the same wave: a workgroup-scope fence (a wait for the stores, the CU's vector
+// cache is coherent within a workgroup) orders them.
+RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t dist, uint32_t len) {
+    const uint32_t pos = o.pos;
+    if (dist > INF_NEAR) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+        for (uint32_t j = INF_LANE; j < len; j += INF_W) S.ring[(pos + j) & INF_RMASK] = o.dst[pos - dist + j];     // (dist > 258 >= len: no overlap)
+    } else if (dist >= len) {
+        for (uint32_t j = INF_LANE; j < len; j += INF_W) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos + j - dist) & INF_RMASK];
+    } else if (dist < 64u) {
+        const uint32_t recip = (65536u + dist - 1u) / dist;            // j / dist == (j * recip) >> 16 for j < 1040, dist < 64 (tests: every pair)
+        for (uint32_t j = INF_LANE; j < len; j += INF_W) {
+            const uint32_t r = j - ((j * recip) >> 16) * dist;
+            S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
+        }
+    } else {
+        for (uint32_t j = INF_LANE; j < len; j += INF_W) {              // len <= 258 < 5 * 64
+            uint32_t r = j;
+            r -= (r >= dist) ? dist : 0u; r -= (r >= dist) ? dist : 0u; r -= (r >= dist) ? dist : 0u; r -= (r >= dist) ? dist : 0u;
+            S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
+        }
+    }
+}
+
 // Inflates `in_len` payload bytes at `in` into exactly `out_len` bytes at `dst` and checks their CRC-32 (inflate_crc_init
 // has filled S.crc_tab).  Returns an InflateStatus (wave-uniform).
 // The caller provides 16 readable bytes past the payload's end (the bit reader looks ahead by whole dwords).
@@ -270,7 +362,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                 const uint32_t n = (len - done < INF_FLUSH) ? len - done : INF_FLUSH;
                 for (uint32_t j = INF_LANE; j < n; j += INF_W) S.ring[(o.pos + j) & INF_RMASK] = src[done + j];
                 o.pos += n; done += n;
-                if (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+                while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
             }
             bi.seek(at + len);
         } else if (btype == 1u || btype == 2u) {
@@ -309,45 +401,61 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
             }
             if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfast, INF_LBITS, S.offs)) return INF_ERR_TABLE;
             if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfast, INF_DBITS, S.offs)) return INF_ERR_TABLE;
-            for (;;) {
+            // ---- the symbols, in rounds.  The serial part of DEFLATE is that a symbol's position is known only once the one
+            // before it has been decoded; what is NOT serial is the table look-up itself.  So every lane looks up the
+            // literal/length table AND the distance table at "its" bit offset of the buffered 97+ bits (two LDS reads, one
+            // latency), and the wave-uniform walk then hops from symbol to symbol with v_readlane -- a handful of scalar
+            // instructions per symbol instead of an LDS round trip.
+            for (bool end_of_block = false; !end_of_block;) {
                 bi.refill();
-                uint32_t s = inflate_symbol(bi, S.lfast, INF_LBITS, S.lcount, S.lsym);
-                if (s < 256u) {
-                    if (o.pos >= out_len) return INF_ERR_OUTPUT;
-                    INF_ST(S.ring[o.pos & INF_RMASK] = (uint8_t)s);
-                    o.pos++;
-                    if (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
-                    continue;
+                const uint32_t avail = bi.cnt;
+                InfVec E, F, L;
+                INF_FOREACH(k) {
+                    const uint64_t w = bi.bits_at(k);
+                    INF_AT(E, k) = S.lfast[(uint32_t)w & ((1u << INF_LBITS) - 1u)];
+                    INF_AT(F, k) = S.dfast[(uint32_t)w & ((1u << INF_DBITS) - 1u)];
+                    INF_AT(L, k) = 0u;
                 }
-                if (s == 256u) break;
-                s -= 257u;
-                if (s >= 29u) return INF_ERR_SYMBOL;
-                const uint32_t len = kLenBase[s] + bi.take(kLenExtra[s]);
-                bi.refill();
-                const uint32_t ds = inflate_symbol(bi, S.dfast, INF_DBITS, S.dcount, S.dsym);
-                if (ds >= 30u) return INF_ERR_SYMBOL;
-                const uint32_t dist = kDistBase[ds] + bi.take(kDistExtra[ds]);
-                if (dist > o.pos) return INF_ERR_DISTANCE;
-                if (o.pos + len > out_len) return INF_ERR_OUTPUT;
-                // out[pos + j] = out[pos + j - dist].  A match that overlaps its own output (dist < len) is periodic with
-                // period dist: the copy offset doubles (dist, 2 dist, ...) while the bytes written so far allow it, so that every
-                // pass only reads bytes that exist and a run of one repeated byte takes ~10 passes instead of 258 steps
-                uint32_t off = dist, done = 0;
-                while (done < len) {
-                    const uint32_t n = (len - done < off) ? len - done : off;
-                    for (uint32_t j = INF_LANE; j < n; j += INF_W)
-                        S.ring[(o.pos + done + j) & INF_RMASK] = S.ring[(o.pos + done + j - off) & INF_RMASK];
-                    done += n;
-                    if (off < 64u) off <<= 1;
+                uint32_t off = 0, nlit = 0;
+                while (off < 64u && off + 20u <= avail) {               // a literal/length code and its extra bits are in the buffer
+                    uint32_t e = INF_GET(E, off), len, s;
+                    if (e) { len = e & 15u; s = e >> 4; }
+                    else { s = inflate_symbol_slow(bi.bits_at(off), S.lcount, S.lsym, len); if (s == 0xFFFFu) return INF_ERR_SYMBOL; }
+                    if (s < 256u) { INF_SET(L, nlit, s); ++nlit; off += len; continue; }
+                    if (nlit) { if (!inflate_put_literals(S, o, L, nlit)) return INF_ERR_OUTPUT; nlit = 0; }
+                    off += len;
+                    if (s == 256u) { end_of_block = true; break; }
+                    s -= 257u;
+                    if (s >= 29u) return INF_ERR_SYMBOL;
+                    const uint32_t xb = kLenExtra[s];
+                    const uint32_t mlen = kLenBase[s] + ((uint32_t)bi.bits_at(off) & ((1u << xb) - 1u));
+                    off += xb;
+                    bool moved = false;
+                    if (off + 28u > avail) { bi.drop(off); off = 0; bi.refill(); moved = true; }     // the distance code does not fit what is buffered
+                    uint32_t f = (!moved && off < 64u) ? INF_GET(F, off) : INF_UNI(S.dfast[(uint32_t)bi.bits_at(off) & ((1u << INF_DBITS) - 1u)]);
+                    uint32_t dl, ds;
+                    if (f) { dl = f & 15u; ds = f >> 4; }
+                    else { ds = inflate_symbol_slow(bi.bits_at(off), S.dcount, S.dsym, dl); if (ds == 0xFFFFu) return INF_ERR_SYMBOL; }
+                    if (ds >= 30u) return INF_ERR_SYMBOL;
+                    off += dl;
+                    const uint32_t db = kDistExtra[ds];
+                    const uint32_t dist = kDistBase[ds] + ((uint32_t)bi.bits_at(off) & ((1u << db) - 1u));
+                    off += db;
+                    if (dist > o.pos) return INF_ERR_DISTANCE;
+                    if (o.pos + mlen > out_len) return INF_ERR_OUTPUT;
+                    inflate_copy(S, o, dist, mlen);
+                    o.pos += mlen;
+                    while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+                    if (moved) break;                                   // this round's look-ups belong to bits that are gone
                 }
-                o.pos += len;
-                if (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+                if (nlit && !inflate_put_literals(S, o, L, nlit)) return INF_ERR_OUTPUT;
+                bi.drop(off);
             }
         } else return INF_ERR_BTYPE;
         if (bfinal) break;
     }
-    if (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
-    inflate_flush(S, o, o.pos - o.flushed);
+    while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+    inflate_flush(S, o, o.pos - o.flushed);                           // (the last, shorter piece)
     if (o.pos != out_len) return INF_ERR_OUTPUT;
     if (bi.byte_pos() > lead + in_len) return INF_ERR_INPUT;
     if ((o.crc ^ 0xFFFFFFFFu) != crc32) return INF_ERR_CRC;

@@ -58,6 +58,10 @@ def load_library():
         lib.rsqc_counter_name.argtypes = [C.c_int]; lib.rsqc_counter_name.restype = C.c_char_p
         lib.rsqc_version.restype = C.c_char_p
         lib.rsqc_qname_hash.argtypes = [C.c_char_p, C.c_size_t]; lib.rsqc_qname_hash.restype = C.c_uint64
+        lib.rsqc_decode_begin.argtypes = [vp, C.POINTER(abi.DecodeParams)]
+        lib.rsqc_decode_submit.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(abi.DecodeWindow)]
+        lib.rsqc_decode_end.argtypes = [vp, C.POINTER(abi.DecodeInfo)]
+        lib.rsqc_debug_last_decoded.argtypes = [vp, C.POINTER(abi.BatchStruct)]
         _lib = lib
     return _lib
 
@@ -67,6 +71,7 @@ EXPORTED_SYMBOLS = [
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
     "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
+    "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end", "rsqc_debug_last_decoded",
 ]
 
 
@@ -132,6 +137,54 @@ class Engine:
 
     def wait(self):
         self._check(self._l.rsqc_wait(self._h))
+
+    # ---- device-side BAM decode (rsqc_decode_*) -----------------------------------------------------------------
+    def decode_begin(self, n_ref, ch_tag="ch", filter_tags=(), file_index_base=0):
+        p = abi.DecodeParams()
+        p.n_ref = n_ref
+        if ch_tag and len(ch_tag) == 2:
+            p.has_chimeric_tag = 1; p.chimeric_tag = ch_tag.encode()
+        for k, f in enumerate(filter_tags):
+            if len(f) == 2:
+                p.filter_tag[k].value = f.encode()
+        p.file_index_base = file_index_base
+        self._check(self._l.rsqc_decode_begin(self._h, C.byref(p)))
+
+    def decode_submit(self, compressed, blocks, skip=0, limit=0):
+        """compressed: bytes-like or (address, nbytes); blocks: numpy array of abi BGZF block records (or (address, n)).
+        Returns (records, [RefID of every run of records])."""
+        if isinstance(compressed, tuple):
+            caddr, cbytes = compressed
+        else:
+            buf = np.frombuffer(compressed, np.uint8)
+            self._keep_decode = buf
+            caddr, cbytes = buf.ctypes.data, buf.size
+        if isinstance(blocks, tuple):
+            baddr, nb = blocks
+        else:
+            blocks = np.ascontiguousarray(blocks)
+            baddr, nb = blocks.ctypes.data, len(blocks)
+        w = abi.DecodeWindow()
+        self._check(self._l.rsqc_decode_submit(self._h, caddr, cbytes, baddr, nb, skip, limit, C.byref(w)))
+        runs = list(np.ctypeslib.as_array(C.cast(w.run_tid, C.POINTER(C.c_int32)), (w.n_runs,))) if w.n_runs else []
+        return int(w.n_records), [int(t) for t in runs]
+
+    def decode_end(self):
+        """(records, unsorted, number of records with an unrecognised RefID, first names of those)"""
+        info = abi.DecodeInfo()
+        rc = self._l.rsqc_decode_end(self._h, C.byref(info))
+        names = []
+        if info.n_bad_refid and info.bad_refid:
+            arr = C.cast(info.bad_refid, C.POINTER(C.c_char_p))
+            names = [arr[k].decode() for k in range(min(info.n_bad_refid, 64))]
+        self._check(rc)
+        return int(info.records), bool(info.unsorted), int(info.n_bad_refid), names
+
+    def last_decoded(self):
+        """abi.BatchStruct of DEVICE pointers: the batch of the last decode_submit (tests read it back with hipMemcpy)."""
+        s = abi.BatchStruct()
+        self._check(self._l.rsqc_debug_last_decoded(self._h, C.byref(s)))
+        return s
 
     def upload(self, batch) -> int:
         s = batch.to_struct()

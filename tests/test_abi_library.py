@@ -26,8 +26,9 @@ def test_struct_sizes_match_header():
     src = r'''
     #include <stdio.h>
     #include "rnaseqc_amd.h"
-    int main(void){ printf("%zu %zu %zu %zu %zu %zu %d\n", sizeof(rsqc_params), sizeof(rsqc_annotation), sizeof(rsqc_bed),
-      sizeof(rsqc_batch), sizeof(rsqc_results), sizeof(rsqc_timing), (int)RSQC_N_COUNTERS); return 0; }'''
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %d %zu %zu %zu %zu\n", sizeof(rsqc_params), sizeof(rsqc_annotation), sizeof(rsqc_bed),
+      sizeof(rsqc_batch), sizeof(rsqc_results), sizeof(rsqc_timing), (int)RSQC_N_COUNTERS,
+      sizeof(rsqc_bgzf_block), sizeof(rsqc_decode_params), sizeof(rsqc_decode_window), sizeof(rsqc_decode_info)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
@@ -36,6 +37,7 @@ def test_struct_sizes_match_header():
     assert sizes[:6] == [C.sizeof(abi.Params), C.sizeof(abi.AnnotationStruct), C.sizeof(abi.BedStruct),
                          C.sizeof(abi.BatchStruct), C.sizeof(abi.ResultsStruct), C.sizeof(abi.TimingStruct)]
     assert sizes[6] == abi.N_COUNTERS
+    assert sizes[7:11] == [C.sizeof(abi.BgzfBlock), C.sizeof(abi.DecodeParams), C.sizeof(abi.DecodeWindow), C.sizeof(abi.DecodeInfo)]
 
 
 def test_counter_names_and_version():
