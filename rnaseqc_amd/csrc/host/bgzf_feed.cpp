@@ -107,13 +107,10 @@ void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes,
     has_end_ = voff_end != 0;
     chunk_bytes_ = std::max<size_t>(chunk_bytes, (size_t)1 << 17); max_out_ = max_out;      // (a chunk holds at least one whole block)
     done_ = cpos_ >= file_size_;
-    for (auto &c : ring_) if (!c.data || c.cap < chunk_bytes_) {
-        if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
-        c.data = (uint8_t *)rsqc_host_alloc(chunk_bytes_ + 64); c.pinned = c.data != nullptr;
-        if (!c.data) c.data = (uint8_t *)malloc(chunk_bytes_ + 64);       // (no device: the tests of the feeder alone)
-        if (!c.data) throw std::bad_alloc();
-        c.cap = chunk_bytes_;
-    }
+    // (a chunk never needs more than what is left of the file; the buffers are page-locked by the read-ahead thread the first
+    //  time it fills them, so that pinning the second one overlaps the GPU's work on the first)
+    chunk_bytes_ = (size_t)std::min<uint64_t>(chunk_bytes_, std::max<uint64_t>(file_size_ - std::min(file_size_, cpos_), (uint64_t)1 << 17));
+    n_filled_ = 0;
     head_ = tail_ = count_ = 0; lent_ = nullptr; eof_ = false; stop_ = false; error_.clear();
     if (th_.joinable()) th_.join();
     th_ = std::thread([this] { producer(); });
@@ -122,7 +119,20 @@ void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes,
 bool BgzfFeeder::fill(Chunk &c) {
     c.blocks.clear(); c.bytes = 0; c.skip = 0; c.limit = 0; c.last = false;
     if (done_) return false;
-    const size_t want = (size_t)std::min<uint64_t>(chunk_bytes_, file_size_ - cpos_);
+
+    // the first chunks are small so that the GPU starts early; later ones are as large as allowed (a call should hold
+    // thousands of blocks)
+    const size_t ramp = std::min<size_t>(chunk_bytes_, ((size_t)24 << 20) << std::min(n_filled_, 8));
+    ++n_filled_;
+    const size_t want = (size_t)std::min<uint64_t>(ramp, file_size_ - cpos_);
+    if (!c.data || c.cap < want) {
+        if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
+        const size_t cap = std::min(chunk_bytes_, std::max(want, ramp * 4));      // (room for the next steps of the ramp)
+        c.data = (uint8_t *)rsqc_host_alloc(cap + 64); c.pinned = c.data != nullptr;
+        if (!c.data) c.data = (uint8_t *)malloc(cap + 64);               // (no device: the tests of the feeder alone)
+        if (!c.data) throw std::bad_alloc();
+        c.cap = cap;
+    }
     // the slices of one chunk are read side by side (a single pread stream from the page cache is ~3-5 GB/s)
     const int T = std::max(1, std::min(read_threads, (int)(want >> 22) + 1));
     std::vector<std::thread> th;

@@ -33,7 +33,7 @@ public:
     // Throws std::runtime_error on a file that is not a BAM.
     uint64_t first_record_voffset();
     // the blocks from virtual offset `beg` to `end` (0 = end of file); starts the read-ahead thread
-    void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)48 << 20, uint64_t max_out = (uint64_t)768 << 20);
+    void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)192 << 20, uint64_t max_out = (uint64_t)1536 << 20);
     // next chunk, or nullptr at the end; the previous chunk becomes reusable.  Throws on a malformed block header.
     Chunk *next();
     int read_threads = 4;
@@ -43,7 +43,7 @@ private:
     bool fill(Chunk &c);
     int fd_ = -1; uint64_t file_size_ = 0;
     uint64_t cpos_ = 0, cend_ = 0; uint32_t skip_ = 0, uend_ = 0; bool done_ = false, has_end_ = false;
-    size_t chunk_bytes_ = 0; uint64_t max_out_ = 0;
+    size_t chunk_bytes_ = 0; uint64_t max_out_ = 0; int n_filled_ = 0;
     Chunk ring_[3];
     int head_ = 0, tail_ = 0, count_ = 0; Chunk *lent_ = nullptr;
     bool eof_ = false, stop_ = false; std::string error_;

@@ -216,18 +216,28 @@ template <class F>
 int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, uint64_t voff_beg, uint64_t voff_end, rsqc_decode_info &info, F &&on_window) {
     int rc = rsqc_decode_begin(gpu, &dp);
     if (rc != RSQC_OK) return rc;
-    // (RSQC_DECODE_CHUNK / RSQC_DECODE_MAX_OUT: compressed bytes read per call / inflated bytes per call -- the tests use
-    //  small values so that records straddle many calls)
-    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)48 << 20;
-    const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)768 << 20;
+    // Calls are large on purpose: the inflate kernel runs one wave per BGZF block, sixteen waves per CU -- a call needs well
+    // over 4096 blocks (256 MB of inflated data) to fill the chip.  (RSQC_DECODE_CHUNK / RSQC_DECODE_MAX_OUT: compressed bytes
+    // read per call / inflated bytes per call -- the tests use small values so that records straddle many calls)
+    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)192 << 20;
+    const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1536 << 20;
+    const bool prof = getenv("RSQC_DECODE_PROFILE") != nullptr;
+    double t_feed = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
     feed.start(voff_beg, voff_end, chunk, max_out);
-    while (BgzfFeeder::Chunk *ch = feed.next()) {
+    for (;;) {
+        auto tf = now();
+        BgzfFeeder::Chunk *ch = feed.next();
+        t_feed += std::chrono::duration<double, std::milli>(now() - tf).count();
+        if (!ch) break;
         if (ch->blocks.empty()) continue;
         rsqc_decode_window w{};
         rc = rsqc_decode_submit(gpu, ch->data, ch->bytes, ch->blocks.data(), (uint32_t)ch->blocks.size(), ch->skip, ch->limit, &w);
         if (rc != RSQC_OK) { rsqc_decode_info dropped{}; (void)rsqc_decode_end(gpu, &dropped); return rc; }
         on_window(w);
     }
+    if (prof) fprintf(stderr, "[decode] host: %.1f ms waiting for file chunks of %.1f ms in the range\n", t_feed, std::chrono::duration<double, std::milli>(now() - t0).count());
     return rsqc_decode_end(gpu, &info);
 }
 

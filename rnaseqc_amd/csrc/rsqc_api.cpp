@@ -83,7 +83,7 @@ struct DecodeState {
     uint32_t tail = 0;                 // bytes carried over, parked at [head - tail, head)
     size_t out_cap = 0, comp_cap = 0, blk_cap = 0;
     DevBuf comp, blocks, ubuf, seg, seg_rec0, seg_ops0, rec_off, ops_at, mark, core, aux, cigar, seg_tid, seg_start,
-           wide_index, wide_nm, wide_lq, wide_nc, sum, carry, tailtmp;
+           wide_index, wide_nm, wide_lq, wide_nc, sum, carry, tailtmp, scratch;
     DecodeSummary *h_sum = nullptr;    // page-locked
     DevBgzfBlock *h_blocks = nullptr;  // page-locked, blk_cap entries
     bool unsorted = false;
@@ -93,6 +93,7 @@ struct DecodeState {
     // RSQC_DECODE_PROFILE: stage times of the stream, printed at rsqc_decode_end
     bool profile = false; hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms_copy = 0, ms_inflate = 0, ms_parse = 0, ms_call = 0; uint64_t prof_in = 0, prof_out = 0, prof_calls = 0;
+    std::chrono::steady_clock::time_point prof_t0;
     std::vector<int32_t> run_tid;      // contig segments of the last window
     rsqc_batch last{};                 // the last window's batch (device pointers), for rsqc_debug_last_decoded
 };
@@ -596,7 +597,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     {
         DecodeState &D = c->dec;
         for (DevBuf *b : {&D.comp, &D.blocks, &D.ubuf, &D.seg, &D.seg_rec0, &D.seg_ops0, &D.rec_off, &D.ops_at, &D.mark, &D.core, &D.aux, &D.cigar,
-                          &D.seg_tid, &D.seg_start, &D.wide_index, &D.wide_nm, &D.wide_lq, &D.wide_nc, &D.sum, &D.carry, &D.tailtmp}) b->release();
+                          &D.seg_tid, &D.seg_start, &D.wide_index, &D.wide_nm, &D.wide_lq, &D.wide_nc, &D.sum, &D.carry, &D.tailtmp, &D.scratch}) b->release();
         if (D.h_sum) (void)hipHostFree(D.h_sum);
         if (D.h_blocks) (void)hipHostFree(D.h_blocks);
     }
@@ -1223,9 +1224,11 @@ int rsqc_decode_begin(rsqc_ctx *c, const rsqc_decode_params *p) {
     D.unsorted = false; D.n_bad = 0; D.bad_names.clear();
     D.profile = getenv("RSQC_DECODE_PROFILE") != nullptr;
     D.ms_copy = D.ms_inflate = D.ms_parse = D.ms_call = 0; D.prof_in = D.prof_out = D.prof_calls = 0;
+    D.prof_t0 = std::chrono::steady_clock::now();
     if (D.profile && !D.pe[0]) for (auto &e : D.pe) HIP_TRY(c, hipEventCreate(&e));
     int rc;
-    if ((rc = dev_alloc(c, D.sum, sizeof(DecodeSummary), false)) || (rc = dev_alloc(c, D.carry, sizeof(DecodeCarry), true))) return rc;
+    if ((rc = dev_alloc(c, D.sum, sizeof(DecodeSummary), false)) || (rc = dev_alloc(c, D.carry, sizeof(DecodeCarry), true)) ||
+        (rc = dev_alloc(c, D.scratch, DEC_SCRATCH_WORDS * 4, false))) return rc;
     if (!D.h_sum) HIP_TRY(c, hipHostMalloc((void **)&D.h_sum, sizeof(DecodeSummary), hipHostMallocDefault));
     D.active = true;
     return RSQC_OK;
@@ -1286,7 +1289,7 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
             return fail(c, RSQC_ERR_ARG, "BGZF block outside the compressed buffer or with ISIZE above 64 KiB");
         total += b.out_bytes;
     }
-    if (total > (1ull << 30)) return fail(c, RSQC_ERR_ARG, "more than 1 GiB of inflated data in one rsqc_decode_submit");
+    if (total + D.head > (1ull << 31)) return fail(c, RSQC_ERR_ARG, "too much inflated data in one rsqc_decode_submit (2 GiB with the bytes carried over)");
     if (skip_bytes && D.tail) return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record");
     if (skip_bytes > total) return fail(c, RSQC_ERR_ARG, "skip_bytes beyond the inflated data");
     int rc;
@@ -1314,7 +1317,7 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     W.wide_index = (uint64_t *)D.wide_index.p; W.wide_nm = (int32_t *)D.wide_nm.p; W.wide_lq = (int32_t *)D.wide_lq.p; W.wide_nc = (uint32_t *)D.wide_nc.p;
     W.sum = (DecodeSummary *)D.sum.p; W.carry = (DecodeCarry *)D.carry.p; W.tags = D.tags;
     if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[2], c->stream));
-    launch_decode_window(c->stream, W);
+    launch_decode_window(c->stream, W, (uint32_t *)D.scratch.p);
     if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[3], c->stream));
     HIP_TRY(c, hipMemcpyAsync(D.h_sum, D.sum.p, sizeof(DecodeSummary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1393,9 +1396,9 @@ int rsqc_decode_end(rsqc_ctx *c, rsqc_decode_info *out) {
     if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_end");
     D.active = false;
     if (D.profile)
-        fprintf(stderr, "[decode] %llu calls, %.1f MB in, %.1f MB inflated: copy %.1f ms, inflate %.1f ms (%.2f GB/s out), frame+parse %.1f ms, host wait per call %.2f ms\n",
+        fprintf(stderr, "[decode] %llu calls, %.1f MB in, %.1f MB inflated: copy %.1f ms, inflate %.1f ms (%.2f GB/s out), frame+parse %.1f ms, in the calls %.1f ms of %.1f ms between begin and end\n",
                 (unsigned long long)D.prof_calls, D.prof_in / 1e6, D.prof_out / 1e6, D.ms_copy, D.ms_inflate, D.ms_inflate > 0 ? D.prof_out / D.ms_inflate / 1e6 : 0.0,
-                D.ms_parse, D.prof_calls ? D.ms_call / (double)D.prof_calls : 0.0);
+                D.ms_parse, D.ms_call, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - D.prof_t0).count());
     if (out) {
         D.bad_ptrs.clear();
         for (auto &n : D.bad_names) D.bad_ptrs.push_back(n.c_str());

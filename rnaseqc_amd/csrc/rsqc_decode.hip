@@ -44,37 +44,95 @@ __global__ __launch_bounds__(256) void bam_frame_kernel(DecodeWindow W) {
     if (s < W.n_seg) decode_frame_one(W, s);
 }
 
-// ---- chain: one workgroup ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bam_chain_kernel(DecodeWindow W) {
-    __shared__ uint32_t s_ok, s_consumed, s_bad;
-    __shared__ uint32_t s_rec[1024], s_ops[1024];
-    const uint32_t t = threadIdx.x, T = 1024;
-    if (t == 0) { s_ok = 1; s_bad = 0; s_consumed = W.start; }
+// ---- exclusive sums of a workgroup of 256 threads (one value per thread; returns the total in `total`) --------------
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *lds /* [256] */, uint32_t &total) {
+    const uint32_t t = threadIdx.x;
+    lds[t] = v;
     __syncthreads();
-    bool ok = true;
-    for (uint32_t s = t; s < W.n_seg; s += T) ok = ok && decode_guess_confirmed(W, s);
-    if (!ok) atomicAnd(&s_ok, 0u);
-    __syncthreads();
-    if (t == 0 && W.n_seg) {
-        if (s_ok) s_consumed = W.seg[W.n_seg - 1].land;
-        else { uint32_t bad = 0; s_consumed = bam_verify_chain(W.buf, W.seg, W.n_seg, W.start, DEC_SEG_BYTES, W.end, bad); s_bad = bad; }
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint32_t x = t >= d ? lds[t - d] : 0u;
+        __syncthreads();
+        lds[t] += x;
+        __syncthreads();
     }
+    total = lds[255];
+    const uint32_t incl = lds[t];
     __syncthreads();
-    // exclusive sums of the per-segment counts: a contiguous run of segments per thread, the 1024 partial sums by thread 0
-    const uint32_t per = (W.n_seg + T - 1) / T, lo = min(W.n_seg, t * per), hi = min(W.n_seg, lo + per);
+    return incl - v;
+}
+
+// ---- repair: a segment whose guess is not where the walk of the segment before it landed is walked again from there.
+// A few rounds settle the isolated wrong guesses that low-entropy SEQ/QUAL bytes produce; whatever is still unconfirmed
+// after them (a run of consecutive wrong guesses) is left to the sequential walk in bam_chain_top_kernel.
+__global__ __launch_bounds__(256) void bam_repair_kernel(DecodeWindow W) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s == 0 || s >= W.n_seg) return;
+    const uint32_t truth = W.seg[s - 1].land;
+    BamSegment g = W.seg[s];
+    if (g.start == truth && !g.bad) return;
+    uint32_t lo, hi;
+    decode_segment_bounds(W, s, lo, hi);
+    g.start = truth;
+    bam_walk(W.buf, truth, hi, W.end, g);
+    W.seg[s] = g;
+}
+
+// ---- chain: are all guesses confirmed, and where do a segment's records and operations go.  Three launches: sums per
+// workgroup of 256 segments, one workgroup over those sums (and the exact, sequential repair when a guess was wrong), then
+// the positions inside every workgroup.
+constexpr uint32_t DEC_CHAIN_BLOCK = 256;
+__global__ __launch_bounds__(256) void bam_chain_sums_kernel(DecodeWindow W, uint32_t *blk_rec, uint32_t *blk_ops, uint32_t *all_ok) {
+    __shared__ uint32_t lds[256];
+    const uint32_t s = blockIdx.x * DEC_CHAIN_BLOCK + threadIdx.x;
     uint32_t nr = 0, no = 0;
-    for (uint32_t s = lo; s < hi; ++s) { nr += W.seg[s].n_rec; no += W.seg[s].n_ops; }
-    s_rec[t] = nr; s_ops[t] = no;
+    if (s < W.n_seg) {
+        if (!decode_guess_confirmed(W, s)) atomicAnd(all_ok, 0u);
+        nr = W.seg[s].n_rec; no = W.seg[s].n_ops;
+    }
+    uint32_t tr, to;
+    (void)block_scan_256(nr, lds, tr);
+    (void)block_scan_256(no, lds, to);
+    if (threadIdx.x == 0) { blk_rec[blockIdx.x] = tr; blk_ops[blockIdx.x] = to; }
+}
+__global__ __launch_bounds__(1024) void bam_chain_top_kernel(DecodeWindow W, uint32_t *blk_rec, uint32_t *blk_ops, uint32_t n_blk, uint32_t *all_ok) {
+    __shared__ uint32_t s_rec[1024], s_ops[1024], s_consumed, s_bad;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) { s_bad = 0; s_consumed = W.n_seg ? W.seg[W.n_seg - 1].land : W.start; }
     __syncthreads();
+    if (W.n_seg && !*all_ok) {                                          // (uniform) a wrong guess: walk again from the truth, then redo the sums
+        if (t == 0) { uint32_t bad = 0; s_consumed = bam_verify_chain(W.buf, W.seg, W.n_seg, W.start, DEC_SEG_BYTES, W.end, bad); s_bad = bad; }
+        __syncthreads();
+        for (uint32_t b = t; b < n_blk; b += 1024u) {
+            uint32_t nr = 0, no = 0;
+            const uint32_t lo = b * DEC_CHAIN_BLOCK, hi = min(W.n_seg, lo + DEC_CHAIN_BLOCK);
+            for (uint32_t s = lo; s < hi; ++s) { nr += W.seg[s].n_rec; no += W.seg[s].n_ops; }
+            blk_rec[b] = nr; blk_ops[b] = no;
+        }
+        __syncthreads();
+    }
+    // exclusive sums over the workgroups' totals (at most 1024 of them: 2 GiB / 8 KiB / 256)
+    s_rec[t] = t < n_blk ? blk_rec[t] : 0u; s_ops[t] = t < n_blk ? blk_ops[t] : 0u;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t x = t >= d ? s_rec[t - d] : 0u, y = t >= d ? s_ops[t - d] : 0u;
+        __syncthreads();
+        s_rec[t] += x; s_ops[t] += y;
+        __syncthreads();
+    }
+    if (t < n_blk) { const uint32_t r = s_rec[t] - blk_rec[t], o = s_ops[t] - blk_ops[t]; blk_rec[t] = r; blk_ops[t] = o; }
     if (t == 0) {
-        uint32_t a = 0, b = 0;
-        for (uint32_t k = 0; k < T; ++k) { const uint32_t x = s_rec[k], y = s_ops[k]; s_rec[k] = a; s_ops[k] = b; a += x; b += y; }
-        W.sum->n_rec = a; W.sum->n_ops = b; W.sum->consumed_end = s_consumed;
+        W.sum->n_rec = s_rec[1023]; W.sum->n_ops = s_ops[1023]; W.sum->consumed_end = s_consumed;
         if (s_bad) atomicOr(&W.sum->status, DEC_ST_BAD_RECORD);
     }
-    __syncthreads();
-    nr = s_rec[t]; no = s_ops[t];
-    for (uint32_t s = lo; s < hi; ++s) { W.seg_rec0[s] = nr; W.seg_ops0[s] = no; nr += W.seg[s].n_rec; no += W.seg[s].n_ops; }
+}
+__global__ __launch_bounds__(256) void bam_chain_place_kernel(DecodeWindow W, const uint32_t *blk_rec, const uint32_t *blk_ops) {
+    __shared__ uint32_t lds[256];
+    const uint32_t s = blockIdx.x * DEC_CHAIN_BLOCK + threadIdx.x;
+    uint32_t nr = 0, no = 0;
+    if (s < W.n_seg) { nr = W.seg[s].n_rec; no = W.seg[s].n_ops; }
+    uint32_t tot;
+    const uint32_t r0 = block_scan_256(nr, lds, tot), o0 = block_scan_256(no, lds, tot);
+    if (s < W.n_seg) { W.seg_rec0[s] = blk_rec[blockIdx.x] + r0; W.seg_ops0[s] = blk_ops[blockIdx.x] + o0; }
 }
 
 __global__ __launch_bounds__(256) void bam_offsets_kernel(DecodeWindow W) {
@@ -93,29 +151,69 @@ __global__ __launch_bounds__(256) void bam_parse_kernel(DecodeWindow W) {
     if (unsorted) W.sum->unsorted = 1u;
 }
 
-// ---- lists: one workgroup ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bam_lists_kernel(DecodeWindow W) {
-    __shared__ uint32_t s_seg[1024], s_wide[1024], s_bad[1024];
-    __shared__ int32_t s_last[1024];
+// ---- lists: the marks, in record order, become the batch's segment and wide tables.  Same three-launch shape: counts per
+// workgroup (256 threads x 32 consecutive records), one workgroup over those, then the writes.
+constexpr uint32_t DEC_LIST_PER_THREAD = 32, DEC_LIST_BLOCK = 256 * DEC_LIST_PER_THREAD;
+struct DecodeListBlock { uint32_t seg, wide, bad; int32_t last_judged; };
+__global__ __launch_bounds__(256) void bam_lists_count_kernel(DecodeWindow W, DecodeListBlock *blk) {
+    __shared__ uint32_t lds[256];
+    __shared__ int32_t s_last;
     if (W.sum->status) return;
-    const uint32_t t = threadIdx.x, T = 1024, n = W.sum->n_rec;
-    const uint32_t per = (n + T - 1) / T, lo = min(n, t * per), hi = min(n, lo + per);
+    const uint32_t n = W.sum->n_rec;
+    const uint32_t first = blockIdx.x * DEC_LIST_BLOCK;
+    if (first >= n) return;                                             // (the grid is sized for the most records the window can hold)
+    const uint32_t lo = min(n, first + threadIdx.x * DEC_LIST_PER_THREAD), hi = min(n, lo + DEC_LIST_PER_THREAD);
+    if (threadIdx.x == 0) s_last = -1;
     DecodeListCounts c;
     decode_lists_count(W, lo, hi, c);
-    s_seg[t] = c.seg; s_wide[t] = c.wide; s_bad[t] = c.bad; s_last[t] = c.last_judged;
+    uint32_t ts, tw, tb;
+    (void)block_scan_256(c.seg, lds, ts); (void)block_scan_256(c.wide, lds, tw); (void)block_scan_256(c.bad, lds, tb);
+    if (c.last_judged >= 0) atomicMax(&s_last, c.last_judged);
     __syncthreads();
-    if (t == 0) {
-        DecodeListCounts run{0, 0, 0, -1};
-        for (uint32_t k = 0; k < T; ++k) {
-            const uint32_t a = s_seg[k], b = s_wide[k], d = s_bad[k];
-            s_seg[k] = run.seg; s_wide[k] = run.wide; s_bad[k] = run.bad;
-            run.seg += a; run.wide += b; run.bad += d;
-            if (s_last[k] >= 0) run.last_judged = s_last[k];
-        }
-        decode_lists_finish(W, n, run);
+    if (threadIdx.x == 0) blk[blockIdx.x] = DecodeListBlock{ts, tw, tb, s_last};
+}
+__global__ __launch_bounds__(1024) void bam_lists_top_kernel(DecodeWindow W, DecodeListBlock *blk) {
+    __shared__ uint32_t s_seg[1024], s_wide[1024], s_bad[1024];
+    __shared__ int32_t s_last;
+    if (W.sum->status) return;
+    const uint32_t t = threadIdx.x, n = W.sum->n_rec, n_blk = (n + DEC_LIST_BLOCK - 1) / DEC_LIST_BLOCK;
+    const uint32_t per = (n_blk + 1023u) / 1024u, lo = min(n_blk, t * per), hi = min(n_blk, lo + per);
+    if (t == 0) s_last = -1;
+    __syncthreads();
+    uint32_t a = 0, b = 0, d = 0; int32_t last = -1;
+    for (uint32_t k = lo; k < hi; ++k) { a += blk[k].seg; b += blk[k].wide; d += blk[k].bad; if (blk[k].last_judged >= 0) last = blk[k].last_judged; }
+    s_seg[t] = a; s_wide[t] = b; s_bad[t] = d;
+    if (last >= 0) atomicMax(&s_last, last);
+    __syncthreads();
+    for (uint32_t st = 1; st < 1024u; st <<= 1) {
+        const uint32_t x = t >= st ? s_seg[t - st] : 0u, y = t >= st ? s_wide[t - st] : 0u, z = t >= st ? s_bad[t - st] : 0u;
+        __syncthreads();
+        s_seg[t] += x; s_wide[t] += y; s_bad[t] += z;
+        __syncthreads();
     }
-    __syncthreads();
-    decode_lists_write(W, lo, hi, DecodeListCounts{s_seg[t], s_wide[t], s_bad[t], -1});
+    uint32_t ra = s_seg[t] - a, rb = s_wide[t] - b, rd = s_bad[t] - d;          // this thread's run of workgroups starts here
+    for (uint32_t k = lo; k < hi; ++k) {
+        const DecodeListBlock x = blk[k];
+        blk[k] = DecodeListBlock{ra, rb, rd, x.last_judged};
+        ra += x.seg; rb += x.wide; rd += x.bad;
+    }
+    if (t == 0) decode_lists_finish(W, n, DecodeListCounts{s_seg[1023], s_wide[1023], s_bad[1023], s_last});
+}
+__global__ __launch_bounds__(256) void bam_lists_write_kernel(DecodeWindow W, const DecodeListBlock *blk) {
+    __shared__ uint32_t lds[256];
+    if (W.sum->status) return;
+    const uint32_t n = W.sum->n_rec;
+    const uint32_t first = blockIdx.x * DEC_LIST_BLOCK;
+    if (first >= n) return;
+    const uint32_t lo = min(n, first + threadIdx.x * DEC_LIST_PER_THREAD), hi = min(n, lo + DEC_LIST_PER_THREAD);
+    DecodeListCounts c;
+    decode_lists_count(W, lo, hi, c);
+    uint32_t tot;
+    const uint32_t s0 = block_scan_256(c.seg, lds, tot), w0 = block_scan_256(c.wide, lds, tot), b0 = block_scan_256(c.bad, lds, tot);
+    if (c.seg | c.wide | c.bad) {
+        const DecodeListBlock base = blk[blockIdx.x];
+        decode_lists_write(W, lo, hi, DecodeListCounts{base.seg + s0, base.wide + w0, base.bad + b0, -1});
+    }
 }
 
 // ---- launches ----------------------------------------------------------------------------------------------------
@@ -139,12 +237,24 @@ void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *b
         bgzf_inflate_kernel<4><<<grid, 256, 0, s>>>(in, blk, n_blk, out, sum);
     }
 }
-void launch_decode_window(hipStream_t s, const DecodeWindow &W) {
+void launch_decode_window(hipStream_t s, const DecodeWindow &W, uint32_t *scratch) {
+    // scratch: DEC_SCRATCH_WORDS words: [0] the all-guesses-confirmed flag, then the per-workgroup sums of the two scans
+    const uint32_t seg_blocks = (W.n_seg + DEC_CHAIN_BLOCK - 1) / DEC_CHAIN_BLOCK;
+    uint32_t *all_ok = scratch, *blk_rec = scratch + 16, *blk_ops = blk_rec + 1024;
+    DecodeListBlock *lblk = (DecodeListBlock *)(blk_ops + 1024);
+    (void)hipMemsetAsync(all_ok, 0xff, 4, s);
     if (W.n_seg) bam_frame_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);
-    bam_chain_kernel<<<1, 1024, 0, s>>>(W);
+    for (int round = 0; round < 3 && W.n_seg > 1; ++round) bam_repair_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);
+    if (seg_blocks) bam_chain_sums_kernel<<<seg_blocks, 256, 0, s>>>(W, blk_rec, blk_ops, all_ok);
+    bam_chain_top_kernel<<<1, 1024, 0, s>>>(W, blk_rec, blk_ops, seg_blocks, all_ok);
+    if (seg_blocks) bam_chain_place_kernel<<<seg_blocks, 256, 0, s>>>(W, blk_rec, blk_ops);
     if (W.n_seg) bam_offsets_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);
     bam_parse_kernel<<<256 * 8, 256, 0, s>>>(W);
-    bam_lists_kernel<<<1, 1024, 0, s>>>(W);
+    // (the record count is on the device: grids for the most records the window's bytes can hold; surplus workgroups leave at once)
+    const uint32_t max_rec = (W.end - W.start) / 36u + 1u, list_blocks = (max_rec + DEC_LIST_BLOCK - 1) / DEC_LIST_BLOCK;
+    bam_lists_count_kernel<<<list_blocks, 256, 0, s>>>(W, lblk);
+    bam_lists_top_kernel<<<1, 1024, 0, s>>>(W, lblk);
+    bam_lists_write_kernel<<<list_blocks, 256, 0, s>>>(W, lblk);
 }
 
 }  // namespace rsqc

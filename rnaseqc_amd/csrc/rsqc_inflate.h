@@ -84,15 +84,15 @@ enum InflateStatus {
 #endif
 constexpr uint32_t INF_RING_BITS = INF_RING_BITS_CFG, INF_RING = 1u << INF_RING_BITS, INF_RMASK = INF_RING - 1u;
 constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this are served from the ring
-constexpr uint32_t INF_LBITS = 10, INF_DBITS = 8;
-constexpr uint32_t INF_FLUSH = 1024;                   // the ring goes out to HBM (and through the CRC) in pieces of this size
+constexpr uint32_t INF_LBITS = 9, INF_DBITS = 8;
+constexpr uint32_t INF_FLUSH = 2048;                   // the ring goes out to HBM (and through the CRC) in pieces of this size
 static_assert(INF_RING >= INF_FLUSH + 774u + 258u, "the far-match argument needs this");
 
 // decoding tables + output history of one wave (LDS on the device)
 struct InflateScratch {
     uint8_t ring[INF_RING];
-    uint16_t lfast[1u << INF_LBITS];     // index: next LBITS bits of the stream; (symbol << 4) | code length, 0 = longer code
-    uint16_t dfast[1u << INF_DBITS];
+    uint32_t lfast[1u << INF_LBITS];     // index: the next LBITS bits of the stream; an InflateEntry, 0 = longer code (or none)
+    uint32_t dfast[1u << INF_DBITS];
     uint16_t lcount[16], dcount[16];     // codes per length
     uint16_t lsym[288], dsym[32];        // symbols by (length, symbol): canonical decoding of the codes the fast table does not hold
     uint8_t lens[320];                   // code lengths of the block being set up
@@ -188,10 +188,32 @@ struct InflateIn {
 };
 
 // ---- Huffman tables ------------------------------------------------------------------------------------------
+// A table entry says everything the decoder needs about the symbol, so that the symbol loop never goes back to the
+// constant tables of RFC 1951 3.2.5:
+//   bits 0-3 code length | bits 4-7 extra bits that follow | bits 8-23 value: the literal, the length base or the distance base
+//   bit 31 literal | bit 30 end of block | bit 29 a symbol the format does not define (286, 287; distance 30, 31)
+constexpr uint32_t INF_E_LITERAL = 0x80000000u, INF_E_END = 0x40000000u, INF_E_INVALID = 0x20000000u;
+enum InflateTableKind { INF_T_PLAIN = 0, INF_T_LITLEN = 1, INF_T_DIST = 2 };      // PLAIN: (symbol << 4) | length, the code-length code
+RSQC_INF_FN uint32_t inflate_entry(int kind, uint32_t sym, uint32_t len) {
+    static const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    if (kind == INF_T_PLAIN) return (sym << 4) | len;
+    if (kind == INF_T_LITLEN) {
+        if (sym < 256u) return INF_E_LITERAL | (sym << 8) | len;
+        if (sym == 256u) return INF_E_END | len;
+        if (sym >= 286u) return INF_E_INVALID | len;
+        return ((uint32_t)kLenBase[sym - 257u] << 8) | ((uint32_t)kLenExtra[sym - 257u] << 4) | len;
+    }
+    if (sym >= 30u) return INF_E_INVALID | len;
+    return ((uint32_t)kDistBase[sym] << 8) | ((uint32_t)kDistExtra[sym] << 4) | len;
+}
+
 // lens[0..n): code lengths.  Builds count[]/sym[] (canonical order) and the fast table of `fbits` bits.  false = the
 // lengths over-subscribe the code space (zlib: "invalid code lengths set").  An incomplete set is accepted, as zlib
 // accepts a single distance code; a code nobody owns is an error when the stream uses it.
-RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *sym, uint16_t *fast, uint32_t fbits, uint16_t *offs) {
+RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *sym, uint32_t *fast, uint32_t fbits, uint16_t *offs, int kind) {
     for (uint32_t l = INF_LANE; l < 16u; l += INF_W) count[l] = 0;
     for (uint32_t k = INF_LANE; k < (1u << fbits); k += INF_W) fast[k] = 0;
     for (uint32_t s = 0; s < n; ++s) { const uint32_t l = INF_UNI(lens[s]); INF_ST(count[l]++); }
@@ -218,7 +240,7 @@ RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count,
             const uint32_t s = INF_UNI(sym[idx]);
             uint32_t rev = 0;
             for (uint32_t b = 0; b < l; ++b) rev |= ((code >> b) & 1u) << (l - 1u - b);
-            const uint16_t e = (uint16_t)((s << 4) | l);
+            const uint32_t e = inflate_entry(kind, s, l);
             for (uint32_t t = rev + (INF_LANE << l); t < (1u << fbits); t += (INF_W << l)) fast[t] = e;
         }
         code <<= 1;
@@ -239,7 +261,7 @@ RSQC_INF_FN uint32_t inflate_symbol_slow(uint64_t bits, const uint16_t *count, c
     return 0xFFFFu;
 }
 // one symbol at the head of the reader (the block headers' code-length code)
-RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint16_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *sym) {
+RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint32_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *sym) {
     const uint32_t e = INF_UNI(fast[in.peek(fbits)]);
     if (e) { in.drop(e & 15u); return e >> 4; }
     uint32_t len;
@@ -332,10 +354,6 @@ RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t d
 // has filled S.crc_tab).  Returns an InflateStatus (wave-uniform).
 // The caller provides 16 readable bytes past the payload's end (the bit reader looks ahead by whole dwords).
 RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_len, uint8_t *dst, uint32_t out_len, uint32_t crc32) {
-    static const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    static const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    static const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    static const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
     const uintptr_t addr = (uintptr_t)in;
@@ -359,7 +377,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
             if (at + len > lead + in_len) return INF_ERR_INPUT;
             const uint8_t *src = (const uint8_t *)bi.base + at;
             for (uint32_t done = 0; done < len;) {
-                const uint32_t n = (len - done < INF_FLUSH) ? len - done : INF_FLUSH;
+                const uint32_t n = (len - done < 1024u) ? len - done : 1024u;      // (unflushed output stays inside the ring)
                 for (uint32_t j = INF_LANE; j < n; j += INF_W) S.ring[(o.pos + j) & INF_RMASK] = src[done + j];
                 o.pos += n; done += n;
                 while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
@@ -382,7 +400,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                     INF_ST(S.lens[kClOrder[k]] = (uint8_t)v);
                 }
                 // the code-length code is decoded with the distance tables' storage (7-bit codes fit the 8-bit fast table)
-                if (!inflate_build(S.lens, 19, S.dcount, S.dsym, S.dfast, 7, S.offs)) return INF_ERR_TABLE;
+                if (!inflate_build(S.lens, 19, S.dcount, S.dsym, S.dfast, 7, S.offs, INF_T_PLAIN)) return INF_ERR_TABLE;
                 uint32_t i = 0, prev = 0;
                 while (i < nlit + ndist) {                         // (the code-length code's own lengths in lens[0..19) are not needed any more)
                     bi.refill();
@@ -399,8 +417,8 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                 }
                 if (INF_UNI(S.lens[256]) == 0u) return INF_ERR_TABLE;                // no end-of-block code
             }
-            if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfast, INF_LBITS, S.offs)) return INF_ERR_TABLE;
-            if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfast, INF_DBITS, S.offs)) return INF_ERR_TABLE;
+            if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
+            if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
             // ---- the symbols, in rounds.  The serial part of DEFLATE is that a symbol's position is known only once the one
             // before it has been decoded; what is NOT serial is the table look-up itself.  So every lane looks up the
             // literal/length table AND the distance table at "its" bit offset of the buffered 97+ bits (two LDS reads, one
@@ -417,29 +435,43 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                     INF_AT(L, k) = 0u;
                 }
                 uint32_t off = 0, nlit = 0;
-                while (off < 64u && off + 20u <= avail) {               // a literal/length code and its extra bits are in the buffer
-                    uint32_t e = INF_GET(E, off), len, s;
-                    if (e) { len = e & 15u; s = e >> 4; }
-                    else { s = inflate_symbol_slow(bi.bits_at(off), S.lcount, S.lsym, len); if (s == 0xFFFFu) return INF_ERR_SYMBOL; }
-                    if (s < 256u) { INF_SET(L, nlit, s); ++nlit; off += len; continue; }
+                const uint32_t walk_end = avail - 19u < 64u ? avail - 19u : 64u;      // a symbol may start at off < walk_end: its code and extra bits are buffered
+                for (;;) {
+                    // runs of literals: one v_readlane and a few scalar instructions each
+                    uint32_t e = 0;
+                    while (off < walk_end) {
+                        e = INF_GET(E, off);
+                        if (!(e & INF_E_LITERAL)) break;
+                        INF_SET(L, nlit, (e >> 8) & 0xFFu); ++nlit; off += e & 15u;
+                    }
+                    if (off >= walk_end) break;
+                    if (!e) {                                           // a code longer than the table's index
+                        uint32_t len;
+                        const uint32_t s = inflate_symbol_slow(bi.bits_at(off), S.lcount, S.lsym, len);
+                        if (s == 0xFFFFu) return INF_ERR_SYMBOL;
+                        e = inflate_entry(INF_T_LITLEN, s, len);
+                        if (e & INF_E_LITERAL) { INF_SET(L, nlit, (e >> 8) & 0xFFu); ++nlit; off += len; continue; }
+                    }
                     if (nlit) { if (!inflate_put_literals(S, o, L, nlit)) return INF_ERR_OUTPUT; nlit = 0; }
-                    off += len;
-                    if (s == 256u) { end_of_block = true; break; }
-                    s -= 257u;
-                    if (s >= 29u) return INF_ERR_SYMBOL;
-                    const uint32_t xb = kLenExtra[s];
-                    const uint32_t mlen = kLenBase[s] + ((uint32_t)bi.bits_at(off) & ((1u << xb) - 1u));
+                    off += e & 15u;
+                    if (e & INF_E_END) { end_of_block = true; break; }
+                    if (e & INF_E_INVALID) return INF_ERR_SYMBOL;
+                    const uint32_t xb = (e >> 4) & 15u;
+                    const uint32_t mlen = ((e >> 8) & 0xFFFFu) + ((uint32_t)bi.bits_at(off) & ((1u << xb) - 1u));
                     off += xb;
                     bool moved = false;
                     if (off + 28u > avail) { bi.drop(off); off = 0; bi.refill(); moved = true; }     // the distance code does not fit what is buffered
                     uint32_t f = (!moved && off < 64u) ? INF_GET(F, off) : INF_UNI(S.dfast[(uint32_t)bi.bits_at(off) & ((1u << INF_DBITS) - 1u)]);
-                    uint32_t dl, ds;
-                    if (f) { dl = f & 15u; ds = f >> 4; }
-                    else { ds = inflate_symbol_slow(bi.bits_at(off), S.dcount, S.dsym, dl); if (ds == 0xFFFFu) return INF_ERR_SYMBOL; }
-                    if (ds >= 30u) return INF_ERR_SYMBOL;
-                    off += dl;
-                    const uint32_t db = kDistExtra[ds];
-                    const uint32_t dist = kDistBase[ds] + ((uint32_t)bi.bits_at(off) & ((1u << db) - 1u));
+                    if (!f) {
+                        uint32_t dl;
+                        const uint32_t ds = inflate_symbol_slow(bi.bits_at(off), S.dcount, S.dsym, dl);
+                        if (ds == 0xFFFFu) return INF_ERR_SYMBOL;
+                        f = inflate_entry(INF_T_DIST, ds, dl);
+                    }
+                    if (f & INF_E_INVALID) return INF_ERR_SYMBOL;
+                    off += f & 15u;
+                    const uint32_t db = (f >> 4) & 15u;
+                    const uint32_t dist = ((f >> 8) & 0xFFFFu) + ((uint32_t)bi.bits_at(off) & ((1u << db) - 1u));
                     off += db;
                     if (dist > o.pos) return INF_ERR_DISTANCE;
                     if (o.pos + mlen > out_len) return INF_ERR_OUTPUT;
