@@ -477,6 +477,9 @@ typedef struct rsqc_decode_params {
     char    chimeric_tag[2];
     char    filter_tag[RSQC_MAX_FILTER_TAGS][2];   /* params.n_filter_tags names; {0,0} never matches          */
     uint64_t file_index_base;          /* index of the stream's first record in the whole file                 */
+    uint64_t reserve_inflated_bytes;   /* 0, or: size the device buffers at rsqc_decode_begin for calls of up to this many
+                                          inflated bytes (they grow on demand otherwise, which costs a re-allocation
+                                          of every window buffer each time a larger call arrives)                 */
 } rsqc_decode_params;
 typedef struct rsqc_decode_info {
     uint64_t records;                  /* records decoded and submitted since rsqc_decode_begin                */

@@ -135,7 +135,7 @@ class BgzfBlock(C.Structure):
 
 class DecodeParams(C.Structure):
     _fields_ = [("n_ref", C.c_int32), ("has_chimeric_tag", C.c_int32), ("chimeric_tag", C.c_char * 2),
-                ("filter_tag", (C.c_char * 2) * MAX_FILTER_TAGS), ("file_index_base", C.c_uint64)]
+                ("filter_tag", (C.c_char * 2) * MAX_FILTER_TAGS), ("file_index_base", C.c_uint64), ("reserve_inflated_bytes", C.c_uint64)]
 
 
 class DecodeWindow(C.Structure):

@@ -33,9 +33,10 @@ public:
     // Throws std::runtime_error on a file that is not a BAM.
     uint64_t first_record_voffset();
     // the blocks from virtual offset `beg` to `end` (0 = end of file); starts the read-ahead thread
-    void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)192 << 20, uint64_t max_out = (uint64_t)1536 << 20);
+    void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)128 << 20, uint64_t max_out = (uint64_t)1024 << 20);
     // next chunk, or nullptr at the end; the previous chunk becomes reusable.  Throws on a malformed block header.
     Chunk *next();
+    uint64_t file_size() const { return file_size_; }
     int read_threads = 4;
 
 private:

@@ -214,13 +214,16 @@ rsqc_decode_params decode_params(const Options &o, int n_ref, uint64_t file_inde
 // rsqc_decode_submit.  on_window sees what each call decoded.  Returns an RSQC_* code; info describes the whole stream.
 template <class F>
 int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, uint64_t voff_beg, uint64_t voff_end, rsqc_decode_info &info, F &&on_window) {
-    int rc = rsqc_decode_begin(gpu, &dp);
+    // Calls are large on purpose: the inflate kernel runs one wave per BGZF block, sixteen waves per CU -- a call needs
+    // thousands of blocks to fill the chip: up to 1 GB of inflated data (128 MB of file) per call, the device buffers sized for that once.
+    // (RSQC_DECODE_CHUNK / RSQC_DECODE_MAX_OUT: compressed bytes read per call at most / inflated bytes per call -- the tests use
+    //  small values so that records straddle many calls)
+    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
+    const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1024 << 20;
+    rsqc_decode_params dpr = dp;
+    dpr.reserve_inflated_bytes = std::min<uint64_t>(max_out + (1u << 20), feed.file_size() * 16 + (1u << 20));
+    int rc = rsqc_decode_begin(gpu, &dpr);
     if (rc != RSQC_OK) return rc;
-    // Calls are large on purpose: the inflate kernel runs one wave per BGZF block, sixteen waves per CU -- a call needs well
-    // over 4096 blocks (256 MB of inflated data) to fill the chip.  (RSQC_DECODE_CHUNK / RSQC_DECODE_MAX_OUT: compressed bytes
-    // read per call / inflated bytes per call -- the tests use small values so that records straddle many calls)
-    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)192 << 20;
-    const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1536 << 20;
     const bool prof = getenv("RSQC_DECODE_PROFILE") != nullptr;
     double t_feed = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };

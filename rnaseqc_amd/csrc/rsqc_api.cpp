@@ -1210,6 +1210,7 @@ int rsqc_reset_timing(rsqc_ctx *c) {
 }
 
 // ---- device-side BAM decode ---------------------------------------------------------------------------------------
+namespace { int decode_reserve(rsqc_ctx *c, size_t out_bytes, size_t comp_bytes, size_t n_blocks); }
 int rsqc_decode_begin(rsqc_ctx *c, const rsqc_decode_params *p) {
     if (!c || !p || p->n_ref < 0) return RSQC_ERR_ARG;
     if (!c->have_ann) return fail(c, RSQC_ERR_ARG, "rsqc_set_annotation must precede rsqc_decode_begin");
@@ -1230,6 +1231,10 @@ int rsqc_decode_begin(rsqc_ctx *c, const rsqc_decode_params *p) {
     if ((rc = dev_alloc(c, D.sum, sizeof(DecodeSummary), false)) || (rc = dev_alloc(c, D.carry, sizeof(DecodeCarry), true)) ||
         (rc = dev_alloc(c, D.scratch, DEC_SCRATCH_WORDS * 4, false))) return rc;
     if (!D.h_sum) HIP_TRY(c, hipHostMalloc((void **)&D.h_sum, sizeof(DecodeSummary), hipHostMallocDefault));
+    if (p->reserve_inflated_bytes) {
+        const size_t want = (size_t)std::min<uint64_t>(p->reserve_inflated_bytes, (1ull << 31) - D.head);
+        if ((rc = decode_reserve(c, want, want / 2, want / 32768 + 64))) return rc;
+    }
     D.active = true;
     return RSQC_OK;
 }
