@@ -8,9 +8,9 @@
 // Shape of the decoder on CDNA4:
 //  * the bit reader, the Huffman walk and the output position are WAVE-UNIFORM values (every lane computes the same
 //    thing), so the compiler keeps them in SGPRs and the walk runs on the scalar unit;
-//  * the table look-ups are NOT serial: every lane looks both Huffman tables up at its own bit offset of the buffered
-//    input, and the walk hops from symbol to symbol with v_readlane; literals are gathered one per lane and stored
-//    together;
+//  * only WHERE a symbol starts is serial: every lane decodes the whole symbol that would start at its own bit offset of
+//    the buffered input (both Huffman tables, extra bits, output length), the walk hops along those results with one
+//    v_readlane per symbol, a prefix sum places the symbols, literals are stored by their own lanes (inflate_round);
 //  * the compressed bytes arrive as one coalesced 256-byte vector load per 64 dwords (lane l holds dword l of the
 //    window, the next window is already in flight) and are handed to the bit reader with v_readlane;
 //  * the last 4 KiB of output live in an LDS ring, so a match is an LDS-to-LDS copy done by all lanes at once; the ring goes
@@ -63,6 +63,18 @@ struct InfVec { uint32_t v[64]; };
 
 namespace rsqc {
 
+// wave-wide helpers on lane vectors: which lanes hold a non-zero value, and the running (inclusive) sum over the lanes
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t inf_ballot(const InfVec &v) { return __ballot(v != 0u); }
+__device__ __forceinline__ InfVec inf_scan(InfVec v) {
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)v, d, 64); if (INF_LANE >= d) v += x; }
+    return v;
+}
+#else
+inline uint64_t inf_ballot(const InfVec &v) { uint64_t m = 0; for (uint32_t k = 0; k < 64u; ++k) if (v.v[k]) m |= 1ull << k; return m; }
+inline InfVec inf_scan(InfVec v) { for (uint32_t k = 1; k < 64u; ++k) v.v[k] += v.v[k - 1]; return v; }
+#endif
+
 enum InflateStatus {
     INF_OK = 0,
     INF_ERR_BTYPE = 1,        // reserved block type
@@ -86,7 +98,7 @@ constexpr uint32_t INF_RING_BITS = INF_RING_BITS_CFG, INF_RING = 1u << INF_RING_
 constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this are served from the ring
 constexpr uint32_t INF_LBITS = 9, INF_DBITS = 8;
 constexpr uint32_t INF_FLUSH = 2048;                   // the ring goes out to HBM (and through the CRC) in pieces of this size
-static_assert(INF_RING >= INF_FLUSH + 774u + 258u, "the far-match argument needs this");
+static_assert(INF_RING >= INF_FLUSH + 1024u + 774u, "the far-match argument needs this (a round adds up to 1024 bytes before the next flush)");
 
 // decoding tables + output history of one wave (LDS on the device)
 struct InflateScratch {
@@ -308,25 +320,26 @@ RSQC_INF_FN void inflate_flush(InflateScratch &S, InflateOut &o, uint32_t n) {
     o.flushed += n;
 }
 
-// the literals gathered in a round (lane j: the j-th) go into the ring with one store
-RSQC_INF_FN bool inflate_put_literals(InflateScratch &S, InflateOut &o, const InfVec &L, uint32_t n) {
-    if (o.pos + n > o.out_len) return false;
-    INF_FOREACH(j) { if (j < n) S.ring[(o.pos + j) & INF_RMASK] = (uint8_t)INF_AT(L, j); }
-    o.pos += n;
-    while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
-    return true;
-}
 // out[pos + j] = out[pos + j - dist], j < len.
 // Near (dist <= INF_NEAR): ring to ring.  A match that overlaps its own output (dist < len) repeats the dist bytes before
 // pos: every lane reads byte (j mod dist) of that period, so all of it is ONE round of independent LDS reads -- a run of a
 // single byte (dist 1, the bulk of SEQ/QUAL in low-entropy files) costs the same as any other match.  No write of the copy
 // can land on a slot that a later pass still has to read: that needs dist >= INF_RING - 257.
-// Far: the source left the ring; it is read back from the stream.  Those bytes have been flushed: unflushed output stays
-// below INF_FLUSH + 258 bytes, and the source ends before pos - dist + 258 < pos - INF_RING + 516 <= pos - INF_FLUSH - 258.
+// Far: the source left the ring; it is read back from the stream.  Those bytes have been flushed: a round starts with less
+// than INF_FLUSH unflushed bytes and adds at most INF_ROUND_BYTES before the next flush, and the source ends before
+// pos - dist + 258 < pos - INF_RING + 516 <= pos - INF_FLUSH - INF_ROUND_BYTES.
 // The loads follow the flush's stores of the same wave: a workgroup-scope fence (a wait for the stores, the CU's vector
 // cache is coherent within a workgroup) orders them.
-RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t dist, uint32_t len) {
-    const uint32_t pos = o.pos;
+#if defined(INF_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+struct InflateStats { unsigned long long near_matches, far_matches, match_bytes, rounds, round_symbols, slow_symbols, dist_hist[16], far_len_hist[10]; };
+inline InflateStats &inflate_stats() { static InflateStats st{}; return st; }
+#define INF_STAT(x) (x)
+#else
+#define INF_STAT(x) ((void)0)
+#endif
+RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t pos, uint32_t dist, uint32_t len) {
+    INF_STAT((dist > INF_NEAR ? inflate_stats().far_matches : inflate_stats().near_matches)++); INF_STAT(inflate_stats().match_bytes += len); INF_STAT(inflate_stats().dist_hist[32 - __builtin_clz(dist | 1u) > 15 ? 15 : 32 - __builtin_clz(dist | 1u)]++);
+    INF_STAT(dist > INF_NEAR ? inflate_stats().far_len_hist[len < 4 ? 0 : len <= 8 ? 1 : len <= 16 ? 2 : len <= 32 ? 3 : len <= 64 ? 4 : 5]++ : 0);
     if (dist > INF_NEAR) {
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -348,6 +361,140 @@ RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t d
             S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
         }
     }
+}
+
+// ---- the symbols of a block ---------------------------------------------------------------------------------------
+// What is serial in DEFLATE is only WHERE the next symbol starts.  Everything else about a symbol -- literal or match,
+// its length and distance, how many bits it takes, how many bytes it puts out -- depends on nothing but the bits at its
+// own offset.  So in a round every lane decodes, completely, "the symbol that would start at my bit offset" of the 97+
+// buffered bits (both Huffman tables, extra bits included); the wave-uniform walk then only hops along those results
+// (one v_readlane and four scalar instructions per symbol) to mark the lanes that ARE symbol starts; a prefix sum over
+// the marked lanes gives every symbol its place in the output; the literals are stored by their own lanes, the matches
+// are copied one after the other by the whole wave.
+enum { INF_K_LIT = 0, INF_K_MATCH = 1, INF_K_END = 2, INF_K_OTHER = 3 };      // OTHER: a code longer than the fast table, an undefined one, or bits not buffered yet
+constexpr uint32_t INF_ROUND_BYTES = 1024;       // output of one round at most (the ring keeps unflushed bytes: INF_FLUSH + this < INF_RING)
+
+// one symbol the long way (a code longer than the fast table's index, or the symbol the buffered bits ended in).
+// 0 = go on, 1 = end of block, < 0 = -InflateStatus
+RSQC_INF_FN int inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut &o) {
+    bi.refill();
+    uint32_t e = INF_UNI(S.lfast[bi.peek(INF_LBITS)]);
+    if (!e) {
+        uint32_t len;
+        const uint32_t s = inflate_symbol_slow(bi.lo, S.lcount, S.lsym, len);
+        if (s == 0xFFFFu) return -INF_ERR_SYMBOL;
+        e = inflate_entry(INF_T_LITLEN, s, len);
+    }
+    bi.drop(e & 15u);
+    if (e & INF_E_LITERAL) {
+        if (o.pos >= o.out_len) return -INF_ERR_OUTPUT;
+        INF_ST(S.ring[o.pos & INF_RMASK] = (uint8_t)(e >> 8));
+        o.pos++;
+        while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+        return 0;
+    }
+    if (e & INF_E_END) return 1;
+    if (e & INF_E_INVALID) return -INF_ERR_SYMBOL;
+    const uint32_t xb = (e >> 4) & 15u;
+    const uint32_t mlen = ((e >> 8) & 0xFFFFu) + bi.take(xb);
+    bi.refill();
+    uint32_t f = INF_UNI(S.dfast[bi.peek(INF_DBITS)]);
+    if (!f) {
+        uint32_t dl;
+        const uint32_t ds = inflate_symbol_slow(bi.lo, S.dcount, S.dsym, dl);
+        if (ds == 0xFFFFu) return -INF_ERR_SYMBOL;
+        f = inflate_entry(INF_T_DIST, ds, dl);
+    }
+    if (f & INF_E_INVALID) return -INF_ERR_SYMBOL;
+    bi.drop(f & 15u);
+    const uint32_t dist = ((f >> 8) & 0xFFFFu) + bi.take((f >> 4) & 15u);
+    if (dist > o.pos) return -INF_ERR_DISTANCE;
+    if (o.pos + mlen > o.out_len) return -INF_ERR_OUTPUT;
+    inflate_copy(S, o, o.pos, dist, mlen);
+    o.pos += mlen;
+    while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+    return 0;
+}
+
+RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
+    bi.refill();
+    const uint32_t avail = bi.cnt;
+    InfVec PK, VAL, OL;                                                     // (kind << 8) | bits of the whole symbol; literal byte or distance; output bytes
+    INF_FOREACH(k) {
+        const uint64_t w = bi.bits_at(k);
+        const uint32_t e = S.lfast[(uint32_t)w & ((1u << INF_LBITS) - 1u)];
+        uint32_t kind = INF_K_OTHER, adv = 0, ol = 0, val = 0;
+        if (e & INF_E_LITERAL) { kind = INF_K_LIT; adv = e & 15u; ol = 1; val = (e >> 8) & 0xFFu; }
+        else if (e & INF_E_END) { kind = INF_K_END; adv = e & 15u; }
+        else if (e && !(e & INF_E_INVALID)) {
+            const uint32_t l1 = e & 15u, xb = (e >> 4) & 15u;
+            const uint64_t w1 = w >> l1;
+            const uint32_t mlen = ((e >> 8) & 0xFFFFu) + ((uint32_t)w1 & ((1u << xb) - 1u));
+            const uint64_t w2 = w1 >> xb;
+            const uint32_t f = S.dfast[(uint32_t)w2 & ((1u << INF_DBITS) - 1u)];
+            if (f && !(f & INF_E_INVALID)) {
+                const uint32_t l2 = f & 15u, db = (f >> 4) & 15u;
+                kind = INF_K_MATCH; adv = l1 + xb + l2 + db; ol = mlen;
+                val = ((f >> 8) & 0xFFFFu) + ((uint32_t)(w2 >> l2) & ((1u << db) - 1u));
+            }
+        }
+        if (k + adv > avail) kind = INF_K_OTHER;                            // the symbol runs past the buffered bits
+        INF_AT(PK, k) = (kind << 8) | adv; INF_AT(VAL, k) = val; INF_AT(OL, k) = ol;
+    }
+    // the walk: which lanes are symbol starts
+    uint64_t starts = 0;
+    uint32_t off = 0, stopped_at = 0;
+    bool stopped = false;
+    while (off < 64u) {
+        const uint32_t a = INF_GET(PK, off);
+        if (a >= ((uint32_t)INF_K_END << 8)) { stopped = true; stopped_at = a; break; }
+        starts |= 1ull << off;
+        off += a & 0xFFu;
+    }
+    INF_STAT(inflate_stats().rounds++); INF_STAT(inflate_stats().round_symbols += (unsigned)__builtin_popcountll(starts)); INF_STAT(inflate_stats().slow_symbols += stopped ? 1 : 0);
+    if (starts) {
+        // every symbol's place in the output
+        InfVec X, INC;
+        INF_FOREACH(k) { INF_AT(X, k) = ((starts >> k) & 1ull) ? INF_AT(OL, k) : 0u; }
+        INC = inf_scan(X);
+        uint32_t total = INF_GET(INC, 63u);
+        if (total > INF_ROUND_BYTES) {                                      // keep the round's output inside the ring: cut it at the symbol that crosses the line
+            InfVec OVER;
+            INF_FOREACH(k) { INF_AT(OVER, k) = (((starts >> k) & 1ull) && INF_AT(INC, k) > INF_ROUND_BYTES) ? 1u : 0u; }
+            const uint32_t c = (uint32_t)__builtin_ctzll(inf_ballot(OVER));
+            starts &= (1ull << c) - 1ull;
+            total = INF_GET(INC, c) - INF_GET(X, c);
+            off = c; stopped = false;                                       // (the lane index IS the bit offset: the next round starts at that symbol)
+        }
+        if (o.pos + total > o.out_len) return -INF_ERR_OUTPUT;
+        InfVec ISLIT, ISMATCH;
+        INF_FOREACH(k) {
+            const bool mine = (starts >> k) & 1ull;
+            INF_AT(ISLIT, k) = (mine && (INF_AT(PK, k) >> 8) == (uint32_t)INF_K_LIT) ? 1u : 0u;
+            INF_AT(ISMATCH, k) = (mine && (INF_AT(PK, k) >> 8) == (uint32_t)INF_K_MATCH) ? 1u : 0u;
+        }
+        uint64_t lit = inf_ballot(ISLIT), match = inf_ballot(ISMATCH);
+        for (;;) {                                                          // in stream order: the literals before the next match, then the match
+            const uint32_t m = match ? (uint32_t)__builtin_ctzll(match) : 64u;
+            const uint64_t below = (m >= 64u) ? ~0ull : (1ull << m) - 1ull;
+            const uint64_t now = lit & below;
+            if (now) {
+                INF_FOREACH(k) { if ((now >> k) & 1ull) S.ring[(o.pos + INF_AT(INC, k) - 1u) & INF_RMASK] = (uint8_t)INF_AT(VAL, k); }
+                lit &= ~below;
+            }
+            if (m >= 64u) break;
+            const uint32_t mlen = INF_GET(OL, m), dist = INF_GET(VAL, m), at = o.pos + INF_GET(INC, m) - mlen;
+            if (dist > at) return -INF_ERR_DISTANCE;
+            inflate_copy(S, o, at, dist, mlen);
+            match &= match - 1ull;
+        }
+        o.pos += total;
+        while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
+    }
+    bi.drop(off);
+    if (!stopped) return 0;
+    if ((stopped_at >> 8) == (uint32_t)INF_K_END) { bi.drop(stopped_at & 0xFFu); return 1; }
+    return inflate_one_symbol(S, bi, o);
 }
 
 // Inflates `in_len` payload bytes at `in` into exactly `out_len` bytes at `dst` and checks their CRC-32 (inflate_crc_init
@@ -419,69 +566,11 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
             }
             if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
             if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
-            // ---- the symbols, in rounds.  The serial part of DEFLATE is that a symbol's position is known only once the one
-            // before it has been decoded; what is NOT serial is the table look-up itself.  So every lane looks up the
-            // literal/length table AND the distance table at "its" bit offset of the buffered 97+ bits (two LDS reads, one
-            // latency), and the wave-uniform walk then hops from symbol to symbol with v_readlane -- a handful of scalar
-            // instructions per symbol instead of an LDS round trip.
-            for (bool end_of_block = false; !end_of_block;) {
-                bi.refill();
-                const uint32_t avail = bi.cnt;
-                InfVec E, F, L;
-                INF_FOREACH(k) {
-                    const uint64_t w = bi.bits_at(k);
-                    INF_AT(E, k) = S.lfast[(uint32_t)w & ((1u << INF_LBITS) - 1u)];
-                    INF_AT(F, k) = S.dfast[(uint32_t)w & ((1u << INF_DBITS) - 1u)];
-                    INF_AT(L, k) = 0u;
-                }
-                uint32_t off = 0, nlit = 0;
-                const uint32_t walk_end = avail - 19u < 64u ? avail - 19u : 64u;      // a symbol may start at off < walk_end: its code and extra bits are buffered
-                for (;;) {
-                    // runs of literals: one v_readlane and a few scalar instructions each
-                    uint32_t e = 0;
-                    while (off < walk_end) {
-                        e = INF_GET(E, off);
-                        if (!(e & INF_E_LITERAL)) break;
-                        INF_SET(L, nlit, (e >> 8) & 0xFFu); ++nlit; off += e & 15u;
-                    }
-                    if (off >= walk_end) break;
-                    if (!e) {                                           // a code longer than the table's index
-                        uint32_t len;
-                        const uint32_t s = inflate_symbol_slow(bi.bits_at(off), S.lcount, S.lsym, len);
-                        if (s == 0xFFFFu) return INF_ERR_SYMBOL;
-                        e = inflate_entry(INF_T_LITLEN, s, len);
-                        if (e & INF_E_LITERAL) { INF_SET(L, nlit, (e >> 8) & 0xFFu); ++nlit; off += len; continue; }
-                    }
-                    if (nlit) { if (!inflate_put_literals(S, o, L, nlit)) return INF_ERR_OUTPUT; nlit = 0; }
-                    off += e & 15u;
-                    if (e & INF_E_END) { end_of_block = true; break; }
-                    if (e & INF_E_INVALID) return INF_ERR_SYMBOL;
-                    const uint32_t xb = (e >> 4) & 15u;
-                    const uint32_t mlen = ((e >> 8) & 0xFFFFu) + ((uint32_t)bi.bits_at(off) & ((1u << xb) - 1u));
-                    off += xb;
-                    bool moved = false;
-                    if (off + 28u > avail) { bi.drop(off); off = 0; bi.refill(); moved = true; }     // the distance code does not fit what is buffered
-                    uint32_t f = (!moved && off < 64u) ? INF_GET(F, off) : INF_UNI(S.dfast[(uint32_t)bi.bits_at(off) & ((1u << INF_DBITS) - 1u)]);
-                    if (!f) {
-                        uint32_t dl;
-                        const uint32_t ds = inflate_symbol_slow(bi.bits_at(off), S.dcount, S.dsym, dl);
-                        if (ds == 0xFFFFu) return INF_ERR_SYMBOL;
-                        f = inflate_entry(INF_T_DIST, ds, dl);
-                    }
-                    if (f & INF_E_INVALID) return INF_ERR_SYMBOL;
-                    off += f & 15u;
-                    const uint32_t db = (f >> 4) & 15u;
-                    const uint32_t dist = ((f >> 8) & 0xFFFFu) + ((uint32_t)bi.bits_at(off) & ((1u << db) - 1u));
-                    off += db;
-                    if (dist > o.pos) return INF_ERR_DISTANCE;
-                    if (o.pos + mlen > out_len) return INF_ERR_OUTPUT;
-                    inflate_copy(S, o, dist, mlen);
-                    o.pos += mlen;
-                    while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
-                    if (moved) break;                                   // this round's look-ups belong to bits that are gone
-                }
-                if (nlit && !inflate_put_literals(S, o, L, nlit)) return INF_ERR_OUTPUT;
-                bi.drop(off);
+            // ---- the symbols, in rounds (inflate_round)
+            for (;;) {
+                const int r = inflate_round(S, bi, o);
+                if (r < 0) return -r;
+                if (r > 0) break;
             }
         } else return INF_ERR_BTYPE;
         if (bfinal) break;
