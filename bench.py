@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--chr1", action="store_true", help="(diagnostic) BASELINE.json configs[1]: chr1-like GTF + --pairs pairs "
                                                          "(default 5 M) on one GPU; output marked invalid")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end tier (CLI on a BAM of the same records)")
-    ap.add_argument("--e2e-real", type=int, default=20_000_000, help="records of the realistic-entropy BAM flavour (0 = skip)")
+    ap.add_argument("--e2e-real", type=int, default=50_000_000, help="records of the realistic-entropy BAM flavour (0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="RSQC_HOST_THREADS for the CLI runs (0 = its default)")
     ap.add_argument("--tmp", default="", help="directory for the end_to_end files (default: the system temp dir)")
     ap.add_argument("--no-finalize", action="store_true", help="(diagnostic) time K1 only; output marked invalid")

@@ -506,6 +506,9 @@ RSQC_API int rsqc_decode_submit(rsqc_ctx *ctx, const void *compressed, uint64_t 
                                 uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out);
 /* Test hook: the batch the last rsqc_decode_submit produced, as DEVICE pointers (valid until the next decode call). */
 RSQC_API int rsqc_debug_last_decoded(rsqc_ctx *ctx, rsqc_batch *out);
+/* Test hook: bytes from a device pointer of this context's device (through the library's own HIP runtime, which a
+ * process that also loads another copy of the runtime -- PyTorch's -- cannot reach otherwise).                    */
+RSQC_API int rsqc_debug_read_device(rsqc_ctx *ctx, void *dst, const void *src_device, uint64_t bytes);
 /* End of the stream: RSQC_ERR_INPUT if an incomplete record is left over ("truncated BAM record").             */
 RSQC_API int rsqc_decode_end(rsqc_ctx *ctx, rsqc_decode_info *out);
 

@@ -125,3 +125,47 @@ def write_fasta(path, names, reference, line_bases=60, index_path=None):
     with open(index_path or path + ".fai", "w") as f:
         for rec in idx:
             f.write("%s\t%d\t%d\t%d\t%d\n" % rec)
+
+
+# ---- the host side of the device decode (rsqc_decode_*): file chunks and BGZF block tables from host/bgzf_feed.cpp ----
+import ctypes as C  # noqa: E402
+import os  # noqa: E402
+
+def _feed_lib():
+    l = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsqc_host.so"))
+    l.host_feed_open.restype = C.c_void_p; l.host_feed_open.argtypes = [C.c_char_p]
+    l.host_feed_first_voffset.restype = C.c_ulonglong; l.host_feed_first_voffset.argtypes = [C.c_void_p]
+    l.host_feed_start.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_int]
+    l.host_feed_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ulonglong), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                 C.POINTER(C.c_uint32), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+    l.host_feed_error.restype = C.c_char_p; l.host_feed_error.argtypes = [C.c_void_p]
+    l.host_feed_free.argtypes = [C.c_void_p]
+    return l
+
+
+BGZF_BLOCK = np.dtype([("in_offset", "<u8"), ("in_bytes", "<u4"), ("out_bytes", "<u4"), ("crc32", "<u4"), ("reserved", "<u4")])
+
+
+def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 << 40, threads=2):
+    """[(compressed bytes, block table, skip, limit, last)] of a range, through BgzfFeeder."""
+    l = _feed_lib()
+    h = l.host_feed_open(str(path).encode())
+    assert h
+    if voff_beg is None:
+        voff_beg = l.host_feed_first_voffset(h)
+        assert voff_beg != 2 ** 64 - 1, l.host_feed_error(h)
+    assert l.host_feed_start(h, voff_beg, voff_end, chunk_bytes, max_out, threads) == 0
+    out = []
+    while True:
+        data, nbytes, blocks, nb, skip, limit, last = C.c_void_p(), C.c_ulonglong(), C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_ulonglong(), C.c_int()
+        rc = l.host_feed_next(h, C.byref(data), C.byref(nbytes), C.byref(blocks), C.byref(nb), C.byref(skip), C.byref(limit), C.byref(last))
+        if rc < 0:
+            err = l.host_feed_error(h).decode(); l.host_feed_free(h)
+            raise RuntimeError(err)
+        if rc == 0:
+            break
+        comp = C.string_at(data.value, nbytes.value)
+        tab = np.frombuffer(C.string_at(blocks.value, nb.value * BGZF_BLOCK.itemsize), BGZF_BLOCK).copy() if nb.value else np.zeros(0, BGZF_BLOCK)
+        out.append((comp, tab, skip.value, limit.value, bool(last.value)))
+    l.host_feed_free(h)
+    return out

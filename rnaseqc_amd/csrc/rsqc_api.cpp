@@ -1395,6 +1395,14 @@ int rsqc_debug_last_decoded(rsqc_ctx *c, rsqc_batch *out) {
     return RSQC_OK;
 }
 
+int rsqc_debug_read_device(rsqc_ctx *c, void *dst, const void *src_device, uint64_t bytes) {
+    if (!c || (!dst && bytes) || (!src_device && bytes)) return RSQC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bytes) HIP_TRY(c, hipMemcpy(dst, src_device, (size_t)bytes, hipMemcpyDeviceToHost));
+    return RSQC_OK;
+}
+
 int rsqc_decode_end(rsqc_ctx *c, rsqc_decode_info *out) {
     if (!c) return RSQC_ERR_ARG;
     DecodeState &D = c->dec;

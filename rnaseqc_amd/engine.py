@@ -62,6 +62,7 @@ def load_library():
         lib.rsqc_decode_submit.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(abi.DecodeWindow)]
         lib.rsqc_decode_end.argtypes = [vp, C.POINTER(abi.DecodeInfo)]
         lib.rsqc_debug_last_decoded.argtypes = [vp, C.POINTER(abi.BatchStruct)]
+        lib.rsqc_debug_read_device.argtypes = [vp, vp, vp, C.c_uint64]
         _lib = lib
     return _lib
 
@@ -71,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
     "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
-    "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end", "rsqc_debug_last_decoded",
+    "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end", "rsqc_debug_last_decoded", "rsqc_debug_read_device",
 ]
 
 
@@ -179,6 +180,13 @@ class Engine:
             names = [arr[k].decode() for k in range(min(info.n_bad_refid, 64))]
         self._check(rc)
         return int(info.records), bool(info.unsorted), int(info.n_bad_refid), names
+
+    def read_device(self, ptr, count, dtype):
+        """count items of dtype from a device pointer (test hook)."""
+        out = np.zeros(count, dtype)
+        if count:
+            self._check(self._l.rsqc_debug_read_device(self._h, out.ctypes.data, ptr, out.nbytes))
+        return out
 
     def last_decoded(self):
         """abi.BatchStruct of DEVICE pointers: the batch of the last decode_submit (tests read it back with hipMemcpy)."""

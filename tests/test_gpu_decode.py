@@ -1,7 +1,6 @@
 """-m gpu: the device-side BAM decode (rsqc_decode_*) through the C ABI -- BGZF inflate, record framing
 and record parsing on the GPU -- against the records that were written (column for column, read back from the device),
 against the host-decoded run of the same file (every result), and through the command line in both decode modes."""
-import ctypes as C
 import os
 import subprocess
 
@@ -16,21 +15,6 @@ from tests.test_cli import cli, read_table, _compare_tables  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
-_hip = None
-
-
-def _dev_read(ptr, count, dtype):
-    """count items of dtype from a device pointer."""
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    out = np.zeros(count, dtype)
-    if count:
-        assert _hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0
-    return out
-
-
 def decode_file(e, path, n_ref, ch_tag="ch", filter_tags=(), chunk_bytes=48 << 20, max_out=768 << 20, collect=True, voff=None, base=0):
     """Feeds a BAM file (or the range voff = (beg, end)) through rsqc_decode_*.  With collect, reads every decoded
     batch back from the device and returns it concatenated."""
@@ -44,11 +28,11 @@ def decode_file(e, path, n_ref, ch_tag="ch", filter_tags=(), chunk_bytes=48 << 2
             e.wait()
             s = e.last_decoded()
             assert s.n == n and s.n_seg == len(runs)
-            core = _dev_read(s.core, n, abi.REC_CORE); aux = _dev_read(s.aux, n, abi.REC_AUX)
-            parts.append(dict(core=core, aux=aux, cigar=_dev_read(s.cigar, s.n_cigar_total, np.uint32),
-                              seg_tid=_dev_read(s.seg_tid, s.n_seg, np.int32), seg_start=_dev_read(s.seg_start, s.n_seg + 1, np.uint64),
-                              wide_index=_dev_read(s.wide_index, s.n_wide, np.uint64), wide_nm=_dev_read(s.wide_nm, s.n_wide, np.int32),
-                              wide_lq=_dev_read(s.wide_l_qseq, s.n_wide, np.int32), wide_nc=_dev_read(s.wide_n_cigar, s.n_wide, np.uint32),
+            rd = e.read_device
+            parts.append(dict(core=rd(s.core, n, abi.REC_CORE), aux=rd(s.aux, n, abi.REC_AUX), cigar=rd(s.cigar, s.n_cigar_total, np.uint32),
+                              seg_tid=rd(s.seg_tid, s.n_seg, np.int32), seg_start=rd(s.seg_start, s.n_seg + 1, np.uint64),
+                              wide_index=rd(s.wide_index, s.n_wide, np.uint64), wide_nm=rd(s.wide_nm, s.n_wide, np.int32),
+                              wide_lq=rd(s.wide_l_qseq, s.n_wide, np.int32), wide_nc=rd(s.wide_n_cigar, s.n_wide, np.uint32),
                               base=s.file_index_base))
     info = e.decode_end()
     return parts, runs_all, total, info, len(chunks)
