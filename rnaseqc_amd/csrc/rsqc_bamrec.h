@@ -207,10 +207,13 @@ RSQC_BAM_FN void bam_walk(const uint8_t *buf, uint32_t p, uint32_t hi, uint32_t 
 RSQC_BAM_FN void bam_frame_segment(const uint8_t *buf, uint32_t lo, uint32_t hi, uint32_t end, int32_t n_ref, uint32_t true_start, BamSegment &s) {
     uint32_t p = true_start;
     if (p == BAM_SEG_NONE) {
-        for (uint32_t c = lo; c < hi; ++c) {
+        for (uint32_t c = lo; c < hi; ++c) {                                 // three plausible records in a row (low-entropy SEQ / QUAL bytes pass two now and then)
             if (!bam_plausible(buf, c, end, n_ref)) continue;
             const uint64_t q = (uint64_t)c + 4 + bam_ld32(buf + c);
-            if (q + 36 <= end ? bam_plausible(buf, q, end, n_ref) : true) { p = c; break; }
+            if (q + 36 > end) { p = c; break; }
+            if (!bam_plausible(buf, q, end, n_ref)) continue;
+            const uint64_t r = q + 4 + bam_ld32(buf + q);
+            if (r + 36 <= end ? bam_plausible(buf, r, end, n_ref) : true) { p = c; break; }
         }
     }
     s.start = p;
@@ -233,6 +236,31 @@ RSQC_BAM_FN uint32_t bam_verify_chain(const uint8_t *buf, BamSegment *seg, uint3
     }
     for (; s < n_seg; ++s) { seg[s].start = truth; seg[s].land = truth; seg[s].n_rec = seg[s].n_ops = 0; }
     return truth;
+}
+// the same result as bam_verify_chain when only a few guesses are wrong: `list` holds, ascending, the segments whose guess is
+// not where the walk of the segment before them landed.  Each is walked again from the truth, and so is every segment
+// after it for as long as the corrected landing differs from that segment's start.  O(wrong guesses), not O(segments).
+// (Re-walking ALL unconfirmed segments in parallel does not converge: a segment with a correct guess behind a wrong one gets
+// re-walked from the wrong landing, and the defect moves forward one segment per round.)
+RSQC_BAM_FN uint32_t bam_repair_listed(const uint8_t *buf, BamSegment *seg, uint32_t n_seg, uint32_t base, uint32_t seg_bytes, uint32_t end,
+                                       const uint32_t *list, uint32_t n_list, uint32_t &bad) {
+    bad = seg[0].bad;
+    uint32_t done = 0;                                                   // segments below this are settled
+    for (uint32_t k = 0; k < n_list && !bad; ++k) {
+        uint32_t s = list[k];
+        if (s < done || s == 0) continue;
+        for (; s < n_seg; ++s) {
+            const uint32_t truth = seg[s - 1].land;
+            if (seg[s].start == truth && !seg[s].bad) break;
+            const uint32_t lo = base + s * seg_bytes, hi = (end - lo < seg_bytes) ? end : lo + seg_bytes;
+            seg[s].start = truth;
+            if (truth >= hi) { seg[s].land = truth; seg[s].n_rec = seg[s].n_ops = 0; seg[s].bad = 0; }    // a long record spans the segment
+            else bam_walk(buf, truth, hi, end, seg[s]);
+            if (seg[s].bad) { bad = 1; break; }
+        }
+        done = s;
+    }
+    return n_seg ? seg[n_seg - 1].land : base;
 }
 // second walk of a verified segment: where every record starts and where its operations go
 RSQC_BAM_FN void bam_segment_offsets(const uint8_t *buf, const BamSegment &s, uint32_t rec0, uint32_t ops0, uint32_t *rec_off, uint32_t *ops_at) {

@@ -137,7 +137,7 @@ RSQC_BAM_FN void decode_lists_finish(const DecodeWindow &W, uint32_t n, DecodeLi
 // rsqc_decode.hip
 void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *blk, uint32_t n_blk, uint8_t *out, DecodeSummary *sum);
 // scratch: DEC_SCRATCH_WORDS words of device memory for the scans' per-workgroup sums (window of at most 2 GiB)
-constexpr size_t DEC_SCRATCH_WORDS = 16 + 2 * 1024 + 4 * ((((size_t)1 << 31) / 36 + 8192) / 8192 + 8);
+constexpr size_t DEC_SCRATCH_WORDS = 16 + 2 * 1024 + 2048 + 4 * ((((size_t)1 << 31) / 36 + 8192) / 8192 + 8);
 void launch_decode_window(hipStream_t s, const DecodeWindow &W, uint32_t *scratch);
 #endif
 

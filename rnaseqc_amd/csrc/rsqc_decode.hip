@@ -15,11 +15,15 @@
 
 namespace rsqc {
 
+#ifndef RSQC_INFLATE_WAVES
+#define RSQC_INFLATE_WAVES 5
+#endif
 // ---- K0: one wave per BGZF block (work handed out by an atomic counter: block decode times differ) -----------------
-// LDS: 8.7 KB per wave, registers capped for four waves per SIMD (sixteen per CU): the decoder is a chain of dependent scalar
-// instructions, so the waves of a SIMD take turns in its issue slots.  WPW waves share a workgroup, each with its own scratch.
+// LDS: 7.7 KB per wave, registers capped for five waves per SIMD (twenty per CU): the decoder is a chain of dependent
+// instructions and LDS round trips, so the waves of a SIMD take turns in its issue slots (four waves per CU instead of
+// sixteen: 2.6 times slower).  WPW waves share a workgroup, each with its own scratch.
 template <int WPW>
-__global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_inflate_kernel(const uint8_t *__restrict__ in, const DevBgzfBlock *__restrict__ blk, uint32_t n_blk,
+__global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(RSQC_INFLATE_WAVES, RSQC_INFLATE_WAVES))) void bgzf_inflate_kernel(const uint8_t *__restrict__ in, const DevBgzfBlock *__restrict__ blk, uint32_t n_blk,
                                                                 uint8_t *__restrict__ out, DecodeSummary *sum) {
     __shared__ InflateScratch SS[WPW];
     InflateScratch &S = SS[WPW == 1 ? 0 : (threadIdx.x >> 6)];
@@ -61,32 +65,16 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *lds /* 
     return incl - v;
 }
 
-// ---- repair: a segment whose guess is not where the walk of the segment before it landed is walked again from there.
-// A few rounds settle the isolated wrong guesses that low-entropy SEQ/QUAL bytes produce; whatever is still unconfirmed
-// after them (a run of consecutive wrong guesses) is left to the sequential walk in bam_chain_top_kernel.
-__global__ __launch_bounds__(256) void bam_repair_kernel(DecodeWindow W) {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s == 0 || s >= W.n_seg) return;
-    const uint32_t truth = W.seg[s - 1].land;
-    BamSegment g = W.seg[s];
-    if (g.start == truth && !g.bad) return;
-    uint32_t lo, hi;
-    decode_segment_bounds(W, s, lo, hi);
-    g.start = truth;
-    bam_walk(W.buf, truth, hi, W.end, g);
-    W.seg[s] = g;
-}
-
 // ---- chain: are all guesses confirmed, and where do a segment's records and operations go.  Three launches: sums per
-// workgroup of 256 segments, one workgroup over those sums (and the exact, sequential repair when a guess was wrong), then
-// the positions inside every workgroup.
-constexpr uint32_t DEC_CHAIN_BLOCK = 256;
-__global__ __launch_bounds__(256) void bam_chain_sums_kernel(DecodeWindow W, uint32_t *blk_rec, uint32_t *blk_ops, uint32_t *all_ok) {
+// workgroup of 256 segments (and the list of segments whose guess is not confirmed), one workgroup over those sums (after
+// the exact repair of the listed segments: bam_repair_listed, a handful of walks), then the positions inside every workgroup.
+constexpr uint32_t DEC_CHAIN_BLOCK = 256, DEC_BAD_LIST = 2048;
+__global__ __launch_bounds__(256) void bam_chain_sums_kernel(DecodeWindow W, uint32_t *blk_rec, uint32_t *blk_ops, uint32_t *all_ok, uint32_t *bad_list) {
     __shared__ uint32_t lds[256];
     const uint32_t s = blockIdx.x * DEC_CHAIN_BLOCK + threadIdx.x;
     uint32_t nr = 0, no = 0;
     if (s < W.n_seg) {
-        if (!decode_guess_confirmed(W, s)) atomicAnd(all_ok, 0u);
+        if (!decode_guess_confirmed(W, s)) { const uint32_t k = atomicAdd(all_ok + 1, 1u); if (k < DEC_BAD_LIST) bad_list[k] = s; atomicAnd(all_ok, 0u); }
         nr = W.seg[s].n_rec; no = W.seg[s].n_ops;
     }
     uint32_t tr, to;
@@ -94,13 +82,25 @@ __global__ __launch_bounds__(256) void bam_chain_sums_kernel(DecodeWindow W, uin
     (void)block_scan_256(no, lds, to);
     if (threadIdx.x == 0) { blk_rec[blockIdx.x] = tr; blk_ops[blockIdx.x] = to; }
 }
-__global__ __launch_bounds__(1024) void bam_chain_top_kernel(DecodeWindow W, uint32_t *blk_rec, uint32_t *blk_ops, uint32_t n_blk, uint32_t *all_ok) {
+__global__ __launch_bounds__(1024) void bam_chain_top_kernel(DecodeWindow W, uint32_t *blk_rec, uint32_t *blk_ops, uint32_t n_blk, uint32_t *all_ok, uint32_t *bad_list) {
     __shared__ uint32_t s_rec[1024], s_ops[1024], s_consumed, s_bad;
     const uint32_t t = threadIdx.x;
     if (t == 0) { s_bad = 0; s_consumed = W.n_seg ? W.seg[W.n_seg - 1].land : W.start; }
     __syncthreads();
     if (W.n_seg && !*all_ok) {                                          // (uniform) a wrong guess: walk again from the truth, then redo the sums
-        if (t == 0) { uint32_t bad = 0; s_consumed = bam_verify_chain(W.buf, W.seg, W.n_seg, W.start, DEC_SEG_BYTES, W.end, bad); s_bad = bad; }
+        if (t == 0) {
+            uint32_t bad = 0;
+            const uint32_t n_list = all_ok[1];
+            if (n_list <= DEC_BAD_LIST) {
+                for (uint32_t i = 1; i < n_list; ++i) {                  // (the list arrives in the order of the atomics: a few entries, insertion sort)
+                    const uint32_t v = bad_list[i]; uint32_t j = i;
+                    for (; j > 0 && bad_list[j - 1] > v; --j) bad_list[j] = bad_list[j - 1];
+                    bad_list[j] = v;
+                }
+                s_consumed = bam_repair_listed(W.buf, W.seg, W.n_seg, W.start, DEC_SEG_BYTES, W.end, bad_list, n_list, bad);
+            } else s_consumed = bam_verify_chain(W.buf, W.seg, W.n_seg, W.start, DEC_SEG_BYTES, W.end, bad);
+            s_bad = bad;
+        }
         __syncthreads();
         for (uint32_t b = t; b < n_blk; b += 1024u) {
             uint32_t nr = 0, no = 0;
@@ -233,20 +233,20 @@ void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *b
         const uint32_t grid = n_blk < 256u * 16u ? n_blk : 256u * 16u;
         bgzf_inflate_kernel<1><<<grid, 64, 0, s>>>(in, blk, n_blk, out, sum);
     } else {
-        const uint32_t need = (n_blk + 3u) / 4u, grid = need < 256u * 4u ? need : 256u * 4u;
+        const uint32_t need = (n_blk + 3u) / 4u, grid = need < 256u * 8u ? need : 256u * 8u;
         bgzf_inflate_kernel<4><<<grid, 256, 0, s>>>(in, blk, n_blk, out, sum);
     }
 }
 void launch_decode_window(hipStream_t s, const DecodeWindow &W, uint32_t *scratch) {
     // scratch: DEC_SCRATCH_WORDS words: [0] the all-guesses-confirmed flag, then the per-workgroup sums of the two scans
     const uint32_t seg_blocks = (W.n_seg + DEC_CHAIN_BLOCK - 1) / DEC_CHAIN_BLOCK;
-    uint32_t *all_ok = scratch, *blk_rec = scratch + 16, *blk_ops = blk_rec + 1024;
-    DecodeListBlock *lblk = (DecodeListBlock *)(blk_ops + 1024);
-    (void)hipMemsetAsync(all_ok, 0xff, 4, s);
+    uint32_t *all_ok = scratch, *blk_rec = scratch + 16, *blk_ops = blk_rec + 1024, *bad_list = blk_ops + 1024;
+    DecodeListBlock *lblk = (DecodeListBlock *)(bad_list + DEC_BAD_LIST);
+    (void)hipMemsetAsync(all_ok, 0xff, 4, s);                                // [0] every guess confirmed so far
+    (void)hipMemsetAsync(all_ok + 1, 0, 4, s);                               // [1] entries of bad_list
     if (W.n_seg) bam_frame_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);
-    for (int round = 0; round < 3 && W.n_seg > 1; ++round) bam_repair_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);
-    if (seg_blocks) bam_chain_sums_kernel<<<seg_blocks, 256, 0, s>>>(W, blk_rec, blk_ops, all_ok);
-    bam_chain_top_kernel<<<1, 1024, 0, s>>>(W, blk_rec, blk_ops, seg_blocks, all_ok);
+    if (seg_blocks) bam_chain_sums_kernel<<<seg_blocks, 256, 0, s>>>(W, blk_rec, blk_ops, all_ok, bad_list);
+    bam_chain_top_kernel<<<1, 1024, 0, s>>>(W, blk_rec, blk_ops, seg_blocks, all_ok, bad_list);
     if (seg_blocks) bam_chain_place_kernel<<<seg_blocks, 256, 0, s>>>(W, blk_rec, blk_ops);
     if (W.n_seg) bam_offsets_kernel<<<(W.n_seg + 255u) / 256u, 256, 0, s>>>(W);
     bam_parse_kernel<<<256 * 8, 256, 0, s>>>(W);

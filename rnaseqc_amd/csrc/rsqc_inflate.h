@@ -14,10 +14,11 @@
 //  * the compressed bytes arrive as one coalesced 256-byte vector load per 64 dwords (lane l holds dword l of the
 //    window, the next window is already in flight) and are handed to the bit reader with v_readlane;
 //  * the last 4 KiB of output live in an LDS ring, so a match is an LDS-to-LDS copy done by all lanes at once; the ring goes
-//    out to HBM (and through the block's CRC-32) 1 KiB at a time, and the few matches that reach further back than the
+//    out to HBM (and through the block's CRC-32) 2 KiB at a time, and the matches that reach further back than the
 //    ring read the flushed bytes from HBM;
-//  * LDS per wave: 4 KiB ring + 4.6 KiB of tables, so four waves share a SIMD (the decoder is a chain of dependent
-//    scalar instructions: more waves is what fills the issue slots).
+//  * LDS per wave: 4 KiB ring + 3.7 KiB of tables, so five waves share a SIMD (a round is a chain of dependent steps --
+//    LDS look-ups, the walk, a prefix sum, LDS-to-LDS copies: other waves are what fills the gaps; one wave per SIMD is
+//    2.6 times slower, profiles/r2_decode_variants.txt).
 //
 // The same source compiles for the host with a wave of ONE lane (tests/hostemu/decode_emu.cpp), which is how it is
 // checked against zlib in the GPU-less container.
@@ -96,9 +97,23 @@ enum InflateStatus {
 #endif
 constexpr uint32_t INF_RING_BITS = INF_RING_BITS_CFG, INF_RING = 1u << INF_RING_BITS, INF_RMASK = INF_RING - 1u;
 constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this are served from the ring
-constexpr uint32_t INF_LBITS = 9, INF_DBITS = 8;            // (measured: 11 / 9 is 25 % slower -- the tables are rebuilt for every block)
-constexpr uint32_t INF_FLUSH = 2048;                   // the ring goes out to HBM (and through the CRC) in pieces of this size
-static_assert(INF_RING >= INF_FLUSH + 1024u + 774u, "the far-match argument needs this (a round adds up to 1024 bytes before the next flush)");
+// (sizes measured as whole-library variants on one box, profiles/r2_decode_variants.txt: 2^8 / 2^7 entry tables + five waves
+//  per SIMD beat 2^9 / 2^8 + four by 2 % / 6 % on the two files; 2^11 / 2^9 loses 25 %: the tables are rebuilt per block)
+#ifndef INF_LBITS_CFG
+#define INF_LBITS_CFG 8
+#endif
+#ifndef INF_DBITS_CFG
+#define INF_DBITS_CFG 7
+#endif
+#ifndef INF_FLUSH_CFG
+#define INF_FLUSH_CFG 2048
+#endif
+#ifndef INF_ROUND_BYTES_CFG
+#define INF_ROUND_BYTES_CFG 1024
+#endif
+constexpr uint32_t INF_LBITS = INF_LBITS_CFG, INF_DBITS = INF_DBITS_CFG;
+constexpr uint32_t INF_FLUSH = INF_FLUSH_CFG;          // the ring goes out to HBM (and through the CRC) in pieces of this size
+static_assert(INF_RING >= INF_FLUSH + INF_ROUND_BYTES_CFG + 774u, "the far-match argument needs this (a round adds up to 1024 bytes before the next flush)");
 
 // decoding tables + output history of one wave (LDS on the device)
 struct InflateScratch {
@@ -305,12 +320,23 @@ RSQC_INF_FN void inflate_flush(InflateScratch &S, InflateOut &o, uint32_t n) {
         if (v >= pad) { const uint32_t b = S.ring[(o.flushed + v - pad) & INF_RMASK]; r = S.crc_tab[(r ^ b) & 0xFFu] ^ (r >> 8); }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr uint32_t kFullPiece = crc_xpow(8ull * (INF_FLUSH / 64u));
-    uint32_t m = (n == INF_FLUSH) ? kFullPiece : crc_xpow(8ull * plen);                                // x^(8 plen): a constant for full chunks
-    for (uint32_t d = 1; d < 64u; d <<= 1) {                                                          // r[l] = r[l] * x^(8 plen d) + r[l + d]
-        const uint32_t hi = inflate_lane_down(r, d);
-        r = crc_mulmod(r, m) ^ hi;
-        m = crc_mulmod(m, m);
+    // r[l] = r[l] * x^(8 plen d) + r[l + d], d = 1, 2, .. 32
+    if (n == INF_FLUSH) {                                           // a full chunk's six multipliers are compile-time constants (-5 % kernel time)
+        constexpr uint32_t P = 8u * (INF_FLUSH / 64u);
+        constexpr uint32_t M0 = crc_xpow(P), M1 = crc_xpow(2ull * P), M2 = crc_xpow(4ull * P), M3 = crc_xpow(8ull * P), M4 = crc_xpow(16ull * P), M5 = crc_xpow(32ull * P);
+        r = crc_mulmod(r, M0) ^ inflate_lane_down(r, 1);
+        r = crc_mulmod(r, M1) ^ inflate_lane_down(r, 2);
+        r = crc_mulmod(r, M2) ^ inflate_lane_down(r, 4);
+        r = crc_mulmod(r, M3) ^ inflate_lane_down(r, 8);
+        r = crc_mulmod(r, M4) ^ inflate_lane_down(r, 16);
+        r = crc_mulmod(r, M5) ^ inflate_lane_down(r, 32);
+    } else {
+        uint32_t m = crc_xpow(8ull * plen);
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t hi = inflate_lane_down(r, d);
+            r = crc_mulmod(r, m) ^ hi;
+            m = crc_mulmod(m, m);
+        }
     }
     r = INF_UNI(r);
 #endif
@@ -349,7 +375,10 @@ RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t p
     } else if (dist >= len) {
         for (uint32_t j = INF_LANE; j < len; j += INF_W) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos + j - dist) & INF_RMASK];
     } else if (dist < 64u) {
-        const uint32_t recip = (65536u + dist - 1u) / dist;            // j / dist == (j * recip) >> 16 for j < 1040, dist < 64 (tests: every pair)
+        static const uint32_t kRecip[64] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096, 3856, 3641, 3450, 3277,
+                                            3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2048, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599,
+                                            1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041};
+        const uint32_t recip = kRecip[dist];                           // ceil(65536 / dist): j / dist == (j * recip) >> 16 for j < 1040, dist < 64 (tests: every pair)
         for (uint32_t j = INF_LANE; j < len; j += INF_W) {
             const uint32_t r = j - ((j * recip) >> 16) * dist;
             S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
@@ -372,7 +401,7 @@ RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t p
 // the marked lanes gives every symbol its place in the output; the literals are stored by their own lanes, the matches
 // are copied one after the other by the whole wave.
 enum { INF_K_LIT = 0, INF_K_MATCH = 1, INF_K_END = 2, INF_K_OTHER = 3 };      // OTHER: a code longer than the fast table, an undefined one, or bits not buffered yet
-constexpr uint32_t INF_ROUND_BYTES = 1024;       // output of one round at most (the ring keeps unflushed bytes: INF_FLUSH + this < INF_RING)
+constexpr uint32_t INF_ROUND_BYTES = INF_ROUND_BYTES_CFG;   // output of one round at most (the ring keeps unflushed bytes: INF_FLUSH + this < INF_RING)
 
 // one symbol the long way (a code longer than the fast table's index, or the symbol the buffered bits ended in).
 // 0 = go on, 1 = end of block, < 0 = -InflateStatus
@@ -524,7 +553,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
             if (at + len > lead + in_len) return INF_ERR_INPUT;
             const uint8_t *src = (const uint8_t *)bi.base + at;
             for (uint32_t done = 0; done < len;) {
-                const uint32_t n = (len - done < 1024u) ? len - done : 1024u;      // (unflushed output stays inside the ring)
+                const uint32_t step = INF_RING / 4u < 1024u ? INF_RING / 4u : 1024u, n = (len - done < step) ? len - done : step;      // (unflushed output stays inside the ring)
                 for (uint32_t j = INF_LANE; j < n; j += INF_W) S.ring[(o.pos + j) & INF_RMASK] = src[done + j];
                 o.pos += n; done += n;
                 while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);

@@ -118,8 +118,9 @@ def decode_stream(stream, first, n_ref, window_bytes, ch_tag="ch", filter_tags=(
         wi = np.zeros(cap, np.uint64); wn = np.zeros(cap, np.int32); wl = np.zeros(cap, np.int32); wc = np.zeros(cap, np.uint32)
         summ = np.zeros(8 + 64, np.uint32)
         padded = buf + b"\0" * 64
-        l.emu_decode_window(padded, 0, len(buf), C.byref(tags), threads, carry, perturb, abi.ptr(core), abi.ptr(aux), abi.ptr(cig),
-                            abi.ptr(st), abi.ptr(ss), abi.ptr(wi), abi.ptr(wn), abi.ptr(wl), abi.ptr(wc), abi.ptr(summ))
+        rc = l.emu_decode_window(padded, 0, len(buf), C.byref(tags), threads, carry, perturb, abi.ptr(core), abi.ptr(aux), abi.ptr(cig),
+                                 abi.ptr(st), abi.ptr(ss), abi.ptr(wi), abi.ptr(wn), abi.ptr(wl), abi.ptr(wc), abi.ptr(summ))
+        assert rc == 0, "the listed repair and the sequential walk disagree (%d)" % rc
         n, ops, nseg, nwide, nbad, uns, consumed, status = [int(x) for x in summ[:8]]
         out.status |= status
         if status:

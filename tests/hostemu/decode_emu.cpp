@@ -69,10 +69,23 @@ int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const Ba
     W.wide_index = wide_index; W.wide_nm = wide_nm; W.wide_lq = wide_lq; W.wide_nc = wide_nc;
     for (uint32_t s = 0; s < W.n_seg; ++s) decode_frame_one(W, s);
     if (perturb) for (uint32_t s = 1; s < W.n_seg; s += 3) { seg[s].start += (s % 2) ? 1 : 40; seg[s].n_rec += 1; }
-    bool all = true;
-    for (uint32_t s = 0; s < W.n_seg; ++s) all = all && decode_guess_confirmed(W, s);
+    // the chain step: the segments whose guess is not confirmed are repaired in order (bam_repair_listed); the plain sequential
+    // walk (what the device falls back to when the list overflows) must give the same segments
+    std::vector<uint32_t> list;
+    for (uint32_t s = 0; s < W.n_seg; ++s) if (!decode_guess_confirmed(W, s)) list.push_back(s);
     uint32_t consumed = start, bad = 0;
-    if (W.n_seg) consumed = all ? seg[W.n_seg - 1].land : bam_verify_chain(buf, seg.data(), W.n_seg, start, DEC_SEG_BYTES, end, bad);
+    if (W.n_seg) {
+        std::vector<BamSegment> ref = seg;
+        uint32_t bad_ref = 0;
+        const uint32_t c_ref = bam_verify_chain(buf, ref.data(), W.n_seg, start, DEC_SEG_BYTES, end, bad_ref);
+        consumed = list.empty() ? seg[W.n_seg - 1].land : bam_repair_listed(buf, seg.data(), W.n_seg, start, DEC_SEG_BYTES, end, list.data(), (uint32_t)list.size(), bad);
+        if (bad != bad_ref) return 101;
+        if (!bad) {
+            if (consumed != c_ref) return 102;
+            for (uint32_t s = 0; s < W.n_seg; ++s)
+                if (seg[s].n_rec != ref[s].n_rec || seg[s].n_ops != ref[s].n_ops || (seg[s].n_rec && seg[s].start != ref[s].start)) return 103;
+        }
+    }
     uint32_t n = 0, ops = 0;
     for (uint32_t s = 0; s < W.n_seg; ++s) { rec0[s] = n; ops0[s] = ops; n += seg[s].n_rec; ops += seg[s].n_ops; }
     sum.n_rec = n; sum.n_ops = ops; sum.consumed_end = consumed; sum.status = bad ? DEC_ST_BAD_RECORD : 0;
