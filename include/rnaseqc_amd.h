@@ -477,22 +477,27 @@ typedef struct rsqc_decode_params {
     char    chimeric_tag[2];
     char    filter_tag[RSQC_MAX_FILTER_TAGS][2];   /* params.n_filter_tags names; {0,0} never matches          */
     uint64_t file_index_base;          /* index of the stream's first record in the whole file                 */
+    int32_t  pipelined;                /* 1: a call returns once its kernels are enqueued; the NEXT call (or rsqc_decode_end)
+                                          completes it, so `out` then describes the call before -- the next chunk of the
+                                          file crosses PCIe beside this call's kernels                            */
+    int32_t  reserved;
     uint64_t reserve_inflated_bytes;   /* 0, or: size the device buffers at rsqc_decode_begin for calls of up to this many
                                           inflated bytes (they grow on demand otherwise, which costs a re-allocation
                                           of every window buffer each time a larger call arrives)                 */
 } rsqc_decode_params;
+typedef struct rsqc_decode_window {    /* what one rsqc_decode_submit decoded (arrays owned by the context, valid until its next decode call) */
+    uint64_t n_records;
+    uint32_t n_runs;                   /* runs of consecutive records on one reference sequence ...            */
+    const int32_t *run_tid;            /* ... their RefIDs, in file order (the batch's contig segments)        */
+} rsqc_decode_window;
 typedef struct rsqc_decode_info {
+    rsqc_decode_window last;           /* pipelined streams: what the last rsqc_decode_submit decoded            */
     uint64_t records;                  /* records decoded and submitted since rsqc_decode_begin                */
     int32_t  unsorted;                 /* a record starts before its predecessor on the same contig, judged on primary,
                                           mapped, QC-passed records: the reference's sort warning (src/RNASeQC.cpp:354) */
     int32_t  n_bad_refid;              /* records whose RefID the header does not define (:333-337) ...        */
     const char *const *bad_refid;      /* ... and the first 64 of their names (owned by the context)           */
 } rsqc_decode_info;
-typedef struct rsqc_decode_window {    /* what one rsqc_decode_submit decoded (arrays owned by the context, valid until its next call) */
-    uint64_t n_records;
-    uint32_t n_runs;                   /* runs of consecutive records on one reference sequence ...            */
-    const int32_t *run_tid;            /* ... their RefIDs, in file order (the batch's contig segments)        */
-} rsqc_decode_window;
 RSQC_API int rsqc_decode_begin(rsqc_ctx *ctx, const rsqc_decode_params *p);
 /* Inflates n_blocks consecutive blocks behind what the stream already holds, decodes every complete record and submits
  * them as one batch (asynchronous like rsqc_submit; `compressed` may be reused when the call returns).

@@ -135,7 +135,8 @@ class BgzfBlock(C.Structure):
 
 class DecodeParams(C.Structure):
     _fields_ = [("n_ref", C.c_int32), ("has_chimeric_tag", C.c_int32), ("chimeric_tag", C.c_char * 2),
-                ("filter_tag", (C.c_char * 2) * MAX_FILTER_TAGS), ("file_index_base", C.c_uint64), ("reserve_inflated_bytes", C.c_uint64)]
+                ("filter_tag", (C.c_char * 2) * MAX_FILTER_TAGS), ("file_index_base", C.c_uint64), ("pipelined", C.c_int32), ("reserved", C.c_int32),
+                ("reserve_inflated_bytes", C.c_uint64)]
 
 
 class DecodeWindow(C.Structure):
@@ -143,7 +144,7 @@ class DecodeWindow(C.Structure):
 
 
 class DecodeInfo(C.Structure):
-    _fields_ = [("records", C.c_uint64), ("unsorted", C.c_int32), ("n_bad_refid", C.c_int32), ("bad_refid", _P)]
+    _fields_ = [("last", DecodeWindow), ("records", C.c_uint64), ("unsorted", C.c_int32), ("n_bad_refid", C.c_int32), ("bad_refid", _P)]
 
 
 class ResultsStruct(C.Structure):

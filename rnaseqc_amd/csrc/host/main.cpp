@@ -221,6 +221,7 @@ int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, 
     const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
     const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1024 << 20;
     rsqc_decode_params dpr = dp;
+    dpr.pipelined = 1;                          // a call's records are reported by the call after it (the last by rsqc_decode_end)
     dpr.reserve_inflated_bytes = std::min<uint64_t>(max_out + (1u << 20), feed.file_size() * 16 + (1u << 20));
     int rc = rsqc_decode_begin(gpu, &dpr);
     if (rc != RSQC_OK) return rc;
@@ -238,10 +239,12 @@ int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, 
         rsqc_decode_window w{};
         rc = rsqc_decode_submit(gpu, ch->data, ch->bytes, ch->blocks.data(), (uint32_t)ch->blocks.size(), ch->skip, ch->limit, &w);
         if (rc != RSQC_OK) { rsqc_decode_info dropped{}; (void)rsqc_decode_end(gpu, &dropped); return rc; }
-        on_window(w);
+        if (w.n_records) on_window(w);
     }
     if (prof) fprintf(stderr, "[decode] host: %.1f ms waiting for file chunks of %.1f ms in the range\n", t_feed, std::chrono::duration<double, std::milli>(now() - t0).count());
-    return rsqc_decode_end(gpu, &info);
+    rc = rsqc_decode_end(gpu, &info);
+    if (rc == RSQC_OK && info.last.n_records) on_window(info.last);
+    return rc;
 }
 
 void shard_worker(Shard &sh, const std::string &bam_path, const Options &o, int threads, const std::vector<BamReader::ContigRange> &index,

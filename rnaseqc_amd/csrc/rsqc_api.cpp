@@ -94,6 +94,13 @@ struct DecodeState {
     bool profile = false; hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms_copy = 0, ms_inflate = 0, ms_parse = 0, ms_call = 0; uint64_t prof_in = 0, prof_out = 0, prof_calls = 0;
     std::chrono::steady_clock::time_point prof_t0;
+    // a call is enqueued, then finished (its summary read, its records submitted) -- at once, or by the next call when the
+    // stream is pipelined: the next call's file bytes then cross PCIe beside this call's kernels
+    bool pipelined = false, pending = false, pend_limited = false;
+    int slot = 0;                      // which half of comp / blocks / h_blocks the call in flight reads
+    DecodeWindow pend_w{};
+    std::chrono::steady_clock::time_point pend_wall0;
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_copy = nullptr;
     std::vector<int32_t> run_tid;      // contig segments of the last window
     rsqc_batch last{};                 // the last window's batch (device pointers), for rsqc_debug_last_decoded
 };
@@ -600,6 +607,8 @@ void rsqc_destroy(rsqc_ctx *c) {
                           &D.seg_tid, &D.seg_start, &D.wide_index, &D.wide_nm, &D.wide_lq, &D.wide_nc, &D.sum, &D.carry, &D.tailtmp, &D.scratch}) b->release();
         if (D.h_sum) (void)hipHostFree(D.h_sum);
         if (D.h_blocks) (void)hipHostFree(D.h_blocks);
+        if (D.ev_copy) (void)hipEventDestroy(D.ev_copy);
+        if (D.copy_stream) (void)hipStreamDestroy(D.copy_stream);
     }
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
@@ -1223,6 +1232,8 @@ int rsqc_decode_begin(rsqc_ctx *c, const rsqc_decode_params *p) {
     for (int k = 0; k < c->params.n_filter_tags; ++k) { D.tags.f0[k] = (uint8_t)p->filter_tag[k][0]; D.tags.f1[k] = (uint8_t)p->filter_tag[k][1]; }
     D.next_file_index = p->file_index_base; D.records = 0; D.tail = 0;
     D.unsorted = false; D.n_bad = 0; D.bad_names.clear();
+    D.pipelined = p->pipelined != 0; D.pending = false; D.slot = 0;
+    if (!D.copy_stream) { HIP_TRY(c, hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking)); HIP_TRY(c, hipEventCreateWithFlags(&D.ev_copy, hipEventDisableTiming)); }
     D.profile = getenv("RSQC_DECODE_PROFILE") != nullptr;
     D.ms_copy = D.ms_inflate = D.ms_parse = D.ms_call = 0; D.prof_in = D.prof_out = D.prof_calls = 0;
     D.prof_t0 = std::chrono::steady_clock::now();
@@ -1244,16 +1255,16 @@ namespace {
 int decode_reserve(rsqc_ctx *c, size_t out_bytes, size_t comp_bytes, size_t n_blocks) {
     DecodeState &D = c->dec;
     int rc;
-    if (comp_bytes + 64 > D.comp_cap) {
-        D.comp_cap = comp_bytes + comp_bytes / 4 + 64;
-        if ((rc = dev_alloc(c, D.comp, D.comp_cap, false))) return rc;
+    if (comp_bytes + 64 > D.comp_cap) {                        // (two halves: the call in flight and the one being copied)
+        D.comp_cap = (comp_bytes + comp_bytes / 4 + 64 + 255) & ~(size_t)255;
+        if ((rc = dev_alloc(c, D.comp, 2 * D.comp_cap, false))) return rc;
     }
     if (n_blocks > D.blk_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         D.blk_cap = n_blocks + n_blocks / 4 + 64;
-        if ((rc = dev_alloc(c, D.blocks, D.blk_cap * sizeof(DevBgzfBlock), false))) return rc;
+        if ((rc = dev_alloc(c, D.blocks, 2 * D.blk_cap * sizeof(DevBgzfBlock), false))) return rc;
         if (D.h_blocks) (void)hipHostFree(D.h_blocks);
-        HIP_TRY(c, hipHostMalloc((void **)&D.h_blocks, D.blk_cap * sizeof(DevBgzfBlock), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&D.h_blocks, 2 * D.blk_cap * sizeof(DevBgzfBlock), hipHostMallocDefault));
     }
     if (out_bytes <= D.out_cap) return 0;
     const size_t cap = std::max<size_t>(out_bytes + out_bytes / 8, 64u << 20);
@@ -1278,60 +1289,21 @@ int decode_reserve(rsqc_ctx *c, size_t out_bytes, size_t comp_bytes, size_t n_bl
 }
 }  // namespace
 
-int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_bytes, const rsqc_bgzf_block *blocks, uint32_t n_blocks,
-                       uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out) {
-    if (!c || (!compressed && compressed_bytes) || (!blocks && n_blocks)) return RSQC_ERR_ARG;
-    if (c->sticky) return c->sticky;
+namespace {
+// second half of a call: wait for the window's kernels, read its summary, submit its records as a batch, park what is left
+int decode_finish(rsqc_ctx *c, rsqc_decode_window *out) {
     DecodeState &D = c->dec;
-    if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_submit");
-    if (out) { out->n_records = 0; out->n_runs = 0; out->run_tid = nullptr; }
-    D.last = rsqc_batch{};
-    HIP_TRY(c, hipSetDevice(c->device));
-    uint64_t total = 0;
-    for (uint32_t k = 0; k < n_blocks; ++k) {
-        const rsqc_bgzf_block &b = blocks[k];
-        if (b.out_bytes > 65536u || b.in_offset > compressed_bytes || b.in_bytes > compressed_bytes - b.in_offset)
-            return fail(c, RSQC_ERR_ARG, "BGZF block outside the compressed buffer or with ISIZE above 64 KiB");
-        total += b.out_bytes;
-    }
-    if (total + D.head > (1ull << 31)) return fail(c, RSQC_ERR_ARG, "too much inflated data in one rsqc_decode_submit (2 GiB with the bytes carried over)");
-    if (skip_bytes && D.tail) return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record");
-    if (skip_bytes > total) return fail(c, RSQC_ERR_ARG, "skip_bytes beyond the inflated data");
+    if (!D.pending) return RSQC_OK;
+    D.pending = false;
+    const DecodeWindow &W = D.pend_w;
     int rc;
-    if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
-    { uint32_t at = D.head;
-      for (uint32_t k = 0; k < n_blocks; ++k) { D.h_blocks[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; } }
-    const auto wall0 = std::chrono::steady_clock::now();
-    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[0], c->stream));
-    if (compressed_bytes) HIP_TRY(c, hipMemcpyAsync(D.comp.p, compressed, (size_t)compressed_bytes, hipMemcpyHostToDevice, c->stream));
-    if (n_blocks) HIP_TRY(c, hipMemcpyAsync(D.blocks.p, D.h_blocks, (size_t)n_blocks * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(D.sum.p, 0, sizeof(DecodeSummary), c->stream));
-    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[1], c->stream));
-    launch_bgzf_inflate(c->stream, (const uint8_t *)D.comp.p, (const DevBgzfBlock *)D.blocks.p, n_blocks, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
-    const bool limited = limit_bytes && limit_bytes < total;
-    DecodeWindow W{};
-    W.buf = (const uint8_t *)D.ubuf.p;
-    W.start = D.head - D.tail + skip_bytes;
-    W.end = D.head + (uint32_t)(limited ? limit_bytes : total);
-    if (W.start > W.end) W.start = W.end;
-    W.n_seg = (W.end - W.start + DEC_SEG_BYTES - 1) / DEC_SEG_BYTES;
-    W.seg = (BamSegment *)D.seg.p; W.seg_rec0 = (uint32_t *)D.seg_rec0.p; W.seg_ops0 = (uint32_t *)D.seg_ops0.p;
-    W.rec_off = (uint32_t *)D.rec_off.p; W.ops_at = (uint32_t *)D.ops_at.p; W.mark = (uint8_t *)D.mark.p;
-    W.core = (rsqc_rec_core *)D.core.p; W.aux = (rsqc_rec_aux *)D.aux.p; W.cigar = (uint32_t *)D.cigar.p;
-    W.seg_tid = (int32_t *)D.seg_tid.p; W.seg_start = (uint64_t *)D.seg_start.p;
-    W.wide_index = (uint64_t *)D.wide_index.p; W.wide_nm = (int32_t *)D.wide_nm.p; W.wide_lq = (int32_t *)D.wide_lq.p; W.wide_nc = (uint32_t *)D.wide_nc.p;
-    W.sum = (DecodeSummary *)D.sum.p; W.carry = (DecodeCarry *)D.carry.p; W.tags = D.tags;
-    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[2], c->stream));
-    launch_decode_window(c->stream, W, (uint32_t *)D.scratch.p);
-    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[3], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(D.h_sum, D.sum.p, sizeof(DecodeSummary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (D.profile) {
         float a = 0, b = 0, d = 0;
         (void)hipEventElapsedTime(&a, D.pe[0], D.pe[1]); (void)hipEventElapsedTime(&b, D.pe[1], D.pe[2]); (void)hipEventElapsedTime(&d, D.pe[2], D.pe[3]);
         D.ms_copy += a; D.ms_inflate += b; D.ms_parse += d;
-        D.ms_call += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-        D.prof_in += compressed_bytes; D.prof_out += total; D.prof_calls++;
+        D.ms_call += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - D.pend_wall0).count();
+        D.prof_calls++;
     }
     HIP_TRY(c, hipGetLastError());
     const DecodeSummary &S = *D.h_sum;
@@ -1351,7 +1323,7 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     }
     D.n_bad += S.n_bad;
     // what is left of the window: an incomplete record stays in front of the next one
-    const uint32_t left = limited ? 0u : W.end - S.consumed_end;
+    const uint32_t left = D.pend_limited ? 0u : W.end - S.consumed_end;
     if (left) {
         if ((rc = dev_alloc(c, D.tailtmp, left, false))) return rc;
         HIP_TRY(c, hipMemcpyAsync(D.tailtmp.p, (const char *)D.ubuf.p + S.consumed_end, left, hipMemcpyDeviceToDevice, c->stream));
@@ -1388,6 +1360,75 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     D.tail = left;
     return RSQC_OK;
 }
+}  // namespace
+
+int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_bytes, const rsqc_bgzf_block *blocks, uint32_t n_blocks,
+                       uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out) {
+    if (!c || (!compressed && compressed_bytes) || (!blocks && n_blocks)) return RSQC_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    DecodeState &D = c->dec;
+    if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_submit");
+    if (out) { out->n_records = 0; out->n_runs = 0; out->run_tid = nullptr; }
+    D.last = rsqc_batch{};
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_blocks; ++k) {
+        const rsqc_bgzf_block &b = blocks[k];
+        if (b.out_bytes > 65536u || b.in_offset > compressed_bytes || b.in_bytes > compressed_bytes - b.in_offset)
+            return fail(c, RSQC_ERR_ARG, "BGZF block outside the compressed buffer or with ISIZE above 64 KiB");
+        total += b.out_bytes;
+    }
+    if (total + D.head > (1ull << 31)) return fail(c, RSQC_ERR_ARG, "too much inflated data in one rsqc_decode_submit (2 GiB with the bytes carried over)");
+    if (skip_bytes > total) return fail(c, RSQC_ERR_ARG, "skip_bytes beyond the inflated data");
+    int rc;
+    // buffers that have to grow are in use by the call in flight: it is finished first (rare: rsqc_decode_params.reserve_inflated_bytes)
+    const int slot = D.slot ^ 1;
+    if (D.pending && ((size_t)total > D.out_cap || (size_t)compressed_bytes + 64 > D.comp_cap || n_blocks > D.blk_cap)) { if ((rc = decode_finish(c, out))) return rc; }
+    if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
+    DevBgzfBlock *hb = D.h_blocks + (size_t)slot * D.blk_cap;
+    { uint32_t at = D.head;
+      for (uint32_t k = 0; k < n_blocks; ++k) { hb[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; } }
+    // the file bytes go up on the copy stream, beside the kernels of the call before this one (pipelined streams)
+    uint8_t *dcomp = (uint8_t *)D.comp.p + (size_t)slot * D.comp_cap;
+    DevBgzfBlock *dblk = (DevBgzfBlock *)D.blocks.p + (size_t)slot * D.blk_cap;
+    if (compressed_bytes) HIP_TRY(c, hipMemcpyAsync(dcomp, compressed, (size_t)compressed_bytes, hipMemcpyHostToDevice, D.copy_stream));
+    if (n_blocks) HIP_TRY(c, hipMemcpyAsync(dblk, hb, (size_t)n_blocks * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, D.copy_stream));
+    HIP_TRY(c, hipEventRecord(D.ev_copy, D.copy_stream));
+    // the call before this one: its kernels have had the time of this call's preparation
+    if (D.pending) { if ((rc = decode_finish(c, out))) return rc; }
+    if (skip_bytes && D.tail) return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record");
+    D.slot = slot;
+    D.pend_wall0 = std::chrono::steady_clock::now();
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[0], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, D.ev_copy, 0));
+    HIP_TRY(c, hipMemsetAsync(D.sum.p, 0, sizeof(DecodeSummary), c->stream));
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[1], c->stream));
+    launch_bgzf_inflate(c->stream, dcomp, dblk, n_blocks, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
+    const bool limited = limit_bytes && limit_bytes < total;
+    DecodeWindow &W = D.pend_w;
+    W = DecodeWindow{};
+    W.buf = (const uint8_t *)D.ubuf.p;
+    W.start = D.head - D.tail + skip_bytes;
+    W.end = D.head + (uint32_t)(limited ? limit_bytes : total);
+    if (W.start > W.end) W.start = W.end;
+    W.n_seg = (W.end - W.start + DEC_SEG_BYTES - 1) / DEC_SEG_BYTES;
+    W.seg = (BamSegment *)D.seg.p; W.seg_rec0 = (uint32_t *)D.seg_rec0.p; W.seg_ops0 = (uint32_t *)D.seg_ops0.p;
+    W.rec_off = (uint32_t *)D.rec_off.p; W.ops_at = (uint32_t *)D.ops_at.p; W.mark = (uint8_t *)D.mark.p;
+    W.core = (rsqc_rec_core *)D.core.p; W.aux = (rsqc_rec_aux *)D.aux.p; W.cigar = (uint32_t *)D.cigar.p;
+    W.seg_tid = (int32_t *)D.seg_tid.p; W.seg_start = (uint64_t *)D.seg_start.p;
+    W.wide_index = (uint64_t *)D.wide_index.p; W.wide_nm = (int32_t *)D.wide_nm.p; W.wide_lq = (int32_t *)D.wide_lq.p; W.wide_nc = (uint32_t *)D.wide_nc.p;
+    W.sum = (DecodeSummary *)D.sum.p; W.carry = (DecodeCarry *)D.carry.p; W.tags = D.tags;
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[2], c->stream));
+    launch_decode_window(c->stream, W, (uint32_t *)D.scratch.p);
+    if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[3], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(D.h_sum, D.sum.p, sizeof(DecodeSummary), hipMemcpyDeviceToHost, c->stream));
+    D.pending = true; D.pend_limited = limited;
+    if (D.profile) { D.prof_in += compressed_bytes; D.prof_out += total; }
+    // the caller's buffer is free again once the copy is through (the copy engine works beside the kernels)
+    HIP_TRY(c, hipStreamSynchronize(D.copy_stream));
+    if (!D.pipelined) return decode_finish(c, out);
+    return RSQC_OK;
+}
 
 int rsqc_debug_last_decoded(rsqc_ctx *c, rsqc_batch *out) {
     if (!c || !out) return RSQC_ERR_ARG;
@@ -1408,6 +1449,9 @@ int rsqc_decode_end(rsqc_ctx *c, rsqc_decode_info *out) {
     DecodeState &D = c->dec;
     if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_end");
     D.active = false;
+    rsqc_decode_window last{};
+    if (D.pending) { const int rcf = decode_finish(c, &last); if (rcf) return rcf; }
+    if (out) out->last = last;
     if (D.profile)
         fprintf(stderr, "[decode] %llu calls, %.1f MB in, %.1f MB inflated: copy %.1f ms, inflate %.1f ms (%.2f GB/s out), frame+parse %.1f ms, in the calls %.1f ms of %.1f ms between begin and end\n",
                 (unsigned long long)D.prof_calls, D.prof_in / 1e6, D.prof_out / 1e6, D.ms_copy, D.ms_inflate, D.ms_inflate > 0 ? D.prof_out / D.ms_inflate / 1e6 : 0.0,

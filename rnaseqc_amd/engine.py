@@ -140,8 +140,10 @@ class Engine:
         self._check(self._l.rsqc_wait(self._h))
 
     # ---- device-side BAM decode (rsqc_decode_*) -----------------------------------------------------------------
-    def decode_begin(self, n_ref, ch_tag="ch", filter_tags=(), file_index_base=0):
+    def decode_begin(self, n_ref, ch_tag="ch", filter_tags=(), file_index_base=0, pipelined=False, reserve=0):
         p = abi.DecodeParams()
+        p.pipelined = 1 if pipelined else 0
+        p.reserve_inflated_bytes = reserve
         p.n_ref = n_ref
         if ch_tag and len(ch_tag) == 2:
             p.has_chimeric_tag = 1; p.chimeric_tag = ch_tag.encode()
@@ -171,9 +173,12 @@ class Engine:
         return int(w.n_records), [int(t) for t in runs]
 
     def decode_end(self):
-        """(records, unsorted, number of records with an unrecognised RefID, first names of those)"""
+        """(records, unsorted, number of records with an unrecognised RefID, first names of those); .decode_last = (records,
+        runs) of the call that rsqc_decode_end completed (pipelined streams)"""
         info = abi.DecodeInfo()
         rc = self._l.rsqc_decode_end(self._h, C.byref(info))
+        lw = info.last
+        self.decode_last = (int(lw.n_records), [int(t) for t in np.ctypeslib.as_array(C.cast(lw.run_tid, C.POINTER(C.c_int32)), (lw.n_runs,))] if lw.n_runs else [])
         names = []
         if info.n_bad_refid and info.bad_refid:
             arr = C.cast(info.bad_refid, C.POINTER(C.c_char_p))

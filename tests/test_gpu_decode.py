@@ -92,6 +92,34 @@ def test_decode_columns_and_results(tmp_path, chunk_bytes, max_out):
     assert_results_match(got, want)
 
 
+def test_decode_pipelined_stream(tmp_path):
+    """rsqc_decode_params.pipelined: a call returns once its kernels are enqueued and is completed by the next one (the next
+    chunk of the file is copied beside its kernels); the counts arrive one call late, the last with rsqc_decode_end."""
+    contigs = [("chrA", 3_000_000), ("chrB", 1_000_000), ("chrC", 500_000)]
+    ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40), ("chrC", 500_000, 10)])
+    batch = synth.make_reads(ann, 60_000, seed=36, contig_lengths=np.array([3_000_000, 1_000_000, 500_000]))
+    path = str(tmp_path / "p.bam")
+    bamio.write_bam_fast(path, contigs, batch, threads=3, seq_mode=1)
+    p = abi.default_params()
+    want = engine.run_engine(p, ann, [batch])
+    for chunk, reserve in ((1 << 17, 0), (1 << 18, 64 << 20), (48 << 20, 0)):
+        e = engine.Engine(p)
+        e.set_annotation(ann)
+        e.decode_begin(3, pipelined=True, reserve=reserve)
+        counts, runs = [], []
+        chunks = feed_chunks(path, chunk_bytes=chunk)
+        for comp, tab, skip, limit, _last in chunks:
+            n, r = e.decode_submit(comp, tab, skip, limit)
+            counts.append(n); runs += r
+        info = e.decode_end()
+        counts.append(e.decode_last[0]); runs += e.decode_last[1]
+        assert counts[0] == 0 and sum(counts) == batch.n == info[0]
+        assert [t for k, t in enumerate(runs) if k == 0 or runs[k - 1] != t] == [int(t) for t in batch.seg_tid]
+        got = e.finalize()
+        e.close()
+        assert_results_match(got, want)
+
+
 def test_decode_fast_writer_blocks_long_record_and_ranges(tmp_path):
     """libdeflate-written blocks (the CLI benchmark's files), a 3 MB record that outgrows the head room kept for records that
     straddle two calls, and one contig at a time through the index's virtual offsets."""
