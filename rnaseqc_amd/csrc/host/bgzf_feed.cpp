@@ -52,7 +52,7 @@ bool BgzfFeeder::open(const std::string &path) {
     return true;
 }
 
-uint64_t BgzfFeeder::first_record_voffset() {
+uint64_t BgzfFeeder::first_record_voffset(std::vector<std::string> *names) {
     std::vector<uint8_t> raw, text;
     std::vector<std::pair<uint64_t, uint64_t>> blocks;                 // (file offset, inflated bytes before the block)
     uint64_t fpos = 0;
@@ -88,6 +88,7 @@ uint64_t BgzfFeeder::first_record_voffset() {
         need(p + 4);
         const uint32_t l_name = le32(text.data() + p);
         need(p + 8 + (size_t)l_name);
+        if (names) names->emplace_back((const char *)text.data() + p + 4, l_name ? l_name - 1 : 0);
         p += 8 + (size_t)l_name;
     }
     // the block that holds inflated offset p (the next block when the header ends with its block)

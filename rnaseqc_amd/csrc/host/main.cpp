@@ -409,15 +409,34 @@ int main(int argc, char **argv) {
             ann.load_bed(o.bed);
         }
         if (!make_dirs(out_dir)) { cerr << "Filesystem error:  cannot create " << out_dir << endl; return 8; }
+        // The header: with the device decode (the default) the host only inflates the header's own blocks; the multi-threaded
+        // CPU reader (whose pools start inflating the file as soon as it is opened) comes up only for RSQC_DECODE=host.
         BamReader bam;
-        if (!bam.open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
-        bam.set_tags(o.chimeric_tag, o.tags);
+        std::vector<std::string> bam_contigs;
+        uint64_t first_voff = 0;
+        bool bam_open = false;
+        auto open_host_reader = [&]() -> bool {
+            if (bam_open) return true;
+            if (!bam.open(bam_path)) return false;
+            bam.set_tags(o.chimeric_tag, o.tags);
+            bam_open = true;
+            return true;
+        };
+        if (device_decode_wanted()) {
+            BgzfFeeder probe;
+            if (!probe.open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+            try { first_voff = probe.first_record_voffset(&bam_contigs); }
+            catch (std::exception &) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+        } else {
+            if (!open_host_reader()) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+            bam_contigs = bam.contigs();
+        }
         // header check: at least one BAM contig must carry GTF features (src/RNASeQC.cpp:216-238)
         if (o.verbosity > 1) cout << "Checking bam header..." << endl;
         bool overlap = false;
-        for (auto &n : bam.contigs()) { auto it = ann.chrom_id.find(n); if (it != ann.chrom_id.end() && (size_t)it->second < gtf_chrom.size() && gtf_chrom[(size_t)it->second]) overlap = true; }
+        for (auto &n : bam_contigs) { auto it = ann.chrom_id.find(n); if (it != ann.chrom_id.end() && (size_t)it->second < gtf_chrom.size() && gtf_chrom[(size_t)it->second]) overlap = true; }
         if (!overlap) { cerr << "BAM file shares no contigs with GTF" << endl; return 11; }
-        ann.flatten(bam.contigs());
+        ann.flatten(bam_contigs);
 
         // ---- GPUs: one by default; --gpus N (or RSQC_GPUS) shards the file by contig, which needs the BAM index
         std::vector<int> devices;
@@ -430,7 +449,7 @@ int main(int argc, char **argv) {
                 devices.resize(1);
             }
         }
-        const int n_ref_bam = (int)bam.contigs().size();
+        const int n_ref_bam = (int)bam_contigs.size();
         std::vector<Shard> shards(devices.size());
         uint64_t tail_voff = 0;
         if (devices.size() > 1) {
@@ -494,6 +513,7 @@ int main(int argc, char **argv) {
         bool device_decode = device_decode_wanted();
         if (device_decode && shards.size() > 1)
             for (auto &r : bam.index()) if (r.present && !r.end) device_decode = false;
+        if (!device_decode && shards.size() == 1 && !open_host_reader()) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
         if (o.verbosity) cout << "Parsing bam..." << endl;
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
         HostBatch bufs[2];
@@ -541,7 +561,7 @@ int main(int argc, char **argv) {
             if (!feed.open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
             feed.read_threads = std::max(1, std::min(8, effective_cpus() / 2));
             rsqc_decode_info di{};
-            rc = decode_range(gpu, feed, decode_params(o, n_ref_bam, 0), feed.first_record_voffset(), 0, di, [&](const rsqc_decode_window &w) {
+            rc = decode_range(gpu, feed, decode_params(o, n_ref_bam, 0), first_voff, 0, di, [&](const rsqc_decode_window &w) {
                 bool revisit = false;
                 for (uint32_t k = 0; k < w.n_runs; ++k) {
                     const int32_t t = w.run_tid[k];
