@@ -210,6 +210,11 @@ rsqc_decode_params decode_params(const Options &o, int n_ref, uint64_t file_inde
     dp.file_index_base = file_index_base;
     return dp;
 }
+// inflated bytes a call of decode_range can hold: what the device's window buffers are sized for, once (rsqc_decode_begin)
+uint64_t decode_reserve_bytes(uint64_t file_size) {
+    const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1024 << 20;
+    return std::min<uint64_t>(max_out + (1u << 20), file_size * 16 + (1u << 20));
+}
 // One stream of BGZF blocks [voff_beg, voff_end) through the GPU: the feeder reads and frames the blocks, every chunk is one
 // rsqc_decode_submit.  on_window sees what each call decoded.  Returns an RSQC_* code; info describes the whole stream.
 template <class F>
@@ -222,7 +227,7 @@ int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, 
     const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1024 << 20;
     rsqc_decode_params dpr = dp;
     dpr.pipelined = 1;                          // a call's records are reported by the call after it (the last by rsqc_decode_end)
-    dpr.reserve_inflated_bytes = std::min<uint64_t>(max_out + (1u << 20), feed.file_size() * 16 + (1u << 20));
+    dpr.reserve_inflated_bytes = decode_reserve_bytes(feed.file_size());
     int rc = rsqc_decode_begin(gpu, &dpr);
     if (rc != RSQC_OK) return rc;
     const bool prof = getenv("RSQC_DECODE_PROFILE") != nullptr;
@@ -514,6 +519,19 @@ int main(int argc, char **argv) {
         if (device_decode && shards.size() > 1)
             for (auto &r : bam.index()) if (r.present && !r.end) device_decode = false;
         if (!device_decode && shards.size() == 1 && !open_host_reader()) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+        if (device_decode && !(getenv("RSQC_DECODE_PRERESERVE") && !atoi(getenv("RSQC_DECODE_PRERESERVE")))) {
+            // the device's window buffers are set up before the loop, like the host path's page-locked batches below
+            struct stat st{};
+            const uint64_t fsz = stat(bam_path.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+            for (auto &sh : shards) {
+                rsqc_decode_params dp = decode_params(o, n_ref_bam, 0);
+                dp.reserve_inflated_bytes = decode_reserve_bytes(fsz);
+                rsqc_decode_info none{};
+                if ((rc = rsqc_decode_begin(sh.gpu, &dp)) != RSQC_OK || (rc = rsqc_decode_end(sh.gpu, &none)) != RSQC_OK) {
+                    cerr << "Unable to set up the device decode: " << rsqc_last_error(sh.gpu) << endl; return 10;
+                }
+            }
+        }
         if (o.verbosity) cout << "Parsing bam..." << endl;
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
         HostBatch bufs[2];
