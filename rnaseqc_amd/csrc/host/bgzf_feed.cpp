@@ -102,6 +102,18 @@ uint64_t BgzfFeeder::first_record_voffset(std::vector<std::string> *names) {
     return 0;
 }
 
+void BgzfFeeder::reserve(size_t chunk_bytes) {
+    const size_t cap = (size_t)std::min<uint64_t>(std::max<size_t>(chunk_bytes, (size_t)1 << 17), std::max<uint64_t>(file_size_, (uint64_t)1 << 17));
+    for (auto &c : ring_) {
+        if (c.data && c.cap >= cap) continue;
+        if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
+        c.data = (uint8_t *)rsqc_host_alloc(cap + 64); c.pinned = c.data != nullptr;
+        if (!c.data) c.data = (uint8_t *)malloc(cap + 64);
+        if (!c.data) throw std::bad_alloc();
+        c.cap = cap;
+    }
+}
+
 void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes, uint64_t max_out) {
     cpos_ = voff_beg >> 16; skip_ = (uint32_t)(voff_beg & 0xffff);
     cend_ = voff_end >> 16; uend_ = (uint32_t)(voff_end & 0xffff);

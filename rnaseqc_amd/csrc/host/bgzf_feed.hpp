@@ -32,6 +32,9 @@ public:
     // Virtual offset (coffset << 16 | uoffset) of the first alignment record: inflates the header's blocks on the host.
     // names (may be null): the reference sequence names of the header.  Throws std::runtime_error on a file that is not a BAM.
     uint64_t first_record_voffset(std::vector<std::string> *names = nullptr);
+    // page-locks the three chunk buffers now (else: by the read-ahead thread when it first fills them -- page-locking takes
+    // the HIP runtime's lock, and the thread that feeds the GPU stalls behind it)
+    void reserve(size_t chunk_bytes);
     // the blocks from virtual offset `beg` to `end` (0 = end of file); starts the read-ahead thread
     void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)128 << 20, uint64_t max_out = (uint64_t)1024 << 20);
     // next chunk, or nullptr at the end; the previous chunk becomes reusable.  Throws on a malformed block header.
