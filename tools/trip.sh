@@ -1,22 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 600 python -m pytest tests/test_gpu_decode.py::test_cli_device_decode_equals_host_decode -m gpu -x -q 2>&1 | tail -3 ) > gpurun_out/t56_tests.log
-python - > gpurun_out/t56_ab.log 2>&1 <<'PY'
-import os, subprocess, sys, re
-R = os.environ["GRAFT_REPO_ROOT"]
-sys.path.insert(0, R)
-from rnaseqc_amd import bamio, synth
-contigs = synth.human_contigs(); ann = synth.make_annotation(seed=1, contigs=contigs)
-batch, _ = synth.make_reads_sharded(ann, 50_000_000, seed=2, workers=16)
-bamio.write_gtf("/tmp/s.gtf", ann)
-exe = os.path.join(R, "rnaseqc_amd", "bin", "rnaseqc")
-bam = "/tmp/s0.bam"
-bamio.write_bam_fast(bam, [(c[0], c[1]) for c in contigs], batch, threads=16, seq_mode=0)
-for rep in range(3):
-    for pre in ("1", "0"):
-        env = dict(os.environ, RSQC_DECODE="device", RSQC_DECODE_PROFILE="1", RSQC_FEED_PREPIN=pre)
-        p = subprocess.run([exe, "/tmp/s.gtf", bam, "/tmp/out", "-vv"], env=env, capture_output=True, text=True)
-        m = re.search(r"Average Reads/Sec: ([0-9.e+]+)", p.stdout)
-        d = [l[9:] for l in p.stderr.split("\n") if ("calls" in l and not l.startswith("[decode] 0 calls")) or "host:" in l]
-        print("prepin %s: %.1f M reads/s | %s" % (pre, float(m.group(1)) / 1e6 if m else -1, " | ".join(d) if d else p.stderr[-300:]), flush=True)
-PY
+( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ) > gpurun_out/t57_tests.log
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > gpurun_out/t57_smoke.log
+( timeout 900 python bench.py > gpurun_out/t57_bench.json 2> gpurun_out/t57_bench.err; tail -3 gpurun_out/t57_bench.err ) > gpurun_out/t57_bench.log 2>&1
