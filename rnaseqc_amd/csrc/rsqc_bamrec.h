@@ -134,11 +134,32 @@ RSQC_BAM_FN bool bam_parse_record(const uint8_t *rec, uint32_t block_size, const
     const int32_t l_seq = (int32_t)bam_ld32(r + 16), mtid = (int32_t)bam_ld32(r + 20), mpos = (int32_t)bam_ld32(r + 24), isize = (int32_t)bam_ld32(r + 28);
     const uint8_t *end_r = r + block_size;
     if (!bam_record_ops(rec, block_size, o.n_ops, o.ops_off)) return false;
+    // QNAME up to its NUL, hashed on the way (== bam_qname_hash of those bytes).  Eight bytes per load: on the device a lane's
+    // byte loads are a memory round trip each, and the name is the longest run of them in a record
     uint32_t qlen = 0;
-    { const uint8_t *qn = r + 32; const uint32_t room = (32ull + l_name <= block_size) ? l_name : 0u; while (qlen < room && qn[qlen]) ++qlen; }
+    uint64_t qh = 0xCBF29CE484222325ull;
+    {
+        const uint8_t *qn = r + 32;
+        const uint32_t room = (32ull + l_name <= block_size) ? l_name : 0u;
+        bool open_ = true;
+        while (open_ && qlen + 8u <= room) {
+            uint64_t w; __builtin_memcpy(&w, qn + qlen, 8);
+            for (uint32_t k = 0; k < 8u; ++k, w >>= 8) {
+                const uint32_t b = (uint32_t)w & 0xFFu;
+                if (!b) { open_ = false; break; }
+                qh ^= b; qh *= 0x100000001B3ull; ++qlen;
+            }
+        }
+        while (open_ && qlen < room) {
+            const uint32_t b = qn[qlen];
+            if (!b) break;
+            qh ^= b; qh *= 0x100000001B3ull; ++qlen;
+        }
+        qh ^= qh >> 33; qh *= 0xFF51AFD7ED558CCDull; qh ^= qh >> 33; qh *= 0xC4CEB9FE1A85EC53ull; qh ^= qh >> 33;
+    }
     o.qname_len = qlen;
     o.core.pos = pos; o.core.mpos = mpos; o.core.isize = isize; o.core.cigar_off = 0;
-    o.aux.qhash = bam_qname_hash(r + 32, qlen);
+    o.aux.qhash = qh;
     o.aux.flag = (uint16_t)flag; o.aux.mapq = (uint8_t)mapq;
     o.tid = tid;
     uint32_t tagbits = (tid == mtid) ? RSQC_TB_MTID_SAME : 0;
