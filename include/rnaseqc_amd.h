@@ -469,8 +469,12 @@ typedef struct rsqc_bgzf_block {
     uint32_t in_bytes;                 /* DEFLATE bytes (BSIZE + 1 - XLEN - 20)                                */
     uint32_t out_bytes;                /* ISIZE (<= 65536)                                                     */
     uint32_t crc32;                    /* of the inflated bytes (the gzip trailer)                             */
-    uint32_t reserved;
+    uint32_t flags;                    /* RSQC_BGZF_*                                                          */
 } rsqc_bgzf_block;
+/* The block has been inflated by the caller (spare CPU threads sharing the work with the GPU): in_offset locates its
+ * INFLATED bytes in `compressed`, in_bytes == out_bytes, the CRC-32 has been checked.  Such blocks form one run at the
+ * END of a call's table, their bytes one after the other in `compressed`.                                          */
+#define RSQC_BGZF_INFLATED 1u
 typedef struct rsqc_decode_params {
     int32_t n_ref;                     /* reference sequences in the BAM header                                */
     int32_t has_chimeric_tag;          /* --chimeric-tag (readStringTag, src/RNASeQC.cpp:780-800)              */

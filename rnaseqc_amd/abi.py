@@ -129,8 +129,11 @@ class BatchStruct(C.Structure):
     ]
 
 
+BGZF_INFLATED = 1
+
+
 class BgzfBlock(C.Structure):
-    _fields_ = [("in_offset", C.c_uint64), ("in_bytes", C.c_uint32), ("out_bytes", C.c_uint32), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("in_offset", C.c_uint64), ("in_bytes", C.c_uint32), ("out_bytes", C.c_uint32), ("crc32", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class DecodeParams(C.Structure):

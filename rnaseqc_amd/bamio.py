@@ -143,10 +143,10 @@ def _feed_lib():
     return l
 
 
-BGZF_BLOCK = np.dtype([("in_offset", "<u8"), ("in_bytes", "<u4"), ("out_bytes", "<u4"), ("crc32", "<u4"), ("reserved", "<u4")])
+BGZF_BLOCK = np.dtype([("in_offset", "<u8"), ("in_bytes", "<u4"), ("out_bytes", "<u4"), ("crc32", "<u4"), ("flags", "<u4")])
 
 
-def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 << 40, threads=2):
+def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 << 40, threads=2, cpu_share=None):
     """[(compressed bytes, block table, skip, limit, last)] of a range, through BgzfFeeder."""
     l = _feed_lib()
     h = l.host_feed_open(str(path).encode())
@@ -154,6 +154,9 @@ def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 
     if voff_beg is None:
         voff_beg = l.host_feed_first_voffset(h)
         assert voff_beg != 2 ** 64 - 1, l.host_feed_error(h)
+    if cpu_share:                                  # (threads, initial share, largest share): blocks the CPU inflates arrive flagged BGZF_INFLATED
+        l.host_feed_cpu_share.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        l.host_feed_cpu_share(h, *cpu_share)
     assert l.host_feed_start(h, voff_beg, voff_end, chunk_bytes, max_out, threads) == 0
     out = []
     while True:

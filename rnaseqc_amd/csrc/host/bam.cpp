@@ -258,6 +258,25 @@ struct LibDeflate {
 const LibDeflate &libdeflate() { static const LibDeflate d; return d; }
 }  // namespace
 
+bool bgzf_inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, uint32_t crc) {
+    if (!out_len) return true;
+    const LibDeflate &ld = libdeflate();
+    if (ld.ok) {
+        static thread_local void *d = nullptr;                      // (one decompressor per thread, kept)
+        if (!d) d = ld.alloc();
+        if (!d) return false;
+        return ld.decompress(d, in, in_len, out, out_len, nullptr) == 0 && ld.crc(0, out, out_len) == crc;
+    }
+    z_stream zs{};
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(in); zs.avail_in = (uInt)in_len;
+    zs.next_out = out; zs.avail_out = (uInt)out_len;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)out_len) == crc;
+    inflateEnd(&zs);
+    return ok;
+}
+
 // BGZF blocks are independent deflate streams whose uncompressed size sits in the trailer, so a group of
 // blocks is framed sequentially (headers only) and inflated in parallel straight into place.
 bool BamReader::produce_group(RawVec<uint8_t> &dst, size_t head) {

@@ -95,6 +95,8 @@ struct HostBatch {                       // owns the arrays an rsqc_batch points
 
 // CPUs the process may use: affinity mask capped by the cgroup CPU quota
 int effective_cpus();
+// one BGZF block's payload -> exactly out_len bytes, CRC-32 checked (libdeflate when the system has it, zlib otherwise)
+bool bgzf_inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, uint32_t crc);
 
 // fork-join helper: run(n, fn) calls fn(task) for task in [0, n) on the pool's threads and the caller
 class WorkPool {

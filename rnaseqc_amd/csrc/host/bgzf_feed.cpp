@@ -1,4 +1,5 @@
 #include "bgzf_feed.hpp"
+#include "bam.hpp"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -6,6 +7,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -35,10 +37,19 @@ uint32_t block_size(const uint8_t *h, size_t avail) {
 }
 }  // namespace
 
+void BgzfFeeder::set_cpu_share(int threads, double initial_share, double max_share) {
+    cpu_threads_ = std::max(0, threads);
+    max_share_ = std::min(0.9, std::max(0.0, max_share));
+    share_ = cpu_threads_ ? std::min(max_share_, std::max(0.0, initial_share)) : 0.0;
+    raw_cap_ = cpu_threads_ ? (size_t)(max_share_ * (double)((uint64_t)1 << 30)) + (1u << 20) : 0;       // the CPU's share of a 1 GB call, behind the file bytes
+    if (cpu_threads_ && !pool_) pool_ = new WorkPool(cpu_threads_);
+}
+
 BgzfFeeder::~BgzfFeeder() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
     cv_.notify_all();
     if (th_.joinable()) th_.join();
+    delete (WorkPool *)pool_;
     for (auto &c : ring_) if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
     if (fd_ >= 0) close(fd_);
 }
@@ -103,7 +114,8 @@ uint64_t BgzfFeeder::first_record_voffset(std::vector<std::string> *names) {
 }
 
 void BgzfFeeder::reserve(size_t chunk_bytes) {
-    const size_t cap = (size_t)std::min<uint64_t>(std::max<size_t>(chunk_bytes, (size_t)1 << 17), std::max<uint64_t>(file_size_, (uint64_t)1 << 17));
+    size_t cap = (size_t)std::min<uint64_t>(std::max<size_t>(chunk_bytes, (size_t)1 << 17), std::max<uint64_t>(file_size_, (uint64_t)1 << 17));
+    if (cpu_threads_) cap += raw_cap_ + 256;
     for (auto &c : ring_) {
         if (c.data && c.cap >= cap) continue;
         if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
@@ -138,9 +150,9 @@ bool BgzfFeeder::fill(Chunk &c) {
     const size_t ramp = std::min<size_t>(chunk_bytes_, ((size_t)24 << 20) << std::min(n_filled_, 8));
     ++n_filled_;
     const size_t want = (size_t)std::min<uint64_t>(ramp, file_size_ - cpos_);
-    if (!c.data || c.cap < want) {
+    if (!c.data || c.cap < want + (cpu_threads_ ? raw_cap_ + 256 : 0)) {
         if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
-        const size_t cap = std::min(chunk_bytes_, std::max(want, ramp * 4));      // (room for the next steps of the ramp)
+        const size_t cap = std::min(chunk_bytes_, std::max(want, ramp * 4)) + (cpu_threads_ ? raw_cap_ + 256 : 0);      // (room for the next steps of the ramp)
         c.data = (uint8_t *)rsqc_host_alloc(cap + 64); c.pinned = c.data != nullptr;
         if (!c.data) c.data = (uint8_t *)malloc(cap + 64);               // (no device: the tests of the feeder alone)
         if (!c.data) throw std::bad_alloc();
@@ -181,7 +193,31 @@ bool BgzfFeeder::fill(Chunk &c) {
         if (cpos_ + want >= file_size_) throw std::runtime_error("truncated BGZF block");
         throw std::runtime_error("BGZF block larger than the read chunk");
     }
-    c.bytes = p; cpos_ += p;
+    c.bytes = p; c.total_bytes = p; cpos_ += p;
+    // ---- the CPU's share: the last blocks of the chunk, inflated here into the buffer behind the file bytes
+    if (cpu_threads_ && share_ > 0 && !c.blocks.empty()) {
+        const size_t raw_off = (p + 255) & ~(size_t)255;
+        const uint64_t want_raw = (uint64_t)(share_ * (double)total_out);
+        size_t first = c.blocks.size(); uint64_t raw = 0;
+        while (first > 0 && raw + c.blocks[first - 1].out_bytes <= want_raw && raw_off + raw + c.blocks[first - 1].out_bytes <= c.cap) { --first; raw += c.blocks[first].out_bytes; }
+        if (first < c.blocks.size()) {
+            std::vector<uint64_t> at(c.blocks.size() - first + 1, 0);
+            for (size_t k = first; k < c.blocks.size(); ++k) at[k - first + 1] = at[k - first] + c.blocks[k].out_bytes;
+            std::atomic<bool> bad{false};
+            const size_t per = 4, n_tasks = (c.blocks.size() - first + per - 1) / per;
+            ((WorkPool *)pool_)->run(n_tasks, [&](size_t t) {
+                for (size_t k = first + t * per; k < std::min(c.blocks.size(), first + (t + 1) * per); ++k) {
+                    const rsqc_bgzf_block &b = c.blocks[k];
+                    if (!bgzf_inflate_block(c.data + b.in_offset, b.in_bytes, c.data + raw_off + at[k - first], b.out_bytes, b.crc32)) bad = true;
+                }
+            });
+            if (bad) throw std::runtime_error("BGZF inflate failed (corrupt block)");
+            for (size_t k = first; k < c.blocks.size(); ++k) {
+                c.blocks[k].in_offset = raw_off + at[k - first]; c.blocks[k].in_bytes = c.blocks[k].out_bytes; c.blocks[k].flags = RSQC_BGZF_INFLATED;
+            }
+            c.total_bytes = raw_off + (size_t)raw;
+        }
+    }
     c.skip = skip_; skip_ = 0;
     if (cpos_ >= file_size_) done_ = true;
     c.last = done_;
@@ -213,6 +249,10 @@ void BgzfFeeder::producer() {
 BgzfFeeder::Chunk *BgzfFeeder::next() {
     std::unique_lock<std::mutex> lk(mu_);
     if (lent_) { lent_ = nullptr; cv_.notify_all(); }
+    if (cpu_threads_) {                                             // the CPU's share follows the consumer (see set_cpu_share)
+        if (count_ > 0) share_ = std::min(max_share_, share_ + 0.01);
+        else if (!eof_) share_ = std::max(0.0, share_ - 0.04);
+    }
     cv_.wait(lk, [&] { return count_ > 0 || eof_; });
     if (count_ == 0) {
         if (!error_.empty()) throw std::runtime_error(error_);

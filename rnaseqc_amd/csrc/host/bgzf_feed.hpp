@@ -19,6 +19,7 @@ public:
     struct Chunk {
         uint8_t *data = nullptr; size_t cap = 0, bytes = 0; bool pinned = false;   // page-locked when a device is present
         std::vector<rsqc_bgzf_block> blocks;
+        size_t total_bytes = 0;                                    // file bytes + the inflated bytes of the CPU's share behind them: what the GPU call uploads
         uint32_t skip = 0;                                         // inflated bytes of the first block that precede the first record
         uint64_t limit = 0;                                        // 0, or the inflated offset (from the chunk's first block) where the range ends
         bool last = false;                                         // the range / file ends with this chunk
@@ -41,6 +42,11 @@ public:
     Chunk *next();
     uint64_t file_size() const { return file_size_; }
     int read_threads = 4;
+    // CPU share of the inflate work (device decode): the last blocks of every chunk are inflated here, by `threads` spare CPU
+    // threads (libdeflate), and handed over as RSQC_BGZF_INFLATED; the share follows the consumer -- it grows while
+    // next() finds a chunk waiting and shrinks when the consumer had to wait.  0 threads (default) = everything to the GPU.
+    void set_cpu_share(int threads, double initial_share = 0.15, double max_share = 0.5);
+    double cpu_share() const { return share_; }
 
 private:
     void producer();
@@ -51,6 +57,8 @@ private:
     Chunk ring_[3];
     int head_ = 0, tail_ = 0, count_ = 0; Chunk *lent_ = nullptr;
     bool eof_ = false, stop_ = false; std::string error_;
+    int cpu_threads_ = 0; double share_ = 0, max_share_ = 0.5; size_t raw_cap_ = 0;
+    void *pool_ = nullptr;                                           // WorkPool of the CPU share
     std::mutex mu_; std::condition_variable cv_;
     std::thread th_;
 };

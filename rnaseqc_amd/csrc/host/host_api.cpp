@@ -126,6 +126,7 @@ HAPI unsigned long long host_feed_first_voffset(void *hv) {
     FeedHandle *h = (FeedHandle *)hv;
     try { return h->feed.first_record_voffset(); } catch (std::exception &e) { h->error = e.what(); return ~0ull; }
 }
+HAPI void host_feed_cpu_share(void *hv, int threads, double initial_share, double max_share) { ((FeedHandle *)hv)->feed.set_cpu_share(threads, initial_share, max_share); }
 HAPI int host_feed_start(void *hv, unsigned long long voff_beg, unsigned long long voff_end, unsigned long long chunk_bytes, unsigned long long max_out, int read_threads) {
     FeedHandle *h = (FeedHandle *)hv;
     try { h->feed.read_threads = read_threads; h->feed.start(voff_beg, voff_end, (size_t)chunk_bytes, max_out); return 0; }
@@ -138,7 +139,7 @@ HAPI int host_feed_next(void *hv, const uint8_t **data, unsigned long long *byte
     try {
         rsqc_host::BgzfFeeder::Chunk *c = h->feed.next();
         if (!c) return 0;
-        *data = c->data; *bytes = c->bytes; *blocks = c->blocks.data(); *n_blocks = (uint32_t)c->blocks.size(); *skip = c->skip; *limit = c->limit; *last = c->last ? 1 : 0;
+        *data = c->data; *bytes = c->total_bytes; *blocks = c->blocks.data(); *n_blocks = (uint32_t)c->blocks.size(); *skip = c->skip; *limit = c->limit; *last = c->last ? 1 : 0;
         return 1;
     } catch (std::exception &e) { h->error = e.what(); return -1; }
 }

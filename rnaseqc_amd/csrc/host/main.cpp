@@ -244,11 +244,11 @@ int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, 
         if (!ch) break;
         if (ch->blocks.empty()) continue;
         rsqc_decode_window w{};
-        rc = rsqc_decode_submit(gpu, ch->data, ch->bytes, ch->blocks.data(), (uint32_t)ch->blocks.size(), ch->skip, ch->limit, &w);
+        rc = rsqc_decode_submit(gpu, ch->data, ch->total_bytes, ch->blocks.data(), (uint32_t)ch->blocks.size(), ch->skip, ch->limit, &w);
         if (rc != RSQC_OK) { rsqc_decode_info dropped{}; (void)rsqc_decode_end(gpu, &dropped); return rc; }
         if (w.n_records) on_window(w);
     }
-    if (prof) fprintf(stderr, "[decode] host: %.1f ms waiting for file chunks of %.1f ms in the range\n", t_feed, std::chrono::duration<double, std::milli>(now() - t0).count());
+    if (prof) fprintf(stderr, "[decode] host: CPU share of the inflate work at the end %.2f; %.1f ms waiting for file chunks of %.1f ms in the range\n", feed.cpu_share(), t_feed, std::chrono::duration<double, std::milli>(now() - t0).count());
     rc = rsqc_decode_end(gpu, &info);
     if (rc == RSQC_OK && info.last.n_records) on_window(info.last);
     return rc;
@@ -538,9 +538,15 @@ int main(int argc, char **argv) {
         std::vector<std::unique_ptr<BgzfFeeder>> feeders;
         if (device_decode) {
             const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
+            // RSQC_DECODE_CPU_THREADS=n: n spare CPU threads inflate the tail of every chunk beside the GPU (BgzfFeeder::set_cpu_share)
+            // (default: the CPUs the process may use minus four for the file reads and the thread that feeds the GPU; measured on the
+            //  16-CPU box, 12 threads: 258 -> 279 M reads/s, 85 -> 97 M on the realistic-entropy file, profiles/r2_decode_cpu_share_ab.txt)
+            const int spare = effective_cpus() - 4;
+            const int cpu_share_threads = getenv("RSQC_DECODE_CPU_THREADS") ? atoi(getenv("RSQC_DECODE_CPU_THREADS")) : (spare >= 4 ? spare : 0);
             for (size_t g = 0; g < shards.size(); ++g) {
                 feeders.emplace_back(new BgzfFeeder());
                 if (!feeders.back()->open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
+                if (cpu_share_threads > 0) feeders.back()->set_cpu_share(std::max(1, cpu_share_threads / (int)shards.size()));
                 if (!(getenv("RSQC_FEED_PREPIN") && !atoi(getenv("RSQC_FEED_PREPIN")))) feeders.back()->reserve(shards.size() == 1 ? chunk : std::max<size_t>(chunk / shards.size(), (size_t)16 << 20));
             }
             feeders[0]->read_threads = std::max(1, std::min(8, effective_cpus() / 2));

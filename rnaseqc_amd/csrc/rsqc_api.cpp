@@ -1371,11 +1371,18 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     if (out) { out->n_records = 0; out->n_runs = 0; out->run_tid = nullptr; }
     D.last = rsqc_batch{};
     HIP_TRY(c, hipSetDevice(c->device));
-    uint64_t total = 0;
+    uint64_t total = 0, raw_total = 0;
+    uint32_t n_gpu = n_blocks;                                          // blocks [n_gpu, n_blocks) arrive inflated (RSQC_BGZF_INFLATED)
     for (uint32_t k = 0; k < n_blocks; ++k) {
         const rsqc_bgzf_block &b = blocks[k];
         if (b.out_bytes > 65536u || b.in_offset > compressed_bytes || b.in_bytes > compressed_bytes - b.in_offset)
             return fail(c, RSQC_ERR_ARG, "BGZF block outside the compressed buffer or with ISIZE above 64 KiB");
+        if (b.flags & RSQC_BGZF_INFLATED) {
+            if (n_gpu == n_blocks) n_gpu = k;
+            if (b.in_bytes != b.out_bytes || b.in_offset != blocks[n_gpu].in_offset + raw_total)
+                return fail(c, RSQC_ERR_ARG, "inflated blocks must lie one after the other in the buffer, in_bytes == out_bytes");
+            raw_total += b.out_bytes;
+        } else if (n_gpu != n_blocks) return fail(c, RSQC_ERR_ARG, "inflated blocks must form one run at the end of the call");
         total += b.out_bytes;
     }
     if (total + D.head > (1ull << 31)) return fail(c, RSQC_ERR_ARG, "too much inflated data in one rsqc_decode_submit (2 GiB with the bytes carried over)");
@@ -1386,13 +1393,15 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     if (D.pending && ((size_t)total > D.out_cap || (size_t)compressed_bytes + 64 > D.comp_cap || n_blocks > D.blk_cap)) { if ((rc = decode_finish(c, out))) return rc; }
     if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
     DevBgzfBlock *hb = D.h_blocks + (size_t)slot * D.blk_cap;
+    uint32_t raw_at = D.head;                                           // where the caller-inflated run goes in the window
     { uint32_t at = D.head;
-      for (uint32_t k = 0; k < n_blocks; ++k) { hb[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; } }
+      for (uint32_t k = 0; k < n_gpu; ++k) { hb[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; }
+      raw_at = at; }
     // the file bytes go up on the copy stream, beside the kernels of the call before this one (pipelined streams)
     uint8_t *dcomp = (uint8_t *)D.comp.p + (size_t)slot * D.comp_cap;
     DevBgzfBlock *dblk = (DevBgzfBlock *)D.blocks.p + (size_t)slot * D.blk_cap;
     if (compressed_bytes) HIP_TRY(c, hipMemcpyAsync(dcomp, compressed, (size_t)compressed_bytes, hipMemcpyHostToDevice, D.copy_stream));
-    if (n_blocks) HIP_TRY(c, hipMemcpyAsync(dblk, hb, (size_t)n_blocks * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, D.copy_stream));
+    if (n_gpu) HIP_TRY(c, hipMemcpyAsync(dblk, hb, (size_t)n_gpu * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, D.copy_stream));
     HIP_TRY(c, hipEventRecord(D.ev_copy, D.copy_stream));
     // the call before this one: its kernels have had the time of this call's preparation
     if (D.pending) { if ((rc = decode_finish(c, out))) return rc; }
@@ -1403,7 +1412,9 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     HIP_TRY(c, hipStreamWaitEvent(c->stream, D.ev_copy, 0));
     HIP_TRY(c, hipMemsetAsync(D.sum.p, 0, sizeof(DecodeSummary), c->stream));
     if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[1], c->stream));
-    launch_bgzf_inflate(c->stream, dcomp, dblk, n_blocks, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
+    launch_bgzf_inflate(c->stream, dcomp, dblk, n_gpu, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
+    if (raw_total)                                                      // the caller-inflated run: staged with the file bytes, now moved into the window
+        HIP_TRY(c, hipMemcpyAsync((char *)D.ubuf.p + raw_at, dcomp + blocks[n_gpu].in_offset, (size_t)raw_total, hipMemcpyDeviceToDevice, c->stream));
     const bool limited = limit_bytes && limit_bytes < total;
     DecodeWindow &W = D.pend_w;
     W = DecodeWindow{};

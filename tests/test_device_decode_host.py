@@ -171,7 +171,10 @@ def _inflate_chunks(chunks):
     for comp, tab, skip, limit, _last in chunks:
         raw = []
         for b in tab:
-            d = zlib.decompress(comp[int(b["in_offset"]):int(b["in_offset"]) + int(b["in_bytes"])], -15)
+            if b["flags"] & abi.BGZF_INFLATED:                     # the feeder's CPU share: the bytes are already inflated (and checked)
+                d = comp[int(b["in_offset"]):int(b["in_offset"]) + int(b["in_bytes"])]
+            else:
+                d = zlib.decompress(comp[int(b["in_offset"]):int(b["in_offset"]) + int(b["in_bytes"])], -15)
             assert len(d) == b["out_bytes"] and zlib.crc32(d) == b["crc32"]
             raw.append(d)
         raw = b"".join(raw)
@@ -200,6 +203,31 @@ def test_feeder_whole_file_and_contig_ranges(tmp_path, chunk_bytes, max_out):
         assert d.n == hi - lo and list(d.seg_tid) == [int(batch.seg_tid[s])]
         np.testing.assert_array_equal(d.core["pos"], batch.pos[lo:hi])
         np.testing.assert_array_equal(d.aux["qhash"], batch.qhash[lo:hi])
+
+
+def test_feeder_cpu_share(tmp_path):
+    """The feeder inflates the tail of every chunk on CPU threads (RSQC_BGZF_INFLATED blocks behind the file bytes): one run at
+    the end of the table, bytes one after the other, and the stream is the same."""
+    contigs = [("chrA", 3_000_000), ("chrB", 1_000_000)]
+    ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40)])
+    batch = synth.make_reads(ann, 60_000, seed=36, keep_qnames=True, contig_lengths=np.array([3_000_000, 1_000_000]))
+    path = str(tmp_path / "c.bam")
+    bamio.write_bam_fast(path, contigs, batch, threads=3, seq_mode=1)
+    plain = _inflate_chunks(feed_chunks(path, chunk_bytes=1 << 20))
+    seen = 0
+    for share in ((3, 0.4, 0.5), (2, 0.05, 0.9)):
+        chunks = feed_chunks(path, chunk_bytes=1 << 20, cpu_share=share)
+        for comp, tab, _s, _l, _last in chunks:
+            fl = (tab["flags"] & abi.BGZF_INFLATED) != 0
+            seen += int(fl.sum())
+            if fl.any():
+                k = int(np.argmax(fl))
+                assert fl[k:].all() and not fl[:k].any()
+                assert (tab["in_bytes"][k:] == tab["out_bytes"][k:]).all()
+                assert (np.diff(tab["in_offset"][k:].astype(np.int64)) == tab["out_bytes"][k:-1]).all()
+                assert int(tab["in_offset"][-1]) + int(tab["out_bytes"][-1]) == len(comp)
+        assert _inflate_chunks(chunks) == plain
+    assert seen > 10
 
 
 def test_feeder_reports_truncated_and_foreign_files(tmp_path):

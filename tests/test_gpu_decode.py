@@ -15,10 +15,10 @@ from tests.test_cli import cli, read_table, _compare_tables  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
-def decode_file(e, path, n_ref, ch_tag="ch", filter_tags=(), chunk_bytes=48 << 20, max_out=768 << 20, collect=True, voff=None, base=0):
+def decode_file(e, path, n_ref, ch_tag="ch", filter_tags=(), chunk_bytes=48 << 20, max_out=768 << 20, collect=True, voff=None, base=0, cpu_share=None):
     """Feeds a BAM file (or the range voff = (beg, end)) through rsqc_decode_*.  With collect, reads every decoded
     batch back from the device and returns it concatenated."""
-    chunks = feed_chunks(path, *(voff or (None, 0)), chunk_bytes=chunk_bytes, max_out=max_out)
+    chunks = feed_chunks(path, *(voff or (None, 0)), chunk_bytes=chunk_bytes, max_out=max_out, cpu_share=cpu_share)
     e.decode_begin(n_ref, ch_tag, filter_tags, base)
     parts, runs_all, total = [], [], 0
     for comp, tab, skip, limit, _last in chunks:
@@ -90,6 +90,27 @@ def test_decode_columns_and_results(tmp_path, chunk_bytes, max_out):
     e.close()
     want = engine.run_engine(p, ann, [batch])
     assert_results_match(got, want)
+
+
+def test_decode_with_cpu_share(tmp_path):
+    """The feeder's CPU threads inflate the tail of every chunk (RSQC_BGZF_INFLATED blocks): same columns, same results."""
+    contigs = [("chrA", 3_000_000), ("chrB", 1_000_000), ("chrC", 500_000)]
+    ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40), ("chrC", 500_000, 10)])
+    batch = synth.make_reads(ann, 40_000, seed=36, keep_qnames=True, chimeric_tag_frac=0.02, filter_tag_frac=0.03,
+                             contig_lengths=np.array([3_000_000, 1_000_000, 500_000]))
+    path = str(tmp_path / "p.bam")
+    bamio.write_bam(path, contigs, batch)
+    p = abi.default_params(); p.n_filter_tags = 1
+    want = engine.run_engine(p, ann, [batch])
+    for chunk, share in ((1 << 19, (3, 0.4, 0.5)), (48 << 20, (2, 0.3, 0.9))):
+        e = engine.Engine(p)
+        e.set_annotation(ann)
+        parts, runs, total, info, n_calls = decode_file(e, path, 3, "ch", ("XF",), chunk, cpu_share=share)
+        assert total == batch.n
+        check_columns(parts, batch)
+        got = e.finalize()
+        e.close()
+        assert_results_match(got, want)
 
 
 def test_decode_pipelined_stream(tmp_path):
