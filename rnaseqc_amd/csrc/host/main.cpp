@@ -386,6 +386,30 @@ int main(int argc, char **argv) {
         // reference would first need it, so input errors keep their precedence and exit codes
         rsqc_ctx *gpu = nullptr;
         std::future<int> gpu_ready = std::async(std::launch::async, [&P, &gpu] { return rsqc_create(&P, &gpu); });
+        // ... and so do the page-locked chunk buffers of the device decode's feeder (one GPU: ~1.3 GB, a few hundred ms of
+        // page-locking that would otherwise sit between the GTF and the BAM loop).  A file that cannot be opened is reported
+        // later, where the reference reports it.
+        auto feeder_cpu_threads = [] {
+            const int spare = effective_cpus() - 4;
+            return getenv("RSQC_DECODE_CPU_THREADS") ? atoi(getenv("RSQC_DECODE_CPU_THREADS")) : (spare >= 4 ? spare : 0);
+        };
+        const size_t feeder_chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
+        const bool feeder_prepin = !(getenv("RSQC_FEED_PREPIN") && !atoi(getenv("RSQC_FEED_PREPIN")));
+        std::unique_ptr<BgzfFeeder> early_feed;
+        std::future<bool> early_feed_ready;
+        if (device_decode_wanted() && feeder_prepin && o.gpus <= 1 && !getenv("RSQC_GPUS") && !getenv("RSQC_GPU_LIST")) {
+            early_feed.reset(new BgzfFeeder());
+            BgzfFeeder *ef = early_feed.get();
+            const int ct = feeder_cpu_threads();
+            early_feed_ready = std::async(std::launch::async, [ef, bam_path, ct, feeder_chunk] {
+                try {
+                    if (!ef->open(bam_path)) return false;
+                    if (ct > 0) ef->set_cpu_share(ct);
+                    ef->reserve(feeder_chunk);
+                    return true;
+                } catch (std::exception &) { return false; }
+            });
+        }
         const auto t0 = std::chrono::steady_clock::now();
         Annotation ann;
         ann.legacy = o.legacy;
@@ -537,17 +561,17 @@ int main(int argc, char **argv) {
         // by the read-ahead thread during the loop it stalled the thread that feeds the GPU (193 -> 237 M reads/s)
         std::vector<std::unique_ptr<BgzfFeeder>> feeders;
         if (device_decode) {
-            const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
             // RSQC_DECODE_CPU_THREADS=n: n spare CPU threads inflate the tail of every chunk beside the GPU (BgzfFeeder::set_cpu_share)
             // (default: the CPUs the process may use minus four for the file reads and the thread that feeds the GPU; measured on the
             //  16-CPU box, 12 threads: 258 -> 279 M reads/s, 85 -> 97 M on the realistic-entropy file, profiles/r2_decode_cpu_share_ab.txt)
-            const int spare = effective_cpus() - 4;
-            const int cpu_share_threads = getenv("RSQC_DECODE_CPU_THREADS") ? atoi(getenv("RSQC_DECODE_CPU_THREADS")) : (spare >= 4 ? spare : 0);
+            const int cpu_share_threads = feeder_cpu_threads();
+            const bool early_ok = early_feed && early_feed_ready.valid() && early_feed_ready.get();
             for (size_t g = 0; g < shards.size(); ++g) {
+                if (g == 0 && early_ok && shards.size() == 1) { feeders.push_back(std::move(early_feed)); continue; }
                 feeders.emplace_back(new BgzfFeeder());
                 if (!feeders.back()->open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
                 if (cpu_share_threads > 0) feeders.back()->set_cpu_share(std::max(1, cpu_share_threads / (int)shards.size()));
-                if (!(getenv("RSQC_FEED_PREPIN") && !atoi(getenv("RSQC_FEED_PREPIN")))) feeders.back()->reserve(shards.size() == 1 ? chunk : std::max<size_t>(chunk / shards.size(), (size_t)16 << 20));
+                if (feeder_prepin) feeders.back()->reserve(shards.size() == 1 ? feeder_chunk : std::max<size_t>(feeder_chunk / shards.size(), (size_t)16 << 20));
             }
             feeders[0]->read_threads = std::max(1, std::min(8, effective_cpus() / 2));
         }
