@@ -37,11 +37,11 @@ uint32_t block_size(const uint8_t *h, size_t avail) {
 }
 }  // namespace
 
-void BgzfFeeder::set_cpu_share(int threads, double initial_share, double max_share) {
+void BgzfFeeder::set_cpu_share(int threads, double initial_share, double max_share, uint64_t call_out_bytes) {
     cpu_threads_ = std::max(0, threads);
     max_share_ = std::min(0.9, std::max(0.0, max_share));
     share_ = cpu_threads_ ? std::min(max_share_, std::max(0.0, initial_share)) : 0.0;
-    raw_cap_ = cpu_threads_ ? (size_t)(max_share_ * (double)((uint64_t)1 << 30)) + (1u << 20) : 0;       // the CPU's share of a 1 GB call, behind the file bytes
+    raw_cap_ = cpu_threads_ ? (size_t)(max_share_ * (double)call_out_bytes) + (1u << 20) : 0;             // the CPU's share of the largest call, behind the file bytes
     if (cpu_threads_ && !pool_) pool_ = new WorkPool(cpu_threads_);
 }
 

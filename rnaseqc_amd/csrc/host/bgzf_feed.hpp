@@ -45,7 +45,8 @@ public:
     // CPU share of the inflate work (device decode): the last blocks of every chunk are inflated here, by `threads` spare CPU
     // threads (libdeflate), and handed over as RSQC_BGZF_INFLATED; the share follows the consumer -- it grows while
     // next() finds a chunk waiting and shrinks when the consumer had to wait.  0 threads (default) = everything to the GPU.
-    void set_cpu_share(int threads, double initial_share = 0.15, double max_share = 0.5);
+    // call_out_bytes: the inflated bytes of the largest call (start()'s max_out): sizes the room behind the file bytes.
+    void set_cpu_share(int threads, double initial_share = 0.15, double max_share = 0.5, uint64_t call_out_bytes = (uint64_t)1 << 30);
     double cpu_share() const { return share_; }
 
 private:

@@ -570,7 +570,8 @@ int main(int argc, char **argv) {
                 if (g == 0 && early_ok && shards.size() == 1) { feeders.push_back(std::move(early_feed)); continue; }
                 feeders.emplace_back(new BgzfFeeder());
                 if (!feeders.back()->open(bam_path)) { cerr << "Unable to open BAM file: " << bam_path << endl; return 10; }
-                if (cpu_share_threads > 0) feeders.back()->set_cpu_share(std::max(1, cpu_share_threads / (int)shards.size()));
+                if (cpu_share_threads > 0)             // (a shard's calls are a contig at a time: a fraction of the room)
+                    feeders.back()->set_cpu_share(std::max(1, cpu_share_threads / (int)shards.size()), 0.15, 0.5, ((uint64_t)1 << 30) / shards.size());
                 if (feeder_prepin) feeders.back()->reserve(shards.size() == 1 ? feeder_chunk : std::max<size_t>(feeder_chunk / shards.size(), (size_t)16 << 20));
             }
             feeders[0]->read_threads = std::max(1, std::min(8, effective_cpus() / 2));
