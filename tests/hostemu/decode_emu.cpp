@@ -68,7 +68,20 @@ int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const Ba
     W.core = core; W.aux = aux; W.cigar = cigar; W.seg_tid = seg_tid; W.seg_start = seg_start;
     W.wide_index = wide_index; W.wide_nm = wide_nm; W.wide_lq = wide_lq; W.wide_nc = wide_nc;
     for (uint32_t s = 0; s < W.n_seg; ++s) decode_frame_one(W, s);
-    if (perturb) for (uint32_t s = 1; s < W.n_seg; s += 3) { seg[s].start += (s % 2) ? 1 : 40; seg[s].n_rec += 1; }
+    if (perturb == 1) for (uint32_t s = 1; s < W.n_seg; s += 3) { seg[s].start += (s % 2) ? 1 : 40; seg[s].n_rec += 1; }
+    if (perturb == 2) {                                            // a third of the guesses somewhere else in their segment, walked from there
+        uint32_t x = 12345u;
+        for (uint32_t s = 1; s < W.n_seg; ++s) {
+            x = x * 1664525u + 1013904223u;
+            if ((x >> 8) % 3u) continue;
+            uint32_t lo, hi; decode_segment_bounds(W, s, lo, hi);
+            seg[s].start = lo + (x >> 12) % (hi - lo);
+            bam_walk(buf, seg[s].start, hi, end, seg[s]);
+        }
+    }
+    if (perturb == 3) for (uint32_t s = 2; s < W.n_seg && s < 14; ++s) { seg[s].start += 7; seg[s].land += 3; }      // a run of consecutive wrong guesses
+    if (perturb == 4) for (uint32_t s = 1; s < W.n_seg; ++s) { seg[s].start = BAM_SEG_NONE; seg[s].n_rec = 0; seg[s].n_ops = 0; }   // no guess anywhere
+    if (perturb == 5) for (uint32_t s = 1; s < W.n_seg; s += 2) seg[s].bad = 1;                                   // walks that ran into garbage
     // the chain step: the segments whose guess is not confirmed are repaired in order (bam_repair_listed); the plain sequential
     // walk (what the device falls back to when the list overflows) must give the same segments
     std::vector<uint32_t> list;

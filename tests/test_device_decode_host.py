@@ -90,10 +90,13 @@ def _check(dec, batch):
     np.testing.assert_array_equal(np.array([w[0] for w in dec.wide], np.uint64), batch.wide_index)
 
 
-@pytest.mark.parametrize("window,threads,perturb", [(1 << 30, 7, 0), (100_000, 3, 0), (20_000, 1, 0), (333_333, 1024, 0), (150_000, 5, 1)])
+@pytest.mark.parametrize("window,threads,perturb", [(1 << 30, 7, 0), (100_000, 3, 0), (20_000, 1, 0), (333_333, 1024, 0), (150_000, 5, 1),
+                                                    (1 << 30, 4, 2), (250_000, 4, 2), (1 << 30, 4, 3), (1 << 30, 2, 4), (90_000, 2, 4), (1 << 30, 3, 5)])
 def test_window_decode_matches_the_written_records(tmp_path, window, threads, perturb):
     """BGZF blocks through the emulated inflate, then frame / chain / offsets / parse / lists in windows: records that
-    span windows, windows smaller than a segment's worth of records, moved guesses the chain step has to repair."""
+    span windows, windows smaller than a segment's worth of records, and guesses made wrong on purpose that the chain step has
+    to repair (moved, random, a run of consecutive ones, none at all, walks flagged as garbage): the listed repair must leave
+    the segments the plain sequential walk leaves (checked inside the emulation for every window)."""
     contigs = [("chrA", 3_000_000), ("chrB", 1_000_000), ("chrC", 500_000)]
     ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40), ("chrC", 500_000, 10)])
     batch = synth.make_reads(ann, 12_000, seed=36, keep_qnames=True, chimeric_tag_frac=0.02, filter_tag_frac=0.03,
