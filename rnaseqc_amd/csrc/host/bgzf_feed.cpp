@@ -195,9 +195,10 @@ bool BgzfFeeder::fill(Chunk &c) {
     }
     c.bytes = p; c.total_bytes = p; cpos_ += p;
     // ---- the CPU's share: the last blocks of the chunk, inflated here into the buffer behind the file bytes
-    if (cpu_threads_ && share_ > 0 && !c.blocks.empty()) {
+    const double share = share_.load();
+    if (cpu_threads_ && share > 0 && !c.blocks.empty()) {
         const size_t raw_off = (p + 255) & ~(size_t)255;
-        const uint64_t want_raw = (uint64_t)(share_ * (double)total_out);
+        const uint64_t want_raw = (uint64_t)(share * (double)total_out);
         size_t first = c.blocks.size(); uint64_t raw = 0;
         while (first > 0 && raw + c.blocks[first - 1].out_bytes <= want_raw && raw_off + raw + c.blocks[first - 1].out_bytes <= c.cap) { --first; raw += c.blocks[first].out_bytes; }
         if (first < c.blocks.size()) {
@@ -250,8 +251,8 @@ BgzfFeeder::Chunk *BgzfFeeder::next() {
     std::unique_lock<std::mutex> lk(mu_);
     if (lent_) { lent_ = nullptr; cv_.notify_all(); }
     if (cpu_threads_) {                                             // the CPU's share follows the consumer (see set_cpu_share)
-        if (count_ > 0) share_ = std::min(max_share_, share_ + 0.01);
-        else if (!eof_) share_ = std::max(0.0, share_ - 0.04);
+        if (count_ > 0) share_ = std::min(max_share_, share_.load() + 0.01);
+        else if (!eof_) share_ = std::max(0.0, share_.load() - 0.04);
     }
     cv_.wait(lk, [&] { return count_ > 0 || eof_; });
     if (count_ == 0) {

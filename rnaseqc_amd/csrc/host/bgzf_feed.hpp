@@ -3,6 +3,7 @@
 // Replaces, together with the device kernels, the reference's SeqlibReader loop (src/BamReader.{h,cpp}) for BAM input.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <condition_variable>
 #include <mutex>
@@ -47,7 +48,7 @@ public:
     // next() finds a chunk waiting and shrinks when the consumer had to wait.  0 threads (default) = everything to the GPU.
     // call_out_bytes: the inflated bytes of the largest call (start()'s max_out): sizes the room behind the file bytes.
     void set_cpu_share(int threads, double initial_share = 0.15, double max_share = 0.5, uint64_t call_out_bytes = (uint64_t)1 << 30);
-    double cpu_share() const { return share_; }
+    double cpu_share() const { return share_.load(); }
 
 private:
     void producer();
@@ -58,7 +59,8 @@ private:
     Chunk ring_[3];
     int head_ = 0, tail_ = 0, count_ = 0; Chunk *lent_ = nullptr;
     bool eof_ = false, stop_ = false; std::string error_;
-    int cpu_threads_ = 0; double share_ = 0, max_share_ = 0.5; size_t raw_cap_ = 0;
+    int cpu_threads_ = 0; double max_share_ = 0.5; size_t raw_cap_ = 0;
+    std::atomic<double> share_{0.0};                                 // written by next() (the consumer), read by the read-ahead thread
     void *pool_ = nullptr;                                           // WorkPool of the CPU share
     std::mutex mu_; std::condition_variable cv_;
     std::thread th_;

@@ -609,6 +609,7 @@ void rsqc_destroy(rsqc_ctx *c) {
         if (D.h_blocks) (void)hipHostFree(D.h_blocks);
         if (D.ev_copy) (void)hipEventDestroy(D.ev_copy);
         if (D.copy_stream) (void)hipStreamDestroy(D.copy_stream);
+        for (auto &e : D.pe) if (e) (void)hipEventDestroy(e);
     }
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
@@ -1404,8 +1405,9 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     if (n_gpu) HIP_TRY(c, hipMemcpyAsync(dblk, hb, (size_t)n_gpu * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, D.copy_stream));
     HIP_TRY(c, hipEventRecord(D.ev_copy, D.copy_stream));
     // the call before this one: its kernels have had the time of this call's preparation
-    if (D.pending) { if ((rc = decode_finish(c, out))) return rc; }
-    if (skip_bytes && D.tail) return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record");
+    // (an error from here on leaves with the copy drained: the caller's buffer is the caller's again when the call returns)
+    if (D.pending) { if ((rc = decode_finish(c, out))) { (void)hipStreamSynchronize(D.copy_stream); return rc; } }
+    if (skip_bytes && D.tail) { (void)hipStreamSynchronize(D.copy_stream); return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record"); }
     D.slot = slot;
     D.pend_wall0 = std::chrono::steady_clock::now();
     if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[0], c->stream));

@@ -107,7 +107,7 @@ RSQC_BAM_FN bool bam_record_ops(const uint8_t *rec, uint32_t block_size, uint32_
         const uint8_t *v = q + 3;
         const uint32_t vlen = bam_aux_size(type, v, end_r);
         if ((uint64_t)(end_r - v) < vlen) break;
-        if (t0 == 'C' && t1 == 'G' && type == 'B' && v[0] == 'I' && vlen >= 5) { cg_n = bam_ld32(v + 1); cg_off = (uint32_t)(v + 5 - rec); }   // (the last CG field counts)
+        if (t0 == 'C' && t1 == 'G' && type == 'B' && vlen >= 5 && v[0] == 'I') { cg_n = bam_ld32(v + 1); cg_off = (uint32_t)(v + 5 - rec); }   // (the last CG field counts)
         q = v + vlen;
     }
     if (cg_n > 0) { n_ops = cg_n; ops_off = cg_off; }
