@@ -56,3 +56,20 @@ def test_many_overlapping_genes_take_the_slow_path(oracle_lib):
     assert o.n_overflow == 40
     _compare(o, oracle_lib.run_oracle(p, ann, [b]))
     assert list(o.gene_reads) == [40] * 12
+
+
+def test_hostile_records_under_sanitizers():
+    """The per-record core on records whose fields are anywhere inside the format's ranges (positions next to 2^31,
+    operations of 2^28 - 1 bases, thousands of N operations, any flag / mate / NM / l_seq): every access stays inside the
+    annotation's tables and the coverage array.  tests/hostemu/core_fuzz.py with hostemu.cpp built under the address and
+    undefined-behaviour sanitizers (32-bit wrap-around is left alone: it is what the device does with such input)."""
+    import os
+    import subprocess
+    import sys
+    asan = subprocess.check_output(["g++", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan):
+        pytest.skip("no libasan in this toolchain")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "tests.hostemu.core_fuzz", "3", "7"], cwd=root, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "core_fuzz: 9 runs" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
