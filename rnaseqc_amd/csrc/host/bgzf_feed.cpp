@@ -205,9 +205,9 @@ bool BgzfFeeder::fill(Chunk &c) {
             std::vector<uint64_t> at(c.blocks.size() - first + 1, 0);
             for (size_t k = first; k < c.blocks.size(); ++k) at[k - first + 1] = at[k - first] + c.blocks[k].out_bytes;
             std::atomic<bool> bad{false};
-            const size_t per = 4, n_tasks = (c.blocks.size() - first + per - 1) / per;
+            const size_t per_task = 4, n_tasks = (c.blocks.size() - first + per_task - 1) / per_task;
             ((WorkPool *)pool_)->run(n_tasks, [&](size_t t) {
-                for (size_t k = first + t * per; k < std::min(c.blocks.size(), first + (t + 1) * per); ++k) {
+                for (size_t k = first + t * per_task; k < std::min(c.blocks.size(), first + (t + 1) * per_task); ++k) {
                     const rsqc_bgzf_block &b = c.blocks[k];
                     if (!bgzf_inflate_block(c.data + b.in_offset, b.in_bytes, c.data + raw_off + at[k - first], b.out_bytes, b.crc32)) bad = true;
                 }
