@@ -9,7 +9,7 @@ import re, sys
 lines = open(sys.argv[1]).read().split("\n")
 name = sys.argv[2]
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4rsqc\d+" + name + r"[A-Za-z0-9_]*:", l))
-end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+end = next(i for i in range(start, len(lines)) if re.match(r"^\.Lfunc_end", lines[i]))   # (the kernel has early s_endpgm exits)
 k = lines[start:end + 1]
 meta = [l.strip() for l in lines if False]
 labels = {m.group(1): i for i, l in enumerate(k) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}

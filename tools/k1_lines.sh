@@ -13,7 +13,7 @@ for l in lines:
     m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
     if m: files[int(m.group(1))] = (m.group(3) or m.group(2)).split("/")[-1]
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4rsqc\d+" + sys.argv[2] + r"[A-Za-z0-9_]*:", l))
-end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+end = next(i for i in range(start, len(lines)) if re.match(r"^\.Lfunc_end", lines[i]))   # (the kernel has early s_endpgm exits)
 k = lines[start:end + 1]
 labels = {m.group(1): i for i, l in enumerate(k) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
 back = [(i - labels[m.group(1)], labels[m.group(1)], i) for i, l in enumerate(k)
