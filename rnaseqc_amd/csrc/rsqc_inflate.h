@@ -122,6 +122,8 @@ struct InflateScratch {
     uint32_t dfast[1u << INF_DBITS];
     uint16_t lcount[16], dcount[16];     // codes per length
     uint16_t lsym[288], dsym[32];        // symbols by (length, symbol): canonical decoding of the codes the fast table does not hold
+    uint16_t lfirst[16], dfirst[16];     // first canonical code of a length ...
+    uint16_t lidx[16], didx[16];         // ... and the slot of its symbol in lsym / dsym
     uint8_t lens[320];                   // code lengths of the block being set up
     uint16_t offs[16];                   // first slot of a length in lsym / dsym while a table is built
     uint32_t crc_tab[256];               // CRC-32 (reflected 0xEDB88320), one byte per step
@@ -160,7 +162,10 @@ struct InflateIn {
     const uint32_t *base;    // dword-aligned address at or before the first payload byte
     uint32_t n_words;        // dwords that may be read
     uint32_t next;           // next dword index
-    uint64_t lo, hi; uint32_t cnt;      // the next cnt bits of the stream, bit 0 of lo first (up to 128)
+    // The buffer is four RAW dwords of the stream, base[next - 4 .. next) (lo = the first two, hi = the last two), and the bit
+    // offset `bo` of the first unconsumed bit in them: consuming bits is an addition, refilling moves whole dwords (register
+    // moves) -- no 128-bit shifts by variable amounts on the scalar unit, which is what bounds this decoder.
+    uint64_t lo, hi; uint32_t bo;
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t win, win_next;  // lane l: base[win_base + l] and base[win_base + 64 + l]
     uint32_t win_base;
@@ -188,30 +193,25 @@ struct InflateIn {
     RSQC_INF_FN void seek(uint32_t byte_pos) {
         next = byte_pos >> 2;
         open_window(next);
-        const uint32_t lead = byte_pos & 3u;
-        const uint32_t w = next32();
-        lo = (uint64_t)(w >> (8u * lead)); hi = 0;
-        cnt = 32u - 8u * lead;
+        const uint32_t w0 = next32(), w1 = next32(), w2 = next32(), w3 = next32();
+        lo = (uint64_t)w0 | ((uint64_t)w1 << 32); hi = (uint64_t)w2 | ((uint64_t)w3 << 32);
+        bo = 8u * (byte_pos & 3u);
     }
-    RSQC_INF_FN void insert32(uint32_t w) {
-        if (cnt < 64u) { lo |= (uint64_t)w << cnt; if (cnt > 32u) hi |= (uint64_t)w >> (64u - cnt); }
-        else hi |= (uint64_t)w << (cnt - 64u);
-        cnt += 32u;
+    RSQC_INF_FN uint32_t avail() const { return 128u - bo; }                             // buffered bits not consumed yet
+    RSQC_INF_FN void refill() {                                                          // afterwards 97 <= avail() <= 128
+        while (bo >= 32u) { lo = (lo >> 32) | (hi << 32); hi = (hi >> 32) | ((uint64_t)next32() << 32); bo -= 32u; }
     }
-    RSQC_INF_FN void refill() { while (cnt <= 96u) insert32(next32()); }                 // afterwards 97 <= cnt <= 128
-    // the stream from bit `off` on (off < 128); only the first cnt - off bits are meaningful
+    // the stream from bit `off` behind the first unconsumed one (bo + off < 128); only the first avail() - off bits are meaningful
     RSQC_INF_FN uint64_t bits_at(uint32_t off) const {
-        if (off >= 64u) return hi >> (off - 64u);
-        return off ? (lo >> off) | (hi << (64u - off)) : lo;
+        const uint32_t sh = bo + off;
+        if (sh >= 64u) return hi >> (sh - 64u);
+        return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
     }
-    RSQC_INF_FN uint32_t peek(uint32_t n) const { return (uint32_t)lo & ((1u << n) - 1u); }      // n < 32
-    RSQC_INF_FN void drop(uint32_t n) {                                                           // n <= cnt
-        if (n >= 64u) { lo = (n == 64u) ? hi : hi >> (n - 64u); hi = 0; }
-        else if (n) { lo = (lo >> n) | (hi << (64u - n)); hi >>= n; }
-        cnt -= n;
-    }
+    RSQC_INF_FN uint32_t head32() const { return (uint32_t)bits_at(0); }                 // the next 32 bits (bo <= 96)
+    RSQC_INF_FN uint32_t peek(uint32_t n) const { return head32() & ((1u << n) - 1u); }  // n < 32
+    RSQC_INF_FN void drop(uint32_t n) { bo += n; }                                       // n <= avail()
     RSQC_INF_FN uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
-    RSQC_INF_FN uint32_t byte_pos() const { return next * 4u - cnt / 8u; }    // first byte not consumed yet (whole bytes left in the buffer)
+    RSQC_INF_FN uint32_t byte_pos() const { return next * 4u - avail() / 8u; }           // first byte not consumed yet (whole bytes left in the buffer)
 };
 
 // ---- Huffman tables ------------------------------------------------------------------------------------------
@@ -240,19 +240,20 @@ RSQC_INF_FN uint32_t inflate_entry(int kind, uint32_t sym, uint32_t len) {
 // lens[0..n): code lengths.  Builds count[]/sym[] (canonical order) and the fast table of `fbits` bits.  false = the
 // lengths over-subscribe the code space (zlib: "invalid code lengths set").  An incomplete set is accepted, as zlib
 // accepts a single distance code; a code nobody owns is an error when the stream uses it.
-RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *sym, uint32_t *fast, uint32_t fbits, uint16_t *offs, int kind) {
+RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *sym, uint16_t *first, uint16_t *index, uint32_t *fast, uint32_t fbits, uint16_t *offs, int kind) {
     for (uint32_t l = INF_LANE; l < 16u; l += INF_W) count[l] = 0;
     for (uint32_t k = INF_LANE; k < (1u << fbits); k += INF_W) fast[k] = 0;
     for (uint32_t s = 0; s < n; ++s) { const uint32_t l = INF_UNI(lens[s]); INF_ST(count[l]++); }
     if (INF_UNI(count[0]) == n) return true;                       // no codes at all: legal as long as none is used
     int32_t left = 1;
-    uint32_t run = 0;
+    uint32_t run = 0, fcode = 0;
     for (uint32_t l = 1; l <= 15u; ++l) {
         const uint32_t c = INF_UNI(count[l]);
         left = (left << 1) - (int32_t)c;
         if (left < 0) return false;
-        INF_ST(offs[l] = (uint16_t)run);
+        INF_ST(offs[l] = (uint16_t)run; index[l] = (uint16_t)run; first[l] = (uint16_t)fcode);      // (fcode <= 2^l: the lengths do not over-subscribe)
         run += c;
+        fcode = (fcode + c) << 1;
     }
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t l = INF_UNI(lens[s]);
@@ -275,24 +276,38 @@ RSQC_INF_FN bool inflate_build(const uint8_t *lens, uint32_t n, uint16_t *count,
     return true;
 }
 
-// a code longer than the fast table's index (or one nobody owns), bit by bit from `bits`: the symbol and its length, or 0xFFFF
-RSQC_INF_FN uint32_t inflate_symbol_slow(uint64_t bits, const uint16_t *count, const uint16_t *sym, uint32_t &len) {
-    uint32_t code = 0, first = 0, index = 0;
-    for (uint32_t l = 1; l <= 15u; ++l) {
-        code |= (uint32_t)bits & 1u; bits >>= 1;
-        const uint32_t c = INF_UNI(count[l]);
-        if (code - first < c) { len = l; return INF_UNI(sym[index + (code - first)]); }
-        index += c; first = (first + c) << 1; code <<= 1;
+// a code longer than the fast table's index (or one nobody owns) at the head of `bits`: the symbol and its length, or 0xFFFF.
+// Canonical decoding: the code of length l is the first l bits, most significant first; it is a symbol's iff it lies less
+// than count[l] above first[l], and the shortest such l wins.  Lane l tests length l, so the whole search is one step of the
+// wave instead of fifteen dependent ones on the scalar unit (every 20th symbol of a real file takes this path).
+RSQC_INF_FN uint32_t inflate_bitrev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4); x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+RSQC_INF_FN uint32_t inflate_symbol_slow(uint32_t bits, const uint16_t *count, const uint16_t *first, const uint16_t *index, const uint16_t *sym, uint32_t &len) {
+    const uint32_t rev = inflate_bitrev32(bits);
+    InfVec OWN;
+    INF_FOREACH(k) {
+        const uint32_t l = k < 1u ? 1u : k > 15u ? 15u : k;                 // lanes 1..15 test their own length (the others repeat one and are masked)
+        INF_AT(OWN, k) = (k == l && (rev >> (32u - l)) - (uint32_t)first[l] < (uint32_t)count[l]) ? 1u : 0u;
     }
-    len = 0;
-    return 0xFFFFu;
+    const uint64_t own = inf_ballot(OWN);
+    if (!own) { len = 0; return 0xFFFFu; }
+    const uint32_t l = (uint32_t)__builtin_ctzll(own);
+    len = l;
+    return INF_UNI(sym[INF_UNI(index[l]) + (rev >> (32u - l)) - INF_UNI(first[l])]);
 }
 // one symbol at the head of the reader (the block headers' code-length code)
-RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint32_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *sym) {
+RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint32_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *first, const uint16_t *index, const uint16_t *sym) {
     const uint32_t e = INF_UNI(fast[in.peek(fbits)]);
     if (e) { in.drop(e & 15u); return e >> 4; }
     uint32_t len;
-    const uint32_t s = inflate_symbol_slow(in.lo, count, sym, len);
+    const uint32_t s = inflate_symbol_slow(in.head32(), count, first, index, sym, len);
     in.drop(len);
     return s;
 }
@@ -366,29 +381,50 @@ inline InflateStats &inflate_stats() { static InflateStats st{}; return st; }
 RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t pos, uint32_t dist, uint32_t len) {
     INF_STAT((dist > INF_NEAR ? inflate_stats().far_matches : inflate_stats().near_matches)++); INF_STAT(inflate_stats().match_bytes += len); INF_STAT(inflate_stats().dist_hist[32 - __builtin_clz(dist | 1u) > 15 ? 15 : 32 - __builtin_clz(dist | 1u)]++);
     INF_STAT(dist > INF_NEAR ? inflate_stats().far_len_hist[len < 4 ? 0 : len <= 8 ? 1 : len <= 16 ? 2 : len <= 32 ? 3 : len <= 64 ? 4 : 5]++ : 0);
-    if (dist > INF_NEAR) {
+    // (the loops count wave-uniform passes of one byte per lane and predicate the lanes inside: a loop whose trip count differs per lane
+    //  makes the compiler wrap the whole function in exec-mask bookkeeping, and this code is bound by the scalar unit)
+    // len >= 3 (RFC 1951), so every loop runs at least once: do-while saves the entry test
+    if (dist >= len) {                                                 // no overlap
+        if (dist <= INF_NEAR) {                                        // the common case: ring to ring
+            uint32_t b = 0;
+            do {
+                const uint32_t j = b + INF_LANE;
+                if (j < len) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos + j - dist) & INF_RMASK];
+                b += INF_W;
+            } while (b < len);
+        } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
-        for (uint32_t j = INF_LANE; j < len; j += INF_W) S.ring[(pos + j) & INF_RMASK] = o.dst[pos - dist + j];     // (dist > 258 >= len: no overlap)
-    } else if (dist >= len) {
-        for (uint32_t j = INF_LANE; j < len; j += INF_W) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos + j - dist) & INF_RMASK];
-    } else if (dist < 64u) {
+            uint32_t b = 0;
+            do {
+                const uint32_t j = b + INF_LANE;
+                if (j < len) S.ring[(pos + j) & INF_RMASK] = o.dst[pos - dist + j];
+                b += INF_W;
+            } while (b < len);
+        }
+    } else if (dist < 64u) {                                           // (dist < len <= 258: the source is in the ring)
         static const uint32_t kRecip[64] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096, 3856, 3641, 3450, 3277,
                                             3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2048, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599,
                                             1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041};
         const uint32_t recip = kRecip[dist];                           // ceil(65536 / dist): j / dist == (j * recip) >> 16 for j < 1040, dist < 64 (tests: every pair)
-        for (uint32_t j = INF_LANE; j < len; j += INF_W) {
+        uint32_t b = 0;
+        do {
+            const uint32_t j = b + INF_LANE;
             const uint32_t r = j - ((j * recip) >> 16) * dist;
-            S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
-        }
+            if (j < len) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
+            b += INF_W;
+        } while (b < len);
     } else {
-        for (uint32_t j = INF_LANE; j < len; j += INF_W) {              // len <= 258 < 5 * 64
+        uint32_t b = 0;
+        do {                                                            // len <= 258 < 5 * 64
+            const uint32_t j = b + INF_LANE;
             uint32_t r = j;
             r -= (r >= dist) ? dist : 0u; r -= (r >= dist) ? dist : 0u; r -= (r >= dist) ? dist : 0u; r -= (r >= dist) ? dist : 0u;
-            S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
-        }
+            if (j < len) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos - dist + r) & INF_RMASK];
+            b += INF_W;
+        } while (b < len);
     }
 }
 
@@ -410,7 +446,7 @@ RSQC_INF_FN int inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut 
     uint32_t e = INF_UNI(S.lfast[bi.peek(INF_LBITS)]);
     if (!e) {
         uint32_t len;
-        const uint32_t s = inflate_symbol_slow(bi.lo, S.lcount, S.lsym, len);
+        const uint32_t s = inflate_symbol_slow(bi.head32(), S.lcount, S.lfirst, S.lidx, S.lsym, len);
         if (s == 0xFFFFu) return -INF_ERR_SYMBOL;
         e = inflate_entry(INF_T_LITLEN, s, len);
     }
@@ -430,7 +466,7 @@ RSQC_INF_FN int inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut 
     uint32_t f = INF_UNI(S.dfast[bi.peek(INF_DBITS)]);
     if (!f) {
         uint32_t dl;
-        const uint32_t ds = inflate_symbol_slow(bi.lo, S.dcount, S.dsym, dl);
+        const uint32_t ds = inflate_symbol_slow(bi.head32(), S.dcount, S.dfirst, S.didx, S.dsym, dl);
         if (ds == 0xFFFFu) return -INF_ERR_SYMBOL;
         f = inflate_entry(INF_T_DIST, ds, dl);
     }
@@ -447,7 +483,7 @@ RSQC_INF_FN int inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut 
 
 RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
     bi.refill();
-    const uint32_t avail = bi.cnt;
+    const uint32_t avail = bi.avail();
     InfVec PK, VAL, OL;                                                     // (kind << 8) | bits of the whole symbol; literal byte or distance; output bytes
     INF_FOREACH(k) {
         const uint64_t w = bi.bits_at(k);
@@ -470,16 +506,18 @@ RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
         if (k + adv > avail) kind = INF_K_OTHER;                            // the symbol runs past the buffered bits
         INF_AT(PK, k) = (kind << 8) | adv; INF_AT(VAL, k) = val; INF_AT(OL, k) = ol;
     }
-    // the walk: which lanes are symbol starts
+    // the walk: which lanes are symbol starts.  One exit test: a lane that ends the walk (END, OTHER) holds a value >= END << 8,
+    // and off << 3 reaches that value exactly when the walk has left the 64 buffered offsets (off < 112: a symbol is at most 48 bits)
     uint64_t starts = 0;
-    uint32_t off = 0, stopped_at = 0;
-    bool stopped = false;
-    while (off < 64u) {
-        const uint32_t a = INF_GET(PK, off);
-        if (a >= ((uint32_t)INF_K_END << 8)) { stopped = true; stopped_at = a; break; }
+    uint32_t off = 0;
+    uint32_t a = INF_GET(PK, 0u);
+    while ((a | (off << 3)) < ((uint32_t)INF_K_END << 8)) {
         starts |= 1ull << off;
         off += a & 0xFFu;
+        a = INF_GET(PK, off & 63u);
     }
+    bool stopped = off < 64u;                                               // the walk met a symbol it cannot take, at bit offset off
+    const uint32_t stopped_at = a;
     INF_STAT(inflate_stats().rounds++); INF_STAT(inflate_stats().round_symbols += (unsigned)__builtin_popcountll(starts)); INF_STAT(inflate_stats().slow_symbols += stopped ? 1 : 0);
     if (starts) {
         // every symbol's place in the output
@@ -503,20 +541,21 @@ RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
             INF_AT(ISMATCH, k) = (mine && (INF_AT(PK, k) >> 8) == (uint32_t)INF_K_MATCH) ? 1u : 0u;
         }
         uint64_t lit = inf_ballot(ISLIT), match = inf_ballot(ISMATCH);
-        for (;;) {                                                          // in stream order: the literals before the next match, then the match
-            const uint32_t m = match ? (uint32_t)__builtin_ctzll(match) : 64u;
-            const uint64_t below = (m >= 64u) ? ~0ull : (1ull << m) - 1ull;
-            const uint64_t now = lit & below;
-            if (now) {
-                INF_FOREACH(k) { if ((now >> k) & 1ull) S.ring[(o.pos + INF_AT(INC, k) - 1u) & INF_RMASK] = (uint8_t)INF_AT(VAL, k); }
-                lit &= ~below;
-            }
-            if (m >= 64u) break;
-            const uint32_t mlen = INF_GET(OL, m), dist = INF_GET(VAL, m), at = o.pos + INF_GET(INC, m) - mlen;
-            if (dist > at) return -INF_ERR_DISTANCE;
-            inflate_copy(S, o, at, dist, mlen);
+        {                                                                   // a match that reaches before the block's first byte (all of them at once)
+            InfVec BADM;
+            INF_FOREACH(k) { (void)k; INF_AT(BADM, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) > o.pos + INF_AT(INC, k) - INF_AT(OL, k)) ? 1u : 0u; }
+            if (inf_ballot(BADM)) return -INF_ERR_DISTANCE;
+        }
+        while (match) {                                                     // in stream order: the literals before the next match, then the match
+            const uint32_t m = (uint32_t)__builtin_ctzll(match);
+            const uint64_t now = lit & ((1ull << m) - 1ull);
+            INF_FOREACH(k) { if ((now >> k) & 1ull) S.ring[(o.pos + INF_AT(INC, k) - 1u) & INF_RMASK] = (uint8_t)INF_AT(VAL, k); }
+            lit ^= now;
+            const uint32_t mlen = INF_GET(OL, m);
+            inflate_copy(S, o, o.pos + INF_GET(INC, m) - mlen, INF_GET(VAL, m), mlen);
             match &= match - 1ull;
         }
+        INF_FOREACH(k) { if ((lit >> k) & 1ull) S.ring[(o.pos + INF_AT(INC, k) - 1u) & INF_RMASK] = (uint8_t)INF_AT(VAL, k); }      // the literals behind the last match
         o.pos += total;
         while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
     }
@@ -544,7 +583,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
         bi.refill();
         const uint32_t bfinal = bi.take(1), btype = bi.take(2);
         if (btype == 0u) {                                          // stored: LEN, ~LEN on a byte boundary, then the bytes
-            bi.drop(bi.cnt & 7u);
+            bi.drop(bi.avail() & 7u);
             bi.refill();
             const uint32_t len = bi.take(16), nlen = bi.take(16);
             if ((len ^ nlen) != 0xFFFFu) return INF_ERR_STORED;
@@ -576,11 +615,11 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                     INF_ST(S.lens[kClOrder[k]] = (uint8_t)v);
                 }
                 // the code-length code is decoded with the distance tables' storage (7-bit codes fit the 8-bit fast table)
-                if (!inflate_build(S.lens, 19, S.dcount, S.dsym, S.dfast, 7, S.offs, INF_T_PLAIN)) return INF_ERR_TABLE;
+                if (!inflate_build(S.lens, 19, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, 7, S.offs, INF_T_PLAIN)) return INF_ERR_TABLE;
                 uint32_t i = 0, prev = 0;
                 while (i < nlit + ndist) {                         // (the code-length code's own lengths in lens[0..19) are not needed any more)
                     bi.refill();
-                    const uint32_t s = inflate_symbol(bi, S.dfast, 7, S.dcount, S.dsym);
+                    const uint32_t s = inflate_symbol(bi, S.dfast, 7, S.dcount, S.dfirst, S.didx, S.dsym);
                     if (s < 16u) { INF_ST(S.lens[i] = (uint8_t)s); prev = s; ++i; continue; }
                     uint32_t rep, val = 0;
                     if (s == 16u) { if (i == 0u) return INF_ERR_TABLE; val = prev; rep = 3u + bi.take(2); }
@@ -593,8 +632,8 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                 }
                 if (INF_UNI(S.lens[256]) == 0u) return INF_ERR_TABLE;                // no end-of-block code
             }
-            if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
-            if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
+            if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfirst, S.lidx, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
+            if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
             // ---- the symbols, in rounds (inflate_round)
             for (;;) {
                 const int r = inflate_round(S, bi, o);
