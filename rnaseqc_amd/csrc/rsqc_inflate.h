@@ -386,23 +386,21 @@ RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t p
     // len >= 3 (RFC 1951), so every loop runs at least once: do-while saves the entry test
     if (dist >= len) {                                                 // no overlap
         if (dist <= INF_NEAR) {                                        // the common case: ring to ring
-            uint32_t b = 0;
-            do {
+            if (INF_LANE < len) S.ring[(pos + INF_LANE) & INF_RMASK] = S.ring[(pos + INF_LANE - dist) & INF_RMASK];      // (most matches fit one pass)
+            for (uint32_t b = INF_W; b < len; b += INF_W) {
                 const uint32_t j = b + INF_LANE;
                 if (j < len) S.ring[(pos + j) & INF_RMASK] = S.ring[(pos + j - dist) & INF_RMASK];
-                b += INF_W;
-            } while (b < len);
+            }
         } else {
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
-            uint32_t b = 0;
-            do {
+            if (INF_LANE < len) S.ring[(pos + INF_LANE) & INF_RMASK] = o.dst[pos - dist + INF_LANE];
+            for (uint32_t b = INF_W; b < len; b += INF_W) {
                 const uint32_t j = b + INF_LANE;
                 if (j < len) S.ring[(pos + j) & INF_RMASK] = o.dst[pos - dist + j];
-                b += INF_W;
-            } while (b < len);
+            }
         }
     } else if (dist < 64u) {                                           // (dist < len <= 258: the source is in the ring)
         static const uint32_t kRecip[64] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096, 3856, 3641, 3450, 3277,
@@ -440,26 +438,26 @@ enum { INF_K_LIT = 0, INF_K_MATCH = 1, INF_K_END = 2, INF_K_OTHER = 3 };      //
 constexpr uint32_t INF_ROUND_BYTES = INF_ROUND_BYTES_CFG;   // output of one round at most (the ring keeps unflushed bytes: INF_FLUSH + this < INF_RING)
 
 // one symbol the long way (a code longer than the fast table's index, or the symbol the buffered bits ended in).
-// 0 = go on, 1 = end of block, < 0 = -InflateStatus
-RSQC_INF_FN int inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut &o) {
+// true = the block goes on; false = it ended (status untouched) or failed (status = the InflateStatus)
+RSQC_INF_FN bool inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut &o, uint32_t &status) {
     bi.refill();
     uint32_t e = INF_UNI(S.lfast[bi.peek(INF_LBITS)]);
     if (!e) {
         uint32_t len;
         const uint32_t s = inflate_symbol_slow(bi.head32(), S.lcount, S.lfirst, S.lidx, S.lsym, len);
-        if (s == 0xFFFFu) return -INF_ERR_SYMBOL;
+        if (s == 0xFFFFu) { status = INF_ERR_SYMBOL; return false; }
         e = inflate_entry(INF_T_LITLEN, s, len);
     }
     bi.drop(e & 15u);
     if (e & INF_E_LITERAL) {
-        if (o.pos >= o.out_len) return -INF_ERR_OUTPUT;
+        if (o.pos >= o.out_len) { status = INF_ERR_OUTPUT; return false; }
         INF_ST(S.ring[o.pos & INF_RMASK] = (uint8_t)(e >> 8));
         o.pos++;
         while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
-        return 0;
+        return true;
     }
-    if (e & INF_E_END) return 1;
-    if (e & INF_E_INVALID) return -INF_ERR_SYMBOL;
+    if (e & INF_E_END) return false;
+    if (e & INF_E_INVALID) { status = INF_ERR_SYMBOL; return false; }
     const uint32_t xb = (e >> 4) & 15u;
     const uint32_t mlen = ((e >> 8) & 0xFFFFu) + bi.take(xb);
     bi.refill();
@@ -467,21 +465,22 @@ RSQC_INF_FN int inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut 
     if (!f) {
         uint32_t dl;
         const uint32_t ds = inflate_symbol_slow(bi.head32(), S.dcount, S.dfirst, S.didx, S.dsym, dl);
-        if (ds == 0xFFFFu) return -INF_ERR_SYMBOL;
+        if (ds == 0xFFFFu) { status = INF_ERR_SYMBOL; return false; }
         f = inflate_entry(INF_T_DIST, ds, dl);
     }
-    if (f & INF_E_INVALID) return -INF_ERR_SYMBOL;
+    if (f & INF_E_INVALID) { status = INF_ERR_SYMBOL; return false; }
     bi.drop(f & 15u);
     const uint32_t dist = ((f >> 8) & 0xFFFFu) + bi.take((f >> 4) & 15u);
-    if (dist > o.pos) return -INF_ERR_DISTANCE;
-    if (o.pos + mlen > o.out_len) return -INF_ERR_OUTPUT;
+    if (dist > o.pos) { status = INF_ERR_DISTANCE; return false; }
+    if (o.pos + mlen > o.out_len) { status = INF_ERR_OUTPUT; return false; }
     inflate_copy(S, o, o.pos, dist, mlen);
     o.pos += mlen;
     while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
-    return 0;
+    return true;
 }
 
-RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
+// true = the block goes on; false = it ended (status untouched) or failed (status = the InflateStatus)
+RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, uint32_t &status) {
     bi.refill();
     const uint32_t avail = bi.avail();
     InfVec PK, VAL, OL;                                                     // (kind << 8) | bits of the whole symbol; literal byte or distance; output bytes
@@ -533,7 +532,7 @@ RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
             total = INF_GET(INC, c) - INF_GET(X, c);
             off = c; stopped = false;                                       // (the lane index IS the bit offset: the next round starts at that symbol)
         }
-        if (o.pos + total > o.out_len) return -INF_ERR_OUTPUT;
+        if (o.pos + total > o.out_len) { status = INF_ERR_OUTPUT; return false; }
         InfVec ISLIT, ISMATCH;
         INF_FOREACH(k) {
             const bool mine = (starts >> k) & 1ull;
@@ -544,7 +543,7 @@ RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
         {                                                                   // a match that reaches before the block's first byte (all of them at once)
             InfVec BADM;
             INF_FOREACH(k) { (void)k; INF_AT(BADM, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) > o.pos + INF_AT(INC, k) - INF_AT(OL, k)) ? 1u : 0u; }
-            if (inf_ballot(BADM)) return -INF_ERR_DISTANCE;
+            if (inf_ballot(BADM)) { status = INF_ERR_DISTANCE; return false; }
         }
         while (match) {                                                     // in stream order: the literals before the next match, then the match
             const uint32_t m = (uint32_t)__builtin_ctzll(match);
@@ -560,9 +559,9 @@ RSQC_INF_FN int inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o) {
         while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
     }
     bi.drop(off);
-    if (!stopped) return 0;
-    if ((stopped_at >> 8) == (uint32_t)INF_K_END) { bi.drop(stopped_at & 0xFFu); return 1; }
-    return inflate_one_symbol(S, bi, o);
+    if (!stopped) return true;
+    if ((stopped_at >> 8) == (uint32_t)INF_K_END) { bi.drop(stopped_at & 0xFFu); return false; }
+    return inflate_one_symbol(S, bi, o, status);
 }
 
 // Inflates `in_len` payload bytes at `in` into exactly `out_len` bytes at `dst` and checks their CRC-32 (inflate_crc_init
@@ -635,11 +634,9 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
             if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfirst, S.lidx, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
             if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
             // ---- the symbols, in rounds (inflate_round)
-            for (;;) {
-                const int r = inflate_round(S, bi, o);
-                if (r < 0) return -r;
-                if (r > 0) break;
-            }
+            uint32_t status = INF_OK;
+            while (inflate_round(S, bi, o, status)) {}
+            if (status) return (int)status;
         } else return INF_ERR_BTYPE;
         if (bfinal) break;
     }
