@@ -7,7 +7,10 @@
 //
 // Shape of the decoder on CDNA4:
 //  * the bit reader, the Huffman walk and the output position are WAVE-UNIFORM values (every lane computes the same
-//    thing), so the compiler keeps them in SGPRs and the walk runs on the scalar unit;
+//    thing), so the compiler keeps them in SGPRs and the walk runs on the scalar unit -- which is what BOUNDS this kernel
+//    (rocprofv3 --pmc: the CU's scalar issue port is ~97 % busy at five waves per SIMD, profiles/r2_decode_pmc_realistic_6M.txt):
+//    the code below is written to keep scalar instructions per symbol down (raw-dword bit buffer, single-exit walk,
+//    wave-uniform loop counts, a one-step decode of long codes), see DESIGN.md 6b;
 //  * only WHERE a symbol starts is serial: every lane decodes the whole symbol that would start at its own bit offset of
 //    the buffered input (both Huffman tables, extra bits, output length), the walk hops along those results with one
 //    v_readlane per symbol, a prefix sum places the symbols, literals are stored by their own lanes (inflate_round);
@@ -431,7 +434,7 @@ RSQC_INF_FN void inflate_copy(InflateScratch &S, const InflateOut &o, uint32_t p
 // its length and distance, how many bits it takes, how many bytes it puts out -- depends on nothing but the bits at its
 // own offset.  So in a round every lane decodes, completely, "the symbol that would start at my bit offset" of the 97+
 // buffered bits (both Huffman tables, extra bits included); the wave-uniform walk then only hops along those results
-// (one v_readlane and four scalar instructions per symbol) to mark the lanes that ARE symbol starts; a prefix sum over
+// (one v_readlane and eight scalar instructions per symbol) to mark the lanes that ARE symbol starts; a prefix sum over
 // the marked lanes gives every symbol its place in the output; the literals are stored by their own lanes, the matches
 // are copied one after the other by the whole wave.
 enum { INF_K_LIT = 0, INF_K_MATCH = 1, INF_K_END = 2, INF_K_OTHER = 3 };      // OTHER: a code longer than the fast table, an undefined one, or bits not buffered yet
