@@ -289,3 +289,18 @@ def test_window_decode_on_damaged_records_under_sanitizers(tmp_path):
         r = subprocess.run([exe, "1500", str(seed)], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert "1500 cases" in r.stdout
+
+
+@pytest.mark.parametrize("level", [0, 6, 9])
+def test_bam_of_other_compression_levels_through_the_emulation(tmp_path, level):
+    """The files of tests/test_zz_gpu_decode_levels.py (stored blocks, zlib's default and best levels) through the emulated
+    inflate and window decode."""
+    contigs = [("chrA", 3_000_000), ("chrB", 1_000_000), ("chrC", 500_000)]
+    ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40), ("chrC", 500_000, 10)])
+    batch = synth.make_reads(ann, 30_000, seed=37 + level, keep_qnames=True, chimeric_tag_frac=0.02, filter_tag_frac=0.03,
+                             contig_lengths=np.array([3_000_000, 1_000_000, 500_000]))
+    path = str(tmp_path / "l.bam")
+    bamio.write_bam(path, contigs, batch, level=level)
+    stream, first, n_ref = emu.inflate_bam(path)
+    dec = emu.decode_stream(stream, first, n_ref, 1 << 30, "ch", ("XF",), threads=5)
+    _check(dec, batch)
