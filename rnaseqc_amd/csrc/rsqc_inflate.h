@@ -114,6 +114,11 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 #ifndef INF_ROUND_BYTES_CFG
 #define INF_ROUND_BYTES_CFG 1024
 #endif
+// 1: a round whose output fits one byte per lane and whose matches all copy from before the round is committed in ONE vector pass
+// (inflate_round).  Off in the product build until it has been measured on the GPU; the host tests run both.
+#ifndef INF_PAR_COMMIT_CFG
+#define INF_PAR_COMMIT_CFG 0
+#endif
 constexpr uint32_t INF_LBITS = INF_LBITS_CFG, INF_DBITS = INF_DBITS_CFG;
 constexpr uint32_t INF_FLUSH = INF_FLUSH_CFG;          // the ring goes out to HBM (and through the CRC) in pieces of this size
 static_assert(INF_RING >= INF_FLUSH + INF_ROUND_BYTES_CFG + 774u, "the far-match argument needs this (a round adds up to 1024 bytes before the next flush)");
@@ -130,6 +135,9 @@ struct InflateScratch {
     uint8_t lens[320];                   // code lengths of the block being set up
     uint16_t offs[16];                   // first slot of a length in lsym / dsym while a table is built
     uint32_t crc_tab[256];               // CRC-32 (reflected 0xEDB88320), one byte per step
+#if INF_PAR_COMMIT_CFG
+    uint32_t slot[64];                   // one-pass commit of a round: the symbol that starts at output byte i of the round
+#endif
 };
 
 // ---- CRC-32 of the inflated bytes (the gzip member's trailer; htslib's bgzf reader checks it, so a corrupt block is an
@@ -548,6 +556,50 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
             INF_FOREACH(k) { (void)k; INF_AT(BADM, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) > o.pos + INF_AT(INC, k) - INF_AT(OL, k)) ? 1u : 0u; }
             if (inf_ballot(BADM)) { status = INF_ERR_DISTANCE; return false; }
         }
+#if INF_PAR_COMMIT_CFG
+        // One pass for the whole round, one lane per OUTPUT byte, when the round puts out at most 64 bytes and no match reads what
+        // this round writes (distance >= the match's end inside the round; 84 % of the rounds of a real file).  The symbols leave
+        // (literal byte | distance) in the slot of their first output byte; a ballot over the slots is the mask of first bytes; a
+        // byte lane finds its symbol as the highest first byte at or below it.  Every source is read before any byte is stored,
+        // so a store cannot land on a ring slot that a match of the same round still has to read.
+        InfVec DEP;
+        INF_FOREACH(k) { (void)k; INF_AT(DEP, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) < INF_AT(INC, k)) ? 1u : 0u; }
+        if (total <= 64u && !inf_ballot(DEP)) {
+            InfVec FAR_;
+            INF_FOREACH(k) { (void)k; INF_AT(FAR_, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) > INF_NEAR) ? 1u : 0u; }
+            if (inf_ballot(FAR_)) {                                         // sources that left the ring are read from the stream (see inflate_copy)
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+            }
+            const uint32_t r0 = o.pos;
+            INF_FOREACH(k) { S.slot[k] = 0u; }
+            INF_FOREACH(k) {
+                if ((starts >> k) & 1ull)
+                    S.slot[INF_AT(INC, k) - INF_AT(OL, k)] = 0x80000000u | (INF_AT(ISLIT, k) ? 0x40000000u : 0u) | (INF_AT(VAL, k) & 0xFFFFu);
+            }
+            InfVec FIRST;
+            INF_FOREACH(k) { INF_AT(FIRST, k) = S.slot[k] >> 31; }
+            const uint64_t firsts = inf_ballot(FIRST);                      // bit 0 is set: the round's first symbol starts at its first byte
+            InfVec BYTE_;
+            INF_FOREACH(j) {
+                uint32_t b = 0;
+                if (j < total) {
+                    const uint64_t le = firsts & ((2ull << j) - 1ull);
+                    const uint32_t info = S.slot[63u - (uint32_t)__builtin_clzll(le)];
+                    if (info & 0x40000000u) b = info & 0xFFu;
+                    else {
+                        const uint32_t dist = info & 0xFFFFu, src = r0 + j - dist;
+                        b = (dist <= INF_NEAR) ? (uint32_t)S.ring[src & INF_RMASK] : (uint32_t)o.dst[src];
+                    }
+                }
+                INF_AT(BYTE_, j) = b;
+            }
+            INF_FOREACH(j) { if (j < total) S.ring[(r0 + j) & INF_RMASK] = (uint8_t)INF_AT(BYTE_, j); }
+        } else
+#endif
+        {
         while (match) {                                                     // in stream order: the literals before the next match, then the match
             const uint32_t m = (uint32_t)__builtin_ctzll(match);
             const uint64_t now = lit & ((1ull << m) - 1ull);
@@ -558,6 +610,7 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
             match &= match - 1ull;
         }
         INF_FOREACH(k) { if ((lit >> k) & 1ull) S.ring[(o.pos + INF_AT(INC, k) - 1u) & INF_RMASK] = (uint8_t)INF_AT(VAL, k); }      // the literals behind the last match
+        }
         o.pos += total;
         while (o.pos - o.flushed >= INF_FLUSH) inflate_flush(S, o, INF_FLUSH);
     }

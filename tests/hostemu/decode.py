@@ -15,27 +15,30 @@ _SO = os.path.join(_HERE, "libdecode_emu.so")
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 
 
-def build():
+def build(par_commit=False):
+    """par_commit: the decoder with INF_PAR_COMMIT_CFG=1 (the one-pass commit of a round; off in the product build)."""
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
     srcs = [os.path.join(_HERE, "decode_emu.cpp")] + [os.path.join(csrc, h) for h in ("rsqc_inflate.h", "rsqc_bamrec.h", "rsqc_decode.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
-    if not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", srcs[0], "-o", _SO])
-    return _SO
+    so = _SO.replace(".so", "_par.so") if par_commit else _SO
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden"] + (["-DINF_PAR_COMMIT_CFG=1"] if par_commit else []) +
+                              [srcs[0], "-o", so])
+    return so
 
 
-def lib():
-    l = C.CDLL(build())
+def lib(par_commit=False):
+    l = C.CDLL(build(par_commit))
     l.emu_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32]
     l.emu_crc_wave64.restype = C.c_uint32
     l.emu_crc_wave64.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
     return l
 
 
-def inflate(comp, n, crc):
+def inflate(comp, n, crc, par_commit=False):
     """(status, bytes) of the wave-emulated DEFLATE decoder on one raw stream."""
     out = C.create_string_buffer(n + 64)
-    rc = lib().emu_inflate(comp, len(comp), out, n, crc & 0xFFFFFFFF)
+    rc = lib(par_commit).emu_inflate(comp, len(comp), out, n, crc & 0xFFFFFFFF)
     return rc, out.raw[:n]
 
 
