@@ -5,6 +5,8 @@
 // what the writer compressed), built with -fsanitize=address,undefined: the reader frames in parallel from guessed record
 // starts and verifies the chain, so what is searched for here is a read or write outside its buffers, a loop that does
 // not end, a thread that does not come back.  A damaged file must end in an exception or in a record count, never in a crash.
+// A third of the files are damaged in the CONTAINER as well (BGZF headers, BSIZE, trailers, cut files), and every file also goes
+// through the device decode's host side (host/bgzf_feed.cpp: block table, read-ahead thread, the CPU threads' share of the inflate).
 //
 //   reader_fuzz <cases> <seed> <tmp file>      exit 0 = nothing found
 #include <signal.h>
@@ -18,6 +20,7 @@
 #include <string>
 
 #include "../../rnaseqc_amd/csrc/host/bam.hpp"
+#include "../../rnaseqc_amd/csrc/host/bgzf_feed.hpp"
 #include "fuzz_records.h"
 
 static void bgzf_write(FILE *f, const uint8_t *p, size_t n) {              // one block (n <= 60000), zlib level 1; n = 0: the end-of-file marker
@@ -90,6 +93,21 @@ int main(int argc, char **argv) {
         for (size_t o = 0; o < file.size();) { const size_t n = std::min<size_t>(file.size() - o, 1 + rnd(rnd(4) ? 60000 : 3000)); bgzf_write(f, file.data() + o, n); o += n; }
         bgzf_write(f, nullptr, 0);
         fclose(f);
+        if (rnd(3) == 0) {                                                                  // the container: bytes of the file itself
+            damaged = true;
+            FILE *g = fopen(path.c_str(), "rb"); std::vector<uint8_t> raw; uint8_t tmp[65536]; size_t got;
+            while ((got = fread(tmp, 1, sizeof tmp, g)) > 0) raw.insert(raw.end(), tmp, tmp + got);
+            fclose(g);
+            switch (rnd(4)) {
+            case 0: for (uint32_t k = 0, n = 1 + rnd(6); k < n; ++k) raw[rnd((uint32_t)raw.size())] ^= (uint8_t)(1u << rnd(8)); break;
+            case 1: raw.resize(rnd((uint32_t)raw.size())); break;
+            case 2: { size_t p = 0; for (uint32_t hops = rnd(30); hops && p + 18 <= raw.size(); --hops) p += (size_t)(raw[p + 16] | (raw[p + 17] << 8)) + 1;     // a block header field
+                      if (p + 18 <= raw.size()) raw[p + rnd(18)] = (uint8_t)rnd(256); break; }
+            default: { size_t p = 0; for (uint32_t hops = rnd(30); hops && p + 18 <= raw.size(); --hops) p += (size_t)(raw[p + 16] | (raw[p + 17] << 8)) + 1;   // a trailer (CRC-32 / ISIZE)
+                       const size_t e = p + 18 <= raw.size() ? p + (size_t)(raw[p + 16] | (raw[p + 17] << 8)) + 1 : 0; if (e >= 8 && e <= raw.size()) raw[e - 1 - rnd(8)] ^= (uint8_t)(1u << rnd(8)); break; }
+            }
+            g = fopen(path.c_str(), "wb"); if (!raw.empty()) fwrite(raw.data(), 1, raw.size(), g); fclose(g);
+        }
         alarm(120);
         uint64_t n = 0; bool threw = false;
         try {
@@ -101,7 +119,21 @@ int main(int argc, char **argv) {
                 for (;;) { rsqc_host::HostBatch b; const size_t k = r.read_batch(b, 1 + rnd(rnd(3) ? 5000 : 50)); if (!k) break; n += k; (void)b.view(); }
             }
         } catch (const std::exception &) { threw = true; }
+        // the same file through the feeder of the device decode
+        uint64_t fed_blocks = 0; bool feeder_threw = false;
+        try {
+            rsqc_host::BgzfFeeder fd;
+            if (!fd.open(path)) feeder_threw = true;
+            else {
+                std::vector<std::string> names;
+                const uint64_t v = fd.first_record_voffset(&names);
+                if (rnd(2)) fd.set_cpu_share(1 + (int)rnd(3), 0.3, 0.6, 1u << 20);
+                fd.start(v, 0, (size_t)1 << (17 + rnd(4)), (uint64_t)1 << (18 + rnd(6)));
+                while (auto *ch = fd.next()) fed_blocks += ch->blocks.size();
+            }
+        } catch (const std::exception &) { feeder_threw = true; }
         alarm(0);
+        if (!damaged && (feeder_threw || fed_blocks == 0)) { fprintf(stderr, "reader_fuzz: case %ld: the feeder refused an undamaged file\n", c); return 1; }
         if (!damaged) {
             if (threw || n != base_records) { fprintf(stderr, "reader_fuzz: case %ld: an undamaged file of %llu records read as %llu%s\n", c, (unsigned long long)base_records, (unsigned long long)n, threw ? " and refused" : ""); return 1; }
             ++clean;

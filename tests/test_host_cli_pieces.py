@@ -642,13 +642,15 @@ def test_bam_by_contig_reading_through_the_index(host, tmp_path):
 def test_host_reader_on_damaged_records_under_sanitizers(tmp_path):
     """The host BAM reader (parallel framing from guessed record starts + chain verification, host/bam.cpp) on files whose
     records are damaged behind valid BGZF blocks: an exception or a record count, never an access outside its buffers or a
-    loop that does not end.  tests/hostemu/reader_fuzz.cpp under the address / undefined-behaviour sanitizers."""
+    loop that does not end; the same for damaged containers (BGZF headers, trailers, cut files), and for the device decode's
+    feeder (host/bgzf_feed.cpp) on every file.  tests/hostemu/reader_fuzz.cpp under the address / undefined-behaviour sanitizers."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "reader_fuzz")
     libdir = os.path.join(root, "rnaseqc_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            os.path.join(root, "tests", "hostemu", "reader_fuzz.cpp"), os.path.join(root, "rnaseqc_amd", "csrc", "host", "bam.cpp"),
+                           os.path.join(root, "rnaseqc_amd", "csrc", "host", "bgzf_feed.cpp"),
                            "-o", exe, "-L" + libdir, "-lrnaseqc_amd", "-lz", "-ldl", "-lpthread", "-Wl,-rpath," + libdir])
     r = subprocess.run([exe, "500", "11", str(tmp_path / "f.bam")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
