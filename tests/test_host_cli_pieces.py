@@ -655,3 +655,15 @@ def test_host_reader_on_damaged_records_under_sanitizers(tmp_path):
     r = subprocess.run([exe, "500", "11", str(tmp_path / "f.bam")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and "500 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_annotation_ingest_on_damaged_text_under_sanitizers(tmp_path):
+    """GTF / BED ingest (host/gtf.cpp) on damaged lines (cut, fields missing or empty, coordinates that are no numbers or beyond
+    64 bits, unbalanced quotes, CRLF, garbage): the reference's error classes (exit codes 10 / 11) or a loaded annotation,
+    nothing else.  tests/hostemu/gtf_fuzz.cpp under the address / undefined-behaviour sanitizers."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gtf_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(root, "tests", "hostemu", "gtf_fuzz.cpp"), os.path.join(root, "rnaseqc_amd", "csrc", "host", "gtf.cpp"), "-o", exe])
+    r = subprocess.run([exe, "1500", "5", str(tmp_path)], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "1500 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
