@@ -119,6 +119,11 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 #ifndef INF_PAR_COMMIT_CFG
 #define INF_PAR_COMMIT_CFG 0
 #endif
+// 1: the Huffman tables of a block are built by the lanes (inflate_build_par) instead of symbol by symbol on the scalar unit.
+// Off in the product build until measured, like the above.
+#ifndef INF_PAR_BUILD_CFG
+#define INF_PAR_BUILD_CFG 0
+#endif
 constexpr uint32_t INF_LBITS = INF_LBITS_CFG, INF_DBITS = INF_DBITS_CFG;
 constexpr uint32_t INF_FLUSH = INF_FLUSH_CFG;          // the ring goes out to HBM (and through the CRC) in pieces of this size
 static_assert(INF_RING >= INF_FLUSH + INF_ROUND_BYTES_CFG + 774u, "the far-match argument needs this (a round adds up to 1024 bytes before the next flush)");
@@ -313,6 +318,76 @@ RSQC_INF_FN uint32_t inflate_symbol_slow(uint32_t bits, const uint16_t *count, c
     len = l;
     return INF_UNI(sym[INF_UNI(index[l]) + (rev >> (32u - l)) - INF_UNI(first[l])]);
 }
+#if INF_PAR_BUILD_CFG
+// inflate_build with the lanes: the same tables (count / sym / first / index / fast), built without a per-symbol step on the
+// scalar unit.  64 symbols per pass; the lengths that occur in a pass are taken one after the other, a ballot each: the symbols
+// of one length keep their order (canonical codes are assigned in symbol order), a lane's slot is the length's cursor plus the
+// number of lanes below it in the ballot.  The fast table is filled by ENTRY: lane t decodes index t canonically (the same
+// test as inflate_symbol_slow, lengths 1 .. fbits) and stores what it finds, 0 when no code that short begins the index.
+RSQC_INF_FN bool inflate_build_par(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *sym, uint16_t *first, uint16_t *index, uint32_t *fast, uint32_t fbits, uint16_t *offs, int kind) {
+    INF_FOREACH(k) { if (k < 16u) count[k] = 0; }
+    uint32_t used = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {                       // codes per length
+        InfVec L, ANY;
+        INF_FOREACH(k) { INF_AT(L, k) = (base + k < n) ? (uint32_t)lens[base + k] : 0u; INF_AT(ANY, k) = INF_AT(L, k) ? 1u : 0u; }
+        uint64_t todo = inf_ballot(ANY);
+        used += (uint32_t)__builtin_popcountll(todo);
+        while (todo) {
+            const uint32_t l = INF_GET(L, (uint32_t)__builtin_ctzll(todo));
+            InfVec EQ;
+            INF_FOREACH(k) { (void)k; INF_AT(EQ, k) = (INF_AT(L, k) == l) ? 1u : 0u; }
+            const uint64_t m = inf_ballot(EQ);
+            INF_ST(count[l] = (uint16_t)(count[l] + (uint32_t)__builtin_popcountll(m)));
+            todo &= ~m;
+        }
+    }
+    if (!used) {                                                            // no codes at all: legal as long as none is used
+        for (uint32_t b = 0; b < (1u << fbits); b += 64u) { INF_FOREACH(k) { if (b + k < (1u << fbits)) fast[b + k] = 0u; } }
+        return true;
+    }
+    int32_t left = 1;
+    uint32_t run = 0, fcode = 0;
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        const uint32_t c = INF_UNI(count[l]);
+        left = (left << 1) - (int32_t)c;
+        if (left < 0) return false;
+        INF_ST(offs[l] = (uint16_t)run; index[l] = (uint16_t)run; first[l] = (uint16_t)fcode);
+        run += c;
+        fcode = (fcode + c) << 1;
+    }
+    for (uint32_t base = 0; base < n; base += 64u) {                       // symbols by (length, symbol)
+        InfVec L, ANY;
+        INF_FOREACH(k) { INF_AT(L, k) = (base + k < n) ? (uint32_t)lens[base + k] : 0u; INF_AT(ANY, k) = INF_AT(L, k) ? 1u : 0u; }
+        uint64_t todo = inf_ballot(ANY);
+        while (todo) {
+            const uint32_t l = INF_GET(L, (uint32_t)__builtin_ctzll(todo));
+            InfVec EQ;
+            INF_FOREACH(k) { (void)k; INF_AT(EQ, k) = (INF_AT(L, k) == l) ? 1u : 0u; }
+            const uint64_t m = inf_ballot(EQ);
+            const uint32_t at = INF_UNI(offs[l]);
+            INF_FOREACH(k) { if ((m >> k) & 1ull) sym[at + (uint32_t)__builtin_popcountll(m & ((1ull << k) - 1ull))] = (uint16_t)(base + k); }
+            INF_ST(offs[l] = (uint16_t)(at + (uint32_t)__builtin_popcountll(m)));
+            todo &= ~m;
+        }
+    }
+    for (uint32_t b = 0; b < (1u << fbits); b += 64u) {                     // the fast table, by entry
+        INF_FOREACH(k) {
+            const uint32_t idx = b + k, rev = inflate_bitrev32(idx);       // bit 0 of the index is the first bit of the stream
+            uint32_t e = 0;
+            for (uint32_t l = 1; l <= fbits; ++l) {
+                const uint32_t d = (rev >> (32u - l)) - (uint32_t)first[l];
+                if (!e && d < (uint32_t)count[l]) e = inflate_entry(kind, (uint32_t)sym[(uint32_t)index[l] + d], l);
+            }
+            if (idx < (1u << fbits)) fast[idx] = e;
+        }
+    }
+    return true;
+}
+#define INF_BUILD inflate_build_par
+#else
+#define INF_BUILD inflate_build
+#endif
+
 // one symbol at the head of the reader (the block headers' code-length code)
 RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint32_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *first, const uint16_t *index, const uint16_t *sym) {
     const uint32_t e = INF_UNI(fast[in.peek(fbits)]);
@@ -670,7 +745,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                     INF_ST(S.lens[kClOrder[k]] = (uint8_t)v);
                 }
                 // the code-length code is decoded with the distance tables' storage (7-bit codes fit the 8-bit fast table)
-                if (!inflate_build(S.lens, 19, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, 7, S.offs, INF_T_PLAIN)) return INF_ERR_TABLE;
+                if (!INF_BUILD(S.lens, 19, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, 7, S.offs, INF_T_PLAIN)) return INF_ERR_TABLE;
                 uint32_t i = 0, prev = 0;
                 while (i < nlit + ndist) {                         // (the code-length code's own lengths in lens[0..19) are not needed any more)
                     bi.refill();
@@ -687,8 +762,8 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
                 }
                 if (INF_UNI(S.lens[256]) == 0u) return INF_ERR_TABLE;                // no end-of-block code
             }
-            if (!inflate_build(S.lens, nlit, S.lcount, S.lsym, S.lfirst, S.lidx, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
-            if (!inflate_build(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
+            if (!INF_BUILD(S.lens, nlit, S.lcount, S.lsym, S.lfirst, S.lidx, S.lfast, INF_LBITS, S.offs, INF_T_LITLEN)) return INF_ERR_TABLE;
+            if (!INF_BUILD(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
             // ---- the symbols, in rounds (inflate_round)
             uint32_t status = INF_OK;
             while (inflate_round(S, bi, o, status)) {}

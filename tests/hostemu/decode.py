@@ -15,30 +15,34 @@ _SO = os.path.join(_HERE, "libdecode_emu.so")
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 
 
-def build(par_commit=False):
-    """par_commit: the decoder with INF_PAR_COMMIT_CFG=1 (the one-pass commit of a round; off in the product build)."""
+VARIANTS = {"": (), "par_commit": ("-DINF_PAR_COMMIT_CFG=1",), "par_build": ("-DINF_PAR_BUILD_CFG=1",),
+            "par_commit+par_build": ("-DINF_PAR_COMMIT_CFG=1", "-DINF_PAR_BUILD_CFG=1")}
+
+
+def build(variant=""):
+    """variant: a key of VARIANTS -- the decoder with the candidates of rsqc_inflate.h that are off in the product build
+    (the one-pass commit of a round, the lane-parallel table build)."""
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
     srcs = [os.path.join(_HERE, "decode_emu.cpp")] + [os.path.join(csrc, h) for h in ("rsqc_inflate.h", "rsqc_bamrec.h", "rsqc_decode.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
-    so = _SO.replace(".so", "_par.so") if par_commit else _SO
+    so = _SO.replace(".so", "_" + variant.replace("+", "_") + ".so") if variant else _SO
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden"] + (["-DINF_PAR_COMMIT_CFG=1"] if par_commit else []) +
-                              [srcs[0], "-o", so])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", *VARIANTS[variant], srcs[0], "-o", so])
     return so
 
 
-def lib(par_commit=False):
-    l = C.CDLL(build(par_commit))
+def lib(variant=""):
+    l = C.CDLL(build(variant))
     l.emu_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32]
     l.emu_crc_wave64.restype = C.c_uint32
     l.emu_crc_wave64.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
     return l
 
 
-def inflate(comp, n, crc, par_commit=False):
+def inflate(comp, n, crc, variant=""):
     """(status, bytes) of the wave-emulated DEFLATE decoder on one raw stream."""
     out = C.create_string_buffer(n + 64)
-    rc = lib(par_commit).emu_inflate(comp, len(comp), out, n, crc & 0xFFFFFFFF)
+    rc = lib(variant).emu_inflate(comp, len(comp), out, n, crc & 0xFFFFFFFF)
     return rc, out.raw[:n]
 
 

@@ -36,11 +36,11 @@ def _payloads():
             yield bytes([rng.randrange(2)]) * n
 
 
-@pytest.mark.parametrize("par_commit", [False, True])
-def test_inflate_matches_zlib_on_every_block_type(par_commit):
+@pytest.mark.parametrize("variant", ["", "par_commit", "par_build", "par_commit+par_build"])
+def test_inflate_matches_zlib_on_every_block_type(variant):
     """Stored, fixed and dynamic blocks, several blocks per stream, small windows, long codes (Huffman-only on random bytes),
-    runs (distance 1) and distances up to 32 KiB.  par_commit: the build with the one-pass commit of a round
-    (INF_PAR_COMMIT_CFG=1, rsqc_inflate.h; off in the product until measured)."""
+    runs (distance 1) and distances up to 32 KiB.  variant: the builds with the one-pass commit of a round and / or the
+    lane-parallel table build (INF_PAR_COMMIT_CFG, INF_PAR_BUILD_CFG in rsqc_inflate.h; off in the product until measured)."""
     n = 0
     for d in _payloads():
         for level in (0, 1, 6, 9):
@@ -49,7 +49,7 @@ def test_inflate_matches_zlib_on_every_block_type(par_commit):
                     co = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strat)
                     half = len(d) // 2
                     comp = co.compress(d[:half]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(d[half:]) + co.flush()
-                    rc, out = emu.inflate(comp, len(d), zlib.crc32(d), par_commit)
+                    rc, out = emu.inflate(comp, len(d), zlib.crc32(d), variant)
                     assert rc == 0 and out == d, (len(d), level, strat, wbits, rc)
                     n += 1
     assert n > 500
@@ -269,13 +269,13 @@ def _sanitized(tmp_path, name, libs=(), defs=()):
     return exe
 
 
-@pytest.mark.parametrize("par_commit", [False, True])
-def test_inflate_on_damaged_input_under_sanitizers(tmp_path, par_commit):
+@pytest.mark.parametrize("variant", ["", "par_commit+par_build"])
+def test_inflate_on_damaged_input_under_sanitizers(tmp_path, variant):
     """What the wave's DEFLATE decoder does with flipped bits, overwritten bytes, cut payloads, garbage and wrong ISIZE values:
     it stays inside its input, its ISIZE bytes of output and its tables, it ends, and it never hands on wrong bytes (on the
     GPU the first two are a dead device).  Verdicts are zlib's, see tests/hostemu/inflate_fuzz.cpp."""
     import subprocess
-    exe = _sanitized(tmp_path, "inflate_fuzz", ["-lz"], ["-DINF_PAR_COMMIT_CFG=1"] if par_commit else [])
+    exe = _sanitized(tmp_path, "inflate_fuzz", ["-lz"], emu.VARIANTS[variant])
     for seed in (1, 2):
         r = subprocess.run([exe, "4000", str(seed)], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
