@@ -70,10 +70,25 @@ namespace rsqc {
 // wave-wide helpers on lane vectors: which lanes hold a non-zero value, and the running (inclusive) sum over the lanes
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint64_t inf_ballot(const InfVec &v) { return __ballot(v != 0u); }
+#if defined(INF_DPP_SCAN_CFG) && INF_DPP_SCAN_CFG
+// The running sum as six DPP additions (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2 into rows 1
+// and 3, then lane 31 into rows 2 and 3) instead of six ds_bpermute round trips.  DEVICE-ONLY code: the host tests cannot run
+// it; off until an A/B run (tools/decode_ab.sh checks every block's CRC-32 and the outputs) has shown it right and faster.
+__device__ __forceinline__ InfVec inf_scan(InfVec v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+#else
 __device__ __forceinline__ InfVec inf_scan(InfVec v) {
     for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)v, d, 64); if (INF_LANE >= d) v += x; }
     return v;
 }
+#endif
 #else
 inline uint64_t inf_ballot(const InfVec &v) { uint64_t m = 0; for (uint32_t k = 0; k < 64u; ++k) if (v.v[k]) m |= 1ull << k; return m; }
 inline InfVec inf_scan(InfVec v) { for (uint32_t k = 1; k < 64u; ++k) v.v[k] += v.v[k - 1]; return v; }
