@@ -139,6 +139,11 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 #ifndef INF_PAR_BUILD_CFG
 #define INF_PAR_BUILD_CFG 0
 #endif
+// 1: a code longer than the fast table does not end the round: the walk decodes it where it stands (one step of the wave,
+// inflate_symbol_slow), writes the result into that lane and goes on over the lanes behind it.  Off until measured.
+#ifndef INF_INWALK_CFG
+#define INF_INWALK_CFG 0
+#endif
 constexpr uint32_t INF_LBITS = INF_LBITS_CFG, INF_DBITS = INF_DBITS_CFG;
 constexpr uint32_t INF_FLUSH = INF_FLUSH_CFG;          // the ring goes out to HBM (and through the CRC) in pieces of this size
 static_assert(INF_RING >= INF_FLUSH + INF_ROUND_BYTES_CFG + 774u, "the far-match argument needs this (a round adds up to 1024 bytes before the next flush)");
@@ -611,11 +616,51 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
     uint64_t starts = 0;
     uint32_t off = 0;
     uint32_t a = INF_GET(PK, 0u);
+#if INF_INWALK_CFG
+    for (;;) {
+#endif
     while ((a | (off << 3)) < ((uint32_t)INF_K_END << 8)) {
         starts |= 1ull << off;
         off += a & 0xFFu;
         a = INF_GET(PK, off & 63u);
     }
+#if INF_INWALK_CFG
+        // A lane the walk cannot take.  When it is a code the fast table does not hold, the symbol is decoded here -- its bits are
+        // buffered, the lanes behind it have decoded what follows -- and the walk goes on; everything else (the buffered bits
+        // end inside the symbol, a code nobody owns, the end of the block) ends the round as before.
+        if (off >= 64u || (a >> 8) != (uint32_t)INF_K_OTHER) break;
+        const uint64_t w = bi.bits_at(off);
+        if (INF_UNI(S.lfast[(uint32_t)w & ((1u << INF_LBITS) - 1u)])) break;   // (not a long code: the symbol runs past the buffered bits, or is undefined)
+        uint32_t len;
+        const uint32_t sy = inflate_symbol_slow((uint32_t)w, S.lcount, S.lfirst, S.lidx, S.lsym, len);
+        if (sy == 0xFFFFu) break;
+        const uint32_t e = inflate_entry(INF_T_LITLEN, sy, len);
+        uint32_t kind, adv, ol = 0, val = 0;
+        if (e & INF_E_LITERAL) { kind = INF_K_LIT; adv = len; ol = 1; val = (e >> 8) & 0xFFu; }
+        else if (e & INF_E_END) { kind = INF_K_END; adv = len; }
+        else if (e & INF_E_INVALID) break;
+        else {
+            const uint32_t xb = (e >> 4) & 15u;
+            const uint64_t w1 = w >> len;
+            const uint32_t mlen = ((e >> 8) & 0xFFFFu) + ((uint32_t)w1 & ((1u << xb) - 1u));
+            const uint64_t w2 = w1 >> xb;
+            uint32_t f = INF_UNI(S.dfast[(uint32_t)w2 & ((1u << INF_DBITS) - 1u)]);
+            if (!f) {
+                uint32_t dl;
+                const uint32_t ds = inflate_symbol_slow((uint32_t)w2, S.dcount, S.dfirst, S.didx, S.dsym, dl);
+                if (ds == 0xFFFFu) break;
+                f = inflate_entry(INF_T_DIST, ds, dl);
+            }
+            if (f & INF_E_INVALID) break;
+            const uint32_t l2 = f & 15u, db = (f >> 4) & 15u;
+            kind = INF_K_MATCH; adv = len + xb + l2 + db; ol = mlen;
+            val = ((f >> 8) & 0xFFFFu) + ((uint32_t)(w2 >> l2) & ((1u << db) - 1u));
+        }
+        if (off + adv > avail) break;                                       // the symbol runs past the buffered bits
+        a = (kind << 8) | adv;
+        INF_SET(PK, off, a); INF_SET(VAL, off, val); INF_SET(OL, off, ol);
+    }
+#endif
     bool stopped = off < 64u;                                               // the walk met a symbol it cannot take, at bit offset off
     const uint32_t stopped_at = a;
     INF_STAT(inflate_stats().rounds++); INF_STAT(inflate_stats().round_symbols += (unsigned)__builtin_popcountll(starts)); INF_STAT(inflate_stats().slow_symbols += stopped ? 1 : 0);

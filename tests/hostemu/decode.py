@@ -15,13 +15,13 @@ _SO = os.path.join(_HERE, "libdecode_emu.so")
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 
 
-VARIANTS = {"": (), "par_commit": ("-DINF_PAR_COMMIT_CFG=1",), "par_build": ("-DINF_PAR_BUILD_CFG=1",),
-            "par_commit+par_build": ("-DINF_PAR_COMMIT_CFG=1", "-DINF_PAR_BUILD_CFG=1")}
+VARIANTS = {"": (), "par_commit": ("-DINF_PAR_COMMIT_CFG=1",), "par_build": ("-DINF_PAR_BUILD_CFG=1",), "inwalk": ("-DINF_INWALK_CFG=1",),
+            "all": ("-DINF_PAR_COMMIT_CFG=1", "-DINF_PAR_BUILD_CFG=1", "-DINF_INWALK_CFG=1")}
 
 
 def build(variant=""):
     """variant: a key of VARIANTS -- the decoder with the candidates of rsqc_inflate.h that are off in the product build
-    (the one-pass commit of a round, the lane-parallel table build)."""
+    (the one-pass commit of a round, the lane-parallel table build, long codes decoded inside the walk)."""
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
     srcs = [os.path.join(_HERE, "decode_emu.cpp")] + [os.path.join(csrc, h) for h in ("rsqc_inflate.h", "rsqc_bamrec.h", "rsqc_decode.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]

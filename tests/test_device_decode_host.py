@@ -36,11 +36,11 @@ def _payloads():
             yield bytes([rng.randrange(2)]) * n
 
 
-@pytest.mark.parametrize("variant", ["", "par_commit", "par_build", "par_commit+par_build"])
+@pytest.mark.parametrize("variant", ["", "par_commit", "par_build", "inwalk", "all"])
 def test_inflate_matches_zlib_on_every_block_type(variant):
     """Stored, fixed and dynamic blocks, several blocks per stream, small windows, long codes (Huffman-only on random bytes),
-    runs (distance 1) and distances up to 32 KiB.  variant: the builds with the one-pass commit of a round and / or the
-    lane-parallel table build (INF_PAR_COMMIT_CFG, INF_PAR_BUILD_CFG in rsqc_inflate.h; off in the product until measured)."""
+    runs (distance 1) and distances up to 32 KiB.  variant: the builds with the candidates of rsqc_inflate.h that are off in the
+    product until measured (INF_PAR_COMMIT_CFG, INF_PAR_BUILD_CFG, INF_INWALK_CFG)."""
     n = 0
     for d in _payloads():
         for level in (0, 1, 6, 9):
@@ -269,7 +269,7 @@ def _sanitized(tmp_path, name, libs=(), defs=()):
     return exe
 
 
-@pytest.mark.parametrize("variant", ["", "par_commit+par_build"])
+@pytest.mark.parametrize("variant", ["", "all"])
 def test_inflate_on_damaged_input_under_sanitizers(tmp_path, variant):
     """What the wave's DEFLATE decoder does with flipped bits, overwritten bytes, cut payloads, garbage and wrong ISIZE values:
     it stays inside its input, its ISIZE bytes of output and its tables, it ends, and it never hands on wrong bytes (on the
