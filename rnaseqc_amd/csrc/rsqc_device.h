@@ -1,7 +1,9 @@
 // rsqc_device.h -- device-side views shared by the kernels and the C-ABI host code.
 #pragma once
 
+#if !defined(RSQC_WAVE_EMU)      /* tests/hostemu/wavemu.h stands in for the HIP runtime in the host build of K1 */
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "rsqc_read.h"
@@ -128,8 +130,11 @@ void launch_reduce_add(hipStream_t s, unsigned long long *du, const unsigned lon
                        uint8_t *db, const uint8_t *sb, size_t nb);
 void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons);
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min);
+// records with longer CIGARs, listed by classify_ei_kernel for classify_multi_kernel: workgroup k owns [k * cap, + count[k])
+struct MultiList { uint2 *list; uint32_t *count; uint32_t cap; };
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                     const DevAccum &acc);
+                     const DevAccum &acc, const MultiList &ml);
+void launch_ei_rank(hipStream_t s, const EiEntry *ei, uint32_t ei_lo, uint32_t ei_hi, EiRank *rank, uint32_t n_words);
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc);
 // summary (may be NULL): RSQC_RL_SUMMARY_WORDS words of the batch's Read-Length transfer function (rsqc_kernels.hip, KR)

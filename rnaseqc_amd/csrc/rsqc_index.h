@@ -20,6 +20,9 @@ struct HostIndex {
     std::vector<GeneBreak> gb;
     std::vector<int32_t> ex_pmax, g_pmax;
     std::vector<ExonRow> ex_rows;
+    std::vector<EiEntry> ei;                          // elementary intervals (rsqc_read.h)
+    std::vector<uint32_t> ei_range;                   // [n_contigs + 1]
+    uint64_t rank_words = 0;                          // words of the rank table over all contigs
     std::vector<GeneRow> gr_rows;                     // --legacy tables (LegacyTables)
     std::vector<uint32_t> ex_ord;
     std::vector<ContigInfo> contig;
@@ -149,6 +152,74 @@ struct HostIndex {
             ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_cov[(size_t)i],
                                          a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
         }
+        // elementary intervals per contig: sweep over the starts (+) and ends + 1 (-) of gene and exon rows
+        ei.clear(); ei_range.assign((size_t)nc + 1, 0); rank_words = 0;
+        for (int k = 0; k < nc; ++k) {
+            struct Ev { int64_t pos; int32_t what; uint32_t idx; };      // what: +-(1 + class + 3 * ribo) gene, +-100 exon row idx
+            std::vector<Ev> ev;
+            for (uint32_t i = g_range[(size_t)k]; i < g_range[(size_t)k + 1]; ++i) {
+                const int cls = a->gene_row_flags[i] & RSQC_FF_STRAND_MASK, ribo = (a->gene_row_flags[i] & RSQC_FF_RIBOSOMAL) ? 1 : 0;
+                const int code = 1 + cls + 3 * ribo;
+                ev.push_back(Ev{std::max<int64_t>(0, a->gene_row_start[i]), code, 0u});
+                ev.push_back(Ev{(int64_t)a->gene_row_end[i] + 1, -code, 0u});
+            }
+            for (uint32_t i = ex_range[(size_t)k]; i < ex_range[(size_t)k + 1]; ++i) {
+                ev.push_back(Ev{std::max<int64_t>(0, a->exon_row_start[i]), 100, i});
+                ev.push_back(Ev{(int64_t)a->exon_row_end[i] + 1, -100, i});
+            }
+            contig[(size_t)k].rk_base = (uint32_t)rank_words; contig[(size_t)k].rk_words = 0;
+            if (ev.empty()) { ei_range[(size_t)k + 1] = (uint32_t)ei.size(); continue; }
+            std::stable_sort(ev.begin(), ev.end(), [](const Ev &x, const Ev &y) { return x.pos < y.pos; });
+            int cnt[6] = {0, 0, 0, 0, 0, 0};
+            std::vector<uint32_t> active;                      // exon rows covering the current interval, ascending
+            auto emit = [&](int64_t pos) {
+                EiEntry e{(int32_t)pos, 0u, EI_NONE, EI_NONE, 0u, 0u, 0u, 0u};
+                for (int cls = 0; cls < 3; ++cls) {
+                    if (cnt[cls] + cnt[3 + cls] > 0) e.mask |= 1u << cls;
+                    if (cnt[3 + cls] > 0) e.mask |= 1u << (3 + cls);
+                }
+                for (uint32_t row : active) {
+                    const uint32_t fl = a->exon_row_flags[row];
+                    e.mask |= 1u << (EIM_EXON_SHIFT + (fl & RSQC_FF_STRAND_MASK));
+                    if (fl & RSQC_FF_RIBOSOMAL) e.mask |= 1u << (EIM_EXON_SHIFT + 3 + (fl & RSQC_FF_STRAND_MASK));
+                }
+                if (active.size() > 2) e.mask |= EIM_DEEP;
+                if (!active.empty()) {
+                    const uint32_t r = active.back();
+                    e.eidA = a->exon_row_id[r]; e.gfA = ex_rows[r].gf; e.cdA = ex_rows[r].cov - (uint32_t)ex_rows[r].start;
+                }
+                if (active.size() > 1) {
+                    const uint32_t r = active[active.size() - 2];
+                    e.eidB = a->exon_row_id[r]; e.gfB = ex_rows[r].gf; e.cdB = ex_rows[r].cov - (uint32_t)ex_rows[r].start;
+                }
+                const bool first = ei.size() == ei_range[(size_t)k];
+                if (!first) {
+                    const EiEntry &p = ei.back();
+                    if (p.mask == e.mask && p.eidA == e.eidA && p.eidB == e.eidB) return;     // nothing changed
+                }
+                ei.push_back(e);
+            };
+            size_t e = 0;
+            if (ev[0].pos > 0) emit(0);                        // the sentinel interval
+            while (e < ev.size()) {
+                const int64_t pos = ev[e].pos;
+                if (pos > 0x7FFFFFFFll) break;
+                while (e < ev.size() && ev[e].pos == pos) {
+                    const Ev &x = ev[e++];
+                    if (x.what == 100) active.insert(std::upper_bound(active.begin(), active.end(), x.idx), x.idx);
+                    else if (x.what == -100) active.erase(std::find(active.begin(), active.end(), x.idx));
+                    else if (x.what > 0) cnt[x.what - 1]++;
+                    else cnt[-x.what - 1]--;
+                }
+                emit(pos);
+            }
+            ei_range[(size_t)k + 1] = (uint32_t)ei.size();
+            const uint64_t words = ((uint64_t)(uint32_t)ei.back().pos >> 6) + 1;
+            contig[(size_t)k].rk_words = (uint32_t)words;
+            rank_words += words;
+            if (rank_words >= (1ull << 28) || ei.size() >= (1ull << 27)) { err = "annotation too large for the interval index"; return RSQC_ERR_CAPACITY; }
+        }
+        if (ei.empty()) ei.push_back(EiEntry{0, 0u, EI_NONE, EI_NONE, 0u, 0u, 0u, 0u});    // lanes without a look-up read entry 0
         gene_flags.assign((size_t)std::max(L, 1), 0);
         gene_owned.assign((size_t)std::max(L, 1), 0);
         for (int i = 0; i < L; ++i) {
@@ -183,6 +254,23 @@ struct HostIndex {
             }
         }
         return 0;
+    }
+    // the rank table over all contigs, on the host (tests; the product fills it on the device: ei_rank_kernel)
+    void build_rank(std::vector<EiRank> &out) const {
+        out.assign((size_t)rank_words + 1, EiRank{0u, 0u, 0u, 0u});
+        for (int k = 0; k < n_contigs; ++k) {
+            const ContigInfo &ci = contig[(size_t)k];
+            uint32_t j = ei_range[(size_t)k];
+            for (uint32_t w = 0; w < ci.rk_words; ++w) {
+                EiRank &r = out[(size_t)ci.rk_base + w];
+                r.rank = j;
+                while (j < ei_range[(size_t)k + 1] && ((uint32_t)ei[j].pos >> 6) == w) {
+                    const uint32_t b = (uint32_t)ei[j].pos & 63u;
+                    if (b < 32) r.lo |= 1u << b; else r.hi |= 1u << (b - 32);
+                    ++j;
+                }
+            }
+        }
     }
 };
 

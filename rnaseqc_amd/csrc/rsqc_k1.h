@@ -1,0 +1,473 @@
+// rsqc_k1.h -- K1, the per-record kernel of the default rule set since round 3 (included by rsqc_kernels.hip, which
+// provides the wave helpers).  Replaces src/RNASeQC.cpp:254-369 and src/Expression.cpp:26-67,106-117,308-458.
+//
+// The shape follows from two measurements of the round-2 kernel: the vector pipe was 63 % of its time
+// (1 083 VALU instructions per 64-record tile) and the rest was exposed latency of a chain of dependent index loads
+// at 4 waves per SIMD.  Both came from running ONE predicated program over records of every shape -- four block rounds
+// and eight commit slots for a stream in which 58 % of the records have one block.
+//
+//   classify_ei_kernel     every WAVE streams its own contiguous range of records.  Per 64-record tile ("phase A") it
+//       unpacks the record words, walks the first operations of the CIGAR, runs the gate cascade with its counters
+//       (WaveSink) and the Read-Length inputs, and then SORTS the surviving records by block count into per-wave LDS
+//       queues: one block, two blocks.  Whenever a queue holds 64 records the wave runs the feature stage of exactly
+//       that shape on them (`k1e_process<NB>`): all lanes busy, one / two look-up rounds, two / four commit slots, no
+//       block-count predicates.  Records with longer CIGARs (more than 4 operations or more than 2 blocks: 9 % of an
+//       RNA-seq file) are listed for classify_multi_kernel; a record whose blocks meet an interval covered by more than
+//       two exons goes to the general code (classify_slow_kernel) as before.
+//   classify_multi_kernel  the listed records, one per lane: full CIGAR walk (8 operations from registers, more from
+//       memory), up to FAST_BLOCKS blocks per record through the same feature stage and commit code.
+//
+// The feature stage reads the ELEMENTARY-INTERVAL index (rsqc_read.h: EiEntry / EiRank): a block costs two 16-byte
+// rank-word loads (independent, no walk) and one round of entry loads, instead of bin -> rows -> rows further down.
+#pragma once
+
+namespace rsqc {
+
+constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
+constexpr int K1E_QCAP = 128;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
+constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
+constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's flag word | K1E_HQ when high quality
+
+// Workgroup-local accumulators: a workgroup streams a short genomic window, so it touches a handful of neighbouring
+// exons and genes; direct-mapped LDS tables take every update and each distinct key costs ONE global atomic when the
+// workgroup retires.  A key that finds its slot taken by another key goes straight to memory.
+struct K1eTables {
+    unsigned long long cnt[RSQC_N_COUNTERS];     // sum-type counters
+    uint32_t cnt32[64];                          // one-per-record counters (a workgroup sees < 2^32 records)
+    double eval[K1E_ESLOTS];
+    uint32_t ekey[K1E_ESLOTS];                   // exon id
+    unsigned long long gval[K1E_GSLOTS];         // low word: records, high word: records that are not duplicates
+    uint32_t gkey[K1E_GSLOTS];
+    uint32_t rl[3];
+    uint32_t pairs;                              // pairs in the workgroup's chunk
+    uint32_t multi;                              // records listed for classify_multi_kernel
+    __device__ __forceinline__ void init(uint32_t pairs0) {
+        for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
+        if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
+        for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
+        for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
+        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; multi = 0u; }
+    }
+    __device__ __forceinline__ void exon_add(const DevAccum &acc, uint32_t eid, double frac) {
+        const uint32_t slot = eid & (K1E_ESLOTS - 1);
+        const uint32_t old = atomicCAS(&ekey[slot], 0xFFFFFFFFu, eid);
+        if (old == 0xFFFFFFFFu || old == eid) atomicAdd(&eval[slot], frac);
+        else atomicAdd(&acc.exon_acc[eid], frac);
+    }
+    __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, bool notdup) {
+        const uint32_t slot = g & (K1E_GSLOTS - 1);
+        const uint32_t old = atomicCAS(&gkey[slot], 0xFFFFFFFFu, g);
+        if (old == 0xFFFFFFFFu || old == g) atomicAdd(&gval[slot], notdup ? 0x100000001ull : 1ull);
+        else { atomicAdd(&acc.gene_reads[g], 1ull); if (notdup) atomicAdd(&acc.gene_unique[g], 1ull); }
+    }
+    // after a __syncthreads(): every table goes to memory, one atomic per distinct key
+    __device__ __forceinline__ void flush(const DevAccum &acc) {
+        for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) {
+            const unsigned long long v = cnt[c] + (unsigned long long)cnt32[c];
+            if (v) atomicAdd(&acc.counters[c], v);
+        }
+        for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x)
+            if (ekey[c] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[ekey[c]], eval[c]);
+        for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x)
+            if (gkey[c] != 0xFFFFFFFFu) {
+                const unsigned long long v = gval[c];
+                atomicAdd(&acc.gene_reads[gkey[c]], v & 0xFFFFFFFFull);
+                if (v >> 32) atomicAdd(&acc.gene_unique[gkey[c]], v >> 32);
+            }
+    }
+};
+
+struct K1eShared {
+    K1eTables T;
+    uint4 q1[K1E_WAVES][K1E_QCAP];               // one block:  bs, len, record index, flhq
+    uint4 q2[K1E_WAVES][K1E_QCAP];               // two blocks: bs0, len0, bs1, len1
+    uint2 q2x[K1E_WAVES][K1E_QCAP];              //             record index, flhq
+};
+
+// ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
+// exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
+// workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
+// its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
+template <int NB>
+__device__ __forceinline__ void k1e_commit(const DevAccum &acc, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], bool notdup,
+                                           uint64_t qhash, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
+    const int l = lane_id();
+    double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
+    if (NB > 1) {
+        uint32_t aligned = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) aligned += len[b];
+        inv_aligned = 1.0 / (double)(aligned ? aligned : 1u);     // (a slot adds len * (1 / aligned): within 1 ulp of len / aligned)
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NB; ++k) {
+        const bool has = (eo.cmask >> k) & 1u;
+        if (__ballot(has) == 0ull) continue;
+        const uint32_t ln = len[k >> 1];
+        const bool hv = has && ln > 0;
+        if (hv) T.exon_add(acc, eo.eid[k], NB > 1 ? (double)ln * inv_aligned : 1.0);
+        const uint32_t base = hv ? eo.cidx[k] : 0u;
+        cov_add_merged(acc.cov_diff, hv, base, 1u);
+        cov_add_merged(acc.cov_diff, hv, base + ln, 0xFFFFFFFFu);
+    }
+#pragma unroll
+    for (int k = 0; k < FAST_SET; ++k) {
+        const bool has = eo.n_hit > k;
+        const uint64_t m = __ballot(has);
+        if (m == 0ull) break;
+        const uint32_t g = eo.hit[k];
+        const int lead = __ffsll((unsigned long long)m) - 1;
+        uint32_t base = 0;
+        if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
+        base = __shfl(base, lead, 64);
+        if (has) {
+            const uint32_t slot = base + mask_rank(m);
+            if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
+            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+            T.gene_add(acc, g, notdup);
+        }
+    }
+}
+
+__device__ __forceinline__ void k1e_overflow(const DevAccum &acc, bool over, uint64_t index) {
+    if (over) {
+        const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
+        if (slot < acc.ovf_cap) acc.ovf_index[slot] = index;
+        else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+    }
+}
+
+// ---- the feature stage of 64 queued records of NB blocks each (n < 64 only when a queue is drained) -----------------
+template <int NB>
+__device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevAccum &acc,
+                                            const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
+                                            uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
+    const int l = lane_id();
+    const bool on = (uint32_t)l < n;
+    const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
+    int32_t bs[NB]; uint32_t len[NB]; uint32_t idx, flhq;
+    if (NB == 1) {
+        const uint4 it = S.q1[wave][slot];
+        bs[0] = (int32_t)it.x; len[0] = it.y; idx = it.z; flhq = it.w;
+    } else {
+        const uint4 it = S.q2[wave][slot]; const uint2 ix = S.q2x[wave][slot];
+        bs[0] = (int32_t)it.x; len[0] = it.y; bs[NB - 1] = (int32_t)it.z; len[NB - 1] = it.w; idx = ix.x; flhq = ix.y;
+    }
+    if (!on) { idx = 0u; flhq = 0u; }
+    // the name hash is only needed by records that are counted to a gene: it comes back from the record array (the lines
+    // were streamed through this CU's caches a few tiles ago) instead of riding through the queue
+    const uint2 qh = ld32(reinterpret_cast<const uint2 *>(b.aux), idx * 2u);
+    WaveSink cnt;
+    EiOut eo; bool over = false;
+    exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on);
+    k1e_overflow(acc, on && over, (uint64_t)idx);
+    k1e_commit<NB>(acc, S.T, eo, len, !(flhq & RSQC_FDUP), (uint64_t)qh.x | ((uint64_t)qh.y << 32), my_pair_gene, my_pair_hash, chunk_cap);
+    if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+}
+
+// ---- CIGAR, first pass (extractBlocks + bam_endpos, src/Expression.cpp:26-67): operations 0-3 with the first two
+// blocks captured, operations 4-7 for the reference length only; operations past the eighth come from memory ----------
+struct Walk2 { uint32_t ref_len, nb; bool bad; int32_t bs0, bs1; uint32_t len0, len1; };
+__device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t (&c)[8], const uint32_t *cigar, Walk2 &w) {
+    w.ref_len = 0; w.nb = 0; w.bad = false; w.bs0 = 0; w.bs1 = 0; w.len0 = 0; w.len1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ck = (uint32_t)k < n ? c[k] : 5u;               // past the end: a hard clip of length 0 (no block, no reference, legal)
+        const uint32_t op = ck & 0xf, len = ck >> 4;
+        const bool blk = (CIG_BLOCK_SET >> op) & 1u, ref = (CIG_REF_SET >> op) & 1u;
+        w.bad = w.bad || op > 8;                                       // Expression.cpp:61-63
+        const int32_t start = pos + 1 + (int32_t)w.ref_len;
+        if (k == 0) { w.bs0 = start; w.len0 = blk ? len : 0u; }
+        else {
+            const bool is0 = blk && w.nb == 0, is1 = blk && w.nb == 1;
+            w.bs0 = is0 ? start : w.bs0; w.len0 = is0 ? len : w.len0;
+            w.bs1 = is1 ? start : w.bs1; w.len1 = is1 ? len : w.len1;
+        }
+        w.nb += blk ? 1u : 0u;
+        w.ref_len += ref ? len : 0u;
+    }
+    if (__ballot(n > 4) != 0ull) {
+#pragma unroll
+        for (int k = 4; k < 8; ++k) {
+            const uint32_t ck = (uint32_t)k < n ? c[k] : 5u;
+            w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u;
+        }
+        for (uint32_t i = 8; i < n; ++i) { const uint32_t ck = cigar[i]; w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u; }
+    }
+}
+
+__global__ void __launch_bounds__(RSQC_K1_THREADS, 5)
+classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2 *multi_list, uint32_t *multi_count, uint32_t multi_cap) {
+    __shared__ K1eShared S;
+    const int l = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    S.T.init(0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
+    __syncthreads();
+
+    // the seven sum-type counters stay per-lane sums, reduced every 31 tiles
+    uint32_t sum_e1mm = 0, sum_e1b = 0, sum_e2mm = 0, sum_e2b = 0, sum_mm = 0, sum_b = 0, sum_blk = 0;
+    int pending = 0;
+    uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
+    auto flush_counts = [&]() {
+        const uint32_t s0 = wave_sum(sum_e1mm), s1 = wave_sum(sum_e1b), s2 = wave_sum(sum_e2mm), s3 = wave_sum(sum_e2b),
+                       s4 = wave_sum(sum_mm), s5 = wave_sum(sum_b), s6 = wave_sum(sum_blk);
+        if (l == 0 && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
+        if (l == 0 && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
+        if (l == 0 && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
+        if (l == 0 && s3) atomicAdd(&S.T.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
+        if (l == 0 && s4) atomicAdd(&S.T.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
+        if (l == 0 && s5) atomicAdd(&S.T.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
+        if (l == 0 && s6) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
+        sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
+        pending = 0;
+    };
+
+    const uint64_t total_waves = (uint64_t)gridDim.x * K1E_WAVES;
+    const uint64_t per_wave = (((b.n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
+    const uint64_t wbeg = ((uint64_t)blockIdx.x * K1E_WAVES + (uint64_t)wave) * per_wave;
+    const uint64_t wend = wbeg + per_wave < b.n ? wbeg + per_wave : b.n;
+    const uint32_t chunk_cap = acc.pair_chunk_cap;
+    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
+    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
+    uint2 *const my_multi = multi_list + (size_t)blockIdx.x * multi_cap;
+    uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
+    int32_t u_tid = -1;
+    ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_contig = [&]() {
+        u_tid = b.n_seg ? b.seg_tid[seg] : -1;
+        if (u_tid >= 0 && u_tid < a.n_contigs) u_ci = a.contig[u_tid];
+        else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    load_contig();
+    uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0;             // queue heads and fills (wave-uniform)
+
+    // Record words are staged one tile ahead (core words two tiles ahead: they carry the CIGAR address), eight CIGAR
+    // words per record with them.
+    const int4 zero4 = {0, 0, 0, 0};
+    int4 cur_cv = zero4, cur_av = zero4, nx_cv = zero4;
+    uint32_t cg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
+    if (wbeg + (uint64_t)l < wend) { cur_cv = ld32(core4 + wbeg, (uint32_t)l); cur_av = ld32(aux4 + wbeg, (uint32_t)l); }
+    if (wbeg + 64ull + (uint64_t)l < wend) nx_cv = ld32(core4 + wbeg + 64, (uint32_t)l);
+    {
+        const uint32_t co = (uint32_t)cur_cv.w;                          // buffers carry 32 bytes of slack
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, co + (uint32_t)k);
+    }
+    for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
+        const uint64_t i = w0 + (uint64_t)l;
+        const bool valid = i < wend;
+        {
+            bool moved = false;
+            while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) { ++seg; moved = true; }
+            if (moved) load_contig();                       // (the queues were emptied by the tile before the boundary)
+        }
+        const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
+        WaveSink cnt;
+        // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
+        Record r;
+        {
+            const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
+            r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
+            r.cigar = b.cigar + (uint32_t)cv.w;
+            r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+            r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
+            r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
+            r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
+        }
+        bool ok = true;
+        if (valid && (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE)) {
+            uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
+            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
+            if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
+            else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
+        }
+        r.tid = u_tid;
+        if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
+        if (valid && !ok) atomicExch(acc.error, RSQC_ERR_ARG);
+        const bool lane_on = valid && ok;
+        if (!lane_on) r.n_cigar = 0;
+        Walk2 w2;
+        k1e_walk(r.pos, r.n_cigar, cg, r.cigar, w2);
+        const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: classify_multi_kernel
+        CigarWalk cw;
+        cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad;
+        RecordCounters rc; bool hq = false;
+        bool go = gate_cascade<false, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
+        if (!lane_on) { go = false; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
+        if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
+            const int32_t name = bed_interval_of(a, r);
+            if (name >= 0) {
+                const uint32_t slot = atomicAdd(acc.frag.count, 1u);
+                if (slot < acc.frag.cap) {
+                    acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
+                    acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
+                    const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
+                    const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
+                    acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
+                } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+            }
+        }
+        if (rc.error) atomicExch(acc.error, rc.error);
+        sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
+        sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
+        const bool big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
+        {   // Read-Length inputs: per-tile max span + batch-level extremes
+            const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
+            const uint32_t wsp = wave_max_u32(sp);
+            if (l == 0) acc.tile_span[w0 >> 6] = wsp;
+            l_span = sp > l_span ? sp : l_span;
+            if (rc.rl_eligible) {
+                const uint32_t lq = (uint32_t)rc.rl_lqseq;
+                l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
+            }
+        }
+        const uint32_t flhq = r.flag | (hq ? K1E_HQ : 0u);
+        const bool mine = go && r.tid == u_tid;              // stragglers of a boundary tile: general code
+        // ---- stage the next tile -----------------------------------------------------------------------------------
+        {
+            const uint64_t i1 = i + 64ull, i2 = i + 128ull;
+            const int4 t_cv = nx_cv;
+            int4 t_av = zero4;
+            if (i1 < wend) t_av = ld32(aux4 + w0 + 64, (uint32_t)l);
+            const uint32_t co = (uint32_t)t_cv.w;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, co + (uint32_t)k);
+            nx_cv = zero4;
+            if (i2 < wend) nx_cv = ld32(core4 + w0 + 128, (uint32_t)l);
+            cur_cv = t_cv; cur_av = t_av;
+        }
+        // ---- sort by shape ------------------------------------------------------------------------------------------
+        const bool simple = mine && shortc && w2.nb <= 2;
+        const bool listed = mine && !simple;
+        k1e_overflow(acc, go && !mine, i);
+        {   // no block at all (clips / insertions only): intergenic, src/Expression.cpp:407-441 with no feature seen
+            const bool none = simple && w2.nb == 0;
+            RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
+        }
+        const uint64_t m1 = __ballot(simple && w2.nb == 1), m2 = __ballot(simple && w2.nb == 2), mm = __ballot(listed);
+        if (simple && w2.nb == 1)
+            S.q1[wave][(h1 + c1 + mask_rank(m1)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)i, flhq);
+        if (simple && w2.nb == 2) {
+            const uint32_t slot = (h2 + c2 + mask_rank(m2)) & (K1E_QCAP - 1);
+            S.q2[wave][slot] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)w2.bs1, w2.len1);
+            S.q2x[wave][slot] = make_uint2((uint32_t)i, flhq);
+        }
+        c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2);
+        if (mm) {
+            const int lead = __ffsll((unsigned long long)mm) - 1;
+            uint32_t base = 0;
+            if (l == lead) base = atomicAdd(&S.T.multi, (uint32_t)__popcll(mm));
+            base = __shfl(base, lead, 64);
+            if (listed) {
+                const uint32_t slot = base + mask_rank(mm);
+                if (slot < multi_cap) my_multi[slot] = make_uint2((uint32_t)i | (hq ? 0x80000000u : 0u), (uint32_t)r.tid);
+                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+            }
+        }
+        if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+        if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
+        // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
+        //      (the queued records belong to it) and at the end of the range ------------------------------------------------
+        const bool leaving = w0 + 64ull >= wend || (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0 + 64ull);
+        const uint32_t thr = leaving ? 1u : 64u;
+        while (c1 >= thr) {
+            const uint32_t take = c1 < 64u ? c1 : 64u;
+            k1e_process<1>(a, p, b, acc, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
+            h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
+        }
+        while (c2 >= thr) {
+            const uint32_t take = c2 < 64u ? c2 : 64u;
+            k1e_process<2>(a, p, b, acc, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
+            h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
+        }
+    }
+    flush_counts();
+    {
+        const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
+        if (l == 0) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
+    }
+    __syncthreads();
+    S.T.flush(acc);
+    if (threadIdx.x == 0) {
+        atomicMax(&acc.rl_stats[0], S.T.rl[0]); atomicMin(&acc.rl_stats[1], S.T.rl[1]); atomicMax(&acc.rl_stats[2], S.T.rl[2]);
+        acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
+        multi_count[blockIdx.x] = S.T.multi < multi_cap ? S.T.multi : multi_cap;
+    }
+}
+
+// ---- the records with longer CIGARs: workgroup k takes the list workgroup k of classify_ei_kernel wrote ---------------
+struct K1mShared { K1eTables T; };
+
+__global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
+classify_multi_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, const uint2 *multi_list, const uint32_t *multi_count, uint32_t multi_cap) {
+    __shared__ K1mShared S;
+    const int l = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n = multi_count[blockIdx.x];
+    if (n == 0) return;
+    const uint32_t chunk_cap = acc.pair_chunk_cap;
+    S.T.init(acc.pair_chunk_count[blockIdx.x]);              // the pairs go behind the ones classify_ei_kernel left in the chunk
+    __syncthreads();
+    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
+    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
+    const uint2 *const list = multi_list + (size_t)blockIdx.x * multi_cap;
+    const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
+    uint32_t sum_blk = 0;
+    for (uint32_t t0 = (uint32_t)wave * 64u; t0 < n; t0 += K1E_WAVES * 64u) {
+        const bool on0 = t0 + (uint32_t)l < n;
+        const uint2 it = list[on0 ? t0 + (uint32_t)l : t0];
+        const uint32_t idx = it.x & 0x7FFFFFFFu; const bool hq = (it.x >> 31) != 0; const int32_t tid = (int32_t)it.y;
+        const int4 cv = ld32(core4, idx), av = ld32(aux4, idx);
+        uint32_t cg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, (uint32_t)cv.w + (uint32_t)k);
+        const ContigInfo ci = a.contig[tid];                  // (tid is inside the annotation's contigs: the record passed :333)
+        const uint32_t fl = (uint32_t)av.z & 0xFFFFu;
+        uint32_t n_cigar = (uint32_t)av.w >> 24;
+        bool ok = true;
+        if (on0 && n_cigar == RSQC_NCIGAR_ESCAPE) {
+            uint32_t lo = 0, hi = b.n_wide;
+            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < idx) lo = m + 1; else hi = m; }
+            if (lo >= b.n_wide || b.wide_index[lo] != idx) ok = false; else n_cigar = b.wide_n_cigar[lo];
+        }
+        // full walk: every block counted, the first FAST_BLOCKS captured
+        CigarWalk cw; Blocks B;
+        cw.ref_len = 0; cw.nblocks = 0; cw.aligned = 0; cw.bad = false;
+#pragma unroll
+        for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
+        const uint32_t nc = (on0 && ok) ? n_cigar : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cigar_op(cg[k], cv.x, cw, B, (uint32_t)k < nc);
+        {
+            const uint32_t *cp = b.cigar + (uint32_t)cv.w;
+            for (uint32_t i = 8; i < nc; ++i) cigar_op(cp[i], cv.x, cw, B);
+        }
+        const bool longc = nc > 4;                            // classify_ei_kernel left legality and the block count of these to this kernel
+        if (longc && cw.bad) atomicExch(acc.error, RSQC_ERR_BAD_CIGAR);
+        const bool on = on0 && ok && !(longc && cw.bad);
+        sum_blk += (on && longc) ? cw.nblocks : 0u;                                   // src/RNASeQC.cpp:360
+        WaveSink cnt;
+        {
+            const bool none = on && cw.nblocks == 0;
+            RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
+        }
+        const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
+        EiOut eo; bool over = false;
+        exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
+        k1e_overflow(acc, on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
+        k1e_commit<FAST_BLOCKS>(acc, S.T, eo, B.len, !(fl & RSQC_FDUP), (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32),
+                                my_pair_gene, my_pair_hash, chunk_cap);
+        if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+    }
+    {
+        const uint32_t s = wave_sum(sum_blk);
+        if (l == 0 && s) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s);
+    }
+    __syncthreads();
+    S.T.flush(acc);
+    if (threadIdx.x == 0) acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
+}
+
+}  // namespace rsqc

@@ -32,8 +32,10 @@ namespace rsqc { __device__ __forceinline__ void k1_mark(int sec); __device__ __
 
 namespace rsqc {
 
-// ------------------------------------------------------------------ wave helpers
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// ------------------------------------------------------------------ wave helpers: rsqc_wave.h
+}  // namespace rsqc
+#include "rsqc_wave.h"
+namespace rsqc {
 
 #ifdef RSQC_K1_PROF
 __device__ unsigned long long g_k1_prof[48];          // [sec] cycles, [16 + sec] marks, [32 + id] / [36 + id] slow-branch events
@@ -59,99 +61,6 @@ extern "C" __attribute__((visibility("default"))) int rsqc_debug_k1_prof(unsigne
     return 0;
 }
 #endif
-
-__device__ __forceinline__ uint32_t mask_rank(uint64_t m) {      // #set bits below this lane
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-template <class T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o, 64); if (l >= o) v += t; }
-    return v;
-}
-
-// One atomic per distinct key in the wave.  Must be called by all 64 lanes (converged).
-template <class F>
-__device__ __forceinline__ void wave_aggregate(bool valid, uint32_t key, uint64_t flagmask, F &&leader) {
-    uint64_t todo = __ballot(valid);
-    const int l = lane_id();
-    while (todo) {
-        const int lead = __ffsll((unsigned long long)todo) - 1;
-        const uint32_t k0 = __shfl(key, lead, 64);
-        const uint64_t same = __ballot(valid && key == k0);
-        if (l == lead) leader(k0, (uint32_t)__popcll(same), (uint32_t)__popcll(same & flagmask));
-        todo &= ~same;
-    }
-}
-
-// Runs of equal keys in lane order.  The input is coordinate-sorted, so records that hit the
-// same exon / gene / coverage slot sit in neighbouring lanes: merging each run into one atomic
-// removes the same-address serialisation on highly expressed genes in O(1) instructions.
-struct Run { bool head; uint32_t count; int end; uint64_t mask; };
-__device__ __forceinline__ Run make_run(bool valid, uint32_t key) {
-    const int l = lane_id();
-    const uint32_t pk = __shfl_up(key, 1, 64);
-    const uint64_t vmask = __ballot(valid);
-    const bool pvalid = l > 0 && ((vmask >> (l - 1)) & 1ull);
-    Run r;
-    r.head = valid && (!pvalid || pk != key);
-    const uint64_t stop = __ballot(r.head) | ~vmask;                 // lanes that end the run before them
-    const uint64_t above = l == 63 ? 0ull : stop & ~((2ull << l) - 1ull);
-    r.end = above ? __ffsll((unsigned long long)above) - 1 : 64;
-    r.count = (uint32_t)(r.end - l);
-    const uint64_t upto = r.end == 64 ? ~0ull : ((1ull << r.end) - 1ull);
-    r.mask = upto & ~((1ull << l) - 1ull);
-    return r;
-}
-// sum of v over the run that starts at this (head) lane
-__device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
-    const int l = lane_id();
-    double sc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(sc, o, 64); if (l >= o) sc += t; }
-    const double at_end = __shfl(sc, r.end - 1, 64);
-    return at_end - (sc - v);
-}
-
-// integer variant: sum of v over the run that starts at this (head) lane
-__device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
-    const uint32_t sc = wave_inclusive_scan_u32(v);
-    const uint32_t at_end = __shfl(sc, r.end - 1, 64);
-    return at_end - (sc - v);
-}
-
-// cov[idx] += sign * (number of lanes of the run) with identical neighbouring slots merged into one atomic.
-// Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
-// then is the run structure built.
-__device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {
-    const uint32_t pidx = __shfl_up(idx, 1, 64);
-    const uint64_t vmask = __ballot(valid);
-    const int l = lane_id();
-    const bool dup = valid && l > 0 && ((vmask >> (l - 1)) & 1ull) && pidx == idx;
-    if (__ballot(dup) == 0ull) {
-        if (valid) atomicAdd(&cov[idx], sign);
-    } else {
-        const Run r = make_run(valid, idx);
-        if (r.head) atomicAdd(&cov[idx], sign * r.count);
-    }
-}
 
 // accumulator used by the general (slow-path) code when it re-walks a CIGAR
 struct DirectAcc {
@@ -185,13 +94,6 @@ __device__ __forceinline__ bool load_record(const DevBatch &b, uint64_t i, uint3
     r.tid = b.seg_tid[seg];
     return ok;
 }
-// last segment whose start <= i (wave-uniform i -> scalar loads)
-__device__ __forceinline__ uint32_t find_segment(const DevBatch &b, uint64_t i) {
-    uint32_t lo = 0, hi = b.n_seg;
-    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (b.seg_start[m] <= i) lo = m; else hi = m; }
-    return lo;
-}
-
 // ------------------------------------------------------------------ K1
 // grid-stride over tiles of RSQC_K1_THREADS records; one record per lane per iteration.
 // Workgroup-local accumulators.  A workgroup streams a short genomic window (a few thousand
@@ -692,6 +594,28 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
         if (s_key[i] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[a.ex_id[s_key[i]]], s_val[i]);
     for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x)
         if (s_ckey[i] != 0xFFFFFFFFu && s_cval[i] != 0u) atomicAdd(&acc.cov_diff[s_ckey[i]], s_cval[i]);
+}
+
+}  // namespace rsqc
+#include "rsqc_k1.h"
+namespace rsqc {
+
+// rank table of the elementary-interval index (rsqc_read.h: EiRank): one thread per word of 64 positions of one contig
+__global__ void __launch_bounds__(256)
+ei_rank_kernel(const EiEntry *ei, uint32_t ei_lo, uint32_t ei_hi, EiRank *rank, uint32_t n_words) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t lo = ei_lo, hi = ei_hi;                      // first entry of the contig with pos >= w * 64
+    while (lo < hi) { const uint32_t m = lo + ((hi - lo) >> 1); if (((uint32_t)ei[m].pos >> 6) < w) lo = m + 1; else hi = m; }
+    EiRank r = {0u, 0u, lo, 0u};
+    for (uint32_t j = lo; j < ei_hi && ((uint32_t)ei[j].pos >> 6) == w; ++j) {
+        const uint32_t bit = (uint32_t)ei[j].pos & 63u;
+        if (bit < 32) r.lo |= 1u << bit; else r.hi |= 1u << (bit - 32);
+    }
+    rank[w] = r;
+}
+void launch_ei_rank(hipStream_t s, const EiEntry *ei, uint32_t ei_lo, uint32_t ei_hi, EiRank *rank, uint32_t n_words) {
+    if (n_words) hipLaunchKernelGGL(ei_rank_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, ei, ei_lo, ei_hi, rank, n_words);
 }
 
 // ------------------------------------------------------------------ KR
@@ -1496,11 +1420,14 @@ void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, siz
     hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_vec);
 }
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                     const DevAccum &acc) {
-    // (diagnostic) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
-    static const unsigned pad = getenv("RSQC_K1_LDS_PAD") ? (unsigned)atoi(getenv("RSQC_K1_LDS_PAD")) : 0u;
+                     const DevAccum &acc, const MultiList &ml) {
     if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
-    else hipLaunchKernelGGL(classify_count_kernel_w4r1, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc);
+    else {
+        // (diagnostic) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
+        static const unsigned pad = getenv("RSQC_K1_LDS_PAD") ? (unsigned)atoi(getenv("RSQC_K1_LDS_PAD")) : 0u;
+        hipLaunchKernelGGL(classify_ei_kernel, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc, ml.list, ml.count, ml.cap);
+        hipLaunchKernelGGL(classify_multi_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc, ml.list, ml.count, ml.cap);
+    }
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {

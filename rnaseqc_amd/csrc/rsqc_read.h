@@ -72,8 +72,34 @@ struct ContigInfo {          // 32 bytes per contig
     uint32_t gb_lo, gb_hi;   // gene breakpoints of the contig
     uint32_t bin_base;       // first entry of the contig in the two bin tables
     uint32_t n_bins;         // bins of 2^bin_shift bases (0 = contig without features)
-    uint32_t pad0, pad1;
+    uint32_t rk_base;        // first word of the contig in the rank table (EiRank)
+    uint32_t rk_words;       // words of 64 positions the contig has there (0 = contig without features)
 };
+
+// ---- elementary intervals (the index of the per-record kernel since round 3) ------------------------------------------
+// The start and end + 1 of every gene and exon row of a contig cut it into ELEMENTARY INTERVALS inside which the set of
+// covering features is constant.  One 32-byte entry per interval carries everything a block needs from the features
+// that cover it: the class bits of the covering genes and exons (per strand class, so that --stranded is a mask) and
+// the (at most two) covering exons as ready-made commit operands -- exon id (= accumulator index), gene | flags,
+// and `cov - start` so that the coverage index of a block is one addition.  An interval covered by more than two exons
+// is marked EIM_DEEP and its records take the general code (classify_slow_kernel).
+//   block [bs, be] (be inclusive, src/Expression.cpp:111, src/GTF.cpp:171-179):
+//     class flags      = OR of the masks of intervals find(bs) .. find(be)
+//     containing exons = refs(find(bs)) that are also refs(find(max(bs, be - 1)))          (src/GTF.cpp:181-186)
+// find(x) = the last breakpoint <= x comes from a bit vector with one bit per position and a running count per 64
+// positions (EiRank): ONE 16-byte load and a popcount, no walk and no dependent second load.  Every contig with
+// features starts with a sentinel interval at position 0 (mask 0, no exons).
+struct EiEntry {
+    int32_t pos;             // first position of the interval
+    uint32_t mask;           // bits 0-5: GeneBreak::mask; bit 6+s: an exon of strand class s covers it; bit 9+s: ... a ribosomal one; EIM_DEEP
+    uint32_t eidA, eidB;     // exon ids of the covering exons (higher row first), EI_NONE = none
+    uint32_t gfA, cdA;       // ExonRow::gf of A (gene | RowFlags << 26); ExonRow::cov - ExonRow::start (mod 2^32)
+    uint32_t gfB, cdB;
+};
+struct EiRank { uint32_t lo, hi; uint32_t rank; uint32_t pad; };   // bits of 64 positions; global index of the first breakpoint at or after the word
+constexpr uint32_t EI_NONE = 0xFFFFFFFFu;
+constexpr uint32_t EIM_DEEP = 1u << 31;
+constexpr int EIM_EXON_SHIFT = 6;
 
 // Tables read only by the --legacy rules (legacy_metrics below): the gene ROWS themselves (the default rules need
 // only the breakpoint masks) and the rank of every row in the reference's one start-sorted list of genes and exons.
@@ -94,6 +120,8 @@ struct DevAnnotation {
     int32_t bin_shift;
     const ExonRow *ex;                 // sorted by (contig, start)
     const int32_t *ex_pmax;            // running max of end, per row (see ExonRow)
+    const EiEntry *ei;                 // elementary intervals, sorted by (contig, pos)
+    const EiRank *ei_rank;             // rank table: ContigInfo::rk_base + (pos >> 6)
     const GeneBreak *gb;               // sorted by (contig, pos)
     const ContigInfo *contig;          // [n_contigs]
     // bin tables: ex_binhi = first exon row whose start >= (bin + 1) << bin_shift;
@@ -163,6 +191,14 @@ struct WaveSink {
 #else
         (void)cond;
 #endif
+    }
+};
+#elif defined(RSQC_WAVE_EMU)
+struct WaveSink {                              // the same on the host's wave emulation (tests/hostemu/wavemu.h)
+    uint32_t vec = 0;
+    template <int C> void add(bool cond) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(cond));
+        if ((int)(threadIdx.x & 63u) == C) vec = n;
     }
 };
 #endif
@@ -488,7 +524,7 @@ RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f
 constexpr int NSLOT = 2 * FAST_BLOCKS;
 constexpr uint32_t CF_INTRAGENIC = 1u, CF_PLUS = 2u, CF_MINUS = 4u, CF_RIBOSOMAL = 8u, CF_EXONIC = 16u;
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(RSQC_WAVE_EMU)
 #define RSQC_ANY_LANE(x) (__ballot(x) != 0ull)
 #else
 #define RSQC_ANY_LANE(x) (x)
@@ -649,6 +685,129 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
             out.n_hit = nlast;
         }
     }
+    ClassFlags f;
+    f.intragenic = (cf & CF_INTRAGENIC) != 0; f.plus = (cf & CF_PLUS) != 0; f.minus = (cf & CF_MINUS) != 0;
+    f.ribosomal = (cf & CF_RIBOSOMAL) != 0; f.exonic = (cf & CF_EXONIC) != 0;
+    class_counts(cnt, p, fl, f, nlast > 0, hq, !over);
+}
+
+// ---- the feature stage on elementary intervals (EiEntry / EiRank above) -----------------------------------------------
+// find(x): index of the last breakpoint <= x on the contig, and whether x itself is one.  x is clamped into the
+// positions the contig's rank words cover (beyond the last breakpoint nothing changes any more).
+struct EiFind { uint32_t j; bool at; };
+RSQC_HD EiFind ei_find(const DevAnnotation &a, const ContigInfo &ci, int32_t x, bool have) {
+    const int32_t top = (int32_t)(ci.rk_words << 6) - 1;
+    const int32_t xc = x < 0 ? 0 : (x > top ? top : x);
+    const EiRank w = ld32(a.ei_rank, have ? ci.rk_base + ((uint32_t)xc >> 6) : 0u);
+    // bits 0..(xc & 63) of the word, moved to the top: their count is the number of breakpoints <= xc inside the word and
+    // the top bit says whether xc is one
+    const uint32_t sh = 63u - ((uint32_t)xc & 63u);
+    const uint64_t t = (((uint64_t)w.hi << 32) | (uint64_t)w.lo) << sh;
+    EiFind f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f.j = w.rank + (uint32_t)__popcll(t) - 1u;
+#else
+    f.j = w.rank + (uint32_t)__builtin_popcountll(t) - 1u;
+#endif
+    f.at = (t >> 63) != 0 && xc == x;
+    return f;
+}
+
+// class flags (CF_*) of a record from the OR of the interval masks its blocks touch
+RSQC_HD uint32_t ei_class_flags(uint32_t mask, int rstrand) {
+    const uint32_t sel = rstrand == RSQC_STRAND_UNKNOWN ? 7u : 1u << rstrand;                  // src/Expression.cpp:331
+    const uint32_t gp = mask & sel, gr = (mask >> 3) & sel, ep = (mask >> EIM_EXON_SHIFT) & sel, er = (mask >> (EIM_EXON_SHIFT + 3)) & sel;
+    return (gp ? CF_INTRAGENIC : 0u) | (((gp | ep) & (1u << RSQC_STRAND_FORWARD)) ? CF_PLUS : 0u) |
+           (((gp | ep) & (1u << RSQC_STRAND_REVERSE)) ? CF_MINUS : 0u) | ((gr | er) ? CF_RIBOSOMAL : 0u) | (ep ? CF_EXONIC : 0u);
+}
+
+// One block against the index.  Returns the OR of the interval masks of [bs, be] (incl. EIM_DEEP of the two intervals
+// the containment test reads) and the block's (at most two) containing exons as commit operands.
+struct EiBlock { uint32_t mask; bool cA, cB; uint32_t eidA, gfA, cidxA, eidB, gfB, cidxB; };
+RSQC_HD void ei_query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, uint32_t len, bool on, int rstrand, EiBlock &o) {
+    const int32_t be = bs + (int32_t)len;
+    const bool have = on && ci.rk_words != 0 && be >= 0;
+    const EiFind fs = ei_find(a, ci, bs, have), fe = ei_find(a, ci, be, have);
+    const uint32_t js = have ? fs.j : 0u, je = have ? fe.j : 0u;
+    const uint32_t j1 = (fe.at && len > 0 && je > js) ? je - 1 : je;      // find(max(bs, be - 1))
+    const EiEntry S = ld32(a.ei, js);
+    const uint32_t m1 = ld32(a.ei, j1).mask, e1A = ld32(a.ei, j1).eidA, e1B = ld32(a.ei, j1).eidB;
+    // intervals js .. je: js, j1 (= je - 1 or je), je and js + 1 are read in one round of independent loads; only a block
+    // across more than three intervals goes back to memory
+    uint32_t mask = S.mask | m1 | ld32(a.ei, je).mask | ld32(a.ei, js < je ? js + 1 : je).mask;
+    if (RSQC_ANY_LANE(have && je > js + 2))
+        for (uint32_t j = js + 2; have && j < je; ++j) mask |= ld32(a.ei, j).mask;
+    // EIM_DEEP matters only where the exon lists are read
+    mask = (mask & ~EIM_DEEP) | ((S.mask | m1) & EIM_DEEP);
+    const bool same = j1 == js;
+    const bool sA = rstrand == RSQC_STRAND_UNKNOWN || rstrand == (int)((S.gfA >> ROW_FLAG_SHIFT) & RSQC_FF_STRAND_MASK);
+    const bool sB = rstrand == RSQC_STRAND_UNKNOWN || rstrand == (int)((S.gfB >> ROW_FLAG_SHIFT) & RSQC_FF_STRAND_MASK);
+    o.mask = have ? mask : 0u;
+    o.cA = have && S.eidA != EI_NONE && sA && (same || S.eidA == e1A || S.eidA == e1B);
+    o.cB = have && S.eidB != EI_NONE && sB && (same || S.eidB == e1A || S.eidB == e1B);
+    o.eidA = S.eidA; o.gfA = S.gfA; o.cidxA = S.cdA + (uint32_t)bs;
+    o.eidB = S.eidB; o.gfB = S.gfB; o.cidxB = S.cdB + (uint32_t)bs;
+}
+
+// exonAlignmentMetrics (src/Expression.cpp:308-458) for a record of NB <= FAST_BLOCKS blocks, all lanes of a wave
+// running the same NB (the per-record kernel sorts records by block count first).  Same contract as exon_metrics_fast:
+// slot 2b + j commits block b to exon id `eid[2b + j]` at coverage index `cidx[2b + j]` when bit 2b + j of cmask is set;
+// `overflow` hands the record to the general code (more than two exons on an interval, more than FAST_SET genes).
+struct EiOut {
+    int n_hit; uint32_t hit[FAST_SET];
+    uint32_t cmask;
+    uint32_t eid[NSLOT], cidx[NSLOT];
+};
+// `nbv` = the record's own block count (1 .. NB) where a wave mixes records of different counts (the kernel for long CIGARs).
+template <int NB, class Sink>
+RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl, const int32_t (&bs)[NB],
+                             const uint32_t (&len)[NB], bool hq, EiOut &out, bool &overflow, Sink &cnt, bool lane_on = true,
+                             uint32_t nbv = (uint32_t)NB) {
+    static_assert(NB >= 1 && NB <= FAST_BLOCKS, "blocks per record on the fast path");
+    const int rstrand = read_strand_of(p, fl);
+    uint32_t mask = 0, con = 0, ma = 0, mb = 0;
+    uint32_t la = 0, lb = 0; bool va = false, vb = false, ga = false, gb = false;
+    uint32_t aligned = 0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) { out.eid[k] = 0; out.cidx[k] = 0; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool live = (uint32_t)b < nbv;
+        EiBlock q;
+        ei_query_block(a, ci, bs[b], len[b], lane_on && live, rstrand, q);
+        mask |= q.mask;
+        aligned += live ? len[b] : 0u;
+        const uint32_t g0 = q.gfA & ROW_GENE_MASK, g1 = q.gfB & ROW_GENE_MASK;
+        // containing exons in slot order: A first; when only B contains the block it takes slot 2b
+        const bool c0 = q.cA || q.cB, c1 = q.cA && q.cB;
+        const uint32_t gX = q.cA ? g0 : g1, gfX = q.cA ? q.gfA : q.gfB;
+        out.eid[2 * b] = q.cA ? q.eidA : q.eidB; out.cidx[2 * b] = q.cA ? q.cidxA : q.cidxB;
+        out.eid[2 * b + 1] = q.eidB; out.cidx[2 * b + 1] = q.cidxB;
+        con |= (c0 ? 1u : 0u) << (2 * b) | (c1 ? 1u : 0u) << (2 * b + 1);
+        if (b == 0) {                                                      // genes.front(), :363-367
+            la = gX; va = c0; ga = c0 && ((gfX >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+            lb = g1; vb = c1 && g1 != gX; gb = vb && ((q.gfB >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+            ma = (c0 ? 1u : 0u) | ((c1 && g1 == gX) ? 2u : 0u); mb = vb ? 2u : 0u;
+        } else {                                                           // set_intersection, :368-374
+            const bool a_in = (c0 && la == gX) || (c1 && la == g1), b_in = (c0 && lb == gX) || (c1 && lb == g1);
+            va = live ? (va && a_in) : va; vb = live ? (vb && b_in) : vb;
+            ma |= ((c0 && la == gX) ? 1u : 0u) << (2 * b) | ((c1 && la == g1) ? 1u : 0u) << (2 * b + 1);
+            mb |= ((c0 && lb == gX) ? 1u : 0u) << (2 * b) | ((c1 && lb == g1) ? 1u : 0u) << (2 * b + 1);
+        }
+    }
+    const bool over = (mask & EIM_DEEP) != 0 || !lane_on;
+    overflow = over;
+    ga = ga && va; gb = gb && vb;
+    const int nlast = (va ? 1 : 0) + (vb ? 1 : 0);
+    const bool nonglobin = !over && !(ga || gb);                                               // :363,395-404
+    RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, nonglobin);
+    RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, nonglobin && (fl & RSQC_FDUP) != 0);
+    out.n_hit = 0; out.cmask = 0;
+    if (hq && nlast > 0 && !over) {                                                            // :377-392
+        out.cmask = con & ((va ? ma : 0u) | (vb ? mb : 0u));
+        if (aligned > 0) { out.hit[0] = va ? la : lb; out.hit[1] = lb; out.n_hit = nlast; }
+    }
+    const uint32_t cf = ei_class_flags(mask, rstrand);
     ClassFlags f;
     f.intragenic = (cf & CF_INTRAGENIC) != 0; f.plus = (cf & CF_PLUS) != 0; f.minus = (cf & CF_MINUS) != 0;
     f.ribosomal = (cf & CF_RIBOSOMAL) != 0; f.exonic = (cf & CF_EXONIC) != 0;

@@ -1,0 +1,111 @@
+// rsqc_wave.h -- 64-lane wavefront helpers shared by the kernels (rsqc_kernels.hip, rsqc_k1.h).  Written against the
+// HIP wave intrinsics (__ballot, __shfl*, mbcnt); tests/hostemu/k1_emu.cpp compiles the same source for the host on top
+// of a 64-fiber wave emulation that provides those intrinsics.
+#pragma once
+
+namespace rsqc {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ uint32_t mask_rank(uint64_t m) {      // #set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o, 64); if (l >= o) v += t; }
+    return v;
+}
+
+// One atomic per distinct key in the wave.  Must be called by all 64 lanes (converged).
+template <class F>
+__device__ __forceinline__ void wave_aggregate(bool valid, uint32_t key, uint64_t flagmask, F &&leader) {
+    uint64_t todo = __ballot(valid);
+    const int l = lane_id();
+    while (todo) {
+        const int lead = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(key, lead, 64);
+        const uint64_t same = __ballot(valid && key == k0);
+        if (l == lead) leader(k0, (uint32_t)__popcll(same), (uint32_t)__popcll(same & flagmask));
+        todo &= ~same;
+    }
+}
+
+// Runs of equal keys in lane order.  The input is coordinate-sorted, so records that hit the
+// same exon / gene / coverage slot sit in neighbouring lanes: merging each run into one atomic
+// removes the same-address serialisation on highly expressed genes in O(1) instructions.
+struct Run { bool head; uint32_t count; int end; uint64_t mask; };
+__device__ __forceinline__ Run make_run(bool valid, uint32_t key) {
+    const int l = lane_id();
+    const uint32_t pk = __shfl_up(key, 1, 64);
+    const uint64_t vmask = __ballot(valid);
+    const bool pvalid = l > 0 && ((vmask >> (l - 1)) & 1ull);
+    Run r;
+    r.head = valid && (!pvalid || pk != key);
+    const uint64_t stop = __ballot(r.head) | ~vmask;                 // lanes that end the run before them
+    const uint64_t above = l == 63 ? 0ull : stop & ~((2ull << l) - 1ull);
+    r.end = above ? __ffsll((unsigned long long)above) - 1 : 64;
+    r.count = (uint32_t)(r.end - l);
+    const uint64_t upto = r.end == 64 ? ~0ull : ((1ull << r.end) - 1ull);
+    r.mask = upto & ~((1ull << l) - 1ull);
+    return r;
+}
+// sum of v over the run that starts at this (head) lane
+__device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
+    const int l = lane_id();
+    double sc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(sc, o, 64); if (l >= o) sc += t; }
+    const double at_end = __shfl(sc, r.end - 1, 64);
+    return at_end - (sc - v);
+}
+
+// integer variant: sum of v over the run that starts at this (head) lane
+__device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
+    const uint32_t sc = wave_inclusive_scan_u32(v);
+    const uint32_t at_end = __shfl(sc, r.end - 1, 64);
+    return at_end - (sc - v);
+}
+
+// cov[idx] += sign * (number of lanes of the run) with identical neighbouring slots merged into one atomic.
+// Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
+// then is the run structure built.
+__device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {
+    const uint32_t pidx = __shfl_up(idx, 1, 64);
+    const uint64_t vmask = __ballot(valid);
+    const int l = lane_id();
+    const bool dup = valid && l > 0 && ((vmask >> (l - 1)) & 1ull) && pidx == idx;
+    if (__ballot(dup) == 0ull) {
+        if (valid) atomicAdd(&cov[idx], sign);
+    } else {
+        const Run r = make_run(valid, idx);
+        if (r.head) atomicAdd(&cov[idx], sign * r.count);
+    }
+}
+
+// last segment whose start <= i (wave-uniform i -> scalar loads)
+__device__ __forceinline__ uint32_t find_segment(const DevBatch &b, uint64_t i) {
+    uint32_t lo = 0, hi = b.n_seg;
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (b.seg_start[m] <= i) lo = m; else hi = m; }
+    return lo;
+}
+
+
+}  // namespace rsqc

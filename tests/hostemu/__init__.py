@@ -24,8 +24,10 @@ class Out:
     pass
 
 
-def run(params, ann, batch):
+def run(params, ann, batch, mode=1, want_cov=False):
+    """mode 1: the elementary-interval feature stage (what the per-record kernel runs), 0: the row-table one."""
     lib = C.CDLL(build())
+    lib.hostemu_set_mode(int(mode))
     a, b = ann.to_struct(), batch.to_struct()
     o = Out()
     G, E = ann.n_genes_listed, ann.n_exons
@@ -33,11 +35,53 @@ def run(params, ann, batch):
     o.gene_reads = np.zeros(G, np.uint64); o.gene_unique = np.zeros(G, np.uint64); o.gene_fragments = np.zeros(G, np.uint64)
     o.exon_reads = np.zeros(E, np.float64)
     rl, nov = C.c_int32(), C.c_uint64()
+    o.cov = None
+    if want_cov:
+        total = int(sum(int(ann.exon_row_end[i]) - int(ann.exon_row_start[i]) + 1 for i in range(E))) + ann.n_genes + 8
+        o.cov = np.zeros(total, np.uint32)
     rc = lib.hostemu_run(C.byref(params), C.byref(a), C.byref(b), abi.ptr(o.counters), abi.ptr(o.gene_reads),
-                         abi.ptr(o.gene_unique), abi.ptr(o.gene_fragments), abi.ptr(o.exon_reads), C.byref(rl), None,
-                         C.byref(nov))
+                         abi.ptr(o.gene_unique), abi.ptr(o.gene_fragments), abi.ptr(o.exon_reads), C.byref(rl),
+                         abi.ptr(o.cov) if want_cov else None, C.byref(nov))
     if rc:
         raise RuntimeError("hostemu rc=%d" % rc)
     o.read_length = rl.value
     o.n_overflow = nov.value
+    return o
+
+
+_K1SO = os.path.join(_HERE, "libk1emu.so")
+
+
+def build_k1():
+    csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
+    srcs = [os.path.join(_HERE, "k1_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
+           [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_wave.h", "rsqc_device.h")] + \
+           [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
+    if not os.path.exists(_K1SO) or any(os.path.getmtime(_K1SO) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
+                               "-Wno-unused-variable", srcs[0], "-o", _K1SO])
+    return _K1SO
+
+
+def run_k1(params, ann, batch, grid=2, want_cov=False):
+    """The per-record KERNELS (rsqc_k1.h) on the 64-lane fiber emulation of wavemu.h, `grid` workgroups of 256 lanes."""
+    lib = C.CDLL(build_k1())
+    a, b = ann.to_struct(), batch.to_struct()
+    o = Out()
+    G, E = ann.n_genes_listed, ann.n_exons
+    o.counters = np.zeros(abi.N_COUNTERS, np.uint64)
+    o.gene_reads = np.zeros(G, np.uint64); o.gene_unique = np.zeros(G, np.uint64); o.gene_fragments = np.zeros(G, np.uint64)
+    o.exon_reads = np.zeros(E, np.float64)
+    rl = C.c_int32(); stats = np.zeros(4, np.uint64)
+    o.cov = None
+    if want_cov:
+        total = int(sum(int(ann.exon_row_end[i]) - int(ann.exon_row_start[i]) + 1 for i in range(E))) + ann.n_genes + 8
+        o.cov = np.zeros(total, np.uint32)
+    rc = lib.k1emu_run(C.byref(params), C.byref(a), C.byref(b), C.c_int(grid), abi.ptr(o.counters), abi.ptr(o.gene_reads),
+                       abi.ptr(o.gene_unique), abi.ptr(o.gene_fragments), abi.ptr(o.exon_reads), C.byref(rl),
+                       abi.ptr(o.cov) if want_cov else None, abi.ptr(stats))
+    if rc:
+        raise RuntimeError("k1emu rc=%d" % rc)
+    o.read_length = rl.value
+    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]); o.n_pairs = int(stats[2])
     return o

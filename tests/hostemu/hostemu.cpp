@@ -44,6 +44,18 @@ void apply(Acc &acc, const DevAnnotation &d, const FeatureOut<K, NST> &fo, const
 }
 }  // namespace
 
+// 0: the row-table feature stage (exon_metrics_fast), 1: the elementary-interval one (exon_metrics_ei) for records of
+// 1-4 blocks -- what the per-record kernel runs since round 3
+static int g_mode = 1;
+extern "C" __attribute__((visibility("default"))) void hostemu_set_mode(int m) { g_mode = m; }
+
+template <int NB>
+static void run_ei(const DevAnnotation &d, const DevParams &dp, const Record &r, const Blocks &B, bool hq, EiOut &eo, bool &over, BitSink &sink) {
+    int32_t bs[NB]; uint32_t len[NB];
+    for (int k = 0; k < NB; ++k) { bs[k] = B.bs[k]; len[k] = B.len[k]; }
+    exon_metrics_ei<NB, BitSink>(d, dp, d.contig[r.tid], r.flag, bs, len, hq, eo, over, sink);
+}
+
 extern "C" __attribute__((visibility("default")))
 int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b,
                 uint64_t *counters /*N_COUNTERS*/, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag,
@@ -62,6 +74,10 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     if (hx.ex_pmax.empty()) hx.ex_pmax.push_back(0);
     d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.ex_pmax = hx.ex_pmax.data();
     d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
+    std::vector<EiRank> rank;
+    hx.build_rank(rank);
+    d.ei = hx.ei.data(); d.ei_rank = rank.data();
+    std::vector<double> exon_ids((size_t)a->n_exons, 0.0);       // by exon id (the elementary-interval stage commits by id)
     DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u,
                  p->legacy ? 1 : 0};
     if (hx.gr_rows.empty()) hx.gr_rows.push_back(GeneRow{0, 0, 0, 0});
@@ -96,6 +112,29 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
             legacy_metrics<MID_SET>(d, dp, r, hq, acc, lo);
             bits |= lo.bits;
             for (int k = 0; k < lo.n_hit; ++k) acc.gene_hit(lo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
+        } else if (go && g_mode == 1 && B.nb >= 1 && B.nb <= (uint32_t)FAST_BLOCKS) {
+            bool over = false;
+            EiOut eo; BitSink fsink;
+            if (B.nb == 1) run_ei<1>(d, dp, r, B, hq, eo, over, fsink);
+            else if (B.nb == 2) run_ei<2>(d, dp, r, B, hq, eo, over, fsink);
+            else if (B.nb == 3) run_ei<3>(d, dp, r, B, hq, eo, over, fsink);
+            else run_ei<4>(d, dp, r, B, hq, eo, over, fsink);
+            if (!over) {
+                bits |= fsink.bits;
+                for (int k = 0; k < NSLOT; ++k) {
+                    if (!((eo.cmask >> k) & 1u)) continue;
+                    const uint32_t len = B.len[k >> 1];
+                    if (len > 0) exon_ids[eo.eid[k]] += (double)len / (double)aligned;
+                    acc.cov_range(eo.cidx[k], len);
+                }
+                for (int k = 0; k < eo.n_hit; ++k) acc.gene_hit(eo.hit[k], !(r.flag & RSQC_FDUP), r.qhash);
+            } else {
+                ++*n_overflow;
+                FeatureOut<SLOW_SET, SLOW_STAGE> so;
+                exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, acc, so, over);
+                if (over) return RSQC_ERR_CAPACITY;
+                bits |= so.bits; apply(acc, d, so, r, aligned);
+            }
         } else if (go) {
             bool over = false;
             FastOut fo;
@@ -127,7 +166,7 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
         if (rc2.rl_eligible && rc2.rl_span > rl) rl = (uint32_t)rc2.rl_lqseq;
     }
     for (int g = 0; g < a->n_genes_listed; ++g) { gene_reads[g] = reads[(size_t)g]; gene_unique[g] = unique[(size_t)g]; gene_frag[g] = names[(size_t)g].size(); }
-    for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e];
+    for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e] + exon_ids[a->exon_row_id[e]];
     *read_length = (int32_t)rl;
     if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
     return 0;

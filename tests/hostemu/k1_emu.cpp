@@ -1,0 +1,192 @@
+// k1_emu.cpp -- TEST HARNESS ONLY (never loaded by the product).
+//
+// The per-record KERNELS themselves -- rnaseqc_amd/csrc/rsqc_k1.h (classify_ei_kernel, classify_multi_kernel) with the
+// wave helpers of rsqc_wave.h, unmodified -- compiled for the host on top of the 64-lane fiber emulation of wavemu.h:
+// per-wave LDS queues, ballot / mbcnt compaction, workgroup LDS tables, pair chunks, the list of long-CIGAR records, the
+// overflow list.  hostemu.cpp covers the per-record functions one record at a time; this covers what the wavefronts do
+// with them.  The records on the overflow list go through the general per-record code here (the GPU runs
+// classify_slow_kernel on them).
+#include "wavemu.h"
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../rnaseqc_amd/csrc/rsqc_read.h"
+#include "../../rnaseqc_amd/csrc/rsqc_device.h"
+#include "../../rnaseqc_amd/csrc/rsqc_index.h"
+#include "../../rnaseqc_amd/csrc/rsqc_wave.h"
+#include "../../rnaseqc_amd/csrc/rsqc_k1.h"
+
+using namespace rsqc;
+
+namespace {
+struct SlowAccH {
+    std::vector<uint64_t> *reads, *unique;
+    std::vector<double> *exon_rows;
+    std::vector<uint32_t> *cov;
+    std::vector<std::set<uint64_t>> *names;
+    void gene_hit(uint32_t g, bool nd, uint64_t qh) { (*reads)[g]++; if (nd) (*unique)[g]++; (*names)[g].insert(qh); }
+    void exon_add(uint32_t row, double f) { (*exon_rows)[row] += f; }
+    void cov_range(uint32_t cidx, uint32_t len) { if (!len) return; (*cov)[cidx] += 1u; (*cov)[cidx + len] -= 1u; }
+};
+}  // namespace
+
+// returns 0, an RSQC_ERR_* code, or 1000 + k for a failed internal check k
+extern "C" __attribute__((visibility("default")))
+int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, int grid,
+              uint64_t *counters, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag, double *exon_reads /*by exon id*/,
+              int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/, uint64_t *stats /*[4]: overflow, listed, pairs, tiles processed*/) {
+    HostIndex hx; std::string err;
+    int rc = hx.build(a, nullptr, err);
+    if (rc) return rc;
+    DevAnnotation d{};
+    d.n_ref = a->n_ref; d.n_contigs = a->n_contigs; d.n_genes = a->n_genes; d.n_listed = a->n_genes_listed; d.n_exons = a->n_exons;
+    d.bin_shift = HostIndex::kBinShift;
+    d.contig = hx.contig.data();
+    if (hx.ex_rows.empty()) hx.ex_rows.push_back(ExonRow{0, 0, 0, 0});
+    if (hx.gb.empty()) hx.gb.push_back(GeneBreak{0, 0});
+    if (hx.ex_pmax.empty()) hx.ex_pmax.push_back(0);
+    d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.ex_pmax = hx.ex_pmax.data();
+    d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
+    std::vector<EiRank> rank; hx.build_rank(rank);
+    d.ei = hx.ei.data(); d.ei_rank = rank.data();
+    std::vector<uint32_t> ex_id(a->exon_row_id, a->exon_row_id + a->n_exons); if (ex_id.empty()) ex_id.push_back(0);
+    d.ex_id = ex_id.data();
+    std::vector<uint32_t> zero_range((size_t)a->n_contigs + 1, 0);
+    d.bed_range = zero_range.data(); d.have_bed = 0;
+    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u, 0};
+
+    // the batch with the slack the device buffers carry (kernels read a few entries past the end with ignored loads)
+    const uint64_t n = b->n;
+    std::vector<rsqc_rec_core> core((size_t)n + 2); std::vector<rsqc_rec_aux> aux((size_t)n + 2);
+    std::vector<uint32_t> cigar((size_t)b->n_cigar_total + 8, 0u);
+    if (n) { memcpy(core.data(), b->core, (size_t)n * sizeof(rsqc_rec_core)); memcpy(aux.data(), b->aux, (size_t)n * sizeof(rsqc_rec_aux)); }
+    if (b->n_cigar_total) memcpy(cigar.data(), b->cigar, (size_t)b->n_cigar_total * 4);
+    DevBatch db{};
+    db.n = n; db.record_base = b->file_index_base; db.core = core.data(); db.aux = aux.data(); db.cigar = cigar.data();
+    db.n_seg = b->n_seg; db.seg_tid = b->seg_tid; db.seg_start = b->seg_start;
+    db.n_wide = b->n_wide; db.wide_index = b->wide_index; db.wide_nm = b->wide_nm; db.wide_l_qseq = b->wide_l_qseq; db.wide_n_cigar = b->wide_n_cigar;
+
+    const size_t G = (size_t)a->n_genes, E = (size_t)a->n_exons;
+    std::vector<unsigned long long> u64(3 * G + RSQC_N_COUNTERS + 1, 0ull);
+    std::vector<double> exon_acc(E + 1, 0.0);
+    std::vector<uint32_t> cov((size_t)hx.cov_entries + 64, 0u);
+    const uint64_t total_waves = (uint64_t)grid * K1E_WAVES;
+    const uint64_t per_wave = (((n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
+    const uint32_t chunk_cap = (uint32_t)(per_wave * K1E_WAVES * FAST_SET), multi_cap = (uint32_t)(per_wave * K1E_WAVES);
+    const uint32_t slow_cap = 1u << 16;
+    std::vector<uint32_t> pair_gene((size_t)chunk_cap * grid + slow_cap + 8); std::vector<uint64_t> pair_hash(pair_gene.size());
+    std::vector<uint32_t> chunk_count((size_t)grid + 2, 0xDEADu);
+    std::vector<uint32_t> ovf_count(4, 0u); std::vector<uint64_t> ovf_index(1u << 20);
+    std::vector<uint32_t> tile_span((size_t)((n + 63) / 64) + 64 * (size_t)total_waves + 64, 0xABCDu);
+    std::vector<uint32_t> rl_stats = {0u, 0xFFFFFFFFu, 0u};
+    int32_t rl_state = 0; int error = 0;
+    DevAccum acc{};
+    acc.gene_reads = u64.data(); acc.gene_unique = acc.gene_reads + G; acc.gene_frag = acc.gene_unique + G; acc.counters = acc.gene_frag + G;
+    acc.exon_acc = exon_acc.data(); acc.cov_diff = cov.data();
+    acc.pair_gene = pair_gene.data(); acc.pair_hash = (uint64_t *)pair_hash.data();
+    acc.pair_chunk_cap = chunk_cap; acc.pair_chunk_count = chunk_count.data();
+    acc.pair_slow_base = chunk_cap * (uint32_t)grid; acc.pair_slow_cap = slow_cap; acc.pair_slow_count = chunk_count.data() + grid;
+    acc.ovf_count = ovf_count.data(); acc.ovf_index = (uint64_t *)ovf_index.data(); acc.ovf_cap = (uint32_t)ovf_index.size();
+    acc.tile_span = tile_span.data();
+    acc.rl_stats = rl_stats.data(); acc.read_length = &rl_state; acc.error = &error;
+    std::vector<uint2> multi((size_t)multi_cap * grid + 8); std::vector<uint32_t> multi_count((size_t)grid + 1, 0xDEADu);
+
+    wavemu::grid_dim().x = (uint32_t)grid;
+    for (int k = 0; k < grid; ++k) {
+        wavemu::block_idx().x = (uint32_t)k;
+        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel(d, dp, db, acc, multi.data(), multi_count.data(), multi_cap); });
+    }
+    uint64_t listed = 0;
+    for (int k = 0; k < grid; ++k) {
+        if (multi_count[(size_t)k] > multi_cap) return 1001;
+        listed += multi_count[(size_t)k];
+        wavemu::block_idx().x = (uint32_t)k;
+        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_multi_kernel(d, dp, db, acc, multi.data(), multi_count.data(), multi_cap); });
+    }
+    if (error) return error;
+
+    // ---- the overflow list through the general per-record code ------------------------------------------------------
+    std::vector<uint64_t> reads(G, 0), unique(G, 0);
+    std::vector<double> exon_rows(E, 0.0);
+    std::vector<std::set<uint64_t>> names(G);
+    SlowAccH sacc{&reads, &unique, &exon_rows, &cov, &names};
+    std::vector<int32_t> tid_of((size_t)n, -1);
+    for (uint32_t s = 0; s < b->n_seg; ++s) for (uint64_t i = b->seg_start[s]; i < b->seg_start[s + 1]; ++i) tid_of[(size_t)i] = b->seg_tid[s];
+    auto load = [&](uint64_t i, Record &r) -> bool {
+        const rsqc_rec_core &co = b->core[i]; const rsqc_rec_aux &au = b->aux[i];
+        r.tid = tid_of[(size_t)i]; r.pos = co.pos; r.mpos = co.mpos; r.isize = co.isize; r.flag = au.flag;
+        r.mapq = au.mapq; r.tagbits = au.tagbits; r.l_qseq = au.l_qseq; r.nm = au.nm; r.n_cigar = au.n_cigar;
+        if (au.l_qseq == RSQC_LQSEQ_ESCAPE || au.nm == RSQC_NM_ESCAPE || au.n_cigar == RSQC_NCIGAR_ESCAPE) {
+            uint32_t w = 0;
+            while (w < b->n_wide && b->wide_index[w] < i) ++w;
+            if (w >= b->n_wide || b->wide_index[w] != i) return false;
+            r.l_qseq = b->wide_l_qseq[w]; r.nm = b->wide_nm[w]; r.n_cigar = b->wide_n_cigar[w];
+        }
+        r.cigar = cigar.data() + co.cigar_off; r.qhash = au.qhash;
+        return true;
+    };
+    std::set<uint64_t> seen_ovf;
+    for (uint32_t k = 0; k < ovf_count[0]; ++k) {
+        const uint64_t i = ovf_index[k];
+        if (i >= n || !seen_ovf.insert(i).second) return 1002;            // every record at most once
+        Record r;
+        if (!load(i, r)) return RSQC_ERR_ARG;
+        RecordCounters rc2; bool hq; uint32_t aligned; Blocks B;
+        if (!gate_cascade(d, dp, r, rc2, hq, aligned, B)) return 1003;    // only records that reach the feature stage are listed
+        bool over = false;
+        FeatureOut<SLOW_SET, SLOW_STAGE> so;
+        exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, sacc, so, over);
+        if (over) return RSQC_ERR_CAPACITY;
+        for (int k2 = 0; k2 < SLOW_STAGE; ++k2) {
+            if (!((so.cmask >> k2) & 1u)) continue;
+            const Commit &c = so.commit[k2];
+            if (c.len > 0) sacc.exon_add(c.row, (double)c.len / (double)aligned);
+            sacc.cov_range(c.cidx, c.len);
+        }
+        for (int k2 = 0; k2 < so.n_hit; ++k2) sacc.gene_hit(so.hit[k2], !(r.flag & RSQC_FDUP), r.qhash);
+        for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((so.bits >> c) & 1ull) acc.counters[c]++;
+    }
+    // ---- pairs -> distinct names per gene ------------------------------------------------------------------------------
+    uint64_t n_pairs = 0;
+    for (int k = 0; k < grid; ++k) {
+        const uint32_t cnt = chunk_count[(size_t)k];
+        if (cnt > chunk_cap) return 1004;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t g = pair_gene[(size_t)k * chunk_cap + j];
+            if (g >= G) return 1005;
+            names[g].insert(pair_hash[(size_t)k * chunk_cap + j]); ++n_pairs;
+        }
+    }
+    // ---- Read-Length inputs: tile maxima and batch extremes against the per-record values; the state machine itself ---
+    uint32_t rl = 0, smax = 0, lmin = 0xFFFFFFFFu, lmax = 0;
+    {
+        std::vector<uint32_t> want((size_t)((n + 63) / 64), 0u);
+        for (uint64_t i = 0; i < n; ++i) {
+            Record r;
+            if (!load(i, r)) return RSQC_ERR_ARG;
+            RecordCounters rc2; bool hq; uint32_t aligned; Blocks B;
+            gate_cascade(d, dp, r, rc2, hq, aligned, B);
+            if (rc2.error) return rc2.error;
+            if (rc2.rl_eligible) {
+                want[(size_t)(i >> 6)] = std::max(want[(size_t)(i >> 6)], rc2.rl_span);
+                smax = std::max(smax, rc2.rl_span); lmin = std::min(lmin, (uint32_t)rc2.rl_lqseq); lmax = std::max(lmax, (uint32_t)rc2.rl_lqseq);
+                if (rc2.rl_span > rl) rl = (uint32_t)rc2.rl_lqseq;
+            }
+        }
+        // per-wave ranges are multiples of 64 records, so a wave's tile t is batch tile (wbeg / 64 + t)
+        for (size_t t = 0; t < want.size(); ++t) if (tile_span[t] != want[t]) return 1006;
+        if (rl_stats[0] != smax || rl_stats[1] != lmin || rl_stats[2] != lmax) return 1007;
+    }
+    for (size_t g = 0; g < (size_t)a->n_genes_listed; ++g) {
+        gene_reads[g] = acc.gene_reads[g] + reads[g]; gene_unique[g] = acc.gene_unique[g] + unique[g]; gene_frag[g] = names[g].size();
+    }
+    for (int c = 0; c < RSQC_N_COUNTERS; ++c) counters[c] = acc.counters[c];
+    for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e] + exon_acc[a->exon_row_id[e]];
+    *read_length = (int32_t)rl;
+    if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
+    stats[0] = ovf_count[0]; stats[1] = listed; stats[2] = n_pairs; stats[3] = 0;
+    return 0;
+}

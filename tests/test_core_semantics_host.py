@@ -73,3 +73,19 @@ def test_hostile_records_under_sanitizers():
     r = subprocess.run([sys.executable, "-m", "tests.hostemu.core_fuzz", "3", "7"], cwd=root, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and "core_fuzz: 9 runs" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_interval_index_equals_row_index(oracle_lib, seed):
+    """The two feature stages of the core -- elementary intervals + rank bit vector (exon_metrics_ei, what the per-record
+    kernel runs) and the start-sorted row table (exon_metrics_fast, still the general code's index) -- on hostile
+    annotations: every output incl. the per-base coverage difference array is identical, and equals the oracle's."""
+    from tests.test_legacy_rules import hostile_case, stacked_case
+    for ann, batch in (hostile_case(100 + seed), stacked_case(200 + seed)):
+        for kw in (dict(), dict(stranded=abi.STRAND_FORWARD), dict(stranded=abi.STRAND_REVERSE, unpaired=1)):
+            p = abi.default_params(mapq_threshold=4, **kw)
+            a0 = hostemu.run(p, ann, batch, mode=0, want_cov=True)
+            a1 = hostemu.run(p, ann, batch, mode=1, want_cov=True)
+            _compare(a1, a0)
+            np.testing.assert_array_equal(a1.cov, a0.cov)
+            _compare(a1, oracle_lib.run_oracle(p, ann, [batch]))

@@ -1,0 +1,136 @@
+"""The per-record KERNELS (rnaseqc_amd/csrc/rsqc_k1.h: classify_ei_kernel + classify_multi_kernel, with rsqc_wave.h),
+unmodified, on a 64-lane SIMT emulation for the host (tests/hostemu/wavemu.h: one fiber per lane; ballot / shuffle / mbcnt /
+LDS and memory atomics / __syncthreads on a cooperative scheduler) against the oracle: per-wave LDS queues sorted by block
+count, the feature stage on full and on drained tiles, workgroup tables, pair chunks, the long-CIGAR list, the overflow
+list, Read-Length inputs per tile.  The GPU tests run the same source on the device."""
+import numpy as np
+import pytest
+
+from rnaseqc_amd import abi, synth
+from rnaseqc_amd.model import Annotation, Batch
+from tests import cases, hostemu
+from tests.test_legacy_rules import hostile_case, stacked_case
+
+
+def _compare(o, r, cov=None):
+    for i, n in enumerate(abi.COUNTER_NAMES):
+        assert int(o.counters[i]) == int(r.counters[i]), n
+    np.testing.assert_array_equal(o.gene_reads, r.gene_reads)
+    np.testing.assert_array_equal(o.gene_unique, r.gene_unique)
+    np.testing.assert_array_equal(o.gene_fragments, r.gene_fragments)
+    np.testing.assert_allclose(o.exon_reads, r.exon_reads, rtol=0, atol=1e-9)
+    assert o.read_length == r.read_length
+    if cov is not None:
+        np.testing.assert_array_equal(o.cov, cov)
+
+
+def test_quirk_case(oracle_lib):
+    ann, batch = cases.quirk_case()
+    p = abi.default_params()
+    for grid in (1, 3):
+        _compare(hostemu.run_k1(p, ann, batch, grid=grid), oracle_lib.run_oracle(p, ann, [batch]))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stranded=abi.STRAND_REVERSE), dict(stranded=abi.STRAND_FORWARD, unpaired=1),
+                                dict(unpaired=1, mapq_threshold=3, n_filter_tags=1, exclude_chimeric=1),
+                                dict(base_mismatch=1, chimeric_distance=100)])
+def test_synthetic_vs_oracle(oracle_lib, kw):
+    """Three contigs (one without features), ~12 k records: several tiles per wave, queues that fill and drain, contig
+    boundaries inside tiles, the records of the last contig."""
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 3_000_000, 300), ("chrB", 1_500_000, 150), ("chrC", 400_000, 0)])
+    batch = synth.make_reads(ann, 6000, seed=4, dup_frac=0.1, chimeric_tag_frac=0.01, filter_tag_frac=0.02,
+                             contig_lengths=np.array([3_000_000, 1_500_000, 400_000]))
+    p = abi.default_params(**kw)
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    ref = hostemu.run(p, ann, batch, mode=1, want_cov=True)
+    for grid in (1, 2, 5):
+        o = hostemu.run_k1(p, ann, batch, grid=grid, want_cov=True)
+        _compare(o, r, ref.cov)
+        assert o.n_listed > 200 and o.n_pairs > 1000
+    assert r.gene_reads.sum() > 1000
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hostile_annotations(oracle_lib, seed):
+    """Overlapping / nested genes and exons (intervals covered by more than two exons -> overflow list), 1-4 blocks per record,
+    zero-length operations, long CIGARs, records at position 0."""
+    for ann, batch in (hostile_case(400 + seed), stacked_case(500 + seed)):
+        for kw in (dict(), dict(stranded=abi.STRAND_FORWARD), dict(stranded=abi.STRAND_REVERSE, unpaired=1)):
+            p = abi.default_params(mapq_threshold=4, **kw)
+            ref = hostemu.run(p, ann, batch, mode=1, want_cov=True)
+            o = hostemu.run_k1(p, ann, batch, grid=2, want_cov=True)
+            _compare(o, oracle_lib.run_oracle(p, ann, [batch]), ref.cov)
+
+
+def test_small_and_ragged_batches(oracle_lib):
+    """Fewer records than lanes, one record, sizes around the tile and queue boundaries, more workgroups than tiles."""
+    ann = synth.make_annotation(seed=5, contigs=[("chrA", 400_000, 60), ("chrB", 200_000, 30)])
+    full = synth.make_reads(ann, 500, seed=6, contig_lengths=np.array([400_000, 200_000]))
+    p = abi.default_params()
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 191, 257, 640, full.n):
+        b = full.slice(0, min(n, full.n))
+        r = oracle_lib.run_oracle(p, ann, [b])
+        for grid in (1, 4):
+            _compare(hostemu.run_k1(p, ann, b, grid=grid), r)
+
+
+def test_wide_records_and_long_cigars(oracle_lib):
+    """Escape values (l_qseq >= 65535, NM >= 255, >= 255 CIGAR operations) come from the wide table in both kernels; CIGARs of
+    5-8 operations are walked from registers, longer ones from memory; 3- and 4-block records; more than 4 blocks -> general code."""
+    rows = [dict(contig="c", type="gene", start=100, end=90000, strand="+", gene_id="G0"),
+            dict(contig="c", type="exon", start=100, end=90000, strand="+", gene_id="G0", exon_id="E0"),
+            dict(contig="c", type="gene", start=95000, end=99000, strand="-", gene_id="G1"),
+            dict(contig="c", type="exon", start=95000, end=96000, strand="-", gene_id="G1", exon_id="E1"),
+            dict(contig="c", type="exon", start=97000, end=99000, strand="-", gene_id="G1", exon_id="E2")]
+    ann = Annotation.from_rows(["c"], rows)
+    M, I, D, N, S = abi.CIG_M, abi.CIG_I, abi.CIG_D, abi.CIG_N, abi.CIG_S
+    recs = []
+    rng = np.random.default_rng(11)
+    for i in range(300):
+        kind = i % 10
+        pos = 150 + 10 * i
+        if kind == 0:
+            cig = [(M, 40)] + [(I, 1), (M, 1)] * 140                  # 281 operations: wide n_cigar, 141 blocks -> general code
+        elif kind == 1:
+            cig = [(S, 3), (M, 30), (N, 20), (M, 30), (N, 20), (M, 30), (S, 2)]   # 7 operations, 3 blocks
+        elif kind == 2:
+            cig = [(M, 20), (N, 5), (M, 20), (D, 2), (M, 20), (N, 7), (M, 20)]    # 4 blocks
+        elif kind == 3:
+            cig = [(M, 10), (I, 2), (M, 10), (D, 1), (M, 10), (I, 1), (M, 10), (N, 30), (M, 10), (S, 4)]   # 10 operations, 5 blocks
+        elif kind == 4:
+            cig = [(M, 70000)]                                         # l_qseq beyond 16 bits
+        elif kind == 5:
+            cig = [(S, 5), (M, 95), (S, 5), (abi.CIG_H, 3), (abi.CIG_P, 0)]       # 5 operations, 1 block
+        else:
+            cig = [(M, 50), (N, 100), (M, 50)] if rng.random() < 0.5 else [(M, 100)]
+        recs.append(dict(qname="q%d" % (i // 2), tid=0, pos=pos, cigar=cig, flag=99 if i % 2 == 0 else 147, mapq=255,
+                         nm=300 if kind == 6 else 1, mpos=pos + 50, mtid=0))
+    b = Batch.from_records(recs)
+    assert len(b.wide_index) > 0
+    p = abi.default_params()
+    r = oracle_lib.run_oracle(p, ann, [b])
+    for grid in (1, 2):
+        o = hostemu.run_k1(p, ann, b, grid=grid)
+        _compare(o, r)
+        assert o.n_overflow >= 60 and o.n_listed >= 120
+
+
+def test_many_small_contigs_in_one_tile(oracle_lib):
+    """Several contigs inside one 64-record tile: the records beyond the tile's first contig take the general code."""
+    rows = []
+    names = ["c%d" % k for k in range(12)]
+    for k, nm in enumerate(names):
+        rows.append(dict(contig=nm, type="gene", start=100, end=5000, strand="+-"[k % 2], gene_id="G%d" % k))
+        rows.append(dict(contig=nm, type="exon", start=200, end=1200, strand="+-"[k % 2], gene_id="G%d" % k, exon_id="E%d" % k))
+    ann = Annotation.from_rows(names, rows)
+    recs = []
+    for k in range(12):
+        for j in range(5 + 7 * (k % 3)):
+            recs.append(dict(qname="q%d_%d" % (k, j // 2), tid=k, pos=150 + 40 * j, cigar=[(abi.CIG_M, 100)], flag=99 if j % 2 == 0 else 147,
+                             mapq=255, nm=0, mpos=300, mtid=k))
+    b = Batch.from_records(recs)
+    p = abi.default_params()
+    r = oracle_lib.run_oracle(p, ann, [b])
+    for grid in (1, 2):
+        _compare(hostemu.run_k1(p, ann, b, grid=grid), r)
+    assert r.gene_reads.sum() > 50
