@@ -23,10 +23,25 @@
 
 namespace rsqc {
 
+// A rarely taken branch that loads (wide-table values, the contig of a boundary tile, operations past the eighth) ends with
+// this: the loaded value is waited for INSIDE the branch.  Left to the compiler, the wait lands at the first use after the
+// branches join -- on the common path -- and, vmcnt being one in-order counter, becomes a wait for everything the wave has
+// in flight, the record words staged for the next tile and the previous tile's atomics included.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define K1E_LANDED(x) asm volatile("" : "+v"(x))
+#else
+#define K1E_LANDED(x) (void)(x)
+#endif
+
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
 constexpr int K1E_QCAP = 128;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
 constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
 constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's flag word | K1E_HQ when high quality
+// (timing experiments, `make variant DEFS=-DK1E_ABL=<bits>`: 1 no feature stage, 2 no LDS table updates, 4 no coverage atomics,
+//  8 no pairs, 16 no long-CIGAR kernel -- wrong results by design; the product build has K1E_ABL == 0 and none of it)
+#ifndef K1E_ABL
+#define K1E_ABL 0
+#endif
 
 // Workgroup-local accumulators: a workgroup streams a short genomic window, so it touches a handful of neighbouring
 // exons and genes; direct-mapped LDS tables take every update and each distinct key costs ONE global atomic when the
@@ -54,11 +69,12 @@ struct K1eTables {
         if (old == 0xFFFFFFFFu || old == eid) atomicAdd(&eval[slot], frac);
         else atomicAdd(&acc.exon_acc[eid], frac);
     }
-    __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, bool notdup) {
+    // n records, nd of them not duplicates
+    __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, uint32_t n, uint32_t nd) {
         const uint32_t slot = g & (K1E_GSLOTS - 1);
         const uint32_t old = atomicCAS(&gkey[slot], 0xFFFFFFFFu, g);
-        if (old == 0xFFFFFFFFu || old == g) atomicAdd(&gval[slot], notdup ? 0x100000001ull : 1ull);
-        else { atomicAdd(&acc.gene_reads[g], 1ull); if (notdup) atomicAdd(&acc.gene_unique[g], 1ull); }
+        if (old == 0xFFFFFFFFu || old == g) atomicAdd(&gval[slot], (unsigned long long)n | ((unsigned long long)nd << 32));
+        else { atomicAdd(&acc.gene_reads[g], (unsigned long long)n); if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd); }
     }
     // after a __syncthreads(): every table goes to memory, one atomic per distinct key
     __device__ __forceinline__ void flush(const DevAccum &acc) {
@@ -105,10 +121,18 @@ __device__ __forceinline__ void k1e_commit(const DevAccum &acc, K1eTables &T, co
         if (__ballot(has) == 0ull) continue;
         const uint32_t ln = len[k >> 1];
         const bool hv = has && ln > 0;
-        if (hv) T.exon_add(acc, eo.eid[k], NB > 1 ? (double)ln * inv_aligned : 1.0);
+        // The input is coordinate-sorted, so the lanes of a tile that hit one exon / gene sit next to each other: the first lane
+        // of a run of equal keys adds for the whole run (64 LDS atomics on one address take 64 passes of the LDS, one takes one).
+        // One-block records add exactly 1 each, so their runs need no sum; fractions of longer records go lane by lane.
+        if (NB == 1) {
+            const Run r = make_run(hv, eo.eid[k]);
+            if (r.head && !(K1E_ABL & 2)) T.exon_add(acc, eo.eid[k], (double)r.count);
+        } else if (hv && !(K1E_ABL & 2)) T.exon_add(acc, eo.eid[k], (double)ln * inv_aligned);
         const uint32_t base = hv ? eo.cidx[k] : 0u;
-        cov_add_merged(acc.cov_diff, hv, base, 1u);
-        cov_add_merged(acc.cov_diff, hv, base + ln, 0xFFFFFFFFu);
+        if (!(K1E_ABL & 4)) {
+            cov_add_merged(acc.cov_diff, hv, base, 1u);
+            cov_add_merged(acc.cov_diff, hv, base + ln, 0xFFFFFFFFu);
+        }
     }
 #pragma unroll
     for (int k = 0; k < FAST_SET; ++k) {
@@ -116,15 +140,21 @@ __device__ __forceinline__ void k1e_commit(const DevAccum &acc, K1eTables &T, co
         const uint64_t m = __ballot(has);
         if (m == 0ull) break;
         const uint32_t g = eo.hit[k];
-        const int lead = __ffsll((unsigned long long)m) - 1;
-        uint32_t base = 0;
-        if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
-        base = __shfl(base, lead, 64);
-        if (has) {
-            const uint32_t slot = base + mask_rank(m);
-            if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
-            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-            T.gene_add(acc, g, notdup);
+        if (!(K1E_ABL & 8)) {
+            const int lead = __ffsll((unsigned long long)m) - 1;
+            uint32_t base = 0;
+            if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
+            base = __shfl(base, lead, 64);
+            if (has) {
+                const uint32_t slot = base + mask_rank(m);
+                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
+                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+            }
+        }
+        {
+            const Run r = make_run(has, g);
+            const uint64_t nd = __ballot(has && notdup);
+            if (r.head && !(K1E_ABL & 2)) T.gene_add(acc, g, r.count, (uint32_t)__popcll(nd & r.mask));
         }
     }
 }
@@ -192,11 +222,17 @@ __device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t
             const uint32_t ck = (uint32_t)k < n ? c[k] : 5u;
             w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u;
         }
-        for (uint32_t i = 8; i < n; ++i) { const uint32_t ck = cigar[i]; w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u; }
+        if (__ballot(n > 8) != 0ull) {
+            for (uint32_t i = 8; i < n; ++i) { const uint32_t ck = cigar[i]; w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u; }
+            K1E_LANDED(w.ref_len);
+        }
     }
 }
 
-__global__ void __launch_bounds__(RSQC_K1_THREADS, 5)
+#ifndef K1E_MINW
+#define K1E_MINW 4            /* waves per SIMD the register allocation aims at: 128 VGPRs, no spills (at 5 the loop spills: 7.7 vs 4.65 ms) */
+#endif
+__global__ void __launch_bounds__(RSQC_K1_THREADS, K1E_MINW)
 classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2 *multi_list, uint32_t *multi_count, uint32_t multi_cap) {
     __shared__ K1eShared S;
     const int l = lane_id();
@@ -242,19 +278,32 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
     load_contig();
     uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0;             // queue heads and fills (wave-uniform)
 
-    // Record words are staged one tile ahead (core words two tiles ahead: they carry the CIGAR address), eight CIGAR
-    // words per record with them.
+    // Record words and eight CIGAR words per record are staged ONE TILE AHEAD; the CIGAR address of the tile after that
+    // comes with them (it is the fourth word of the core record).  The staged loads are issued at the TOP of a tile and
+    // waited for at the END of its phase A, right before the feature stages: on gfx9 loads, stores and atomics retire through
+    // ONE in-order counter (vmcnt), so a wave that waits for a load also waits for every memory operation it issued before
+    // it.  Placed there, that wait finds the coverage atomics of the previous tile's feature stage a whole phase A old, and
+    // the feature stage's own atomics are never waited for by the record stream (round 2: 69 of the loop's 96 waits were
+    // vmcnt(0) with atomics in flight -- the exposed latency of its T = a + b / waves).
     const int4 zero4 = {0, 0, 0, 0};
-    int4 cur_cv = zero4, cur_av = zero4, nx_cv = zero4;
+    int4 cur_cv = zero4, cur_av = zero4;
     uint32_t cg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nx_co = 0;                                                   // CIGAR offset of this lane's record of the NEXT tile
     const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
+    const uint32_t *const core1 = reinterpret_cast<const uint32_t *>(b.core);
     if (wbeg + (uint64_t)l < wend) { cur_cv = ld32(core4 + wbeg, (uint32_t)l); cur_av = ld32(aux4 + wbeg, (uint32_t)l); }
-    if (wbeg + 64ull + (uint64_t)l < wend) nx_cv = ld32(core4 + wbeg + 64, (uint32_t)l);
+    if (wbeg + 64ull + (uint64_t)l < wend) nx_co = ld32(core1 + 4 * (wbeg + 64), 4u * (uint32_t)l + 3u);
     {
         const uint32_t co = (uint32_t)cur_cv.w;                          // buffers carry 32 bytes of slack
 #pragma unroll
         for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, co + (uint32_t)k);
     }
+    // (the wait of the first tile's words sits here, not in the loop: the compiler places a wait where ANY path into an
+    //  instruction has the load pending, and a wait inside the loop is executed by every tile)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"(cur_cv.x), "v"(cur_cv.y), "v"(cur_cv.z), "v"(cur_cv.w), "v"(cur_av.x), "v"(cur_av.y), "v"(cur_av.z), "v"(cur_av.w), "v"(nx_co));
+    asm volatile("" :: "v"(cg[0]), "v"(cg[1]), "v"(cg[2]), "v"(cg[3]), "v"(cg[4]), "v"(cg[5]), "v"(cg[6]), "v"(cg[7]));
+#endif
     for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
@@ -264,6 +313,12 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
             if (moved) load_contig();                       // (the queues were emptied by the tile before the boundary)
         }
         const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
+        // ---- the next tile's words start their trip now -----------------------------------------------------------------
+        int4 n_cv = zero4, n_av = zero4; uint32_t n_cg[8]; uint32_t n_co = 0;
+        if (i + 64ull < wend) { n_cv = ld32(core4 + w0 + 64, (uint32_t)l); n_av = ld32(aux4 + w0 + 64, (uint32_t)l); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) n_cg[k] = ld32(b.cigar, nx_co + (uint32_t)k);
+        if (i + 128ull < wend) n_co = ld32(core1 + 4 * (w0 + 128), 4u * (uint32_t)l + 3u);
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
         Record r;
@@ -282,9 +337,10 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
             while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
             if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
             else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
+            K1E_LANDED(r.l_qseq); K1E_LANDED(r.nm); K1E_LANDED(r.n_cigar);
         }
         r.tid = u_tid;
-        if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; }
+        if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; K1E_LANDED(r.tid); }
         if (valid && !ok) atomicExch(acc.error, RSQC_ERR_ARG);
         const bool lane_on = valid && ok;
         if (!lane_on) r.n_cigar = 0;
@@ -325,23 +381,13 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         }
         const uint32_t flhq = r.flag | (hq ? K1E_HQ : 0u);
         const bool mine = go && r.tid == u_tid;              // stragglers of a boundary tile: general code
-        // ---- stage the next tile -----------------------------------------------------------------------------------
-        {
-            const uint64_t i1 = i + 64ull, i2 = i + 128ull;
-            const int4 t_cv = nx_cv;
-            int4 t_av = zero4;
-            if (i1 < wend) t_av = ld32(aux4 + w0 + 64, (uint32_t)l);
-            const uint32_t co = (uint32_t)t_cv.w;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, co + (uint32_t)k);
-            nx_cv = zero4;
-            if (i2 < wend) nx_cv = ld32(core4 + w0 + 128, (uint32_t)l);
-            cur_cv = t_cv; cur_av = t_av;
-        }
         // ---- sort by shape ------------------------------------------------------------------------------------------
-        const bool simple = mine && shortc && w2.nb <= 2;
-        const bool listed = mine && !simple;
-        k1e_overflow(acc, go && !mine, i);
+        // (a straggler of a boundary tile with a long CIGAR is listed like the others -- the list carries the contig; one of a
+        //  simple shape takes the general code, which finds its contig itself)
+        const bool shape12 = shortc && w2.nb <= 2;
+        const bool simple = mine && shape12;
+        const bool listed = go && !shape12;
+        k1e_overflow(acc, go && !mine && shape12, i);
         {   // no block at all (clips / insertions only): intergenic, src/Expression.cpp:407-441 with no feature seen
             const bool none = simple && w2.nb == 0;
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
@@ -368,18 +414,26 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         }
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
+        // ---- the staged words have landed (see above): from here on they are the current tile ----------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
+        asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
+#endif
+        cur_cv = n_cv; cur_av = n_av; nx_co = n_co;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cg[k] = n_cg[k];
         // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
         //      (the queued records belong to it) and at the end of the range ------------------------------------------------
         const bool leaving = w0 + 64ull >= wend || (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0 + 64ull);
         const uint32_t thr = leaving ? 1u : 64u;
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
-            k1e_process<1>(a, p, b, acc, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b, acc, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
-            k1e_process<2>(a, p, b, acc, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b, acc, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
         }
     }
@@ -405,7 +459,7 @@ classify_multi_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, co
     __shared__ K1mShared S;
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t n = multi_count[blockIdx.x];
+    const uint32_t n = (K1E_ABL & 16) ? 0u : multi_count[blockIdx.x];
     if (n == 0) return;
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     S.T.init(acc.pair_chunk_count[blockIdx.x]);              // the pairs go behind the ones classify_ei_kernel left in the chunk

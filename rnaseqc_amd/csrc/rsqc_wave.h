@@ -7,6 +7,15 @@ namespace rsqc {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// the value of the lane below (lane 0 keeps its own): ONE DPP move (wave_shr:1) instead of a trip through the LDS crossbar
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+#else
+    return __shfl_up(v, 1, 64);
+#endif
+}
+
 __device__ __forceinline__ uint32_t mask_rank(uint64_t m) {      // #set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -54,7 +63,7 @@ __device__ __forceinline__ void wave_aggregate(bool valid, uint32_t key, uint64_
 struct Run { bool head; uint32_t count; int end; uint64_t mask; };
 __device__ __forceinline__ Run make_run(bool valid, uint32_t key) {
     const int l = lane_id();
-    const uint32_t pk = __shfl_up(key, 1, 64);
+    const uint32_t pk = lane_below(key);
     const uint64_t vmask = __ballot(valid);
     const bool pvalid = l > 0 && ((vmask >> (l - 1)) & 1ull);
     Run r;
@@ -88,7 +97,7 @@ __device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
 // Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
 // then is the run structure built.
 __device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {
-    const uint32_t pidx = __shfl_up(idx, 1, 64);
+    const uint32_t pidx = lane_below(idx);
     const uint64_t vmask = __ballot(valid);
     const int l = lane_id();
     const bool dup = valid && l > 0 && ((vmask >> (l - 1)) & 1ull) && pidx == idx;
