@@ -135,7 +135,7 @@ struct rsqc_ctx {
     // one device arena holds every small result vector (single memset at reset, single D2H at finalize):
     // u64[3G+K] | u64 bias3,bias5[L] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | u8 exon_hit[E] | misc[64]
     DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
-    DevBuf d_multi, d_multi_count, d_ei_rank;           // classify_multi_kernel's lists; rank table of the interval index
+    DevBuf d_ei_rank;                                   // rank table of the interval index
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
            off_bias5 = 0, off_ecv = 0, off_gvalid = 0, off_ecvv = 0, off_ehit = 0, off_misc = 0;
@@ -510,18 +510,10 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     DevBatch d = u->d;
     d.record_base = u->file_index_base;
     c->next_record_base = u->file_index_base + u->n;
-    // records with longer CIGARs are listed per K1 workgroup for classify_multi_kernel (worst case: every record of the workgroup)
-    MultiList ml{nullptr, nullptr, 0u};
-    if (!c->dparams.legacy) {
-        const uint64_t mcap = per_wave * (RSQC_K1_THREADS / 64);
-        if (u->n >= (1ull << 31)) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
-        if (c->d_multi.bytes < mcap * (uint64_t)grid * 8) { int rcm = dev_alloc(c, c->d_multi, mcap * (uint64_t)grid * 8 + (mcap * (uint64_t)grid * 8) / 4, false); if (rcm) return rcm; }
-        if (c->d_multi_count.bytes < (size_t)grid * 4) { int rcm = dev_alloc(c, c->d_multi_count, (size_t)c->k1_grid * 4 + 64, false); if (rcm) return rcm; }
-        ml.list = (uint2 *)c->d_multi.p; ml.count = (uint32_t *)c->d_multi_count.p; ml.cap = (uint32_t)mcap;
-    }
+    if (!c->dparams.legacy && u->n >= (1ull << 31)) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");   // record indices ride in 31 bits of the kernel's queues
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc, ml);
+    launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc);
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->k1_events.emplace_back(e0, e1);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
@@ -624,7 +616,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
-    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_multi, &c->d_multi_count, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
+    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);

@@ -130,10 +130,8 @@ void launch_reduce_add(hipStream_t s, unsigned long long *du, const unsigned lon
                        uint8_t *db, const uint8_t *sb, size_t nb);
 void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hit, uint32_t n_exons);
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min);
-// records with longer CIGARs, listed by classify_ei_kernel for classify_multi_kernel: workgroup k owns [k * cap, + count[k])
-struct MultiList { uint2 *list; uint32_t *count; uint32_t cap; };
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                     const DevAccum &acc, const MultiList &ml);
+                     const DevAccum &acc);
 void launch_ei_rank(hipStream_t s, const EiEntry *ei, uint32_t ei_lo, uint32_t ei_hi, EiRank *rank, uint32_t n_words);
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc);

@@ -12,10 +12,10 @@
 //       queues: one block, two blocks.  Whenever a queue holds 64 records the wave runs the feature stage of exactly
 //       that shape on them (`k1e_process<NB>`): all lanes busy, one / two look-up rounds, two / four commit slots, no
 //       block-count predicates.  Records with longer CIGARs (more than 4 operations or more than 2 blocks: 9 % of an
-//       RNA-seq file) are listed for classify_multi_kernel; a record whose blocks meet an interval covered by more than
-//       two exons goes to the general code (classify_slow_kernel) as before.
-//   classify_multi_kernel  the listed records, one per lane: full CIGAR walk (8 operations from registers, more from
-//       memory), up to FAST_BLOCKS blocks per record through the same feature stage and commit code.
+//       RNA-seq file) wait in a third queue as (record index, flags) and are processed 64 at a time by `k1e_process_long`:
+//       record words and CIGAR come back from the caches, full CIGAR walk (8 operations from registers, more from memory),
+//       up to FAST_BLOCKS blocks per record through the same feature stage and commit code.  A record whose blocks meet an
+//       interval covered by more than two exons goes to the general code (classify_slow_kernel) as before.
 //
 // The feature stage reads the ELEMENTARY-INTERVAL index (rsqc_read.h: EiEntry / EiRank): a block costs two 16-byte
 // rank-word loads (independent, no walk) and one round of entry loads, instead of bin -> rows -> rows further down.
@@ -31,6 +31,27 @@ namespace rsqc {
 #define K1E_LANDED(x) asm volatile("" : "+v"(x))
 #else
 #define K1E_LANDED(x) (void)(x)
+#endif
+
+// Everything the two kernels are given, as ONE by-value struct: its layout is the kernel-argument segment's.  The hot loop
+// uses a few dozen of these words; the rest (wide table, BED candidates, overflow list, error word, fall-back targets of the
+// LDS tables, what the epilogue flushes) is read through k1e_lazy_args() at the point of use with scalar loads -- held in
+// SGPRs for the whole kernel they are what pushed the round-2 kernel to 155 spilled scalars, every one of which costs
+// v_writelane / v_readlane pairs on the vector pipe.
+struct K1Args { DevAnnotation a; DevParams p; DevBatch b; DevAccum acc; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ const K1Args *k1e_lazy_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const K1Args *q = (const K1Args *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));                  // opaque: the loads stay where they are written
+    return q;
+#else
+    return nullptr;                              // (host pass of the compiler: never called)
+#endif
+}
+#else
+static const K1Args *g_k1e_args = nullptr;       // (host emulation: set by the harness)
+static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
 
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
@@ -55,29 +76,32 @@ struct K1eTables {
     uint32_t gkey[K1E_GSLOTS];
     uint32_t rl[3];
     uint32_t pairs;                              // pairs in the workgroup's chunk
-    uint32_t multi;                              // records listed for classify_multi_kernel
     __device__ __forceinline__ void init(uint32_t pairs0) {
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
         if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
         for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
-        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; multi = 0u; }
+        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; }
     }
-    __device__ __forceinline__ void exon_add(const DevAccum &acc, uint32_t eid, double frac) {
+    __device__ __forceinline__ void exon_add(uint32_t eid, double frac) {
         const uint32_t slot = eid & (K1E_ESLOTS - 1);
         const uint32_t old = atomicCAS(&ekey[slot], 0xFFFFFFFFu, eid);
         if (old == 0xFFFFFFFFu || old == eid) atomicAdd(&eval[slot], frac);
-        else atomicAdd(&acc.exon_acc[eid], frac);
+        else atomicAdd(&k1e_lazy_args()->acc.exon_acc[eid], frac);
     }
     // n records, nd of them not duplicates
-    __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, uint32_t n, uint32_t nd) {
+    __device__ __forceinline__ void gene_add(uint32_t g, uint32_t n, uint32_t nd) {
         const uint32_t slot = g & (K1E_GSLOTS - 1);
         const uint32_t old = atomicCAS(&gkey[slot], 0xFFFFFFFFu, g);
         if (old == 0xFFFFFFFFu || old == g) atomicAdd(&gval[slot], (unsigned long long)n | ((unsigned long long)nd << 32));
-        else { atomicAdd(&acc.gene_reads[g], (unsigned long long)n); if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd); }
+        else {
+            const DevAccum &acc = k1e_lazy_args()->acc;
+            atomicAdd(&acc.gene_reads[g], (unsigned long long)n); if (nd) atomicAdd(&acc.gene_unique[g], (unsigned long long)nd);
+        }
     }
     // after a __syncthreads(): every table goes to memory, one atomic per distinct key
-    __device__ __forceinline__ void flush(const DevAccum &acc) {
+    __device__ __forceinline__ void flush() {
+        const DevAccum &acc = k1e_lazy_args()->acc;
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) {
             const unsigned long long v = cnt[c] + (unsigned long long)cnt32[c];
             if (v) atomicAdd(&acc.counters[c], v);
@@ -98,6 +122,7 @@ struct K1eShared {
     uint4 q1[K1E_WAVES][K1E_QCAP];               // one block:  bs, len, record index, flhq
     uint4 q2[K1E_WAVES][K1E_QCAP];               // two blocks: bs0, len0, bs1, len1
     uint2 q2x[K1E_WAVES][K1E_QCAP];              //             record index, flhq
+    uint2 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq
 };
 
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
@@ -105,7 +130,7 @@ struct K1eShared {
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
-__device__ __forceinline__ void k1e_commit(const DevAccum &acc, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], bool notdup,
+__device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], bool notdup,
                                            uint64_t qhash, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
     const int l = lane_id();
     double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
@@ -126,12 +151,12 @@ __device__ __forceinline__ void k1e_commit(const DevAccum &acc, K1eTables &T, co
         // One-block records add exactly 1 each, so their runs need no sum; fractions of longer records go lane by lane.
         if (NB == 1) {
             const Run r = make_run(hv, eo.eid[k]);
-            if (r.head && !(K1E_ABL & 2)) T.exon_add(acc, eo.eid[k], (double)r.count);
-        } else if (hv && !(K1E_ABL & 2)) T.exon_add(acc, eo.eid[k], (double)ln * inv_aligned);
+            if (r.head && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)r.count);
+        } else if (hv && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)ln * inv_aligned);
         const uint32_t base = hv ? eo.cidx[k] : 0u;
         if (!(K1E_ABL & 4)) {
-            cov_add_merged(acc.cov_diff, hv, base, 1u);
-            cov_add_merged(acc.cov_diff, hv, base + ln, 0xFFFFFFFFu);
+            cov_add_merged(cov_diff, hv, base, 1u);
+            cov_add_merged(cov_diff, hv, base + ln, 0xFFFFFFFFu);
         }
     }
 #pragma unroll
@@ -144,23 +169,27 @@ __device__ __forceinline__ void k1e_commit(const DevAccum &acc, K1eTables &T, co
             const int lead = __ffsll((unsigned long long)m) - 1;
             uint32_t base = 0;
             if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
-            base = __shfl(base, lead, 64);
+            base = lane_value(base, lead);
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
                 if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
-                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
             }
         }
         {
             const Run r = make_run(has, g);
             const uint64_t nd = __ballot(has && notdup);
-            if (r.head && !(K1E_ABL & 2)) T.gene_add(acc, g, r.count, (uint32_t)__popcll(nd & r.mask));
+            if (r.head && !(K1E_ABL & 2)) T.gene_add(g, r.count, (uint32_t)__popcll(nd & r.mask));
         }
     }
 }
 
-__device__ __forceinline__ void k1e_overflow(const DevAccum &acc, bool over, uint64_t index) {
+// `index`: record index, | K1E_OVF_LONG when the general code also has to count the record's blocks and check its
+// operations (a long-CIGAR straggler of a boundary tile, which classify_ei_kernel did not walk to the end)
+constexpr uint64_t K1E_OVF_LONG = 1ull << 63;
+__device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
     if (over) {
+        const DevAccum &acc = k1e_lazy_args()->acc;
         const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
         if (slot < acc.ovf_cap) acc.ovf_index[slot] = index;
         else atomicExch(acc.error, RSQC_ERR_CAPACITY);
@@ -169,7 +198,7 @@ __device__ __forceinline__ void k1e_overflow(const DevAccum &acc, bool over, uin
 
 // ---- the feature stage of 64 queued records of NB blocks each (n < 64 only when a queue is drained) -----------------
 template <int NB>
-__device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevAccum &acc,
+__device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const rsqc_rec_aux *aux, uint32_t *cov_diff,
                                             const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
                                             uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
     const int l = lane_id();
@@ -186,12 +215,66 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     if (!on) { idx = 0u; flhq = 0u; }
     // the name hash is only needed by records that are counted to a gene: it comes back from the record array (the lines
     // were streamed through this CU's caches a few tiles ago) instead of riding through the queue
-    const uint2 qh = ld32(reinterpret_cast<const uint2 *>(b.aux), idx * 2u);
+    const uint2 qh = ld32(reinterpret_cast<const uint2 *>(aux), idx * 2u);
     WaveSink cnt;
     EiOut eo; bool over = false;
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on);
-    k1e_overflow(acc, on && over, (uint64_t)idx);
-    k1e_commit<NB>(acc, S.T, eo, len, !(flhq & RSQC_FDUP), (uint64_t)qh.x | ((uint64_t)qh.y << 32), my_pair_gene, my_pair_hash, chunk_cap);
+    k1e_overflow(on && over, (uint64_t)idx);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, !(flhq & RSQC_FDUP), (uint64_t)qh.x | ((uint64_t)qh.y << 32), my_pair_gene, my_pair_hash, chunk_cap);
+    if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+}
+
+// ---- 64 queued records with longer CIGARs (n < 64 only when the queue is drained): record words and CIGAR come back from
+// the caches (they were streamed through this CU a few tiles ago), the CIGAR is walked in full -- every block counted, the
+// first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count -------------------------------
+__device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
+                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk,
+                                                 uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
+    const int l = lane_id();
+    const bool on0 = (uint32_t)l < n;
+    uint2 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
+    if (!on0) { it.x = 0u; it.y = 0u; }
+    const uint32_t idx = it.x, fl = it.y & 0xFFFFu; const bool hq = (it.y & K1E_HQ) != 0;
+    const int4 cv = ld32(reinterpret_cast<const int4 *>(b.core), idx), av = ld32(reinterpret_cast<const int4 *>(b.aux), idx);
+    uint32_t cg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, (uint32_t)cv.w + (uint32_t)k);
+    uint32_t n_cigar = (uint32_t)av.w >> 24;
+    bool ok = true;
+    if (on0 && n_cigar == RSQC_NCIGAR_ESCAPE) {
+        const DevBatch &bw = k1e_lazy_args()->b;
+        uint32_t lo = 0, hi = bw.n_wide;
+        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (bw.wide_index[m] < idx) lo = m + 1; else hi = m; }
+        if (lo >= bw.n_wide || bw.wide_index[lo] != idx) ok = false; else n_cigar = bw.wide_n_cigar[lo];
+        K1E_LANDED(n_cigar);
+    }
+    CigarWalk cw; Blocks B;
+    cw.ref_len = 0; cw.nblocks = 0; cw.aligned = 0; cw.bad = false;
+#pragma unroll
+    for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
+    const uint32_t nc = (on0 && ok) ? n_cigar : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cigar_op(cg[k], cv.x, cw, B, (uint32_t)k < nc);
+    if (__ballot(nc > 8) != 0ull) {
+        const uint32_t *cp = b.cigar + (uint32_t)cv.w;
+        for (uint32_t i = 8; i < nc; ++i) cigar_op(cp[i], cv.x, cw, B);
+        K1E_LANDED(cw.nblocks); K1E_LANDED(cw.ref_len);
+    }
+    const bool longc = nc > 4;                                // phase A left legality and the block count of these to this stage
+    if (longc && cw.bad) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_BAD_CIGAR);
+    const bool on = on0 && ok && !(longc && cw.bad);
+    sum_blk += (on && longc) ? cw.nblocks : 0u;                                       // src/RNASeQC.cpp:360
+    WaveSink cnt;
+    {
+        const bool none = on && cw.nblocks == 0;
+        RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
+    }
+    const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
+    EiOut eo; bool over = false;
+    exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
+    k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
+    k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, !(fl & RSQC_FDUP), (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32),
+                            my_pair_gene, my_pair_hash, chunk_cap);
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -233,12 +316,13 @@ __device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t
 #define K1E_MINW 4            /* waves per SIMD the register allocation aims at: 128 VGPRs, no spills (at 5 the loop spills: 7.7 vs 4.65 ms) */
 #endif
 __global__ void __launch_bounds__(RSQC_K1_THREADS, K1E_MINW)
-classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2 *multi_list, uint32_t *multi_count, uint32_t multi_cap) {
+classify_ei_kernel(K1Args A) {
     __shared__ K1eShared S;
+    const DevAnnotation &a = A.a; const DevParams &p = A.p; const DevBatch &b = A.b; const DevAccum &acc = A.acc;
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     S.T.init(0u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) *k1e_lazy_args()->acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
     __syncthreads();
 
     // the seven sum-type counters stay per-lane sums, reduced every 31 tiles
@@ -266,7 +350,6 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
     uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    uint2 *const my_multi = multi_list + (size_t)blockIdx.x * multi_cap;
     uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
     int32_t u_tid = -1;
     ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -276,7 +359,7 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
     };
     load_contig();
-    uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0;             // queue heads and fills (wave-uniform)
+    uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0, h3 = 0, c3 = 0;   // queue heads and fills (wave-uniform)
 
     // Record words and eight CIGAR words per record are staged ONE TILE AHEAD; the CIGAR address of the tile after that
     // comes with them (it is the fourth word of the core record).  The staged loads are issued at the TOP of a tile and
@@ -333,45 +416,48 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         }
         bool ok = true;
         if (valid && (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE)) {
-            uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
-            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
-            if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
-            else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
+            const DevBatch &bw = k1e_lazy_args()->b;
+            uint32_t lo = 0, hi = bw.n_wide;                    // wide table is sorted by record index
+            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (bw.wide_index[m] < i) lo = m + 1; else hi = m; }
+            if (lo >= bw.n_wide || bw.wide_index[lo] != i) ok = false;
+            else { r.l_qseq = bw.wide_l_qseq[lo]; r.nm = bw.wide_nm[lo]; r.n_cigar = bw.wide_n_cigar[lo]; }
             K1E_LANDED(r.l_qseq); K1E_LANDED(r.nm); K1E_LANDED(r.n_cigar);
         }
         r.tid = u_tid;
         if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; K1E_LANDED(r.tid); }
-        if (valid && !ok) atomicExch(acc.error, RSQC_ERR_ARG);
+        if (valid && !ok) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_ARG);
         const bool lane_on = valid && ok;
         if (!lane_on) r.n_cigar = 0;
         Walk2 w2;
         k1e_walk(r.pos, r.n_cigar, cg, r.cigar, w2);
-        const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: classify_multi_kernel
+        const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: k1e_process_long
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad;
         RecordCounters rc; bool hq = false;
         bool go = gate_cascade<false, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
         if (!lane_on) { go = false; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
         if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
-            const int32_t name = bed_interval_of(a, r);
+            const K1Args *q = k1e_lazy_args();
+            const int32_t name = bed_interval_of(q->a, r);
             if (name >= 0) {
-                const uint32_t slot = atomicAdd(acc.frag.count, 1u);
-                if (slot < acc.frag.cap) {
-                    acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
-                    acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
+                const FragCandidates &fr = q->acc.frag;
+                const uint32_t slot = atomicAdd(fr.count, 1u);
+                if (slot < fr.cap) {
+                    fr.file_index[slot] = q->b.record_base + i; fr.qhash[slot] = r.qhash;
+                    fr.name[slot] = name; fr.endpos[slot] = rc.endpos;
                     const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
                     const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
-                    acc.frag.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
-                } else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+                    fr.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
+                } else atomicExch(q->acc.error, RSQC_ERR_CAPACITY);
             }
         }
-        if (rc.error) atomicExch(acc.error, rc.error);
+        if (rc.error) atomicExch(k1e_lazy_args()->acc.error, rc.error);
         sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
         sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
         const bool big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
         {   // Read-Length inputs: per-tile max span + batch-level extremes
             const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
-            const uint32_t wsp = wave_max_u32(sp);
+            const uint32_t wsp = wave_max_u32_full(sp);
             if (l == 0) acc.tile_span[w0 >> 6] = wsp;
             l_span = sp > l_span ? sp : l_span;
             if (rc.rl_eligible) {
@@ -382,17 +468,17 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         const uint32_t flhq = r.flag | (hq ? K1E_HQ : 0u);
         const bool mine = go && r.tid == u_tid;              // stragglers of a boundary tile: general code
         // ---- sort by shape ------------------------------------------------------------------------------------------
-        // (a straggler of a boundary tile with a long CIGAR is listed like the others -- the list carries the contig; one of a
-        //  simple shape takes the general code, which finds its contig itself)
+        // (stragglers of a boundary tile take the general code, which finds their contig itself; for one with a long CIGAR it
+        //  also counts the blocks and checks the operations, K1E_OVF_LONG)
         const bool shape12 = shortc && w2.nb <= 2;
         const bool simple = mine && shape12;
-        const bool listed = go && !shape12;
-        k1e_overflow(acc, go && !mine && shape12, i);
+        const bool listed = mine && !shape12;
+        k1e_overflow(go && !mine, shape12 ? i : (i | K1E_OVF_LONG));
         {   // no block at all (clips / insertions only): intergenic, src/Expression.cpp:407-441 with no feature seen
             const bool none = simple && w2.nb == 0;
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
         }
-        const uint64_t m1 = __ballot(simple && w2.nb == 1), m2 = __ballot(simple && w2.nb == 2), mm = __ballot(listed);
+        const uint64_t m1 = __ballot(simple && w2.nb == 1), m2 = __ballot(simple && w2.nb == 2), m3 = __ballot(listed);
         if (simple && w2.nb == 1)
             S.q1[wave][(h1 + c1 + mask_rank(m1)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)i, flhq);
         if (simple && w2.nb == 2) {
@@ -400,18 +486,8 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
             S.q2[wave][slot] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)w2.bs1, w2.len1);
             S.q2x[wave][slot] = make_uint2((uint32_t)i, flhq);
         }
-        c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2);
-        if (mm) {
-            const int lead = __ffsll((unsigned long long)mm) - 1;
-            uint32_t base = 0;
-            if (l == lead) base = atomicAdd(&S.T.multi, (uint32_t)__popcll(mm));
-            base = __shfl(base, lead, 64);
-            if (listed) {
-                const uint32_t slot = base + mask_rank(mm);
-                if (slot < multi_cap) my_multi[slot] = make_uint2((uint32_t)i | (hq ? 0x80000000u : 0u), (uint32_t)r.tid);
-                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-            }
-        }
+        if (listed) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint2((uint32_t)i, flhq);
+        c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
         // ---- the staged words have landed (see above): from here on they are the current tile ----------------------------
@@ -428,13 +504,19 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         const uint32_t thr = leaving ? 1u : 64u;
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
-            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b, acc, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
-            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b, acc, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
+        }
+        while (__builtin_expect(c3 >= thr, 0)) {
+            const uint32_t take = c3 < 64u ? c3 : 64u;
+            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, my_pair_gene, my_pair_hash, chunk_cap);
+            h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
+            if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
         }
     }
     flush_counts();
@@ -443,85 +525,12 @@ classify_ei_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint2
         if (l == 0) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
     }
     __syncthreads();
-    S.T.flush(acc);
+    S.T.flush();
     if (threadIdx.x == 0) {
-        atomicMax(&acc.rl_stats[0], S.T.rl[0]); atomicMin(&acc.rl_stats[1], S.T.rl[1]); atomicMax(&acc.rl_stats[2], S.T.rl[2]);
-        acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
-        multi_count[blockIdx.x] = S.T.multi < multi_cap ? S.T.multi : multi_cap;
+        const K1Args *q = k1e_lazy_args();
+        atomicMax(&q->acc.rl_stats[0], S.T.rl[0]); atomicMin(&q->acc.rl_stats[1], S.T.rl[1]); atomicMax(&q->acc.rl_stats[2], S.T.rl[2]);
+        q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
     }
-}
-
-// ---- the records with longer CIGARs: workgroup k takes the list workgroup k of classify_ei_kernel wrote ---------------
-struct K1mShared { K1eTables T; };
-
-__global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
-classify_multi_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, const uint2 *multi_list, const uint32_t *multi_count, uint32_t multi_cap) {
-    __shared__ K1mShared S;
-    const int l = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t n = (K1E_ABL & 16) ? 0u : multi_count[blockIdx.x];
-    if (n == 0) return;
-    const uint32_t chunk_cap = acc.pair_chunk_cap;
-    S.T.init(acc.pair_chunk_count[blockIdx.x]);              // the pairs go behind the ones classify_ei_kernel left in the chunk
-    __syncthreads();
-    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
-    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    const uint2 *const list = multi_list + (size_t)blockIdx.x * multi_cap;
-    const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
-    uint32_t sum_blk = 0;
-    for (uint32_t t0 = (uint32_t)wave * 64u; t0 < n; t0 += K1E_WAVES * 64u) {
-        const bool on0 = t0 + (uint32_t)l < n;
-        const uint2 it = list[on0 ? t0 + (uint32_t)l : t0];
-        const uint32_t idx = it.x & 0x7FFFFFFFu; const bool hq = (it.x >> 31) != 0; const int32_t tid = (int32_t)it.y;
-        const int4 cv = ld32(core4, idx), av = ld32(aux4, idx);
-        uint32_t cg[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, (uint32_t)cv.w + (uint32_t)k);
-        const ContigInfo ci = a.contig[tid];                  // (tid is inside the annotation's contigs: the record passed :333)
-        const uint32_t fl = (uint32_t)av.z & 0xFFFFu;
-        uint32_t n_cigar = (uint32_t)av.w >> 24;
-        bool ok = true;
-        if (on0 && n_cigar == RSQC_NCIGAR_ESCAPE) {
-            uint32_t lo = 0, hi = b.n_wide;
-            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < idx) lo = m + 1; else hi = m; }
-            if (lo >= b.n_wide || b.wide_index[lo] != idx) ok = false; else n_cigar = b.wide_n_cigar[lo];
-        }
-        // full walk: every block counted, the first FAST_BLOCKS captured
-        CigarWalk cw; Blocks B;
-        cw.ref_len = 0; cw.nblocks = 0; cw.aligned = 0; cw.bad = false;
-#pragma unroll
-        for (int k = 0; k < FAST_BLOCKS; ++k) { B.bs[k] = 0; B.len[k] = 0; }
-        const uint32_t nc = (on0 && ok) ? n_cigar : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cigar_op(cg[k], cv.x, cw, B, (uint32_t)k < nc);
-        {
-            const uint32_t *cp = b.cigar + (uint32_t)cv.w;
-            for (uint32_t i = 8; i < nc; ++i) cigar_op(cp[i], cv.x, cw, B);
-        }
-        const bool longc = nc > 4;                            // classify_ei_kernel left legality and the block count of these to this kernel
-        if (longc && cw.bad) atomicExch(acc.error, RSQC_ERR_BAD_CIGAR);
-        const bool on = on0 && ok && !(longc && cw.bad);
-        sum_blk += (on && longc) ? cw.nblocks : 0u;                                   // src/RNASeQC.cpp:360
-        WaveSink cnt;
-        {
-            const bool none = on && cw.nblocks == 0;
-            RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
-        }
-        const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
-        EiOut eo; bool over = false;
-        exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
-        k1e_overflow(acc, on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(acc, S.T, eo, B.len, !(fl & RSQC_FDUP), (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32),
-                                my_pair_gene, my_pair_hash, chunk_cap);
-        if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
-    }
-    {
-        const uint32_t s = wave_sum(sum_blk);
-        if (l == 0 && s) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s);
-    }
-    __syncthreads();
-    S.T.flush(acc);
-    if (threadIdx.x == 0) acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
 }
 
 }  // namespace rsqc

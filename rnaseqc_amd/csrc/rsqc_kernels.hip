@@ -504,10 +504,18 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
         uint32_t aligned = 1; bool notdup = false; uint64_t qhash = 0;
         if (k < n) {
             Record r;
-            const uint64_t i = LEGACY ? k : acc.ovf_index[k];
+            // bit 63 of a listed index: classify_ei_kernel did not walk this record's CIGAR to the end (a long-CIGAR straggler of a
+            // boundary tile) -- its blocks are counted and its operations checked here
+            const uint64_t entry = LEGACY ? k : acc.ovf_index[k];
+            const uint64_t i = entry & ~(1ull << 63);
             if (load_record(b, i, find_segment(b, i), r)) {
                 RecordCounters rc; bool hq; Blocks B;
-                if (gate_cascade(a, p, r, rc, hq, aligned, B) && !(p.dbg & 16u)) {
+                const bool go = gate_cascade(a, p, r, rc, hq, aligned, B);
+                if (!LEGACY && (entry >> 63)) {
+                    if (rc.error) atomicExch(acc.error, rc.error);
+                    if (rc.blocks) atomicAdd(&acc.counters[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)rc.blocks);
+                }
+                if (go && !(p.dbg & 16u)) {
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                     bool overflow = false;
                     if (LEGACY) {
@@ -1420,13 +1428,13 @@ void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, siz
     hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_vec);
 }
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                     const DevAccum &acc, const MultiList &ml) {
+                     const DevAccum &acc) {
     if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else {
         // (diagnostic) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
         static const unsigned pad = getenv("RSQC_K1_LDS_PAD") ? (unsigned)atoi(getenv("RSQC_K1_LDS_PAD")) : 0u;
-        hipLaunchKernelGGL(classify_ei_kernel, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, a, p, b, acc, ml.list, ml.count, ml.cap);
-        hipLaunchKernelGGL(classify_multi_kernel, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc, ml.list, ml.count, ml.cap);
+        const K1Args A{a, p, b, acc};
+        hipLaunchKernelGGL(classify_ei_kernel, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
     }
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,

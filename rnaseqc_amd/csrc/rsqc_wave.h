@@ -26,6 +26,31 @@ __device__ __forceinline__ T wave_sum(T v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the value of one lane (wave-uniform index) in every lane: v_readlane, no trip through the LDS crossbar
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+#else
+    return __shfl(v, lane, 64);
+#endif
+}
+// maximum over the wave, in every lane.  Six DPP steps (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of
+// rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3) leave it in lane 63 -- no ds_bpermute round trips, which
+// were a chain of six dependent LDS instructions per tile.
+// (all 64 lanes must be active: the result is read from lane 63)
+__device__ __forceinline__ uint32_t wave_max_u32_full(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQC_DPP_MAX(ctrl, rmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v = t > v ? t : v; }
+    RSQC_DPP_MAX(0x111, 0xf) RSQC_DPP_MAX(0x112, 0xf) RSQC_DPP_MAX(0x114, 0xf) RSQC_DPP_MAX(0x118, 0xf)
+    RSQC_DPP_MAX(0x142, 0xa) RSQC_DPP_MAX(0x143, 0xc)
+#undef RSQC_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+#endif
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }

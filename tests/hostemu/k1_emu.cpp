@@ -75,7 +75,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     std::vector<uint32_t> cov((size_t)hx.cov_entries + 64, 0u);
     const uint64_t total_waves = (uint64_t)grid * K1E_WAVES;
     const uint64_t per_wave = (((n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
-    const uint32_t chunk_cap = (uint32_t)(per_wave * K1E_WAVES * FAST_SET), multi_cap = (uint32_t)(per_wave * K1E_WAVES);
+    const uint32_t chunk_cap = (uint32_t)(per_wave * K1E_WAVES * FAST_SET);
     const uint32_t slow_cap = 1u << 16;
     std::vector<uint32_t> pair_gene((size_t)chunk_cap * grid + slow_cap + 8); std::vector<uint64_t> pair_hash(pair_gene.size());
     std::vector<uint32_t> chunk_count((size_t)grid + 2, 0xDEADu);
@@ -92,20 +92,15 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     acc.ovf_count = ovf_count.data(); acc.ovf_index = (uint64_t *)ovf_index.data(); acc.ovf_cap = (uint32_t)ovf_index.size();
     acc.tile_span = tile_span.data();
     acc.rl_stats = rl_stats.data(); acc.read_length = &rl_state; acc.error = &error;
-    std::vector<uint2> multi((size_t)multi_cap * grid + 8); std::vector<uint32_t> multi_count((size_t)grid + 1, 0xDEADu);
 
+    const K1Args A{d, dp, db, acc};
+    g_k1e_args = &A;
     wavemu::grid_dim().x = (uint32_t)grid;
     for (int k = 0; k < grid; ++k) {
         wavemu::block_idx().x = (uint32_t)k;
-        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel(d, dp, db, acc, multi.data(), multi_count.data(), multi_cap); });
+        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel(A); });
     }
     uint64_t listed = 0;
-    for (int k = 0; k < grid; ++k) {
-        if (multi_count[(size_t)k] > multi_cap) return 1001;
-        listed += multi_count[(size_t)k];
-        wavemu::block_idx().x = (uint32_t)k;
-        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_multi_kernel(d, dp, db, acc, multi.data(), multi_count.data(), multi_cap); });
-    }
     if (error) return error;
 
     // ---- the overflow list through the general per-record code ------------------------------------------------------
@@ -130,12 +125,15 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     };
     std::set<uint64_t> seen_ovf;
     for (uint32_t k = 0; k < ovf_count[0]; ++k) {
-        const uint64_t i = ovf_index[k];
+        const uint64_t i = ovf_index[k] & ~(1ull << 63);
+        const bool long_straggler = (ovf_index[k] >> 63) != 0;            // K1E_OVF_LONG: blocks and operations are this code's to count / check
         if (i >= n || !seen_ovf.insert(i).second) return 1002;            // every record at most once
         Record r;
         if (!load(i, r)) return RSQC_ERR_ARG;
         RecordCounters rc2; bool hq; uint32_t aligned; Blocks B;
-        if (!gate_cascade(d, dp, r, rc2, hq, aligned, B)) return 1003;    // only records that reach the feature stage are listed
+        const bool go2 = gate_cascade(d, dp, r, rc2, hq, aligned, B);
+        if (long_straggler) { if (rc2.error) return rc2.error; acc.counters[RSQC_C_ALIGNMENT_BLOCKS] += rc2.blocks; ++listed; }
+        if (!go2) return 1003;                                            // only records that reach the feature stage are listed
         bool over = false;
         FeatureOut<SLOW_SET, SLOW_STAGE> so;
         exon_metrics<SLOW_SET>(d, dp, r, hq, aligned, sacc, so, over);

@@ -1,7 +1,7 @@
-"""The per-record KERNELS (rnaseqc_amd/csrc/rsqc_k1.h: classify_ei_kernel + classify_multi_kernel, with rsqc_wave.h),
+"""The per-record KERNEL (rnaseqc_amd/csrc/rsqc_k1.h: classify_ei_kernel, with rsqc_wave.h),
 unmodified, on a 64-lane SIMT emulation for the host (tests/hostemu/wavemu.h: one fiber per lane; ballot / shuffle / mbcnt /
 LDS and memory atomics / __syncthreads on a cooperative scheduler) against the oracle: per-wave LDS queues sorted by block
-count, the feature stage on full and on drained tiles, workgroup tables, pair chunks, the long-CIGAR list, the overflow
+count, the feature stage on full and on drained tiles, workgroup tables, pair chunks, the long-CIGAR queue, the overflow
 list, Read-Length inputs per tile.  The GPU tests run the same source on the device."""
 import numpy as np
 import pytest
@@ -46,7 +46,7 @@ def test_synthetic_vs_oracle(oracle_lib, kw):
     for grid in (1, 2, 5):
         o = hostemu.run_k1(p, ann, batch, grid=grid, want_cov=True)
         _compare(o, r, ref.cov)
-        assert o.n_listed > 200 and o.n_pairs > 1000
+        assert o.n_pairs > 1000
     assert r.gene_reads.sum() > 1000
 
 
@@ -112,13 +112,13 @@ def test_wide_records_and_long_cigars(oracle_lib):
     for grid in (1, 2):
         o = hostemu.run_k1(p, ann, b, grid=grid)
         _compare(o, r)
-        assert o.n_overflow >= 60 and o.n_listed >= 120
+        assert o.n_overflow >= 60
 
 
 def test_many_small_contigs_in_one_tile(oracle_lib):
-    """Several contigs inside one 64-record tile: the records beyond the tile's first contig take the general code when their
-    shape is simple and the long-CIGAR list (which carries the contig) otherwise -- "Alignment Blocks" of the latter is counted
-    by classify_multi_kernel (a 1-GPU / by-contig-sharded difference of 9 blocks in 60 k records found this on the GPU)."""
+    """Several contigs inside one 64-record tile: the records beyond the tile's first contig take the general code and find their
+    contig themselves; for one with a long CIGAR the general code also counts "Alignment Blocks" and checks the operations
+    (a 1-GPU / by-contig-sharded difference of 9 blocks in 60 k records found the missing count on the GPU)."""
     rows = []
     names = ["c%d" % k for k in range(12)]
     for k, nm in enumerate(names):
