@@ -43,19 +43,70 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def end_to_end(args, ann, contigs, batch, st, log):
-    """The whole-node tier: `rnaseqc gtf bam out -vv` on a BAM of the bench records.  Driver-timed here; the
+def _kv(path):
+    out = {}
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if len(f) >= 2:
+            out[f[0]] = f[1]
+    return out
+
+
+def _gct(path):
+    """(row count of the header line, last column of every row) of a GCT file"""
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    n_hdr = int(lines[1].split("\t")[0])
+    vals = np.array([float(x.rsplit("\t", 1)[1]) for x in lines[3:] if x], np.float64)
+    return n_hdr, vals
+
+
+def e2e_parity(odir, sample, res, read_length):
+    """The CLI's report files against the kernel tier's result of the SAME records (one engine, resident input): every
+    integer counter the metrics file prints, Read Length, gene_reads / gene_fragments row by row, the exon_reads header
+    count (src/RNASeQC.cpp:513) and exon values within the contract's 1e-6."""
+    from rnaseqc_amd import abi
+    bad = []
+    m = _kv(os.path.join(odir, sample + ".metrics.tsv"))
+    checked = 0
+    for name in abi.COUNTER_NAMES:
+        if name in m:
+            checked += 1
+            if int(float(m[name])) != int(res.counter(name)):
+                bad.append("%s: file %s, kernel tier %d" % (name, m[name], res.counter(name)))
+    if int(float(m.get("Read Length", -1))) != int(read_length):
+        bad.append("Read Length: file %s, kernel tier %d" % (m.get("Read Length"), read_length))
+    n, v = _gct(os.path.join(odir, sample + ".gene_reads.gct"))
+    if n != len(res.gene_reads) or not np.array_equal(v.astype(np.int64), np.asarray(res.gene_reads).astype(np.int64)):
+        bad.append("gene_reads.gct differs (file sum %d, kernel tier %d)" % (int(v.sum()), int(res.gene_reads.sum())))
+    n, v = _gct(os.path.join(odir, sample + ".gene_fragments.gct"))
+    if not np.array_equal(v.astype(np.int64), np.asarray(res.gene_fragments).astype(np.int64)):
+        bad.append("gene_fragments.gct differs (file sum %d, kernel tier %d)" % (int(v.sum()), int(res.gene_fragments.sum())))
+    n, v = _gct(os.path.join(odir, sample + ".exon_reads.gct"))
+    if n != int(np.count_nonzero(res.exon_hit)):
+        bad.append("exon_reads.gct header count %d, kernel tier %d" % (n, int(np.count_nonzero(res.exon_hit))))
+    if len(v) != len(res.exon_reads) or not np.allclose(v, np.asarray(res.exon_reads), rtol=0, atol=1.5e-6):   # (the file has 6 decimals)
+        bad.append("exon_reads.gct values differ")
+    return {"parity": not bad, "counters_checked": checked + 1, "gene_reads_sum": int(res.gene_reads.sum()),
+            "against": "kernel tier of this run (same records resident in HBM, one engine): integer counters + Read Length exact, "
+                       "gene_reads / gene_fragments row by row, exon_reads header count and values within 1e-6",
+            "mismatches": bad[:8]}
+
+
+def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, gpus=1, gpu_list=None):
+    """The whole-node tier: `rnaseqc gtf bam out -vv [--gpus N]` on a BAM of the bench records.  Driver-timed here; the
     reads/s is the CLI's own `Average Reads/Sec` line (BAM loop + end-of-file stage, GTF load and report writing
-    excluded, exactly the reference's window)."""
+    excluded, exactly the reference's window, src/RNASeQC.cpp:240-241,389-394).  The report files of the timed run are
+    compared with the kernel tier's result before they are deleted."""
     from rnaseqc_amd import bamio, hostinfo
     cores = hostinfo.effective_cpus()
     d = tempfile.mkdtemp(prefix="rsqc_e2e_", dir=args.tmp or None)
-    out = {"cores": cores, "hardware_threads": os.cpu_count(),
+    out = {"cores": cores, "hardware_threads": os.cpu_count(), "gpus": gpus,
            "cores_note": "CPUs the process may use = affinity mask capped by the cgroup CPU quota (cpu.max); the decode pools are sized to it"}
     try:
-        bam, gtf, odir = os.path.join(d, "s.bam"), os.path.join(d, "s.gtf"), os.path.join(d, "out")
+        bam, gtf = os.path.join(d, "s.bam"), os.path.join(d, "s.gtf")
         t = time.time()
-        bamio.write_bam_fast(bam, [(c[0], c[1]) for c in contigs], batch, threads=min(cores, 96), struct=st)
+        bamio.write_bam_fast(bam, [(c[0], c[1]) for c in contigs], batch, threads=min(cores, 96), struct=st, bai=gpus > 1)
         out["bam_write_s"] = round(time.time() - t, 1)
         out["bam_bytes"] = os.path.getsize(bam)
         bamio.write_gtf(gtf, ann)
@@ -63,13 +114,17 @@ def end_to_end(args, ann, contigs, batch, st, log):
         env = dict(os.environ)
         if args.e2e_threads:
             env["RSQC_HOST_THREADS"] = str(args.e2e_threads)
-        def cli_runs(bam_path, mode, reps=2):
+        if gpu_list:
+            env["RSQC_GPU_LIST"] = gpu_list
+        extra = ["--gpus", str(gpus)] if gpus > 1 else []
+        def cli_runs(bam_path, mode, tag, reps=2):
             """`rnaseqc gtf bam out -vv` with RSQC_DECODE=mode; the best of reps runs (the second has the file in the page cache
-            and the GPU driver warm)."""
+            and the GPU driver warm).  Every run writes its own output directory."""
             runs = []
             for rep in range(reps):
+                odir = os.path.join(d, "out_%s_%d" % (tag, rep))
                 t = time.time()
-                p = subprocess.run([exe, gtf, bam_path, odir, "-vv"], env=dict(env, RSQC_DECODE=mode), capture_output=True, text=True)
+                p = subprocess.run([exe, gtf, bam_path, odir, "-vv"] + extra, env=dict(env, RSQC_DECODE=mode), capture_output=True, text=True)
                 wall = time.time() - t
                 m = re.search(r"Average Reads/Sec: ([0-9.e+]+)", p.stdout)
                 e = re.search(r"Time Elapsed: ([0-9.e+-]+); Alignments processed: (\d+)", p.stdout)
@@ -78,28 +133,41 @@ def end_to_end(args, ann, contigs, batch, st, log):
                              "alignments": int(e.group(2)) if e else None,
                              "reads_per_s": float(m.group(1)) if m else None,
                              "decode": "device" if "on the GPU" in p.stdout else "host",
-                             "decode_threads": [int(th.group(1)), int(th.group(2))] if th else None})
+                             "decode_threads": [int(th.group(1)), int(th.group(2))] if th else None, "odir": odir})
                 if p.returncode:
                     log("end_to_end: rnaseqc (%s decode) exited %d: %s" % (mode, p.returncode, p.stderr[-400:]))
-            return max(runs, key=lambda r: r["reads_per_s"] or 0.0), runs
+            best = max(runs, key=lambda r: r["reads_per_s"] or 0.0)
+            return best, [{k: v for k, v in r.items() if k != "odir"} for r in runs]
         # the product's default: BGZF inflate + record framing + parsing on the GPU (rsqc_decode_*); the host-decode path beside it
-        best, runs = cli_runs(bam, "device")
-        host_best, _hr = cli_runs(bam, "host")
+        best, runs = cli_runs(bam, "device", "dev")
+        host_best, _hr = cli_runs(bam, "host", "host")
         out.update({"value": best["reads_per_s"], "unit": "reads/s", "bam_loop_s": best["bam_loop_s"], "wall_s": best["wall_s"],
                     "alignments": best["alignments"], "decode": best["decode"], "runs": runs,
                     "host_decode": {"value": host_best["reads_per_s"], "unit": "reads/s", "decode_threads": host_best["decode_threads"],
                                     "note": "RSQC_DECODE=host: libdeflate inflate + record parsing on the CPU threads, batches over PCIe"},
                     "window": "CLI `Average Reads/Sec` = alignments / (BAM loop incl. end-of-file stage), src/RNASeQC.cpp:240-241,389-394",
                     "bam": "SEQ all 'A', QUAL 0xff, BGZF level 1 (SURVEY.md 8(d)): %.1f B/record compressed" % (out["bam_bytes"] / max(batch.n, 1))})
+        if res is not None and best["rc"] == 0:
+            try:
+                out.update(e2e_parity(best["odir"], "s.bam", res, read_length))
+                hp = e2e_parity(host_best["odir"], "s.bam", res, read_length) if host_best["rc"] == 0 else {"parity": False}
+                out["host_decode"]["parity"] = hp["parity"]
+            except Exception as ex:
+                out.update({"parity": False, "mismatches": ["parity check failed to run: %r" % (ex,)]})
         if args.e2e_real:                       # second flavour: the compressibility of a real file, first --e2e-real records
             nr = min(args.e2e_real, batch.n)
             sub = batch.slice(0, nr) if nr < batch.n else batch
             bam2 = os.path.join(d, "r.bam")
-            bamio.write_bam_fast(bam2, [(c[0], c[1]) for c in contigs], sub, threads=min(cores, 96), seq_mode=1)
-            b2, _r2 = cli_runs(bam2, "device")
-            h2, _r3 = cli_runs(bam2, "host", reps=1)
+            bamio.write_bam_fast(bam2, [(c[0], c[1]) for c in contigs], sub, threads=min(cores, 96), seq_mode=1, bai=gpus > 1)
+            b2, _r2 = cli_runs(bam2, "device", "rdev")
+            h2, _r3 = cli_runs(bam2, "host", "rhost", reps=1)
+            same = None
+            if b2["rc"] == 0 and h2["rc"] == 0:     # two decoders (GPU kernels / libdeflate + host parser), one set of report files
+                same = all(open(os.path.join(b2["odir"], "r.bam." + f), "rb").read() == open(os.path.join(h2["odir"], "r.bam." + f), "rb").read()
+                           for f in ("metrics.tsv", "gene_reads.gct", "gene_fragments.gct", "exon_reads.gct", "gene_tpm.gct"))
             out["realistic_entropy"] = {"value": b2["reads_per_s"], "unit": "reads/s", "records": int(sub.n), "bam_bytes": os.path.getsize(bam2),
                                         "decode": b2["decode"], "host_decode": h2["reads_per_s"],
+                                        "parity": same, "against": "the host-decode run of the same file: report files byte for byte",
                                         "bam": "random bases, binned Phred-like qualities with runs: %.1f B/record compressed" %
                                                (os.path.getsize(bam2) / max(sub.n, 1))}
     finally:
@@ -175,11 +243,24 @@ def main():
     elif world > 1 or args.dist_selftest:
         # sharded runs submit one batch per owned contig: a batch is a contiguous range of the file, and the
         # order-dependent outputs are composed per batch in file order (rsqc_shard_info)
-        parts, _ = synth.make_reads_sharded(ann, args.pairs, seed=2, contigs=mine, workers=workers, with_unmapped=(rank == tail_rank), as_parts=True)
+        want_e2e = rank == 0 and not args.no_e2e and not (args.no_finalize or args.host_fed or args.fasta or args.legacy or args.bed)
+        if want_e2e and world > 1:
+            # rank 0 also runs the whole-node tier (`rnaseqc --gpus N` on a BAM of ALL the records): it generates every contig
+            # and keeps its own for the kernel tier
+            every, _ = synth.make_reads_sharded(ann, args.pairs, seed=2, workers=max(workers, cores // 2), with_unmapped=True, as_parts=True)
+            ids = [c for c in range(ann.n_ref) if share[c] > 0]
+            parts = [every[k] for k, c in enumerate(ids) if c in mine] + ([every[-1]] if (rank == tail_rank and len(every) > len(ids)) else [])
+            full_parts = every
+        else:
+            parts, _ = synth.make_reads_sharded(ann, args.pairs, seed=2, contigs=mine, workers=workers, with_unmapped=(rank == tail_rank), as_parts=True)
+            full_parts = parts if world == 1 else None
         batch = None
     else:
         batch, _ = synth.make_reads_sharded(ann, args.pairs, seed=2, contigs=mine, workers=workers, with_unmapped=(rank == tail_rank))
         parts = [batch]
+        full_parts = None
+    if args.chr1:
+        full_parts = None
     structs = [b.to_struct() for b in parts]
     st = structs[0] if len(structs) == 1 else None
     n_local = sum(b.n for b in parts)
@@ -304,16 +385,28 @@ def main():
                              "SoA input, no BAM decode, incl. its end-of-file stage" % ns, "seconds": round(tc, 3)}
             del sample
         e2e = None
-        if world == 1 and not args.no_e2e and not (args.no_finalize or args.host_fed or args.dist_selftest or args.fasta or args.legacy or args.bed):
+        if not args.no_e2e and not (args.no_finalize or args.host_fed or args.fasta or args.legacy or args.bed):
             try:
-                e2e = end_to_end(args, ann, contigs, batch, st, log)
+                rl_now = int(order_dep[0][0]) if order_dep[0] else int(res.read_length)
+                if reduce_path:
+                    # the N > 1 form: `rnaseqc --gpus N` shards the BAM by contig through its index, one context per GPU, and sums the
+                    # shards over xGMI; --dist-selftest (one rank) drives the same code with two contexts on the one GPU
+                    from rnaseqc_amd.model import Batch
+                    whole = Batch.concat(full_parts)
+                    n_cli = world if world > 1 else 2
+                    e2e = end_to_end(args, ann, contigs, whole, None, log, res, rl_now, gpus=n_cli,
+                                     gpu_list=None if world > 1 else "0,0")
+                else:
+                    e2e = end_to_end(args, ann, contigs, batch, st, log, res, rl_now)
             except Exception as ex:             # the kernel tier stands on its own
                 e2e = {"error": repr(ex)}
         wl = ("configs[1] (diagnostic): chr1-like collapsed GTF (%d genes, %d exons) + %d records" if args.chr1 else
               "GENCODE-sized collapsed GTF (%d genes, %d exons, 25 contigs) + %d synthetic 2x150 coordinate-sorted records") % (
                   ann.n_genes, ann.n_exons, total_records)
         out = {
-            "metric": "reads/sec, device-resident kernel tier (100 M-record synthetic input, GENCODE-sized GTF); whole-node tier in end_to_end",
+            "metric": "reads/sec whole-node (100 M-read synthetic BAM, GENCODE GTF) at 1/2/4/8 GPU -- `value`: the hot path over the records resident in "
+                      "HBM (the bench contract's definition of value); `whole_node.value`: the same job from the BAM file to the reports "
+                      "(CLI `Average Reads/Sec` window), checked against `value`'s results",
             "value": total_records * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,11 +420,16 @@ def main():
                        "records_per_gpu": per_rank, "load_imbalance": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 4),
                        "sharding": "by contig, LPT on record counts" if world > 1 else "none (one GPU holds every contig)",
                        "collective": ("RCCL all_reduce(sum) of i64[3G+%d+2G] + f64[2E+3G] + u8[G+E] per step" % abi.N_COUNTERS) if reduce_path else "none"},
-            "roofline": {"bound": "hbm", "kernel": "classify_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "classify_ei_kernel" if not args.legacy else "classify_count_kernel_legacy + classify_slow_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": k1_ms,
                          "timer": "hipEvents around the launch on the context's stream (rsqc_get_timing), rank 0"},
             "cpu_baseline": cpu,
+            "whole_node": None if not e2e or "value" not in e2e else {
+                "value": e2e["value"], "unit": "reads/s", "n_gpus": e2e.get("gpus", 1), "parity": e2e.get("parity"),
+                "realistic_entropy_value": (e2e.get("realistic_entropy") or {}).get("value"),
+                "realistic_entropy_parity": (e2e.get("realistic_entropy") or {}).get("parity"),
+                "note": "`rnaseqc gtf bam out` on a BAM of the same records: BGZF inflate + BAM parse on the GPU + the hot path + end-of-file stage; details in end_to_end"},
             "end_to_end": e2e,
             "stage_ms": {"classify_k1": k1_ms * len(handles), "classify_launches_per_step": len(handles), "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
                          "slow_path_records": int(tm["slow_records"])},
@@ -356,6 +454,8 @@ def main():
         if args.host_fed:
             out["h2d_ms_per_step"] = tm["h2d_ms"] / max(args.steps, 1)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist and world > 1:
+        dist.barrier()                          # (ranks > 0 keep their contexts until rank 0's `rnaseqc --gpus N` run is over)
     e.close()
     if dist:
         dist.destroy_process_group()

@@ -447,6 +447,12 @@ RSQC_API int rsqc_shard_summary(rsqc_ctx *ctx, rsqc_shard_info *out);
  * peer's ranges cross xGMI by hipMemcpyPeerAsync and are added on dst's device.  Both contexts must hold the same
  * annotation and be past rsqc_finalize_device.  A process-per-GPU host uses an RCCL all_reduce on the ranges instead.  */
 RSQC_API int rsqc_reduce_peer(rsqc_ctx *dst, rsqc_ctx *src);
+/* The exchange step of ONE process that drives n GPUs (the command line with --gpus): the three ranges of every context
+ * are sum-reduced onto ctxs[0] with one RCCL ncclReduce per range inside one group call, each GPU's part on its context's
+ * stream, over communicators made with ncclCommInitAll on the contexts' devices (src/RNASeQC.cpp:385-394 is the reference's
+ * end-of-file window).  librccl is bound at run time; without it, or when two contexts share a device
+ * (a communicator cannot), the peer-copy path of rsqc_reduce_peer is taken instead.  *used_rccl (may be NULL) says which. */
+RSQC_API int rsqc_reduce_group(rsqc_ctx **ctxs, int n, int *used_rccl);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
 /* Page-locked host memory for the arrays of an rsqc_batch: rsqc_submit then copies by DMA and returns without

@@ -610,12 +610,18 @@ int main(int argc, char **argv) {
                          << ". No GC statistics will be collected for this chromosome" << endl;
             }
             // the exchange step: result ranges summed onto the first GPU, order-dependent outputs composed from the summaries
-            for (size_t g = 1; g < shards.size() && rc == RSQC_OK; ++g) rc = rsqc_reduce_peer(shards[0].gpu, shards[g].gpu);
+            int used_rccl = 0;
+            if (rc == RSQC_OK) {
+                std::vector<rsqc_ctx *> group;
+                for (auto &sh : shards) group.push_back(sh.gpu);
+                rc = rsqc_reduce_group(group.data(), (int)group.size(), &used_rccl);
+                if (rc != RSQC_OK) cerr << rsqc_last_error(shards[0].gpu) << endl;
+            }
             if (rc == RSQC_OK) { std::string merr; rc = merge_shards(shards, P.fragment_samples, merged, merr); if (rc != RSQC_OK) cerr << merr << endl; }
             if (o.verbosity > 1) {
                 cout << "Alignments processed: " << alignmentCount << " on " << shards.size() << " GPUs (";
                 for (size_t g = 0; g < shards.size(); ++g) cout << (g ? ", " : "") << shards[g].n_records;
-                cout << " records)" << endl;
+                cout << " records); shards summed by " << (used_rccl ? "RCCL ncclReduce" : "peer copies") << endl;
             }
         } else if (device_decode) {
             // ---- one GPU, device decode: the host reads the file and frames the BGZF blocks, nothing else

@@ -6,6 +6,8 @@
 // work on the context's stream and reads the small result vectors back at end of file.
 // There is no CPU fallback: without a HIP device rsqc_create() fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is bound at run time (rccl_api)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1197,6 +1199,96 @@ int rsqc_reduce_peer(rsqc_ctx *dst, rsqc_ctx *src) {
     HIP_TRY(src, hipSetDevice(src->device));
     HIP_TRY(src, hipMemcpy(&err, src->acc.error, sizeof(int), hipMemcpyDeviceToHost));
     if (err) { dst->sticky = err; return fail(dst, err, "a shard reported a device-side error"); }
+    return RSQC_OK;
+}
+
+// ---- the exchange step of a sharded run as ONE RCCL reduction per result range (north_star: "an RCCL
+// reduce of the per-gene count vectors and scalar metrics over xGMI at end-of-file") ---------------------------------------
+// One process drives the node's GPUs (the command line with --gpus), so the communicators come from ncclCommInitAll over
+// the contexts' devices and the three reductions of every GPU are issued inside one group call, each on its context's
+// stream.  librccl is bound at run time (like libdeflate in the host reader): a machine without it, or two contexts on
+// one device (a communicator cannot hold a device twice: the single-GPU test configuration RSQC_GPU_LIST=0,0), takes the
+// peer-copy path below instead.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl_api() {
+    static RcclApi A;
+    static bool tried = false;
+    if (tried) return A;
+    tried = true;
+    if (getenv("RSQC_NO_RCCL")) return A;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { A.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (A.lib) break; }
+    if (!A.lib) return A;
+#define RSQC_RCCL_SYM(field, sym) A.field = reinterpret_cast<decltype(A.field)>(dlsym(A.lib, sym))
+    RSQC_RCCL_SYM(CommInitAll, "ncclCommInitAll"); RSQC_RCCL_SYM(CommDestroy, "ncclCommDestroy"); RSQC_RCCL_SYM(GroupStart, "ncclGroupStart");
+    RSQC_RCCL_SYM(GroupEnd, "ncclGroupEnd"); RSQC_RCCL_SYM(Reduce, "ncclReduce"); RSQC_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RSQC_RCCL_SYM
+    A.ok = A.CommInitAll && A.CommDestroy && A.GroupStart && A.GroupEnd && A.Reduce && A.GetErrorString;
+    return A;
+}
+}  // namespace
+
+int rsqc_reduce_group(rsqc_ctx **ctxs, int n, int *used_rccl) {
+    if (used_rccl) *used_rccl = 0;
+    if (!ctxs || n < 1 || !ctxs[0]) return RSQC_ERR_ARG;
+    rsqc_ctx *root = ctxs[0];
+    for (int i = 0; i < n; ++i) {
+        rsqc_ctx *c = ctxs[i];
+        if (!c || !c->have_ann || !c->finalized) return RSQC_ERR_ARG;
+        if (c->arena_bytes != root->arena_bytes || c->n_genes != root->n_genes || c->n_exons != root->n_exons)
+            return fail(root, RSQC_ERR_ARG, "rsqc_reduce_group: the contexts hold different annotations");
+    }
+    bool distinct = true;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
+    RcclApi &R = rccl_api();
+    if (R.ok && distinct) {
+        std::vector<int> devs((size_t)n);
+        for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
+        std::vector<ncclComm_t> comms((size_t)n, nullptr);
+        ncclResult_t r = R.CommInitAll(comms.data(), n, devs.data());
+        if (r != ncclSuccess) return fail(root, RSQC_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
+        // the three reducible ranges of the arena (rsqc_device_vectors): u64 counts | f64 sums + owner-only statistics | u8 flags
+        const size_t n_u64 = (root->off_exon - root->off_u64) / 8, n_f64 = (root->off_gvalid - root->off_exon) / 8, n_u8 = root->off_ehit - root->off_gvalid;
+        r = R.GroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i) {
+            rsqc_ctx *c = ctxs[i];
+            char *A = (char *)c->d_arena.p;
+            (void)hipSetDevice(c->device);
+            r = R.Reduce(A + c->off_u64, A + c->off_u64, n_u64, ncclUint64, ncclSum, 0, comms[(size_t)i], c->stream);
+            if (r == ncclSuccess) r = R.Reduce(A + c->off_exon, A + c->off_exon, n_f64, ncclFloat64, ncclSum, 0, comms[(size_t)i], c->stream);
+            if (r == ncclSuccess) r = R.Reduce(A + c->off_gvalid, A + c->off_gvalid, n_u8, ncclUint8, ncclSum, 0, comms[(size_t)i], c->stream);
+        }
+        const ncclResult_t re = R.GroupEnd();
+        if (r == ncclSuccess) r = re;
+        int rc = RSQC_OK;
+        for (int i = 0; i < n; ++i) {
+            rsqc_ctx *c = ctxs[i];
+            (void)hipSetDevice(c->device);
+            if (hipStreamSynchronize(c->stream) != hipSuccess && rc == RSQC_OK) rc = fail(root, RSQC_ERR_HIP, "hipStreamSynchronize after the RCCL reduction failed");
+        }
+        for (int i = 0; i < n; ++i) if (comms[(size_t)i]) (void)R.CommDestroy(comms[(size_t)i]);
+        if (r != ncclSuccess) return fail(root, RSQC_ERR_HIP, std::string("ncclReduce: ") + R.GetErrorString(r));
+        if (rc) return rc;
+        for (int i = 1; i < n; ++i) {               // the device error flags travel too: a shard's failure is the run's failure
+            int err = 0;
+            HIP_TRY(ctxs[i], hipSetDevice(ctxs[i]->device));
+            HIP_TRY(ctxs[i], hipMemcpy(&err, ctxs[i]->acc.error, sizeof(int), hipMemcpyDeviceToHost));
+            if (err) { root->sticky = err; return fail(root, err, "a shard reported a device-side error"); }
+        }
+        HIP_TRY(root, hipSetDevice(root->device));
+        if (used_rccl) *used_rccl = 1;
+        return RSQC_OK;
+    }
+    for (int i = 1; i < n; ++i) { const int rc = rsqc_reduce_peer(root, ctxs[i]); if (rc != RSQC_OK) return rc; }
     return RSQC_OK;
 }
 

@@ -322,6 +322,10 @@ classify_ei_kernel(K1Args A) {
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     S.T.init(0u);
+#ifdef RSQC_K1_PROF
+    if (threadIdx.x < 48) s_prof_acc[threadIdx.x] = 0ull;
+    if (l == 0) s_prof_last[wave] = __builtin_amdgcn_s_memtime();
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) *k1e_lazy_args()->acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
     __syncthreads();
 
@@ -388,6 +392,7 @@ classify_ei_kernel(K1Args A) {
     asm volatile("" :: "v"(cg[0]), "v"(cg[1]), "v"(cg[2]), "v"(cg[3]), "v"(cg[4]), "v"(cg[5]), "v"(cg[6]), "v"(cg[7]));
 #endif
     for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
+        RSQC_MARK(0);
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
         {
@@ -404,6 +409,7 @@ classify_ei_kernel(K1Args A) {
         if (i + 128ull < wend) n_co = ld32(core1 + 4 * (w0 + 128), 4u * (uint32_t)l + 3u);
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
+        RSQC_MARK(1);
         Record r;
         {
             const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
@@ -428,13 +434,16 @@ classify_ei_kernel(K1Args A) {
         if (valid && !ok) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_ARG);
         const bool lane_on = valid && ok;
         if (!lane_on) r.n_cigar = 0;
+        RSQC_MARK(2);
         Walk2 w2;
         k1e_walk(r.pos, r.n_cigar, cg, r.cigar, w2);
+        RSQC_MARK(3);
         const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: k1e_process_long
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad;
         RecordCounters rc; bool hq = false;
         bool go = gate_cascade<false, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
+        RSQC_MARK(4);
         if (!lane_on) { go = false; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
         if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
             const K1Args *q = k1e_lazy_args();
@@ -465,6 +474,7 @@ classify_ei_kernel(K1Args A) {
                 l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
             }
         }
+        RSQC_MARK(5);
         const uint32_t flhq = r.flag | (hq ? K1E_HQ : 0u);
         const bool mine = go && r.tid == u_tid;              // stragglers of a boundary tile: general code
         // ---- sort by shape ------------------------------------------------------------------------------------------
@@ -490,6 +500,7 @@ classify_ei_kernel(K1Args A) {
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
+        RSQC_MARK(6);
         // ---- the staged words have landed (see above): from here on they are the current tile ----------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
@@ -498,24 +509,31 @@ classify_ei_kernel(K1Args A) {
         cur_cv = n_cv; cur_av = n_av; nx_co = n_co;
 #pragma unroll
         for (int k = 0; k < 8; ++k) cg[k] = n_cg[k];
+        RSQC_MARK(7);
         // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
         //      (the queued records belong to it) and at the end of the range ------------------------------------------------
         const bool leaving = w0 + 64ull >= wend || (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0 + 64ull);
         const uint32_t thr = leaving ? 1u : 64u;
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
+            RSQC_MARK(8);
             if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
+            RSQC_MARK(9);                          // [9] one-block tiles
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
+            RSQC_MARK(8);
             if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
+            RSQC_MARK(10);                         // [10] two-block tiles
         }
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
+            RSQC_MARK(8);
             if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, my_pair_gene, my_pair_hash, chunk_cap);
             h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
+            RSQC_MARK(11);                         // [11] long-CIGAR tiles
             if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
         }
     }
@@ -524,8 +542,14 @@ classify_ei_kernel(K1Args A) {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
         if (l == 0) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
     }
+    RSQC_MARK(12);
     __syncthreads();
     S.T.flush();
+#ifdef RSQC_K1_PROF
+    RSQC_MARK(13);                                 // [13] workgroup epilogue (barrier + flush of the LDS tables)
+    __syncthreads();
+    if (threadIdx.x < 48 && s_prof_acc[threadIdx.x]) atomicAdd(&g_k1_prof[threadIdx.x], s_prof_acc[threadIdx.x]);
+#endif
     if (threadIdx.x == 0) {
         const K1Args *q = k1e_lazy_args();
         atomicMax(&q->acc.rl_stats[0], S.T.rl[0]); atomicMin(&q->acc.rl_stats[1], S.T.rl[1]); atomicMax(&q->acc.rl_stats[2], S.T.rl[2]);

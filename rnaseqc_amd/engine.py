@@ -49,6 +49,7 @@ def load_library():
         lib.rsqc_device_vectors.argtypes = [vp, C.POINTER(abi.DeviceRange * 3)]
         lib.rsqc_shard_summary.argtypes = [vp, C.POINTER(abi.ShardInfoStruct)]
         lib.rsqc_reduce_peer.argtypes = [vp, vp]
+        lib.rsqc_reduce_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
         lib.rsqc_finalize_device.argtypes = [vp]
         lib.rsqc_host_alloc.argtypes = [C.c_size_t]; lib.rsqc_host_alloc.restype = vp
@@ -70,7 +71,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_set_reference", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_reduce_group", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
     "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end", "rsqc_debug_last_decoded", "rsqc_debug_read_device",
 ]
@@ -229,6 +230,15 @@ class Engine:
     def finalize_device(self):
         """End-of-file stage without the read-back (the distributed path reduces first, then refresh_results())."""
         self._check(self._l.rsqc_finalize_device(self._h))
+
+    @staticmethod
+    def reduce_group(engines) -> bool:
+        """rsqc_reduce_group over the contexts of `engines` (all past finalize_device): results summed onto engines[0].
+        Returns True when the RCCL path was taken (False: peer copies)."""
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        used = C.c_int(0)
+        engines[0]._check(engines[0]._l.rsqc_reduce_group(arr, len(engines), C.byref(used)))
+        return bool(used.value)
 
     def refresh_results(self, lazy: bool = False) -> abi.Results:
         rs = abi.ResultsStruct()

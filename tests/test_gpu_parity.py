@@ -188,6 +188,41 @@ def test_contig_ownership_shards(oracle_lib):
     np.testing.assert_array_equal(r0.bias_three + r1.bias_three, whole.bias_three)
 
 
+def test_group_reduce_rccl_and_peer_paths(oracle_lib):
+    """rsqc_reduce_group, the exchange step of `rnaseqc --gpus N`: (i) a group of ONE context takes the RCCL path (librccl bound at
+    run time, ncclCommInitAll, three ncclReduce in a group call on the context's stream) and leaves the results what they were;
+    (ii) two contexts sharded by contig on the box's one device cannot share a communicator and take the peer-copy path: the sum
+    on the first context equals the unsharded run.  (Two devices, RCCL path: the same code with n = 2.)"""
+    ann, batch = small_inputs(n_pairs=8000)
+    p = abi.default_params()
+    whole = oracle_lib.run_oracle(p, ann, [batch])
+    e = engine.Engine(p)
+    try:
+        e.set_annotation(ann)
+        e.submit(batch); e.wait()
+        e.finalize_device()
+        assert engine.Engine.reduce_group([e]) is True          # RCCL, one rank
+        assert_results_match(e.refresh_results(), whole)
+    finally:
+        e.close()
+    tid = batch.tid_per_record()
+    a_end = int(np.searchsorted(tid, 1))
+    e0, e1 = engine.Engine(p), engine.Engine(p)
+    try:
+        e0.set_annotation(ann, np.array([1, 0, 0], np.uint8)); e1.set_annotation(ann, np.array([0, 1, 1], np.uint8))
+        e0.submit(batch.slice(0, a_end)); e1.submit(batch.slice(a_end, batch.n)); e0.wait(); e1.wait()
+        e0.finalize_device(); e1.finalize_device()
+        assert engine.Engine.reduce_group([e0, e1]) is False     # same device twice: peer copies
+        got = e0.refresh_results()
+        np.testing.assert_array_equal(got.gene_reads, whole.gene_reads)
+        np.testing.assert_array_equal(got.gene_fragments, whole.gene_fragments)
+        np.testing.assert_array_equal(got.counters, whole.counters)
+        np.testing.assert_allclose(got.exon_reads, whole.exon_reads, rtol=1e-9, atol=1e-6)
+        np.testing.assert_array_equal(got.gene_cov_valid, whole.gene_cov_valid)
+    finally:
+        e0.close(); e1.close()
+
+
 def test_chr1_scale_million_reads(oracle_lib):
     ann = synth.make_annotation(seed=1)                       # chr1-like: 5 234 genes
     batch = synth.make_reads(ann, 500_000, seed=2)

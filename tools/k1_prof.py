@@ -14,8 +14,9 @@ ann = synth.make_annotation(seed=1, contigs=contigs)
 batch = synth.make_reads(ann, args.pairs, seed=2) if args.chr1 else synth.make_reads_sharded(ann, args.pairs, seed=2, workers=24)[0]
 e = engine.Engine(abi.default_params()); e.set_annotation(ann); h = e.upload(batch)
 lib = engine.load_library()
-names = ["loop+flush", "load-wait+unpack+cigar+gate", "gate counters+RL", "bins load", "round0", "round1", "round2", "round3",
-         "feature epilogue", "class bits/ovf", "stage next tile", "commit slots", "gene hits", "tail flush", "wg epilogue", ""]
+names = ["loop tail (prev. tile)", "segments + issue next loads", "unpack", "CIGAR walk", "gate cascade", "sums + Read-Length (+BED)",
+         "sort by shape + queues", "landing wait", "(before a feature stage)", "one-block tiles", "two-block tiles", "long-CIGAR tiles",
+         "tail flush", "wg epilogue", "", ""]
 for rep in range(2):
     e.reset(); lib.rsqc_debug_k1_prof(None, 1); e.submit_resident(h); e.wait()
 out = (C.c_ulonglong * 48)(); lib.rsqc_debug_k1_prof(out, 0)
