@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSQC_ABI_VERSION 1
+#define RSQC_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define RSQC_API __attribute__((visibility("default")))
@@ -499,6 +499,10 @@ typedef struct rsqc_decode_window {    /* what one rsqc_decode_submit decoded (a
     uint64_t n_records;
     uint32_t n_runs;                   /* runs of consecutive records on one reference sequence ...            */
     const int32_t *run_tid;            /* ... their RefIDs, in file order (the batch's contig segments)        */
+    rsqc_batch device_batch;           /* the decoded records as the boundary's SoA batch, every pointer a DEVICE pointer into the
+                                          context's window buffers (valid until its next decode call; n == n_records): what the
+                                          per-read kernels were given -- a host that wants the columns copies them out with
+                                          hipMemcpy after rsqc_wait                                             */
 } rsqc_decode_window;
 typedef struct rsqc_decode_info {
     rsqc_decode_window last;           /* pipelined streams: what the last rsqc_decode_submit decoded            */
@@ -519,11 +523,6 @@ RSQC_API int rsqc_decode_begin(rsqc_ctx *ctx, const rsqc_decode_params *p);
 RSQC_API int rsqc_decode_submit(rsqc_ctx *ctx, const void *compressed, uint64_t compressed_bytes,
                                 const rsqc_bgzf_block *blocks, uint32_t n_blocks,
                                 uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out);
-/* Test hook: the batch the last rsqc_decode_submit produced, as DEVICE pointers (valid until the next decode call). */
-RSQC_API int rsqc_debug_last_decoded(rsqc_ctx *ctx, rsqc_batch *out);
-/* Test hook: bytes from a device pointer of this context's device (through the library's own HIP runtime, which a
- * process that also loads another copy of the runtime -- PyTorch's -- cannot reach otherwise).                    */
-RSQC_API int rsqc_debug_read_device(rsqc_ctx *ctx, void *dst, const void *src_device, uint64_t bytes);
 /* End of the stream: RSQC_ERR_INPUT if an incomplete record is left over ("truncated BAM record").             */
 RSQC_API int rsqc_decode_end(rsqc_ctx *ctx, rsqc_decode_info *out);
 

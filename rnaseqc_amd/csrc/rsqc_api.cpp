@@ -104,7 +104,7 @@ struct DecodeState {
     std::chrono::steady_clock::time_point pend_wall0;
     hipStream_t copy_stream = nullptr; hipEvent_t ev_copy = nullptr;
     std::vector<int32_t> run_tid;      // contig segments of the last window
-    rsqc_batch last{};                 // the last window's batch (device pointers), for rsqc_debug_last_decoded
+    rsqc_batch last{};                 // the last window's batch (device pointers): rsqc_decode_window::device_batch
 };
 
 }  // namespace
@@ -581,13 +581,11 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.unpaired = params->unpaired;
     c->dparams.exclude_chimeric = params->exclude_chimeric;
     c->dparams.n_filter_tags = params->n_filter_tags;
-    c->dparams.dbg = 0;
     c->dparams.legacy = params->legacy ? 1 : 0;
     c->pair_arena.n_col = 2; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8;                       // gene, name hash
     c->frag_arena.n_col = 5; { const size_t w[5] = {8, 8, 4, 4, 4}; for (int k = 0; k < 5; ++k) c->frag_arena.width[k] = w[k]; }
     c->gc_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->gc_arena.width[k] = w[k]; }
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
-    if (const char *e = getenv("RSQC_DEBUG_MASK")) c->dparams.dbg = (uint32_t)strtoul(e, nullptr, 0);   // profiling ablations only
     *out = c;
     return RSQC_OK;
 }
@@ -1432,11 +1430,12 @@ int decode_finish(rsqc_ctx *c, rsqc_decode_window *out) {
     }
     D.run_tid.assign(S.n_seg, 0);
     if (S.n_seg) HIP_TRY(c, hipMemcpy(D.run_tid.data(), D.seg_tid.p, (size_t)S.n_seg * 4, hipMemcpyDeviceToHost));
-    if (out) { out->n_records = S.n_rec; out->n_runs = S.n_seg; out->run_tid = D.run_tid.data(); }
+    if (out) { out->n_records = S.n_rec; out->n_runs = S.n_seg; out->run_tid = D.run_tid.data(); out->device_batch = rsqc_batch{}; }
     if (S.n_rec) {
         D.last.n = S.n_rec; D.last.file_index_base = D.next_file_index; D.last.core = W.core; D.last.aux = W.aux; D.last.cigar = W.cigar;
         D.last.n_cigar_total = S.n_ops; D.last.n_seg = S.n_seg; D.last.seg_tid = W.seg_tid; D.last.seg_start = W.seg_start;
         D.last.n_wide = S.n_wide; D.last.wide_index = W.wide_index; D.last.wide_nm = W.wide_nm; D.last.wide_l_qseq = W.wide_lq; D.last.wide_n_cigar = W.wide_nc;
+        if (out) out->device_batch = D.last;
         UploadedBatch *u = new UploadedBatch();
         u->pooled = false;
         u->n = S.n_rec; u->n_cigar_total = S.n_ops; u->file_index_base = D.next_file_index;
@@ -1469,7 +1468,7 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     if (c->sticky) return c->sticky;
     DecodeState &D = c->dec;
     if (!D.active) return fail(c, RSQC_ERR_ARG, "rsqc_decode_begin must precede rsqc_decode_submit");
-    if (out) { out->n_records = 0; out->n_runs = 0; out->run_tid = nullptr; }
+    if (out) { out->n_records = 0; out->n_runs = 0; out->run_tid = nullptr; out->device_batch = rsqc_batch{}; }
     D.last = rsqc_batch{};
     HIP_TRY(c, hipSetDevice(c->device));
     uint64_t total = 0, raw_total = 0;
@@ -1540,20 +1539,6 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     // the caller's buffer is free again once the copy is through (the copy engine works beside the kernels)
     HIP_TRY(c, hipStreamSynchronize(D.copy_stream));
     if (!D.pipelined) return decode_finish(c, out);
-    return RSQC_OK;
-}
-
-int rsqc_debug_last_decoded(rsqc_ctx *c, rsqc_batch *out) {
-    if (!c || !out) return RSQC_ERR_ARG;
-    *out = c->dec.last;
-    return RSQC_OK;
-}
-
-int rsqc_debug_read_device(rsqc_ctx *c, void *dst, const void *src_device, uint64_t bytes) {
-    if (!c || (!dst && bytes) || (!src_device && bytes)) return RSQC_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (bytes) HIP_TRY(c, hipMemcpy(dst, src_device, (size_t)bytes, hipMemcpyDeviceToHost));
     return RSQC_OK;
 }
 

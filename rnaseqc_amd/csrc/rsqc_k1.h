@@ -54,6 +54,16 @@ static const K1Args *g_k1e_args = nullptr;       // (host emulation: set by the 
 static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
 
+// eight CIGAR operations of one record in TWO loads (a 16-byte global load needs only dword alignment; eight separate
+// dword gathers were eight trips through the address unit)
+struct alignas(4) Cig4 { uint32_t v[4]; };
+__device__ __forceinline__ void k1e_load_cigar8(const uint32_t *cigar, uint32_t off, uint32_t (&c)[8]) {
+    const char *const at = reinterpret_cast<const char *>(cigar) + (uint32_t)(off * 4u);       // buffers carry 32 bytes of slack
+    const Cig4 lo = *reinterpret_cast<const Cig4 *>(at), hi = *reinterpret_cast<const Cig4 *>(at + 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = lo.v[k]; c[4 + k] = hi.v[k]; }
+}
+
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
 constexpr int K1E_QCAP = 128;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
 constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
@@ -122,7 +132,7 @@ struct K1eShared {
     uint4 q1[K1E_WAVES][K1E_QCAP];               // one block:  bs, len, record index, flhq
     uint4 q2[K1E_WAVES][K1E_QCAP];               // two blocks: bs0, len0, bs1, len1
     uint2 q2x[K1E_WAVES][K1E_QCAP];              //             record index, flhq
-    uint2 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq
+    uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
 };
 
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
@@ -152,6 +162,12 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
         if (NB == 1) {
             const Run r = make_run(hv, eo.eid[k]);
             if (r.head && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)r.count);
+            // a one-block record that commits slot 0 is counted to that exon's gene (hit[0], see exon_metrics_ei: the first gene of
+            // the set is the gene of the block's first containing exon): the exon's run serves the gene counters too
+            if (k == 0) {
+                const uint64_t nd = __ballot(hv && notdup);
+                if (r.head && !(K1E_ABL & 2)) T.gene_add(eo.hit[0], r.count, (uint32_t)__popcll(nd & r.mask));
+            }
         } else if (hv && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)ln * inv_aligned);
         const uint32_t base = hv ? eo.cidx[k] : 0u;
         if (!(K1E_ABL & 4)) {
@@ -176,7 +192,7 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
                 else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
             }
         }
-        {
+        if (NB > 1 || k > 0) {
             const Run r = make_run(has, g);
             const uint64_t nd = __ballot(has && notdup);
             if (r.head && !(K1E_ABL & 2)) T.gene_add(g, r.count, (uint32_t)__popcll(nd & r.mask));
@@ -232,13 +248,15 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
                                                  uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
     const int l = lane_id();
     const bool on0 = (uint32_t)l < n;
-    uint2 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
-    if (!on0) { it.x = 0u; it.y = 0u; }
+    uint4 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
+    if (!on0) it = make_uint4(0u, 0u, 0u, 0u);
+    // the queue carries the record words the walk needs, so the CIGAR is the only dependent gather; the name hash and the
+    // operation count ride in the auxiliary half-record, fetched beside it
     const uint32_t idx = it.x, fl = it.y & 0xFFFFu; const bool hq = (it.y & K1E_HQ) != 0;
-    const int4 cv = ld32(reinterpret_cast<const int4 *>(b.core), idx), av = ld32(reinterpret_cast<const int4 *>(b.aux), idx);
+    struct { int32_t x; uint32_t w; } cv = {(int32_t)it.z, it.w};
+    const int4 av = ld32(reinterpret_cast<const int4 *>(b.aux), idx);
     uint32_t cg[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, (uint32_t)cv.w + (uint32_t)k);
+    k1e_load_cigar8(b.cigar, cv.w, cg);
     uint32_t n_cigar = (uint32_t)av.w >> 24;
     bool ok = true;
     if (on0 && n_cigar == RSQC_NCIGAR_ESCAPE) {
@@ -357,10 +375,14 @@ classify_ei_kernel(K1Args A) {
     uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
     int32_t u_tid = -1;
     ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t seg_next = ~0ull;                            // first record of the next segment: kept in scalar registers, so that the
+                                                          // per-tile boundary tests are compares (a scalar load per tile also waits,
+                                                          // through the shared lgkmcnt, for every LDS operation in flight)
     auto load_contig = [&]() {
         u_tid = b.n_seg ? b.seg_tid[seg] : -1;
         if (u_tid >= 0 && u_tid < a.n_contigs) u_ci = a.contig[u_tid];
         else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
+        seg_next = seg + 1 < b.n_seg ? b.seg_start[seg + 1] : ~0ull;
     };
     load_contig();
     uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0, h3 = 0, c3 = 0;   // queue heads and fills (wave-uniform)
@@ -380,11 +402,7 @@ classify_ei_kernel(K1Args A) {
     const uint32_t *const core1 = reinterpret_cast<const uint32_t *>(b.core);
     if (wbeg + (uint64_t)l < wend) { cur_cv = ld32(core4 + wbeg, (uint32_t)l); cur_av = ld32(aux4 + wbeg, (uint32_t)l); }
     if (wbeg + 64ull + (uint64_t)l < wend) nx_co = ld32(core1 + 4 * (wbeg + 64), 4u * (uint32_t)l + 3u);
-    {
-        const uint32_t co = (uint32_t)cur_cv.w;                          // buffers carry 32 bytes of slack
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cg[k] = ld32(b.cigar, co + (uint32_t)k);
-    }
+    k1e_load_cigar8(b.cigar, (uint32_t)cur_cv.w, cg);
     // (the wait of the first tile's words sits here, not in the loop: the compiler places a wait where ANY path into an
     //  instruction has the load pending, and a wait inside the loop is executed by every tile)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -395,17 +413,15 @@ classify_ei_kernel(K1Args A) {
         RSQC_MARK(0);
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
-        {
-            bool moved = false;
-            while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) { ++seg; moved = true; }
-            if (moved) load_contig();                       // (the queues were emptied by the tile before the boundary)
+        if (seg_next <= w0) {                               // (the queues were emptied by the tile before the boundary)
+            while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;
+            load_contig();
         }
-        const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
+        const bool mixed = seg_next < w0 + 64ull;           // a contig boundary inside the tile
         // ---- the next tile's words start their trip now -----------------------------------------------------------------
         int4 n_cv = zero4, n_av = zero4; uint32_t n_cg[8]; uint32_t n_co = 0;
         if (i + 64ull < wend) { n_cv = ld32(core4 + w0 + 64, (uint32_t)l); n_av = ld32(aux4 + w0 + 64, (uint32_t)l); }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) n_cg[k] = ld32(b.cigar, nx_co + (uint32_t)k);
+        k1e_load_cigar8(b.cigar, nx_co, n_cg);
         if (i + 128ull < wend) n_co = ld32(core1 + 4 * (w0 + 128), 4u * (uint32_t)l + 3u);
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
@@ -496,7 +512,7 @@ classify_ei_kernel(K1Args A) {
             S.q2[wave][slot] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)w2.bs1, w2.len1);
             S.q2x[wave][slot] = make_uint2((uint32_t)i, flhq);
         }
-        if (listed) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint2((uint32_t)i, flhq);
+        if (listed) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)i, flhq, (uint32_t)r.pos, (uint32_t)(r.cigar - b.cigar));
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
@@ -512,7 +528,7 @@ classify_ei_kernel(K1Args A) {
         RSQC_MARK(7);
         // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
         //      (the queued records belong to it) and at the end of the range ------------------------------------------------
-        const bool leaving = w0 + 64ull >= wend || (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0 + 64ull);
+        const bool leaving = w0 + 64ull >= wend || seg_next <= w0 + 64ull;
         const uint32_t thr = leaving ? 1u : 64u;
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;

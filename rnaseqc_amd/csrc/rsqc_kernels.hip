@@ -258,7 +258,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             aligned = cw.aligned;
             if (!lane_on || r.tid != u_tid) B.nb = 0;          // (stragglers of a boundary tile go to the general code: no look-up here)
             if (!LEGACY) fast_load_bins(a, u_ci, B, fb_early);  // round 1 of the overlap query: in flight during the gate cascade
-            go = gate_cascade<LEGACY, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on) && !(p.dbg & 8u);
+            go = gate_cascade<LEGACY, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
             fl = r.flag; tid = r.tid;
             notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
             if (!lane_on) { B.nb = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
@@ -332,8 +332,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (hm == 0ull) continue;
             struct { uint32_t row, cidx, len; } cm = {fo.row[k], fo.cidx[k], B.len[k >> 1]};
             const bool hv = has && cm.len > 0;
-            if (hv && !(p.dbg & (2u | 1024u))) S.exon_add(acc, a.ex_id, cm.row, (double)cm.len * inv_aligned);
-            if (!(p.dbg & 1u)) {                 // +1 at the block start, -1 after its last base
+            if (hv) S.exon_add(acc, a.ex_id, cm.row, (double)cm.len * inv_aligned);
+            {                                    // +1 at the block start, -1 after its last base
                 const uint32_t base = hv ? cm.cidx : 0u;
                 cov_add_merged(acc.cov_diff, hv, base, 1u);
                 cov_add_merged(acc.cov_diff, hv, base + cm.len, 0xFFFFFFFFu);
@@ -346,7 +346,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             const uint64_t m = __ballot(has);
             if (m == 0ull) break;
             const uint32_t g = fo.hit[k];
-            if (!(p.dbg & 2048u)) {
+            {
                 // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
                 const int lead = __ffsll((unsigned long long)m) - 1;
                 uint32_t base = 0;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                     else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                 }
             }
-            if (has && !(p.dbg & 4096u)) S.gene_add(acc, g, notdup);
+            if (has) S.gene_add(acc, g, notdup);
         }
         RSQC_MARK(12);                             // [12] gene hits: pairs + gene counters
         // ---- the tile's one-per-record counters: lane c holds counter c's increment (one LDS instruction) ----
@@ -484,7 +484,6 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     uint32_t *const s_key = SH.key; double *const s_val = SH.val; uint32_t *const s_ckey = SH.ckey, *const s_cval = SH.cval;
     uint64_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
     if (LEGACY) n = b.n;
-    if (p.dbg & 64u) n = 0;
     if ((uint64_t)blockIdx.x * blockDim.x >= n) return;  // nothing for this workgroup (the usual case for most of the grid)
     for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x) { s_key[i] = 0xFFFFFFFFu; s_val[i] = 0.0; }
     for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x) { s_ckey[i] = 0xFFFFFFFFu; s_cval[i] = 0u; }
@@ -515,7 +514,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                     if (rc.error) atomicExch(acc.error, rc.error);
                     if (rc.blocks) atomicAdd(&acc.counters[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)rc.blocks);
                 }
-                if (go && !(p.dbg & 16u)) {
+                if (go) {
                     notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
                     bool overflow = false;
                     if (LEGACY) {
@@ -554,16 +553,14 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
         }
         // ---- scatter of the first-tier results: few records, so exon fractions and coverage go out as
         //      plain atomics; gene counts and pair slots are aggregated per wave (same-address traffic)
-        if (p.dbg & 32u) { fm.n_commit = 0; fm.n_hit = 0; }
         for (int j = 0; j < fm.n_commit; ++j) {
             const Commit cm = fm.commit[j];
-            if (cm.len > 0 && !(p.dbg & 128u)) exon_add_lds(cm.row, (double)cm.len / (double)aligned);
-            if (!(p.dbg & 256u) && cm.len > 0) {
+            if (cm.len > 0) exon_add_lds(cm.row, (double)cm.len / (double)aligned);
+            if (cm.len > 0) {
                 const uint32_t base = cm.cidx;
                 cov_add_lds(base, 1u); cov_add_lds(base + cm.len, 0xFFFFFFFFu);
             }
         }
-        if (p.dbg & 512u) fm.n_hit = 0;
         {
             const uint64_t nd_mask = __ballot(notdup);
 #pragma unroll

@@ -143,7 +143,6 @@ struct DevParams {
     uint32_t mapq_threshold, base_mismatch;
     int32_t  chimeric_distance;
     int32_t  stranded, unpaired, exclude_chimeric, n_filter_tags;
-    uint32_t dbg;      // profiling ablations (RSQC_DEBUG_MASK); 0 in every real run
     int32_t  legacy;   // --legacy rules (rsqc_params.legacy)
 };
 
@@ -678,9 +677,9 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
     const bool nonglobin = !over && B.nb >= 1 && !(ga || gb);                              // :363,395-404
     RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, nonglobin);
     RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, nonglobin && (fl & RSQC_FDUP) != 0);
-    if (hq && nlast > 0 && !(p.dbg & 4u)) {                                                // :377-392
+    if (hq && nlast > 0) {                                                                 // :377-392
         out.cmask = con & ((va ? ma : 0u) | (vb ? mb : 0u));
-        if (aligned > 0 && !(p.dbg & 2u)) {
+        if (aligned > 0) {
             out.hit[0] = va ? la : lb; out.hit[1] = lb;
             out.n_hit = nlast;
         }
@@ -896,7 +895,7 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
         }
     }
     // commit (only HQ records counted to at least one gene, :377-392)
-    if (hq && nlast > 0 && !(p.dbg & 4u)) {
+    if (hq && nlast > 0) {
         if (!st_over) {
 #pragma unroll
             for (int k = 0; k < NSTAGE; ++k) {
@@ -918,14 +917,14 @@ RSQC_HD void exon_metrics(const DevAnnotation &a, const DevParams &p, const Reco
                         if (!contained) return;
                         const uint32_t g = row.gf & ROW_GENE_MASK;
                         if (!set_contains<K>(last, nlast, g)) return;
-                        if (len > 0 && !(p.dbg & 2u)) acc.exon_add(row_i, (double)len / (double)aligned);   // :345
-                        if (!(p.dbg & 1u)) acc.cov_range(row.cov + (uint32_t)(bs - row.start), len);
+                        if (len > 0) acc.exon_add(row_i, (double)len / (double)aligned);   // :345
+                        acc.cov_range(row.cov + (uint32_t)(bs - row.start), len);
                     });
                 }
                 if (cigar_is_ref(op)) start += (int32_t)len;
             }
         }
-        if (aligned > 0 && !(p.dbg & 2u)) {                // Collector::queryGene, :380
+        if (aligned > 0) {                                 // Collector::queryGene, :380
 #pragma unroll
             for (int k = 0; k < K; ++k) out.hit[k] = last[k];
             out.n_hit = nlast;

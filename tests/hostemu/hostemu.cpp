@@ -78,7 +78,7 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     hx.build_rank(rank);
     d.ei = hx.ei.data(); d.ei_rank = rank.data();
     std::vector<double> exon_ids((size_t)a->n_exons, 0.0);       // by exon id (the elementary-interval stage commits by id)
-    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u,
+    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags,
                  p->legacy ? 1 : 0};
     if (hx.gr_rows.empty()) hx.gr_rows.push_back(GeneRow{0, 0, 0, 0});
     if (hx.g_pmax.empty()) hx.g_pmax.push_back(0);

@@ -56,7 +56,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     d.ex_id = ex_id.data();
     std::vector<uint32_t> zero_range((size_t)a->n_contigs + 1, 0);
     d.bed_range = zero_range.data(); d.have_bed = 0;
-    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0u, 0};
+    DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0};
 
     // the batch with the slack the device buffers carry (kernels read a few entries past the end with ignored loads)
     const uint64_t n = b->n;
