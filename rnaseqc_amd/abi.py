@@ -143,7 +143,7 @@ class DecodeParams(C.Structure):
 
 
 class DecodeWindow(C.Structure):
-    _fields_ = [("n_records", C.c_uint64), ("n_runs", C.c_uint32), ("run_tid", _P)]
+    _fields_ = [("n_records", C.c_uint64), ("n_runs", C.c_uint32), ("run_tid", _P), ("device_batch", BatchStruct)]
 
 
 class DecodeInfo(C.Structure):

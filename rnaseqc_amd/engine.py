@@ -16,6 +16,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSQC_LIB") or os.path.join(_HERE, "lib", "librnaseqc_amd.so")   # RSQC_LIB: a diagnostic build (make prof)
 _lib = None
+_hip = None
 
 
 class EngineError(RuntimeError):
@@ -62,8 +63,6 @@ def load_library():
         lib.rsqc_decode_begin.argtypes = [vp, C.POINTER(abi.DecodeParams)]
         lib.rsqc_decode_submit.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(abi.DecodeWindow)]
         lib.rsqc_decode_end.argtypes = [vp, C.POINTER(abi.DecodeInfo)]
-        lib.rsqc_debug_last_decoded.argtypes = [vp, C.POINTER(abi.BatchStruct)]
-        lib.rsqc_debug_read_device.argtypes = [vp, vp, vp, C.c_uint64]
         _lib = lib
     return _lib
 
@@ -73,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
     "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_reduce_group", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
-    "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end", "rsqc_debug_last_decoded", "rsqc_debug_read_device",
+    "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end",
 ]
 
 
@@ -170,6 +169,7 @@ class Engine:
             baddr, nb = blocks.ctypes.data, len(blocks)
         w = abi.DecodeWindow()
         self._check(self._l.rsqc_decode_submit(self._h, caddr, cbytes, baddr, nb, skip, limit, C.byref(w)))
+        self._last_window = w
         runs = list(np.ctypeslib.as_array(C.cast(w.run_tid, C.POINTER(C.c_int32)), (w.n_runs,))) if w.n_runs else []
         return int(w.n_records), [int(t) for t in runs]
 
@@ -188,17 +188,23 @@ class Engine:
         return int(info.records), bool(info.unsorted), int(info.n_bad_refid), names
 
     def read_device(self, ptr, count, dtype):
-        """count items of dtype from a device pointer (test hook)."""
+        """count items of dtype from a device pointer of this context (tests): hipMemcpy of the HIP runtime the library itself is
+        linked against, after rsqc_wait."""
         out = np.zeros(count, dtype)
         if count:
-            self._check(self._l.rsqc_debug_read_device(self._h, out.ctypes.data, ptr, out.nbytes))
+            global _hip
+            if _hip is None:
+                _hip = C.CDLL("libamdhip64.so")
+                _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            self.wait()
+            rc = _hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2)     # hipMemcpyDeviceToHost
+            if rc:
+                raise EngineError(abi.ERR_HIP if hasattr(abi, "ERR_HIP") else -1, "hipMemcpy(device -> host) failed: %d" % rc)
         return out
 
     def last_decoded(self):
-        """abi.BatchStruct of DEVICE pointers: the batch of the last decode_submit (tests read it back with hipMemcpy)."""
-        s = abi.BatchStruct()
-        self._check(self._l.rsqc_debug_last_decoded(self._h, C.byref(s)))
-        return s
+        """abi.BatchStruct of DEVICE pointers: rsqc_decode_window.device_batch of the last decode_submit."""
+        return self._last_window.device_batch
 
     def upload(self, batch) -> int:
         s = batch.to_struct()
