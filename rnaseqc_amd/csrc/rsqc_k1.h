@@ -65,6 +65,7 @@ __device__ __forceinline__ void k1e_load_cigar8(const uint32_t *cigar, uint32_t 
 }
 
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
+constexpr uint64_t K1E_PIECE = 256;             // records a wave takes from its workgroup's range at a time (4 tiles)
 constexpr int K1E_QCAP = 128;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
 constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
 constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's flag word | K1E_HQ when high quality
@@ -86,12 +87,13 @@ struct K1eTables {
     uint32_t gkey[K1E_GSLOTS];
     uint32_t rl[3];
     uint32_t pairs;                              // pairs in the workgroup's chunk
+    uint32_t piece;                              // next piece of the workgroup's range to hand to a wave
     __device__ __forceinline__ void init(uint32_t pairs0) {
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
         if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
         for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
-        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; }
+        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; piece = 0u; }
     }
     __device__ __forceinline__ void exon_add(uint32_t eid, double frac) {
         const uint32_t slot = eid & (K1E_ESLOTS - 1);
@@ -365,10 +367,30 @@ classify_ei_kernel(K1Args A) {
         pending = 0;
     };
 
+    // A WORKGROUP owns a contiguous range of records (the same one as before: its pair chunk is sized for it); its waves take
+    // the range in PIECES of K1E_PIECE records from an LDS counter.  With one fixed quarter per wave the four waves finished
+    // up to 100 us apart (dense and sparse stretches cost differently) and waited for each other at the final barrier:
+    // 10.8 % of the kernel (profiles/r3_k1_sections_v2.txt).  A piece is still a contiguous, coordinate-sorted run.
     const uint64_t total_waves = (uint64_t)gridDim.x * K1E_WAVES;
     const uint64_t per_wave = (((b.n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
-    const uint64_t wbeg = ((uint64_t)blockIdx.x * K1E_WAVES + (uint64_t)wave) * per_wave;
-    const uint64_t wend = wbeg + per_wave < b.n ? wbeg + per_wave : b.n;
+    const uint64_t wg_beg = (uint64_t)blockIdx.x * K1E_WAVES * per_wave;
+    const uint64_t wg_end = wg_beg + K1E_WAVES * per_wave < b.n ? wg_beg + K1E_WAVES * per_wave : b.n;
+    constexpr uint64_t NONE = ~0ull;
+    auto take_piece = [&]() -> uint64_t {                 // first record of the next unclaimed piece, NONE when the range is used up
+        uint32_t c = 0;
+        if (l == 0) c = atomicAdd(&S.T.piece, 1u);
+        c = lane_value(c, 0);
+        const uint64_t at = wg_beg + (uint64_t)c * K1E_PIECE;
+        return at < wg_end ? at : NONE;
+    };
+    auto tile_after = [&](uint64_t t) -> uint64_t {       // the tile this wave works on after tile t
+        if (t == NONE) return NONE;
+        const uint64_t nx = t + 64ull;
+        if (nx < wg_end && ((nx - wg_beg) % K1E_PIECE) != 0ull) return nx;
+        return take_piece();
+    };
+    uint64_t w0 = wg_beg < wg_end ? take_piece() : NONE, w1 = tile_after(w0), w2 = tile_after(w1);
+    const uint64_t wbeg = w0 == NONE ? b.n : w0, wend = wg_end;
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
     uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
@@ -400,8 +422,8 @@ classify_ei_kernel(K1Args A) {
     uint32_t nx_co = 0;                                                   // CIGAR offset of this lane's record of the NEXT tile
     const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
     const uint32_t *const core1 = reinterpret_cast<const uint32_t *>(b.core);
-    if (wbeg + (uint64_t)l < wend) { cur_cv = ld32(core4 + wbeg, (uint32_t)l); cur_av = ld32(aux4 + wbeg, (uint32_t)l); }
-    if (wbeg + 64ull + (uint64_t)l < wend) nx_co = ld32(core1 + 4 * (wbeg + 64), 4u * (uint32_t)l + 3u);
+    if (w0 != NONE && w0 + (uint64_t)l < wend) { cur_cv = ld32(core4 + w0, (uint32_t)l); cur_av = ld32(aux4 + w0, (uint32_t)l); }
+    if (w1 != NONE && w1 + (uint64_t)l < wend) nx_co = ld32(core1 + 4 * w1, 4u * (uint32_t)l + 3u);
     k1e_load_cigar8(b.cigar, (uint32_t)cur_cv.w, cg);
     // (the wait of the first tile's words sits here, not in the loop: the compiler places a wait where ANY path into an
     //  instruction has the load pending, and a wait inside the loop is executed by every tile)
@@ -409,7 +431,7 @@ classify_ei_kernel(K1Args A) {
     asm volatile("" :: "v"(cur_cv.x), "v"(cur_cv.y), "v"(cur_cv.z), "v"(cur_cv.w), "v"(cur_av.x), "v"(cur_av.y), "v"(cur_av.z), "v"(cur_av.w), "v"(nx_co));
     asm volatile("" :: "v"(cg[0]), "v"(cg[1]), "v"(cg[2]), "v"(cg[3]), "v"(cg[4]), "v"(cg[5]), "v"(cg[6]), "v"(cg[7]));
 #endif
-    for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
+    for (; w0 != NONE; w0 = w1, w1 = w2, w2 = tile_after(w2)) {
         RSQC_MARK(0);
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
@@ -420,9 +442,9 @@ classify_ei_kernel(K1Args A) {
         const bool mixed = seg_next < w0 + 64ull;           // a contig boundary inside the tile
         // ---- the next tile's words start their trip now -----------------------------------------------------------------
         int4 n_cv = zero4, n_av = zero4; uint32_t n_cg[8]; uint32_t n_co = 0;
-        if (i + 64ull < wend) { n_cv = ld32(core4 + w0 + 64, (uint32_t)l); n_av = ld32(aux4 + w0 + 64, (uint32_t)l); }
+        if (w1 != NONE && w1 + (uint64_t)l < wend) { n_cv = ld32(core4 + w1, (uint32_t)l); n_av = ld32(aux4 + w1, (uint32_t)l); }
         k1e_load_cigar8(b.cigar, nx_co, n_cg);
-        if (i + 128ull < wend) n_co = ld32(core1 + 4 * (w0 + 128), 4u * (uint32_t)l + 3u);
+        if (w2 != NONE && w2 + (uint64_t)l < wend) n_co = ld32(core1 + 4 * w2, 4u * (uint32_t)l + 3u);
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
         RSQC_MARK(1);
@@ -528,7 +550,7 @@ classify_ei_kernel(K1Args A) {
         RSQC_MARK(7);
         // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
         //      (the queued records belong to it) and at the end of the range ------------------------------------------------
-        const bool leaving = w0 + 64ull >= wend || seg_next <= w0 + 64ull;
+        const bool leaving = w1 == NONE || seg_next <= w1;             // the wave's next tile lies in another segment (or there is none)
         const uint32_t thr = leaving ? 1u : 64u;
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;

@@ -194,7 +194,13 @@ class Engine:
         if count:
             global _hip
             if _hip is None:
-                _hip = C.CDLL("libamdhip64.so")
+                # the very copy of the HIP runtime the product library is running on (a process may hold a second one, e.g.
+                # PyTorch's bundled runtime, which knows nothing of this context's allocations)
+                path = "libamdhip64.so"
+                for line in open("/proc/self/maps"):
+                    if "libamdhip64" in line and "/torch/" not in line:
+                        path = line.split()[-1]; break
+                _hip = C.CDLL(path)
                 _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             self.wait()
             rc = _hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2)     # hipMemcpyDeviceToHost
