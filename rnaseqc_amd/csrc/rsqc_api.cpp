@@ -1224,7 +1224,17 @@ RcclApi &rccl_api() {
     if (tried) return A;
     tried = true;
     if (getenv("RSQC_NO_RCCL")) return A;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { A.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (A.lib) break; }
+    // the librccl that sits beside the HIP runtime THIS library runs on: a process may hold a second ROCm stack (PyTorch
+    // bundles its own runtime and RCCL), and a communicator of that one cannot touch this runtime's allocations
+    std::vector<std::string> names;
+    Dl_info di{};
+    if (dladdr(reinterpret_cast<const void *>(static_cast<hipError_t (*)(hipStream_t)>(&hipStreamSynchronize)), &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.find_last_of('/');
+        if (slash != std::string::npos) { dir.resize(slash + 1); names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
+    }
+    names.push_back("librccl.so.1"); names.push_back("librccl.so");
+    for (const std::string &name : names) { A.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL); if (A.lib) break; }
     if (!A.lib) return A;
 #define RSQC_RCCL_SYM(field, sym) A.field = reinterpret_cast<decltype(A.field)>(dlsym(A.lib, sym))
     RSQC_RCCL_SYM(CommInitAll, "ncclCommInitAll"); RSQC_RCCL_SYM(CommDestroy, "ncclCommDestroy"); RSQC_RCCL_SYM(GroupStart, "ncclGroupStart");
