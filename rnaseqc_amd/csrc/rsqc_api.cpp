@@ -585,7 +585,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->pair_arena.n_col = 2; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8;                       // gene, name hash
     c->frag_arena.n_col = 5; { const size_t w[5] = {8, 8, 4, 4, 4}; for (int k = 0; k < 5; ++k) c->frag_arena.width[k] = w[k]; }
     c->gc_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->gc_arena.width[k] = w[k]; }
-    if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(4096, std::max(1, atoi(e)));
+    if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(16384, std::max(1, atoi(e)));
     *out = c;
     return RSQC_OK;
 }

@@ -112,10 +112,15 @@ struct K1eTables {
         }
     }
     // after a __syncthreads(): every table goes to memory, one atomic per distinct key
-    __device__ __forceinline__ void flush() {
+    // n_records: records of the workgroup's range (-> Total Alignments; the gate cascade runs LEAN, rsqc_read.h)
+    __device__ __forceinline__ void flush(unsigned long long n_records) {
         const DevAccum &acc = k1e_lazy_args()->acc;
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) {
-            const unsigned long long v = cnt[c] + (unsigned long long)cnt32[c];
+            unsigned long long v = cnt[c] + (unsigned long long)cnt32[c];
+            if (c == RSQC_C_TOTAL_ALIGNMENTS) v += n_records;
+            if (c == RSQC_C_MAPPED_UNIQUE_READS) v += (unsigned long long)cnt32[RSQC_C_MAPPED_READS] - cnt32[RSQC_C_MAPPED_DUPLICATE_READS];
+            if (c == RSQC_C_UNIQUE_FRAGMENTS) v += (unsigned long long)cnt32[RSQC_C_END1_MAPPED_READS] - cnt32[RSQC_C_DUPLICATE_PAIRS];
+            if (c == RSQC_C_LOW_QUALITY_READS) v += (unsigned long long)cnt32[RSQC_C_READS_USED] - cnt32[RSQC_C_HIGH_QUALITY_READS];
             if (v) atomicAdd(&acc.counters[c], v);
         }
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x)
@@ -290,11 +295,21 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
     }
     const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
-    EiOut eo; bool over = false;
-    exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
-    k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-    k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, !(fl & RSQC_FDUP), (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32),
-                            my_pair_gene, my_pair_hash, chunk_cap);
+    const uint64_t qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+    // three blocks (aMbNcMdNeM) are nine in ten of these records: a tile without a four-block record runs three look-up rounds
+    // and six commit slots instead of four and eight
+    if (__ballot(fast && cw.nblocks > 3u) == 0ull) {
+        const int32_t bs3[3] = {B.bs[0], B.bs[1], B.bs[2]}; const uint32_t len3[3] = {B.len[0], B.len[1], B.len[2]};
+        EiOut eo; bool over = false;
+        exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
+        k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, !(fl & RSQC_FDUP), qhash, my_pair_gene, my_pair_hash, chunk_cap);
+    } else {
+        EiOut eo; bool over = false;
+        exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
+        k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, !(fl & RSQC_FDUP), qhash, my_pair_gene, my_pair_hash, chunk_cap);
+    }
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -480,7 +495,7 @@ classify_ei_kernel(K1Args A) {
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad;
         RecordCounters rc; bool hq = false;
-        bool go = gate_cascade<false, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
+        bool go = gate_cascade<false, WaveSink, true>(a, p, r, cw, rc, hq, cnt, lane_on);
         RSQC_MARK(4);
         if (!lane_on) { go = false; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
         if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
@@ -582,7 +597,7 @@ classify_ei_kernel(K1Args A) {
     }
     RSQC_MARK(12);
     __syncthreads();
-    S.T.flush();
+    S.T.flush(wg_beg < wg_end ? wg_end - wg_beg : 0ull);
 #ifdef RSQC_K1_PROF
     RSQC_MARK(13);                                 // [13] workgroup epilogue (barrier + flush of the LDS tables)
     __syncthreads();

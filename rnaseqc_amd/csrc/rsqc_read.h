@@ -329,7 +329,10 @@ RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &
 // reaches the feature stage; `hq` = highQuality (:330).
 // LEGACY: the LegacyMode tests of the loop body (src/RNASeQC.cpp:258,276,279,287) as a compile-time switch, so
 // that the default kernel carries none of them.
-template <bool LEGACY = false, class Sink = BitSink>
+// LEAN: the caller derives the counters that are differences of others when it flushes its totals (Total Alignments = records
+// seen, Mapped Unique = Mapped - Mapped Duplicate, Unique Fragments = End 1 Mapped - Duplicate Pairs, Low Quality = Reads used -
+// High Quality: rsqc_k1.h, K1eTables::flush) and the tag filters are skipped as a whole when the run has none.
+template <bool LEGACY = false, class Sink = BitSink, bool LEAN = false>
 RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
                           RecordCounters &out, bool &hq, Sink &cnt, bool on = true) {
     // `on` = the caller's lane holds a record at all (a whole wave runs the cascade converged; see WaveSink)
@@ -340,7 +343,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     const bool excl = p.exclude_chimeric != 0;
     const bool paired = (fl & RSQC_FPAIRED) != 0, read1 = (fl & RSQC_FREAD1) != 0, dup = (fl & RSQC_FDUP) != 0;
     const bool sec = (fl & RSQC_FSECONDARY) != 0, supp = (fl & RSQC_FSUPP) != 0, qcf = (fl & RSQC_FQCFAIL) != 0;
-    RSQC_COUNT(cnt, RSQC_C_TOTAL_ALIGNMENTS, on);                                                  // :245,397
+    if (!LEAN) RSQC_COUNT(cnt, RSQC_C_TOTAL_ALIGNMENTS, on);                                       // :245,397
     RSQC_COUNT(cnt, RSQC_C_ALTERNATIVE_ALIGNMENTS, on && sec);                                     // :254
     RSQC_COUNT(cnt, RSQC_C_SUPPLEMENTARY_ALIGNMENTS, on && supp);                                  // :255
     RSQC_COUNT(cnt, RSQC_C_FAILED_VENDOR_QC, on && !supp && qcf);                                  // :256
@@ -353,7 +356,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     RSQC_COUNT(cnt, RSQC_C_UNPAIRED_READS, alive && !paired);
     alive = alive && !(fl & RSQC_FUNMAP);                                                  // :268
     RSQC_COUNT(cnt, RSQC_C_MAPPED_READS, alive);
-    RSQC_COUNT(cnt, RSQC_C_MAPPED_DUPLICATE_READS, alive && dup); RSQC_COUNT(cnt, RSQC_C_MAPPED_UNIQUE_READS, alive && !dup);
+    RSQC_COUNT(cnt, RSQC_C_MAPPED_DUPLICATE_READS, alive && dup); if (!LEAN) RSQC_COUNT(cnt, RSQC_C_MAPPED_UNIQUE_READS, alive && !dup);
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
     const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || w.ref_len == 0) ? 1u : w.ref_len);
     if (LEGACY) alive = alive && !((uint32_t)(endpos - r.pos) > 100000u);                  // :276, LEGACY_MAX_READ_LENGTH
@@ -372,7 +375,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     const bool has_nm = alive && (r.tagbits & RSQC_TB_HAS_NM) != 0;                        // :295-316
     const int32_t mismatches = (r.tagbits & RSQC_TB_HAS_NM) ? r.nm : 0;
     const bool nm1 = has_nm && paired && read1, nm2 = has_nm && paired && !read1;
-    RSQC_COUNT(cnt, RSQC_C_END1_MAPPED_READS, nm1); RSQC_COUNT(cnt, RSQC_C_DUPLICATE_PAIRS, nm1 && dup); RSQC_COUNT(cnt, RSQC_C_UNIQUE_FRAGMENTS, nm1 && !dup);
+    RSQC_COUNT(cnt, RSQC_C_END1_MAPPED_READS, nm1); RSQC_COUNT(cnt, RSQC_C_DUPLICATE_PAIRS, nm1 && dup); if (!LEAN) RSQC_COUNT(cnt, RSQC_C_UNIQUE_FRAGMENTS, nm1 && !dup);
     RSQC_COUNT(cnt, RSQC_C_END2_MAPPED_READS, nm2);
     out.e1_mm = nm1 ? (uint32_t)mismatches : 0u; out.e1_bases = nm1 ? (uint32_t)r.l_qseq : 0u;
     out.e2_mm = nm2 ? (uint32_t)mismatches : 0u; out.e2_bases = nm2 ? (uint32_t)r.l_qseq : 0u;
@@ -381,7 +384,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
     bool discard = false;                                                                  // :319-328
 #define RSQC_FILTER_TAG(t) { const bool hit = (t) < p.n_filter_tags && alive && (r.tagbits & (RSQC_TB_FILTER0 << (t))) != 0; \
                              RSQC_COUNT(cnt, RSQC_C_FILTERED_TAG0 + (t), hit); discard = discard || hit; }
-    RSQC_FILTER_TAG(0) RSQC_FILTER_TAG(1) RSQC_FILTER_TAG(2) RSQC_FILTER_TAG(3) RSQC_FILTER_TAG(4)
+    if (!LEAN || p.n_filter_tags > 0) { RSQC_FILTER_TAG(0) RSQC_FILTER_TAG(1) RSQC_FILTER_TAG(2) RSQC_FILTER_TAG(3) RSQC_FILTER_TAG(4) }
 #undef RSQC_FILTER_TAG
     static_assert(RSQC_MAX_FILTER_TAGS == 5, "one line per filter tag above");
     alive = alive && !discard;
@@ -389,7 +392,7 @@ RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Reco
          (r.mapq >= p.mapq_threshold);                                                     // :330
     alive = alive && !(r.tid < 0 || r.tid >= a.n_ref);                                     // :333-337
     hq = hq && alive;
-    RSQC_COUNT(cnt, RSQC_C_HIGH_QUALITY_READS, hq); RSQC_COUNT(cnt, RSQC_C_LOW_QUALITY_READS, alive && !hq); RSQC_COUNT(cnt, RSQC_C_READS_USED, alive);
+    RSQC_COUNT(cnt, RSQC_C_HIGH_QUALITY_READS, hq); if (!LEAN) RSQC_COUNT(cnt, RSQC_C_LOW_QUALITY_READS, alive && !hq); RSQC_COUNT(cnt, RSQC_C_READS_USED, alive);
     out.error = (alive && w.bad) ? RSQC_ERR_BAD_CIGAR : 0;
     alive = alive && !w.bad;
     out.blocks = alive ? w.nblocks : 0u;                                                   // :360
