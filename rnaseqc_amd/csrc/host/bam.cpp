@@ -229,7 +229,10 @@ bool BamReader::seek(uint64_t voff, uint64_t voff_end) {
     buf_.clear(); pos_ = 0; eof_ = false; file_eof_ = false;
     cpos_ = (size_t)(voff >> 16);
     skip_ = (size_t)(voff & 0xFFFF);
-    climit_ = voff_end ? (size_t)(voff_end >> 16) + 1 : 0;          // the block that holds the end is still inflated
+    // the block that holds the end is still inflated -- unless the range ends exactly on its first byte (htslib writes such an end
+    // when the last record of a contig fills its block): that block holds nothing of the range, and when it starts with the
+    // first part of a record larger than a block, framing it would report a truncated record instead of the end of the range
+    climit_ = voff_end ? (size_t)(voff_end >> 16) + ((voff_end & 0xFFFF) ? 1 : 0) : 0;
     if (cpos_ > map_size_) return false;
     return true;
 }

@@ -127,6 +127,13 @@ void BgzfFeeder::reserve(size_t chunk_bytes) {
 }
 
 void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes, uint64_t max_out) {
+    // the producer of the previous range (a sharded run starts one range per contig on the same feeder) is told to stop and
+    // joined BEFORE any of the state it reads is reset
+    if (th_.joinable()) {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
     cpos_ = voff_beg >> 16; skip_ = (uint32_t)(voff_beg & 0xffff);
     cend_ = voff_end >> 16; uend_ = (uint32_t)(voff_end & 0xffff);
     has_end_ = voff_end != 0;
@@ -137,7 +144,6 @@ void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes,
     chunk_bytes_ = (size_t)std::min<uint64_t>(chunk_bytes_, std::max<uint64_t>(file_size_ - std::min(file_size_, cpos_), (uint64_t)1 << 17));
     n_filled_ = 0;
     head_ = tail_ = count_ = 0; lent_ = nullptr; eof_ = false; stop_ = false; error_.clear();
-    if (th_.joinable()) th_.join();
     th_ = std::thread([this] { producer(); });
 }
 
@@ -236,14 +242,16 @@ void BgzfFeeder::producer() {
         }
         bool ok = false; std::string err;
         try { ok = fill(*slot); } catch (std::exception &e) { err = e.what(); }
+        bool finished;
         {
             std::lock_guard<std::mutex> lk(mu_);
             if (!err.empty()) { error_ = err; eof_ = true; }
             else if (!ok) eof_ = true;
             else { head_ = (head_ + 1) % 3; ++count_; if (slot->last) eof_ = true; }
+            finished = eof_ || stop_;                      // (decided under the lock: start() may be resetting the flags next)
         }
         cv_.notify_all();
-        if (eof_) return;
+        if (finished) return;
     }
 }
 

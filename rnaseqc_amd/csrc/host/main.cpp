@@ -199,7 +199,11 @@ struct Shard {
 constexpr int kFileIndexShift = 36;      // virtual file index of a batch: (contig << 36) + records of the contig before it
 
 // ---- device decode (rsqc_decode_*): the default.  RSQC_DECODE=host keeps inflate + record parsing on the CPU threads.
+// The device path reads the file with pread through the block feeder, which needs a regular file: a FIFO, /dev/stdin or a
+// process substitution is streamed by the host reader instead (as every input was before the device decode existed).
+bool g_input_is_stream = false;
 bool device_decode_wanted() {
+    if (g_input_is_stream) return false;
     const char *e = getenv("RSQC_DECODE");
     return !(e && (!strcmp(e, "host") || !strcmp(e, "cpu")));
 }
@@ -373,6 +377,7 @@ int main(int argc, char **argv) {
         rsqc_params P{};
         P.abi_version = RSQC_ABI_VERSION;
         P.device = getenv("RSQC_DEVICE") ? atoi(getenv("RSQC_DEVICE")) : 0;
+        if (const char *e = getenv("RSQC_GPU_LIST")) if (*e) P.device = atoi(e);       // the first shard's context runs on the list's first device
         P.mapq_threshold = o.has_mapq ? (uint32_t)o.mapq : (o.legacy ? 4u : 255u);     // src/RNASeQC.cpp:90
         P.legacy = o.legacy ? 1 : 0;
         P.base_mismatch = (uint32_t)o.base_mismatch;
@@ -389,6 +394,7 @@ int main(int argc, char **argv) {
         // ... and so do the page-locked chunk buffers of the device decode's feeder (one GPU: ~1.3 GB, a few hundred ms of
         // page-locking that would otherwise sit between the GTF and the BAM loop).  A file that cannot be opened is reported
         // later, where the reference reports it.
+        { struct stat st_in; g_input_is_stream = stat(bam_path.c_str(), &st_in) == 0 && !S_ISREG(st_in.st_mode); }
         auto feeder_cpu_threads = [] {
             const int spare = effective_cpus() - 4;
             return getenv("RSQC_DECODE_CPU_THREADS") ? atoi(getenv("RSQC_DECODE_CPU_THREADS")) : (spare >= 4 ? spare : 0);

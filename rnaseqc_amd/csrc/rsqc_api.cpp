@@ -1504,9 +1504,14 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
     DevBgzfBlock *hb = D.h_blocks + (size_t)slot * D.blk_cap;
     uint32_t raw_at = D.head;                                           // where the caller-inflated run goes in the window
-    { uint32_t at = D.head;
-      for (uint32_t k = 0; k < n_gpu; ++k) { hb[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; }
-      raw_at = at; }
+    uint32_t head_used = D.head;                                        // the window origin the table below was laid out for
+    auto lay_out_blocks = [&]() {
+        head_used = D.head;
+        uint32_t at = D.head;
+        for (uint32_t k = 0; k < n_gpu; ++k) { hb[k] = DevBgzfBlock{blocks[k].in_offset, blocks[k].in_bytes, blocks[k].out_bytes, at, blocks[k].crc32}; at += blocks[k].out_bytes; }
+        raw_at = at;
+    };
+    lay_out_blocks();
     // the file bytes go up on the copy stream, beside the kernels of the call before this one (pipelined streams)
     uint8_t *dcomp = (uint8_t *)D.comp.p + (size_t)slot * D.comp_cap;
     DevBgzfBlock *dblk = (DevBgzfBlock *)D.blocks.p + (size_t)slot * D.blk_cap;
@@ -1516,6 +1521,17 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     // the call before this one: its kernels have had the time of this call's preparation
     // (an error from here on leaves with the copy drained: the caller's buffer is the caller's again when the call returns)
     if (D.pending) { if ((rc = decode_finish(c, out))) { (void)hipStreamSynchronize(D.copy_stream); return rc; } }
+    if (D.head != head_used) {
+        // the call just finished left a partial record larger than the head room, and decode_finish moved the window origin to
+        // make room for it: the block table above was laid out for the old origin -- lay it out again and send it once more
+        // (inflating to the old places would overwrite the carried bytes and shift the window)
+        if (total + D.head > (1ull << 31)) { (void)hipStreamSynchronize(D.copy_stream); return fail(c, RSQC_ERR_ARG, "too much inflated data in one rsqc_decode_submit (2 GiB with the bytes carried over)"); }
+        HIP_TRY(c, hipStreamSynchronize(D.copy_stream));               // (the first copy of the table reads hb)
+        if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
+        lay_out_blocks();
+        if (n_gpu) HIP_TRY(c, hipMemcpyAsync(dblk, hb, (size_t)n_gpu * sizeof(DevBgzfBlock), hipMemcpyHostToDevice, D.copy_stream));
+        HIP_TRY(c, hipEventRecord(D.ev_copy, D.copy_stream));
+    }
     if (skip_bytes && D.tail) { (void)hipStreamSynchronize(D.copy_stream); return fail(c, RSQC_ERR_ARG, "skip_bytes in the middle of a record"); }
     D.slot = slot;
     D.pend_wall0 = std::chrono::steady_clock::now();

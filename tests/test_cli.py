@@ -121,6 +121,33 @@ def test_cli_end_to_end_matches_oracle_outputs(cli, host, oracle_lib, tmp_path, 
 
 
 @pytest.mark.gpu
+def test_cli_reads_a_bam_from_a_fifo(cli, tmp_path):
+    """A BAM that is not a regular file (FIFO, /dev/stdin, process substitution): the block feeder of the device decode needs
+    pread, so such an input is streamed by the host reader -- same report files as the run on the file itself."""
+    import threading
+    contigs = [("chrA", 900_000, 70), ("chrB", 500_000, 40)]
+    ann = synth.make_annotation(seed=41, contigs=contigs)
+    batch = synth.make_reads(ann, 8000, seed=42, keep_qnames=True, contig_lengths=np.array([c[1] for c in contigs]))
+    gtf, bam, fifo = str(tmp_path / "s.gtf"), str(tmp_path / "s.bam"), str(tmp_path / "s.fifo")
+    bamio.write_gtf(gtf, ann)
+    bamio.write_bam(bam, [(c[0], c[1]) for c in contigs], batch)
+    os.mkfifo(fifo)
+    def writer():
+        with open(fifo, "wb") as w, open(bam, "rb") as r:
+            w.write(r.read())
+    t = threading.Thread(target=writer); t.start()
+    a = subprocess.run([cli, gtf, fifo, str(tmp_path / "from_fifo"), "-s", "x", "-vv"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t.join()
+    assert a.returncode == 0, a.stderr.decode()
+    assert "on the GPU" not in a.stdout.decode()                 # host decode
+    b = subprocess.run([cli, gtf, bam, str(tmp_path / "from_file"), "-s", "x", "-vv"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert b.returncode == 0, b.stderr.decode()
+    assert "on the GPU" in b.stdout.decode()
+    for f in ("metrics.tsv", "gene_reads.gct", "gene_fragments.gct", "exon_reads.gct", "gene_tpm.gct"):
+        assert open(str(tmp_path / "from_fifo" / ("x." + f))).read() == open(str(tmp_path / "from_file" / ("x." + f))).read(), f
+
+
+@pytest.mark.gpu
 def test_cli_stderr_of_the_reference_loop(cli, tmp_path):
     """src/RNASeQC.cpp:354-355: the sort warning (positions going backwards inside a contig, or a contig visited twice);
     :333-337: under -v, the names of primary mapped records whose RefID the header does not define.  A sorted file with

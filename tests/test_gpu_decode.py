@@ -141,6 +141,38 @@ def test_decode_pipelined_stream(tmp_path):
         assert_results_match(got, want)
 
 
+def test_decode_pipelined_record_larger_than_head_room(tmp_path):
+    """A pipelined stream whose window origin moves while a call is in preparation: a 7.5 MB record (5 M bases) straddles two
+    calls, the call that completes its predecessor finds a carried part larger than the 4 MB head room, the window is rebuilt
+    around a larger head -- and the block table of the call being prepared, laid out for the old origin, has to follow
+    (it did not: the inflate overwrote the carried bytes and the window was shifted)."""
+    recs = []
+    for i in range(2000):
+        recs.append(dict(tid=0, pos=100 + i, mpos=100 + i, isize=0, flag=0, cigar=[(abi.CIG_M, 100)], qname="s%d" % i))
+    recs.append(dict(tid=0, pos=5000, mpos=5000, isize=0, flag=0, cigar=[(abi.CIG_M, 5_000_000)], qname="long"))
+    for i in range(2000):
+        recs.append(dict(tid=1 if i > 1000 else 0, pos=6000 + i, mpos=6000 + i, isize=0, flag=0, cigar=[(abi.CIG_M, 90), (abi.CIG_S, 10)], qname="t%d" % i))
+    batch = Batch.from_records(recs)
+    path = str(tmp_path / "pl.bam")
+    bamio.write_bam(path, [("chrA", 8_000_000), ("chrB", 1_000_000)], batch)
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 8_000_000, 50), ("chrB", 1_000_000, 20)])
+    p = abi.default_params()
+    want = engine.run_engine(p, ann, [batch])
+    for chunk in (1 << 17, 1 << 20):
+        e = engine.Engine(p)
+        e.set_annotation(ann)
+        e.decode_begin(2, pipelined=True)
+        total = 0
+        for comp, tab, skip, limit, _last in feed_chunks(path, chunk_bytes=chunk):
+            total += e.decode_submit(comp, tab, skip, limit)[0]
+        info = e.decode_end()
+        total += e.decode_last[0]
+        assert total == batch.n == info[0]
+        got = e.finalize()
+        e.close()
+        assert_results_match(got, want)
+
+
 def test_decode_fast_writer_blocks_long_record_and_ranges(tmp_path):
     """libdeflate-written blocks (the CLI benchmark's files), a 3 MB record that outgrows the head room kept for records that
     straddle two calls, and one contig at a time through the index's virtual offsets."""
