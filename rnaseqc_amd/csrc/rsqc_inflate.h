@@ -70,10 +70,11 @@ namespace rsqc {
 // wave-wide helpers on lane vectors: which lanes hold a non-zero value, and the running (inclusive) sum over the lanes
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint64_t inf_ballot(const InfVec &v) { return __ballot(v != 0u); }
-#if defined(INF_DPP_SCAN_CFG) && INF_DPP_SCAN_CFG
+#if !defined(INF_DPP_SCAN_CFG) || INF_DPP_SCAN_CFG
 // The running sum as six DPP additions (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2 into rows 1
-// and 3, then lane 31 into rows 2 and 3) instead of six ds_bpermute round trips.  DEVICE-ONLY code: the host tests cannot run
-// it; off until an A/B run (tools/decode_ab.sh checks every block's CRC-32 and the outputs) has shown it right and faster.
+// and 3, then lane 31 into rows 2 and 3) instead of six ds_bpermute round trips: +12.5 % / +8.7 % inflate rate on the realistic /
+// the SURVEY 8(d) file (profiles/r3_decode_ab.txt; every block's CRC-32 and the report files are its check -- the host build
+// runs the sequential form below).  -DINF_DPP_SCAN_CFG=0 builds the ds_bpermute form.
 __device__ __forceinline__ InfVec inf_scan(InfVec v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
@@ -134,15 +135,11 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 #ifndef INF_PAR_COMMIT_CFG
 #define INF_PAR_COMMIT_CFG 0
 #endif
-// 1: the Huffman tables of a block are built by the lanes (inflate_build_par) instead of symbol by symbol on the scalar unit.
-// Off in the product build until measured, like the above.
-#ifndef INF_PAR_BUILD_CFG
-#define INF_PAR_BUILD_CFG 0
-#endif
 // 1: a code longer than the fast table does not end the round: the walk decodes it where it stands (one step of the wave,
-// inflate_symbol_slow), writes the result into that lane and goes on over the lanes behind it.  Off until measured.
+// inflate_symbol_slow), writes the result into that lane and goes on over the lanes behind it (+1.5 % / +3.8 %,
+// profiles/r3_decode_ab.txt; the lane-parallel table build measured beside it was +-0 and is gone).
 #ifndef INF_INWALK_CFG
-#define INF_INWALK_CFG 0
+#define INF_INWALK_CFG 1
 #endif
 constexpr uint32_t INF_LBITS = INF_LBITS_CFG, INF_DBITS = INF_DBITS_CFG;
 constexpr uint32_t INF_FLUSH = INF_FLUSH_CFG;          // the ring goes out to HBM (and through the CRC) in pieces of this size
@@ -338,75 +335,7 @@ RSQC_INF_FN uint32_t inflate_symbol_slow(uint32_t bits, const uint16_t *count, c
     len = l;
     return INF_UNI(sym[INF_UNI(index[l]) + (rev >> (32u - l)) - INF_UNI(first[l])]);
 }
-#if INF_PAR_BUILD_CFG
-// inflate_build with the lanes: the same tables (count / sym / first / index / fast), built without a per-symbol step on the
-// scalar unit.  64 symbols per pass; the lengths that occur in a pass are taken one after the other, a ballot each: the symbols
-// of one length keep their order (canonical codes are assigned in symbol order), a lane's slot is the length's cursor plus the
-// number of lanes below it in the ballot.  The fast table is filled by ENTRY: lane t decodes index t canonically (the same
-// test as inflate_symbol_slow, lengths 1 .. fbits) and stores what it finds, 0 when no code that short begins the index.
-RSQC_INF_FN bool inflate_build_par(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *sym, uint16_t *first, uint16_t *index, uint32_t *fast, uint32_t fbits, uint16_t *offs, int kind) {
-    INF_FOREACH(k) { if (k < 16u) count[k] = 0; }
-    uint32_t used = 0;
-    for (uint32_t base = 0; base < n; base += 64u) {                       // codes per length
-        InfVec L, ANY;
-        INF_FOREACH(k) { INF_AT(L, k) = (base + k < n) ? (uint32_t)lens[base + k] : 0u; INF_AT(ANY, k) = INF_AT(L, k) ? 1u : 0u; }
-        uint64_t todo = inf_ballot(ANY);
-        used += (uint32_t)__builtin_popcountll(todo);
-        while (todo) {
-            const uint32_t l = INF_GET(L, (uint32_t)__builtin_ctzll(todo));
-            InfVec EQ;
-            INF_FOREACH(k) { (void)k; INF_AT(EQ, k) = (INF_AT(L, k) == l) ? 1u : 0u; }
-            const uint64_t m = inf_ballot(EQ);
-            INF_ST(count[l] = (uint16_t)(count[l] + (uint32_t)__builtin_popcountll(m)));
-            todo &= ~m;
-        }
-    }
-    if (!used) {                                                            // no codes at all: legal as long as none is used
-        for (uint32_t b = 0; b < (1u << fbits); b += 64u) { INF_FOREACH(k) { if (b + k < (1u << fbits)) fast[b + k] = 0u; } }
-        return true;
-    }
-    int32_t left = 1;
-    uint32_t run = 0, fcode = 0;
-    for (uint32_t l = 1; l <= 15u; ++l) {
-        const uint32_t c = INF_UNI(count[l]);
-        left = (left << 1) - (int32_t)c;
-        if (left < 0) return false;
-        INF_ST(offs[l] = (uint16_t)run; index[l] = (uint16_t)run; first[l] = (uint16_t)fcode);
-        run += c;
-        fcode = (fcode + c) << 1;
-    }
-    for (uint32_t base = 0; base < n; base += 64u) {                       // symbols by (length, symbol)
-        InfVec L, ANY;
-        INF_FOREACH(k) { INF_AT(L, k) = (base + k < n) ? (uint32_t)lens[base + k] : 0u; INF_AT(ANY, k) = INF_AT(L, k) ? 1u : 0u; }
-        uint64_t todo = inf_ballot(ANY);
-        while (todo) {
-            const uint32_t l = INF_GET(L, (uint32_t)__builtin_ctzll(todo));
-            InfVec EQ;
-            INF_FOREACH(k) { (void)k; INF_AT(EQ, k) = (INF_AT(L, k) == l) ? 1u : 0u; }
-            const uint64_t m = inf_ballot(EQ);
-            const uint32_t at = INF_UNI(offs[l]);
-            INF_FOREACH(k) { if ((m >> k) & 1ull) sym[at + (uint32_t)__builtin_popcountll(m & ((1ull << k) - 1ull))] = (uint16_t)(base + k); }
-            INF_ST(offs[l] = (uint16_t)(at + (uint32_t)__builtin_popcountll(m)));
-            todo &= ~m;
-        }
-    }
-    for (uint32_t b = 0; b < (1u << fbits); b += 64u) {                     // the fast table, by entry
-        INF_FOREACH(k) {
-            const uint32_t idx = b + k, rev = inflate_bitrev32(idx);       // bit 0 of the index is the first bit of the stream
-            uint32_t e = 0;
-            for (uint32_t l = 1; l <= fbits; ++l) {
-                const uint32_t d = (rev >> (32u - l)) - (uint32_t)first[l];
-                if (!e && d < (uint32_t)count[l]) e = inflate_entry(kind, (uint32_t)sym[(uint32_t)index[l] + d], l);
-            }
-            if (idx < (1u << fbits)) fast[idx] = e;
-        }
-    }
-    return true;
-}
-#define INF_BUILD inflate_build_par
-#else
 #define INF_BUILD inflate_build
-#endif
 
 // one symbol at the head of the reader (the block headers' code-length code)
 RSQC_INF_FN uint32_t inflate_symbol(InflateIn &in, const uint32_t *fast, uint32_t fbits, const uint16_t *count, const uint16_t *first, const uint16_t *index, const uint16_t *sym) {
@@ -714,6 +643,14 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
                 if ((starts >> k) & 1ull)
                     S.slot[INF_AT(INC, k) - INF_AT(OL, k)] = 0x80000000u | (INF_AT(ISLIT, k) ? 0x40000000u : 0u) | (INF_AT(VAL, k) & 0xFFFFu);
             }
+            // the slots were written by OTHER lanes of this wave: without a fence the compiler may forward a lane's own zero to the
+            // read below (the accesses are plain LDS traffic of one wave, which the hardware runs in order -- what is needed is
+            // that the compiler reloads).  This was the variant's failure on the device in profiles/r3_decode_ab.txt; the one-lane
+            // host build cannot show it.
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
             InfVec FIRST;
             INF_FOREACH(k) { INF_AT(FIRST, k) = S.slot[k] >> 31; }
             const uint64_t firsts = inf_ballot(FIRST);                      // bit 0 is set: the round's first symbol starts at its first byte
