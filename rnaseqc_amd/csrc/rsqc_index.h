@@ -152,6 +152,29 @@ struct HostIndex {
             ex_rows[(size_t)i] = ExonRow{a->exon_row_start[i], a->exon_row_end[i], ex_cov[(size_t)i],
                                          a->exon_row_gene[i] | (fl << ROW_FLAG_SHIFT)};
         }
+        // An exon lies inside its gene's row.  The reference retires a gene (coverage computed, fragment set dropped) when its ROW
+        // leaves the window of the sorted stream (src/Expression.cpp:84-93), so an exon that sticks out keeps collecting reads
+        // for a gene that is gone -- it then prints "Gene encountered after computing coverage" (src/Metrics.cpp:106-112) and
+        // counts into a fresh state.  A static index cannot reproduce that order dependence; such an annotation is refused
+        // instead of being counted differently.
+        {
+            std::vector<int32_t> gs((size_t)std::max(L, 1), 0), ge((size_t)std::max(L, 1), 0), gc((size_t)std::max(L, 1), -1);
+            for (int i = 0; i < L; ++i) {
+                const uint32_t id = a->gene_row_id[i];
+                if (id >= (uint32_t)L) { err = "gene_row_id out of range"; return RSQC_ERR_ARG; }
+                gs[id] = a->gene_row_start[i]; ge[id] = a->gene_row_end[i]; gc[id] = a->gene_row_contig[i];
+            }
+            for (int i = 0; i < E; ++i) {
+                const uint32_t g = a->exon_row_gene[i];
+                if (g >= (uint32_t)L) continue;                                   // (a gene id that only exon rows carry has no row to retire)
+                if (a->exon_row_contig[i] != gc[g] || a->exon_row_start[i] < gs[g] || a->exon_row_end[i] > ge[g]) {
+                    err = "exon row " + std::to_string(i) + " (" + std::to_string(a->exon_row_start[i]) + "-" + std::to_string(a->exon_row_end[i]) +
+                          ") lies outside the row of its gene (" + std::to_string(gs[g]) + "-" + std::to_string(ge[g]) +
+                          "): unsupported -- the reference's result on such an annotation depends on when the gene leaves its window";
+                    return RSQC_ERR_ARG;
+                }
+            }
+        }
         // elementary intervals per contig: sweep over the starts (+) and ends + 1 (-) of gene and exon rows
         ei.clear(); ei_range.assign((size_t)nc + 1, 0); rank_words = 0;
         for (int k = 0; k < nc; ++k) {

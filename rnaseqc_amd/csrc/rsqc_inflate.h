@@ -626,9 +626,13 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
         // (literal byte | distance) in the slot of their first output byte; a ballot over the slots is the mask of first bytes; a
         // byte lane finds its symbol as the highest first byte at or below it.  Every source is read before any byte is stored,
         // so a store cannot land on a ring slot that a match of the same round still has to read.
-        InfVec DEP;
-        INF_FOREACH(k) { (void)k; INF_AT(DEP, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) < INF_AT(INC, k)) ? 1u : 0u; }
-        if (total <= 64u && !inf_ballot(DEP)) {
+        bool one_pass = total <= 64u;                                       // (rounds of long matches -- a low-entropy file -- skip even the test)
+        if (one_pass) {
+            InfVec DEP;
+            INF_FOREACH(k) { (void)k; INF_AT(DEP, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) < INF_AT(INC, k)) ? 1u : 0u; }
+            one_pass = !inf_ballot(DEP);
+        }
+        if (one_pass) {
             InfVec FAR_;
             INF_FOREACH(k) { (void)k; INF_AT(FAR_, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) > INF_NEAR) ? 1u : 0u; }
             if (inf_ballot(FAR_)) {                                         // sources that left the ring are read from the stream (see inflate_copy)

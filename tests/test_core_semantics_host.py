@@ -89,3 +89,19 @@ def test_interval_index_equals_row_index(oracle_lib, seed):
             _compare(a1, a0)
             np.testing.assert_array_equal(a1.cov, a0.cov)
             _compare(a1, oracle_lib.run_oracle(p, ann, [batch]))
+
+
+def test_exon_outside_its_gene_row_is_refused():
+    """An exon that sticks out of its gene's row: the reference's counts then depend on when the gene leaves its window
+    (src/Metrics.cpp:106-112, "Gene encountered after computing coverage"); the static index cannot follow that, so the
+    annotation is refused by the index builder (rsqc_set_annotation / the CLI: exit 11 with the message) instead of being
+    counted differently."""
+    from rnaseqc_amd.model import Annotation, Batch
+    rows = [dict(contig="c", type="gene", start=100, end=900, strand="+", gene_id="G0"),
+            dict(contig="c", type="exon", start=100, end=300, strand="+", gene_id="G0", exon_id="E0"),
+            dict(contig="c", type="exon", start=800, end=1000, strand="+", gene_id="G0", exon_id="E1")]      # 100 bases beyond the gene row
+    ann = Annotation.from_rows(["c"], rows)
+    b = Batch.from_records([dict(qname="a", tid=0, pos=150, cigar=[(abi.CIG_M, 50)], flag=99)])
+    with pytest.raises(RuntimeError) as e:
+        hostemu.run(abi.default_params(), ann, b)
+    assert "rc=-1" in str(e.value)
