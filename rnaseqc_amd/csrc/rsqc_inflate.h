@@ -131,9 +131,12 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 #define INF_ROUND_BYTES_CFG 1024
 #endif
 // 1: a round whose output fits one byte per lane and whose matches all copy from before the round is committed in ONE vector pass
-// (inflate_round).  Off in the product build until it has been measured on the GPU; the host tests run both.
+// (inflate_round).  Measured (profiles/r3_decode_ab.txt, same box, alternating builds, outputs identical): +7.4 % on the file with
+// the entropy of a real BAM (35.1 -> 37.7 GB/s: most of its rounds qualify), -6 % on the SURVEY 8(d) file (131 -> 124 GB/s: its
+// rounds are long matches and never qualify -- the cost there is the 256 bytes of LDS and the registers the path holds).  ON: real
+// files are what the decoder is for.  The host tests run both forms.
 #ifndef INF_PAR_COMMIT_CFG
-#define INF_PAR_COMMIT_CFG 0
+#define INF_PAR_COMMIT_CFG 1
 #endif
 // 1: a code longer than the fast table does not end the round: the walk decodes it where it stands (one step of the wave,
 // inflate_symbol_slow), writes the result into that lane and goes on over the lanes behind it (+1.5 % / +3.8 %,

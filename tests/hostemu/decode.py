@@ -15,9 +15,9 @@ _SO = os.path.join(_HERE, "libdecode_emu.so")
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 
 
-# "" = the product's configuration (long codes decoded inside the walk); the others flip one switch of rsqc_inflate.h
-VARIANTS = {"": (), "par_commit": ("-DINF_PAR_COMMIT_CFG=1",), "no_inwalk": ("-DINF_INWALK_CFG=0",),
-            "all": ("-DINF_PAR_COMMIT_CFG=1", "-DINF_INWALK_CFG=1")}
+# "" = the product's configuration (one-pass commit of a round, long codes decoded inside the walk); the others flip the switches
+VARIANTS = {"": (), "no_par_commit": ("-DINF_PAR_COMMIT_CFG=0",), "no_inwalk": ("-DINF_INWALK_CFG=0",),
+            "all": ("-DINF_PAR_COMMIT_CFG=0", "-DINF_INWALK_CFG=0")}
 
 
 def build(variant=""):

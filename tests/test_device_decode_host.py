@@ -36,11 +36,11 @@ def _payloads():
             yield bytes([rng.randrange(2)]) * n
 
 
-@pytest.mark.parametrize("variant", ["", "par_commit", "no_inwalk", "all"])
+@pytest.mark.parametrize("variant", ["", "no_par_commit", "no_inwalk", "all"])
 def test_inflate_matches_zlib_on_every_block_type(variant):
     """Stored, fixed and dynamic blocks, several blocks per stream, small windows, long codes (Huffman-only on random bytes),
-    runs (distance 1) and distances up to 32 KiB.  variant: "" is the product's configuration; the others flip a switch of
-    rsqc_inflate.h (the one-pass commit of a round, INF_PAR_COMMIT_CFG, off in the product; long codes outside the walk)."""
+    runs (distance 1) and distances up to 32 KiB.  variant: "" is the product's configuration; the others switch off the one-pass
+    commit of a round (INF_PAR_COMMIT_CFG) and / or the in-walk decode of long codes (INF_INWALK_CFG) of rsqc_inflate.h."""
     n = 0
     for d in _payloads():
         for level in (0, 1, 6, 9):
