@@ -394,6 +394,7 @@ int main(int argc, char **argv) {
         // ... and so do the page-locked chunk buffers of the device decode's feeder (one GPU: ~1.3 GB, a few hundred ms of
         // page-locking that would otherwise sit between the GTF and the BAM loop).  A file that cannot be opened is reported
         // later, where the reference reports it.
+        const auto t_start = std::chrono::steady_clock::now();
         { struct stat st_in; g_input_is_stream = stat(bam_path.c_str(), &st_in) == 0 && !S_ISREG(st_in.st_mode); }
         auto feeder_cpu_threads = [] {
             const int spare = effective_cpus() - 4;
@@ -510,7 +511,9 @@ int main(int argc, char **argv) {
             for (auto &sh : shards) std::sort(sh.contigs.begin(), sh.contigs.end());
         }
 
+        const auto t_gpu0 = std::chrono::steady_clock::now();
         int rc = gpu_ready.get();
+        const auto t_gpu1 = std::chrono::steady_clock::now();
         if (rc != RSQC_OK) { cerr << "Unable to initialise the GPU hot path: " << rsqc_strerror(rc) << endl; return 10; }
         std::vector<std::vector<uint8_t>> owned_masks(shards.size());
         for (size_t g = 0; g < shards.size(); ++g) {
@@ -716,8 +719,18 @@ int main(int argc, char **argv) {
         cfg.output_dir = out_dir; cfg.sample_name = SAMPLENAME; cfg.sample_given = o.has_sample;
         cfg.use_rpkm = o.rpkm; cfg.write_coverage = o.coverage; cfg.detection_threshold = (unsigned)o.detection;
         cfg.filter_tags = o.tags;
+        const auto tr0 = std::chrono::steady_clock::now();
         write_reports(cfg, ann, res, visit);
+        const auto tr1 = std::chrono::steady_clock::now();
         for (auto &sh : shards) rsqc_destroy(sh.gpu);
+        if (o.verbosity > 1) {
+            // where the wall time outside the reference's `Average Reads/Sec` window goes (extension; the window itself is above)
+            auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+            cout << "Wall time: " << sec(t_start, std::chrono::steady_clock::now()) << " s = GTF " << sec(t0, t1)
+                 << " + waiting for the GPU context " << sec(t_gpu0, t_gpu1) << " + index / annotation upload / buffers " << sec(t_gpu1, tb0) - 0.0
+                 << " + BAM loop " << sec(tb0, tb1) << " + reports " << sec(tr0, tr1) << " + release " << sec(tr1, std::chrono::steady_clock::now())
+                 << " (the GPU context and the page-locked feed buffers come up beside the GTF parse)" << endl;
+        }
     } catch (Help &) {
         usage(cout);
         return 4;
