@@ -1539,7 +1539,11 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     HIP_TRY(c, hipStreamWaitEvent(c->stream, D.ev_copy, 0));
     HIP_TRY(c, hipMemsetAsync(D.sum.p, 0, sizeof(DecodeSummary), c->stream));
     if (D.profile) HIP_TRY(c, hipEventRecord(D.pe[1], c->stream));
-    launch_bgzf_inflate(c->stream, dcomp, dblk, n_gpu, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p);
+    // the inflate kernel's form follows the call's compression ratio: below 5x the rounds are short matches and literals and the
+    // one-pass commit pays; above, long matches dominate and it only costs (RSQC_INFLATE_ONE_PASS=0/1 forces a form)
+    static const int force_one_pass = getenv("RSQC_INFLATE_ONE_PASS") ? atoi(getenv("RSQC_INFLATE_ONE_PASS")) : -1;
+    const bool one_pass = force_one_pass >= 0 ? force_one_pass != 0 : total < 5 * (uint64_t)std::max<uint64_t>(compressed_bytes - raw_total, 1);
+    launch_bgzf_inflate(c->stream, dcomp, dblk, n_gpu, (uint8_t *)D.ubuf.p, (DecodeSummary *)D.sum.p, one_pass);
     if (raw_total)                                                      // the caller-inflated run: staged with the file bytes, now moved into the window
         HIP_TRY(c, hipMemcpyAsync((char *)D.ubuf.p + raw_at, dcomp + blocks[n_gpu].in_offset, (size_t)raw_total, hipMemcpyDeviceToDevice, c->stream));
     const bool limited = limit_bytes && limit_bytes < total;

@@ -135,7 +135,9 @@ RSQC_BAM_FN void decode_lists_finish(const DecodeWindow &W, uint32_t n, DecodeLi
 
 #if defined(__HIPCC__)
 // rsqc_decode.hip
-void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *blk, uint32_t n_blk, uint8_t *out, DecodeSummary *sum);
+// one_pass: the form of the inflate kernel that commits short rounds in one vector pass (rsqc_inflate.h): pays on streams of short
+// matches and literals (a real BAM, ~3x), costs 6 % on streams of long matches (ratio 8x): the caller decides from the call's ratio
+void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *blk, uint32_t n_blk, uint8_t *out, DecodeSummary *sum, bool one_pass);
 // scratch: DEC_SCRATCH_WORDS words of device memory for the scans' per-workgroup sums (window of at most 2 GiB)
 constexpr size_t DEC_SCRATCH_WORDS = 16 + 2 * 1024 + 2048 + 4 * ((((size_t)1 << 31) / 36 + 8192) / 8192 + 8);
 void launch_decode_window(hipStream_t s, const DecodeWindow &W, uint32_t *scratch);

@@ -22,7 +22,8 @@ namespace rsqc {
 // LDS: 7.7 KB per wave, registers capped for five waves per SIMD (twenty per CU): the decoder is a chain of dependent
 // instructions and LDS round trips, so the waves of a SIMD take turns in its issue slots (four waves per CU instead of
 // sixteen: 2.6 times slower).  WPW waves share a workgroup, each with its own scratch.
-template <int WPW>
+// PAR: the one-pass commit of a round (rsqc_inflate.h) -- compiled both ways, picked per call by launch_bgzf_inflate.
+template <int WPW, bool PAR>
 __global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(RSQC_INFLATE_WAVES, RSQC_INFLATE_WAVES))) void bgzf_inflate_kernel(const uint8_t *__restrict__ in, const DevBgzfBlock *__restrict__ blk, uint32_t n_blk,
                                                                 uint8_t *__restrict__ out, DecodeSummary *sum) {
     __shared__ InflateScratch SS[WPW];
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(RSQC_I
         b = INF_UNI(b);
         if (b >= n_blk) break;
         const DevBgzfBlock k = blk[b];
-        const int rc = inflate_block(S, in + k.in_off, k.in_len, out + k.out_off, k.out_len, k.crc);
+        const int rc = inflate_block<PAR>(S, in + k.in_off, k.in_len, out + k.out_off, k.out_len, k.crc);
         if (rc && INF_LANE == 0u) {
             atomicCAS(&sum->inflate_fail, 0u, ((b + 1u) << 4) | (uint32_t)rc);
             atomicOr(&sum->status, DEC_ST_INFLATE);
@@ -217,24 +218,26 @@ __global__ __launch_bounds__(256) void bam_lists_write_kernel(DecodeWindow W, co
 }
 
 // ---- launches ----------------------------------------------------------------------------------------------------
-void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *blk, uint32_t n_blk, uint8_t *out, DecodeSummary *sum) {
+void launch_bgzf_inflate(hipStream_t s, const uint8_t *in, const DevBgzfBlock *blk, uint32_t n_blk, uint8_t *out, DecodeSummary *sum, bool one_pass) {
     if (!n_blk) return;
     // four waves per SIMD of the chip; the counter feeds them
     static const int wpw = getenv("RSQC_INFLATE_WPW") ? atoi(getenv("RSQC_INFLATE_WPW")) : 4;
     static bool told = false;
     if (!told && getenv("RSQC_DECODE_PROFILE")) {
         int a = 0, b = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bgzf_inflate_kernel<1>, 64, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bgzf_inflate_kernel<4>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bgzf_inflate_kernel<1, true>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bgzf_inflate_kernel<4, true>, 256, 0);
         fprintf(stderr, "[decode] inflate kernel: %d workgroups of 1 wave or %d of 4 waves per CU; running %d waves per workgroup\n", a, b, wpw);
         told = true;
     }
     if (wpw == 1) {
         const uint32_t grid = n_blk < 256u * 16u ? n_blk : 256u * 16u;
-        bgzf_inflate_kernel<1><<<grid, 64, 0, s>>>(in, blk, n_blk, out, sum);
+        if (one_pass) bgzf_inflate_kernel<1, true><<<grid, 64, 0, s>>>(in, blk, n_blk, out, sum);
+        else bgzf_inflate_kernel<1, false><<<grid, 64, 0, s>>>(in, blk, n_blk, out, sum);
     } else {
         const uint32_t need = (n_blk + 3u) / 4u, grid = need < 256u * 8u ? need : 256u * 8u;
-        bgzf_inflate_kernel<4><<<grid, 256, 0, s>>>(in, blk, n_blk, out, sum);
+        if (one_pass) bgzf_inflate_kernel<4, true><<<grid, 256, 0, s>>>(in, blk, n_blk, out, sum);
+        else bgzf_inflate_kernel<4, false><<<grid, 256, 0, s>>>(in, blk, n_blk, out, sum);
     }
 }
 void launch_decode_window(hipStream_t s, const DecodeWindow &W, uint32_t *scratch) {

@@ -130,11 +130,12 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 #ifndef INF_ROUND_BYTES_CFG
 #define INF_ROUND_BYTES_CFG 1024
 #endif
-// 1: a round whose output fits one byte per lane and whose matches all copy from before the round is committed in ONE vector pass
-// (inflate_round).  Measured (profiles/r3_decode_ab.txt, same box, alternating builds, outputs identical): +7.4 % on the file with
-// the entropy of a real BAM (35.1 -> 37.7 GB/s: most of its rounds qualify), -6 % on the SURVEY 8(d) file (131 -> 124 GB/s: its
-// rounds are long matches and never qualify -- the cost there is the 256 bytes of LDS and the registers the path holds).  ON: real
-// files are what the decoder is for.  The host tests run both forms.
+// The one-pass commit of a round (inflate_round<true>): a round whose output fits one byte per lane and whose matches all copy from
+// before the round is committed in ONE vector pass.  Measured (profiles/r3_decode_ab.txt, same box, alternating builds, outputs
+// identical): +7.4 % on the file with the entropy of a real BAM (35.1 -> 37.7 GB/s: most of its rounds qualify), -6 % on the
+// SURVEY 8(d) file (131 -> 124 GB/s: its rounds are long matches and never qualify -- the cost there is the registers the path
+// holds).  Both forms are therefore compiled (template parameter PAR) and rsqc_decode_submit picks per call by the call's
+// compression ratio.  INF_PAR_COMMIT_CFG is the form the host tests and a caller without a preference get.
 #ifndef INF_PAR_COMMIT_CFG
 #define INF_PAR_COMMIT_CFG 1
 #endif
@@ -160,9 +161,7 @@ struct InflateScratch {
     uint8_t lens[320];                   // code lengths of the block being set up
     uint16_t offs[16];                   // first slot of a length in lsym / dsym while a table is built
     uint32_t crc_tab[256];               // CRC-32 (reflected 0xEDB88320), one byte per step
-#if INF_PAR_COMMIT_CFG
     uint32_t slot[64];                   // one-pass commit of a round: the symbol that starts at output byte i of the round
-#endif
 };
 
 // ---- CRC-32 of the inflated bytes (the gzip member's trailer; htslib's bgzf reader checks it, so a corrupt block is an
@@ -518,6 +517,7 @@ RSQC_INF_FN bool inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut
 }
 
 // true = the block goes on; false = it ended (status untouched) or failed (status = the InflateStatus)
+template <bool PAR = (INF_PAR_COMMIT_CFG != 0)>
 RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, uint32_t &status) {
     bi.refill();
     const uint32_t avail = bi.avail();
@@ -623,13 +623,12 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
             INF_FOREACH(k) { (void)k; INF_AT(BADM, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) > o.pos + INF_AT(INC, k) - INF_AT(OL, k)) ? 1u : 0u; }
             if (inf_ballot(BADM)) { status = INF_ERR_DISTANCE; return false; }
         }
-#if INF_PAR_COMMIT_CFG
         // One pass for the whole round, one lane per OUTPUT byte, when the round puts out at most 64 bytes and no match reads what
         // this round writes (distance >= the match's end inside the round; 84 % of the rounds of a real file).  The symbols leave
         // (literal byte | distance) in the slot of their first output byte; a ballot over the slots is the mask of first bytes; a
         // byte lane finds its symbol as the highest first byte at or below it.  Every source is read before any byte is stored,
         // so a store cannot land on a ring slot that a match of the same round still has to read.
-        bool one_pass = total <= 64u;                                       // (rounds of long matches -- a low-entropy file -- skip even the test)
+        bool one_pass = PAR && total <= 64u;                                       // (rounds of long matches -- a low-entropy file -- skip even the test)
         if (one_pass) {
             InfVec DEP;
             INF_FOREACH(k) { (void)k; INF_AT(DEP, k) = (INF_AT(ISMATCH, k) && INF_AT(VAL, k) < INF_AT(INC, k)) ? 1u : 0u; }
@@ -677,7 +676,6 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
             }
             INF_FOREACH(j) { if (j < total) S.ring[(r0 + j) & INF_RMASK] = (uint8_t)INF_AT(BYTE_, j); }
         } else
-#endif
         {
         while (match) {                                                     // in stream order: the literals before the next match, then the match
             const uint32_t m = (uint32_t)__builtin_ctzll(match);
@@ -702,6 +700,7 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
 // Inflates `in_len` payload bytes at `in` into exactly `out_len` bytes at `dst` and checks their CRC-32 (inflate_crc_init
 // has filled S.crc_tab).  Returns an InflateStatus (wave-uniform).
 // The caller provides 16 readable bytes past the payload's end (the bit reader looks ahead by whole dwords).
+template <bool PAR = (INF_PAR_COMMIT_CFG != 0)>
 RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_len, uint8_t *dst, uint32_t out_len, uint32_t crc32) {
     static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -770,7 +769,7 @@ RSQC_INF_FN int inflate_block(InflateScratch &S, const uint8_t *in, uint32_t in_
             if (!INF_BUILD(S.lens + nlit, ndist, S.dcount, S.dsym, S.dfirst, S.didx, S.dfast, INF_DBITS, S.offs, INF_T_DIST)) return INF_ERR_TABLE;
             // ---- the symbols, in rounds (inflate_round)
             uint32_t status = INF_OK;
-            while (inflate_round(S, bi, o, status)) {}
+            while (inflate_round<PAR>(S, bi, o, status)) {}
             if (status) return (int)status;
         } else return INF_ERR_BTYPE;
         if (bfinal) break;

@@ -697,10 +697,15 @@ RSQC_HD void exon_metrics_fast(const DevAnnotation &a, const DevParams &p, const
 // find(x): index of the last breakpoint <= x on the contig, and whether x itself is one.  x is clamped into the
 // positions the contig's rank words cover (beyond the last breakpoint nothing changes any more).
 struct EiFind { uint32_t j; bool at; };
-RSQC_HD EiFind ei_find(const DevAnnotation &a, const ContigInfo &ci, int32_t x, bool have) {
+// the rank word that answers find(x) (phase 1 of a block query: the load), and the answer from it (phase 2)
+RSQC_HD EiRank ei_find_word(const DevAnnotation &a, const ContigInfo &ci, int32_t x, bool have) {
     const int32_t top = (int32_t)(ci.rk_words << 6) - 1;
     const int32_t xc = x < 0 ? 0 : (x > top ? top : x);
-    const EiRank w = ld32(a.ei_rank, have ? ci.rk_base + ((uint32_t)xc >> 6) : 0u);
+    return ld32(a.ei_rank, have ? ci.rk_base + ((uint32_t)xc >> 6) : 0u);
+}
+RSQC_HD EiFind ei_find_in(const EiRank &w, const ContigInfo &ci, int32_t x) {
+    const int32_t top = (int32_t)(ci.rk_words << 6) - 1;
+    const int32_t xc = x < 0 ? 0 : (x > top ? top : x);
     // bits 0..(xc & 63) of the word, moved to the top: their count is the number of breakpoints <= xc inside the word and
     // the top bit says whether xc is one
     const uint32_t sh = 63u - ((uint32_t)xc & 63u);
@@ -726,29 +731,41 @@ RSQC_HD uint32_t ei_class_flags(uint32_t mask, int rstrand) {
 // One block against the index.  Returns the OR of the interval masks of [bs, be] (incl. EIM_DEEP of the two intervals
 // the containment test reads) and the block's (at most two) containing exons as commit operands.
 struct EiBlock { uint32_t mask; bool cA, cB; uint32_t eidA, gfA, cidxA, eidB, gfB, cidxB; };
-RSQC_HD void ei_query_block(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, uint32_t len, bool on, int rstrand, EiBlock &o) {
-    const int32_t be = bs + (int32_t)len;
-    const bool have = on && ci.rk_words != 0 && be >= 0;
-    const EiFind fs = ei_find(a, ci, bs, have), fe = ei_find(a, ci, be, have);
-    const uint32_t js = have ? fs.j : 0u, je = have ? fe.j : 0u;
-    const uint32_t j1 = (fe.at && len > 0 && je > js) ? je - 1 : je;      // find(max(bs, be - 1))
-    const EiEntry S = ld32(a.ei, js);
-    const uint32_t m1 = ld32(a.ei, j1).mask, e1A = ld32(a.ei, j1).eidA, e1B = ld32(a.ei, j1).eidB;
-    // intervals js .. je: js, j1 (= je - 1 or je), je and js + 1 are read in one round of independent loads; only a block
-    // across more than three intervals goes back to memory
-    uint32_t mask = S.mask | m1 | ld32(a.ei, je).mask | ld32(a.ei, js < je ? js + 1 : je).mask;
-    if (RSQC_ANY_LANE(have && je > js + 2))
-        for (uint32_t j = js + 2; have && j < je; ++j) mask |= ld32(a.ei, j).mask;
+// A block query in three phases, so that the loads of SEVERAL blocks of a record travel together (a record of two blocks costs
+// two round trips, not four: the latency of dependent loads, not their number, is what a wave waits for):
+//   ei_probe    the two rank words (independent loads)
+//   ei_fetch    indices from the rank words; the interval entries (one round of independent loads)
+//   ei_resolve  masks and containing exons; only a block across more than three intervals goes back to memory
+struct EiProbe { EiRank ws, we; int32_t bs, be; uint32_t len; bool have; };
+struct EiFetch { EiEntry S; uint32_t m1, e1A, e1B, m_je, m_js1; uint32_t js, je, j1; };
+RSQC_HD void ei_probe(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, uint32_t len, bool on, EiProbe &q) {
+    q.bs = bs; q.len = len; q.be = bs + (int32_t)len;
+    q.have = on && ci.rk_words != 0 && q.be >= 0;
+    q.ws = ei_find_word(a, ci, q.bs, q.have); q.we = ei_find_word(a, ci, q.be, q.have);
+}
+RSQC_HD void ei_fetch(const DevAnnotation &a, const ContigInfo &ci, const EiProbe &q, EiFetch &f) {
+    const EiFind fs = ei_find_in(q.ws, ci, q.bs), fe = ei_find_in(q.we, ci, q.be);
+    f.js = q.have ? fs.j : 0u; f.je = q.have ? fe.j : 0u;
+    f.j1 = (fe.at && q.len > 0 && f.je > f.js) ? f.je - 1 : f.je;        // find(max(bs, be - 1))
+    f.S = ld32(a.ei, f.js);
+    f.m1 = ld32(a.ei, f.j1).mask; f.e1A = ld32(a.ei, f.j1).eidA; f.e1B = ld32(a.ei, f.j1).eidB;
+    // intervals js .. je: js, j1 (= je - 1 or je), je and js + 1 are read in this one round
+    f.m_je = ld32(a.ei, f.je).mask; f.m_js1 = ld32(a.ei, f.js < f.je ? f.js + 1 : f.je).mask;
+}
+RSQC_HD void ei_resolve(const DevAnnotation &a, const EiProbe &q, const EiFetch &f, int rstrand, EiBlock &o) {
+    uint32_t mask = f.S.mask | f.m1 | f.m_je | f.m_js1;
+    if (RSQC_ANY_LANE(q.have && f.je > f.js + 2))
+        for (uint32_t j = f.js + 2; q.have && j < f.je; ++j) mask |= ld32(a.ei, j).mask;
     // EIM_DEEP matters only where the exon lists are read
-    mask = (mask & ~EIM_DEEP) | ((S.mask | m1) & EIM_DEEP);
-    const bool same = j1 == js;
-    const bool sA = rstrand == RSQC_STRAND_UNKNOWN || rstrand == (int)((S.gfA >> ROW_FLAG_SHIFT) & RSQC_FF_STRAND_MASK);
-    const bool sB = rstrand == RSQC_STRAND_UNKNOWN || rstrand == (int)((S.gfB >> ROW_FLAG_SHIFT) & RSQC_FF_STRAND_MASK);
-    o.mask = have ? mask : 0u;
-    o.cA = have && S.eidA != EI_NONE && sA && (same || S.eidA == e1A || S.eidA == e1B);
-    o.cB = have && S.eidB != EI_NONE && sB && (same || S.eidB == e1A || S.eidB == e1B);
-    o.eidA = S.eidA; o.gfA = S.gfA; o.cidxA = S.cdA + (uint32_t)bs;
-    o.eidB = S.eidB; o.gfB = S.gfB; o.cidxB = S.cdB + (uint32_t)bs;
+    mask = (mask & ~EIM_DEEP) | ((f.S.mask | f.m1) & EIM_DEEP);
+    const bool same = f.j1 == f.js;
+    const bool sA = rstrand == RSQC_STRAND_UNKNOWN || rstrand == (int)((f.S.gfA >> ROW_FLAG_SHIFT) & RSQC_FF_STRAND_MASK);
+    const bool sB = rstrand == RSQC_STRAND_UNKNOWN || rstrand == (int)((f.S.gfB >> ROW_FLAG_SHIFT) & RSQC_FF_STRAND_MASK);
+    o.mask = q.have ? mask : 0u;
+    o.cA = q.have && f.S.eidA != EI_NONE && sA && (same || f.S.eidA == f.e1A || f.S.eidA == f.e1B);
+    o.cB = q.have && f.S.eidB != EI_NONE && sB && (same || f.S.eidB == f.e1A || f.S.eidB == f.e1B);
+    o.eidA = f.S.eidA; o.gfA = f.S.gfA; o.cidxA = f.S.cdA + (uint32_t)q.bs;
+    o.eidB = f.S.eidB; o.gfB = f.S.gfB; o.cidxB = f.S.cdB + (uint32_t)q.bs;
 }
 
 // exonAlignmentMetrics (src/Expression.cpp:308-458) for a record of NB <= FAST_BLOCKS blocks, all lanes of a wave
@@ -772,11 +789,22 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
     uint32_t aligned = 0;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) { out.eid[k] = 0; out.cidx[k] = 0; }
+    EiBlock qb[NB];
+#pragma unroll
+    for (int b0 = 0; b0 < NB; b0 += 2) {                  // two blocks' loads in flight at a time
+        constexpr int G = 2;
+        EiProbe pr[G]; EiFetch fe[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_probe(a, ci, bs[b0 + j], len[b0 + j], lane_on && (uint32_t)(b0 + j) < nbv, pr[j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_fetch(a, ci, pr[j], fe[j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_resolve(a, pr[j], fe[j], rstrand, qb[b0 + j]);
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const bool live = (uint32_t)b < nbv;
-        EiBlock q;
-        ei_query_block(a, ci, bs[b], len[b], lane_on && live, rstrand, q);
+        const EiBlock &q = qb[b];
         mask |= q.mask;
         aligned += live ? len[b] : 0u;
         const uint32_t g0 = q.gfA & ROW_GENE_MASK, g1 = q.gfB & ROW_GENE_MASK;
