@@ -943,19 +943,20 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             // streaming form: survivors appended to per-partition key lists, then counted per partition in LDS.
             // bounds from the host's pair bound: partitions <= pairs / PART_READS + G, keys <= 2 x pairs + SUB_CAP x parts
             const uint64_t Gz = (uint64_t)std::max(G, 1);
-            const uint64_t parts_bound = pair_bound / 1024 + Gz + 1;
-            const uint64_t keys_bound = 2 * pair_bound + 2048 * std::min<uint64_t>(parts_bound, pair_bound / 1024 + 1) + 16;
+            const uint64_t parts_bound = pair_bound / RSQC_K4_PART_READS + Gz + 1;
+            const uint64_t keys_bound = 2 * pair_bound + RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, pair_bound / RSQC_K4_PART_READS + 1) + 16;
             if (parts_bound > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment partitions");
             const uint64_t lay_blocks = (Gz + 1023) / 1024;
-            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 12 + 64 + lay_blocks * 12 + 64, false))) return rc;  // gene_base | part_first | layout totals
-            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 8 + 64, false))) return rc;                    // cursor | part_gene
+            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 28 + 64 + lay_blocks * 12 + 64, false))) return rc;  // per-gene rows | gene_base | part_first | layout totals
+            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 20 + 64, false))) return rc;                   // per-partition rows | cursor
             if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
             FragPlan P;
-            P.gene_base = (uint64_t *)c->d_tab_off.p;
-            P.part_first = (uint32_t *)((uint64_t *)c->d_tab_off.p + Gz + 1);
+            P.ginfo = (uint4 *)c->d_tab_off.p;
+            P.gene_base = (uint64_t *)(P.ginfo + Gz + 1);
+            P.part_first = (uint32_t *)(P.gene_base + Gz + 1);
             P.blk_space = (unsigned long long *)(((uintptr_t)(P.part_first + Gz + 2) + 15) & ~(uintptr_t)15);
             P.blk_parts = (uint32_t *)(P.blk_space + lay_blocks);
-            P.cursor = (uint32_t *)c->d_tab_cap.p; P.part_gene = P.cursor + parts_bound;
+            P.part_info = (uint4 *)c->d_tab_cap.p; P.cursor = (uint32_t *)(P.part_info + parts_bound);
             P.list = (unsigned long long *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
             if (c->pair_arena.used && !getenv("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces
@@ -978,7 +979,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
                 launch_frag_local(c->stream, acc, pb.n_chunks, P, 0);
             }
-            if (!getenv("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, c->acc.gene_reads, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
+            if (!getenv("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
         }
         // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));

@@ -140,11 +140,18 @@ void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc, uint32_t *summary);
 // K4, streaming form (rsqc_kernels.hip): partition tables laid out on the device from the final geneCounts
+// fragment partitions (rsqc_kernels.hip, K4): a gene with n counted records owns ceil(n / PART_READS) partitions of capacity
+// SUB_CAP keys each (or one partition of capacity n); a partition's keys are counted by one workgroup in an LDS set of PART_SLOTS
+#define RSQC_K4_PART_READS 1024
+#define RSQC_K4_SUB_CAP 2048
+#define RSQC_K4_PART_SLOTS 4096
+#define RSQC_K4_COUNT_THREADS 256
 struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
     uint64_t *gene_base;           // [G] offset of the gene's key lists
     uint32_t *cursor;              // [parts] keys appended so far
-    uint32_t *part_gene;           // [parts] owning gene
+    uint4 *ginfo;                  // [G] {first partition, partitions, capacity of one, 0}: what frag_local_kernel gathers per pair
+    uint4 *part_info;              // [parts] {owning gene, capacity, list offset lo, hi}
     unsigned long long *list;      // key lists
     unsigned long long *blk_space; uint32_t *blk_parts;   // [ceil(G / 1024)] per-workgroup totals of the layout scan
 };
@@ -152,8 +159,7 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks);
 void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, uint32_t chunk_cap, const uint32_t *counts,
                          uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash);
-void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound,
-                       unsigned long long *gene_frag, int *error);
+void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error);
 
 }  // namespace rsqc
 

@@ -29,6 +29,11 @@ namespace rsqc { __device__ __forceinline__ void k1_mark(int sec); __device__ __
 #endif
 
 #include "rsqc_device.h"
+#ifndef RSQC_K1_PROF
+#define RSQC_FIN_STAMP(sec)
+#define RSQC_FIN_SECT(base, sec)
+#define RSQC_FIN_BEGIN
+#endif
 
 namespace rsqc {
 
@@ -54,6 +59,25 @@ __device__ __forceinline__ void k1_mark(int sec) {
 __device__ __forceinline__ void k1_event(int id, bool cond) {
     const unsigned long long m = __ballot(cond);
     if (m && lane_id() == 0) { atomicAdd(&s_prof_acc[32 + id], 1ull); atomicAdd(&s_prof_acc[36 + id], (unsigned long long)__popcll(m)); }
+}
+// end-of-file stage: [0..31] absolute shader-clock stamps of thread 0 of the first workgroup of the longest-gene launch of K3,
+// [32..47] cycles per section of frag_local_kernel summed over its workgroups (thread 0), [48..63] the same for frag_count_kernel
+__device__ unsigned long long g_fin_prof[64];
+__shared__ unsigned long long s_fin_stamp[12];      // the stamps of this workgroup; the slowest workgroup of the launch publishes its set
+#define RSQC_FIN_STAMP(sec) do { if (first == 0 && threadIdx.x == 0) s_fin_stamp[sec] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RSQC_FIN_SECT(base, sec) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_fin_prof[(base) + (sec)], t_ - fin_last); fin_last = t_; } } while (0)
+#define RSQC_FIN_BEGIN unsigned long long fin_last = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long g_dbg_pair_hash[32768]; __device__ uint32_t g_dbg_pair_gene[32768]; __device__ uint32_t g_dbg_pair_count;
+extern "C" __attribute__((visibility("default"))) int rsqc_debug_pairs(unsigned long long *hash, uint32_t *gene, uint32_t *count) {
+    if (hipMemcpyFromSymbol(hash, HIP_SYMBOL(g_dbg_pair_hash), sizeof(g_dbg_pair_hash)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(gene, HIP_SYMBOL(g_dbg_pair_gene), sizeof(g_dbg_pair_gene)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_dbg_pair_count), 4) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int rsqc_debug_fin_prof(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_prof), sizeof(g_fin_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fin_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
 }
 extern "C" __attribute__((visibility("default"))) int rsqc_debug_k1_prof(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1_prof), sizeof(g_k1_prof)) != hipSuccess) return -1;
@@ -770,11 +794,14 @@ void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t
 //                       keys is added to geneFragmentCounts
 // A partition expects <= RSQC_K4_PART_READS / 2 .. RSQC_K4_PART_READS keys and has room for RSQC_K4_SUB_CAP; one
 // that overflows (never with random hashes) reports RSQC_ERR_CAPACITY instead of miscounting.
-#define RSQC_K4_PART_READS 1024
-#define RSQC_K4_SUB_CAP 2048
-#define RSQC_K4_PART_SLOTS 4096
-#define RSQC_K4_COUNT_THREADS 256
 
+// the partition of a key inside its gene comes from the key's HIGH word (the keys are rsqc_qname_hash values: FNV-1a + fmix64;
+// one multiply-xorshift on top keeps a caller's weaker hash from piling up), the slot inside the partition's set from the low word
+__device__ __forceinline__ uint32_t frag_part_hash(uint64_t key) {
+    uint32_t h = (uint32_t)(key >> 32);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
 __device__ __forceinline__ uint32_t frag_parts_of(unsigned long long reads) {
     return (uint32_t)((reads + RSQC_K4_PART_READS - 1) / RSQC_K4_PART_READS);
 }
@@ -808,7 +835,7 @@ frag_layout_totals_kernel(const unsigned long long *gene_reads, uint32_t n_genes
 }
 __global__ void __launch_bounds__(1024)
 frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const unsigned long long *blk_space, const uint32_t *blk_parts,
-                   uint32_t *part_first, uint64_t *gene_base) {
+                   uint32_t *part_first, uint4 *ginfo, uint64_t *gene_base, uint32_t *cursor, uint4 *part_info) {
     __shared__ unsigned long long w_space[16];
     __shared__ uint32_t w_parts[16];
     __shared__ unsigned long long s_base; __shared__ uint32_t p_base;
@@ -820,8 +847,8 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
         if (l == 0) { s_base = s; p_base = p; }
     }
     const uint32_t g = blockIdx.x * 1024u + threadIdx.x;
-    unsigned long long space = 0; uint32_t parts = 0;
-    if (g < n_genes) { const unsigned long long n = gene_reads[g]; parts = frag_parts_of(n); space = (unsigned long long)parts * frag_cap_of(n); }
+    unsigned long long space = 0; uint32_t parts = 0, cap = 0;
+    if (g < n_genes) { const unsigned long long n = gene_reads[g]; parts = frag_parts_of(n); cap = frag_cap_of(n); space = (unsigned long long)parts * cap; }
     unsigned long long isp = space; uint32_t ipt = parts;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -832,38 +859,51 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
     __syncthreads();
     unsigned long long bs = s_base; uint32_t bp = p_base;
     for (int w = 0; w < wv; ++w) { bs += w_space[w]; bp += w_parts[w]; }
-    if (g < n_genes) { part_first[g] = bp + ipt - parts; gene_base[g] = bs + isp - space; }
+    const uint32_t pf = bp + ipt - parts; const unsigned long long gb = bs + isp - space;
+    if (g < n_genes) { part_first[g] = pf; gene_base[g] = gb; ginfo[g] = make_uint4(pf, parts, cap, 0u); }
     if (g == n_genes - 1) part_first[n_genes] = bp + ipt;
-}
-// per partition: fill cursor = 0 and its owning gene (one binary search per partition, all in parallel, so that
-// the counting kernel starts from a single load)
-__global__ void __launch_bounds__(256)
-frag_zero_kernel(uint32_t *cursor, uint32_t *part_gene, const uint32_t *part_first, uint32_t n_genes) {
-    const uint32_t n = part_first[n_genes];
-    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
-        cursor[w] = 0u;
-        uint32_t lo = 0, hi = n_genes;                                 // last g with part_first[g] <= w (genes without
-        while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (part_first[m] <= w) lo = m; else hi = m; }   // partitions share their value with the owner)
-        part_gene[w] = lo;
+    // per partition: fill cursor = 0 and what the counting kernel needs in one load {gene, capacity, list offset}.  Most genes
+    // own one partition; the wave walks the partitions of its larger genes together
+    if (parts >= 1) { cursor[pf] = 0u; part_info[pf] = make_uint4(g, cap, (uint32_t)gb, (uint32_t)(gb >> 32)); }
+    unsigned long long big = __ballot(parts > 1);
+    while (big) {
+        const int src = __ffsll(big) - 1; big &= big - 1;
+        const uint32_t pf_s = lane_value(pf, src), n_s = lane_value(parts, src), cap_s = lane_value(cap, src), g_s = lane_value(g, src);
+        const unsigned long long gb_s = (unsigned long long)lane_value((uint32_t)gb, src) | ((unsigned long long)lane_value((uint32_t)(gb >> 32), src) << 32);
+        for (uint32_t k = 1u + (uint32_t)l; k < n_s; k += 64) {
+            const unsigned long long off = gb_s + (unsigned long long)k * cap_s;
+            cursor[pf_s + k] = 0u; part_info[pf_s + k] = make_uint4(g_s, cap_s, (uint32_t)off, (uint32_t)(off >> 32));
+        }
     }
 }
 
-// frag_local_kernel: 256 threads take 1024 pairs per LDS pass (4 per thread) through a 2048-slot table: 25 KB of LDS,
-// six workgroups per CU (measured against 512 / 2048 / 4096 and 128 / 512 / 1024)
+// frag_local_kernel: every (gene, name hash) pair of a chunk goes to the key list of its partition (partition = gene's first +
+// hash-scaled index).  256 threads take 1024 pairs per pass (4 per thread): the pairs of a pass that share a partition reserve
+// their list slots with ONE memory atomic (ranks inside the pass come from a small LDS table keyed by partition id).
+// The kernel is a chain of dependent gathers, so it is laid out as a pipeline: the pairs of pass k + 1 and the per-gene rows of
+// pass k are in flight while pass k - 1's ranks are taken.
+// What bounds it is the memory side: one returning atomic and one scattered 8-byte store per pair of a gene with many
+// partitions.  The two mates of a fragment sit a few hundred records apart, i.e. in the same chunk, so half of the pairs are
+// repeats the counting kernel would throw away: a direct-mapped LDS window over the WHOLE chunk (one 64-bit exchange per pair,
+// never cleared between passes, no probing: a newer pair simply replaces an older one) drops a pair whose word is already
+// there.  (A per-pass table with probing removed 12 % of the keys for 18 % of the kernel; the window removes the mates.)
+// The word is key ^ f(gene): two different (gene, key) pairs share a word with probability 2^-64 per comparison, the same
+// order as two names sharing a 64-bit hash, which is the identity this stage works with (include/rnaseqc_amd.h).
 #define RSQC_K4L_THREADS 256
-#define RSQC_K4L_LSLOTS 2048
 #define RSQC_K4L_PIECE 1024
+#define RSQC_K4L_GSLOTS 1024
+#ifndef RSQC_K4L_WIN
+#define RSQC_K4L_WIN 2048
+#endif
 struct K4LocalShared {
-    unsigned long long lkey[RSQC_K4L_LSLOTS];
-    uint32_t lgene[RSQC_K4L_LSLOTS];
-    uint32_t gkey[RSQC_K4_GSLOTS], gcnt[RSQC_K4_GSLOTS], gbase[RSQC_K4_GSLOTS];      // keyed by partition id
+    uint32_t gkey[RSQC_K4L_GSLOTS], gcnt[RSQC_K4L_GSLOTS];      // keyed by partition id: pairs of the pass, then their first list slot
+    unsigned long long win[RSQC_K4L_WIN];       // direct-mapped window of the chunk's recent (gene, key) words: see the kernel
 };
 
 __global__ void __launch_bounds__(RSQC_K4L_THREADS)
 frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-                  const unsigned long long *gene_reads, const uint32_t *part_first, const uint64_t *gene_base, uint32_t *cursor,
-                  unsigned long long *list, int *error) {
+                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, unsigned long long *list, int *error) {
     __shared__ K4LocalShared S;
     uint32_t base, count, piece0 = 0, piece_step = 1;
     if (blockIdx.x < n_chunks) {
@@ -875,105 +915,179 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
         piece0 = blockIdx.x - n_chunks; piece_step = gridDim.x - n_chunks;
     }
     constexpr int U = RSQC_K4L_PIECE / RSQC_K4L_THREADS;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;
-    for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < RSQC_K4L_LSLOTS; i += blockDim.x) { S.lkey[i] = 0ull; S.lgene[i] = 0xFFFFFFFFu; }
-        for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x) { S.gkey[i] = 0xFFFFFFFFu; S.gcnt[i] = 0u; }
-        __syncthreads();
-        const uint32_t p0 = piece * RSQC_K4L_PIECE, p1 = p0 + RSQC_K4L_PIECE < count ? p0 + RSQC_K4L_PIECE : count;
-        bool live[U]; uint32_t g[U], gp[U], gslot[U], rank[U]; uint64_t key[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                      // the pairs of the piece
-            const uint32_t j = p0 + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
-            live[u] = j < p1;
-            g[u] = live[u] ? pair_gene[base + j] : 0u;
-            key[u] = live[u] ? pair_hash[base + j] : 0ull;
-            gslot[u] = 0xFFFFFFFFu; rank[u] = 0; gp[u] = 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                      // de-dup inside the piece (see dedup_kernel)
-            if (key[u] == 0) key[u] = 0x9e3779b97f4a7c15ull;
-            if (live[u]) {
-                unsigned long long lk = key[u] ^ ((unsigned long long)g[u] * 0x9E3779B97F4A7C15ull);
-                if (lk == 0ull) lk = 1ull;
-                uint32_t slot = (uint32_t)(mix64(lk) >> 32) & (RSQC_K4L_LSLOTS - 1);
-                bool done = false;
-#pragma unroll 1
-                for (int probe = 0; probe < 8 && !done; ++probe) {
-                    const unsigned long long old = atomicCAS(&S.lkey[slot], 0ull, lk);
-                    if (old == 0ull) { S.lgene[slot] = g[u]; done = true; }
-                    if (!done && old == lk) { if (S.lgene[slot] == g[u]) live[u] = false; done = true; }
-                    slot = (slot + 1) & (RSQC_K4L_LSLOTS - 1);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                      // survivors per partition: rank inside the piece
-            if (!live[u]) continue;
-            const uint32_t first = part_first[g[u]], n_part = part_first[g[u] + 1] - first;
-            gp[u] = first + (n_part > 1 ? (uint32_t)(((mix64(key[u]) >> 32) * (unsigned long long)n_part) >> 32) : 0u);
-            uint32_t sl = gp[u] & (RSQC_K4_GSLOTS - 1);
-#pragma unroll 1
-            for (int probe = 0; probe < 8; ++probe) {
-                const uint32_t o = atomicCAS(&S.gkey[sl], 0xFFFFFFFFu, gp[u]);
-                if (o == 0xFFFFFFFFu || o == gp[u]) { gslot[u] = sl; rank[u] = atomicAdd(&S.gcnt[sl], 1u); break; }
-                sl = (sl + 1) & (RSQC_K4_GSLOTS - 1);
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < RSQC_K4_GSLOTS; i += blockDim.x)     // one reservation per partition of the piece
-            if (S.gkey[i] != 0xFFFFFFFFu) S.gbase[i] = atomicAdd(&cursor[S.gkey[i]], S.gcnt[i]);
-        __syncthreads();
+    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!live[u]) continue;
-            const uint32_t at = gslot[u] != 0xFFFFFFFFu ? S.gbase[gslot[u]] + rank[u] : atomicAdd(&cursor[gp[u]], 1u);   // (crowded table)
-            const uint32_t cap = frag_cap_of(gene_reads[g[u]]);
-            if (at < cap) list[gene_base[g[u]] + (unsigned long long)(gp[u] - part_first[g[u]]) * cap + at] = key[u];
+            const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
+            const bool ok = piece < n_pieces && j < count;
+            g[u] = ok ? pair_gene[base + j] : NONE;
+            key[u] = ok ? pair_hash[base + j] : 0ull;
+        }
+    };
+#ifdef RSQC_K1_PROF
+    if (blockIdx.x == 1000 && n_chunks > 1000) {                           // (diagnostic: one chunk, as K1 wrote it)
+        for (uint32_t i = threadIdx.x; i < count && i < 32768u; i += blockDim.x) { g_dbg_pair_hash[i] = pair_hash[base + i]; g_dbg_pair_gene[i] = pair_gene[base + i]; }
+        if (threadIdx.x == 0) g_dbg_pair_count = count;
+    }
+#endif
+    uint32_t g[U]; uint64_t key[U];
+    load_piece(piece0, g, key);
+    for (int i = threadIdx.x; i < RSQC_K4L_WIN; i += blockDim.x) S.win[i] = 0ull;
+    RSQC_FIN_BEGIN
+    for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
+        RSQC_FIN_SECT(32, 0);
+        uint4 gi[U]; uint64_t gb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; gb[u] = gene_base[gq]; }
+        uint32_t gn[U]; uint64_t keyn[U];
+        load_piece(piece + piece_step, gn, keyn);
+        __syncthreads();                                                   // (the previous pass has read its list slots)
+        for (int i = threadIdx.x; i < RSQC_K4L_GSLOTS; i += blockDim.x) { S.gkey[i] = NONE; S.gcnt[i] = 0u; }
+        __syncthreads();
+        RSQC_FIN_SECT(32, 1);
+        uint32_t gp[U], gslot[U], rank[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                      // rank of the pair among the pass's pairs of its partition
+            gslot[u] = NONE; rank[u] = 0; gp[u] = 0;
+            if (key[u] == 0) key[u] = 0x9e3779b97f4a7c15ull;
+            if (g[u] == NONE) continue;
+            {
+                unsigned long long lk = key[u] ^ (((unsigned long long)g[u] << 32) | (unsigned long long)(g[u] * 0x9E3779B1u));
+                if (lk == 0ull) lk = 1ull;
+                static_assert((RSQC_K4L_WIN & (RSQC_K4L_WIN - 1)) == 0, "window size");
+                const uint32_t ws = ((((uint32_t)lk ^ (uint32_t)(lk >> 32)) * 0x9E3779B1u) >> 12) & (RSQC_K4L_WIN - 1);
+                if (atomicExch(&S.win[ws], lk) == lk) { g[u] = NONE; continue; }      // its mate went through this chunk already
+            }
+            gp[u] = gi[u].x + (gi[u].y > 1 ? (uint32_t)(((unsigned long long)frag_part_hash(key[u]) * gi[u].y) >> 32) : 0u);
+            uint32_t sl = (gp[u] * 0x9E3779B1u) >> (32 - 10);
+            static_assert(RSQC_K4L_GSLOTS == 1 << 10, "slot hash");
+#pragma unroll 1
+            for (int probe = 0; probe < 16; ++probe) {
+                const uint32_t o = atomicCAS(&S.gkey[sl], NONE, gp[u]);
+                if (o == NONE || o == gp[u]) { gslot[u] = sl; rank[u] = atomicAdd(&S.gcnt[sl], 1u); break; }
+                sl = (sl + 1) & (RSQC_K4L_GSLOTS - 1);
+            }
+        }
+        RSQC_FIN_SECT(32, 3);
+        __syncthreads();
+        RSQC_FIN_SECT(32, 4);
+        {                                                                  // one reservation per partition of the pass, all in flight
+            constexpr int R = RSQC_K4L_GSLOTS / RSQC_K4L_THREADS;
+            uint32_t pk[R], pc[R], pr[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) { pk[j] = S.gkey[j * RSQC_K4L_THREADS + threadIdx.x]; pc[j] = S.gcnt[j * RSQC_K4L_THREADS + threadIdx.x]; }
+#pragma unroll
+            for (int j = 0; j < R; ++j) pr[j] = pk[j] != NONE ? atomicAdd(&cursor[pk[j]], pc[j]) : 0u;
+#pragma unroll
+            for (int j = 0; j < R; ++j) S.gcnt[j * RSQC_K4L_THREADS + threadIdx.x] = pr[j];
+        }
+        __syncthreads();
+        RSQC_FIN_SECT(32, 5);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (g[u] == NONE) continue;
+            const uint32_t at = gslot[u] != NONE ? S.gcnt[gslot[u]] + rank[u] : atomicAdd(&cursor[gp[u]], 1u);   // (crowded table)
+            const uint32_t cap = gi[u].z;
+            if (at < cap) list[gb[u] + (unsigned long long)(gp[u] - gi[u].x) * cap + at] = key[u];
             else atomicExch(error, RSQC_ERR_CAPACITY);
         }
+        RSQC_FIN_SECT(32, 6);
+#ifdef RSQC_K1_PROF
+        if (threadIdx.x == 0) atomicAdd(&g_fin_prof[32 + 15], 1ull);
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; }
     }
 }
 
+// barrier of a T-thread workgroup; a one-wave "workgroup" only needs its LDS traffic ordered (it is executed in order)
+template <int T> __device__ __forceinline__ void k3_sync() {
+    if constexpr (T > 64) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+}
+// frag_count_kernel: one workgroup per partition at a time: its keys go through an LDS set sized to the partition, the number
+// of distinct keys is added to the gene.  Three partitions are in flight per workgroup: the row {gene, capacity, list
+// offset} + fill count of the one after next, the keys of the next one (all loads issued together), the set of the current one.
+// (Measured against one WAVE per partition with partitions a quarter of the size: the counting got 15 % faster, the
+// scatter in front of it 40 % slower -- it pays one returning atomic per partition touched by a pass.)
 __global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
-frag_count_kernel(const unsigned long long *gene_reads, const uint32_t *part_first, uint32_t n_genes, const uint64_t *gene_base,
-                  const uint32_t *cursor, const uint32_t *part_gene, const unsigned long long *list, unsigned long long *gene_frag, int *error) {
+frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const unsigned long long *list,
+                  unsigned long long *gene_frag, int *error) {
     __shared__ unsigned long long s_keys[RSQC_K4_PART_SLOTS];
-    __shared__ uint32_t s_fresh;
-    const uint32_t n_parts = part_first[n_genes];
-    for (uint32_t w = blockIdx.x; w < n_parts; w += gridDim.x) {
-        if (cursor[w] == 0) continue;                                  // (uniform)
-        const uint32_t gene = part_gene[w];
-        const uint32_t cap = frag_cap_of(gene_reads[gene]);
-        const uint32_t n = cursor[w] < cap ? cursor[w] : cap;
-        const unsigned long long *keys = list + gene_base[gene] + (unsigned long long)(w - part_first[gene]) * cap;
-        // the set is sized to the partition: the smallest power of two >= 2 n (most partitions hold a few dozen keys)
-        uint32_t slots = 64;
-        while (slots < 2 * n && slots < RSQC_K4_PART_SLOTS) slots <<= 1;
-        const uint32_t smask = slots - 1;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) s_keys[i] = 0ull;
-        if (threadIdx.x == 0) s_fresh = 0u;
-        __syncthreads();
-        uint32_t fresh = 0;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned long long k = keys[i];
-            uint32_t slot = (uint32_t)mix64(k) & smask;
-            bool placed = false;
+    __shared__ uint32_t s_fresh[2];
+    constexpr int KPT = RSQC_K4_SUB_CAP / RSQC_K4_COUNT_THREADS;            // keys per thread of a full list
+    const uint32_t n_parts = *n_parts_at;
+    struct Row { uint32_t fill; uint4 info; };
+    auto row_of = [&](uint32_t w) -> Row {
+        Row r; r.fill = w < n_parts ? cursor[w] : 0u; r.info = w < n_parts ? part_info[w] : make_uint4(0u, 0u, 0u, 0u); return r;
+    };
+    auto keys_of = [&](const Row &r, unsigned long long (&kv)[KPT]) {
+        const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
+        const unsigned long long *keys = list + ((unsigned long long)r.info.z | ((unsigned long long)r.info.w << 32));
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) { const uint32_t i = (uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x; kv[j] = i < n ? keys[i] : 0ull; }
+    };
+    uint32_t w = blockIdx.x;
+    Row cur = row_of(w), nxt = row_of(w + gridDim.x);
+    unsigned long long kv[KPT], kvn[KPT];
+    keys_of(cur, kv);
+    if (threadIdx.x < 2) s_fresh[threadIdx.x] = 0u;
+    uint32_t round = 0;
+    RSQC_FIN_BEGIN
+    while (w < n_parts) {
+        RSQC_FIN_SECT(48, 0);
+        const Row nn = row_of(w + 2u * gridDim.x);
+        keys_of(nxt, kvn);
+        if (cur.fill != 0u) {                                               // (uniform)
+            const uint32_t gene = cur.info.x, cap = cur.info.y;
+            const uint32_t n = cur.fill < cap ? cur.fill : cap;
+            // the set is sized to the partition: the smallest power of two >= 2 n (most partitions hold a few hundred keys)
+            uint32_t slots = 64;
+            while (slots < 2 * n && slots < RSQC_K4_PART_SLOTS) slots <<= 1;
+            const uint32_t smask = slots - 1;
+            __syncthreads();                                                // (the previous partition's set is done with)
+            for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) s_keys[i] = 0ull;
+            __syncthreads();
+            RSQC_FIN_SECT(48, 1);
+            uint32_t fresh = 0;
+            auto insert = [&](unsigned long long k) {
+                // (the keys are fmix64 outputs and the partition was chosen from the HIGH word: the low word is as good as a
+                //  fresh hash inside the partition; one multiply spreads neighbouring values anyway)
+                uint32_t slot = (((uint32_t)k * 0x9E3779B1u) >> 16) & smask;
+                bool placed = false;
 #pragma unroll 1
-            for (uint32_t probe = 0; probe < slots; ++probe) {
-                const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
-                if (old == 0ull) { ++fresh; placed = true; break; }
-                if (old == k) { placed = true; break; }
-                slot = (slot + 1) & smask;
+                for (uint32_t probe = 0; probe < slots; ++probe) {
+                    const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
+                    if (old == 0ull) { ++fresh; placed = true; break; }
+                    if (old == k) { placed = true; break; }
+                    slot = (slot + 1) & smask;
+                }
+                if (!placed) atomicExch(error, RSQC_ERR_CAPACITY);
+            };
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) if ((uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x < n) insert(kv[j]);
+            if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) {               // (a list is never longer than SUB_CAP: kept for safety)
+                const unsigned long long *keys = list + ((unsigned long long)cur.info.z | ((unsigned long long)cur.info.w << 32));
+                for (uint32_t i = (uint32_t)KPT * RSQC_K4_COUNT_THREADS + threadIdx.x; i < n; i += RSQC_K4_COUNT_THREADS) insert(keys[i]);
             }
-            if (!placed) atomicExch(error, RSQC_ERR_CAPACITY);
+            RSQC_FIN_SECT(48, 2);
+            fresh = wave_sum(fresh);
+            // the per-partition total alternates between two LDS cells: one barrier separates "all waves have added" from
+            // "thread 0 reads and clears"
+            if (lane_id() == 0 && fresh) atomicAdd(&s_fresh[round & 1], fresh);
+            __syncthreads();
+            if (threadIdx.x == 0) { const uint32_t t = s_fresh[round & 1]; s_fresh[round & 1] = 0u; if (t) atomicAdd(&gene_frag[gene], (unsigned long long)t); }
+            ++round;
+            RSQC_FIN_SECT(48, 3);
+#ifdef RSQC_K1_PROF
+            if (threadIdx.x == 0) { atomicAdd(&g_fin_prof[48 + 15], 1ull); atomicAdd(&g_fin_prof[48 + 14], (unsigned long long)n); }
+#endif
         }
-        fresh = wave_sum(fresh);
-        if (lane_id() == 0 && fresh) atomicAdd(&s_fresh, fresh);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_fresh) atomicAdd(&gene_frag[gene], (unsigned long long)s_fresh);
+        w += gridDim.x; cur = nxt; nxt = nn;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) kv[j] = kvn[j];
     }
 }
 
@@ -985,10 +1099,6 @@ frag_count_kernel(const unsigned long long *gene_reads, const uint32_t *part_fir
 // time is (genes / genes in flight) x (barriers x barrier cost): the workgroup is sized to the gene.
 // Most genes have a few thousand coding bases and run as ONE WAVE each (T = 64: barriers degenerate
 // to in-order LDS traffic and thousands of genes are in flight); longer ones get 256 or 1024 threads.
-template <int T> __device__ __forceinline__ void k3_sync() {
-    if constexpr (T > 64) __syncthreads();
-    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-}
 template <int T_, int WIN_, class CovT_, int LDSCAP_>
 struct K3Shared {
     static constexpr int T = T_, WIN = WIN_, W = T_ / 64, LDSCAP = LDSCAP_;
@@ -1101,64 +1211,107 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
         }
         return;
     }
-    // (1) difference array -> coverage: block-wide inclusive scan, 16 consecutive bases per thread per round
+#ifdef RSQC_K1_PROF
+    if (first == 0 && threadIdx.x == 0) for (int k = 0; k < 12; ++k) s_fin_stamp[k] = 0ull;
+#endif
+    RSQC_FIN_STAMP(0);
+    // (1) difference array -> coverage: block-wide inclusive scan.  A round covers T x 16 bases; wave w of the round takes 1024
+    //     consecutive bases as 16 rows of 64 (lane l loads base row * 64 + l: one 256-byte line run per instruction -- 16
+    //     consecutive bases per LANE cost the texture addresser 64 separate lines per instruction and made the scan of a long gene
+    //     the longest stage of the kernel), scans each row across the lanes and chains the rows; the next round's rows are in flight
+    //     while this one is scanned.
     auto scan = [&]() -> bool {                        // returns false when a value does not fit the LDS cell type
         constexpr int PER = 16;
         uint32_t carry = 0, vmax = 0;
+        uint32_t v[PER], nx[PER];
+        auto load_round = [&](uint32_t base, uint32_t (&o)[PER]) {
+            const uint32_t j0 = base + (uint32_t)wv * (64u * PER) + (uint32_t)l;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const uint32_t j = j0 + (uint32_t)k * 64u; o[k] = j < coding ? D[j] : 0u; }
+        };
+        load_round(0u, v);
         for (uint32_t base = 0; base < coding; base += T * PER) {
-            const uint32_t j = base + (uint32_t)tid * PER;
-            uint32_t v[PER];
+            if (base + T * PER < coding) load_round(base + T * PER, nx);
+            // rows scanned across the lanes, each row offset by the total of the rows before it
+            uint32_t run = 0;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) v[k] = j + k < coding ? D[j + k] : 0u;
-#pragma unroll
-            for (int k = 1; k < PER; ++k) v[k] += v[k - 1];
-            const uint32_t inc = wave_inclusive_scan_u32(v[PER - 1]);
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t inc = wave_inclusive_scan_u32(v[k]);
+                v[k] = inc + run;
+                run += lane_value(inc, 63);
+            }
             k3_sync<T>();
-            if (l == 63) S.u32b[wv] = inc;
+            if (l == 0) S.u32b[wv] = run;
             k3_sync<T>();
             uint32_t before = carry, total = 0;
 #pragma unroll
             for (int w = 0; w < (T / 64); ++w) { const uint32_t t = S.u32b[w]; if (w < wv) before += t; total += t; }
-            const uint32_t ex = before + inc - v[PER - 1];
+            const uint32_t j0 = base + (uint32_t)wv * (64u * PER) + (uint32_t)l;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) if (j + k < coding) {
-                const uint32_t x = v[k] + ex;
-                vmax = x > vmax ? x : vmax;
-                if (in_lds) S.covbuf[j + k] = (CovT)x; else D[j + k] = x;
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t j = j0 + (uint32_t)k * 64u;
+                if (j < coding) {
+                    const uint32_t x = v[k] + before;
+                    vmax = x > vmax ? x : vmax;
+                    if (in_lds) S.covbuf[j] = (CovT)x; else D[j] = x;
+                }
             }
             carry += total;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = nx[k];
         }
         if constexpr (sizeof(CovT) < 4) { if (in_lds) return block_max_u32(vmax, S) <= (uint32_t)(CovT)~(CovT)0; }
         return true;
     };
-    if (!scan()) { in_lds = false; scan(); }           // (uniform: block_max_u32 broadcasts) too deep for 16 bits: in memory
+    if (!scan()) { in_lds = false; RSQC_FIN_STAMP(1); scan(); }           // (uniform: block_max_u32 broadcasts) too deep for 16 bits: in memory
     __threadfence_block();
     k3_sync<T>();
+    RSQC_FIN_STAMP(2);
+#ifdef RSQC_K1_PROF
+    if (first == 0 && threadIdx.x == 0) { s_fin_stamp[9] = coding; s_fin_stamp[10] = n_ex; s_fin_stamp[11] = in_lds; }
+#endif
     // (2) per-exon CV over transcript positions [MASK, coding-MASK) (src/Metrics.cpp:267-305): one wave per
-    //     exon at a time (an exon's bases are contiguous in C): register sums, no shared accumulators
+    //     exon at a time (an exon's bases are contiguous in C): register sums, no shared accumulators.  The rows of the next
+    //     64 exons of a wave are gathered by its lanes in one go (exon k of the wave in lane k: two dependent gathers per 64
+    //     exons instead of per exon) and handed to the wave one by one.
     {
         const uint64_t lo_t = MASK, hi_t = coding > MASK ? coding - MASK : 0;
         if (hi_t > lo_t) {
-            for (uint32_t k = (uint32_t)wv; k < n_ex; k += (uint32_t)(T / 64)) {
-                const uint32_t row = A.ge_row[e0 + k];
-                const ExonRow er = A.ex[row];
-                const uint32_t t0 = er.cov - A.gene_cov_off[gene], len = (uint32_t)(er.end - er.start + 1);
-                const uint64_t a0 = t0 > lo_t ? t0 : lo_t, b0 = (uint64_t)t0 + len < hi_t ? (uint64_t)t0 + len : hi_t;
-                if (b0 > a0) {
-                    const double size = (double)(b0 - a0);
-                    unsigned long long sm = 0;
+            constexpr uint32_t W = (uint32_t)(T / 64);
+            const uint32_t gcov = A.gene_cov_off[gene];
+            for (uint32_t k0 = (uint32_t)wv; k0 < n_ex; k0 += 64u * W) {
+                const uint32_t mine = k0 + (uint32_t)l * W;
+                uint32_t r_t0 = 0, r_len = 0, r_id = 0;
+                if (mine < n_ex) {
+                    const uint32_t row = A.ge_row[e0 + mine];
+                    const ExonRow er = A.ex[row];
+                    r_t0 = er.cov - gcov; r_len = (uint32_t)(er.end - er.start + 1); r_id = A.ex_id[row];
+                }
+                const uint32_t left = (n_ex - k0 + W - 1) / W;
+                const uint32_t cnt = left < 64u ? left : 64u;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint32_t t0 = lane_value(r_t0, (int)i), len = lane_value(r_len, (int)i), id = lane_value(r_id, (int)i);
+                    const uint64_t a0 = t0 > lo_t ? t0 : lo_t, b0 = (uint64_t)t0 + len < hi_t ? (uint64_t)t0 + len : hi_t;
+                    if (b0 > a0) {
+                        const double size = (double)(b0 - a0);
+                        unsigned long long sm = 0;
 #pragma unroll 4
-                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) sm += Cget(j);
-                    const double mean = (double)wave_sum(sm) / size;
-                    double q = 0.0;
+                        for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) sm += Cget(j);
+                        const double mean = (double)wave_sum(sm) / size;
+                        double q = 0.0;
 #pragma unroll 4
-                    for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) { const double d = (double)Cget(j) - mean; q += d * d; }
-                    const double cv = sqrt(wave_sum(q) / size) / mean;
-                    if (l == 0 && !(isnan(cv) || isinf(cv))) { const uint32_t id = A.ex_id[row]; A.e_cv[id] = cv; A.e_cv_valid[id] = 1; }
+                        for (uint32_t j = (uint32_t)a0 + (uint32_t)l; j < b0; j += 64) { const double d = (double)Cget(j) - mean; q += d * d; }
+                        const double cv = sqrt(wave_sum(q) / size) / mean;
+                        if (l == 0 && !(isnan(cv) || isinf(cv))) { A.e_cv[id] = cv; A.e_cv_valid[id] = 1; }
+                    }
                 }
             }
         }
     }
+#ifdef RSQC_K1_PROF
+    k3_sync<T>();
+    RSQC_FIN_STAMP(3);
+#endif
     // (3) bias (src/Metrics.cpp:160-235) on the stitched, unmasked coverage vector [0, coding)
     uint32_t v0 = 0, v1 = coding;          // the (possibly trimmed) vector the gene stats use (Q14)
     if (coding >= A.bias_gene_length) {
@@ -1188,6 +1341,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             const uint32_t mid = (n - 1) / 2;
             gate = (n & 1u) ? ((double)Cget(cur + mid) + (double)Cget(cur + mid + 1)) / 2.0 : (double)Cget(cur + mid);
         }
+        RSQC_FIN_STAMP(4);
         if (n != 0 && gate >= 100.0) {
             // 5th percentile of the non-zero coverage = order statistic R of the whole vector
             const uint32_t nnz = (uint32_t)block_sum_u64(nz, S);
@@ -1225,6 +1379,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
                 prefix |= S.bc_u32[2] << shift; pmask |= 0xFFu << shift;
             }
             const uint32_t lower = prefix;
+            RSQC_FIN_STAMP(5);
             // trim leading / trailing entries <= lower (in place in the reference: Q14)
             uint32_t first_gt = 0xFFFFFFFFu, last_gt = 0;
 #pragma unroll 8
@@ -1233,6 +1388,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             last_gt = block_max_u32(last_gt, S);
             if (first_gt == 0xFFFFFFFFu) { v0 = coding; v1 = coding; } else { v0 = first_gt; v1 = last_gt; }
             const uint32_t tlen = v1 - v0;
+            RSQC_FIN_STAMP(6);
             if (tlen >= A.bias_gene_length) {
                 // left window [OFF, min(OFF+W, tlen)), right window [tlen-W-OFF, tlen-OFF)
                 const uint32_t lhi = OFF + W < tlen ? OFF + W : tlen;
@@ -1255,6 +1411,7 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             }
         }
     }
+    RSQC_FIN_STAMP(7);
     // (4) gene mean / std / CV on positions [v0, v1) with MASK bases removed at both ends
     {
         const uint32_t len = v1 - v0;
@@ -1275,6 +1432,16 @@ gene_coverage_kernel(GeneCovArgs A, uint32_t first) {
             if (tid == 0) { A.g_valid[gene] = 1; A.g_mean[gene] = mean; A.g_std[gene] = sd; A.g_cv[gene] = sd / mean; }
         } else if (tid == 0) { A.g_valid[gene] = 0; A.g_mean[gene] = 0.0; A.g_std[gene] = 0.0; A.g_cv[gene] = 0.0; }
     }
+    RSQC_FIN_STAMP(8);
+#ifdef RSQC_K1_PROF
+    if (first == 0 && threadIdx.x == 0) {
+        const unsigned long long tot = s_fin_stamp[8] - s_fin_stamp[0];
+        if (atomicMax(&g_fin_prof[31], tot) < tot) {
+            for (int k = 0; k < 9; ++k) g_fin_prof[k] = s_fin_stamp[k];
+            g_fin_prof[28] = s_fin_stamp[9]; g_fin_prof[29] = s_fin_stamp[10]; g_fin_prof[30] = s_fin_stamp[11]; g_fin_prof[27] = blockIdx.x;
+        }
+    }
+#endif
 }
 // ------------------------------------------------------------------ --fasta
 // One G/C bit per base from the FASTA text of a contig (64 bases per thread).
@@ -1454,26 +1621,24 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
     const uint32_t blocks = (n_genes + 1023u) / 1024u;
     if (!blocks) return;
     hipLaunchKernelGGL(frag_layout_totals_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, error);
-    hipLaunchKernelGGL(frag_layout_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, P.part_first, P.gene_base);
-    hipLaunchKernelGGL(frag_zero_kernel, dim3(64), dim3(256), 0, s, P.cursor, P.part_gene, P.part_first, n_genes);
+    hipLaunchKernelGGL(frag_layout_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, P.part_first,
+                       P.ginfo, P.gene_base, P.cursor, P.part_info);
 }
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
     hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
-                       acc.gene_reads, P.part_first, P.gene_base, P.cursor, P.list, acc.error);
+                       P.ginfo, P.gene_base, P.cursor, P.list, acc.error);
 }
-void launch_frag_count(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound,
-                       unsigned long long *gene_frag, int *error) {
+void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {
     const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
-    hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, gene_reads, P.part_first, n_genes, P.gene_base,
-                       P.cursor, P.part_gene, P.list, gene_frag, error);
+    hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag, error);
 }
 void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge) {
     if (A.n_listed <= 0) return;
     // gene_order is sorted by coding length, longest first: [0, n_large) x 1024 threads,
-    // [n_large, n_large + n_medium) x 256 threads, the rest one wave each; the three launches are independent
-    // (disjoint genes) and go to three streams so that they overlap
+    // [n_large, n_large + n_medium) x 256 threads, the rest one wave each; the launches are independent
+    // (disjoint genes) and go to their own streams so that they overlap
     const uint32_t n = (uint32_t)A.n_listed, n_small = n - n_large - n_medium;
     const bool wide = A.bias_window > 128;
 #define RSQC_K3_LAUNCH(T, COVT, CAP, COUNT, FIRST, STREAM)                                                                   \
@@ -1482,10 +1647,11 @@ void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const G
         else hipLaunchKernelGGL((gene_coverage_kernel<T, 128, COVT, CAP>), dim3(COUNT), dim3(T), 0, STREAM, A, FIRST);  \
     }
     // the 1024-thread class in two LDS sizes: a workgroup that holds 146 KB keeps its CU to itself, one that holds 64 KB leaves
-    // room for the fragment de-dup workgroups running beside it (the longest genes go first on the same stream)
+    // room for the fragment workgroups running beside it.  (The runtime maps streams onto four hardware queues: with K4 on the
+    // context's stream there are three for K3; the 64 KB class goes in front of the one-wave class.)
     RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE_LDS16, n_xlarge, 0u, s)
-    RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE2_LDS16, n_large - n_xlarge, n_xlarge, s)
     RSQC_K3_LAUNCH(256, uint32_t, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
+    RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE2_LDS16, n_large - n_xlarge, n_xlarge, s3)
     RSQC_K3_LAUNCH(64, uint32_t, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
 #undef RSQC_K3_LAUNCH
 }
