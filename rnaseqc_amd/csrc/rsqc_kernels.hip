@@ -905,18 +905,25 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
                   const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, unsigned long long *list, int *error) {
     __shared__ K4LocalShared S;
-    uint32_t base, count, piece0 = 0, piece_step = 1;
+    uint32_t base, count, piece0 = 0; constexpr uint32_t piece_step = 1;
     if (blockIdx.x < n_chunks) {
         base = blockIdx.x * chunk_cap;
         count = chunk_count[blockIdx.x] < chunk_cap ? chunk_count[blockIdx.x] : chunk_cap;
     } else {
         base = slow_base;
         count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
-        piece0 = blockIdx.x - n_chunks; piece_step = gridDim.x - n_chunks;
     }
     constexpr int U = RSQC_K4L_PIECE / RSQC_K4L_THREADS;
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    const uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;
+    uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;
+    if (blockIdx.x >= n_chunks) {
+        // a dense region shared by several workgroups (a batch's slow-path region, the arena of retired batches): each takes a
+        // CONTIGUOUS run of passes, so that its window sees neighbouring records
+        const uint32_t sharers = gridDim.x - n_chunks, me = blockIdx.x - n_chunks;
+        const uint32_t per = (n_pieces + sharers - 1) / sharers;
+        piece0 = me * per < n_pieces ? me * per : n_pieces;
+        n_pieces = piece0 + per < n_pieces ? piece0 + per : n_pieces;
+    }
     auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {

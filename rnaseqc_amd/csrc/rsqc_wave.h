@@ -118,6 +118,9 @@ __device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
     return at_end - (sc - v);
 }
 
+#ifndef RSQC_COV_MERGE_MIN
+#define RSQC_COV_MERGE_MIN 1
+#endif
 // cov[idx] += sign * (number of lanes of the run) with identical neighbouring slots merged into one atomic.
 // Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
 // then is the run structure built.
@@ -126,7 +129,7 @@ __device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32
     const uint64_t vmask = __ballot(valid);
     const int l = lane_id();
     const bool dup = valid && l > 0 && ((vmask >> (l - 1)) & 1ull) && pidx == idx;
-    if (__ballot(dup) == 0ull) {
+    if (__popcll(__ballot(dup)) < RSQC_COV_MERGE_MIN) {
         if (valid) atomicAdd(&cov[idx], sign);
     } else {
         const Run r = make_run(valid, idx);
