@@ -17,9 +17,12 @@ generates and owns only its contigs, and at end of file the ranks sum-reduce the
 rsqc_device_vectors over RCCL (counts + exon sums are additive, per-gene statistics are owner-only).
 
 Three tiers, never mixed:
-  value / roofline   device-resident kernel tier (what the contract's `value` is)
-  end_to_end         the CLI's `Average Reads/Sec` window (src/RNASeQC.cpp:240-241,389-394) on a BAM of the same
-                     records: BGZF inflate + BAM parse on the host cores + H2D + the same kernels
+  value / roofline   device-resident kernel tier (what the contract's `value` is); roofline.kernel_ms comes from hipEvents
+                     around the per-read kernel on the context's stream (rsqc_get_timing)
+  whole_node /       the CLI's `Average Reads/Sec` window (src/RNASeQC.cpp:240-241,389-394) on a BAM of the same records:
+  end_to_end         BGZF inflate + BAM parse on the GPU + the same kernels + the end-of-file stage, report files written;
+                     at every N (rank 0 writes the BAM, `rnaseqc --gpus N` reads it by contig).  Its report files are
+                     compared with the kernel tier's results (whole_node.parity) -- the two tiers measure the same job
   cpu_baseline       the C oracle on one host core, bounded sample
 
 Prints ONE JSON line on rank 0.

@@ -23,6 +23,15 @@
 #include "rsqc_index.h"
 #include "rsqc_decode.h"
 
+// Knobs that make the library SKIP work (wrong or incomplete results) exist only in the diagnostic build (`make prof`,
+// -DRSQC_K1_PROF): the product library does not read them.
+#ifdef RSQC_K1_PROF
+#define RSQC_DIAG(name) getenv(name)
+#else
+#define RSQC_DIAG(name) ((const char *)nullptr)
+#endif
+
+
 using namespace rsqc;
 
 namespace {
@@ -959,7 +968,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             P.part_info = (uint4 *)c->d_tab_cap.p; P.cursor = (uint32_t *)(P.part_info + parts_bound);
             P.list = (unsigned long long *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
-            if (c->pair_arena.used && !getenv("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces
+            if (c->pair_arena.used && !RSQC_DIAG("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces
                 if ((rc = dev_alloc(c, c->d_arena_count, 16, false))) return rc;
                 const uint32_t used32 = (uint32_t)c->pair_arena.used;
                 HIP_TRY(c, hipMemcpyAsync(c->d_arena_count.p, &used32, 4, hipMemcpyHostToDevice, c->stream));
@@ -970,7 +979,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 launch_frag_local(c->stream, acc, 0, P, (uint32_t)std::min<uint64_t>(4096, c->pair_arena.used / 1024 + 1));
             }
             for (size_t idx : c->pairs_in_flight) {
-                if (getenv("RSQC_DIAG_SKIP_K4")) break;                   // (diagnostic knob: results incomplete)
+                if (RSQC_DIAG("RSQC_DIAG_SKIP_K4")) break;                // (diagnostic build only: results incomplete)
                 PairBuf &pb = c->pair_pool[idx];
                 DevAccum acc = c->acc;
                 acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p;
@@ -979,7 +988,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
                 launch_frag_local(c->stream, acc, pb.n_chunks, P, 0);
             }
-            if (!getenv("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
+            if (!RSQC_DIAG("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
         }
         // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -1000,11 +1009,11 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         Ga.error = c->acc.error;
         {
             uint32_t nl = c->k3_large, nm = c->k3_medium, nx = c->k3_xlarge;
-            if (const char *e = getenv("RSQC_K3_FORCE")) {           // diagnostic: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
+            if (const char *e = RSQC_DIAG("RSQC_K3_FORCE")) {        // diagnostic build only: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
                 const int f = atoi(e);
                 if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; nx = 0; } else if (f == 3) { nl = 0; nm = 0; nx = 0; } else if (f == 4) { nl = (uint32_t)L; nm = 0; nx = (uint32_t)L; }
             }
-            if (!getenv("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm, nx);   // (diagnostic knob: results incomplete)
+            if (!RSQC_DIAG("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm, nx);   // (diagnostic build only: results incomplete)
         }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));

@@ -3,6 +3,7 @@ refuses to run without a GPU (there is no CPU path)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -56,3 +57,16 @@ def test_no_cpu_fallback():
     with pytest.raises(engine.EngineError) as e:
         engine.Engine(abi.default_params())
     assert e.value.code == abi.ERR_NO_DEVICE
+
+
+def test_product_library_has_no_skip_knobs_or_debug_exports():
+    """The shipped library cannot be told to skip work and exports nothing outside include/rnaseqc_amd.h: the ablation masks,
+    RSQC_DIAG_* / RSQC_K3_FORCE environment knobs and rsqc_debug_* functions exist only in the diagnostic build (`make prof`)."""
+    path = os.path.join(ROOT, "rnaseqc_amd", "lib", "librnaseqc_amd.so")
+    blob = open(path, "rb").read()
+    for needle in (b"RSQC_DEBUG_MASK", b"RSQC_DIAG_", b"RSQC_K3_FORCE", b"rsqc_debug_"):
+        assert needle not in blob, needle
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    names = {line.split()[-1] for line in exported.splitlines() if " T " in line}
+    declared = set(re.findall(r"\b(rsqc_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "rnaseqc_amd.h")).read()))
+    assert {n for n in names if n.startswith("rsqc_")} <= declared, sorted(n for n in names if n.startswith("rsqc_") and n not in declared)
