@@ -142,10 +142,14 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 // K4, streaming form (rsqc_kernels.hip): partition tables laid out on the device from the final geneCounts
 // fragment partitions (rsqc_kernels.hip, K4): a gene with n counted records owns ceil(n / PART_READS) partitions of capacity
 // SUB_CAP keys each (or one partition of capacity n); a partition's keys are counted by one workgroup in an LDS set of PART_SLOTS
+#ifndef RSQC_K4_PART_READS
 #define RSQC_K4_PART_READS 1024
-#define RSQC_K4_SUB_CAP 2048
-#define RSQC_K4_PART_SLOTS 4096
+#endif
+#define RSQC_K4_SUB_CAP (2 * RSQC_K4_PART_READS)
+#define RSQC_K4_PART_SLOTS (4 * RSQC_K4_PART_READS)
+#ifndef RSQC_K4_COUNT_THREADS
 #define RSQC_K4_COUNT_THREADS 256
+#endif
 struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
     uint64_t *gene_base;           // [G] offset of the gene's key lists

@@ -889,9 +889,15 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
 // there.  (A per-pass table with probing removed 12 % of the keys for 18 % of the kernel; the window removes the mates.)
 // The word is key ^ f(gene): two different (gene, key) pairs share a word with probability 2^-64 per comparison, the same
 // order as two names sharing a 64-bit hash, which is the identity this stage works with (include/rnaseqc_amd.h).
-#define RSQC_K4L_THREADS 256
-#define RSQC_K4L_PIECE 1024
-#define RSQC_K4L_GSLOTS 1024
+#ifndef RSQC_K4L_THREADS
+#define RSQC_K4L_THREADS 512
+#endif
+#ifndef RSQC_K4L_U
+#define RSQC_K4L_U 4
+#endif
+#define RSQC_K4L_PIECE (RSQC_K4L_U * RSQC_K4L_THREADS)
+#define RSQC_K4L_GSLOTS RSQC_K4L_PIECE
+constexpr int k4l_log2(unsigned v) { return v <= 1 ? 0 : 1 + k4l_log2(v >> 1); }
 #ifndef RSQC_K4L_WIN
 #define RSQC_K4L_WIN 2048
 #endif
@@ -968,8 +974,8 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
                 if (atomicExch(&S.win[ws], lk) == lk) { g[u] = NONE; continue; }      // its mate went through this chunk already
             }
             gp[u] = gi[u].x + (gi[u].y > 1 ? (uint32_t)(((unsigned long long)frag_part_hash(key[u]) * gi[u].y) >> 32) : 0u);
-            uint32_t sl = (gp[u] * 0x9E3779B1u) >> (32 - 10);
-            static_assert(RSQC_K4L_GSLOTS == 1 << 10, "slot hash");
+            static_assert((RSQC_K4L_GSLOTS & (RSQC_K4L_GSLOTS - 1)) == 0, "slot hash");
+            uint32_t sl = (gp[u] * 0x9E3779B1u) >> (32 - k4l_log2(RSQC_K4L_GSLOTS));
 #pragma unroll 1
             for (int probe = 0; probe < 16; ++probe) {
                 const uint32_t o = atomicCAS(&S.gkey[sl], NONE, gp[u]);
