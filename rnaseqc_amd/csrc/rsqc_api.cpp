@@ -957,7 +957,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             if (parts_bound > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment partitions");
             const uint64_t lay_blocks = (Gz + 1023) / 1024;
             if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 28 + 64 + lay_blocks * 12 + 64, false))) return rc;  // per-gene rows | gene_base | part_first | layout totals
-            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 20 + 64, false))) return rc;                   // per-partition rows | cursor
+            if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 24 + 128, false))) return rc;                  // per-partition rows | cursor | list of the fuller ones + its counter
             if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
             FragPlan P;
             P.ginfo = (uint4 *)c->d_tab_off.p;
@@ -966,6 +966,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             P.blk_space = (unsigned long long *)(((uintptr_t)(P.part_first + Gz + 2) + 15) & ~(uintptr_t)15);
             P.blk_parts = (uint32_t *)(P.blk_space + lay_blocks);
             P.part_info = (uint4 *)c->d_tab_cap.p; P.cursor = (uint32_t *)(P.part_info + parts_bound);
+            P.full_list = P.cursor + parts_bound; P.full_n = P.full_list + parts_bound;
             P.list = (unsigned long long *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
             if (c->pair_arena.used && !RSQC_DIAG("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces

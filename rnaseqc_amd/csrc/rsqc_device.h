@@ -12,7 +12,9 @@
 #define RSQC_MAX_BIAS_WINDOW 1024
 #define RSQC_K3_THREADS 1024
 // coding-length classes of the end-of-file coverage stage: one wave / 256 threads with the vector in LDS, 1024 threads in memory
+#ifndef RSQC_K3_SMALL_MAX
 #define RSQC_K3_SMALL_MAX 4096
+#endif
 #define RSQC_K3_MEDIUM_MAX 12288
 #define RSQC_K3_LARGE_LDS16 73000      /* bases a 1024-thread workgroup keeps in LDS as 16-bit depths (146 KB of the CU's 160 KB) */
 #define RSQC_K3_LARGE2_LDS16 32768     /* ... the shorter genes of that class: 64 KB */
@@ -156,6 +158,7 @@ struct FragPlan {
     uint32_t *cursor;              // [parts] keys appended so far
     uint4 *ginfo;                  // [G] {first partition, partitions, capacity of one, 0}: what frag_local_kernel gathers per pair
     uint4 *part_info;              // [parts] {owning gene, capacity, list offset lo, hi}
+    uint32_t *full_list, *full_n;  // [parts] + counter: the partitions frag_count_kernel's first instance leaves to the second
     unsigned long long *list;      // key lists
     unsigned long long *blk_space; uint32_t *blk_parts;   // [ceil(G / 1024)] per-workgroup totals of the layout scan
 };

@@ -835,7 +835,7 @@ frag_layout_totals_kernel(const unsigned long long *gene_reads, uint32_t n_genes
 }
 __global__ void __launch_bounds__(1024)
 frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const unsigned long long *blk_space, const uint32_t *blk_parts,
-                   uint32_t *part_first, uint4 *ginfo, uint64_t *gene_base, uint32_t *cursor, uint4 *part_info) {
+                   uint32_t *part_first, uint4 *ginfo, uint64_t *gene_base, uint32_t *cursor, uint4 *part_info, uint32_t *full_n) {
     __shared__ unsigned long long w_space[16];
     __shared__ uint32_t w_parts[16];
     __shared__ unsigned long long s_base; __shared__ uint32_t p_base;
@@ -862,6 +862,7 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
     const uint32_t pf = bp + ipt - parts; const unsigned long long gb = bs + isp - space;
     if (g < n_genes) { part_first[g] = pf; gene_base[g] = gb; ginfo[g] = make_uint4(pf, parts, cap, 0u); }
     if (g == n_genes - 1) part_first[n_genes] = bp + ipt;
+    if (g == 0) *full_n = 0u;
     // per partition: fill cursor = 0 and what the counting kernel needs in one load {gene, capacity, list offset}.  Most genes
     // own one partition; the wave walks the partitions of its larger genes together
     if (parts >= 1) { cursor[pf] = 0u; part_info[pf] = make_uint4(g, cap, (uint32_t)gb, (uint32_t)(gb >> 32)); }
@@ -1025,16 +1026,31 @@ template <int T> __device__ __forceinline__ void k3_sync() {
 // offset} + fill count of the one after next, the keys of the next one (all loads issued together), the set of the current one.
 // (Measured against one WAVE per partition with partitions a quarter of the size: the counting got 15 % faster, the
 // scatter in front of it 40 % slower -- it pays one returning atomic per partition touched by a pass.)
+// Two instances: SLOTS = PART_SLOTS / 2 (16 KB of LDS, eight workgroups per CU) takes the partitions whose keys fit it at half
+// load -- with the window de-dup in front nearly all of them --, SLOTS = PART_SLOTS (32 KB) the fuller ones; each skips the
+// other's partitions: the first instance walks all partitions and LISTS the fuller ones (`full_list`, counter zeroed by
+// frag_layout_kernel), the second walks that list.
+template <int SLOTS>
 __global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
 frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const unsigned long long *list,
-                  unsigned long long *gene_frag, int *error) {
-    __shared__ unsigned long long s_keys[RSQC_K4_PART_SLOTS];
+                  unsigned long long *gene_frag, uint32_t *full_list, uint32_t *full_n, int *error) {
+    constexpr bool LISTED = SLOTS == RSQC_K4_PART_SLOTS;
+    __shared__ unsigned long long s_keys[SLOTS];
     __shared__ uint32_t s_fresh[2];
-    constexpr int KPT = RSQC_K4_SUB_CAP / RSQC_K4_COUNT_THREADS;            // keys per thread of a full list
-    const uint32_t n_parts = *n_parts_at;
-    struct Row { uint32_t fill; uint4 info; };
-    auto row_of = [&](uint32_t w) -> Row {
-        Row r; r.fill = w < n_parts ? cursor[w] : 0u; r.info = w < n_parts ? part_info[w] : make_uint4(0u, 0u, 0u, 0u); return r;
+    constexpr int KPT = (SLOTS / 2) / RSQC_K4_COUNT_THREADS;                // keys per thread of the fullest list of this instance
+    constexpr uint32_t N_LO = SLOTS == RSQC_K4_PART_SLOTS ? (uint32_t)SLOTS / 4u : 0u;   // this instance: N_LO < keys <= SLOTS / 2
+    const uint32_t n_parts = LISTED ? *full_n : *n_parts_at;               // (iterations: partitions, or entries of the list)
+    struct Row { uint32_t fill; uint4 info; bool fuller; };
+    auto row_of = [&](uint32_t i) -> Row {
+        Row r; r.fill = 0u; r.info = make_uint4(0u, 0u, 0u, 0u); r.fuller = false;
+        if (i < n_parts) {
+            const uint32_t w = LISTED ? full_list[i] : i;
+            r.fill = cursor[w]; r.info = part_info[w];
+            const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
+            r.fuller = n > (uint32_t)SLOTS / 2u;
+            if (n <= N_LO || r.fuller) r.fill = 0u;                        // (the other instance's, or empty)
+        }
+        return r;
     };
     auto keys_of = [&](const Row &r, unsigned long long (&kv)[KPT]) {
         const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
@@ -1053,12 +1069,13 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
         RSQC_FIN_SECT(48, 0);
         const Row nn = row_of(w + 2u * gridDim.x);
         keys_of(nxt, kvn);
+        if (!LISTED && cur.fuller && threadIdx.x == 0) full_list[atomicAdd(full_n, 1u)] = w;
         if (cur.fill != 0u) {                                               // (uniform)
             const uint32_t gene = cur.info.x, cap = cur.info.y;
             const uint32_t n = cur.fill < cap ? cur.fill : cap;
             // the set is sized to the partition: the smallest power of two >= 2 n (most partitions hold a few hundred keys)
             uint32_t slots = 64;
-            while (slots < 2 * n && slots < RSQC_K4_PART_SLOTS) slots <<= 1;
+            while (slots < 2 * n && slots < (uint32_t)SLOTS) slots <<= 1;
             const uint32_t smask = slots - 1;
             __syncthreads();                                                // (the previous partition's set is done with)
             for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) s_keys[i] = 0ull;
@@ -1635,7 +1652,7 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
     if (!blocks) return;
     hipLaunchKernelGGL(frag_layout_totals_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, error);
     hipLaunchKernelGGL(frag_layout_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, P.part_first,
-                       P.ginfo, P.gene_base, P.cursor, P.part_info);
+                       P.ginfo, P.gene_base, P.cursor, P.part_info, P.full_n);
 }
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
@@ -1645,8 +1662,17 @@ void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, co
 }
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {
     const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
-    hipLaunchKernelGGL(frag_count_kernel, dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag, error);
+    hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS / 2>), dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag,
+                       P.full_list, P.full_n, error);
+    hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS>), dim3(grid < 1024u ? grid : 1024u), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag,
+                       P.full_list, P.full_n, error);
 }
+#ifndef RSQC_K3_MEDIUM_T
+#define RSQC_K3_MEDIUM_T uint32_t
+#endif
+#ifndef RSQC_K3_SMALL_T
+#define RSQC_K3_SMALL_T uint32_t
+#endif
 void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge) {
     if (A.n_listed <= 0) return;
     // gene_order is sorted by coding length, longest first: [0, n_large) x 1024 threads,
@@ -1663,9 +1689,9 @@ void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const G
     // room for the fragment workgroups running beside it.  (The runtime maps streams onto four hardware queues: with K4 on the
     // context's stream there are three for K3; the 64 KB class goes in front of the one-wave class.)
     RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE_LDS16, n_xlarge, 0u, s)
-    RSQC_K3_LAUNCH(256, uint32_t, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
+    RSQC_K3_LAUNCH(256, RSQC_K3_MEDIUM_T, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
     RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE2_LDS16, n_large - n_xlarge, n_xlarge, s3)
-    RSQC_K3_LAUNCH(64, uint32_t, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
+    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_T, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
 #undef RSQC_K3_LAUNCH
 }
 
