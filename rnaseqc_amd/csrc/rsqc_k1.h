@@ -65,7 +65,10 @@ __device__ __forceinline__ void k1e_load_cigar8(const uint32_t *cigar, uint32_t 
 }
 
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
-constexpr uint64_t K1E_PIECE = 256;             // records a wave takes from its workgroup's range at a time (4 tiles)
+#ifndef K1E_PIECE_RECORDS
+#define K1E_PIECE_RECORDS 256
+#endif
+constexpr uint64_t K1E_PIECE = K1E_PIECE_RECORDS;   // records a wave takes from its workgroup's range at a time (4 tiles)
 constexpr int K1E_QCAP = 128;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
 constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
 constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's flag word | K1E_HQ when high quality
