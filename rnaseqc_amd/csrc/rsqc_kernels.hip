@@ -742,18 +742,9 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint3
     }
 }
 
-// ------------------------------------------------------------------ K4
-// geneFragmentCounts: number of distinct QNAMEs among the records counted to a gene
-// (src/Expression.cpp:383-387).  Every gene owns a slice of an open-addressing table sized
-// 2 x geneCounts[gene], so the probes of one gene stay inside a small, cache-resident range.
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-    return x;
-}
-
+// ------------------------------------------------------------------ K4 (rsqc_k4.h) and the retirement of a batch's pairs
 // The pairs of a batch live in per-K1-block chunks (+ one slow-path region), each chunk in file order; the pairs of
 // batches that have been retired (rsqc_api.cpp) sit in one dense arena in file order.
-#define RSQC_K4_GSLOTS 256
 #define RSQC_K4_SLOW_BLOCKS 32
 
 // Retirement of a batch: its chunks, one after the other, appended to the arena.  Workgroup k < n_chunks copies chunk k
@@ -782,346 +773,16 @@ void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t
                        n_chunks, slow_base, slow_cap, dst_gene, dst_hash);
 }
 
-// ------------------------------------------------------------------ K4: no memory-side atomics
-// An open-addressing table per gene (round 1's first form) is bound by the chip's rate of random memory-side CAS
-// operations (one per distinct fragment).  Two streaming passes over PARTITIONS instead: a gene with n counted
-// records owns ceil(n / RSQC_K4_PART_READS) partitions (by high bits of the name hash), each with a key list of
-// fixed capacity laid out by frag_layout_kernel from the final geneCounts:
-//   frag_local_kernel   per pair chunk: LDS de-dup as before; the survivors' name hashes are APPENDED to their
-//                       partition's list (space for one piece's survivors of a partition is reserved with ONE
-//                       global atomicAdd; positions inside the reservation come from an LDS counter)
-//   frag_count_kernel   one workgroup per partition: its keys go through an LDS hash set; the number of distinct
-//                       keys is added to geneFragmentCounts
-// A partition expects <= RSQC_K4_PART_READS / 2 .. RSQC_K4_PART_READS keys and has room for RSQC_K4_SUB_CAP; one
-// that overflows (never with random hashes) reports RSQC_ERR_CAPACITY instead of miscounting.
+}  // namespace rsqc
+#include "rsqc_k4.h"
+namespace rsqc {
 
-// the partition of a key inside its gene comes from the key's HIGH word (the keys are rsqc_qname_hash values: FNV-1a + fmix64;
-// one multiply-xorshift on top keeps a caller's weaker hash from piling up), the slot inside the partition's set from the low word
-__device__ __forceinline__ uint32_t frag_part_hash(uint64_t key) {
-    uint32_t h = (uint32_t)(key >> 32);
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    return h;
-}
-__device__ __forceinline__ uint32_t frag_parts_of(unsigned long long reads) {
-    return (uint32_t)((reads + RSQC_K4_PART_READS - 1) / RSQC_K4_PART_READS);
-}
-// per gene: part_first[g] = its first partition (part_first[n_genes] = partition count) and gene_base[g] = offset of
-// its key lists; partition k of the gene has capacity frag_cap_of(reads) and starts at gene_base + k * capacity
-__device__ __forceinline__ uint32_t frag_cap_of(unsigned long long reads) {
-    return frag_parts_of(reads) == 1 ? (uint32_t)reads : (uint32_t)RSQC_K4_SUB_CAP;
-}
-// Two launches of 1024-thread workgroups, 1024 genes each (coalesced loads): (1) per-workgroup totals, (2) every workgroup
-// adds the totals before it (a few dozen values) to its own scan.  (One workgroup walking all the genes serially took
-// 0.24 ms at 56 202 genes: 55 dependent loads per thread, twice.)
-__global__ void __launch_bounds__(1024)
-frag_layout_totals_kernel(const unsigned long long *gene_reads, uint32_t n_genes, unsigned long long *blk_space, uint32_t *blk_parts, int *error) {
-    __shared__ unsigned long long w_space[16];
-    __shared__ uint32_t w_parts[16];
-    const uint32_t g = blockIdx.x * 1024u + threadIdx.x;
-    unsigned long long space = 0; uint32_t parts = 0;
-    if (g < n_genes) {
-        const unsigned long long n = gene_reads[g];
-        if (n > 0xFFFFFFF0ull) atomicExch(error, RSQC_ERR_CAPACITY);
-        parts = frag_parts_of(n); space = (unsigned long long)parts * frag_cap_of(n);
-    }
-    space = wave_sum(space); parts = wave_sum(parts);
-    if (lane_id() == 0) { w_space[threadIdx.x >> 6] = space; w_parts[threadIdx.x >> 6] = parts; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long s = 0; uint32_t p = 0;
-        for (int w = 0; w < 16; ++w) { s += w_space[w]; p += w_parts[w]; }
-        blk_space[blockIdx.x] = s; blk_parts[blockIdx.x] = p;
-    }
-}
-__global__ void __launch_bounds__(1024)
-frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const unsigned long long *blk_space, const uint32_t *blk_parts,
-                   uint32_t *part_first, uint4 *ginfo, uint64_t *gene_base, uint32_t *cursor, uint4 *part_info, uint32_t *full_n) {
-    __shared__ unsigned long long w_space[16];
-    __shared__ uint32_t w_parts[16];
-    __shared__ unsigned long long s_base; __shared__ uint32_t p_base;
-    const int l = lane_id(), wv = (int)(threadIdx.x >> 6);
-    if (wv == 0) {                                                     // offsets of this workgroup: totals of the ones before it
-        unsigned long long s = 0; uint32_t p = 0;
-        for (uint32_t k = (uint32_t)l; k < blockIdx.x; k += 64) { s += blk_space[k]; p += blk_parts[k]; }
-        s = wave_sum(s); p = wave_sum(p);
-        if (l == 0) { s_base = s; p_base = p; }
-    }
-    const uint32_t g = blockIdx.x * 1024u + threadIdx.x;
-    unsigned long long space = 0; uint32_t parts = 0, cap = 0;
-    if (g < n_genes) { const unsigned long long n = gene_reads[g]; parts = frag_parts_of(n); cap = frag_cap_of(n); space = (unsigned long long)parts * cap; }
-    unsigned long long isp = space; uint32_t ipt = parts;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long ts = __shfl_up(isp, o, 64); const uint32_t tp = __shfl_up(ipt, o, 64);
-        if (l >= o) { isp += ts; ipt += tp; }
-    }
-    if (l == 63) { w_space[wv] = isp; w_parts[wv] = ipt; }
-    __syncthreads();
-    unsigned long long bs = s_base; uint32_t bp = p_base;
-    for (int w = 0; w < wv; ++w) { bs += w_space[w]; bp += w_parts[w]; }
-    const uint32_t pf = bp + ipt - parts; const unsigned long long gb = bs + isp - space;
-    if (g < n_genes) { part_first[g] = pf; gene_base[g] = gb; ginfo[g] = make_uint4(pf, parts, cap, 0u); }
-    if (g == n_genes - 1) part_first[n_genes] = bp + ipt;
-    if (g == 0) *full_n = 0u;
-    // per partition: fill cursor = 0 and what the counting kernel needs in one load {gene, capacity, list offset}.  Most genes
-    // own one partition; the wave walks the partitions of its larger genes together
-    if (parts >= 1) { cursor[pf] = 0u; part_info[pf] = make_uint4(g, cap, (uint32_t)gb, (uint32_t)(gb >> 32)); }
-    unsigned long long big = __ballot(parts > 1);
-    while (big) {
-        const int src = __ffsll(big) - 1; big &= big - 1;
-        const uint32_t pf_s = lane_value(pf, src), n_s = lane_value(parts, src), cap_s = lane_value(cap, src), g_s = lane_value(g, src);
-        const unsigned long long gb_s = (unsigned long long)lane_value((uint32_t)gb, src) | ((unsigned long long)lane_value((uint32_t)(gb >> 32), src) << 32);
-        for (uint32_t k = 1u + (uint32_t)l; k < n_s; k += 64) {
-            const unsigned long long off = gb_s + (unsigned long long)k * cap_s;
-            cursor[pf_s + k] = 0u; part_info[pf_s + k] = make_uint4(g_s, cap_s, (uint32_t)off, (uint32_t)(off >> 32));
-        }
-    }
-}
-
-// frag_local_kernel: every (gene, name hash) pair of a chunk goes to the key list of its partition (partition = gene's first +
-// hash-scaled index).  256 threads take 1024 pairs per pass (4 per thread): the pairs of a pass that share a partition reserve
-// their list slots with ONE memory atomic (ranks inside the pass come from a small LDS table keyed by partition id).
-// The kernel is a chain of dependent gathers, so it is laid out as a pipeline: the pairs of pass k + 1 and the per-gene rows of
-// pass k are in flight while pass k - 1's ranks are taken.
-// What bounds it is the memory side: one returning atomic and one scattered 8-byte store per pair of a gene with many
-// partitions.  The two mates of a fragment sit a few hundred records apart, i.e. in the same chunk, so half of the pairs are
-// repeats the counting kernel would throw away: a direct-mapped LDS window over the WHOLE chunk (one 64-bit exchange per pair,
-// never cleared between passes, no probing: a newer pair simply replaces an older one) drops a pair whose word is already
-// there.  (A per-pass table with probing removed 12 % of the keys for 18 % of the kernel; the window removes the mates.)
-// The word is key ^ f(gene): two different (gene, key) pairs share a word with probability 2^-64 per comparison, the same
-// order as two names sharing a 64-bit hash, which is the identity this stage works with (include/rnaseqc_amd.h).
-#ifndef RSQC_K4L_THREADS
-#define RSQC_K4L_THREADS 512
-#endif
-#ifndef RSQC_K4L_U
-#define RSQC_K4L_U 4
-#endif
-#define RSQC_K4L_PIECE (RSQC_K4L_U * RSQC_K4L_THREADS)
-#define RSQC_K4L_GSLOTS RSQC_K4L_PIECE
-constexpr int k4l_log2(unsigned v) { return v <= 1 ? 0 : 1 + k4l_log2(v >> 1); }
-#ifndef RSQC_K4L_WIN
-#define RSQC_K4L_WIN 2048
-#endif
-struct K4LocalShared {
-    uint32_t gkey[RSQC_K4L_GSLOTS], gcnt[RSQC_K4L_GSLOTS];      // keyed by partition id: pairs of the pass, then their first list slot
-    unsigned long long win[RSQC_K4L_WIN];       // direct-mapped window of the chunk's recent (gene, key) words: see the kernel
-};
-
-__global__ void __launch_bounds__(RSQC_K4L_THREADS)
-frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
-                  const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, unsigned long long *list, int *error) {
-    __shared__ K4LocalShared S;
-    uint32_t base, count, piece0 = 0; constexpr uint32_t piece_step = 1;
-    if (blockIdx.x < n_chunks) {
-        base = blockIdx.x * chunk_cap;
-        count = chunk_count[blockIdx.x] < chunk_cap ? chunk_count[blockIdx.x] : chunk_cap;
-    } else {
-        base = slow_base;
-        count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
-    }
-    constexpr int U = RSQC_K4L_PIECE / RSQC_K4L_THREADS;
-    constexpr uint32_t NONE = 0xFFFFFFFFu;
-    uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;
-    if (blockIdx.x >= n_chunks) {
-        // a dense region shared by several workgroups (a batch's slow-path region, the arena of retired batches): each takes a
-        // CONTIGUOUS run of passes, so that its window sees neighbouring records
-        const uint32_t sharers = gridDim.x - n_chunks, me = blockIdx.x - n_chunks;
-        const uint32_t per = (n_pieces + sharers - 1) / sharers;
-        piece0 = me * per < n_pieces ? me * per : n_pieces;
-        n_pieces = piece0 + per < n_pieces ? piece0 + per : n_pieces;
-    }
-    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
-            const bool ok = piece < n_pieces && j < count;
-            g[u] = ok ? pair_gene[base + j] : NONE;
-            key[u] = ok ? pair_hash[base + j] : 0ull;
-        }
-    };
-#ifdef RSQC_K1_PROF
-    if (blockIdx.x == 1000 && n_chunks > 1000) {                           // (diagnostic: one chunk, as K1 wrote it)
-        for (uint32_t i = threadIdx.x; i < count && i < 32768u; i += blockDim.x) { g_dbg_pair_hash[i] = pair_hash[base + i]; g_dbg_pair_gene[i] = pair_gene[base + i]; }
-        if (threadIdx.x == 0) g_dbg_pair_count = count;
-    }
-#endif
-    uint32_t g[U]; uint64_t key[U];
-    load_piece(piece0, g, key);
-    for (int i = threadIdx.x; i < RSQC_K4L_WIN; i += blockDim.x) S.win[i] = 0ull;
-    RSQC_FIN_BEGIN
-    for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
-        RSQC_FIN_SECT(32, 0);
-        uint4 gi[U]; uint64_t gb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; gb[u] = gene_base[gq]; }
-        uint32_t gn[U]; uint64_t keyn[U];
-        load_piece(piece + piece_step, gn, keyn);
-        __syncthreads();                                                   // (the previous pass has read its list slots)
-        for (int i = threadIdx.x; i < RSQC_K4L_GSLOTS; i += blockDim.x) { S.gkey[i] = NONE; S.gcnt[i] = 0u; }
-        __syncthreads();
-        RSQC_FIN_SECT(32, 1);
-        uint32_t gp[U], gslot[U], rank[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                      // rank of the pair among the pass's pairs of its partition
-            gslot[u] = NONE; rank[u] = 0; gp[u] = 0;
-            if (key[u] == 0) key[u] = 0x9e3779b97f4a7c15ull;
-            if (g[u] == NONE) continue;
-            {
-                unsigned long long lk = key[u] ^ (((unsigned long long)g[u] << 32) | (unsigned long long)(g[u] * 0x9E3779B1u));
-                if (lk == 0ull) lk = 1ull;
-                static_assert((RSQC_K4L_WIN & (RSQC_K4L_WIN - 1)) == 0, "window size");
-                const uint32_t ws = ((((uint32_t)lk ^ (uint32_t)(lk >> 32)) * 0x9E3779B1u) >> 12) & (RSQC_K4L_WIN - 1);
-                if (atomicExch(&S.win[ws], lk) == lk) { g[u] = NONE; continue; }      // its mate went through this chunk already
-            }
-            gp[u] = gi[u].x + (gi[u].y > 1 ? (uint32_t)(((unsigned long long)frag_part_hash(key[u]) * gi[u].y) >> 32) : 0u);
-            static_assert((RSQC_K4L_GSLOTS & (RSQC_K4L_GSLOTS - 1)) == 0, "slot hash");
-            uint32_t sl = (gp[u] * 0x9E3779B1u) >> (32 - k4l_log2(RSQC_K4L_GSLOTS));
-#pragma unroll 1
-            for (int probe = 0; probe < 16; ++probe) {
-                const uint32_t o = atomicCAS(&S.gkey[sl], NONE, gp[u]);
-                if (o == NONE || o == gp[u]) { gslot[u] = sl; rank[u] = atomicAdd(&S.gcnt[sl], 1u); break; }
-                sl = (sl + 1) & (RSQC_K4L_GSLOTS - 1);
-            }
-        }
-        RSQC_FIN_SECT(32, 3);
-        __syncthreads();
-        RSQC_FIN_SECT(32, 4);
-        {                                                                  // one reservation per partition of the pass, all in flight
-            constexpr int R = RSQC_K4L_GSLOTS / RSQC_K4L_THREADS;
-            uint32_t pk[R], pc[R], pr[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) { pk[j] = S.gkey[j * RSQC_K4L_THREADS + threadIdx.x]; pc[j] = S.gcnt[j * RSQC_K4L_THREADS + threadIdx.x]; }
-#pragma unroll
-            for (int j = 0; j < R; ++j) pr[j] = pk[j] != NONE ? atomicAdd(&cursor[pk[j]], pc[j]) : 0u;
-#pragma unroll
-            for (int j = 0; j < R; ++j) S.gcnt[j * RSQC_K4L_THREADS + threadIdx.x] = pr[j];
-        }
-        __syncthreads();
-        RSQC_FIN_SECT(32, 5);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (g[u] == NONE) continue;
-            const uint32_t at = gslot[u] != NONE ? S.gcnt[gslot[u]] + rank[u] : atomicAdd(&cursor[gp[u]], 1u);   // (crowded table)
-            const uint32_t cap = gi[u].z;
-            if (at < cap) list[gb[u] + (unsigned long long)(gp[u] - gi[u].x) * cap + at] = key[u];
-            else atomicExch(error, RSQC_ERR_CAPACITY);
-        }
-        RSQC_FIN_SECT(32, 6);
-#ifdef RSQC_K1_PROF
-        if (threadIdx.x == 0) atomicAdd(&g_fin_prof[32 + 15], 1ull);
-#endif
-#pragma unroll
-        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; }
-    }
-}
-
+// ------------------------------------------------------------------ K3
 // barrier of a T-thread workgroup; a one-wave "workgroup" only needs its LDS traffic ordered (it is executed in order)
 template <int T> __device__ __forceinline__ void k3_sync() {
     if constexpr (T > 64) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 }
-// frag_count_kernel: one workgroup per partition at a time: its keys go through an LDS set sized to the partition, the number
-// of distinct keys is added to the gene.  Three partitions are in flight per workgroup: the row {gene, capacity, list
-// offset} + fill count of the one after next, the keys of the next one (all loads issued together), the set of the current one.
-// (Measured against one WAVE per partition with partitions a quarter of the size: the counting got 15 % faster, the
-// scatter in front of it 40 % slower -- it pays one returning atomic per partition touched by a pass.)
-// Two instances: SLOTS = PART_SLOTS / 2 (16 KB of LDS, eight workgroups per CU) takes the partitions whose keys fit it at half
-// load -- with the window de-dup in front nearly all of them --, SLOTS = PART_SLOTS (32 KB) the fuller ones; each skips the
-// other's partitions: the first instance walks all partitions and LISTS the fuller ones (`full_list`, counter zeroed by
-// frag_layout_kernel), the second walks that list.
-template <int SLOTS>
-__global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
-frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const unsigned long long *list,
-                  unsigned long long *gene_frag, uint32_t *full_list, uint32_t *full_n, int *error) {
-    constexpr bool LISTED = SLOTS == RSQC_K4_PART_SLOTS;
-    __shared__ unsigned long long s_keys[SLOTS];
-    __shared__ uint32_t s_fresh[2];
-    constexpr int KPT = (SLOTS / 2) / RSQC_K4_COUNT_THREADS;                // keys per thread of the fullest list of this instance
-    constexpr uint32_t N_LO = SLOTS == RSQC_K4_PART_SLOTS ? (uint32_t)SLOTS / 4u : 0u;   // this instance: N_LO < keys <= SLOTS / 2
-    const uint32_t n_parts = LISTED ? *full_n : *n_parts_at;               // (iterations: partitions, or entries of the list)
-    struct Row { uint32_t fill; uint4 info; bool fuller; };
-    auto row_of = [&](uint32_t i) -> Row {
-        Row r; r.fill = 0u; r.info = make_uint4(0u, 0u, 0u, 0u); r.fuller = false;
-        if (i < n_parts) {
-            const uint32_t w = LISTED ? full_list[i] : i;
-            r.fill = cursor[w]; r.info = part_info[w];
-            const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
-            r.fuller = n > (uint32_t)SLOTS / 2u;
-            if (n <= N_LO || r.fuller) r.fill = 0u;                        // (the other instance's, or empty)
-        }
-        return r;
-    };
-    auto keys_of = [&](const Row &r, unsigned long long (&kv)[KPT]) {
-        const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
-        const unsigned long long *keys = list + ((unsigned long long)r.info.z | ((unsigned long long)r.info.w << 32));
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) { const uint32_t i = (uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x; kv[j] = i < n ? keys[i] : 0ull; }
-    };
-    uint32_t w = blockIdx.x;
-    Row cur = row_of(w), nxt = row_of(w + gridDim.x);
-    unsigned long long kv[KPT], kvn[KPT];
-    keys_of(cur, kv);
-    if (threadIdx.x < 2) s_fresh[threadIdx.x] = 0u;
-    uint32_t round = 0;
-    RSQC_FIN_BEGIN
-    while (w < n_parts) {
-        RSQC_FIN_SECT(48, 0);
-        const Row nn = row_of(w + 2u * gridDim.x);
-        keys_of(nxt, kvn);
-        if (!LISTED && cur.fuller && threadIdx.x == 0) full_list[atomicAdd(full_n, 1u)] = w;
-        if (cur.fill != 0u) {                                               // (uniform)
-            const uint32_t gene = cur.info.x, cap = cur.info.y;
-            const uint32_t n = cur.fill < cap ? cur.fill : cap;
-            // the set is sized to the partition: the smallest power of two >= 2 n (most partitions hold a few hundred keys)
-            uint32_t slots = 64;
-            while (slots < 2 * n && slots < (uint32_t)SLOTS) slots <<= 1;
-            const uint32_t smask = slots - 1;
-            __syncthreads();                                                // (the previous partition's set is done with)
-            for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) s_keys[i] = 0ull;
-            __syncthreads();
-            RSQC_FIN_SECT(48, 1);
-            uint32_t fresh = 0;
-            auto insert = [&](unsigned long long k) {
-                // (the keys are fmix64 outputs and the partition was chosen from the HIGH word: the low word is as good as a
-                //  fresh hash inside the partition; one multiply spreads neighbouring values anyway)
-                uint32_t slot = (((uint32_t)k * 0x9E3779B1u) >> 16) & smask;
-                bool placed = false;
-#pragma unroll 1
-                for (uint32_t probe = 0; probe < slots; ++probe) {
-                    const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
-                    if (old == 0ull) { ++fresh; placed = true; break; }
-                    if (old == k) { placed = true; break; }
-                    slot = (slot + 1) & smask;
-                }
-                if (!placed) atomicExch(error, RSQC_ERR_CAPACITY);
-            };
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) if ((uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x < n) insert(kv[j]);
-            if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) {               // (a list is never longer than SUB_CAP: kept for safety)
-                const unsigned long long *keys = list + ((unsigned long long)cur.info.z | ((unsigned long long)cur.info.w << 32));
-                for (uint32_t i = (uint32_t)KPT * RSQC_K4_COUNT_THREADS + threadIdx.x; i < n; i += RSQC_K4_COUNT_THREADS) insert(keys[i]);
-            }
-            RSQC_FIN_SECT(48, 2);
-            fresh = wave_sum(fresh);
-            // the per-partition total alternates between two LDS cells: one barrier separates "all waves have added" from
-            // "thread 0 reads and clears"
-            if (lane_id() == 0 && fresh) atomicAdd(&s_fresh[round & 1], fresh);
-            __syncthreads();
-            if (threadIdx.x == 0) { const uint32_t t = s_fresh[round & 1]; s_fresh[round & 1] = 0u; if (t) atomicAdd(&gene_frag[gene], (unsigned long long)t); }
-            ++round;
-            RSQC_FIN_SECT(48, 3);
-#ifdef RSQC_K1_PROF
-            if (threadIdx.x == 0) { atomicAdd(&g_fin_prof[48 + 15], 1ull); atomicAdd(&g_fin_prof[48 + 14], (unsigned long long)n); }
-#endif
-        }
-        w += gridDim.x; cur = nxt; nxt = nn;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) kv[j] = kvn[j];
-    }
-}
-
-// ------------------------------------------------------------------ K3
 // One workgroup per gene, longest genes first.  cov[] holds the per-base DIFFERENCE array of the
 // gene's exons, contiguous in exonsForGene order (+1 pad slot), so a plain prefix sum yields the
 // stitched transcript vector of computeCoverage (src/Metrics.cpp:306-308).
@@ -1661,6 +1322,7 @@ void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, co
                        P.ginfo, P.gene_base, P.cursor, P.list, acc.error);
 }
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {
+    if (n_genes == 0) return;                   // (no layout was written: launch_frag_layout returns early too)
     const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
     hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS / 2>), dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag,
                        P.full_list, P.full_n, error);

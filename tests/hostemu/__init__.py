@@ -85,3 +85,27 @@ def run_k1(params, ann, batch, grid=2, want_cov=False):
     o.read_length = rl.value
     o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]); o.n_pairs = int(stats[2])
     return o
+
+
+_K4SO = os.path.join(_HERE, "libk4emu.so")
+
+
+def build_k4():
+    csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
+    srcs = [os.path.join(_HERE, "k4_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
+           [os.path.join(csrc, f) for f in ("rsqc_k4.h", "rsqc_wave.h", "rsqc_device.h", "rsqc_read.h")]
+    if not os.path.exists(_K4SO) or any(os.path.getmtime(_K4SO) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
+                               "-Wno-unused-variable", srcs[0], "-o", _K4SO])
+    return _K4SO
+
+
+def run_k4(seed, n_genes, n_chunks, n_names, hot_reads, arena=False):
+    """The fragment-counting KERNELS (rsqc_k4.h) on the 64-lane fiber emulation against a std::set per gene.
+    Returns (rc, stats): rc 0 = every gene's count equals its name set; stats = pairs, keys kept by frag_local, partitions,
+    partitions left to the second counting instance, distinct (gene, name) pairs, chunk capacity."""
+    lib = C.CDLL(build_k4())
+    lib.k4emu_run.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    st = np.zeros(6, np.uint64)
+    rc = lib.k4emu_run(seed, n_genes, n_chunks, n_names, hot_reads, 1 if arena else 0, st.ctypes.data)
+    return rc, dict(zip(("pairs", "kept", "partitions", "fuller", "distinct", "chunk_cap"), (int(x) for x in st)))

@@ -27,7 +27,4 @@ print("records %d  tiles %d  K1 %.3f ms" % (batch.n, tiles, tm["classify_ms"] / 
 for k in range(15):
     if cnt[k]: print("  [%2d] %-30s %5.1f %%   %8.0f cycles/tile   (%.2f marks/tile)" % (k, names[k], 100 * cyc[k] / cyc.sum(), cyc[k] / tiles, cnt[k] / tiles))
 print("  total %.0f cycles/tile/wave (s_memtime ticks)" % (cyc[:16].sum() / tiles))
-ev = np.array(out[32:40], dtype=np.float64)
-for k, nm in enumerate(["gene mask beyond 3 breakpoints", "running-max column load", "walk beyond the two staged rows"]):
-    print("  slow branch %-34s taken in %.3f block rounds per tile, %.3f lanes per tile" % (nm, ev[k] / tiles, ev[4 + k] / tiles))
 e.close()
