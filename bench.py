@@ -132,7 +132,11 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
                 m = re.search(r"Average Reads/Sec: ([0-9.e+]+)", p.stdout)
                 e = re.search(r"Time Elapsed: ([0-9.e+-]+); Alignments processed: (\d+)", p.stdout)
                 th = re.search(r"decode threads: (\d+) inflate \+ (\d+) parse", p.stdout)
+                wb = re.search(r"Wall time: ([0-9.e+-]+) s = GTF ([0-9.e+-]+) \+ waiting for the GPU context ([0-9.e+-]+) \+ index / annotation upload / buffers ([0-9.e+-]+)"
+                               r" \+ BAM loop ([0-9.e+-]+) \+ reports ([0-9.e+-]+) \+ release ([0-9.e+-]+)", p.stdout)
                 runs.append({"rc": p.returncode, "wall_s": round(wall, 3), "bam_loop_s": float(e.group(1)) if e else None,
+                             "wall_breakdown_s": dict(zip(("process", "gtf", "gpu_context_wait", "index_upload_buffers", "bam_loop", "reports", "release"),
+                                                          (round(float(x), 3) for x in wb.groups()))) if wb else None,
                              "alignments": int(e.group(2)) if e else None,
                              "reads_per_s": float(m.group(1)) if m else None,
                              "decode": "device" if "on the GPU" in p.stdout else "host",
@@ -145,7 +149,7 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
         best, runs = cli_runs(bam, "device", "dev")
         host_best, _hr = cli_runs(bam, "host", "host")
         out.update({"value": best["reads_per_s"], "unit": "reads/s", "bam_loop_s": best["bam_loop_s"], "wall_s": best["wall_s"],
-                    "alignments": best["alignments"], "decode": best["decode"], "runs": runs,
+                    "alignments": best["alignments"], "decode": best["decode"], "runs": runs, "wall_breakdown_s": best.get("wall_breakdown_s"),
                     "host_decode": {"value": host_best["reads_per_s"], "unit": "reads/s", "decode_threads": host_best["decode_threads"],
                                     "note": "RSQC_DECODE=host: libdeflate inflate + record parsing on the CPU threads, batches over PCIe"},
                     "window": "CLI `Average Reads/Sec` = alignments / (BAM loop incl. end-of-file stage), src/RNASeQC.cpp:240-241,389-394",
