@@ -25,7 +25,7 @@
 
 // Knobs that make the library SKIP work (wrong or incomplete results) exist only in the diagnostic build (`make prof`,
 // -DRSQC_K1_PROF): the product library does not read them.
-#ifdef RSQC_K1_PROF
+#if defined(RSQC_K1_PROF) || defined(RSQC_DIAG_KNOBS)       /* (`make variant NAME=diag DEFS=-DRSQC_DIAG_KNOBS`: the knobs without the section timers) */
 #define RSQC_DIAG(name) getenv(name)
 #else
 #define RSQC_DIAG(name) ((const char *)nullptr)
