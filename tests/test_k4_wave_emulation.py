@@ -16,6 +16,7 @@ CASES = [
     (6, 20, 0, 4000, 30000, True),          # the same through the dense list
     (7, 3, 2, 0, 0, False),                 # nothing counted at all
     (8, 2, 1, 300, 0, False),               # one gene, one short chunk
+    (11, 20000, 6, 100000, 0, False),       # a pass touches ~1 700 partitions: the rank table runs crowded (direct reservations)
 ]
 
 
