@@ -125,3 +125,29 @@ def single_pair_case():
     recs = [dict(qname="pair", tid=0, pos=14400, cigar=[(M, 76)], flag=163, mpos=14500, isize=176, nm=0),
             dict(qname="pair", tid=0, pos=14500, cigar=[(M, 76)], flag=83, mpos=14400, isize=-176, nm=0)]
     return ann, Batch.from_records(recs)
+
+
+def many_exon_case():
+    """One gene of 150 thirty-base exons (more exons than a wave has lanes: the end-of-file coverage kernel gathers a wave's exon
+    rows 64 at a time) + one ordinary gene; 6 000 one-block records of 24 bases."""
+    from rnaseqc_amd.model import Annotation, Batch
+    from rnaseqc_amd import abi
+    rows = [dict(contig="c", type="gene", start=1_000, end=1_000 + 150 * 100, strand="+", gene_id="many", gene_name="many")]
+    for k in range(150):
+        rows.append(dict(contig="c", type="exon", start=1_000 + k * 100, end=1_000 + k * 100 + 29, strand="+", gene_id="many", exon_id="m_e%d" % k))
+    rows.append(dict(contig="c", type="gene", start=40_000, end=42_000, strand="-", gene_id="plain", gene_name="plain"))
+    rows.append(dict(contig="c", type="exon", start=40_000, end=42_000, strand="-", gene_id="plain", exon_id="p_e0"))
+    ann = Annotation.from_rows(["c"], rows)
+    rng = np.random.default_rng(21)
+    n = 6_000
+    ex = rng.integers(0, 150, n - 1_000); off = rng.integers(0, 6, n - 1_000)
+    pos = np.sort(np.concatenate([1_000 + ex * 100 + off, 40_000 + rng.integers(0, 1_900, 1_000)])).astype(np.int32) - 1
+    qh = abi.qname_hash_bytes(np.frombuffer(b"".join(b"%015d" % i for i in range(n)), np.uint8).reshape(n, 15))
+    batch = Batch(pos=pos, mpos=pos.copy(), isize=np.zeros(n, np.int32), qhash=qh, cigar_off=np.arange(n, dtype=np.uint32),
+                  flag=np.zeros(n, np.uint16), l_qseq=np.full(n, 24, np.uint16), mapq=np.full(n, 255, np.uint8),
+                  nm=np.zeros(n, np.uint8), tagbits=np.full(n, abi.TB_HAS_NM | abi.TB_MTID_SAME, np.uint8),
+                  n_cigar=np.ones(n, np.uint8), cigar=np.full(n, (24 << 4) | abi.CIG_M, np.uint32),
+                  seg_tid=np.array([0], np.int32), seg_start=np.array([0, n], np.uint64),
+                  wide_index=np.zeros(0, np.uint64), wide_nm=np.zeros(0, np.int32), wide_l_qseq=np.zeros(0, np.int32),
+                  wide_n_cigar=np.zeros(0, np.uint32))
+    return ann, batch

@@ -109,3 +109,36 @@ def run_k4(seed, n_genes, n_chunks, n_names, hot_reads, arena=False):
     st = np.zeros(6, np.uint64)
     rc = lib.k4emu_run(seed, n_genes, n_chunks, n_names, hot_reads, 1 if arena else 0, st.ctypes.data)
     return rc, dict(zip(("pairs", "kept", "partitions", "fuller", "distinct", "chunk_cap"), (int(x) for x in st)))
+
+
+_K3SO = os.path.join(_HERE, "libk3emu.so")
+
+
+def build_k3():
+    csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
+    srcs = [os.path.join(_HERE, "k3_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
+           [os.path.join(csrc, f) for f in ("rsqc_k3.h", "rsqc_wave.h", "rsqc_device.h", "rsqc_read.h", "rsqc_index.h")]
+    if not os.path.exists(_K3SO) or any(os.path.getmtime(_K3SO) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
+                               "-Wno-unused-variable", srcs[0], "-o", _K3SO])
+    return _K3SO
+
+
+def run_k3(params, ann, cov_diff, gene_reads, force=0):
+    """The end-of-file coverage KERNEL (rsqc_k3.h) on the 64-lane fiber emulation: from the difference array and the gene counts
+    of a pass (hostemu.run(..., want_cov=True)) to per-gene mean / std / CV, per-exon CV and the bias accumulators."""
+    lib = C.CDLL(build_k3())
+    a = ann.to_struct()
+    o = Out()
+    G, E = ann.n_genes_listed, ann.n_exons
+    o.gene_cov_mean = np.zeros(G, np.float64); o.gene_cov_std = np.zeros(G, np.float64); o.gene_cov_cv = np.zeros(G, np.float64)
+    o.gene_cov_valid = np.zeros(G, np.uint8); o.exon_cv = np.zeros(E, np.float64); o.exon_cv_valid = np.zeros(E, np.uint8)
+    o.bias_three = np.zeros(G, np.uint64); o.bias_five = np.zeros(G, np.uint64)
+    stats = np.zeros(4, np.uint64)
+    cov = np.ascontiguousarray(cov_diff, np.uint32); gr = np.ascontiguousarray(gene_reads, np.uint64)
+    rc = lib.k3emu_run(C.byref(params), C.byref(a), abi.ptr(cov), abi.ptr(gr), C.c_int(force), abi.ptr(o.gene_cov_mean), abi.ptr(o.gene_cov_std),
+                       abi.ptr(o.gene_cov_cv), abi.ptr(o.gene_cov_valid), abi.ptr(o.exon_cv), abi.ptr(o.exon_cv_valid),
+                       abi.ptr(o.bias_three), abi.ptr(o.bias_five), abi.ptr(stats))
+    o.rc = rc
+    o.classes = [int(x) for x in stats]
+    return o

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <ucontext.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -138,6 +139,13 @@ template <class T> inline T __shfl(T v, int src, int width = 64) { (void)width; 
 template <class T> inline T __shfl_up(T v, unsigned delta, int width = 64) { (void)width; const int l = wavemu::tid() % 64; return wavemu_exchange(v, l >= (int)delta ? l - (int)delta : l); }
 template <class T> inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; const int l = wavemu::tid() % 64; return wavemu_exchange(v, l ^ mask); }
 inline void __syncthreads() { wavemu::block_sync(); }
+// a one-wave "workgroup" orders its LDS traffic with a fence + wave barrier (rsqc_k3.h, k3_sync<64>): the lanes are fibers here,
+// so the wave barrier is where they wait for each other; fences order nothing on one thread
+#define __builtin_amdgcn_fence(...) ((void)0)
+inline void __builtin_amdgcn_wave_barrier() { (void)wavemu::wave_arrive(); }
+inline void __threadfence_block() {}
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+using std::isnan; using std::isinf;
 inline uint32_t wavemu_mbcnt_lo(uint32_t m, uint32_t add) { const int l = wavemu::tid() % 64; return add + (uint32_t)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
 inline uint32_t wavemu_mbcnt_hi(uint32_t m, uint32_t add) { const int l = wavemu::tid() % 64; return add + (uint32_t)(l > 32 ? __builtin_popcount(m & ((1u << (l - 32)) - 1u)) : 0); }
 #define __builtin_amdgcn_mbcnt_lo wavemu_mbcnt_lo

@@ -58,6 +58,15 @@ def test_deep_coverage_bias_path(oracle_lib, kw):
     assert_results_match(engine.run_engine(p, ann, [batch]), want)
 
 
+def test_gene_with_more_exons_than_lanes(oracle_lib):
+    """150 exons in one gene: the coverage kernel hands a wave its exon rows 64 at a time (tests/cases.py)."""
+    ann, batch = cases.many_exon_case()
+    p = abi.default_params(unpaired=1, coverage_mask=0)
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert want.exon_cv_valid.sum() >= 140
+    assert_results_match(engine.run_engine(p, ann, [batch]), want)
+
+
 @pytest.mark.parametrize("n_exons", [5, 10])
 def test_depth_beyond_16_bits_on_a_long_gene(oracle_lib, n_exons):
     """The longest genes keep 16-bit depths in LDS; a base covered >= 65 536 times must send the gene through the
