@@ -86,38 +86,11 @@ extern "C" __attribute__((visibility("default"))) int rsqc_debug_k1_prof(unsigne
 }
 #endif
 
-// accumulator used by the general (slow-path) code when it re-walks a CIGAR
-struct DirectAcc {
-    double *exon_acc; uint32_t *cov_diff; const uint32_t *ex_id;
-    __device__ __forceinline__ void exon_add(uint32_t row, double frac) { atomicAdd(&exon_acc[ex_id[row]], frac); }
-    __device__ __forceinline__ void cov_range(uint32_t cidx, uint32_t len) {
-        if (len == 0) return;
-        atomicAdd(&cov_diff[cidx], 1u);
-        atomicAdd(&cov_diff[cidx + len], 0xFFFFFFFFu);            // lands on the next exon / the gene's pad slot
-    }
-};
+// ------------------------------------------------------------------ K1s (and the record loader): rsqc_k1s.h
+}  // namespace rsqc
+#include "rsqc_k1s.h"
+namespace rsqc {
 
-// record i of the batch; `seg` is a wave-uniform hint for the contig segment
-__device__ __forceinline__ bool load_record(const DevBatch &b, uint64_t i, uint32_t seg, Record &r) {
-    const int4 cv = *reinterpret_cast<const int4 *>(&b.core[i]);          // global_load_dwordx4
-    const int4 av = *reinterpret_cast<const int4 *>(&b.aux[i]);
-    r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
-    r.cigar = b.cigar + (uint32_t)cv.w;
-    r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
-    r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
-    r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
-    r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
-    bool ok = true;
-    if (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE) {
-        uint32_t lo = 0, hi = b.n_wide;                     // wide table is sorted by record index
-        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (b.wide_index[m] < i) lo = m + 1; else hi = m; }
-        if (lo >= b.n_wide || b.wide_index[lo] != i) ok = false;
-        else { r.l_qseq = b.wide_l_qseq[lo]; r.nm = b.wide_nm[lo]; r.n_cigar = b.wide_n_cigar[lo]; }
-    }
-    while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= i) ++seg;          // rarely iterates
-    r.tid = b.seg_tid[seg];
-    return ok;
-}
 // ------------------------------------------------------------------ K1
 // grid-stride over tiles of RSQC_K1_THREADS records; one record per lane per iteration.
 // Workgroup-local accumulators.  A workgroup streams a short genomic window (a few thousand
@@ -434,197 +407,6 @@ classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum 
     classify_count_body<1, true>(a, p, b, acc, S);
 }
 
-// ------------------------------------------------------------------ K1s
-// Records whose block sits fully inside exons of more than FAST_SET genes (pathological
-// annotations).  The gate cascade already counted them; only the feature stage runs here.
-// full in-wave aggregation by key (not only neighbouring lanes): the slow-path list is not in file order
-template <class F>
-__device__ __forceinline__ void wave_by_key(bool valid, uint32_t key, F &&leader) {
-    uint64_t todo = __ballot(valid);
-    while (todo) {
-        const int lead = __ffsll((unsigned long long)todo) - 1;
-        const uint32_t k0 = __shfl(key, lead, 64);
-        const bool mine = valid && key == k0;
-        const uint64_t same = __ballot(mine);
-        leader(lead, k0, mine, same);
-        todo &= ~same;
-    }
-}
-
-#define RSQC_SLOW_THREADS 256
-#define RSQC_SLOW_SLOTS 1024
-#define RSQC_SLOW_CSLOTS 8192
-// A single hot address sustains only ~90 M atomics/s on this chip (tools/atomic_bench.hip), and the
-// slow-path records concentrate on a few genes: exon fractions are summed per workgroup in an LDS
-// hash (row -> f64) and flushed with one global atomic per distinct row.
-// Atomics into one cache line serialise at ~5-10 ns each as well, and the coverage slots these records
-// touch are few (short exons of a few genes): the +1/-1 events go through an LDS hash too.
-struct SlowShared {
-    uint32_t key[RSQC_SLOW_SLOTS];
-    double val[RSQC_SLOW_SLOTS];
-    uint32_t ckey[RSQC_SLOW_CSLOTS];
-    uint32_t cval[RSQC_SLOW_CSLOTS];
-};
-// accumulator of the general code inside classify_slow_kernel (the `Acc` of legacy_metrics)
-struct SlowAcc {
-    SlowShared *S; const DevAccum *acc; const uint32_t *ex_id;
-    __device__ __forceinline__ void exon_add(uint32_t row, double frac) {
-        uint32_t slot = (row * 2654435761u) >> 22;                      // 10 bits
-        for (int probe = 0; probe < 16; ++probe) {
-            const uint32_t old = atomicCAS(&S->key[slot], 0xFFFFFFFFu, row);
-            if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&S->val[slot], frac); return; }
-            slot = (slot + 1) & (RSQC_SLOW_SLOTS - 1);
-        }
-        atomicAdd(&acc->exon_acc[ex_id[row]], frac);                    // table crowded: straight to memory
-    }
-    __device__ __forceinline__ void cov_add(uint32_t idx, uint32_t delta) {
-        uint32_t slot = (idx * 2654435761u) >> 19;                      // 13 bits
-        for (int probe = 0; probe < 16; ++probe) {
-            const uint32_t old = atomicCAS(&S->ckey[slot], 0xFFFFFFFFu, idx);
-            if (old == 0xFFFFFFFFu || old == idx) { atomicAdd(&S->cval[slot], delta); return; }
-            slot = (slot + 1) & (RSQC_SLOW_CSLOTS - 1);
-        }
-        atomicAdd(&acc->cov_diff[idx], delta);
-    }
-    __device__ __forceinline__ void cov_range(uint32_t cidx, uint32_t len) {
-        if (len == 0) return;
-        cov_add(cidx, 1u); cov_add(cidx + len, 0xFFFFFFFFu);
-    }
-    __device__ __forceinline__ void gene_hit(uint32_t g, bool notdup, uint64_t qhash) {   // genes beyond the wave-aggregated ones
-        atomicAdd(&acc->gene_reads[g], 1ull);
-        if (notdup) atomicAdd(&acc->gene_unique[g], 1ull);
-        const uint32_t slot = atomicAdd(acc->pair_slow_count, 1u);
-        if (slot < acc->pair_slow_cap) { acc->pair_gene[acc->pair_slow_base + slot] = g; acc->pair_hash[acc->pair_slow_base + slot] = qhash; }
-        else atomicExch(acc->error, RSQC_ERR_CAPACITY);
-    }
-};
-
-// LEGACY = false: the records K1 listed in ovf_index.  LEGACY = true (--legacy): every record of the batch, in file
-// order, through legacy_metrics (rsqc_read.h).
-template <bool LEGACY>
-__global__ void __launch_bounds__(RSQC_SLOW_THREADS)
-classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
-    __shared__ SlowShared SH;
-    uint32_t *const s_key = SH.key; double *const s_val = SH.val; uint32_t *const s_ckey = SH.ckey, *const s_cval = SH.cval;
-    uint64_t n = *acc.ovf_count < acc.ovf_cap ? *acc.ovf_count : acc.ovf_cap;
-    if (LEGACY) n = b.n;
-    if ((uint64_t)blockIdx.x * blockDim.x >= n) return;  // nothing for this workgroup (the usual case for most of the grid)
-    for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x) { s_key[i] = 0xFFFFFFFFu; s_val[i] = 0.0; }
-    for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x) { s_ckey[i] = 0xFFFFFFFFu; s_cval[i] = 0u; }
-    __syncthreads();
-    const int l = lane_id();
-    DirectAcc dacc{acc.exon_acc, acc.cov_diff, a.ex_id};
-    SlowAcc sacc{&SH, &acc, a.ex_id};
-    auto exon_add_lds = [&](uint32_t row, double frac) { sacc.exon_add(row, frac); };
-    auto cov_add_lds = [&](uint32_t idx, uint32_t delta) { sacc.cov_add(idx, delta); };
-    unsigned long long my_cnt = 0ull;                 // lane c accumulates counter c
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t k0 = (uint64_t)blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
-        const uint64_t k = k0 + threadIdx.x;
-        uint64_t bits = 0;
-        FeatureOut<MID_SET, SLOW_STAGE> fm;
-        fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
-        uint32_t aligned = 1; bool notdup = false; uint64_t qhash = 0;
-        if (k < n) {
-            Record r;
-            // bit 63 of a listed index: classify_ei_kernel did not walk this record's CIGAR to the end (a long-CIGAR straggler of a
-            // boundary tile) -- its blocks are counted and its operations checked here
-            const uint64_t entry = LEGACY ? k : acc.ovf_index[k];
-            const uint64_t i = entry & ~(1ull << 63);
-            if (load_record(b, i, find_segment(b, i), r)) {
-                RecordCounters rc; bool hq; Blocks B;
-                const bool go = gate_cascade(a, p, r, rc, hq, aligned, B);
-                if (!LEGACY && (entry >> 63)) {
-                    if (rc.error) atomicExch(acc.error, rc.error);
-                    if (rc.blocks) atomicAdd(&acc.counters[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)rc.blocks);
-                }
-                if (go) {
-                    notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
-                    bool overflow = false;
-                    if (LEGACY) {
-                        LegacyOut<MID_SET> lo;
-                        legacy_metrics<MID_SET>(a, p, r, hq, sacc, lo);
-                        bits = lo.bits; fm.n_hit = lo.n_hit;
-#pragma unroll
-                        for (int j = 0; j < MID_SET; ++j) fm.hit[j] = lo.hit[j];
-                    } else {
-                    exon_metrics<MID_SET>(a, p, r, hq, aligned, dacc, fm, overflow);
-                    if (overflow) {                  // rare second tier: up to 32 genes, plain atomics
-                        fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
-                        FeatureOut<SLOW_SET, SLOW_STAGE> fo;
-                        exon_metrics<SLOW_SET>(a, p, r, hq, aligned, dacc, fo, overflow);
-                        if (overflow) atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                        else {
-                            for (int j = 0; j < fo.n_commit; ++j) {
-                                const Commit cm = fo.commit[j];
-                                if (cm.len > 0) dacc.exon_add(cm.row, (double)cm.len / (double)aligned);
-                                dacc.cov_range(cm.cidx, cm.len);
-                            }
-                            for (int j = 0; j < fo.n_hit; ++j) {
-                                const uint32_t g = fo.hit[j];
-                                atomicAdd(&acc.gene_reads[g], 1ull);
-                                if (notdup) atomicAdd(&acc.gene_unique[g], 1ull);
-                                const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
-                                if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; }
-                                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                            }
-                            bits = fo.bits;
-                        }
-                    } else bits = fm.bits;
-                    }
-                }
-            }
-        }
-        // ---- scatter of the first-tier results: few records, so exon fractions and coverage go out as
-        //      plain atomics; gene counts and pair slots are aggregated per wave (same-address traffic)
-        for (int j = 0; j < fm.n_commit; ++j) {
-            const Commit cm = fm.commit[j];
-            if (cm.len > 0) exon_add_lds(cm.row, (double)cm.len / (double)aligned);
-            if (cm.len > 0) {
-                const uint32_t base = cm.cidx;
-                cov_add_lds(base, 1u); cov_add_lds(base + cm.len, 0xFFFFFFFFu);
-            }
-        }
-        {
-            const uint64_t nd_mask = __ballot(notdup);
-#pragma unroll
-            for (int j = 0; j < MID_SET; ++j) {
-                const bool has = fm.n_hit > j;
-                const uint64_t m = __ballot(has);
-                if (m == 0ull) break;
-                const uint32_t g = fm.hit[j];
-                const int lead0 = __ffsll((unsigned long long)m) - 1;
-                uint32_t base = 0;
-                if (l == lead0) base = atomicAdd(acc.pair_slow_count, (uint32_t)__popcll(m));
-                base = __shfl(base, lead0, 64);
-                if (has) {
-                    const uint32_t slot = base + mask_rank(m);
-                    if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; }
-                    else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                }
-                wave_by_key(has, g, [&](int lead, uint32_t gg, bool, uint64_t same) {
-                    if (l == lead) {
-                        atomicAdd(&acc.gene_reads[gg], (unsigned long long)__popcll(same));
-                        const uint32_t nd = (uint32_t)__popcll(same & nd_mask);
-                        if (nd) atomicAdd(&acc.gene_unique[gg], (unsigned long long)nd);
-                    }
-                });
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < RSQC_N_COUNTERS; ++c) {       // the gate cascade was counted by K1; only feature-stage bits here
-            const uint64_t m = __ballot((bits >> c) & 1ull);
-            if (l == c) my_cnt += (unsigned long long)__popcll(m);
-        }
-    }
-    if (l < RSQC_N_COUNTERS && my_cnt) atomicAdd(&acc.counters[l], my_cnt);
-    __syncthreads();
-    for (int i = threadIdx.x; i < RSQC_SLOW_SLOTS; i += blockDim.x)
-        if (s_key[i] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[a.ex_id[s_key[i]]], s_val[i]);
-    for (int i = threadIdx.x; i < RSQC_SLOW_CSLOTS; i += blockDim.x)
-        if (s_ckey[i] != 0xFFFFFFFFu && s_cval[i] != 0u) atomicAdd(&acc.cov_diff[s_ckey[i]], s_cval[i]);
-}
-
 }  // namespace rsqc
 #include "rsqc_k1.h"
 namespace rsqc {
@@ -647,100 +429,10 @@ void launch_ei_rank(hipStream_t s, const EiEntry *ei, uint32_t ei_lo, uint32_t e
     if (n_words) hipLaunchKernelGGL(ei_rank_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, ei, ei_lo, ei_hi, rank, n_words);
 }
 
-// ------------------------------------------------------------------ KR
-// "Read Length" (src/RNASeQC.cpp:275-278): readLength = l_qseq of each record whose span exceeds the current value, in
-// FILE order.  The kernel computes, per batch, the batch's TRANSFER FUNCTION state-in -> state-out, applies it to the
-// context's state, and leaves the function in the batch's summary slot, so that a contig-sharded run can compose the
-// batches of all shards in file order on the host (rsqc_shard_info) -- exact for any mix of read lengths.
-//
-// Shape of the function: entered with state r, the first record that fires is the first record whose span exceeds r,
-// which is necessarily a PREFIX MAXIMUM of span over the batch's eligible records; from there the walk no longer
-// depends on r.  With the prefix maxima p_1..p_P (spans s_1 < .. < s_P) and g_k = the final state of the walk that
-// starts by firing p_k:   f(r) = g_k for the first k with s_k > r,  f(r) = r when no span exceeds r.
-// When every eligible record of the batch has the same l_qseq L (the normal case) all g_k equal L:  P = 1,
-// (s, g) = (max span, L) -- O(1).  Otherwise one wavefront replays the batch with ALL the walks at once (lane j carries
-// the walk started by p_j and p_{64+j}), opening only the 64-record tiles whose max span can still change something.
-#define RSQC_RL_MAXP 128
-__global__ void __launch_bounds__(64)
-read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint32_t *summary) {
-    const int l = lane_id();
-    const uint32_t r_in = (uint32_t)*acc.read_length;
-    const uint32_t Smax = acc.rl_stats[0], Lmin = acc.rl_stats[1], Lmax = acc.rl_stats[2];
-    uint32_t P = 0;
-    uint32_t s0 = 0, s1 = 0, v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;      // lane j: walks j and 64 + j (key span, state)
-    bool too_many = false;
-    if (Lmin == 0xFFFFFFFFu) {
-        P = 0;                                                         // no eligible record: identity
-    } else if (Lmin == Lmax) {
-        P = 1;
-        if (l == 0) { s0 = Smax; v0 = Lmin; }
-    } else {
-        uint32_t cur_max = 0u, vmin = 0xFFFFFFFFu;                     // prefix max of span so far; smallest live state
-        const uint64_t n_tiles = (b.n + 63) / 64;
-        for (uint64_t t0 = 0; t0 < n_tiles; t0 += 64) {
-            const uint64_t t = t0 + l;
-            uint32_t S = 0;
-            if (t < n_tiles) S = acc.tile_span[t];
-            uint64_t need = __ballot(S > (cur_max < vmin ? cur_max : vmin));
-            while (need) {
-                const int tl = __ffsll((unsigned long long)need) - 1;
-                need &= need - 1;
-                const uint32_t St = __shfl(S, tl, 64);
-                if (!(St > (cur_max < vmin ? cur_max : vmin))) continue;   // the thresholds moved since the ballot
-                const uint64_t i = (t0 + tl) * 64 + l;                 // replay the tile's 64 records in order
-                uint32_t span = 0, lq = 0; bool elig = false;
-                if (i < b.n) {
-                    Record rec;
-                    if (load_record(b, i, find_segment(b, (t0 + tl) * 64), rec)) {
-                        RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
-                        gate_cascade(a, p, rec, rc, hq, aligned, B);
-                        elig = rc.rl_eligible != 0; span = rc.rl_span; lq = (uint32_t)rc.rl_lqseq;
-                    }
-                }
-                int from = 0;
-                while (true) {
-                    const uint32_t thr = cur_max < vmin ? cur_max : vmin;
-                    const uint64_t m = __ballot(elig && l >= from && span > thr);
-                    if (!m) break;
-                    const int w = __ffsll((unsigned long long)m) - 1;
-                    const uint32_t sp = __shfl(span, w, 64), q = __shfl(lq, w, 64);
-                    if (sp > v0 && v0 != 0xFFFFFFFFu) v0 = q;          // every live walk sees the record
-                    if (sp > v1 && v1 != 0xFFFFFFFFu) v1 = q;
-                    if (sp > cur_max) {                                // a new prefix maximum starts a walk of its own
-                        if (P < RSQC_RL_MAXP) {
-                            if (l == (int)(P & 63u)) { if (P < 64) { s0 = sp; v0 = q; } else { s1 = sp; v1 = q; } }
-                            ++P;
-                        } else too_many = true;
-                        cur_max = sp;
-                    }
-                    const uint32_t lm = v0 < v1 ? v0 : v1;
-                    vmin = wave_min_u32(lm);
-                    from = w + 1;
-                }
-                need &= __ballot(S > (cur_max < vmin ? cur_max : vmin));
-            }
-        }
-    }
-    // the function applied to the incoming state: the first key above it decides
-    uint32_t r = r_in;
-    {
-        const uint64_t m0 = __ballot(P > (uint32_t)l && s0 > r_in), m1 = __ballot(P > 64u + (uint32_t)l && s1 > r_in);
-        if (m0) r = __shfl(v0, __ffsll((unsigned long long)m0) - 1, 64);
-        else if (m1) r = __shfl(v1, __ffsll((unsigned long long)m1) - 1, 64);
-    }
-    if (summary) {                                                     // [0] P, [1] flags, then P x (span, state)
-        if (l == 0) { summary[0] = P; summary[1] = too_many ? 1u : 0u; }
-        if ((uint32_t)l < P) { summary[2 + 2 * l] = s0; summary[3 + 2 * l] = v0; }
-        if (64u + (uint32_t)l < P) { summary[2 + 2 * (64 + l)] = s1; summary[3 + 2 * (64 + l)] = v1; }
-    }
-    if (l == 0) {
-        if (too_many) atomicExch(acc.error, RSQC_ERR_CAPACITY);
-        *acc.read_length = (int32_t)r;
-        acc.rl_stats[0] = 0u; acc.rl_stats[1] = 0xFFFFFFFFu; acc.rl_stats[2] = 0u;    // ready for the next batch
-        acc.ovf_count[1] += *acc.ovf_count;   // records the general kernel took since the last reset (rsqc_timing.slow_records)
-        *acc.ovf_count = 0u;                  // (the slow kernel, this batch's only reader, ran before this kernel)
-    }
-}
+// ------------------------------------------------------------------ KR: rsqc_kr.h
+}  // namespace rsqc
+#include "rsqc_kr.h"
+namespace rsqc {
 
 // ------------------------------------------------------------------ K4 (rsqc_k4.h) and the retirement of a batch's pairs
 // The pairs of a batch live in per-K1-block chunks (+ one slow-path region), each chunk in file order; the pairs of

@@ -55,7 +55,7 @@ _K1SO = os.path.join(_HERE, "libk1emu.so")
 def build_k1():
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
     srcs = [os.path.join(_HERE, "k1_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
-           [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_wave.h", "rsqc_device.h")] + \
+           [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_k1s.h", "rsqc_kr.h", "rsqc_wave.h", "rsqc_device.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
     if not os.path.exists(_K1SO) or any(os.path.getmtime(_K1SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
@@ -63,7 +63,7 @@ def build_k1():
     return _K1SO
 
 
-def run_k1(params, ann, batch, grid=2, want_cov=False):
+def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True):
     """The per-record KERNELS (rsqc_k1.h) on the 64-lane fiber emulation of wavemu.h, `grid` workgroups of 256 lanes."""
     lib = C.CDLL(build_k1())
     a, b = ann.to_struct(), batch.to_struct()
@@ -77,7 +77,7 @@ def run_k1(params, ann, batch, grid=2, want_cov=False):
     if want_cov:
         total = int(sum(int(ann.exon_row_end[i]) - int(ann.exon_row_start[i]) + 1 for i in range(E))) + ann.n_genes + 8
         o.cov = np.zeros(total, np.uint32)
-    rc = lib.k1emu_run(C.byref(params), C.byref(a), C.byref(b), C.c_int(grid), abi.ptr(o.counters), abi.ptr(o.gene_reads),
+    rc = lib.k1emu_run(C.byref(params), C.byref(a), C.byref(b), C.c_int(grid), C.c_int(1 if slow_kernel else 0), abi.ptr(o.counters), abi.ptr(o.gene_reads),
                        abi.ptr(o.gene_unique), abi.ptr(o.gene_fragments), abi.ptr(o.exon_reads), C.byref(rl),
                        abi.ptr(o.cov) if want_cov else None, abi.ptr(stats))
     if rc:

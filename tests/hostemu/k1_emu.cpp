@@ -1,11 +1,11 @@
 // k1_emu.cpp -- TEST HARNESS ONLY (never loaded by the product).
 //
-// The per-record KERNELS themselves -- rnaseqc_amd/csrc/rsqc_k1.h (classify_ei_kernel, classify_multi_kernel) with the
-// wave helpers of rsqc_wave.h, unmodified -- compiled for the host on top of the 64-lane fiber emulation of wavemu.h:
-// per-wave LDS queues, ballot / mbcnt compaction, workgroup LDS tables, pair chunks, the list of long-CIGAR records, the
-// overflow list.  hostemu.cpp covers the per-record functions one record at a time; this covers what the wavefronts do
-// with them.  The records on the overflow list go through the general per-record code here (the GPU runs
-// classify_slow_kernel on them).
+// The per-record KERNELS themselves -- rnaseqc_amd/csrc/rsqc_k1.h (classify_ei_kernel), rsqc_k1s.h (classify_slow_kernel) and
+// rsqc_kr.h (read_length_kernel) with the wave helpers of rsqc_wave.h, unmodified -- compiled for the host on top of the
+// 64-lane fiber emulation of wavemu.h: per-wave LDS queues, ballot / mbcnt compaction, workgroup LDS tables, pair chunks, the
+// overflow list and the general kernel that takes it, the Read-Length transfer function.  hostemu.cpp covers the per-record
+// functions one record at a time; this covers what the wavefronts do with them.  `slow_kernel` = 0 sends the overflow list
+// through the general per-record code on the host instead of classify_slow_kernel (the two must agree).
 #include "wavemu.h"
 
 #include <map>
@@ -18,6 +18,8 @@
 #include "../../rnaseqc_amd/csrc/rsqc_index.h"
 #include "../../rnaseqc_amd/csrc/rsqc_wave.h"
 #include "../../rnaseqc_amd/csrc/rsqc_k1.h"
+#include "../../rnaseqc_amd/csrc/rsqc_k1s.h"
+#include "../../rnaseqc_amd/csrc/rsqc_kr.h"
 
 using namespace rsqc;
 
@@ -35,7 +37,7 @@ struct SlowAccH {
 
 // returns 0, an RSQC_ERR_* code, or 1000 + k for a failed internal check k
 extern "C" __attribute__((visibility("default")))
-int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, int grid,
+int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, int grid, int slow_kernel,
               uint64_t *counters, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag, double *exon_reads /*by exon id*/,
               int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/, uint64_t *stats /*[4]: overflow, listed, pairs, tiles processed*/) {
     HostIndex hx; std::string err;
@@ -124,6 +126,30 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         return true;
     };
     std::set<uint64_t> seen_ovf;
+    const uint32_t n_overflow = ovf_count[0];                  // (read_length_kernel, the batch's last kernel, zeroes the counter)
+    if (slow_kernel) {
+        // the general KERNEL on the list, sized as launch_classify_slow sizes it; it adds to the same accumulators and appends
+        // its (gene, name) pairs to the slow-path region of the pair buffer
+        for (uint32_t k = 0; k < ovf_count[0]; ++k) {
+            const uint64_t i = ovf_index[k] & ~(1ull << 63);
+            if (i >= n || !seen_ovf.insert(i).second) return 1002;
+            if (ovf_index[k] >> 63) ++listed;
+        }
+        const uint32_t blocks = (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(8, n / 200 / RSQC_SLOW_THREADS + 1));
+        wavemu::grid_dim().x = blocks;
+        for (uint32_t k = 0; k < blocks; ++k) {
+            wavemu::block_idx().x = k;
+            wavemu::run_block(RSQC_SLOW_THREADS, [&]() { classify_slow_kernel<false>(d, dp, db, acc); });
+        }
+        if (error) return error;
+        const uint32_t ns = chunk_count[(size_t)grid];
+        if (ns > slow_cap) return 1008;
+        for (uint32_t j = 0; j < ns; ++j) {
+            const uint32_t g = pair_gene[(size_t)acc.pair_slow_base + j];
+            if (g >= G) return 1005;
+            names[g].insert(pair_hash[(size_t)acc.pair_slow_base + j]);
+        }
+    } else
     for (uint32_t k = 0; k < ovf_count[0]; ++k) {
         const uint64_t i = ovf_index[k] & ~(1ull << 63);
         const bool long_straggler = (ovf_index[k] >> 63) != 0;            // K1E_OVF_LONG: blocks and operations are this code's to count / check
@@ -177,6 +203,12 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         // per-wave ranges are multiples of 64 records, so a wave's tile t is batch tile (wbeg / 64 + t)
         for (size_t t = 0; t < want.size(); ++t) if (tile_span[t] != want[t]) return 1006;
         if (rl_stats[0] != smax || rl_stats[1] != lmin || rl_stats[2] != lmax) return 1007;
+        // the Read-Length KERNEL: the batch's transfer function applied to state 0 must leave the value of the walk above
+        std::vector<uint32_t> summary(RSQC_RL_SUMMARY_WORDS + 8, 0u);
+        wavemu::grid_dim().x = 1; wavemu::block_idx().x = 0;
+        wavemu::run_block(64, [&]() { read_length_kernel(d, dp, db, acc, summary.data()); });
+        if (error) return error;
+        if ((uint32_t)rl_state != rl) return 1009;
     }
     for (size_t g = 0; g < (size_t)a->n_genes_listed; ++g) {
         gene_reads[g] = acc.gene_reads[g] + reads[g]; gene_unique[g] = acc.gene_unique[g] + unique[g]; gene_frag[g] = names[g].size();
@@ -185,6 +217,6 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e] + exon_acc[a->exon_row_id[e]];
     *read_length = (int32_t)rl;
     if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
-    stats[0] = ovf_count[0]; stats[1] = listed; stats[2] = n_pairs; stats[3] = 0;
+    stats[0] = n_overflow; stats[1] = listed; stats[2] = n_pairs; stats[3] = 0;
     return 0;
 }

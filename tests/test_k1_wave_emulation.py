@@ -1,5 +1,5 @@
-"""The per-record KERNEL (rnaseqc_amd/csrc/rsqc_k1.h: classify_ei_kernel, with rsqc_wave.h),
-unmodified, on a 64-lane SIMT emulation for the host (tests/hostemu/wavemu.h: one fiber per lane; ballot / shuffle / mbcnt /
+"""The per-record KERNELS (rnaseqc_amd/csrc/rsqc_k1.h: classify_ei_kernel; rsqc_k1s.h: classify_slow_kernel on its overflow list;
+rsqc_kr.h: read_length_kernel; with rsqc_wave.h), unmodified, on a 64-lane SIMT emulation for the host (tests/hostemu/wavemu.h: one fiber per lane; ballot / shuffle / mbcnt /
 LDS and memory atomics / __syncthreads on a cooperative scheduler) against the oracle: per-wave LDS queues sorted by block
 count, the feature stage on full and on drained tiles, workgroup tables, pair chunks, the long-CIGAR queue, the overflow
 list, Read-Length inputs per tile.  The GPU tests run the same source on the device."""
@@ -58,8 +58,11 @@ def test_hostile_annotations(oracle_lib, seed):
         for kw in (dict(), dict(stranded=abi.STRAND_FORWARD), dict(stranded=abi.STRAND_REVERSE, unpaired=1)):
             p = abi.default_params(mapq_threshold=4, **kw)
             ref = hostemu.run(p, ann, batch, mode=1, want_cov=True)
-            o = hostemu.run_k1(p, ann, batch, grid=2, want_cov=True)
-            _compare(o, oracle_lib.run_oracle(p, ann, [batch]), ref.cov)
+            want = oracle_lib.run_oracle(p, ann, [batch])
+            o = hostemu.run_k1(p, ann, batch, grid=2, want_cov=True)                      # overflow list -> classify_slow_kernel
+            _compare(o, want, ref.cov)
+            _compare(hostemu.run_k1(p, ann, batch, grid=2, want_cov=True, slow_kernel=False), want, ref.cov)   # -> per-record code on the host
+            assert o.n_overflow > 0
 
 
 def test_small_and_ragged_batches(oracle_lib):
