@@ -96,3 +96,15 @@ def test_gene_with_more_exons_than_lanes(oracle_lib):
     cov, gr = _pass(p, ann, batch)
     for force in (0, 3, 4, 2):
         _compare(hostemu.run_k3(p, ann, cov, gr, force=force), want)
+
+
+def test_chained_with_the_emulated_per_read_kernels(oracle_lib):
+    """The difference array and the gene counts come from the EMULATED per-read kernels (classify_ei_kernel + classify_slow_kernel,
+    tests/hostemu/k1_emu.cpp) instead of the per-record host code: per-read kernels -> coverage kernel, all on the fiber emulation."""
+    ann = synth.make_annotation(seed=8, contigs=[("chrA", 400_000, 40)])
+    batch = synth.make_reads(ann, 30000, seed=9, frac=(0.97, 0.01, 0.01, 0.01), expr_sigma=1.0, contig_lengths=np.array([400_000]))
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    k1 = hostemu.run_k1(p, ann, batch, grid=3, want_cov=True)
+    np.testing.assert_array_equal(k1.gene_reads, want.gene_reads)
+    _compare(hostemu.run_k3(p, ann, k1.cov, k1.gene_reads, force=0), want)
