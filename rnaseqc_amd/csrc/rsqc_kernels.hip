@@ -392,15 +392,11 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
 #endif
 }
 
-// 4 waves per SIMD (at most 128 VGPRs), one block's row loads in flight at a time (ROUND = 1): measured against 3 waves
+// The row-index kernel of rounds 1-2 (bin tables + downward walk of the start-sorted exon rows).  The default rules run
+// classify_ei_kernel (rsqc_k1.h) since round 3; this body serves --legacy, where the per-record work of the feature stage belongs to
+// classify_slow_kernel<true> and only the gate cascade, the counters and the Read-Length inputs are taken here (LEGACY = true).
+// 4 waves per SIMD (at most 128 VGPRs), one block's row loads in flight at a time (ROUND = 1): measured in round 2 against 3 waves
 // (168 VGPRs, no spills: +14 %), 5 waves (96 VGPRs, spills in the loop: 2.2x) and ROUND = 2 (profiles/r2_k1_occupancy_v1.txt).
-#define RSQC_DEFINE_K1(NAME, MINW, ROUND)                                                       \
-    __global__ void __launch_bounds__(RSQC_K1_THREADS, MINW)                                    \
-    NAME(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {                              \
-        __shared__ K1Shared S;                                                                  \
-        classify_count_body<ROUND>(a, p, b, acc, S);                                            \
-    }
-RSQC_DEFINE_K1(classify_count_kernel_w4r1, 4, 1)
 __global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
 classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
     __shared__ K1Shared S;
@@ -626,8 +622,12 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
                      const DevAccum &acc) {
     if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
     else {
-        // (diagnostic) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
+#if defined(RSQC_K1_PROF) || defined(RSQC_DIAG_KNOBS)
+        // (diagnostic builds) RSQC_K1_LDS_PAD: extra dynamic LDS per workgroup, i.e. fewer resident waves -- tells latency-bound from issue-bound
         static const unsigned pad = getenv("RSQC_K1_LDS_PAD") ? (unsigned)atoi(getenv("RSQC_K1_LDS_PAD")) : 0u;
+#else
+        const unsigned pad = 0u;
+#endif
         const K1Args A{a, p, b, acc};
         hipLaunchKernelGGL(classify_ei_kernel, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
     }
