@@ -55,7 +55,7 @@ _K1SO = os.path.join(_HERE, "libk1emu.so")
 def build_k1():
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
     srcs = [os.path.join(_HERE, "k1_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
-           [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_k1s.h", "rsqc_kr.h", "rsqc_wave.h", "rsqc_device.h")] + \
+           [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_k1s.h", "rsqc_kr.h", "rsqc_k4.h", "rsqc_wave.h", "rsqc_device.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
     if not os.path.exists(_K1SO) or any(os.path.getmtime(_K1SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
