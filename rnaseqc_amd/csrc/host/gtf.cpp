@@ -186,22 +186,48 @@ void Annotation::load_gtf(const std::string &path) {
     }
 }
 
-void Annotation::load_bed(const std::string &path) {                   // extractBED, src/BED.cpp:18-45
+// One BED line = one interval, `extractBED` (src/BED.cpp:18-45) as the loop of src/RNASeQC.cpp:185 drives it.  The reference
+// pulls three whitespace-separated tokens through ONE string, so what a malformed line does follows from that and is kept:
+//   * a line whose first character is '#' is skipped; an empty line is NOT (its chromosome is the empty name and its start
+//     fails to parse: the run ends with "Failed to parse the BED");
+//   * a missing token leaves the previous one in place: "chr1 100" ends at 101 like it starts, "chr1" alone fails on "chr1";
+//   * numbers are std::stoull's: optional sign (a '-' wraps around), leading digits only ("100abc" is 100), nothing
+//     parsable or a value beyond 64 bits is an exception; both bounds are stored + 1.
+// pinned against the reference's own BED.cpp: tests/test_reference_metrics.py::test_bed_loader_vs_reference_extractBED
+namespace {
+struct BedTokens { const char *tok[3]; size_t len[3]; int n; };
+inline BedTokens bed_split(const std::string &line) {
+    BedTokens t{{nullptr, nullptr, nullptr}, {0, 0, 0}, 0};
+    const char *p = line.data(), *const e = p + line.size();
+    auto space = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };         // the "C" locale's isspace, what operator>> skips
+    while (t.n < 3) {
+        while (p < e && space(*p)) ++p;
+        if (p == e) break;
+        const char *q = p;
+        while (q < e && !space(*q)) ++q;
+        t.tok[t.n] = p; t.len[t.n] = (size_t)(q - p); ++t.n;
+        p = q;
+    }
+    return t;
+}
+}  // namespace
+
+void Annotation::load_bed(const std::string &path) {
     std::ifstream in(path);
     if (!in.is_open()) throw FileError("Unable to open BED file: " + path);
-    std::string line;
+    std::string line, field;
     try {
         while (std::getline(in, line)) {
-            if (line[0] == '#') continue;
-            std::istringstream tokenizer(line);
-            std::string buffer;
-            tokenizer >> buffer;
-            const int chrom = chromosome(buffer);
-            tokenizer >> buffer;
-            const long long start = (long long)std::stoull(buffer) + 1;
-            tokenizer >> buffer;
-            const long long end = (long long)std::stoull(buffer) + 1;
-            bed_rows.push_back(BedRow{chrom, start, end});
+            if (!line.empty() && line[0] == '#') continue;
+            const BedTokens t = bed_split(line);
+            // token k that is missing repeats token k - 1 (the reference's buffer keeps its value when extraction fails)
+            auto text = [&](int k) { while (k >= t.n && k > 0) --k; return t.n ? std::string(t.tok[k], t.len[k]) : std::string(); };
+            const int chrom = chromosome(text(0));
+            field = text(1);
+            const unsigned long long lo = std::stoull(field);
+            field = text(2);
+            const unsigned long long hi = std::stoull(field);
+            bed_rows.push_back(BedRow{chrom, (long long)(lo + 1ull), (long long)(hi + 1ull)});
         }
     } catch (std::exception &e) {
         throw BedError(std::string("Encountered an unknown error while parsing the BED: ") + e.what());

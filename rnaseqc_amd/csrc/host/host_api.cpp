@@ -35,6 +35,22 @@ HAPI void *host_annotation_load(const char *gtf, const char *bed, const char *co
 }
 HAPI const rsqc_annotation *host_annotation_struct(void *h) { return &((Annotation *)h)->ann; }
 HAPI const rsqc_bed *host_annotation_bed(void *h) { return &((Annotation *)h)->bed; }
+// the BED loader alone, rows as read (file order, before flattening): returns the number of rows, -1 = cannot open,
+// -2 - n = BedError after n rows (message -> err).  chrom_index = index into the '\n'-joined names (first-sight order).
+HAPI long long host_bed_read(const char *path, long long cap, int32_t *chrom_index, long long *start, long long *end,
+                             char *names, long long names_cap, char *err, long long err_cap) {
+    Annotation a;
+    bool threw = false;
+    try { a.load_bed(path); }
+    catch (FileError &) { return -1; }
+    catch (BedError &e) { threw = true; if (err && err_cap > 0) { strncpy(err, e.what(), (size_t)err_cap - 1); err[err_cap - 1] = 0; } }
+    long long n = 0;
+    for (auto &r : a.bed_rows) { if (n < cap) { chrom_index[n] = r.chrom - 1; start[n] = r.start; end[n] = r.end; } ++n; }
+    std::string joined;
+    for (auto &s : a.chrom_name) { joined += s; joined += '\n'; }
+    if (names && names_cap > 0) { strncpy(names, joined.c_str(), (size_t)names_cap - 1); names[names_cap - 1] = 0; }
+    return threw ? -2 - n : n;
+}
 HAPI const char *host_annotation_gene_name(void *h, int listed_gene) {
     Annotation *a = (Annotation *)h; static thread_local std::string tmp; tmp = a->gene_name(a->gene_list[(size_t)listed_gene]); return tmp.c_str();
 }

@@ -185,3 +185,80 @@ def test_collector_vs_reference_class(ref):
     assert 0.99 < mx.value <= 2.0 + 1e-9                        # Collector::sum(): a read counted to two overlapping genes adds up twice
     # geneCounts only moves when queryGene says so (src/Expression.cpp:380-382)
     assert int(want.gene_reads.sum()) == int(query[kind == 1].sum())
+
+
+# ---- src/BED.cpp (extractBED), compiled unmodified into the same library (oracle/ref_bed_harness.cpp) -------------------
+def _bed_read(fn, path, cap=4096):
+    import ctypes as C
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_longlong, C.c_char_p, C.c_longlong]
+    ci = np.zeros(cap, np.int32); st = np.zeros(cap, np.int64); en = np.zeros(cap, np.int64)
+    names = C.create_string_buffer(1 << 16); err = C.create_string_buffer(512)
+    n = fn(path.encode(), cap, ci.ctypes.data, st.ctypes.data, en.ctypes.data, names, len(names), err, len(err))
+    threw = n <= -2
+    k = -2 - n if threw else n
+    return dict(status="open" if n == -1 else ("threw" if threw else "ok"), rows=[] if n == -1 else list(zip(ci[:k].tolist(), st[:k].tolist(), en[:k].tolist())),
+                names=names.value.decode("latin-1").split("\n")[:-1] if n != -1 else [], err=err.value.decode("latin-1") if threw else "")
+
+
+HOSTILE_BEDS = {
+    "plain": "chr1\t100\t200\nchr1\t300\t400\nchr2\t5\t50\n",
+    "no_trailing_newline": "chr1\t100\t200\nchr2 7 9",
+    "comments_and_mixed_space": "#track name=x\nchr1   10 \t 20\textra\tfields\t+\n# not a comment: leading space\n#c\nchrM\t0\t1\n",
+    "short_line_repeats_previous_token": "chr1\t100\nchr2\t7\t9\n",
+    "one_token_line_throws": "chr1\t1\t2\nchrX\nchr1\t5\t6\n",
+    "empty_line_throws": "chr1\t1\t2\n\nchr1\t5\t6\n",
+    "whitespace_only_line_throws": "chr1\t1\t2\n   \t \nchr1\t5\t6\n",
+    "trailing_junk_and_signs": "chr1\t100abc\t200.7\nchr1\t+5\t-5\nchr1\t-1\t0x10\n",
+    "not_a_number": "chr1\tabc\t5\n",
+    "beyond_64_bits": "chr1\t1\t99999999999999999999999\nchr1\t2\t3\n",
+    "max_u64_wraps_to_zero": "chr1\t18446744073709551615\t18446744073709551614\n",
+    "comment_tail_only": "chr1\t1\t2\n#end\n#really\n",
+    "crlf": "chr1\t1\t2\r\nchr2\t3\t4\r\n",
+    "vertical_tab_and_formfeed": "chr1\v1\f2\n",
+    "name_reuse_and_order": "b\t1\t2\na\t3\t4\nb\t5\t6\nc\t7\t8\na\t9\t10\n",
+    "hash_inside_line": "chr#1\t1\t2\n chr1\t#3\t4\n",
+    "only_comments": "#a\n#b\n",
+    "empty_file": "",
+}
+
+
+@pytest.mark.parametrize("name", sorted(HOSTILE_BEDS))
+def test_bed_loader_vs_reference_extractBED(ref, name, tmp_path):
+    """The product's BED loader (rnaseqc_amd/csrc/host/gtf.cpp, Annotation::load_bed) against the reference's own
+    extractBED (src/BED.cpp:18-46, compiled unmodified; the loop of src/RNASeQC.cpp:185 around it) on well-formed and
+    hostile files: same rows (+1/+1 coordinates), same contig names in the same first-sight order, and an exception with the
+    same message at the same row."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "rnaseqc_amd", "csrc"), "../lib/librsqc_host.so"])
+    host = C.CDLL(os.path.join(root, "rnaseqc_amd", "lib", "librsqc_host.so"))
+    rl = ref.ref_lib()
+    if not hasattr(rl, "ref_bed_read"):
+        pytest.skip("oracle/_ref/libref_metrics.so predates the BED harness")
+    path = str(tmp_path / (name + ".bed"))
+    with open(path, "wb") as f:
+        f.write(HOSTILE_BEDS[name].encode("latin-1"))
+    want = _bed_read(rl.ref_bed_read, path)
+    got = _bed_read(host.host_bed_read, path)
+    assert got == want, (name, got, want)
+    if name in ("one_token_line_throws", "empty_line_throws", "whitespace_only_line_throws", "not_a_number", "beyond_64_bits"):
+        assert want["status"] == "threw" and want["err"].startswith("Encountered an unknown error while parsing the BED: ")
+    if name == "short_line_repeats_previous_token":
+        assert want["rows"][0] == (0, 101, 101)
+    if name == "trailing_junk_and_signs":
+        assert want["rows"] == [(0, 101, 201), (0, 6, -4), (0, 0, 1)]
+
+
+def test_bed_missing_file_both_report_open_failure(ref, tmp_path):
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = C.CDLL(os.path.join(root, "rnaseqc_amd", "lib", "librsqc_host.so"))
+    rl = ref.ref_lib()
+    if not hasattr(rl, "ref_bed_read"):
+        pytest.skip("oracle/_ref/libref_metrics.so predates the BED harness")
+    missing = str(tmp_path / "nope.bed")
+    assert _bed_read(rl.ref_bed_read, missing)["status"] == "open" and _bed_read(host.host_bed_read, missing)["status"] == "open"
