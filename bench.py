@@ -315,6 +315,7 @@ def main():
 
     vec = None
     order_dep = [None]
+    collective_s = [0.0]
     if reduce_path:
         vec = [torch.as_tensor(v, device="cuda") for v in e.device_vectors()]
 
@@ -330,18 +331,24 @@ def main():
             return None
         if not reduce_path:
             return e.finalize(lazy=True)     # the vectors are on the host (library buffers); Python copies are made on access
-        e.finalize_device()                  # results stay on the device until they are reduced
-        for t in vec:                        # RCCL over xGMI: u64 counts | f64 sums + owner-only statistics | u8 validity flags
-            dist.all_reduce(t)
+        e.finalize_device()                  # results stay on the device until they are reduced (returns with the stream idle)
+        tc = time.perf_counter()
+        # RCCL over xGMI: u64 counts | f64 sums + owner-only statistics | u8 validity flags -- issued together, waited for after
+        # the host-side merge below (the three reductions overlap each other and the two small gathers of the merge)
+        pending = [dist.all_reduce(t, async_op=True) for t in vec]
         # the order-dependent outputs (Read Length; the fragment-size cut-off with --bed): per-batch transfer functions
         # and kept samples of every rank, composed in file order on the host
         order_dep[0] = distributed.merge_order_dependent(e.shard_summary(), dist, torch.device("cuda", local_rank), p.fragment_samples)
+        for w in pending:
+            w.wait()
         torch.cuda.synchronize()
+        collective_s[0] += time.perf_counter() - tc
         return e.refresh_results(lazy=True)
 
     for _ in range(args.warmup):
         step()
     e.reset_timing()
+    collective_s[0] = 0.0
     if dist: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -438,6 +445,7 @@ def main():
                 "realistic_entropy_parity": (e2e.get("realistic_entropy") or {}).get("parity"),
                 "note": "`rnaseqc gtf bam out` on a BAM of the same records: BGZF inflate + BAM parse on the GPU + the hot path + end-of-file stage; details in end_to_end"},
             "end_to_end": e2e,
+            "collective_ms": (1e3 * collective_s[0] / max(args.steps, 1)) if reduce_path else None,   # per step: 3 async all_reduce + 2 gathers + host merge
             "stage_ms": {"classify_k1": k1_ms * len(handles), "classify_launches_per_step": len(handles), "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
                          "slow_path_records": int(tm["slow_records"])},
             "checks": None if res is None else {"gene_reads_sum": int(res.gene_reads.sum()),

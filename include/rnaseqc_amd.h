@@ -453,6 +453,18 @@ RSQC_API int rsqc_reduce_peer(rsqc_ctx *dst, rsqc_ctx *src);
  * end-of-file window).  librccl is bound at run time; without it, or when two contexts share a device
  * (a communicator cannot), the peer-copy path of rsqc_reduce_peer is taken instead.  *used_rccl (may be NULL) says which. */
 RSQC_API int rsqc_reduce_group(rsqc_ctx **ctxs, int n, int *used_rccl);
+/* The same exchange with the communicators made ONCE, outside the caller's timed region: rsqc_group_create brings RCCL up on
+ * the contexts' devices (any time after rsqc_create; ncclCommInitAll over eight GPUs takes longer than the BAM loop of a
+ * 100 M-record file, so the command line calls it beside the GTF parse, before the reference's `Average Reads/Sec` window
+ * opens); rsqc_group_reduce = what rsqc_reduce_group does at end of file, on the group's communicators.  A group whose
+ * communicators cannot be made (no librccl, RSQC_NO_RCCL, two contexts on one device, ncclCommInitAll failing for lack of
+ * P2P or shared memory) is still a valid group: it sums the shards by peer copies, and rsqc_group_info says why.  An RCCL
+ * failure AFTER reductions were issued is fatal (ctxs[0] may hold partial sums); one before takes the peer path.          */
+typedef struct rsqc_group rsqc_group;
+RSQC_API int rsqc_group_create(rsqc_ctx **ctxs, int n, rsqc_group **out);
+RSQC_API int rsqc_group_reduce(rsqc_group *group, int *used_rccl);
+RSQC_API int rsqc_group_info(const rsqc_group *group, int *uses_rccl, double *init_ms, double *last_reduce_ms, const char **note);
+RSQC_API void rsqc_group_destroy(rsqc_group *group);
 /* Re-reads the (reduced) device accumulators into the results struct.         */
 RSQC_API int rsqc_refresh_results(rsqc_ctx *ctx, rsqc_results *out);
 /* Page-locked host memory for the arrays of an rsqc_batch: rsqc_submit then copies by DMA and returns without

@@ -521,6 +521,18 @@ int main(int argc, char **argv) {
             sh.device = devices[g];
             if (g == 0) sh.gpu = gpu;
             else { rsqc_params Pg = P; Pg.device = sh.device; if ((rc = rsqc_create(&Pg, &sh.gpu)) != RSQC_OK) { cerr << "Unable to initialise GPU " << sh.device << ": " << rsqc_strerror(rc) << endl; return 10; } }
+        }
+        // the exchange group of a sharded run: the RCCL communicators come up HERE, on a thread beside the annotation upload and
+        // the feeders' set-up -- not inside the `Average Reads/Sec` window that the end-of-file reduction belongs to
+        rsqc_group *xgroup = nullptr;
+        std::future<int> group_ready;
+        if (shards.size() > 1) {
+            std::vector<rsqc_ctx *> members;
+            for (auto &sh : shards) members.push_back(sh.gpu);
+            group_ready = std::async(std::launch::async, [members, &xgroup]() mutable { return rsqc_group_create(members.data(), (int)members.size(), &xgroup); });
+        }
+        for (size_t g = 0; g < shards.size(); ++g) {
+            Shard &sh = shards[g];
             const uint8_t *owned = nullptr;
             if (shards.size() > 1) {
                 owned_masks[g].assign(ann.contig_names.size(), 0);
@@ -596,6 +608,14 @@ int main(int argc, char **argv) {
         unsigned long long alignmentCount = 0;
         int cur = 0; bool in_flight = false, warned_unsorted = false;
         ShardMerge merged;
+        double group_init_ms = 0.0;
+        if (group_ready.valid()) {                               // (before the window opens)
+            if ((rc = group_ready.get()) != RSQC_OK) { cerr << "Unable to set up the multi-GPU exchange: " << rsqc_strerror(rc) << endl; return 10; }
+            int uses = 0; const char *note = "";
+            rsqc_group_info(xgroup, &uses, &group_init_ms, nullptr, &note);
+            if (o.verbosity > 1) cout << "Exchange group of " << shards.size() << " GPUs ready in " << group_init_ms << " ms ("
+                                      << (uses ? "RCCL communicators" : (std::string("peer copies: ") + note).c_str()) << "), before the BAM loop" << endl;
+        }
         const auto tb0 = std::chrono::steady_clock::now();
         if (shards.size() > 1) {
             // one reader thread per GPU; the decode threads of the process are shared out between them
@@ -621,16 +641,15 @@ int main(int argc, char **argv) {
             // the exchange step: result ranges summed onto the first GPU, order-dependent outputs composed from the summaries
             int used_rccl = 0;
             if (rc == RSQC_OK) {
-                std::vector<rsqc_ctx *> group;
-                for (auto &sh : shards) group.push_back(sh.gpu);
-                rc = rsqc_reduce_group(group.data(), (int)group.size(), &used_rccl);
+                rc = rsqc_group_reduce(xgroup, &used_rccl);
                 if (rc != RSQC_OK) cerr << rsqc_last_error(shards[0].gpu) << endl;
             }
             if (rc == RSQC_OK) { std::string merr; rc = merge_shards(shards, P.fragment_samples, merged, merr); if (rc != RSQC_OK) cerr << merr << endl; }
             if (o.verbosity > 1) {
                 cout << "Alignments processed: " << alignmentCount << " on " << shards.size() << " GPUs (";
                 for (size_t g = 0; g < shards.size(); ++g) cout << (g ? ", " : "") << shards[g].n_records;
-                cout << " records); shards summed by " << (used_rccl ? "RCCL ncclReduce" : "peer copies") << endl;
+                double reduce_ms = 0.0; rsqc_group_info(xgroup, nullptr, nullptr, &reduce_ms, nullptr);
+                cout << " records); shards summed by " << (used_rccl ? "RCCL ncclReduce" : "peer copies") << " in " << reduce_ms << " ms (group set-up " << group_init_ms << " ms, outside the window)" << endl;
             }
         } else if (device_decode) {
             // ---- one GPU, device decode: the host reads the file and frames the BGZF blocks, nothing else
@@ -722,6 +741,7 @@ int main(int argc, char **argv) {
         const auto tr0 = std::chrono::steady_clock::now();
         write_reports(cfg, ann, res, visit);
         const auto tr1 = std::chrono::steady_clock::now();
+        rsqc_group_destroy(xgroup);
         for (auto &sh : shards) rsqc_destroy(sh.gpu);
         if (o.verbosity > 1) {
             // where the wall time outside the reference's `Average Reads/Sec` window goes (extension; the window itself is above)

@@ -667,7 +667,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     UPV(d.ex, hx.ex_rows); UPV(d.gb, hx.gb); UPV(d.contig, hx.contig);
     UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov); UPV(d.ex_pmax, hx.ex_pmax);
     UPV(d.ex_id, c->exon_row_id);
-    UPV(d.ei, hx.ei);
+    UPV(d.ei, hx.ei); UPV(d.ei_coarse, hx.ei_coarse);
     if ((rc = dev_alloc(c, c->d_ei_rank, ((size_t)hx.rank_words + 1) * sizeof(EiRank), true))) return rc;
     d.ei_rank = (const EiRank *)c->d_ei_rank.p;
     for (int k = 0; k < nc; ++k)                  // (stream order: after the upload of the entries)
@@ -1256,59 +1256,135 @@ RcclApi &rccl_api() {
 }
 }  // namespace
 
-int rsqc_reduce_group(rsqc_ctx **ctxs, int n, int *used_rccl) {
-    if (used_rccl) *used_rccl = 0;
-    if (!ctxs || n < 1 || !ctxs[0]) return RSQC_ERR_ARG;
-    rsqc_ctx *root = ctxs[0];
-    for (int i = 0; i < n; ++i) {
-        rsqc_ctx *c = ctxs[i];
-        if (!c || !c->have_ann || !c->finalized) return RSQC_ERR_ARG;
-        if (c->arena_bytes != root->arena_bytes || c->n_genes != root->n_genes || c->n_exons != root->n_exons)
-            return fail(root, RSQC_ERR_ARG, "rsqc_reduce_group: the contexts hold different annotations");
-    }
+// A group = the contexts of one sharded run + (when RCCL is usable on their devices) one communicator per context, made
+// ONCE: ncclCommInitAll over eight GPUs takes longer than the whole BAM loop of a 100 M-record file, so the command line
+// brings the group up beside the GTF parse, outside the reference's `Average Reads/Sec` window (src/RNASeQC.cpp:385-394),
+// and the end-of-file exchange only issues the reductions.
+struct rsqc_group {
+    std::vector<rsqc_ctx *> ctxs;
+    std::vector<ncclComm_t> comms;       // empty: the peer-copy path
+    std::string note;                    // why RCCL is not in use (for -vv)
+    double init_ms = 0.0, last_reduce_ms = 0.0;
+};
+
+int rsqc_group_create(rsqc_ctx **ctxs, int n, rsqc_group **out) {
+    if (!out) return RSQC_ERR_ARG;
+    *out = nullptr;
+    if (!ctxs || n < 1) return RSQC_ERR_ARG;
+    for (int i = 0; i < n; ++i) if (!ctxs[i]) return RSQC_ERR_ARG;
+    rsqc_group *g = new rsqc_group();
+    g->ctxs.assign(ctxs, ctxs + n);
+    const auto t0 = std::chrono::steady_clock::now();
     bool distinct = true;
     for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
     RcclApi &R = rccl_api();
-    if (R.ok && distinct) {
+    if (!R.ok) g->note = getenv("RSQC_NO_RCCL") ? "RSQC_NO_RCCL is set" : "librccl not found";
+    else if (!distinct) g->note = "two contexts share a device";
+    else {
         std::vector<int> devs((size_t)n);
         for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
-        std::vector<ncclComm_t> comms((size_t)n, nullptr);
-        ncclResult_t r = R.CommInitAll(comms.data(), n, devs.data());
-        if (r != ncclSuccess) return fail(root, RSQC_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
+        g->comms.assign((size_t)n, nullptr);
+        const ncclResult_t r = R.CommInitAll(g->comms.data(), n, devs.data());
+        if (r != ncclSuccess) {
+            // no P2P / no shared memory / a mismatched RCCL: not an error of the run -- the peer-copy path sums the shards
+            g->note = std::string("ncclCommInitAll: ") + R.GetErrorString(r);
+            for (ncclComm_t c : g->comms) if (c) (void)R.CommDestroy(c);
+            g->comms.clear();
+        }
+        (void)hipSetDevice(ctxs[0]->device);
+    }
+    g->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = g;
+    return RSQC_OK;
+}
+
+void rsqc_group_destroy(rsqc_group *g) {
+    if (!g) return;
+    if (!g->comms.empty()) { RcclApi &R = rccl_api(); for (ncclComm_t c : g->comms) if (c) (void)R.CommDestroy(c); }
+    delete g;
+}
+
+int rsqc_group_info(const rsqc_group *g, int *uses_rccl, double *init_ms, double *last_reduce_ms, const char **note) {
+    if (!g) return RSQC_ERR_ARG;
+    if (uses_rccl) *uses_rccl = g->comms.empty() ? 0 : 1;
+    if (init_ms) *init_ms = g->init_ms;
+    if (last_reduce_ms) *last_reduce_ms = g->last_reduce_ms;
+    if (note) *note = g->note.c_str();
+    return RSQC_OK;
+}
+
+static int shard_error_flags(rsqc_ctx *root, const std::vector<rsqc_ctx *> &ctxs) {
+    for (size_t i = 1; i < ctxs.size(); ++i) {      // the device error flags travel too: a shard's failure is the run's failure
+        int err = 0;
+        HIP_TRY(ctxs[i], hipSetDevice(ctxs[i]->device));
+        HIP_TRY(ctxs[i], hipMemcpy(&err, ctxs[i]->acc.error, sizeof(int), hipMemcpyDeviceToHost));
+        if (err) { root->sticky = err; return fail(root, err, "a shard reported a device-side error"); }
+    }
+    HIP_TRY(root, hipSetDevice(root->device));
+    return RSQC_OK;
+}
+
+int rsqc_group_reduce(rsqc_group *g, int *used_rccl) {
+    if (used_rccl) *used_rccl = 0;
+    if (!g || g->ctxs.empty()) return RSQC_ERR_ARG;
+    const int n = (int)g->ctxs.size();
+    rsqc_ctx *root = g->ctxs[0];
+    for (int i = 0; i < n; ++i) {
+        rsqc_ctx *c = g->ctxs[(size_t)i];
+        if (!c->have_ann || !c->finalized) return RSQC_ERR_ARG;
+        if (c->arena_bytes != root->arena_bytes || c->n_genes != root->n_genes || c->n_exons != root->n_exons)
+            return fail(root, RSQC_ERR_ARG, "rsqc_group_reduce: the contexts hold different annotations");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto done = [&](int rc) { g->last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); return rc; };
+    if (!g->comms.empty()) {
+        RcclApi &R = rccl_api();
         // the three reducible ranges of the arena (rsqc_device_vectors): u64 counts | f64 sums + owner-only statistics | u8 flags
         const size_t n_u64 = (root->off_exon - root->off_u64) / 8, n_f64 = (root->off_gvalid - root->off_exon) / 8, n_u8 = root->off_ehit - root->off_gvalid;
-        r = R.GroupStart();
-        for (int i = 0; i < n && r == ncclSuccess; ++i) {
-            rsqc_ctx *c = ctxs[i];
-            char *A = (char *)c->d_arena.p;
-            (void)hipSetDevice(c->device);
-            r = R.Reduce(A + c->off_u64, A + c->off_u64, n_u64, ncclUint64, ncclSum, 0, comms[(size_t)i], c->stream);
-            if (r == ncclSuccess) r = R.Reduce(A + c->off_exon, A + c->off_exon, n_f64, ncclFloat64, ncclSum, 0, comms[(size_t)i], c->stream);
-            if (r == ncclSuccess) r = R.Reduce(A + c->off_gvalid, A + c->off_gvalid, n_u8, ncclUint8, ncclSum, 0, comms[(size_t)i], c->stream);
+        ncclResult_t r = R.GroupStart();
+        bool issued = false;
+        if (r == ncclSuccess) {
+            for (int i = 0; i < n && r == ncclSuccess; ++i) {
+                rsqc_ctx *c = g->ctxs[(size_t)i];
+                char *A = (char *)c->d_arena.p;
+                (void)hipSetDevice(c->device);
+                r = R.Reduce(A + c->off_u64, A + c->off_u64, n_u64, ncclUint64, ncclSum, 0, g->comms[(size_t)i], c->stream);
+                if (r == ncclSuccess) r = R.Reduce(A + c->off_exon, A + c->off_exon, n_f64, ncclFloat64, ncclSum, 0, g->comms[(size_t)i], c->stream);
+                if (r == ncclSuccess) r = R.Reduce(A + c->off_gvalid, A + c->off_gvalid, n_u8, ncclUint8, ncclSum, 0, g->comms[(size_t)i], c->stream);
+                issued = true;
+            }
+            const ncclResult_t re = R.GroupEnd();
+            if (r == ncclSuccess) r = re;
         }
-        const ncclResult_t re = R.GroupEnd();
-        if (r == ncclSuccess) r = re;
-        int rc = RSQC_OK;
-        for (int i = 0; i < n; ++i) {
-            rsqc_ctx *c = ctxs[i];
-            (void)hipSetDevice(c->device);
-            if (hipStreamSynchronize(c->stream) != hipSuccess && rc == RSQC_OK) rc = fail(root, RSQC_ERR_HIP, "hipStreamSynchronize after the RCCL reduction failed");
+        if (r != ncclSuccess) {
+            // a reduction that was (partly) enqueued may have changed ctxs[0]'s ranges, and waiting on a half-issued group can
+            // hang: nothing is synchronised, the run ends here.  A failure before anything was issued takes the peer path.
+            if (issued) return done(fail(root, RSQC_ERR_HIP, std::string("RCCL reduction failed after it was issued: ") + R.GetErrorString(r)));
+            g->note = std::string("ncclGroupStart: ") + R.GetErrorString(r);
+        } else {
+            for (int i = 0; i < n; ++i) {
+                rsqc_ctx *c = g->ctxs[(size_t)i];
+                (void)hipSetDevice(c->device);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(root, RSQC_ERR_HIP, "hipStreamSynchronize after the RCCL reduction failed"));
+            }
+            const int rc = shard_error_flags(root, g->ctxs);
+            if (rc == RSQC_OK && used_rccl) *used_rccl = 1;
+            return done(rc);
         }
-        for (int i = 0; i < n; ++i) if (comms[(size_t)i]) (void)R.CommDestroy(comms[(size_t)i]);
-        if (r != ncclSuccess) return fail(root, RSQC_ERR_HIP, std::string("ncclReduce: ") + R.GetErrorString(r));
-        if (rc) return rc;
-        for (int i = 1; i < n; ++i) {               // the device error flags travel too: a shard's failure is the run's failure
-            int err = 0;
-            HIP_TRY(ctxs[i], hipSetDevice(ctxs[i]->device));
-            HIP_TRY(ctxs[i], hipMemcpy(&err, ctxs[i]->acc.error, sizeof(int), hipMemcpyDeviceToHost));
-            if (err) { root->sticky = err; return fail(root, err, "a shard reported a device-side error"); }
-        }
-        HIP_TRY(root, hipSetDevice(root->device));
-        if (used_rccl) *used_rccl = 1;
-        return RSQC_OK;
     }
-    for (int i = 1; i < n; ++i) { const int rc = rsqc_reduce_peer(root, ctxs[i]); if (rc != RSQC_OK) return rc; }
-    return RSQC_OK;
+    for (int i = 1; i < n; ++i) { const int rc = rsqc_reduce_peer(root, g->ctxs[(size_t)i]); if (rc != RSQC_OK) return done(rc); }
+    return done(RSQC_OK);
+}
+
+// create + reduce + destroy in one call (a caller that does not mind the bring-up inside its timed region)
+int rsqc_reduce_group(rsqc_ctx **ctxs, int n, int *used_rccl) {
+    if (used_rccl) *used_rccl = 0;
+    rsqc_group *g = nullptr;
+    int rc = rsqc_group_create(ctxs, n, &g);
+    if (rc != RSQC_OK) return rc;
+    rc = rsqc_group_reduce(g, used_rccl);
+    rsqc_group_destroy(g);
+    return rc;
 }
 
 int rsqc_refresh_results(rsqc_ctx *c, rsqc_results *out) {

@@ -23,6 +23,13 @@ struct HostIndex {
     std::vector<EiEntry> ei;                          // elementary intervals (rsqc_read.h)
     std::vector<uint32_t> ei_range;                   // [n_contigs + 1]
     uint64_t rank_words = 0;                          // words of the rank table over all contigs
+    // Coarse table over the same positions, one word per 512 (= 8 rank words; every contig's part of the rank table starts at a
+    // multiple of 8 words, so the two tables share ContigInfo::rk_base): 0, or 1 + the index of the interval that covers ALL of
+    // the 1024 positions [b * 512, (b + 2) * 512) -- no breakpoint in there.  A read in the empty stretches of the genome
+    // (intergenic, deep intronic: every sixth record of an RNA-seq file) then needs no rank word at all; each of them used to
+    // pull a 64-byte sector of the 775 MB rank table from HBM for one look-up (2.5 GB per 102 M records, profiles/k1_traffic.json
+    // of round 3), and every tile waited for the slowest of those misses.  24 MB for the human contig lengths.
+    std::vector<uint32_t> ei_coarse;
     std::vector<GeneRow> gr_rows;                     // --legacy tables (LegacyTables)
     std::vector<uint32_t> ex_ord;
     std::vector<ContigInfo> contig;
@@ -190,6 +197,7 @@ struct HostIndex {
                 ev.push_back(Ev{std::max<int64_t>(0, a->exon_row_start[i]), 100, i});
                 ev.push_back(Ev{(int64_t)a->exon_row_end[i] + 1, -100, i});
             }
+            rank_words = (rank_words + 7ull) & ~7ull;               // (ei_coarse: 8 rank words per entry, see above)
             contig[(size_t)k].rk_base = (uint32_t)rank_words; contig[(size_t)k].rk_words = 0;
             if (ev.empty()) { ei_range[(size_t)k + 1] = (uint32_t)ei.size(); continue; }
             std::stable_sort(ev.begin(), ev.end(), [](const Ev &x, const Ev &y) { return x.pos < y.pos; });
@@ -241,6 +249,21 @@ struct HostIndex {
             contig[(size_t)k].rk_words = (uint32_t)words;
             rank_words += words;
             if (rank_words >= (1ull << 28) || ei.size() >= (1ull << 27)) { err = "annotation too large for the interval index"; return RSQC_ERR_CAPACITY; }
+        }
+        ei_coarse.assign((size_t)((rank_words + 7ull) >> 3) + 2, 0u);
+        for (int k = 0; k < nc; ++k) {
+            const ContigInfo &ci = contig[(size_t)k];
+            if (ci.rk_words == 0) continue;
+            const uint32_t nb = (ci.rk_words + 7u) >> 3;                       // blocks of 512 positions that hold the contig's breakpoints
+            std::vector<uint32_t> first((size_t)nb + 1);                       // index of the first breakpoint at or after b * 512
+            uint32_t j = ei_range[(size_t)k];
+            for (uint32_t b = 0; b <= nb; ++b) {
+                while (j < ei_range[(size_t)k + 1] && ((uint64_t)(uint32_t)ei[j].pos >> 9) < b) ++j;
+                first[b] = j;
+            }
+            // (block 0 holds the contig's first interval at position 0 and the last block its last breakpoint: neither is empty)
+            for (uint32_t b = 0; b + 2 <= nb; ++b)
+                if (first[b + 2] == first[b] && first[b] > ei_range[(size_t)k]) ei_coarse[(size_t)(ci.rk_base >> 3) + b] = first[b];   // = 1 + (first[b] - 1)
         }
         if (ei.empty()) ei.push_back(EiEntry{0, 0u, EI_NONE, EI_NONE, 0u, 0u, 0u, 0u});    // lanes without a look-up read entry 0
         gene_flags.assign((size_t)std::max(L, 1), 0);

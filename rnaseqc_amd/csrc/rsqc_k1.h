@@ -29,8 +29,14 @@ namespace rsqc {
 // in flight, the record words staged for the next tile and the previous tile's atomics included.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define K1E_LANDED(x) asm volatile("" : "+v"(x))
+#ifndef K1E_NO_PIN
+#define K1E_PIN(x) asm volatile("" : "+s"(x))            /* a wave-uniform value the compiler may not re-derive: it stays in SGPRs */
+#else
+#define K1E_PIN(x) (void)(x)                             /* (A/B build) */
+#endif
 #else
 #define K1E_LANDED(x) (void)(x)
+#define K1E_PIN(x) (void)(x)
 #endif
 
 // Everything the two kernels are given, as ONE by-value struct: its layout is the kernel-argument segment's.  The hot loop
@@ -51,6 +57,7 @@ __device__ __forceinline__ const K1Args *k1e_lazy_args() {
 }
 #else
 static const K1Args *g_k1e_args = nullptr;       // (host emulation: set by the harness)
+static unsigned long long g_k1e_coarse_hits = 0;
 static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
 
@@ -139,7 +146,7 @@ struct K1eTables {
 
 struct K1eShared {
     K1eTables T;
-    uint4 q1[K1E_WAVES][K1E_QCAP];               // one block:  bs, len, record index, flhq
+    uint4 q1[K1E_WAVES][K1E_QCAP];               // one block:  bs, len (16 bits) | flag bits 0-11 << 16 | high quality << 28, record index, coarse-table answer (0 = none)
     uint4 q2[K1E_WAVES][K1E_QCAP];               // two blocks: bs0, len0, bs1, len1
     uint2 q2x[K1E_WAVES][K1E_QCAP];              //             record index, flhq
     uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
@@ -150,9 +157,11 @@ struct K1eShared {
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
-__device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], bool notdup,
+__device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
                                            uint64_t qhash, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
     const int l = lane_id();
+    typedef WaveSink WS;
+    const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
     double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
     if (NB > 1) {
         uint32_t aligned = 0;
@@ -162,34 +171,35 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
     }
 #pragma unroll
     for (int k = 0; k < 2 * NB; ++k) {
-        const bool has = (eo.cmask >> k) & 1u;
-        if (__ballot(has) == 0ull) continue;
+        const uint64_t has = WS::prim(((eo.cmask >> k) & 1u) != 0).m;
+        if (has == 0ull) continue;
         const uint32_t ln = len[k >> 1];
-        const bool hv = has && ln > 0;
+        const uint64_t hvm = has & WS::prim(ln > 0).m;
+        const bool hv = WS::lane(LaneMask{hvm});
         // The input is coordinate-sorted, so the lanes of a tile that hit one exon / gene sit next to each other: the first lane
         // of a run of equal keys adds for the whole run (64 LDS atomics on one address take 64 passes of the LDS, one takes one).
         // One-block records add exactly 1 each, so their runs need no sum; fractions of longer records go lane by lane.
         if (NB == 1) {
-            const Run r = make_run(hv, eo.eid[k]);
+            const Run r = make_run(hvm, eo.eid[k]);
             if (r.head && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)r.count);
             // a one-block record that commits slot 0 is counted to that exon's gene (hit[0], see exon_metrics_ei: the first gene of
             // the set is the gene of the block's first containing exon): the exon's run serves the gene counters too
             if (k == 0) {
-                const uint64_t nd = __ballot(hv && notdup);
+                const uint64_t nd = hvm & notdup;
                 if (r.head && !(K1E_ABL & 2)) T.gene_add(eo.hit[0], r.count, (uint32_t)__popcll(nd & r.mask));
             }
         } else if (hv && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)ln * inv_aligned);
         const uint32_t base = hv ? eo.cidx[k] : 0u;
         if (!(K1E_ABL & 4)) {
-            cov_add_merged(cov_diff, hv, base, 1u);
-            cov_add_merged(cov_diff, hv, base + ln, 0xFFFFFFFFu);
+            cov_add_merged(cov_diff, hvm, base, 1u);
+            cov_add_merged(cov_diff, hvm, base + ln, 0xFFFFFFFFu);
         }
     }
 #pragma unroll
     for (int k = 0; k < FAST_SET; ++k) {
-        const bool has = eo.n_hit > k;
-        const uint64_t m = __ballot(has);
+        const uint64_t m = WS::prim(eo.n_hit > k).m;
         if (m == 0ull) break;
+        const bool has = WS::lane(LaneMask{m});
         const uint32_t g = eo.hit[k];
         if (!(K1E_ABL & 8)) {
             const int lead = __ffsll((unsigned long long)m) - 1;
@@ -203,8 +213,8 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             }
         }
         if (NB > 1 || k > 0) {
-            const Run r = make_run(has, g);
-            const uint64_t nd = __ballot(has && notdup);
+            const Run r = make_run(m, g);
+            const uint64_t nd = m & notdup;
             if (r.head && !(K1E_ABL & 2)) T.gene_add(g, r.count, (uint32_t)__popcll(nd & r.mask));
         }
     }
@@ -230,23 +240,27 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
     const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
-    int32_t bs[NB]; uint32_t len[NB]; uint32_t idx, flhq;
+    int32_t bs[NB]; uint32_t len[NB]; uint32_t idx, flhq, pre0 = 0u;
     if (NB == 1) {
         const uint4 it = S.q1[wave][slot];
-        bs[0] = (int32_t)it.x; len[0] = it.y; idx = it.z; flhq = it.w;
+        bs[0] = (int32_t)it.x; len[0] = it.y & 0xFFFFu; idx = it.z; pre0 = it.w;
+        flhq = ((it.y >> 16) & 0xFFFu) | ((it.y >> 28) << 16);              // flag bits 0-11, K1E_HQ
     } else {
         const uint4 it = S.q2[wave][slot]; const uint2 ix = S.q2x[wave][slot];
         bs[0] = (int32_t)it.x; len[0] = it.y; bs[NB - 1] = (int32_t)it.z; len[NB - 1] = it.w; idx = ix.x; flhq = ix.y;
     }
-    if (!on) { idx = 0u; flhq = 0u; }
+    if (!on) { idx = 0u; flhq = 0u; pre0 = 0u; }
+#if defined(RSQC_WAVE_EMU)
+    if (pre0) ++g_k1e_coarse_hits;                 // (test harness: records answered by the coarse table)
+#endif
     // the name hash is only needed by records that are counted to a gene: it comes back from the record array (the lines
     // were streamed through this CU's caches a few tiles ago) instead of riding through the queue
     const uint2 qh = ld32(reinterpret_cast<const uint2 *>(aux), idx * 2u);
     WaveSink cnt;
     EiOut eo; bool over = false;
-    exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on);
+    exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, !(flhq & RSQC_FDUP), (uint64_t)qh.x | ((uint64_t)qh.y << 32), my_pair_gene, my_pair_hash, chunk_cap);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), my_pair_gene, my_pair_hash, chunk_cap);
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -306,48 +320,57 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         EiOut eo; bool over = false;
         exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, !(fl & RSQC_FDUP), qhash, my_pair_gene, my_pair_hash, chunk_cap);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, my_pair_gene, my_pair_hash, chunk_cap);
     } else {
         EiOut eo; bool over = false;
         exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, !(fl & RSQC_FDUP), qhash, my_pair_gene, my_pair_hash, chunk_cap);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, my_pair_gene, my_pair_hash, chunk_cap);
     }
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
 // ---- CIGAR, first pass (extractBlocks + bam_endpos, src/Expression.cpp:26-67): operations 0-3 with the first two
 // blocks captured, operations 4-7 for the reference length only; operations past the eighth come from memory ----------
-struct Walk2 { uint32_t ref_len, nb; bool bad; int32_t bs0, bs1; uint32_t len0, len1; };
+struct Walk2 { uint32_t ref_len, nb; uint32_t bad /* non-zero: an operation code above 8 among the first four */; int32_t bs0, bs1; uint32_t len0, len1; };
+// Written on integers and select masks, one vector instruction per line where it matters (round 3's form went through
+// per-lane bools: v_cmp / v_cndmask pairs with wait states between them, about 25 instructions per operation):
+//   class of an operation = a bit of a 16-bit table indexed by the operation word itself (bfe_u / bfe_m, rsqc_wave.h);
+//   the running reference position doubles as the start of the next block;
+//   the first two blocks are picked by walking the four operations BACKWARDS with v_bfi selects (the last write wins).
+constexpr uint32_t K1E_TAB_BLOCK = CIG_BLOCK_SET | (CIG_BLOCK_SET << 16), K1E_TAB_REF = CIG_REF_SET | (CIG_REF_SET << 16), K1E_TAB_BAD = 0xFE00FE00u;
 __device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t (&c)[8], const uint32_t *cigar, Walk2 &w) {
-    w.ref_len = 0; w.nb = 0; w.bad = false; w.bs0 = 0; w.bs1 = 0; w.len0 = 0; w.len1 = 0;
+    uint32_t ck[4], len[4], blk[4], start[4];
+    uint32_t cur = (uint32_t)pos + 1u;                                     // 1-based position of the next reference base
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t ck = (uint32_t)k < n ? c[k] : 5u;               // past the end: a hard clip of length 0 (no block, no reference, legal)
-        const uint32_t op = ck & 0xf, len = ck >> 4;
-        const bool blk = (CIG_BLOCK_SET >> op) & 1u, ref = (CIG_REF_SET >> op) & 1u;
-        w.bad = w.bad || op > 8;                                       // Expression.cpp:61-63
-        const int32_t start = pos + 1 + (int32_t)w.ref_len;
-        if (k == 0) { w.bs0 = start; w.len0 = blk ? len : 0u; }
-        else {
-            const bool is0 = blk && w.nb == 0, is1 = blk && w.nb == 1;
-            w.bs0 = is0 ? start : w.bs0; w.len0 = is0 ? len : w.len0;
-            w.bs1 = is1 ? start : w.bs1; w.len1 = is1 ? len : w.len1;
-        }
-        w.nb += blk ? 1u : 0u;
-        w.ref_len += ref ? len : 0u;
+        ck[k] = (uint32_t)k < n ? c[k] : 5u;                               // past the end: a hard clip of length 0 (no block, no reference, legal)
+        len[k] = ck[k] >> 4;
+        blk[k] = bfe_m(K1E_TAB_BLOCK, ck[k]);
+        start[k] = cur;
+        cur += len[k] & bfe_m(K1E_TAB_REF, ck[k]);
     }
-    if (__ballot(n > 4) != 0ull) {
+    w.bad = bfe_u(K1E_TAB_BAD, ck[0], 1u) | bfe_u(K1E_TAB_BAD, ck[1], 1u) | bfe_u(K1E_TAB_BAD, ck[2], 1u) | bfe_u(K1E_TAB_BAD, ck[3], 1u);   // Expression.cpp:61-63
+    w.nb = 0u - (blk[0] + blk[1] + blk[2] + blk[3]);
+    uint32_t b0 = start[3] & blk[3], l0 = len[3] & blk[3], b1 = 0u, l1 = 0u;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+        b1 = bfi(blk[k], b0, b1); l1 = bfi(blk[k], l0, l1);
+        b0 = bfi(blk[k], start[k], b0); l0 = bfi(blk[k], len[k], l0);
+    }
+    w.bs0 = (int32_t)b0; w.len0 = l0; w.bs1 = (int32_t)b1; w.len1 = l1;
+    if (__ballot(n > 4) != 0ull) {                                         // operations 4-7: the reference length only
 #pragma unroll
         for (int k = 4; k < 8; ++k) {
-            const uint32_t ck = (uint32_t)k < n ? c[k] : 5u;
-            w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u;
+            const uint32_t cx = (uint32_t)k < n ? c[k] : 5u;
+            cur += (cx >> 4) & bfe_m(K1E_TAB_REF, cx);
         }
         if (__ballot(n > 8) != 0ull) {
-            for (uint32_t i = 8; i < n; ++i) { const uint32_t ck = cigar[i]; w.ref_len += ((CIG_REF_SET >> (ck & 0xf)) & 1u) ? ck >> 4 : 0u; }
-            K1E_LANDED(w.ref_len);
+            for (uint32_t i = 8; i < n; ++i) { const uint32_t cx = cigar[i]; cur += (cx >> 4) & bfe_m(K1E_TAB_REF, cx); }
+            K1E_LANDED(cur);
         }
     }
+    w.ref_len = cur - ((uint32_t)pos + 1u);
 }
 
 #ifndef K1E_MINW
@@ -356,7 +379,15 @@ __device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t
 __global__ void __launch_bounds__(RSQC_K1_THREADS, K1E_MINW)
 classify_ei_kernel(K1Args A) {
     __shared__ K1eShared S;
-    const DevAnnotation &a = A.a; const DevParams &p = A.p; const DevBatch &b = A.b; const DevAccum &acc = A.acc;
+    const DevAnnotation &a = A.a; const DevBatch &b = A.b; const DevAccum &acc = A.acc;
+    // The run parameters and the CIGAR pool's address are used by every tile.  Left in the kernel-argument segment the compiler
+    // re-loads them where it needs them (s_load + s_waitcnt lgkmcnt(0): five such stalls per tile in round 3's listing, and
+    // lgkmcnt(0) also waits for every LDS operation in flight); as opaque scalars they live in SGPRs for the whole kernel.
+    DevParams p = A.p;
+    K1E_PIN(p.mapq_threshold); K1E_PIN(p.base_mismatch); K1E_PIN(p.chimeric_distance); K1E_PIN(p.stranded); K1E_PIN(p.unpaired);
+    K1E_PIN(p.exclude_chimeric); K1E_PIN(p.n_filter_tags);
+    const uint32_t *cigar_pool = b.cigar; K1E_PIN(cigar_pool);
+    uint32_t *tile_span = acc.tile_span; K1E_PIN(tile_span);
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     S.T.init(0u);
@@ -389,40 +420,44 @@ classify_ei_kernel(K1Args A) {
     // the range in PIECES of K1E_PIECE records from an LDS counter.  With one fixed quarter per wave the four waves finished
     // up to 100 us apart (dense and sparse stretches cost differently) and waited for each other at the final barrier:
     // 10.8 % of the kernel (profiles/r3_k1_sections_v2.txt).  A piece is still a contiguous, coordinate-sorted run.
-    const uint64_t total_waves = (uint64_t)gridDim.x * K1E_WAVES;
-    const uint64_t per_wave = (((b.n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
-    const uint64_t wg_beg = (uint64_t)blockIdx.x * K1E_WAVES * per_wave;
-    const uint64_t wg_end = wg_beg + K1E_WAVES * per_wave < b.n ? wg_beg + K1E_WAVES * per_wave : b.n;
-    constexpr uint64_t NONE = ~0ull;
-    auto take_piece = [&]() -> uint64_t {                 // first record of the next unclaimed piece, NONE when the range is used up
+    // record indices are 32-bit inside the kernel (a batch holds fewer than 2^31 records, rsqc_api.cpp: run_batch): 64-bit
+    // indices cost a register pair, a v_cmp_*_u64 and a v_lshl_add_u64 wherever a lane touches one
+    const uint32_t n_rec = (uint32_t)b.n;
+    const uint32_t total_waves = gridDim.x * K1E_WAVES;
+    const uint32_t per_wave = (((n_rec + total_waves - 1u) / total_waves) + 63u) & ~63u;
+    const uint64_t wg_beg64 = (uint64_t)blockIdx.x * K1E_WAVES * per_wave;
+    const uint32_t wg_beg = wg_beg64 < (uint64_t)n_rec ? (uint32_t)wg_beg64 : n_rec;
+    const uint32_t wg_end = wg_beg64 + (uint64_t)K1E_WAVES * per_wave < (uint64_t)n_rec ? (uint32_t)(wg_beg64 + (uint64_t)K1E_WAVES * per_wave) : n_rec;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    auto take_piece = [&]() -> uint32_t {                 // first record of the next unclaimed piece, NONE when the range is used up
         uint32_t c = 0;
         if (l == 0) c = atomicAdd(&S.T.piece, 1u);
         c = lane_value(c, 0);
-        const uint64_t at = wg_beg + (uint64_t)c * K1E_PIECE;
-        return at < wg_end ? at : NONE;
+        const uint64_t at = (uint64_t)wg_beg + (uint64_t)c * K1E_PIECE;
+        return at < (uint64_t)wg_end ? (uint32_t)at : NONE;
     };
-    auto tile_after = [&](uint64_t t) -> uint64_t {       // the tile this wave works on after tile t
+    auto tile_after = [&](uint32_t t) -> uint32_t {       // the tile this wave works on after tile t
         if (t == NONE) return NONE;
-        const uint64_t nx = t + 64ull;
-        if (nx < wg_end && ((nx - wg_beg) % K1E_PIECE) != 0ull) return nx;
+        const uint32_t nx = t + 64u;
+        if (nx < wg_end && ((nx - wg_beg) % (uint32_t)K1E_PIECE) != 0u) return nx;
         return take_piece();
     };
-    uint64_t w0 = wg_beg < wg_end ? take_piece() : NONE, w1 = tile_after(w0), w2 = tile_after(w1);
-    const uint64_t wbeg = w0 == NONE ? b.n : w0, wend = wg_end;
+    uint32_t w0 = wg_beg < wg_end ? take_piece() : NONE, w1 = tile_after(w0), w2 = tile_after(w1);
+    const uint32_t wbeg = w0 == NONE ? n_rec : w0, wend = wg_end;
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
     uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
+    uint32_t seg = wbeg < n_rec ? find_segment(b, wbeg) : 0u;
     int32_t u_tid = -1;
     ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t seg_next = ~0ull;                            // first record of the next segment: kept in scalar registers, so that the
+    uint32_t seg_next = NONE;                             // first record of the next segment: kept in scalar registers, so that the
                                                           // per-tile boundary tests are compares (a scalar load per tile also waits,
                                                           // through the shared lgkmcnt, for every LDS operation in flight)
     auto load_contig = [&]() {
         u_tid = b.n_seg ? b.seg_tid[seg] : -1;
         if (u_tid >= 0 && u_tid < a.n_contigs) u_ci = a.contig[u_tid];
         else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
-        seg_next = seg + 1 < b.n_seg ? b.seg_start[seg + 1] : ~0ull;
+        seg_next = seg + 1 < b.n_seg ? (uint32_t)b.seg_start[seg + 1] : NONE;
     };
     load_contig();
     uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0, h3 = 0, c3 = 0;   // queue heads and fills (wave-uniform)
@@ -438,11 +473,13 @@ classify_ei_kernel(K1Args A) {
     int4 cur_cv = zero4, cur_av = zero4;
     uint32_t cg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nx_co = 0;                                                   // CIGAR offset of this lane's record of the NEXT tile
+    uint32_t cur_cz = 0;                                                  // coarse-table word of this lane's record (DevAnnotation::ei_coarse): 0, or 1 + the
+                                                                          // interval that covers the 1024 breakpoint-free positions around its start
     const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
     const uint32_t *const core1 = reinterpret_cast<const uint32_t *>(b.core);
-    if (w0 != NONE && w0 + (uint64_t)l < wend) { cur_cv = ld32(core4 + w0, (uint32_t)l); cur_av = ld32(aux4 + w0, (uint32_t)l); }
-    if (w1 != NONE && w1 + (uint64_t)l < wend) nx_co = ld32(core1 + 4 * w1, 4u * (uint32_t)l + 3u);
-    k1e_load_cigar8(b.cigar, (uint32_t)cur_cv.w, cg);
+    if (w0 != NONE && w0 + (uint32_t)l < wend) { cur_cv = ld32(core4 + w0, (uint32_t)l); cur_av = ld32(aux4 + w0, (uint32_t)l); }
+    if (w1 != NONE && w1 + (uint32_t)l < wend) nx_co = ld32(core1 + 4 * (size_t)w1, 4u * (uint32_t)l + 3u);
+    k1e_load_cigar8(cigar_pool, (uint32_t)cur_cv.w, cg);
     // (the wait of the first tile's words sits here, not in the loop: the compiler places a wait where ANY path into an
     //  instruction has the load pending, and a wait inside the loop is executed by every tile)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -451,57 +488,57 @@ classify_ei_kernel(K1Args A) {
 #endif
     for (; w0 != NONE; w0 = w1, w1 = w2, w2 = tile_after(w2)) {
         RSQC_MARK(0);
-        const uint64_t i = w0 + (uint64_t)l;
+        const uint32_t i = w0 + (uint32_t)l;
         const bool valid = i < wend;
         if (seg_next <= w0) {                               // (the queues were emptied by the tile before the boundary)
             while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;
             load_contig();
         }
-        const bool mixed = seg_next < w0 + 64ull;           // a contig boundary inside the tile
+        const bool mixed = seg_next != NONE && seg_next - w0 < 64u;           // a contig boundary inside the tile
         // ---- the next tile's words start their trip now -----------------------------------------------------------------
         int4 n_cv = zero4, n_av = zero4; uint32_t n_cg[8]; uint32_t n_co = 0;
-        if (w1 != NONE && w1 + (uint64_t)l < wend) { n_cv = ld32(core4 + w1, (uint32_t)l); n_av = ld32(aux4 + w1, (uint32_t)l); }
-        k1e_load_cigar8(b.cigar, nx_co, n_cg);
-        if (w2 != NONE && w2 + (uint64_t)l < wend) n_co = ld32(core1 + 4 * w2, 4u * (uint32_t)l + 3u);
+        if (w1 != NONE && w1 + (uint32_t)l < wend) { n_cv = ld32(core4 + w1, (uint32_t)l); n_av = ld32(aux4 + w1, (uint32_t)l); }
+        k1e_load_cigar8(cigar_pool, nx_co, n_cg);
+        if (w2 != NONE && w2 + (uint32_t)l < wend) n_co = ld32(core1 + 4 * (size_t)w2, 4u * (uint32_t)l + 3u);
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
         RSQC_MARK(1);
-        Record r;
+        Record r; uint32_t cur_cigar_off;
         {
             const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
-            r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
-            r.cigar = b.cigar + (uint32_t)cv.w;
+            r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z; cur_cigar_off = (uint32_t)cv.w;
+            r.cigar = cigar_pool + (uint32_t)cv.w;
             r.qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
             r.flag = (uint32_t)av.z & 0xFFFFu; r.l_qseq = (int32_t)((uint32_t)av.z >> 16);
             r.mapq = (uint32_t)av.w & 0xFFu; r.nm = (int32_t)(((uint32_t)av.w >> 8) & 0xFFu);
             r.tagbits = ((uint32_t)av.w >> 16) & 0xFFu; r.n_cigar = (uint32_t)av.w >> 24;
         }
-        bool ok = true;
+        typedef WaveSink WS; typedef WaveSink::B WB;
+        uint32_t bad_wide = 0;                                // (an integer, so that its lane mask below is one compare)
         if (valid && (r.l_qseq == RSQC_LQSEQ_ESCAPE || r.nm == RSQC_NM_ESCAPE || r.n_cigar == RSQC_NCIGAR_ESCAPE)) {
             const DevBatch &bw = k1e_lazy_args()->b;
             uint32_t lo = 0, hi = bw.n_wide;                    // wide table is sorted by record index
             while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (bw.wide_index[m] < i) lo = m + 1; else hi = m; }
-            if (lo >= bw.n_wide || bw.wide_index[lo] != i) ok = false;
+            if (lo >= bw.n_wide || bw.wide_index[lo] != i) bad_wide = 1u;
             else { r.l_qseq = bw.wide_l_qseq[lo]; r.nm = bw.wide_nm[lo]; r.n_cigar = bw.wide_n_cigar[lo]; }
             K1E_LANDED(r.l_qseq); K1E_LANDED(r.nm); K1E_LANDED(r.n_cigar);
         }
         r.tid = u_tid;
         if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; K1E_LANDED(r.tid); }
-        if (valid && !ok) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_ARG);
-        const bool lane_on = valid && ok;
-        if (!lane_on) r.n_cigar = 0;
+        if (bad_wide) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_ARG);
+        const WB lane_on = WS::prim(valid) && !WS::prim(bad_wide != 0u);
+        if (!WS::lane(lane_on)) r.n_cigar = 0;
         RSQC_MARK(2);
         Walk2 w2;
         k1e_walk(r.pos, r.n_cigar, cg, r.cigar, w2);
         RSQC_MARK(3);
         const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: k1e_process_long
         CigarWalk cw;
-        cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad;
-        RecordCounters rc; bool hq = false;
-        bool go = gate_cascade<false, WaveSink, true>(a, p, r, cw, rc, hq, cnt, lane_on);
+        cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad != 0u;
+        RecordCounters rc; WB hq = lane_on;
+        const WB go = gate_cascade_b<false, WaveSink, true>(a, p, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
         RSQC_MARK(4);
-        if (!lane_on) { go = false; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
-        if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
+        if (a.have_bed && rc.frag_candidate) {                // src/RNASeQC.cpp:372
             const K1Args *q = k1e_lazy_args();
             const int32_t name = bed_interval_of(q->a, r);
             if (name >= 0) {
@@ -519,43 +556,51 @@ classify_ei_kernel(K1Args A) {
         if (rc.error) atomicExch(k1e_lazy_args()->acc.error, rc.error);
         sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
         sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
-        const bool big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
+        const WB big_any = WS::prim((rc.bases | rc.mm | rc.blocks) >= (1u << 26));
         {   // Read-Length inputs: per-tile max span + batch-level extremes
-            const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
+            const uint32_t sp = rc.rl_span;                  // (0 unless the record reaches src/RNASeQC.cpp:275)
             const uint32_t wsp = wave_max_u32_full(sp);
-            if (l == 0) acc.tile_span[w0 >> 6] = wsp;
+            if (l == 0) tile_span[w0 >> 6] = wsp;
             l_span = sp > l_span ? sp : l_span;
-            if (rc.rl_eligible) {
-                const uint32_t lq = (uint32_t)rc.rl_lqseq;
-                l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
-            }
+            const uint32_t lq = (uint32_t)rc.rl_lqseq;
+            l_lmin = (rc.rl_eligible && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
         }
         RSQC_MARK(5);
-        const uint32_t flhq = r.flag | (hq ? K1E_HQ : 0u);
-        const bool mine = go && r.tid == u_tid;              // stragglers of a boundary tile: general code
+        const uint32_t flhq = r.flag | (WS::lane(hq) ? K1E_HQ : 0u);
         // ---- sort by shape ------------------------------------------------------------------------------------------
         // (stragglers of a boundary tile take the general code, which finds their contig itself; for one with a long CIGAR it
         //  also counts the blocks and checks the operations, K1E_OVF_LONG)
-        const bool shape12 = shortc && w2.nb <= 2;
-        const bool simple = mine && shape12;
-        const bool listed = mine && !shape12;
-        k1e_overflow(go && !mine, shape12 ? i : (i | K1E_OVF_LONG));
+        const WB nb0 = WS::prim(w2.nb == 0u), nb1 = WS::prim(w2.nb == 1u), nb2 = WS::prim(w2.nb == 2u);
+        const WB shape12 = WS::prim(r.n_cigar <= 4u) && (nb0 || nb1 || nb2);
+        WB mine = go;                                        // stragglers of a boundary tile: general code
+        if (mixed) {
+            mine = go && WS::prim(r.tid == u_tid);
+            k1e_overflow(WS::lane(go && !mine), WS::lane(shape12) ? (uint64_t)i : ((uint64_t)i | K1E_OVF_LONG));
+        }
+        const WB simple = mine && shape12, listed = mine && !shape12;
         {   // no block at all (clips / insertions only): intergenic, src/Expression.cpp:407-441 with no feature seen
-            const bool none = simple && w2.nb == 0;
+            const WB none = simple && nb0;
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
         }
-        const uint64_t m1 = __ballot(simple && w2.nb == 1), m2 = __ballot(simple && w2.nb == 2), m3 = __ballot(listed);
-        if (simple && w2.nb == 1)
-            S.q1[wave][(h1 + c1 + mask_rank(m1)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)i, flhq);
-        if (simple && w2.nb == 2) {
+        // one-block records whose length fits the queue's 16 bits (a longer block -- never seen in RNA-seq -- takes the long-CIGAR stage)
+        const WB fits = WS::prim(w2.len0 < 65536u);
+        const uint64_t m1 = (simple && nb1 && fits).m, m2 = (simple && nb2).m, m3 = (listed || (simple && nb1 && !fits)).m;
+        if (WS::lane(LaneMask{m1})) {
+            // the coarse word answers the block's look-ups when the block ends inside the 1024 positions it speaks for
+            const bool inside = (((uint32_t)(w2.bs0 + (int32_t)w2.len0)) >> 9) - (((uint32_t)(r.pos + 1)) >> 9) <= 1u;
+            S.q1[wave][(h1 + c1 + mask_rank(m1)) & (K1E_QCAP - 1)] =
+                make_uint4((uint32_t)w2.bs0, w2.len0 | ((flhq & 0xFFFu) << 16) | ((flhq >> 16) << 28), (uint32_t)i, inside ? cur_cz : 0u);
+        }
+        if (WS::lane(LaneMask{m2})) {
             const uint32_t slot = (h2 + c2 + mask_rank(m2)) & (K1E_QCAP - 1);
             S.q2[wave][slot] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)w2.bs1, w2.len1);
             S.q2x[wave][slot] = make_uint2((uint32_t)i, flhq);
         }
-        if (listed) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)i, flhq, (uint32_t)r.pos, (uint32_t)(r.cigar - b.cigar));
+        if (WS::lane(LaneMask{m3})) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)i, flhq, (uint32_t)r.pos, (uint32_t)cur_cigar_off);
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
+        __builtin_amdgcn_wave_barrier();                     // the queue entries are read by OTHER lanes of the wave (no instruction: an ordering point)
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
-        if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
+        if (++pending == 31 || WS::any(big_any)) flush_counts();
         RSQC_MARK(6);
         // ---- the staged words have landed (see above): from here on they are the current tile ----------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -563,12 +608,23 @@ classify_ei_kernel(K1Args A) {
         asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
 #endif
         cur_cv = n_cv; cur_av = n_av; nx_co = n_co;
+        // the next tile's positions are here: its coarse-table words start their trip now and are looked at when that tile sorts
+        // its records by shape, a feature stage and most of a phase A later (a read in an empty stretch of the genome then needs
+        // no rank word).  Not across a contig boundary: the table is addressed through THIS tile's contig.
+        cur_cz = 0u;
+#ifndef K1E_NO_COARSE                                /* (A/B build without the coarse table) */
+        if (!(w1 == NONE || seg_next <= w1) && u_ci.rk_words != 0u) {
+            const int32_t top = (int32_t)(u_ci.rk_words << 6) - 1;
+            const int32_t x = n_cv.x + 1, xc = x < 0 ? 0 : (x > top ? top : x);
+            cur_cz = ld32(a.ei_coarse, (u_ci.rk_base >> 3) + ((uint32_t)xc >> 9));
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) cg[k] = n_cg[k];
         RSQC_MARK(7);
         // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
         //      (the queued records belong to it) and at the end of the range ------------------------------------------------
-        const bool leaving = w1 == NONE || seg_next <= w1;             // the wave's next tile lies in another segment (or there is none)
+        const bool leaving = w1 == NONE || seg_next <= w1;    // (NONE is the largest index)             // the wave's next tile lies in another segment (or there is none)
         const uint32_t thr = leaving ? 1u : 64u;
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;

@@ -122,6 +122,7 @@ struct DevAnnotation {
     const int32_t *ex_pmax;            // running max of end, per row (see ExonRow)
     const EiEntry *ei;                 // elementary intervals, sorted by (contig, pos)
     const EiRank *ei_rank;             // rank table: ContigInfo::rk_base + (pos >> 6)
+    const uint32_t *ei_coarse;         // (ContigInfo::rk_base >> 3) + (pos >> 9): 1 + the interval that covers 1024 breakpoint-free positions, or 0 (rsqc_index.h)
     const GeneBreak *gb;               // sorted by (contig, pos)
     const ContigInfo *contig;          // [n_contigs]
     // bin tables: ex_binhi = first exon row whose start >= (bin + 1) << bin_shift;
@@ -170,35 +171,74 @@ struct RecordCounters {
 
 #define RSQC_BIT(c) (1ull << (c))
 
-// Where the one-per-record counter increments go.  BitSink keeps them as a 64-bit set for one record (general code, host
-// emulation).  The per-record kernel uses WaveSink instead: a condition is a lane mask already, so the count of a tile is
-// one scalar popcount of the ballot, dropped into lane `c` of ONE vector register (v_writelane) -- the scalar unit does
-// the counting and the vector pipe sees one instruction per counter instead of the select / or / carry chains a
-// per-lane bit set costs.
+// Where the one-per-record counter increments go, and the BOOLEAN DOMAIN the conditions live in.
+// BitSink: one record, conditions are `bool`, the increments a 64-bit set (general code, host emulation).
+// WaveSink (the per-record kernels): the whole wave runs the code converged, and a condition is a 64-bit LANE MASK in
+// scalar registers (LaneMask).  A primitive test (`prim`: a compare on a per-lane value) is ONE v_cmp that writes the mask;
+// and / or / not are scalar instructions; a counter is s_bcnt1 of the mask dropped into lane `c` of one vector register
+// (v_writelane); a select reads the mask back as the condition of v_cndmask (`lane`).  Round 3 kept the conditions as
+// per-lane `bool`s and took `__ballot` of every derived one: the compiler materialises such a bool in a VGPR and compares
+// it again (v_cndmask + v_cmp per ballot -- 2 of the 3 vector instructions every counter cost; tools/k1_sections.py).
 struct BitSink {
+    using B = bool;
     uint64_t bits = 0;
+    static RSQC_HD bool prim(bool c) { return c; }
+    static RSQC_HD bool lane(bool c) { return c; }
+    static RSQC_HD bool any(bool c) { return c; }
     template <int C> RSQC_HD void add(bool cond) { bits |= cond ? RSQC_BIT(C) : 0ull; }
 };
+// a condition of all 64 lanes (every lane of the wave is active where these are used, so `!` is a plain complement)
+struct LaneMask { uint64_t m; };
+RSQC_HD LaneMask operator&&(LaneMask a, LaneMask b) { return LaneMask{a.m & b.m}; }
+RSQC_HD LaneMask operator||(LaneMask a, LaneMask b) { return LaneMask{a.m | b.m}; }
+RSQC_HD LaneMask operator!(LaneMask a) { return LaneMask{~a.m}; }
+RSQC_HD LaneMask operator!=(LaneMask a, LaneMask b) { return LaneMask{a.m ^ b.m}; }
+RSQC_HD LaneMask operator&&(LaneMask a, bool u) { return LaneMask{u ? a.m : 0ull}; }            // (wave-uniform operand)
+RSQC_HD LaneMask operator&&(bool u, LaneMask a) { return LaneMask{u ? a.m : 0ull}; }
+RSQC_HD LaneMask operator||(LaneMask a, bool u) { return LaneMask{u ? ~0ull : a.m}; }
+RSQC_HD LaneMask operator||(bool u, LaneMask a) { return LaneMask{u ? ~0ull : a.m}; }
 #if defined(__HIPCC__)
 struct WaveSink {
+    using B = LaneMask;
     uint32_t vec = 0;                          // lane c: records of this tile that increment counter c
-    template <int C> __device__ __forceinline__ void add(bool cond) {
+    static __device__ __forceinline__ LaneMask prim(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return LaneMask{__builtin_amdgcn_ballot_w64(c)};
+#else
+        return LaneMask{c ? ~0ull : 0ull};
+#endif
+    }
+    static __device__ __forceinline__ bool lane(LaneMask x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_inverse_ballot_w64(x.m);
+#else
+        return x.m != 0;
+#endif
+    }
+    static __device__ __forceinline__ bool any(LaneMask x) { return x.m != 0ull; }
+    template <int C> __device__ __forceinline__ void add(LaneMask cond) {
         static_assert(C >= 0 && C < 64, "one lane per counter");
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t n = (uint32_t)__popcll(__ballot(cond));          // s_bcnt1_i32_b64 of the condition mask
+        const uint32_t n = (uint32_t)__popcll(cond.m);                   // s_bcnt1_i32_b64 of the condition mask
         asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(n), "n"(C));  // (no clang builtin for v_writelane in this toolchain)
 #else
         (void)cond;
 #endif
     }
+    template <int C> __device__ __forceinline__ void add(bool cond) { add<C>(prim(cond)); }
 };
 #elif defined(RSQC_WAVE_EMU)
 struct WaveSink {                              // the same on the host's wave emulation (tests/hostemu/wavemu.h)
+    using B = LaneMask;
     uint32_t vec = 0;
-    template <int C> void add(bool cond) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(cond));
+    static LaneMask prim(bool c) { return LaneMask{(uint64_t)__ballot(c)}; }
+    static bool lane(LaneMask x) { return ((x.m >> (threadIdx.x & 63u)) & 1ull) != 0; }
+    static bool any(LaneMask x) { return x.m != 0ull; }
+    template <int C> void add(LaneMask cond) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(cond.m);
         if ((int)(threadIdx.x & 63u) == C) vec = n;
     }
+    template <int C> void add(bool cond) { add<C>(prim(cond)); }
 };
 #endif
 #define RSQC_COUNT(sink, c, cond) (sink).template add<(c)>(cond)
@@ -333,71 +373,94 @@ RSQC_HD void walk_cigar(const Record &r, const uint32_t (&first)[4], CigarWalk &
 // seen, Mapped Unique = Mapped - Mapped Duplicate, Unique Fragments = End 1 Mapped - Duplicate Pairs, Low Quality = Reads used -
 // High Quality: rsqc_k1.h, K1eTables::flush) and the tag filters are skipped as a whole when the run has none.
 template <bool LEGACY = false, class Sink = BitSink, bool LEAN = false>
-RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
-                          RecordCounters &out, bool &hq, Sink &cnt, bool on = true) {
+RSQC_HD typename Sink::B gate_cascade_b(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
+                                        RecordCounters &out, typename Sink::B &hq, Sink &cnt, typename Sink::B on) {
     // `on` = the caller's lane holds a record at all (a whole wave runs the cascade converged; see WaveSink)
     // Straight-line form of the cascade: `alive` stays true while the reference's loop body has not hit a
     // `continue`; every counter is added under the conjunction of `alive` and its own condition.  (In a 64-lane
     // wave every early exit is taken by some lane, so branching only adds exec-mask bookkeeping.)
+    // Conditions live in the sink's boolean domain B (bool, or a lane mask: and / or / not are scalar instructions there).
+    using B = typename Sink::B;
+#define RSQC_P(x) Sink::prim(x)
+#define RSQC_L(x) Sink::lane(x)
     const uint32_t fl = r.flag;
     const bool excl = p.exclude_chimeric != 0;
-    const bool paired = (fl & RSQC_FPAIRED) != 0, read1 = (fl & RSQC_FREAD1) != 0, dup = (fl & RSQC_FDUP) != 0;
-    const bool sec = (fl & RSQC_FSECONDARY) != 0, supp = (fl & RSQC_FSUPP) != 0, qcf = (fl & RSQC_FQCFAIL) != 0;
+    const B paired = RSQC_P((fl & RSQC_FPAIRED) != 0), read1 = RSQC_P((fl & RSQC_FREAD1) != 0), dup = RSQC_P((fl & RSQC_FDUP) != 0);
+    const B sec = RSQC_P((fl & RSQC_FSECONDARY) != 0), supp = RSQC_P((fl & RSQC_FSUPP) != 0), qcf = RSQC_P((fl & RSQC_FQCFAIL) != 0);
     if (!LEAN) RSQC_COUNT(cnt, RSQC_C_TOTAL_ALIGNMENTS, on);                                       // :245,397
     RSQC_COUNT(cnt, RSQC_C_ALTERNATIVE_ALIGNMENTS, on && sec);                                     // :254
     RSQC_COUNT(cnt, RSQC_C_SUPPLEMENTARY_ALIGNMENTS, on && supp);                                  // :255
     RSQC_COUNT(cnt, RSQC_C_FAILED_VENDOR_QC, on && !supp && qcf);                                  // :256
-    RSQC_COUNT(cnt, RSQC_C_LOW_MAPPING_QUALITY, on && !supp && !qcf && r.mapq < p.mapq_threshold); // :257
-    const bool has_ch = (r.tagbits & RSQC_TB_HAS_CH) != 0;
-    const bool supp_auto = on && !LEGACY && supp && !has_ch;                               // :258-262
-    bool alive = on && !(supp_auto && excl);
+    const B lowq = RSQC_P(r.mapq < p.mapq_threshold);
+    RSQC_COUNT(cnt, RSQC_C_LOW_MAPPING_QUALITY, on && !supp && !qcf && lowq);                      // :257
+    const B has_ch = RSQC_P((r.tagbits & RSQC_TB_HAS_CH) != 0);
+    const B supp_auto = on && !LEGACY && supp && !has_ch;                                  // :258-262
+    B alive = on && !(supp_auto && excl);
     alive = alive && !(sec || qcf || supp);                                                // :263
     RSQC_COUNT(cnt, RSQC_C_UNIQUE_VENDOR_PASSED, alive);
     RSQC_COUNT(cnt, RSQC_C_UNPAIRED_READS, alive && !paired);
-    alive = alive && !(fl & RSQC_FUNMAP);                                                  // :268
+    alive = alive && !RSQC_P((fl & RSQC_FUNMAP) != 0);                                     // :268
     RSQC_COUNT(cnt, RSQC_C_MAPPED_READS, alive);
     RSQC_COUNT(cnt, RSQC_C_MAPPED_DUPLICATE_READS, alive && dup); if (!LEAN) RSQC_COUNT(cnt, RSQC_C_MAPPED_UNIQUE_READS, alive && !dup);
     // bam_endpos: pos + rlen, rlen = 1 for CIGAR-less records or when no reference base is consumed
-    const int32_t endpos = r.pos + (int32_t)((r.n_cigar == 0 || w.ref_len == 0) ? 1u : w.ref_len);
-    if (LEGACY) alive = alive && !((uint32_t)(endpos - r.pos) > 100000u);                  // :276, LEGACY_MAX_READ_LENGTH
-    out.endpos = alive ? endpos : 0;
-    out.rl_eligible = alive ? 1u : 0u;                                                     // :275-278
-    out.rl_span = alive ? (uint32_t)(endpos - r.pos) : 0u; out.rl_lqseq = alive ? r.l_qseq : 0;
-    const bool ch_here = !LEGACY && alive && has_ch;                                       // :279-283
+    // (a record without operations has walked none: ref_len == 0)
+    const int32_t endpos = r.pos + (int32_t)(w.ref_len == 0 ? 1u : w.ref_len);
+    if (LEGACY) alive = alive && !RSQC_P((uint32_t)(endpos - r.pos) > 100000u);            // :276, LEGACY_MAX_READ_LENGTH
+    {
+        const bool al = RSQC_L(alive);
+        out.endpos = al ? endpos : 0;
+        out.rl_eligible = al ? 1u : 0u;                                                    // :275-278
+        out.rl_span = al ? (uint32_t)(endpos - r.pos) : 0u; out.rl_lqseq = al ? r.l_qseq : 0;
+    }
+    const B ch_here = !LEGACY && alive && has_ch;                                          // :279-283
     RSQC_COUNT(cnt, RSQC_C_CHIMERIC_TAG, ch_here && read1);
     alive = alive && !(ch_here && excl);
-    const bool mate_mapped = alive && paired && !(fl & RSQC_FMUNMAP);                      // :284-292
+    const B mate_mapped = alive && paired && !RSQC_P((fl & RSQC_FMUNMAP) != 0);            // :284-292
     RSQC_COUNT(cnt, RSQC_C_TOTAL_MAPPED_PAIRS, mate_mapped && read1);
     int32_t d = r.pos - r.mpos; if (d < 0) d = -d;
-    const bool far = mate_mapped && (!(r.tagbits & RSQC_TB_MTID_SAME) || d > p.chimeric_distance || (LEGACY && r.tid > 127));
+    const B far = mate_mapped && (RSQC_P((r.tagbits & RSQC_TB_MTID_SAME) == 0) || RSQC_P(d > p.chimeric_distance) || (LEGACY && RSQC_P(r.tid > 127)));
     RSQC_COUNT(cnt, RSQC_C_CHIMERIC_AUTO, supp_auto || (far && read1));                            // (:258 and :289 exclude each other: :263)
     alive = alive && !(far && excl);
-    const bool has_nm = alive && (r.tagbits & RSQC_TB_HAS_NM) != 0;                        // :295-316
+    const B has_nm = alive && RSQC_P((r.tagbits & RSQC_TB_HAS_NM) != 0);                   // :295-316
     const int32_t mismatches = (r.tagbits & RSQC_TB_HAS_NM) ? r.nm : 0;
-    const bool nm1 = has_nm && paired && read1, nm2 = has_nm && paired && !read1;
+    const B nm1 = has_nm && paired && read1, nm2 = has_nm && paired && !read1;
     RSQC_COUNT(cnt, RSQC_C_END1_MAPPED_READS, nm1); RSQC_COUNT(cnt, RSQC_C_DUPLICATE_PAIRS, nm1 && dup); if (!LEAN) RSQC_COUNT(cnt, RSQC_C_UNIQUE_FRAGMENTS, nm1 && !dup);
     RSQC_COUNT(cnt, RSQC_C_END2_MAPPED_READS, nm2);
-    out.e1_mm = nm1 ? (uint32_t)mismatches : 0u; out.e1_bases = nm1 ? (uint32_t)r.l_qseq : 0u;
-    out.e2_mm = nm2 ? (uint32_t)mismatches : 0u; out.e2_bases = nm2 ? (uint32_t)r.l_qseq : 0u;
-    out.mm = has_nm ? (uint32_t)mismatches : 0u;
-    out.bases = alive ? (uint32_t)r.l_qseq : 0u;                                           // :317
-    bool discard = false;                                                                  // :319-328
-#define RSQC_FILTER_TAG(t) { const bool hit = (t) < p.n_filter_tags && alive && (r.tagbits & (RSQC_TB_FILTER0 << (t))) != 0; \
+    {
+        const bool l1 = RSQC_L(nm1), l2 = RSQC_L(nm2);
+        out.e1_mm = l1 ? (uint32_t)mismatches : 0u; out.e1_bases = l1 ? (uint32_t)r.l_qseq : 0u;
+        out.e2_mm = l2 ? (uint32_t)mismatches : 0u; out.e2_bases = l2 ? (uint32_t)r.l_qseq : 0u;
+        out.mm = RSQC_L(has_nm) ? (uint32_t)mismatches : 0u;
+        out.bases = RSQC_L(alive) ? (uint32_t)r.l_qseq : 0u;                               // :317
+    }
+    B discard = alive && false;                                                            // :319-328
+#define RSQC_FILTER_TAG(t) { const B hit = ((t) < p.n_filter_tags) && alive && RSQC_P((r.tagbits & (RSQC_TB_FILTER0 << (t))) != 0); \
                              RSQC_COUNT(cnt, RSQC_C_FILTERED_TAG0 + (t), hit); discard = discard || hit; }
     if (!LEAN || p.n_filter_tags > 0) { RSQC_FILTER_TAG(0) RSQC_FILTER_TAG(1) RSQC_FILTER_TAG(2) RSQC_FILTER_TAG(3) RSQC_FILTER_TAG(4) }
 #undef RSQC_FILTER_TAG
     static_assert(RSQC_MAX_FILTER_TAGS == 5, "one line per filter tag above");
     alive = alive && !discard;
-    hq = alive && ((uint32_t)mismatches <= p.base_mismatch) && (p.unpaired || (fl & RSQC_FPROPER)) &&
-         (r.mapq >= p.mapq_threshold);                                                     // :330
-    alive = alive && !(r.tid < 0 || r.tid >= a.n_ref);                                     // :333-337
+    hq = alive && RSQC_P((uint32_t)mismatches <= p.base_mismatch) && ((p.unpaired != 0) || RSQC_P((fl & RSQC_FPROPER) != 0)) &&
+         !lowq;                                                                            // :330
+    alive = alive && !RSQC_P((uint32_t)r.tid >= (uint32_t)a.n_ref);                        // :333-337 (tid < 0 || tid >= n_ref)
     hq = hq && alive;
     RSQC_COUNT(cnt, RSQC_C_HIGH_QUALITY_READS, hq); if (!LEAN) RSQC_COUNT(cnt, RSQC_C_LOW_QUALITY_READS, alive && !hq); RSQC_COUNT(cnt, RSQC_C_READS_USED, alive);
-    out.error = (alive && w.bad) ? RSQC_ERR_BAD_CIGAR : 0;
-    alive = alive && !w.bad;
-    out.blocks = alive ? w.nblocks : 0u;                                                   // :360
-    out.frag_candidate = (alive && hq && paired) ? 1u : 0u;                                // :372
+    const B bad = alive && RSQC_P(w.bad);
+    out.error = RSQC_L(bad) ? RSQC_ERR_BAD_CIGAR : 0;
+    alive = alive && !bad;
+    out.blocks = RSQC_L(alive) ? w.nblocks : 0u;                                           // :360
+    out.frag_candidate = RSQC_L(alive && hq && paired) ? 1u : 0u;                          // :372
+#undef RSQC_P
+#undef RSQC_L
     return alive;
+}
+template <bool LEGACY = false, class Sink = BitSink, bool LEAN = false>
+RSQC_HD bool gate_cascade(const DevAnnotation &a, const DevParams &p, const Record &r, const CigarWalk &w,
+                          RecordCounters &out, bool &hq, Sink &cnt, bool on = true) {
+    typename Sink::B hqb = Sink::prim(false);
+    const typename Sink::B alive = gate_cascade_b<LEGACY, Sink, LEAN>(a, p, r, w, out, hqb, cnt, Sink::prim(on));
+    hq = Sink::lane(hqb);
+    return Sink::lane(alive);
 }
 // the same with the counters as a bit set in out.bits
 template <bool LEGACY = false>
@@ -492,21 +555,40 @@ template <int K> RSQC_HD void set_put(uint32_t (&s)[K], int idx, uint32_t v) {
 
 // classification counters of exonAlignmentMetrics, src/Expression.cpp:407-457; `keep` = the record is counted here
 // (a record handed to the general code is counted there)
+template <class B> struct ClassFlagsT { B intragenic, plus, minus, ribosomal, exonic; };
 template <class Sink>
-RSQC_HD void class_counts(Sink &cnt, const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq, bool keep) {
-    const bool intronic = keep && !f.exonic && f.intragenic, intergenic = keep && !f.exonic && !f.intragenic;
-    const bool exonic = keep && f.exonic && do_exon, ambiguous = keep && f.exonic && !do_exon;
+RSQC_HD void class_counts_b(Sink &cnt, const DevParams &p, uint32_t fl, const ClassFlagsT<typename Sink::B> &f,
+                            typename Sink::B do_exon, typename Sink::B hq, typename Sink::B keep) {
+    using B = typename Sink::B;
+    const B intronic = keep && !f.exonic && f.intragenic, intergenic = keep && !f.exonic && !f.intragenic;
+    const B exonic = keep && f.exonic && do_exon, ambiguous = keep && f.exonic && !do_exon;
     RSQC_COUNT(cnt, RSQC_C_INTRONIC_READS, intronic); RSQC_COUNT(cnt, RSQC_C_HQ_INTRONIC_READS, intronic && hq);
     RSQC_COUNT(cnt, RSQC_C_INTRAGENIC_READS, intronic || exonic); RSQC_COUNT(cnt, RSQC_C_HQ_INTRAGENIC_READS, (intronic || exonic) && hq);
     RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, intergenic); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, intergenic && hq);
     RSQC_COUNT(cnt, RSQC_C_EXONIC_READS, exonic); RSQC_COUNT(cnt, RSQC_C_HQ_EXONIC_READS, exonic && hq);
     RSQC_COUNT(cnt, RSQC_C_AMBIGUOUS_READS, ambiguous); RSQC_COUNT(cnt, RSQC_C_HQ_AMBIGUOUS_READS, ambiguous && hq);
     RSQC_COUNT(cnt, RSQC_C_RRNA_READS, keep && f.ribosomal);
-    const bool one_strand = keep && (f.minus != f.plus) && (p.unpaired || (fl & RSQC_FPAIRED));
-    const bool sense = (fl & RSQC_FREVERSE) ? f.minus : f.plus;
-    const bool end1 = p.unpaired || (fl & RSQC_FREAD1);
+    const B one_strand = keep && (f.minus != f.plus) && ((p.unpaired != 0) || Sink::prim((fl & RSQC_FPAIRED) != 0));
+    const B rev = Sink::prim((fl & RSQC_FREVERSE) != 0);
+    const B sense = (rev && f.minus) || (!rev && f.plus);
+    const B end1 = (p.unpaired != 0) || Sink::prim((fl & RSQC_FREAD1) != 0);
     RSQC_COUNT(cnt, RSQC_C_END1_SENSE, one_strand && end1 && sense); RSQC_COUNT(cnt, RSQC_C_END1_ANTISENSE, one_strand && end1 && !sense);
     RSQC_COUNT(cnt, RSQC_C_END2_SENSE, one_strand && !end1 && sense); RSQC_COUNT(cnt, RSQC_C_END2_ANTISENSE, one_strand && !end1 && !sense);
+}
+// the same from the CF_* bits of a record (what the feature stages hold)
+template <class Sink>
+RSQC_HD void class_counts_cf(Sink &cnt, const DevParams &p, uint32_t fl, uint32_t cf, typename Sink::B do_exon, typename Sink::B hq, typename Sink::B keep) {
+    ClassFlagsT<typename Sink::B> f;
+    f.intragenic = Sink::prim((cf & 1u /*CF_INTRAGENIC*/) != 0); f.plus = Sink::prim((cf & 2u /*CF_PLUS*/) != 0); f.minus = Sink::prim((cf & 4u /*CF_MINUS*/) != 0);
+    f.ribosomal = Sink::prim((cf & 8u /*CF_RIBOSOMAL*/) != 0); f.exonic = Sink::prim((cf & 16u /*CF_EXONIC*/) != 0);
+    class_counts_b(cnt, p, fl, f, do_exon, hq, keep);
+}
+template <class Sink>
+RSQC_HD void class_counts(Sink &cnt, const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq, bool keep) {
+    ClassFlagsT<typename Sink::B> fb;
+    fb.intragenic = Sink::prim(f.intragenic); fb.plus = Sink::prim(f.plus); fb.minus = Sink::prim(f.minus);
+    fb.ribosomal = Sink::prim(f.ribosomal); fb.exonic = Sink::prim(f.exonic);
+    class_counts_b(cnt, p, fl, fb, Sink::prim(do_exon), Sink::prim(hq), Sink::prim(keep));
 }
 RSQC_HD uint64_t class_bits(const DevParams &p, uint32_t fl, const ClassFlags &f, bool do_exon, bool hq) {
     BitSink s;
@@ -736,17 +818,22 @@ struct EiBlock { uint32_t mask; bool cA, cB; uint32_t eidA, gfA, cidxA, eidB, gf
 //   ei_probe    the two rank words (independent loads)
 //   ei_fetch    indices from the rank words; the interval entries (one round of independent loads)
 //   ei_resolve  masks and containing exons; only a block across more than three intervals goes back to memory
-struct EiProbe { EiRank ws, we; int32_t bs, be; uint32_t len; bool have; };
+struct EiProbe { EiRank ws, we; int32_t bs, be; uint32_t len; bool have; uint32_t pre; };
 struct EiFetch { EiEntry S; uint32_t m1, e1A, e1B, m_je, m_js1; uint32_t js, je, j1; };
-RSQC_HD void ei_probe(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, uint32_t len, bool on, EiProbe &q) {
+// `pre` != 0: the caller already knows the answer from the coarse table (DevAnnotation::ei_coarse) -- the whole block lies
+// in interval pre - 1 and no rank word is read (the lane loads word 0 like a lane without a block: one shared line)
+RSQC_HD void ei_probe(const DevAnnotation &a, const ContigInfo &ci, int32_t bs, uint32_t len, bool on, EiProbe &q, uint32_t pre = 0u) {
     q.bs = bs; q.len = len; q.be = bs + (int32_t)len;
     q.have = on && ci.rk_words != 0 && q.be >= 0;
-    q.ws = ei_find_word(a, ci, q.bs, q.have); q.we = ei_find_word(a, ci, q.be, q.have);
+    q.pre = pre;
+    const bool look = q.have && pre == 0u;
+    q.ws = ei_find_word(a, ci, q.bs, look); q.we = ei_find_word(a, ci, q.be, look);
 }
 RSQC_HD void ei_fetch(const DevAnnotation &a, const ContigInfo &ci, const EiProbe &q, EiFetch &f) {
     const EiFind fs = ei_find_in(q.ws, ci, q.bs), fe = ei_find_in(q.we, ci, q.be);
-    f.js = q.have ? fs.j : 0u; f.je = q.have ? fe.j : 0u;
-    f.j1 = (fe.at && q.len > 0 && f.je > f.js) ? f.je - 1 : f.je;        // find(max(bs, be - 1))
+    const bool known = q.pre != 0u;
+    f.js = q.have ? (known ? q.pre - 1u : fs.j) : 0u; f.je = q.have ? (known ? q.pre - 1u : fe.j) : 0u;
+    f.j1 = (!known && fe.at && q.len > 0 && f.je > f.js) ? f.je - 1 : f.je;        // find(max(bs, be - 1))
     f.S = ld32(a.ei, f.js);
     f.m1 = ld32(a.ei, f.j1).mask; f.e1A = ld32(a.ei, f.j1).eidA; f.e1B = ld32(a.ei, f.j1).eidB;
     // intervals js .. je: js, j1 (= je - 1 or je), je and js + 1 are read in this one round
@@ -781,7 +868,7 @@ struct EiOut {
 template <int NB, class Sink>
 RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const ContigInfo &ci, uint32_t fl, const int32_t (&bs)[NB],
                              const uint32_t (&len)[NB], bool hq, EiOut &out, bool &overflow, Sink &cnt, bool lane_on = true,
-                             uint32_t nbv = (uint32_t)NB) {
+                             uint32_t nbv = (uint32_t)NB, uint32_t pre0 = 0u /* coarse-table answer for block 0, see ei_probe */) {
     static_assert(NB >= 1 && NB <= FAST_BLOCKS, "blocks per record on the fast path");
     const int rstrand = read_strand_of(p, fl);
     uint32_t mask = 0, con = 0, ma = 0, mb = 0;
@@ -795,7 +882,7 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
         constexpr int G = 2;
         EiProbe pr[G]; EiFetch fe[G];
 #pragma unroll
-        for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_probe(a, ci, bs[b0 + j], len[b0 + j], lane_on && (uint32_t)(b0 + j) < nbv, pr[j]);
+        for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_probe(a, ci, bs[b0 + j], len[b0 + j], lane_on && (uint32_t)(b0 + j) < nbv, pr[j], (b0 + j == 0) ? pre0 : 0u);
 #pragma unroll
         for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_fetch(a, ci, pr[j], fe[j]);
 #pragma unroll
@@ -829,19 +916,18 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
     overflow = over;
     ga = ga && va; gb = gb && vb;
     const int nlast = (va ? 1 : 0) + (vb ? 1 : 0);
-    const bool nonglobin = !over && !(ga || gb);                                               // :363,395-404
+    // counters in the sink's boolean domain (lane masks in the per-record kernel: rsqc_read.h, WaveSink)
+    using SB = typename Sink::B;
+    const SB keep = !Sink::prim(over), hqb = Sink::prim(hq), any_gene = Sink::prim(va || vb);
+    const SB nonglobin = keep && !Sink::prim(ga || gb);                                        // :363,395-404
     RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, nonglobin);
-    RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, nonglobin && (fl & RSQC_FDUP) != 0);
+    RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, nonglobin && Sink::prim((fl & RSQC_FDUP) != 0));
     out.n_hit = 0; out.cmask = 0;
-    if (hq && nlast > 0 && !over) {                                                            // :377-392
+    if (Sink::lane(hqb && any_gene && keep)) {                                                 // :377-392
         out.cmask = con & ((va ? ma : 0u) | (vb ? mb : 0u));
         if (aligned > 0) { out.hit[0] = va ? la : lb; out.hit[1] = lb; out.n_hit = nlast; }
     }
-    const uint32_t cf = ei_class_flags(mask, rstrand);
-    ClassFlags f;
-    f.intragenic = (cf & CF_INTRAGENIC) != 0; f.plus = (cf & CF_PLUS) != 0; f.minus = (cf & CF_MINUS) != 0;
-    f.ribosomal = (cf & CF_RIBOSOMAL) != 0; f.exonic = (cf & CF_EXONIC) != 0;
-    class_counts(cnt, p, fl, f, nlast > 0, hq, !over);
+    class_counts_cf(cnt, p, fl, ei_class_flags(mask, rstrand), any_gene, hqb, keep);
 }
 
 // ---- stage 2: exonAlignmentMetrics, src/Expression.cpp:308-458 ---------------------------

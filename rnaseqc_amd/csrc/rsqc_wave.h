@@ -16,6 +16,26 @@ __device__ __forceinline__ uint32_t lane_below(uint32_t v) {
 #endif
 }
 
+// bit-field helpers that map to ONE vector instruction each (v_bfe_u32 / v_bfe_i32 / v_bfi_b32).  The hardware takes the low
+// five bits of the offset operand, so a 16-bit table repeated in both halves of `src` can be indexed by a value whose bit 4
+// is garbage: bfe_u(0x01810181, cigar_word, 1) is "operation code in {M, =, X}" without masking the code out first.
+__device__ __forceinline__ uint32_t bfe_u(uint32_t src, uint32_t off, uint32_t width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(src, off, width);
+#else
+    return (src >> (off & 31u)) & ((width & 31u) ? ((1u << (width & 31u)) - 1u) : 0u);
+#endif
+}
+// the same, sign-extended: a 1-bit field becomes an all-ones / all-zeros select mask
+__device__ __forceinline__ uint32_t bfe_m(uint32_t src, uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_sbfe((int)src, off, 1u);
+#else
+    return ((src >> (off & 31u)) & 1u) ? 0xFFFFFFFFu : 0u;
+#endif
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // v_bfi_b32
+
 __device__ __forceinline__ uint32_t mask_rank(uint64_t m) {      // #set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -86,14 +106,16 @@ __device__ __forceinline__ void wave_aggregate(bool valid, uint32_t key, uint64_
 // same exon / gene / coverage slot sit in neighbouring lanes: merging each run into one atomic
 // removes the same-address serialisation on highly expressed genes in O(1) instructions.
 struct Run { bool head; uint32_t count; int end; uint64_t mask; };
-__device__ __forceinline__ Run make_run(bool valid, uint32_t key) {
+// `vmask`: the lanes that take part, as a lane mask (rsqc_read.h, LaneMask: conditions of the per-record kernel are masks in
+// scalar registers; a ballot of a derived per-lane bool would cost a v_cndmask + v_cmp round trip through a VGPR)
+__device__ __forceinline__ Run make_run(uint64_t vmask, uint32_t key) {
     const int l = lane_id();
     const uint32_t pk = lane_below(key);
-    const uint64_t vmask = __ballot(valid);
-    const bool pvalid = l > 0 && ((vmask >> (l - 1)) & 1ull);
+    const uint64_t neq = WaveSink::prim(pk != key).m;                // (lane 0 compares with itself: its bit of vmask << 1 is 0)
+    const uint64_t headm = vmask & (~(vmask << 1) | neq);
     Run r;
-    r.head = valid && (!pvalid || pk != key);
-    const uint64_t stop = __ballot(r.head) | ~vmask;                 // lanes that end the run before them
+    r.head = WaveSink::lane(LaneMask{headm});
+    const uint64_t stop = headm | ~vmask;                            // lanes that end the run before them
     const uint64_t above = l == 63 ? 0ull : stop & ~((2ull << l) - 1ull);
     r.end = above ? __ffsll((unsigned long long)above) - 1 : 64;
     r.count = (uint32_t)(r.end - l);
@@ -101,6 +123,7 @@ __device__ __forceinline__ Run make_run(bool valid, uint32_t key) {
     r.mask = upto & ~((1ull << l) - 1ull);
     return r;
 }
+__device__ __forceinline__ Run make_run(bool valid, uint32_t key) { return make_run(WaveSink::prim(valid).m, key); }
 // sum of v over the run that starts at this (head) lane
 __device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
     const int l = lane_id();
@@ -124,17 +147,18 @@ __device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
 // cov[idx] += sign * (number of lanes of the run) with identical neighbouring slots merged into one atomic.
 // Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
 // then is the run structure built.
-__device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {
+__device__ __forceinline__ void cov_add_merged(uint32_t *cov, uint64_t vmask, uint32_t idx, uint32_t sign) {
     const uint32_t pidx = lane_below(idx);
-    const uint64_t vmask = __ballot(valid);
-    const int l = lane_id();
-    const bool dup = valid && l > 0 && ((vmask >> (l - 1)) & 1ull) && pidx == idx;
-    if (__popcll(__ballot(dup)) < RSQC_COV_MERGE_MIN) {
-        if (valid) atomicAdd(&cov[idx], sign);
+    const uint64_t dupm = vmask & (vmask << 1) & WaveSink::prim(pidx == idx).m;      // a lane on the slot of the lane below it
+    if (__popcll(dupm) < RSQC_COV_MERGE_MIN) {
+        if (WaveSink::lane(LaneMask{vmask})) atomicAdd(&cov[idx], sign);
     } else {
-        const Run r = make_run(valid, idx);
+        const Run r = make_run(vmask, idx);
         if (r.head) atomicAdd(&cov[idx], sign * r.count);
     }
+}
+__device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {
+    cov_add_merged(cov, WaveSink::prim(valid).m, idx, sign);
 }
 
 // last segment whose start <= i (wave-uniform i -> scalar loads)

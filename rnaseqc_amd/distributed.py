@@ -99,24 +99,32 @@ def merge_order_dependent(shard: ShardInfo, dist=None, device=None, fragment_sam
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
 
-    def gather_var(a):
-        """Every rank's 1-D array (different lengths) -> list of int64 arrays, by padding to the longest.
-        (uint32 / uint64 travel as int64: gloo and RCCL both carry it, values are far below 2^63.)"""
-        a = np.ascontiguousarray(a).astype(np.int64)
-        if dist is None:
-            return [a]
-        n = torch.zeros(world, dtype=torch.int64, device=device); n[rank] = len(a)
-        dist.all_reduce(n)
-        n = n.cpu().numpy()
-        buf = torch.zeros(max(int(n.max()), 1), dtype=torch.int64, device=device)
-        if len(a):
-            buf[:len(a)] = torch.from_numpy(a).to(buf.device)
+    # Seven 1-D arrays of different lengths per rank travel as ONE packed int64 buffer: a gather of the 7 lengths, then a gather
+    # of the concatenated payload padded to the longest rank (two collectives and two host copies per step; one gather per array
+    # was fourteen collectives with a device-to-host copy behind each).  uint32 / uint64 travel as int64: gloo and RCCL both carry
+    # it, values are far below 2^63.
+    fields = [np.ascontiguousarray(x).astype(np.int64).ravel() for x in
+              (shard.batch_file_index, shard.batch_records, shard.rl_offset, shard.rl_span, shard.rl_state, shard.sample_file_index, shard.sample_size)]
+    if dist is None:
+        cols = [[f] for f in fields]
+    else:
+        lens = torch.tensor([len(f) for f in fields], dtype=torch.int64, device=device)
+        all_lens = [torch.empty_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens)
+        all_lens = np.stack([t.cpu().numpy() for t in all_lens])                      # [world, 7]
+        width = max(int(all_lens.sum(axis=1).max()), 1)
+        mine = np.zeros(width, np.int64)
+        cat = np.concatenate(fields) if sum(len(f) for f in fields) else np.zeros(0, np.int64)
+        mine[:len(cat)] = cat
+        buf = torch.from_numpy(mine).to(device)
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
-        return [o.cpu().numpy()[:int(n[k])] for k, o in enumerate(out)]
-
-    cols = [gather_var(x) for x in (shard.batch_file_index, shard.batch_records, shard.rl_offset, shard.rl_span,
-                                    shard.rl_state, shard.sample_file_index, shard.sample_size)]
+        cols = [[] for _ in fields]
+        for k, o in enumerate(out):
+            flat = o.cpu().numpy()
+            at = 0
+            for j in range(len(fields)):
+                n = int(all_lens[k, j]); cols[j].append(flat[at:at + n].copy()); at += n
     infos = [ShardInfo(*(c[k] for c in cols)) for k in range(world)]
     sizes, counts, remaining = merge_fragment_samples(infos, fragment_samples)
     return compose_read_length(infos), sizes, counts, remaining, infos

@@ -51,6 +51,10 @@ def load_library():
         lib.rsqc_shard_summary.argtypes = [vp, C.POINTER(abi.ShardInfoStruct)]
         lib.rsqc_reduce_peer.argtypes = [vp, vp]
         lib.rsqc_reduce_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+        lib.rsqc_group_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        lib.rsqc_group_reduce.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.rsqc_group_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
+        lib.rsqc_group_destroy.argtypes = [vp]; lib.rsqc_group_destroy.restype = None
         lib.rsqc_refresh_results.argtypes = [vp, C.POINTER(abi.ResultsStruct)]
         lib.rsqc_finalize_device.argtypes = [vp]
         lib.rsqc_host_alloc.argtypes = [C.c_size_t]; lib.rsqc_host_alloc.restype = vp
@@ -70,7 +74,8 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rsqc_create", "rsqc_destroy", "rsqc_set_annotation", "rsqc_set_bed", "rsqc_set_reference", "rsqc_submit", "rsqc_wait",
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
-    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_reduce_group", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
+    "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_reduce_group",
+    "rsqc_group_create", "rsqc_group_reduce", "rsqc_group_info", "rsqc_group_destroy", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
     "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
     "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end",
 ]
@@ -251,6 +256,32 @@ class Engine:
         used = C.c_int(0)
         engines[0]._check(engines[0]._l.rsqc_reduce_group(arr, len(engines), C.byref(used)))
         return bool(used.value)
+
+    class Group:
+        """rsqc_group_*: the exchange group of a sharded run, its RCCL communicators made once (any time after the contexts
+        exist) and reused by every reduce()."""
+
+        def __init__(self, engines):
+            self._engines = list(engines)
+            self._l = engines[0]._l
+            arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+            h = C.c_void_p()
+            engines[0]._check(self._l.rsqc_group_create(arr, len(engines), C.byref(h)))
+            self._g = h
+
+        def info(self):
+            uses, init_ms, red_ms, note = C.c_int(), C.c_double(), C.c_double(), C.c_char_p()
+            self._l.rsqc_group_info(self._g, C.byref(uses), C.byref(init_ms), C.byref(red_ms), C.byref(note))
+            return dict(uses_rccl=bool(uses.value), init_ms=init_ms.value, last_reduce_ms=red_ms.value, note=(note.value or b"").decode())
+
+        def reduce(self) -> bool:
+            used = C.c_int(0)
+            self._engines[0]._check(self._l.rsqc_group_reduce(self._g, C.byref(used)))
+            return bool(used.value)
+
+        def close(self):
+            if self._g:
+                self._l.rsqc_group_destroy(self._g); self._g = None
 
     def refresh_results(self, lazy: bool = False) -> abi.Results:
         rs = abi.ResultsStruct()

@@ -83,7 +83,7 @@ def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True):
     if rc:
         raise RuntimeError("k1emu rc=%d" % rc)
     o.read_length = rl.value
-    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]); o.n_pairs = int(stats[2])
+    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]); o.n_pairs = int(stats[2]); o.n_coarse = int(stats[3])
     return o
 
 

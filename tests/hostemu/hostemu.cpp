@@ -76,7 +76,7 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
     std::vector<EiRank> rank;
     hx.build_rank(rank);
-    d.ei = hx.ei.data(); d.ei_rank = rank.data();
+    d.ei = hx.ei.data(); d.ei_rank = rank.data(); d.ei_coarse = hx.ei_coarse.data();
     std::vector<double> exon_ids((size_t)a->n_exons, 0.0);       // by exon id (the elementary-interval stage commits by id)
     DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags,
                  p->legacy ? 1 : 0};

@@ -57,7 +57,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     d.ex = hx.ex_rows.data(); d.gb = hx.gb.data(); d.ex_pmax = hx.ex_pmax.data();
     d.ex_binhi = hx.ex_binhi.data(); d.gb_bin = hx.gb_bin.data(); d.ex_cov = hx.ex_cov.data();
     std::vector<EiRank> rank; hx.build_rank(rank);
-    d.ei = hx.ei.data(); d.ei_rank = rank.data();
+    d.ei = hx.ei.data(); d.ei_rank = rank.data(); d.ei_coarse = hx.ei_coarse.data();
     std::vector<uint32_t> ex_id(a->exon_row_id, a->exon_row_id + a->n_exons); if (ex_id.empty()) ex_id.push_back(0);
     d.ex_id = ex_id.data();
     std::vector<uint32_t> zero_range((size_t)a->n_contigs + 1, 0);
@@ -100,7 +100,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     acc.rl_stats = rl_stats.data(); acc.read_length = &rl_state; acc.error = &error;
 
     const K1Args A{d, dp, db, acc};
-    g_k1e_args = &A;
+    g_k1e_args = &A; g_k1e_coarse_hits = 0;
     wavemu::grid_dim().x = (uint32_t)grid;
     for (int k = 0; k < grid; ++k) {
         wavemu::block_idx().x = (uint32_t)k;
@@ -255,6 +255,6 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e] + exon_acc[a->exon_row_id[e]];
     *read_length = (int32_t)rl;
     if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
-    stats[0] = n_overflow; stats[1] = listed; stats[2] = n_pairs; stats[3] = 0;
+    stats[0] = n_overflow; stats[1] = listed; stats[2] = n_pairs; stats[3] = g_k1e_coarse_hits;
     return 0;
 }

@@ -232,6 +232,69 @@ def test_group_reduce_rccl_and_peer_paths(oracle_lib):
         e0.close(); e1.close()
 
 
+@pytest.mark.gpu
+def test_group_handle_reused_across_steps(oracle_lib):
+    """rsqc_group_create / rsqc_group_reduce / rsqc_group_destroy: the communicators are made once, BEFORE the contexts hold an
+    annotation, and serve several end-of-file exchanges (reset between them); the one-rank group takes the RCCL path, a group of
+    two contexts on one device is still a valid group (peer copies) and says why."""
+    ann, batch = small_inputs(n_pairs=6000)
+    p = abi.default_params()
+    whole = oracle_lib.run_oracle(p, ann, [batch])
+    e = engine.Engine(p)
+    g = engine.Engine.Group([e])                                  # before set_annotation: the group only needs the devices
+    try:
+        info = g.info()
+        assert info["uses_rccl"] and info["init_ms"] >= 0.0
+        e.set_annotation(ann)
+        for _ in range(2):
+            e.reset(); e.submit(batch); e.wait(); e.finalize_device()
+            assert g.reduce() is True
+            assert_results_match(e.refresh_results(), whole)
+        assert g.info()["last_reduce_ms"] > 0.0
+    finally:
+        g.close(); e.close()
+    e0, e1 = engine.Engine(p), engine.Engine(p)
+    g = engine.Engine.Group([e0, e1])
+    try:
+        info = g.info()
+        assert not info["uses_rccl"] and "share a device" in info["note"]
+    finally:
+        g.close(); e0.close(); e1.close()
+
+
+@pytest.mark.gpu
+def test_group_reduce_on_two_devices(oracle_lib):
+    """The N >= 2 RCCL branch on REAL devices: two contexts on two GPUs sharded by contig, communicators from ncclCommInitAll,
+    grouped ncclReduce onto the first.  Runs wherever the box has two GPUs (hipGetDeviceCount() >= 2); the 1-GPU boxes skip it."""
+    ann, batch = small_inputs(n_pairs=8000)
+    p = abi.default_params()
+    whole = oracle_lib.run_oracle(p, ann, [batch])
+    tid = batch.tid_per_record()
+    a_end = int(np.searchsorted(tid, 1))
+    p0, p1 = abi.default_params(), abi.default_params()
+    p0.device, p1.device = 0, 1
+    e0 = engine.Engine(p0)
+    try:
+        e1 = engine.Engine(p1)                                    # rsqc_create on device 1: fails on a one-GPU box
+    except engine.EngineError:
+        e0.close()
+        pytest.skip("needs two GPUs (hipGetDeviceCount() < 2 here)")
+    g = engine.Engine.Group([e0, e1])
+    try:
+        assert g.info()["uses_rccl"], g.info()
+        e0.set_annotation(ann, np.array([1, 0, 0], np.uint8)); e1.set_annotation(ann, np.array([0, 1, 1], np.uint8))
+        e0.submit(batch.slice(0, a_end)); e1.submit(batch.slice(a_end, batch.n)); e0.wait(); e1.wait()
+        e0.finalize_device(); e1.finalize_device()
+        assert g.reduce() is True
+        got = e0.refresh_results()
+        np.testing.assert_array_equal(got.gene_reads, whole.gene_reads)
+        np.testing.assert_array_equal(got.gene_fragments, whole.gene_fragments)
+        np.testing.assert_array_equal(got.counters, whole.counters)
+        np.testing.assert_allclose(got.exon_reads, whole.exon_reads, rtol=1e-9, atol=1e-6)
+    finally:
+        g.close(); e0.close(); e1.close()
+
+
 def test_chr1_scale_million_reads(oracle_lib):
     ann = synth.make_annotation(seed=1)                       # chr1-like: 5 234 genes
     batch = synth.make_reads(ann, 500_000, seed=2)
