@@ -376,12 +376,17 @@ def main():
         achieved = bytes_per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         # HBM traffic of K1 per launch comes from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE and WRITE_SIZE cannot share a pass); tools/pmc.sh stores them in profiles/k1_traffic.json
-        traffic = None
+        traffic = None; traffic_note = None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
+            from rnaseqc_amd.hostinfo import k1_code_hash
+            # (the figure is only valid for the code it was measured on: the file carries the hash of the kernel's sources)
             if int(tj.get("records") or 0) == int(n_local) and int(tj.get("genes") or 0) == int(ann.n_genes):
-                traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("k1_code_hash") == k1_code_hash():
+                    traffic = tj.get("hbm_bytes_per_launch")
+                else:
+                    traffic_note = "profiles/k1_traffic.json was measured on other K1 code (hash %s, now %s): dropped" % (tj.get("k1_code_hash"), k1_code_hash())
         cpu = None
         if args.cpu_sample > 0 and world == 1 and batch is not None:          # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             from oracle import binding
@@ -435,12 +440,16 @@ def main():
                        "sharding": "by contig, LPT on record counts" if world > 1 else "none (one GPU holds every contig)",
                        "collective": ("RCCL all_reduce(sum) of i64[3G+%d+2G] + f64[2E+3G] + u8[G+E] per step" % abi.N_COUNTERS) if reduce_path else "none"},
             "roofline": {"bound": "hbm", "kernel": "classify_ei_kernel" if not args.legacy else "classify_count_kernel_legacy + classify_slow_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": k1_ms,
                          "timer": "hipEvents around the launch on the context's stream (rsqc_get_timing), rank 0"},
             "cpu_baseline": cpu,
             "whole_node": None if not e2e or "value" not in e2e else {
                 "value": e2e["value"], "unit": "reads/s", "n_gpus": e2e.get("gpus", 1), "parity": e2e.get("parity"),
+                # the same run by the driver's clock: records / wall time of the whole `rnaseqc` process (GTF parse, GPU start-up, BAM
+                # loop, report files, exit) -- `value` is the reference's own `Average Reads/Sec` window, a part of that process
+                "wall_value": (e2e["alignments"] / e2e["wall_s"]) if e2e.get("alignments") and e2e.get("wall_s") else None,
+                "wall_s": e2e.get("wall_s"), "bam_loop_s": e2e.get("bam_loop_s"),
                 "realistic_entropy_value": (e2e.get("realistic_entropy") or {}).get("value"),
                 "realistic_entropy_parity": (e2e.get("realistic_entropy") or {}).get("parity"),
                 "note": "`rnaseqc gtf bam out` on a BAM of the same records: BGZF inflate + BAM parse on the GPU + the hot path + end-of-file stage; details in end_to_end"},

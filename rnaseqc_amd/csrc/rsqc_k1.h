@@ -29,7 +29,7 @@ namespace rsqc {
 // in flight, the record words staged for the next tile and the previous tile's atomics included.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define K1E_LANDED(x) asm volatile("" : "+v"(x))
-#ifndef K1E_NO_PIN
+#ifdef K1E_PIN_ARGS                                      /* (A/B build; measured 1-2 % slower: the pinned scalars are spilled to VGPR lanes instead) */
 #define K1E_PIN(x) asm volatile("" : "+s"(x))            /* a wave-uniform value the compiler may not re-derive: it stays in SGPRs */
 #else
 #define K1E_PIN(x) (void)(x)                             /* (A/B build) */
@@ -71,6 +71,17 @@ __device__ __forceinline__ void k1e_load_cigar8(const uint32_t *cigar, uint32_t 
     for (int k = 0; k < 4; ++k) { c[k] = lo.v[k]; c[4 + k] = hi.v[k]; }
 }
 
+// (instruction-count experiments, `make variant DEFS=-DK1E_STOP_AT=<mark>`: phase A ends at that section mark with its results
+//  kept alive, no feature stage -- wrong results by design, never in the product build)
+#if defined(K1E_STOP_AT) && defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ int k1e_keep_v(T x) { asm volatile("" :: "v"(x)); return 0; }
+template <class T> __device__ __forceinline__ int k1e_keep_s(T x) { asm volatile("" :: "s"(x)); return 0; }
+template <class... T> __device__ __forceinline__ void k1e_sink_v(T... x) { const int d[] = {k1e_keep_v(x)...}; (void)d; }
+template <class... T> __device__ __forceinline__ void k1e_sink_s(T... x) { const int d[] = {k1e_keep_s(x)...}; (void)d; }
+#define K1E_STOP(n, V, S) if (K1E_STOP_AT == (n)) { k1e_sink_v V; k1e_sink_s S; break; }
+#else
+#define K1E_STOP(n, V, S)
+#endif
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
 #ifndef K1E_PIECE_RECORDS
 #define K1E_PIECE_RECORDS 256
@@ -180,13 +191,13 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
         // of a run of equal keys adds for the whole run (64 LDS atomics on one address take 64 passes of the LDS, one takes one).
         // One-block records add exactly 1 each, so their runs need no sum; fractions of longer records go lane by lane.
         if (NB == 1) {
-            const Run r = make_run(hvm, eo.eid[k]);
+            const RunLite r = make_run_lite(hvm, eo.eid[k]);
             if (r.head && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)r.count);
             // a one-block record that commits slot 0 is counted to that exon's gene (hit[0], see exon_metrics_ei: the first gene of
             // the set is the gene of the block's first containing exon): the exon's run serves the gene counters too
             if (k == 0) {
                 const uint64_t nd = hvm & notdup;
-                if (r.head && !(K1E_ABL & 2)) T.gene_add(eo.hit[0], r.count, (uint32_t)__popcll(nd & r.mask));
+                if (r.head && !(K1E_ABL & 2)) T.gene_add(eo.hit[0], r.count, run_popcount(nd, r.count));
             }
         } else if (hv && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)ln * inv_aligned);
         const uint32_t base = hv ? eo.cidx[k] : 0u;
@@ -213,9 +224,9 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             }
         }
         if (NB > 1 || k > 0) {
-            const Run r = make_run(m, g);
+            const RunLite r = make_run_lite(m, g);
             const uint64_t nd = m & notdup;
-            if (r.head && !(K1E_ABL & 2)) T.gene_add(g, r.count, (uint32_t)__popcll(nd & r.mask));
+            if (r.head && !(K1E_ABL & 2)) T.gene_add(g, r.count, run_popcount(nd, r.count));
         }
     }
 }
@@ -477,8 +488,15 @@ classify_ei_kernel(K1Args A) {
                                                                           // interval that covers the 1024 breakpoint-free positions around its start
     const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
     const uint32_t *const core1 = reinterpret_cast<const uint32_t *>(b.core);
-    if (w0 != NONE && w0 + (uint32_t)l < wend) { cur_cv = ld32(core4 + w0, (uint32_t)l); cur_av = ld32(aux4 + w0, (uint32_t)l); }
-    if (w1 != NONE && w1 + (uint32_t)l < wend) nx_co = ld32(core1 + 4 * (size_t)w1, 4u * (uint32_t)l + 3u);
+    // Staged loads are UNCONDITIONAL: a lane past the end of the range (or a wave without a next tile) reads the batch's last
+    // record instead and is switched off by `valid` -- zeroing nine registers and branching around every load cost more than
+    // the ignored load (the kernel is not launched on an empty batch).
+    const uint32_t last_rec = n_rec - 1u;
+    // (addresses stay scalar base + 32-bit lane offset: the tile's first record, then min(lane, records left - 1))
+    auto tile_base = [&](uint32_t w) -> uint32_t { return w == NONE ? 0u : w; };
+    auto lane_off = [&](uint32_t wb) -> uint32_t { const uint32_t left = last_rec - wb; return (uint32_t)l < left ? (uint32_t)l : left; };
+    { const uint32_t wb = tile_base(w0), lo = lane_off(wb); cur_cv = ld32(core4 + wb, lo); cur_av = ld32(aux4 + wb, lo); }
+    { const uint32_t wb = tile_base(w1); nx_co = ld32(core1 + 4 * (size_t)wb, 4u * lane_off(wb) + 3u); }
     k1e_load_cigar8(cigar_pool, (uint32_t)cur_cv.w, cg);
     // (the wait of the first tile's words sits here, not in the loop: the compiler places a wait where ANY path into an
     //  instruction has the load pending, and a wait inside the loop is executed by every tile)
@@ -496,13 +514,14 @@ classify_ei_kernel(K1Args A) {
         }
         const bool mixed = seg_next != NONE && seg_next - w0 < 64u;           // a contig boundary inside the tile
         // ---- the next tile's words start their trip now -----------------------------------------------------------------
-        int4 n_cv = zero4, n_av = zero4; uint32_t n_cg[8]; uint32_t n_co = 0;
-        if (w1 != NONE && w1 + (uint32_t)l < wend) { n_cv = ld32(core4 + w1, (uint32_t)l); n_av = ld32(aux4 + w1, (uint32_t)l); }
+        int4 n_cv, n_av; uint32_t n_cg[8]; uint32_t n_co;
+        { const uint32_t wb = tile_base(w1), lo = lane_off(wb); n_cv = ld32(core4 + wb, lo); n_av = ld32(aux4 + wb, lo); }
         k1e_load_cigar8(cigar_pool, nx_co, n_cg);
-        if (w2 != NONE && w2 + (uint32_t)l < wend) n_co = ld32(core1 + 4 * (size_t)w2, 4u * (uint32_t)l + 3u);
+        { const uint32_t wb = tile_base(w2); n_co = ld32(core1 + 4 * (size_t)wb, 4u * lane_off(wb) + 3u); }
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
         RSQC_MARK(1);
+        do {                                                  // (K1E_STOP leaves through `break`)
         Record r; uint32_t cur_cigar_off;
         {
             const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
@@ -529,15 +548,18 @@ classify_ei_kernel(K1Args A) {
         const WB lane_on = WS::prim(valid) && !WS::prim(bad_wide != 0u);
         if (!WS::lane(lane_on)) r.n_cigar = 0;
         RSQC_MARK(2);
+        K1E_STOP(2, (r.pos, r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off), (lane_on.m))
         Walk2 w2;
         k1e_walk(r.pos, r.n_cigar, cg, r.cigar, w2);
         RSQC_MARK(3);
+        K1E_STOP(3, (r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off, w2.ref_len, w2.nb, w2.bad, w2.bs0, w2.bs1, w2.len0, w2.len1), (lane_on.m))
         const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: k1e_process_long
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad != 0u;
         RecordCounters rc; WB hq = lane_on;
         const WB go = gate_cascade_b<false, WaveSink, true>(a, p, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
         RSQC_MARK(4);
+        K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
         if (a.have_bed && rc.frag_candidate) {                // src/RNASeQC.cpp:372
             const K1Args *q = k1e_lazy_args();
             const int32_t name = bed_interval_of(q->a, r);
@@ -566,6 +588,7 @@ classify_ei_kernel(K1Args A) {
             l_lmin = (rc.rl_eligible && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
         }
         RSQC_MARK(5);
+        K1E_STOP(5, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, cnt.vec), (go.m, hq.m, big_any.m))
         const uint32_t flhq = r.flag | (WS::lane(hq) ? K1E_HQ : 0u);
         // ---- sort by shape ------------------------------------------------------------------------------------------
         // (stragglers of a boundary tile take the general code, which finds their contig itself; for one with a long CIGAR it
@@ -582,6 +605,14 @@ classify_ei_kernel(K1Args A) {
             const WB none = simple && nb0;
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
         }
+        RSQC_MARK(6);
+        // ---- the staged words have landed (see above).  The wait sits HERE, in front of the queue writes: the coarse word of
+        //      this tile's records (loaded a tile ago, i.e. older than the staged words) is then complete without a wait of its
+        //      own -- a wait anywhere earlier in phase A would also wait for the previous feature stage's atomics ---------------
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
+        asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
+#endif
         // one-block records whose length fits the queue's 16 bits (a longer block -- never seen in RNA-seq -- takes the long-CIGAR stage)
         const WB fits = WS::prim(w2.len0 < 65536u);
         const uint64_t m1 = (simple && nb1 && fits).m, m2 = (simple && nb2).m, m3 = (listed || (simple && nb1 && !fits)).m;
@@ -601,18 +632,14 @@ classify_ei_kernel(K1Args A) {
         __builtin_amdgcn_wave_barrier();                     // the queue entries are read by OTHER lanes of the wave (no instruction: an ordering point)
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || WS::any(big_any)) flush_counts();
-        RSQC_MARK(6);
-        // ---- the staged words have landed (see above): from here on they are the current tile ----------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
-        asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
-#endif
+        } while (0);
+        RSQC_MARK(7);
         cur_cv = n_cv; cur_av = n_av; nx_co = n_co;
         // the next tile's positions are here: its coarse-table words start their trip now and are looked at when that tile sorts
         // its records by shape, a feature stage and most of a phase A later (a read in an empty stretch of the genome then needs
         // no rank word).  Not across a contig boundary: the table is addressed through THIS tile's contig.
         cur_cz = 0u;
-#ifndef K1E_NO_COARSE                                /* (A/B build without the coarse table) */
+#ifdef K1E_COARSE                                    /* opt-in build: -0.7 GB of HBM traffic per 102 M records, +3 % time (profiles/r4_k1_variants.txt) */
         if (!(w1 == NONE || seg_next <= w1) && u_ci.rk_words != 0u) {
             const int32_t top = (int32_t)(u_ci.rk_words << 6) - 1;
             const int32_t x = n_cv.x + 1, xc = x < 0 ? 0 : (x > top ? top : x);
@@ -621,7 +648,6 @@ classify_ei_kernel(K1Args A) {
 #endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) cg[k] = n_cg[k];
-        RSQC_MARK(7);
         // ---- a full tile of one shape: its feature stage.  The queues are emptied before the stream leaves the contig
         //      (the queued records belong to it) and at the end of the range ------------------------------------------------
         const bool leaving = w1 == NONE || seg_next <= w1;    // (NONE is the largest index)             // the wave's next tile lies in another segment (or there is none)

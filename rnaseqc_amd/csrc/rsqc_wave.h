@@ -124,6 +124,44 @@ __device__ __forceinline__ Run make_run(uint64_t vmask, uint32_t key) {
     return r;
 }
 __device__ __forceinline__ Run make_run(bool valid, uint32_t key) { return make_run(WaveSink::prim(valid).m, key); }
+
+// The same runs for callers that need only the LENGTH of the run at its first lane (the per-record kernel's commit: one add of
+// `count` per run).  make_run builds the run's end and lane mask from 64-bit per-lane shifts, subtractions and selects -- about
+// 35 vector instructions, and the commit of ONE slot called it three times (exon, coverage +1, coverage -1).  Here the lanes
+// that CONTINUE a run are a scalar mask, and a first lane counts the consecutive continuing lanes above it:
+//     cont  = lanes whose key equals the key of the (valid) lane below            (one DPP move, one compare, scalar ands)
+//     count = 1 + trailing ones of (cont >> (lane + 1))                           (one 64-bit shift, two nots, two ffbl, min, adds)
+struct RunLite { bool head; uint32_t count; };
+__device__ __forceinline__ uint64_t run_cont_mask(uint64_t vmask, uint32_t key) {
+    const uint32_t pk = lane_below(key);
+    return vmask & (vmask << 1) & ~WaveSink::prim(pk != key).m;      // (lane 0 has nothing below: bit 0 of vmask << 1 is 0)
+}
+__device__ __forceinline__ uint32_t run_length_at(uint64_t cont) {   // for a first lane: lanes of its run
+    const uint64_t t = (cont >> 1) >> (uint32_t)lane_id();           // bit 0: does lane + 1 continue?  (bit 63 of cont >> 1 is 0: the count ends)
+    const uint32_t lo = ~(uint32_t)t, hi = ~(uint32_t)(t >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t a, fh;
+    asm("v_ffbl_b32 %0, %1" : "=v"(a) : "v"(lo));                    // index of the lowest set bit, 0xFFFFFFFF for 0
+    asm("v_ffbl_b32 %0, %1" : "=v"(fh) : "v"(hi));
+    const uint32_t b2 = 32u + fh;
+#else
+    const uint32_t a = lo ? (uint32_t)__builtin_ctz(lo) : 0xFFFFFFFFu, b2 = 32u + (hi ? (uint32_t)__builtin_ctz(hi) : 0xFFFFFFFFu);
+#endif
+    return 1u + (a < b2 ? a : b2);
+}
+__device__ __forceinline__ RunLite make_run_lite(uint64_t vmask, uint32_t key) {
+    const uint64_t cont = run_cont_mask(vmask, key);
+    RunLite r;
+    r.head = WaveSink::lane(LaneMask{vmask & ~cont});
+    r.count = run_length_at(cont);
+    return r;
+}
+// lanes of `m` among the `count` lanes that start at this lane (count <= 64 - lane)
+__device__ __forceinline__ uint32_t run_popcount(uint64_t m, uint32_t count) {
+    const uint64_t t = m >> (uint32_t)lane_id();
+    const uint64_t keep = count >= 64u ? ~0ull : ((1ull << count) - 1ull);
+    return (uint32_t)__popcll(t & keep);
+}
 // sum of v over the run that starts at this (head) lane
 __device__ __forceinline__ double run_sum_f64(double v, const Run &r) {
     const int l = lane_id();
@@ -148,13 +186,12 @@ __device__ __forceinline__ uint32_t run_sum_u32(uint32_t v, const Run &r) {
 // Most tiles have no two neighbouring lanes on the same slot: one shuffle and one ballot decide that, and only
 // then is the run structure built.
 __device__ __forceinline__ void cov_add_merged(uint32_t *cov, uint64_t vmask, uint32_t idx, uint32_t sign) {
-    const uint32_t pidx = lane_below(idx);
-    const uint64_t dupm = vmask & (vmask << 1) & WaveSink::prim(pidx == idx).m;      // a lane on the slot of the lane below it
-    if (__popcll(dupm) < RSQC_COV_MERGE_MIN) {
+    const uint64_t cont = run_cont_mask(vmask, idx);                 // a lane on the slot of the lane below it
+    if (__popcll(cont) < RSQC_COV_MERGE_MIN) {
         if (WaveSink::lane(LaneMask{vmask})) atomicAdd(&cov[idx], sign);
     } else {
-        const Run r = make_run(vmask, idx);
-        if (r.head) atomicAdd(&cov[idx], sign * r.count);
+        const uint32_t n = run_length_at(cont);
+        if (WaveSink::lane(LaneMask{vmask & ~cont})) atomicAdd(&cov[idx], sign * n);
     }
 }
 __device__ __forceinline__ void cov_add_merged(uint32_t *cov, bool valid, uint32_t idx, uint32_t sign) {

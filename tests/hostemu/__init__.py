@@ -50,22 +50,26 @@ def run(params, ann, batch, mode=1, want_cov=False):
 
 
 _K1SO = os.path.join(_HERE, "libk1emu.so")
+_K1SO_DEFAULT = os.path.join(_HERE, "libk1emu_default.so")
 
 
-def build_k1():
+def build_k1(coarse=True):
+    """coarse=True: the kernel with its opt-in coarse-table path compiled in (-DK1E_COARSE: a superset of the default code, so the
+    suite exercises both look-up paths); coarse=False: the product's default configuration."""
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
+    so = _K1SO if coarse else _K1SO_DEFAULT
     srcs = [os.path.join(_HERE, "k1_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
            [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_k1s.h", "rsqc_kr.h", "rsqc_k4.h", "rsqc_wave.h", "rsqc_device.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
-    if not os.path.exists(_K1SO) or any(os.path.getmtime(_K1SO) < os.path.getmtime(s) for s in srcs):
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
-                               "-Wno-unused-variable", srcs[0], "-o", _K1SO])
-    return _K1SO
+                               "-Wno-unused-variable"] + (["-DK1E_COARSE"] if coarse else []) + [srcs[0], "-o", so])
+    return so
 
 
-def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True):
+def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=True):
     """The per-record KERNELS (rsqc_k1.h) on the 64-lane fiber emulation of wavemu.h, `grid` workgroups of 256 lanes."""
-    lib = C.CDLL(build_k1())
+    lib = C.CDLL(build_k1(coarse))
     a, b = ann.to_struct(), batch.to_struct()
     o = Out()
     G, E = ann.n_genes_listed, ann.n_exons

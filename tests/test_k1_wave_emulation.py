@@ -66,6 +66,17 @@ def test_hostile_annotations(oracle_lib, seed):
             assert o.n_overflow > 0
 
 
+def test_default_build_without_the_coarse_table(oracle_lib):
+    """The product's default configuration (no -DK1E_COARSE: every look-up through the rank words) on the same input."""
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 3_000_000, 300), ("chrB", 1_500_000, 150), ("chrC", 400_000, 0)])
+    batch = synth.make_reads(ann, 6000, seed=4, dup_frac=0.1, contig_lengths=np.array([3_000_000, 1_500_000, 400_000]))
+    p = abi.default_params()
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    o = hostemu.run_k1(p, ann, batch, grid=3, coarse=False)
+    _compare(o, r)
+    assert o.n_coarse == 0
+
+
 def test_small_and_ragged_batches(oracle_lib):
     """Fewer records than lanes, one record, sizes around the tile and queue boundaries, more workgroups than tiles."""
     ann = synth.make_annotation(seed=5, contigs=[("chrA", 400_000, 60), ("chrB", 200_000, 30)])

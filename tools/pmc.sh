@@ -36,7 +36,10 @@ if k1 and all("FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k] for k in k1):
             if line.startswith("{"): cfg = json.loads(line).get("config", {})
     except Exception: pass
     # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE uncalibrated, taken as is
-    out = {"kernel": " + ".join(k1), "records": cfg.get("records"), "genes": cfg.get("genes"), "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
+    import sys
+    sys.path.insert(0, "$GRAFT_REPO_ROOT")
+    from rnaseqc_amd.hostinfo import k1_code_hash
+    out = {"kernel": " + ".join(k1), "k1_code_hash": k1_code_hash(), "records": cfg.get("records"), "genes": cfg.get("genes"), "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_correction": 2.0,
            "hbm_bytes_per_launch": fetch_kb * 1024 * 2.0 + write_kb * 1024,
            "note": "FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; separate --pmc passes"}
     json.dump(out, open("$OUT/k1_traffic.json", "w"), indent=1)
