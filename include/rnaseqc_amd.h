@@ -360,6 +360,8 @@ typedef struct rsqc_timing {
     double   finalize_ms;              /* de-dup + coverage scan/stats + bias           */
     double   h2d_ms;                   /* rsqc_submit host->device copies               */
     uint64_t slow_records;             /* records the general (slow-path) kernel took in the last finalized pass */
+    double   fragment_sizes_ms;        /* --bed runs: the fragment-size stage of the end-of-file passes (host clock around its kernels and its
+                                          two read-backs; src/Expression.cpp:482-540), summed since reset                              */
 } rsqc_timing;
 
 typedef struct rsqc_ctx rsqc_ctx;

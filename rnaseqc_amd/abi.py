@@ -177,7 +177,7 @@ class TimingStruct(C.Structure):
     _fields_ = [
         ("classify_ms", C.c_double), ("classify_launches", C.c_uint64),
         ("classify_records", C.c_uint64), ("classify_bytes", C.c_uint64),
-        ("finalize_ms", C.c_double), ("h2d_ms", C.c_double), ("slow_records", C.c_uint64),
+        ("finalize_ms", C.c_double), ("h2d_ms", C.c_double), ("slow_records", C.c_uint64), ("fragment_sizes_ms", C.c_double),
     ]
 
 

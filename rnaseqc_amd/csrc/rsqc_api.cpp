@@ -685,7 +685,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     // empty BED until rsqc_set_bed
     std::vector<uint32_t> zero_range((size_t)nc + 1, 0);
     UPV(d.bed_range, zero_range);
-    d.bed_start = d.bed_end = d.bed_pmax = nullptr; d.have_bed = 0;
+    d.bed_start = d.bed_end = d.bed_pmax = nullptr; d.bed_binhi = d.bed_bin_base = nullptr; d.have_bed = 0;
     UPA(c->d_ge_off, a->gene_exon_off, (size_t)G + 1);
     UPA(c->d_ge_row, a->gene_exon_row, E);
     UPV(c->d_gene_cov_off, gene_cov_off);
@@ -824,6 +824,23 @@ int rsqc_set_bed(rsqc_ctx *c, const rsqc_bed *bed) {
     if ((rc = upload(c, c->ann_bufs, bed->end, (size_t)n, &c->dann.bed_end))) return rc;
     if ((rc = upload(c, c->ann_bufs, pmax.data(), pmax.size(), &c->dann.bed_pmax))) return rc;
     if ((rc = upload(c, c->ann_bufs, range.data(), range.size(), &c->dann.bed_range))) return rc;
+    {   // bin table (DevAnnotation::bed_binhi): a block's upper bound is one load and a short step down
+        std::vector<uint32_t> bin_base((size_t)nc + 1, 0), binhi;
+        for (int k = 0; k < nc; ++k) {
+            const uint32_t lo = range[(size_t)k], hi = range[(size_t)k + 1];
+            const int32_t top = hi > lo ? std::max(bed->start[hi - 1], 0) : 0;
+            const uint32_t nb = hi > lo ? ((uint32_t)top >> RSQC_BED_BIN_SHIFT) + 1u : 1u;
+            bin_base[(size_t)k + 1] = bin_base[(size_t)k] + nb;
+            uint32_t row = lo;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const int64_t limit = ((int64_t)b + 1) << RSQC_BED_BIN_SHIFT;
+                while (row < hi && (int64_t)bed->start[row] < limit) ++row;
+                binhi.push_back(row);
+            }
+        }
+        if ((rc = upload(c, c->ann_bufs, binhi.data(), binhi.size(), &c->dann.bed_binhi))) return rc;
+        if ((rc = upload(c, c->ann_bufs, bin_base.data(), bin_base.size(), &c->dann.bed_bin_base))) return rc;
+    }
     c->dann.have_bed = 1;
     c->have_bed = true;
     c->frag_remaining = c->params.fragment_samples;
@@ -1045,8 +1062,10 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment-size candidates");
             FragCandidates fc{(uint64_t *)c->frag_arena.col[0].p, (uint64_t *)c->frag_arena.col[1].p, (int32_t *)c->frag_arena.col[2].p,
                               (int32_t *)c->frag_arena.col[3].p, (uint32_t *)c->frag_arena.col[4].p, nullptr, (uint32_t)total};
+            const auto tf0 = std::chrono::steady_clock::now();
             rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
-                                    c->frag_remaining, c->frag_scratch, c->frag_kept);
+                                    c->frag_remaining, c->frag_scratch, c->frag_kept, c->acc.error);
+            c->timing.fragment_sizes_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
         // ---- fragment GC content (--fasta runs): the same mate pairing, no cut-off --------------------------
@@ -1080,7 +1099,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             }
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many GC candidates");
             if (total) {
-                rc = run_gc_content(c->stream, gc, (uint32_t)total, c->dref, (unsigned long long *)c->d_gc_bins.p, c->gc_scratch);
+                rc = run_gc_content(c->stream, gc, (uint32_t)total, c->dref, (unsigned long long *)c->d_gc_bins.p, c->gc_scratch, c->acc.error);
                 if (rc) return fail(c, rc, "GC content stage failed");
             }
             HIP_TRY(c, hipMemcpyAsync(c->h_gc.data(), c->d_gc_bins.p, (RSQC_GC_BINS + 1) * 8, hipMemcpyDeviceToHost, c->stream));

@@ -172,13 +172,15 @@ void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint3
 
 #include <vector>
 namespace rsqc {
-// device scratch of the pairing steps, kept by the context between passes (allocation and release synchronise the device)
+// device scratch of the pairing steps (rsqc_fragsize.hip), kept by the context between passes (allocation and release synchronise
+// the device): k0 / v0 samples (file index, size), k1 / v1 the kept ones, v2 candidate indices bucket by bucket, tmp the bucket
+// counts / offsets / cursors, count the control words, table / out_* the size histogram and its compacted (size, count) pairs
 struct SortScratch { void *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *tmp = nullptr, *count = nullptr;
-                     size_t cap_n = 0, tmp_bytes = 0; uint32_t *h_sizes = nullptr; uint32_t h_cap = 0; };
+                     size_t cap_n = 0, tmp_bytes = 0; uint32_t *table = nullptr, *out_size = nullptr, *out_count = nullptr; };
 void free_sort_scratch(SortScratch &s);
 // leaves the kept samples (first max_samples by file index, unordered) on the device: S.k1 = file index, S.v1 = size, n_kept of them
 int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
-                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining, SortScratch &S, uint32_t &n_kept);
+                       std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining, SortScratch &S, uint32_t &n_kept, int *d_error);
 // --fasta (rsqc_kernels.hip / rsqc_fragsize.hip)
 void launch_gc_pack(hipStream_t s, const uint8_t *ascii, uint64_t len, unsigned long long *words);
 void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R, double *exon_gc);
@@ -186,5 +188,5 @@ void launch_gc_candidates(hipStream_t s, const DevAnnotation &a, const DevParams
                           const GcCandidates &out, int *error);
 // pairs the candidates by QNAME in file order and adds every usable fragment to bins[0..100] (slot 100 = 100 % GC);
 // asynchronous on `stream`
-int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins, SortScratch &scratch);
+int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const DevReference &R, unsigned long long *bins, SortScratch &scratch, int *d_error);
 }

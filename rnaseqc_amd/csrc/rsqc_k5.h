@@ -1,0 +1,185 @@
+// rsqc_k5.h -- K5, device code only: the kernels of the fragment-size sampler (src/Expression.cpp:482-540) and of the mate pairing
+// of the fragment GC statistics (src/Expression.cpp:459-477).  Included by rsqc_fragsize.hip (which holds the description and
+// the host side) and, unmodified, by the host SIMT emulation of the tests (tests/hostemu/k5_emu.cpp).
+#pragma once
+
+namespace rsqc {
+
+constexpr uint32_t PB_MEAN = 512;            // candidates per bucket on average (the name hashes are fmix64 outputs: Poisson)
+constexpr uint32_t PB_CAP = 2048;            // LDS slots of the per-bucket sort; a fuller bucket reports RSQC_ERR_CAPACITY
+constexpr int PB_THREADS = 256;
+constexpr uint32_t SIZE_TABLE = 1u << 20;    // direct histogram of |isize| below this; larger values are listed
+
+__device__ __forceinline__ uint32_t pair_bucket_of(uint64_t qhash, uint32_t n_buckets) {
+    return (uint32_t)(((qhash >> 32) * (uint64_t)n_buckets) >> 32);
+}
+__global__ void pair_bucket_count_kernel(const uint64_t *qhash, uint32_t n, uint32_t n_buckets, uint32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&count[pair_bucket_of(qhash[i], n_buckets)], 1u);
+}
+// exclusive sums of the bucket counts (one workgroup; n_buckets is a few thousand); off[n_buckets] = n; cursors = offsets
+__global__ void __launch_bounds__(1024) pair_bucket_scan_kernel(const uint32_t *count, uint32_t n_buckets, uint32_t *off, uint32_t *cursor, int *error) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n_buckets + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < n_buckets ? lo + per : n_buckets;
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; ++b) { s += count[b]; if (count[b] > PB_CAP) atomicExch(error, RSQC_ERR_CAPACITY); }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t t = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t b = lo; b < hi; ++b) { off[b] = run; cursor[b] = run; run += count[b]; }
+    if (threadIdx.x == 1023) off[n_buckets] = part[1023];
+}
+__global__ void pair_bucket_scatter_kernel(const uint64_t *qhash, uint32_t n, uint32_t n_buckets, uint32_t *cursor, uint32_t *perm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[atomicAdd(&cursor[pair_bucket_of(qhash[i], n_buckets)], 1u)] = i;
+}
+
+// The candidates of one bucket in LDS, ordered by (name hash, file index).  Returns the bucket's size (0 when it overflowed:
+// the scan kernel has raised the error).  Slots behind the bucket's entries hold the largest key and sort to the end.
+struct PairBucket { uint64_t q[PB_CAP], f[PB_CAP]; uint32_t e[PB_CAP]; };
+__device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint64_t *qhash, const uint64_t *file_index, const uint32_t *off, const uint32_t *perm) {
+    const uint32_t lo = off[blockIdx.x], m = off[blockIdx.x + 1] - lo;
+    if (m == 0 || m > PB_CAP) return 0u;
+    uint32_t slots = 2;
+    while (slots < m) slots <<= 1;
+    for (uint32_t i = threadIdx.x; i < slots; i += PB_THREADS) {
+        if (i < m) { const uint32_t c = perm[lo + i]; S.q[i] = qhash[c]; S.f[i] = file_index[c]; S.e[i] = c; }
+        else { S.q[i] = ~0ull; S.f[i] = ~0ull; S.e[i] = 0xFFFFFFFFu; }
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= slots; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < slots; i += PB_THREADS) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const bool up = (i & k) == 0;
+                    const uint64_t qi = S.q[i], qx = S.q[x], fi = S.f[i], fx = S.f[x];
+                    const bool greater = qi > qx || (qi == qx && fi > fx);
+                    if (greater == up) { S.q[i] = qx; S.q[x] = qi; S.f[i] = fx; S.f[x] = fi; const uint32_t t = S.e[i]; S.e[i] = S.e[x]; S.e[x] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    return m;
+}
+
+// src/Expression.cpp:511-538 for every name of the bucket
+__global__ void __launch_bounds__(PB_THREADS)
+frag_replay_kernel(const FragCandidates c, const uint32_t *off, const uint32_t *perm, uint64_t *sample_file, uint32_t *sample_size, uint32_t *n_samples) {
+    __shared__ PairBucket S;
+    const uint32_t m = pair_bucket_sorted(S, c.qhash, c.file_index, off, perm);
+    for (uint32_t j = threadIdx.x; j < m; j += PB_THREADS) {
+        const uint64_t q = S.q[j];
+        if (j > 0 && S.q[j - 1] == q) continue;              // not the first record of its name
+        bool pending = false; int32_t p_name = 0, p_end = 0;
+        for (uint32_t k = j; k < m && S.q[k] == q; ++k) {
+            const uint32_t e = S.e[k];
+            const int32_t name = c.name[e], endpos = c.endpos[e];
+            if (!pending) { pending = true; p_name = name; p_end = endpos; }            // :512-516
+            else if (name == p_name) {                                                  // :517
+                const uint32_t fs = c.flag_size[e];
+                if (!(fs >> 31) || endpos <= p_end) continue;                            // :528 (the entry stays)
+                const uint32_t slot = atomicAdd(n_samples, 1u);
+                sample_file[slot] = S.f[k]; sample_size[slot] = fs & 0x7FFFFFFFu;        // :530
+                pending = false;                                                        // :531
+            }
+        }
+    }
+}
+
+#if defined(__HIPCC__)   /* (needs the G/C bit helpers of rsqc_device.h, device build only) */
+// src/Expression.cpp:461-476 for every name of the bucket.  Real fragments pile up in a dozen neighbouring bins, i.e. in two
+// cache lines: memory-side atomics on them serialise; the histogram is kept per workgroup in LDS and flushed once.
+__global__ void __launch_bounds__(PB_THREADS)
+gc_replay_kernel(const GcCandidates c, const uint32_t *off, const uint32_t *perm, const DevReference R, unsigned long long *bins) {
+    __shared__ PairBucket S;
+    __shared__ uint32_t hist[RSQC_GC_BINS + 1];
+    for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += PB_THREADS) hist[i] = 0u;
+    const uint32_t m = pair_bucket_sorted(S, c.qhash, c.file_index, off, perm);        // (ends with a barrier when m > 0)
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < m; j += PB_THREADS) {
+        const uint64_t q = S.q[j];
+        if (j > 0 && S.q[j - 1] == q) continue;
+        bool pending = false; uint32_t p_row = 0; int32_t p_end = 0;
+        for (uint32_t k = j; k < m && S.q[k] == q; ++k) {
+            const uint32_t e = S.e[k];
+            const uint32_t row = c.row[e]; const int32_t endpos = c.endpos[e];
+            if (!pending) { pending = true; p_row = row; p_end = endpos; }              // :462-466
+            else if (row == p_row) {                                                    // :467
+                const uint32_t fl = c.flag_lq[e];
+                if (endpos <= p_end || !(fl >> 31)) continue;                            // :471 (the entry stays)
+                pending = false;                                                        // erase, :474
+                const int tid = c.tid[e];
+                const int64_t L = (int64_t)R.length[tid];
+                int64_t s = (int64_t)p_end - (int64_t)(fl & 0x7FFFFFFFu), en = endpos;  // getSeq(chr, stored end - Length(), PositionEnd()) :473
+                if (s < 0 || s >= L) continue;               // outside the contig: error paths of the reference, no fragment here
+                if (en > L) en = L;                          // a page is clipped at the contig end (bioio.hpp:306)
+                if (en <= s) continue;
+                const double v = gc_value(gc_count(R, tid, s, en), (uint64_t)(en - s));
+                const unsigned int bin = (unsigned int)(v * 100.0);                     // src/RNASeQC.cpp:368
+                atomicAdd(&hist[bin < RSQC_GC_BINS ? bin : RSQC_GC_BINS], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += PB_THREADS) if (hist[i]) atomicAdd(&bins[i], (unsigned long long)hist[i]);
+}
+
+#endif
+
+// ---- the N smallest file indices among the samples: radix select, one 8-bit digit per pass ---------------------------------
+// counts, per value of the digit at `shift`, the samples whose higher digits equal those of `prefix`
+__global__ void __launch_bounds__(256) sample_digit_hist_kernel(const uint64_t *v, uint32_t n, int shift, uint64_t prefix, uint32_t *hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t high_mask = shift >= 56 ? 0ull : ~0ull << (shift + 8);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t x = v[i];
+        if ((x & high_mask) == (prefix & high_mask)) atomicAdd(&h[(x >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void sample_keep_kernel(const uint64_t *file, const uint32_t *size, uint32_t n, uint64_t last_kept, uint64_t *kept_file, uint32_t *kept_size, uint32_t *n_kept) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && file[i] <= last_kept) { const uint32_t s = atomicAdd(n_kept, 1u); kept_file[s] = file[i]; kept_size[s] = size[i]; }
+}
+
+// ---- (size, count) pairs, ascending size ------------------------------------------------------------------------------------------
+__global__ void size_hist_kernel(const uint32_t *size, uint32_t n, uint32_t *table, uint32_t *big, uint32_t *n_big) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = size[i];
+    if (s < SIZE_TABLE) atomicAdd(&table[s], 1u);
+    else big[atomicAdd(n_big, 1u)] = s;
+}
+// one workgroup: every thread owns a contiguous stretch of the table, counts its non-empty cells, the counts are scanned and
+// the cells written in order
+__global__ void __launch_bounds__(1024) size_hist_compact_kernel(const uint32_t *table, uint32_t *out_size, uint32_t *out_count, uint32_t *n_out) {
+    __shared__ uint32_t part[1024];
+    constexpr uint32_t PER = SIZE_TABLE / 1024u;
+    const uint32_t lo = threadIdx.x * PER;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < PER; ++k) mine += table[lo + k] ? 1u : 0u;
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t t = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t at = part[threadIdx.x] - mine;
+    for (uint32_t k = 0; k < PER; ++k) { const uint32_t c = table[lo + k]; if (c) { out_size[at] = lo + k; out_count[at] = c; ++at; } }
+    if (threadIdx.x == 1023) *n_out = part[1023];
+}
+
+
+}  // namespace rsqc

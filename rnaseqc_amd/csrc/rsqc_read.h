@@ -136,6 +136,9 @@ struct DevAnnotation {
     // BED rows (sorted by contig,start), optional
     const int32_t  *bed_start, *bed_end, *bed_pmax;
     const uint32_t *bed_range;         // [n_contigs+1]
+    // bins of 2^RSQC_BED_BIN_SHIFT positions per contig: bed_binhi[bed_bin_base[contig] + bin] = first BED row of the contig whose start
+    // >= (bin + 1) << shift (one load and a step or two down instead of a 14-step binary search per block; null = search)
+    const uint32_t *bed_binhi, *bed_bin_base;
     int32_t have_bed;
     const LegacyTables *legacy;        // device copy of the struct above (always built; read under DevParams::legacy)
 };
@@ -243,6 +246,7 @@ struct WaveSink {                              // the same on the host's wave em
 #endif
 #define RSQC_COUNT(sink, c, cond) (sink).template add<(c)>(cond)
 
+constexpr int RSQC_BED_BIN_SHIFT = 12;
 constexpr int FAST_SET = 2;    // genes per block handled on the fast path (registers)
 constexpr int FAST_BLOCKS = 4; // aligned blocks per record on the fast path; more -> slow path
 constexpr int FAST_HITS = 2;   // exons fully containing one block on the fast path
@@ -1225,7 +1229,14 @@ RSQC_HD int32_t bed_interval_of(const DevAnnotation &a, const Record &r) {
         const uint32_t c = r.cigar[i], op = c & 0xf, len = c >> 4;
         if (cigar_is_block(op)) {
             const int32_t bs = start, be = start + (int32_t)len;
-            uint32_t ub = upper_bound_rows(a.bed_start, lo, hi, be);
+            uint32_t ub;
+            if (a.bed_binhi) {
+                const uint32_t nb = a.bed_bin_base[r.tid + 1] - a.bed_bin_base[r.tid];
+                uint32_t bin = be < 0 ? 0u : (uint32_t)be >> RSQC_BED_BIN_SHIFT;
+                if (bin >= nb) bin = nb - 1u;
+                ub = a.bed_binhi[a.bed_bin_base[r.tid] + bin];
+                while (ub > lo && a.bed_start[ub - 1] > be) --ub;
+            } else ub = upper_bound_rows(a.bed_start, lo, hi, be);
             int hits = 0; uint32_t hit = 0;
             for (uint32_t k = ub; k > lo;) {
                 --k;

@@ -146,3 +146,25 @@ def run_k3(params, ann, cov_diff, gene_reads, force=0):
     o.rc = rc
     o.classes = [int(x) for x in stats]
     return o
+
+
+_K5SO = os.path.join(_HERE, "libk5emu.so")
+
+
+def build_k5():
+    csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
+    srcs = [os.path.join(_HERE, "k5_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + [os.path.join(csrc, f) for f in ("rsqc_k5.h", "rsqc_device.h", "rsqc_read.h")]
+    if not os.path.exists(_K5SO) or any(os.path.getmtime(_K5SO) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
+                               "-Wno-unused-variable", srcs[0], "-o", _K5SO])
+    return _K5SO
+
+
+def run_k5(seed, n_names, max_samples):
+    """The fragment-size KERNELS (rsqc_k5.h) on the 64-lane fiber emulation against a literal std::map walk in file order.
+    Returns (rc, candidates, samples, kept, distinct sizes)."""
+    lib = C.CDLL(build_k5())
+    lib.k5emu_run.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
+    stats = np.zeros(4, np.uint64)
+    rc = lib.k5emu_run(seed, n_names, max_samples, stats.ctypes.data)
+    return (rc,) + tuple(int(x) for x in stats)

@@ -295,6 +295,22 @@ def test_group_reduce_on_two_devices(oracle_lib):
         g.close(); e0.close(); e1.close()
 
 
+def test_crafted_qname_hash_collision_is_the_documented_identity(oracle_lib):
+    """tests/golden/qname_hash_collision.json through the device: the hot path de-duplicates on the 64-bit name hash of the batch
+    format, so the two colliding names are ONE fragment there (the oracle given the hashes agrees; given the names it counts one
+    more -- DESIGN.md 5).  Everything else of the case is bit-exact."""
+    from tests.test_oracle_semantics import _collision_case
+    import copy
+    _fx, ann, batch = _collision_case()
+    p = abi.default_params()
+    got = engine.run_engine(p, ann, [batch])
+    hashed = copy.copy(batch); hashed.qname = None; hashed.qname_off = None
+    assert_results_match(got, oracle_lib.run_oracle(p, ann, [hashed]))
+    exact = oracle_lib.run_oracle(p, ann, [batch])
+    assert int(exact.gene_fragments[0]) == int(got.gene_fragments[0]) + 1 == 3
+    np.testing.assert_array_equal(got.gene_reads, exact.gene_reads)
+
+
 def test_chr1_scale_million_reads(oracle_lib):
     ann = synth.make_annotation(seed=1)                       # chr1-like: 5 234 genes
     batch = synth.make_reads(ann, 500_000, seed=2)

@@ -1,0 +1,17 @@
+"""The fragment-size KERNELS (rnaseqc_amd/csrc/rsqc_k5.h: partition by name hash, per-bucket LDS bitonic sort + replay of
+src/Expression.cpp:509-538, radix select of the first --fragment-samples samples by file index, size histogram + compaction),
+unmodified, on the 64-lane SIMT emulation for the host (tests/hostemu/wavemu.h) against a literal std::map walk in file order.
+The GPU tests run the same kernels on the device through the C ABI (tests/test_gpu_parity.py, tests/test_gpu_contract.py)."""
+import pytest
+
+from tests import hostemu
+
+
+@pytest.mark.parametrize("seed,n_names,max_samples", [(1, 40, 1000), (2, 3000, 1_000_000), (3, 3000, 700), (4, 9000, 1),
+                                                       (5, 9000, 2500), (6, 1, 10), (7, 700, 0)])
+def test_fragment_size_kernels_vs_literal_walk(seed, n_names, max_samples):
+    rc, n, ns, kept, distinct = hostemu.run_k5(seed, n_names, max_samples)
+    assert rc == 0, rc
+    assert kept == min(ns, max_samples)
+    if n_names >= 700 and max_samples:
+        assert ns > 50 and distinct >= 1

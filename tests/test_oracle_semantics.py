@@ -94,3 +94,41 @@ def test_stranded(oracle_lib):
     assert c["End 1 Sense"] == 0 and c["End 1 Antisense"] == 3   # t1 and k1 (last block touches GB_1) on GB, h1 on GH
     r2 = oracle_lib.run_oracle(abi.default_params(stranded=abi.STRAND_FORWARD), ann, [batch])
     assert list(r2.gene_reads) == [6, 0, 1, 0, 3]
+
+
+def _collision_case():
+    """Two read pairs whose NAMES differ but share their 64-bit rsqc_qname_hash (tests/golden/qname_hash_collision.json, found by
+    tools/qname_collision.c), both counted to the one gene of a one-contig annotation; a third, ordinary pair beside them."""
+    import json
+    import os
+    from rnaseqc_amd.model import Annotation, Batch
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qname_hash_collision.json")))
+    rows = [dict(contig="c", type="gene", start=100, end=5000, strand="+", gene_id="G0"),
+            dict(contig="c", type="exon", start=100, end=5000, strand="+", gene_id="G0", exon_id="E0")]
+    ann = Annotation.from_rows(["c"], rows)
+    M = abi.CIG_M
+    recs = []
+    for k, name in enumerate((fx["a"], fx["b"], "ordinary")):
+        p1, p2 = 200 + 300 * k, 400 + 300 * k
+        recs.append(dict(qname=name, tid=0, pos=p1, cigar=[(M, 100)], flag=99, mapq=255, nm=0, mpos=p2, mtid=0))
+        recs.append(dict(qname=name, tid=0, pos=p2, cigar=[(M, 100)], flag=147, mapq=255, nm=0, mpos=p1, mtid=0))
+    recs.sort(key=lambda r: r["pos"])
+    return fx, ann, Batch.from_records(recs)
+
+
+def test_crafted_qname_hash_collision_fixture(oracle_lib):
+    """The fixture is what it says (two different names, one hash), and it shows what the 64-bit name identity of the batch
+    format means: the oracle counts THREE fragments from the names (the reference's std::set<std::string>,
+    src/Expression.cpp:383-387) and TWO when it is given only the hashes, which is all the device ever sees
+    (include/rnaseqc_amd.h: rsqc_rec_aux::qhash).  DESIGN.md 5 discusses the identity and why it stays a 64-bit hash."""
+    fx, ann, batch = _collision_case()
+    assert fx["a"] != fx["b"]
+    assert abi.qname_hash(fx["a"].encode()) == abi.qname_hash(fx["b"].encode()) == int(fx["hash"], 16)
+    p = abi.default_params()
+    exact = oracle_lib.run_oracle(p, ann, [batch])
+    assert int(exact.gene_reads[0]) == 6 and int(exact.gene_fragments[0]) == 3
+    import copy
+    hashed = copy.copy(batch)
+    hashed.qname = None; hashed.qname_off = None
+    by_hash = oracle_lib.run_oracle(p, ann, [hashed])
+    assert int(by_hash.gene_reads[0]) == 6 and int(by_hash.gene_fragments[0]) == 2
