@@ -513,10 +513,12 @@ typedef struct rsqc_decode_window {    /* what one rsqc_decode_submit decoded (a
     uint64_t n_records;
     uint32_t n_runs;                   /* runs of consecutive records on one reference sequence ...            */
     const int32_t *run_tid;            /* ... their RefIDs, in file order (the batch's contig segments)        */
-    rsqc_batch device_batch;           /* the decoded records as the boundary's SoA batch, every pointer a DEVICE pointer into the
-                                          context's window buffers (valid until its next decode call; n == n_records): what the
-                                          per-read kernels were given -- a host that wants the columns copies them out with
-                                          hipMemcpy after rsqc_wait                                             */
+    rsqc_batch device_batch;           /* NON-PIPELINED streams only (all zero otherwise): the decoded records as the boundary's SoA
+                                          batch, every pointer a DEVICE pointer into the context's window buffers (valid until its
+                                          next decode call; n == n_records): what the per-read kernels were given -- a host that
+                                          wants the columns copies them out with hipMemcpy after rsqc_wait.  A pipelined stream
+                                          returns window n from submit n + 1, which has already queued window n + 1's kernels
+                                          into the same buffers: there is no moment at which the pointers could be read          */
 } rsqc_decode_window;
 typedef struct rsqc_decode_info {
     rsqc_decode_window last;           /* pipelined streams: what the last rsqc_decode_submit decoded            */

@@ -539,7 +539,11 @@ int main(int argc, char **argv) {
                 for (int c2 : sh.contigs) owned_masks[g][(size_t)c2] = 1;
                 owned = owned_masks[g].data();
             }
-            if ((rc = rsqc_set_annotation(sh.gpu, &ann.ann, owned)) != RSQC_OK) { cerr << "Failed to parse the GTF: " << rsqc_last_error(sh.gpu) << endl; return 11; }
+            if ((rc = rsqc_set_annotation(sh.gpu, &ann.ann, owned)) != RSQC_OK) {
+                // (the GTF parsed: this is the device index refusing the annotation -- e.g. an exon outside its gene's row, or no memory
+                //  for the interval tables -- and its own message says which)
+                cerr << "Unable to build the annotation index on the GPU: " << rsqc_last_error(sh.gpu) << endl; return 11;
+            }
             if (o.has_bed && (rc = rsqc_set_bed(sh.gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(sh.gpu) << endl; return 11; }
         }
         std::vector<char> in_fasta;

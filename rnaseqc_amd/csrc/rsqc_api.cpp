@@ -67,7 +67,8 @@ struct PairBuf {                // (gene, qname-hash) pairs of one submitted bat
 
 struct FragBuf {                // fragment-size candidates of one submitted batch (BED runs only)
     DevBuf file, qhash, name, endpos, fs, count;
-    uint32_t cap = 0;
+    DevBuf r_file, r_qhash, r_name, r_endpos, r_fs, r_counts;   // the per-record kernel's workgroup regions (packed into the columns above by frag_compact_kernel)
+    uint32_t cap = 0, grid_cap = 0;
     uint32_t *h_count = nullptr;
     bool used = false;
 };
@@ -452,6 +453,8 @@ PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *ind
 }
 
 int run_batch(rsqc_ctx *c, UploadedBatch *u) {
+    // record indices ride in 32 bits inside the per-record kernel (31 in its overflow list): checked before anything is recorded for the batch
+    if (u->n >= (1ull << 31)) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
     if (!c->have_ann) return fail(c, RSQC_ERR_ARG, "rsqc_set_annotation must precede rsqc_submit");
     if (c->finalized) return fail(c, RSQC_ERR_ARG, "rsqc_reset required after rsqc_finalize");
     if (u->n == 0) return 0;
@@ -489,15 +492,22 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
     acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
     acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
+    FragCandidates frag_dense{};
     if (c->have_bed) {
         size_t fidx = c->frag_pool.size();
-        for (size_t i = 0; i < c->frag_pool.size(); ++i) if (!c->frag_pool[i].used && c->frag_pool[i].cap >= u->n) { fidx = i; break; }
+        for (size_t i = 0; i < c->frag_pool.size(); ++i) if (!c->frag_pool[i].used && c->frag_pool[i].cap >= u->n && (c->dparams.legacy || c->frag_pool[i].grid_cap >= (uint32_t)grid)) { fidx = i; break; }
         if (fidx == c->frag_pool.size()) {
             FragBuf fb; fb.cap = (uint32_t)u->n;
             int rc2;
             if ((rc2 = dev_alloc(c, fb.file, u->n * 8, false)) || (rc2 = dev_alloc(c, fb.qhash, u->n * 8, false)) ||
                 (rc2 = dev_alloc(c, fb.name, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.endpos, u->n * 4, false)) ||
                 (rc2 = dev_alloc(c, fb.fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.count, 16, false))) return rc2;
+            if (!c->dparams.legacy) {
+                fb.grid_cap = (uint32_t)grid;
+                if ((rc2 = dev_alloc(c, fb.r_file, u->n * 8, false)) || (rc2 = dev_alloc(c, fb.r_qhash, u->n * 8, false)) ||
+                    (rc2 = dev_alloc(c, fb.r_name, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.r_endpos, u->n * 4, false)) ||
+                    (rc2 = dev_alloc(c, fb.r_fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.r_counts, (size_t)grid * 4, false))) return rc2;
+            }
             HIP_TRY(c, hipHostMalloc((void **)&fb.h_count, 16, hipHostMallocDefault));
             c->frag_pool.push_back(fb);
         }
@@ -507,7 +517,12 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
         HIP_TRY(c, hipMemsetAsync(fb.count.p, 0, 16, c->stream));
         acc.frag.file_index = (uint64_t *)fb.file.p; acc.frag.qhash = (uint64_t *)fb.qhash.p;
         acc.frag.name = (int32_t *)fb.name.p; acc.frag.endpos = (int32_t *)fb.endpos.p;
-        acc.frag.flag_size = (uint32_t *)fb.fs.p; acc.frag.count = (uint32_t *)fb.count.p; acc.frag.cap = fb.cap;
+        acc.frag.flag_size = (uint32_t *)fb.fs.p; acc.frag.count = (uint32_t *)fb.count.p; acc.frag.cap = fb.cap; acc.frag.chunk_count = nullptr;
+        frag_dense = acc.frag;
+        if (!c->dparams.legacy) {                 // the per-record kernel writes workgroup regions; frag_compact_kernel packs them (below)
+            acc.frag.file_index = (uint64_t *)fb.r_file.p; acc.frag.qhash = (uint64_t *)fb.r_qhash.p; acc.frag.name = (int32_t *)fb.r_name.p;
+            acc.frag.endpos = (int32_t *)fb.r_endpos.p; acc.frag.flag_size = (uint32_t *)fb.r_fs.p; acc.frag.chunk_count = (uint32_t *)fb.r_counts.p;
+        }
     }
     // file order is part of the boundary: the index of record 0 in the whole file comes from the caller (it decides the
     // first-N cut-off of the fragment-size sampler and the order in which shards are composed); batches arrive in file order
@@ -521,12 +536,12 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     DevBatch d = u->d;
     d.record_base = u->file_index_base;
     c->next_record_base = u->file_index_base + u->n;
-    if (!c->dparams.legacy && u->n >= (1ull << 31)) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");   // record indices ride in 31 bits of the kernel's queues
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc);
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->k1_events.emplace_back(e0, e1);
+    if (c->have_bed && !c->dparams.legacy) launch_frag_compact(c->stream, acc.frag, frag_dense, u->n, grid);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
     launch_read_length(c->stream, c->dann, c->dparams, d, acc, rl_slot);
     if (c->have_ref && !c->dparams.legacy) {          // --fasta: fragment GC candidates, a separate pass over the batch
@@ -608,7 +623,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); }
-    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
+    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); fb.r_file.release(); fb.r_qhash.release(); fb.r_name.release(); fb.r_endpos.release(); fb.r_fs.release(); fb.r_counts.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
     c->d_arena_count.release(); c->d_rl_summary.release();
@@ -668,7 +683,9 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     UPV(d.ex_binhi, hx.ex_binhi); UPV(d.gb_bin, hx.gb_bin); UPV(d.ex_cov, hx.ex_cov); UPV(d.ex_pmax, hx.ex_pmax);
     UPV(d.ex_id, c->exon_row_id);
     UPV(d.ei, hx.ei); UPV(d.ei_coarse, hx.ei_coarse);
-    if ((rc = dev_alloc(c, c->d_ei_rank, ((size_t)hx.rank_words + 1) * sizeof(EiRank), true))) return rc;
+    if ((rc = dev_alloc(c, c->d_ei_rank, ((size_t)hx.rank_words + 1) * sizeof(EiRank), true)))
+        return fail(c, rc, "no device memory for the interval index's rank table: " + std::to_string((((size_t)hx.rank_words + 1) * sizeof(EiRank)) >> 20) +
+                           " MiB (16 bytes per 64 positions up to every contig's last feature; 775 MB for the human contig lengths)");
     d.ei_rank = (const EiRank *)c->d_ei_rank.p;
     for (int k = 0; k < nc; ++k)                  // (stream order: after the upload of the entries)
         launch_ei_rank(c->stream, d.ei, hx.ei_range[(size_t)k], hx.ei_range[(size_t)k + 1],
@@ -1551,7 +1568,7 @@ int decode_finish(rsqc_ctx *c, rsqc_decode_window *out) {
         D.last.n = S.n_rec; D.last.file_index_base = D.next_file_index; D.last.core = W.core; D.last.aux = W.aux; D.last.cigar = W.cigar;
         D.last.n_cigar_total = S.n_ops; D.last.n_seg = S.n_seg; D.last.seg_tid = W.seg_tid; D.last.seg_start = W.seg_start;
         D.last.n_wide = S.n_wide; D.last.wide_index = W.wide_index; D.last.wide_nm = W.wide_nm; D.last.wide_l_qseq = W.wide_lq; D.last.wide_n_cigar = W.wide_nc;
-        if (out) out->device_batch = D.last;
+        if (out && !D.pipelined) out->device_batch = D.last;     // (pipelined: the next call's kernels are already queued into these buffers)
         UploadedBatch *u = new UploadedBatch();
         u->pooled = false;
         u->n = S.n_rec; u->n_cigar_total = S.n_ops; u->file_index_base = D.next_file_index;
@@ -1606,7 +1623,11 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     int rc;
     // buffers that have to grow are in use by the call in flight: it is finished first (rare: rsqc_decode_params.reserve_inflated_bytes)
     const int slot = D.slot ^ 1;
-    if (D.pending && ((size_t)total > D.out_cap || (size_t)compressed_bytes + 64 > D.comp_cap || n_blocks > D.blk_cap)) { if ((rc = decode_finish(c, out))) return rc; }
+    if (D.pending && ((size_t)total > D.out_cap || (size_t)compressed_bytes + 64 > D.comp_cap || n_blocks > D.blk_cap)) {
+        if ((rc = decode_finish(c, out))) return rc;
+        // (finishing the call in flight may have enlarged the head room for a carried-over record: the limit is about THIS origin)
+        if (total + D.head > (1ull << 31)) return fail(c, RSQC_ERR_ARG, "too much inflated data in one rsqc_decode_submit (2 GiB with the bytes carried over)");
+    }
     if ((rc = decode_reserve(c, (size_t)total, (size_t)compressed_bytes, n_blocks))) return rc;
     DevBgzfBlock *hb = D.h_blocks + (size_t)slot * D.blk_cap;
     uint32_t raw_at = D.head;                                           // where the caller-inflated run goes in the window

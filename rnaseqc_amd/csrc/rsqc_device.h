@@ -47,6 +47,10 @@ struct FragCandidates {
     int32_t *endpos;             // PositionEnd()
     uint32_t *flag_size;         // bit 31: !MateReverse && Reverse && pos != mpos ; low 31 bits |isize|
     uint32_t *count; uint32_t cap;
+    // classify_ei_kernel: a workgroup writes into its OWN region -- slot = first record of its range + an LDS counter (a record
+    // yields at most one candidate), no memory atomic -- and leaves its count here; frag_compact_kernel then packs the regions
+    // into the dense list.  (One shared counter was 70 M memory atomics on one address: 41 of the 44 ms of a --bed pass.)
+    uint32_t *chunk_count;       // [workgroups of the per-record kernel]; null: `count` is a plain shared counter
 };
 
 // --fasta: one G/C bit per base (gc(), src/Fasta.cpp:67-74, counts G g C c only); every contig starts on a word
@@ -181,6 +185,7 @@ void free_sort_scratch(SortScratch &s);
 // leaves the kept samples (first max_samples by file index, unordered) on the device: S.k1 = file index, S.v1 = size, n_kept of them
 int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, uint32_t max_samples,
                        std::vector<int64_t> &sizes, std::vector<uint64_t> &counts, uint32_t &remaining, SortScratch &S, uint32_t &n_kept, int *d_error);
+void launch_frag_compact(hipStream_t s, const FragCandidates &src, const FragCandidates &dst, uint64_t n_rec, int k1_grid);
 // --fasta (rsqc_kernels.hip / rsqc_fragsize.hip)
 void launch_gc_pack(hipStream_t s, const uint8_t *ascii, uint64_t len, unsigned long long *words);
 void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R, double *exon_gc);

@@ -87,7 +87,10 @@ constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
 #define K1E_PIECE_RECORDS 256
 #endif
 constexpr uint64_t K1E_PIECE = K1E_PIECE_RECORDS;   // records a wave takes from its workgroup's range at a time (4 tiles)
-constexpr int K1E_QCAP = 128;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
+#ifndef K1E_QCAP_N
+#define K1E_QCAP_N 128
+#endif
+constexpr int K1E_QCAP = K1E_QCAP_N;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
 constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
 constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's flag word | K1E_HQ when high quality
 // (timing experiments, `make variant DEFS=-DK1E_ABL=<bits>`: 1 no feature stage, 2 no LDS table updates, 4 no coverage atomics,
@@ -108,13 +111,14 @@ struct K1eTables {
     uint32_t gkey[K1E_GSLOTS];
     uint32_t rl[3];
     uint32_t pairs;                              // pairs in the workgroup's chunk
+    uint32_t frags;                              // fragment-size candidates in the workgroup's region (BED runs)
     uint32_t piece;                              // next piece of the workgroup's range to hand to a wave
     __device__ __forceinline__ void init(uint32_t pairs0) {
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
         if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
         for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
-        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; piece = 0u; }
+        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; piece = 0u; frags = 0u; }
     }
     __device__ __forceinline__ void exon_add(uint32_t eid, double frac) {
         const uint32_t slot = eid & (K1E_ESLOTS - 1);
@@ -384,6 +388,35 @@ __device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t
     w.ref_len = cur - ((uint32_t)pos + 1u);
 }
 
+// the record range of workgroup `block` of `grid` (the same split for the kernel and for what reads its per-workgroup regions)
+__device__ __forceinline__ void k1e_wg_range(uint32_t n_rec, uint32_t grid, uint32_t block, uint32_t &beg, uint32_t &end) {
+    const uint32_t total_waves = grid * K1E_WAVES;
+    const uint32_t per_wave = (((n_rec + total_waves - 1u) / total_waves) + 63u) & ~63u;
+    const uint64_t b64 = (uint64_t)block * K1E_WAVES * per_wave, e64 = b64 + (uint64_t)K1E_WAVES * per_wave;
+    beg = b64 < (uint64_t)n_rec ? (uint32_t)b64 : n_rec;
+    end = e64 < (uint64_t)n_rec ? (uint32_t)e64 : n_rec;
+}
+// packs the workgroups' candidate regions (FragCandidates::chunk_count) into the dense list the pairing stage reads
+__global__ void __launch_bounds__(256)
+frag_compact_kernel(FragCandidates src, FragCandidates dst, uint32_t n_rec, uint32_t k1_grid) {
+    __shared__ uint32_t s_part[4], s_off;
+    uint32_t before = 0;
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += blockDim.x) before += src.chunk_count[k];
+    before = wave_sum(before);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) s_off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    const uint32_t off = s_off, mine = src.chunk_count[blockIdx.x];
+    uint32_t beg, end;
+    k1e_wg_range(n_rec, k1_grid, blockIdx.x, beg, end);
+    for (uint32_t j = threadIdx.x; j < mine; j += blockDim.x) {
+        dst.file_index[off + j] = src.file_index[beg + j]; dst.qhash[off + j] = src.qhash[beg + j];
+        dst.name[off + j] = src.name[beg + j]; dst.endpos[off + j] = src.endpos[beg + j]; dst.flag_size[off + j] = src.flag_size[beg + j];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *dst.count = off + mine;
+}
+
 #ifndef K1E_MINW
 #define K1E_MINW 4            /* waves per SIMD the register allocation aims at: 128 VGPRs, no spills (at 5 the loop spills: 7.7 vs 4.65 ms) */
 #endif
@@ -434,11 +467,8 @@ classify_ei_kernel(K1Args A) {
     // record indices are 32-bit inside the kernel (a batch holds fewer than 2^31 records, rsqc_api.cpp: run_batch): 64-bit
     // indices cost a register pair, a v_cmp_*_u64 and a v_lshl_add_u64 wherever a lane touches one
     const uint32_t n_rec = (uint32_t)b.n;
-    const uint32_t total_waves = gridDim.x * K1E_WAVES;
-    const uint32_t per_wave = (((n_rec + total_waves - 1u) / total_waves) + 63u) & ~63u;
-    const uint64_t wg_beg64 = (uint64_t)blockIdx.x * K1E_WAVES * per_wave;
-    const uint32_t wg_beg = wg_beg64 < (uint64_t)n_rec ? (uint32_t)wg_beg64 : n_rec;
-    const uint32_t wg_end = wg_beg64 + (uint64_t)K1E_WAVES * per_wave < (uint64_t)n_rec ? (uint32_t)(wg_beg64 + (uint64_t)K1E_WAVES * per_wave) : n_rec;
+    uint32_t wg_beg, wg_end;
+    k1e_wg_range(n_rec, gridDim.x, blockIdx.x, wg_beg, wg_end);
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     auto take_piece = [&]() -> uint32_t {                 // first record of the next unclaimed piece, NONE when the range is used up
         uint32_t c = 0;
@@ -565,14 +595,14 @@ classify_ei_kernel(K1Args A) {
             const int32_t name = bed_interval_of(q->a, r);
             if (name >= 0) {
                 const FragCandidates &fr = q->acc.frag;
-                const uint32_t slot = atomicAdd(fr.count, 1u);
-                if (slot < fr.cap) {
+                const uint32_t slot = wg_beg + atomicAdd(&S.T.frags, 1u);       // the workgroup's own region (<= one candidate per record)
+                {
                     fr.file_index[slot] = q->b.record_base + i; fr.qhash[slot] = r.qhash;
                     fr.name[slot] = name; fr.endpos[slot] = rc.endpos;
                     const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
                     const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
                     fr.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
-                } else atomicExch(q->acc.error, RSQC_ERR_CAPACITY);
+                }
             }
         }
         if (rc.error) atomicExch(k1e_lazy_args()->acc.error, rc.error);
@@ -692,6 +722,7 @@ classify_ei_kernel(K1Args A) {
         const K1Args *q = k1e_lazy_args();
         atomicMax(&q->acc.rl_stats[0], S.T.rl[0]); atomicMin(&q->acc.rl_stats[1], S.T.rl[1]); atomicMax(&q->acc.rl_stats[2], S.T.rl[2]);
         q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
+        if (q->a.have_bed) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
     }
 }
 

@@ -618,6 +618,9 @@ void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, siz
     const size_t rl_vec = (size_t)((char *)rl_min - 4 - (char *)arena) / 16;
     hipLaunchKernelGGL(reset_kernel, dim3(1024), dim3(256), 0, s, (uint4 *)arena, (arena_bytes + 15) / 16, (uint4 *)cov, (cov_bytes + 15) / 16, rl_vec);
 }
+void launch_frag_compact(hipStream_t s, const FragCandidates &src, const FragCandidates &dst, uint64_t n_rec, int k1_grid) {
+    hipLaunchKernelGGL(frag_compact_kernel, dim3(k1_grid), dim3(256), 0, s, src, dst, (uint32_t)n_rec, (uint32_t)k1_grid);
+}
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc) {
     if (variant < 0) hipLaunchKernelGGL(classify_count_kernel_legacy, dim3(grid), dim3(RSQC_K1_THREADS), 0, s, a, p, b, acc);
