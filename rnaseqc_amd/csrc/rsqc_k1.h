@@ -447,8 +447,8 @@ classify_ei_kernel(K1Args A) {
     int pending = 0;
     uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
     auto flush_counts = [&]() {
-        const uint32_t s0 = wave_sum(sum_e1mm), s1 = wave_sum(sum_e1b), s2 = wave_sum(sum_e2mm), s3 = wave_sum(sum_e2b),
-                       s4 = wave_sum(sum_mm), s5 = wave_sum(sum_b), s6 = wave_sum(sum_blk);
+        const uint32_t s0 = wave_sum_u32_full(sum_e1mm), s1 = wave_sum_u32_full(sum_e1b), s2 = wave_sum_u32_full(sum_e2mm), s3 = wave_sum_u32_full(sum_e2b),
+                       s4 = wave_sum_u32_full(sum_mm), s5 = wave_sum_u32_full(sum_b), s6 = wave_sum_u32_full(sum_blk);
         if (l == 0 && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
         if (l == 0 && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
         if (l == 0 && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
