@@ -636,12 +636,15 @@ classify_ei_kernel(K1Args A) {
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
         }
         RSQC_MARK(6);
-        // ---- the staged words have landed (see above).  The wait sits HERE, in front of the queue writes: the coarse word of
-        //      this tile's records (loaded a tile ago, i.e. older than the staged words) is then complete without a wait of its
-        //      own -- a wait anywhere earlier in phase A would also wait for the previous feature stage's atomics ---------------
+        // ---- the staged words have landed (see above).  In the -DK1E_COARSE build the wait sits HERE, in front of the queue writes:
+        //      the coarse word of this tile's records (loaded a tile ago, i.e. older than the staged words) is then complete without
+        //      a wait of its own -- a wait anywhere earlier in phase A would also wait for the previous feature stage's atomics.
+        //      The default build waits behind the queue writes and the counters (below): the LDS traffic overlaps the landing ------
+#if defined(K1E_COARSE)                               /* (only that build consumes a loaded word in the queue writes) */
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
         asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
+#endif
 #endif
         // one-block records whose length fits the queue's 16 bits (a longer block -- never seen in RNA-seq -- takes the long-CIGAR stage)
         const WB fits = WS::prim(w2.len0 < 65536u);
@@ -664,6 +667,12 @@ classify_ei_kernel(K1Args A) {
         if (++pending == 31 || WS::any(big_any)) flush_counts();
         } while (0);
         RSQC_MARK(7);
+#if !defined(K1E_COARSE)                              /* the landing wait behind the queue writes and the counters: 2.59 -> 2.52 ms (profiles/r4_k1_variants.txt) */
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
+        asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
+#endif
+#endif
         cur_cv = n_cv; cur_av = n_av; nx_co = n_co;
         // the next tile's positions are here: its coarse-table words start their trip now and are looked at when that tile sorts
         // its records by shape, a feature stage and most of a phase A later (a read in an empty stretch of the genome then needs
