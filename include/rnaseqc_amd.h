@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSQC_ABI_VERSION 2
+#define RSQC_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define RSQC_API __attribute__((visibility("default")))
@@ -305,6 +305,14 @@ typedef struct rsqc_batch {
        that hashing does not change the fragment de-duplication               */
     const uint32_t *qname_off;         /* [n + 1]                              */
     const char     *qname;
+
+    /* optional (may be NULL): a SECOND, independent hash of every record's QNAME (rsqc_qname_hash2).  With it the hot path
+       identifies a read name by 96 bits -- (qhash, qhash2) compared exactly in the fragment de-duplication (src/Expression.cpp:
+       383-387 compares the strings): two different names are merged only if BOTH hashes collide.  Without it the identity is the
+       64-bit qhash alone.  The 32-byte record itself has no room for it (its layout is the contract's: 32 + 4 n_cigar bytes per
+       record); the column is read only for records that are counted to a gene.  Both ingest paths of the library (the device
+       decode and the host reader) fill it.                                                                              */
+    const uint32_t *qhash2;            /* [n]                                  */
 } rsqc_batch;
 
 /* ---- results ---------------------------------------------------------------- */
@@ -550,6 +558,9 @@ RSQC_API const char *rsqc_version(void);               /* "RNASeQC 2.4.3 ..." pr
 
 /* QNAME hash used at the boundary (host decoders must use exactly this).     */
 RSQC_API uint64_t rsqc_qname_hash(const char *name, size_t len);
+/* the second hash of a name (rsqc_batch.qhash2): a multiply-xorshift recurrence with its own constants + the murmur3 fmix32
+ * finaliser over (state ^ length); it shares no structure with the FNV-1a of rsqc_qname_hash                                  */
+RSQC_API uint32_t rsqc_qname_hash2(const char *name, size_t len);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ typedef struct {
 typedef struct {              /* fragmentTracker[gene]: unordered_set<string> */
     uint64_t *h;              /* 0 = empty slot; hashes are forced non-zero   */
     char    **s;              /* exact names when the batch carries them      */
+    uint32_t *h2;             /* second hash (rsqc_batch.qhash2) for the hash-only mode */
     size_t    cap, n;
 } nameset_t;
 
@@ -155,38 +156,40 @@ static void *dup_array(const void *src, size_t n, size_t sz) {
 
 /* ------------------------------------------------------------- name sets */
 
-static int nameset_insert(nameset_t *t, uint64_t h, const char *s, size_t len) {
+static int nameset_insert(nameset_t *t, uint64_t h, uint32_t h2, int has2, const char *s, size_t len) {
     /* returns 1 if newly inserted (fragmentTracker[gene].count(qname) == 0,
-       src/Expression.cpp:383-387)                                           */
+       src/Expression.cpp:383-387).  With the names: string comparison, the reference's.  Without: the identity the device works
+       with -- the 64-bit hash, and the second hash as well when the batch carries one (rsqc_batch.qhash2)                       */
     if (h == 0) h = 0x9e3779b97f4a7c15ull;
     if ((t->n + 1) * 2 > t->cap) {
         size_t ncap = t->cap ? t->cap * 2 : 16;
         uint64_t *nh = xcalloc(ncap, sizeof(uint64_t));
         char **ns = xcalloc(ncap, sizeof(char *));
+        uint32_t *n2 = xcalloc(ncap, sizeof(uint32_t));
         for (size_t i = 0; i < t->cap; ++i) if (t->h[i]) {
             size_t j = (size_t)(t->h[i] * 0x9e3779b97f4a7c15ull >> 17) & (ncap - 1);
             while (nh[j]) j = (j + 1) & (ncap - 1);
-            nh[j] = t->h[i]; ns[j] = t->s[i];
+            nh[j] = t->h[i]; ns[j] = t->s[i]; n2[j] = t->h2[i];
         }
-        free(t->h); free(t->s);
-        t->h = nh; t->s = ns; t->cap = ncap;
+        free(t->h); free(t->s); free(t->h2);
+        t->h = nh; t->s = ns; t->h2 = n2; t->cap = ncap;
     }
     size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (t->cap - 1);
     while (t->h[j]) {
         if (t->h[j] == h) {
-            if (!s) return 0;                       /* hash-only mode         */
-            if (t->s[j] && strlen(t->s[j]) == len && memcmp(t->s[j], s, len) == 0) return 0;
+            if (!s) { if (!has2 || t->h2[j] == h2) return 0; }      /* hash-only mode */
+            else if (t->s[j] && strlen(t->s[j]) == len && memcmp(t->s[j], s, len) == 0) return 0;
         }
         j = (j + 1) & (t->cap - 1);
     }
-    t->h[j] = h;
+    t->h[j] = h; t->h2[j] = h2;
     if (s) { t->s[j] = xcalloc(len + 1, 1); memcpy(t->s[j], s, len); }
     t->n++;
     return 1;
 }
 static void nameset_clear(nameset_t *t) {
     if (t->s) for (size_t i = 0; i < t->cap; ++i) free(t->s[i]);
-    free(t->h); free(t->s);
+    free(t->h); free(t->s); free(t->h2);
     memset(t, 0, sizeof(*t));
 }
 
@@ -453,7 +456,7 @@ typedef struct {
     int32_t tid, pos, mpos, isize, l_qseq, nm;
     uint32_t flag, mapq, tagbits, n_cigar;
     const uint32_t *cigar;
-    uint64_t qhash;
+    uint64_t qhash; uint32_t qhash2; int has_qhash2;
     const char *qname; size_t qname_len;
 } rec_t;
 
@@ -669,7 +672,7 @@ static double exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const block_
                 if (c->ctrace) { ct_push(c, 1, gene, 0, 0.0, query); ct_push(c, 2, gene, 0, 0.0, 0); }  /* queryGene :380, collect :390 */
                 if (query) {
                     c->gene_reads[gene] += 1.0;                             /* :382 */
-                    if (nameset_insert(&c->tracker[gene], r->qhash, r->qname, r->qname_len))
+                    if (nameset_insert(&c->tracker[gene], r->qhash, r->qhash2, r->has_qhash2, r->qname, r->qname_len))
                         c->gene_frag[gene] += 1.0;                          /* :383-387 */
                     if (!(r->flag & RSQC_FDUP)) c->gene_unique[gene] += 1.0;/* :388 */
                 }
@@ -808,7 +811,7 @@ static void legacy_exon_alignment_metrics(oracle_ctx *c, const rec_t *r, const b
                 }
                 const uint32_t gene = exon->gene;
                 c->gene_reads[gene] += 1.0;                                 /* :229 */
-                if (nameset_insert(&c->tracker[gene], r->qhash, r->qname, r->qname_len))
+                if (nameset_insert(&c->tracker[gene], r->qhash, r->qhash2, r->has_qhash2, r->qname, r->qname_len))
                     c->gene_frag[gene] += 1.0;                              /* :230-234 */
                 if (!(r->flag & RSQC_FDUP)) c->gene_unique[gene] += 1.0;    /* :235 */
                 if (c->seen[gene]) {                                        /* commit :236, Metrics.cpp:106-124 */
@@ -1081,7 +1084,7 @@ ORACLE_API int oracle_submit(oracle_ctx *c, const rsqc_batch *b) {
                 r.l_qseq = b->wide_l_qseq[w]; r.nm = b->wide_nm[w]; r.n_cigar = b->wide_n_cigar[w];
             }
             r.cigar = b->cigar + rcore->cigar_off;
-            r.qhash = ra->qhash;
+            r.qhash = ra->qhash; r.has_qhash2 = b->qhash2 != NULL; r.qhash2 = b->qhash2 ? b->qhash2[i] : 0u;
             r.qname = NULL; r.qname_len = 0;
             if (b->qname && b->qname_off) { r.qname = b->qname + b->qname_off[i]; r.qname_len = b->qname_off[i + 1] - b->qname_off[i]; }
             c->cur_file_index = b->file_index_base + i;

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # error codes
 OK, ERR_ARG, ERR_HIP, ERR_BAD_CIGAR, ERR_CAPACITY, ERR_NO_DEVICE, ERR_EMPTY_MEDIAN, ERR_INPUT = 0, -1, -2, -3, -4, -5, -6, -7
@@ -126,6 +126,7 @@ class BatchStruct(C.Structure):
         ("n_wide", C.c_uint32), ("wide_index", _P), ("wide_nm", _P), ("wide_l_qseq", _P),
         ("wide_n_cigar", _P),
         ("qname_off", _P), ("qname", _P),
+        ("qhash2", _P),
     ]
 
 
@@ -267,3 +268,23 @@ def qname_hash_bytes(names: np.ndarray) -> np.ndarray:
 
 def qname_hash(name: bytes) -> int:
     return int(qname_hash_bytes(np.frombuffer(name, dtype=np.uint8)[None, :])[0])
+
+
+def qname_hash2_bytes(names: np.ndarray) -> np.ndarray:
+    """rsqc_qname_hash2 (the second, independent name hash: rsqc_batch.qhash2) over a [n, width] uint8 matrix, vectorised:
+    per byte h = (h + b) * 0xCC9E2D51, h ^= h >> 15; then murmur3's fmix32 of (h ^ width)."""
+    names = np.ascontiguousarray(names, dtype=np.uint8)
+    M = np.uint64(0xFFFFFFFF)
+    h = np.full(names.shape[0], 0x2F0B4A87, dtype=np.uint64)
+    for j in range(names.shape[1]):
+        h = ((h + names[:, j].astype(np.uint64)) * np.uint64(0xCC9E2D51)) & M
+        h ^= h >> np.uint64(15)
+    h ^= np.uint64(names.shape[1])
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & M
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & M
+    h ^= h >> np.uint64(16)
+    return h.astype(np.uint32)
+
+
+def qname_hash2(name: bytes) -> int:
+    return int(qname_hash2_bytes(np.frombuffer(name, dtype=np.uint8)[None, :])[0])

@@ -23,7 +23,7 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 void HostBatch::clear() {
     unsorted = false; bad_refid.clear();
-    core.clear(); aux.clear(); cigar.clear(); seg_tid.clear(); seg_start.clear();
+    core.clear(); aux.clear(); qh2.clear(); cigar.clear(); seg_tid.clear(); seg_start.clear();
     wide_index.clear(); wide_nm.clear(); wide_lq.clear(); wide_ncig.clear();
 }
 
@@ -34,7 +34,7 @@ bool HostBatch::keep_leading_contig(int32_t tid) {
     if (seg_tid[0] == tid) k = seg_tid.size() > 1 ? (size_t)seg_start[1] : total;
     if (k >= total) return false;
     const size_t c_end = core[k].cigar_off;
-    core.resize(k); aux.resize(k); cigar.resize(c_end);
+    core.resize(k); aux.resize(k); qh2.resize(k); cigar.resize(c_end);
     if (k == 0) { seg_tid.clear(); seg_start.clear(); }
     else { seg_tid.resize(1); seg_start.resize(1); }
     while (!wide_index.empty() && wide_index.back() >= k) { wide_index.pop_back(); wide_nm.pop_back(); wide_lq.pop_back(); wide_ncig.pop_back(); }
@@ -46,7 +46,7 @@ rsqc_batch HostBatch::view() {
     else seg_start.back() = core.size();
     rsqc_batch b{};
     b.n = core.size(); b.file_index_base = file_index_base;
-    b.core = core.data(); b.aux = aux.data(); b.cigar = cigar.data(); b.n_cigar_total = cigar.size();
+    b.core = core.data(); b.aux = aux.data(); b.qhash2 = qh2.data(); b.cigar = cigar.data(); b.n_cigar_total = cigar.size();
     b.n_seg = (uint32_t)seg_tid.size(); b.seg_tid = seg_tid.data(); b.seg_start = seg_start.data();
     b.n_wide = (uint32_t)wide_index.size(); b.wide_index = wide_index.data(); b.wide_nm = wide_nm.data();
     b.wide_l_qseq = wide_lq.data(); b.wide_n_cigar = wide_ncig.data();
@@ -502,6 +502,7 @@ struct ChunkOut {
     std::vector<uint32_t> cig_end;                       // per record: CIGAR words of the chunk up to and including it
     std::vector<rsqc_rec_core> core;                     // cigar_off relative to the chunk
     std::vector<rsqc_rec_aux> aux;
+    std::vector<uint32_t> qh2;                           // second name hash (rsqc_batch.qhash2)
     std::vector<uint32_t> cig;
     std::vector<std::pair<uint32_t, int32_t>> segs;      // (local record index, tid): contig changes inside the chunk (+ its first record)
     std::vector<uint32_t> widx; std::vector<int32_t> wnm, wlq; std::vector<uint32_t> wnc;
@@ -510,14 +511,14 @@ struct ChunkOut {
     // (their names), and positions that go backwards inside a contig (:354); judged on primary, mapped, QC-passed records
     std::vector<std::pair<uint32_t, std::string>> bad_ref;   // (local record index, QNAME)
     bool unsorted = false, have_q = false; int32_t first_tid = 0, first_pos = 0, q_tid = 0, q_pos = 0;
-    void clear() { core.clear(); aux.clear(); cig.clear(); cig_end.clear(); segs.clear(); widx.clear(); wnm.clear(); wlq.clear(); wnc.clear(); last_tid = 0;
+    void clear() { core.clear(); aux.clear(); qh2.clear(); cig.clear(); cig_end.clear(); segs.clear(); widx.clear(); wnm.clear(); wlq.clear(); wnc.clear(); last_tid = 0;
                    bad_ref.clear(); unsorted = false; have_q = false; }
     size_t size() const { return core.size(); }
     // keep the first k records
     void truncate(size_t k) {
         if (k >= core.size()) return;
         const uint32_t nc = k ? cig_end[k - 1] : 0u;
-        core.resize(k); aux.resize(k); cig_end.resize(k); cig.resize(nc);
+        core.resize(k); aux.resize(k); qh2.resize(k); cig_end.resize(k); cig.resize(nc);
         while (!segs.empty() && segs.back().first >= k) segs.pop_back();
         while (!widx.empty() && widx.back() >= k) { widx.pop_back(); wnm.pop_back(); wlq.pop_back(); wnc.pop_back(); }
         last_tid = segs.empty() ? 0 : segs.back().second;
@@ -579,7 +580,7 @@ size_t frame_and_parse(const uint8_t *buf, size_t p, size_t limit, size_t end, c
         const uint8_t *ops = buf + p + ro.ops_off;
         for (uint32_t ci = 0; ci < ro.n_ops; ++ci) o.cig[c0 + ci] = le32(ops + 4 * (size_t)ci);
         o.cig_end.push_back((uint32_t)o.cig.size());
-        o.core.push_back(ro.core); o.aux.push_back(ro.aux);
+        o.core.push_back(ro.core); o.aux.push_back(ro.aux); o.qh2.push_back(ro.qhash2);
         p += 4 + (size_t)block_size;
     }
     o.last_tid = last_tid;
@@ -686,8 +687,8 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
         for (size_t c = 0; c < used; ++c) { rec0[c + 1] = rec0[c] + chunks[c].size(); cig0[c + 1] = cig0[c] + chunks[c].cig.size(); }
         const size_t K = rec0[used], base = out.core.size(), cig_base = out.cigar.size();
         if (cig_base + cig0[used] > 0x3FFFFFF0ull) throw std::runtime_error("batch too large");
-        out.core.resize(base + K); out.aux.resize(base + K); out.cigar.resize(cig_base + cig0[used]);
-        rsqc_rec_core *ocore = out.core.data(); rsqc_rec_aux *oaux = out.aux.data(); uint32_t *ocig = out.cigar.data();
+        out.core.resize(base + K); out.aux.resize(base + K); out.qh2.resize(base + K); out.cigar.resize(cig_base + cig0[used]);
+        rsqc_rec_core *ocore = out.core.data(); rsqc_rec_aux *oaux = out.aux.data(); uint32_t *oqh2 = out.qh2.data(); uint32_t *ocig = out.cigar.data();
         pool_->run(used, [&](size_t c) {
             const ChunkOut &o = chunks[c];
             const size_t m = o.size();
@@ -696,6 +697,7 @@ size_t BamReader::read_batch(HostBatch &out, size_t max_records) {
             rsqc_rec_core *dc = ocore + base + rec0[c];
             for (size_t k = 0; k < m; ++k) { rsqc_rec_core v = o.core[k]; v.cigar_off += shift; dc[k] = v; }
             memcpy(oaux + base + rec0[c], o.aux.data(), m * sizeof(rsqc_rec_aux));
+            memcpy(oqh2 + base + rec0[c], o.qh2.data(), m * sizeof(uint32_t));
             if (!o.cig.empty()) memcpy(ocig + cig_base + cig0[c], o.cig.data(), o.cig.size() * sizeof(uint32_t));
         });
         g_t_parse += now_s() - tp;

@@ -74,6 +74,7 @@ private:
 struct HostBatch {                       // owns the arrays an rsqc_batch points to
     RawVec<rsqc_rec_core> core;
     RawVec<rsqc_rec_aux> aux;
+    RawVec<uint32_t> qh2;                // second name hashes (rsqc_batch.qhash2)
     RawVec<uint32_t> cigar;
     std::vector<int32_t> seg_tid;
     std::vector<uint64_t> seg_start;

@@ -285,7 +285,7 @@ void shard_worker(Shard &sh, const std::string &bam_path, const Options &o, int 
             return;
         }
         HostBatch bufs[2];
-        for (auto &hb : bufs) { hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.cigar.use_pinned(true); hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.cigar.reserve(BATCH * 2); }
+        for (auto &hb : bufs) { hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.qh2.use_pinned(true); hb.cigar.use_pinned(true); hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.qh2.reserve(BATCH); hb.cigar.reserve(BATCH * 2); }
         int cur = 0; bool in_flight = false;
         std::vector<int> ranges = sh.contigs;
         if (sh.tail) ranges.push_back(n_ref);                          // the unplaced records behind the last contig
@@ -605,8 +605,8 @@ int main(int argc, char **argv) {
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
         HostBatch bufs[2];
         for (auto &hb : bufs) {                                  // page-locked staging, sized once
-            hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.cigar.use_pinned(true);
-            hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.cigar.reserve(BATCH * 2);
+            hb.core.use_pinned(true); hb.aux.use_pinned(true); hb.qh2.use_pinned(true); hb.cigar.use_pinned(true);
+            hb.core.reserve(BATCH); hb.aux.reserve(BATCH); hb.qh2.reserve(BATCH); hb.cigar.reserve(BATCH * 2);
         }
         std::vector<int> visit;
         unsigned long long alignmentCount = 0;

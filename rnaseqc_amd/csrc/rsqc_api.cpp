@@ -52,10 +52,11 @@ struct UploadedBatch {
 // What a submitted batch leaves behind for the end-of-file stage is written into WORST-CASE sized buffers (the counts
 // are only known on the device).  A batch that has completed is RETIRED at the next rsqc_submit / rsqc_wait: its
 // counts are read from a page-locked mirror, what it actually emitted is appended to a growing arena, and the
-// worst-case buffers go back to the pool -- so the memory held until rsqc_finalize is what was emitted (12 B per
+// worst-case buffers go back to the pool -- so the memory held until rsqc_finalize is what was emitted (16 B per
 // (gene, name) pair, 28 B per fragment-size candidate, 32 B per GC candidate) plus the buffers of the batches in flight.
 struct PairBuf {                // (gene, qname-hash) pairs of one submitted batch
-    DevBuf gene, hash, counts;  // counts: [n_chunks] per K1 block, then [1] slow-path counter
+    DevBuf gene, hash, h2, counts;  // h2: second name hashes (written when the batch carries rsqc_batch.qhash2); counts: [n_chunks] per K1 block, then [1] slow-path counter
+    bool has2 = false;          // the batch submitted with this buffer carried second name hashes
     uint64_t cap = 0;           // pair slots allocated
     uint32_t n_chunks = 0, chunk_cap = 0, slow_base = 0, slow_cap = 0;
     uint32_t counts_cap = 0;
@@ -94,7 +95,7 @@ struct DecodeState {
     uint32_t head = 1u << 22;          // room in front of the window for the carried-over part of a record
     uint32_t tail = 0;                 // bytes carried over, parked at [head - tail, head)
     size_t out_cap = 0, comp_cap = 0, blk_cap = 0;
-    DevBuf comp, blocks, ubuf, seg, seg_rec0, seg_ops0, rec_off, ops_at, mark, core, aux, cigar, seg_tid, seg_start,
+    DevBuf comp, blocks, ubuf, seg, seg_rec0, seg_ops0, rec_off, ops_at, mark, core, aux, qh2, cigar, seg_tid, seg_start,
            wide_index, wide_nm, wide_lq, wide_nc, sum, carry, tailtmp, scratch;
     DecodeSummary *h_sum = nullptr;    // page-locked
     DevBgzfBlock *h_blocks = nullptr;  // page-locked, blk_cap entries
@@ -142,11 +143,12 @@ struct rsqc_ctx {
     hipEvent_t fin_e0 = nullptr, fin_e1 = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
+    bool pass_has2 = false;                     // a batch of the current pass carried rsqc_batch.qhash2
 
     // accumulators
     // one device arena holds every small result vector (single memset at reset, single D2H at finalize):
     // u64[3G+K] | u64 bias3,bias5[L] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | u8 exon_hit[E] | misc[64]
-    DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
+    DevBuf d_arena, d_cov, d_ovf_index, d_tiles, d_table2;
     DevBuf d_ei_rank;                                   // rank table of the interval index
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
@@ -317,6 +319,7 @@ int zero_accumulators(rsqc_ctx *c) {
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
     c->pair_arena.used = c->frag_arena.used = c->gc_arena.used = 0;
+    c->pass_has2 = false;
     for (auto &fb : c->frag_pool) fb.used = false;
     c->frags_in_flight.clear();
     c->h_fsize.clear(); c->h_fcount.clear();
@@ -348,6 +351,8 @@ int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u, bool pooled
     UP(cigar, b->n_cigar_total);
     UP(seg_tid, b->n_seg); UP(seg_start, (size_t)b->n_seg + 1);
     UP(wide_index, b->n_wide); UP(wide_nm, b->n_wide); UP(wide_l_qseq, b->n_wide); UP(wide_n_cigar, b->n_wide);
+    d.qhash2 = nullptr;
+    if (b->qhash2) UP(qhash2, b->n);
 #undef UP
     return 0;
 }
@@ -396,9 +401,10 @@ int retire_completed(rsqc_ctx *c, bool all) {
         if (c->pair_arena.used + total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "more than 2^32 (gene, name) pairs in one pass");
         int rc = arena_reserve(c, c->pair_arena, total);
         if (rc) return rc;
-        if (total) launch_pairs_append(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, pb.chunk_cap, (const uint32_t *)pb.counts.p,
+        if (total) launch_pairs_append(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, pb.has2 ? (const uint32_t *)pb.h2.p : nullptr,
+                                       pb.chunk_cap, (const uint32_t *)pb.counts.p,
                                        pb.n_chunks, pb.slow_base, pb.slow_cap, (uint32_t *)c->pair_arena.col[0].p + c->pair_arena.used,
-                                       (uint64_t *)c->pair_arena.col[1].p + c->pair_arena.used);
+                                       (uint64_t *)c->pair_arena.col[1].p + c->pair_arena.used, (uint32_t *)c->pair_arena.col[2].p + c->pair_arena.used);
         c->pair_arena.used += total;
         pb.used = false;                       // (stream order: the append reads the buffer before a later batch writes it)
     }
@@ -442,8 +448,9 @@ PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *ind
     PairBuf pb;
     if (hipMalloc(&pb.gene.p, (size_t)cap * 4) != hipSuccess) return nullptr;
     if (hipMalloc(&pb.hash.p, (size_t)cap * 8) != hipSuccess) return nullptr;
+    if (hipMalloc(&pb.h2.p, (size_t)cap * 4) != hipSuccess) return nullptr;
     if (hipMalloc(&pb.counts.p, (size_t)n_counts * 4) != hipSuccess) return nullptr;
-    pb.gene.bytes = (size_t)cap * 4; pb.hash.bytes = (size_t)cap * 8; pb.counts.bytes = (size_t)n_counts * 4;
+    pb.gene.bytes = (size_t)cap * 4; pb.hash.bytes = (size_t)cap * 8; pb.h2.bytes = (size_t)cap * 4; pb.counts.bytes = (size_t)n_counts * 4;
     if (hipHostMalloc((void **)&pb.h_counts, (size_t)n_counts * 4, hipHostMallocDefault) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&pb.done, hipEventDisableTiming) != hipSuccess) return nullptr;
     pb.cap = cap; pb.counts_cap = n_counts; pb.used = true;
@@ -488,7 +495,9 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     // (no per-batch memsets: every K1 workgroup writes its own chunk count, workgroup 0 zeroes the slow-path pair
     //  counter, and the overflow counter is re-armed by the last kernel of the previous batch / the reset kernel)
     DevAccum acc = c->acc;
-    acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p;
+    acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p; acc.pair_h2 = (uint32_t *)pb->h2.p;
+    pb->has2 = u->d.qhash2 != nullptr;
+    if (pb->has2) c->pass_has2 = true;          // the end-of-file stage of this pass runs on the 96-bit identity (batches without second hashes count as 0)
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
     acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
     acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
@@ -606,7 +615,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.exclude_chimeric = params->exclude_chimeric;
     c->dparams.n_filter_tags = params->n_filter_tags;
     c->dparams.legacy = params->legacy ? 1 : 0;
-    c->pair_arena.n_col = 2; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8;                       // gene, name hash
+    c->pair_arena.n_col = 3; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8; c->pair_arena.width[2] = 4;   // gene, name hash, second name hash
     c->frag_arena.n_col = 5; { const size_t w[5] = {8, 8, 4, 4, 4}; for (int k = 0; k < 5; ++k) c->frag_arena.width[k] = w[k]; }
     c->gc_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->gc_arena.width[k] = w[k]; }
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(16384, std::max(1, atoi(e)));
@@ -622,14 +631,14 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto *u : c->transient) free_batch(u);
     for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
-    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); }
+    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.h2.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); fb.r_file.release(); fb.r_qhash.release(); fb.r_name.release(); fb.r_endpos.release(); fb.r_fs.release(); fb.r_counts.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
     c->d_arena_count.release(); c->d_rl_summary.release();
     {
         DecodeState &D = c->dec;
-        for (DevBuf *b : {&D.comp, &D.blocks, &D.ubuf, &D.seg, &D.seg_rec0, &D.seg_ops0, &D.rec_off, &D.ops_at, &D.mark, &D.core, &D.aux, &D.cigar,
+        for (DevBuf *b : {&D.comp, &D.blocks, &D.ubuf, &D.seg, &D.seg_rec0, &D.seg_ops0, &D.rec_off, &D.ops_at, &D.mark, &D.core, &D.aux, &D.qh2, &D.cigar,
                           &D.seg_tid, &D.seg_start, &D.wide_index, &D.wide_nm, &D.wide_lq, &D.wide_nc, &D.sum, &D.carry, &D.tailtmp, &D.scratch}) b->release();
         if (D.h_sum) (void)hipHostFree(D.h_sum);
         if (D.h_blocks) (void)hipHostFree(D.h_blocks);
@@ -640,7 +649,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
-    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
+    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_table2, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -993,6 +1002,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 28 + 64 + lay_blocks * 12 + 64, false))) return rc;  // per-gene rows | gene_base | part_first | layout totals
             if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 24 + 128, false))) return rc;                  // per-partition rows | cursor | list of the fuller ones + its counter
             if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
+            if (c->pass_has2 && c->d_table2.bytes < (size_t)keys_bound * 4) { if ((rc = dev_alloc(c, c->d_table2, (size_t)keys_bound * 4 + (1u << 20), false))) return rc; }
             FragPlan P;
             P.ginfo = (uint4 *)c->d_tab_off.p;
             P.gene_base = (uint64_t *)(P.ginfo + Gz + 1);
@@ -1002,13 +1012,14 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             P.part_info = (uint4 *)c->d_tab_cap.p; P.cursor = (uint32_t *)(P.part_info + parts_bound);
             P.full_list = P.cursor + parts_bound; P.full_n = P.full_list + parts_bound;
             P.list = (unsigned long long *)c->d_table.p;
+            P.list2 = c->pass_has2 ? (uint32_t *)c->d_table2.p : nullptr;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
             if (c->pair_arena.used && !RSQC_DIAG("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces
                 if ((rc = dev_alloc(c, c->d_arena_count, 16, false))) return rc;
                 const uint32_t used32 = (uint32_t)c->pair_arena.used;
                 HIP_TRY(c, hipMemcpyAsync(c->d_arena_count.p, &used32, 4, hipMemcpyHostToDevice, c->stream));
                 DevAccum acc = c->acc;
-                acc.pair_gene = (uint32_t *)c->pair_arena.col[0].p; acc.pair_hash = (uint64_t *)c->pair_arena.col[1].p;
+                acc.pair_gene = (uint32_t *)c->pair_arena.col[0].p; acc.pair_hash = (uint64_t *)c->pair_arena.col[1].p; acc.pair_h2 = (uint32_t *)c->pair_arena.col[2].p;
                 acc.pair_chunk_cap = 0; acc.pair_chunk_count = (uint32_t *)c->d_arena_count.p;
                 acc.pair_slow_base = 0; acc.pair_slow_cap = used32;
                 launch_frag_local(c->stream, acc, 0, P, (uint32_t)std::min<uint64_t>(4096, c->pair_arena.used / 1024 + 1));
@@ -1017,7 +1028,8 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 if (RSQC_DIAG("RSQC_DIAG_SKIP_K4")) break;                // (diagnostic build only: results incomplete)
                 PairBuf &pb = c->pair_pool[idx];
                 DevAccum acc = c->acc;
-                acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p;
+                acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p; acc.pair_h2 = (uint32_t *)pb.h2.p;
+                if (c->pass_has2 && !pb.has2) HIP_TRY(c, hipMemsetAsync(pb.h2.p, 0, pb.h2.bytes, c->stream));   // (a batch without second hashes in a pass that has them)
                 acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
                 acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
@@ -1511,7 +1523,7 @@ int decode_reserve(rsqc_ctx *c, size_t out_bytes, size_t comp_bytes, size_t n_bl
     if ((rc = dev_alloc(c, D.seg, n_seg * sizeof(BamSegment), false)) || (rc = dev_alloc(c, D.seg_rec0, n_seg * 4, false)) ||
         (rc = dev_alloc(c, D.seg_ops0, n_seg * 4, false)) || (rc = dev_alloc(c, D.rec_off, n_rec * 4, false)) ||
         (rc = dev_alloc(c, D.ops_at, n_rec * 4, false)) || (rc = dev_alloc(c, D.mark, n_rec, false)) ||
-        (rc = dev_alloc(c, D.core, n_rec * 16 + 64, false)) || (rc = dev_alloc(c, D.aux, n_rec * 16 + 64, false)) ||
+        (rc = dev_alloc(c, D.core, n_rec * 16 + 64, false)) || (rc = dev_alloc(c, D.aux, n_rec * 16 + 64, false)) || (rc = dev_alloc(c, D.qh2, n_rec * 4 + 64, false)) ||
         (rc = dev_alloc(c, D.cigar, W + 256, false)) || (rc = dev_alloc(c, D.seg_tid, n_rec * 4 + 64, false)) ||
         (rc = dev_alloc(c, D.seg_start, (n_rec + 1) * 8 + 64, false)) || (rc = dev_alloc(c, D.wide_index, n_rec * 8 + 64, false)) ||
         (rc = dev_alloc(c, D.wide_nm, n_rec * 4 + 64, false)) || (rc = dev_alloc(c, D.wide_lq, n_rec * 4 + 64, false)) ||
@@ -1565,7 +1577,7 @@ int decode_finish(rsqc_ctx *c, rsqc_decode_window *out) {
     if (S.n_seg) HIP_TRY(c, hipMemcpy(D.run_tid.data(), D.seg_tid.p, (size_t)S.n_seg * 4, hipMemcpyDeviceToHost));
     if (out) { out->n_records = S.n_rec; out->n_runs = S.n_seg; out->run_tid = D.run_tid.data(); out->device_batch = rsqc_batch{}; }
     if (S.n_rec) {
-        D.last.n = S.n_rec; D.last.file_index_base = D.next_file_index; D.last.core = W.core; D.last.aux = W.aux; D.last.cigar = W.cigar;
+        D.last.n = S.n_rec; D.last.file_index_base = D.next_file_index; D.last.core = W.core; D.last.aux = W.aux; D.last.qhash2 = W.qh2; D.last.cigar = W.cigar;
         D.last.n_cigar_total = S.n_ops; D.last.n_seg = S.n_seg; D.last.seg_tid = W.seg_tid; D.last.seg_start = W.seg_start;
         D.last.n_wide = S.n_wide; D.last.wide_index = W.wide_index; D.last.wide_nm = W.wide_nm; D.last.wide_l_qseq = W.wide_lq; D.last.wide_n_cigar = W.wide_nc;
         if (out && !D.pipelined) out->device_batch = D.last;     // (pipelined: the next call's kernels are already queued into these buffers)
@@ -1573,7 +1585,7 @@ int decode_finish(rsqc_ctx *c, rsqc_decode_window *out) {
         u->pooled = false;
         u->n = S.n_rec; u->n_cigar_total = S.n_ops; u->file_index_base = D.next_file_index;
         DevBatch &d = u->d;
-        d.n = S.n_rec; d.core = W.core; d.aux = W.aux; d.cigar = W.cigar;
+        d.n = S.n_rec; d.core = W.core; d.aux = W.aux; d.qhash2 = W.qh2; d.cigar = W.cigar;
         d.n_seg = S.n_seg; d.seg_tid = W.seg_tid; d.seg_start = W.seg_start;
         d.n_wide = S.n_wide; d.wide_index = W.wide_index; d.wide_nm = W.wide_nm; d.wide_l_qseq = W.wide_lq; d.wide_n_cigar = W.wide_nc;
         c->transient.push_back(u);
@@ -1683,7 +1695,7 @@ int rsqc_decode_submit(rsqc_ctx *c, const void *compressed, uint64_t compressed_
     W.n_seg = (W.end - W.start + DEC_SEG_BYTES - 1) / DEC_SEG_BYTES;
     W.seg = (BamSegment *)D.seg.p; W.seg_rec0 = (uint32_t *)D.seg_rec0.p; W.seg_ops0 = (uint32_t *)D.seg_ops0.p;
     W.rec_off = (uint32_t *)D.rec_off.p; W.ops_at = (uint32_t *)D.ops_at.p; W.mark = (uint8_t *)D.mark.p;
-    W.core = (rsqc_rec_core *)D.core.p; W.aux = (rsqc_rec_aux *)D.aux.p; W.cigar = (uint32_t *)D.cigar.p;
+    W.core = (rsqc_rec_core *)D.core.p; W.aux = (rsqc_rec_aux *)D.aux.p; W.qh2 = (uint32_t *)D.qh2.p; W.cigar = (uint32_t *)D.cigar.p;
     W.seg_tid = (int32_t *)D.seg_tid.p; W.seg_start = (uint64_t *)D.seg_start.p;
     W.wide_index = (uint64_t *)D.wide_index.p; W.wide_nm = (int32_t *)D.wide_nm.p; W.wide_lq = (int32_t *)D.wide_lq.p; W.wide_nc = (uint32_t *)D.wide_nc.p;
     W.sum = (DecodeSummary *)D.sum.p; W.carry = (DecodeCarry *)D.carry.p; W.tags = D.tags;
@@ -1766,5 +1778,7 @@ uint64_t rsqc_qname_hash(const char *name, size_t len) {
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;   // fmix64
     return h;
 }
+
+uint32_t rsqc_qname_hash2(const char *name, size_t len) { return rsqc::bam_qname_hash2((const uint8_t *)name, (uint32_t)len); }
 
 }  // extern "C"

@@ -31,6 +31,21 @@ RSQC_BAM_FN uint64_t bam_qname_hash(const uint8_t *name, uint32_t len) {
     return h;
 }
 
+// the SECOND name hash (rsqc_qname_hash2, rsqc_batch.qhash2): per byte  h = (h + b) * 0xCC9E2D51; h ^= h >> 15;  then the murmur3
+// fmix32 of (h ^ length).  Its own recurrence and constants: nothing of FNV-1a's structure, so a pair of names crafted to
+// collide in the first hash does not collide here
+constexpr uint32_t BAM_QH2_SEED = 0x2F0B4A87u;
+RSQC_BAM_FN uint32_t bam_qh2_step(uint32_t h, uint32_t b) { h = (h + b) * 0xCC9E2D51u; return h ^ (h >> 15); }
+RSQC_BAM_FN uint32_t bam_qh2_finish(uint32_t h, uint32_t len) {
+    h ^= len; h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+RSQC_BAM_FN uint32_t bam_qname_hash2(const uint8_t *name, uint32_t len) {
+    uint32_t h = BAM_QH2_SEED;
+    for (uint32_t i = 0; i < len; ++i) h = bam_qh2_step(h, name[i]);
+    return bam_qh2_finish(h, len);
+}
+
 struct BamTagSpec {
     int32_t n_ref;
     uint8_t have_ch, ch0, ch1, n_filter;
@@ -122,6 +137,7 @@ struct BamRecOut {
     uint32_t n_ops, ops_off;     // operations and where they start, from rec
     uint32_t wide;
     uint32_t qname_len;          // bytes before the NUL
+    uint32_t qhash2;             // rsqc_qname_hash2 of the name (the batch's qhash2 column)
 };
 
 // one record; false = malformed ("bad BAM record")
@@ -138,6 +154,7 @@ RSQC_BAM_FN bool bam_parse_record(const uint8_t *rec, uint32_t block_size, const
     // byte loads are a memory round trip each, and the name is the longest run of them in a record
     uint32_t qlen = 0;
     uint64_t qh = 0xCBF29CE484222325ull;
+    uint32_t qh2 = BAM_QH2_SEED;
     {
         const uint8_t *qn = r + 32;
         const uint32_t room = (32ull + l_name <= block_size) ? l_name : 0u;
@@ -147,17 +164,18 @@ RSQC_BAM_FN bool bam_parse_record(const uint8_t *rec, uint32_t block_size, const
             for (uint32_t k = 0; k < 8u; ++k, w >>= 8) {
                 const uint32_t b = (uint32_t)w & 0xFFu;
                 if (!b) { open_ = false; break; }
-                qh ^= b; qh *= 0x100000001B3ull; ++qlen;
+                qh ^= b; qh *= 0x100000001B3ull; qh2 = bam_qh2_step(qh2, b); ++qlen;
             }
         }
         while (open_ && qlen < room) {
             const uint32_t b = qn[qlen];
             if (!b) break;
-            qh ^= b; qh *= 0x100000001B3ull; ++qlen;
+            qh ^= b; qh *= 0x100000001B3ull; qh2 = bam_qh2_step(qh2, b); ++qlen;
         }
         qh ^= qh >> 33; qh *= 0xFF51AFD7ED558CCDull; qh ^= qh >> 33; qh *= 0xC4CEB9FE1A85EC53ull; qh ^= qh >> 33;
     }
     o.qname_len = qlen;
+    o.qhash2 = bam_qh2_finish(qh2, qlen);
     o.core.pos = pos; o.core.mpos = mpos; o.core.isize = isize; o.core.cigar_off = 0;
     o.aux.qhash = qh;
     o.aux.flag = (uint16_t)flag; o.aux.mapq = (uint8_t)mapq;

@@ -37,7 +37,7 @@ struct DecodeWindow {
     const uint8_t *buf; uint32_t start, end, n_seg;        // records live in buf[start, end), cut into n_seg segments
     BamSegment *seg; uint32_t *seg_rec0, *seg_ops0;
     uint32_t *rec_off, *ops_at; uint8_t *mark;
-    rsqc_rec_core *core; rsqc_rec_aux *aux; uint32_t *cigar;
+    rsqc_rec_core *core; rsqc_rec_aux *aux; uint32_t *qh2, *cigar;
     int32_t *seg_tid; uint64_t *seg_start;
     uint64_t *wide_index; int32_t *wide_nm, *wide_lq; uint32_t *wide_nc;
     DecodeSummary *sum; DecodeCarry *carry;
@@ -71,7 +71,7 @@ RSQC_BAM_FN uint32_t decode_parse_one(const DecodeWindow &W, uint32_t i, bool &u
     if (!bam_parse_record(rec, bs, W.tags, ro)) { W.mark[i] = 0; return DEC_ST_BAD_RECORD; }
     const uint32_t at = W.ops_at[i];
     ro.core.cigar_off = at;
-    W.core[i] = ro.core; W.aux[i] = ro.aux;
+    W.core[i] = ro.core; W.aux[i] = ro.aux; W.qh2[i] = ro.qhash2;
     const uint8_t *ops = rec + ro.ops_off;
     for (uint32_t k = 0; k < ro.n_ops; ++k) W.cigar[at + k] = bam_ld32(ops + 4u * k);
     uint32_t m = 0;

@@ -173,7 +173,7 @@ struct K1eShared {
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
-                                           uint64_t qhash, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
+                                           uint64_t qhash, uint32_t qh2, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2 /* null: the batch has no second hashes */, uint32_t chunk_cap) {
     const int l = lane_id();
     typedef WaveSink WS;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             base = lane_value(base, lead);
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
-                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; }
+                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; if (my_pair_h2) my_pair_h2[slot] = qh2; }
                 else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
             }
         }
@@ -251,7 +251,7 @@ __device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
 template <int NB>
 __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const rsqc_rec_aux *aux, uint32_t *cov_diff,
                                             const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
-                                            uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
+                                            uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, const uint32_t *qh2col, uint32_t chunk_cap) {
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
     const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
@@ -271,11 +271,12 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     // the name hash is only needed by records that are counted to a gene: it comes back from the record array (the lines
     // were streamed through this CU's caches a few tiles ago) instead of riding through the queue
     const uint2 qh = ld32(reinterpret_cast<const uint2 *>(aux), idx * 2u);
+    const uint32_t qh2 = qh2col ? ld32(qh2col, idx) : 0u;        // (uniform branch: the batch carries second name hashes or it does not)
     WaveSink cnt;
     EiOut eo; bool over = false;
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), my_pair_gene, my_pair_hash, chunk_cap);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, my_pair_gene, my_pair_hash, qh2col ? my_pair_h2 : nullptr, chunk_cap);
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -284,7 +285,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
 // first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count -------------------------------
 __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
                                                  const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk,
-                                                 uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t chunk_cap) {
+                                                 uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, uint32_t chunk_cap) {
     const int l = lane_id();
     const bool on0 = (uint32_t)l < n;
     uint4 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
@@ -328,6 +329,8 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
     }
     const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
     const uint64_t qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
+    const uint32_t qh2 = b.qhash2 ? ld32(b.qhash2, idx) : 0u;
+    uint32_t *const pair_h2_or_null = b.qhash2 ? my_pair_h2 : nullptr;
     // three blocks (aMbNcMdNeM) are nine in ten of these records: a tile without a four-block record runs three look-up rounds
     // and six commit slots instead of four and eight
     if (__ballot(fast && cw.nblocks > 3u) == 0ull) {
@@ -335,12 +338,12 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         EiOut eo; bool over = false;
         exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, my_pair_gene, my_pair_hash, chunk_cap);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, my_pair_gene, my_pair_hash, pair_h2_or_null, chunk_cap);
     } else {
         EiOut eo; bool over = false;
         exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, my_pair_gene, my_pair_hash, chunk_cap);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, my_pair_gene, my_pair_hash, pair_h2_or_null, chunk_cap);
     }
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
@@ -488,6 +491,7 @@ classify_ei_kernel(K1Args A) {
     const uint32_t chunk_cap = acc.pair_chunk_cap;
     uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
     uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
+    uint32_t *const my_pair_h2 = acc.pair_h2 + (size_t)blockIdx.x * chunk_cap;
     uint32_t seg = wbeg < n_rec ? find_segment(b, wbeg) : 0u;
     int32_t u_tid = -1;
     ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -694,21 +698,21 @@ classify_ei_kernel(K1Args A) {
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, my_pair_h2, b.qhash2, chunk_cap);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
             RSQC_MARK(9);                          // [9] one-block tiles
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, my_pair_h2, b.qhash2, chunk_cap);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
             RSQC_MARK(10);                         // [10] two-block tiles
         }
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, my_pair_gene, my_pair_hash, chunk_cap);
+            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
             h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
             RSQC_MARK(11);                         // [11] long-CIGAR tiles
             if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)

@@ -94,11 +94,12 @@ struct SlowAcc {
         if (len == 0) return;
         cov_add(cidx, 1u); cov_add(cidx + len, 0xFFFFFFFFu);
     }
+    uint32_t qh2 = 0;            // second name hash of the record being counted (0 without rsqc_batch.qhash2)
     __device__ __forceinline__ void gene_hit(uint32_t g, bool notdup, uint64_t qhash) {   // genes beyond the wave-aggregated ones
         atomicAdd(&acc->gene_reads[g], 1ull);
         if (notdup) atomicAdd(&acc->gene_unique[g], 1ull);
         const uint32_t slot = atomicAdd(acc->pair_slow_count, 1u);
-        if (slot < acc->pair_slow_cap) { acc->pair_gene[acc->pair_slow_base + slot] = g; acc->pair_hash[acc->pair_slow_base + slot] = qhash; }
+        if (slot < acc->pair_slow_cap) { acc->pair_gene[acc->pair_slow_base + slot] = g; acc->pair_hash[acc->pair_slow_base + slot] = qhash; acc->pair_h2[acc->pair_slow_base + slot] = qh2; }
         else atomicExch(acc->error, RSQC_ERR_CAPACITY);
     }
 };
@@ -128,7 +129,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
         uint64_t bits = 0;
         FeatureOut<MID_SET, SLOW_STAGE> fm;
         fm.bits = 0; fm.n_hit = 0; fm.n_commit = 0;
-        uint32_t aligned = 1; bool notdup = false; uint64_t qhash = 0;
+        uint32_t aligned = 1; bool notdup = false; uint64_t qhash = 0; uint32_t qh2 = 0;
         if (k < n) {
             Record r;
             // bit 63 of a listed index: classify_ei_kernel did not walk this record's CIGAR to the end (a long-CIGAR straggler of a
@@ -143,7 +144,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                     if (rc.blocks) atomicAdd(&acc.counters[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)rc.blocks);
                 }
                 if (go) {
-                    notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
+                    notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash; qh2 = b.qhash2 ? b.qhash2[i] : 0u; sacc.qh2 = qh2;
                     bool overflow = false;
                     if (LEGACY) {
                         LegacyOut<MID_SET> lo;
@@ -169,7 +170,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                                 atomicAdd(&acc.gene_reads[g], 1ull);
                                 if (notdup) atomicAdd(&acc.gene_unique[g], 1ull);
                                 const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
-                                if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; }
+                                if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; acc.pair_h2[acc.pair_slow_base + slot] = qh2; }
                                 else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                             }
                             bits = fo.bits;
@@ -203,7 +204,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                 base = __shfl(base, lead0, 64);
                 if (has) {
                     const uint32_t slot = base + mask_rank(m);
-                    if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; }
+                    if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; acc.pair_h2[acc.pair_slow_base + slot] = qh2; }
                     else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                 }
                 wave_by_key(has, g, [&](int lead, uint32_t gg, bool, uint64_t same) {

@@ -110,8 +110,8 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
 // repeats the counting kernel would throw away: a direct-mapped LDS window over the WHOLE chunk (one 64-bit exchange per pair,
 // never cleared between passes, no probing: a newer pair simply replaces an older one) drops a pair whose word is already
 // there.  (A per-pass table with probing removed 12 % of the keys for 18 % of the kernel; the window removes the mates.)
-// The word is key ^ f(gene): two different (gene, key) pairs share a word with probability 2^-64 per comparison, the same
-// order as two names sharing a 64-bit hash, which is the identity this stage works with (include/rnaseqc_amd.h).
+// The word is key ^ f(gene), compared together with the pair's second name hash (rsqc_batch.qhash2, a parallel 32-bit window):
+// a pair is dropped only against its own (gene, 96-bit name identity).
 #ifndef RSQC_K4L_THREADS
 #define RSQC_K4L_THREADS 512
 #endif
@@ -127,12 +127,13 @@ constexpr int k4l_log2(unsigned v) { return v <= 1 ? 0 : 1 + k4l_log2(v >> 1); }
 struct K4LocalShared {
     uint32_t gkey[RSQC_K4L_GSLOTS], gcnt[RSQC_K4L_GSLOTS];      // keyed by partition id: pairs of the pass, then their first list slot
     unsigned long long win[RSQC_K4L_WIN];       // direct-mapped window of the chunk's recent (gene, key) words: see the kernel
+    uint32_t win2[RSQC_K4L_WIN];                // ... and their second name hash (rsqc_batch.qhash2; all 0 without it)
 };
 
 __global__ void __launch_bounds__(RSQC_K4L_THREADS)
-frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t chunk_cap,
+frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const uint32_t *pair_h2 /* null: 64-bit identity */, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, unsigned long long *list, int *error) {
+                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, unsigned long long *list, uint32_t *list2 /* with pair_h2 */, int *error) {
     __shared__ K4LocalShared S;
     uint32_t base, count, piece0 = 0; constexpr uint32_t piece_step = 1;
     if (blockIdx.x < n_chunks) {
@@ -153,13 +154,14 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
         piece0 = me * per < n_pieces ? me * per : n_pieces;
         n_pieces = piece0 + per < n_pieces ? piece0 + per : n_pieces;
     }
-    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U]) {
+    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U], uint32_t (&h2)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
             const bool ok = piece < n_pieces && j < count;
             g[u] = ok ? pair_gene[base + j] : NONE;
             key[u] = ok ? pair_hash[base + j] : 0ull;
+            h2[u] = (ok && pair_h2) ? pair_h2[base + j] : 0u;
         }
     };
 #ifdef RSQC_K1_PROF
@@ -168,17 +170,17 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
         if (threadIdx.x == 0) g_dbg_pair_count = count;
     }
 #endif
-    uint32_t g[U]; uint64_t key[U];
-    load_piece(piece0, g, key);
-    for (int i = threadIdx.x; i < RSQC_K4L_WIN; i += blockDim.x) S.win[i] = 0ull;
+    uint32_t g[U]; uint64_t key[U]; uint32_t h2[U];
+    load_piece(piece0, g, key, h2);
+    for (int i = threadIdx.x; i < RSQC_K4L_WIN; i += blockDim.x) { S.win[i] = 0ull; S.win2[i] = 0u; }
     RSQC_FIN_BEGIN
     for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
         RSQC_FIN_SECT(32, 0);
         uint4 gi[U]; uint64_t gb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; gb[u] = gene_base[gq]; }
-        uint32_t gn[U]; uint64_t keyn[U];
-        load_piece(piece + piece_step, gn, keyn);
+        uint32_t gn[U]; uint64_t keyn[U]; uint32_t h2n[U];
+        load_piece(piece + piece_step, gn, keyn, h2n);
         __syncthreads();                                                   // (the previous pass has read its list slots)
         for (int i = threadIdx.x; i < RSQC_K4L_GSLOTS; i += blockDim.x) { S.gkey[i] = NONE; S.gcnt[i] = 0u; }
         __syncthreads();
@@ -194,7 +196,10 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
                 if (lk == 0ull) lk = 1ull;
                 static_assert((RSQC_K4L_WIN & (RSQC_K4L_WIN - 1)) == 0, "window size");
                 const uint32_t ws = ((((uint32_t)lk ^ (uint32_t)(lk >> 32)) * 0x9E3779B1u) >> 12) & (RSQC_K4L_WIN - 1);
-                if (atomicExch(&S.win[ws], lk) == lk) { g[u] = NONE; continue; }      // its mate went through this chunk already
+                // (both words are exchanged: a pair is dropped only when the slot held ITS 96 bits -- two concurrent writers of one
+                //  slot can at worst make each other survive, which the exact count behind this stage absorbs)
+                const bool seen1 = atomicExch(&S.win[ws], lk) == lk, seen2 = atomicExch(&S.win2[ws], h2[u]) == h2[u];
+                if (seen1 && seen2) { g[u] = NONE; continue; }                          // its mate went through this chunk already
             }
             gp[u] = gi[u].x + (gi[u].y > 1 ? (uint32_t)(((unsigned long long)frag_part_hash(key[u]) * gi[u].y) >> 32) : 0u);
             static_assert((RSQC_K4L_GSLOTS & (RSQC_K4L_GSLOTS - 1)) == 0, "slot hash");
@@ -226,15 +231,18 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
             if (g[u] == NONE) continue;
             const uint32_t at = gslot[u] != NONE ? S.gcnt[gslot[u]] + rank[u] : atomicAdd(&cursor[gp[u]], 1u);   // (crowded table)
             const uint32_t cap = gi[u].z;
-            if (at < cap) list[gb[u] + (unsigned long long)(gp[u] - gi[u].x) * cap + at] = key[u];
-            else atomicExch(error, RSQC_ERR_CAPACITY);
+            if (at < cap) {
+                const unsigned long long where = gb[u] + (unsigned long long)(gp[u] - gi[u].x) * cap + at;
+                list[where] = key[u];
+                if (list2) list2[where] = h2[u];
+            } else atomicExch(error, RSQC_ERR_CAPACITY);
         }
         RSQC_FIN_SECT(32, 6);
 #ifdef RSQC_K1_PROF
         if (threadIdx.x == 0) atomicAdd(&g_fin_prof[32 + 15], 1ull);
 #endif
 #pragma unroll
-        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; }
+        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; h2[u] = h2n[u]; }
     }
 }
 
@@ -249,10 +257,16 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, uint32_t
 // frag_layout_kernel), the second walks that list.
 template <int SLOTS>
 __global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
-frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const unsigned long long *list,
+frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const unsigned long long *list, const uint32_t *list2 /* null: 64-bit identity */,
                   unsigned long long *gene_frag, uint32_t *full_list, uint32_t *full_n, int *error) {
     constexpr bool LISTED = SLOTS == RSQC_K4_PART_SLOTS;
     __shared__ unsigned long long s_keys[SLOTS];
+    __shared__ uint32_t s_h2[SLOTS];                                       // second hash of the slot's owner (list2)
+    // two names with one 64-bit hash and different second hashes (never seen outside the crafted fixture): set aside here and
+    // counted by one thread
+    constexpr uint32_t OVF = 32;
+    __shared__ unsigned long long s_ovk[OVF];
+    __shared__ uint32_t s_ov2[OVF], s_ovn;
     __shared__ uint32_t s_fresh[2];
     constexpr int KPT = (SLOTS / 2) / RSQC_K4_COUNT_THREADS;                // keys per thread of the fullest list of this instance
     constexpr uint32_t N_LO = SLOTS == RSQC_K4_PART_SLOTS ? (uint32_t)SLOTS / 4u : 0u;   // this instance: N_LO < keys <= SLOTS / 2
@@ -269,23 +283,29 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
         }
         return r;
     };
-    auto keys_of = [&](const Row &r, unsigned long long (&kv)[KPT]) {
+    auto keys_of = [&](const Row &r, unsigned long long (&kv)[KPT], uint32_t (&k2)[KPT]) {
         const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
-        const unsigned long long *keys = list + ((unsigned long long)r.info.z | ((unsigned long long)r.info.w << 32));
+        const unsigned long long off = (unsigned long long)r.info.z | ((unsigned long long)r.info.w << 32);
+        const unsigned long long *keys = list + off;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) { const uint32_t i = (uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x; kv[j] = i < n ? keys[i] : 0ull; }
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t i = (uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x;
+            kv[j] = i < n ? keys[i] : 0ull;
+            k2[j] = (i < n && list2) ? list2[off + i] : 0u;
+        }
     };
     uint32_t w = blockIdx.x;
     Row cur = row_of(w), nxt = row_of(w + gridDim.x);
-    unsigned long long kv[KPT], kvn[KPT];
-    keys_of(cur, kv);
+    unsigned long long kv[KPT], kvn[KPT]; uint32_t k2[KPT], k2n[KPT];
+    keys_of(cur, kv, k2);
     if (threadIdx.x < 2) s_fresh[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_ovn = 0u;
     uint32_t round = 0;
     RSQC_FIN_BEGIN
     while (w < n_parts) {
         RSQC_FIN_SECT(48, 0);
         const Row nn = row_of(w + 2u * gridDim.x);
-        keys_of(nxt, kvn);
+        keys_of(nxt, kvn, k2n);
         if (!LISTED && cur.fuller && threadIdx.x == 0) full_list[atomicAdd(full_n, 1u)] = w;
         if (cur.fill != 0u) {                                               // (uniform)
             const uint32_t gene = cur.info.x, cap = cur.info.y;
@@ -299,25 +319,49 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
             __syncthreads();
             RSQC_FIN_SECT(48, 1);
             uint32_t fresh = 0;
-            auto insert = [&](unsigned long long k) {
+            constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+            // returns the slot whose owner has the same 64-bit key (its second hash is compared after the barrier below: the owner
+            // may not have written it yet), NO_SLOT when the key was placed (or the set is full)
+            auto insert = [&](unsigned long long k, uint32_t h2) -> uint32_t {
                 // (the keys are fmix64 outputs and the partition was chosen from the HIGH word: the low word is as good as a
                 //  fresh hash inside the partition; one multiply spreads neighbouring values anyway)
                 uint32_t slot = (((uint32_t)k * 0x9E3779B1u) >> 16) & smask;
-                bool placed = false;
 #pragma unroll 1
                 for (uint32_t probe = 0; probe < slots; ++probe) {
                     const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
-                    if (old == 0ull) { ++fresh; placed = true; break; }
-                    if (old == k) { placed = true; break; }
+                    if (old == 0ull) { s_h2[slot] = h2; ++fresh; return NO_SLOT; }
+                    if (old == k) return list2 ? slot : NO_SLOT;
                     slot = (slot + 1) & smask;
                 }
-                if (!placed) atomicExch(error, RSQC_ERR_CAPACITY);
+                atomicExch(error, RSQC_ERR_CAPACITY);
+                return NO_SLOT;
             };
+            uint32_t same[KPT];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) if ((uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x < n) insert(kv[j]);
-            if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) {               // (a list is never longer than SUB_CAP: kept for safety)
+            for (int j = 0; j < KPT; ++j) same[j] = ((uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x < n) ? insert(kv[j], k2[j]) : NO_SLOT;
+            if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) {               // (a list is never longer than SUB_CAP: kept for safety; 64-bit identity there)
                 const unsigned long long *keys = list + ((unsigned long long)cur.info.z | ((unsigned long long)cur.info.w << 32));
-                for (uint32_t i = (uint32_t)KPT * RSQC_K4_COUNT_THREADS + threadIdx.x; i < n; i += RSQC_K4_COUNT_THREADS) insert(keys[i]);
+                for (uint32_t i = (uint32_t)KPT * RSQC_K4_COUNT_THREADS + threadIdx.x; i < n; i += RSQC_K4_COUNT_THREADS) (void)insert(keys[i], 0u);
+                if (list2) atomicExch(error, RSQC_ERR_CAPACITY);
+            }
+            if (list2) {                                                    // (uniform) the 96-bit identity: second hashes of equal keys
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < KPT; ++j)
+                    if (same[j] != NO_SLOT && s_h2[same[j]] != k2[j]) {
+                        const uint32_t at = atomicAdd(&s_ovn, 1u);
+                        if (at < OVF) { s_ovk[at] = kv[j]; s_ov2[at] = k2[j]; } else atomicExch(error, RSQC_ERR_CAPACITY);
+                    }
+                __syncthreads();
+                if (threadIdx.x == 0 && s_ovn) {
+                    const uint32_t m = s_ovn < OVF ? s_ovn : OVF;
+                    for (uint32_t a = 0; a < m; ++a) {
+                        bool first = true;
+                        for (uint32_t b2 = 0; b2 < a; ++b2) if (s_ovk[b2] == s_ovk[a] && s_ov2[b2] == s_ov2[a]) first = false;
+                        if (first) ++fresh;
+                    }
+                    s_ovn = 0u;
+                }
             }
             RSQC_FIN_SECT(48, 2);
             fresh = wave_sum(fresh);
@@ -334,7 +378,7 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
         }
         w += gridDim.x; cur = nxt; nxt = nn;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) kv[j] = kvn[j];
+        for (int j = 0; j < KPT; ++j) { kv[j] = kvn[j]; k2[j] = k2n[j]; }
     }
 }
 

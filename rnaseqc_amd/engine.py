@@ -64,6 +64,7 @@ def load_library():
         lib.rsqc_counter_name.argtypes = [C.c_int]; lib.rsqc_counter_name.restype = C.c_char_p
         lib.rsqc_version.restype = C.c_char_p
         lib.rsqc_qname_hash.argtypes = [C.c_char_p, C.c_size_t]; lib.rsqc_qname_hash.restype = C.c_uint64
+        lib.rsqc_qname_hash2.argtypes = [C.c_char_p, C.c_size_t]; lib.rsqc_qname_hash2.restype = C.c_uint32
         lib.rsqc_decode_begin.argtypes = [vp, C.POINTER(abi.DecodeParams)]
         lib.rsqc_decode_submit.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(abi.DecodeWindow)]
         lib.rsqc_decode_end.argtypes = [vp, C.POINTER(abi.DecodeInfo)]
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "rsqc_upload", "rsqc_submit_resident", "rsqc_release", "rsqc_finalize", "rsqc_reset", "rsqc_get_timing",
     "rsqc_reset_timing", "rsqc_device_accumulators", "rsqc_device_vectors", "rsqc_shard_summary", "rsqc_reduce_peer", "rsqc_reduce_group",
     "rsqc_group_create", "rsqc_group_reduce", "rsqc_group_info", "rsqc_group_destroy", "rsqc_refresh_results", "rsqc_finalize_device", "rsqc_host_alloc", "rsqc_host_free", "rsqc_strerror",
-    "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash",
+    "rsqc_last_error", "rsqc_counter_name", "rsqc_version", "rsqc_qname_hash", "rsqc_qname_hash2",
     "rsqc_decode_begin", "rsqc_decode_submit", "rsqc_decode_end",
 ]
 

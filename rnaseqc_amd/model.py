@@ -257,6 +257,7 @@ class Batch:
     qname_off: np.ndarray | None = None
     qname: np.ndarray | None = None
     file_index_base: int = 0
+    qhash2: np.ndarray | None = None      # rsqc_batch.qhash2 (second name hash, uint32 per record); None = the 64-bit identity
 
     _DT = dict(pos=np.int32, mpos=np.int32, isize=np.int32, qhash=np.uint64, cigar_off=np.uint32,
                flag=np.uint16, l_qseq=np.uint16, mapq=np.uint8, nm=np.uint8, tagbits=np.uint8,
@@ -303,6 +304,9 @@ class Batch:
             self.qname_off = np.ascontiguousarray(self.qname_off, dtype=np.uint32)
             self.qname = np.ascontiguousarray(self.qname, dtype=np.uint8)
             s.qname_off, s.qname = abi.ptr(self.qname_off), abi.ptr(self.qname)
+        if self.qhash2 is not None:
+            self.qhash2 = np.ascontiguousarray(self.qhash2, dtype=np.uint32)
+            s.qhash2 = abi.ptr(self.qhash2)
         return s
 
     # ---------------------------------------------------------------- builders
@@ -318,6 +322,7 @@ class Batch:
         cig, wide = [], []
         seg_tid, seg_start = [], []
         names, noff = bytearray(), [0]
+        qh2 = np.zeros(n, np.uint32)
         for i, r in enumerate(records):
             tid = int(r.get("tid", 0))
             if not seg_tid or seg_tid[-1] != tid:
@@ -332,6 +337,7 @@ class Batch:
             names += qn
             noff.append(len(names))
             b["qhash"][i] = abi.qname_hash(qn)
+            qh2[i] = abi.qname_hash2(qn)
             tb = 0
             nmv = r.get("nm", 0)
             if nmv is not None:
@@ -365,7 +371,7 @@ class Batch:
                      wide_l_qseq=np.array([w[2] for w in wide], np.int32),
                      wide_n_cigar=np.array([w[3] for w in wide], np.uint32),
                      qname_off=np.array(noff, np.uint32), qname=np.frombuffer(bytes(names), dtype=np.uint8).copy(),
-                     **b)
+                     qhash2=qh2, **b)
 
     @staticmethod
     def concat(parts: Sequence["Batch"]) -> "Batch":
@@ -403,7 +409,8 @@ class Batch:
                      seg_start=np.asarray(seg_start, np.uint64),
                      wide_index=np.concatenate([(p.wide_index.astype(np.int64) + n_at[k]) for k, p in enumerate(parts)]).astype(np.uint64),
                      wide_nm=cat("wide_nm"), wide_l_qseq=cat("wide_l_qseq"), wide_n_cigar=cat("wide_n_cigar"),
-                     file_index_base=parts[0].file_index_base, **kw)
+                     file_index_base=parts[0].file_index_base,
+                     qhash2=(np.concatenate([p.qhash2 for p in parts]) if all(p.qhash2 is not None for p in parts) else None), **kw)
 
     def take(self, idx) -> "Batch":
         """The records idx[0], idx[1], ... as a new batch (any order, e.g. a coordinate sort of a concatenation)."""
@@ -441,7 +448,8 @@ class Batch:
                      seg_tid=np.asarray(seg_tid, np.int32), seg_start=np.asarray(seg_start, np.uint64),
                      wide_index=np.array([w[0] for w in wsel], np.uint64), wide_nm=self.wide_nm[[w[1] for w in wsel]] if wsel else np.zeros(0, np.int32),
                      wide_l_qseq=self.wide_l_qseq[[w[1] for w in wsel]] if wsel else np.zeros(0, np.int32),
-                     wide_n_cigar=self.wide_n_cigar[[w[1] for w in wsel]] if wsel else np.zeros(0, np.uint32), **kw)
+                     wide_n_cigar=self.wide_n_cigar[[w[1] for w in wsel]] if wsel else np.zeros(0, np.uint32),
+                     qhash2=(self.qhash2[idx] if self.qhash2 is not None else None), **kw)
 
     def coordinate_sorted(self) -> "Batch":
         """Stable sort by (contig, position), unplaced records last: what a coordinate-sorted BAM holds."""
@@ -479,4 +487,5 @@ class Batch:
                      seg_start=np.asarray(seg_start, np.uint64),
                      wide_index=(self.wide_index[wm] - lo).astype(np.uint64), wide_nm=self.wide_nm[wm].copy(),
                      wide_l_qseq=self.wide_l_qseq[wm].copy(), wide_n_cigar=self.wide_n_cigar[wm].copy(),
-                     file_index_base=self.file_index_base + lo, **kw)
+                     file_index_base=self.file_index_base + lo,
+                     qhash2=(self.qhash2[lo:hi].copy() if self.qhash2 is not None else None), **kw)

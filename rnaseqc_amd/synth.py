@@ -465,7 +465,7 @@ def make_reads(ann: Annotation, n_pairs: int, seed: int = 2, read_len: int = 150
               cigar_off=coff.astype(np.uint32), flag=flag.astype(np.uint16), l_qseq=lq.astype(np.uint16),
               mapq=mapq.astype(np.uint8), nm=nm.astype(np.uint8), tagbits=tagbits.astype(np.uint8),
               n_cigar=ncig.astype(np.uint8), cigar=flat.astype(np.uint32), seg_tid=seg_tid.astype(np.int32),
-              seg_start=seg_start)
+              seg_start=seg_start, qhash2=abi.qname_hash2_bytes(digits))
     if keep_qnames:
         b.qname = digits.reshape(-1).copy()
         b.qname_off = (np.arange(N + 1, dtype=np.uint32) * 16).astype(np.uint32)
@@ -545,7 +545,7 @@ def make_reads_sharded(ann: Annotation, n_pairs: int, seed: int = 2, contigs=Non
                                mapq=np.zeros(nu, np.uint8), nm=np.zeros(nu, np.uint8),
                                tagbits=np.full(nu, abi.TB_MTID_SAME, np.uint8), n_cigar=np.zeros(nu, np.uint8),
                                cigar=np.zeros(0, np.uint32), seg_tid=np.array([-1], np.int32),
-                               seg_start=np.array([0, nu], np.uint64)))
+                               seg_start=np.array([0, nu], np.uint64), qhash2=abi.qname_hash2_bytes(digits)))
     if as_parts:
         # one batch per contig (+ the unmapped tail), each a contiguous range of the file.  file_index_base is a VIRTUAL
         # file index, contig << 32: monotone in file order, which is all the boundary asks for (gaps are allowed), and

@@ -104,14 +104,14 @@ def build_k4():
     return _K4SO
 
 
-def run_k4(seed, n_genes, n_chunks, n_names, hot_reads, arena=False):
+def run_k4(seed, n_genes, n_chunks, n_names, hot_reads, arena=False, wide=False):
     """The fragment-counting KERNELS (rsqc_k4.h) on the 64-lane fiber emulation against a std::set per gene.
     Returns (rc, stats): rc 0 = every gene's count equals its name set; stats = pairs, keys kept by frag_local, partitions,
     partitions left to the second counting instance, distinct (gene, name) pairs, chunk capacity."""
     lib = C.CDLL(build_k4())
     lib.k4emu_run.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     st = np.zeros(6, np.uint64)
-    rc = lib.k4emu_run(seed, n_genes, n_chunks, n_names, hot_reads, 1 if arena else 0, st.ctypes.data)
+    rc = lib.k4emu_run(seed, n_genes, n_chunks, n_names, hot_reads, (1 if arena else 0) | (2 if wide else 0), st.ctypes.data)
     return rc, dict(zip(("pairs", "kept", "partitions", "fuller", "distinct", "chunk_cap"), (int(x) for x in st)))
 
 

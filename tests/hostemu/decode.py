@@ -112,7 +112,7 @@ def decode_stream(stream, first, n_ref, window_bytes, ch_tag="ch", filter_tags=(
     l = lib()
     tags = tag_spec(n_ref, ch_tag, filter_tags)
     carry = (C.c_int32 * 3)(0, 0, 0)
-    cores, auxs, cigs, seg_tid, seg_start, wide = [], [], [], [], [], []
+    cores, auxs, qh2s, cigs, seg_tid, seg_start, wide = [], [], [], [], [], [], []
     out = Decoded(); out.unsorted = False; out.bad_names = []; out.status = 0; out.windows = 0
     pos, tail, n_total, ops_total = first, b"", 0, 0
     while pos < len(stream) or tail:
@@ -121,12 +121,12 @@ def decode_stream(stream, first, n_ref, window_bytes, ch_tag="ch", filter_tags=(
         if not new and tail:
             raise RuntimeError("truncated BAM record")
         cap = len(buf) // 36 + 2
-        core = np.zeros(cap, abi.REC_CORE); aux = np.zeros(cap, abi.REC_AUX); cig = np.zeros(len(buf) // 4 + 2, np.uint32)
+        core = np.zeros(cap, abi.REC_CORE); aux = np.zeros(cap, abi.REC_AUX); qh2 = np.zeros(cap, np.uint32); cig = np.zeros(len(buf) // 4 + 2, np.uint32)
         st = np.zeros(cap, np.int32); ss = np.zeros(cap + 1, np.uint64)
         wi = np.zeros(cap, np.uint64); wn = np.zeros(cap, np.int32); wl = np.zeros(cap, np.int32); wc = np.zeros(cap, np.uint32)
         summ = np.zeros(8 + 64, np.uint32)
         padded = buf + b"\0" * 64
-        rc = l.emu_decode_window(padded, 0, len(buf), C.byref(tags), threads, carry, perturb, abi.ptr(core), abi.ptr(aux), abi.ptr(cig),
+        rc = l.emu_decode_window(padded, 0, len(buf), C.byref(tags), threads, carry, perturb, abi.ptr(core), abi.ptr(aux), abi.ptr(qh2), abi.ptr(cig),
                                  abi.ptr(st), abi.ptr(ss), abi.ptr(wi), abi.ptr(wn), abi.ptr(wl), abi.ptr(wc), abi.ptr(summ))
         assert rc == 0, "the listed repair and the sequential walk disagree (%d)" % rc
         n, ops, nseg, nwide, nbad, uns, consumed, status = [int(x) for x in summ[:8]]
@@ -135,7 +135,7 @@ def decode_stream(stream, first, n_ref, window_bytes, ch_tag="ch", filter_tags=(
             break
         out.windows += 1
         core = core[:n].copy(); core["cigar_off"] += ops_total
-        cores.append(core); auxs.append(aux[:n].copy()); cigs.append(cig[:ops].copy())
+        cores.append(core); auxs.append(aux[:n].copy()); qh2s.append(qh2[:n].copy()); cigs.append(cig[:ops].copy())
         for k in range(nseg):
             if seg_tid and k == 0 and seg_tid[-1] == int(st[0]):
                 continue                                    # the window continues the previous one's contig
@@ -150,6 +150,7 @@ def decode_stream(stream, first, n_ref, window_bytes, ch_tag="ch", filter_tags=(
         tail = buf[consumed:]
     out.core = np.concatenate(cores) if cores else np.zeros(0, abi.REC_CORE)
     out.aux = np.concatenate(auxs) if auxs else np.zeros(0, abi.REC_AUX)
+    out.qhash2 = np.concatenate(qh2s) if qh2s else np.zeros(0, np.uint32)
     out.cigar = np.concatenate(cigs) if cigs else np.zeros(0, np.uint32)
     out.seg_tid = np.array(seg_tid, np.int32); out.seg_start = np.array(seg_start + [n_total], np.uint64)
     out.wide = wide; out.n = n_total

@@ -55,7 +55,7 @@ uint32_t emu_crc_wave64(const uint8_t *data, uint32_t n, uint32_t crc_before) {
 
 extern "C" __attribute__((visibility("default")))
 int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const BamTagSpec *tags, int threads, int32_t *carry3, int perturb,
-                      rsqc_rec_core *core, rsqc_rec_aux *aux, uint32_t *cigar, int32_t *seg_tid, uint64_t *seg_start,
+                      rsqc_rec_core *core, rsqc_rec_aux *aux, uint32_t *qh2, uint32_t *cigar, int32_t *seg_tid, uint64_t *seg_start,
                       uint64_t *wide_index, int32_t *wide_nm, int32_t *wide_lq, uint32_t *wide_nc, uint32_t *summary /* 8 + 64 */) {
     DecodeWindow W{};
     W.buf = buf; W.start = start; W.end = end;
@@ -65,7 +65,7 @@ int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const Ba
     W.seg = seg.data(); W.seg_rec0 = rec0.data(); W.seg_ops0 = ops0.data();
     DecodeSummary sum{}; DecodeCarry carry{carry3[0], carry3[1], carry3[2]};
     W.sum = &sum; W.carry = &carry; W.tags = *tags;
-    W.core = core; W.aux = aux; W.cigar = cigar; W.seg_tid = seg_tid; W.seg_start = seg_start;
+    W.core = core; W.aux = aux; W.qh2 = qh2; W.cigar = cigar; W.seg_tid = seg_tid; W.seg_start = seg_start;
     W.wide_index = wide_index; W.wide_nm = wide_nm; W.wide_lq = wide_lq; W.wide_nc = wide_nc;
     for (uint32_t s = 0; s < W.n_seg; ++s) decode_frame_one(W, s);
     if (perturb == 1) for (uint32_t s = 1; s < W.n_seg; s += 3) { seg[s].start += (s % 2) ? 1 : 40; seg[s].n_rec += 1; }

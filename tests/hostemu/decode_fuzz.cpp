@@ -71,6 +71,7 @@ int main(int argc, char **argv) {
         if (end) memcpy(buf, w.data(), end);
         rsqc_rec_core *core = (rsqc_rec_core *)malloc(n_rec * sizeof(rsqc_rec_core));
         rsqc_rec_aux *aux = (rsqc_rec_aux *)malloc(n_rec * sizeof(rsqc_rec_aux));
+        uint32_t *qh2 = (uint32_t *)malloc(n_rec * 4);
         uint32_t *cigar = (uint32_t *)malloc(bytes + 256);
         int32_t *seg_tid = (int32_t *)malloc(n_rec * 4); uint64_t *seg_start = (uint64_t *)malloc((n_rec + 1) * 8);
         uint64_t *wide_index = (uint64_t *)malloc(n_rec * 8); int32_t *wide_nm = (int32_t *)malloc(n_rec * 4), *wide_lq = (int32_t *)malloc(n_rec * 4);
@@ -80,7 +81,7 @@ int main(int argc, char **argv) {
         BamTagSpec tags{};
         tags.n_ref = n_ref; tags.have_ch = 1; tags.ch0 = 'c'; tags.ch1 = 'h'; tags.n_filter = 1; tags.f0[0] = 'X'; tags.f1[0] = 'F';
         alarm(60);
-        const int rc = emu_decode_window(buf, start, end, &tags, 1 + (int)rnd(64), carry, 0, core, aux, cigar, seg_tid, seg_start, wide_index, wide_nm, wide_lq, wide_nc, summary);
+        const int rc = emu_decode_window(buf, start, end, &tags, 1 + (int)rnd(64), carry, 0, core, aux, qh2, cigar, seg_tid, seg_start, wide_index, wide_nm, wide_lq, wide_nc, summary);
         alarm(0);
         if (rc != 0) { fprintf(stderr, "decode_fuzz: case %ld (%s): the listed repair and the sequential walk disagree (%d)\n", c, g_what, rc); return 1; }
         const uint32_t n = summary[0], n_ops = summary[1], consumed = summary[6], status = summary[7];
@@ -90,7 +91,7 @@ int main(int argc, char **argv) {
             if (n > bytes / 36 || (uint64_t)n_ops * 4 > bytes || consumed > end || consumed < start) { fprintf(stderr, "decode_fuzz: case %ld (%s): counts beyond what the window can hold\n", c, g_what); return 1; }
             if (g_what[0] == 'c' && g_what[1] == 'l') { if (start == 0 && consumed != end) { fprintf(stderr, "decode_fuzz: case %ld: clean window not consumed\n", c); return 1; } ++clean; }
         }
-        free(buf); free(core); free(aux); free(cigar); free(seg_tid); free(seg_start); free(wide_index); free(wide_nm); free(wide_lq); free(wide_nc);
+        free(buf); free(core); free(aux); free(qh2); free(cigar); free(seg_tid); free(seg_start); free(wide_index); free(wide_nm); free(wide_lq); free(wide_nc);
     }
     printf("decode_fuzz: %ld cases: %ld windows decoded (%ld of them undamaged), %ld refused as bad records\n", cases, decoded, clean, refused);
     return 0;

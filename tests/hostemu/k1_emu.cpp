@@ -32,8 +32,8 @@ struct SlowAccH {
     std::vector<uint64_t> *reads, *unique;
     std::vector<double> *exon_rows;
     std::vector<uint32_t> *cov;
-    std::vector<std::set<uint64_t>> *names;
-    void gene_hit(uint32_t g, bool nd, uint64_t qh) { (*reads)[g]++; if (nd) (*unique)[g]++; (*names)[g].insert(qh); }
+    std::vector<std::set<std::pair<uint64_t, uint32_t>>> *names;          // a name = (64-bit hash, second hash)
+    void gene_hit(uint32_t g, bool nd, uint64_t qh, uint32_t qh2) { (*reads)[g]++; if (nd) (*unique)[g]++; (*names)[g].insert({qh, qh2}); }
     void exon_add(uint32_t row, double f) { (*exon_rows)[row] += f; }
     void cov_range(uint32_t cidx, uint32_t len) { if (!len) return; (*cov)[cidx] += 1u; (*cov)[cidx + len] -= 1u; }
 };
@@ -70,7 +70,10 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     std::vector<uint32_t> cigar((size_t)b->n_cigar_total + 8, 0u);
     if (n) { memcpy(core.data(), b->core, (size_t)n * sizeof(rsqc_rec_core)); memcpy(aux.data(), b->aux, (size_t)n * sizeof(rsqc_rec_aux)); }
     if (b->n_cigar_total) memcpy(cigar.data(), b->cigar, (size_t)b->n_cigar_total * 4);
+    std::vector<uint32_t> qh2((size_t)n + 2, 0u);
+    if (n && b->qhash2) memcpy(qh2.data(), b->qhash2, (size_t)n * 4);
     DevBatch db{};
+    db.qhash2 = b->qhash2 ? qh2.data() : nullptr;
     db.n = n; db.record_base = b->file_index_base; db.core = core.data(); db.aux = aux.data(); db.cigar = cigar.data();
     db.n_seg = b->n_seg; db.seg_tid = b->seg_tid; db.seg_start = b->seg_start;
     db.n_wide = b->n_wide; db.wide_index = b->wide_index; db.wide_nm = b->wide_nm; db.wide_l_qseq = b->wide_l_qseq; db.wide_n_cigar = b->wide_n_cigar;
@@ -83,7 +86,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     const uint64_t per_wave = (((n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
     const uint32_t chunk_cap = (uint32_t)(per_wave * K1E_WAVES * FAST_SET);
     const uint32_t slow_cap = 1u << 16;
-    std::vector<uint32_t> pair_gene((size_t)chunk_cap * grid + slow_cap + 8); std::vector<uint64_t> pair_hash(pair_gene.size());
+    std::vector<uint32_t> pair_gene((size_t)chunk_cap * grid + slow_cap + 8); std::vector<uint64_t> pair_hash(pair_gene.size()); std::vector<uint32_t> pair_h2(pair_gene.size(), 0xFEEDu);
     std::vector<uint32_t> chunk_count((size_t)grid + 2, 0xDEADu);
     std::vector<uint32_t> ovf_count(4, 0u); std::vector<uint64_t> ovf_index(1u << 20);
     std::vector<uint32_t> tile_span((size_t)((n + 63) / 64) + 64 * (size_t)total_waves + 64, 0xABCDu);
@@ -92,7 +95,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     DevAccum acc{};
     acc.gene_reads = u64.data(); acc.gene_unique = acc.gene_reads + G; acc.gene_frag = acc.gene_unique + G; acc.counters = acc.gene_frag + G;
     acc.exon_acc = exon_acc.data(); acc.cov_diff = cov.data();
-    acc.pair_gene = pair_gene.data(); acc.pair_hash = (uint64_t *)pair_hash.data();
+    acc.pair_gene = pair_gene.data(); acc.pair_hash = (uint64_t *)pair_hash.data(); acc.pair_h2 = pair_h2.data();
     acc.pair_chunk_cap = chunk_cap; acc.pair_chunk_count = chunk_count.data();
     acc.pair_slow_base = chunk_cap * (uint32_t)grid; acc.pair_slow_cap = slow_cap; acc.pair_slow_count = chunk_count.data() + grid;
     acc.ovf_count = ovf_count.data(); acc.ovf_index = (uint64_t *)ovf_index.data(); acc.ovf_cap = (uint32_t)ovf_index.size();
@@ -112,7 +115,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     // ---- the overflow list through the general per-record code ------------------------------------------------------
     std::vector<uint64_t> reads(G, 0), unique(G, 0);
     std::vector<double> exon_rows(E, 0.0);
-    std::vector<std::set<uint64_t>> names(G);
+    std::vector<std::set<std::pair<uint64_t, uint32_t>>> names(G);
     SlowAccH sacc{&reads, &unique, &exon_rows, &cov, &names};
     std::vector<int32_t> tid_of((size_t)n, -1);
     for (uint32_t s = 0; s < b->n_seg; ++s) for (uint64_t i = b->seg_start[s]; i < b->seg_start[s + 1]; ++i) tid_of[(size_t)i] = b->seg_tid[s];
@@ -151,7 +154,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         for (uint32_t j = 0; j < ns; ++j) {
             const uint32_t g = pair_gene[(size_t)acc.pair_slow_base + j];
             if (g >= G) return 1005;
-            names[g].insert(pair_hash[(size_t)acc.pair_slow_base + j]);
+            names[g].insert({pair_hash[(size_t)acc.pair_slow_base + j], pair_h2[(size_t)acc.pair_slow_base + j]});
         }
     } else
     for (uint32_t k = 0; k < ovf_count[0]; ++k) {
@@ -174,7 +177,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
             if (c.len > 0) sacc.exon_add(c.row, (double)c.len / (double)aligned);
             sacc.cov_range(c.cidx, c.len);
         }
-        for (int k2 = 0; k2 < so.n_hit; ++k2) sacc.gene_hit(so.hit[k2], !(r.flag & RSQC_FDUP), r.qhash);
+        for (int k2 = 0; k2 < so.n_hit; ++k2) sacc.gene_hit(so.hit[k2], !(r.flag & RSQC_FDUP), r.qhash, b->qhash2 ? b->qhash2[i] : 0u);
         for (int c = 0; c < RSQC_N_COUNTERS; ++c) if ((so.bits >> c) & 1ull) acc.counters[c]++;
     }
     // ---- pairs -> distinct names per gene ------------------------------------------------------------------------------
@@ -185,7 +188,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         for (uint32_t j = 0; j < cnt; ++j) {
             const uint32_t g = pair_gene[(size_t)k * chunk_cap + j];
             if (g >= G) return 1005;
-            names[g].insert(pair_hash[(size_t)k * chunk_cap + j]); ++n_pairs;
+            names[g].insert({pair_hash[(size_t)k * chunk_cap + j], pair_h2[(size_t)k * chunk_cap + j]}); ++n_pairs;
         }
     }
     // ---- Read-Length inputs: tile maxima and batch extremes against the per-record values; the state machine itself ---
@@ -223,7 +226,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         std::vector<uint4> ginfo(G + 1), part_info(parts_bound);
         std::vector<uint64_t> gene_base(G + 1);
         std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0u), full_list(parts_bound), blk_parts(lay_blocks);
-        std::vector<unsigned long long> blk_space(lay_blocks), list(keys_bound), frag(G, 0ull);
+        std::vector<unsigned long long> blk_space(lay_blocks), list(keys_bound), frag(G, 0ull); std::vector<uint32_t> list2(keys_bound);
         uint32_t full_n = 0;
         wavemu::grid_dim().x = lay_blocks;
         for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_totals_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), &error); }); }
@@ -234,13 +237,13 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         wavemu::grid_dim().x = lgrid;
         for (uint32_t k = 0; k < lgrid; ++k) {
             wavemu::block_idx().x = k;
-            wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), (const uint64_t *)pair_hash.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
-                                                                          ginfo.data(), gene_base.data(), cursor.data(), list.data(), &error); });
+            wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), (const uint64_t *)pair_hash.data(), pair_h2.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
+                                                                          ginfo.data(), gene_base.data(), cursor.data(), list.data(), list2.data(), &error); });
         }
         wavemu::grid_dim().x = 8;
-        for (uint32_t k = 0; k < 8; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), frag.data(), full_list.data(), &full_n, &error); }); }
+        for (uint32_t k = 0; k < 8; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), list2.data(), frag.data(), full_list.data(), &full_n, &error); }); }
         wavemu::grid_dim().x = 2;
-        for (uint32_t k = 0; k < 2; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), frag.data(), full_list.data(), &full_n, &error); }); }
+        for (uint32_t k = 0; k < 2; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), list2.data(), frag.data(), full_list.data(), &full_n, &error); }); }
         if (error) return error;
         for (size_t g = 0; g < G; ++g) {
             // (a key of 0 is stored as a fixed non-zero constant by frag_local_kernel: a name hashing to 0 and one hashing to that

@@ -30,18 +30,23 @@ struct Rng { uint64_t s; uint64_t next() { s += 0x9E3779B97F4A7C15ull; uint64_t 
 // returns 0 when every gene's count equals the size of its name set, else 1 + the first gene that differs; -code on a device error.
 extern "C" __attribute__((visibility("default")))
 int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_reads, int mode, uint64_t *stats /*[6]*/) {
+    // mode bit 0: dense-list form; bit 1: the 96-bit identity (second name hashes, with names that share their 64-bit key)
+    const bool has2 = (mode & 2) != 0; mode &= 1;
     Rng R{seed};
-    struct Pair { uint32_t g; uint64_t key; };
+    struct Pair { uint32_t g; uint64_t key; uint32_t h2; };
     std::vector<Pair> stream;
     // names: one or two records each; the second sits a random distance behind the first (inside or beyond the window, sometimes in
     // another chunk); one name in sixteen is also counted to a second gene with the same key; a few keys are 0
     for (int i = 0; i < n_names; ++i) {
         const uint32_t g = 1u + R.below((uint32_t)n_genes - 1u);
         uint64_t key = R.next(); if (i % 997 == 0) key = 0ull;
-        stream.push_back(Pair{g, key});
-        if (R.below(16) == 0) stream.push_back(Pair{1u + R.below((uint32_t)n_genes - 1u), key});
+        uint32_t h2 = has2 ? (uint32_t)R.next() : 0u;
+        // (96-bit identity) one name in 53 takes the 64-bit key -- and the gene -- of an earlier, different name: one more fragment
+        if (has2 && i % 53 == 52 && !stream.empty()) { const Pair &o = stream[R.below((uint32_t)stream.size())]; stream.push_back(Pair{o.g, o.key, h2}); if (R.below(2)) stream.push_back(Pair{o.g, o.key, h2}); continue; }
+        stream.push_back(Pair{g, key, h2});
+        if (R.below(16) == 0) stream.push_back(Pair{1u + R.below((uint32_t)n_genes - 1u), key, h2});
     }
-    for (int i = 0; i < hot_reads; ++i) stream.push_back(Pair{0u, R.next()});
+    for (int i = 0; i < hot_reads; ++i) stream.push_back(Pair{0u, R.next(), has2 ? (uint32_t)R.next() : 0u});
     // shuffle lightly, then add the mates at their distances
     for (size_t i = stream.size(); i > 1; --i) std::swap(stream[i - 1], stream[R.below((uint32_t)i)]);
     {
@@ -63,8 +68,8 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     const size_t n_pairs = stream.size();
     const uint32_t G = (uint32_t)n_genes;
     std::vector<unsigned long long> gene_reads(G, 0ull);
-    std::vector<std::set<uint64_t>> names(G);
-    for (const Pair &p : stream) { gene_reads[p.g]++; names[p.g].insert(p.key == 0ull ? 0x9e3779b97f4a7c15ull : p.key); }
+    std::vector<std::set<std::pair<uint64_t, uint32_t>>> names(G);
+    for (const Pair &p : stream) { gene_reads[p.g]++; names[p.g].insert({p.key == 0ull ? 0x9e3779b97f4a7c15ull : p.key, p.h2}); }
 
     // ---- the plan's arrays, sized like rsqc_api.cpp sizes them
     const uint64_t parts_bound = n_pairs / RSQC_K4_PART_READS + G + 1;
@@ -74,6 +79,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     std::vector<uint64_t> gene_base(G + 1);
     std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0xDEADBEEFu), full_list(parts_bound), blk_parts(lay_blocks);
     std::vector<unsigned long long> blk_space(lay_blocks), list(keys_bound, 0xABABABABABABABABull), gene_frag(G, 0ull);
+    std::vector<uint32_t> list2(keys_bound, 0xCDCDCDCDu);
     uint32_t full_n = 0xDEADBEEFu; int error = 0;
 
     wavemu::grid_dim().x = lay_blocks;
@@ -84,7 +90,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     if (n_parts > parts_bound || full_n != 0u) return -1000;
 
     // ---- the pairs as K1 leaves them
-    std::vector<uint32_t> pair_gene; std::vector<uint64_t> pair_hash; std::vector<uint32_t> counts;
+    std::vector<uint32_t> pair_gene; std::vector<uint64_t> pair_hash; std::vector<uint32_t> pair_h2; std::vector<uint32_t> counts;
     uint32_t chunk_cap = 0, slow_base = 0, slow_cap = 0, grid = 0, nch = 0;
     if (mode == 0) {
         nch = (uint32_t)n_chunks;
@@ -95,26 +101,26 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
         cut[nch] = body; std::sort(cut.begin(), cut.end());
         for (uint32_t c = 0; c < nch; ++c) chunk_cap = std::max<uint32_t>(chunk_cap, (uint32_t)(cut[c + 1] - cut[c]));
         chunk_cap += 7; slow_base = nch * chunk_cap; slow_cap = (uint32_t)slow_n + 5;
-        pair_gene.assign((size_t)slow_base + slow_cap, 0xFFFFFFF0u); pair_hash.assign((size_t)slow_base + slow_cap, 0ull);
+        pair_gene.assign((size_t)slow_base + slow_cap, 0xFFFFFFF0u); pair_hash.assign((size_t)slow_base + slow_cap, 0ull); pair_h2.assign((size_t)slow_base + slow_cap, 0xDEADu);
         counts.assign(nch + 1, 0u);
         for (uint32_t c = 0; c < nch; ++c) {
             counts[c] = (uint32_t)(cut[c + 1] - cut[c]);
-            for (size_t i = cut[c]; i < cut[c + 1]; ++i) { pair_gene[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].g; pair_hash[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].key; }
+            for (size_t i = cut[c]; i < cut[c + 1]; ++i) { pair_gene[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].g; pair_hash[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].key; pair_h2[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].h2; }
         }
         counts[nch] = (uint32_t)slow_n;
-        for (size_t i = 0; i < slow_n; ++i) { pair_gene[slow_base + i] = stream[body + i].g; pair_hash[slow_base + i] = stream[body + i].key; }
+        for (size_t i = 0; i < slow_n; ++i) { pair_gene[slow_base + i] = stream[body + i].g; pair_hash[slow_base + i] = stream[body + i].key; pair_h2[slow_base + i] = stream[body + i].h2; }
         grid = nch + 32u;
     } else {
         nch = 0; chunk_cap = 0; slow_base = 0; slow_cap = (uint32_t)n_pairs;
-        pair_gene.resize(n_pairs); pair_hash.resize(n_pairs); counts.assign(1, (uint32_t)n_pairs);
-        for (size_t i = 0; i < n_pairs; ++i) { pair_gene[i] = stream[i].g; pair_hash[i] = stream[i].key; }
+        pair_gene.resize(n_pairs); pair_hash.resize(n_pairs); pair_h2.resize(n_pairs); counts.assign(1, (uint32_t)n_pairs);
+        for (size_t i = 0; i < n_pairs; ++i) { pair_gene[i] = stream[i].g; pair_hash[i] = stream[i].key; pair_h2[i] = stream[i].h2; }
         grid = (uint32_t)std::min<uint64_t>(4096, n_pairs / 1024 + 1);
         grid = std::min<uint32_t>(grid, 24u);                                 // (emulation time; any sharing is legal)
     }
     wavemu::grid_dim().x = grid;
     for (uint32_t b = 0; b < grid; ++b) {
         wavemu::block_idx().x = b;
-        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), gene_base.data(), cursor.data(), list.data(), &error); });
+        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), has2 ? pair_h2.data() : nullptr, chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), gene_base.data(), cursor.data(), list.data(), has2 ? list2.data() : nullptr, &error); });
     }
     if (error) return -error;
     uint64_t kept = 0; uint32_t fuller = 0;
@@ -122,10 +128,10 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
 
     const uint32_t cgrid = 16;
     wavemu::grid_dim().x = cgrid;
-    for (uint32_t b = 0; b < cgrid; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), gene_frag.data(), full_list.data(), &full_n, &error); }); }
+    for (uint32_t b = 0; b < cgrid; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), has2 ? list2.data() : nullptr, gene_frag.data(), full_list.data(), &full_n, &error); }); }
     if (full_n != fuller) return -1002;
     wavemu::grid_dim().x = 4;
-    for (uint32_t b = 0; b < 4; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), gene_frag.data(), full_list.data(), &full_n, &error); }); }
+    for (uint32_t b = 0; b < 4; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), has2 ? list2.data() : nullptr, gene_frag.data(), full_list.data(), &full_n, &error); }); }
     if (error) return -error;
     if (stats) { stats[0] = n_pairs; stats[1] = kept; stats[2] = n_parts; stats[3] = fuller; stats[4] = 0; for (uint32_t g = 0; g < G; ++g) stats[4] += names[g].size(); stats[5] = chunk_cap; }
     for (uint32_t g = 0; g < G; ++g) if (gene_frag[g] != (unsigned long long)names[g].size()) return 1 + (int)g;

@@ -164,5 +164,6 @@ inline uint32_t atomicCAS(uint32_t *p, uint32_t cmp, uint32_t v) { const uint32_
 inline uint32_t atomicMax(uint32_t *p, uint32_t v) { const uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomicMin(uint32_t *p, uint32_t v) { const uint32_t o = *p; if (v < o) *p = v; return o; }
 inline int atomicExch(int *p, int v) { const int o = *p; *p = v; return o; }
+inline uint32_t atomicExch(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = v; return o; }
 inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long cmp, unsigned long long v) { const unsigned long long o = *p; if (o == cmp) *p = v; return o; }
 inline unsigned long long atomicExch(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = v; return o; }

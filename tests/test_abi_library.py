@@ -48,6 +48,7 @@ def test_counter_names_and_version():
     assert lib.rsqc_version().decode().startswith("RNASeQC 2")      # python/rnaseqc/run.py:25
     for name in [b"", b"a", b"SYN:000000000042", b"HWI-ST1234:100:C0ABCACXX:1:1101:1234:5678"]:
         assert lib.rsqc_qname_hash(name, len(name)) == abi.qname_hash(name)
+        assert lib.rsqc_qname_hash2(name, len(name)) == abi.qname_hash2(name)
 
 
 def test_no_cpu_fallback():

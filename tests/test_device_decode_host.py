@@ -86,6 +86,8 @@ def _check(dec, batch):
         np.testing.assert_array_equal(dec.core[f], getattr(batch, f), err_msg=f)
     for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
         np.testing.assert_array_equal(dec.aux[f], getattr(batch, f), err_msg=f)
+    if batch.qhash2 is not None:
+        np.testing.assert_array_equal(dec.qhash2, batch.qhash2, err_msg="qhash2")
     np.testing.assert_array_equal(dec.cigar, batch.cigar)
     np.testing.assert_array_equal(dec.seg_tid, batch.seg_tid)
     np.testing.assert_array_equal(dec.seg_start, batch.seg_start)

@@ -29,7 +29,7 @@ def decode_file(e, path, n_ref, ch_tag="ch", filter_tags=(), chunk_bytes=48 << 2
             s = e.last_decoded()
             assert s.n == n and s.n_seg == len(runs)
             rd = e.read_device
-            parts.append(dict(core=rd(s.core, n, abi.REC_CORE), aux=rd(s.aux, n, abi.REC_AUX), cigar=rd(s.cigar, s.n_cigar_total, np.uint32),
+            parts.append(dict(core=rd(s.core, n, abi.REC_CORE), aux=rd(s.aux, n, abi.REC_AUX), qhash2=rd(s.qhash2, n, np.uint32), cigar=rd(s.cigar, s.n_cigar_total, np.uint32),
                               seg_tid=rd(s.seg_tid, s.n_seg, np.int32), seg_start=rd(s.seg_start, s.n_seg + 1, np.uint64),
                               wide_index=rd(s.wide_index, s.n_wide, np.uint64), wide_nm=rd(s.wide_nm, s.n_wide, np.int32),
                               wide_lq=rd(s.wide_l_qseq, s.n_wide, np.int32), wide_nc=rd(s.wide_n_cigar, s.n_wide, np.uint32),
@@ -49,6 +49,8 @@ def check_columns(parts, batch, first_base=0):
             np.testing.assert_array_equal(p["core"][f], getattr(batch, f)[at:at + n], err_msg=f)
         for f in ("qhash", "flag", "l_qseq", "mapq", "nm", "tagbits", "n_cigar"):
             np.testing.assert_array_equal(p["aux"][f], getattr(batch, f)[at:at + n], err_msg=f)
+        if batch.qhash2 is not None:
+            np.testing.assert_array_equal(p["qhash2"], batch.qhash2[at:at + n], err_msg="qhash2")
         np.testing.assert_array_equal(p["cigar"], batch.cigar[ops:ops + len(p["cigar"])])
         at += n; ops += len(p["cigar"])
     assert at == batch.n and ops == len(batch.cigar)

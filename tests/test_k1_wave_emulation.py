@@ -152,3 +152,27 @@ def test_many_small_contigs_in_one_tile(oracle_lib):
     for grid in (1, 2):
         _compare(hostemu.run_k1(p, ann, b, grid=grid), r)
     assert r.gene_reads.sum() > 50
+
+
+def test_names_sharing_a_64_bit_hash_stay_distinct(oracle_lib):
+    """rsqc_batch.qhash2: one name in sixty takes the 64-bit hash of its predecessor in the sorted list of hashes (the two
+    then collide wherever they meet in a gene); the second hashes stay as they were.  The oracle keyed by (qhash, qhash2) and
+    the kernels (per-read emission of both words, frag_local / frag_count comparing both) must agree gene by gene -- and
+    differ from the 64-bit-only answer.  (A partition absorbs 32 such entries; beyond that the stage reports
+    RSQC_ERR_CAPACITY -- sixty-fold this rate, unreachable with real names -- instead of miscounting.)"""
+    import copy
+    ann = synth.make_annotation(seed=3, contigs=[("chrA", 200_000, 12)])
+    batch = synth.make_reads(ann, 3000, seed=9, contig_lengths=np.array([200_000]))
+    assert batch.qhash2 is not None
+    batch.qname = None; batch.qname_off = None
+    keys = np.unique(np.asarray(batch.qhash, np.uint64))
+    remap = {int(k): int(keys[i - 1]) for i, k in enumerate(keys) if i % 60 == 5}
+    batch.qhash = np.array([remap.get(int(h), int(h)) for h in batch.qhash], np.uint64)
+    p = abi.default_params()
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    o = hostemu.run_k1(p, ann, batch, grid=2)
+    _compare(o, r)
+    narrow = copy.copy(batch); narrow.qhash2 = None
+    r64 = oracle_lib.run_oracle(p, ann, [narrow])
+    _compare(hostemu.run_k1(p, ann, narrow, grid=2), r64)
+    assert int(r.gene_fragments.sum()) > int(r64.gene_fragments.sum()) + 10

@@ -29,3 +29,13 @@ def test_fragment_kernels_against_name_sets(seed, genes, chunks, names, hot, are
         assert st["fuller"] > 0, st                                         # the case does reach the 32 KB instance
     if names >= 20000 and not arena:
         assert st["kept"] < st["pairs"], st                                 # the window does find mates
+
+
+@pytest.mark.parametrize("seed,genes,chunks,names,hot,arena", [CASES[0], CASES[1], CASES[2], CASES[4], CASES[5], CASES[7]])
+def test_fragment_kernels_with_the_96_bit_identity(seed, genes, chunks, names, hot, arena):
+    """The same with second name hashes (rsqc_batch.qhash2): one name in 53 shares its 64-bit key -- and its gene -- with an earlier,
+    different name and must be counted on its own (window: both words compared; counting sets: the owner's second hash is compared
+    after the barrier, unequal ones are set aside and counted by one thread)."""
+    rc, st = hostemu.run_k4(seed + 100, genes, chunks, names, hot, arena, wide=True)
+    assert rc == 0, (rc, st)
+    assert st["kept"] <= st["pairs"] and st["kept"] >= st["distinct"]

@@ -117,18 +117,23 @@ def _collision_case():
 
 
 def test_crafted_qname_hash_collision_fixture(oracle_lib):
-    """The fixture is what it says (two different names, one hash), and it shows what the 64-bit name identity of the batch
-    format means: the oracle counts THREE fragments from the names (the reference's std::set<std::string>,
-    src/Expression.cpp:383-387) and TWO when it is given only the hashes, which is all the device ever sees
-    (include/rnaseqc_amd.h: rsqc_rec_aux::qhash).  DESIGN.md 5 discusses the identity and why it stays a 64-bit hash."""
+    """The fixture is what it says (two different names, one 64-bit hash, different second hashes), and it shows what the name
+    identity of the batch format means: the oracle counts THREE fragments from the names (the reference's std::set<std::string>,
+    src/Expression.cpp:383-387), THREE from the 96-bit identity (qhash, qhash2) the library's ingest paths provide, and TWO from
+    the 64-bit hash alone (a caller that leaves rsqc_batch.qhash2 NULL).  DESIGN.md 5."""
     fx, ann, batch = _collision_case()
     assert fx["a"] != fx["b"]
     assert abi.qname_hash(fx["a"].encode()) == abi.qname_hash(fx["b"].encode()) == int(fx["hash"], 16)
+    assert abi.qname_hash2(fx["a"].encode()) != abi.qname_hash2(fx["b"].encode())
     p = abi.default_params()
     exact = oracle_lib.run_oracle(p, ann, [batch])
     assert int(exact.gene_reads[0]) == 6 and int(exact.gene_fragments[0]) == 3
     import copy
     hashed = copy.copy(batch)
     hashed.qname = None; hashed.qname_off = None
-    by_hash = oracle_lib.run_oracle(p, ann, [hashed])
-    assert int(by_hash.gene_reads[0]) == 6 and int(by_hash.gene_fragments[0]) == 2
+    by_hashes = oracle_lib.run_oracle(p, ann, [hashed])
+    assert int(by_hashes.gene_reads[0]) == 6 and int(by_hashes.gene_fragments[0]) == 3
+    narrow = copy.copy(hashed)
+    narrow.qhash2 = None
+    by_hash64 = oracle_lib.run_oracle(p, ann, [narrow])
+    assert int(by_hash64.gene_reads[0]) == 6 and int(by_hash64.gene_fragments[0]) == 2
