@@ -55,8 +55,7 @@ struct UploadedBatch {
 // worst-case buffers go back to the pool -- so the memory held until rsqc_finalize is what was emitted (16 B per
 // (gene, name) pair, 28 B per fragment-size candidate, 32 B per GC candidate) plus the buffers of the batches in flight.
 struct PairBuf {                // (gene, qname-hash) pairs of one submitted batch
-    DevBuf gene, hash, h2, counts;  // h2: second name hashes (written when the batch carries rsqc_batch.qhash2); counts: [n_chunks] per K1 block, then [1] slow-path counter
-    bool has2 = false;          // the batch submitted with this buffer carried second name hashes
+    DevBuf gene, hash, h2, counts;  // h2: second name hashes (rsqc_batch.qhash2; zeros for a batch without); counts: [n_chunks] per K1 block, then [1] slow-path counter
     uint64_t cap = 0;           // pair slots allocated
     uint32_t n_chunks = 0, chunk_cap = 0, slow_base = 0, slow_cap = 0;
     uint32_t counts_cap = 0;
@@ -143,12 +142,11 @@ struct rsqc_ctx {
     hipEvent_t fin_e0 = nullptr, fin_e1 = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
-    bool pass_has2 = false;                     // a batch of the current pass carried rsqc_batch.qhash2
 
     // accumulators
     // one device arena holds every small result vector (single memset at reset, single D2H at finalize):
     // u64[3G+K] | u64 bias3,bias5[L] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | u8 exon_hit[E] | misc[64]
-    DevBuf d_arena, d_cov, d_ovf_index, d_tiles, d_table2;
+    DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
     DevBuf d_ei_rank;                                   // rank table of the interval index
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
@@ -319,7 +317,6 @@ int zero_accumulators(rsqc_ctx *c) {
     for (auto &pb : c->pair_pool) pb.used = false;
     c->pairs_in_flight.clear();
     c->pair_arena.used = c->frag_arena.used = c->gc_arena.used = 0;
-    c->pass_has2 = false;
     for (auto &fb : c->frag_pool) fb.used = false;
     c->frags_in_flight.clear();
     c->h_fsize.clear(); c->h_fcount.clear();
@@ -401,7 +398,7 @@ int retire_completed(rsqc_ctx *c, bool all) {
         if (c->pair_arena.used + total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "more than 2^32 (gene, name) pairs in one pass");
         int rc = arena_reserve(c, c->pair_arena, total);
         if (rc) return rc;
-        if (total) launch_pairs_append(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, pb.has2 ? (const uint32_t *)pb.h2.p : nullptr,
+        if (total) launch_pairs_append(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, (const uint32_t *)pb.h2.p,
                                        pb.chunk_cap, (const uint32_t *)pb.counts.p,
                                        pb.n_chunks, pb.slow_base, pb.slow_cap, (uint32_t *)c->pair_arena.col[0].p + c->pair_arena.used,
                                        (uint64_t *)c->pair_arena.col[1].p + c->pair_arena.used, (uint32_t *)c->pair_arena.col[2].p + c->pair_arena.used);
@@ -496,8 +493,6 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     //  counter, and the overflow counter is re-armed by the last kernel of the previous batch / the reset kernel)
     DevAccum acc = c->acc;
     acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p; acc.pair_h2 = (uint32_t *)pb->h2.p;
-    pb->has2 = u->d.qhash2 != nullptr;
-    if (pb->has2) c->pass_has2 = true;          // the end-of-file stage of this pass runs on the 96-bit identity (batches without second hashes count as 0)
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
     acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
     acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
@@ -649,7 +644,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
-    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_table2, &c->d_tab_off, &c->d_tab_cap};
+    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -1001,8 +996,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             const uint64_t lay_blocks = (Gz + 1023) / 1024;
             if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 28 + 64 + lay_blocks * 12 + 64, false))) return rc;  // per-gene rows | gene_base | part_first | layout totals
             if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 24 + 128, false))) return rc;                  // per-partition rows | cursor | list of the fuller ones + its counter
-            if (c->d_table.bytes < (size_t)keys_bound * 8) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * 8 + (1u << 20), false))) return rc; }
-            if (c->pass_has2 && c->d_table2.bytes < (size_t)keys_bound * 4) { if ((rc = dev_alloc(c, c->d_table2, (size_t)keys_bound * 4 + (1u << 20), false))) return rc; }
+            if (c->d_table.bytes < (size_t)keys_bound * sizeof(FragKey)) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * sizeof(FragKey) + (1u << 20), false))) return rc; }
             FragPlan P;
             P.ginfo = (uint4 *)c->d_tab_off.p;
             P.gene_base = (uint64_t *)(P.ginfo + Gz + 1);
@@ -1011,8 +1005,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             P.blk_parts = (uint32_t *)(P.blk_space + lay_blocks);
             P.part_info = (uint4 *)c->d_tab_cap.p; P.cursor = (uint32_t *)(P.part_info + parts_bound);
             P.full_list = P.cursor + parts_bound; P.full_n = P.full_list + parts_bound;
-            P.list = (unsigned long long *)c->d_table.p;
-            P.list2 = c->pass_has2 ? (uint32_t *)c->d_table2.p : nullptr;
+            P.list = (FragKey *)c->d_table.p;
             launch_frag_layout(c->stream, c->acc.gene_reads, (uint32_t)G, P, c->acc.error);
             if (c->pair_arena.used && !RSQC_DIAG("RSQC_DIAG_SKIP_K4")) {     // the retired batches: one dense list, cut into pieces
                 if ((rc = dev_alloc(c, c->d_arena_count, 16, false))) return rc;
@@ -1029,7 +1022,6 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 PairBuf &pb = c->pair_pool[idx];
                 DevAccum acc = c->acc;
                 acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p; acc.pair_h2 = (uint32_t *)pb.h2.p;
-                if (c->pass_has2 && !pb.has2) HIP_TRY(c, hipMemsetAsync(pb.h2.p, 0, pb.h2.bytes, c->stream));   // (a batch without second hashes in a pass that has them)
                 acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
                 acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;

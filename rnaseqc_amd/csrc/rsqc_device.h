@@ -102,7 +102,7 @@ struct DevAccum {
     // (gene, qname-hash) pairs of one batch: K1 block k owns [k*pair_chunk_cap, +pair_chunk_count[k]);
     // the slow path appends to [pair_slow_base, +*pair_slow_count)
     uint32_t *pair_gene; uint64_t *pair_hash;
-    uint32_t *pair_h2;           // second name hash of the pair's record (written when the batch has rsqc_batch.qhash2; same indexing)
+    uint32_t *pair_h2;           // second name hash of the pair's record (rsqc_batch.qhash2, 0 without it; same indexing)
     uint32_t pair_chunk_cap; uint32_t *pair_chunk_count;
     uint32_t pair_slow_base, pair_slow_cap; uint32_t *pair_slow_count;
     uint32_t *ovf_count; uint64_t *ovf_index; uint32_t ovf_cap;
@@ -158,6 +158,9 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 #ifndef RSQC_K4_COUNT_THREADS
 #define RSQC_K4_COUNT_THREADS 256
 #endif
+// one entry of a partition's key list: the 96-bit identity of a read name (rsqc_rec_aux::qhash, rsqc_batch.qhash2 -- 0 for a
+// caller that has none), written with ONE 12-byte store
+struct FragKey { uint32_t lo, hi, h2; };
 struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
     uint64_t *gene_base;           // [G] offset of the gene's key lists
@@ -165,12 +168,11 @@ struct FragPlan {
     uint4 *ginfo;                  // [G] {first partition, partitions, capacity of one, 0}: what frag_local_kernel gathers per pair
     uint4 *part_info;              // [parts] {owning gene, capacity, list offset lo, hi}
     uint32_t *full_list, *full_n;  // [parts] + counter: the partitions frag_count_kernel's first instance leaves to the second
-    unsigned long long *list;      // key lists
-    uint32_t *list2;               // second name hashes of the keys (same indexing); null: the pass runs on the 64-bit identity
+    FragKey *list;                 // key lists
     unsigned long long *blk_space; uint32_t *blk_parts;   // [ceil(G / 1024)] per-workgroup totals of the layout scan
 };
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error);
-void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks);   // (96-bit identity iff P.list2)
+void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks);
 void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2, uint32_t chunk_cap, const uint32_t *counts,
                          uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash, uint32_t *dst_h2);
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error);

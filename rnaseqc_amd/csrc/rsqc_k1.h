@@ -173,7 +173,7 @@ struct K1eShared {
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
-                                           uint64_t qhash, uint32_t qh2, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2 /* null: the batch has no second hashes */, uint32_t chunk_cap) {
+                                           uint64_t qhash, uint32_t qh2, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, uint32_t chunk_cap) {
     const int l = lane_id();
     typedef WaveSink WS;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             base = lane_value(base, lead);
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
-                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; if (my_pair_h2) my_pair_h2[slot] = qh2; }
+                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; my_pair_h2[slot] = qh2; }
                 else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
             }
         }
@@ -276,7 +276,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     EiOut eo; bool over = false;
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, my_pair_gene, my_pair_hash, qh2col ? my_pair_h2 : nullptr, chunk_cap);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -330,7 +330,6 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
     const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
     const uint64_t qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
     const uint32_t qh2 = b.qhash2 ? ld32(b.qhash2, idx) : 0u;
-    uint32_t *const pair_h2_or_null = b.qhash2 ? my_pair_h2 : nullptr;
     // three blocks (aMbNcMdNeM) are nine in ten of these records: a tile without a four-block record runs three look-up rounds
     // and six commit slots instead of four and eight
     if (__ballot(fast && cw.nblocks > 3u) == 0ull) {
@@ -338,12 +337,12 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         EiOut eo; bool over = false;
         exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, my_pair_gene, my_pair_hash, pair_h2_or_null, chunk_cap);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
     } else {
         EiOut eo; bool over = false;
         exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, my_pair_gene, my_pair_hash, pair_h2_or_null, chunk_cap);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
     }
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }

@@ -130,10 +130,15 @@ struct K4LocalShared {
     uint32_t win2[RSQC_K4L_WIN];                // ... and their second name hash (rsqc_batch.qhash2; all 0 without it)
 };
 
-__global__ void __launch_bounds__(RSQC_K4L_THREADS)
-frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const uint32_t *pair_h2 /* null: 64-bit identity */, uint32_t chunk_cap,
+#ifdef __HIPCC__
+#define RSQC_K4L_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))   // three workgroups per CU (<= 80 VGPRs): at 90 two fit, +20 % time
+#else
+#define RSQC_K4L_OCC
+#endif
+__global__ void __launch_bounds__(RSQC_K4L_THREADS) RSQC_K4L_OCC
+frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const uint32_t *pair_h2, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, unsigned long long *list, uint32_t *list2 /* with pair_h2 */, int *error) {
+                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, FragKey *list, int *error) {
     __shared__ K4LocalShared S;
     uint32_t base, count, piece0 = 0; constexpr uint32_t piece_step = 1;
     if (blockIdx.x < n_chunks) {
@@ -154,14 +159,13 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         piece0 = me * per < n_pieces ? me * per : n_pieces;
         n_pieces = piece0 + per < n_pieces ? piece0 + per : n_pieces;
     }
-    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U], uint32_t (&h2)[U]) {
+    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
             const bool ok = piece < n_pieces && j < count;
             g[u] = ok ? pair_gene[base + j] : NONE;
             key[u] = ok ? pair_hash[base + j] : 0ull;
-            h2[u] = (ok && pair_h2) ? pair_h2[base + j] : 0u;
         }
     };
 #ifdef RSQC_K1_PROF
@@ -170,8 +174,8 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         if (threadIdx.x == 0) g_dbg_pair_count = count;
     }
 #endif
-    uint32_t g[U]; uint64_t key[U]; uint32_t h2[U];
-    load_piece(piece0, g, key, h2);
+    uint32_t g[U]; uint64_t key[U];
+    load_piece(piece0, g, key);
     for (int i = threadIdx.x; i < RSQC_K4L_WIN; i += blockDim.x) { S.win[i] = 0ull; S.win2[i] = 0u; }
     RSQC_FIN_BEGIN
     for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
@@ -179,8 +183,14 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         uint4 gi[U]; uint64_t gb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; gb[u] = gene_base[gq]; }
-        uint32_t gn[U]; uint64_t keyn[U]; uint32_t h2n[U];
-        load_piece(piece + piece_step, gn, keyn, h2n);
+        uint32_t h2[U];                                                     // (second hashes: coalesced, in flight with the rows; not carried a pass ahead -- registers)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
+            h2[u] = j < count ? pair_h2[base + j] : 0u;
+        }
+        uint32_t gn[U]; uint64_t keyn[U];
+        load_piece(piece + piece_step, gn, keyn);
         __syncthreads();                                                   // (the previous pass has read its list slots)
         for (int i = threadIdx.x; i < RSQC_K4L_GSLOTS; i += blockDim.x) { S.gkey[i] = NONE; S.gcnt[i] = 0u; }
         __syncthreads();
@@ -233,8 +243,7 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
             const uint32_t cap = gi[u].z;
             if (at < cap) {
                 const unsigned long long where = gb[u] + (unsigned long long)(gp[u] - gi[u].x) * cap + at;
-                list[where] = key[u];
-                if (list2) list2[where] = h2[u];
+                list[where] = FragKey{(uint32_t)key[u], (uint32_t)(key[u] >> 32), h2[u]};   // (one 12-byte store)
             } else atomicExch(error, RSQC_ERR_CAPACITY);
         }
         RSQC_FIN_SECT(32, 6);
@@ -242,7 +251,7 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         if (threadIdx.x == 0) atomicAdd(&g_fin_prof[32 + 15], 1ull);
 #endif
 #pragma unroll
-        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; h2[u] = h2n[u]; }
+        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; }
     }
 }
 
@@ -257,11 +266,11 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
 // frag_layout_kernel), the second walks that list.
 template <int SLOTS>
 __global__ void __launch_bounds__(RSQC_K4_COUNT_THREADS)
-frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const unsigned long long *list, const uint32_t *list2 /* null: 64-bit identity */,
+frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint4 *part_info, const FragKey *list,
                   unsigned long long *gene_frag, uint32_t *full_list, uint32_t *full_n, int *error) {
     constexpr bool LISTED = SLOTS == RSQC_K4_PART_SLOTS;
     __shared__ unsigned long long s_keys[SLOTS];
-    __shared__ uint32_t s_h2[SLOTS];                                       // second hash of the slot's owner (list2)
+    __shared__ uint32_t s_h2[SLOTS];                                       // second hash of the slot's owner
     // two names with one 64-bit hash and different second hashes (never seen outside the crafted fixture): set aside here and
     // counted by one thread
     constexpr uint32_t OVF = 32;
@@ -286,12 +295,13 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
     auto keys_of = [&](const Row &r, unsigned long long (&kv)[KPT], uint32_t (&k2)[KPT]) {
         const uint32_t n = r.fill < r.info.y ? r.fill : r.info.y;
         const unsigned long long off = (unsigned long long)r.info.z | ((unsigned long long)r.info.w << 32);
-        const unsigned long long *keys = list + off;
+        const FragKey *keys = list + off;
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t i = (uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x;
-            kv[j] = i < n ? keys[i] : 0ull;
-            k2[j] = (i < n && list2) ? list2[off + i] : 0u;
+            FragKey e{0u, 0u, 0u};
+            if (i < n) e = keys[i];
+            kv[j] = (unsigned long long)e.lo | ((unsigned long long)e.hi << 32); k2[j] = e.h2;
         }
     };
     uint32_t w = blockIdx.x;
@@ -330,7 +340,7 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
                 for (uint32_t probe = 0; probe < slots; ++probe) {
                     const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, k);
                     if (old == 0ull) { s_h2[slot] = h2; ++fresh; return NO_SLOT; }
-                    if (old == k) return list2 ? slot : NO_SLOT;
+                    if (old == k) return slot;
                     slot = (slot + 1) & smask;
                 }
                 atomicExch(error, RSQC_ERR_CAPACITY);
@@ -339,37 +349,36 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
             uint32_t same[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) same[j] = ((uint32_t)j * RSQC_K4_COUNT_THREADS + threadIdx.x < n) ? insert(kv[j], k2[j]) : NO_SLOT;
-            if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) {               // (a list is never longer than SUB_CAP: kept for safety; 64-bit identity there)
-                const unsigned long long *keys = list + ((unsigned long long)cur.info.z | ((unsigned long long)cur.info.w << 32));
-                for (uint32_t i = (uint32_t)KPT * RSQC_K4_COUNT_THREADS + threadIdx.x; i < n; i += RSQC_K4_COUNT_THREADS) (void)insert(keys[i], 0u);
-                if (list2) atomicExch(error, RSQC_ERR_CAPACITY);
-            }
-            if (list2) {                                                    // (uniform) the 96-bit identity: second hashes of equal keys
-                __syncthreads();
+            static_assert(RSQC_K4_SUB_CAP <= RSQC_K4_PART_SLOTS / 2 && RSQC_K4_PART_READS <= RSQC_K4_PART_SLOTS / 2, "a list fits the registers of its instance");
+            if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) atomicExch(error, RSQC_ERR_CAPACITY);   // (cannot happen: capacities are <= SUB_CAP)
+            // second hashes of the entries whose 64-bit key was there already (the owner's is in s_h2 once every wave is past its
+            // inserts): an entry that differs is set aside; thread 0 counts the distinct ones behind the barrier of the total
+            __syncthreads();
 #pragma unroll
-                for (int j = 0; j < KPT; ++j)
-                    if (same[j] != NO_SLOT && s_h2[same[j]] != k2[j]) {
-                        const uint32_t at = atomicAdd(&s_ovn, 1u);
-                        if (at < OVF) { s_ovk[at] = kv[j]; s_ov2[at] = k2[j]; } else atomicExch(error, RSQC_ERR_CAPACITY);
-                    }
-                __syncthreads();
-                if (threadIdx.x == 0 && s_ovn) {
-                    const uint32_t m = s_ovn < OVF ? s_ovn : OVF;
-                    for (uint32_t a = 0; a < m; ++a) {
-                        bool first = true;
-                        for (uint32_t b2 = 0; b2 < a; ++b2) if (s_ovk[b2] == s_ovk[a] && s_ov2[b2] == s_ov2[a]) first = false;
-                        if (first) ++fresh;
-                    }
-                    s_ovn = 0u;
+            for (int j = 0; j < KPT; ++j)
+                if (same[j] != NO_SLOT && s_h2[same[j]] != k2[j]) {
+                    const uint32_t at = atomicAdd(&s_ovn, 1u);
+                    if (at < OVF) { s_ovk[at] = kv[j]; s_ov2[at] = k2[j]; } else atomicExch(error, RSQC_ERR_CAPACITY);
                 }
-            }
             RSQC_FIN_SECT(48, 2);
             fresh = wave_sum(fresh);
             // the per-partition total alternates between two LDS cells: one barrier separates "all waves have added" from
             // "thread 0 reads and clears"
             if (lane_id() == 0 && fresh) atomicAdd(&s_fresh[round & 1], fresh);
             __syncthreads();
-            if (threadIdx.x == 0) { const uint32_t t = s_fresh[round & 1]; s_fresh[round & 1] = 0u; if (t) atomicAdd(&gene_frag[gene], (unsigned long long)t); }
+            if (threadIdx.x == 0) {
+                uint32_t t = s_fresh[round & 1]; s_fresh[round & 1] = 0u;
+                if (s_ovn) {
+                    const uint32_t m = s_ovn < OVF ? s_ovn : OVF;
+                    for (uint32_t a = 0; a < m; ++a) {
+                        bool first = true;
+                        for (uint32_t b2 = 0; b2 < a; ++b2) if (s_ovk[b2] == s_ovk[a] && s_ov2[b2] == s_ov2[a]) first = false;
+                        if (first) ++t;
+                    }
+                    s_ovn = 0u;                                             // (the next partition's entries come behind its two barriers)
+                }
+                if (t) atomicAdd(&gene_frag[gene], (unsigned long long)t);
+            }
             ++round;
             RSQC_FIN_SECT(48, 3);
 #ifdef RSQC_K1_PROF

@@ -438,7 +438,7 @@ namespace rsqc {
 // Retirement of a batch: its chunks, one after the other, appended to the arena.  Workgroup k < n_chunks copies chunk k
 // (its destination = the sum of the counts before it); the last RSQC_K4_SLOW_BLOCKS workgroups share the slow-path region.
 __global__ void __launch_bounds__(256)
-pairs_append_kernel(const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2 /* null: the batch had no second hashes (zeros are appended) */,
+pairs_append_kernel(const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2,
                     uint32_t chunk_cap, const uint32_t *counts, uint32_t n_chunks,
                     uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash, uint32_t *dst_h2) {
     __shared__ unsigned long long s_part[256];
@@ -453,7 +453,7 @@ pairs_append_kernel(const uint32_t *src_gene, const uint64_t *src_hash, const ui
     if (blockIdx.x < n_chunks) { base = blockIdx.x * chunk_cap; count = counts[k] < chunk_cap ? counts[k] : chunk_cap; }
     else { base = slow_base; count = counts[n_chunks] < slow_cap ? counts[n_chunks] : slow_cap; lo = blockIdx.x - n_chunks; step = gridDim.x - n_chunks; }
     for (uint32_t i = lo * blockDim.x + threadIdx.x; i < count; i += step * blockDim.x) {
-        dst_gene[dst + i] = src_gene[base + i]; dst_hash[dst + i] = src_hash[base + i]; dst_h2[dst + i] = src_h2 ? src_h2[base + i] : 0u;
+        dst_gene[dst + i] = src_gene[base + i]; dst_hash[dst + i] = src_hash[base + i]; dst_h2[dst + i] = src_h2[base + i];
     }
 }
 void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2, uint32_t chunk_cap, const uint32_t *counts,
@@ -662,15 +662,15 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
     hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
-                       P.list2 ? acc.pair_h2 : (const uint32_t *)nullptr, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
-                       P.ginfo, P.gene_base, P.cursor, P.list, P.list2, acc.error);
+                       acc.pair_h2, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
+                       P.ginfo, P.gene_base, P.cursor, P.list, acc.error);
 }
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {
     if (n_genes == 0) return;                   // (no layout was written: launch_frag_layout returns early too)
     const uint32_t grid = parts_bound < 16384u ? (parts_bound ? parts_bound : 1u) : 16384u;
-    hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS / 2>), dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, (const uint32_t *)P.list2, gene_frag,
+    hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS / 2>), dim3(grid), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag,
                        P.full_list, P.full_n, error);
-    hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS>), dim3(grid < 1024u ? grid : 1024u), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, (const uint32_t *)P.list2, gene_frag,
+    hipLaunchKernelGGL((frag_count_kernel<RSQC_K4_PART_SLOTS>), dim3(grid < 1024u ? grid : 1024u), dim3(RSQC_K4_COUNT_THREADS), 0, s, P.part_first + n_genes, P.cursor, P.part_info, P.list, gene_frag,
                        P.full_list, P.full_n, error);
 }
 #ifndef RSQC_K3_MEDIUM_T

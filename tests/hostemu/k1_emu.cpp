@@ -226,7 +226,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         std::vector<uint4> ginfo(G + 1), part_info(parts_bound);
         std::vector<uint64_t> gene_base(G + 1);
         std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0u), full_list(parts_bound), blk_parts(lay_blocks);
-        std::vector<unsigned long long> blk_space(lay_blocks), list(keys_bound), frag(G, 0ull); std::vector<uint32_t> list2(keys_bound);
+        std::vector<unsigned long long> blk_space(lay_blocks), frag(G, 0ull); std::vector<FragKey> list(keys_bound);
         uint32_t full_n = 0;
         wavemu::grid_dim().x = lay_blocks;
         for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_totals_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), &error); }); }
@@ -238,12 +238,12 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         for (uint32_t k = 0; k < lgrid; ++k) {
             wavemu::block_idx().x = k;
             wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), (const uint64_t *)pair_hash.data(), pair_h2.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
-                                                                          ginfo.data(), gene_base.data(), cursor.data(), list.data(), list2.data(), &error); });
+                                                                          ginfo.data(), gene_base.data(), cursor.data(), list.data(), &error); });
         }
         wavemu::grid_dim().x = 8;
-        for (uint32_t k = 0; k < 8; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), list2.data(), frag.data(), full_list.data(), &full_n, &error); }); }
+        for (uint32_t k = 0; k < 8; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), frag.data(), full_list.data(), &full_n, &error); }); }
         wavemu::grid_dim().x = 2;
-        for (uint32_t k = 0; k < 2; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), list2.data(), frag.data(), full_list.data(), &full_n, &error); }); }
+        for (uint32_t k = 0; k < 2; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), frag.data(), full_list.data(), &full_n, &error); }); }
         if (error) return error;
         for (size_t g = 0; g < G; ++g) {
             // (a key of 0 is stored as a fixed non-zero constant by frag_local_kernel: a name hashing to 0 and one hashing to that

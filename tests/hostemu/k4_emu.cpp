@@ -30,7 +30,7 @@ struct Rng { uint64_t s; uint64_t next() { s += 0x9E3779B97F4A7C15ull; uint64_t 
 // returns 0 when every gene's count equals the size of its name set, else 1 + the first gene that differs; -code on a device error.
 extern "C" __attribute__((visibility("default")))
 int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_reads, int mode, uint64_t *stats /*[6]*/) {
-    // mode bit 0: dense-list form; bit 1: the 96-bit identity (second name hashes, with names that share their 64-bit key)
+    // mode bit 0: dense-list form; bit 1: names with second hashes (rsqc_batch.qhash2), some sharing their 64-bit key; without it every second hash is 0
     const bool has2 = (mode & 2) != 0; mode &= 1;
     Rng R{seed};
     struct Pair { uint32_t g; uint64_t key; uint32_t h2; };
@@ -78,8 +78,8 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     std::vector<uint4> ginfo(G + 1), part_info(parts_bound);
     std::vector<uint64_t> gene_base(G + 1);
     std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0xDEADBEEFu), full_list(parts_bound), blk_parts(lay_blocks);
-    std::vector<unsigned long long> blk_space(lay_blocks), list(keys_bound, 0xABABABABABABABABull), gene_frag(G, 0ull);
-    std::vector<uint32_t> list2(keys_bound, 0xCDCDCDCDu);
+    std::vector<unsigned long long> blk_space(lay_blocks), gene_frag(G, 0ull);
+    std::vector<FragKey> list(keys_bound, FragKey{0xABABABABu, 0xABABABABu, 0xCDCDCDCDu});
     uint32_t full_n = 0xDEADBEEFu; int error = 0;
 
     wavemu::grid_dim().x = lay_blocks;
@@ -120,7 +120,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     wavemu::grid_dim().x = grid;
     for (uint32_t b = 0; b < grid; ++b) {
         wavemu::block_idx().x = b;
-        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), has2 ? pair_h2.data() : nullptr, chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), gene_base.data(), cursor.data(), list.data(), has2 ? list2.data() : nullptr, &error); });
+        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), pair_h2.data(), chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), gene_base.data(), cursor.data(), list.data(), &error); });
     }
     if (error) return -error;
     uint64_t kept = 0; uint32_t fuller = 0;
@@ -128,10 +128,10 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
 
     const uint32_t cgrid = 16;
     wavemu::grid_dim().x = cgrid;
-    for (uint32_t b = 0; b < cgrid; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), has2 ? list2.data() : nullptr, gene_frag.data(), full_list.data(), &full_n, &error); }); }
+    for (uint32_t b = 0; b < cgrid; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), gene_frag.data(), full_list.data(), &full_n, &error); }); }
     if (full_n != fuller) return -1002;
     wavemu::grid_dim().x = 4;
-    for (uint32_t b = 0; b < 4; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), has2 ? list2.data() : nullptr, gene_frag.data(), full_list.data(), &full_n, &error); }); }
+    for (uint32_t b = 0; b < 4; ++b) { wavemu::block_idx().x = b; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), gene_frag.data(), full_list.data(), &full_n, &error); }); }
     if (error) return -error;
     if (stats) { stats[0] = n_pairs; stats[1] = kept; stats[2] = n_parts; stats[3] = fuller; stats[4] = 0; for (uint32_t g = 0; g < G; ++g) stats[4] += names[g].size(); stats[5] = chunk_cap; }
     for (uint32_t g = 0; g < G; ++g) if (gene_frag[g] != (unsigned long long)names[g].size()) return 1 + (int)g;
