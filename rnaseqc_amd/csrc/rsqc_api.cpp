@@ -991,16 +991,15 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             // bounds from the host's pair bound: partitions <= pairs / PART_READS + G, keys <= 2 x pairs + SUB_CAP x parts
             const uint64_t Gz = (uint64_t)std::max(G, 1);
             const uint64_t parts_bound = pair_bound / RSQC_K4_PART_READS + Gz + 1;
-            const uint64_t keys_bound = 2 * pair_bound + RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, pair_bound / RSQC_K4_PART_READS + 1) + 16;
+            const uint64_t keys_bound = 2 * pair_bound + RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, pair_bound / RSQC_K4_PART_READS + 1) + 16 * Gz + 16;   // (+ the round-up of every gene's space to 16 entries)
             if (parts_bound > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment partitions");
             const uint64_t lay_blocks = (Gz + 1023) / 1024;
-            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 28 + 64 + lay_blocks * 12 + 64, false))) return rc;  // per-gene rows | gene_base | part_first | layout totals
+            if ((rc = dev_alloc(c, c->d_tab_off, (Gz + 2) * 28 + 64 + lay_blocks * 12 + 64, false))) return rc;  // per-gene rows | part_first | layout totals
             if ((rc = dev_alloc(c, c->d_tab_cap, parts_bound * 24 + 128, false))) return rc;                  // per-partition rows | cursor | list of the fuller ones + its counter
             if (c->d_table.bytes < (size_t)keys_bound * sizeof(FragKey)) { if ((rc = dev_alloc(c, c->d_table, (size_t)keys_bound * sizeof(FragKey) + (1u << 20), false))) return rc; }
             FragPlan P;
             P.ginfo = (uint4 *)c->d_tab_off.p;
-            P.gene_base = (uint64_t *)(P.ginfo + Gz + 1);
-            P.part_first = (uint32_t *)(P.gene_base + Gz + 1);
+            P.part_first = (uint32_t *)(P.ginfo + Gz + 1);
             P.blk_space = (unsigned long long *)(((uintptr_t)(P.part_first + Gz + 2) + 15) & ~(uintptr_t)15);
             P.blk_parts = (uint32_t *)(P.blk_space + lay_blocks);
             P.part_info = (uint4 *)c->d_tab_cap.p; P.cursor = (uint32_t *)(P.part_info + parts_bound);

@@ -163,9 +163,8 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 struct FragKey { uint32_t lo, hi, h2; };
 struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
-    uint64_t *gene_base;           // [G] offset of the gene's key lists
     uint32_t *cursor;              // [parts] keys appended so far
-    uint4 *ginfo;                  // [G] {first partition, partitions, capacity of one, 0}: what frag_local_kernel gathers per pair
+    uint4 *ginfo;                  // [G] {first partition, partitions, capacity of one, offset of the gene's key lists / 16}: what frag_local_kernel gathers per pair
     uint4 *part_info;              // [parts] {owning gene, capacity, list offset lo, hi}
     uint32_t *full_list, *full_n;  // [parts] + counter: the partitions frag_count_kernel's first instance leaves to the second
     FragKey *list;                 // key lists

@@ -27,10 +27,15 @@ __device__ __forceinline__ uint32_t frag_part_hash(uint64_t key) {
 __device__ __forceinline__ uint32_t frag_parts_of(unsigned long long reads) {
     return (uint32_t)((reads + RSQC_K4_PART_READS - 1) / RSQC_K4_PART_READS);
 }
-// per gene: part_first[g] = its first partition (part_first[n_genes] = partition count) and gene_base[g] = offset of
-// its key lists; partition k of the gene has capacity frag_cap_of(reads) and starts at gene_base + k * capacity
+// per gene: part_first[g] = its first partition (part_first[n_genes] = partition count) and the offset of its key lists (a
+// multiple of 16 entries, kept / 16 in the gene's row); partition k of the gene has capacity frag_cap_of(reads) and starts at
+// offset + k * capacity
 __device__ __forceinline__ uint32_t frag_cap_of(unsigned long long reads) {
     return frag_parts_of(reads) == 1 ? (uint32_t)reads : (uint32_t)RSQC_K4_SUB_CAP;
+}
+// list entries a gene owns: partitions x capacity, rounded up to 16 so that the gene's offset fits the 32-bit field of its row
+__device__ __forceinline__ unsigned long long frag_space_of(unsigned long long reads) {
+    return ((unsigned long long)frag_parts_of(reads) * frag_cap_of(reads) + 15ull) & ~15ull;
 }
 // Two launches of 1024-thread workgroups, 1024 genes each (coalesced loads): (1) per-workgroup totals, (2) every workgroup
 // adds the totals before it (a few dozen values) to its own scan.  (One workgroup walking all the genes serially took
@@ -44,7 +49,7 @@ frag_layout_totals_kernel(const unsigned long long *gene_reads, uint32_t n_genes
     if (g < n_genes) {
         const unsigned long long n = gene_reads[g];
         if (n > 0xFFFFFFF0ull) atomicExch(error, RSQC_ERR_CAPACITY);
-        parts = frag_parts_of(n); space = (unsigned long long)parts * frag_cap_of(n);
+        parts = frag_parts_of(n); space = frag_space_of(n);
     }
     space = wave_sum(space); parts = wave_sum(parts);
     if (lane_id() == 0) { w_space[threadIdx.x >> 6] = space; w_parts[threadIdx.x >> 6] = parts; }
@@ -57,7 +62,7 @@ frag_layout_totals_kernel(const unsigned long long *gene_reads, uint32_t n_genes
 }
 __global__ void __launch_bounds__(1024)
 frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const unsigned long long *blk_space, const uint32_t *blk_parts,
-                   uint32_t *part_first, uint4 *ginfo, uint64_t *gene_base, uint32_t *cursor, uint4 *part_info, uint32_t *full_n) {
+                   uint32_t *part_first, uint4 *ginfo, uint32_t *cursor, uint4 *part_info, uint32_t *full_n) {
     __shared__ unsigned long long w_space[16];
     __shared__ uint32_t w_parts[16];
     __shared__ unsigned long long s_base; __shared__ uint32_t p_base;
@@ -70,7 +75,7 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
     }
     const uint32_t g = blockIdx.x * 1024u + threadIdx.x;
     unsigned long long space = 0; uint32_t parts = 0, cap = 0;
-    if (g < n_genes) { const unsigned long long n = gene_reads[g]; parts = frag_parts_of(n); cap = frag_cap_of(n); space = (unsigned long long)parts * cap; }
+    if (g < n_genes) { const unsigned long long n = gene_reads[g]; parts = frag_parts_of(n); cap = frag_cap_of(n); space = frag_space_of(n); }
     unsigned long long isp = space; uint32_t ipt = parts;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -82,7 +87,7 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
     unsigned long long bs = s_base; uint32_t bp = p_base;
     for (int w = 0; w < wv; ++w) { bs += w_space[w]; bp += w_parts[w]; }
     const uint32_t pf = bp + ipt - parts; const unsigned long long gb = bs + isp - space;
-    if (g < n_genes) { part_first[g] = pf; gene_base[g] = gb; ginfo[g] = make_uint4(pf, parts, cap, 0u); }
+    if (g < n_genes) { part_first[g] = pf; ginfo[g] = make_uint4(pf, parts, cap, (uint32_t)(gb >> 4)); }
     if (g == n_genes - 1) part_first[n_genes] = bp + ipt;
     if (g == 0) *full_n = 0u;
     // per partition: fill cursor = 0 and what the counting kernel needs in one load {gene, capacity, list offset}.  Most genes
@@ -138,7 +143,7 @@ struct K4LocalShared {
 __global__ void __launch_bounds__(RSQC_K4L_THREADS) RSQC_K4L_OCC
 frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const uint32_t *pair_h2, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
-                  const uint4 *ginfo, const uint64_t *gene_base, uint32_t *cursor, FragKey *list, int *error) {
+                  const uint4 *ginfo, uint32_t *cursor, FragKey *list, int *error) {
     __shared__ K4LocalShared S;
     uint32_t base, count, piece0 = 0; constexpr uint32_t piece_step = 1;
     if (blockIdx.x < n_chunks) {
@@ -180,9 +185,9 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
     RSQC_FIN_BEGIN
     for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
         RSQC_FIN_SECT(32, 0);
-        uint4 gi[U]; uint64_t gb[U];
+        uint4 gi[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; gb[u] = gene_base[gq]; }
+        for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; }
         uint32_t h2[U];                                                     // (second hashes: coalesced, in flight with the rows; not carried a pass ahead -- registers)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -242,7 +247,7 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
             const uint32_t at = gslot[u] != NONE ? S.gcnt[gslot[u]] + rank[u] : atomicAdd(&cursor[gp[u]], 1u);   // (crowded table)
             const uint32_t cap = gi[u].z;
             if (at < cap) {
-                const unsigned long long where = gb[u] + (unsigned long long)(gp[u] - gi[u].x) * cap + at;
+                const unsigned long long where = ((unsigned long long)gi[u].w << 4) + (unsigned long long)(gp[u] - gi[u].x) * cap + at;
                 list[where] = FragKey{(uint32_t)key[u], (uint32_t)(key[u] >> 32), h2[u]};   // (one 12-byte store)
             } else atomicExch(error, RSQC_ERR_CAPACITY);
         }

@@ -657,13 +657,13 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
     if (!blocks) return;
     hipLaunchKernelGGL(frag_layout_totals_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, error);
     hipLaunchKernelGGL(frag_layout_kernel, dim3(blocks), dim3(1024), 0, s, gene_reads, n_genes, P.blk_space, P.blk_parts, P.part_first,
-                       P.ginfo, P.gene_base, P.cursor, P.part_info, P.full_n);
+                       P.ginfo, P.cursor, P.part_info, P.full_n);
 }
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
     hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
                        acc.pair_h2, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
-                       P.ginfo, P.gene_base, P.cursor, P.list, acc.error);
+                       P.ginfo, P.cursor, P.list, acc.error);
 }
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {
     if (n_genes == 0) return;                   // (no layout was written: launch_frag_layout returns early too)

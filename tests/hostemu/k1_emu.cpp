@@ -221,16 +221,15 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     if (slow_kernel && G > 0) {
         const uint64_t parts_bound = n_pairs / RSQC_K4_PART_READS + chunk_count[(size_t)grid] / RSQC_K4_PART_READS + G + 2;
         const uint64_t all_pairs = n_pairs + chunk_count[(size_t)grid];
-        const uint64_t keys_bound = 2 * all_pairs + (uint64_t)RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, all_pairs / RSQC_K4_PART_READS + 1) + 16;
+        const uint64_t keys_bound = 2 * all_pairs + (uint64_t)RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, all_pairs / RSQC_K4_PART_READS + 1) + 16 * G + 16;
         const uint32_t lay_blocks = (uint32_t)((G + 1023) / 1024);
         std::vector<uint4> ginfo(G + 1), part_info(parts_bound);
-        std::vector<uint64_t> gene_base(G + 1);
-        std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0u), full_list(parts_bound), blk_parts(lay_blocks);
+            std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0u), full_list(parts_bound), blk_parts(lay_blocks);
         std::vector<unsigned long long> blk_space(lay_blocks), frag(G, 0ull); std::vector<FragKey> list(keys_bound);
         uint32_t full_n = 0;
         wavemu::grid_dim().x = lay_blocks;
         for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_totals_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), &error); }); }
-        for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), part_first.data(), ginfo.data(), gene_base.data(), cursor.data(), part_info.data(), &full_n); }); }
+        for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), part_first.data(), ginfo.data(), cursor.data(), part_info.data(), &full_n); }); }
         if (error) return error;
         if (part_first[G] > parts_bound) return 1010;
         const uint32_t lgrid = (uint32_t)grid + 4u;
@@ -238,7 +237,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         for (uint32_t k = 0; k < lgrid; ++k) {
             wavemu::block_idx().x = k;
             wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), (const uint64_t *)pair_hash.data(), pair_h2.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
-                                                                          ginfo.data(), gene_base.data(), cursor.data(), list.data(), &error); });
+                                                                          ginfo.data(), cursor.data(), list.data(), &error); });
         }
         wavemu::grid_dim().x = 8;
         for (uint32_t k = 0; k < 8; ++k) { wavemu::block_idx().x = k; wavemu::run_block(RSQC_K4_COUNT_THREADS, [&]() { frag_count_kernel<RSQC_K4_PART_SLOTS / 2>(part_first.data() + G, cursor.data(), part_info.data(), list.data(), frag.data(), full_list.data(), &full_n, &error); }); }

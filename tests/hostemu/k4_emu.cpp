@@ -73,10 +73,9 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
 
     // ---- the plan's arrays, sized like rsqc_api.cpp sizes them
     const uint64_t parts_bound = n_pairs / RSQC_K4_PART_READS + G + 1;
-    const uint64_t keys_bound = 2 * n_pairs + (uint64_t)RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, n_pairs / RSQC_K4_PART_READS + 1) + 16;
+    const uint64_t keys_bound = 2 * n_pairs + (uint64_t)RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, n_pairs / RSQC_K4_PART_READS + 1) + 16ull * G + 16;
     const uint32_t lay_blocks = (G + 1023u) / 1024u;
     std::vector<uint4> ginfo(G + 1), part_info(parts_bound);
-    std::vector<uint64_t> gene_base(G + 1);
     std::vector<uint32_t> part_first(G + 2), cursor(parts_bound, 0xDEADBEEFu), full_list(parts_bound), blk_parts(lay_blocks);
     std::vector<unsigned long long> blk_space(lay_blocks), gene_frag(G, 0ull);
     std::vector<FragKey> list(keys_bound, FragKey{0xABABABABu, 0xABABABABu, 0xCDCDCDCDu});
@@ -84,7 +83,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
 
     wavemu::grid_dim().x = lay_blocks;
     for (uint32_t b = 0; b < lay_blocks; ++b) { wavemu::block_idx().x = b; wavemu::run_block(1024, [&]() { frag_layout_totals_kernel(gene_reads.data(), G, blk_space.data(), blk_parts.data(), &error); }); }
-    for (uint32_t b = 0; b < lay_blocks; ++b) { wavemu::block_idx().x = b; wavemu::run_block(1024, [&]() { frag_layout_kernel(gene_reads.data(), G, blk_space.data(), blk_parts.data(), part_first.data(), ginfo.data(), gene_base.data(), cursor.data(), part_info.data(), &full_n); }); }
+    for (uint32_t b = 0; b < lay_blocks; ++b) { wavemu::block_idx().x = b; wavemu::run_block(1024, [&]() { frag_layout_kernel(gene_reads.data(), G, blk_space.data(), blk_parts.data(), part_first.data(), ginfo.data(), cursor.data(), part_info.data(), &full_n); }); }
     if (error) return -error;
     const uint32_t n_parts = part_first[G];
     if (n_parts > parts_bound || full_n != 0u) return -1000;
@@ -120,7 +119,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     wavemu::grid_dim().x = grid;
     for (uint32_t b = 0; b < grid; ++b) {
         wavemu::block_idx().x = b;
-        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), pair_h2.data(), chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), gene_base.data(), cursor.data(), list.data(), &error); });
+        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), pair_h2.data(), chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), cursor.data(), list.data(), &error); });
     }
     if (error) return -error;
     uint64_t kept = 0; uint32_t fuller = 0;
