@@ -893,17 +893,6 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
         for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_resolve(a, pr[j], fe[j], rstrand, qb[b0 + j]);
     }
 #pragma unroll
-#if defined(RSQC_WAVE_EMU) && defined(K1E_UNIFORM_STATS)
-    {   // (experiment: how often all lanes of a call sit in the same intervals)
-        extern unsigned long long g_k1e_calls[8], g_k1e_uniform[8];
-        uint64_t sig = 0;
-        for (int b = 0; b < NB; ++b) sig = sig * 1000003ull + qb[b].eidA * 31ull + qb[b].mask + (qb[b].cA ? 7 : 0) + (qb[b].cB ? 13 : 0) + qb[b].eidB * 17ull;
-        const uint64_t on_m = __ballot(lane_on);
-        const uint64_t first = on_m ? __shfl(sig, __builtin_ctzll(on_m), 64) : 0;
-        const uint64_t diff = __ballot(lane_on && sig != first);
-        if ((threadIdx.x & 63u) == 0) { g_k1e_calls[NB]++; if (!diff) g_k1e_uniform[NB]++; }
-    }
-#endif
     for (int b = 0; b < NB; ++b) {
         const bool live = (uint32_t)b < nbv;
         const EiBlock &q = qb[b];
