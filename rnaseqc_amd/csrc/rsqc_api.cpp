@@ -1268,12 +1268,12 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
-RcclApi &rccl_api() {
+static RcclApi *rccl_api_ptr() {
     static RcclApi A;
     static bool tried = false;
-    if (tried) return A;
+    if (tried) return &A;
     tried = true;
-    if (getenv("RSQC_NO_RCCL")) return A;
+    if (getenv("RSQC_NO_RCCL")) return &A;
     // the librccl that sits beside the HIP runtime THIS library runs on: a process may hold a second ROCm stack (PyTorch
     // bundles its own runtime and RCCL), and a communicator of that one cannot touch this runtime's allocations
     std::vector<std::string> names;
@@ -1285,13 +1285,13 @@ RcclApi &rccl_api() {
     }
     names.push_back("librccl.so.1"); names.push_back("librccl.so");
     for (const std::string &name : names) { A.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL); if (A.lib) break; }
-    if (!A.lib) return A;
+    if (!A.lib) return &A;
 #define RSQC_RCCL_SYM(field, sym) A.field = reinterpret_cast<decltype(A.field)>(dlsym(A.lib, sym))
     RSQC_RCCL_SYM(CommInitAll, "ncclCommInitAll"); RSQC_RCCL_SYM(CommDestroy, "ncclCommDestroy"); RSQC_RCCL_SYM(GroupStart, "ncclGroupStart");
     RSQC_RCCL_SYM(GroupEnd, "ncclGroupEnd"); RSQC_RCCL_SYM(Reduce, "ncclReduce"); RSQC_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RSQC_RCCL_SYM
     A.ok = A.CommInitAll && A.CommDestroy && A.GroupStart && A.GroupEnd && A.Reduce && A.GetErrorString;
-    return A;
+    return &A;
 }
 }  // namespace
 
@@ -1316,7 +1316,7 @@ int rsqc_group_create(rsqc_ctx **ctxs, int n, rsqc_group **out) {
     const auto t0 = std::chrono::steady_clock::now();
     bool distinct = true;
     for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
-    RcclApi &R = rccl_api();
+    RcclApi &R = *rccl_api_ptr();
     if (!R.ok) g->note = getenv("RSQC_NO_RCCL") ? "RSQC_NO_RCCL is set" : "librccl not found";
     else if (!distinct) g->note = "two contexts share a device";
     else {
@@ -1339,7 +1339,7 @@ int rsqc_group_create(rsqc_ctx **ctxs, int n, rsqc_group **out) {
 
 void rsqc_group_destroy(rsqc_group *g) {
     if (!g) return;
-    if (!g->comms.empty()) { RcclApi &R = rccl_api(); for (ncclComm_t c : g->comms) if (c) (void)R.CommDestroy(c); }
+    if (!g->comms.empty()) { RcclApi &R = *rccl_api_ptr(); for (ncclComm_t c : g->comms) if (c) (void)R.CommDestroy(c); }
     delete g;
 }
 
@@ -1377,7 +1377,7 @@ int rsqc_group_reduce(rsqc_group *g, int *used_rccl) {
     const auto t0 = std::chrono::steady_clock::now();
     auto done = [&](int rc) { g->last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); return rc; };
     if (!g->comms.empty()) {
-        RcclApi &R = rccl_api();
+        RcclApi &R = *rccl_api_ptr();
         // the three reducible ranges of the arena (rsqc_device_vectors): u64 counts | f64 sums + owner-only statistics | u8 flags
         const size_t n_u64 = (root->off_exon - root->off_u64) / 8, n_f64 = (root->off_gvalid - root->off_exon) / 8, n_u8 = root->off_ehit - root->off_gvalid;
         ncclResult_t r = R.GroupStart();
