@@ -246,14 +246,21 @@ RSQC_BAM_FN void bam_walk(const uint8_t *buf, uint32_t p, uint32_t hi, uint32_t 
 RSQC_BAM_FN void bam_frame_segment(const uint8_t *buf, uint32_t lo, uint32_t hi, uint32_t end, int32_t n_ref, uint32_t true_start, BamSegment &s) {
     uint32_t p = true_start;
     if (p == BAM_SEG_NONE) {
-        for (uint32_t c = lo; c < hi; ++c) {                                 // three plausible records in a row (low-entropy SEQ / QUAL bytes pass two now and then)
+        // three plausible records in a row (low-entropy SEQ / QUAL bytes pass two now and then).  A candidate whose record reaches
+        // past the window's end cannot be checked against a second one: it is kept as a LAST RESORT only.  (Taken at once, as in
+        // round 3, the two bytes in front of a true record start -- the tail of an aux field + the low half of block_size, read as
+        // a block_size of a few MB -- won in every segment of the window's last megabytes on RefID 0: hundreds of wrong guesses
+        // per call, each repaired by ONE thread: 8 % of the decode time on the realistic-entropy file, profiles/r4_decode_guess.txt.)
+        uint32_t last_resort = BAM_SEG_NONE;
+        for (uint32_t c = lo; c < hi; ++c) {
             if (!bam_plausible(buf, c, end, n_ref)) continue;
             const uint64_t q = (uint64_t)c + 4 + bam_ld32(buf + c);
-            if (q + 36 > end) { p = c; break; }
+            if (q + 36 > end) { if (last_resort == BAM_SEG_NONE) last_resort = c; continue; }
             if (!bam_plausible(buf, q, end, n_ref)) continue;
             const uint64_t r = q + 4 + bam_ld32(buf + q);
             if (r + 36 <= end ? bam_plausible(buf, r, end, n_ref) : true) { p = c; break; }
         }
+        if (p == BAM_SEG_NONE) p = last_resort;
     }
     s.start = p;
     if (p == BAM_SEG_NONE) { s.land = hi; s.n_rec = s.n_ops = 0; s.bad = 0; return; }

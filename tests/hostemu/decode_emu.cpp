@@ -3,6 +3,8 @@
 // Compiles the product's device-decode cores (rnaseqc_amd/csrc/rsqc_inflate.h: the DEFLATE decoder one wavefront runs
 // per BGZF block; rsqc_bamrec.h: BAM record framing and parsing) with g++ as a wave of ONE lane, so that what the HIP
 // kernels execute can be diffed against zlib and against the host BAM reader in the GPU-less build container.
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -53,6 +55,11 @@ uint32_t emu_crc_wave64(const uint8_t *data, uint32_t n, uint32_t crc_before) {
 // perturb != 0 moves some guesses, which the chain step has to repair.
 #include "../../rnaseqc_amd/csrc/rsqc_decode.h"
 
+static unsigned long long g_unconfirmed_total = 0;
+// segments whose guess the chain did not confirm, summed over the emu_decode_window calls since the last reset (reset != 0 clears)
+extern "C" __attribute__((visibility("default")))
+unsigned long long emu_decode_unconfirmed(int reset) { const unsigned long long v = g_unconfirmed_total; if (reset) g_unconfirmed_total = 0; return v; }
+
 extern "C" __attribute__((visibility("default")))
 int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const BamTagSpec *tags, int threads, int32_t *carry3, int perturb,
                       rsqc_rec_core *core, rsqc_rec_aux *aux, uint32_t *qh2, uint32_t *cigar, int32_t *seg_tid, uint64_t *seg_start,
@@ -87,6 +94,12 @@ int emu_decode_window(const uint8_t *buf, uint32_t start, uint32_t end, const Ba
     std::vector<uint32_t> list;
     for (uint32_t s = 0; s < W.n_seg; ++s) if (!decode_guess_confirmed(W, s)) list.push_back(s);
     uint32_t consumed = start, bad = 0;
+    if (!perturb) g_unconfirmed_total += list.size();
+    if (getenv("DEC_EMU_STATS")) {
+        fprintf(stderr, "[decode_emu] %u segments, %zu unconfirmed:", W.n_seg, list.size());
+        for (size_t i = 0; i < list.size() && i < 12; ++i) { const uint32_t sg = list[i]; fprintf(stderr, " s%u(start %u, prev land %u, prev bad %u, bad %u)", sg, seg[sg].start, sg ? seg[sg - 1].land : 0u, sg ? seg[sg - 1].bad : 0u, seg[sg].bad); }
+        fprintf(stderr, "\n");
+    }
     if (W.n_seg) {
         std::vector<BamSegment> ref = seg;
         uint32_t bad_ref = 0;
