@@ -61,7 +61,8 @@ struct PairBuf {                // (gene, qname-hash) pairs of one submitted bat
     uint32_t counts_cap = 0;
     uint64_t pairs_bound = 0;   // most pairs the batch can have emitted
     uint32_t *h_counts = nullptr;   // page-locked mirror of `counts` (copied when the batch's kernels are done)
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;      // the counts have arrived in h_counts
+    hipEvent_t kernels = nullptr;   // the batch's per-record kernels are through (what the copy of the counts waits for, on a side stream)
     bool used = false;
 };
 
@@ -392,6 +393,7 @@ int retire_completed(rsqc_ctx *c, bool all) {
         // in submission order only: the arena keeps file order, which the fragment de-dup's LDS pass relies on for locality
         const bool done = keep == k && (all || hipEventQuery(pb.done) == hipSuccess);
         if (!done) { c->pairs_in_flight[keep++] = idx; continue; }
+        if (all) HIP_TRY(c, hipEventSynchronize(pb.done));          // (the counts travel on a side stream)
         uint64_t total = 0;
         for (uint32_t j = 0; j < pb.n_chunks; ++j) total += std::min(pb.h_counts[j], pb.chunk_cap);
         total += std::min(pb.h_counts[pb.n_chunks], pb.slow_cap);
@@ -450,6 +452,7 @@ PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *ind
     pb.gene.bytes = (size_t)cap * 4; pb.hash.bytes = (size_t)cap * 8; pb.h2.bytes = (size_t)cap * 4; pb.counts.bytes = (size_t)n_counts * 4;
     if (hipHostMalloc((void **)&pb.h_counts, (size_t)n_counts * 4, hipHostMallocDefault) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&pb.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&pb.kernels, hipEventDisableTiming) != hipSuccess) return nullptr;
     pb.cap = cap; pb.counts_cap = n_counts; pb.used = true;
     c->pair_pool.push_back(pb);
     *index = c->pair_pool.size() - 1;
@@ -569,11 +572,15 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
                         (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, (uint32_t *)gb.count.p, gb.cap};
         launch_gc_candidates(c->stream, c->dann, c->dparams, d, c->dref, gc, acc.error);
     }
-    // the batch's counts, for its retirement: page-locked mirrors + an event that tells when they are valid
-    HIP_TRY(c, hipMemcpyAsync(pb->h_counts, pb->counts.p, ((size_t)grid + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    // the batch's counts, for its retirement: page-locked mirrors + an event that tells when they are valid.  The copy of the
+    // pair counts rides on a side stream: a copy between two kernels of the main stream costs ~40 us of queue hand-over there
+    // (profiles/r4_step_timeline.txt), and nothing on the main stream reads what it brings
     if (c->have_bed) { FragBuf &fb = c->frag_pool[c->frags_in_flight.back()]; HIP_TRY(c, hipMemcpyAsync(fb.h_count, fb.count.p, 4, hipMemcpyDeviceToHost, c->stream)); }
     if (c->have_ref && !c->dparams.legacy) { GcBuf &gb = c->gc_pool[c->gcs_in_flight.back()]; HIP_TRY(c, hipMemcpyAsync(gb.h_count, gb.count.p, 4, hipMemcpyDeviceToHost, c->stream)); }
-    HIP_TRY(c, hipEventRecord(pb->done, c->stream));
+    HIP_TRY(c, hipEventRecord(pb->kernels, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, pb->kernels, 0));
+    HIP_TRY(c, hipMemcpyAsync(pb->h_counts, pb->counts.p, ((size_t)grid + 1) * 4, hipMemcpyDeviceToHost, c->stream2));
+    HIP_TRY(c, hipEventRecord(pb->done, c->stream2));
     HIP_TRY(c, hipGetLastError());
     c->timing.classify_launches += 1;
     c->timing.classify_records += u->n;
@@ -626,7 +633,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto *u : c->transient) free_batch(u);
     for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
-    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.h2.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); }
+    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.h2.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); if (pb.kernels) (void)hipEventDestroy(pb.kernels); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); fb.r_file.release(); fb.r_qhash.release(); fb.r_name.release(); fb.r_endpos.release(); fb.r_fs.release(); fb.r_counts.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
@@ -1053,6 +1060,13 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             }
             if (!RSQC_DIAG("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm, nx);   // (diagnostic build only: results incomplete)
         }
+        {   // per-batch Read-Length transfer functions (rsqc_shard_info): final since the last batch's read_length_kernel; the copy
+            // goes out on a side stream behind its coverage kernel (behind frag_count on the main stream it cost a queue hand-over:
+            // ~40 us) and is covered by that stream's join below.  (Enqueued last: the destination is pageable, the call may block)
+            const size_t nb = c->batch_file_index.size();
+            c->h_rl_raw.resize(nb * RSQC_RL_SUMMARY_WORDS);
+            if (nb) HIP_TRY(c, hipMemcpyAsync(c->h_rl_raw.data(), c->d_rl_summary.p, nb * RSQC_RL_SUMMARY_WORDS * 4, hipMemcpyDeviceToHost, c->stream2));
+        }
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
         HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
@@ -1125,12 +1139,6 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             HIP_TRY(c, hipMemcpyAsync(c->h_gc.data(), c->d_gc_bins.p, (RSQC_GC_BINS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
-    // ---- per-batch Read-Length transfer functions (rsqc_shard_info) -----------------------------------------------
-    {
-        const size_t nb = c->batch_file_index.size();
-        c->h_rl_raw.resize(nb * RSQC_RL_SUMMARY_WORDS);
-        if (nb) HIP_TRY(c, hipMemcpyAsync(c->h_rl_raw.data(), c->d_rl_summary.p, nb * RSQC_RL_SUMMARY_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
-    }
     c->fin_e0 = e0; c->fin_e1 = e1;
     return 0;
 }
