@@ -9,11 +9,12 @@ namespace rsqc {
 // operations (one per distinct fragment).  Streaming passes over PARTITIONS instead: a gene with n counted records owns
 // ceil(n / RSQC_K4_PART_READS) partitions (chosen by the high word of the name hash), each with a key list of fixed
 // capacity laid out by frag_layout_kernel from the final geneCounts:
-//   frag_local_kernel   per pair chunk: pairs already seen in the chunk are dropped (LDS window), the others' name hashes
-//                       are APPENDED to their partition's list (space for one pass's keys of a partition is reserved with
+//   frag_local_kernel   per pair chunk: pairs already seen in the chunk are dropped (LDS window), the others' 96-bit name
+//                       identities (FragKey: rsqc_rec_aux::qhash + rsqc_batch.qhash2) are APPENDED to their partition's list (space for one pass's keys of a partition is reserved with
 //                       ONE memory atomicAdd; positions inside the reservation come from an LDS counter)
-//   frag_count_kernel   one workgroup per partition: its keys go through an LDS hash set; the number of distinct
-//                       keys is added to geneFragmentCounts
+//   frag_count_kernel   one workgroup per partition: its keys go through an LDS hash set (64-bit words claimed by CAS, the
+//                       second hash beside them, equal words with different second hashes set aside and counted exactly);
+//                       the number of distinct keys is added to geneFragmentCounts
 // A partition expects <= RSQC_K4_PART_READS keys and has room for RSQC_K4_SUB_CAP; one that overflows (never with
 // rsqc_qname_hash values) reports RSQC_ERR_CAPACITY instead of miscounting.
 
@@ -106,13 +107,13 @@ frag_layout_kernel(const unsigned long long *gene_reads, uint32_t n_genes, const
 }
 
 // frag_local_kernel: every (gene, name hash) pair of a chunk goes to the key list of its partition (partition = gene's first +
-// hash-scaled index).  256 threads take 1024 pairs per pass (4 per thread): the pairs of a pass that share a partition reserve
+// hash-scaled index).  512 threads take 2048 pairs per pass (4 per thread): the pairs of a pass that share a partition reserve
 // their list slots with ONE memory atomic (ranks inside the pass come from a small LDS table keyed by partition id).
 // The kernel is a chain of dependent gathers, so it is laid out as a pipeline: the pairs of pass k + 1 and the per-gene rows of
 // pass k are in flight while pass k - 1's ranks are taken.
-// What bounds it is the memory side: one returning atomic and one scattered 8-byte store per pair of a gene with many
+// What bounds it is the memory side: one returning atomic and one scattered 12-byte store (FragKey) per pair of a gene with many
 // partitions.  The two mates of a fragment sit a few hundred records apart, i.e. in the same chunk, so half of the pairs are
-// repeats the counting kernel would throw away: a direct-mapped LDS window over the WHOLE chunk (one 64-bit exchange per pair,
+// repeats the counting kernel would throw away: a direct-mapped LDS window over the WHOLE chunk (one 64-bit + one 32-bit exchange per pair,
 // never cleared between passes, no probing: a newer pair simply replaces an older one) drops a pair whose word is already
 // there.  (A per-pass table with probing removed 12 % of the keys for 18 % of the kernel; the window removes the mates.)
 // The word is key ^ f(gene), compared together with the pair's second name hash (rsqc_batch.qhash2, a parallel 32-bit window):
