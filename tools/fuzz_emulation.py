@@ -4,7 +4,7 @@
   python tools/fuzz_emulation.py k1-dense   <seed>  <n>   random contigs / genes / read sets of the synthetic generator, 1-8 workgroups
   python tools/fuzz_emulation.py k4         <seed>  <n>   random (gene, name) pair streams: chunk and dense-list form
 Every case compares the UNMODIFIED kernel source (rsqc_k1.h / rsqc_k4.h) with the oracle (K1: counters, gene tables, exon values,
-Read Length, the coverage difference array) or with a std::set of names per gene (K4).  Round 3: 3 000 + 2 500 + 400 cases, 0 mismatches."""
+Read Length, the coverage difference array) or with a std::set of names per gene (K4).  Round 3: 3 000 + 2 500 + 400 cases, 0 mismatches; round 4 (lane-mask gate, 96-bit name identity): see profiles/r4_fuzz_emulation.txt."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,8 +74,9 @@ def main():
         for it in range(n):
             s = int(rng.integers(1, 2**40)); G = int(rng.integers(2, 600)); arena = bool(rng.random() < 0.4)
             nch = 0 if arena else int(rng.integers(1, 12)); names = int(rng.integers(0, 40000)); hot = int(rng.choice([0, 0, 500, 3000, 20000, 50000]))
-            rc, st = hostemu.run_k4(s, G, nch, names, hot, arena); done += 1
-            if rc != 0: fails += 1; print("MISMATCH", s, G, nch, names, hot, arena, rc, st, flush=True)
+            wide = bool(rng.random() < 0.5)                # second name hashes, some names sharing their 64-bit key
+            rc, st = hostemu.run_k4(s, G, nch, names, hot, arena, wide=wide); done += 1
+            if rc != 0: fails += 1; print("MISMATCH", s, G, nch, names, hot, arena, wide, rc, st, flush=True)
     else:
         sys.exit(__doc__)
     print("%s: %d cases, %d mismatches, %.0f s" % (what, done, fails, time.time() - t0))
