@@ -46,7 +46,7 @@ def one_k1(ann, batch, kw, grid):
 def main():
     what, seed, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     rng = np.random.default_rng(seed)
-    fails = done = 0
+    fails = done = refused = 0
     t0 = time.time()
     if what == "k1-hostile":
         from tests.test_legacy_rules import hostile_case, stacked_case
@@ -76,10 +76,13 @@ def main():
             nch = 0 if arena else int(rng.integers(1, 12)); names = int(rng.integers(0, 40000)); hot = int(rng.choice([0, 0, 500, 3000, 20000, 50000]))
             wide = bool(rng.random() < 0.5)                # second name hashes, some names sharing their 64-bit key
             rc, st = hostemu.run_k4(s, G, nch, names, hot, arena, wide=wide); done += 1
-            if rc != 0: fails += 1; print("MISMATCH", s, G, nch, names, hot, arena, wide, rc, st, flush=True)
+            # (the generator makes one name in 53 share its 64-bit key with another of its gene: a partition that collects more than 32
+            #  such entries reports RSQC_ERR_CAPACITY by design -- a refusal, not a miscount; real names never get near it)
+            if wide and rc == 4: refused += 1
+            elif rc != 0: fails += 1; print("MISMATCH", s, G, nch, names, hot, arena, wide, rc, st, flush=True)
     else:
         sys.exit(__doc__)
-    print("%s: %d cases, %d mismatches, %.0f s" % (what, done, fails, time.time() - t0))
+    print("%s: %d cases, %d mismatches%s, %.0f s" % (what, done, fails, (", %d capacity refusals of the overflow list" % refused) if refused else "", time.time() - t0))
     sys.exit(1 if fails else 0)
 
 
