@@ -167,13 +167,15 @@ struct K1eShared {
     uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
 };
 
+__device__ __forceinline__ uint32_t k1e_chunk_of_block() { return blockIdx.x; }
+
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
-                                           uint64_t qhash, uint32_t qh2, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, uint32_t chunk_cap) {
+                                           uint64_t qhash, uint32_t qh2) {
     const int l = lane_id();
     typedef WaveSink WS;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
@@ -221,10 +223,16 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             uint32_t base = 0;
             if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
             base = lane_value(base, lead);
+            // (the three chunk pointers and the capacity come from the kernel-argument segment HERE, with scalar loads: held in
+            //  scalar registers across the tile they were spilled to VGPR lanes around the gate cascade and came back with seven
+            //  v_readlane per executed slot -- vector instructions, which is what this kernel is short of)
+            const DevAccum &pa = k1e_lazy_args()->acc;
+            const uint32_t chunk_cap = pa.pair_chunk_cap;
+            const size_t chunk_at = (size_t)k1e_chunk_of_block() * chunk_cap;
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
-                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; my_pair_h2[slot] = qh2; }
-                else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
+                if (slot < chunk_cap) { pa.pair_gene[chunk_at + slot] = g; pa.pair_hash[chunk_at + slot] = qhash; pa.pair_h2[chunk_at + slot] = qh2; }
+                else atomicExch(pa.error, RSQC_ERR_CAPACITY);
             }
         }
         if (NB > 1 || k > 0) {
@@ -251,7 +259,7 @@ __device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
 template <int NB>
 __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const rsqc_rec_aux *aux, uint32_t *cov_diff,
                                             const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
-                                            uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, const uint32_t *qh2col, uint32_t chunk_cap) {
+                                            const uint32_t *qh2col) {
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
     const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
@@ -276,7 +284,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     EiOut eo; bool over = false;
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2);
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -284,8 +292,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
 // the caches (they were streamed through this CU a few tiles ago), the CIGAR is walked in full -- every block counted, the
 // first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count -------------------------------
 __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
-                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk,
-                                                 uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, uint32_t chunk_cap) {
+                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk) {
     const int l = lane_id();
     const bool on0 = (uint32_t)l < n;
     uint4 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
@@ -337,12 +344,12 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         EiOut eo; bool over = false;
         exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2);
     } else {
         EiOut eo; bool over = false;
         exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2);
     }
     if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
@@ -487,10 +494,6 @@ classify_ei_kernel(K1Args A) {
     };
     uint32_t w0 = wg_beg < wg_end ? take_piece() : NONE, w1 = tile_after(w0), w2 = tile_after(w1);
     const uint32_t wbeg = w0 == NONE ? n_rec : w0, wend = wg_end;
-    const uint32_t chunk_cap = acc.pair_chunk_cap;
-    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
-    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    uint32_t *const my_pair_h2 = acc.pair_h2 + (size_t)blockIdx.x * chunk_cap;
     uint32_t seg = wbeg < n_rec ? find_segment(b, wbeg) : 0u;
     int32_t u_tid = -1;
     ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -697,21 +700,21 @@ classify_ei_kernel(K1Args A) {
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, my_pair_h2, b.qhash2, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, b.qhash2);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
             RSQC_MARK(9);                          // [9] one-block tiles
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, my_pair_h2, b.qhash2, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, b.qhash2);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
             RSQC_MARK(10);                         // [10] two-block tiles
         }
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk);
             h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
             RSQC_MARK(11);                         // [11] long-CIGAR tiles
             if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
@@ -733,7 +736,7 @@ classify_ei_kernel(K1Args A) {
     if (threadIdx.x == 0) {
         const K1Args *q = k1e_lazy_args();
         atomicMax(&q->acc.rl_stats[0], S.T.rl[0]); atomicMin(&q->acc.rl_stats[1], S.T.rl[1]); atomicMax(&q->acc.rl_stats[2], S.T.rl[2]);
-        q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
+        q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < q->acc.pair_chunk_cap ? S.T.pairs : q->acc.pair_chunk_cap;
         if (q->a.have_bed) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
     }
 }
