@@ -168,6 +168,11 @@ struct K1eShared {
 };
 
 __device__ __forceinline__ uint32_t k1e_chunk_of_block() { return blockIdx.x; }
+// "is this lane 0" / "is this lane below N" as CONSTANT lane masks (WaveSink::lane of a literal): written as `l == 0` the test is
+// one v_cmp whose 64-bit result the compiler computes once, hoists out of the tile loop, spills to a VGPR lane with the other
+// long-lived scalars and brings back with two v_readlane at each of its nine uses per tile -- vector instructions all
+__device__ __forceinline__ bool k1e_first_lane() { return WaveSink::lane(LaneMask{1ull}); }
+template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return WaveSink::lane(LaneMask{(1ull << N) - 1ull}); }
 
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
@@ -285,7 +290,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
     k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2);
-    if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+    if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
 // ---- 64 queued records with longer CIGARs (n < 64 only when the queue is drained): record words and CIGAR come back from
@@ -351,7 +356,7 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
         k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2);
     }
-    if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+    if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
 // ---- CIGAR, first pass (extractBlocks + bam_endpos, src/Expression.cpp:26-67): operations 0-3 with the first two
@@ -458,13 +463,13 @@ classify_ei_kernel(K1Args A) {
     auto flush_counts = [&]() {
         const uint32_t s0 = wave_sum_u32_full(sum_e1mm), s1 = wave_sum_u32_full(sum_e1b), s2 = wave_sum_u32_full(sum_e2mm), s3 = wave_sum_u32_full(sum_e2b),
                        s4 = wave_sum_u32_full(sum_mm), s5 = wave_sum_u32_full(sum_b), s6 = wave_sum_u32_full(sum_blk);
-        if (l == 0 && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
-        if (l == 0 && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
-        if (l == 0 && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
-        if (l == 0 && s3) atomicAdd(&S.T.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
-        if (l == 0 && s4) atomicAdd(&S.T.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
-        if (l == 0 && s5) atomicAdd(&S.T.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
-        if (l == 0 && s6) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
+        if (k1e_first_lane() && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
+        if (k1e_first_lane() && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
+        if (k1e_first_lane() && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
+        if (k1e_first_lane() && s3) atomicAdd(&S.T.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
+        if (k1e_first_lane() && s4) atomicAdd(&S.T.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
+        if (k1e_first_lane() && s5) atomicAdd(&S.T.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
+        if (k1e_first_lane() && s6) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
         sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
         pending = 0;
     };
@@ -481,7 +486,7 @@ classify_ei_kernel(K1Args A) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     auto take_piece = [&]() -> uint32_t {                 // first record of the next unclaimed piece, NONE when the range is used up
         uint32_t c = 0;
-        if (l == 0) c = atomicAdd(&S.T.piece, 1u);
+        if (k1e_first_lane()) c = atomicAdd(&S.T.piece, 1u);
         c = lane_value(c, 0);
         const uint64_t at = (uint64_t)wg_beg + (uint64_t)c * K1E_PIECE;
         return at < (uint64_t)wg_end ? (uint32_t)at : NONE;
@@ -557,6 +562,14 @@ classify_ei_kernel(K1Args A) {
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
         RSQC_MARK(1);
+        // The run's switches (--unpaired, chimeric exclusion, configured tag filters) are the same for every tile: the conditions the
+        // cascade derives from them are 64-bit lane masks that the compiler computes ONCE, keeps in scalar register pairs across
+        // the tile loop, spills to VGPR lanes under the cascade's pressure and reloads with two v_readlane each, every tile.
+        // Opaque per tile, they are re-derived with two scalar instructions where they are used and occupy nothing in between.
+        DevParams pt = p;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(pt.unpaired), "+s"(pt.exclude_chimeric), "+s"(pt.n_filter_tags));
+#endif
         do {                                                  // (K1E_STOP leaves through `break`)
         Record r; uint32_t cur_cigar_off;
         {
@@ -593,7 +606,7 @@ classify_ei_kernel(K1Args A) {
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad != 0u;
         RecordCounters rc; WB hq = lane_on;
-        const WB go = gate_cascade_b<false, WaveSink, true>(a, p, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
+        const WB go = gate_cascade_b<false, WaveSink, true>(a, pt, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
         RSQC_MARK(4);
         K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
         if (a.have_bed && rc.frag_candidate) {                // src/RNASeQC.cpp:372
@@ -618,7 +631,7 @@ classify_ei_kernel(K1Args A) {
         {   // Read-Length inputs: per-tile max span + batch-level extremes
             const uint32_t sp = rc.rl_span;                  // (0 unless the record reaches src/RNASeQC.cpp:275)
             const uint32_t wsp = wave_max_u32_full(sp);
-            if (l == 0) tile_span[w0 >> 6] = wsp;
+            if (k1e_first_lane()) tile_span[w0 >> 6] = wsp;
             l_span = sp > l_span ? sp : l_span;
             const uint32_t lq = (uint32_t)rc.rl_lqseq;
             l_lmin = (rc.rl_eligible && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
@@ -669,7 +682,7 @@ classify_ei_kernel(K1Args A) {
         if (WS::lane(LaneMask{m3})) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)i, flhq, (uint32_t)r.pos, (uint32_t)cur_cigar_off);
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         __builtin_amdgcn_wave_barrier();                     // the queue entries are read by OTHER lanes of the wave (no instruction: an ordering point)
-        if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+        if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || WS::any(big_any)) flush_counts();
         } while (0);
         RSQC_MARK(7);
@@ -700,21 +713,21 @@ classify_ei_kernel(K1Args A) {
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, b.qhash2);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, b.qhash2);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
             RSQC_MARK(9);                          // [9] one-block tiles
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, b.qhash2);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, b.qhash2);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
             RSQC_MARK(10);                         // [10] two-block tiles
         }
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk);
+            if (!(K1E_ABL & 16)) k1e_process_long(a, pt, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk);
             h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
             RSQC_MARK(11);                         // [11] long-CIGAR tiles
             if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
@@ -723,7 +736,7 @@ classify_ei_kernel(K1Args A) {
     flush_counts();
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
-        if (l == 0) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
+        if (k1e_first_lane()) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
     }
     RSQC_MARK(12);
     __syncthreads();
