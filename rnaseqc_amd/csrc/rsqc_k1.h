@@ -167,6 +167,11 @@ struct K1eShared {
     uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define K1E_GLOBAL(T, p) ((__attribute__((address_space(1))) T *)(p))      /* a pointer known to be global memory */
+#else
+#define K1E_GLOBAL(T, p) (p)
+#endif
 __device__ __forceinline__ uint32_t k1e_chunk_of_block() { return blockIdx.x; }
 // "is this lane 0" / "is this lane below N" as CONSTANT lane masks (WaveSink::lane of a literal): written as `l == 0` the test is
 // one v_cmp whose 64-bit result the compiler computes once, hoists out of the tile loop, spills to a VGPR lane with the other
@@ -236,7 +241,10 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             const size_t chunk_at = (size_t)k1e_chunk_of_block() * chunk_cap;
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
-                if (slot < chunk_cap) { pa.pair_gene[chunk_at + slot] = g; pa.pair_hash[chunk_at + slot] = qhash; pa.pair_h2[chunk_at + slot] = qh2; }
+                // (pointers read through the kernel-argument segment are GENERIC pointers to the compiler: stores through them are
+                //  flat_store -- the slow path through the aperture check that also ties up lgkmcnt; the first form of this change
+                //  measured 21 % slower as part of k1-next.  They are global memory: say so)
+                if (slot < chunk_cap) { K1E_GLOBAL(uint32_t, pa.pair_gene)[chunk_at + slot] = g; K1E_GLOBAL(uint64_t, pa.pair_hash)[chunk_at + slot] = qhash; K1E_GLOBAL(uint32_t, pa.pair_h2)[chunk_at + slot] = qh2; }
                 else atomicExch(pa.error, RSQC_ERR_CAPACITY);
             }
         }
