@@ -173,11 +173,36 @@ struct K1eShared {
 #define K1E_GLOBAL(T, p) (p)
 #endif
 __device__ __forceinline__ uint32_t k1e_chunk_of_block() { return blockIdx.x; }
+// where a workgroup's (gene, name) pairs go: the three streams of DevAccum and the chunk capacity
+struct K1ePairDst { uint64_t gene, hash, h2; uint32_t cap; };
+#ifndef K1E_LAZYPAIR
+#define K1E_LAZYPAIR 1        /* 1: read at the head of every commit with scalar loads; 0: held across the tile loop (the tree's form) */
+#endif
+// The four words straight from the kernel-argument segment, as SCALAR loads in wave-uniform code.  (Read through k1e_lazy_args()
+// they become flat VECTOR loads followed by a wait for every outstanding memory operation of the wave -- fine in the rare paths
+// that function serves, 21 % of the kernel when it sat in the commit: profiles/r4_k1_variants.txt, r4n2.)
+__device__ __forceinline__ K1ePairDst k1e_pair_dst() {
+    K1ePairDst d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const void *q = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dwordx2 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d.gene), "=&s"(d.hash), "=&s"(d.h2), "=&s"(d.cap)
+                 : "s"(q), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_gene)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_hash)),
+                   "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_h2)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_chunk_cap)));
+#else
+    const DevAccum &a = k1e_lazy_args()->acc;
+    d.gene = (uint64_t)(uintptr_t)a.pair_gene; d.hash = (uint64_t)(uintptr_t)a.pair_hash; d.h2 = (uint64_t)(uintptr_t)a.pair_h2; d.cap = a.pair_chunk_cap;
+#endif
+    return d;
+}
 // "is this lane 0" / "is this lane below N" as CONSTANT lane masks (WaveSink::lane of a literal): written as `l == 0` the test is
 // one v_cmp whose 64-bit result the compiler computes once, hoists out of the tile loop, spills to a VGPR lane with the other
 // long-lived scalars and brings back with two v_readlane at each of its nine uses per tile -- vector instructions all
-__device__ __forceinline__ bool k1e_first_lane() { return WaveSink::lane(LaneMask{1ull}); }
-template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return WaveSink::lane(LaneMask{(1ull << N) - 1ull}); }
+#ifndef K1E_CONSTMASK
+#define K1E_CONSTMASK 1       /* 0: the compare form, for an A/B */
+#endif
+__device__ __forceinline__ bool k1e_first_lane() { return K1E_CONSTMASK ? WaveSink::lane(LaneMask{1ull}) : lane_id() == 0; }
+template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return K1E_CONSTMASK ? WaveSink::lane(LaneMask{(1ull << N) - 1ull}) : lane_id() < N; }
 
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
@@ -185,9 +210,12 @@ template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_asser
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
-                                           uint64_t qhash, uint32_t qh2) {
+                                           uint64_t qhash, uint32_t qh2, const K1ePairDst &held) {
     const int l = lane_id();
     typedef WaveSink WS;
+    const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
+    const uint32_t chunk_cap = pd.cap;
+    const size_t chunk_at = (size_t)k1e_chunk_of_block() * chunk_cap;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
     double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
     if (NB > 1) {
@@ -233,19 +261,13 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             uint32_t base = 0;
             if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
             base = lane_value(base, lead);
-            // (the three chunk pointers and the capacity come from the kernel-argument segment HERE, with scalar loads: held in
-            //  scalar registers across the tile they were spilled to VGPR lanes around the gate cascade and came back with seven
-            //  v_readlane per executed slot -- vector instructions, which is what this kernel is short of)
-            const DevAccum &pa = k1e_lazy_args()->acc;
-            const uint32_t chunk_cap = pa.pair_chunk_cap;
-            const size_t chunk_at = (size_t)k1e_chunk_of_block() * chunk_cap;
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
-                // (pointers read through the kernel-argument segment are GENERIC pointers to the compiler: stores through them are
-                //  flat_store -- the slow path through the aperture check that also ties up lgkmcnt; the first form of this change
-                //  measured 21 % slower as part of k1-next.  They are global memory: say so)
-                if (slot < chunk_cap) { K1E_GLOBAL(uint32_t, pa.pair_gene)[chunk_at + slot] = g; K1E_GLOBAL(uint64_t, pa.pair_hash)[chunk_at + slot] = qhash; K1E_GLOBAL(uint32_t, pa.pair_h2)[chunk_at + slot] = qh2; }
-                else atomicExch(pa.error, RSQC_ERR_CAPACITY);
+                if (slot < chunk_cap) {
+                    K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.gene)[chunk_at + slot] = g;
+                    K1E_GLOBAL(uint64_t, (uint64_t *)(uintptr_t)pd.hash)[chunk_at + slot] = qhash;
+                    K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.h2)[chunk_at + slot] = qh2;
+                } else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
             }
         }
         if (NB > 1 || k > 0) {
@@ -272,7 +294,7 @@ __device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
 template <int NB>
 __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const rsqc_rec_aux *aux, uint32_t *cov_diff,
                                             const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
-                                            const uint32_t *qh2col) {
+                                            const uint32_t *qh2col, const K1ePairDst &held) {
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
     const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
@@ -297,7 +319,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     EiOut eo; bool over = false;
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, held);
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -305,7 +327,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
 // the caches (they were streamed through this CU a few tiles ago), the CIGAR is walked in full -- every block counted, the
 // first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count -------------------------------
 __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
-                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk) {
+                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk, const K1ePairDst &held) {
     const int l = lane_id();
     const bool on0 = (uint32_t)l < n;
     uint4 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
@@ -357,12 +379,12 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         EiOut eo; bool over = false;
         exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, held);
     } else {
         EiOut eo; bool over = false;
         exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, held);
     }
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
@@ -450,6 +472,8 @@ classify_ei_kernel(K1Args A) {
     // re-loads them where it needs them (s_load + s_waitcnt lgkmcnt(0): five such stalls per tile in round 3's listing, and
     // lgkmcnt(0) also waits for every LDS operation in flight); as opaque scalars they live in SGPRs for the whole kernel.
     DevParams p = A.p;
+    // (K1E_LAZYPAIR = 0: the pair destination held across the tile loop, the tree's form)
+    const K1ePairDst held = {(uint64_t)(uintptr_t)acc.pair_gene, (uint64_t)(uintptr_t)acc.pair_hash, (uint64_t)(uintptr_t)acc.pair_h2, acc.pair_chunk_cap};
     K1E_PIN(p.mapq_threshold); K1E_PIN(p.base_mismatch); K1E_PIN(p.chimeric_distance); K1E_PIN(p.stranded); K1E_PIN(p.unpaired);
     K1E_PIN(p.exclude_chimeric); K1E_PIN(p.n_filter_tags);
     const uint32_t *cigar_pool = b.cigar; K1E_PIN(cigar_pool);
@@ -575,7 +599,7 @@ classify_ei_kernel(K1Args A) {
         // the tile loop, spills to VGPR lanes under the cascade's pressure and reloads with two v_readlane each, every tile.
         // Opaque per tile, they are re-derived with two scalar instructions where they are used and occupy nothing in between.
         DevParams pt = p;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(K1E_NO_OPAQUE_SWITCHES)
         asm volatile("" : "+s"(pt.unpaired), "+s"(pt.exclude_chimeric), "+s"(pt.n_filter_tags));
 #endif
         do {                                                  // (K1E_STOP leaves through `break`)
@@ -721,21 +745,21 @@ classify_ei_kernel(K1Args A) {
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<1>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, b.qhash2);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, b.qhash2, held);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
             RSQC_MARK(9);                          // [9] one-block tiles
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<2>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, b.qhash2);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, b.qhash2, held);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
             RSQC_MARK(10);                         // [10] two-block tiles
         }
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 16)) k1e_process_long(a, pt, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk);
+            if (!(K1E_ABL & 16)) k1e_process_long(a, pt, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, held);
             h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
             RSQC_MARK(11);                         // [11] long-CIGAR tiles
             if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
