@@ -167,15 +167,55 @@ struct K1eShared {
     uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define K1E_GLOBAL(T, p) ((__attribute__((address_space(1))) T *)(p))      /* a pointer known to be global memory */
+#else
+#define K1E_GLOBAL(T, p) (p)
+#endif
+__device__ __forceinline__ uint32_t k1e_chunk_of_block() { return blockIdx.x; }
+// where a workgroup's (gene, name) pairs go: the three streams of DevAccum and the chunk capacity
+struct K1ePairDst { uint64_t gene, hash, h2; uint32_t cap; };
+#ifndef K1E_LAZYPAIR
+#define K1E_LAZYPAIR 1        /* 1: read at the head of every commit with scalar loads; 0: held across the tile loop (the tree's form) */
+#endif
+// The four words straight from the kernel-argument segment, as SCALAR loads in wave-uniform code.  (Read through k1e_lazy_args()
+// they become flat VECTOR loads followed by a wait for every outstanding memory operation of the wave -- fine in the rare paths
+// that function serves, 21 % of the kernel when it sat in the commit: profiles/r4_k1_variants.txt, r4n2.)
+__device__ __forceinline__ K1ePairDst k1e_pair_dst() {
+    K1ePairDst d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const void *q = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dwordx2 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d.gene), "=&s"(d.hash), "=&s"(d.h2), "=&s"(d.cap)
+                 : "s"(q), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_gene)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_hash)),
+                   "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_h2)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_chunk_cap)));
+#else
+    const DevAccum &a = k1e_lazy_args()->acc;
+    d.gene = (uint64_t)(uintptr_t)a.pair_gene; d.hash = (uint64_t)(uintptr_t)a.pair_hash; d.h2 = (uint64_t)(uintptr_t)a.pair_h2; d.cap = a.pair_chunk_cap;
+#endif
+    return d;
+}
+// "is this lane 0" / "is this lane below N" as CONSTANT lane masks (WaveSink::lane of a literal): written as `l == 0` the test is
+// one v_cmp whose 64-bit result the compiler computes once, hoists out of the tile loop, spills to a VGPR lane with the other
+// long-lived scalars and brings back with two v_readlane at each of its nine uses per tile -- vector instructions all
+#ifndef K1E_CONSTMASK
+#define K1E_CONSTMASK 1       /* 0: the compare form, for an A/B */
+#endif
+__device__ __forceinline__ bool k1e_first_lane() { return K1E_CONSTMASK ? WaveSink::lane(LaneMask{1ull}) : lane_id() == 0; }
+template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return K1E_CONSTMASK ? WaveSink::lane(LaneMask{(1ull << N) - 1ull}) : lane_id() < N; }
+
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
 template <int NB>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
-                                           uint64_t qhash, uint32_t qh2, uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, uint32_t chunk_cap) {
+                                           uint64_t qhash, uint32_t qh2, const K1ePairDst &held) {
     const int l = lane_id();
     typedef WaveSink WS;
+    const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
+    const uint32_t chunk_cap = pd.cap;
+    const size_t chunk_at = (size_t)k1e_chunk_of_block() * chunk_cap;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
     double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
     if (NB > 1) {
@@ -223,8 +263,11 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
             base = lane_value(base, lead);
             if (has) {
                 const uint32_t slot = base + mask_rank(m);
-                if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; my_pair_h2[slot] = qh2; }
-                else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
+                if (slot < chunk_cap) {
+                    K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.gene)[chunk_at + slot] = g;
+                    K1E_GLOBAL(uint64_t, (uint64_t *)(uintptr_t)pd.hash)[chunk_at + slot] = qhash;
+                    K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.h2)[chunk_at + slot] = qh2;
+                } else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
             }
         }
         if (NB > 1 || k > 0) {
@@ -251,7 +294,7 @@ __device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
 template <int NB>
 __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const rsqc_rec_aux *aux, uint32_t *cov_diff,
                                             const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
-                                            uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, const uint32_t *qh2col, uint32_t chunk_cap) {
+                                            const uint32_t *qh2col, const K1ePairDst &held) {
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
     const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
@@ -276,16 +319,15 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     EiOut eo; bool over = false;
     exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
     k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
-    if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, held);
+    if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
 // ---- 64 queued records with longer CIGARs (n < 64 only when the queue is drained): record words and CIGAR come back from
 // the caches (they were streamed through this CU a few tiles ago), the CIGAR is walked in full -- every block counted, the
 // first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count -------------------------------
 __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
-                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk,
-                                                 uint32_t *my_pair_gene, uint64_t *my_pair_hash, uint32_t *my_pair_h2, uint32_t chunk_cap) {
+                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk, const K1ePairDst &held) {
     const int l = lane_id();
     const bool on0 = (uint32_t)l < n;
     uint4 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
@@ -337,14 +379,14 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         EiOut eo; bool over = false;
         exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, held);
     } else {
         EiOut eo; bool over = false;
         exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
         k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, held);
     }
-    if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+    if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
 // ---- CIGAR, first pass (extractBlocks + bam_endpos, src/Expression.cpp:26-67): operations 0-3 with the first two
@@ -430,6 +472,8 @@ classify_ei_kernel(K1Args A) {
     // re-loads them where it needs them (s_load + s_waitcnt lgkmcnt(0): five such stalls per tile in round 3's listing, and
     // lgkmcnt(0) also waits for every LDS operation in flight); as opaque scalars they live in SGPRs for the whole kernel.
     DevParams p = A.p;
+    // (K1E_LAZYPAIR = 0: the pair destination held across the tile loop, the tree's form)
+    const K1ePairDst held = {(uint64_t)(uintptr_t)acc.pair_gene, (uint64_t)(uintptr_t)acc.pair_hash, (uint64_t)(uintptr_t)acc.pair_h2, acc.pair_chunk_cap};
     K1E_PIN(p.mapq_threshold); K1E_PIN(p.base_mismatch); K1E_PIN(p.chimeric_distance); K1E_PIN(p.stranded); K1E_PIN(p.unpaired);
     K1E_PIN(p.exclude_chimeric); K1E_PIN(p.n_filter_tags);
     const uint32_t *cigar_pool = b.cigar; K1E_PIN(cigar_pool);
@@ -451,13 +495,13 @@ classify_ei_kernel(K1Args A) {
     auto flush_counts = [&]() {
         const uint32_t s0 = wave_sum_u32_full(sum_e1mm), s1 = wave_sum_u32_full(sum_e1b), s2 = wave_sum_u32_full(sum_e2mm), s3 = wave_sum_u32_full(sum_e2b),
                        s4 = wave_sum_u32_full(sum_mm), s5 = wave_sum_u32_full(sum_b), s6 = wave_sum_u32_full(sum_blk);
-        if (l == 0 && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
-        if (l == 0 && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
-        if (l == 0 && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
-        if (l == 0 && s3) atomicAdd(&S.T.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
-        if (l == 0 && s4) atomicAdd(&S.T.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
-        if (l == 0 && s5) atomicAdd(&S.T.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
-        if (l == 0 && s6) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
+        if (k1e_first_lane() && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
+        if (k1e_first_lane() && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
+        if (k1e_first_lane() && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
+        if (k1e_first_lane() && s3) atomicAdd(&S.T.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
+        if (k1e_first_lane() && s4) atomicAdd(&S.T.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
+        if (k1e_first_lane() && s5) atomicAdd(&S.T.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
+        if (k1e_first_lane() && s6) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
         sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
         pending = 0;
     };
@@ -474,7 +518,7 @@ classify_ei_kernel(K1Args A) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     auto take_piece = [&]() -> uint32_t {                 // first record of the next unclaimed piece, NONE when the range is used up
         uint32_t c = 0;
-        if (l == 0) c = atomicAdd(&S.T.piece, 1u);
+        if (k1e_first_lane()) c = atomicAdd(&S.T.piece, 1u);
         c = lane_value(c, 0);
         const uint64_t at = (uint64_t)wg_beg + (uint64_t)c * K1E_PIECE;
         return at < (uint64_t)wg_end ? (uint32_t)at : NONE;
@@ -487,10 +531,6 @@ classify_ei_kernel(K1Args A) {
     };
     uint32_t w0 = wg_beg < wg_end ? take_piece() : NONE, w1 = tile_after(w0), w2 = tile_after(w1);
     const uint32_t wbeg = w0 == NONE ? n_rec : w0, wend = wg_end;
-    const uint32_t chunk_cap = acc.pair_chunk_cap;
-    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
-    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    uint32_t *const my_pair_h2 = acc.pair_h2 + (size_t)blockIdx.x * chunk_cap;
     uint32_t seg = wbeg < n_rec ? find_segment(b, wbeg) : 0u;
     int32_t u_tid = -1;
     ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -554,6 +594,14 @@ classify_ei_kernel(K1Args A) {
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
         RSQC_MARK(1);
+        // The run's switches (--unpaired, chimeric exclusion, configured tag filters) are the same for every tile: the conditions the
+        // cascade derives from them are 64-bit lane masks that the compiler computes ONCE, keeps in scalar register pairs across
+        // the tile loop, spills to VGPR lanes under the cascade's pressure and reloads with two v_readlane each, every tile.
+        // Opaque per tile, they are re-derived with two scalar instructions where they are used and occupy nothing in between.
+        DevParams pt = p;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(K1E_NO_OPAQUE_SWITCHES)
+        asm volatile("" : "+s"(pt.unpaired), "+s"(pt.exclude_chimeric), "+s"(pt.n_filter_tags));
+#endif
         do {                                                  // (K1E_STOP leaves through `break`)
         Record r; uint32_t cur_cigar_off;
         {
@@ -590,7 +638,7 @@ classify_ei_kernel(K1Args A) {
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad != 0u;
         RecordCounters rc; WB hq = lane_on;
-        const WB go = gate_cascade_b<false, WaveSink, true>(a, p, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
+        const WB go = gate_cascade_b<false, WaveSink, true>(a, pt, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
         RSQC_MARK(4);
         K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
         if (a.have_bed && rc.frag_candidate) {                // src/RNASeQC.cpp:372
@@ -615,7 +663,7 @@ classify_ei_kernel(K1Args A) {
         {   // Read-Length inputs: per-tile max span + batch-level extremes
             const uint32_t sp = rc.rl_span;                  // (0 unless the record reaches src/RNASeQC.cpp:275)
             const uint32_t wsp = wave_max_u32_full(sp);
-            if (l == 0) tile_span[w0 >> 6] = wsp;
+            if (k1e_first_lane()) tile_span[w0 >> 6] = wsp;
             l_span = sp > l_span ? sp : l_span;
             const uint32_t lq = (uint32_t)rc.rl_lqseq;
             l_lmin = (rc.rl_eligible && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
@@ -666,7 +714,7 @@ classify_ei_kernel(K1Args A) {
         if (WS::lane(LaneMask{m3})) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)i, flhq, (uint32_t)r.pos, (uint32_t)cur_cigar_off);
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         __builtin_amdgcn_wave_barrier();                     // the queue entries are read by OTHER lanes of the wave (no instruction: an ordering point)
-        if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
+        if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || WS::any(big_any)) flush_counts();
         } while (0);
         RSQC_MARK(7);
@@ -697,21 +745,21 @@ classify_ei_kernel(K1Args A) {
         while (c1 >= thr) {
             const uint32_t take = c1 < 64u ? c1 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<1>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, my_pair_gene, my_pair_hash, my_pair_h2, b.qhash2, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<1>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h1, take, b.qhash2, held);
             h1 = (h1 + take) & (K1E_QCAP - 1); c1 -= take;
             RSQC_MARK(9);                          // [9] one-block tiles
         }
         while (c2 >= thr) {
             const uint32_t take = c2 < 64u ? c2 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 1)) k1e_process<2>(a, p, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, my_pair_gene, my_pair_hash, my_pair_h2, b.qhash2, chunk_cap);
+            if (!(K1E_ABL & 1)) k1e_process<2>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h2, take, b.qhash2, held);
             h2 = (h2 + take) & (K1E_QCAP - 1); c2 -= take;
             RSQC_MARK(10);                         // [10] two-block tiles
         }
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 16)) k1e_process_long(a, p, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, my_pair_gene, my_pair_hash, my_pair_h2, chunk_cap);
+            if (!(K1E_ABL & 16)) k1e_process_long(a, pt, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, held);
             h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
             RSQC_MARK(11);                         // [11] long-CIGAR tiles
             if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
@@ -720,7 +768,7 @@ classify_ei_kernel(K1Args A) {
     flush_counts();
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
-        if (l == 0) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
+        if (k1e_first_lane()) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }
     }
     RSQC_MARK(12);
     __syncthreads();
@@ -733,7 +781,7 @@ classify_ei_kernel(K1Args A) {
     if (threadIdx.x == 0) {
         const K1Args *q = k1e_lazy_args();
         atomicMax(&q->acc.rl_stats[0], S.T.rl[0]); atomicMin(&q->acc.rl_stats[1], S.T.rl[1]); atomicMax(&q->acc.rl_stats[2], S.T.rl[2]);
-        q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < chunk_cap ? S.T.pairs : chunk_cap;
+        q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < q->acc.pair_chunk_cap ? S.T.pairs : q->acc.pair_chunk_cap;
         if (q->a.have_bed) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
     }
 }
