@@ -261,9 +261,6 @@ void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results 
     const Tally tally{r};
     const size_t n_genes = ann.gene_list.size();
     auto column = [&](const char *fallback) { return cfg.sample_given ? cfg.sample_name : std::string(fallback); };
-    Crew crew;
-
-    if (cfg.write_coverage) crew.go([&] { emit_coverage_table(stem + ".coverage.tsv", ann, r, contig_visit_order); });
 
     // ---- the three gene tables and the exon table (src/RNASeQC.cpp:419-475, 509-521): values first, then one thread per file --
     std::vector<double> abundance(n_genes, 0.0);                  // RPKM, or TPM after scaling
@@ -291,6 +288,10 @@ void write_reports(const ReportConfig &cfg, Annotation &ann, const rsqc_results 
         {stem + ".exon_reads.gct", column("Counts"), exon_entries, true, &ann.exon_list,
          [&](std::ostream &o, size_t e) { o << r.exon_reads[e]; }},
     };
+    // declared AFTER everything its threads read (`abundance`, `tables`): when a row below throws (Q15: no gene survives the
+    // coverage mask), the unwinding joins the writers (~Crew) before those are destroyed, and the files they write are complete
+    Crew crew;
+    if (cfg.write_coverage) crew.go([&] { emit_coverage_table(stem + ".coverage.tsv", ann, r, contig_visit_order); });
     for (const GctSpec &t : tables) crew.go([&t, &ann] { emit_gct(t, ann); });
 
     // ---- metrics.tsv, in the reference's row order; a throw below leaves the rows written so far, as it does there --------

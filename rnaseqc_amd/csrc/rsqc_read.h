@@ -838,27 +838,9 @@ RSQC_HD void ei_fetch(const DevAnnotation &a, const ContigInfo &ci, const EiProb
     const bool known = q.pre != 0u;
     f.js = q.have ? (known ? q.pre - 1u : fs.j) : 0u; f.je = q.have ? (known ? q.pre - 1u : fe.j) : 0u;
     f.j1 = (!known && fe.at && q.len > 0 && f.je > f.js) ? f.je - 1 : f.je;        // find(max(bs, be - 1))
-#if (defined(__HIP_DEVICE_COMPILE__) || defined(RSQC_WAVE_EMU)) && !defined(K1E_NO_UNIFORM)
-    // The blocks of a tile are neighbours on the genome: more often than not ALL of them lie inside ONE elementary interval (the
-    // body of an exon of a well-expressed gene).  Then js == je == j1 == J in every lane and the five gathers below are one
-    // entry read by all lanes from the same address (wave-uniform test: two compares and a ballot).
-    {
-        const unsigned long long hm = __ballot(q.have);
-        if (hm) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            const uint32_t J = (uint32_t)__builtin_amdgcn_readlane((int)f.js, __builtin_amdgcn_readfirstlane(__ffsll((long long)hm) - 1));
-#else
-            const uint32_t J = __shfl(f.js, __ffsll((long long)hm) - 1, 64);
-#endif
-            if (__ballot(q.have && (f.js != J || f.je != J)) == 0ull) {
-                const EiEntry S = ld32(a.ei, J);
-                f.js = f.je = f.j1 = J;                                             // (lanes without a block too: their results are masked by `have`)
-                f.S = S; f.m1 = S.mask; f.e1A = S.eidA; f.e1B = S.eidB; f.m_je = S.mask; f.m_js1 = S.mask;
-                return;
-            }
-        }
-    }
-#endif
+    // (Measured and removed, profiles/r5_k1_variants.txt call r5a: a wave-uniform shortcut HERE -- all lanes' blocks in one interval: one
+    //  entry load instead of the five gathers -- made the kernel 9 % SLOWER: a branch between the rounds of a block query puts a join in
+    //  front of the gathers of the record's other block, and the wait the compiler places at a join is for everything in flight.)
     f.S = ld32(a.ei, f.js);
     f.m1 = ld32(a.ei, f.j1).mask; f.e1A = ld32(a.ei, f.j1).eidA; f.e1B = ld32(a.ei, f.j1).eidB;
     // intervals js .. je: js, j1 (= je - 1 or je), je and js + 1 are read in this one round
