@@ -266,6 +266,9 @@ struct HostIndex {
                 if (first[b + 2] == first[b] && first[b] > ei_range[(size_t)k]) ei_coarse[(size_t)(ci.rk_base >> 3) + b] = first[b];   // = 1 + (first[b] - 1)
         }
         if (ei.empty()) ei.push_back(EiEntry{0, 0u, EI_NONE, EI_NONE, 0u, 0u, 0u, 0u});    // lanes without a look-up read entry 0
+        // a terminator behind the last contig's last interval: the scalar look-up of the per-record kernel (rsqc_k1.h, k1e_interval_of)
+        // reads the start of entry j + 1 with entry j; position 0 reads as "entry j is the last interval of its contig"
+        ei.push_back(EiEntry{0, 0u, EI_NONE, EI_NONE, 0u, 0u, 0u, 0u});
         gene_flags.assign((size_t)std::max(L, 1), 0);
         gene_owned.assign((size_t)std::max(L, 1), 0);
         for (int i = 0; i < L; ++i) {

@@ -58,6 +58,7 @@ __device__ __forceinline__ const K1Args *k1e_lazy_args() {
 #else
 static const K1Args *g_k1e_args = nullptr;       // (host emulation: set by the harness)
 static unsigned long long g_k1e_coarse_hits = 0;
+static unsigned long long g_k1e_uniform_calls = 0;   // (test harness: one-block feature-stage calls answered by the wave-uniform path)
 static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
 
@@ -165,6 +166,9 @@ struct K1eShared {
     uint4 q2[K1E_WAVES][K1E_QCAP];               // two blocks: bs0, len0, bs1, len1
     uint2 q2x[K1E_WAVES][K1E_QCAP];              //             record index, flhq
     uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
+#ifdef K1E_LDS_PAD
+    char pad[K1E_LDS_PAD];                       // (occupancy experiments: `make variant DEFS=-DK1E_LDS_PAD=12288` leaves room for three workgroups per CU)
+#endif
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -204,6 +208,23 @@ __device__ __forceinline__ K1ePairDst k1e_pair_dst() {
 __device__ __forceinline__ bool k1e_first_lane() { return K1E_CONSTMASK ? WaveSink::lane(LaneMask{1ull}) : lane_id() == 0; }
 template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return K1E_CONSTMASK ? WaveSink::lane(LaneMask{(1ull << N) - 1ull}) : lane_id() < N; }
 
+// ---- (gene, name) pairs of the lanes of `m` into the workgroup's chunk: one LDS slot reservation per wave, three coalesced stores ----
+__device__ __forceinline__ void k1e_emit_pairs(K1eTables &T, uint64_t m, uint32_t g, uint64_t qhash, uint32_t qh2, const K1ePairDst &pd) {
+    const int lead = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane_id() == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));
+    base = lane_value(base, lead);
+    if (WaveSink::lane(LaneMask{m})) {
+        const uint32_t slot = base + mask_rank(m);
+        const size_t chunk_at = (size_t)k1e_chunk_of_block() * pd.cap;
+        if (slot < pd.cap) {
+            K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.gene)[chunk_at + slot] = g;
+            K1E_GLOBAL(uint64_t, (uint64_t *)(uintptr_t)pd.hash)[chunk_at + slot] = qhash;
+            K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.h2)[chunk_at + slot] = qh2;
+        } else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
+    }
+}
+
 // ---- commit: what exon_metrics_ei returned goes to the accumulators ------------------------------------------------
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
@@ -211,11 +232,8 @@ template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_asser
 template <int NB>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
                                            uint64_t qhash, uint32_t qh2, const K1ePairDst &held) {
-    const int l = lane_id();
     typedef WaveSink WS;
     const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
-    const uint32_t chunk_cap = pd.cap;
-    const size_t chunk_at = (size_t)k1e_chunk_of_block() * chunk_cap;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
     double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
     if (NB > 1) {
@@ -254,22 +272,8 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
     for (int k = 0; k < FAST_SET; ++k) {
         const uint64_t m = WS::prim(eo.n_hit > k).m;
         if (m == 0ull) break;
-        const bool has = WS::lane(LaneMask{m});
         const uint32_t g = eo.hit[k];
-        if (!(K1E_ABL & 8)) {
-            const int lead = __ffsll((unsigned long long)m) - 1;
-            uint32_t base = 0;
-            if (l == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));      // one LDS slot reservation per wave
-            base = lane_value(base, lead);
-            if (has) {
-                const uint32_t slot = base + mask_rank(m);
-                if (slot < chunk_cap) {
-                    K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.gene)[chunk_at + slot] = g;
-                    K1E_GLOBAL(uint64_t, (uint64_t *)(uintptr_t)pd.hash)[chunk_at + slot] = qhash;
-                    K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.h2)[chunk_at + slot] = qh2;
-                } else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
-            }
-        }
+        if (!(K1E_ABL & 8)) k1e_emit_pairs(T, m, g, qhash, qh2, pd);
         if (NB > 1 || k > 0) {
             const RunLite r = make_run_lite(m, g);
             const uint64_t nd = m & notdup;
@@ -288,6 +292,119 @@ __device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
         if (slot < acc.ovf_cap) acc.ovf_index[slot] = index;
         else atomicExch(acc.error, RSQC_ERR_CAPACITY);
     }
+}
+
+// ---- one-block tiles whose blocks ALL lie in ONE elementary interval (round 5) ------------------------------------------------------
+// The queued records are neighbours in the sorted stream: on the contract workload two thirds of the one-block feature-stage calls
+// have every block inside one interval (the body of an exon of an expressed gene, a stretch of intron; tools/uniform_tiles.py).  Such a
+// call needs ONE index look-up, and it is a SCALAR one: the interval of the first lane's block from its rank word (s_load, scalar
+// shift and popcount), the interval's entry and the start of the next one in one 64-byte scalar load, then two compares per lane
+// decide whether every block lies inside [start, next start).  If so, everything exon_metrics_ei derives from the index --
+// containing exons, gene set, class flags, globin, the commit slots -- is a property of the WAVE: the counters are popcounts of
+// the lanes' quality / flag masks written to a counter lane chosen by a scalar, the exon and gene tables take one add per call
+// instead of one per run of lanes, and only coverage slots and (gene, name) pairs remain per-lane work.  Unstranded runs only
+// (--stranded makes the containing exons a per-lane property again); an interval under more than two exons (EIM_DEEP) and a
+// contig without features take the general path, as does any call that fails the test.
+#ifndef K1E_UNIFORM1
+#define K1E_UNIFORM1 1
+#endif
+struct K1eInterval { EiEntry S; int32_t next_pos; };          // (wave-uniform)
+// the interval of position x0 and the start of the one behind it, by scalar loads
+__device__ __forceinline__ K1eInterval k1e_interval_of(const DevAnnotation &a, const ContigInfo &ci, int32_t x0) {
+    const int32_t top = (int32_t)(ci.rk_words << 6) - 1;
+    const int32_t xc = x0 < 0 ? 0 : (x0 > top ? top : x0);
+    const uint32_t word = ci.rk_base + ((uint32_t)xc >> 6);
+    K1eInterval r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x4 w;
+    asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(a.ei_rank), "s"(word * 16u));
+    const uint64_t t = (((uint64_t)w.y << 32) | (uint64_t)w.x) << (63u - ((uint32_t)xc & 63u));
+    const uint32_t j = w.z + (uint32_t)__popcll(t) - 1u;
+    u32x16 e;                                                   // entry j and the first words of entry j + 1 (the table ends with a terminator entry)
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(a.ei), "s"(j * 32u));
+    r.S = EiEntry{(int32_t)e.s0, e.s1, e.s2, e.s3, e.s4, e.s5, e.s6, e.s7};
+    r.next_pos = (int32_t)e.s8;
+#else
+    const EiRank w = a.ei_rank[word];
+    const uint64_t t = (((uint64_t)w.hi << 32) | (uint64_t)w.lo) << (63u - ((uint32_t)xc & 63u));
+    const uint32_t j = w.rank + (uint32_t)__builtin_popcountll(t) - 1u;
+    r.S = a.ei[j]; r.next_pos = a.ei[j + 1].pos;
+#endif
+    return r;
+}
+// one lane per counter, chosen at run time (WaveSink::add takes the lane as a template argument: v_writelane with a constant lane
+// select; with the value AND the lane in scalar registers the instruction would read two of them, one more than gfx9's constant bus
+// carries, and routing the lane through M0 means clobbering a register the compiler reserves -- a compare and a select instead)
+__device__ __forceinline__ void k1e_count_at(WaveSink &cnt, int counter, uint32_t n) {
+    cnt.vec = lane_id() == counter ? n : cnt.vec;
+}
+// true: the call was handled here.  `onm`: lanes that hold a record (the low n lanes).
+__device__ __forceinline__ bool k1e_uniform1(const DevAnnotation &a, const DevParams &p, uint32_t *cov_diff, const ContigInfo &ci, K1eTables &T,
+                                             int32_t bs, uint32_t len, uint32_t flhq, uint64_t qhash, uint32_t qh2, uint64_t onm,
+                                             WaveSink &cnt, const K1ePairDst &held) {
+    typedef WaveSink WS;
+    if (p.stranded != RSQC_STRAND_UNKNOWN || ci.rk_words == 0u) return false;
+    const K1eInterval iv = k1e_interval_of(a, ci, (int32_t)lane_value((uint32_t)bs, 0));      // (lane 0 holds a record: n >= 1)
+    const EiEntry &S = iv.S;
+    if (S.mask & EIM_DEEP) return false;
+    const int32_t lo = S.pos, hi = iv.next_pos > S.pos ? iv.next_pos : 0x7FFFFFFF;              // (next_pos <= pos: the contig's last interval)
+    if ((WS::prim(bs < lo || (int32_t)(bs + (int32_t)len) >= hi).m & onm) != 0ull) return false;
+#if defined(RSQC_WAVE_EMU)
+    if (lane_id() == 0) ++g_k1e_uniform_calls;
+#endif
+    // ---- exon_metrics_ei<1> with js == je == j1 in every lane: every value below is wave-uniform --------------------------------
+    const bool cA = S.eidA != EI_NONE, cB = S.eidB != EI_NONE, c1 = cA && cB;
+    const uint32_t g0 = S.gfA & ROW_GENE_MASK, g1 = S.gfB & ROW_GENE_MASK;
+    const uint32_t gX = cA ? g0 : g1, gfX = cA ? S.gfA : S.gfB;
+    const bool va = cA || cB, vb = c1 && g1 != gX;                                              // genes.front(), src/Expression.cpp:363-367
+    const bool globin = (va && ((gfX >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0) || (vb && ((S.gfB >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0);
+    const uint64_t hqm = WS::prim((flhq & K1E_HQ) != 0).m & onm, dupm = WS::prim((flhq & RSQC_FDUP) != 0).m;
+    const uint32_t n_on = (uint32_t)__popcll(onm), n_hq = (uint32_t)__popcll(hqm);
+    if (!globin) {                                                                              // :363,395-404
+        RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, LaneMask{onm}); RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, LaneMask{onm & dupm});
+    }
+    {   // class_counts_b with uniform class flags: one class for the whole call (:407-457)
+        const uint32_t cf = ei_class_flags(S.mask, RSQC_STRAND_UNKNOWN);
+        const bool exonic = (cf & CF_EXONIC) != 0, intragenic = (cf & CF_INTRAGENIC) != 0;
+        const int cls = !exonic ? (intragenic ? RSQC_C_INTRONIC_READS : RSQC_C_INTERGENIC_READS) : (va ? RSQC_C_EXONIC_READS : RSQC_C_AMBIGUOUS_READS);
+        static_assert(RSQC_C_HQ_INTRONIC_READS == RSQC_C_INTRONIC_READS + 2 && RSQC_C_HQ_INTERGENIC_READS == RSQC_C_INTERGENIC_READS + 1 &&
+                      RSQC_C_HQ_EXONIC_READS == RSQC_C_EXONIC_READS + 1 && RSQC_C_HQ_AMBIGUOUS_READS == RSQC_C_AMBIGUOUS_READS + 1, "counter order");
+        k1e_count_at(cnt, cls, n_on); k1e_count_at(cnt, cls + (cls == RSQC_C_INTRONIC_READS ? 2 : 1), n_hq);
+        if ((!exonic && intragenic) || (exonic && va)) { k1e_count_at(cnt, RSQC_C_INTRAGENIC_READS, n_on); k1e_count_at(cnt, RSQC_C_HQ_INTRAGENIC_READS, n_hq); }
+        if (cf & CF_RIBOSOMAL) k1e_count_at(cnt, RSQC_C_RRNA_READS, n_on);
+        const bool plus = (cf & CF_PLUS) != 0, minus = (cf & CF_MINUS) != 0;
+        if (plus != minus) {                                                                    // :445-457
+            const uint64_t one = p.unpaired ? onm : (onm & WS::prim((flhq & RSQC_FPAIRED) != 0).m);
+            const uint64_t revm = WS::prim((flhq & RSQC_FREVERSE) != 0).m, sense = minus ? revm : ~revm;
+            const uint64_t end1 = p.unpaired ? ~0ull : WS::prim((flhq & RSQC_FREAD1) != 0).m;
+            RSQC_COUNT(cnt, RSQC_C_END1_SENSE, LaneMask{one & end1 & sense}); RSQC_COUNT(cnt, RSQC_C_END1_ANTISENSE, LaneMask{one & end1 & ~sense});
+            RSQC_COUNT(cnt, RSQC_C_END2_SENSE, LaneMask{one & ~end1 & sense}); RSQC_COUNT(cnt, RSQC_C_END2_ANTISENSE, LaneMask{one & ~end1 & ~sense});
+        }
+    }
+    // ---- k1e_commit<1>: high-quality records of a call that has a gene (:377-392) -------------------------------------------------
+    if (!va || hqm == 0ull) return true;
+    const uint64_t hvm = hqm & WS::prim(len > 0).m;                                              // (a zero-length block commits nothing)
+    if (hvm == 0ull) return true;
+    const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
+    const uint32_t n0 = (uint32_t)__popcll(hvm), nd0 = (uint32_t)__popcll(hvm & ~dupm);
+    const bool first = k1e_first_lane();
+    if (!(K1E_ABL & 2)) {
+        if (first) { T.exon_add(cA ? S.eidA : S.eidB, (double)n0); T.gene_add(gX, n0, nd0); }
+        if (first && c1) T.exon_add(S.eidB, (double)n0);
+        if (first && vb) T.gene_add(g1, n0, nd0);
+    }
+    if (!(K1E_ABL & 4)) {
+        const uint32_t base = (cA ? S.cdA : S.cdB) + (uint32_t)bs;
+        cov_add_merged(cov_diff, hvm, base, 1u); cov_add_merged(cov_diff, hvm, base + len, 0xFFFFFFFFu);
+        if (c1) { const uint32_t b1 = S.cdB + (uint32_t)bs; cov_add_merged(cov_diff, hvm, b1, 1u); cov_add_merged(cov_diff, hvm, b1 + len, 0xFFFFFFFFu); }
+    }
+    if (!(K1E_ABL & 8)) {
+        k1e_emit_pairs(T, hvm, gX, qhash, qh2, pd);
+        if (vb) k1e_emit_pairs(T, hvm, g1, qhash, qh2, pd);
+    }
+    return true;
 }
 
 // ---- the feature stage of 64 queued records of NB blocks each (n < 64 only when a queue is drained) -----------------
@@ -316,10 +433,13 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     const uint2 qh = ld32(reinterpret_cast<const uint2 *>(aux), idx * 2u);
     const uint32_t qh2 = qh2col ? ld32(qh2col, idx) : 0u;        // (uniform branch: the batch carries second name hashes or it does not)
     WaveSink cnt;
-    EiOut eo; bool over = false;
-    exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
-    k1e_overflow(on && over, (uint64_t)idx);
-    k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, held);
+    const uint64_t qhash = (uint64_t)qh.x | ((uint64_t)qh.y << 32);
+    if (NB != 1 || !K1E_UNIFORM1 || !k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, qhash, qh2, n >= 64u ? ~0ull : (1ull << n) - 1ull, cnt, held)) {
+        EiOut eo; bool over = false;
+        exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
+        k1e_overflow(on && over, (uint64_t)idx);
+        k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, qhash, qh2, held);
+    }
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -557,6 +677,7 @@ classify_ei_kernel(K1Args A) {
     int4 cur_cv = zero4, cur_av = zero4;
     uint32_t cg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nx_co = 0;                                                   // CIGAR offset of this lane's record of the NEXT tile
+    uint32_t rk_pf = 0, rk_pf2 = 0; (void)rk_pf; (void)rk_pf2;                                       // rank-table words prefetched for the NEXT tile's records (K1E_RANK_PREFETCH; never read)
     uint32_t cur_cz = 0;                                                  // coarse-table word of this lane's record (DevAnnotation::ei_coarse): 0, or 1 + the
                                                                           // interval that covers the 1024 breakpoint-free positions around its start
     const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
@@ -722,9 +843,28 @@ classify_ei_kernel(K1Args A) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));
         asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
+        asm volatile("" :: "v"(rk_pf), "v"(rk_pf2));           // (the previous tile's prefetch: older than the staged words, so this asks for no wait of its own)
 #endif
 #endif
         cur_cv = n_cv; cur_av = n_av; nx_co = n_co;
+        // (Measured and left off, profiles/r5_k1_variants.txt call r5c: touching the rank-table word of every record of the NEXT tile here,
+        //  a tile ahead of the feature stage that reads it -- a cold HBM line per ~256 positions of a 775 MB table streamed once --
+        //  with a load nobody reads made the kernel 1-6 % SLOWER: loads return in order, so every wait behind the prefetch, the next
+        //  feature stage's first look-up included, now also waits for the slowest line of the wave's prefetch.)
+#ifndef K1E_RANK_PREFETCH
+#define K1E_RANK_PREFETCH 0
+#endif
+#if K1E_RANK_PREFETCH
+        if (!(w1 == NONE || seg_next <= w1) && u_ci.rk_words != 0u) {
+            const int32_t top = (int32_t)(u_ci.rk_words << 6) - 1;
+            const int32_t x = n_cv.x + 1, xc = x < 0 ? 0 : (x > top ? top : x);
+            rk_pf = ld32(reinterpret_cast<const uint32_t *>(a.ei_rank), (u_ci.rk_base + ((uint32_t)xc >> 6)) * 4u);
+#if K1E_RANK_PREFETCH > 1
+            const int32_t x2 = x + 192, xc2 = x2 < 0 ? 0 : (x2 > top ? top : x2);
+            rk_pf2 = ld32(reinterpret_cast<const uint32_t *>(a.ei_rank), (u_ci.rk_base + ((uint32_t)xc2 >> 6)) * 4u);
+#endif
+        }
+#endif
         // the next tile's positions are here: its coarse-table words start their trip now and are looked at when that tile sorts
         // its records by shape, a feature stage and most of a phase A later (a read in an empty stretch of the genome then needs
         // no rank word).  Not across a contig boundary: the table is addressed through THIS tile's contig.

@@ -248,7 +248,10 @@ struct WaveSink {                              // the same on the host's wave em
 
 constexpr int RSQC_BED_BIN_SHIFT = 12;
 constexpr int FAST_SET = 2;    // genes per block handled on the fast path (registers)
-constexpr int FAST_BLOCKS = 4; // aligned blocks per record on the fast path; more -> slow path
+#ifndef RSQC_FAST_BLOCKS
+#define RSQC_FAST_BLOCKS 4
+#endif
+constexpr int FAST_BLOCKS = RSQC_FAST_BLOCKS; // aligned blocks per record on the fast path; more -> slow path
 constexpr int FAST_HITS = 2;   // exons fully containing one block on the fast path
 
 // the first FAST_BLOCKS aligned blocks of a record (extractBlocks, src/Expression.cpp:26-67)

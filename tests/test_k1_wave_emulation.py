@@ -176,3 +176,61 @@ def test_names_sharing_a_64_bit_hash_stay_distinct(oracle_lib):
     r64 = oracle_lib.run_oracle(p, ann, [narrow])
     _compare(hostemu.run_k1(p, ann, narrow, grid=2), r64)
     assert int(r.gene_fragments.sum()) > int(r64.gene_fragments.sum()) + 10
+
+
+def dense_case(seed, n_genes=7, n_reads=14000, span=2400):
+    """Short one-block reads packed onto a few overlapping genes (both strands, a globin, an rRNA gene, exons that overlap exons of
+    their own and of other genes, an interval under three exons): most 64-record feature-stage calls of one-block records then
+    have every block inside ONE elementary interval -- the wave-uniform path of classify_ei_kernel (rsqc_k1.h, k1e_uniform1) --
+    and the calls that straddle a breakpoint take the general path next to them."""
+    from rnaseqc_amd.abi import CIG_M as M, CIG_S as S, CIG_N as N, CIG_I as I
+    rng = np.random.default_rng(seed)
+    rows = []
+    for g in range(n_genes):
+        gs = int(rng.integers(1, span - 500)); ge = gs + int(rng.integers(120, 480))
+        strand = "+-."[int(rng.integers(0, 3))]
+        ttype = "rRNA" if g % 5 == 1 else "protein_coding"
+        name = "HBB" if g % 6 == 2 else "N%d" % g
+        rows.append(dict(contig="c", type="gene", start=gs, end=ge, strand=strand, gene_id="G%d" % g, gene_name=name, transcript_type=ttype))
+        for e in range(int(rng.integers(1, 4))):
+            es = int(rng.integers(gs, ge - 60)); ee = min(ge, es + int(rng.integers(60, 300)))
+            rows.append(dict(contig="c", type="exon", start=es, end=ee, strand=strand, gene_id="G%d" % g, exon_id="G%d_e%d" % (g, e),
+                             gene_name=name, transcript_type=ttype))
+    ann = Annotation.from_rows(["c"], rows)
+    recs = []
+    starts = np.sort(rng.integers(0, span, n_reads))
+    for pos in starts:
+        u = rng.random()
+        if u < 0.85:
+            cig = [(M, int(rng.integers(0 if rng.random() < 0.02 else 1, 14)))]
+            if rng.random() < 0.2:
+                cig = [(S, 3)] + cig
+            if rng.random() < 0.1:
+                cig = cig + [(I, 2)]
+        elif u < 0.95:
+            cig = [(M, int(rng.integers(1, 30))), (N, int(rng.choice([1, 40, 200]))), (M, int(rng.integers(1, 30)))]
+        else:
+            cig = [(M, 10), (N, 30), (M, 10), (N, 30), (M, 10)]
+        flag = (0x1 if rng.random() < 0.9 else 0) | (0x2 if rng.random() < 0.9 else 0) | (0x10 if rng.random() < 0.5 else 0) | \
+               (0x40 if rng.random() < 0.5 else 0x80) | (0x400 if rng.random() < 0.1 else 0)
+        recs.append(dict(qname="q%d" % int(rng.integers(0, n_reads // 2)), tid=0, pos=int(pos), cigar=cig, flag=flag,
+                         mapq=int(rng.choice([0, 3, 60, 255, 255, 255])), nm=int(rng.integers(0, 9)) if rng.random() < 0.9 else None,
+                         mpos=int(pos) + int(rng.integers(0, 300)), mtid=0))
+    return ann, Batch.from_records(recs)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_dense_one_block_tiles_take_the_uniform_path(oracle_lib, seed):
+    ann, batch = dense_case(700 + seed)
+    for kw in (dict(), dict(unpaired=1, mapq_threshold=3), dict(stranded=abi.STRAND_FORWARD)):
+        p = abi.default_params(**kw)
+        want = oracle_lib.run_oracle(p, ann, [batch])
+        ref = hostemu.run(p, ann, batch, mode=1, want_cov=True)
+        for grid in (1, 3):
+            o = hostemu.run_k1(p, ann, batch, grid=grid, want_cov=True, coarse=False)
+            _compare(o, want, ref.cov)
+            if "stranded" not in kw:
+                assert o.n_uniform >= 40, o.n_uniform        # (of ~190 one-block calls)
+            else:
+                assert o.n_uniform == 0                     # --stranded: the containing exons are a per-lane property
+    assert want.gene_reads.sum() > 300 and want.counters[abi.COUNTER_NAMES.index("rRNA Reads")] > 0
