@@ -311,7 +311,10 @@ typedef struct rsqc_batch {
        383-387 compares the strings): two different names are merged only if BOTH hashes collide.  Without it the identity is the
        64-bit qhash alone.  The 32-byte record itself has no room for it (its layout is the contract's: 32 + 4 n_cigar bytes per
        record); the column is read only for records that are counted to a gene.  Both ingest paths of the library (the device
-       decode and the host reader) fill it.                                                                              */
+       decode and the host reader) fill it.  Every QNAME-keyed stage uses the same identity: geneFragmentCounts, the fragment-size
+       sampler (src/Expression.cpp:511-531) and the fragment GC pairing (:461-474).  ALL OR NONE: the batches of one pass (between
+       two rsqc_reset) either all carry the column or none does -- a submit that disagrees with the pass's first batch fails with
+       RSQC_ERR_ARG (the two mates of a fragment would otherwise carry (qhash, h2) and (qhash, 0): two names).                  */
     const uint32_t *qhash2;            /* [n]                                  */
 } rsqc_batch;
 
@@ -381,7 +384,12 @@ RSQC_API void rsqc_destroy(rsqc_ctx *ctx);
 
 /* Copies the annotation into HBM and builds the device index.  `owned_contig`
  * (n_contigs bytes, may be NULL = all) marks the contigs of this shard: only
- * their genes get coverage/bias results (multi-GPU by contig).  */
+ * their genes get coverage/bias results (multi-GPU by contig).
+ * RSQC_OK may come WITH A WARNING in rsqc_last_error (empty otherwise): an exon row outside the row of its gene.  The
+ * reference runs such a GTF and prints "Gene encountered after computing coverage" (src/Metrics.cpp:108-112) when a read
+ * reaches the exon after the gene row has left its window; here every record is answered from the rows as given: counters,
+ * gene reads / unique reads and exon reads are the reference's, fragment counts and coverage statistics of THAT gene are
+ * computed as if the gene had stayed in the window.                                                        */
 RSQC_API int rsqc_set_annotation(rsqc_ctx *ctx, const rsqc_annotation *ann,
                         const uint8_t *owned_contig);
 RSQC_API int rsqc_set_bed(rsqc_ctx *ctx, const rsqc_bed *bed);

@@ -67,7 +67,7 @@ typedef struct {              /* Collector entry / CoverageEntry              */
 } staged_t;
 
 typedef struct {              /* fragmentSizeMetrics pending mate             */
-    uint64_t h; char *s; int32_t bed; int64_t endpos; int used;
+    uint64_t h; uint32_t h2 /* second hash of the name when the batch carries one and no strings (hash-only mode) */; char *s; int32_t bed; int64_t endpos; int used;
 } pending_t;
 
 typedef struct oracle_ctx {
@@ -500,8 +500,8 @@ static void fragment_size(oracle_ctx *c, const rec_t *r, const block_t *blocks, 
         size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (c->pend_cap - 1);
         while (c->pend[j].used) {
             if (c->pend[j].used == 1 && c->pend[j].h == h &&
-                (!r->qname || (c->pend[j].s && strlen(c->pend[j].s) == r->qname_len &&
-                               memcmp(c->pend[j].s, r->qname, r->qname_len) == 0))) { found = &c->pend[j]; break; }
+                (r->qname ? (c->pend[j].s && strlen(c->pend[j].s) == r->qname_len && memcmp(c->pend[j].s, r->qname, r->qname_len) == 0)
+                          : (!r->has_qhash2 || c->pend[j].h2 == r->qhash2))) { found = &c->pend[j]; break; }   /* names; else the 96-bit identity */
             j = (j + 1) & (c->pend_cap - 1);
         }
     }
@@ -521,7 +521,7 @@ static void fragment_size(oracle_ctx *c, const rec_t *r, const block_t *blocks, 
         size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (c->pend_cap - 1);
         while (c->pend[j].used == 1) j = (j + 1) & (c->pend_cap - 1);
         int was_tomb = c->pend[j].used == 2;
-        c->pend[j].used = 1; c->pend[j].h = h; c->pend[j].bed = name; c->pend[j].endpos = endpos;
+        c->pend[j].used = 1; c->pend[j].h = h; c->pend[j].h2 = r->has_qhash2 ? r->qhash2 : 0u; c->pend[j].bed = name; c->pend[j].endpos = endpos;
         c->pend[j].s = NULL;
         if (r->qname) { c->pend[j].s = xcalloc(r->qname_len + 1, 1); memcpy(c->pend[j].s, r->qname, r->qname_len); }
         if (!was_tomb) c->pend_n++;
@@ -563,8 +563,8 @@ static double fragment_gc(oracle_ctx *c, const rec_t *r, uint32_t exon_row) {
         size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (c->gcp_cap - 1);
         while (c->gcp[j].used) {
             if (c->gcp[j].used == 1 && c->gcp[j].h == h &&
-                (!r->qname || (c->gcp[j].s && strlen(c->gcp[j].s) == r->qname_len &&
-                               memcmp(c->gcp[j].s, r->qname, r->qname_len) == 0))) { found = &c->gcp[j]; break; }
+                (r->qname ? (c->gcp[j].s && strlen(c->gcp[j].s) == r->qname_len && memcmp(c->gcp[j].s, r->qname, r->qname_len) == 0)
+                          : (!r->has_qhash2 || c->gcp[j].h2 == r->qhash2))) { found = &c->gcp[j]; break; }   /* names; else the 96-bit identity */
             j = (j + 1) & (c->gcp_cap - 1);
         }
     }
@@ -583,7 +583,7 @@ static double fragment_gc(oracle_ctx *c, const rec_t *r, uint32_t exon_row) {
         size_t j = (size_t)(h * 0x9e3779b97f4a7c15ull >> 17) & (c->gcp_cap - 1);
         while (c->gcp[j].used == 1) j = (j + 1) & (c->gcp_cap - 1);
         int was_tomb = c->gcp[j].used == 2;
-        c->gcp[j].used = 1; c->gcp[j].h = h; c->gcp[j].bed = (int32_t)exon_row; c->gcp[j].endpos = endpos;
+        c->gcp[j].used = 1; c->gcp[j].h = h; c->gcp[j].h2 = r->has_qhash2 ? r->qhash2 : 0u; c->gcp[j].bed = (int32_t)exon_row; c->gcp[j].endpos = endpos;
         c->gcp[j].s = NULL;
         if (r->qname) { c->gcp[j].s = xcalloc(r->qname_len + 1, 1); memcpy(c->gcp[j].s, r->qname, r->qname_len); }
         if (!was_tomb) c->gcp_n++;

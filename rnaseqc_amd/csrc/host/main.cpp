@@ -540,10 +540,13 @@ int main(int argc, char **argv) {
                 owned = owned_masks[g].data();
             }
             if ((rc = rsqc_set_annotation(sh.gpu, &ann.ann, owned)) != RSQC_OK) {
-                // (the GTF parsed: this is the device index refusing the annotation -- e.g. an exon outside its gene's row, or no memory
-                //  for the interval tables -- and its own message says which)
+                // (the GTF parsed: this is the device index refusing the annotation -- e.g. no memory for the interval tables -- and
+                //  its own message says which)
                 cerr << "Unable to build the annotation index on the GPU: " << rsqc_last_error(sh.gpu) << endl; return 11;
             }
+            // accepted with a warning (an exon outside its gene's row): the reference's counterpart is its per-read
+            // "Gene encountered after computing coverage" (src/Metrics.cpp:108-112); said once, before the BAM loop
+            if (g == 0 && rsqc_last_error(sh.gpu)[0]) cerr << "Warning: " << rsqc_last_error(sh.gpu) << endl;
             if (o.has_bed && (rc = rsqc_set_bed(sh.gpu, &ann.bed)) != RSQC_OK) { cerr << "Failed to parse the BED: " << rsqc_last_error(sh.gpu) << endl; return 11; }
         }
         std::vector<char> in_fasta;

@@ -67,21 +67,21 @@ struct PairBuf {                // (gene, qname-hash) pairs of one submitted bat
 };
 
 struct FragBuf {                // fragment-size candidates of one submitted batch (BED runs only)
-    DevBuf file, qhash, name, endpos, fs, count;
-    DevBuf r_file, r_qhash, r_name, r_endpos, r_fs, r_counts;   // the per-record kernel's workgroup regions (packed into the columns above by frag_compact_kernel)
+    DevBuf file, qhash, name, endpos, fs, h2, count;
+    DevBuf r_file, r_qhash, r_name, r_endpos, r_fs, r_h2, r_counts;   // the per-record kernel's workgroup regions (packed into the columns above by frag_compact_kernel)
     uint32_t cap = 0, grid_cap = 0;
     uint32_t *h_count = nullptr;
     bool used = false;
 };
 struct GcBuf {                  // fragment GC candidates of one submitted batch (--fasta runs only)
-    DevBuf file, qhash, row, endpos, flag_lq, tid, count;
+    DevBuf file, qhash, row, endpos, flag_lq, tid, h2, count;
     uint32_t cap = 0;
     uint32_t *h_count = nullptr;
     bool used = false;
 };
 // growing device arrays of the retired batches: a few parallel columns with one fill level
 struct Arena {
-    DevBuf col[6]; size_t width[6] = {0, 0, 0, 0, 0, 0}; int n_col = 0;
+    DevBuf col[8]; size_t width[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n_col = 0;
     uint64_t used = 0, cap = 0;
 };
 
@@ -182,6 +182,7 @@ struct rsqc_ctx {
     std::vector<UploadedBatch *> resident;
     std::vector<UploadedBatch *> transient;     // owned by submit(), freed at wait()
     uint64_t next_record_base = 0;
+    int name_mode = -1;                         // -1 no batch yet in this pass; 0 batches without qhash2 (64-bit names); 1 with (96-bit names)
     // per submitted batch: file index of its first record and the Read-Length transfer function the KR kernel leaves
     // on the device (rsqc_shard_info)
     std::vector<uint64_t> batch_file_index, batch_records;
@@ -329,7 +330,7 @@ int zero_accumulators(rsqc_ctx *c) {
         c->h_gc.assign(RSQC_GC_BINS + 1, 0);
     }
     c->finalized = false;
-    c->next_record_base = 0;
+    c->next_record_base = 0; c->name_mode = -1;
     c->batch_file_index.clear(); c->batch_records.clear();
     c->h_rl_offset.clear(); c->h_rl_span.clear(); c->h_rl_state.clear();
     c->h_sample_file.clear(); c->h_sample_size.clear(); c->frag_kept = 0;
@@ -413,7 +414,7 @@ int retire_completed(rsqc_ctx *c, bool all) {
     auto retire_list = [&](std::vector<size_t> &in_flight, size_t n_keep, Arena &arena, auto &&buf_of) -> int {
         const size_t n_retire = in_flight.size() > n_keep ? in_flight.size() - n_keep : 0;
         for (size_t k = 0; k < n_retire; ++k) {
-            uint32_t count = 0; uint32_t cap = 0; const void *src[6]; bool *used = nullptr;
+            uint32_t count = 0; uint32_t cap = 0; const void *src[8]; bool *used = nullptr;
             buf_of(in_flight[k], count, cap, src, used);
             if (count > cap) return fail(c, RSQC_ERR_CAPACITY, "candidate overflow");
             int rc = arena_reserve(c, arena, count);
@@ -429,13 +430,13 @@ int retire_completed(rsqc_ctx *c, bool all) {
     int rc = retire_list(c->frags_in_flight, c->have_bed ? keep : c->frags_in_flight.size(), c->frag_arena,
                          [&](size_t i, uint32_t &count, uint32_t &cap, const void **src, bool *&used) {
                              FragBuf &fb = c->frag_pool[i]; count = *fb.h_count; cap = fb.cap; used = &fb.used;
-                             src[0] = fb.file.p; src[1] = fb.qhash.p; src[2] = fb.name.p; src[3] = fb.endpos.p; src[4] = fb.fs.p; src[5] = nullptr;
+                             src[0] = fb.file.p; src[1] = fb.qhash.p; src[2] = fb.name.p; src[3] = fb.endpos.p; src[4] = fb.fs.p; src[5] = fb.h2.p;
                          });
     if (rc) return rc;
     return retire_list(c->gcs_in_flight, (c->have_ref && !c->dparams.legacy) ? keep : c->gcs_in_flight.size(), c->gc_arena,
                        [&](size_t i, uint32_t &count, uint32_t &cap, const void **src, bool *&used) {
                            GcBuf &gb = c->gc_pool[i]; count = *gb.h_count; cap = gb.cap; used = &gb.used;
-                           src[0] = gb.file.p; src[1] = gb.qhash.p; src[2] = gb.row.p; src[3] = gb.endpos.p; src[4] = gb.flag_lq.p; src[5] = gb.tid.p;
+                           src[0] = gb.file.p; src[1] = gb.qhash.p; src[2] = gb.row.p; src[3] = gb.endpos.p; src[4] = gb.flag_lq.p; src[5] = gb.tid.p; src[6] = gb.h2.p;
                        });
 }
 
@@ -465,6 +466,13 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     if (!c->have_ann) return fail(c, RSQC_ERR_ARG, "rsqc_set_annotation must precede rsqc_submit");
     if (c->finalized) return fail(c, RSQC_ERR_ARG, "rsqc_reset required after rsqc_finalize");
     if (u->n == 0) return 0;
+    // one name identity per pass: a fragment whose mates carry (qhash, h2) and (qhash, 0) would count as two names
+    {
+        const int mode = u->d.qhash2 ? 1 : 0;
+        if (c->name_mode < 0) c->name_mode = mode;
+        else if (c->name_mode != mode)
+            return fail(c, RSQC_ERR_ARG, "rsqc_batch.qhash2 must be given for every batch of a pass or for none (the name identity is 96 or 64 bits for the whole pass)");
+    }
     const uint64_t tiles = (u->n + RSQC_K1_THREADS - 1) / RSQC_K1_THREADS;
     const uint64_t wave_tiles = (u->n + 63) / 64 + 64;
     if (wave_tiles > c->tile_cap) {
@@ -508,12 +516,12 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
             int rc2;
             if ((rc2 = dev_alloc(c, fb.file, u->n * 8, false)) || (rc2 = dev_alloc(c, fb.qhash, u->n * 8, false)) ||
                 (rc2 = dev_alloc(c, fb.name, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.endpos, u->n * 4, false)) ||
-                (rc2 = dev_alloc(c, fb.fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.count, 16, false))) return rc2;
+                (rc2 = dev_alloc(c, fb.fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.h2, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.count, 16, false))) return rc2;
             if (!c->dparams.legacy) {
                 fb.grid_cap = (uint32_t)grid;
                 if ((rc2 = dev_alloc(c, fb.r_file, u->n * 8, false)) || (rc2 = dev_alloc(c, fb.r_qhash, u->n * 8, false)) ||
                     (rc2 = dev_alloc(c, fb.r_name, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.r_endpos, u->n * 4, false)) ||
-                    (rc2 = dev_alloc(c, fb.r_fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.r_counts, (size_t)grid * 4, false))) return rc2;
+                    (rc2 = dev_alloc(c, fb.r_fs, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.r_h2, u->n * 4, false)) || (rc2 = dev_alloc(c, fb.r_counts, (size_t)grid * 4, false))) return rc2;
             }
             HIP_TRY(c, hipHostMalloc((void **)&fb.h_count, 16, hipHostMallocDefault));
             c->frag_pool.push_back(fb);
@@ -525,10 +533,12 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
         acc.frag.file_index = (uint64_t *)fb.file.p; acc.frag.qhash = (uint64_t *)fb.qhash.p;
         acc.frag.name = (int32_t *)fb.name.p; acc.frag.endpos = (int32_t *)fb.endpos.p;
         acc.frag.flag_size = (uint32_t *)fb.fs.p; acc.frag.count = (uint32_t *)fb.count.p; acc.frag.cap = fb.cap; acc.frag.chunk_count = nullptr;
+        acc.frag.h2 = (uint32_t *)fb.h2.p;
         frag_dense = acc.frag;
         if (!c->dparams.legacy) {                 // the per-record kernel writes workgroup regions; frag_compact_kernel packs them (below)
             acc.frag.file_index = (uint64_t *)fb.r_file.p; acc.frag.qhash = (uint64_t *)fb.r_qhash.p; acc.frag.name = (int32_t *)fb.r_name.p;
             acc.frag.endpos = (int32_t *)fb.r_endpos.p; acc.frag.flag_size = (uint32_t *)fb.r_fs.p; acc.frag.chunk_count = (uint32_t *)fb.r_counts.p;
+            acc.frag.h2 = (uint32_t *)fb.r_h2.p;
         }
     }
     // file order is part of the boundary: the index of record 0 in the whole file comes from the caller (it decides the
@@ -559,7 +569,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
             int rc2;
             if ((rc2 = dev_alloc(c, gb.file, u->n * 8, false)) || (rc2 = dev_alloc(c, gb.qhash, u->n * 8, false)) ||
                 (rc2 = dev_alloc(c, gb.row, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.endpos, u->n * 4, false)) ||
-                (rc2 = dev_alloc(c, gb.flag_lq, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.tid, u->n * 4, false)) ||
+                (rc2 = dev_alloc(c, gb.flag_lq, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.tid, u->n * 4, false)) || (rc2 = dev_alloc(c, gb.h2, u->n * 4, false)) ||
                 (rc2 = dev_alloc(c, gb.count, 16, false))) return rc2;
             HIP_TRY(c, hipHostMalloc((void **)&gb.h_count, 16, hipHostMallocDefault));
             c->gc_pool.push_back(gb);
@@ -569,7 +579,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
         c->gcs_in_flight.push_back(gidx);
         HIP_TRY(c, hipMemsetAsync(gb.count.p, 0, 16, c->stream));
         GcCandidates gc{(uint64_t *)gb.file.p, (uint64_t *)gb.qhash.p, (uint32_t *)gb.row.p, (int32_t *)gb.endpos.p,
-                        (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, (uint32_t *)gb.count.p, gb.cap};
+                        (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, (uint32_t *)gb.count.p, gb.cap, (uint32_t *)gb.h2.p};
         launch_gc_candidates(c->stream, c->dann, c->dparams, d, c->dref, gc, acc.error);
     }
     // the batch's counts, for its retirement: page-locked mirrors + an event that tells when they are valid.  The copy of the
@@ -618,8 +628,8 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.n_filter_tags = params->n_filter_tags;
     c->dparams.legacy = params->legacy ? 1 : 0;
     c->pair_arena.n_col = 3; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8; c->pair_arena.width[2] = 4;   // gene, name hash, second name hash
-    c->frag_arena.n_col = 5; { const size_t w[5] = {8, 8, 4, 4, 4}; for (int k = 0; k < 5; ++k) c->frag_arena.width[k] = w[k]; }
-    c->gc_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->gc_arena.width[k] = w[k]; }
+    c->frag_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->frag_arena.width[k] = w[k]; }   // ..., second name hash
+    c->gc_arena.n_col = 7; { const size_t w[7] = {8, 8, 4, 4, 4, 4, 4}; for (int k = 0; k < 7; ++k) c->gc_arena.width[k] = w[k]; }   // ..., second name hash
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(16384, std::max(1, atoi(e)));
     *out = c;
     return RSQC_OK;
@@ -634,8 +644,8 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
     for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.h2.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); if (pb.kernels) (void)hipEventDestroy(pb.kernels); }
-    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.count.release(); fb.r_file.release(); fb.r_qhash.release(); fb.r_name.release(); fb.r_endpos.release(); fb.r_fs.release(); fb.r_counts.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
-    for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
+    for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.h2.release(); fb.count.release(); fb.r_file.release(); fb.r_qhash.release(); fb.r_name.release(); fb.r_endpos.release(); fb.r_fs.release(); fb.r_h2.release(); fb.r_counts.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
+    for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.h2.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
     c->d_arena_count.release(); c->d_rl_summary.release();
     {
@@ -782,6 +792,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     c->have_ann = true;
     if ((rc = zero_accumulators(c))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->last_error = hx.warning;                  // (RSQC_OK with a warning: an exon outside its gene's row, see rsqc_index.h)
     return RSQC_OK;
 }
 
@@ -1084,8 +1095,8 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 const uint32_t n = *fb.h_count;               // (copied when the batch was submitted; the stream has been synchronised)
                 if (n > fb.cap) return fail(c, RSQC_ERR_CAPACITY, "fragment candidate overflow");
                 if ((rc = arena_reserve(c, c->frag_arena, n))) return rc;
-                const void *src[5] = {fb.file.p, fb.qhash.p, fb.name.p, fb.endpos.p, fb.fs.p};
-                for (int f = 0; f < 5 && n; ++f)
+                const void *src[6] = {fb.file.p, fb.qhash.p, fb.name.p, fb.endpos.p, fb.fs.p, fb.h2.p};
+                for (int f = 0; f < 6 && n; ++f)
                     HIP_TRY(c, hipMemcpyAsync((char *)c->frag_arena.col[f].p + c->frag_arena.used * c->frag_arena.width[f], src[f],
                                               (size_t)n * c->frag_arena.width[f], hipMemcpyDeviceToDevice, c->stream));
                 c->frag_arena.used += n;
@@ -1095,7 +1106,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
             const uint64_t total = c->frag_arena.used;
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many fragment-size candidates");
             FragCandidates fc{(uint64_t *)c->frag_arena.col[0].p, (uint64_t *)c->frag_arena.col[1].p, (int32_t *)c->frag_arena.col[2].p,
-                              (int32_t *)c->frag_arena.col[3].p, (uint32_t *)c->frag_arena.col[4].p, nullptr, (uint32_t)total};
+                              (int32_t *)c->frag_arena.col[3].p, (uint32_t *)c->frag_arena.col[4].p, nullptr, (uint32_t)total, nullptr, (uint32_t *)c->frag_arena.col[5].p};
             const auto tf0 = std::chrono::steady_clock::now();
             rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
                                     c->frag_remaining, c->frag_scratch, c->frag_kept, c->acc.error);
@@ -1112,15 +1123,15 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 total = *gb.h_count;
                 if (total > gb.cap) return fail(c, RSQC_ERR_CAPACITY, "GC candidate overflow");
                 gc = GcCandidates{(uint64_t *)gb.file.p, (uint64_t *)gb.qhash.p, (uint32_t *)gb.row.p, (int32_t *)gb.endpos.p,
-                                  (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, nullptr, (uint32_t)total};
+                                  (uint32_t *)gb.flag_lq.p, (int32_t *)gb.tid.p, nullptr, (uint32_t)total, (uint32_t *)gb.h2.p};
             } else {
                 for (size_t k = 0; k < c->gcs_in_flight.size(); ++k) {
                     GcBuf &gb = c->gc_pool[c->gcs_in_flight[k]];
                     const uint32_t n = *gb.h_count;
                     if (n > gb.cap) return fail(c, RSQC_ERR_CAPACITY, "GC candidate overflow");
                     if ((rc = arena_reserve(c, c->gc_arena, n))) return rc;
-                    const void *src[6] = {gb.file.p, gb.qhash.p, gb.row.p, gb.endpos.p, gb.flag_lq.p, gb.tid.p};
-                    for (int f = 0; f < 6 && n; ++f)
+                    const void *src[7] = {gb.file.p, gb.qhash.p, gb.row.p, gb.endpos.p, gb.flag_lq.p, gb.tid.p, gb.h2.p};
+                    for (int f = 0; f < 7 && n; ++f)
                         HIP_TRY(c, hipMemcpyAsync((char *)c->gc_arena.col[f].p + c->gc_arena.used * c->gc_arena.width[f], src[f],
                                                   (size_t)n * c->gc_arena.width[f], hipMemcpyDeviceToDevice, c->stream));
                     c->gc_arena.used += n;
@@ -1129,7 +1140,7 @@ static int run_finalize_kernels(rsqc_ctx *c) {
                 c->gcs_in_flight.clear();
                 total = c->gc_arena.used;
                 gc = GcCandidates{(uint64_t *)c->gc_arena.col[0].p, (uint64_t *)c->gc_arena.col[1].p, (uint32_t *)c->gc_arena.col[2].p,
-                                  (int32_t *)c->gc_arena.col[3].p, (uint32_t *)c->gc_arena.col[4].p, (int32_t *)c->gc_arena.col[5].p, nullptr, (uint32_t)total};
+                                  (int32_t *)c->gc_arena.col[3].p, (uint32_t *)c->gc_arena.col[4].p, (int32_t *)c->gc_arena.col[5].p, nullptr, (uint32_t)total, (uint32_t *)c->gc_arena.col[6].p};
             }
             if (total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "too many GC candidates");
             if (total) {

@@ -52,6 +52,7 @@ struct FragCandidates {
     // yields at most one candidate), no memory atomic -- and leaves its count here; frag_compact_kernel then packs the regions
     // into the dense list.  (One shared counter was 70 M memory atomics on one address: 41 of the 44 ms of a --bed pass.)
     uint32_t *chunk_count;       // [workgroups of the per-record kernel]; null: `count` is a plain shared counter
+    uint32_t *h2;                // second name hash of the record (rsqc_batch.qhash2; zeros for a batch without): a name is (qhash, h2), as in K4
 };
 
 // --fasta: one G/C bit per base (gc(), src/Fasta.cpp:67-74, counts G g C c only); every contig starts on a word
@@ -69,6 +70,7 @@ struct GcCandidates {
     uint32_t *flag_lq;           // bit 31: pos != mpos ; low 31 bits alignment.Length()
     int32_t *tid;
     uint32_t *count; uint32_t cap;
+    uint32_t *h2;                // second name hash of the record (rsqc_batch.qhash2; zeros for a batch without)
 };
 #if defined(__HIPCC__)
 // bases of [s, e) (0-based, inside the contig) that are G/C

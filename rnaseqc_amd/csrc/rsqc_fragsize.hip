@@ -36,8 +36,10 @@ namespace rsqc {
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 namespace {
-// control words on the device (S.count): [0] samples, [1] kept, [2] distinct sizes, [3] sizes beyond the table, [8..263] digit histogram
-constexpr size_t CTL_WORDS = 8 + 256;
+// control words on the device (S.count): [0] samples, [1] kept, [2] distinct sizes, [3] sizes beyond the table, [4] largest size in the
+// table, [8..263] digit histogram, [264..267] the select's state (two 64-bit words: prefix, rank still wanted)
+constexpr size_t CTL_WORDS = 8 + 256 + 4;
+constexpr uint32_t PAIRS_FIRST = 2048;        // (size, count) pairs read back with the control words; more only if there are more
 int grow_scratch(SortScratch &S, uint32_t n) {
     if (n <= S.cap_n) return 0;
     for (void **q : {&S.k0, &S.k1, &S.v0, &S.v1, &S.v2, &S.tmp}) { if (*q) (void)hipFree(*q); *q = nullptr; }
@@ -88,45 +90,41 @@ int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, 
     Buckets B;
     if (partition_by_name(stream, c.qhash, n, S, d_error, B)) return RSQC_ERR_HIP;
     hipLaunchKernelGGL(frag_replay_kernel, dim3(B.n_buckets), dim3(PB_THREADS), 0, stream, c, B.off, (const uint32_t *)S.v2, s_file, s_size, ctl + 0);
-    uint32_t ns = 0;
-    FS_TRY(hipMemcpyAsync(&ns, ctl + 0, 4, hipMemcpyDeviceToHost, stream));
-    FS_TRY(hipStreamSynchronize(stream));
-    if (!ns) return 0;
-    // (3) the first max_samples samples in file order: a selection, only when there are more than that
-    const uint32_t keep = std::min(ns, max_samples);
-    if (keep == 0) return 0;
-    if (keep < ns) {
-        uint64_t prefix = 0; uint32_t want = keep;                   // the sample of rank `keep` (1-based) among the file indices
-        uint32_t h[256];
-        for (int shift = 56; shift >= 0; shift -= 8) {
-            FS_TRY(hipMemsetAsync(ctl + 8, 0, 256 * 4, stream));
-            hipLaunchKernelGGL(sample_digit_hist_kernel, dim3(std::min<uint32_t>(1024u, (ns + 255u) / 256u)), dim3(256), 0, stream, s_file, ns, shift, prefix, ctl + 8);
-            FS_TRY(hipMemcpyAsync(h, ctl + 8, sizeof h, hipMemcpyDeviceToHost, stream));
-            FS_TRY(hipStreamSynchronize(stream));
-            uint32_t d = 0;
-            while (d < 255 && want > h[d]) { want -= h[d]; ++d; }
-            prefix |= (uint64_t)d << shift;
-        }
-        hipLaunchKernelGGL(sample_keep_kernel, dim3((ns + 255) / 256), dim3(256), 0, stream, s_file, s_size, ns, prefix, k_file, k_size, ctl + 1);
-    } else {
-        FS_TRY(hipMemcpyAsync(k_file, s_file, (size_t)ns * 8, hipMemcpyDeviceToDevice, stream));
-        FS_TRY(hipMemcpyAsync(k_size, s_size, (size_t)ns * 4, hipMemcpyDeviceToDevice, stream));
+    // (3) the first max_samples samples in file order: a radix select of the sample of rank min(samples, max_samples) among the file
+    //     indices, decided ON THE DEVICE digit by digit (round 4 read 256 counters back per digit and the sample count before: nine
+    //     synchronous copies per pass); with fewer samples than the limit it selects the last one and everything is kept
+    if (max_samples == 0) return 0;
+    uint64_t *state = (uint64_t *)(ctl + 264);
+    hipLaunchKernelGGL(sample_plan_kernel, dim3(1), dim3(64), 0, stream, ctl + 0, max_samples, state);
+    const uint32_t ns_bound = n / 2u + 1u;                              // (a sample takes two candidates)
+    const uint32_t sel_grid = std::min<uint32_t>(1024u, (ns_bound + 255u) / 256u);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(sample_digit_hist_kernel, dim3(sel_grid), dim3(256), 0, stream, s_file, ctl + 0, shift, state, ctl + 8);
+        hipLaunchKernelGGL(sample_digit_pick_kernel, dim3(1), dim3(256), 0, stream, ctl + 8, shift, state);
     }
-    n_kept = keep; remaining = max_samples - keep;
+    hipLaunchKernelGGL(sample_keep_kernel, dim3((ns_bound + 1023) / 1024), dim3(1024), 0, stream, s_file, s_size, ctl + 0, state, k_file, k_size, ctl + 1);
     // (4) the histogram of the kept sizes as (size, count) pairs, ascending
     FS_TRY(hipMemsetAsync(S.table, 0, (size_t)SIZE_TABLE * 4, stream));
     uint32_t *big = (uint32_t *)S.v2;                                  // (the bucket order is no longer needed)
-    hipLaunchKernelGGL(size_hist_kernel, dim3((keep + 255) / 256), dim3(256), 0, stream, k_size, keep, S.table, big, ctl + 3);
-    hipLaunchKernelGGL(size_hist_compact_kernel, dim3(1), dim3(1024), 0, stream, S.table, S.out_size, S.out_count, ctl + 2);
-    uint32_t tail[4] = {0, 0, 0, 0};
+    hipLaunchKernelGGL(size_hist_kernel, dim3(std::min<uint32_t>(512u, (std::min(ns_bound, max_samples) + 255u) / 256u)), dim3(256), 0, stream, k_size, ctl + 1, S.table, big, ctl + 3, ctl + 4);
+    hipLaunchKernelGGL(size_hist_compact_kernel, dim3(1), dim3(1024), 0, stream, S.table, ctl + 4, S.out_size, S.out_count, ctl + 2);
+    // ONE read-back: the control words and the first pairs (a fragment-size histogram has a few hundred distinct sizes)
+    uint32_t tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> hs(PAIRS_FIRST), hc(PAIRS_FIRST);
     FS_TRY(hipMemcpyAsync(tail, ctl, sizeof tail, hipMemcpyDeviceToHost, stream));
+    FS_TRY(hipMemcpyAsync(hs.data(), S.out_size, PAIRS_FIRST * 4, hipMemcpyDeviceToHost, stream));
+    FS_TRY(hipMemcpyAsync(hc.data(), S.out_count, PAIRS_FIRST * 4, hipMemcpyDeviceToHost, stream));
     FS_TRY(hipStreamSynchronize(stream));
-    if (keep < ns && tail[1] != keep) return RSQC_ERR_HIP;               // (file indices are unique: the selection keeps exactly `keep`)
+    const uint32_t ns = tail[0], keep = std::min(ns, max_samples);
+    if (!ns) return 0;
+    if (tail[1] != keep) return RSQC_ERR_HIP;                           // (file indices are unique: the selection keeps exactly `keep`)
+    n_kept = keep; remaining = max_samples - keep;
     const uint32_t nd = tail[2], nb = tail[3];
-    std::vector<uint32_t> hs(nd), hc(nd), hb(nb);
-    if (nd) { FS_TRY(hipMemcpyAsync(hs.data(), S.out_size, (size_t)nd * 4, hipMemcpyDeviceToHost, stream)); FS_TRY(hipMemcpyAsync(hc.data(), S.out_count, (size_t)nd * 4, hipMemcpyDeviceToHost, stream)); }
+    std::vector<uint32_t> hb(nb);
+    hs.resize(std::max<uint32_t>(nd, 1)); hc.resize(std::max<uint32_t>(nd, 1));
+    if (nd > PAIRS_FIRST) { FS_TRY(hipMemcpyAsync(hs.data(), S.out_size, (size_t)nd * 4, hipMemcpyDeviceToHost, stream)); FS_TRY(hipMemcpyAsync(hc.data(), S.out_count, (size_t)nd * 4, hipMemcpyDeviceToHost, stream)); }
     if (nb) FS_TRY(hipMemcpyAsync(hb.data(), big, (size_t)nb * 4, hipMemcpyDeviceToHost, stream));
-    FS_TRY(hipStreamSynchronize(stream));
+    if (nd > PAIRS_FIRST || nb) FS_TRY(hipStreamSynchronize(stream));
     for (uint32_t i = 0; i < nd; ++i) { sizes.push_back((int64_t)hs[i]); counts.push_back((uint64_t)hc[i]); }
     std::sort(hb.begin(), hb.end());                                    // insert sizes of 2^20 and more (a handful, if any): all behind the table's
     for (uint32_t i = 0; i < nb;) {

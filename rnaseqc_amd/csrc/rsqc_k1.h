@@ -577,6 +577,7 @@ frag_compact_kernel(FragCandidates src, FragCandidates dst, uint32_t n_rec, uint
     for (uint32_t j = threadIdx.x; j < mine; j += blockDim.x) {
         dst.file_index[off + j] = src.file_index[beg + j]; dst.qhash[off + j] = src.qhash[beg + j];
         dst.name[off + j] = src.name[beg + j]; dst.endpos[off + j] = src.endpos[beg + j]; dst.flag_size[off + j] = src.flag_size[beg + j];
+        dst.h2[off + j] = src.h2[beg + j];
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *dst.count = off + mine;
 }
@@ -584,6 +585,9 @@ frag_compact_kernel(FragCandidates src, FragCandidates dst, uint32_t n_rec, uint
 #ifndef K1E_MINW
 #define K1E_MINW 4            /* waves per SIMD the register allocation aims at: 128 VGPRs, no spills (at 5 the loop spills: 7.7 vs 4.65 ms) */
 #endif
+// BED: the run has a BED (--bed: fragment-size candidates).  A template parameter, so that the instance of runs without one carries
+// none of its state (the candidate cursor alone took the kernel from 123 to 128 VGPRs and into scratch).
+template <bool BED>
 __global__ void __launch_bounds__(RSQC_K1_THREADS, K1E_MINW)
 classify_ei_kernel(K1Args A) {
     __shared__ K1eShared S;
@@ -665,6 +669,9 @@ classify_ei_kernel(K1Args A) {
     };
     load_contig();
     uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0, h3 = 0, c3 = 0;   // queue heads and fills (wave-uniform)
+    // --bed: the wave's cursor into its contig's BED rows (see phase A): rows [bed_lo, bed_hi), bed_k = first row that starts behind
+    // the last tile's end, start of row bed_k - 1 / running max of end up to it / start of row bed_k
+    uint32_t bed_seg = NONE, bed_lo = 0, bed_hi = 0, bed_k = 0; int32_t bed_cur = 0, bed_pm = 0, bed_nxt = 0;
 
     // Record words and eight CIGAR words per record are staged ONE TILE AHEAD; the CIGAR address of the tile after that
     // comes with them (it is the fourth word of the core record).  The staged loads are issued at the TOP of a tile and
@@ -762,7 +769,41 @@ classify_ei_kernel(K1Args A) {
         const WB go = gate_cascade_b<false, WaveSink, true>(a, pt, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
         RSQC_MARK(4);
         K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
-        if (a.have_bed && rc.frag_candidate) {                // src/RNASeQC.cpp:372
+        // --bed (src/RNASeQC.cpp:372): the block tests of fragmentSizeMetrics walk the CIGAR again and chase the BED rows per lane --
+        // divergent code with dependent loads, and as soon as ONE lane of the tile takes it the wave does (round 4: 4.2 instead of
+        // 2.6 ms).  Most tiles lie nowhere near a BED interval: a wave-level test first -- does ANY interval of the contig overlap
+        // the span [first candidate start, last candidate end + 1] of this tile?  The answer comes from a cursor into the contig's
+        // start-sorted rows that the wave moves along with the sorted stream (scalar registers; a binary search only when the tile's
+        // end passes the next interval's start): in steady state two wave reductions and no memory access.
+        bool bed_near = false;
+        if (BED) {
+            const bool cand = rc.frag_candidate != 0u;
+            const uint32_t t_lo = wave_min_u32_full(cand ? (uint32_t)(r.pos + 1) : 0x7FFFFFFFu), t_hi = wave_max_u32_full(cand ? (uint32_t)rc.endpos + 1u : 0u);
+            if (t_hi != 0u) {                                 // (some lane holds a candidate)
+                if (mixed) bed_near = true;                   // (a contig boundary inside the tile: no shortcut)
+                else {
+                    if (bed_seg != seg) {                     // first candidate tile on this contig: its rows
+                        const K1Args *q = k1e_lazy_args();
+                        bed_seg = seg; bed_lo = 0u; bed_hi = 0u;
+                        if (u_tid >= 0 && u_tid < q->a.n_contigs) { bed_lo = q->a.bed_range[u_tid]; bed_hi = q->a.bed_range[u_tid + 1]; }
+                        bed_k = bed_lo; bed_cur = (int32_t)0x7FFFFFFF; bed_nxt = (int32_t)0x80000000; bed_pm = (int32_t)0x80000000;   // (forces the search below)
+                    }
+                    if (bed_hi > bed_lo) {
+                        if ((int32_t)t_hi >= bed_nxt || (int32_t)t_hi < bed_cur) {      // the tile's end passed the next row's start (or the stream went backwards)
+                            const K1Args *q = k1e_lazy_args();
+                            uint32_t lo2 = bed_lo, hi2 = bed_hi;                      // first row with start > t_hi
+                            while (lo2 < hi2) { const uint32_t m = lo2 + ((hi2 - lo2) >> 1); if (q->a.bed_start[m] <= (int32_t)t_hi) lo2 = m + 1; else hi2 = m; }
+                            bed_k = lo2;
+                            bed_cur = bed_k > bed_lo ? q->a.bed_start[bed_k - 1] : (int32_t)0x80000000;
+                            bed_pm = bed_k > bed_lo ? q->a.bed_pmax[bed_k - 1] : (int32_t)0x80000000;
+                            bed_nxt = bed_k < bed_hi ? q->a.bed_start[bed_k] : (int32_t)0x7FFFFFFF;
+                        }
+                        bed_near = bed_k > bed_lo && bed_pm >= (int32_t)t_lo;          // a row starts at or before the span's end and one of those reaches its start
+                    }
+                }
+            }
+        }
+        if (bed_near && rc.frag_candidate) {                  // src/RNASeQC.cpp:372
             const K1Args *q = k1e_lazy_args();
             const int32_t name = bed_interval_of(q->a, r);
             if (name >= 0) {
@@ -770,6 +811,7 @@ classify_ei_kernel(K1Args A) {
                 const uint32_t slot = wg_beg + atomicAdd(&S.T.frags, 1u);       // the workgroup's own region (<= one candidate per record)
                 {
                     fr.file_index[slot] = q->b.record_base + i; fr.qhash[slot] = r.qhash;
+                    fr.h2[slot] = q->b.qhash2 ? q->b.qhash2[i] : 0u;                 // (the name is 96 bits on every path that keys on it)
                     fr.name[slot] = name; fr.endpos[slot] = rc.endpos;
                     const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
                     const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
@@ -922,7 +964,7 @@ classify_ei_kernel(K1Args A) {
         const K1Args *q = k1e_lazy_args();
         atomicMax(&q->acc.rl_stats[0], S.T.rl[0]); atomicMin(&q->acc.rl_stats[1], S.T.rl[1]); atomicMax(&q->acc.rl_stats[2], S.T.rl[2]);
         q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < q->acc.pair_chunk_cap ? S.T.pairs : q->acc.pair_chunk_cap;
-        if (q->a.have_bed) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
+        if (BED) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
     }
 }
 

@@ -42,15 +42,17 @@ __global__ void pair_bucket_scatter_kernel(const uint64_t *qhash, uint32_t n, ui
 
 // The candidates of one bucket in LDS, ordered by (name hash, file index).  Returns the bucket's size (0 when it overflowed:
 // the scan kernel has raised the error).  Slots behind the bucket's entries hold the largest key and sort to the end.
-struct PairBucket { uint64_t q[PB_CAP], f[PB_CAP]; uint32_t e[PB_CAP]; };
-__device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint64_t *qhash, const uint64_t *file_index, const uint32_t *off, const uint32_t *perm) {
+// A NAME is 96 bits here as in the fragment de-duplication (K4): the 64-bit hash the buckets are formed on AND the second hash
+// (rsqc_batch.qhash2) -- two names that share the first and differ in the second are two groups of the sort.
+struct PairBucket { uint64_t q[PB_CAP], f[PB_CAP]; uint32_t e[PB_CAP], h[PB_CAP]; };
+__device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint64_t *qhash, const uint32_t *h2, const uint64_t *file_index, const uint32_t *off, const uint32_t *perm) {
     const uint32_t lo = off[blockIdx.x], m = off[blockIdx.x + 1] - lo;
     if (m == 0 || m > PB_CAP) return 0u;
     uint32_t slots = 2;
     while (slots < m) slots <<= 1;
     for (uint32_t i = threadIdx.x; i < slots; i += PB_THREADS) {
-        if (i < m) { const uint32_t c = perm[lo + i]; S.q[i] = qhash[c]; S.f[i] = file_index[c]; S.e[i] = c; }
-        else { S.q[i] = ~0ull; S.f[i] = ~0ull; S.e[i] = 0xFFFFFFFFu; }
+        if (i < m) { const uint32_t c = perm[lo + i]; S.q[i] = qhash[c]; S.h[i] = h2 ? h2[c] : 0u; S.f[i] = file_index[c]; S.e[i] = c; }
+        else { S.q[i] = ~0ull; S.h[i] = 0xFFFFFFFFu; S.f[i] = ~0ull; S.e[i] = 0xFFFFFFFFu; }
     }
     __syncthreads();
     for (uint32_t k = 2; k <= slots; k <<= 1)
@@ -60,8 +62,9 @@ __device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint
                 if (x > i) {
                     const bool up = (i & k) == 0;
                     const uint64_t qi = S.q[i], qx = S.q[x], fi = S.f[i], fx = S.f[x];
-                    const bool greater = qi > qx || (qi == qx && fi > fx);
-                    if (greater == up) { S.q[i] = qx; S.q[x] = qi; S.f[i] = fx; S.f[x] = fi; const uint32_t t = S.e[i]; S.e[i] = S.e[x]; S.e[x] = t; }
+                    const uint32_t hi = S.h[i], hx = S.h[x];
+                    const bool greater = qi > qx || (qi == qx && (hi > hx || (hi == hx && fi > fx)));
+                    if (greater == up) { S.q[i] = qx; S.q[x] = qi; S.h[i] = hx; S.h[x] = hi; S.f[i] = fx; S.f[x] = fi; const uint32_t t = S.e[i]; S.e[i] = S.e[x]; S.e[x] = t; }
                 }
             }
             __syncthreads();
@@ -69,28 +72,39 @@ __device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint
     return m;
 }
 
-// src/Expression.cpp:511-538 for every name of the bucket
+// src/Expression.cpp:511-538 for every name of the bucket.  A name yields at most one sample per two of its records: the samples of
+// a bucket are collected in LDS and written behind ONE reservation of the output list (round 4 took a slot of the list per
+// sample: millions of atomics on one address).
 __global__ void __launch_bounds__(PB_THREADS)
 frag_replay_kernel(const FragCandidates c, const uint32_t *off, const uint32_t *perm, uint64_t *sample_file, uint32_t *sample_size, uint32_t *n_samples) {
     __shared__ PairBucket S;
-    const uint32_t m = pair_bucket_sorted(S, c.qhash, c.file_index, off, perm);
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0u;
+    const uint32_t m = pair_bucket_sorted(S, c.qhash, c.h2, c.file_index, off, perm);
+    __syncthreads();
+    uint64_t my_file[2]; uint32_t my_size[2]; uint32_t mine = 0;       // a thread owns the names that START at its slots j, j + 256, ...: a handful of samples
     for (uint32_t j = threadIdx.x; j < m; j += PB_THREADS) {
-        const uint64_t q = S.q[j];
-        if (j > 0 && S.q[j - 1] == q) continue;              // not the first record of its name
+        const uint64_t q = S.q[j]; const uint32_t h = S.h[j];
+        if (j > 0 && S.q[j - 1] == q && S.h[j - 1] == h) continue;   // not the first record of its name
         bool pending = false; int32_t p_name = 0, p_end = 0;
-        for (uint32_t k = j; k < m && S.q[k] == q; ++k) {
+        for (uint32_t k = j; k < m && S.q[k] == q && S.h[k] == h; ++k) {
             const uint32_t e = S.e[k];
             const int32_t name = c.name[e], endpos = c.endpos[e];
             if (!pending) { pending = true; p_name = name; p_end = endpos; }            // :512-516
             else if (name == p_name) {                                                  // :517
                 const uint32_t fs = c.flag_size[e];
                 if (!(fs >> 31) || endpos <= p_end) continue;                            // :528 (the entry stays)
-                const uint32_t slot = atomicAdd(n_samples, 1u);
-                sample_file[slot] = S.f[k]; sample_size[slot] = fs & 0x7FFFFFFFu;        // :530
+                if (mine < 2u) { my_file[mine] = S.f[k]; my_size[mine] = fs & 0x7FFFFFFFu; ++mine; }     // :530
+                else { const uint32_t slot = atomicAdd(n_samples, 1u); sample_file[slot] = S.f[k]; sample_size[slot] = fs & 0x7FFFFFFFu; }   // (a name with dozens of records)
                 pending = false;                                                        // :531
             }
         }
     }
+    const uint32_t at = mine ? atomicAdd(&s_n, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_samples, s_n);
+    __syncthreads();
+    for (uint32_t k = 0; k < mine; ++k) { sample_file[s_base + at + k] = my_file[k]; sample_size[s_base + at + k] = my_size[k]; }
 }
 
 #if defined(__HIPCC__)   /* (needs the G/C bit helpers of rsqc_device.h, device build only) */
@@ -101,13 +115,13 @@ gc_replay_kernel(const GcCandidates c, const uint32_t *off, const uint32_t *perm
     __shared__ PairBucket S;
     __shared__ uint32_t hist[RSQC_GC_BINS + 1];
     for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += PB_THREADS) hist[i] = 0u;
-    const uint32_t m = pair_bucket_sorted(S, c.qhash, c.file_index, off, perm);        // (ends with a barrier when m > 0)
+    const uint32_t m = pair_bucket_sorted(S, c.qhash, c.h2, c.file_index, off, perm);  // (ends with a barrier when m > 0)
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < m; j += PB_THREADS) {
-        const uint64_t q = S.q[j];
-        if (j > 0 && S.q[j - 1] == q) continue;
+        const uint64_t q = S.q[j]; const uint32_t h = S.h[j];
+        if (j > 0 && S.q[j - 1] == q && S.h[j - 1] == h) continue;
         bool pending = false; uint32_t p_row = 0; int32_t p_end = 0;
-        for (uint32_t k = j; k < m && S.q[k] == q; ++k) {
+        for (uint32_t k = j; k < m && S.q[k] == q && S.h[k] == h; ++k) {
             const uint32_t e = S.e[k];
             const uint32_t row = c.row[e]; const int32_t endpos = c.endpos[e];
             if (!pending) { pending = true; p_row = row; p_end = endpos; }              // :462-466
@@ -135,8 +149,9 @@ gc_replay_kernel(const GcCandidates c, const uint32_t *off, const uint32_t *perm
 
 // ---- the N smallest file indices among the samples: radix select, one 8-bit digit per pass ---------------------------------
 // counts, per value of the digit at `shift`, the samples whose higher digits equal those of `prefix`
-__global__ void __launch_bounds__(256) sample_digit_hist_kernel(const uint64_t *v, uint32_t n, int shift, uint64_t prefix, uint32_t *hist) {
+__global__ void __launch_bounds__(256) sample_digit_hist_kernel(const uint64_t *v, const uint32_t *n_at, int shift, const uint64_t *state, uint32_t *hist) {
     __shared__ uint32_t h[256];
+    const uint64_t prefix = state[0]; const uint32_t n = *n_at;
     h[threadIdx.x] = 0u;
     __syncthreads();
     const uint64_t high_mask = shift >= 56 ? 0ull : ~0ull << (shift + 8);
@@ -147,27 +162,73 @@ __global__ void __launch_bounds__(256) sample_digit_hist_kernel(const uint64_t *
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
-__global__ void sample_keep_kernel(const uint64_t *file, const uint32_t *size, uint32_t n, uint64_t last_kept, uint64_t *kept_file, uint32_t *kept_size, uint32_t *n_kept) {
+// (one reservation of the output per WORKGROUP of 1024: a slot per kept sample was a million atomics on one address -- 0.28 ms --
+//  and one per wave still 55 thousand of them: same-address memory atomics retire one after the other)
+__global__ void __launch_bounds__(1024) sample_keep_kernel(const uint64_t *file, const uint32_t *size, const uint32_t *n_at, const uint64_t *last_kept, uint64_t *kept_file, uint32_t *kept_size, uint32_t *n_kept) {
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && file[i] <= last_kept) { const uint32_t s = atomicAdd(n_kept, 1u); kept_file[s] = file[i]; kept_size[s] = size[i]; }
+    const bool keep = i < *n_at && file[i] <= *last_kept;
+    const unsigned long long m = __ballot(keep);
+    const int lane = (int)(threadIdx.x & 63u), lead = m ? __ffsll(m) - 1 : 0;
+    uint32_t base = 0;
+    if (m && lane == lead) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+    base = __shfl(base, lead, 64);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_kept, s_n);
+    __syncthreads();
+    if (keep) { const uint32_t s = s_base + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); kept_file[s] = file[i]; kept_size[s] = size[i]; }
+}
+// the select's start: rank of the last sample to keep = min(samples, --fragment-samples); nothing to keep -> a bound no file index reaches
+__global__ void sample_plan_kernel(const uint32_t *n_samples, uint32_t max_samples, uint64_t *state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { const uint32_t ns = *n_samples; state[0] = 0ull; state[1] = ns < max_samples ? ns : max_samples; }
+}
+// the radix select's decision on the device (round 4 read 256 counters back per digit: eight synchronous copies): from the digit
+// histogram of this pass, the digit that holds the sample of rank `want`; prefix and want move on in `state`, the histogram is cleared
+__global__ void __launch_bounds__(256) sample_digit_pick_kernel(uint32_t *hist, int shift, uint64_t *state /*[0] prefix, [1] want*/) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = hist[threadIdx.x]; hist[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t want = state[1]; uint32_t d = 0;
+        while (d < 255 && want > h[d]) { want -= h[d]; ++d; }
+        state[0] |= (uint64_t)d << shift; state[1] = want;
+    }
 }
 
 // ---- (size, count) pairs, ascending size ------------------------------------------------------------------------------------------
-__global__ void size_hist_kernel(const uint32_t *size, uint32_t n, uint32_t *table, uint32_t *big, uint32_t *n_big) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = size[i];
-    if (s < SIZE_TABLE) atomicAdd(&table[s], 1u);
-    else big[atomicAdd(n_big, 1u)] = s;
+// sizes below SIZE_LDS are counted per workgroup in LDS and flushed once (fragment sizes sit in a few hundred neighbouring cells:
+// a memory atomic per sample serialised on them -- 0.65 ms per million samples); `top` = largest size seen below SIZE_TABLE
+constexpr uint32_t SIZE_LDS = 4096;
+__global__ void __launch_bounds__(256) size_hist_kernel(const uint32_t *size, const uint32_t *n_at, uint32_t *table, uint32_t *big, uint32_t *n_big, uint32_t *top) {
+    __shared__ uint32_t h[SIZE_LDS];
+    __shared__ uint32_t s_top;
+    for (uint32_t k = threadIdx.x; k < SIZE_LDS; k += blockDim.x) h[k] = 0u;
+    if (threadIdx.x == 0) s_top = 0u;
+    __syncthreads();
+    const uint32_t n = *n_at;
+    uint32_t mx = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t s = size[i];
+        if (s < SIZE_LDS) atomicAdd(&h[s], 1u);
+        else if (s < SIZE_TABLE) atomicAdd(&table[s], 1u);
+        else big[atomicAdd(n_big, 1u)] = s;
+        if (s < SIZE_TABLE && s > mx) mx = s;
+    }
+    if (mx) atomicMax(&s_top, mx);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < SIZE_LDS; k += blockDim.x) if (h[k]) atomicAdd(&table[k], h[k]);
+    if (threadIdx.x == 0 && s_top) atomicMax(top, s_top);
 }
-// one workgroup: every thread owns a contiguous stretch of the table, counts its non-empty cells, the counts are scanned and
-// the cells written in order
-__global__ void __launch_bounds__(1024) size_hist_compact_kernel(const uint32_t *table, uint32_t *out_size, uint32_t *out_count, uint32_t *n_out) {
+// one workgroup: every thread owns a contiguous stretch of the USED part of the table [0, *top], counts its non-empty cells, the
+// counts are scanned and the cells written in order
+__global__ void __launch_bounds__(1024) size_hist_compact_kernel(const uint32_t *table, const uint32_t *top, uint32_t *out_size, uint32_t *out_count, uint32_t *n_out) {
     __shared__ uint32_t part[1024];
-    constexpr uint32_t PER = SIZE_TABLE / 1024u;
-    const uint32_t lo = threadIdx.x * PER;
+    const uint32_t used = *top + 1u, PER = (used + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * PER, hi = lo + PER < used ? lo + PER : used;
     uint32_t mine = 0;
-    for (uint32_t k = 0; k < PER; ++k) mine += table[lo + k] ? 1u : 0u;
+    for (uint32_t k = lo; k < hi; ++k) mine += table[k] ? 1u : 0u;
     part[threadIdx.x] = mine;
     __syncthreads();
     for (uint32_t o = 1; o < 1024u; o <<= 1) {
@@ -177,7 +238,7 @@ __global__ void __launch_bounds__(1024) size_hist_compact_kernel(const uint32_t 
         __syncthreads();
     }
     uint32_t at = part[threadIdx.x] - mine;
-    for (uint32_t k = 0; k < PER; ++k) { const uint32_t c = table[lo + k]; if (c) { out_size[at] = lo + k; out_count[at] = c; ++at; } }
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = table[k]; if (c) { out_size[at] = k; out_count[at] = c; ++at; } }
     if (threadIdx.x == 1023) *n_out = part[1023];
 }
 

@@ -265,6 +265,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                     const uint32_t slot = atomicAdd(acc.frag.count, 1u);
                     if (slot < acc.frag.cap) {
                         acc.frag.file_index[slot] = b.record_base + i; acc.frag.qhash[slot] = r.qhash;
+                        acc.frag.h2[slot] = b.qhash2 ? b.qhash2[i] : 0u;
                         acc.frag.name[slot] = name; acc.frag.endpos[slot] = rc.endpos;
                         const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
                         const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
@@ -558,6 +559,7 @@ gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, G
             const uint32_t slot = s_base + my;
             if (slot < out.cap) {
                 out.file_index[slot] = b.record_base + i; out.qhash[slot] = qhash; out.row[slot] = row_hit;
+                out.h2[slot] = b.qhash2 ? b.qhash2[i] : 0u;
                 out.endpos[slot] = endpos; out.flag_lq[slot] = flag_lq; out.tid[slot] = tid;
             } else atomicExch(error, RSQC_ERR_CAPACITY);
         }
@@ -633,7 +635,8 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
         const unsigned pad = 0u;
 #endif
         const K1Args A{a, p, b, acc};
-        hipLaunchKernelGGL(classify_ei_kernel, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
+        if (a.have_bed) hipLaunchKernelGGL(classify_ei_kernel<true>, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
+        else hipLaunchKernelGGL(classify_ei_kernel<false>, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
     }
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,

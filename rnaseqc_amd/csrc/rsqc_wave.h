@@ -71,6 +71,20 @@ __device__ __forceinline__ uint32_t wave_max_u32_full(uint32_t v) {
     return v;
 #endif
 }
+// minimum over the wave (all 64 lanes active): the same six DPP steps (lanes without a source keep their own value: old = v)
+__device__ __forceinline__ uint32_t wave_min_u32_full(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQC_DPP_MIN(ctrl, rmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = t < v ? t : v; }
+    RSQC_DPP_MIN(0x111, 0xf) RSQC_DPP_MIN(0x112, 0xf) RSQC_DPP_MIN(0x114, 0xf) RSQC_DPP_MIN(0x118, 0xf)
+    RSQC_DPP_MIN(0x142, 0xa) RSQC_DPP_MIN(0x143, 0xc)
+#undef RSQC_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+#endif
+}
 // sum over the wave (all 64 lanes active), in every lane: the same six DPP steps with an add (a ds_bpermute butterfly is six
 // dependent LDS round trips and five address computations per step)
 __device__ __forceinline__ uint32_t wave_sum_u32_full(uint32_t v) {

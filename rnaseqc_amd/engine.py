@@ -106,6 +106,10 @@ class Engine:
             raise EngineError(rc, "%s (%s)" % (self._l.rsqc_strerror(rc).decode(),
                                                self._l.rsqc_last_error(self._h).decode()))
 
+    def last_error(self) -> str:
+        """rsqc_last_error: the message of the last failure -- or the WARNING an accepted annotation left (an exon outside its gene's row)."""
+        return self._l.rsqc_last_error(self._h).decode()
+
     def set_annotation(self, ann, owned=None):
         s = ann.to_struct()
         o = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)

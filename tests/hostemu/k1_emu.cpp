@@ -109,7 +109,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     wavemu::grid_dim().x = (uint32_t)grid;
     for (int k = 0; k < grid; ++k) {
         wavemu::block_idx().x = (uint32_t)k;
-        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel(A); });
+        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel<false>(A); });      // (the instance of runs without a BED)
     }
     uint64_t listed = 0;
     if (error) return error;

@@ -32,18 +32,20 @@ template <class F> void launch(uint32_t grid, int threads, F &&body) {
 extern "C" __attribute__((visibility("default")))
 int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats /*[4]: candidates, samples, kept, distinct sizes*/) {
     Rng R{seed};
-    struct Cand { uint64_t file, q; int32_t name, endpos; uint32_t flag_size; };
+    struct Cand { uint64_t file, q; uint32_t h2; int32_t name, endpos; uint32_t flag_size; };
     std::vector<Cand> cands;
     uint64_t file = 1000;
     for (int i = 0; i < n_names; ++i) {
         uint64_t q = R.next();
         if (i % 311 == 0) q = ~0ull;                                  // (the padding key of the LDS sort, as a real name)
-        if (i % 313 == 0 && !cands.empty()) q = cands[R.below((uint32_t)cands.size())].q;   // a name that comes back much later
+        uint32_t h2 = (uint32_t)R.next();
+        if (i % 313 == 0 && !cands.empty()) { const Cand &o = cands[R.below((uint32_t)cands.size())]; q = o.q; h2 = o.h2; }   // a name that comes back much later
+        if (i % 47 == 0 && !cands.empty()) { q = cands[R.below((uint32_t)cands.size())].q; h2 = (uint32_t)R.next() | 1u; }  // ANOTHER name with the same 64-bit hash (differs in the second hash)
         const int k = 1 + (int)R.below(R.below(8) == 0 ? 4 : 2);
         const int32_t iv = (int32_t)R.below(50);
         for (int j = 0; j < k; ++j) {
             Cand c;
-            c.q = q; c.name = R.below(5) == 0 ? iv + 1 : iv; c.endpos = 1000 + (int32_t)R.below(400);
+            c.q = q; c.h2 = h2; c.name = R.below(5) == 0 ? iv + 1 : iv; c.endpos = 1000 + (int32_t)R.below(400);
             const uint32_t size = R.below(97) == 0 ? (1u << 20) + R.below(5000) * 1000u : 80u + R.below(700);
             c.flag_size = size | (R.below(4) ? 0x80000000u : 0u);
             c.file = 0; cands.push_back(c);
@@ -53,11 +55,11 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
     for (size_t i = cands.size(); i > 1; --i) std::swap(cands[i - 1], cands[R.below((uint32_t)i)]);
     for (auto &c : cands) { file += 1 + R.below(3); c.file = file; }
     // the literal walk, file order
-    std::map<uint64_t, std::pair<int32_t, int32_t>> open_names;
+    std::map<std::pair<uint64_t, uint32_t>, std::pair<int32_t, int32_t>> open_names;          // a name = (64-bit hash, second hash)
     std::vector<std::pair<uint64_t, uint32_t>> want_samples;
     for (const Cand &c : cands) {
-        auto it = open_names.find(c.q);
-        if (it == open_names.end()) open_names[c.q] = {c.name, c.endpos};
+        auto it = open_names.find({c.q, c.h2});
+        if (it == open_names.end()) open_names[{c.q, c.h2}] = {c.name, c.endpos};
         else if (it->second.first == c.name) {
             if (!(c.flag_size >> 31) || c.endpos <= it->second.second) continue;
             want_samples.push_back({c.file, c.flag_size & 0x7FFFFFFFu});
@@ -71,9 +73,9 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
     // emission order differs from file order
     for (size_t i = cands.size(); i > 1; --i) std::swap(cands[i - 1], cands[R.below((uint32_t)i)]);
     const uint32_t n = (uint32_t)cands.size();
-    std::vector<uint64_t> c_file(n), c_q(n); std::vector<int32_t> c_name(n), c_end(n); std::vector<uint32_t> c_fs(n);
-    for (uint32_t i = 0; i < n; ++i) { c_file[i] = cands[i].file; c_q[i] = cands[i].q; c_name[i] = cands[i].name; c_end[i] = cands[i].endpos; c_fs[i] = cands[i].flag_size; }
-    FragCandidates fc{c_file.data(), c_q.data(), c_name.data(), c_end.data(), c_fs.data(), nullptr, n};
+    std::vector<uint64_t> c_file(n), c_q(n); std::vector<int32_t> c_name(n), c_end(n); std::vector<uint32_t> c_fs(n), c_h2(n);
+    for (uint32_t i = 0; i < n; ++i) { c_file[i] = cands[i].file; c_q[i] = cands[i].q; c_name[i] = cands[i].name; c_end[i] = cands[i].endpos; c_fs[i] = cands[i].flag_size; c_h2[i] = cands[i].h2; }
+    FragCandidates fc{c_file.data(), c_q.data(), c_name.data(), c_end.data(), c_fs.data(), nullptr, n, nullptr, c_h2.data()};
 
     int error = 0;
     const uint32_t nb = std::max<uint32_t>(1u, n / PB_MEAN);
@@ -90,18 +92,18 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
     if (ns != want_samples.size()) return 1002;
     const uint32_t keep = std::min(ns, max_samples);
     uint32_t n_kept = 0;
-    if (keep < ns && keep > 0) {
-        uint64_t prefix = 0; uint32_t want = keep;
+    {   // the select as rsqc_fragsize.hip runs it: planned and decided on the "device", no counters read back in between
+        uint64_t state[2] = {~0ull, ~0ull};
+        std::vector<uint32_t> h(256, 0u);
+        launch(1, 64, [&]() { sample_plan_kernel(&ns, max_samples, state); });
+        const uint32_t ns_bound = n / 2u + 1u;
         for (int shift = 56; shift >= 0; shift -= 8) {
-            std::vector<uint32_t> h(256, 0u);
-            launch(std::min<uint32_t>(1024u, (ns + 255u) / 256u), 256, [&]() { sample_digit_hist_kernel(s_file.data(), ns, shift, prefix, h.data()); });
-            uint32_t d = 0;
-            while (d < 255 && want > h[d]) { want -= h[d]; ++d; }
-            prefix |= (uint64_t)d << shift;
+            launch(std::min<uint32_t>(1024u, (ns_bound + 255u) / 256u), 256, [&]() { sample_digit_hist_kernel(s_file.data(), &ns, shift, state, h.data()); });
+            launch(1, 256, [&]() { sample_digit_pick_kernel(h.data(), shift, state); });
         }
-        launch((ns + 255) / 256, 256, [&]() { sample_keep_kernel(s_file.data(), s_size.data(), ns, prefix, k_file.data(), k_size.data(), &n_kept); });
+        launch((ns_bound + 1023) / 1024, 1024, [&]() { sample_keep_kernel(s_file.data(), s_size.data(), &ns, state, k_file.data(), k_size.data(), &n_kept); });
         if (n_kept != keep) return 1003;
-    } else { k_file = s_file; k_size = s_size; n_kept = keep; }
+    }
     {
         std::vector<std::pair<uint64_t, uint32_t>> got(n_kept);
         for (uint32_t i = 0; i < n_kept; ++i) got[i] = {k_file[i], k_size[i]};
@@ -109,9 +111,9 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
         for (uint32_t i = 0; i < n_kept; ++i) if (got[i] != want_samples[i]) return 1004;
     }
     std::vector<uint32_t> table(SIZE_TABLE, 0u), out_size(SIZE_TABLE), out_count(SIZE_TABLE), big(n + 1);
-    uint32_t n_big = 0, n_out = 0xDEADu;
-    if (n_kept) launch((n_kept + 255) / 256, 256, [&]() { size_hist_kernel(k_size.data(), n_kept, table.data(), big.data(), &n_big); });
-    launch(1, 1024, [&]() { size_hist_compact_kernel(table.data(), out_size.data(), out_count.data(), &n_out); });
+    uint32_t n_big = 0, n_out = 0xDEADu, top = 0;
+    launch(std::min<uint32_t>(512u, (std::min(n / 2u + 1u, max_samples) + 255u) / 256u), 256, [&]() { size_hist_kernel(k_size.data(), &n_kept, table.data(), big.data(), &n_big, &top); });
+    launch(1, 1024, [&]() { size_hist_compact_kernel(table.data(), &top, out_size.data(), out_count.data(), &n_out); });
     std::vector<std::pair<int64_t, uint64_t>> got_hist;
     for (uint32_t i = 0; i < n_out; ++i) got_hist.push_back({(int64_t)out_size[i], (uint64_t)out_count[i]});
     std::sort(big.begin(), big.begin() + n_big);

@@ -91,17 +91,60 @@ def test_interval_index_equals_row_index(oracle_lib, seed):
             _compare(a1, oracle_lib.run_oracle(p, ann, [batch]))
 
 
-def test_exon_outside_its_gene_row_is_refused():
-    """An exon that sticks out of its gene's row: the reference's counts then depend on when the gene leaves its window
-    (src/Metrics.cpp:106-112, "Gene encountered after computing coverage"); the static index cannot follow that, so the
-    annotation is refused by the index builder (rsqc_set_annotation / the CLI: exit 11 with the message) instead of being
-    counted differently."""
-    from rnaseqc_amd.model import Annotation, Batch
-    rows = [dict(contig="c", type="gene", start=100, end=900, strand="+", gene_id="G0"),
+def _outside_rows():
+    return [dict(contig="c", type="gene", start=100, end=900, strand="+", gene_id="G0"),
             dict(contig="c", type="exon", start=100, end=300, strand="+", gene_id="G0", exon_id="E0"),
-            dict(contig="c", type="exon", start=800, end=1000, strand="+", gene_id="G0", exon_id="E1")]      # 100 bases beyond the gene row
-    ann = Annotation.from_rows(["c"], rows)
-    b = Batch.from_records([dict(qname="a", tid=0, pos=150, cigar=[(abi.CIG_M, 50)], flag=99)])
-    with pytest.raises(RuntimeError) as e:
-        hostemu.run(abi.default_params(), ann, b)
-    assert "rc=-1" in str(e.value)
+            dict(contig="c", type="exon", start=800, end=1000, strand="+", gene_id="G0", exon_id="E1"),     # 100 bases beyond the gene row
+            dict(contig="c", type="gene", start=2000, end=3000, strand="-", gene_id="G1"),
+            dict(contig="c", type="exon", start=1900, end=2400, strand="-", gene_id="G1", exon_id="E2"),    # starts before its gene row
+            dict(contig="c", type="exon", start=2600, end=3000, strand="-", gene_id="G1", exon_id="E3")]
+
+
+def _pair(name, p1, p2, n=50):
+    M = abi.CIG_M
+    return [dict(qname=name, tid=0, pos=p1, cigar=[(M, n)], flag=99, mapq=255, nm=0, mpos=p2, mtid=0, isize=p2 + n - p1),
+            dict(qname=name, tid=0, pos=p2, cigar=[(M, n)], flag=147, mapq=255, nm=0, mpos=p1, mtid=0, isize=-(p2 + n - p1))]
+
+
+def test_exon_outside_its_gene_row_is_accepted(oracle_lib):
+    """An exon that sticks out of its gene's row (rounds 3-4 refused such an annotation; the reference runs it).  As long as no
+    record that is counted to the gene STARTS behind the gene row's end -- i.e. the reference has not retired the gene yet
+    (src/Expression.cpp:84-93) -- the static index gives the reference's streamed result in full: counts, fragments, coverage.
+    Records inside the part of E1 that lies beyond the row (they start at or before the row's end), and records in the part of E2
+    in front of its gene row."""
+    from rnaseqc_amd.model import Annotation, Batch
+    ann = Annotation.from_rows(["c"], _outside_rows())
+    recs = _pair("a", 150, 820) + _pair("b", 810, 880, n=100) + _pair("c", 1905, 2650) + _pair("d", 1950, 2300) + _pair("e", 120, 200)
+    recs.sort(key=lambda r: r["pos"])
+    b = Batch.from_records(recs)
+    for kw in (dict(), dict(stranded=abi.STRAND_FORWARD)):
+        p = abi.default_params(coverage_mask=0, **kw)
+        want = oracle_lib.run_oracle(p, ann, [b])
+        a0 = hostemu.run(p, ann, b, mode=0, want_cov=True)
+        a1 = hostemu.run(p, ann, b, mode=1, want_cov=True)
+        _compare(a1, a0); _compare(a1, want)
+        k = hostemu.run_k1(p, ann, b, grid=1, want_cov=True)
+        _compare(k, want); np.testing.assert_array_equal(k.cov, a1.cov)
+    assert int(want.gene_reads.sum()) > 0
+
+
+def test_records_behind_a_retired_gene_row(oracle_lib):
+    """... and where the two differ, stated: a record that STARTS behind the end of G0's row (901 > 900) inside E1.  The reference has
+    retired G0 by then: it still counts the record to the gene and the exon (maps keyed by id), counts its name into a fresh
+    fragment set and ignores its coverage with a warning (src/Metrics.cpp:108-112).  The static index counts the same reads and
+    exon fractions and every classification counter; its fragment count is the number of distinct names over the whole file."""
+    from rnaseqc_amd.model import Annotation, Batch
+    ann = Annotation.from_rows(["c"], _outside_rows())
+    recs = _pair("a", 810, 905, n=60) + _pair("late", 910, 930, n=40)
+    recs.sort(key=lambda r: r["pos"])
+    b = Batch.from_records(recs)
+    p = abi.default_params(coverage_mask=0)
+    want = oracle_lib.run_oracle(p, ann, [b])
+    got = hostemu.run(p, ann, b, mode=1)
+    for i, n in enumerate(abi.COUNTER_NAMES):
+        assert int(got.counters[i]) == int(want.counters[i]), n
+    np.testing.assert_array_equal(got.gene_reads, want.gene_reads)
+    np.testing.assert_array_equal(got.gene_unique, want.gene_unique)
+    np.testing.assert_allclose(got.exon_reads, want.exon_reads, rtol=0, atol=1e-9)
+    assert int(got.gene_reads[0]) == 4 and int(got.gene_fragments[0]) == 2          # two names
+    assert int(want.gene_fragments[0]) == 3                                         # the reference: "a" once before the gene retired, once after

@@ -499,3 +499,68 @@ def test_fasta_gc_vs_oracle(oracle_lib, kw):
     assert_results_match(got, want)
     n = batch.n                                                      # mates of a fragment in different batches
     assert_results_match(engine.run_engine(p, ann, [batch.slice(0, n // 2), batch.slice(n // 2, n)], reference=ref), want)
+
+
+def test_crafted_collision_in_the_pairing_stages(oracle_lib):
+    """tests/test_oracle_semantics.py::_collision_pairing_case through the device with --bed and --fasta: the fragment-size sampler
+    and the fragment GC pairing (rsqc_k5.h) key a name on (qhash, qhash2) like the fragment de-duplication -- three fragments with
+    the reference's sizes and GC bins, not the two of the 64-bit hash alone.  Also through rsqc_submit in two
+    batches (the candidates of the first are retired into the arenas) and for a caller without qhash2."""
+    import copy
+    from tests.test_oracle_semantics import _collision_pairing_case
+    ann, batch, bed, ref = _collision_pairing_case()
+    p = abi.default_params(coverage_mask=0)
+    exact = oracle_lib.run_oracle(p, ann, [batch], bed=bed, reference=ref)            # by the names
+    got = engine.run_engine(p, ann, [batch], bed=bed, reference=ref)
+    assert_results_match(got, exact)
+    assert sorted(int(x) for x in got.fragment_size) == [320, 360, 400]
+    np.testing.assert_array_equal(got.gc_bins, exact.gc_bins)
+    parts = [batch.slice(0, 3), batch.slice(3, batch.n)]
+    split = engine.run_engine(p, ann, parts, bed=bed, reference=ref)
+    assert_results_match(split, exact)
+    np.testing.assert_array_equal(split.gc_bins, exact.gc_bins)
+    narrow = copy.copy(batch); narrow.qname = None; narrow.qname_off = None; narrow.qhash2 = None
+    got64 = engine.run_engine(p, ann, [narrow], bed=bed, reference=ref)
+    want64 = oracle_lib.run_oracle(p, ann, [narrow], bed=bed, reference=ref)
+    assert_results_match(got64, want64)
+    np.testing.assert_array_equal(got64.gc_bins, want64.gc_bins)
+    assert int(got64.fragment_count.sum()) == 2
+
+
+def test_name_identity_is_one_per_pass(oracle_lib):
+    """A pass whose batches disagree about rsqc_batch.qhash2 is refused (RSQC_ERR_ARG): the mates of a fragment would carry two
+    different identities."""
+    import copy
+    from tests.test_oracle_semantics import _collision_case
+    _fx, ann, batch = _collision_case()
+    with_h2, without = batch.slice(0, 3), batch.slice(3, batch.n)
+    without = copy.copy(without); without.qhash2 = None
+    e = engine.Engine(abi.default_params())
+    try:
+        e.set_annotation(ann)
+        e.submit(with_h2)
+        with pytest.raises(Exception):
+            e.submit(without)
+    finally:
+        e.close()
+
+
+def test_exon_outside_its_gene_row_on_the_device(oracle_lib):
+    """tests/test_core_semantics_host.py::test_exon_outside_its_gene_row_is_accepted on the device: rsqc_set_annotation accepts the
+    annotation with a warning in rsqc_last_error (the reference's "Gene encountered after computing coverage") and the result is the
+    reference's streamed one for records that reach the gene before its row retires."""
+    from rnaseqc_amd.model import Annotation, Batch
+    from tests.test_core_semantics_host import _outside_rows, _pair
+    ann = Annotation.from_rows(["c"], _outside_rows())
+    recs = _pair("a", 150, 820) + _pair("b", 810, 880, n=100) + _pair("c", 1905, 2650) + _pair("d", 1950, 2300) + _pair("e", 120, 200)
+    recs.sort(key=lambda r: r["pos"])
+    b = Batch.from_records(recs)
+    p = abi.default_params(coverage_mask=0)
+    e = engine.Engine(p)
+    try:
+        e.set_annotation(ann)
+        assert "outside the row of its gene" in e.last_error()
+        e.submit(b)
+        assert_results_match(e.finalize(), oracle_lib.run_oracle(p, ann, [b]))
+    finally:
+        e.close()

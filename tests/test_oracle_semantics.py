@@ -137,3 +137,48 @@ def test_crafted_qname_hash_collision_fixture(oracle_lib):
     narrow.qhash2 = None
     by_hash64 = oracle_lib.run_oracle(p, ann, [narrow])
     assert int(by_hash64.gene_reads[0]) == 6 and int(by_hash64.gene_fragments[0]) == 2
+
+
+def _collision_pairing_case():
+    """The colliding names of tests/golden/qname_hash_collision.json with their mates INTERLEAVED (a1 b1 a2 b2) inside one BED interval /
+    one exon, plus an ordinary pair: the two QNAME-keyed maps beside the fragment tracker -- fragmentSizeMetrics
+    (src/Expression.cpp:511-531) and the GC branch (:461-474) -- pair a1 with a2 and b1 with b2 when they compare names, and
+    a1 with a2 only (b1 finds a's entry and leaves it, b2 then opens an entry that nobody closes) when `a` and `b` are one key."""
+    import json
+    import os
+    from rnaseqc_amd.model import Annotation, Batch, Bed, Reference
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qname_hash_collision.json")))
+    rows = [dict(contig="c", type="gene", start=100, end=5000, strand="+", gene_id="G0"),
+            dict(contig="c", type="exon", start=100, end=5000, strand="+", gene_id="G0", exon_id="E0")]
+    ann = Annotation.from_rows(["c"], rows)
+    M = abi.CIG_M
+    def pair(name, p1, p2):
+        size = p2 + 100 - p1
+        return [dict(qname=name, tid=0, pos=p1, cigar=[(M, 100)], flag=99, mapq=255, nm=0, mpos=p2, mtid=0, isize=size),
+                dict(qname=name, tid=0, pos=p2, cigar=[(M, 100)], flag=147, mapq=255, nm=0, mpos=p1, mtid=0, isize=-size)]
+    recs = pair(fx["a"], 200, 420) + pair(fx["b"], 300, 560) + pair("ordinary", 1000, 1300)
+    recs.sort(key=lambda r: r["pos"])
+    bed = Bed.from_intervals([0], [99], [5000])
+    seq = np.full(6000, ord("A"), np.uint8); seq[:350] = ord("G")       # G/C only in front: the fragments' GC shares tell the pairings apart
+    ref = Reference(contig=[0], sequence=[seq])
+    return ann, Batch.from_records(recs), bed, ref
+
+
+def test_collision_in_the_pairing_maps(oracle_lib):
+    """Fragment sizes and fragment GC content of the interleaved collision case: by names and by the 96-bit identity three
+    fragments (sizes 320, 360, 400), by the 64-bit hash alone two.  The device keys every QNAME-keyed path on the 96 bits since
+    round 5 (rsqc_k5.h); tests/test_gpu_parity.py runs the same case through it."""
+    import copy
+    ann, batch, bed, ref = _collision_pairing_case()
+    p = abi.default_params(coverage_mask=0)
+    by_name = oracle_lib.run_oracle(p, ann, [batch], bed=bed, reference=ref)
+    assert sorted(int(x) for x in by_name.fragment_size) == [320, 360, 400] and int(by_name.fragment_count.sum()) == 3
+    assert int(by_name.gc_bins[46]) == 1 and int(by_name.gc_bins[13]) == 1 and int(by_name.gc_bins[0]) == 1      # a: [200, 520), b: [300, 660), ordinary
+    hashed = copy.copy(batch); hashed.qname = None; hashed.qname_off = None
+    by96 = oracle_lib.run_oracle(p, ann, [hashed], bed=bed, reference=ref)
+    np.testing.assert_array_equal(by96.fragment_size, by_name.fragment_size); np.testing.assert_array_equal(by96.fragment_count, by_name.fragment_count)
+    np.testing.assert_array_equal(by96.gc_bins, by_name.gc_bins)
+    narrow = copy.copy(hashed); narrow.qhash2 = None
+    by64 = oracle_lib.run_oracle(p, ann, [narrow], bed=bed, reference=ref)
+    assert int(by64.fragment_count.sum()) == 2
+    assert int(by64.gc_bins[75]) == 1 and int(by64.gc_bins[0]) == 2          # b1 closes a1's entry: [200, 400); b2 closes a2's: [420, 660)

@@ -3,6 +3,7 @@
 instruction mix of the tile loop (outermost back edge).  usage: tools/k1_static.py a.s [b.s ...]"""
 import re, sys, collections
 def kernel(lines, frag="classify_ei_kernel"):
+    if any(re.match(r"^_ZN4rsqc\d+" + frag + r"ILb0E", l) for l in lines): frag += "ILb0E"      # (the instance of runs without a BED)
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4rsqc\d+" + frag + r"[A-Za-z0-9_]*:", l))
     end = next(i for i in range(start, len(lines)) if re.match(r"^\.Lfunc_end", lines[i]))
     return lines[start:end + 1]
@@ -29,7 +30,7 @@ def report(path):
         if op.startswith("s_load"): c["s_load"] += 1
     meta = {}
     for i, l in enumerate(lines):
-        if ".amdhsa_kernel" in l and "classify_ei_kernel" in l:
+        if ".amdhsa_kernel" in l and "classify_ei_kernel" in l and ("ILb1E" not in l):
             for x in lines[i:i + 80]:
                 m = re.search(r"\.amdhsa_(next_free_vgpr|next_free_sgpr|private_segment_fixed_size|group_segment_fixed_size)\s+(\d+)", x)
                 if m: meta[m.group(1)] = int(m.group(2))
