@@ -483,7 +483,10 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     }
     // (gene, qname-hash) pairs of this batch: every K1 block owns a private chunk sized for the
     // worst case of its tiles (FAST_SET pairs per record); 1 M extra slots serve the slow path
-    const int grid = (int)std::min<uint64_t>(tiles, (uint64_t)c->k1_grid);
+    // Workgroups: the context's grid for a batch that fills it; a smaller batch gets one round of the chip (256 CUs x 4) or 2048
+    // records per workgroup, whichever is more -- with a workgroup per 256 records (round 4) a 0.8 M-record batch ran three rounds of
+    // workgroups that each initialised and flushed their LDS tables for ONE tile per wave (profiles/r5_kernel_stats_dist_selftest_before.txt)
+    const int grid = (int)std::min<uint64_t>(tiles, std::min<uint64_t>((uint64_t)c->k1_grid, std::max<uint64_t>(1024, u->n / 2048)));
     const uint64_t total_waves = (uint64_t)grid * (RSQC_K1_THREADS / 64);
     const uint64_t per_wave = (((u->n + total_waves - 1) / total_waves) + 63ull) & ~63ull;   // as in the kernel
     const uint64_t chunk_cap = per_wave * (RSQC_K1_THREADS / 64) * FAST_SET;
@@ -1002,6 +1005,11 @@ static int run_finalize_kernels(rsqc_ctx *c) {
         // the side streams start from here (recorded BEFORE the K4 kernels are enqueued on the main stream)
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         // ---- K4 on the main stream: per-gene distinct QNAMEs (the longer chain: enqueued first) ---------------
+        // Several batches still in flight (a host that enqueued its batches faster than the device ran them -- bench.py's resident
+        // batches, one per contig of a sharded run): they are retired into the arena first, so that the fragment stage runs ONE pass
+        // over one dense list instead of one launch per batch over worst-case chunk tables (26 batches: 2.0 ms of frag_local
+        // instead of 1.1).  Costs one wait for the batches' kernels here; a single batch in flight is used in place, uncopied.
+        if (c->pairs_in_flight.size() > 1) { if ((rc = retire_completed(c, true))) return rc; }
         uint64_t pair_bound = c->pair_arena.used;
         for (size_t idx : c->pairs_in_flight) pair_bound += c->pair_pool[idx].pairs_bound;
         {
