@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--host-fed", action="store_true",
                     help="(diagnostic) every step uploads the batch from page-locked host memory through rsqc_submit: the "
                          "PCIe-inclusive rate noted in DESIGN.md; not the bench line")
+    ap.add_argument("--per-contig-batches", action="store_true", help="sharded runs: one resident batch per owned contig (round 4) instead of one batch of file ranges")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="(diagnostic) single process, but through the N > 1 code path: 1-rank RCCL group, finalize_device, "
                          "all_reduce of the device ranges, refresh_results")
@@ -268,6 +269,13 @@ def main():
         full_parts = None
     if args.chr1:
         full_parts = None
+    if (world > 1 or args.dist_selftest) and not args.per_contig_batches and len(parts) > 1:
+        # a shard's contigs are non-adjacent ranges of the file: ONE batch whose segments carry their own file index
+        # (rsqc_batch.seg_file_index), one kernel launch; the order-dependent outputs stay per range (rsqc_shard_info)
+        if full_parts is parts:
+            full_parts = list(parts)
+        from rnaseqc_amd.model import Batch
+        parts = [Batch.concat_ranges(parts)]
     structs = [b.to_struct() for b in parts]
     st = structs[0] if len(structs) == 1 else None
     n_local = sum(b.n for b in parts)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSQC_ABI_VERSION 3
+#define RSQC_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define RSQC_API __attribute__((visibility("default")))
@@ -316,6 +316,14 @@ typedef struct rsqc_batch {
        two rsqc_reset) either all carry the column or none does -- a submit that disagrees with the pass's first batch fails with
        RSQC_ERR_ARG (the two mates of a fragment would otherwise carry (qhash, h2) and (qhash, 0): two names).                  */
     const uint32_t *qhash2;            /* [n]                                  */
+
+    /* optional (may be NULL): the batch is SEVERAL ranges of the file, one per contig segment -- seg_file_index[s] is the file index of
+       segment s's first record (ascending, every range behind the one before and behind everything submitted earlier); the
+       file index of record i of segment s is seg_file_index[s] + (i - seg_start[s]) and file_index_base is ignored.  A GPU
+       that owns a set of NON-ADJACENT contigs of a sorted file (a contig-sharded run) submits them as ONE batch and
+       one kernel launch; the order-dependent outputs are then kept per segment (rsqc_shard_summary lists one entry per segment
+       instead of one per batch) and the context's own "Read Length" is composed from them in file order.  ABI version 4.      */
+    const uint64_t *seg_file_index;    /* [n_seg]                              */
 } rsqc_batch;
 
 /* ---- results ---------------------------------------------------------------- */
@@ -451,7 +459,7 @@ RSQC_API int rsqc_device_vectors(rsqc_ctx *ctx, rsqc_device_range out[3]);
  *   of the union.                                                                                                   */
 typedef struct rsqc_shard_info {
     uint32_t n_batches;
-    const uint64_t *batch_file_index;  /* [n_batches] file_index_base of the batch  */
+    const uint64_t *batch_file_index;  /* [n_batches] file_index_base of the batch (of the SEGMENT for a batch with seg_file_index: one entry per segment) */
     const uint64_t *batch_records;     /* [n_batches]                               */
     const uint32_t *rl_offset;         /* [n_batches + 1]                           */
     const uint32_t *rl_span;           /* ascending inside a batch                  */

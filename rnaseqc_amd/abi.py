@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # error codes
 OK, ERR_ARG, ERR_HIP, ERR_BAD_CIGAR, ERR_CAPACITY, ERR_NO_DEVICE, ERR_EMPTY_MEDIAN, ERR_INPUT = 0, -1, -2, -3, -4, -5, -6, -7
@@ -127,6 +127,7 @@ class BatchStruct(C.Structure):
         ("wide_n_cigar", _P),
         ("qname_off", _P), ("qname", _P),
         ("qhash2", _P),
+        ("seg_file_index", _P),
     ]
 
 

@@ -45,6 +45,8 @@ struct UploadedBatch {
     DevBatch d{};
     std::vector<DevBuf> bufs;
     uint64_t n = 0, n_cigar_total = 0, file_index_base = 0;
+    std::vector<uint64_t> seg_file_index, seg_records;   // a batch of several file ranges (rsqc_batch.seg_file_index): per segment
+    DevBuf rl_seg;                                   // ... and its per-segment Read-Length inputs [3 * n_seg] (armed at every submit)
     bool in_use = false;
     bool pooled = false;           // transient upload: its buffers go back to the context's pool
 };
@@ -182,6 +184,9 @@ struct rsqc_ctx {
     std::vector<UploadedBatch *> resident;
     std::vector<UploadedBatch *> transient;     // owned by submit(), freed at wait()
     uint64_t next_record_base = 0;
+    bool have_ranges = false;                   // a batch of several file ranges was submitted in this pass: Read Length is composed on the host
+    bool have_composed_rl = false; int32_t composed_rl = 0;
+    std::vector<uint32_t> h_rl_arm;
     int name_mode = -1;                         // -1 no batch yet in this pass; 0 batches without qhash2 (64-bit names); 1 with (96-bit names)
     // per submitted batch: file index of its first record and the Read-Length transfer function the KR kernel leaves
     // on the device (rsqc_shard_info)
@@ -330,7 +335,7 @@ int zero_accumulators(rsqc_ctx *c) {
         c->h_gc.assign(RSQC_GC_BINS + 1, 0);
     }
     c->finalized = false;
-    c->next_record_base = 0; c->name_mode = -1;
+    c->next_record_base = 0; c->name_mode = -1; c->have_ranges = false; c->have_composed_rl = false;
     c->batch_file_index.clear(); c->batch_records.clear();
     c->h_rl_offset.clear(); c->h_rl_span.clear(); c->h_rl_state.clear();
     c->h_sample_file.clear(); c->h_sample_size.clear(); c->frag_kept = 0;
@@ -352,6 +357,19 @@ int upload_batch(rsqc_ctx *c, const rsqc_batch *b, UploadedBatch *u, bool pooled
     UP(wide_index, b->n_wide); UP(wide_nm, b->n_wide); UP(wide_l_qseq, b->n_wide); UP(wide_n_cigar, b->n_wide);
     d.qhash2 = nullptr;
     if (b->qhash2) UP(qhash2, b->n);
+    d.seg_file_index = nullptr;
+    u->seg_file_index.clear(); u->seg_records.clear();
+    if (b->seg_file_index && b->n_seg) {
+        UP(seg_file_index, b->n_seg);
+        u->seg_file_index.assign(b->seg_file_index, b->seg_file_index + b->n_seg);
+        for (uint32_t k = 0; k < b->n_seg; ++k) u->seg_records.push_back(b->seg_start[k + 1] - b->seg_start[k]);
+        for (uint32_t k = 0; k + 1 < b->n_seg; ++k)
+            if (u->seg_file_index[k + 1] < u->seg_file_index[k] + u->seg_records[k]) return fail(c, RSQC_ERR_ARG, "rsqc_batch.seg_file_index: the ranges must ascend and not overlap");
+        DevBuf rs = pooled ? take_pooled(c, (size_t)b->n_seg * 12 + 32) : DevBuf{};
+        if (!rs.p) { HIP_TRY(c, hipMalloc(&rs.p, (size_t)b->n_seg * 12 + 32)); rs.bytes = (size_t)b->n_seg * 12 + 32; }
+        u->bufs.push_back(rs); u->rl_seg = rs;           // (owned through bufs)
+        u->file_index_base = u->seg_file_index[0];
+    }
 #undef UP
     return 0;
 }
@@ -549,13 +567,28 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     if (u->file_index_base < c->next_record_base)
         return fail(c, RSQC_ERR_ARG, "batches must be submitted in file order (file_index_base below the end of the previous batch)");
     constexpr size_t kMaxBatches = 1u << 14;
-    if (c->batch_file_index.size() >= kMaxBatches) return fail(c, RSQC_ERR_CAPACITY, "more than 16384 batches in one pass");
+    const bool ranges = !u->seg_file_index.empty();
+    if (ranges && c->dparams.legacy) return fail(c, RSQC_ERR_ARG, "rsqc_batch.seg_file_index is not supported with --legacy");
+    const size_t n_entries = ranges ? u->seg_file_index.size() : 1;          // order-dependent summaries: one per batch, or one per range
+    if (c->batch_file_index.size() + n_entries > kMaxBatches) return fail(c, RSQC_ERR_CAPACITY, "more than 16384 batches / file ranges in one pass");
     if (!c->d_rl_summary.p) { int rc3 = dev_alloc(c, c->d_rl_summary, kMaxBatches * RSQC_RL_SUMMARY_WORDS * 4, false); if (rc3) return rc3; }
     uint32_t *rl_slot = (uint32_t *)c->d_rl_summary.p + c->batch_file_index.size() * RSQC_RL_SUMMARY_WORDS;
-    c->batch_file_index.push_back(u->file_index_base); c->batch_records.push_back(u->n);
     DevBatch d = u->d;
     d.record_base = u->file_index_base;
-    c->next_record_base = u->file_index_base + u->n;
+    acc.rl_seg = nullptr;
+    if (ranges) {
+        for (size_t k = 0; k < n_entries; ++k) { c->batch_file_index.push_back(u->seg_file_index[k]); c->batch_records.push_back(u->seg_records[k]); }
+        c->next_record_base = u->seg_file_index.back() + u->seg_records.back();
+        c->have_ranges = true;
+        // the per-segment Read-Length inputs, armed {max span 0, min l_qseq UINT_MAX, max l_qseq 0}
+        c->h_rl_arm.resize(3 * n_entries);
+        for (size_t k = 0; k < n_entries; ++k) { c->h_rl_arm[3 * k] = 0u; c->h_rl_arm[3 * k + 1] = 0xFFFFFFFFu; c->h_rl_arm[3 * k + 2] = 0u; }
+        HIP_TRY(c, hipMemcpyAsync(u->rl_seg.p, c->h_rl_arm.data(), n_entries * 12, hipMemcpyHostToDevice, c->stream));
+        acc.rl_seg = (uint32_t *)u->rl_seg.p;
+    } else {
+        c->batch_file_index.push_back(u->file_index_base); c->batch_records.push_back(u->n);
+        c->next_record_base = u->file_index_base + u->n;
+    }
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc);
@@ -973,7 +1006,7 @@ static int read_back(rsqc_ctx *c) {
     R.n_genes_listed = L; R.n_exons = E;
     R.gene_reads = u; R.gene_unique = u + G; R.gene_fragments = u + 2 * (size_t)G;
     R.exon_reads = (double *)(H + c->off_exon); R.exon_hit = (uint8_t *)(H + c->off_ehit);
-    R.read_length = *(const int32_t *)(H + c->off_misc + 8);
+    R.read_length = c->have_composed_rl ? c->composed_rl : *(const int32_t *)(H + c->off_misc + 8);
     R.gene_cov_mean = (double *)(H + c->off_gmean); R.gene_cov_std = (double *)(H + c->off_gstd); R.gene_cov_cv = (double *)(H + c->off_gcv);
     R.gene_cov_valid = (uint8_t *)(H + c->off_gvalid); R.exon_cv = (double *)(H + c->off_ecv); R.exon_cv_valid = (uint8_t *)(H + c->off_ecvv);
     R.bias_three = (uint64_t *)(H + c->off_bias3); R.bias_five = (uint64_t *)(H + c->off_bias5);
@@ -1171,6 +1204,18 @@ static void unpack_rl_summaries(rsqc_ctx *c) {           // after the stream has
         c->h_rl_offset[k + 1] = (uint32_t)c->h_rl_span.size();
     }
 }
+// "Read Length" of a pass that held batches of several file ranges: the summaries (one transfer function per batch or range) applied in
+// ascending file index from state 0 -- what read_length_kernel does on the device for a pass of plain batches (src/RNASeQC.cpp:275-278)
+static int32_t compose_read_length(const rsqc_ctx *c) {
+    std::vector<size_t> order(c->batch_file_index.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return c->batch_file_index[x] < c->batch_file_index[y]; });
+    uint32_t r = 0;
+    for (size_t k : order)
+        for (uint32_t j = c->h_rl_offset[k]; j < c->h_rl_offset[k + 1]; ++j)
+            if (c->h_rl_span[j] > r) { r = (uint32_t)c->h_rl_state[j]; break; }     // the first key above the state decides (rsqc_kr.h)
+    return (int32_t)r;
+}
 static void finish_finalize_bookkeeping(rsqc_ctx *c) {
     float ms = 0.f;
     if (c->fin_e0 && hipEventElapsedTime(&ms, c->fin_e0, c->fin_e1) == hipSuccess) c->timing.finalize_ms += ms;
@@ -1179,6 +1224,7 @@ static void finish_finalize_bookkeeping(rsqc_ctx *c) {
     for (auto *u : c->transient) retire_batch(c, u);
     c->transient.clear();
     unpack_rl_summaries(c);
+    if (c->have_ranges) { c->composed_rl = compose_read_length(c); c->have_composed_rl = true; c->results.read_length = c->composed_rl; }
     free_parked(c);
     c->finalized = true;
 }

@@ -33,11 +33,17 @@ struct DevBatch {
     uint32_t n_seg;
     const int32_t *seg_tid;
     const uint64_t *seg_start;
+    const uint64_t *seg_file_index;   // file index of every segment's first record (rsqc_batch.seg_file_index), null = record_base + index
     uint32_t n_wide;
     const uint64_t *wide_index;
     const int32_t *wide_nm, *wide_l_qseq;
     const uint32_t *wide_n_cigar;
 };
+
+// file index of record i (of segment `seg`) of a batch: per segment for a batch of several file ranges
+RSQC_HD uint64_t batch_file_index(const DevBatch &b, uint32_t seg, uint64_t i) {
+    return b.seg_file_index ? b.seg_file_index[seg] + (i - b.seg_start[seg]) : b.record_base + i;
+}
 
 // fragment-size candidates emitted by K1 (only with a BED): one entry per record that passes
 // src/RNASeQC.cpp:372 and the block tests of src/Expression.cpp:490-507
@@ -111,6 +117,7 @@ struct DevAccum {
     uint32_t *tile_span;         // max span per 64-record wave tile (Read-Length fallback scan)
     FragCandidates frag;
     uint32_t *rl_stats;          // [3] batch-level max span, min l_qseq, max l_qseq over eligible records
+    uint32_t *rl_seg;            // [3 * n_seg] the same per contig segment (batches with seg_file_index: a Read-Length function per segment), else null
     int32_t *read_length;
     int *error;
 };

@@ -668,6 +668,16 @@ classify_ei_kernel(K1Args A) {
         seg_next = seg + 1 < b.n_seg ? (uint32_t)b.seg_start[seg + 1] : NONE;
     };
     load_contig();
+    // A batch of several file ranges (rsqc_batch.seg_file_index: the contigs of one shard) keeps the Read-Length inputs per SEGMENT
+    // (DevAccum::rl_seg): the wave hands its lane extremes over whenever it leaves a segment, and at its end.  (Rare path; a batch
+    // without ranges has rl_seg == null and keeps the batch-level extremes below.)
+    auto flush_rl_seg = [&](uint32_t sg) {
+        uint32_t *const rs = k1e_lazy_args()->acc.rl_seg;
+        if (!rs) return;
+        const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
+        if (k1e_first_lane() && wmn != 0xFFFFFFFFu) { atomicMax(&rs[3u * sg], ws); atomicMin(&rs[3u * sg + 1u], wmn); atomicMax(&rs[3u * sg + 2u], wmx); }
+        l_span = 0u; l_lmin = 0xFFFFFFFFu; l_lmax = 0u;
+    };
     uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0, h3 = 0, c3 = 0;   // queue heads and fills (wave-uniform)
     // --bed: the wave's cursor into its contig's BED rows (see phase A): rows [bed_lo, bed_hi), bed_k = first row that starts behind
     // the last tile's end, start of row bed_k - 1 / running max of end up to it / start of row bed_k
@@ -710,6 +720,7 @@ classify_ei_kernel(K1Args A) {
         const uint32_t i = w0 + (uint32_t)l;
         const bool valid = i < wend;
         if (seg_next <= w0) {                               // (the queues were emptied by the tile before the boundary)
+            flush_rl_seg(seg);
             while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) ++seg;
             load_contig();
         }
@@ -752,7 +763,8 @@ classify_ei_kernel(K1Args A) {
             K1E_LANDED(r.l_qseq); K1E_LANDED(r.nm); K1E_LANDED(r.n_cigar);
         }
         r.tid = u_tid;
-        if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; K1E_LANDED(r.tid); }
+        uint32_t my_seg = seg;                                // (the lane's own segment: differs from the wave's only in a boundary tile)
+        if (mixed && valid) { uint32_t s2 = seg; while (s2 + 1 < b.n_seg && b.seg_start[s2 + 1] <= i) ++s2; r.tid = b.seg_tid[s2]; my_seg = s2; K1E_LANDED(r.tid); }
         if (bad_wide) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_ARG);
         const WB lane_on = WS::prim(valid) && !WS::prim(bad_wide != 0u);
         if (!WS::lane(lane_on)) r.n_cigar = 0;
@@ -810,7 +822,7 @@ classify_ei_kernel(K1Args A) {
                 const FragCandidates &fr = q->acc.frag;
                 const uint32_t slot = wg_beg + atomicAdd(&S.T.frags, 1u);       // the workgroup's own region (<= one candidate per record)
                 {
-                    fr.file_index[slot] = q->b.record_base + i; fr.qhash[slot] = r.qhash;
+                    fr.file_index[slot] = batch_file_index(q->b, my_seg, i); fr.qhash[slot] = r.qhash;
                     fr.h2[slot] = q->b.qhash2 ? q->b.qhash2[i] : 0u;                 // (the name is 96 bits on every path that keys on it)
                     fr.name[slot] = name; fr.endpos[slot] = rc.endpos;
                     const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
@@ -824,12 +836,19 @@ classify_ei_kernel(K1Args A) {
         sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
         const WB big_any = WS::prim((rc.bases | rc.mm | rc.blocks) >= (1u << 26));
         {   // Read-Length inputs: per-tile max span + batch-level extremes
-            const uint32_t sp = rc.rl_span;                  // (0 unless the record reaches src/RNASeQC.cpp:275)
+            uint32_t sp = rc.rl_span;                        // (0 unless the record reaches src/RNASeQC.cpp:275)
             const uint32_t wsp = wave_max_u32_full(sp);
             if (k1e_first_lane()) tile_span[w0 >> 6] = wsp;
+            uint32_t lq = (uint32_t)rc.rl_lqseq; bool elig = rc.rl_eligible != 0u;
+            if (mixed) {                                      // a batch of several file ranges keeps these per SEGMENT: the records behind
+                uint32_t *const rs = k1e_lazy_args()->acc.rl_seg;                 // the boundary go to their own segment's slots
+                if (rs && valid && my_seg != seg) {
+                    if (elig) { atomicMax(&rs[3u * my_seg], sp); atomicMin(&rs[3u * my_seg + 1u], lq); atomicMax(&rs[3u * my_seg + 2u], lq); }
+                    sp = 0u; lq = 0u; elig = false;
+                }
+            }
             l_span = sp > l_span ? sp : l_span;
-            const uint32_t lq = (uint32_t)rc.rl_lqseq;
-            l_lmin = (rc.rl_eligible && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
+            l_lmin = (elig && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
         }
         RSQC_MARK(5);
         K1E_STOP(5, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, cnt.vec), (go.m, hq.m, big_any.m))
@@ -948,6 +967,7 @@ classify_ei_kernel(K1Args A) {
         }
     }
     flush_counts();
+    flush_rl_seg(seg);
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
         if (k1e_first_lane()) { atomicMax(&S.T.rl[0], ws); atomicMin(&S.T.rl[1], wmn); atomicMax(&S.T.rl[2], wmx); }

@@ -558,7 +558,7 @@ gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, G
         if (emit) {
             const uint32_t slot = s_base + my;
             if (slot < out.cap) {
-                out.file_index[slot] = b.record_base + i; out.qhash[slot] = qhash; out.row[slot] = row_hit;
+                out.file_index[slot] = batch_file_index(b, find_segment(b, i), i); out.qhash[slot] = qhash; out.row[slot] = row_hit;
                 out.h2[slot] = b.qhash2 ? b.qhash2[i] : 0u;
                 out.endpos[slot] = endpos; out.flag_lq[slot] = flag_lq; out.tid[slot] = tid;
             } else atomicExch(error, RSQC_ERR_CAPACITY);
@@ -653,7 +653,7 @@ void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams
 }
 void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                         const DevAccum &acc, uint32_t *summary) {
-    hipLaunchKernelGGL(read_length_kernel, dim3(1), dim3(64), 0, s, a, p, b, acc, summary);
+    hipLaunchKernelGGL(read_length_kernel, dim3(acc.rl_seg ? b.n_seg : 1u), dim3(64), 0, s, a, p, b, acc, summary);
 }
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error) {
     const uint32_t blocks = (n_genes + 1023u) / 1024u;

@@ -18,11 +18,19 @@ namespace rsqc {
 // (s, g) = (max span, L) -- O(1).  Otherwise one wavefront replays the batch with ALL the walks at once (lane j carries
 // the walk started by p_j and p_{64+j}), opening only the 64-record tiles whose max span can still change something.
 #define RSQC_RL_MAXP 128
+// A batch of several file ranges (rsqc_batch.seg_file_index, DevAccum::rl_seg): one wave PER SEGMENT, each leaves the function of its
+// own record range [seg_start[s], seg_start[s + 1]) in summary slot s; the context's state is then composed on the host from all
+// the slots in file order (rsqc_api.cpp), not here.
 __global__ void __launch_bounds__(64)
 read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint32_t *summary) {
     const int l = lane_id();
-    const uint32_t r_in = (uint32_t)*acc.read_length;
-    const uint32_t Smax = acc.rl_stats[0], Lmin = acc.rl_stats[1], Lmax = acc.rl_stats[2];
+    const bool per_seg = acc.rl_seg != nullptr;
+    const uint32_t sg = per_seg ? blockIdx.x : 0u;
+    const uint64_t rec_lo = per_seg ? b.seg_start[sg] : 0ull, rec_hi = per_seg ? b.seg_start[sg + 1] : b.n;
+    if (per_seg && summary) summary += (size_t)sg * RSQC_RL_SUMMARY_WORDS;
+    const uint32_t r_in = per_seg ? 0u : (uint32_t)*acc.read_length;
+    const uint32_t Smax = per_seg ? acc.rl_seg[3u * sg] : acc.rl_stats[0], Lmin = per_seg ? acc.rl_seg[3u * sg + 1u] : acc.rl_stats[1],
+                   Lmax = per_seg ? acc.rl_seg[3u * sg + 2u] : acc.rl_stats[2];
     uint32_t P = 0;
     uint32_t s0 = 0, s1 = 0, v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;      // lane j: walks j and 64 + j (key span, state)
     bool too_many = false;
@@ -33,11 +41,11 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint3
         if (l == 0) { s0 = Smax; v0 = Lmin; }
     } else {
         uint32_t cur_max = 0u, vmin = 0xFFFFFFFFu;                     // prefix max of span so far; smallest live state
-        const uint64_t n_tiles = (b.n + 63) / 64;
-        for (uint64_t t0 = 0; t0 < n_tiles; t0 += 64) {
+        const uint64_t n_tiles = (rec_hi + 63) / 64;
+        for (uint64_t t0 = (rec_lo / 64) & ~63ull; t0 < n_tiles; t0 += 64) {
             const uint64_t t = t0 + l;
             uint32_t S = 0;
-            if (t < n_tiles) S = acc.tile_span[t];
+            if (t < n_tiles && t >= rec_lo / 64) S = acc.tile_span[t];
             uint64_t need = __ballot(S > (cur_max < vmin ? cur_max : vmin));
             while (need) {
                 const int tl = __ffsll((unsigned long long)need) - 1;
@@ -46,9 +54,9 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint3
                 if (!(St > (cur_max < vmin ? cur_max : vmin))) continue;   // the thresholds moved since the ballot
                 const uint64_t i = (t0 + tl) * 64 + l;                 // replay the tile's 64 records in order
                 uint32_t span = 0, lq = 0; bool elig = false;
-                if (i < b.n) {
+                if (i >= rec_lo && i < rec_hi) {
                     Record rec;
-                    if (load_record(b, i, find_segment(b, (t0 + tl) * 64), rec)) {
+                    if (load_record(b, i, per_seg ? sg : find_segment(b, (t0 + tl) * 64), rec)) {
                         RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
                         gate_cascade(a, p, rec, rc, hq, aligned, B);
                         elig = rc.rl_eligible != 0; span = rc.rl_span; lq = (uint32_t)rc.rl_lqseq;
@@ -90,9 +98,9 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint3
         if ((uint32_t)l < P) { summary[2 + 2 * l] = s0; summary[3 + 2 * l] = v0; }
         if (64u + (uint32_t)l < P) { summary[2 + 2 * (64 + l)] = s1; summary[3 + 2 * (64 + l)] = v1; }
     }
-    if (l == 0) {
-        if (too_many) atomicExch(acc.error, RSQC_ERR_CAPACITY);
-        *acc.read_length = (int32_t)r;
+    if (l == 0 && too_many) atomicExch(acc.error, RSQC_ERR_CAPACITY);
+    if (l == 0 && sg == 0u) {
+        if (!per_seg) *acc.read_length = (int32_t)r;
         acc.rl_stats[0] = 0u; acc.rl_stats[1] = 0xFFFFFFFFu; acc.rl_stats[2] = 0u;    // ready for the next batch
         acc.ovf_count[1] += *acc.ovf_count;   // records the general kernel took since the last reset (rsqc_timing.slow_records)
         *acc.ovf_count = 0u;                  // (the slow kernel, this batch's only reader, ran before this kernel)

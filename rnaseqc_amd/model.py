@@ -258,6 +258,7 @@ class Batch:
     qname: np.ndarray | None = None
     file_index_base: int = 0
     qhash2: np.ndarray | None = None      # rsqc_batch.qhash2 (second name hash, uint32 per record); None = the 64-bit identity
+    seg_file_index: np.ndarray | None = None   # rsqc_batch.seg_file_index: the batch is several file ranges, one per segment (uint64 per segment)
 
     _DT = dict(pos=np.int32, mpos=np.int32, isize=np.int32, qhash=np.uint64, cigar_off=np.uint32,
                flag=np.uint16, l_qseq=np.uint16, mapq=np.uint8, nm=np.uint8, tagbits=np.uint8,
@@ -307,6 +308,10 @@ class Batch:
         if self.qhash2 is not None:
             self.qhash2 = np.ascontiguousarray(self.qhash2, dtype=np.uint32)
             s.qhash2 = abi.ptr(self.qhash2)
+        if self.seg_file_index is not None:
+            self.seg_file_index = np.ascontiguousarray(self.seg_file_index, dtype=np.uint64)
+            assert len(self.seg_file_index) == len(self.seg_tid)
+            s.seg_file_index = abi.ptr(self.seg_file_index)
         return s
 
     # ---------------------------------------------------------------- builders
@@ -411,6 +416,27 @@ class Batch:
                      wide_nm=cat("wide_nm"), wide_l_qseq=cat("wide_l_qseq"), wide_n_cigar=cat("wide_n_cigar"),
                      file_index_base=parts[0].file_index_base,
                      qhash2=(np.concatenate([p.qhash2 for p in parts]) if all(p.qhash2 is not None for p in parts) else None), **kw)
+
+    @staticmethod
+    def concat_ranges(parts: Sequence["Batch"]) -> "Batch":
+        """Batches that are NON-ADJACENT ranges of one file (the contigs a GPU owns in a contig-sharded run), in file order, as ONE
+        batch: every segment keeps the file index of its first record (rsqc_batch.seg_file_index), so that one kernel launch
+        serves all of them and the order-dependent outputs are still kept per range.  A part's own file_index_base (+ the offset
+        of the segment inside the part) is the segment's index."""
+        parts = [p for p in parts if p.n]
+        one = Batch.concat(parts) if len(parts) > 1 else parts[0]
+        idx = []
+        for p in parts:
+            for s in range(len(p.seg_tid)):
+                if int(p.seg_start[s + 1]) > int(p.seg_start[s]):
+                    idx.append(int(p.file_index_base) + int(p.seg_start[s]))
+        if len(idx) != len(one.seg_tid):
+            raise ValueError("concat_ranges: adjacent parts share a contig (segments were merged)")
+        import copy
+        one = copy.copy(one)
+        one.seg_file_index = np.asarray(idx, np.uint64)
+        one.file_index_base = idx[0] if idx else 0
+        return one
 
     def take(self, idx) -> "Batch":
         """The records idx[0], idx[1], ... as a new batch (any order, e.g. a coordinate sort of a concatenation)."""

@@ -34,7 +34,7 @@ def _inputs():
     return ann, batch, bed
 
 
-def _shards(batch, rank_of, rank, world):
+def _shards(batch, rank_of, rank, world, split=True):
     """The records of this rank's contigs as batches that are contiguous file ranges (one per run of records)."""
     tid = batch.tid_per_record()
     mine = np.isin(tid, np.flatnonzero(rank_of == rank))
@@ -46,7 +46,7 @@ def _shards(batch, rank_of, rank, world):
     for r in runs:                            # split long runs further: several batches per contig
         lo, hi = int(r[0]), int(r[-1]) + 1
         mid = lo + (hi - lo) // 3
-        parts += [batch.slice(lo, mid), batch.slice(mid, hi)] if mid > lo else [batch.slice(lo, hi)]
+        parts += [batch.slice(lo, mid), batch.slice(mid, hi)] if (split and mid > lo) else [batch.slice(lo, hi)]
     return parts
 
 
@@ -91,6 +91,10 @@ def _worker(rank, world, port, out_dir, use_gpu):
         from rnaseqc_amd import engine
         e = engine.Engine(p)
         e.set_annotation(ann, owned); e.set_bed(bed)
+        if use_gpu == 2:                          # the rank's file ranges as ONE batch (rsqc_batch.seg_file_index): one kernel launch
+            from rnaseqc_amd.model import Batch
+            parts = [Batch.concat_ranges(_shards(batch, rank_of, rank, world, split=False))]
+            assert len(parts[0].seg_file_index) >= 2
         for b in parts:
             e.submit(b)
         local = e.finalize()
@@ -125,6 +129,15 @@ def test_two_rank_contig_sharding_gloo(tmp_path, oracle_lib):
 def test_two_rank_contig_sharding_hip(tmp_path, oracle_lib):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+@pytest.mark.gpu
+def test_two_rank_contig_sharding_hip_one_batch_of_ranges(tmp_path, oracle_lib):
+    """The same with every rank's contigs submitted as ONE batch of non-adjacent file ranges: per-range
+    Read-Length functions and file indices, one launch per rank."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), 2), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
 
 

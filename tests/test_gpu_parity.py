@@ -564,3 +564,37 @@ def test_exon_outside_its_gene_row_on_the_device(oracle_lib):
         assert_results_match(e.finalize(), oracle_lib.run_oracle(p, ann, [b]))
     finally:
         e.close()
+
+
+def test_one_batch_of_file_ranges_equals_one_batch_per_range(oracle_lib):
+    """rsqc_batch.seg_file_index: the non-adjacent contigs of a shard as ONE batch give the results AND the shard summary (per-range
+    Read-Length functions, kept fragment samples) of the same ranges submitted one batch each; mixed read lengths, --bed with a
+    cut-off, a range that is a contig's unmapped tail."""
+    from rnaseqc_amd.model import Batch
+    from tests.test_distributed_gloo import _inputs, _shards, CONTIGS
+    ann, batch, bed = _inputs()
+    rank_of = np.array([0, 1, 0, 1])
+    owned = np.array([1, 0, 1, 0], np.uint8)
+    runs = _shards(batch, rank_of, 0, 2, split=False)
+    assert len(runs) == 2
+    p = abi.default_params(fragment_samples=150)
+    out = []
+    for parts in (runs, [Batch.concat_ranges(runs)]):
+        e = engine.Engine(p)
+        try:
+            e.set_annotation(ann, owned); e.set_bed(bed)
+            for b in parts:
+                e.submit(b)
+            r = e.finalize(); si = e.shard_summary()
+            out.append((r, si))
+        finally:
+            e.close()
+    (ra, sa), (rb, sb) = out
+    assert_results_match(rb, ra)
+    assert rb.read_length == ra.read_length
+    for f in ("batch_file_index", "batch_records", "rl_offset", "rl_span", "rl_state"):
+        np.testing.assert_array_equal(getattr(sb, f), getattr(sa, f), err_msg=f)
+    oa = np.argsort(sa.sample_file_index); ob = np.argsort(sb.sample_file_index)
+    np.testing.assert_array_equal(sb.sample_file_index[ob], sa.sample_file_index[oa])
+    np.testing.assert_array_equal(sb.sample_size[ob], sa.sample_size[oa])
+    assert len(set(int(x) for x in sa.rl_state)) > 1
