@@ -192,7 +192,7 @@ namespace rsqc {
 // device scratch of the pairing steps (rsqc_fragsize.hip), kept by the context between passes (allocation and release synchronise
 // the device): k0 / v0 samples (file index, size), k1 / v1 the kept ones, v2 candidate indices bucket by bucket, tmp the bucket
 // counts / offsets / cursors, count the control words, table / out_* the size histogram and its compacted (size, count) pairs
-struct SortScratch { void *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *tmp = nullptr, *count = nullptr;
+struct SortScratch { void *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *v3 = nullptr, *tmp = nullptr, *count = nullptr;
                      size_t cap_n = 0, tmp_bytes = 0; uint32_t *table = nullptr, *out_size = nullptr, *out_count = nullptr; };
 void free_sort_scratch(SortScratch &s);
 // leaves the kept samples (first max_samples by file index, unordered) on the device: S.k1 = file index, S.v1 = size, n_kept of them

@@ -42,27 +42,28 @@ constexpr size_t CTL_WORDS = 8 + 256 + 4;
 constexpr uint32_t PAIRS_FIRST = 2048;        // (size, count) pairs read back with the control words; more only if there are more
 int grow_scratch(SortScratch &S, uint32_t n) {
     if (n <= S.cap_n) return 0;
-    for (void **q : {&S.k0, &S.k1, &S.v0, &S.v1, &S.v2, &S.tmp}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (void **q : {&S.k0, &S.k1, &S.v0, &S.v1, &S.v2, &S.v3, &S.tmp}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     S.cap_n = 0;
     const size_t cap = (size_t)n + n / 4 + 1024;
     const size_t buckets = cap / PB_MEAN + 2;
     // k0 samples' file index, k1 kept file index, v0 samples' size, v1 kept size, v2 candidate indices by bucket,
     // tmp: bucket counts | offsets | cursors (3 x (buckets + 1) words)
     if (hipMalloc(&S.k0, cap * 8) != hipSuccess || hipMalloc(&S.k1, cap * 8) != hipSuccess || hipMalloc(&S.v0, cap * 4) != hipSuccess ||
-        hipMalloc(&S.v1, cap * 4) != hipSuccess || hipMalloc(&S.v2, cap * 4) != hipSuccess || hipMalloc(&S.tmp, 3 * (buckets + 1) * 4) != hipSuccess) return RSQC_ERR_HIP;
-    S.tmp_bytes = 3 * (buckets + 1) * 4;
+        hipMalloc(&S.v1, cap * 4) != hipSuccess || hipMalloc(&S.v2, cap * 4) != hipSuccess || hipMalloc(&S.v3, 2 * cap * 4 + 64) != hipSuccess ||
+        hipMalloc(&S.tmp, (3 * (buckets + 1) + PB_BIG_MAX + 1) * 4) != hipSuccess) return RSQC_ERR_HIP;     // v3: the in-memory sort of oversize buckets (2 x their candidates)
+    S.tmp_bytes = (3 * (buckets + 1) + PB_BIG_MAX + 1) * 4;
     S.cap_n = cap;
     return 0;
 }
-struct Buckets { uint32_t n_buckets; uint32_t *count, *off, *cursor; };
+struct Buckets { uint32_t n_buckets; uint32_t *count, *off, *cursor, *big; };
 // partitions `n` candidates by name hash: S.v2 = candidate indices bucket by bucket, offsets in the returned arrays
 int partition_by_name(hipStream_t stream, const uint64_t *qhash, uint32_t n, SortScratch &S, int *d_error, Buckets &B) {
     B.n_buckets = std::max<uint32_t>(1u, n / PB_MEAN);
-    B.count = (uint32_t *)S.tmp; B.off = B.count + (B.n_buckets + 1); B.cursor = B.off + (B.n_buckets + 1);
-    if (hipMemsetAsync(B.count, 0, (size_t)(B.n_buckets + 1) * 4, stream) != hipSuccess) return RSQC_ERR_HIP;
+    B.count = (uint32_t *)S.tmp; B.off = B.count + (B.n_buckets + 1); B.cursor = B.off + (B.n_buckets + 1); B.big = B.cursor + (B.n_buckets + 1);
+    if (hipMemsetAsync(B.count, 0, (size_t)(B.n_buckets + 1) * 4, stream) != hipSuccess || hipMemsetAsync(B.big, 0, 4, stream) != hipSuccess) return RSQC_ERR_HIP;
     const int T = 256, G = (int)((n + T - 1) / T);
     hipLaunchKernelGGL(pair_bucket_count_kernel, dim3(G), dim3(T), 0, stream, qhash, n, B.n_buckets, B.count);
-    hipLaunchKernelGGL(pair_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, B.count, B.n_buckets, B.off, B.cursor, d_error);
+    hipLaunchKernelGGL(pair_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, B.count, B.n_buckets, B.off, B.cursor, B.big, d_error);
     hipLaunchKernelGGL(pair_bucket_scatter_kernel, dim3(G), dim3(T), 0, stream, qhash, n, B.n_buckets, B.cursor, (uint32_t *)S.v2);
     return hipGetLastError() == hipSuccess ? 0 : RSQC_ERR_HIP;
 }
@@ -90,6 +91,8 @@ int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, 
     Buckets B;
     if (partition_by_name(stream, c.qhash, n, S, d_error, B)) return RSQC_ERR_HIP;
     hipLaunchKernelGGL(frag_replay_kernel, dim3(B.n_buckets), dim3(PB_THREADS), 0, stream, c, B.off, (const uint32_t *)S.v2, s_file, s_size, ctl + 0);
+    // (the buckets the LDS sort cannot hold -- none with ordinary read names: the kernel then finds an empty list)
+    hipLaunchKernelGGL(frag_replay_big_kernel, dim3(64), dim3(1024), 0, stream, c, B.off, (const uint32_t *)S.v2, B.big, (uint32_t *)S.v3, s_file, s_size, ctl + 0);
     // (3) the first max_samples samples in file order: a radix select of the sample of rank min(samples, max_samples) among the file
     //     indices, decided ON THE DEVICE digit by digit (round 4 read 256 counters back per digit and the sample count before: nine
     //     synchronous copies per pass); with fewer samples than the limit it selects the last one and everything is kept
@@ -138,7 +141,7 @@ int run_fragment_sizes(hipStream_t stream, const FragCandidates &c, uint32_t n, 
 }
 
 void free_sort_scratch(SortScratch &s) {
-    for (void *p : {s.k0, s.k1, s.v0, s.v1, s.v2, s.tmp, s.count, (void *)s.table, (void *)s.out_size, (void *)s.out_count}) if (p) (void)hipFree(p);
+    for (void *p : {s.k0, s.k1, s.v0, s.v1, s.v2, s.v3, s.tmp, s.count, (void *)s.table, (void *)s.out_size, (void *)s.out_count}) if (p) (void)hipFree(p);
     s = SortScratch{};
 }
 
@@ -148,6 +151,7 @@ int run_gc_content(hipStream_t stream, const GcCandidates &c, uint32_t n, const 
     Buckets B;
     if (partition_by_name(stream, c.qhash, n, S, d_error, B)) return RSQC_ERR_HIP;
     hipLaunchKernelGGL(gc_replay_kernel, dim3(B.n_buckets), dim3(PB_THREADS), 0, stream, c, B.off, (const uint32_t *)S.v2, R, bins);
+    hipLaunchKernelGGL(gc_replay_big_kernel, dim3(64), dim3(1024), 0, stream, c, B.off, (const uint32_t *)S.v2, B.big, (uint32_t *)S.v3, R, bins);
     return hipGetLastError() == hipSuccess ? 0 : RSQC_ERR_HIP;
 }
 

@@ -6,7 +6,7 @@
 namespace rsqc {
 
 constexpr uint32_t PB_MEAN = 512;            // candidates per bucket on average (the name hashes are fmix64 outputs: Poisson)
-constexpr uint32_t PB_CAP = 2048;            // LDS slots of the per-bucket sort; a fuller bucket reports RSQC_ERR_CAPACITY
+constexpr uint32_t PB_CAP = 2048;            // LDS slots of the per-bucket sort; a fuller bucket is listed and sorted in memory (pair_bucket_big_*)
 constexpr int PB_THREADS = 256;
 constexpr uint32_t SIZE_TABLE = 1u << 20;    // direct histogram of |isize| below this; larger values are listed
 
@@ -18,11 +18,18 @@ __global__ void pair_bucket_count_kernel(const uint64_t *qhash, uint32_t n, uint
     if (i < n) atomicAdd(&count[pair_bucket_of(qhash[i], n_buckets)], 1u);
 }
 // exclusive sums of the bucket counts (one workgroup; n_buckets is a few thousand); off[n_buckets] = n; cursors = offsets
-__global__ void __launch_bounds__(1024) pair_bucket_scan_kernel(const uint32_t *count, uint32_t n_buckets, uint32_t *off, uint32_t *cursor, int *error) {
+// Buckets fuller than the LDS sort are LISTED (big[0] = how many, big[1 ..] = which; round 4 failed the run on the first one): all
+// records of one QNAME share a bucket, so a file whose reads carry one name -- stripped or constant names -- is one bucket;
+// pair_bucket_big sorts those in memory.
+constexpr uint32_t PB_BIG_MAX = 1024;        // listed buckets; more of them (a caller's degenerate hash) is RSQC_ERR_CAPACITY
+__global__ void __launch_bounds__(1024) pair_bucket_scan_kernel(const uint32_t *count, uint32_t n_buckets, uint32_t *off, uint32_t *cursor, uint32_t *big, int *error) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (n_buckets + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < n_buckets ? lo + per : n_buckets;
     uint32_t s = 0;
-    for (uint32_t b = lo; b < hi; ++b) { s += count[b]; if (count[b] > PB_CAP) atomicExch(error, RSQC_ERR_CAPACITY); }
+    for (uint32_t b = lo; b < hi; ++b) {
+        s += count[b];
+        if (count[b] > PB_CAP) { const uint32_t at = atomicAdd(&big[0], 1u); if (at < PB_BIG_MAX) big[1u + at] = b; else atomicExch(error, RSQC_ERR_CAPACITY); }
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     for (uint32_t o = 1; o < 1024u; o <<= 1) {
@@ -70,6 +77,78 @@ __device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint
             __syncthreads();
         }
     return m;
+}
+
+// A listed (oversize) bucket, by ONE workgroup of 1024: its candidate indices are sorted in memory by (name hash, second hash, file
+// index) -- a bitonic network over `idx` (the bucket's slice of the scatter, padded to a power of two with 0xFFFFFFFF = larger than
+// any key) -- and `replay(j, m, key_of)` then runs for every first record of a name as in the LDS path.  Slow and exact: the
+// network is log^2 stages of memory gathers, a name with millions of records is replayed by one lane as the reference walks it.
+template <class Cand>
+__device__ __forceinline__ bool pb_less(const Cand &c, uint32_t a, uint32_t b) {           // candidate a sorts before candidate b
+    if (b == 0xFFFFFFFFu) return a != 0xFFFFFFFFu;
+    if (a == 0xFFFFFFFFu) return false;
+    const uint64_t qa = c.qhash[a], qb = c.qhash[b];
+    if (qa != qb) return qa < qb;
+    const uint32_t ha = c.h2 ? c.h2[a] : 0u, hb = c.h2 ? c.h2[b] : 0u;
+    if (ha != hb) return ha < hb;
+    return c.file_index[a] < c.file_index[b];
+}
+template <class Cand>
+__device__ __forceinline__ void pair_bucket_big_sort(const Cand &c, uint32_t *idx, uint32_t slots) {
+    for (uint32_t k = 2; k <= slots; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint32_t a = idx[i], b = idx[x];
+                    const bool up = (i & k) == 0;
+                    if (pb_less(c, b, a) == up) { idx[i] = b; idx[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+// scratch `big_idx`: room for 2 x (candidates) indices; listed bucket t sorts at big_idx + 2 * off[bucket]
+template <class Cand>
+__device__ __forceinline__ uint32_t pair_bucket_big_prepare(const Cand &c, const uint32_t *off, const uint32_t *perm, const uint32_t *big, uint32_t t, uint32_t *big_idx, uint32_t **sorted) {
+    const uint32_t bucket = big[1u + t], lo = off[bucket], m = off[bucket + 1] - lo;
+    uint32_t slots = 2;
+    while (slots < m) slots <<= 1;
+    uint32_t *idx = big_idx + 2u * (size_t)lo;
+    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) idx[i] = i < m ? perm[lo + i] : 0xFFFFFFFFu;
+    __syncthreads();
+    pair_bucket_big_sort(c, idx, slots);
+    *sorted = idx;
+    return m;
+}
+__global__ void __launch_bounds__(1024)
+frag_replay_big_kernel(const FragCandidates c, const uint32_t *off, const uint32_t *perm, const uint32_t *big, uint32_t *big_idx,
+                       uint64_t *sample_file, uint32_t *sample_size, uint32_t *n_samples) {
+    const uint32_t n_big = big[0] < PB_BIG_MAX ? big[0] : PB_BIG_MAX;
+    for (uint32_t t = blockIdx.x; t < n_big; t += gridDim.x) {
+        uint32_t *idx;
+        const uint32_t m = pair_bucket_big_prepare(c, off, perm, big, t, big_idx, &idx);
+        for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) {
+            const uint32_t e0 = idx[j];
+            const uint64_t q = c.qhash[e0]; const uint32_t h = c.h2 ? c.h2[e0] : 0u;
+            if (j > 0) { const uint32_t ep = idx[j - 1]; if (c.qhash[ep] == q && (c.h2 ? c.h2[ep] : 0u) == h) continue; }
+            bool pending = false; int32_t p_name = 0, p_end = 0;
+            for (uint32_t k = j; k < m; ++k) {
+                const uint32_t e = idx[k];
+                if (c.qhash[e] != q || (c.h2 ? c.h2[e] : 0u) != h) break;
+                const int32_t name = c.name[e], endpos = c.endpos[e];
+                if (!pending) { pending = true; p_name = name; p_end = endpos; }
+                else if (name == p_name) {
+                    const uint32_t fs = c.flag_size[e];
+                    if (!(fs >> 31) || endpos <= p_end) continue;
+                    const uint32_t slot = atomicAdd(n_samples, 1u);
+                    sample_file[slot] = c.file_index[e]; sample_size[slot] = fs & 0x7FFFFFFFu;
+                    pending = false;
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // src/Expression.cpp:511-538 for every name of the bucket.  A name yields at most one sample per two of its records: the samples of
@@ -143,6 +222,42 @@ gc_replay_kernel(const GcCandidates c, const uint32_t *off, const uint32_t *perm
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += PB_THREADS) if (hist[i]) atomicAdd(&bins[i], (unsigned long long)hist[i]);
+}
+// the same for the listed (oversize) buckets, sorted in memory (pair_bucket_big_sort)
+__global__ void __launch_bounds__(1024)
+gc_replay_big_kernel(const GcCandidates c, const uint32_t *off, const uint32_t *perm, const uint32_t *big, uint32_t *big_idx, const DevReference R, unsigned long long *bins) {
+    const uint32_t n_big = big[0] < PB_BIG_MAX ? big[0] : PB_BIG_MAX;
+    for (uint32_t t = blockIdx.x; t < n_big; t += gridDim.x) {
+        uint32_t *idx;
+        const uint32_t m = pair_bucket_big_prepare(c, off, perm, big, t, big_idx, &idx);
+        for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) {
+            const uint32_t e0 = idx[j];
+            const uint64_t q = c.qhash[e0]; const uint32_t h = c.h2 ? c.h2[e0] : 0u;
+            if (j > 0) { const uint32_t ep = idx[j - 1]; if (c.qhash[ep] == q && (c.h2 ? c.h2[ep] : 0u) == h) continue; }
+            bool pending = false; uint32_t p_row = 0; int32_t p_end = 0;
+            for (uint32_t k = j; k < m; ++k) {
+                const uint32_t e = idx[k];
+                if (c.qhash[e] != q || (c.h2 ? c.h2[e] : 0u) != h) break;
+                const uint32_t row = c.row[e]; const int32_t endpos = c.endpos[e];
+                if (!pending) { pending = true; p_row = row; p_end = endpos; }
+                else if (row == p_row) {
+                    const uint32_t fl = c.flag_lq[e];
+                    if (endpos <= p_end || !(fl >> 31)) continue;
+                    pending = false;
+                    const int tid = c.tid[e];
+                    const int64_t L = (int64_t)R.length[tid];
+                    int64_t s2 = (int64_t)p_end - (int64_t)(fl & 0x7FFFFFFFu), en = endpos;
+                    if (s2 < 0 || s2 >= L) continue;
+                    if (en > L) en = L;
+                    if (en <= s2) continue;
+                    const double v = gc_value(gc_count(R, tid, s2, en), (uint64_t)(en - s2));
+                    const unsigned int bin = (unsigned int)(v * 100.0);
+                    atomicAdd(&bins[bin < RSQC_GC_BINS ? bin : RSQC_GC_BINS], 1ull);
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 #endif

@@ -162,11 +162,11 @@ def build_k5():
     return _K5SO
 
 
-def run_k5(seed, n_names, max_samples):
+def run_k5(seed, n_names, max_samples, hot=0):
     """The fragment-size KERNELS (rsqc_k5.h) on the 64-lane fiber emulation against a literal std::map walk in file order.
-    Returns (rc, candidates, samples, kept, distinct sizes)."""
+    hot: records of one extra name (a bucket beyond the LDS sort).  Returns (rc, candidates, samples, kept, distinct sizes, listed buckets)."""
     lib = C.CDLL(build_k5())
-    lib.k5emu_run.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
-    stats = np.zeros(4, np.uint64)
-    rc = lib.k5emu_run(seed, n_names, max_samples, stats.ctypes.data)
+    lib.k5emu_run.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+    stats = np.zeros(5, np.uint64)
+    rc = lib.k5emu_run(seed, n_names, max_samples, hot, stats.ctypes.data)
     return (rc,) + tuple(int(x) for x in stats)

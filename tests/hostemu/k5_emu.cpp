@@ -30,7 +30,7 @@ template <class F> void launch(uint32_t grid, int threads, F &&body) {
 // direct table), emitted in a shuffled order like K1's atomic slots.  Returns 0 when samples kept, their (size, count) pairs and
 // the kept (file index, size) set equal the literal walk; 1000 + k for check k; -code for a device error.
 extern "C" __attribute__((visibility("default")))
-int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats /*[4]: candidates, samples, kept, distinct sizes*/) {
+int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, int hot /* records of ONE extra name: a bucket beyond the LDS sort */, uint64_t *stats /*[5]: candidates, samples, kept, distinct sizes, listed buckets*/) {
     Rng R{seed};
     struct Cand { uint64_t file, q; uint32_t h2; int32_t name, endpos; uint32_t flag_size; };
     std::vector<Cand> cands;
@@ -49,6 +49,13 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
             const uint32_t size = R.below(97) == 0 ? (1u << 20) + R.below(5000) * 1000u : 80u + R.below(700);
             c.flag_size = size | (R.below(4) ? 0x80000000u : 0u);
             c.file = 0; cands.push_back(c);
+        }
+    }
+    if (hot > 0) {                                                    // one name with `hot` records (stripped / constant read names): all in one bucket
+        const uint64_t q = R.next(); const uint32_t h2 = (uint32_t)R.next();
+        for (int j = 0; j < hot; ++j) {
+            Cand c; c.q = q; c.h2 = h2; c.name = (int32_t)R.below(3); c.endpos = 1000 + (int32_t)R.below(400);
+            c.flag_size = (80u + R.below(700)) | (R.below(4) ? 0x80000000u : 0u); c.file = 0; cands.push_back(c);
         }
     }
     // file order = a shuffle of the candidates (mates of a name end up a random distance apart); indices are unique and sparse
@@ -79,16 +86,18 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
 
     int error = 0;
     const uint32_t nb = std::max<uint32_t>(1u, n / PB_MEAN);
-    std::vector<uint32_t> count(nb + 1, 0u), off(nb + 1, 0xDEADu), cursor(nb + 1, 0xDEADu), perm(n, 0xFFFFFFFFu);
+    std::vector<uint32_t> count(nb + 1, 0u), off(nb + 1, 0xDEADu), cursor(nb + 1, 0xDEADu), perm(n, 0xFFFFFFFFu), big_list(PB_BIG_MAX + 1, 0u), big_idx(2 * (size_t)n + 16, 0xDEADu);
     const uint32_t G = (n + 255) / 256;
     launch(G, 256, [&]() { pair_bucket_count_kernel(c_q.data(), n, nb, count.data()); });
-    launch(1, 1024, [&]() { pair_bucket_scan_kernel(count.data(), nb, off.data(), cursor.data(), &error); });
+    launch(1, 1024, [&]() { pair_bucket_scan_kernel(count.data(), nb, off.data(), cursor.data(), big_list.data(), &error); });
     launch(G, 256, [&]() { pair_bucket_scatter_kernel(c_q.data(), n, nb, cursor.data(), perm.data()); });
     if (error) return -error;
     if (off[nb] != n) return 1001;
     std::vector<uint64_t> s_file(n + 1), k_file(n + 1); std::vector<uint32_t> s_size(n + 1), k_size(n + 1);
     uint32_t ns = 0;
     launch(nb, PB_THREADS, [&]() { frag_replay_kernel(fc, off.data(), perm.data(), s_file.data(), s_size.data(), &ns); });
+    launch(3, 1024, [&]() { frag_replay_big_kernel(fc, off.data(), perm.data(), big_list.data(), big_idx.data(), s_file.data(), s_size.data(), &ns); });
+    if ((hot > (int)PB_CAP) != (big_list[0] > 0)) return 1007;
     if (ns != want_samples.size()) return 1002;
     const uint32_t keep = std::min(ns, max_samples);
     uint32_t n_kept = 0;
@@ -121,6 +130,6 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, uint64_t *stats 
     if (got_hist.size() != want_hist.size()) return 1005;
     size_t at = 0;
     for (auto &kv : want_hist) { if (got_hist[at].first != kv.first || got_hist[at].second != kv.second) return 1006; ++at; }
-    stats[0] = n; stats[1] = ns; stats[2] = n_kept; stats[3] = got_hist.size();
+    stats[0] = n; stats[1] = ns; stats[2] = n_kept; stats[3] = got_hist.size(); stats[4] = big_list[0];
     return 0;
 }

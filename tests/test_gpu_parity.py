@@ -598,3 +598,32 @@ def test_one_batch_of_file_ranges_equals_one_batch_per_range(oracle_lib):
     np.testing.assert_array_equal(sb.sample_file_index[ob], sa.sample_file_index[oa])
     np.testing.assert_array_equal(sb.sample_size[ob], sa.sample_size[oa])
     assert len(set(int(x) for x in sa.rl_state)) > 1
+
+
+def test_constant_read_names_with_bed_and_fasta(oracle_lib):
+    """3 000 HQ paired records that all carry ONE read name (stripped / constant QNAMEs) inside one BED interval and one exon: the
+    pairing stages' bucket for that name is beyond the LDS sort and is sorted in memory (rsqc_k5.h: pair_bucket_big_sort) -- round 4
+    failed such a run with RSQC_ERR_CAPACITY.  Fragment sizes, their cut-off and the GC histogram equal the oracle's
+    walk of its QNAME-keyed maps."""
+    from rnaseqc_amd.model import Bed, Reference
+    rows = [dict(contig="c", type="gene", start=1000, end=90000, strand="+", gene_id="G"),
+            dict(contig="c", type="exon", start=1000, end=90000, strand="+", gene_id="G", exon_id="E")]
+    ann = Annotation.from_rows(["c"], rows)
+    bed = Bed.from_intervals([0], [1500], [88000])
+    rng = np.random.default_rng(9)
+    ref = Reference(contig=[0], sequence=[np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 100000)]])
+    M = abi.CIG_M
+    recs = []
+    for k in range(1500):
+        p1 = 2000 + 50 * k; p2 = p1 + int(rng.integers(120, 600))
+        size = p2 + 100 - p1
+        recs.append(dict(qname="x", tid=0, pos=p1, cigar=[(M, 100)], flag=99, mapq=255, nm=0, mpos=p2, mtid=0, isize=size))
+        recs.append(dict(qname="x", tid=0, pos=p2, cigar=[(M, 100)], flag=147, mapq=255, nm=0, mpos=p1, mtid=0, isize=-size))
+    recs.sort(key=lambda r: r["pos"])
+    b = Batch.from_records(recs)
+    for samples in (1000000, 37):
+        p = abi.default_params(fragment_samples=samples, coverage_mask=0)
+        want = oracle_lib.run_oracle(p, ann, [b], bed=bed, reference=ref)
+        assert int(want.fragment_count.sum()) == min(samples, int(want.fragment_count.sum())) and int(want.fragment_count.sum()) > 30
+        got = engine.run_engine(p, ann, [b], bed=bed, reference=ref)
+        assert_results_match(got, want)

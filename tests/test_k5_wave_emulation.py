@@ -10,8 +10,19 @@ from tests import hostemu
 @pytest.mark.parametrize("seed,n_names,max_samples", [(1, 40, 1000), (2, 3000, 1_000_000), (3, 3000, 700), (4, 9000, 1),
                                                        (5, 9000, 2500), (6, 1, 10), (7, 700, 0)])
 def test_fragment_size_kernels_vs_literal_walk(seed, n_names, max_samples):
-    rc, n, ns, kept, distinct = hostemu.run_k5(seed, n_names, max_samples)
+    rc, n, ns, kept, distinct, _listed = hostemu.run_k5(seed, n_names, max_samples)
     assert rc == 0, rc
     assert kept == min(ns, max_samples)
     if n_names >= 700 and max_samples:
         assert ns > 50 and distinct >= 1
+
+
+@pytest.mark.parametrize("seed,n_names,hot,max_samples", [(11, 2000, 2100, 1_000_000), (12, 50, 5000, 300), (13, 0, 3000, 1_000_000)])
+def test_one_name_with_thousands_of_records(seed, n_names, hot, max_samples):
+    """Stripped / constant read names: every record of a QNAME lands in one bucket of the pairing stage; beyond the 2 048 slots of
+    the LDS sort the bucket is listed and sorted in memory (rsqc_k5.h: pair_bucket_big_sort) -- round 4 failed the run with
+    RSQC_ERR_CAPACITY.  Same literal walk as above."""
+    rc, n, ns, kept, distinct, listed = hostemu.run_k5(seed, n_names, max_samples, hot=hot)
+    assert rc == 0, rc
+    assert listed == 1 and n >= hot
+    assert kept == min(ns, max_samples) and ns > 100
