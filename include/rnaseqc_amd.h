@@ -314,7 +314,10 @@ typedef struct rsqc_batch {
        decode and the host reader) fill it.  Every QNAME-keyed stage uses the same identity: geneFragmentCounts, the fragment-size
        sampler (src/Expression.cpp:511-531) and the fragment GC pairing (:461-474).  ALL OR NONE: the batches of one pass (between
        two rsqc_reset) either all carry the column or none does -- a submit that disagrees with the pass's first batch fails with
-       RSQC_ERR_ARG (the two mates of a fragment would otherwise carry (qhash, h2) and (qhash, 0): two names).                  */
+       RSQC_ERR_ARG (the two mates of a fragment would otherwise carry (qhash, h2) and (qhash, 0): two names).
+       LIMIT: names that share their 64-bit qhash and differ in qhash2 are counted exactly up to 33 of them per fragment partition
+       (a gene's names of one hash stripe, ~1 000 records); more is RSQC_ERR_CAPACITY, never a miscount.  rsqc_qname_hash values of
+       real read names do not collide at all at these sizes; a crafted 64-bit collision costs ~5e9 hash evaluations each.     */
     const uint32_t *qhash2;            /* [n]                                  */
 
     /* optional (may be NULL): the batch is SEVERAL ranges of the file, one per contig segment -- seg_file_index[s] is the file index of

@@ -627,3 +627,28 @@ def test_constant_read_names_with_bed_and_fasta(oracle_lib):
         assert int(want.fragment_count.sum()) == min(samples, int(want.fragment_count.sum())) and int(want.fragment_count.sum()) > 30
         got = engine.run_engine(p, ann, [b], bed=bed, reference=ref)
         assert_results_match(got, want)
+
+
+@pytest.mark.parametrize("n_names,ok", [(33, True), (34, False)])
+def test_names_sharing_one_64_bit_hash_boundary(oracle_lib, n_names, ok):
+    """The set-aside list of the fragment count (rsqc_k4.h: names whose 64-bit hash is already in a partition's set under ANOTHER
+    second hash) holds 32 entries per partition: 33 names with one 64-bit hash in one gene (the set's owner + 32) are counted exactly,
+    the 34th is a clean RSQC_ERR_CAPACITY, never a miscount (include/rnaseqc_amd.h documents the limit).  Hash-only
+    batch: the hashes are written directly -- one crafted 64-bit collision costs 5e9 hash evaluations (tools/qname_collision.c)."""
+    rows = [dict(contig="c", type="gene", start=100, end=9000, strand="+", gene_id="G0"),
+            dict(contig="c", type="exon", start=100, end=9000, strand="+", gene_id="G0", exon_id="E0")]
+    ann = Annotation.from_rows(["c"], rows)
+    recs = [dict(qname="n%d" % k, tid=0, pos=200 + 10 * k, cigar=[(abi.CIG_M, 50)], flag=0, mapq=255, nm=0) for k in range(n_names)]
+    b = Batch.from_records(recs)
+    b.qname = None; b.qname_off = None
+    b.qhash = np.full(b.n, 0x1234567890ABCDEF, np.uint64)
+    b.qhash2 = (np.arange(b.n, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(17)).astype(np.uint32)
+    p = abi.default_params(unpaired=1)
+    if ok:
+        got = engine.run_engine(p, ann, [b])
+        assert int(got.gene_fragments[0]) == n_names == int(got.gene_reads[0])
+        assert_results_match(got, oracle_lib.run_oracle(p, ann, [b]))
+    else:
+        with pytest.raises(engine.EngineError) as e:
+            engine.run_engine(p, ann, [b])
+        assert e.value.code == abi.ERR_CAPACITY
