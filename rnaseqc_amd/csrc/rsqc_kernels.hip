@@ -91,72 +91,33 @@ extern "C" __attribute__((visibility("default"))) int rsqc_debug_k1_prof(unsigne
 #include "rsqc_k1s.h"
 namespace rsqc {
 
-// ------------------------------------------------------------------ K1
-// grid-stride over tiles of RSQC_K1_THREADS records; one record per lane per iteration.
-// Workgroup-local accumulators.  A workgroup streams a short genomic window (a few thousand
-// coordinate-sorted records), so it touches a handful of neighbouring exon rows and genes: direct-mapped
-// LDS tables indexed by the low bits of the row / gene id take every update, and each distinct key
-// costs ONE global atomic when the workgroup retires.  (A single hot address sustains only ~90 M global
-// atomics/s on this chip -- tools/atomic_bench.hip.)  A key that finds its slot taken by another key
-// probes a few neighbours and otherwise falls through to memory.
-constexpr int K1_ESLOTS = 512, K1_GSLOTS = 256;
-struct K1Shared {
+// ------------------------------------------------------------------ the gate pass of --legacy runs
+// Under --legacy the per-record work of the feature stage belongs to classify_slow_kernel<true> (general code over EVERY record,
+// rsqc_k1s.h); this kernel takes what comes before it: the gate cascade with the LegacyMode tests (src/RNASeQC.cpp:254-342), its
+// counters, the fragment-size candidates and the Read-Length inputs.  (Rounds 1-2 ran the default rules here as well -- bin tables
+// and a downward walk of the start-sorted exon rows; since round 3 they run in classify_ei_kernel, rsqc_k1.h, and round 5 removed
+// the feature stage, scatter and pair emission this body still carried for them.)
+struct LegacyGateShared {
     unsigned long long cnt[RSQC_N_COUNTERS];     // sum-type counters
     uint32_t cnt32[64];                          // one-per-record counters of the workgroup (a workgroup sees < 2^32 records)
-    double eval[K1_ESLOTS];
-    uint32_t ekey[K1_ESLOTS];
-    uint32_t gkey[K1_GSLOTS], gcnt[K1_GSLOTS], gnd[K1_GSLOTS];
     uint32_t rl[3];
-    uint32_t pairs;
-    __device__ __forceinline__ void exon_add(const DevAccum &acc, const uint32_t *ex_id, uint32_t row, double frac) {
-        uint32_t slot = row & (K1_ESLOTS - 1);
-#pragma unroll 1
-        for (int probe = 0; probe < 4; ++probe) {
-            const uint32_t old = atomicCAS(&ekey[slot], 0xFFFFFFFFu, row);
-            if (old == 0xFFFFFFFFu || old == row) { atomicAdd(&eval[slot], frac); return; }
-            slot = (slot + 1) & (K1_ESLOTS - 1);
-        }
-        atomicAdd(&acc.exon_acc[ex_id[row]], frac);
-    }
-    __device__ __forceinline__ void gene_add(const DevAccum &acc, uint32_t g, bool notdup) {
-        uint32_t slot = g & (K1_GSLOTS - 1);
-#pragma unroll 1
-        for (int probe = 0; probe < 4; ++probe) {
-            const uint32_t old = atomicCAS(&gkey[slot], 0xFFFFFFFFu, g);
-            if (old == 0xFFFFFFFFu || old == g) { atomicAdd(&gcnt[slot], 1u); if (notdup) atomicAdd(&gnd[slot], 1u); return; }
-            slot = (slot + 1) & (K1_GSLOTS - 1);
-        }
-        atomicAdd(&acc.gene_reads[g], 1ull);
-        if (notdup) atomicAdd(&acc.gene_unique[g], 1ull);
-    }
 };
-
-// LEGACY (--legacy): only the gate cascade, its counters and the fragment-size candidates are produced here; the
-// legacy feature stage runs as general code in classify_slow_kernel<true> over every record.
-template <int ROUND, bool LEGACY = false>
-__device__ __forceinline__ void classify_count_body(const DevAnnotation &a, const DevParams &p, const DevBatch &b,
-                                                    const DevAccum &acc, K1Shared &S) {
+__global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
+classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
+    __shared__ LegacyGateShared S;
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) S.cnt[c] = 0ull;
     if (threadIdx.x < 64) S.cnt32[threadIdx.x] = 0u;
-    for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x) { S.ekey[c] = 0xFFFFFFFFu; S.eval[c] = 0.0; }
-    for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x) { S.gkey[c] = 0xFFFFFFFFu; S.gcnt[c] = 0u; S.gnd[c] = 0u; }
-    if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; S.pairs = 0u; }
+    if (threadIdx.x == 0) { S.rl[0] = 0u; S.rl[1] = 0xFFFFFFFFu; S.rl[2] = 0u; }
     if (blockIdx.x == 0 && threadIdx.x == 0) *acc.pair_slow_count = 0u;     // written only by the slow kernel, which runs after this one
-#ifdef RSQC_K1_PROF
-    if (threadIdx.x < 48) s_prof_acc[threadIdx.x] = 0ull;
-    if (l == 0) s_prof_last[wave] = __builtin_amdgcn_s_memtime();
-#endif
     __syncthreads();
-
     // One-per-record counters: a WaveSink (rsqc_read.h) -- per tile, lane c of one register receives the number of records
-    // that increment counter c (scalar popcounts of the condition masks), and ONE LDS instruction adds the register to
-    // the workgroup's table.  The seven sum-type counters stay per-lane sums, reduced every 31 tiles.
+    // that increment counter c, and ONE LDS instruction adds the register to the workgroup's table.  The seven sum-type counters
+    // stay per-lane sums, reduced every 31 tiles.
     uint32_t sum_e1mm = 0, sum_e1b = 0, sum_e2mm = 0, sum_e2b = 0, sum_mm = 0, sum_b = 0, sum_blk = 0;
     int pending = 0;
     uint32_t l_span = 0u, l_lmin = 0xFFFFFFFFu, l_lmax = 0u;
-    bool big_any = false;
     auto flush_counts = [&]() {
         const uint32_t s0 = wave_sum(sum_e1mm), s1 = wave_sum(sum_e1b), s2 = wave_sum(sum_e2mm), s3 = wave_sum(sum_e2b),
                        s4 = wave_sum(sum_mm), s5 = wave_sum(sum_b), s6 = wave_sum(sum_blk);
@@ -170,32 +131,15 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
         pending = 0;
     };
-
-    // Every WAVE streams its own contiguous range of records (input is coordinate-sorted), so
-    // consecutive iterations keep hitting the same gene / exon and the trailing run of an
-    // iteration can stay in registers until the key changes.
+    // every WAVE streams its own contiguous range of records
     constexpr uint32_t WPB = RSQC_K1_THREADS / 64;
     const uint64_t total_waves = (uint64_t)gridDim.x * WPB;
     const uint64_t per_wave = (((b.n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
     const uint64_t wbeg = ((uint64_t)blockIdx.x * WPB + (uint64_t)wave) * per_wave;
     const uint64_t wend = wbeg + per_wave < b.n ? wbeg + per_wave : b.n;
-    // this block's private chunk of the (gene, qname-hash) pair buffer: no global slot counter
-    const uint32_t chunk_cap = acc.pair_chunk_cap;
-    uint32_t *const my_pair_gene = acc.pair_gene + (size_t)blockIdx.x * chunk_cap;
-    uint64_t *const my_pair_hash = acc.pair_hash + (size_t)blockIdx.x * chunk_cap;
-    // contig of the tile: wave-uniform (scalar loads), refreshed when the stream crosses a segment
     uint32_t seg = wbeg < b.n ? find_segment(b, wbeg) : 0u;
-    int32_t u_tid = -1;
-    ContigInfo u_ci = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_contig = [&]() {
-        u_tid = b.n_seg ? b.seg_tid[seg] : -1;
-        if (u_tid >= 0 && u_tid < a.n_contigs) u_ci = a.contig[u_tid];
-        else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
-    };
-    load_contig();
-    // Record words are staged one tile ahead (core words two tiles ahead, because the CIGAR address
-    // comes from them): the loads of tile t+1 are issued after the last dependent load of tile t and
-    // land while tile t is being scattered, so the HBM-cold round trips leave the critical chain.
+    int32_t u_tid = b.n_seg ? b.seg_tid[seg] : -1;
+    // record words are staged one tile ahead (core words two tiles ahead: the CIGAR address comes from them)
     const int4 zero4 = {0, 0, 0, 0};
     int4 cur_cv = zero4, cur_av = zero4, nx_cv = zero4;
     uint32_t cur_cg[4] = {0, 0, 0, 0};
@@ -207,30 +151,14 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         cur_cg[0] = ld32(b.cigar, co); cur_cg[1] = ld32(b.cigar, co + 1); cur_cg[2] = ld32(b.cigar, co + 2); cur_cg[3] = ld32(b.cigar, co + 3);
     }
     for (uint64_t w0 = wbeg; w0 < wend; w0 += 64) {
-        RSQC_MARK(0);                              // [0] loop overhead + counter flush of the previous tile
         const uint64_t i = w0 + (uint64_t)l;
         const bool valid = i < wend;
-        {
-            bool moved = false;
-            while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) { ++seg; moved = true; }
-            if (moved) load_contig();
-        }
+        while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= w0) { ++seg; u_tid = b.seg_tid[seg]; }
         const bool mixed = seg + 1 < b.n_seg && b.seg_start[seg + 1] < w0 + 64ull;   // a contig boundary inside the tile
-        FastOut fo;
-        fo.n_hit = 0; fo.cmask = 0;
-        uint32_t aligned = 0; bool notdup = false; uint64_t qhash = 0;
         WaveSink cnt;
-        // Everything that depends only on the gate cascade (scalar counters, Read-Length inputs, the
-        // fragment-size candidate) is retired BEFORE the feature stage, so that the record and its counters
-        // are dead while the index loads of the feature stage are in flight (register pressure).
-        // The cascade and the feature stage run CONVERGED (lanes without a record are predicated off by `lane_on`): the
-        // counter sink works on whole-wave ballots.
-        bool go = false, hq = false; Blocks B; uint32_t fl = 0; int32_t tid = u_tid;
-        FastBins fb_early;
-        fb_early.have = 0;
+        bool big_any;
         {
-            RecordCounters rc;
-            Record r;
+            RecordCounters rc; Record r; Blocks B; bool hq = false;
             const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
             r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z;
             r.cigar = b.cigar + (uint32_t)cv.w;
@@ -252,13 +180,8 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (!lane_on) r.n_cigar = 0;
             CigarWalk cw;
             walk_cigar(r, cur_cg, cw, B);
-            aligned = cw.aligned;
-            if (!lane_on || r.tid != u_tid) B.nb = 0;          // (stragglers of a boundary tile go to the general code: no look-up here)
-            if (!LEGACY) fast_load_bins(a, u_ci, B, fb_early);  // round 1 of the overlap query: in flight during the gate cascade
-            go = gate_cascade<LEGACY, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
-            fl = r.flag; tid = r.tid;
-            notdup = !(r.flag & RSQC_FDUP); qhash = r.qhash;
-            if (!lane_on) { B.nb = 0; rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
+            const bool go = gate_cascade<true, WaveSink>(a, p, r, cw, rc, hq, cnt, lane_on);
+            if (!lane_on) { rc.e1_mm = rc.e1_bases = rc.e2_mm = rc.e2_bases = rc.mm = rc.bases = rc.blocks = 0; rc.rl_eligible = 0; rc.error = 0; rc.frag_candidate = 0; }
             if (go && a.have_bed && rc.frag_candidate) {          // src/RNASeQC.cpp:372
                 const int32_t name = bed_interval_of(a, r);
                 if (name >= 0) {
@@ -274,11 +197,10 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 }
             }
             if (rc.error) atomicExch(acc.error, rc.error);
-            RSQC_MARK(1);                          // [1] wait for the staged record words, unpack, CIGAR walk, gate cascade
             sum_e1mm += rc.e1_mm; sum_e1b += rc.e1_bases; sum_e2mm += rc.e2_mm; sum_e2b += rc.e2_bases;
             sum_mm += rc.mm; sum_b += rc.bases; sum_blk += rc.blocks;
             big_any = (rc.bases | rc.mm | rc.blocks) >= (1u << 26);
-            // Read-Length inputs: per-wave max span + batch-level extremes
+            // Read-Length inputs: per-tile max span + batch-level extremes
             const uint32_t sp = rc.rl_eligible ? rc.rl_span : 0u;
             const uint32_t wsp = wave_max_u32(sp);
             if (l == 0) acc.tile_span[w0 >> 6] = wsp;
@@ -288,23 +210,7 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
                 l_lmin = lq < l_lmin ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;
             }
         }
-        RSQC_MARK(2);                              // [2] gate counters + Read-Length inputs
-        // ---- feature stage ------------------------------------------------------------------------ [3] bins, [4..7] block rounds, [8] epilogue
-        if (!LEGACY) {
-            const bool fast_on = go && tid == u_tid;           // stragglers of a boundary tile: general code
-            bool overflow = false;
-            exon_metrics_fast<ROUND, WaveSink>(a, p, u_ci, fl, B, hq, aligned, fo, overflow, cnt, fast_on, &fb_early);
-            if (go && overflow) {
-                fo.n_hit = 0; fo.cmask = 0;
-                const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
-                if (slot < acc.ovf_cap) acc.ovf_index[slot] = i;
-                else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-            }
-            if (!go) { fo.n_hit = 0; fo.cmask = 0; }
-        }
-        RSQC_MARK(9);                              // [9] class bits + overflow hand-over
-        // ---- stage the next tile (see above) ------------------------------------------------
-        {
+        {   // stage the next tile
             const uint64_t i1 = i + 64ull, i2 = i + 128ull;
             const int4 t_cv = nx_cv;
             int4 t_av = zero4;
@@ -315,57 +221,12 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
             if (i2 < wend) nx_cv = ld32(core4 + w0 + 128, (uint32_t)l);
             cur_cv = t_cv; cur_av = t_av;
         }
-        // ---- scatter -----------------------------------------------------------------------------
-        // exonCounts[row] += len / aligned and the per-gene counters go to the workgroup's LDS tables
-        // (no wave-wide merging, no carried state); per-base coverage goes to memory as a difference
-        // array, identical neighbouring slots merged into one atomic.
-        // one f64 division per record (the expansion is long and would otherwise be repeated per slot); a slot adds
-        // len * (1 / aligned), within 1 ulp of the reference's len / aligned
-        RSQC_MARK(10);                             // [10] issue of the next tile's loads
-        const double inv_aligned = 1.0 / (double)(aligned ? aligned : 1u);
-#pragma unroll
-        for (int k = 0; k < NSLOT; ++k) {
-            const bool has = (fo.cmask >> k) & 1u;
-            const uint64_t hm = __ballot(has);
-            if (hm == 0ull) continue;
-            struct { uint32_t row, cidx, len; } cm = {fo.row[k], fo.cidx[k], B.len[k >> 1]};
-            const bool hv = has && cm.len > 0;
-            if (hv) S.exon_add(acc, a.ex_id, cm.row, (double)cm.len * inv_aligned);
-            {                                    // +1 at the block start, -1 after its last base
-                const uint32_t base = hv ? cm.cidx : 0u;
-                cov_add_merged(acc.cov_diff, hv, base, 1u);
-                cov_add_merged(acc.cov_diff, hv, base + cm.len, 0xFFFFFFFFu);
-            }
-        }
-        RSQC_MARK(11);                             // [11] commit slots: exon fractions (LDS) + coverage atomics
-#pragma unroll
-        for (int k = 0; k < FAST_SET; ++k) {
-            const bool has = fo.n_hit > k;
-            const uint64_t m = __ballot(has);
-            if (m == 0ull) break;
-            const uint32_t g = fo.hit[k];
-            {
-                // (gene, qname-hash) pairs for the fragment de-dup: one LDS slot reservation per wave
-                const int lead = __ffsll((unsigned long long)m) - 1;
-                uint32_t base = 0;
-                if (l == lead) base = atomicAdd(&S.pairs, (uint32_t)__popcll(m));
-                base = __shfl(base, lead, 64);
-                if (has) {
-                    const uint32_t slot = base + mask_rank(m);
-                    if (slot < chunk_cap) { my_pair_gene[slot] = g; my_pair_hash[slot] = qhash; acc.pair_h2[(size_t)blockIdx.x * chunk_cap + slot] = 0u; }
-                    else atomicExch(acc.error, RSQC_ERR_CAPACITY);
-                }
-            }
-            if (has) S.gene_add(acc, g, notdup);
-        }
-        RSQC_MARK(12);                             // [12] gene hits: pairs + gene counters
-        // ---- the tile's one-per-record counters: lane c holds counter c's increment (one LDS instruction) ----
+        // the tile's one-per-record counters: lane c holds counter c's increment (one LDS instruction)
         if (l < RSQC_N_COUNTERS && cnt.vec) atomicAdd(&S.cnt32[l], cnt.vec);
         // the u32 sums cannot overflow within 31 tiles unless a record carries an absurd value: flush right away then
         if (++pending == 31 || __ballot(big_any) != 0ull) flush_counts();
     }
     flush_counts();
-    RSQC_MARK(13);
     {
         const uint32_t ws = wave_max_u32(l_span), wmn = wave_min_u32(l_lmin), wmx = wave_max_u32(l_lmax);
         if (l == 0) { atomicMax(&S.rl[0], ws); atomicMin(&S.rl[1], wmn); atomicMax(&S.rl[2], wmx); }
@@ -375,33 +236,10 @@ __device__ __forceinline__ void classify_count_body(const DevAnnotation &a, cons
         const unsigned long long v = S.cnt[c] + (unsigned long long)S.cnt32[c];
         if (v) atomicAdd(&acc.counters[c], v);
     }
-    for (int c = threadIdx.x; c < K1_ESLOTS; c += blockDim.x)
-        if (S.ekey[c] != 0xFFFFFFFFu) atomicAdd(&acc.exon_acc[a.ex_id[S.ekey[c]]], S.eval[c]);      // accumulators are indexed by exon id
-    for (int c = threadIdx.x; c < K1_GSLOTS; c += blockDim.x)
-        if (S.gkey[c] != 0xFFFFFFFFu) {
-            atomicAdd(&acc.gene_reads[S.gkey[c]], (unsigned long long)S.gcnt[c]);
-            if (S.gnd[c]) atomicAdd(&acc.gene_unique[S.gkey[c]], (unsigned long long)S.gnd[c]);
-        }
     if (threadIdx.x == 0) {
         atomicMax(&acc.rl_stats[0], S.rl[0]); atomicMin(&acc.rl_stats[1], S.rl[1]); atomicMax(&acc.rl_stats[2], S.rl[2]);
-        acc.pair_chunk_count[blockIdx.x] = S.pairs < chunk_cap ? S.pairs : chunk_cap;
+        acc.pair_chunk_count[blockIdx.x] = 0u;       // (this kernel emits no (gene, name) pairs: the general kernel does, into the slow-path region)
     }
-#ifdef RSQC_K1_PROF
-    RSQC_MARK(14);                                 // [14] workgroup epilogue (barrier + flush of the LDS tables)
-    __syncthreads();
-    if (threadIdx.x < 48 && s_prof_acc[threadIdx.x]) atomicAdd(&g_k1_prof[threadIdx.x], s_prof_acc[threadIdx.x]);
-#endif
-}
-
-// The row-index kernel of rounds 1-2 (bin tables + downward walk of the start-sorted exon rows).  The default rules run
-// classify_ei_kernel (rsqc_k1.h) since round 3; this body serves --legacy, where the per-record work of the feature stage belongs to
-// classify_slow_kernel<true> and only the gate cascade, the counters and the Read-Length inputs are taken here (LEGACY = true).
-// 4 waves per SIMD (at most 128 VGPRs), one block's row loads in flight at a time (ROUND = 1): measured in round 2 against 3 waves
-// (168 VGPRs, no spills: +14 %), 5 waves (96 VGPRs, spills in the loop: 2.2x) and ROUND = 2 (profiles/r2_k1_occupancy_v1.txt).
-__global__ void __launch_bounds__(RSQC_K1_THREADS, 4)
-classify_count_kernel_legacy(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
-    __shared__ K1Shared S;
-    classify_count_body<1, true>(a, p, b, acc, S);
 }
 
 }  // namespace rsqc
