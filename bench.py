@@ -361,8 +361,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = None
+    marks = [t0]
     for _ in range(args.steps):
         res = step()
+        marks.append(time.perf_counter())    # (a step ends with its results on the host: the stream is idle here, except with --no-finalize)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -440,6 +442,9 @@ def main():
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_spread": (lambda d: {"min": round(d[0], 4), "median": round(d[len(d) // 2], 4), "max": round(d[-1], 4),
+                                              "note": "rank 0's host clock per step; the kernels' own times are in stage_ms"})(
+                sorted(1e3 * (b - a) for a, b in zip(marks, marks[1:]))) if not args.no_finalize else None,
             "higher_is_better": True, "scaling": "strong" if not args.chr1 else "weak",
             "vs_baseline": None,
             "dtype": "i32/u64 counters, f64 exon fractions",

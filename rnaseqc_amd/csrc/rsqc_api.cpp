@@ -30,6 +30,20 @@
 #else
 #define RSQC_DIAG(name) ((const char *)nullptr)
 #endif
+// (diagnostic build only, RSQC_HOST_TRACE=1: host clock at the steps of a pass to stderr -- where a pass spends what the kernels' events do not show)
+#if defined(RSQC_K1_PROF) || defined(RSQC_DIAG_KNOBS)
+static void host_trace(const char *what) {
+    static const bool on = getenv("RSQC_HOST_TRACE") != nullptr;
+    if (!on) return;
+    static std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host] %-28s +%8.1f us\n", what, std::chrono::duration<double, std::micro>(now - last).count());
+    last = now;
+}
+#define RSQC_TRACE(what) host_trace(what)
+#else
+#define RSQC_TRACE(what) ((void)0)
+#endif
 
 
 using namespace rsqc;
@@ -193,7 +207,9 @@ struct rsqc_ctx {
     // on the device (rsqc_shard_info)
     std::vector<uint64_t> batch_file_index, batch_records;
     DevBuf d_rl_summary;
-    std::vector<uint32_t> h_rl_raw, h_rl_offset, h_rl_span;
+    uint32_t *h_rl_raw = nullptr;               // page-locked (a copy into pageable memory would hold the host until the coverage kernel ahead of it ended)
+    size_t h_rl_raw_cap = 0;                    // ... words
+    std::vector<uint32_t> h_rl_offset, h_rl_span;
     std::vector<int32_t> h_rl_state;
     std::vector<uint64_t> h_sample_file;        // fragment-size samples kept by this shard (first N by file index), ascending
     std::vector<uint32_t> h_sample_size;
@@ -700,6 +716,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
     DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
+    if (c->h_rl_raw) (void)hipHostFree(c->h_rl_raw);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
@@ -973,7 +990,10 @@ int rsqc_submit_resident(rsqc_ctx *c, int handle) {
     if (!c || handle < 0 || handle >= (int)c->resident.size() || !c->resident[(size_t)handle]) return RSQC_ERR_ARG;
     if (c->sticky) return c->sticky;
     HIP_TRY(c, hipSetDevice(c->device));
-    return run_batch(c, c->resident[(size_t)handle]);
+    RSQC_TRACE("submit_resident: enter");
+    const int rc = run_batch(c, c->resident[(size_t)handle]);
+    RSQC_TRACE("submit_resident: enqueued");
+    return rc;
 }
 
 int rsqc_release(rsqc_ctx *c, int handle) {
@@ -988,7 +1008,10 @@ int rsqc_release(rsqc_ctx *c, int handle) {
 int rsqc_reset(rsqc_ctx *c) {
     if (!c || !c->have_ann) return RSQC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    return zero_accumulators(c);
+    RSQC_TRACE("reset: enter");
+    const int rc = zero_accumulators(c);
+    RSQC_TRACE("reset: enqueued");
+    return rc;
 }
 
 // one D2H of the whole arena into the pinned mirror, then unpack into the results struct
@@ -1002,11 +1025,13 @@ static int read_back(rsqc_ctx *c) {
         HIP_TRY(c, hipMemcpyAsync(c->h_arena + frag_lo, (char *)c->d_arena.p + frag_lo, (size_t)G * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_arena + c->off_misc, (char *)c->d_arena.p + c->off_misc, c->arena_bytes - c->off_misc, hipMemcpyDeviceToHost, c->stream));
         c->early_copied = false;
+        RSQC_TRACE("read_back: copies enqueued");
     } else {
         launch_pack_results(c->stream, (const double *)(A + c->off_exon), (uint8_t *)(A + c->off_ehit), (uint32_t)E);
         HIP_TRY(c, hipMemcpyAsync(c->h_arena, c->d_arena.p, c->arena_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    RSQC_TRACE("read_back: stream idle");
     char *H = c->h_arena;
     uint64_t *u = (uint64_t *)(H + c->off_u64);
     rsqc_results &R = c->results;
@@ -1096,6 +1121,7 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
             }
             if (!RSQC_DIAG("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
         }
+        RSQC_TRACE("finalize: K4 enqueued");
         // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
@@ -1123,10 +1149,17 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
         }
         {   // per-batch Read-Length transfer functions (rsqc_shard_info): final since the last batch's read_length_kernel; the copy
             // goes out on a side stream behind its coverage kernel (behind frag_count on the main stream it cost a queue hand-over:
-            // ~40 us) and is covered by that stream's join below.  (Enqueued last: the destination is pageable, the call may block)
+            // ~40 us) and is covered by that stream's join below; the destination is page-locked, the call returns at once
             const size_t nb = c->batch_file_index.size();
-            c->h_rl_raw.resize(nb * RSQC_RL_SUMMARY_WORDS);
-            if (nb) HIP_TRY(c, hipMemcpyAsync(c->h_rl_raw.data(), c->d_rl_summary.p, nb * RSQC_RL_SUMMARY_WORDS * 4, hipMemcpyDeviceToHost, c->stream2));
+            if (nb * RSQC_RL_SUMMARY_WORDS > c->h_rl_raw_cap) {
+                if (c->h_rl_raw) { (void)hipHostFree(c->h_rl_raw); c->h_rl_raw = nullptr; c->h_rl_raw_cap = 0; }
+                const size_t want = std::max<size_t>(2 * nb, 64) * RSQC_RL_SUMMARY_WORDS;
+                HIP_TRY(c, hipHostMalloc((void **)&c->h_rl_raw, want * 4, hipHostMallocDefault));
+                c->h_rl_raw_cap = want;
+            }
+            RSQC_TRACE("finalize: K3 enqueued");
+            if (nb) HIP_TRY(c, hipMemcpyAsync(c->h_rl_raw, c->d_rl_summary.p, nb * RSQC_RL_SUMMARY_WORDS * 4, hipMemcpyDeviceToHost, c->stream2));
+            RSQC_TRACE("finalize: rl copy call returned");
         }
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
         HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
@@ -1219,7 +1252,7 @@ static void unpack_rl_summaries(rsqc_ctx *c) {           // after the stream has
     const size_t nb = c->batch_file_index.size();
     c->h_rl_offset.assign(nb + 1, 0); c->h_rl_span.clear(); c->h_rl_state.clear();
     for (size_t k = 0; k < nb; ++k) {
-        const uint32_t *w = c->h_rl_raw.data() + k * RSQC_RL_SUMMARY_WORDS;
+        const uint32_t *w = c->h_rl_raw + k * RSQC_RL_SUMMARY_WORDS;
         const uint32_t P = std::min<uint32_t>(w[0], 128u);
         for (uint32_t j = 0; j < P; ++j) { c->h_rl_span.push_back(w[2 + 2 * j]); c->h_rl_state.push_back((int32_t)w[3 + 2 * j]); }
         c->h_rl_offset[k + 1] = (uint32_t)c->h_rl_span.size();
@@ -1256,10 +1289,13 @@ int rsqc_finalize(rsqc_ctx *c, rsqc_results *out) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
     if (!c->finalized) {
+        RSQC_TRACE("finalize: enter");
         if ((rc = run_finalize_kernels(c, /*early_readback=*/true))) return rc;
+        RSQC_TRACE("finalize: kernels enqueued");
         // ---- one read-back of every result vector (also carries the device error flag) ----------------
         if ((rc = read_back(c))) return rc;
         finish_finalize_bookkeeping(c);
+        RSQC_TRACE("finalize: bookkeeping done");
     } else if ((rc = read_back(c))) return rc;
     *out = c->results;
     return RSQC_OK;
