@@ -57,12 +57,14 @@ typedef uint32_t InfVec;
 #define INF_AT(vec, k) (vec)
 #define INF_GET(vec, k) ((uint32_t)__builtin_amdgcn_readlane((int)(vec), (int)(k)))           /* k wave-uniform */
 #define INF_SET(vec, k, x) ((vec) = (INF_LANE == (k)) ? (x) : (vec))
+#define INF_GATHER(vec, idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)(vec)))   /* idx per lane, < 64: that lane's value of vec */
 #else
 struct InfVec { uint32_t v[64]; };
 #define INF_FOREACH(k) for (uint32_t k = 0; k < 64u; ++k)
 #define INF_AT(vec, k) ((vec).v[k])
 #define INF_GET(vec, k) ((vec).v[k])
 #define INF_SET(vec, k, x) ((vec).v[k] = (x))
+#define INF_GATHER(vec, idx) ((vec).v[(idx) & 63u])
 #endif
 
 namespace rsqc {
@@ -144,6 +146,18 @@ constexpr uint32_t INF_NEAR = INF_RING - 258u;          // distances up to this 
 // profiles/r3_decode_ab.txt; the lane-parallel table build measured beside it was +-0 and is gone).
 #ifndef INF_INWALK_CFG
 #define INF_INWALK_CFG 1
+#endif
+// > 0: the walk hops 2^INF_VWALK_CFG symbols at a time.  Every lane knows where the symbol at its offset ends; that many rounds of
+// pointer doubling on the vector side (three ds_bpermute each: the landing lane and the 64-bit mask of the starts on the way) give
+// every lane the landing point and the starts of 2^n symbols, and the wave-uniform walk takes one step (three v_readlane + four
+// scalar instructions) where it took 2^n (one v_readlane + ten each).  0: one symbol per step (rounds 2-4).
+// Measured (round 5, profiles/r5_decode_walk_ab.txt, one box, outputs identical): 40.4 / 40.1 / 40.4 / 39.7 GB/s of inflated bytes at
+// 0 / 1 / 2 / 3 on the realistic file, 122.4 / 123.8 / 123.0 / 121.8 on the SURVEY 8(d) file -- NOTHING.  The walk was the scalar
+// port's largest single customer and it is not what holds the kernel: a round is ~800 issued instructions of which the walk was
+// ~110, and what the scalar side gives up the vector side and six LDS round trips take back.  The product builds 0 (the form with
+// three rounds of fuzzing behind it); the others stay under test (tests/test_device_decode_host.py).
+#ifndef INF_VWALK_CFG
+#define INF_VWALK_CFG 0
 #endif
 constexpr uint32_t INF_LBITS = INF_LBITS_CFG, INF_DBITS = INF_DBITS_CFG;
 constexpr uint32_t INF_FLUSH = INF_FLUSH_CFG;          // the ring goes out to HBM (and through the CRC) in pieces of this size
@@ -516,6 +530,39 @@ RSQC_INF_FN bool inflate_one_symbol(InflateScratch &S, InflateIn &bi, InflateOut
     return true;
 }
 
+// the symbol at bit offset `off` of the buffered bits when its code is longer than the fast table's index (wave-uniform; the walk of
+// inflate_round stands on it).  false: not such a symbol -- the buffered bits end inside it, nobody owns the code
+RSQC_INF_FN bool inflate_long_code_here(InflateScratch &S, InflateIn &bi, uint32_t off, uint32_t avail, uint32_t &kind, uint32_t &adv, uint32_t &ol, uint32_t &val) {
+    const uint64_t w = bi.bits_at(off);
+    if (INF_UNI(S.lfast[(uint32_t)w & ((1u << INF_LBITS) - 1u)])) return false;   // (not a long code: the symbol runs past the buffered bits, or is undefined)
+    uint32_t len;
+    const uint32_t sy = inflate_symbol_slow((uint32_t)w, S.lcount, S.lfirst, S.lidx, S.lsym, len);
+    if (sy == 0xFFFFu) return false;
+    const uint32_t e = inflate_entry(INF_T_LITLEN, sy, len);
+    ol = 0; val = 0;
+    if (e & INF_E_LITERAL) { kind = INF_K_LIT; adv = len; ol = 1; val = (e >> 8) & 0xFFu; }
+    else if (e & INF_E_END) { kind = INF_K_END; adv = len; }
+    else if (e & INF_E_INVALID) return false;
+    else {
+        const uint32_t xb = (e >> 4) & 15u;
+        const uint64_t w1 = w >> len;
+        const uint32_t mlen = ((e >> 8) & 0xFFFFu) + ((uint32_t)w1 & ((1u << xb) - 1u));
+        const uint64_t w2 = w1 >> xb;
+        uint32_t f = INF_UNI(S.dfast[(uint32_t)w2 & ((1u << INF_DBITS) - 1u)]);
+        if (!f) {
+            uint32_t dl;
+            const uint32_t ds = inflate_symbol_slow((uint32_t)w2, S.dcount, S.dfirst, S.didx, S.dsym, dl);
+            if (ds == 0xFFFFu) return false;
+            f = inflate_entry(INF_T_DIST, ds, dl);
+        }
+        if (f & INF_E_INVALID) return false;
+        const uint32_t l2 = f & 15u, db = (f >> 4) & 15u;
+        kind = INF_K_MATCH; adv = len + xb + l2 + db; ol = mlen;
+        val = ((f >> 8) & 0xFFFFu) + ((uint32_t)(w2 >> l2) & ((1u << db) - 1u));
+    }
+    return off + adv <= avail;                                              // (false: the symbol runs past the buffered bits)
+}
+
 // true = the block goes on; false = it ended (status untouched) or failed (status = the InflateStatus)
 template <bool PAR = (INF_PAR_COMMIT_CFG != 0)>
 RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, uint32_t &status) {
@@ -547,6 +594,54 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
     // and off << 3 reaches that value exactly when the walk has left the 64 buffered offsets (off < 112: a symbol is at most 48 bits)
     uint64_t starts = 0;
     uint32_t off = 0;
+#if INF_VWALK_CFG
+    // J: where the walk stands after the symbols counted in (MLO, MHI) when it enters at this lane -- 128 + the lane it cannot take
+    // (END, OTHER), or the offset >= 64 at which it has left the buffered offsets (< 112: a symbol is at most 48 bits); either
+    // way a value >= 64 ends the walk, with ONE test per step.  The hops only go up, so what a lane holds never depends on a lane
+    // below it: a long code decoded in place below (INF_INWALK_CFG) leaves the lanes above it valid.
+    InfVec J, MLO, MHI;
+    INF_FOREACH(k) {
+        const uint32_t pk = INF_AT(PK, k);
+        const bool take = pk < ((uint32_t)INF_K_END << 8);
+        INF_AT(J, k) = take ? k + (pk & 0xFFu) : 128u + k;
+        INF_AT(MLO, k) = (take && k < 32u) ? 1u << (k & 31u) : 0u;
+        INF_AT(MHI, k) = (take && k >= 32u) ? 1u << (k & 31u) : 0u;
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < INF_VWALK_CFG; ++lvl) {
+        InfVec J2, L2, H2;
+        INF_FOREACH(k) {
+            (void)k;
+            const uint32_t j = INF_AT(J, k);
+            const uint32_t jj = INF_GATHER(J, j & 63u), lo = INF_GATHER(MLO, j & 63u), hi = INF_GATHER(MHI, j & 63u);
+            const bool in = j < 64u;
+            INF_AT(J2, k) = in ? jj : j; INF_AT(L2, k) = INF_AT(MLO, k) | (in ? lo : 0u); INF_AT(H2, k) = INF_AT(MHI, k) | (in ? hi : 0u);
+        }
+        J = J2; MLO = L2; MHI = H2;
+    }
+    uint32_t a;
+    for (;;) {
+        do {
+            starts |= (uint64_t)INF_GET(MLO, off) | ((uint64_t)INF_GET(MHI, off) << 32);
+            off = INF_GET(J, off);
+        } while (off < 64u);
+        if (off >= 128u) off -= 128u;                                       // stands on a lane it cannot take
+        a = INF_GET(PK, off & 63u);
+#if INF_INWALK_CFG
+        if (off >= 64u || (a >> 8) != (uint32_t)INF_K_OTHER) break;
+        uint32_t kind, adv, ol = 0, val = 0;
+        if (!inflate_long_code_here(S, bi, off, avail, kind, adv, ol, val)) break;
+        a = (kind << 8) | adv;
+        INF_SET(PK, off, a); INF_SET(VAL, off, val); INF_SET(OL, off, ol);
+        if (kind == (uint32_t)INF_K_END) break;
+        starts |= 1ull << off;
+        off += adv;
+        if (off >= 64u) break;
+#else
+        break;
+#endif
+    }
+#else
     uint32_t a = INF_GET(PK, 0u);
 #if INF_INWALK_CFG
     for (;;) {
@@ -561,37 +656,12 @@ RSQC_INF_FN bool inflate_round(InflateScratch &S, InflateIn &bi, InflateOut &o, 
         // buffered, the lanes behind it have decoded what follows -- and the walk goes on; everything else (the buffered bits
         // end inside the symbol, a code nobody owns, the end of the block) ends the round as before.
         if (off >= 64u || (a >> 8) != (uint32_t)INF_K_OTHER) break;
-        const uint64_t w = bi.bits_at(off);
-        if (INF_UNI(S.lfast[(uint32_t)w & ((1u << INF_LBITS) - 1u)])) break;   // (not a long code: the symbol runs past the buffered bits, or is undefined)
-        uint32_t len;
-        const uint32_t sy = inflate_symbol_slow((uint32_t)w, S.lcount, S.lfirst, S.lidx, S.lsym, len);
-        if (sy == 0xFFFFu) break;
-        const uint32_t e = inflate_entry(INF_T_LITLEN, sy, len);
         uint32_t kind, adv, ol = 0, val = 0;
-        if (e & INF_E_LITERAL) { kind = INF_K_LIT; adv = len; ol = 1; val = (e >> 8) & 0xFFu; }
-        else if (e & INF_E_END) { kind = INF_K_END; adv = len; }
-        else if (e & INF_E_INVALID) break;
-        else {
-            const uint32_t xb = (e >> 4) & 15u;
-            const uint64_t w1 = w >> len;
-            const uint32_t mlen = ((e >> 8) & 0xFFFFu) + ((uint32_t)w1 & ((1u << xb) - 1u));
-            const uint64_t w2 = w1 >> xb;
-            uint32_t f = INF_UNI(S.dfast[(uint32_t)w2 & ((1u << INF_DBITS) - 1u)]);
-            if (!f) {
-                uint32_t dl;
-                const uint32_t ds = inflate_symbol_slow((uint32_t)w2, S.dcount, S.dfirst, S.didx, S.dsym, dl);
-                if (ds == 0xFFFFu) break;
-                f = inflate_entry(INF_T_DIST, ds, dl);
-            }
-            if (f & INF_E_INVALID) break;
-            const uint32_t l2 = f & 15u, db = (f >> 4) & 15u;
-            kind = INF_K_MATCH; adv = len + xb + l2 + db; ol = mlen;
-            val = ((f >> 8) & 0xFFFFu) + ((uint32_t)(w2 >> l2) & ((1u << db) - 1u));
-        }
-        if (off + adv > avail) break;                                       // the symbol runs past the buffered bits
+        if (!inflate_long_code_here(S, bi, off, avail, kind, adv, ol, val)) break;
         a = (kind << 8) | adv;
         INF_SET(PK, off, a); INF_SET(VAL, off, val); INF_SET(OL, off, ol);
     }
+#endif
 #endif
     bool stopped = off < 64u;                                               // the walk met a symbol it cannot take, at bit offset off
     const uint32_t stopped_at = a;

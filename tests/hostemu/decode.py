@@ -17,7 +17,9 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 
 # "" = the product's configuration (one-pass commit of a round, long codes decoded inside the walk); the others flip the switches
 VARIANTS = {"": (), "no_par_commit": ("-DINF_PAR_COMMIT_CFG=0",), "no_inwalk": ("-DINF_INWALK_CFG=0",),
-            "all": ("-DINF_PAR_COMMIT_CFG=0", "-DINF_INWALK_CFG=0")}
+            "all": ("-DINF_PAR_COMMIT_CFG=0", "-DINF_INWALK_CFG=0"),
+            "vwalk1": ("-DINF_VWALK_CFG=1",), "vwalk2": ("-DINF_VWALK_CFG=2",), "vwalk3": ("-DINF_VWALK_CFG=3",),
+            "vwalk3_no_inwalk": ("-DINF_VWALK_CFG=3", "-DINF_INWALK_CFG=0")}
 
 
 def build(variant=""):

@@ -36,11 +36,12 @@ def _payloads():
             yield bytes([rng.randrange(2)]) * n
 
 
-@pytest.mark.parametrize("variant", ["", "no_par_commit", "no_inwalk", "all"])
+@pytest.mark.parametrize("variant", ["", "no_par_commit", "no_inwalk", "all", "vwalk1", "vwalk2", "vwalk3", "vwalk3_no_inwalk"])
 def test_inflate_matches_zlib_on_every_block_type(variant):
     """Stored, fixed and dynamic blocks, several blocks per stream, small windows, long codes (Huffman-only on random bytes),
     runs (distance 1) and distances up to 32 KiB.  variant: "" is the product's configuration; the others switch off the one-pass
-    commit of a round (INF_PAR_COMMIT_CFG) and / or the in-walk decode of long codes (INF_INWALK_CFG) of rsqc_inflate.h."""
+    commit of a round (INF_PAR_COMMIT_CFG) and / or the in-walk decode of long codes (INF_INWALK_CFG) of rsqc_inflate.h, or set the
+    number of symbols the walk takes per step (INF_VWALK_CFG: 1 = the product, 2, 4, 8)."""
     n = 0
     for d in _payloads():
         for level in (0, 1, 6, 9):
