@@ -1163,8 +1163,8 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
         }
         HIP_TRY(c, hipEventRecord(c->ev_join3, c->stream3));
         HIP_TRY(c, hipEventRecord(c->ev_join4, c->stream4));
-        if (early_readback && !c->have_bed) {
-            // rsqc_finalize of ONE context: everything the fragment kernels (K4, still running on the main stream) do not write --
+        if (early_readback) {
+            // rsqc_finalize of ONE context: everything the fragment kernels (K4, still running on the main stream; K5 behind it) do not write --
             // all of the arena but geneFragmentCounts and the status words -- crosses PCIe NOW, behind the coverage kernels on their
             // stream, instead of behind K4 (the 9 MB copy was 0.17 ms at the end of every pass); read_back then fetches the rest
             const size_t frag_lo = c->off_u64 + (size_t)2 * (size_t)c->n_genes * 8, frag_hi = frag_lo + (size_t)c->n_genes * 8;
