@@ -146,8 +146,9 @@ def _feed_lib():
 BGZF_BLOCK = np.dtype([("in_offset", "<u8"), ("in_bytes", "<u4"), ("out_bytes", "<u4"), ("crc32", "<u4"), ("flags", "<u4")])
 
 
-def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 << 40, threads=2, cpu_share=None):
-    """[(compressed bytes, block table, skip, limit, last)] of a range, through BgzfFeeder."""
+def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 << 40, threads=2, cpu_share=None, reserve=None):
+    """[(compressed bytes, block table, skip, limit, last)] of a range, through BgzfFeeder.
+    reserve = (chunk_bytes, max_out): the buffers are set up before the range starts, as the command line does."""
     l = _feed_lib()
     h = l.host_feed_open(str(path).encode())
     assert h
@@ -157,6 +158,9 @@ def feed_chunks(path, voff_beg=None, voff_end=0, chunk_bytes=1 << 17, max_out=1 
     if cpu_share:                                  # (threads, initial share, largest share): blocks the CPU inflates arrive flagged BGZF_INFLATED
         l.host_feed_cpu_share.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         l.host_feed_cpu_share(h, *cpu_share)
+    if reserve:
+        l.host_feed_reserve.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong]
+        assert l.host_feed_reserve(h, int(reserve[0]), int(reserve[1])) == 0, l.host_feed_error(h)
     assert l.host_feed_start(h, voff_beg, voff_end, chunk_bytes, max_out, threads) == 0
     out = []
     while True:

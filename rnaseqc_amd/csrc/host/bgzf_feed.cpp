@@ -113,8 +113,29 @@ uint64_t BgzfFeeder::first_record_voffset(std::vector<std::string> *names) {
     return 0;
 }
 
-void BgzfFeeder::reserve(size_t chunk_bytes) {
+double BgzfFeeder::sample_ratio() {
+    if (fd_ < 0 || !file_size_) return 0;
+    const size_t n = (size_t)std::min<uint64_t>(file_size_, (uint64_t)8 << 20);
+    std::vector<uint8_t> buf(n);
+    size_t got = 0;
+    while (got < n) { const ssize_t g = pread(fd_, buf.data() + got, n - got, (off_t)got); if (g <= 0) break; got += (size_t)g; }
+    uint64_t in = 0, out = 0;
+    try {
+        for (size_t p = 0; p < got;) {
+            const uint32_t bs = block_size(buf.data() + p, got - p);
+            if (!bs || p + bs > got) break;
+            in += bs; out += le32(buf.data() + p + bs - 4); p += bs;
+        }
+    } catch (std::exception &) { return 0; }
+    return in ? (double)out / (double)in : 0;
+}
+
+void BgzfFeeder::reserve(size_t chunk_bytes, uint64_t max_out) {
     size_t cap = (size_t)std::min<uint64_t>(std::max<size_t>(chunk_bytes, (size_t)1 << 17), std::max<uint64_t>(file_size_, (uint64_t)1 << 17));
+    if (max_out) {
+        const double r = sample_ratio();
+        if (r > 0) cap = std::min(cap, std::max<size_t>((size_t)((double)max_out / r * 1.15) + ((size_t)4 << 20), (size_t)1 << 17));
+    }
     if (cpu_threads_) cap += raw_cap_ + 256;
     for (auto &c : ring_) {
         if (c.data && c.cap >= cap) continue;
@@ -124,6 +145,7 @@ void BgzfFeeder::reserve(size_t chunk_bytes) {
         if (!c.data) throw std::bad_alloc();
         c.cap = cap;
     }
+    reserved_ = max_out != 0;           // (without it the buffers may still grow with the ramp, as in a sharded run's per-contig ranges)
 }
 
 void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes, uint64_t max_out) {
@@ -142,7 +164,7 @@ void BgzfFeeder::start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes,
     // (a chunk never needs more than what is left of the file; the buffers are page-locked by the read-ahead thread the first
     //  time it fills them, so that pinning the second one overlaps the GPU's work on the first)
     chunk_bytes_ = (size_t)std::min<uint64_t>(chunk_bytes_, std::max<uint64_t>(file_size_ - std::min(file_size_, cpos_), (uint64_t)1 << 17));
-    n_filled_ = 0;
+    n_filled_ = 0; ratio_ = 0;
     head_ = tail_ = count_ = 0; lent_ = nullptr; eof_ = false; stop_ = false; error_.clear();
     th_ = std::thread([this] { producer(); });
 }
@@ -155,7 +177,15 @@ bool BgzfFeeder::fill(Chunk &c) {
     // thousands of blocks)
     const size_t ramp = std::min<size_t>(chunk_bytes_, ((size_t)24 << 20) << std::min(n_filled_, 8));
     ++n_filled_;
-    const size_t want = (size_t)std::min<uint64_t>(ramp, file_size_ - cpos_);
+    // ... and no larger than what max_out_ inflated bytes take in the file at the ratio of the chunk before: what a call cannot
+    // hold would be read again by the next one (a 12 x compressed file fills a 1 GB call from 90 MB)
+    size_t cap_by_out = chunk_bytes_;
+    if (ratio_ > 0) cap_by_out = (size_t)std::min<double>((double)chunk_bytes_, (double)max_out_ / ratio_ * 1.06 + (double)(1u << 20));
+    size_t want = (size_t)std::min<uint64_t>(std::min(ramp, std::max<size_t>(cap_by_out, (size_t)1 << 17)), file_size_ - cpos_);
+    {   // buffers sized by reserve() are not grown in the loop (page-locking stalls the thread that feeds the GPU): a smaller call instead
+        const size_t room = cpu_threads_ ? raw_cap_ + 256 : 0;
+        if (reserved_ && c.data && c.cap > room + ((size_t)1 << 17)) want = std::min(want, c.cap - room);
+    }
     if (!c.data || c.cap < want + (cpu_threads_ ? raw_cap_ + 256 : 0)) {
         if (c.data) { if (c.pinned) rsqc_host_free(c.data); else free(c.data); }
         const size_t cap = std::min(chunk_bytes_, std::max(want, ramp * 4)) + (cpu_threads_ ? raw_cap_ + 256 : 0);      // (room for the next steps of the ramp)
@@ -200,6 +230,7 @@ bool BgzfFeeder::fill(Chunk &c) {
         throw std::runtime_error("BGZF block larger than the read chunk");
     }
     c.bytes = p; c.total_bytes = p; cpos_ += p;
+    if (p) ratio_ = (double)total_out / (double)p;
     // ---- the CPU's share: the last blocks of the chunk, inflated here into the buffer behind the file bytes
     const double share = share_.load();
     if (cpu_threads_ && share > 0 && !c.blocks.empty()) {

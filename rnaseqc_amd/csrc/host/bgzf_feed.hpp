@@ -36,7 +36,10 @@ public:
     uint64_t first_record_voffset(std::vector<std::string> *names = nullptr);
     // page-locks the three chunk buffers now (else: by the read-ahead thread when it first fills them -- page-locking takes
     // the HIP runtime's lock, and the thread that feeds the GPU stalls behind it)
-    void reserve(size_t chunk_bytes);
+    // max_out (0 = unknown): the inflated bytes a call holds at most -- with it the buffers are sized for what that takes in THIS file
+    // (its compression sampled from the first megabytes) instead of for chunk_bytes; a later stretch of the file that compresses
+    // less then makes smaller calls, not larger buffers
+    void reserve(size_t chunk_bytes, uint64_t max_out = 0);
     // the blocks from virtual offset `beg` to `end` (0 = end of file); starts the read-ahead thread
     void start(uint64_t voff_beg, uint64_t voff_end, size_t chunk_bytes = (size_t)128 << 20, uint64_t max_out = (uint64_t)1024 << 20);
     // next chunk, or nullptr at the end; the previous chunk becomes reusable.  Throws on a malformed block header.
@@ -56,6 +59,9 @@ private:
     int fd_ = -1; uint64_t file_size_ = 0;
     uint64_t cpos_ = 0, cend_ = 0; uint32_t skip_ = 0, uend_ = 0; bool done_ = false, has_end_ = false;
     size_t chunk_bytes_ = 0; uint64_t max_out_ = 0; int n_filled_ = 0;
+    double ratio_ = 0;                 // inflated / file bytes of the chunk before (0: none yet)
+    bool reserved_ = false;            // reserve() sized the buffers: fill() stays inside them
+    double sample_ratio();             // inflated / file bytes over the first megabytes (0: unreadable)
     Chunk ring_[3];
     int head_ = 0, tail_ = 0, count_ = 0; Chunk *lent_ = nullptr;
     bool eof_ = false, stop_ = false; std::string error_;

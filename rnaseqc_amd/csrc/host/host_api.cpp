@@ -143,6 +143,12 @@ HAPI unsigned long long host_feed_first_voffset(void *hv) {
     try { return h->feed.first_record_voffset(); } catch (std::exception &e) { h->error = e.what(); return ~0ull; }
 }
 HAPI void host_feed_cpu_share(void *hv, int threads, double initial_share, double max_share) { ((FeedHandle *)hv)->feed.set_cpu_share(threads, initial_share, max_share); }
+// page-locks (or, without a device, allocates) the chunk buffers now; max_out != 0: sized for this file's compression, never grown
+HAPI int host_feed_reserve(void *hv, unsigned long long chunk_bytes, unsigned long long max_out) {
+    FeedHandle *h = (FeedHandle *)hv;
+    try { h->feed.reserve((size_t)chunk_bytes, max_out); return 0; }
+    catch (std::exception &e) { h->error = e.what(); return -1; }
+}
 HAPI int host_feed_start(void *hv, unsigned long long voff_beg, unsigned long long voff_end, unsigned long long chunk_bytes, unsigned long long max_out, int read_threads) {
     FeedHandle *h = (FeedHandle *)hv;
     try { h->feed.read_threads = read_threads; h->feed.start(voff_beg, voff_end, (size_t)chunk_bytes, max_out); return 0; }

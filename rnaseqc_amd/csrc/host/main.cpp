@@ -225,11 +225,13 @@ uint64_t decode_reserve_bytes(uint64_t file_size) {
 // rsqc_decode_submit.  on_window sees what each call decoded.  Returns an RSQC_* code; info describes the whole stream.
 template <class F>
 int decode_range(rsqc_ctx *gpu, BgzfFeeder &feed, const rsqc_decode_params &dp, uint64_t voff_beg, uint64_t voff_end, rsqc_decode_info &info, F &&on_window) {
-    // Calls are large on purpose: the inflate kernel runs one wave per BGZF block, sixteen waves per CU -- a call needs
-    // thousands of blocks to fill the chip: up to 1 GB of inflated data (128 MB of file) per call, the device buffers sized for that once.
+    // Calls are large on purpose: the inflate kernel runs one wave per BGZF block, twenty waves per CU = 5 120 on the chip, and a
+    // call's time is that of its LAST block: a call of 5 300 blocks (128 MB of a file compressed 3 x, round 4's chunk) runs 180 of
+    // them on an empty chip.  Up to 1 GB of inflated data = 16 000 blocks per call whatever the file's compression (the feeder reads
+    // what that takes, up to 512 MB of file), the device buffers sized for that once (profiles/r5_decode_chunk_sweep.txt).
     // (RSQC_DECODE_CHUNK / RSQC_DECODE_MAX_OUT: compressed bytes read per call at most / inflated bytes per call -- the tests use
     //  small values so that records straddle many calls)
-    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
+    const size_t chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)512 << 20;
     const uint64_t max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1024 << 20;
     rsqc_decode_params dpr = dp;
     dpr.pipelined = 1;                          // a call's records are reported by the call after it (the last by rsqc_decode_end)
@@ -400,7 +402,7 @@ int main(int argc, char **argv) {
             const int spare = effective_cpus() - 4;
             return getenv("RSQC_DECODE_CPU_THREADS") ? atoi(getenv("RSQC_DECODE_CPU_THREADS")) : (spare >= 4 ? spare : 0);
         };
-        const size_t feeder_chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)128 << 20;
+        const size_t feeder_chunk = getenv("RSQC_DECODE_CHUNK") ? (size_t)atoll(getenv("RSQC_DECODE_CHUNK")) : (size_t)512 << 20;
         const bool feeder_prepin = !(getenv("RSQC_FEED_PREPIN") && !atoi(getenv("RSQC_FEED_PREPIN")));
         std::unique_ptr<BgzfFeeder> early_feed;
         std::future<bool> early_feed_ready;
@@ -408,11 +410,14 @@ int main(int argc, char **argv) {
             early_feed.reset(new BgzfFeeder());
             BgzfFeeder *ef = early_feed.get();
             const int ct = feeder_cpu_threads();
-            early_feed_ready = std::async(std::launch::async, [ef, bam_path, ct, feeder_chunk] {
+            const uint64_t feeder_max_out = getenv("RSQC_DECODE_MAX_OUT") ? (uint64_t)atoll(getenv("RSQC_DECODE_MAX_OUT")) : (uint64_t)1024 << 20;
+            early_feed_ready = std::async(std::launch::async, [ef, bam_path, ct, feeder_chunk, feeder_max_out] {
                 try {
                     if (!ef->open(bam_path)) return false;
-                    if (ct > 0) ef->set_cpu_share(ct);
-                    ef->reserve(feeder_chunk);
+                    // (the room behind a chunk's file bytes is page-locked for the largest share the CPUs can reach: 12 threads have
+                    //  settled at 0.10-0.25 of a call on every file measured; 0.5 only where there are the threads for it)
+                    if (ct > 0) ef->set_cpu_share(ct, 0.15, std::min(0.5, std::max(0.1, 0.025 * ct)), feeder_max_out);
+                    ef->reserve(feeder_chunk, feeder_max_out);
                     return true;
                 } catch (std::exception &) { return false; }
             });

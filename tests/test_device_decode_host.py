@@ -233,6 +233,32 @@ def test_feeder_whole_file_and_contig_ranges(tmp_path, chunk_bytes, max_out):
         np.testing.assert_array_equal(d.aux["qhash"], batch.qhash[lo:hi])
 
 
+def test_feeder_sizes_its_calls_by_the_files_compression(tmp_path):
+    """A call holds max_out inflated bytes whatever the file's compression: the feeder reads what that takes at the ratio of the chunk
+    before (not chunk_bytes of a file compressed 12 x, most of which the call could not hold and the next one would read again), and
+    buffers set up in advance for the file's sampled ratio are not outgrown -- a call gets smaller instead.  The stream is the same."""
+    contigs = [("chrA", 3_000_000), ("chrB", 1_000_000)]
+    ann = synth.make_annotation(seed=35, contigs=[("chrA", 3_000_000, 120), ("chrB", 1_000_000, 40)])
+    batch = synth.make_reads(ann, 60_000, seed=36, keep_qnames=True, contig_lengths=np.array([3_000_000, 1_000_000]))
+    for mode in (0, 1):
+        path = str(tmp_path / ("r%d.bam" % mode))
+        bamio.write_bam_fast(path, contigs, batch, threads=3, seq_mode=mode)
+        size = os.path.getsize(path)
+        plain = _inflate_chunks(feed_chunks(path, chunk_bytes=1 << 20))
+        max_out = 2 << 20
+        for reserve in (None, (size, max_out), (1 << 18, max_out), (size, max_out, (2, 0.2, 0.5))):
+            share = reserve[2] if reserve and len(reserve) > 2 else None
+            chunks = feed_chunks(path, chunk_bytes=size, max_out=max_out, reserve=reserve[:2] if reserve else None, cpu_share=share)
+            assert _inflate_chunks(chunks) == plain
+            outs = [int(c[1]["out_bytes"].sum()) for c in chunks]
+            assert all(o <= max_out for o in outs)
+            if reserve is None or reserve[0] == size:
+                # steady state: calls filled to within two blocks of max_out, from file bytes that are a fraction of chunk_bytes
+                assert len(chunks) >= 4 and all(o > max_out - 2 * 65536 for o in outs[1:-1])
+                file_bytes = [int((c[1]["in_offset"][-1] + c[1]["in_bytes"][-1]) if not (c[1]["flags"] & abi.BGZF_INFLATED).any() else 0) for c in chunks]
+                assert all(fb < size // 2 for fb in file_bytes)
+
+
 def test_feeder_cpu_share(tmp_path):
     """The feeder inflates the tail of every chunk on CPU threads (RSQC_BGZF_INFLATED blocks behind the file bytes): one run at
     the end of the table, bytes one after the other, and the stream is the same."""

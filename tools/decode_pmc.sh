@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (counters only, each its own rocprofv3 run) of the CLI in device-decode mode on a synthetic BAM
 # -> gpurun_out/prof/$TAG/summary.txt (mean per launch, per kernel).
-# usage: TAG=x PAIRS=3000000 SEQ_MODE=1 SET1="A B" SET2="C D" tools/decode_pmc.sh
+# usage: TAG=x PAIRS=3000000 SEQ_MODE=1 SET1="A B" SET2="C D" [SET3="E F"] tools/decode_pmc.sh
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof/${TAG:-dpmc}
 mkdir -p $OUT
@@ -17,7 +17,7 @@ print("records", batch.n)
 PY
 cd /tmp
 i=0
-for set in "${SET1:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES}" "${SET2:-SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY}"; do
+for set in "${SET1:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES}" "${SET2:-SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY}" ${SET3:+"$SET3"}; do
   i=$((i+1))
   RSQC_DECODE=device RSQC_DECODE_CPU_THREADS=0 timeout ${PMC_TIMEOUT:-25} rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- $GRAFT_REPO_ROOT/rnaseqc_amd/bin/rnaseqc /tmp/dk.gtf /tmp/dk.bam /tmp/dk_out > $OUT/p$i.log 2>$OUT/p$i.err
   echo "pass $i ($set): rc $?" >> $OUT/passes.txt
