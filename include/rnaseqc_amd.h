@@ -562,7 +562,9 @@ RSQC_API int rsqc_decode_begin(rsqc_ctx *ctx, const rsqc_decode_params *p);
  * in-block part of a virtual file offset) -- only in a call that starts on a record boundary.
  * limit_bytes: 0, or the inflated offset (counted from the first block of THIS call) at which the wanted range ends:
  * records that start there or later are left out.  out (may be NULL): what the call decoded.
- * Limits per call: 1.9 GiB of inflated data.                                                                      */
+ * Limits per call: 1.9 GiB of inflated data.  Size the calls by their BLOCKS, not by their file bytes: one wavefront inflates one
+ * block and an MI355X holds 5 120 of them, so a call should carry several times that many (the command line: 1 GiB of inflated
+ * data, about 16 000 blocks); a call with about as many blocks as wave slots takes as long as one block takes one wave.       */
 RSQC_API int rsqc_decode_submit(rsqc_ctx *ctx, const void *compressed, uint64_t compressed_bytes,
                                 const rsqc_bgzf_block *blocks, uint32_t n_blocks,
                                 uint32_t skip_bytes, uint64_t limit_bytes, rsqc_decode_window *out);
