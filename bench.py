@@ -127,8 +127,20 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
             for rep in range(reps):
                 odir = os.path.join(d, "out_%s_%d" % (tag, rep))
                 t = time.time()
-                p = subprocess.run([exe, gtf, bam_path, odir, "-vv"] + extra, env=dict(env, RSQC_DECODE=mode), capture_output=True, text=True)
+                p = subprocess.run([exe, gtf, bam_path, odir, "-vv"] + extra, env=dict(env, RSQC_DECODE=mode, RSQC_DECODE_PROFILE="1"), capture_output=True, text=True)
                 wall = time.time() - t
+                # the decode calls of the run (hipEvents around the kernels of every rsqc_decode_submit, summed by the library; one GPU)
+                dp = None
+                pr = [x for x in re.findall(r"\[decode\] (\d+) calls, ([0-9.]+) MB in, ([0-9.]+) MB inflated: copy ([0-9.]+) ms, inflate ([0-9.]+) ms \(([0-9.]+) GB/s out\), "
+                                            r"frame\+parse ([0-9.]+) ms", p.stderr) if int(x[0]) > 0]
+                if len(pr) == 1:
+                    c, mb_in, mb_out, _cp, inf_ms, gbps, fp_ms = pr[0]
+                    sh = re.search(r"CPU share of the inflate work at the end ([0-9.]+); ([0-9.]+) ms waiting for file chunks", p.stderr)
+                    dp = {"calls": int(c), "uploaded_MB": float(mb_in), "inflated_MB": float(mb_out), "inflate_kernels_ms": float(inf_ms),
+                          "inflate_GBps_of_inflated_bytes": float(gbps), "frame_parse_kernels_ms": float(fp_ms),
+                          "bgzf_blocks_per_call": int(float(mb_out) * 1e6 / 65280 / max(int(c), 1)),
+                          "cpu_share_of_blocks": float(sh.group(1)) if sh else None, "waiting_for_file_ms": float(sh.group(2)) if sh else None,
+                          "note": "one wavefront inflates one BGZF block; the chip holds 5 120 of the kernel's waves (DESIGN.md 6b)"}
                 m = re.search(r"Average Reads/Sec: ([0-9.e+]+)", p.stdout)
                 e = re.search(r"Time Elapsed: ([0-9.e+-]+); Alignments processed: (\d+)", p.stdout)
                 th = re.search(r"decode threads: (\d+) inflate \+ (\d+) parse", p.stdout)
@@ -139,7 +151,7 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
                                                           (round(float(x), 3) for x in wb.groups()))) if wb else None,
                              "alignments": int(e.group(2)) if e else None,
                              "reads_per_s": float(m.group(1)) if m else None,
-                             "decode": "device" if "on the GPU" in p.stdout else "host",
+                             "decode": "device" if "on the GPU" in p.stdout else "host", "decode_profile": dp,
                              "decode_threads": [int(th.group(1)), int(th.group(2))] if th else None, "odir": odir})
                 if p.returncode:
                     log("end_to_end: rnaseqc (%s decode) exited %d: %s" % (mode, p.returncode, p.stderr[-400:]))
@@ -149,7 +161,7 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
         best, runs = cli_runs(bam, "device", "dev")
         host_best, _hr = cli_runs(bam, "host", "host")
         out.update({"value": best["reads_per_s"], "unit": "reads/s", "bam_loop_s": best["bam_loop_s"], "wall_s": best["wall_s"],
-                    "alignments": best["alignments"], "decode": best["decode"], "runs": runs, "wall_breakdown_s": best.get("wall_breakdown_s"),
+                    "alignments": best["alignments"], "decode": best["decode"], "decode_profile": best.get("decode_profile"), "runs": runs, "wall_breakdown_s": best.get("wall_breakdown_s"),
                     "host_decode": {"value": host_best["reads_per_s"], "unit": "reads/s", "decode_threads": host_best["decode_threads"],
                                     "note": "RSQC_DECODE=host: libdeflate inflate + record parsing on the CPU threads, batches over PCIe"},
                     "window": "CLI `Average Reads/Sec` = alignments / (BAM loop incl. end-of-file stage), src/RNASeQC.cpp:240-241,389-394",
@@ -173,7 +185,7 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
                 same = all(open(os.path.join(b2["odir"], "r.bam." + f), "rb").read() == open(os.path.join(h2["odir"], "r.bam." + f), "rb").read()
                            for f in ("metrics.tsv", "gene_reads.gct", "gene_fragments.gct", "exon_reads.gct", "gene_tpm.gct"))
             out["realistic_entropy"] = {"value": b2["reads_per_s"], "unit": "reads/s", "records": int(sub.n), "bam_bytes": os.path.getsize(bam2),
-                                        "decode": b2["decode"], "host_decode": h2["reads_per_s"],
+                                        "decode": b2["decode"], "decode_profile": b2.get("decode_profile"), "host_decode": h2["reads_per_s"],
                                         "parity": same, "against": "the host-decode run of the same file: report files byte for byte",
                                         "bam": "random bases, binned Phred-like qualities with runs: %.1f B/record compressed" %
                                                (os.path.getsize(bam2) / max(sub.n, 1))}
@@ -467,6 +479,9 @@ def main():
                 "wall_s": e2e.get("wall_s"), "bam_loop_s": e2e.get("bam_loop_s"),
                 "realistic_entropy_value": (e2e.get("realistic_entropy") or {}).get("value"),
                 "realistic_entropy_parity": (e2e.get("realistic_entropy") or {}).get("parity"),
+                # the loop's dominant kernel: GB/s of inflated bytes out of bgzf_inflate_kernel, the two files (end_to_end.*.decode_profile)
+                "inflate_GBps": [(e2e.get("decode_profile") or {}).get("inflate_GBps_of_inflated_bytes"),
+                                 ((e2e.get("realistic_entropy") or {}).get("decode_profile") or {}).get("inflate_GBps_of_inflated_bytes")],
                 "note": "`rnaseqc gtf bam out` on a BAM of the same records: BGZF inflate + BAM parse on the GPU + the hot path + end-of-file stage; details in end_to_end"},
             "end_to_end": e2e,
             "collective_ms": (1e3 * collective_s[0] / max(args.steps, 1)) if reduce_path else None,   # per step: 3 async all_reduce + 2 gathers + host merge
