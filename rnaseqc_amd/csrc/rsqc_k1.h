@@ -58,6 +58,7 @@ __device__ __forceinline__ const K1Args *k1e_lazy_args() {
 #else
 static const K1Args *g_k1e_args = nullptr;       // (host emulation: set by the harness)
 static unsigned long long g_k1e_coarse_hits = 0;
+static unsigned long long g_k1e_ucache_hits = 0;     // (test harness: ... of which the interval came from the wave's one-entry cache)
 static unsigned long long g_k1e_uniform_calls = 0;   // (test harness: one-block feature-stage calls answered by the wave-uniform path)
 static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
@@ -114,12 +115,19 @@ struct K1eTables {
     uint32_t pairs;                              // pairs in the workgroup's chunk
     uint32_t frags;                              // fragment-size candidates in the workgroup's region (BED runs)
     uint32_t piece;                              // next piece of the workgroup's range to hand to a wave
+    // The last elementary interval a wave's uniform path (k1e_uniform1) looked up: [lo, hi) and its index entry.  The queued records are
+    // neighbours in the sorted stream, and so are consecutive CALLS: on the contract workload 56 % of the one-block calls lie in the
+    // interval of the call before them (tools/uniform_tiles.py) -- those take their interval from here, two LDS reads, instead of two
+    // dependent scalar loads from the index.  One entry per wave (a wave reads what it wrote itself: no tearing), emptied when the
+    // wave's stream enters another contig.  (The one-entry form of the interval window in LDS that north_star names.)
+    alignas(16) uint32_t ucache[K1E_WAVES][12];  // EiEntry (8 words), lo, hi, 2 unused
     __device__ __forceinline__ void init(uint32_t pairs0) {
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
         if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
         for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
         if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; piece = 0u; frags = 0u; }
+        if (threadIdx.x < K1E_WAVES) { ucache[threadIdx.x][8] = 1u; ucache[threadIdx.x][9] = 0u; }            // [1, 0): holds no position
     }
     __device__ __forceinline__ void exon_add(uint32_t eid, double frac) {
         const uint32_t slot = eid & (K1E_ESLOTS - 1);
@@ -308,7 +316,17 @@ __device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
 #ifndef K1E_UNIFORM1
 #define K1E_UNIFORM1 1
 #endif
+#ifndef K1E_UCACHE
+#define K1E_UCACHE 1                         /* the uniform path asks the wave's last interval (LDS) before the index */
+#endif
 struct K1eInterval { EiEntry S; int32_t next_pos; };          // (wave-uniform)
+// what one lane of the wave stored to LDS is read by all of them behind this point (the hardware runs a wave's LDS traffic in order;
+// this keeps the COMPILER from moving a lane's loads across another lane's store, and lines the lanes of the host emulation up)
+__device__ __forceinline__ void k1e_wave_lds_visible() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // the interval of position x0 and the start of the one behind it, by scalar loads
 __device__ __forceinline__ K1eInterval k1e_interval_of(const DevAnnotation &a, const ContigInfo &ci, int32_t x0) {
     const int32_t top = (int32_t)(ci.rk_words << 6) - 1;
@@ -343,14 +361,42 @@ __device__ __forceinline__ void k1e_count_at(WaveSink &cnt, int counter, uint32_
 // true: the call was handled here.  `onm`: lanes that hold a record (the low n lanes).
 __device__ __forceinline__ bool k1e_uniform1(const DevAnnotation &a, const DevParams &p, uint32_t *cov_diff, const ContigInfo &ci, K1eTables &T,
                                              int32_t bs, uint32_t len, uint32_t flhq, uint64_t qhash, uint32_t qh2, uint64_t onm,
-                                             WaveSink &cnt, const K1ePairDst &held) {
+                                             WaveSink &cnt, const K1ePairDst &held, int wave) {
     typedef WaveSink WS;
     if (p.stranded != RSQC_STRAND_UNKNOWN || ci.rk_words == 0u) return false;
-    const K1eInterval iv = k1e_interval_of(a, ci, (int32_t)lane_value((uint32_t)bs, 0));      // (lane 0 holds a record: n >= 1)
-    const EiEntry &S = iv.S;
-    if (S.mask & EIM_DEEP) return false;
-    const int32_t lo = S.pos, hi = iv.next_pos > S.pos ? iv.next_pos : 0x7FFFFFFF;              // (next_pos <= pos: the contig's last interval)
-    if ((WS::prim(bs < lo || (int32_t)(bs + (int32_t)len) >= hi).m & onm) != 0ull) return false;
+    uint32_t *const uc = T.ucache[wave]; (void)uc;
+    EiEntry S;
+    bool cached = false;
+#if K1E_UCACHE
+    {   // the interval of the call before this one (K1eTables::ucache): the same one more often than not
+        const int32_t lo = (int32_t)__builtin_amdgcn_readfirstlane((int)uc[8]), hi = (int32_t)__builtin_amdgcn_readfirstlane((int)uc[9]);
+        cached = (WS::prim(bs < lo || (int32_t)(bs + (int32_t)len) >= hi).m & onm) == 0ull;
+        if (cached) {
+            const uint4 e0 = *reinterpret_cast<const uint4 *>(uc), e1 = *reinterpret_cast<const uint4 *>(uc + 4);
+#define K1E_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+            S = EiEntry{(int32_t)K1E_U(e0.x), K1E_U(e0.y), K1E_U(e0.z), K1E_U(e0.w), K1E_U(e1.x), K1E_U(e1.y), K1E_U(e1.z), K1E_U(e1.w)};
+#undef K1E_U
+#if defined(RSQC_WAVE_EMU)
+            if (lane_id() == 0) ++g_k1e_ucache_hits;
+#endif
+        }
+    }
+#endif
+    if (!cached) {
+        const K1eInterval iv = k1e_interval_of(a, ci, (int32_t)lane_value((uint32_t)bs, 0));      // (lane 0 holds a record: n >= 1)
+        S = iv.S;
+        if (S.mask & EIM_DEEP) return false;
+        const int32_t lo = S.pos, hi = iv.next_pos > S.pos ? iv.next_pos : 0x7FFFFFFF;              // (next_pos <= pos: the contig's last interval)
+        if ((WS::prim(bs < lo || (int32_t)(bs + (int32_t)len) >= hi).m & onm) != 0ull) return false;
+#if K1E_UCACHE
+        if (k1e_first_lane()) {
+            *reinterpret_cast<uint4 *>(uc) = make_uint4((uint32_t)S.pos, S.mask, S.eidA, S.eidB);
+            *reinterpret_cast<uint4 *>(uc + 4) = make_uint4(S.gfA, S.cdA, S.gfB, S.cdB);
+            *reinterpret_cast<uint2 *>(uc + 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+        }
+        k1e_wave_lds_visible();
+#endif
+    }
 #if defined(RSQC_WAVE_EMU)
     if (lane_id() == 0) ++g_k1e_uniform_calls;
 #endif
@@ -434,7 +480,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     const uint32_t qh2 = qh2col ? ld32(qh2col, idx) : 0u;        // (uniform branch: the batch carries second name hashes or it does not)
     WaveSink cnt;
     const uint64_t qhash = (uint64_t)qh.x | ((uint64_t)qh.y << 32);
-    if (NB != 1 || !K1E_UNIFORM1 || !k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, qhash, qh2, n >= 64u ? ~0ull : (1ull << n) - 1ull, cnt, held)) {
+    if (NB != 1 || !K1E_UNIFORM1 || !k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, qhash, qh2, n >= 64u ? ~0ull : (1ull << n) - 1ull, cnt, held, wave)) {
         EiOut eo; bool over = false;
         exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
         k1e_overflow(on && over, (uint64_t)idx);
@@ -666,6 +712,8 @@ classify_ei_kernel(K1Args A) {
         if (u_tid >= 0 && u_tid < a.n_contigs) u_ci = a.contig[u_tid];
         else u_ci = ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
         seg_next = seg + 1 < b.n_seg ? (uint32_t)b.seg_start[seg + 1] : NONE;
+        if (k1e_first_lane()) { S.T.ucache[wave][8] = 1u; S.T.ucache[wave][9] = 0u; }        // (the cached interval belongs to the contig the wave leaves)
+        k1e_wave_lds_visible();
     };
     load_contig();
     // A batch of several file ranges (rsqc_batch.seg_file_index: the contigs of one shard) keeps the Read-Length inputs per SEGMENT

@@ -90,6 +90,8 @@ def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=
     o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]); o.n_pairs = int(stats[2]); o.n_coarse = int(stats[3])
     lib.k1emu_uniform_calls.restype = C.c_ulonglong
     o.n_uniform = int(lib.k1emu_uniform_calls())
+    lib.k1emu_ucache_hits.restype = C.c_ulonglong
+    o.n_ucache_hits = int(lib.k1emu_ucache_hits())
     return o
 
 

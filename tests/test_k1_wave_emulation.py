@@ -219,6 +219,34 @@ def dense_case(seed, n_genes=7, n_reads=14000, span=2400):
     return ann, Batch.from_records(recs)
 
 
+def test_cached_interval_does_not_survive_a_contig_change(oracle_lib):
+    """The uniform path keeps the last interval it looked up per wave (K1eTables::ucache).  Positions start again on every contig: the
+    same coordinates that lie inside an exon on the first contig are intergenic on the second and inside another gene's exon on the
+    third -- a cached [lo, hi) carried across the boundary would count the later contigs' reads to the first contig's gene."""
+    from rnaseqc_amd.abi import CIG_M as M
+    rows = [dict(contig="a", type="gene", start=1000, end=3000, strand="+", gene_id="GA", gene_name="NA", transcript_type="protein_coding"),
+            dict(contig="a", type="exon", start=1000, end=3000, strand="+", gene_id="GA", exon_id="GA_e0", gene_name="NA", transcript_type="protein_coding"),
+            dict(contig="b", type="gene", start=9000, end=9500, strand="+", gene_id="GB", gene_name="NB", transcript_type="protein_coding"),
+            dict(contig="b", type="exon", start=9000, end=9500, strand="+", gene_id="GB", exon_id="GB_e0", gene_name="NB", transcript_type="protein_coding"),
+            dict(contig="c", type="gene", start=900, end=3100, strand="-", gene_id="GC", gene_name="NC", transcript_type="protein_coding"),
+            dict(contig="c", type="exon", start=900, end=3100, strand="-", gene_id="GC", exon_id="GC_e0", gene_name="NC", transcript_type="protein_coding")]
+    ann = Annotation.from_rows(["a", "b", "c"], rows)
+    rng = np.random.default_rng(5)
+    recs = []
+    for tid in range(3):
+        for pos in np.sort(rng.integers(1200, 2600, 700)):
+            recs.append(dict(qname="q%d_%d" % (tid, len(recs) // 2), tid=tid, pos=int(pos), cigar=[(M, 40)], flag=0x1 | 0x2 | (0x40 if len(recs) % 2 else 0x80),
+                             mapq=255, nm=0, mpos=int(pos) + 50, mtid=tid))
+    batch = Batch.from_records(recs)
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [batch])
+    assert list(want.gene_reads) == [700, 0, 700]
+    for grid in (1, 2):
+        o = hostemu.run_k1(p, ann, batch, grid=grid, want_cov=False, coarse=False)
+        _compare(o, want)
+        assert o.n_ucache_hits >= 8, (o.n_ucache_hits, o.n_uniform)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_dense_one_block_tiles_take_the_uniform_path(oracle_lib, seed):
     ann, batch = dense_case(700 + seed)
@@ -231,6 +259,7 @@ def test_dense_one_block_tiles_take_the_uniform_path(oracle_lib, seed):
             _compare(o, want, ref.cov)
             if "stranded" not in kw:
                 assert o.n_uniform >= 40, o.n_uniform        # (of ~190 one-block calls)
+                assert 10 <= o.n_ucache_hits < o.n_uniform, (o.n_ucache_hits, o.n_uniform)    # ... many in the interval of the call before
             else:
-                assert o.n_uniform == 0                     # --stranded: the containing exons are a per-lane property
+                assert o.n_uniform == 0 and o.n_ucache_hits == 0     # --stranded: the containing exons are a per-lane property
     assert want.gene_reads.sum() > 300 and want.counters[abi.COUNTER_NAMES.index("rRNA Reads")] > 0

@@ -33,3 +33,18 @@ order = np.argsort(b.qhash, kind="stable"); hs = b.qhash[order]
 same = hs[1:] == hs[:-1]
 d = np.abs(order[1:][same] - order[:-1][same])
 print("records between the mates of a fragment: median %d, 90 %% below %d, 99 %% below %d" % (np.median(d), np.percentile(d, 90), np.percentile(d, 99)))
+# ... and of those, how many lie in the SAME interval as the uniform call before them (what a one-entry cache of the last interval
+# answers without touching the index), in file order and in the order of a wave that takes every fourth piece of four tiles
+uni = js.min(1) == je.max(1)
+iv = js.min(1)
+prev_same = np.zeros(len(uni), bool); prev_same[1:] = uni[1:] & uni[:-1] & (iv[1:] == iv[:-1])
+print("uniform calls that repeat the interval of the call before them: %.1f %% of all one-block calls (%.1f %% of the uniform ones)" %
+      (100 * prev_same.mean(), 100 * prev_same.sum() / max(uni.sum(), 1)))
+last = {}
+hits = 0
+for k in range(len(uni)):
+    if uni[k]:
+        # the last uniform interval seen, whatever lay between (the cache is only rewritten by a uniform call that missed)
+        if last.get(0) == iv[k]: hits += 1
+        last[0] = iv[k]
+print("... with non-uniform calls in between not clearing the cache: %.1f %% of all one-block calls" % (100.0 * hits / len(uni)))
