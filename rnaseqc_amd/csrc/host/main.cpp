@@ -607,7 +607,8 @@ int main(int argc, char **argv) {
                     feeders.back()->set_cpu_share(std::max(1, cpu_share_threads / (int)shards.size()), 0.15, 0.5, ((uint64_t)1 << 30) / shards.size());
                 if (feeder_prepin) feeders.back()->reserve(shards.size() == 1 ? feeder_chunk : std::max<size_t>(feeder_chunk / shards.size(), (size_t)16 << 20));
             }
-            feeders[0]->read_threads = std::max(1, std::min(8, effective_cpus() / 2));
+            // (threads that read one chunk's slices side by side; RSQC_FEED_READ_THREADS overrides)
+            feeders[0]->read_threads = getenv("RSQC_FEED_READ_THREADS") ? std::max(1, atoi(getenv("RSQC_FEED_READ_THREADS"))) : std::max(1, std::min(8, effective_cpus() / 2));
         }
         if (o.verbosity) cout << "Parsing bam..." << endl;
         const size_t BATCH = getenv("RSQC_BATCH") ? (size_t)atol(getenv("RSQC_BATCH")) : (size_t)1 << 21;
