@@ -71,7 +71,7 @@ struct UploadedBatch {
 // worst-case buffers go back to the pool -- so the memory held until rsqc_finalize is what was emitted (16 B per
 // (gene, name) pair, 28 B per fragment-size candidate, 32 B per GC candidate) plus the buffers of the batches in flight.
 struct PairBuf {                // (gene, qname-hash) pairs of one submitted batch
-    DevBuf gene, hash, h2, counts;  // h2: second name hashes (rsqc_batch.qhash2; zeros for a batch without); counts: [n_chunks] per K1 block, then [1] slow-path counter
+    DevBuf rec, counts;         // rec: PairRec[cap] {gene, second name hash (zero for a batch without rsqc_batch.qhash2), name hash}; counts: [n_chunks] per K1 block, then [1] slow-path counter
     uint64_t cap = 0;           // pair slots allocated
     uint32_t n_chunks = 0, chunk_cap = 0, slow_base = 0, slow_cap = 0;
     uint32_t counts_cap = 0;
@@ -142,7 +142,7 @@ struct rsqc_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int sticky = 0;
-    int k1_variant = 41, k1_grid = 256 * 16;  // workgroups of the per-read kernel (RSQC_K1_GRID overrides), set once at create
+    int k1_variant = 41, k1_grid = 256 * 20;  // workgroups of the per-read kernel (RSQC_K1_GRID overrides), set once at create: four rounds of five workgroups per CU
 
     // annotation (host copies needed at finalize)
     bool have_ann = false;
@@ -164,6 +164,7 @@ struct rsqc_ctx {
     // one device arena holds every small result vector (single memset at reset, single D2H at finalize):
     // u64[3G+K] | u64 bias3,bias5[L] | f64 exon_acc[E] | f64 gmean,gstd,gcv[L] | f64 ecv[E] | u8 gvalid[L] | u8 ecv_valid[E] | u8 exon_hit[E] | misc[64]
     DevBuf d_arena, d_cov, d_ovf_index, d_tiles;
+    DevBuf d_defer;                             // classify_ei_kernel's deferred list (per-workgroup regions, then the dense list): reused batch after batch (stream order)
     DevBuf d_ei_rank;                                   // rank table of the interval index
     char *h_arena = nullptr;                      // pinned host mirror
     size_t arena_bytes = 0, off_u64 = 0, off_exon = 0, off_gmean = 0, off_gstd = 0, off_gcv = 0, off_bias3 = 0,
@@ -436,10 +437,8 @@ int retire_completed(rsqc_ctx *c, bool all) {
         if (c->pair_arena.used + total > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_CAPACITY, "more than 2^32 (gene, name) pairs in one pass");
         int rc = arena_reserve(c, c->pair_arena, total);
         if (rc) return rc;
-        if (total) launch_pairs_append(c->stream, (const uint32_t *)pb.gene.p, (const uint64_t *)pb.hash.p, (const uint32_t *)pb.h2.p,
-                                       pb.chunk_cap, (const uint32_t *)pb.counts.p,
-                                       pb.n_chunks, pb.slow_base, pb.slow_cap, (uint32_t *)c->pair_arena.col[0].p + c->pair_arena.used,
-                                       (uint64_t *)c->pair_arena.col[1].p + c->pair_arena.used, (uint32_t *)c->pair_arena.col[2].p + c->pair_arena.used);
+        if (total) launch_pairs_append(c->stream, (const PairRec *)pb.rec.p, pb.chunk_cap, (const uint32_t *)pb.counts.p,
+                                       pb.n_chunks, pb.slow_base, pb.slow_cap, (PairRec *)c->pair_arena.col[0].p + c->pair_arena.used);
         c->pair_arena.used += total;
         pb.used = false;                       // (stream order: the append reads the buffer before a later batch writes it)
     }
@@ -481,11 +480,9 @@ PairBuf *acquire_pairs(rsqc_ctx *c, uint64_t cap, uint32_t n_counts, size_t *ind
             c->pair_pool[i].used = true; *index = i; return &c->pair_pool[i];
         }
     PairBuf pb;
-    if (hipMalloc(&pb.gene.p, (size_t)cap * 4) != hipSuccess) return nullptr;
-    if (hipMalloc(&pb.hash.p, (size_t)cap * 8) != hipSuccess) return nullptr;
-    if (hipMalloc(&pb.h2.p, (size_t)cap * 4) != hipSuccess) return nullptr;
+    if (hipMalloc(&pb.rec.p, (size_t)cap * sizeof(PairRec)) != hipSuccess) return nullptr;
     if (hipMalloc(&pb.counts.p, (size_t)n_counts * 4) != hipSuccess) return nullptr;
-    pb.gene.bytes = (size_t)cap * 4; pb.hash.bytes = (size_t)cap * 8; pb.h2.bytes = (size_t)cap * 4; pb.counts.bytes = (size_t)n_counts * 4;
+    pb.rec.bytes = (size_t)cap * sizeof(PairRec); pb.counts.bytes = (size_t)n_counts * 4;
     if (hipHostMalloc((void **)&pb.h_counts, (size_t)n_counts * 4, hipHostMallocDefault) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&pb.done, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&pb.kernels, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -518,12 +515,17 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     }
     // (gene, qname-hash) pairs of this batch: every K1 block owns a private chunk sized for the
     // worst case of its tiles (FAST_SET pairs per record); 1 M extra slots serve the slow path
-    // Workgroups: the context's grid for a batch that fills it; a smaller batch gets one round of the chip (256 CUs x 4) or 2048
+    // Workgroups: the context's grid for a batch that fills it; a smaller batch gets one round of the chip (256 CUs x 5) or 2048
     // records per workgroup, whichever is more -- with a workgroup per 256 records (round 4) a 0.8 M-record batch ran three rounds of
     // workgroups that each initialised and flushed their LDS tables for ONE tile per wave (profiles/r5_kernel_stats_dist_selftest_before.txt)
-    const int grid = (int)std::min<uint64_t>(tiles, std::min<uint64_t>((uint64_t)c->k1_grid, std::max<uint64_t>(1024, u->n / 2048)));
+    const int grid = (int)std::min<uint64_t>(tiles, std::min<uint64_t>((uint64_t)c->k1_grid, std::max<uint64_t>(1280, u->n / 2048)));
     const uint64_t total_waves = (uint64_t)grid * (RSQC_K1_THREADS / 64);
     const uint64_t per_wave = (((u->n + total_waves - 1) / total_waves) + 63ull) & ~63ull;   // as in the kernel
+    if (!c->dparams.legacy) {                  // the deferred list: a slot per record (a workgroup's region is its record range) + the dense list (whole calls of 64 per workgroup)
+        const size_t region_words = u->n + 64, list_words = u->n + 64 * (size_t)grid + 64;
+        if (c->d_defer.bytes < (region_words + list_words) * 4) { int rc = dev_alloc(c, c->d_defer, (region_words + list_words + u->n / 2) * 4, false); if (rc) return rc; }
+        c->acc.defer_index = (uint32_t *)c->d_defer.p; c->acc.defer_list = c->acc.defer_index + region_words;
+    }
     const uint64_t chunk_cap = per_wave * (RSQC_K1_THREADS / 64) * FAST_SET;
     // --legacy: every pair comes from the general kernel (one per gene a record is counted to; 4 per record is far
     // above what annotations produce -- beyond it the run fails with RSQC_ERR_CAPACITY)
@@ -541,7 +543,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     // (no per-batch memsets: every K1 workgroup writes its own chunk count, workgroup 0 zeroes the slow-path pair
     //  counter, and the overflow counter is re-armed by the last kernel of the previous batch / the reset kernel)
     DevAccum acc = c->acc;
-    acc.pair_gene = (uint32_t *)pb->gene.p; acc.pair_hash = (uint64_t *)pb->hash.p; acc.pair_h2 = (uint32_t *)pb->h2.p;
+    acc.pairs = (PairRec *)pb->rec.p;
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
     acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
     acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
@@ -680,7 +682,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->dparams.exclude_chimeric = params->exclude_chimeric;
     c->dparams.n_filter_tags = params->n_filter_tags;
     c->dparams.legacy = params->legacy ? 1 : 0;
-    c->pair_arena.n_col = 3; c->pair_arena.width[0] = 4; c->pair_arena.width[1] = 8; c->pair_arena.width[2] = 4;   // gene, name hash, second name hash
+    c->pair_arena.n_col = 1; c->pair_arena.width[0] = sizeof(PairRec);   // {gene, second name hash, name hash}
     c->frag_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->frag_arena.width[k] = w[k]; }   // ..., second name hash
     c->gc_arena.n_col = 7; { const size_t w[7] = {8, 8, 4, 4, 4, 4, 4}; for (int k = 0; k < 7; ++k) c->gc_arena.width[k] = w[k]; }   // ..., second name hash
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(16384, std::max(1, atoi(e)));
@@ -696,7 +698,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto *u : c->transient) free_batch(u);
     for (auto &b : c->upload_pool) b.release();
     for (auto &b : c->ann_bufs) b.release();
-    for (auto &pb : c->pair_pool) { pb.gene.release(); pb.hash.release(); pb.h2.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); if (pb.kernels) (void)hipEventDestroy(pb.kernels); }
+    for (auto &pb : c->pair_pool) { pb.rec.release(); pb.counts.release(); if (pb.h_counts) (void)hipHostFree(pb.h_counts); if (pb.done) (void)hipEventDestroy(pb.done); if (pb.kernels) (void)hipEventDestroy(pb.kernels); }
     for (auto &fb : c->frag_pool) { fb.file.release(); fb.qhash.release(); fb.name.release(); fb.endpos.release(); fb.fs.release(); fb.h2.release(); fb.count.release(); fb.r_file.release(); fb.r_qhash.release(); fb.r_name.release(); fb.r_endpos.release(); fb.r_fs.release(); fb.r_h2.release(); fb.r_counts.release(); if (fb.h_count) (void)hipHostFree(fb.h_count); }
     for (auto &gb : c->gc_pool) { gb.file.release(); gb.qhash.release(); gb.row.release(); gb.endpos.release(); gb.flag_lq.release(); gb.tid.release(); gb.h2.release(); gb.count.release(); if (gb.h_count) (void)hipHostFree(gb.h_count); }
     for (Arena *a : {&c->pair_arena, &c->frag_arena, &c->gc_arena}) for (int k = 0; k < a->n_col; ++k) a->col[k].release();
@@ -714,7 +716,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     for (auto &b : c->parked) b.release();
     free_sort_scratch(c->gc_scratch); free_sort_scratch(c->frag_scratch);
     c->d_ref_bits.release(); c->d_ref_off.release(); c->d_ref_len.release(); c->d_gc_bins.release(); c->d_exon_gc.release();
-    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
+    DevBuf *all[] = {&c->d_arena, &c->d_cov, &c->d_ovf_index, &c->d_tiles, &c->d_defer, &c->d_ei_rank, &c->d_table, &c->d_tab_off, &c->d_tab_cap};
     if (c->h_arena) (void)hipHostFree(c->h_arena);
     if (c->h_rl_raw) (void)hipHostFree(c->h_rl_raw);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -842,6 +844,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     acc.read_length = (int32_t *)(A + c->off_misc + 8);
     acc.error = (int *)(A + c->off_misc + 16);
     acc.rl_stats = (uint32_t *)(A + c->off_misc + 32);
+    acc.defer_total = (uint32_t *)(A + c->off_misc + 48);    // (zeroed with the arena, re-armed by the last kernel of every batch)
     acc.ovf_index = (uint64_t *)c->d_ovf_index.p; acc.ovf_cap = ovf_cap;
     c->have_ann = true;
     if ((rc = zero_accumulators(c))) return rc;
@@ -1104,7 +1107,7 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
                 const uint32_t used32 = (uint32_t)c->pair_arena.used;
                 HIP_TRY(c, hipMemcpyAsync(c->d_arena_count.p, &used32, 4, hipMemcpyHostToDevice, c->stream));
                 DevAccum acc = c->acc;
-                acc.pair_gene = (uint32_t *)c->pair_arena.col[0].p; acc.pair_hash = (uint64_t *)c->pair_arena.col[1].p; acc.pair_h2 = (uint32_t *)c->pair_arena.col[2].p;
+                acc.pairs = (PairRec *)c->pair_arena.col[0].p;
                 acc.pair_chunk_cap = 0; acc.pair_chunk_count = (uint32_t *)c->d_arena_count.p;
                 acc.pair_slow_base = 0; acc.pair_slow_cap = used32;
                 launch_frag_local(c->stream, acc, 0, P, (uint32_t)std::min<uint64_t>(4096, c->pair_arena.used / 1024 + 1));
@@ -1113,7 +1116,7 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
                 if (RSQC_DIAG("RSQC_DIAG_SKIP_K4")) break;                // (diagnostic build only: results incomplete)
                 PairBuf &pb = c->pair_pool[idx];
                 DevAccum acc = c->acc;
-                acc.pair_gene = (uint32_t *)pb.gene.p; acc.pair_hash = (uint64_t *)pb.hash.p; acc.pair_h2 = (uint32_t *)pb.h2.p;
+                acc.pairs = (PairRec *)pb.rec.p;
                 acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
                 acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;

@@ -102,6 +102,10 @@ __device__ __forceinline__ double gc_value(uint32_t k, uint64_t size) {
 }
 #endif
 
+// one (gene, read name) pair as the per-record kernels emit it.  Round 6: an array of these 16-byte structures -- ONE
+// global_store_dwordx4 per pair in the per-record kernel and one global_load_dwordx4 in frag_local_kernel -- instead of three columns
+// (three stores in front of every later vmcnt wait of the emitting wave: the pairs were 11.5 % of K1, profiles/r5_k1_variants.txt)
+struct alignas(16) PairRec { uint32_t gene, h2; uint64_t hash; };
 // accumulators (device pointers)
 struct DevAccum {
     unsigned long long *gene_reads, *gene_unique, *gene_frag, *counters;   // one allocation, in this order
@@ -109,11 +113,14 @@ struct DevAccum {
     uint32_t *cov_diff;          // per-base difference array / coverage
     // (gene, qname-hash) pairs of one batch: K1 block k owns [k*pair_chunk_cap, +pair_chunk_count[k]);
     // the slow path appends to [pair_slow_base, +*pair_slow_count)
-    uint32_t *pair_gene; uint64_t *pair_hash;
-    uint32_t *pair_h2;           // second name hash of the pair's record (rsqc_batch.qhash2, 0 without it; same indexing)
+    PairRec *pairs;              // {gene, second name hash (rsqc_batch.qhash2, 0 without it), name hash}: one 16-byte store per pair
     uint32_t pair_chunk_cap; uint32_t *pair_chunk_count;
     uint32_t pair_slow_base, pair_slow_cap; uint32_t *pair_slow_count;
     uint32_t *ovf_count; uint64_t *ovf_index; uint32_t ovf_cap;
+    // records classify_ei_kernel leaves to classify_long_kernel (more than eight operations / three blocks): a K1 workgroup lists them in
+    // ITS region of defer_index, from the first record of its range on -- no memory atomic (entry: index | hq << 31) -- and moves them into
+    // the dense defer_list when it retires, in whole calls of 64 entries ([0, *defer_total): one memory atomic per workgroup)
+    uint32_t *defer_index; uint32_t *defer_list; uint32_t *defer_total;
     uint32_t *tile_span;         // max span per 64-record wave tile (Read-Length fallback scan)
     FragCandidates frag;
     uint32_t *rl_stats;          // [3] batch-level max span, min l_qseq, max l_qseq over eligible records
@@ -181,8 +188,8 @@ struct FragPlan {
 };
 void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uint32_t n_genes, const FragPlan &P, int *error);
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks);
-void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2, uint32_t chunk_cap, const uint32_t *counts,
-                         uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash, uint32_t *dst_h2);
+void launch_pairs_append(hipStream_t s, const PairRec *src, uint32_t chunk_cap, const uint32_t *counts,
+                         uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, PairRec *dst);
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error);
 
 }  // namespace rsqc

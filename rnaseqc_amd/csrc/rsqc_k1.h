@@ -12,10 +12,13 @@
 //       queues: one block, two blocks.  Whenever a queue holds 64 records the wave runs the feature stage of exactly
 //       that shape on them (`k1e_process<NB>`): all lanes busy, one / two look-up rounds, two / four commit slots, no
 //       block-count predicates.  Records with longer CIGARs (more than 4 operations or more than 2 blocks: 9 % of an
-//       RNA-seq file) wait in a third queue as (record index, flags) and are processed 64 at a time by `k1e_process_long`:
-//       record words and CIGAR come back from the caches, full CIGAR walk (8 operations from registers, more from memory),
-//       up to FAST_BLOCKS blocks per record through the same feature stage and commit code.  A record whose blocks meet an
-//       interval covered by more than two exons goes to the general code (classify_slow_kernel) as before.
+//       RNA-seq file) wait in a third queue as (record index, flags, position, CIGAR offset) and are processed 64 at a time by
+//       `k1e_process3` (round 6): the eight operations come back from the caches in two loads, a bit-field walk over them
+//       captures up to THREE blocks, and the record takes the three-block feature stage and commit.  What that stage cannot
+//       take -- more than 8 operations, more than 3 blocks: 0.6 % of the records -- is listed in the workgroup's own region of
+//       the deferred list and taken by `classify_long_kernel` behind this kernel with the general walk and FAST_BLOCKS blocks
+//       (rounds 3-5 ran that code inside the tile loop: it alone held the kernel at 126 VGPRs = four waves per SIMD).
+//       A record whose blocks meet an interval covered by more than two exons goes to the general code (classify_slow_kernel).
 //
 // The feature stage reads the ELEMENTARY-INTERVAL index (rsqc_read.h: EiEntry / EiRank): a block costs two 16-byte
 // rank-word loads (independent, no walk) and one round of entry loads, instead of bin -> rows -> rows further down.
@@ -93,7 +96,13 @@ constexpr uint64_t K1E_PIECE = K1E_PIECE_RECORDS;   // records a wave takes from
 #define K1E_QCAP_N 128
 #endif
 constexpr int K1E_QCAP = K1E_QCAP_N;                 // per-wave queue slots: < 64 left over + <= 64 of the next tile
-constexpr int K1E_ESLOTS = 512, K1E_GSLOTS = 256;
+#ifndef K1E_ESLOTS_N
+#define K1E_ESLOTS_N 256      /* (round 5 measured 512 / 256 against 256 / 128: no difference, call r5p; the smaller tables are what lets five workgroups share a CU) */
+#endif
+#ifndef K1E_GSLOTS_N
+#define K1E_GSLOTS_N 128
+#endif
+constexpr int K1E_ESLOTS = K1E_ESLOTS_N, K1E_GSLOTS = K1E_GSLOTS_N;
 constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's flag word | K1E_HQ when high quality
 // (timing experiments, `make variant DEFS=-DK1E_ABL=<bits>`: 1 no feature stage, 2 no LDS table updates, 4 no coverage atomics,
 //  8 no pairs, 16 no long-CIGAR kernel -- wrong results by design; the product build has K1E_ABL == 0 and none of it)
@@ -115,19 +124,24 @@ struct K1eTables {
     uint32_t pairs;                              // pairs in the workgroup's chunk
     uint32_t frags;                              // fragment-size candidates in the workgroup's region (BED runs)
     uint32_t piece;                              // next piece of the workgroup's range to hand to a wave
+    uint32_t defer;                              // records in the workgroup's region of the deferred list (-> classify_long_kernel)
     // The last elementary interval a wave's uniform path (k1e_uniform1) looked up: [lo, hi) and its index entry.  The queued records are
     // neighbours in the sorted stream, and so are consecutive CALLS: on the contract workload 56 % of the one-block calls lie in the
     // interval of the call before them (tools/uniform_tiles.py) -- those take their interval from here, two LDS reads, instead of two
     // dependent scalar loads from the index.  One entry per wave (a wave reads what it wrote itself: no tearing), emptied when the
     // wave's stream enters another contig.  (The one-entry form of the interval window in LDS that north_star names.)
     alignas(16) uint32_t ucache[K1E_WAVES][12];  // EiEntry (8 words), lo, hi, 2 unused
+    // --bed: a wave's cursor into its contig's start-sorted BED rows (classify_ei_kernel<true>, phase A): the segment it belongs to, the
+    // start of the last row that starts at or before the last tile's end / the start of the row behind it / the running max of `end`
+    // up to the former
+    int32_t bedc[K1E_WAVES][4];
     __device__ __forceinline__ void init(uint32_t pairs0) {
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
         if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
         for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
-        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; piece = 0u; frags = 0u; }
-        if (threadIdx.x < K1E_WAVES) { ucache[threadIdx.x][8] = 1u; ucache[threadIdx.x][9] = 0u; }            // [1, 0): holds no position
+        if (threadIdx.x == 0) { rl[0] = 0u; rl[1] = 0xFFFFFFFFu; rl[2] = 0u; pairs = pairs0; piece = 0u; frags = 0u; defer = 0u; }
+        if (threadIdx.x < K1E_WAVES) { ucache[threadIdx.x][8] = 1u; ucache[threadIdx.x][9] = 0u; bedc[threadIdx.x][0] = -1; }   // [1, 0): holds no position; no segment
     }
     __device__ __forceinline__ void exon_add(uint32_t eid, double frac) {
         const uint32_t slot = eid & (K1E_ESLOTS - 1);
@@ -168,12 +182,24 @@ struct K1eTables {
     }
 };
 
+// The per-wave queues are structures of ARRAYS of dwords (round 6): a queue write or read of one field is a ds_write_b32 /
+// ds_read_b32 over 64 consecutive dwords -- conflict-free -- where the 16-byte rows of rounds 3-5 (ds_write_b128: 8 lanes per LDS
+// cycle, and the ring's wrap put rows of one instruction on the same banks) showed SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 48 %.
+struct K1eQueue1 { uint32_t bs[K1E_QCAP], lf[K1E_QCAP], idx[K1E_QCAP];       // one block: start, len (16 bits) | flag bits 0-11 << 16 | high quality << 28, record index
+#ifdef K1E_COARSE
+                   uint32_t cz[K1E_QCAP];                                       // coarse-table answer (0 = none)
+#endif
+};
+struct K1eQueue2 { uint32_t bs0[K1E_QCAP], len0[K1E_QCAP], bs1[K1E_QCAP], len1[K1E_QCAP], idx[K1E_QCAP], flhq[K1E_QCAP]; };   // two blocks
+// three blocks (round 6: captured by phase A's walk over the eight staged operations).  64 slots: a record that finds the ring full goes
+// to the deferred list instead (the ring fills with ~5 records per tile and is emptied at 64: about one three-block record in 25)
+constexpr int K1E_Q3CAP = 64;
+struct K1eQueue3 { uint32_t bs0[K1E_Q3CAP], len0[K1E_Q3CAP], bs1[K1E_Q3CAP], len1[K1E_Q3CAP], bs2[K1E_Q3CAP], len2[K1E_Q3CAP], idx[K1E_Q3CAP], flhq[K1E_Q3CAP]; };
 struct K1eShared {
     K1eTables T;
-    uint4 q1[K1E_WAVES][K1E_QCAP];               // one block:  bs, len (16 bits) | flag bits 0-11 << 16 | high quality << 28, record index, coarse-table answer (0 = none)
-    uint4 q2[K1E_WAVES][K1E_QCAP];               // two blocks: bs0, len0, bs1, len1
-    uint2 q2x[K1E_WAVES][K1E_QCAP];              //             record index, flhq
-    uint4 q3[K1E_WAVES][K1E_QCAP];               // longer CIGARs: record index, flhq, pos, first operation
+    K1eQueue1 q1[K1E_WAVES];
+    K1eQueue2 q2[K1E_WAVES];
+    K1eQueue3 q3[K1E_WAVES];
 #ifdef K1E_LDS_PAD
     char pad[K1E_LDS_PAD];                       // (occupancy experiments: `make variant DEFS=-DK1E_LDS_PAD=12288` leaves room for three workgroups per CU)
 #endif
@@ -184,26 +210,26 @@ struct K1eShared {
 #else
 #define K1E_GLOBAL(T, p) (p)
 #endif
-__device__ __forceinline__ uint32_t k1e_chunk_of_block() { return blockIdx.x; }
+// the pair chunk a wave writes to: its workgroup's own in classify_ei_kernel; in classify_long_kernel the chunk of the K1 workgroup
+// whose deferred records the workgroup is working on (wave-uniform, an SGPR)
 // where a workgroup's (gene, name) pairs go: the three streams of DevAccum and the chunk capacity
-struct K1ePairDst { uint64_t gene, hash, h2; uint32_t cap; };
+struct K1ePairDst { uint64_t pairs; uint32_t cap; };
 #ifndef K1E_LAZYPAIR
 #define K1E_LAZYPAIR 1        /* 1: read at the head of every commit with scalar loads; 0: held across the tile loop (the tree's form) */
 #endif
-// The four words straight from the kernel-argument segment, as SCALAR loads in wave-uniform code.  (Read through k1e_lazy_args()
+// The two words straight from the kernel-argument segment, as SCALAR loads in wave-uniform code.  (Read through k1e_lazy_args()
 // they become flat VECTOR loads followed by a wait for every outstanding memory operation of the wave -- fine in the rare paths
 // that function serves, 21 % of the kernel when it sat in the commit: profiles/r4_k1_variants.txt, r4n2.)
 __device__ __forceinline__ K1ePairDst k1e_pair_dst() {
     K1ePairDst d;
 #if defined(__HIP_DEVICE_COMPILE__)
     const void *q = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("s_load_dwordx2 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(d.gene), "=&s"(d.hash), "=&s"(d.h2), "=&s"(d.cap)
-                 : "s"(q), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_gene)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_hash)),
-                   "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_h2)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_chunk_cap)));
+    asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d.pairs), "=&s"(d.cap)
+                 : "s"(q), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pairs)), "n"(offsetof(K1Args, acc) + offsetof(DevAccum, pair_chunk_cap)));
 #else
     const DevAccum &a = k1e_lazy_args()->acc;
-    d.gene = (uint64_t)(uintptr_t)a.pair_gene; d.hash = (uint64_t)(uintptr_t)a.pair_hash; d.h2 = (uint64_t)(uintptr_t)a.pair_h2; d.cap = a.pair_chunk_cap;
+    d.pairs = (uint64_t)(uintptr_t)a.pairs; d.cap = a.pair_chunk_cap;
 #endif
     return d;
 }
@@ -216,19 +242,19 @@ __device__ __forceinline__ K1ePairDst k1e_pair_dst() {
 __device__ __forceinline__ bool k1e_first_lane() { return K1E_CONSTMASK ? WaveSink::lane(LaneMask{1ull}) : lane_id() == 0; }
 template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return K1E_CONSTMASK ? WaveSink::lane(LaneMask{(1ull << N) - 1ull}) : lane_id() < N; }
 
-// ---- (gene, name) pairs of the lanes of `m` into the workgroup's chunk: one LDS slot reservation per wave, three coalesced stores ----
-__device__ __forceinline__ void k1e_emit_pairs(K1eTables &T, uint64_t m, uint32_t g, uint64_t qhash, uint32_t qh2, const K1ePairDst &pd) {
+// ---- (gene, name) pairs of the lanes of `m` into the workgroup's chunk: one LDS slot reservation per wave, one coalesced 16-byte store per lane ----
+// GLOBAL_SLOT (classify_long_kernel: several workgroups add to one chunk): the reservation is a memory atomic on the chunk's count
+template <bool GLOBAL_SLOT = false>
+__device__ __forceinline__ void k1e_emit_pairs(K1eTables &T, uint64_t m, uint32_t g, uint64_t qhash, uint32_t qh2, const K1ePairDst &pd, uint32_t chunk) {
     const int lead = __ffsll((unsigned long long)m) - 1;
     uint32_t base = 0;
-    if (lane_id() == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));
+    if (lane_id() == lead) base = GLOBAL_SLOT ? atomicAdd(&k1e_lazy_args()->acc.pair_chunk_count[chunk], (uint32_t)__popcll(m)) : atomicAdd(&T.pairs, (uint32_t)__popcll(m));
     base = lane_value(base, lead);
     if (WaveSink::lane(LaneMask{m})) {
         const uint32_t slot = base + mask_rank(m);
-        const size_t chunk_at = (size_t)k1e_chunk_of_block() * pd.cap;
+        const size_t chunk_at = (size_t)chunk * pd.cap;
         if (slot < pd.cap) {
-            K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.gene)[chunk_at + slot] = g;
-            K1E_GLOBAL(uint64_t, (uint64_t *)(uintptr_t)pd.hash)[chunk_at + slot] = qhash;
-            K1E_GLOBAL(uint32_t, (uint32_t *)(uintptr_t)pd.h2)[chunk_at + slot] = qh2;
+            K1E_GLOBAL(PairRec, (PairRec *)(uintptr_t)pd.pairs)[chunk_at + slot] = PairRec{g, qh2, qhash};          // (one 16-byte store)
         } else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
     }
 }
@@ -237,9 +263,9 @@ __device__ __forceinline__ void k1e_emit_pairs(K1eTables &T, uint64_t m, uint32_
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
-template <int NB>
+template <int NB, bool GLOBAL_SLOT = false>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
-                                           uint64_t qhash, uint32_t qh2, const K1ePairDst &held) {
+                                           uint64_t qhash, uint32_t qh2, const K1ePairDst &held, uint32_t chunk) {
     typedef WaveSink WS;
     const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
@@ -281,7 +307,7 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
         const uint64_t m = WS::prim(eo.n_hit > k).m;
         if (m == 0ull) break;
         const uint32_t g = eo.hit[k];
-        if (!(K1E_ABL & 8)) k1e_emit_pairs(T, m, g, qhash, qh2, pd);
+        if (!(K1E_ABL & 8)) k1e_emit_pairs<GLOBAL_SLOT>(T, m, g, qhash, qh2, pd, chunk);
         if (NB > 1 || k > 0) {
             const RunLite r = make_run_lite(m, g);
             const uint64_t nd = m & notdup;
@@ -447,28 +473,38 @@ __device__ __forceinline__ bool k1e_uniform1(const DevAnnotation &a, const DevPa
         if (c1) { const uint32_t b1 = S.cdB + (uint32_t)bs; cov_add_merged(cov_diff, hvm, b1, 1u); cov_add_merged(cov_diff, hvm, b1 + len, 0xFFFFFFFFu); }
     }
     if (!(K1E_ABL & 8)) {
-        k1e_emit_pairs(T, hvm, gX, qhash, qh2, pd);
-        if (vb) k1e_emit_pairs(T, hvm, g1, qhash, qh2, pd);
+        k1e_emit_pairs(T, hvm, gX, qhash, qh2, pd, blockIdx.x);
+        if (vb) k1e_emit_pairs(T, hvm, g1, qhash, qh2, pd, blockIdx.x);
     }
     return true;
 }
 
+constexpr uint32_t K1E_TAB_BLOCK3 = CIG_BLOCK_SET | (CIG_BLOCK_SET << 16), K1E_TAB_REF3 = CIG_REF_SET | (CIG_REF_SET << 16), K1E_TAB_BAD3 = 0xFE00FE00u;   // (k1e_walk3; the same tables as k1e_walk's)
 // ---- the feature stage of 64 queued records of NB blocks each (n < 64 only when a queue is drained) -----------------
 template <int NB>
 __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevParams &p, const rsqc_rec_aux *aux, uint32_t *cov_diff,
                                             const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n,
                                             const uint32_t *qh2col, const K1ePairDst &held) {
+    static_assert(NB >= 1 && NB <= 3, "queues of one-, two- and three-block records");
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
-    const uint32_t slot = (head + (uint32_t)l) & (K1E_QCAP - 1);
+    const uint32_t slot = (head + (uint32_t)l) & ((NB == 3 ? K1E_Q3CAP : K1E_QCAP) - 1);
     int32_t bs[NB]; uint32_t len[NB]; uint32_t idx, flhq, pre0 = 0u;
     if (NB == 1) {
-        const uint4 it = S.q1[wave][slot];
-        bs[0] = (int32_t)it.x; len[0] = it.y & 0xFFFFu; idx = it.z; pre0 = it.w;
-        flhq = ((it.y >> 16) & 0xFFFu) | ((it.y >> 28) << 16);              // flag bits 0-11, K1E_HQ
+        const K1eQueue1 &q = S.q1[wave];
+        const uint32_t lf = q.lf[slot];
+        bs[0] = (int32_t)q.bs[slot]; len[0] = lf & 0xFFFFu; idx = q.idx[slot];
+#ifdef K1E_COARSE
+        pre0 = q.cz[slot];
+#endif
+        flhq = ((lf >> 16) & 0xFFFu) | ((lf >> 28) << 16);                  // flag bits 0-11, K1E_HQ
+    } else if (NB == 2) {
+        const K1eQueue2 &q = S.q2[wave];
+        bs[0] = (int32_t)q.bs0[slot]; len[0] = q.len0[slot]; bs[NB - 1] = (int32_t)q.bs1[slot]; len[NB - 1] = q.len1[slot]; idx = q.idx[slot]; flhq = q.flhq[slot];
     } else {
-        const uint4 it = S.q2[wave][slot]; const uint2 ix = S.q2x[wave][slot];
-        bs[0] = (int32_t)it.x; len[0] = it.y; bs[NB - 1] = (int32_t)it.z; len[NB - 1] = it.w; idx = ix.x; flhq = ix.y;
+        const K1eQueue3 &q = S.q3[wave];
+        bs[0] = (int32_t)q.bs0[slot]; len[0] = q.len0[slot]; bs[NB > 1 ? 1 : 0] = (int32_t)q.bs1[slot]; len[NB > 1 ? 1 : 0] = q.len1[slot];
+        bs[NB - 1] = (int32_t)q.bs2[slot]; len[NB - 1] = q.len2[slot]; idx = q.idx[slot]; flhq = q.flhq[slot];
     }
     if (!on) { idx = 0u; flhq = 0u; pre0 = 0u; }
 #if defined(RSQC_WAVE_EMU)
@@ -484,27 +520,67 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
         EiOut eo; bool over = false;
         exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
         k1e_overflow(on && over, (uint64_t)idx);
-        k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, qhash, qh2, held);
+        k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, qhash, qh2, held, blockIdx.x);
     }
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
-// ---- 64 queued records with longer CIGARs (n < 64 only when the queue is drained): record words and CIGAR come back from
-// the caches (they were streamed through this CU a few tiles ago), the CIGAR is walked in full -- every block counted, the
-// first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count -------------------------------
-__device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
-                                                 const ContigInfo &ci, K1eShared &S, int wave, uint32_t head, uint32_t n, uint32_t &sum_blk, const K1ePairDst &held) {
+// ---- the first eight operations of a CIGAR on bit fields, THREE blocks captured (round 6) -------------------------------------------
+// Same idiom as k1e_walk below (operation class = a bit of a 16-bit table indexed by the operation word, select masks, v_bfi), but
+// forwards, with the captured blocks in a three-deep shift register (a block pushes the two before it down): after the walk
+// (b0, l0) is the LAST block seen, (b1, l1) the one before it, (b2, l2) the one before that -- for a record of at most three blocks,
+// the only kind the caller uses them for, all of its blocks.  No per-operation arrays stay live (the backward selects of k1e_walk
+// need the eight starts and eight class masks at once: sixteen registers this stage does not have at five waves per SIMD).
+struct Walk3 { uint32_t ref_len, nb, bad; uint32_t b0, b1, b2, l0, l1, l2; };
+// `cigar`: the record's operations in memory, for the reference length of a record with more than eight of them (rare; such a record's
+// blocks and legality are classify_long_kernel's to count / check)
+__device__ __forceinline__ void k1e_walk3(int32_t pos, uint32_t n, const uint32_t (&c)[8], const uint32_t *cigar, Walk3 &w) {
+    uint32_t cur = (uint32_t)pos + 1u;                                     // 1-based position of the next reference base
+    uint32_t b0 = 0u, b1 = 0u, b2 = 0u, l0 = 0u, l1 = 0u, l2 = 0u, nbneg = 0u, bad = 0u;
+    const uint32_t live = n >= 8u ? 0xFFu : ((1u << n) - 1u);              // bit k: operation k exists
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t ck = bfi(bfe_m(live, (uint32_t)k), c[k], 5u);       // past the end: a hard clip of length 0 (no block, no reference, legal)
+        const uint32_t len = ck >> 4, blk = bfe_m(K1E_TAB_BLOCK3, ck);
+        bad |= bfe_u(K1E_TAB_BAD3, ck, 1u);                                // Expression.cpp:61-63
+        nbneg += blk;
+        b2 = bfi(blk, b1, b2); l2 = bfi(blk, l1, l2);
+        b1 = bfi(blk, b0, b1); l1 = bfi(blk, l0, l1);
+        b0 = bfi(blk, cur, b0); l0 = bfi(blk, len, l0);
+        cur += len & bfe_m(K1E_TAB_REF3, ck);
+    }
+    if (__ballot(n > 8) != 0ull) {
+        for (uint32_t i = 8; i < n; ++i) { const uint32_t cx = cigar[i]; cur += (cx >> 4) & bfe_m(K1E_TAB_REF3, cx); }
+        K1E_LANDED(cur);
+    }
+    w.ref_len = cur - ((uint32_t)pos + 1u); w.nb = 0u - nbneg; w.bad = bad;
+    w.b0 = b0; w.b1 = b1; w.b2 = b2; w.l0 = l0; w.l1 = l1; w.l2 = l2;
+}
+
+constexpr uint32_t K1E_DEFER_NONE = 0xFFFFFFFFu;       // padding entry of the dense deferred list (no record has index 2^31 - 1 with the flag set: a batch holds fewer than 2^31)
+// a record for classify_long_kernel: the workgroup's own region of the deferred list (slot = first record of its range + an LDS
+// counter: a record is listed at most once), no memory atomic.  Entry: record index | high quality << 31.
+__device__ __forceinline__ void k1e_defer(K1eTables &T, uint64_t m, uint32_t idx, bool hq, uint32_t wg_beg) {
+    if (m == 0ull) return;
+    const int lead = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane_id() == lead) base = atomicAdd(&T.defer, (uint32_t)__popcll(m));
+    base = lane_value(base, lead);
+    if (WaveSink::lane(LaneMask{m})) k1e_lazy_args()->acc.defer_index[wg_beg + base + mask_rank(m)] = idx | (hq ? 0x80000000u : 0u);
+}
+
+// ---- 64 deferred records (classify_long_kernel): record words, CIGAR and name hashes come from memory, the CIGAR is walked in
+// full -- every block counted, the first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count ----
+__device__ __forceinline__ void k1e_long_call(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
+                                              const ContigInfo &ci, K1eTables &T, uint32_t idx, bool hq, bool on0, uint32_t &sum_blk,
+                                              const K1ePairDst &held, uint32_t chunk) {
     const int l = lane_id();
-    const bool on0 = (uint32_t)l < n;
-    uint4 it = S.q3[wave][(head + (uint32_t)l) & (K1E_QCAP - 1)];
-    if (!on0) it = make_uint4(0u, 0u, 0u, 0u);
-    // the queue carries the record words the walk needs, so the CIGAR is the only dependent gather; the name hash and the
-    // operation count ride in the auxiliary half-record, fetched beside it
-    const uint32_t idx = it.x, fl = it.y & 0xFFFFu; const bool hq = (it.y & K1E_HQ) != 0;
-    struct { int32_t x; uint32_t w; } cv = {(int32_t)it.z, it.w};
+    if (!on0) idx = 0u;
+    const int4 cv = ld32(reinterpret_cast<const int4 *>(b.core), idx);
     const int4 av = ld32(reinterpret_cast<const int4 *>(b.aux), idx);
+    const uint32_t fl = (uint32_t)av.z & 0xFFFFu;
     uint32_t cg[8];
-    k1e_load_cigar8(b.cigar, cv.w, cg);
+    k1e_load_cigar8(b.cigar, (uint32_t)cv.w, cg);
     uint32_t n_cigar = (uint32_t)av.w >> 24;
     bool ok = true;
     if (on0 && n_cigar == RSQC_NCIGAR_ESCAPE) {
@@ -526,7 +602,7 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
         for (uint32_t i = 8; i < nc; ++i) cigar_op(cp[i], cv.x, cw, B);
         K1E_LANDED(cw.nblocks); K1E_LANDED(cw.ref_len);
     }
-    const bool longc = nc > 4;                                // phase A left legality and the block count of these to this stage
+    const bool longc = nc > 8;                                // classify_ei_kernel left legality and the block count of these to this kernel
     if (longc && cw.bad) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_BAD_CIGAR);
     const bool on = on0 && ok && !(longc && cw.bad);
     sum_blk += (on && longc) ? cw.nblocks : 0u;                                       // src/RNASeQC.cpp:360
@@ -538,64 +614,11 @@ __device__ __forceinline__ void k1e_process_long(const DevAnnotation &a, const D
     const bool fast = on && cw.nblocks >= 1 && cw.nblocks <= (uint32_t)FAST_BLOCKS;
     const uint64_t qhash = (uint64_t)(uint32_t)av.x | ((uint64_t)(uint32_t)av.y << 32);
     const uint32_t qh2 = b.qhash2 ? ld32(b.qhash2, idx) : 0u;
-    // three blocks (aMbNcMdNeM) are nine in ten of these records: a tile without a four-block record runs three look-up rounds
-    // and six commit slots instead of four and eight
-    if (__ballot(fast && cw.nblocks > 3u) == 0ull) {
-        const int32_t bs3[3] = {B.bs[0], B.bs[1], B.bs[2]}; const uint32_t len3[3] = {B.len[0], B.len[1], B.len[2]};
-        EiOut eo; bool over = false;
-        exon_metrics_ei<3, WaveSink>(a, p, ci, fl, bs3, len3, hq, eo, over, cnt, fast, cw.nblocks);
-        k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<3>(cov_diff, S.T, eo, len3, fl, qhash, qh2, held);
-    } else {
-        EiOut eo; bool over = false;
-        exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
-        k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
-        k1e_commit<FAST_BLOCKS>(cov_diff, S.T, eo, B.len, fl, qhash, qh2, held);
-    }
-    if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
-}
-
-// ---- CIGAR, first pass (extractBlocks + bam_endpos, src/Expression.cpp:26-67): operations 0-3 with the first two
-// blocks captured, operations 4-7 for the reference length only; operations past the eighth come from memory ----------
-struct Walk2 { uint32_t ref_len, nb; uint32_t bad /* non-zero: an operation code above 8 among the first four */; int32_t bs0, bs1; uint32_t len0, len1; };
-// Written on integers and select masks, one vector instruction per line where it matters (round 3's form went through
-// per-lane bools: v_cmp / v_cndmask pairs with wait states between them, about 25 instructions per operation):
-//   class of an operation = a bit of a 16-bit table indexed by the operation word itself (bfe_u / bfe_m, rsqc_wave.h);
-//   the running reference position doubles as the start of the next block;
-//   the first two blocks are picked by walking the four operations BACKWARDS with v_bfi selects (the last write wins).
-constexpr uint32_t K1E_TAB_BLOCK = CIG_BLOCK_SET | (CIG_BLOCK_SET << 16), K1E_TAB_REF = CIG_REF_SET | (CIG_REF_SET << 16), K1E_TAB_BAD = 0xFE00FE00u;
-__device__ __forceinline__ void k1e_walk(int32_t pos, uint32_t n, const uint32_t (&c)[8], const uint32_t *cigar, Walk2 &w) {
-    uint32_t ck[4], len[4], blk[4], start[4];
-    uint32_t cur = (uint32_t)pos + 1u;                                     // 1-based position of the next reference base
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ck[k] = (uint32_t)k < n ? c[k] : 5u;                               // past the end: a hard clip of length 0 (no block, no reference, legal)
-        len[k] = ck[k] >> 4;
-        blk[k] = bfe_m(K1E_TAB_BLOCK, ck[k]);
-        start[k] = cur;
-        cur += len[k] & bfe_m(K1E_TAB_REF, ck[k]);
-    }
-    w.bad = bfe_u(K1E_TAB_BAD, ck[0], 1u) | bfe_u(K1E_TAB_BAD, ck[1], 1u) | bfe_u(K1E_TAB_BAD, ck[2], 1u) | bfe_u(K1E_TAB_BAD, ck[3], 1u);   // Expression.cpp:61-63
-    w.nb = 0u - (blk[0] + blk[1] + blk[2] + blk[3]);
-    uint32_t b0 = start[3] & blk[3], l0 = len[3] & blk[3], b1 = 0u, l1 = 0u;
-#pragma unroll
-    for (int k = 2; k >= 0; --k) {
-        b1 = bfi(blk[k], b0, b1); l1 = bfi(blk[k], l0, l1);
-        b0 = bfi(blk[k], start[k], b0); l0 = bfi(blk[k], len[k], l0);
-    }
-    w.bs0 = (int32_t)b0; w.len0 = l0; w.bs1 = (int32_t)b1; w.len1 = l1;
-    if (__ballot(n > 4) != 0ull) {                                         // operations 4-7: the reference length only
-#pragma unroll
-        for (int k = 4; k < 8; ++k) {
-            const uint32_t cx = (uint32_t)k < n ? c[k] : 5u;
-            cur += (cx >> 4) & bfe_m(K1E_TAB_REF, cx);
-        }
-        if (__ballot(n > 8) != 0ull) {
-            for (uint32_t i = 8; i < n; ++i) { const uint32_t cx = cigar[i]; cur += (cx >> 4) & bfe_m(K1E_TAB_REF, cx); }
-            K1E_LANDED(cur);
-        }
-    }
-    w.ref_len = cur - ((uint32_t)pos + 1u);
+    EiOut eo; bool over = false;
+    exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
+    k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
+    k1e_commit<FAST_BLOCKS, true>(cov_diff, T, eo, B.len, fl, qhash, qh2, held, chunk);
+    if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&T.cnt32[l], cnt.vec);
 }
 
 // the record range of workgroup `block` of `grid` (the same split for the kernel and for what reads its per-workgroup regions)
@@ -629,7 +652,7 @@ frag_compact_kernel(FragCandidates src, FragCandidates dst, uint32_t n_rec, uint
 }
 
 #ifndef K1E_MINW
-#define K1E_MINW 4            /* waves per SIMD the register allocation aims at: 128 VGPRs, no spills (at 5 the loop spills: 7.7 vs 4.65 ms) */
+#define K1E_MINW 5            /* waves per SIMD the register allocation aims at: 96 VGPRs (rounds 3-5: 4 -- the long-CIGAR stage inside the tile loop needed 126) */
 #endif
 // BED: the run has a BED (--bed: fragment-size candidates).  A template parameter, so that the instance of runs without one carries
 // none of its state (the candidate cursor alone took the kernel from 123 to 128 VGPRs and into scratch).
@@ -643,7 +666,7 @@ classify_ei_kernel(K1Args A) {
     // lgkmcnt(0) also waits for every LDS operation in flight); as opaque scalars they live in SGPRs for the whole kernel.
     DevParams p = A.p;
     // (K1E_LAZYPAIR = 0: the pair destination held across the tile loop, the tree's form)
-    const K1ePairDst held = {(uint64_t)(uintptr_t)acc.pair_gene, (uint64_t)(uintptr_t)acc.pair_hash, (uint64_t)(uintptr_t)acc.pair_h2, acc.pair_chunk_cap};
+    const K1ePairDst held = {(uint64_t)(uintptr_t)acc.pairs, acc.pair_chunk_cap};
     K1E_PIN(p.mapq_threshold); K1E_PIN(p.base_mismatch); K1E_PIN(p.chimeric_distance); K1E_PIN(p.stranded); K1E_PIN(p.unpaired);
     K1E_PIN(p.exclude_chimeric); K1E_PIN(p.n_filter_tags);
     const uint32_t *cigar_pool = b.cigar; K1E_PIN(cigar_pool);
@@ -727,9 +750,6 @@ classify_ei_kernel(K1Args A) {
         l_span = 0u; l_lmin = 0xFFFFFFFFu; l_lmax = 0u;
     };
     uint32_t h1 = 0, c1 = 0, h2 = 0, c2 = 0, h3 = 0, c3 = 0;   // queue heads and fills (wave-uniform)
-    // --bed: the wave's cursor into its contig's BED rows (see phase A): rows [bed_lo, bed_hi), bed_k = first row that starts behind
-    // the last tile's end, start of row bed_k - 1 / running max of end up to it / start of row bed_k
-    uint32_t bed_seg = NONE, bed_lo = 0, bed_hi = 0, bed_k = 0; int32_t bed_cur = 0, bed_pm = 0, bed_nxt = 0;
 
     // Record words and eight CIGAR words per record are staged ONE TILE AHEAD; the CIGAR address of the tile after that
     // comes with them (it is the fourth word of the core record).  The staged loads are issued at the TOP of a tile and
@@ -818,17 +838,17 @@ classify_ei_kernel(K1Args A) {
         if (!WS::lane(lane_on)) r.n_cigar = 0;
         RSQC_MARK(2);
         K1E_STOP(2, (r.pos, r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off), (lane_on.m))
-        Walk2 w2;
-        k1e_walk(r.pos, r.n_cigar, cg, r.cigar, w2);
+        Walk3 w2;                                             // all eight staged operations, up to three blocks captured (last block first)
+        k1e_walk3(r.pos, r.n_cigar, cg, r.cigar, w2);
         RSQC_MARK(3);
-        K1E_STOP(3, (r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off, w2.ref_len, w2.nb, w2.bad, w2.bs0, w2.bs1, w2.len0, w2.len1), (lane_on.m))
-        const bool shortc = r.n_cigar <= 4;                    // blocks and legality are known here; longer CIGARs: k1e_process_long
+        K1E_STOP(3, (r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off, w2.ref_len, w2.nb, w2.bad, w2.b0, w2.b1, w2.b2, w2.l0, w2.l1, w2.l2), (lane_on.m))
+        const bool shortc = r.n_cigar <= 8;                    // blocks and legality are known here; longer CIGARs: classify_long_kernel
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad != 0u;
         RecordCounters rc; WB hq = lane_on;
         const WB go = gate_cascade_b<false, WaveSink, true>(a, pt, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
         RSQC_MARK(4);
-        K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
+        K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.b0, w2.b1, w2.b2, w2.l0, w2.l1, w2.l2, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
         // --bed (src/RNASeQC.cpp:372): the block tests of fragmentSizeMetrics walk the CIGAR again and chase the BED rows per lane --
         // divergent code with dependent loads, and as soon as ONE lane of the tile takes it the wave does (round 4: 4.2 instead of
         // 2.6 ms).  Most tiles lie nowhere near a BED interval: a wave-level test first -- does ANY interval of the contig overlap
@@ -842,24 +862,28 @@ classify_ei_kernel(K1Args A) {
             if (t_hi != 0u) {                                 // (some lane holds a candidate)
                 if (mixed) bed_near = true;                   // (a contig boundary inside the tile: no shortcut)
                 else {
-                    if (bed_seg != seg) {                     // first candidate tile on this contig: its rows
+                    // the cursor lives in LDS (K1eTables::bedc: this wave's four words), not in registers: the kernel has no scalar
+                    // registers left (held across the tile loop the seven words of rounds 4-5 were spilled to VGPRs and from there to
+                    // scratch: 32 bytes per lane, written and read in every tile)
+                    int32_t *const bc = S.T.bedc[wave];
+                    int32_t bed_cur = (int32_t)__builtin_amdgcn_readfirstlane(bc[1]), bed_nxt = (int32_t)__builtin_amdgcn_readfirstlane(bc[2]), bed_pm = (int32_t)__builtin_amdgcn_readfirstlane(bc[3]);
+                    const bool fresh = (uint32_t)__builtin_amdgcn_readfirstlane(bc[0]) != seg;        // first candidate tile on this contig
+                    if (fresh || (int32_t)t_hi >= bed_nxt || (int32_t)t_hi < bed_cur) {   // ... or the tile's end passed the next row's start (or the stream went backwards)
                         const K1Args *q = k1e_lazy_args();
-                        bed_seg = seg; bed_lo = 0u; bed_hi = 0u;
+                        uint32_t bed_lo = 0u, bed_hi = 0u;
                         if (u_tid >= 0 && u_tid < q->a.n_contigs) { bed_lo = q->a.bed_range[u_tid]; bed_hi = q->a.bed_range[u_tid + 1]; }
-                        bed_k = bed_lo; bed_cur = (int32_t)0x7FFFFFFF; bed_nxt = (int32_t)0x80000000; bed_pm = (int32_t)0x80000000;   // (forces the search below)
+                        uint32_t lo2 = bed_lo, hi2 = bed_hi;                          // first row with start > t_hi
+                        while (lo2 < hi2) { const uint32_t m = lo2 + ((hi2 - lo2) >> 1); if (q->a.bed_start[m] <= (int32_t)t_hi) lo2 = m + 1; else hi2 = m; }
+                        // (a contig without rows: nothing before, nothing behind -- never near, never searched again)
+                        bed_cur = lo2 > bed_lo ? q->a.bed_start[lo2 - 1] : (int32_t)0x80000000;
+                        bed_pm = lo2 > bed_lo ? q->a.bed_pmax[lo2 - 1] : (int32_t)0x80000000;
+                        bed_nxt = lo2 < bed_hi ? q->a.bed_start[lo2] : (int32_t)0x7FFFFFFF;
+                        if (k1e_first_lane()) { bc[0] = (int32_t)seg; bc[1] = bed_cur; bc[2] = bed_nxt; bc[3] = bed_pm; }
+                        k1e_wave_lds_visible();
                     }
-                    if (bed_hi > bed_lo) {
-                        if ((int32_t)t_hi >= bed_nxt || (int32_t)t_hi < bed_cur) {      // the tile's end passed the next row's start (or the stream went backwards)
-                            const K1Args *q = k1e_lazy_args();
-                            uint32_t lo2 = bed_lo, hi2 = bed_hi;                      // first row with start > t_hi
-                            while (lo2 < hi2) { const uint32_t m = lo2 + ((hi2 - lo2) >> 1); if (q->a.bed_start[m] <= (int32_t)t_hi) lo2 = m + 1; else hi2 = m; }
-                            bed_k = lo2;
-                            bed_cur = bed_k > bed_lo ? q->a.bed_start[bed_k - 1] : (int32_t)0x80000000;
-                            bed_pm = bed_k > bed_lo ? q->a.bed_pmax[bed_k - 1] : (int32_t)0x80000000;
-                            bed_nxt = bed_k < bed_hi ? q->a.bed_start[bed_k] : (int32_t)0x7FFFFFFF;
-                        }
-                        bed_near = bed_k > bed_lo && bed_pm >= (int32_t)t_lo;          // a row starts at or before the span's end and one of those reaches its start
-                    }
+                    // a row starts at or before the span's end and one of those reaches its start (bed_pm = INT_MIN: no such row).  "- 1": a
+                    // zero-length first block sits one position before the record's first base and bed_interval_of tests it too
+                    bed_near = bed_pm >= (int32_t)t_lo - 1;
                 }
             }
         }
@@ -899,19 +923,22 @@ classify_ei_kernel(K1Args A) {
             l_lmin = (elig && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
         }
         RSQC_MARK(5);
-        K1E_STOP(5, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.bs0, w2.bs1, w2.len0, w2.len1, cnt.vec), (go.m, hq.m, big_any.m))
+        K1E_STOP(5, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.b0, w2.b1, w2.b2, w2.l0, w2.l1, w2.l2, cnt.vec), (go.m, hq.m, big_any.m))
         const uint32_t flhq = r.flag | (WS::lane(hq) ? K1E_HQ : 0u);
         // ---- sort by shape ------------------------------------------------------------------------------------------
         // (stragglers of a boundary tile take the general code, which finds their contig itself; for one with a long CIGAR it
         //  also counts the blocks and checks the operations, K1E_OVF_LONG)
-        const WB nb0 = WS::prim(w2.nb == 0u), nb1 = WS::prim(w2.nb == 1u), nb2 = WS::prim(w2.nb == 2u);
-        const WB shape12 = WS::prim(r.n_cigar <= 4u) && (nb0 || nb1 || nb2);
+        const WB walked = WS::prim(r.n_cigar <= 8u);
+        const WB nb0 = WS::prim(w2.nb == 0u), nb1 = WS::prim(w2.nb == 1u), nb2 = WS::prim(w2.nb == 2u), nb3 = WS::prim(w2.nb == 3u);
+        // one-block records whose length fits the queue's 16 bits (a longer block -- never seen in RNA-seq -- is classify_long_kernel's)
+        const WB fits = WS::prim(w2.l0 < 65536u);
+        const WB shape = walked && (nb0 || (nb1 && fits) || nb2 || nb3);
         WB mine = go;                                        // stragglers of a boundary tile: general code
         if (mixed) {
             mine = go && WS::prim(r.tid == u_tid);
-            k1e_overflow(WS::lane(go && !mine), WS::lane(shape12) ? (uint64_t)i : ((uint64_t)i | K1E_OVF_LONG));
+            k1e_overflow(WS::lane(go && !mine), WS::lane(walked) ? (uint64_t)i : ((uint64_t)i | K1E_OVF_LONG));
         }
-        const WB simple = mine && shape12, listed = mine && !shape12;
+        const WB simple = mine && shape, listed = mine && !shape;
         {   // no block at all (clips / insertions only): intergenic, src/Expression.cpp:407-441 with no feature seen
             const WB none = simple && nb0;
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
@@ -927,21 +954,32 @@ classify_ei_kernel(K1Args A) {
         asm volatile("" :: "v"(n_cg[0]), "v"(n_cg[1]), "v"(n_cg[2]), "v"(n_cg[3]), "v"(n_cg[4]), "v"(n_cg[5]), "v"(n_cg[6]), "v"(n_cg[7]));
 #endif
 #endif
-        // one-block records whose length fits the queue's 16 bits (a longer block -- never seen in RNA-seq -- takes the long-CIGAR stage)
-        const WB fits = WS::prim(w2.len0 < 65536u);
-        const uint64_t m1 = (simple && nb1 && fits).m, m2 = (simple && nb2).m, m3 = (listed || (simple && nb1 && !fits)).m;
+        const uint64_t m1 = (simple && nb1).m, m2 = (simple && nb2).m, m3all = (simple && nb3).m;
+        // the three-block ring has 64 slots: the records it has no room for join the deferred ones
+        const uint32_t room3 = (uint32_t)K1E_Q3CAP - c3;
+        const uint64_t m3 = m3all & WS::prim(mask_rank(m3all) < room3).m;
+        k1e_defer(S.T, listed.m | (m3all & ~m3), (uint32_t)i, WS::lane(hq), wg_beg);
         if (WS::lane(LaneMask{m1})) {
+            const uint32_t slot = (h1 + c1 + mask_rank(m1)) & (K1E_QCAP - 1);
+            K1eQueue1 &q = S.q1[wave];
+            q.bs[slot] = w2.b0; q.lf[slot] = w2.l0 | ((flhq & 0xFFFu) << 16) | ((flhq >> 16) << 28); q.idx[slot] = (uint32_t)i;
+#ifdef K1E_COARSE
             // the coarse word answers the block's look-ups when the block ends inside the 1024 positions it speaks for
-            const bool inside = (((uint32_t)(w2.bs0 + (int32_t)w2.len0)) >> 9) - (((uint32_t)(r.pos + 1)) >> 9) <= 1u;
-            S.q1[wave][(h1 + c1 + mask_rank(m1)) & (K1E_QCAP - 1)] =
-                make_uint4((uint32_t)w2.bs0, w2.len0 | ((flhq & 0xFFFu) << 16) | ((flhq >> 16) << 28), (uint32_t)i, inside ? cur_cz : 0u);
+            const bool inside = ((w2.b0 + w2.l0) >> 9) - (((uint32_t)(r.pos + 1)) >> 9) <= 1u;
+            q.cz[slot] = inside ? cur_cz : 0u;
+#endif
         }
-        if (WS::lane(LaneMask{m2})) {
+        if (WS::lane(LaneMask{m2})) {                           // (the walk holds the blocks last-first)
             const uint32_t slot = (h2 + c2 + mask_rank(m2)) & (K1E_QCAP - 1);
-            S.q2[wave][slot] = make_uint4((uint32_t)w2.bs0, w2.len0, (uint32_t)w2.bs1, w2.len1);
-            S.q2x[wave][slot] = make_uint2((uint32_t)i, flhq);
+            K1eQueue2 &q = S.q2[wave];
+            q.bs0[slot] = w2.b1; q.len0[slot] = w2.l1; q.bs1[slot] = w2.b0; q.len1[slot] = w2.l0; q.idx[slot] = (uint32_t)i; q.flhq[slot] = flhq;
         }
-        if (WS::lane(LaneMask{m3})) S.q3[wave][(h3 + c3 + mask_rank(m3)) & (K1E_QCAP - 1)] = make_uint4((uint32_t)i, flhq, (uint32_t)r.pos, (uint32_t)cur_cigar_off);
+        if (WS::lane(LaneMask{m3})) {
+            const uint32_t slot = (h3 + c3 + mask_rank(m3)) & (K1E_Q3CAP - 1);
+            K1eQueue3 &q = S.q3[wave];
+            q.bs0[slot] = w2.b2; q.len0[slot] = w2.l2; q.bs1[slot] = w2.b1; q.len1[slot] = w2.l1; q.bs2[slot] = w2.b0; q.len2[slot] = w2.l0;
+            q.idx[slot] = (uint32_t)i; q.flhq[slot] = flhq;
+        }
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         __builtin_amdgcn_wave_barrier();                     // the queue entries are read by OTHER lanes of the wave (no instruction: an ordering point)
         if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
@@ -1008,10 +1046,25 @@ classify_ei_kernel(K1Args A) {
         while (__builtin_expect(c3 >= thr, 0)) {
             const uint32_t take = c3 < 64u ? c3 : 64u;
             RSQC_MARK(8);
-            if (!(K1E_ABL & 16)) k1e_process_long(a, pt, b, acc.cov_diff, u_ci, S, wave, h3, take, sum_blk, held);
-            h3 = (h3 + take) & (K1E_QCAP - 1); c3 -= take;
-            RSQC_MARK(11);                         // [11] long-CIGAR tiles
-            if (__ballot(sum_blk >= (1u << 27)) != 0ull) flush_counts();       // (absurd block counts: keep the u32 lane sums from wrapping)
+            // The three-block stage is the widest of the loop (three blocks' index words and six commit slots) and the tile loop's own
+            // per-lane state -- six of the seven counter sums, three Read-Length extremes -- would push it past the 96 registers of five waves
+            // per SIMD (12-28 bytes of scratch in every build tried, reloaded through vmcnt in front of the stage's atomics).  That
+            // state is PARKED in LDS for the duration of the call instead: the free part of the wave's own one- and two-block rings
+            // (a ring holds fewer than 64 entries here, so the 64 slots behind its fill are unused), one dword per lane and value.
+            {
+                const uint32_t s1 = (h1 + c1 + (uint32_t)l) & (K1E_QCAP - 1), s2 = (h2 + c2 + (uint32_t)l) & (K1E_QCAP - 1);
+                K1eQueue1 &p1 = S.q1[wave]; K1eQueue2 &p2 = S.q2[wave];
+                p1.bs[s1] = sum_e1mm; p1.lf[s1] = sum_e1b; p1.idx[s1] = sum_e2mm;
+                p2.bs0[s2] = sum_e2b; p2.len0[s2] = sum_mm; p2.bs1[s2] = sum_b; p2.len1[s2] = l_span; p2.idx[s2] = l_lmin; p2.flhq[s2] = l_lmax;
+                if (!(K1E_ABL & 16)) k1e_process<3>(a, pt, b.aux, acc.cov_diff, u_ci, S, wave, h3, take, b.qhash2, held);
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::: "memory");                  // (the parked values are read back from LDS, not kept in registers across the call)
+#endif
+                sum_e1mm = p1.bs[s1]; sum_e1b = p1.lf[s1]; sum_e2mm = p1.idx[s1];
+                sum_e2b = p2.bs0[s2]; sum_mm = p2.len0[s2]; sum_b = p2.bs1[s2]; l_span = p2.len1[s2]; l_lmin = p2.idx[s2]; l_lmax = p2.flhq[s2];
+            }
+            h3 = (h3 + take) & (K1E_Q3CAP - 1); c3 -= take;
+            RSQC_MARK(11);                         // [11] three-block tiles
         }
     }
     flush_counts();
@@ -1034,6 +1087,65 @@ classify_ei_kernel(K1Args A) {
         q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < q->acc.pair_chunk_cap ? S.T.pairs : q->acc.pair_chunk_cap;
         if (BED) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
     }
+    // the workgroup's deferred records move from its region to the dense list classify_long_kernel reads, as whole CALLS of 64 entries
+    // (padded with K1E_DEFER_NONE: the entries of a call share their K1 workgroup, i.e. their pair chunk); one memory atomic per workgroup
+    const uint32_t n_def = S.T.defer;                          // (final since the barrier in front of the flush)
+    if (n_def != 0u) {
+        const K1Args *q = k1e_lazy_args();
+        const uint32_t padded = (n_def + 63u) & ~63u;
+        if (threadIdx.x == 0) S.T.piece = atomicAdd(q->acc.defer_total, padded);
+        __syncthreads();
+        const uint32_t at = S.T.piece;
+        for (uint32_t j = threadIdx.x; j < padded; j += blockDim.x) q->acc.defer_list[at + j] = j < n_def ? q->acc.defer_index[wg_beg + j] : K1E_DEFER_NONE;
+    }
+}
+
+// ---- the records classify_ei_kernel deferred (more than eight operations, more than three blocks, the three-block ring's surplus:
+// about 1 % of an RNA-seq file) -------------------------------------------------------------------------------------------------------
+// One WAVE per call of 64 entries of the dense list (classify_ei_kernel's epilogue: whole calls per K1 workgroup, so the entries of a
+// call share their pair chunk); calls are taken grid-stride.  Pairs go on into that K1 workgroup's chunk behind what it wrote itself (the
+// chunk is sized for FAST_SET pairs of EVERY record of its range, deferred ones included; the slot reservation is a memory atomic on the
+// chunk's count), exon / gene / counter updates to this workgroup's LDS tables.  The entries of a call lie in the K1 workgroup's record
+// range; when that range crosses contigs the call runs once per contig with the other lanes switched off.
+// (First form, call r6a: one workgroup per K1 workgroup's region -- 0.67 ms, the regions of multi-exon genes held thousands of records.)
+__global__ void __launch_bounds__(RSQC_K1_THREADS)
+classify_long_kernel(K1Args A, uint32_t k1_grid) {
+    __shared__ K1eTables T;
+    const DevAnnotation &a = A.a; const DevBatch &b = A.b; const DevAccum &acc = A.acc;
+    const K1ePairDst held = {(uint64_t)(uintptr_t)acc.pairs, acc.pair_chunk_cap};
+    const int l = lane_id();
+    T.init(0u);
+    __syncthreads();
+    uint32_t sum_blk = 0;
+    const uint32_t n_rec = (uint32_t)b.n;
+    const uint32_t total = *acc.defer_total;                    // (a multiple of 64)
+    const uint32_t n_waves = gridDim.x * (uint32_t)K1E_WAVES;
+    for (uint32_t call = blockIdx.x * (uint32_t)K1E_WAVES + (threadIdx.x >> 6); call * 64u < total; call += n_waves) {
+        const uint32_t e = acc.defer_list[call * 64u + (uint32_t)l];
+        const bool on = e != K1E_DEFER_NONE;
+        const uint32_t idx = on ? (e & 0x7FFFFFFFu) : 0u; const bool hq = on && (e >> 31) != 0u;
+        // the K1 workgroup of the call (its first entry is a record), its record range and the contigs it spans
+        const uint32_t idx0 = lane_value(idx, 0);
+        const uint32_t total_waves = k1_grid * (uint32_t)K1E_WAVES;
+        const uint32_t per_wave = (((n_rec + total_waves - 1u) / total_waves) + 63u) & ~63u;      // (as in k1e_wg_range)
+        const uint32_t region = idx0 / ((uint32_t)K1E_WAVES * per_wave);
+        uint32_t beg, end;
+        k1e_wg_range(n_rec, k1_grid, region, beg, end);
+        const uint32_t seg_lo = find_segment(b, beg), seg_hi = find_segment(b, end - 1u);
+        for (uint32_t sg = seg_lo; sg <= seg_hi; ++sg) {
+            const bool mine = on && (seg_lo == seg_hi || (idx >= (uint32_t)b.seg_start[sg] && (sg + 1 >= b.n_seg || idx < (uint32_t)b.seg_start[sg + 1])));
+            if (__ballot(mine) == 0ull) continue;
+            const int32_t tid = b.n_seg ? b.seg_tid[sg] : -1;
+            const ContigInfo ci = (tid >= 0 && tid < a.n_contigs) ? a.contig[tid] : ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
+            k1e_long_call(a, A.p, b, acc.cov_diff, ci, T, idx, hq, mine, sum_blk, held, region);
+        }
+    }
+    {
+        const uint32_t s6 = wave_sum(sum_blk);
+        if (k1e_first_lane() && s6) atomicAdd(&T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
+    }
+    __syncthreads();
+    T.flush(0ull);
 }
 
 }  // namespace rsqc

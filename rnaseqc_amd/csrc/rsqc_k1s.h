@@ -99,7 +99,7 @@ struct SlowAcc {
         atomicAdd(&acc->gene_reads[g], 1ull);
         if (notdup) atomicAdd(&acc->gene_unique[g], 1ull);
         const uint32_t slot = atomicAdd(acc->pair_slow_count, 1u);
-        if (slot < acc->pair_slow_cap) { acc->pair_gene[acc->pair_slow_base + slot] = g; acc->pair_hash[acc->pair_slow_base + slot] = qhash; acc->pair_h2[acc->pair_slow_base + slot] = qh2; }
+        if (slot < acc->pair_slow_cap) acc->pairs[acc->pair_slow_base + slot] = PairRec{g, qh2, qhash};
         else atomicExch(acc->error, RSQC_ERR_CAPACITY);
     }
 };
@@ -170,7 +170,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                                 atomicAdd(&acc.gene_reads[g], 1ull);
                                 if (notdup) atomicAdd(&acc.gene_unique[g], 1ull);
                                 const uint32_t slot = atomicAdd(acc.pair_slow_count, 1u);
-                                if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; acc.pair_h2[acc.pair_slow_base + slot] = qh2; }
+                                if (slot < acc.pair_slow_cap) acc.pairs[acc.pair_slow_base + slot] = PairRec{g, qh2, qhash};
                                 else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                             }
                             bits = fo.bits;
@@ -204,7 +204,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                 base = __shfl(base, lead0, 64);
                 if (has) {
                     const uint32_t slot = base + mask_rank(m);
-                    if (slot < acc.pair_slow_cap) { acc.pair_gene[acc.pair_slow_base + slot] = g; acc.pair_hash[acc.pair_slow_base + slot] = qhash; acc.pair_h2[acc.pair_slow_base + slot] = qh2; }
+                    if (slot < acc.pair_slow_cap) acc.pairs[acc.pair_slow_base + slot] = PairRec{g, qh2, qhash};
                     else atomicExch(acc.error, RSQC_ERR_CAPACITY);
                 }
                 wave_by_key(has, g, [&](int lead, uint32_t gg, bool, uint64_t same) {

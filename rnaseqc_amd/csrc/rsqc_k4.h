@@ -142,7 +142,7 @@ struct K4LocalShared {
 #define RSQC_K4L_OCC
 #endif
 __global__ void __launch_bounds__(RSQC_K4L_THREADS) RSQC_K4L_OCC
-frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const uint32_t *pair_h2, uint32_t chunk_cap,
+frag_local_kernel(const PairRec *pairs, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
                   const uint4 *ginfo, uint32_t *cursor, FragKey *list, int *error) {
     __shared__ K4LocalShared S;
@@ -165,23 +165,24 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         piece0 = me * per < n_pieces ? me * per : n_pieces;
         n_pieces = piece0 + per < n_pieces ? piece0 + per : n_pieces;
     }
-    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U]) {
+    auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U], uint32_t (&h2)[U]) {      // one 16-byte load per pair
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
             const bool ok = piece < n_pieces && j < count;
-            g[u] = ok ? pair_gene[base + j] : NONE;
-            key[u] = ok ? pair_hash[base + j] : 0ull;
+            PairRec r{NONE, 0u, 0ull};
+            if (ok) r = pairs[base + j];
+            g[u] = r.gene; key[u] = r.hash; h2[u] = r.h2;
         }
     };
 #ifdef RSQC_K1_PROF
     if (blockIdx.x == 1000 && n_chunks > 1000) {                           // (diagnostic: one chunk, as K1 wrote it)
-        for (uint32_t i = threadIdx.x; i < count && i < 32768u; i += blockDim.x) { g_dbg_pair_hash[i] = pair_hash[base + i]; g_dbg_pair_gene[i] = pair_gene[base + i]; }
+        for (uint32_t i = threadIdx.x; i < count && i < 32768u; i += blockDim.x) { g_dbg_pair_hash[i] = pairs[base + i].hash; g_dbg_pair_gene[i] = pairs[base + i].gene; }
         if (threadIdx.x == 0) g_dbg_pair_count = count;
     }
 #endif
-    uint32_t g[U]; uint64_t key[U];
-    load_piece(piece0, g, key);
+    uint32_t g[U]; uint64_t key[U]; uint32_t h2[U];
+    load_piece(piece0, g, key, h2);
     for (int i = threadIdx.x; i < RSQC_K4L_WIN; i += blockDim.x) { S.win[i] = 0ull; S.win2[i] = 0u; }
     RSQC_FIN_BEGIN
     for (uint32_t piece = piece0; piece < n_pieces; piece += piece_step) {
@@ -189,14 +190,8 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         uint4 gi[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { const uint32_t gq = g[u] != NONE ? g[u] : 0u; gi[u] = ginfo[gq]; }
-        uint32_t h2[U];                                                     // (second hashes: coalesced, in flight with the rows; not carried a pass ahead -- registers)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
-            h2[u] = j < count ? pair_h2[base + j] : 0u;
-        }
-        uint32_t gn[U]; uint64_t keyn[U];
-        load_piece(piece + piece_step, gn, keyn);
+        uint32_t gn[U]; uint64_t keyn[U]; uint32_t h2n[U];
+        load_piece(piece + piece_step, gn, keyn, h2n);
         __syncthreads();                                                   // (the previous pass has read its list slots)
         for (int i = threadIdx.x; i < RSQC_K4L_GSLOTS; i += blockDim.x) { S.gkey[i] = NONE; S.gcnt[i] = 0u; }
         __syncthreads();
@@ -257,7 +252,7 @@ frag_local_kernel(const uint32_t *pair_gene, const uint64_t *pair_hash, const ui
         if (threadIdx.x == 0) atomicAdd(&g_fin_prof[32 + 15], 1ull);
 #endif
 #pragma unroll
-        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; }
+        for (int u = 0; u < U; ++u) { g[u] = gn[u]; key[u] = keyn[u]; h2[u] = h2n[u]; }
     }
 }
 

@@ -277,9 +277,8 @@ namespace rsqc {
 // Retirement of a batch: its chunks, one after the other, appended to the arena.  Workgroup k < n_chunks copies chunk k
 // (its destination = the sum of the counts before it); the last RSQC_K4_SLOW_BLOCKS workgroups share the slow-path region.
 __global__ void __launch_bounds__(256)
-pairs_append_kernel(const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2,
-                    uint32_t chunk_cap, const uint32_t *counts, uint32_t n_chunks,
-                    uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash, uint32_t *dst_h2) {
+pairs_append_kernel(const PairRec *src, uint32_t chunk_cap, const uint32_t *counts, uint32_t n_chunks,
+                    uint32_t slow_base, uint32_t slow_cap, PairRec *dst_pairs) {
     __shared__ unsigned long long s_part[256];
     const uint32_t k = blockIdx.x < n_chunks ? blockIdx.x : n_chunks;
     unsigned long long before = 0;
@@ -292,13 +291,13 @@ pairs_append_kernel(const uint32_t *src_gene, const uint64_t *src_hash, const ui
     if (blockIdx.x < n_chunks) { base = blockIdx.x * chunk_cap; count = counts[k] < chunk_cap ? counts[k] : chunk_cap; }
     else { base = slow_base; count = counts[n_chunks] < slow_cap ? counts[n_chunks] : slow_cap; lo = blockIdx.x - n_chunks; step = gridDim.x - n_chunks; }
     for (uint32_t i = lo * blockDim.x + threadIdx.x; i < count; i += step * blockDim.x) {
-        dst_gene[dst + i] = src_gene[base + i]; dst_hash[dst + i] = src_hash[base + i]; dst_h2[dst + i] = src_h2[base + i];
+        dst_pairs[dst + i] = src[base + i];
     }
 }
-void launch_pairs_append(hipStream_t s, const uint32_t *src_gene, const uint64_t *src_hash, const uint32_t *src_h2, uint32_t chunk_cap, const uint32_t *counts,
-                         uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, uint32_t *dst_gene, uint64_t *dst_hash, uint32_t *dst_h2) {
-    hipLaunchKernelGGL(pairs_append_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(256), 0, s, src_gene, src_hash, src_h2, chunk_cap, counts,
-                       n_chunks, slow_base, slow_cap, dst_gene, dst_hash, dst_h2);
+void launch_pairs_append(hipStream_t s, const PairRec *src, uint32_t chunk_cap, const uint32_t *counts,
+                         uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap, PairRec *dst) {
+    hipLaunchKernelGGL(pairs_append_kernel, dim3(n_chunks + RSQC_K4_SLOW_BLOCKS), dim3(256), 0, s, src, chunk_cap, counts,
+                       n_chunks, slow_base, slow_cap, dst);
 }
 
 }  // namespace rsqc
@@ -475,6 +474,8 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
         const K1Args A{a, p, b, acc};
         if (a.have_bed) hipLaunchKernelGGL(classify_ei_kernel<true>, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
         else hipLaunchKernelGGL(classify_ei_kernel<false>, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
+        // the records it deferred (more than eight operations / three blocks): one wave per call of 64, grid-stride
+        hipLaunchKernelGGL(classify_long_kernel, dim3((unsigned)std::min(grid, 2048)), dim3(RSQC_K1_THREADS), 0, s, A, (uint32_t)grid);
     }
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
@@ -502,8 +503,7 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
 }
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
-    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pair_gene, acc.pair_hash,
-                       acc.pair_h2, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
+    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pairs, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
                        P.ginfo, P.cursor, P.list, acc.error);
 }
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {

@@ -104,6 +104,7 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint3
         acc.rl_stats[0] = 0u; acc.rl_stats[1] = 0xFFFFFFFFu; acc.rl_stats[2] = 0u;    // ready for the next batch
         acc.ovf_count[1] += *acc.ovf_count;   // records the general kernel took since the last reset (rsqc_timing.slow_records)
         *acc.ovf_count = 0u;                  // (the slow kernel, this batch's only reader, ran before this kernel)
+        if (acc.defer_total) *acc.defer_total = 0u;   // (likewise classify_long_kernel and the deferred list)
     }
 }
 

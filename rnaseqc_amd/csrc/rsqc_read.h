@@ -851,8 +851,12 @@ RSQC_HD void ei_fetch(const DevAnnotation &a, const ContigInfo &ci, const EiProb
 }
 RSQC_HD void ei_resolve(const DevAnnotation &a, const EiProbe &q, const EiFetch &f, int rstrand, EiBlock &o) {
     uint32_t mask = f.S.mask | f.m1 | f.m_je | f.m_js1;
-    if (RSQC_ANY_LANE(q.have && f.je > f.js + 2))
+    if (RSQC_ANY_LANE(q.have && f.je > f.js + 2)) {
+#if defined(__clang__)                                     /* (rare path: interleaved by two it took six more registers -- spills at five waves per SIMD) */
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+#endif
         for (uint32_t j = f.js + 2; q.have && j < f.je; ++j) mask |= ld32(a.ei, j).mask;
+    }
     // EIM_DEEP matters only where the exon lists are read
     mask = (mask & ~EIM_DEEP) | ((f.S.mask | f.m1) & EIM_DEEP);
     const bool same = f.j1 == f.js;
@@ -887,9 +891,12 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) { out.eid[k] = 0; out.cidx[k] = 0; }
     EiBlock qb[NB];
+#ifndef RSQC_EI_GROUP3
+#define RSQC_EI_GROUP3 2                                   /* blocks in flight at a time in the three-block instance (A/B: 1) */
+#endif
+    constexpr int G = NB == 3 ? RSQC_EI_GROUP3 : 2;
 #pragma unroll
-    for (int b0 = 0; b0 < NB; b0 += 2) {                  // two blocks' loads in flight at a time
-        constexpr int G = 2;
+    for (int b0 = 0; b0 < NB; b0 += G) {                  // two blocks' loads in flight at a time
         EiProbe pr[G]; EiFetch fe[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_probe(a, ci, bs[b0 + j], len[b0 + j], lane_on && (uint32_t)(b0 + j) < nbv, pr[j], (b0 + j == 0) ? pre0 : 0u);

@@ -87,7 +87,7 @@ def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=
     if rc:
         raise RuntimeError("k1emu rc=%d" % rc)
     o.read_length = rl.value
-    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]); o.n_pairs = int(stats[2]); o.n_coarse = int(stats[3])
+    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]) & 0xFFFFFFFF; o.n_deferred = int(stats[1]) >> 32; o.n_pairs = int(stats[2]); o.n_coarse = int(stats[3])
     lib.k1emu_uniform_calls.restype = C.c_ulonglong
     o.n_uniform = int(lib.k1emu_uniform_calls())
     lib.k1emu_ucache_hits.restype = C.c_ulonglong

@@ -46,7 +46,7 @@ extern "C" __attribute__((visibility("default"))) unsigned long long k1emu_ucach
 extern "C" __attribute__((visibility("default")))
 int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, int grid, int slow_kernel,
               uint64_t *counters, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag, double *exon_reads /*by exon id*/,
-              int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/, uint64_t *stats /*[4]: overflow, listed, pairs, tiles processed*/) {
+              int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/, uint64_t *stats /*[4]: overflow, listed | deferred << 32, pairs, coarse-table hits*/) {
     HostIndex hx; std::string err;
     int rc = hx.build(a, nullptr, err);
     if (rc) return rc;
@@ -89,19 +89,21 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     const uint64_t per_wave = (((n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
     const uint32_t chunk_cap = (uint32_t)(per_wave * K1E_WAVES * FAST_SET);
     const uint32_t slow_cap = 1u << 16;
-    std::vector<uint32_t> pair_gene((size_t)chunk_cap * grid + slow_cap + 8); std::vector<uint64_t> pair_hash(pair_gene.size()); std::vector<uint32_t> pair_h2(pair_gene.size(), 0xFEEDu);
+    std::vector<PairRec> pairs((size_t)chunk_cap * grid + slow_cap + 8, PairRec{0xFFFFFFF0u, 0xFEEDu, 0ull});
     std::vector<uint32_t> chunk_count((size_t)grid + 2, 0xDEADu);
     std::vector<uint32_t> ovf_count(4, 0u); std::vector<uint64_t> ovf_index(1u << 20);
+    std::vector<uint32_t> defer_index((size_t)n + 64, 0xDEFE0000u), defer_list((size_t)n + 64 * (size_t)grid + 64, 0xDEFE0001u); uint32_t defer_total = 0;
     std::vector<uint32_t> tile_span((size_t)((n + 63) / 64) + 64 * (size_t)total_waves + 64, 0xABCDu);
     std::vector<uint32_t> rl_stats = {0u, 0xFFFFFFFFu, 0u};
     int32_t rl_state = 0; int error = 0;
     DevAccum acc{};
     acc.gene_reads = u64.data(); acc.gene_unique = acc.gene_reads + G; acc.gene_frag = acc.gene_unique + G; acc.counters = acc.gene_frag + G;
     acc.exon_acc = exon_acc.data(); acc.cov_diff = cov.data();
-    acc.pair_gene = pair_gene.data(); acc.pair_hash = (uint64_t *)pair_hash.data(); acc.pair_h2 = pair_h2.data();
+    acc.pairs = pairs.data();
     acc.pair_chunk_cap = chunk_cap; acc.pair_chunk_count = chunk_count.data();
     acc.pair_slow_base = chunk_cap * (uint32_t)grid; acc.pair_slow_cap = slow_cap; acc.pair_slow_count = chunk_count.data() + grid;
     acc.ovf_count = ovf_count.data(); acc.ovf_index = (uint64_t *)ovf_index.data(); acc.ovf_cap = (uint32_t)ovf_index.size();
+    acc.defer_index = defer_index.data(); acc.defer_list = defer_list.data(); acc.defer_total = &defer_total;
     acc.tile_span = tile_span.data();
     acc.rl_stats = rl_stats.data(); acc.read_length = &rl_state; acc.error = &error;
 
@@ -111,6 +113,18 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     for (int k = 0; k < grid; ++k) {
         wavemu::block_idx().x = (uint32_t)k;
         wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel<false>(A); });      // (the instance of runs without a BED)
+    }
+    uint64_t n_deferred = 0;
+    if (defer_total % 64u) return 1012;                                   // whole calls
+    for (uint32_t k = 0; k < defer_total; ++k) if (defer_list[k] != K1E_DEFER_NONE) { ++n_deferred; if ((defer_list[k] & 0x7FFFFFFFu) >= n) return 1013; }
+    {   // the records it deferred (more than eight operations / three blocks, the three-block ring's surplus) -> classify_long_kernel
+        const int lgrid = grid > 2 ? grid - 1 : grid;
+        wavemu::grid_dim().x = (uint32_t)lgrid;
+        for (int k = 0; k < lgrid; ++k) {
+            wavemu::block_idx().x = (uint32_t)k;
+            wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_long_kernel(A, (uint32_t)grid); });
+        }
+        wavemu::grid_dim().x = (uint32_t)grid;
     }
     uint64_t listed = 0;
     if (error) return error;
@@ -155,9 +169,9 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         const uint32_t ns = chunk_count[(size_t)grid];
         if (ns > slow_cap) return 1008;
         for (uint32_t j = 0; j < ns; ++j) {
-            const uint32_t g = pair_gene[(size_t)acc.pair_slow_base + j];
-            if (g >= G) return 1005;
-            names[g].insert({pair_hash[(size_t)acc.pair_slow_base + j], pair_h2[(size_t)acc.pair_slow_base + j]});
+            const PairRec &pr = pairs[(size_t)acc.pair_slow_base + j];
+            if (pr.gene >= G) return 1005;
+            names[pr.gene].insert({(uint64_t)pr.hash, pr.h2});
         }
     } else
     for (uint32_t k = 0; k < ovf_count[0]; ++k) {
@@ -189,9 +203,9 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         const uint32_t cnt = chunk_count[(size_t)k];
         if (cnt > chunk_cap) return 1004;
         for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t g = pair_gene[(size_t)k * chunk_cap + j];
-            if (g >= G) return 1005;
-            names[g].insert({pair_hash[(size_t)k * chunk_cap + j], pair_h2[(size_t)k * chunk_cap + j]}); ++n_pairs;
+            const PairRec &pr = pairs[(size_t)k * chunk_cap + j];
+            if (pr.gene >= G) return 1005;
+            names[pr.gene].insert({(uint64_t)pr.hash, pr.h2}); ++n_pairs;
         }
     }
     // ---- Read-Length inputs: tile maxima and batch extremes against the per-record values; the state machine itself ---
@@ -239,7 +253,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         wavemu::grid_dim().x = lgrid;
         for (uint32_t k = 0; k < lgrid; ++k) {
             wavemu::block_idx().x = k;
-            wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), (const uint64_t *)pair_hash.data(), pair_h2.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
+            wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pairs.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
                                                                           ginfo.data(), cursor.data(), list.data(), &error); });
         }
         wavemu::grid_dim().x = 8;
@@ -260,6 +274,6 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e] + exon_acc[a->exon_row_id[e]];
     *read_length = (int32_t)rl;
     if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
-    stats[0] = n_overflow; stats[1] = listed; stats[2] = n_pairs; stats[3] = g_k1e_coarse_hits;
+    stats[0] = n_overflow; stats[1] = listed | (n_deferred << 32); stats[2] = n_pairs; stats[3] = g_k1e_coarse_hits;
     return 0;
 }

@@ -89,7 +89,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
     if (n_parts > parts_bound || full_n != 0u) return -1000;
 
     // ---- the pairs as K1 leaves them
-    std::vector<uint32_t> pair_gene; std::vector<uint64_t> pair_hash; std::vector<uint32_t> pair_h2; std::vector<uint32_t> counts;
+    std::vector<PairRec> pairs; std::vector<uint32_t> counts;
     uint32_t chunk_cap = 0, slow_base = 0, slow_cap = 0, grid = 0, nch = 0;
     if (mode == 0) {
         nch = (uint32_t)n_chunks;
@@ -100,26 +100,26 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
         cut[nch] = body; std::sort(cut.begin(), cut.end());
         for (uint32_t c = 0; c < nch; ++c) chunk_cap = std::max<uint32_t>(chunk_cap, (uint32_t)(cut[c + 1] - cut[c]));
         chunk_cap += 7; slow_base = nch * chunk_cap; slow_cap = (uint32_t)slow_n + 5;
-        pair_gene.assign((size_t)slow_base + slow_cap, 0xFFFFFFF0u); pair_hash.assign((size_t)slow_base + slow_cap, 0ull); pair_h2.assign((size_t)slow_base + slow_cap, 0xDEADu);
+        pairs.assign((size_t)slow_base + slow_cap, PairRec{0xFFFFFFF0u, 0xDEADu, 0ull});
         counts.assign(nch + 1, 0u);
         for (uint32_t c = 0; c < nch; ++c) {
             counts[c] = (uint32_t)(cut[c + 1] - cut[c]);
-            for (size_t i = cut[c]; i < cut[c + 1]; ++i) { pair_gene[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].g; pair_hash[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].key; pair_h2[(size_t)c * chunk_cap + (i - cut[c])] = stream[i].h2; }
+            for (size_t i = cut[c]; i < cut[c + 1]; ++i) pairs[(size_t)c * chunk_cap + (i - cut[c])] = PairRec{stream[i].g, stream[i].h2, stream[i].key};
         }
         counts[nch] = (uint32_t)slow_n;
-        for (size_t i = 0; i < slow_n; ++i) { pair_gene[slow_base + i] = stream[body + i].g; pair_hash[slow_base + i] = stream[body + i].key; pair_h2[slow_base + i] = stream[body + i].h2; }
+        for (size_t i = 0; i < slow_n; ++i) pairs[slow_base + i] = PairRec{stream[body + i].g, stream[body + i].h2, stream[body + i].key};
         grid = nch + 32u;
     } else {
         nch = 0; chunk_cap = 0; slow_base = 0; slow_cap = (uint32_t)n_pairs;
-        pair_gene.resize(n_pairs); pair_hash.resize(n_pairs); pair_h2.resize(n_pairs); counts.assign(1, (uint32_t)n_pairs);
-        for (size_t i = 0; i < n_pairs; ++i) { pair_gene[i] = stream[i].g; pair_hash[i] = stream[i].key; pair_h2[i] = stream[i].h2; }
+        pairs.resize(n_pairs); counts.assign(1, (uint32_t)n_pairs);
+        for (size_t i = 0; i < n_pairs; ++i) pairs[i] = PairRec{stream[i].g, stream[i].h2, stream[i].key};
         grid = (uint32_t)std::min<uint64_t>(4096, n_pairs / 1024 + 1);
         grid = std::min<uint32_t>(grid, 24u);                                 // (emulation time; any sharing is legal)
     }
     wavemu::grid_dim().x = grid;
     for (uint32_t b = 0; b < grid; ++b) {
         wavemu::block_idx().x = b;
-        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pair_gene.data(), pair_hash.data(), pair_h2.data(), chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), cursor.data(), list.data(), &error); });
+        wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pairs.data(), chunk_cap, counts.data(), nch, slow_base, slow_cap, ginfo.data(), cursor.data(), list.data(), &error); });
     }
     if (error) return -error;
     uint64_t kept = 0; uint32_t fuller = 0;
