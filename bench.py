@@ -194,6 +194,26 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
     return out
 
 
+def k1_floor_model(k1_ms):
+    """Lower bounds of classify_ei_kernel on the contract workload from the counters of THIS build (profiles/k1_model.json, written by
+    tools/k1_model.py from the rocprofv3 --pmc passes of the same bench command; stamped with the hash of the K1 sources).  Three floors,
+    each what the kernel would take if that resource alone were the limit:
+      valu_floor_ms    SQ_INSTS_VALU x cycles per wave64 instruction / (1024 SIMDs x clock)
+      atomic_floor_ms  memory atomics + scattered stores / the chip's measured rate for that pattern (tools/atomic_bench)
+      traffic_floor_ms HBM bytes (FETCH_SIZE / WRITE_SIZE with the calibrated corrections) / 6.3 TB/s achievable"""
+    path = os.path.join(ROOT, "profiles", "k1_model.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        m = json.load(open(path))
+        from rnaseqc_amd.hostinfo import k1_code_hash
+        m["current"] = m.get("k1_code_hash") == k1_code_hash()
+        m["measured_kernel_ms"] = k1_ms
+        return m
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -394,6 +414,7 @@ def main():
 
     if rank == 0:
         k1_ms = tm["classify_ms"] / max(tm["classify_launches"], 1)
+        k1_long_ms = tm.get("classify_long_ms", 0.0) / max(tm["classify_launches"], 1)       # classify_long_kernel: the ~1 % of the records K1 defers
         bytes_per_launch = tm["classify_bytes"] / max(tm["classify_launches"], 1)
         achieved = bytes_per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         # HBM traffic of K1 per launch comes from separate rocprofv3 --pmc passes of this same command
@@ -469,6 +490,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "classify_ei_kernel" if not args.legacy else "classify_count_kernel_legacy + classify_slow_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": k1_ms,
+                         # the ~1 % of the records the kernel defers (more than eight CIGAR operations / three blocks) take their feature stage in
+                         # classify_long_kernel right behind it: its time, and the fraction with it counted in
+                         "deferred_kernel_ms": k1_long_ms,
+                         "frac_incl_deferred_kernel": (bytes_per_launch / ((k1_ms + k1_long_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
+                         "model": k1_floor_model(k1_ms) if not args.legacy else None,
                          "timer": "hipEvents around the launch on the context's stream (rsqc_get_timing), rank 0"},
             "cpu_baseline": cpu,
             "whole_node": None if not e2e or "value" not in e2e else {
@@ -485,7 +511,7 @@ def main():
                 "note": "`rnaseqc gtf bam out` on a BAM of the same records: BGZF inflate + BAM parse on the GPU + the hot path + end-of-file stage; details in end_to_end"},
             "end_to_end": e2e,
             "collective_ms": (1e3 * collective_s[0] / max(args.steps, 1)) if reduce_path else None,   # per step: 3 async all_reduce + 2 gathers + host merge
-            "stage_ms": {"classify_k1": k1_ms * len(handles), "classify_launches_per_step": len(handles), "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
+            "stage_ms": {"classify_k1": k1_ms * len(handles), "classify_long": k1_long_ms * len(handles), "classify_launches_per_step": len(handles), "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
                          "fragment_sizes": (tm.get("fragment_sizes_ms", 0.0) / max(args.steps, 1)) if args.bed else None,
                          "slow_path_records": int(tm["slow_records"])},
             "checks": None if res is None else {"gene_reads_sum": int(res.gene_reads.sum()),

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSQC_ABI_VERSION 4
+#define RSQC_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define RSQC_API __attribute__((visibility("default")))
@@ -384,6 +384,8 @@ typedef struct rsqc_timing {
     uint64_t slow_records;             /* records the general (slow-path) kernel took in the last finalized pass */
     double   fragment_sizes_ms;        /* --bed runs: the fragment-size stage of the end-of-file passes (host clock around its kernels and its
                                           two read-backs; src/Expression.cpp:482-540), summed since reset                              */
+    double   classify_long_ms;         /* ABI 5: the launches of classify_long_kernel (the ~1 % of the records the per-record kernel defers: more than
+                                          eight CIGAR operations or more than three blocks) since reset; NOT part of classify_ms             */
 } rsqc_timing;
 
 typedef struct rsqc_ctx rsqc_ctx;

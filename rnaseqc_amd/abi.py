@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # error codes
 OK, ERR_ARG, ERR_HIP, ERR_BAD_CIGAR, ERR_CAPACITY, ERR_NO_DEVICE, ERR_EMPTY_MEDIAN, ERR_INPUT = 0, -1, -2, -3, -4, -5, -6, -7
@@ -180,6 +180,7 @@ class TimingStruct(C.Structure):
         ("classify_ms", C.c_double), ("classify_launches", C.c_uint64),
         ("classify_records", C.c_uint64), ("classify_bytes", C.c_uint64),
         ("finalize_ms", C.c_double), ("h2d_ms", C.c_double), ("slow_records", C.c_uint64), ("fragment_sizes_ms", C.c_double),
+        ("classify_long_ms", C.c_double),
     ]
 
 

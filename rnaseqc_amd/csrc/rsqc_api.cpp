@@ -156,6 +156,7 @@ struct rsqc_ctx {
     const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
     const uint32_t *d_gene_order = nullptr;
     uint32_t k3_large = 0, k3_medium = 0, k3_xlarge = 0;
+    bool k3_use_xlarge = true;
     hipEvent_t fin_e0 = nullptr, fin_e1 = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
@@ -216,7 +217,7 @@ struct rsqc_ctx {
     std::vector<uint32_t> h_sample_size;
 
     // timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> k1_events, h2d_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> k1_events, h2d_events, long_events;
     std::vector<DevBuf> upload_pool;            // device buffers of retired transient uploads
     std::vector<hipEvent_t> event_pool;
     rsqc_timing timing{};
@@ -307,6 +308,12 @@ int resolve_events(rsqc_ctx *c) {
         c->event_pool.push_back(pr.first); c->event_pool.push_back(pr.second);
     }
     c->k1_events.clear();
+    for (auto &pr : c->long_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->timing.classify_long_ms += ms;
+        c->event_pool.push_back(pr.second);          // (.first is the K1 pair's second event, recycled above)
+    }
+    c->long_events.clear();
     for (auto &pr : c->h2d_events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->timing.h2d_ms += ms;
@@ -613,6 +620,12 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     launch_classify(c->stream, grid, c->dparams.legacy ? -1 : c->k1_variant, c->dann, c->dparams, d, acc);
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     c->k1_events.emplace_back(e0, e1);
+    if (!c->dparams.legacy) {                       // the records it deferred: timed on its own (rsqc_timing.classify_long_ms)
+        hipEvent_t e2 = get_event(c);
+        launch_classify_long(c->stream, grid, c->dann, c->dparams, d, acc);
+        HIP_TRY(c, hipEventRecord(e2, c->stream));
+        c->long_events.emplace_back(e1, e2);
+    }
     if (c->have_bed && !c->dparams.legacy) launch_frag_compact(c->stream, acc.frag, frag_dense, u->n, grid);
     launch_classify_slow(c->stream, c->dann, c->dparams, d, acc);
     launch_read_length(c->stream, c->dann, c->dparams, d, acc, rl_slot);
@@ -686,6 +699,7 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->frag_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->frag_arena.width[k] = w[k]; }   // ..., second name hash
     c->gc_arena.n_col = 7; { const size_t w[7] = {8, 8, 4, 4, 4, 4, 4}; for (int k = 0; k < 7; ++k) c->gc_arena.width[k] = w[k]; }   // ..., second name hash
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(16384, std::max(1, atoi(e)));
+    if (const char *e = getenv("RSQC_K3_XLARGE")) c->k3_use_xlarge = atoi(e) != 0;   // 0: the longest genes run from memory in the 64 KB class (A/B)
     *out = c;
     return RSQC_OK;
 }
@@ -728,6 +742,7 @@ void rsqc_destroy(rsqc_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto *b : all) b->release();
     for (auto &pr : c->k1_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : c->long_events) (void)hipEventDestroy(pr.second);      // (.first is the K1 pair's second event)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1143,7 +1158,7 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
         Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
         Ga.error = c->acc.error;
         {
-            uint32_t nl = c->k3_large, nm = c->k3_medium, nx = c->k3_xlarge;
+            uint32_t nl = c->k3_large, nm = c->k3_medium, nx = c->k3_use_xlarge ? c->k3_xlarge : 0u;
             if (const char *e = RSQC_DIAG("RSQC_K3_FORCE")) {        // diagnostic build only: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
                 const int f = atoi(e);
                 if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; nx = 0; } else if (f == 3) { nl = 0; nm = 0; nx = 0; } else if (f == 4) { nl = (uint32_t)L; nm = 0; nx = (uint32_t)L; }

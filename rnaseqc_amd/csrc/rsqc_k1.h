@@ -109,12 +109,18 @@ constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's 
 #ifndef K1E_ABL
 #define K1E_ABL 0
 #endif
+#ifndef K1E_EXON_RUNSUM
+#define K1E_EXON_RUNSUM 1     /* 0: exon fractions of multi-block records lane by lane (rounds 3-5), for an A/B */
+#endif
 
 // Workgroup-local accumulators: a workgroup streams a short genomic window, so it touches a handful of neighbouring
 // exons and genes; direct-mapped LDS tables take every update and each distinct key costs ONE global atomic when the
 // workgroup retires.  A key that finds its slot taken by another key goes straight to memory.
 struct K1eTables {
-    unsigned long long cnt[RSQC_N_COUNTERS];     // sum-type counters
+    // the seven sum-type counters, 64 bits each (sum slot k1e_sum_slot(counter); the others count records: cnt32).  A table of all
+    // RSQC_N_COUNTERS of them took the structure past 32 000 bytes -- gfx950 hands LDS out in granules of 1 280 bytes, so a workgroup
+    // of more than 25 granules leaves room for FOUR per CU, not five (call r6b: 32 176 bytes ran at four, measured by wave-cycles)
+    unsigned long long cnt[8];
     uint32_t cnt32[64];                          // one-per-record counters (a workgroup sees < 2^32 records)
     double eval[K1E_ESLOTS];
     uint32_t ekey[K1E_ESLOTS];                   // exon id
@@ -135,8 +141,12 @@ struct K1eTables {
     // start of the last row that starts at or before the last tile's end / the start of the row behind it / the running max of `end`
     // up to the former
     int32_t bedc[K1E_WAVES][4];
+    static __device__ __forceinline__ constexpr int sum_slot(int c) {
+        return c == RSQC_C_END1_MISMATCHES ? 0 : c == RSQC_C_END1_BASES ? 1 : c == RSQC_C_END2_MISMATCHES ? 2 : c == RSQC_C_END2_BASES ? 3 :
+               c == RSQC_C_MISMATCHED_BASES ? 4 : c == RSQC_C_TOTAL_BASES ? 5 : c == RSQC_C_ALIGNMENT_BLOCKS ? 6 : 7;      // (7: no sum counter, stays 0)
+    }
     __device__ __forceinline__ void init(uint32_t pairs0) {
-        for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) cnt[c] = 0ull;
+        if (threadIdx.x < 8) cnt[threadIdx.x] = 0ull;
         if (threadIdx.x < 64) cnt32[threadIdx.x] = 0u;
         for (int c = threadIdx.x; c < K1E_ESLOTS; c += blockDim.x) { ekey[c] = 0xFFFFFFFFu; eval[c] = 0.0; }
         for (int c = threadIdx.x; c < K1E_GSLOTS; c += blockDim.x) { gkey[c] = 0xFFFFFFFFu; gval[c] = 0ull; }
@@ -164,7 +174,7 @@ struct K1eTables {
     __device__ __forceinline__ void flush(unsigned long long n_records) {
         const DevAccum &acc = k1e_lazy_args()->acc;
         for (int c = threadIdx.x; c < RSQC_N_COUNTERS; c += blockDim.x) {
-            unsigned long long v = cnt[c] + (unsigned long long)cnt32[c];
+            unsigned long long v = cnt[sum_slot(c)] + (unsigned long long)cnt32[c];
             if (c == RSQC_C_TOTAL_ALIGNMENTS) v += n_records;
             if (c == RSQC_C_MAPPED_UNIQUE_READS) v += (unsigned long long)cnt32[RSQC_C_MAPPED_READS] - cnt32[RSQC_C_MAPPED_DUPLICATE_READS];
             if (c == RSQC_C_UNIQUE_FRAGMENTS) v += (unsigned long long)cnt32[RSQC_C_END1_MAPPED_READS] - cnt32[RSQC_C_DUPLICATE_PAIRS];
@@ -270,11 +280,13 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
     const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
     const uint64_t notdup = WS::prim((fl & RSQC_FDUP) == 0).m;
     double inv_aligned = 1.0;                    // one block: len / aligned is exactly 1
+    uint32_t aligned_of = 0; (void)aligned_of;
     if (NB > 1) {
         uint32_t aligned = 0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) aligned += len[b];
         inv_aligned = 1.0 / (double)(aligned ? aligned : 1u);     // (a slot adds len * (1 / aligned): within 1 ulp of len / aligned)
+        aligned_of = aligned;
     }
 #pragma unroll
     for (int k = 0; k < 2 * NB; ++k) {
@@ -295,7 +307,30 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
                 const uint64_t nd = hvm & notdup;
                 if (r.head && !(K1E_ABL & 2)) T.gene_add(eo.hit[0], r.count, run_popcount(nd, r.count));
             }
-        } else if (hv && !(K1E_ABL & 2)) T.exon_add(eo.eid[k], (double)ln * inv_aligned);
+        } else if (!(K1E_ABL & 2)) {
+#if K1E_EXON_RUNSUM
+            // Neighbouring lanes that hit one exon with the same aligned length (the rule: reads of one length) add through their
+            // first lane: (sum of block lengths) * (1 / aligned), one LDS atomic per run.  Lane by lane, the 64 adds of a tile inside
+            // one exon are 64 passes of the LDS on one address -- ALL of the kernel's LDS bank conflicts (call r6b: 1.4e8 conflict
+            // cycles with the table updates, 0 without).  A run whose lanes differ in aligned length adds lane by lane as before.
+            const uint64_t cont = run_cont_mask(hvm, eo.eid[k]);
+            if (cont == 0ull) { if (hv) T.exon_add(eo.eid[k], (double)ln * inv_aligned); }
+            else {
+                const uint32_t al = aligned_of;
+                const uint64_t mixed_len = cont & WS::prim(lane_below(al) != al).m;          // a lane that continues a run with another aligned length
+                if (mixed_len != 0ull) { if (hv) T.exon_add(eo.eid[k], (double)ln * inv_aligned); }
+                else {
+                    const uint32_t sc = wave_inclusive_scan_u32_dpp(hv ? ln : 0u);           // prefix sums of the lengths over the wave
+                    const uint32_t cnt_run = run_length_at(cont);
+                    const uint32_t at_end = lane_gather(sc, (uint32_t)lane_id() + cnt_run - 1u);
+                    const bool head = WS::lane(LaneMask{hvm & ~cont});
+                    if (head) T.exon_add(eo.eid[k], (double)(at_end - (sc - ln)) * inv_aligned);
+                }
+            }
+#else
+            if (hv) T.exon_add(eo.eid[k], (double)ln * inv_aligned);
+#endif
+        }
         const uint32_t base = hv ? eo.cidx[k] : 0u;
         if (!(K1E_ABL & 4)) {
             cov_add_merged(cov_diff, hvm, base, 1u);
@@ -319,12 +354,34 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
 // `index`: record index, | K1E_OVF_LONG when the general code also has to count the record's blocks and check its
 // operations (a long-CIGAR straggler of a boundary tile, which classify_ei_kernel did not walk to the end)
 constexpr uint64_t K1E_OVF_LONG = 1ull << 63;
-__device__ __forceinline__ void k1e_overflow(bool over, uint64_t index) {
-    if (over) {
+// One reservation per wave call (the lanes of a call that overflow take consecutive slots): the list has ONE counter, and a returning
+// memory atomic on one address completes at about 88 per microsecond chip-wide (MI355X_MICROARCH.md, "dequeue").
+// `stage` / `stage_n` (classify_long_kernel): the workgroup's LDS buffer in front of the list -- its 36 k entries of the contract workload,
+// one memory atomic each, were 0.42 ms of that kernel on their own (call r6b); the workgroup moves its buffer to the list when it retires.
+constexpr uint32_t K1E_OVF_STAGE = 1024;
+__device__ __forceinline__ void k1e_overflow(bool over, uint64_t index, unsigned long long *stage = nullptr, uint32_t *stage_n = nullptr) {
+    const uint64_t m = WaveSink::prim(over).m;
+    if (m == 0ull) return;
+    const int lead = __ffsll((unsigned long long)m) - 1;
+    const uint32_t n = (uint32_t)__popcll(m);
+    uint32_t base = 0;
+    bool staged = false;
+    if (stage) {
+        if (lane_id() == lead) base = atomicAdd(stage_n, n);
+        base = lane_value(base, lead);
+        staged = base + n <= K1E_OVF_STAGE;                  // (wave-uniform; a full buffer: straight to the list, the counter keeps the overshoot)
+        if (staged && over) stage[base + mask_rank(m)] = index;
+        if (!staged && lane_id() == lead) atomicAdd(stage_n, 0u - n);
+    }
+    if (!staged) {
         const DevAccum &acc = k1e_lazy_args()->acc;
-        const uint32_t slot = atomicAdd(acc.ovf_count, 1u);
-        if (slot < acc.ovf_cap) acc.ovf_index[slot] = index;
-        else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+        if (lane_id() == lead) base = atomicAdd(acc.ovf_count, n);
+        base = lane_value(base, lead);
+        if (over) {
+            const uint32_t slot = base + mask_rank(m);
+            if (slot < acc.ovf_cap) acc.ovf_index[slot] = index;
+            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+        }
     }
 }
 
@@ -573,7 +630,7 @@ __device__ __forceinline__ void k1e_defer(K1eTables &T, uint64_t m, uint32_t idx
 // full -- every block counted, the first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count ----
 __device__ __forceinline__ void k1e_long_call(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
                                               const ContigInfo &ci, K1eTables &T, uint32_t idx, bool hq, bool on0, uint32_t &sum_blk,
-                                              const K1ePairDst &held, uint32_t chunk) {
+                                              const K1ePairDst &held, uint32_t chunk, unsigned long long *stage, uint32_t *stage_n) {
     const int l = lane_id();
     if (!on0) idx = 0u;
     const int4 cv = ld32(reinterpret_cast<const int4 *>(b.core), idx);
@@ -616,7 +673,7 @@ __device__ __forceinline__ void k1e_long_call(const DevAnnotation &a, const DevP
     const uint32_t qh2 = b.qhash2 ? ld32(b.qhash2, idx) : 0u;
     EiOut eo; bool over = false;
     exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
-    k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx);
+    k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx, stage, stage_n);
     k1e_commit<FAST_BLOCKS, true>(cov_diff, T, eo, B.len, fl, qhash, qh2, held, chunk);
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&T.cnt32[l], cnt.vec);
 }
@@ -656,8 +713,11 @@ frag_compact_kernel(FragCandidates src, FragCandidates dst, uint32_t n_rec, uint
 #endif
 // BED: the run has a BED (--bed: fragment-size candidates).  A template parameter, so that the instance of runs without one carries
 // none of its state (the candidate cursor alone took the kernel from 123 to 128 VGPRs and into scratch).
+#ifndef K1E_MINW_BED
+#define K1E_MINW_BED 5
+#endif
 template <bool BED>
-__global__ void __launch_bounds__(RSQC_K1_THREADS, K1E_MINW)
+__global__ void __launch_bounds__(RSQC_K1_THREADS, BED ? K1E_MINW_BED : K1E_MINW)
 classify_ei_kernel(K1Args A) {
     __shared__ K1eShared S;
     const DevAnnotation &a = A.a; const DevBatch &b = A.b; const DevAccum &acc = A.acc;
@@ -688,13 +748,13 @@ classify_ei_kernel(K1Args A) {
     auto flush_counts = [&]() {
         const uint32_t s0 = wave_sum_u32_full(sum_e1mm), s1 = wave_sum_u32_full(sum_e1b), s2 = wave_sum_u32_full(sum_e2mm), s3 = wave_sum_u32_full(sum_e2b),
                        s4 = wave_sum_u32_full(sum_mm), s5 = wave_sum_u32_full(sum_b), s6 = wave_sum_u32_full(sum_blk);
-        if (k1e_first_lane() && s0) atomicAdd(&S.T.cnt[RSQC_C_END1_MISMATCHES], (unsigned long long)s0);
-        if (k1e_first_lane() && s1) atomicAdd(&S.T.cnt[RSQC_C_END1_BASES], (unsigned long long)s1);
-        if (k1e_first_lane() && s2) atomicAdd(&S.T.cnt[RSQC_C_END2_MISMATCHES], (unsigned long long)s2);
-        if (k1e_first_lane() && s3) atomicAdd(&S.T.cnt[RSQC_C_END2_BASES], (unsigned long long)s3);
-        if (k1e_first_lane() && s4) atomicAdd(&S.T.cnt[RSQC_C_MISMATCHED_BASES], (unsigned long long)s4);
-        if (k1e_first_lane() && s5) atomicAdd(&S.T.cnt[RSQC_C_TOTAL_BASES], (unsigned long long)s5);
-        if (k1e_first_lane() && s6) atomicAdd(&S.T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
+        if (k1e_first_lane() && s0) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_END1_MISMATCHES)], (unsigned long long)s0);
+        if (k1e_first_lane() && s1) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_END1_BASES)], (unsigned long long)s1);
+        if (k1e_first_lane() && s2) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_END2_MISMATCHES)], (unsigned long long)s2);
+        if (k1e_first_lane() && s3) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_END2_BASES)], (unsigned long long)s3);
+        if (k1e_first_lane() && s4) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_MISMATCHED_BASES)], (unsigned long long)s4);
+        if (k1e_first_lane() && s5) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_TOTAL_BASES)], (unsigned long long)s5);
+        if (k1e_first_lane() && s6) atomicAdd(&S.T.cnt[K1eTables::sum_slot(RSQC_C_ALIGNMENT_BLOCKS)], (unsigned long long)s6);
         sum_e1mm = sum_e1b = sum_e2mm = sum_e2b = sum_mm = sum_b = sum_blk = 0;
         pending = 0;
     };
@@ -894,11 +954,16 @@ classify_ei_kernel(K1Args A) {
                 const FragCandidates &fr = q->acc.frag;
                 const uint32_t slot = wg_beg + atomicAdd(&S.T.frags, 1u);       // the workgroup's own region (<= one candidate per record)
                 {
-                    fr.file_index[slot] = batch_file_index(q->b, my_seg, i); fr.qhash[slot] = r.qhash;
+                    // (name hash, mate position and insert size come back from the record arrays -- cache lines this wave streamed a
+                    //  moment ago -- instead of living in registers from the top of phase A to this rare branch: round 5's instance
+                    //  spilled them, 16 bytes per lane written and read in every tile)
+                    const int4 co = reinterpret_cast<const int4 *>(q->b.core)[i];
+                    const uint2 qh = reinterpret_cast<const uint2 *>(q->b.aux)[2u * i];
+                    fr.file_index[slot] = batch_file_index(q->b, my_seg, i); fr.qhash[slot] = (uint64_t)qh.x | ((uint64_t)qh.y << 32);
                     fr.h2[slot] = q->b.qhash2 ? q->b.qhash2[i] : 0u;                 // (the name is 96 bits on every path that keys on it)
                     fr.name[slot] = name; fr.endpos[slot] = rc.endpos;
-                    const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
-                    const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
+                    const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != co.y;
+                    const uint32_t sz = (uint32_t)(co.z < 0 ? -(int64_t)co.z : (int64_t)co.z);
                     fr.flag_size[slot] = (sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u);
                 }
             }
@@ -1111,10 +1176,13 @@ classify_ei_kernel(K1Args A) {
 __global__ void __launch_bounds__(RSQC_K1_THREADS)
 classify_long_kernel(K1Args A, uint32_t k1_grid) {
     __shared__ K1eTables T;
+    __shared__ unsigned long long s_stage[K1E_OVF_STAGE];       // records for the general kernel, moved to its list at the end (k1e_overflow)
+    __shared__ uint32_t s_stage_n;
     const DevAnnotation &a = A.a; const DevBatch &b = A.b; const DevAccum &acc = A.acc;
     const K1ePairDst held = {(uint64_t)(uintptr_t)acc.pairs, acc.pair_chunk_cap};
     const int l = lane_id();
     T.init(0u);
+    if (threadIdx.x == 0) s_stage_n = 0u;
     __syncthreads();
     uint32_t sum_blk = 0;
     const uint32_t n_rec = (uint32_t)b.n;
@@ -1137,15 +1205,25 @@ classify_long_kernel(K1Args A, uint32_t k1_grid) {
             if (__ballot(mine) == 0ull) continue;
             const int32_t tid = b.n_seg ? b.seg_tid[sg] : -1;
             const ContigInfo ci = (tid >= 0 && tid < a.n_contigs) ? a.contig[tid] : ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
-            k1e_long_call(a, A.p, b, acc.cov_diff, ci, T, idx, hq, mine, sum_blk, held, region);
+            k1e_long_call(a, A.p, b, acc.cov_diff, ci, T, idx, hq, mine, sum_blk, held, region, s_stage, &s_stage_n);
         }
     }
     {
         const uint32_t s6 = wave_sum(sum_blk);
-        if (k1e_first_lane() && s6) atomicAdd(&T.cnt[RSQC_C_ALIGNMENT_BLOCKS], (unsigned long long)s6);
+        if (k1e_first_lane() && s6) atomicAdd(&T.cnt[K1eTables::sum_slot(RSQC_C_ALIGNMENT_BLOCKS)], (unsigned long long)s6);
     }
     __syncthreads();
     T.flush(0ull);
+    const uint32_t n_st = s_stage_n;                            // (final since the barrier)
+    if (n_st != 0u) {
+        if (threadIdx.x == 0) T.piece = atomicAdd(acc.ovf_count, n_st);
+        __syncthreads();
+        const uint32_t at = T.piece;
+        for (uint32_t j = threadIdx.x; j < n_st; j += blockDim.x) {
+            if (at + j < acc.ovf_cap) acc.ovf_index[at + j] = s_stage[j];
+            else atomicExch(acc.error, RSQC_ERR_CAPACITY);
+        }
+    }
 }
 
 }  // namespace rsqc

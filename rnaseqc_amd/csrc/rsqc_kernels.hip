@@ -474,9 +474,12 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
         const K1Args A{a, p, b, acc};
         if (a.have_bed) hipLaunchKernelGGL(classify_ei_kernel<true>, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
         else hipLaunchKernelGGL(classify_ei_kernel<false>, dim3(grid), dim3(RSQC_K1_THREADS), pad, s, A);
-        // the records it deferred (more than eight operations / three blocks): one wave per call of 64, grid-stride
-        hipLaunchKernelGGL(classify_long_kernel, dim3((unsigned)std::min(grid, 2048)), dim3(RSQC_K1_THREADS), 0, s, A, (uint32_t)grid);
     }
+}
+// the records classify_ei_kernel deferred (more than eight operations / three blocks): one wave per call of 64, grid-stride
+void launch_classify_long(hipStream_t s, int k1_grid, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevAccum &acc) {
+    const K1Args A{a, p, b, acc};
+    hipLaunchKernelGGL(classify_long_kernel, dim3((unsigned)std::min(k1_grid, 1024)), dim3(RSQC_K1_THREADS), 0, s, A, (uint32_t)k1_grid);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {

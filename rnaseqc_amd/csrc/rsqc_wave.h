@@ -115,6 +115,29 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
     return v;
 }
 
+// inclusive prefix sum over the wave (all 64 lanes active) on DPP moves: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then
+// row_bcast:15 (lane 15 of a row into the next row) and row_bcast:31 (lane 31 into rows 2 and 3) -- six vector instructions instead
+// of six trips through the LDS crossbar
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32_dpp(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQC_DPP_SCAN(ctrl, rmask) { v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); }
+    RSQC_DPP_SCAN(0x111, 0xf) RSQC_DPP_SCAN(0x112, 0xf) RSQC_DPP_SCAN(0x114, 0xf) RSQC_DPP_SCAN(0x118, 0xf)
+    RSQC_DPP_SCAN(0x142, 0xa) RSQC_DPP_SCAN(0x143, 0xc)
+#undef RSQC_DPP_SCAN
+    return v;
+#else
+    return wave_inclusive_scan_u32(v);
+#endif
+}
+// the value of lane `src` (per-lane index, taken modulo 64): one ds_bpermute
+__device__ __forceinline__ uint32_t lane_gather(uint32_t v, uint32_t src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)v);
+#else
+    return __shfl(v, (int)(src & 63u), 64);
+#endif
+}
+
 // One atomic per distinct key in the wave.  Must be called by all 64 lanes (converged).
 template <class F>
 __device__ __forceinline__ void wave_aggregate(bool valid, uint32_t key, uint64_t flagmask, F &&leader) {
