@@ -194,6 +194,40 @@ def end_to_end(args, ann, contigs, batch, st, log, res=None, read_length=None, g
     return out
 
 
+def inflate_model(measured_gbps):
+    """Ceilings of bgzf_inflate_kernel on the realistic-entropy file from ITS counters (profiles/r5_decode_pmc_realistic_6M.txt: the kernel
+    source has not changed since -- rsqc_inflate.h; one wavefront inflates one BGZF block of <= 65 280 bytes in ~2 500 serial rounds):
+      scalar_port   one scalar ALU per CU, one scalar instruction per cycle: CUs x clock / (SALU per block) x bytes per block
+      issue(W)      a wave issues one instruction per ~4.7 cycles (SQ_ACTIVE_INST_ANY / instructions): 1024 SIMDs x W waves x clock /
+                    (instructions per block x 4.7) x bytes per block -- what more waves per SIMD (a smaller decoder state) could lift
+    The binding one is the scalar port; occupancy does not move it."""
+    path = os.path.join(ROOT, "profiles", "r5_decode_pmc_realistic_6M.txt")
+    try:
+        cur, c = None, {}
+        for line in open(path):
+            if not line.startswith(" "):
+                cur = line.strip(); continue
+            if cur and "bgzf_inflate_kernel" in cur:
+                m = re.match(r"\s+(\S+)\s+n=\d+\s+mean=(\S+)", line)
+                if m: c[m.group(1)] = float(m.group(2))
+        blocks = c["SQ_WAVES"]
+        salu, valu, lds = c["SQ_INSTS_SALU"] / blocks, c["SQ_INSTS_VALU"] / blocks, c["SQ_INSTS_LDS"] / blocks
+        instr = salu + valu + lds
+        cyc_per_instr = 4.0 * c["SQ_ACTIVE_INST_ANY"] / (c["SQ_INSTS_SALU"] + c["SQ_INSTS_VALU"] + c["SQ_INSTS_LDS"])
+        bpb, clk = 65280.0, 2.4e9
+        out = {"per_block": {"salu": round(salu), "valu": round(valu), "lds": round(lds), "rounds": 2500, "bytes_per_round": 26, "symbols_per_round": 5.8},
+               "cycles_per_instruction_of_a_wave": round(cyc_per_instr, 2),
+               "scalar_port_ceiling_GBps": round(256 * clk / salu * bpb / 1e9, 1),
+               "issue_ceiling_GBps_at_waves_per_simd": {str(w): round(1024 * w * clk / (instr * cyc_per_instr) * bpb / 1e9, 1) for w in (5, 6, 7)},
+               "measured_GBps": measured_gbps, "file": "realistic entropy",
+               "source": "profiles/r5_decode_pmc_realistic_6M.txt (kernel unchanged since: rsqc_inflate.h)"}
+        out["binding"] = "scalar_port"
+        out["measured_over_binding"] = (measured_gbps / out["scalar_port_ceiling_GBps"]) if measured_gbps else None
+        return out
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
 def k1_floor_model(k1_ms):
     """Lower bounds of classify_ei_kernel on the contract workload from the counters of THIS build (profiles/k1_model.json, written by
     tools/k1_model.py from the rocprofv3 --pmc passes of the same bench command; stamped with the hash of the K1 sources).  Three floors,
@@ -356,6 +390,7 @@ def main():
     vec = None
     order_dep = [None]
     collective_s = [0.0]
+    collective_parts = [0.0, 0.0]              # [issue of the three all_reduce + the wait for them behind the merge, the host-side merge between]
     if reduce_path:
         vec = [torch.as_tensor(v, device="cuda") for v in e.device_vectors()]
 
@@ -376,19 +411,23 @@ def main():
         # RCCL over xGMI: u64 counts | f64 sums + owner-only statistics | u8 validity flags -- issued together, waited for after
         # the host-side merge below (the three reductions overlap each other and the two small gathers of the merge)
         pending = [dist.all_reduce(t, async_op=True) for t in vec]
+        t1 = time.perf_counter()
         # the order-dependent outputs (Read Length; the fragment-size cut-off with --bed): per-batch transfer functions
         # and kept samples of every rank, composed in file order on the host
         order_dep[0] = distributed.merge_order_dependent(e.shard_summary(), dist, torch.device("cuda", local_rank), p.fragment_samples)
+        t2 = time.perf_counter()
         for w in pending:
             w.wait()
         torch.cuda.synchronize()
-        collective_s[0] += time.perf_counter() - tc
+        t3 = time.perf_counter()
+        collective_s[0] += t3 - tc
+        collective_parts[0] += (t1 - tc) + (t3 - t2); collective_parts[1] += t2 - t1
         return e.refresh_results(lazy=True)
 
     for _ in range(args.warmup):
         step()
     e.reset_timing()
-    collective_s[0] = 0.0
+    collective_s[0] = 0.0; collective_parts[0] = collective_parts[1] = 0.0
     if dist: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -508,9 +547,14 @@ def main():
                 # the loop's dominant kernel: GB/s of inflated bytes out of bgzf_inflate_kernel, the two files (end_to_end.*.decode_profile)
                 "inflate_GBps": [(e2e.get("decode_profile") or {}).get("inflate_GBps_of_inflated_bytes"),
                                  ((e2e.get("realistic_entropy") or {}).get("decode_profile") or {}).get("inflate_GBps_of_inflated_bytes")],
+                "inflate_model": inflate_model(((e2e.get("realistic_entropy") or {}).get("decode_profile") or {}).get("inflate_GBps_of_inflated_bytes")),
                 "note": "`rnaseqc gtf bam out` on a BAM of the same records: BGZF inflate + BAM parse on the GPU + the hot path + end-of-file stage; details in end_to_end"},
             "end_to_end": e2e,
             "collective_ms": (1e3 * collective_s[0] / max(args.steps, 1)) if reduce_path else None,   # per step: 3 async all_reduce + 2 gathers + host merge
+            # ... split: what the three RCCL all_reduce cost by the host's clock (their issue + the wait for them BEHIND the merge: the part
+            # the merge does not hide), and the host-side merge of the order-dependent outputs (two packed all_gathers + numpy) between the two
+            "collective_rccl_exposed_ms": (1e3 * collective_parts[0] / max(args.steps, 1)) if reduce_path else None,
+            "collective_host_merge_ms": (1e3 * collective_parts[1] / max(args.steps, 1)) if reduce_path else None,
             "stage_ms": {"classify_k1": k1_ms * len(handles), "classify_long": k1_long_ms * len(handles), "classify_launches_per_step": len(handles), "finalize_kernels": tm["finalize_ms"] / max(args.steps, 1),
                          "fragment_sizes": (tm.get("fragment_sizes_ms", 0.0) / max(args.steps, 1)) if args.bed else None,
                          "slow_path_records": int(tm["slow_records"])},

@@ -371,6 +371,11 @@ typedef struct rsqc_results {
     const uint64_t *gc_bins;           /* [RSQC_GC_BINS]                       */
     uint64_t gc_out_of_range;
     const double   *exon_gc;           /* [n_exons], exonList order            */
+    /* ABI 5: exon rows of the annotation that lie outside the row of their gene (0 for a well-formed GTF).  Non-zero means that
+       gene_fragments and the coverage / bias statistics of THOSE genes are computed "as if the gene stayed in the window" and can
+       differ from the reference's streamed result (rsqc_set_annotation's warning): the divergence is flagged in the
+       results themselves, not only in rsqc_last_error, which any later failure overwrites.                                    */
+    uint32_t exons_outside_gene_row;
 } rsqc_results;
 
 /* ---- timing of the device work (HIP events on the context's own stream) --- */

@@ -1156,6 +1156,7 @@ ORACLE_API int oracle_finalize(oracle_ctx *c, rsqc_results *out) {
     out->n_fragment_sizes = (uint32_t)c->fs_n; out->fragment_size = c->fs_size; out->fragment_count = c->fs_count;
     out->fragment_samples_remaining = c->frag_remaining;
     out->have_reference = c->have_ref; out->gc_bins = c->gc_bins; out->gc_out_of_range = c->gc_oob; out->exon_gc = c->exon_gc;
+    out->exons_outside_gene_row = 0;          /* (the restatement streams like the reference: such rows get the reference's treatment) */
     return 0;
 }
 

@@ -165,6 +165,7 @@ class ResultsStruct(C.Structure):
         ("n_fragment_sizes", C.c_uint32), ("fragment_size", _P), ("fragment_count", _P),
         ("fragment_samples_remaining", C.c_uint32),
         ("have_reference", C.c_int32), ("gc_bins", _P), ("gc_out_of_range", C.c_uint64), ("exon_gc", _P),
+        ("exons_outside_gene_row", C.c_uint32),
     ]
 
 
@@ -221,6 +222,7 @@ class Results:
         self._rs = rs
         self.have_reference = int(rs.have_reference)
         self.gc_out_of_range = int(rs.gc_out_of_range)
+        self.exons_outside_gene_row = int(rs.exons_outside_gene_row)     # (ABI 5: non-zero flags the divergence DESIGN.md 5 describes)
         self._n = {"G": rs.n_genes_listed, "E": rs.n_exons, "F": rs.n_fragment_sizes,
                    "B": GC_BINS if rs.have_reference else 0, "R": rs.n_exons if rs.have_reference else 0}
         self.read_length = int(rs.read_length)

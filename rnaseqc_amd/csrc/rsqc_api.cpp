@@ -156,7 +156,7 @@ struct rsqc_ctx {
     const uint8_t *d_gene_flags = nullptr, *d_gene_owned = nullptr;   // owned by ann_bufs
     const uint32_t *d_gene_order = nullptr;
     uint32_t k3_large = 0, k3_medium = 0, k3_xlarge = 0;
-    bool k3_use_xlarge = true;
+    uint32_t n_exons_outside_gene = 0;          // of the annotation in use (rsqc_results.exons_outside_gene_row)
     hipEvent_t fin_e0 = nullptr, fin_e1 = nullptr;
     uint64_t cov_entries = 0;
     bool have_bed = false;
@@ -428,7 +428,10 @@ void free_parked(rsqc_ctx *c) {                 // caller: the stream has been s
     c->parked.clear();
 }
 
-// Retires every in-flight batch whose kernels have completed (all of them when `all` -- the caller has synchronised).
+// Retires every in-flight batch whose kernels have completed -- all of them when `all`, waiting for each batch's `done` event
+// (the caller need NOT have synchronised: `done` is recorded on the side stream behind the copy of the batch's pair counts, which
+// waits for `kernels`, recorded on the main stream behind the batch's last kernel AND behind the copies of its fragment-size / GC
+// candidate counts -- so those mirrors are valid too once `done` has fired).
 int retire_completed(rsqc_ctx *c, bool all) {
     size_t keep = 0;
     for (size_t k = 0; k < c->pairs_in_flight.size(); ++k) {
@@ -537,15 +540,17 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     // --legacy: every pair comes from the general kernel (one per gene a record is counted to; 4 per record is far
     // above what annotations produce -- beyond it the run fails with RSQC_ERR_CAPACITY)
     const uint64_t slow_cap = c->dparams.legacy ? std::max<uint64_t>(1ull << 20, 4ull * u->n) : 1ull << 20;
-    const uint64_t want = chunk_cap * (uint64_t)grid + slow_cap;
+    // chunks: one per K1 workgroup, then one per workgroup of classify_long_kernel (the records K1 defers; none under --legacy)
+    const int n_chunks = grid + (c->dparams.legacy ? 0 : rsqc_long_grid(grid));
+    const uint64_t want = chunk_cap * (uint64_t)n_chunks + slow_cap;
     if (want > 0xFFFFFFF0ull) return fail(c, RSQC_ERR_ARG, "batch too large (split it)");
     { int rcr = retire_completed(c, false); if (rcr) return rcr; }     // completed batches hand their buffers back first
     size_t pidx = 0;
-    PairBuf *pb = acquire_pairs(c, want, (uint32_t)grid + 1, &pidx);
+    PairBuf *pb = acquire_pairs(c, want, (uint32_t)n_chunks + 1, &pidx);
     if (!pb) return fail(c, RSQC_ERR_HIP, "hipMalloc(pair buffer) failed");
-    pb->n_chunks = (uint32_t)grid; pb->chunk_cap = (uint32_t)chunk_cap;
+    pb->n_chunks = (uint32_t)n_chunks; pb->chunk_cap = (uint32_t)chunk_cap;
     pb->pairs_bound = std::min<uint64_t>(want, u->n * (uint64_t)FAST_SET + slow_cap);
-    pb->slow_base = (uint32_t)(chunk_cap * (uint64_t)grid); pb->slow_cap = (uint32_t)slow_cap;
+    pb->slow_base = (uint32_t)(chunk_cap * (uint64_t)n_chunks); pb->slow_cap = (uint32_t)slow_cap;
     c->pairs_in_flight.push_back(pidx);
     // (no per-batch memsets: every K1 workgroup writes its own chunk count, workgroup 0 zeroes the slow-path pair
     //  counter, and the overflow counter is re-armed by the last kernel of the previous batch / the reset kernel)
@@ -553,7 +558,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     acc.pairs = (PairRec *)pb->rec.p;
     acc.pair_chunk_cap = pb->chunk_cap; acc.pair_chunk_count = (uint32_t *)pb->counts.p;
     acc.pair_slow_base = pb->slow_base; acc.pair_slow_cap = pb->slow_cap;
-    acc.pair_slow_count = (uint32_t *)pb->counts.p + grid;
+    acc.pair_slow_count = (uint32_t *)pb->counts.p + n_chunks;
     FragCandidates frag_dense{};
     if (c->have_bed) {
         size_t fidx = c->frag_pool.size();
@@ -657,7 +662,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     if (c->have_ref && !c->dparams.legacy) { GcBuf &gb = c->gc_pool[c->gcs_in_flight.back()]; HIP_TRY(c, hipMemcpyAsync(gb.h_count, gb.count.p, 4, hipMemcpyDeviceToHost, c->stream)); }
     HIP_TRY(c, hipEventRecord(pb->kernels, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream2, pb->kernels, 0));
-    HIP_TRY(c, hipMemcpyAsync(pb->h_counts, pb->counts.p, ((size_t)grid + 1) * 4, hipMemcpyDeviceToHost, c->stream2));
+    HIP_TRY(c, hipMemcpyAsync(pb->h_counts, pb->counts.p, ((size_t)n_chunks + 1) * 4, hipMemcpyDeviceToHost, c->stream2));
     HIP_TRY(c, hipEventRecord(pb->done, c->stream2));
     HIP_TRY(c, hipGetLastError());
     c->timing.classify_launches += 1;
@@ -699,7 +704,6 @@ int rsqc_create(const rsqc_params *params, rsqc_ctx **out) {
     c->frag_arena.n_col = 6; { const size_t w[6] = {8, 8, 4, 4, 4, 4}; for (int k = 0; k < 6; ++k) c->frag_arena.width[k] = w[k]; }   // ..., second name hash
     c->gc_arena.n_col = 7; { const size_t w[7] = {8, 8, 4, 4, 4, 4, 4}; for (int k = 0; k < 7; ++k) c->gc_arena.width[k] = w[k]; }   // ..., second name hash
     if (const char *e = getenv("RSQC_K1_GRID")) c->k1_grid = std::min(16384, std::max(1, atoi(e)));
-    if (const char *e = getenv("RSQC_K3_XLARGE")) c->k3_use_xlarge = atoi(e) != 0;   // 0: the longest genes run from memory in the 64 KB class (A/B)
     *out = c;
     return RSQC_OK;
 }
@@ -865,6 +869,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     if ((rc = zero_accumulators(c))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->last_error = hx.warning;                  // (RSQC_OK with a warning: an exon outside its gene's row, see rsqc_index.h)
+    c->n_exons_outside_gene = hx.n_exons_outside_gene;
     return RSQC_OK;
 }
 
@@ -1068,6 +1073,7 @@ static int read_back(rsqc_ctx *c) {
     R.gc_bins = c->have_ref ? c->h_gc.data() : nullptr;
     R.gc_out_of_range = c->have_ref ? c->h_gc[RSQC_GC_BINS] : 0;
     R.exon_gc = c->have_ref ? c->h_exon_gc.data() : nullptr;
+    R.exons_outside_gene_row = c->n_exons_outside_gene;
     c->timing.slow_records = *(const uint32_t *)(H + c->off_misc + 4);
     const int err = *(const int *)(H + c->off_misc + 16);
     if (err) {
@@ -1089,7 +1095,34 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         // the side streams start from here (recorded BEFORE the K4 kernels are enqueued on the main stream)
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        // ---- K4 on the main stream: per-gene distinct QNAMEs (the longer chain: enqueued first) ---------------
+        // ---- K3 on the side streams: coverage scan + per-gene statistics + bias.  Enqueued BEFORE the fragment stage: with several batches
+        //      in flight that stage begins with a host-side wait (retire_completed below), and the coverage kernels -- which depend on
+        //      the fork event only -- would otherwise not even be queued while the host sleeps -----------------------
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
+        GeneCovArgs Ga{};
+        Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
+        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov; Ga.ex_id = c->dann.ex_id;
+        Ga.gene_cov_off = c->d_gene_cov_off; Ga.gene_coding = c->d_gene_coding;
+        Ga.gene_flags = c->d_gene_flags; Ga.gene_owned = c->d_gene_owned;
+        Ga.gene_order = c->d_gene_order;
+        Ga.gene_reads = c->acc.gene_reads; Ga.cov = c->acc.cov_diff; Ga.n_listed = L;
+        Ga.mask = c->params.coverage_mask; Ga.bias_offset = c->params.bias_offset; Ga.bias_window = c->params.bias_window;
+        Ga.bias_gene_length = c->params.bias_gene_length;
+        Ga.g_mean = (double *)(A + c->off_gmean); Ga.g_std = (double *)(A + c->off_gstd); Ga.g_cv = (double *)(A + c->off_gcv);
+        Ga.g_valid = (uint8_t *)(A + c->off_gvalid); Ga.e_cv = (double *)(A + c->off_ecv); Ga.e_cv_valid = (uint8_t *)(A + c->off_ecvv);
+        Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
+        Ga.error = c->acc.error;
+        {
+            uint32_t nl = c->k3_large, nm = c->k3_medium, nx = c->k3_xlarge;
+            if (const char *e = RSQC_DIAG("RSQC_K3_FORCE")) {        // diagnostic build only: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
+                const int f = atoi(e);
+                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; nx = 0; } else if (f == 3) { nl = 0; nm = 0; nx = 0; } else if (f == 4) { nl = (uint32_t)L; nm = 0; nx = (uint32_t)L; }
+            }
+            if (!RSQC_DIAG("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm, nx);   // (diagnostic build only: results incomplete)
+        }
+        // ---- K4 on the main stream: per-gene distinct QNAMEs -------------------------------------------------
         // Several batches still in flight (a host that enqueued its batches faster than the device ran them -- bench.py's resident
         // batches, one per contig of a sharded run): they are retired into the arena first, so that the fragment stage runs ONE pass
         // over one dense list instead of one launch per batch over worst-case chunk tables (26 batches: 2.0 ms of frag_local
@@ -1139,32 +1172,7 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
             }
             if (!RSQC_DIAG("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
         }
-        RSQC_TRACE("finalize: K4 enqueued");
-        // ---- K3 on the second stream: coverage scan + per-gene statistics + bias -----------------------
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
-        GeneCovArgs Ga{};
-        Ga.ge_off = c->d_ge_off; Ga.ge_row = c->d_ge_row;
-        Ga.ex = c->dann.ex; Ga.ex_cov = c->dann.ex_cov; Ga.ex_id = c->dann.ex_id;
-        Ga.gene_cov_off = c->d_gene_cov_off; Ga.gene_coding = c->d_gene_coding;
-        Ga.gene_flags = c->d_gene_flags; Ga.gene_owned = c->d_gene_owned;
-        Ga.gene_order = c->d_gene_order;
-        Ga.gene_reads = c->acc.gene_reads; Ga.cov = c->acc.cov_diff; Ga.n_listed = L;
-        Ga.mask = c->params.coverage_mask; Ga.bias_offset = c->params.bias_offset; Ga.bias_window = c->params.bias_window;
-        Ga.bias_gene_length = c->params.bias_gene_length;
-        Ga.g_mean = (double *)(A + c->off_gmean); Ga.g_std = (double *)(A + c->off_gstd); Ga.g_cv = (double *)(A + c->off_gcv);
-        Ga.g_valid = (uint8_t *)(A + c->off_gvalid); Ga.e_cv = (double *)(A + c->off_ecv); Ga.e_cv_valid = (uint8_t *)(A + c->off_ecvv);
-        Ga.bias3 = (unsigned long long *)(A + c->off_bias3); Ga.bias5 = (unsigned long long *)(A + c->off_bias5);
-        Ga.error = c->acc.error;
-        {
-            uint32_t nl = c->k3_large, nm = c->k3_medium, nx = c->k3_use_xlarge ? c->k3_xlarge : 0u;
-            if (const char *e = RSQC_DIAG("RSQC_K3_FORCE")) {        // diagnostic build only: 1 = all 1024-thread, 2 = all 256, 3 = all one-wave
-                const int f = atoi(e);
-                if (f == 1) { nl = (uint32_t)L; nm = 0; } else if (f == 2) { nl = 0; nm = (uint32_t)L; nx = 0; } else if (f == 3) { nl = 0; nm = 0; nx = 0; } else if (f == 4) { nl = (uint32_t)L; nm = 0; nx = (uint32_t)L; }
-            }
-            if (!RSQC_DIAG("RSQC_DIAG_SKIP_K3")) launch_gene_coverage(c->stream2, c->stream3, c->stream4, Ga, nl, nm, nx);   // (diagnostic build only: results incomplete)
-        }
+        RSQC_TRACE("finalize: K3 + K4 enqueued");
         {   // per-batch Read-Length transfer functions (rsqc_shard_info): final since the last batch's read_length_kernel; the copy
             // goes out on a side stream behind its coverage kernel (behind frag_count on the main stream it cost a queue hand-over:
             // ~40 us) and is covered by that stream's join below; the destination is page-locked, the call returns at once

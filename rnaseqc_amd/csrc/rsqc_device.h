@@ -156,6 +156,8 @@ void launch_pack_results(hipStream_t s, const double *exon_acc, uint8_t *exon_hi
 void launch_reset(hipStream_t s, void *arena, size_t arena_bytes, void *cov, size_t cov_bytes, uint32_t *rl_min);
 void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                      const DevAccum &acc);
+// workgroups of classify_long_kernel for a K1 grid (each owns a pair chunk of its own behind the K1 grid's)
+inline int rsqc_long_grid(int k1_grid) { return k1_grid < 1024 ? k1_grid : 1024; }
 void launch_classify_long(hipStream_t s, int k1_grid, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevAccum &acc);
 void launch_ei_rank(hipStream_t s, const EiEntry *ei, uint32_t ei_lo, uint32_t ei_hi, EiRank *rank, uint32_t n_words);
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
@@ -177,7 +179,7 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 #endif
 // one entry of a partition's key list: the 96-bit identity of a read name (rsqc_rec_aux::qhash, rsqc_batch.qhash2 -- 0 for a
 // caller that has none), written with ONE 12-byte store
-struct FragKey { uint32_t lo, hi, h2; };
+struct FragKey { uint32_t lo, hi, h2; };          // (16-byte aligned entries measured the same: profiles/r6_k1_variants.txt, call r6d)
 struct FragPlan {
     uint32_t *part_first;          // [G + 1] first partition of a gene
     uint32_t *cursor;              // [parts] keys appended so far

@@ -24,6 +24,7 @@ struct HostIndex {
     std::vector<uint32_t> ei_range;                   // [n_contigs + 1]
     uint64_t rank_words = 0;                          // words of the rank table over all contigs
     std::string warning;                              // build(): what the annotation has that the reference only tolerates (empty: nothing)
+    uint32_t n_exons_outside_gene = 0;                // ... exon rows outside the row of their gene (rsqc_results.exons_outside_gene_row)
     // Coarse table over the same positions, one word per 512 (= 8 rank words; every contig's part of the rank table starts at a
     // multiple of 8 words, so the two tables share ContigInfo::rk_base): 0, or 1 + the index of the interval that covers ALL of
     // the 1024 positions [b * 512, (b + 2) * 512) -- no breakpoint in there.  A read in the empty stretches of the genome
@@ -169,7 +170,7 @@ struct HostIndex {
         // overlaps only); geneFragmentCounts and the coverage / bias statistics of such a gene are what the reference would give if
         // the gene never retired early, and differ from its streamed result exactly when a record that starts behind the gene row's
         // end is counted to the gene.  The first such row is reported as a WARNING (`warning`, rsqc_last_error).
-        warning.clear();
+        warning.clear(); n_exons_outside_gene = 0;
         {
             std::vector<int32_t> gs((size_t)std::max(L, 1), 0), ge((size_t)std::max(L, 1), 0), gc((size_t)std::max(L, 1), -1);
             for (int i = 0; i < L; ++i) {
@@ -187,6 +188,7 @@ struct HostIndex {
                                   ") lies outside the row of its gene (" + std::to_string(gs[g]) + "-" + std::to_string(ge[g]) + ")";
                 }
             }
+            n_exons_outside_gene = (uint32_t)n_out;
             if (n_out) warning += (n_out > 1 ? " and " + std::to_string(n_out - 1) + " more" : std::string()) +
                                   ": the reference retires a gene when its row leaves the sorted stream (\"Gene encountered after computing coverage\"); "
                                   "fragment counts and coverage statistics of such genes are computed as if the gene stayed";

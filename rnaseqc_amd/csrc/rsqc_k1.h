@@ -66,11 +66,36 @@ static unsigned long long g_k1e_uniform_calls = 0;   // (test harness: one-block
 static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
 
+// Streams that are read ONCE (the core half-records, the CIGAR pool) and written once (the pairs) can be marked non-temporal: the line is
+// the first to leave the XCD's L2, which then keeps what the feature stages come BACK for -- the auxiliary half-records (name hashes), the
+// rank words and interval entries.  K1E_NT: bit 0 the record / CIGAR loads, bit 1 the pair stores (A/B, call r6f).
+#ifndef K1E_NT
+#define K1E_NT 0
+#endif
+template <class T> __device__ __forceinline__ T k1e_ld32_stream(const T *base, uint32_t idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (K1E_NT & 1) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        static_assert(sizeof(T) == 16, "16-byte streams");
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(base) + (uint32_t)(idx * 16u)));
+        T r; __builtin_memcpy(&r, &v, 16); return r;
+    }
+#endif
+    return ld32(base, idx);
+}
 // eight CIGAR operations of one record in TWO loads (a 16-byte global load needs only dword alignment; eight separate
 // dword gathers were eight trips through the address unit)
 struct alignas(4) Cig4 { uint32_t v[4]; };
 __device__ __forceinline__ void k1e_load_cigar8(const uint32_t *cigar, uint32_t off, uint32_t (&c)[8]) {
     const char *const at = reinterpret_cast<const char *>(cigar) + (uint32_t)(off * 4u);       // buffers carry 32 bytes of slack
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (K1E_NT & 1) {
+        typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+        const u32x4a l4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4a *>(at)), h4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4a *>(at + 16));
+        c[0] = l4.x; c[1] = l4.y; c[2] = l4.z; c[3] = l4.w; c[4] = h4.x; c[5] = h4.y; c[6] = h4.z; c[7] = h4.w;
+        return;
+    }
+#endif
     const Cig4 lo = *reinterpret_cast<const Cig4 *>(at), hi = *reinterpret_cast<const Cig4 *>(at + 16);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { c[k] = lo.v[k]; c[4 + k] = hi.v[k]; }
@@ -201,10 +226,18 @@ struct K1eQueue1 { uint32_t bs[K1E_QCAP], lf[K1E_QCAP], idx[K1E_QCAP];       // 
 #endif
 };
 struct K1eQueue2 { uint32_t bs0[K1E_QCAP], len0[K1E_QCAP], bs1[K1E_QCAP], len1[K1E_QCAP], idx[K1E_QCAP], flhq[K1E_QCAP]; };   // two blocks
-// three blocks (round 6: captured by phase A's walk over the eight staged operations).  64 slots: a record that finds the ring full goes
-// to the deferred list instead (the ring fills with ~5 records per tile and is emptied at 64: about one three-block record in 25)
-constexpr int K1E_Q3CAP = 64;
-struct K1eQueue3 { uint32_t bs0[K1E_Q3CAP], len0[K1E_Q3CAP], bs1[K1E_Q3CAP], len1[K1E_Q3CAP], bs2[K1E_Q3CAP], len2[K1E_Q3CAP], idx[K1E_Q3CAP], flhq[K1E_Q3CAP]; };
+// three blocks (round 6: captured by phase A's walk over the eight staged operations), lengths in 16 bits each (a longer block -- never
+// seen in RNA-seq -- is classify_long_kernel's): lens01 = len0 | len1 << 16, lf2 = len2 | flag bits 0-11 << 16 | high quality << 28.
+// 84 slots (what the workgroup's LDS budget leaves; a ring of any size: the slot index wraps by one compare): the ring is emptied at 64,
+// so a tile's records find it full only when more than 20 of them have three blocks; those go to the deferred list instead.  (Call r6c, 64
+// slots of 8 words: the surplus was a third of the deferred records.)
+#ifndef K1E_Q3CAP_N
+#define K1E_Q3CAP_N 84
+#endif
+constexpr int K1E_Q3CAP = K1E_Q3CAP_N;
+static_assert(K1E_Q3CAP >= 64 && K1E_Q3CAP <= 128, "the three-block ring holds at least one full call");
+struct K1eQueue3 { uint32_t bs0[K1E_Q3CAP], bs1[K1E_Q3CAP], bs2[K1E_Q3CAP], lens01[K1E_Q3CAP], lf2[K1E_Q3CAP], idx[K1E_Q3CAP]; };
+__device__ __forceinline__ uint32_t k1e_wrap3(uint32_t s) { return s >= (uint32_t)K1E_Q3CAP ? s - (uint32_t)K1E_Q3CAP : s; }    // (s < 2 * K1E_Q3CAP)
 struct K1eShared {
     K1eTables T;
     K1eQueue1 q1[K1E_WAVES];
@@ -253,17 +286,34 @@ __device__ __forceinline__ bool k1e_first_lane() { return K1E_CONSTMASK ? WaveSi
 template <int N> __device__ __forceinline__ bool k1e_lane_below() { static_assert(N > 0 && N < 64, "lanes"); return K1E_CONSTMASK ? WaveSink::lane(LaneMask{(1ull << N) - 1ull}) : lane_id() < N; }
 
 // ---- (gene, name) pairs of the lanes of `m` into the workgroup's chunk: one LDS slot reservation per wave, one coalesced 16-byte store per lane ----
-// GLOBAL_SLOT (classify_long_kernel: several workgroups add to one chunk): the reservation is a memory atomic on the chunk's count
-template <bool GLOBAL_SLOT = false>
+// LANE_CHUNK (classify_long_kernel's fall-back, see there): `chunk` is a per-lane value -- the chunk of the K1 workgroup that listed the
+// record -- and the slot a returning memory atomic per pair on that chunk's count.  (As the kernel's only path this cost 0.6 ms, call r6d:
+// the lanes of a call share a few chunks, and same-address returning atomics complete at ~88 per microsecond.)
+template <bool LANE_CHUNK = false>
 __device__ __forceinline__ void k1e_emit_pairs(K1eTables &T, uint64_t m, uint32_t g, uint64_t qhash, uint32_t qh2, const K1ePairDst &pd, uint32_t chunk) {
+    if (LANE_CHUNK) {
+        if (WaveSink::lane(LaneMask{m})) {
+            const uint32_t slot = atomicAdd(&k1e_lazy_args()->acc.pair_chunk_count[chunk], 1u);
+            if (slot < pd.cap) K1E_GLOBAL(PairRec, (PairRec *)(uintptr_t)pd.pairs)[(size_t)chunk * pd.cap + slot] = PairRec{g, qh2, qhash};
+            else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
+        }
+        return;
+    }
     const int lead = __ffsll((unsigned long long)m) - 1;
     uint32_t base = 0;
-    if (lane_id() == lead) base = GLOBAL_SLOT ? atomicAdd(&k1e_lazy_args()->acc.pair_chunk_count[chunk], (uint32_t)__popcll(m)) : atomicAdd(&T.pairs, (uint32_t)__popcll(m));
+    if (lane_id() == lead) base = atomicAdd(&T.pairs, (uint32_t)__popcll(m));
     base = lane_value(base, lead);
     if (WaveSink::lane(LaneMask{m})) {
         const uint32_t slot = base + mask_rank(m);
         const size_t chunk_at = (size_t)chunk * pd.cap;
         if (slot < pd.cap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (K1E_NT & 2) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = {g, qh2, (uint32_t)qhash, (uint32_t)(qhash >> 32)};
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(K1E_GLOBAL(PairRec, (PairRec *)(uintptr_t)pd.pairs) + (chunk_at + slot)));
+            } else
+#endif
             K1E_GLOBAL(PairRec, (PairRec *)(uintptr_t)pd.pairs)[chunk_at + slot] = PairRec{g, qh2, qhash};          // (one 16-byte store)
         } else atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_CAPACITY);
     }
@@ -273,7 +323,7 @@ __device__ __forceinline__ void k1e_emit_pairs(K1eTables &T, uint64_t m, uint32_
 // exonCounts[eid] += len / aligned (src/Expression.cpp:345, Metrics.cpp:59-66) and the per-gene counters go to the
 // workgroup's LDS tables; per-base coverage goes to memory as a difference array (+1 at the block's first base, -1 after
 // its last), identical neighbouring slots merged into one atomic; (gene, qname-hash) pairs go to the workgroup's chunk.
-template <int NB, bool GLOBAL_SLOT = false>
+template <int NB, bool LANE_CHUNK = false>
 __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, const EiOut &eo, const uint32_t (&len)[NB], uint32_t fl,
                                            uint64_t qhash, uint32_t qh2, const K1ePairDst &held, uint32_t chunk) {
     typedef WaveSink WS;
@@ -342,7 +392,7 @@ __device__ __forceinline__ void k1e_commit(uint32_t *cov_diff, K1eTables &T, con
         const uint64_t m = WS::prim(eo.n_hit > k).m;
         if (m == 0ull) break;
         const uint32_t g = eo.hit[k];
-        if (!(K1E_ABL & 8)) k1e_emit_pairs<GLOBAL_SLOT>(T, m, g, qhash, qh2, pd, chunk);
+        if (!(K1E_ABL & 8)) k1e_emit_pairs<LANE_CHUNK>(T, m, g, qhash, qh2, pd, chunk);
         if (NB > 1 || k > 0) {
             const RunLite r = make_run_lite(m, g);
             const uint64_t nd = m & notdup;
@@ -545,7 +595,7 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     static_assert(NB >= 1 && NB <= 3, "queues of one-, two- and three-block records");
     const int l = lane_id();
     const bool on = (uint32_t)l < n;
-    const uint32_t slot = (head + (uint32_t)l) & ((NB == 3 ? K1E_Q3CAP : K1E_QCAP) - 1);
+    const uint32_t slot = NB == 3 ? k1e_wrap3(head + (uint32_t)l) : ((head + (uint32_t)l) & (K1E_QCAP - 1));
     int32_t bs[NB]; uint32_t len[NB]; uint32_t idx, flhq, pre0 = 0u;
     if (NB == 1) {
         const K1eQueue1 &q = S.q1[wave];
@@ -560,8 +610,10 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
         bs[0] = (int32_t)q.bs0[slot]; len[0] = q.len0[slot]; bs[NB - 1] = (int32_t)q.bs1[slot]; len[NB - 1] = q.len1[slot]; idx = q.idx[slot]; flhq = q.flhq[slot];
     } else {
         const K1eQueue3 &q = S.q3[wave];
-        bs[0] = (int32_t)q.bs0[slot]; len[0] = q.len0[slot]; bs[NB > 1 ? 1 : 0] = (int32_t)q.bs1[slot]; len[NB > 1 ? 1 : 0] = q.len1[slot];
-        bs[NB - 1] = (int32_t)q.bs2[slot]; len[NB - 1] = q.len2[slot]; idx = q.idx[slot]; flhq = q.flhq[slot];
+        const uint32_t l01 = q.lens01[slot], lf = q.lf2[slot];
+        bs[0] = (int32_t)q.bs0[slot]; len[0] = l01 & 0xFFFFu; bs[NB > 1 ? 1 : 0] = (int32_t)q.bs1[slot]; len[NB > 1 ? 1 : 0] = l01 >> 16;
+        bs[NB - 1] = (int32_t)q.bs2[slot]; len[NB - 1] = lf & 0xFFFFu; idx = q.idx[slot];
+        flhq = ((lf >> 16) & 0xFFFu) | ((lf >> 28) << 16);                  // flag bits 0-11, K1E_HQ
     }
     if (!on) { idx = 0u; flhq = 0u; pre0 = 0u; }
 #if defined(RSQC_WAVE_EMU)
@@ -614,7 +666,6 @@ __device__ __forceinline__ void k1e_walk3(int32_t pos, uint32_t n, const uint32_
     w.b0 = b0; w.b1 = b1; w.b2 = b2; w.l0 = l0; w.l1 = l1; w.l2 = l2;
 }
 
-constexpr uint32_t K1E_DEFER_NONE = 0xFFFFFFFFu;       // padding entry of the dense deferred list (no record has index 2^31 - 1 with the flag set: a batch holds fewer than 2^31)
 // a record for classify_long_kernel: the workgroup's own region of the deferred list (slot = first record of its range + an LDS
 // counter: a record is listed at most once), no memory atomic.  Entry: record index | high quality << 31.
 __device__ __forceinline__ void k1e_defer(K1eTables &T, uint64_t m, uint32_t idx, bool hq, uint32_t wg_beg) {
@@ -628,6 +679,7 @@ __device__ __forceinline__ void k1e_defer(K1eTables &T, uint64_t m, uint32_t idx
 
 // ---- 64 deferred records (classify_long_kernel): record words, CIGAR and name hashes come from memory, the CIGAR is walked in
 // full -- every block counted, the first FAST_BLOCKS captured -- and the record takes the feature stage with its own block count ----
+template <bool LANE_CHUNK>
 __device__ __forceinline__ void k1e_long_call(const DevAnnotation &a, const DevParams &p, const DevBatch &b, uint32_t *cov_diff,
                                               const ContigInfo &ci, K1eTables &T, uint32_t idx, bool hq, bool on0, uint32_t &sum_blk,
                                               const K1ePairDst &held, uint32_t chunk, unsigned long long *stage, uint32_t *stage_n) {
@@ -674,7 +726,7 @@ __device__ __forceinline__ void k1e_long_call(const DevAnnotation &a, const DevP
     EiOut eo; bool over = false;
     exon_metrics_ei<FAST_BLOCKS, WaveSink>(a, p, ci, fl, B.bs, B.len, hq, eo, over, cnt, fast, cw.nblocks);
     k1e_overflow(on && cw.nblocks >= 1 && (over || !fast), (uint64_t)idx, stage, stage_n);
-    k1e_commit<FAST_BLOCKS, true>(cov_diff, T, eo, B.len, fl, qhash, qh2, held, chunk);
+    k1e_commit<FAST_BLOCKS, LANE_CHUNK>(cov_diff, T, eo, B.len, fl, qhash, qh2, held, chunk);
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&T.cnt32[l], cnt.vec);
 }
 
@@ -714,7 +766,7 @@ frag_compact_kernel(FragCandidates src, FragCandidates dst, uint32_t n_rec, uint
 // BED: the run has a BED (--bed: fragment-size candidates).  A template parameter, so that the instance of runs without one carries
 // none of its state (the candidate cursor alone took the kernel from 123 to 128 VGPRs and into scratch).
 #ifndef K1E_MINW_BED
-#define K1E_MINW_BED 5
+#define K1E_MINW_BED 4           /* the --bed instance: 113 VGPRs, no scratch; held to 96 it spills 60 bytes and runs 3.59 instead of 3.22 ms (call r6d) */
 #endif
 template <bool BED>
 __global__ void __launch_bounds__(RSQC_K1_THREADS, BED ? K1E_MINW_BED : K1E_MINW)
@@ -823,7 +875,7 @@ classify_ei_kernel(K1Args A) {
     uint32_t cg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nx_co = 0;                                                   // CIGAR offset of this lane's record of the NEXT tile
     uint32_t rk_pf = 0, rk_pf2 = 0; (void)rk_pf; (void)rk_pf2;                                       // rank-table words prefetched for the NEXT tile's records (K1E_RANK_PREFETCH; never read)
-    uint32_t cur_cz = 0;                                                  // coarse-table word of this lane's record (DevAnnotation::ei_coarse): 0, or 1 + the
+    uint32_t cur_cz = 0; (void)cur_cz;                                                  // coarse-table word of this lane's record (DevAnnotation::ei_coarse): 0, or 1 + the
                                                                           // interval that covers the 1024 breakpoint-free positions around its start
     const int4 *const core4 = reinterpret_cast<const int4 *>(b.core), *const aux4 = reinterpret_cast<const int4 *>(b.aux);
     const uint32_t *const core1 = reinterpret_cast<const uint32_t *>(b.core);
@@ -834,7 +886,7 @@ classify_ei_kernel(K1Args A) {
     // (addresses stay scalar base + 32-bit lane offset: the tile's first record, then min(lane, records left - 1))
     auto tile_base = [&](uint32_t w) -> uint32_t { return w == NONE ? 0u : w; };
     auto lane_off = [&](uint32_t wb) -> uint32_t { const uint32_t left = last_rec - wb; return (uint32_t)l < left ? (uint32_t)l : left; };
-    { const uint32_t wb = tile_base(w0), lo = lane_off(wb); cur_cv = ld32(core4 + wb, lo); cur_av = ld32(aux4 + wb, lo); }
+    { const uint32_t wb = tile_base(w0), lo = lane_off(wb); cur_cv = k1e_ld32_stream(core4 + wb, lo); cur_av = ld32(aux4 + wb, lo); }
     { const uint32_t wb = tile_base(w1); nx_co = ld32(core1 + 4 * (size_t)wb, 4u * lane_off(wb) + 3u); }
     k1e_load_cigar8(cigar_pool, (uint32_t)cur_cv.w, cg);
     // (the wait of the first tile's words sits here, not in the loop: the compiler places a wait where ANY path into an
@@ -855,7 +907,7 @@ classify_ei_kernel(K1Args A) {
         const bool mixed = seg_next != NONE && seg_next - w0 < 64u;           // a contig boundary inside the tile
         // ---- the next tile's words start their trip now -----------------------------------------------------------------
         int4 n_cv, n_av; uint32_t n_cg[8]; uint32_t n_co;
-        { const uint32_t wb = tile_base(w1), lo = lane_off(wb); n_cv = ld32(core4 + wb, lo); n_av = ld32(aux4 + wb, lo); }
+        { const uint32_t wb = tile_base(w1), lo = lane_off(wb); n_cv = k1e_ld32_stream(core4 + wb, lo); n_av = ld32(aux4 + wb, lo); }
         k1e_load_cigar8(cigar_pool, nx_co, n_cg);
         { const uint32_t wb = tile_base(w2); n_co = ld32(core1 + 4 * (size_t)wb, 4u * lane_off(wb) + 3u); }
         WaveSink cnt;
@@ -870,7 +922,7 @@ classify_ei_kernel(K1Args A) {
         asm volatile("" : "+s"(pt.unpaired), "+s"(pt.exclude_chimeric), "+s"(pt.n_filter_tags));
 #endif
         do {                                                  // (K1E_STOP leaves through `break`)
-        Record r; uint32_t cur_cigar_off;
+        Record r; uint32_t cur_cigar_off; (void)cur_cigar_off;
         {
             const int4 cv = cur_cv, av = cur_av;                                  // (zero for lanes past the range)
             r.pos = cv.x; r.mpos = cv.y; r.isize = cv.z; cur_cigar_off = (uint32_t)cv.w;
@@ -947,6 +999,8 @@ classify_ei_kernel(K1Args A) {
                 }
             }
         }
+        // (Call r6f: the candidates of such tiles through a fourth per-wave ring and a 64-lane stage of their own -- record words and CIGAR
+        //  re-gathered there -- measured SLOWER than these few divergent lanes: K1 3.31 instead of 3.17-3.22 ms, step 6.76 instead of 6.61.)
         if (bed_near && rc.frag_candidate) {                  // src/RNASeQC.cpp:372
             const K1Args *q = k1e_lazy_args();
             const int32_t name = bed_interval_of(q->a, r);
@@ -955,8 +1009,7 @@ classify_ei_kernel(K1Args A) {
                 const uint32_t slot = wg_beg + atomicAdd(&S.T.frags, 1u);       // the workgroup's own region (<= one candidate per record)
                 {
                     // (name hash, mate position and insert size come back from the record arrays -- cache lines this wave streamed a
-                    //  moment ago -- instead of living in registers from the top of phase A to this rare branch: round 5's instance
-                    //  spilled them, 16 bytes per lane written and read in every tile)
+                    //  moment ago -- instead of living in registers from the top of phase A to this rare branch)
                     const int4 co = reinterpret_cast<const int4 *>(q->b.core)[i];
                     const uint2 qh = reinterpret_cast<const uint2 *>(q->b.aux)[2u * i];
                     fr.file_index[slot] = batch_file_index(q->b, my_seg, i); fr.qhash[slot] = (uint64_t)qh.x | ((uint64_t)qh.y << 32);
@@ -996,8 +1049,8 @@ classify_ei_kernel(K1Args A) {
         const WB walked = WS::prim(r.n_cigar <= 8u);
         const WB nb0 = WS::prim(w2.nb == 0u), nb1 = WS::prim(w2.nb == 1u), nb2 = WS::prim(w2.nb == 2u), nb3 = WS::prim(w2.nb == 3u);
         // one-block records whose length fits the queue's 16 bits (a longer block -- never seen in RNA-seq -- is classify_long_kernel's)
-        const WB fits = WS::prim(w2.l0 < 65536u);
-        const WB shape = walked && (nb0 || (nb1 && fits) || nb2 || nb3);
+        const WB fits = WS::prim(w2.l0 < 65536u), fits3 = WS::prim((w2.l0 | w2.l1 | w2.l2) < 65536u);
+        const WB shape = walked && (nb0 || (nb1 && fits) || nb2 || (nb3 && fits3));
         WB mine = go;                                        // stragglers of a boundary tile: general code
         if (mixed) {
             mine = go && WS::prim(r.tid == u_tid);
@@ -1040,10 +1093,10 @@ classify_ei_kernel(K1Args A) {
             q.bs0[slot] = w2.b1; q.len0[slot] = w2.l1; q.bs1[slot] = w2.b0; q.len1[slot] = w2.l0; q.idx[slot] = (uint32_t)i; q.flhq[slot] = flhq;
         }
         if (WS::lane(LaneMask{m3})) {
-            const uint32_t slot = (h3 + c3 + mask_rank(m3)) & (K1E_Q3CAP - 1);
+            const uint32_t slot = k1e_wrap3(h3 + c3 + mask_rank(m3));
             K1eQueue3 &q = S.q3[wave];
-            q.bs0[slot] = w2.b2; q.len0[slot] = w2.l2; q.bs1[slot] = w2.b1; q.len1[slot] = w2.l1; q.bs2[slot] = w2.b0; q.len2[slot] = w2.l0;
-            q.idx[slot] = (uint32_t)i; q.flhq[slot] = flhq;
+            q.bs0[slot] = w2.b2; q.bs1[slot] = w2.b1; q.bs2[slot] = w2.b0; q.lens01[slot] = w2.l2 | (w2.l1 << 16);
+            q.lf2[slot] = w2.l0 | ((flhq & 0xFFFu) << 16) | ((flhq >> 16) << 28); q.idx[slot] = (uint32_t)i;
         }
         c1 += (uint32_t)__popcll(m1); c2 += (uint32_t)__popcll(m2); c3 += (uint32_t)__popcll(m3);
         __builtin_amdgcn_wave_barrier();                     // the queue entries are read by OTHER lanes of the wave (no instruction: an ordering point)
@@ -1128,7 +1181,7 @@ classify_ei_kernel(K1Args A) {
                 sum_e1mm = p1.bs[s1]; sum_e1b = p1.lf[s1]; sum_e2mm = p1.idx[s1];
                 sum_e2b = p2.bs0[s2]; sum_mm = p2.len0[s2]; sum_b = p2.bs1[s2]; l_span = p2.len1[s2]; l_lmin = p2.idx[s2]; l_lmax = p2.flhq[s2];
             }
-            h3 = (h3 + take) & (K1E_Q3CAP - 1); c3 -= take;
+            h3 = k1e_wrap3(h3 + take); c3 -= take;
             RSQC_MARK(11);                         // [11] three-block tiles
         }
     }
@@ -1152,28 +1205,30 @@ classify_ei_kernel(K1Args A) {
         q->acc.pair_chunk_count[blockIdx.x] = S.T.pairs < q->acc.pair_chunk_cap ? S.T.pairs : q->acc.pair_chunk_cap;
         if (BED) q->acc.frag.chunk_count[blockIdx.x] = S.T.frags;
     }
-    // the workgroup's deferred records move from its region to the dense list classify_long_kernel reads, as whole CALLS of 64 entries
-    // (padded with K1E_DEFER_NONE: the entries of a call share their K1 workgroup, i.e. their pair chunk); one memory atomic per workgroup
+    // the workgroup's deferred records move from its region to the dense list classify_long_kernel reads: one memory atomic per workgroup
     const uint32_t n_def = S.T.defer;                          // (final since the barrier in front of the flush)
     if (n_def != 0u) {
         const K1Args *q = k1e_lazy_args();
-        const uint32_t padded = (n_def + 63u) & ~63u;
-        if (threadIdx.x == 0) S.T.piece = atomicAdd(q->acc.defer_total, padded);
+        if (threadIdx.x == 0) S.T.piece = atomicAdd(q->acc.defer_total, n_def);
         __syncthreads();
         const uint32_t at = S.T.piece;
-        for (uint32_t j = threadIdx.x; j < padded; j += blockDim.x) q->acc.defer_list[at + j] = j < n_def ? q->acc.defer_index[wg_beg + j] : K1E_DEFER_NONE;
+        for (uint32_t j = threadIdx.x; j < n_def; j += blockDim.x) q->acc.defer_list[at + j] = q->acc.defer_index[wg_beg + j];
     }
 }
 
 // ---- the records classify_ei_kernel deferred (more than eight operations, more than three blocks, the three-block ring's surplus:
-// about 1 % of an RNA-seq file) -------------------------------------------------------------------------------------------------------
-// One WAVE per call of 64 entries of the dense list (classify_ei_kernel's epilogue: whole calls per K1 workgroup, so the entries of a
-// call share their pair chunk); calls are taken grid-stride.  Pairs go on into that K1 workgroup's chunk behind what it wrote itself (the
-// chunk is sized for FAST_SET pairs of EVERY record of its range, deferred ones included; the slot reservation is a memory atomic on the
-// chunk's count), exon / gene / counter updates to this workgroup's LDS tables.  The entries of a call lie in the K1 workgroup's record
-// range; when that range crosses contigs the call runs once per contig with the other lanes switched off.
-// (First form, call r6a: one workgroup per K1 workgroup's region -- 0.67 ms, the regions of multi-exon genes held thousands of records.)
-__global__ void __launch_bounds__(RSQC_K1_THREADS)
+// about 0.7 % of an RNA-seq file) -----------------------------------------------------------------------------------------------------
+// One WAVE per call of 64 entries of the dense list, calls taken grid-stride.  Every workgroup of THIS kernel owns a pair chunk of its
+// own behind the K1 grid's (chunk k1_grid + blockIdx.x, slots from an LDS counter: no memory atomic); only when that chunk is nearly full
+// -- an input whose records are all deferred -- do a call's pairs go into the chunks of the K1 workgroups that listed the records, which
+// are sized for FAST_SET pairs of EVERY record of their ranges, deferred ones included (per-lane chunk, one returning memory atomic per
+// pair).  Exon / gene / counter updates go to this workgroup's LDS tables.  A call whose records span contigs runs once per contig with
+// the other lanes switched off.
+// (Call r6a: one workgroup per K1 workgroup's region -- 0.67 ms, the regions of multi-exon genes hold thousands of records.  Call r6b: one
+//  wave per call, 0.42 ms -- the 36 k entries it adds to the general kernel's list, one returning atomic each on ONE counter.  Call r6c:
+//  those staged in LDS, calls padded per K1 workgroup: 0.245 ms, 18 k calls of 45 us at 2 calls per wave.  Call r6d: dense list, the
+//  three-block ring's surplus gone (10 k calls), but every pair a returning memory atomic on its K1 chunk's count: 0.61 ms.)
+__global__ void __launch_bounds__(RSQC_K1_THREADS)              // (103 VGPRs: four waves per SIMD; held to 96 it spills 24 bytes)
 classify_long_kernel(K1Args A, uint32_t k1_grid) {
     __shared__ K1eTables T;
     __shared__ unsigned long long s_stage[K1E_OVF_STAGE];       // records for the general kernel, moved to its list at the end (k1e_overflow)
@@ -1186,26 +1241,27 @@ classify_long_kernel(K1Args A, uint32_t k1_grid) {
     __syncthreads();
     uint32_t sum_blk = 0;
     const uint32_t n_rec = (uint32_t)b.n;
-    const uint32_t total = *acc.defer_total;                    // (a multiple of 64)
+    const uint32_t total = *acc.defer_total;
     const uint32_t n_waves = gridDim.x * (uint32_t)K1E_WAVES;
+    const uint32_t total_waves = k1_grid * (uint32_t)K1E_WAVES;
+    const uint32_t per_wg = (uint32_t)K1E_WAVES * ((((n_rec + total_waves - 1u) / total_waves) + 63u) & ~63u);      // records per K1 workgroup (as in k1e_wg_range)
     for (uint32_t call = blockIdx.x * (uint32_t)K1E_WAVES + (threadIdx.x >> 6); call * 64u < total; call += n_waves) {
-        const uint32_t e = acc.defer_list[call * 64u + (uint32_t)l];
-        const bool on = e != K1E_DEFER_NONE;
-        const uint32_t idx = on ? (e & 0x7FFFFFFFu) : 0u; const bool hq = on && (e >> 31) != 0u;
-        // the K1 workgroup of the call (its first entry is a record), its record range and the contigs it spans
-        const uint32_t idx0 = lane_value(idx, 0);
-        const uint32_t total_waves = k1_grid * (uint32_t)K1E_WAVES;
-        const uint32_t per_wave = (((n_rec + total_waves - 1u) / total_waves) + 63u) & ~63u;      // (as in k1e_wg_range)
-        const uint32_t region = idx0 / ((uint32_t)K1E_WAVES * per_wave);
-        uint32_t beg, end;
-        k1e_wg_range(n_rec, k1_grid, region, beg, end);
-        const uint32_t seg_lo = find_segment(b, beg), seg_hi = find_segment(b, end - 1u);
+        const uint32_t at = call * 64u + (uint32_t)l;
+        const bool on = at < total;
+        const uint32_t e = acc.defer_list[on ? at : call * 64u];
+        const uint32_t idx = e & 0x7FFFFFFFu; const bool hq = on && (e >> 31) != 0u;
+        const uint32_t chunk = idx / per_wg;                    // the K1 workgroup that listed the record
+        // the contigs the call spans (its entries are not sorted: several waves of a K1 workgroup list into one region)
+        const uint32_t seg_lo = find_segment(b, wave_min_u32(idx)), seg_hi = find_segment(b, wave_max_u32(idx));
         for (uint32_t sg = seg_lo; sg <= seg_hi; ++sg) {
             const bool mine = on && (seg_lo == seg_hi || (idx >= (uint32_t)b.seg_start[sg] && (sg + 1 >= b.n_seg || idx < (uint32_t)b.seg_start[sg + 1])));
             if (__ballot(mine) == 0ull) continue;
             const int32_t tid = b.n_seg ? b.seg_tid[sg] : -1;
             const ContigInfo ci = (tid >= 0 && tid < a.n_contigs) ? a.contig[tid] : ContigInfo{0, 0, 0, 0, 0, 0, 0, 0};
-            k1e_long_call(a, A.p, b, acc.cov_diff, ci, T, idx, hq, mine, sum_blk, held, region, s_stage, &s_stage_n);
+            // (room for this call's pairs in the workgroup's own chunk even if the three other waves are emitting theirs: 4 x 64 x FAST_SET)
+            const bool own = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.pairs) + 4u * 64u * (uint32_t)FAST_SET <= acc.pair_chunk_cap;
+            if (own) k1e_long_call<false>(a, A.p, b, acc.cov_diff, ci, T, idx, hq, mine, sum_blk, held, k1_grid + blockIdx.x, s_stage, &s_stage_n);
+            else k1e_long_call<true>(a, A.p, b, acc.cov_diff, ci, T, idx, hq, mine, sum_blk, held, chunk, s_stage, &s_stage_n);
         }
     }
     {
@@ -1214,6 +1270,7 @@ classify_long_kernel(K1Args A, uint32_t k1_grid) {
     }
     __syncthreads();
     T.flush(0ull);
+    if (threadIdx.x == 0) acc.pair_chunk_count[k1_grid + blockIdx.x] = T.pairs < acc.pair_chunk_cap ? T.pairs : acc.pair_chunk_cap;
     const uint32_t n_st = s_stage_n;                            // (final since the barrier)
     if (n_st != 0u) {
         if (threadIdx.x == 0) T.piece = atomicAdd(acc.ovf_count, n_st);

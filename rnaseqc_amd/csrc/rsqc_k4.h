@@ -154,6 +154,7 @@ frag_local_kernel(const PairRec *pairs, uint32_t chunk_cap,
         base = slow_base;
         count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
     }
+    if (count == 0u) return;                                               // (an empty chunk: a sparse stretch, an idle workgroup of classify_long_kernel)
     constexpr int U = RSQC_K4L_PIECE / RSQC_K4L_THREADS;
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;

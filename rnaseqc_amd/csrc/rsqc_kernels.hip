@@ -479,7 +479,7 @@ void launch_classify(hipStream_t s, int grid, int variant, const DevAnnotation &
 // the records classify_ei_kernel deferred (more than eight operations / three blocks): one wave per call of 64, grid-stride
 void launch_classify_long(hipStream_t s, int k1_grid, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevAccum &acc) {
     const K1Args A{a, p, b, acc};
-    hipLaunchKernelGGL(classify_long_kernel, dim3((unsigned)std::min(k1_grid, 1024)), dim3(RSQC_K1_THREADS), 0, s, A, (uint32_t)k1_grid);
+    hipLaunchKernelGGL(classify_long_kernel, dim3((unsigned)rsqc_long_grid(k1_grid)), dim3(RSQC_K1_THREADS), 0, s, A, (uint32_t)k1_grid);
 }
 void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b,
                           const DevAccum &acc) {

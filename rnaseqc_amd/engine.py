@@ -115,6 +115,13 @@ class Engine:
         o = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
         self._keep += [ann, s, o]
         self._check(self._l.rsqc_set_annotation(self._h, C.byref(s), abi.ptr(o)))
+        # RSQC_OK may come with a warning (an exon row outside the row of its gene: DESIGN.md 5): returned, kept and logged here,
+        # because rsqc_last_error is overwritten by any later failure; the results carry the count (exons_outside_gene_row)
+        self.annotation_warning = self.last_error() or None
+        if self.annotation_warning:
+            import warnings
+            warnings.warn("rsqc_set_annotation: " + self.annotation_warning, RuntimeWarning, stacklevel=2)
+        return self.annotation_warning
 
     def set_bed(self, bed):
         s = bed.to_struct()

@@ -423,8 +423,17 @@ class Batch:
         batch: every segment keeps the file index of its first record (rsqc_batch.seg_file_index), so that one kernel launch
         serves all of them and the order-dependent outputs are still kept per range.  A part's own file_index_base (+ the offset
         of the segment inside the part) is the segment's index."""
-        parts = [p for p in parts if p.n]
-        one = Batch.concat(parts) if len(parts) > 1 else parts[0]
+        every = list(parts)
+        parts = [p for p in every if p.n]
+        if not parts:                                   # a rank that owns no records: an empty batch of ranges
+            import copy
+            if not every:
+                raise ValueError("concat_ranges: no parts")
+            one = copy.copy(every[0])
+            one.seg_file_index = np.zeros(0, np.uint64)
+            return one
+        # (a single part goes through concat as well: it drops the part's empty segments, which the index list below skips too)
+        one = Batch.concat(parts)
         idx = []
         for p in parts:
             for s in range(len(p.seg_tid)):

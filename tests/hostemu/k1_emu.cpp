@@ -89,8 +89,10 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     const uint64_t per_wave = (((n + total_waves - 1) / total_waves) + 63ull) & ~63ull;
     const uint32_t chunk_cap = (uint32_t)(per_wave * K1E_WAVES * FAST_SET);
     const uint32_t slow_cap = 1u << 16;
-    std::vector<PairRec> pairs((size_t)chunk_cap * grid + slow_cap + 8, PairRec{0xFFFFFFF0u, 0xFEEDu, 0ull});
-    std::vector<uint32_t> chunk_count((size_t)grid + 2, 0xDEADu);
+    const int lgrid = grid > 2 ? grid - 1 : grid;                          // workgroups of classify_long_kernel: each owns a chunk behind the K1 grid's
+    const int n_chunks = grid + lgrid;
+    std::vector<PairRec> pairs((size_t)chunk_cap * n_chunks + slow_cap + 8, PairRec{0xFFFFFFF0u, 0xFEEDu, 0ull});
+    std::vector<uint32_t> chunk_count((size_t)n_chunks + 2, 0xDEADu);
     std::vector<uint32_t> ovf_count(4, 0u); std::vector<uint64_t> ovf_index(1u << 20);
     std::vector<uint32_t> defer_index((size_t)n + 64, 0xDEFE0000u), defer_list((size_t)n + 64 * (size_t)grid + 64, 0xDEFE0001u); uint32_t defer_total = 0;
     std::vector<uint32_t> tile_span((size_t)((n + 63) / 64) + 64 * (size_t)total_waves + 64, 0xABCDu);
@@ -101,7 +103,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     acc.exon_acc = exon_acc.data(); acc.cov_diff = cov.data();
     acc.pairs = pairs.data();
     acc.pair_chunk_cap = chunk_cap; acc.pair_chunk_count = chunk_count.data();
-    acc.pair_slow_base = chunk_cap * (uint32_t)grid; acc.pair_slow_cap = slow_cap; acc.pair_slow_count = chunk_count.data() + grid;
+    acc.pair_slow_base = chunk_cap * (uint32_t)n_chunks; acc.pair_slow_cap = slow_cap; acc.pair_slow_count = chunk_count.data() + n_chunks;
     acc.ovf_count = ovf_count.data(); acc.ovf_index = (uint64_t *)ovf_index.data(); acc.ovf_cap = (uint32_t)ovf_index.size();
     acc.defer_index = defer_index.data(); acc.defer_list = defer_list.data(); acc.defer_total = &defer_total;
     acc.tile_span = tile_span.data();
@@ -115,10 +117,8 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel<false>(A); });      // (the instance of runs without a BED)
     }
     uint64_t n_deferred = 0;
-    if (defer_total % 64u) return 1012;                                   // whole calls
-    for (uint32_t k = 0; k < defer_total; ++k) if (defer_list[k] != K1E_DEFER_NONE) { ++n_deferred; if ((defer_list[k] & 0x7FFFFFFFu) >= n) return 1013; }
+    for (uint32_t k = 0; k < defer_total; ++k) { ++n_deferred; if ((defer_list[k] & 0x7FFFFFFFu) >= n) return 1013; }
     {   // the records it deferred (more than eight operations / three blocks, the three-block ring's surplus) -> classify_long_kernel
-        const int lgrid = grid > 2 ? grid - 1 : grid;
         wavemu::grid_dim().x = (uint32_t)lgrid;
         for (int k = 0; k < lgrid; ++k) {
             wavemu::block_idx().x = (uint32_t)k;
@@ -166,7 +166,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
             wavemu::run_block(RSQC_SLOW_THREADS, [&]() { classify_slow_kernel<false>(d, dp, db, acc); });
         }
         if (error) return error;
-        const uint32_t ns = chunk_count[(size_t)grid];
+        const uint32_t ns = chunk_count[(size_t)n_chunks];
         if (ns > slow_cap) return 1008;
         for (uint32_t j = 0; j < ns; ++j) {
             const PairRec &pr = pairs[(size_t)acc.pair_slow_base + j];
@@ -199,7 +199,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     }
     // ---- pairs -> distinct names per gene ------------------------------------------------------------------------------
     uint64_t n_pairs = 0;
-    for (int k = 0; k < grid; ++k) {
+    for (int k = 0; k < n_chunks; ++k) {
         const uint32_t cnt = chunk_count[(size_t)k];
         if (cnt > chunk_cap) return 1004;
         for (uint32_t j = 0; j < cnt; ++j) {
@@ -236,8 +236,8 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     }
     // ---- the fragment-counting KERNELS (rsqc_k4.h) on the pair buffers as the kernels above left them: must equal the name sets
     if (slow_kernel && G > 0) {
-        const uint64_t parts_bound = n_pairs / RSQC_K4_PART_READS + chunk_count[(size_t)grid] / RSQC_K4_PART_READS + G + 2;
-        const uint64_t all_pairs = n_pairs + chunk_count[(size_t)grid];
+        const uint64_t parts_bound = n_pairs / RSQC_K4_PART_READS + chunk_count[(size_t)n_chunks] / RSQC_K4_PART_READS + G + 2;
+        const uint64_t all_pairs = n_pairs + chunk_count[(size_t)n_chunks];
         const uint64_t keys_bound = 2 * all_pairs + (uint64_t)RSQC_K4_SUB_CAP * std::min<uint64_t>(parts_bound, all_pairs / RSQC_K4_PART_READS + 1) + 16 * G + 16;
         const uint32_t lay_blocks = (uint32_t)((G + 1023) / 1024);
         std::vector<uint4> ginfo(G + 1), part_info(parts_bound);
@@ -249,11 +249,11 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), part_first.data(), ginfo.data(), cursor.data(), part_info.data(), &full_n); }); }
         if (error) return error;
         if (part_first[G] > parts_bound) return 1010;
-        const uint32_t lgrid = (uint32_t)grid + 4u;
-        wavemu::grid_dim().x = lgrid;
-        for (uint32_t k = 0; k < lgrid; ++k) {
+        const uint32_t fgrid = (uint32_t)n_chunks + 4u;
+        wavemu::grid_dim().x = fgrid;
+        for (uint32_t k = 0; k < fgrid; ++k) {
             wavemu::block_idx().x = k;
-            wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pairs.data(), chunk_cap, chunk_count.data(), (uint32_t)grid, acc.pair_slow_base, slow_cap,
+            wavemu::run_block(RSQC_K4L_THREADS, [&]() { frag_local_kernel(pairs.data(), chunk_cap, chunk_count.data(), (uint32_t)n_chunks, acc.pair_slow_base, slow_cap,
                                                                           ginfo.data(), cursor.data(), list.data(), &error); });
         }
         wavemu::grid_dim().x = 8;

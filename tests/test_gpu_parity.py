@@ -558,10 +558,16 @@ def test_exon_outside_its_gene_row_on_the_device(oracle_lib):
     p = abi.default_params(coverage_mask=0)
     e = engine.Engine(p)
     try:
-        e.set_annotation(ann)
-        assert "outside the row of its gene" in e.last_error()
+        import warnings
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            w = e.set_annotation(ann)
+        assert w and "outside the row of its gene" in w and "outside the row of its gene" in e.last_error()
+        assert any("outside the row of its gene" in str(x.message) for x in seen)          # Engine.set_annotation logs it itself
         e.submit(b)
-        assert_results_match(e.finalize(), oracle_lib.run_oracle(p, ann, [b]))
+        got = e.finalize()
+        assert got.exons_outside_gene_row >= 1                                               # ... and the results carry the flag
+        assert_results_match(got, oracle_lib.run_oracle(p, ann, [b]))
     finally:
         e.close()
 

@@ -130,6 +130,33 @@ def test_wide_records_and_long_cigars(oracle_lib):
         assert o.n_overflow >= 60
 
 
+def test_every_record_deferred_fills_the_long_kernels_chunks(oracle_lib):
+    """Every record has four blocks inside the exons of two overlapping genes: classify_ei_kernel defers them all, classify_long_kernel's
+    own pair chunks (sized like a K1 workgroup's, but there are fewer of them than K1 workgroups here) fill up, and the rest of the pairs
+    take the per-lane path into the K1 workgroups' chunks.  Also: the three-block ring's surplus (tiles of 64 three-block records)."""
+    rows = [dict(contig="c", type="gene", start=100, end=200000, strand="+", gene_id="G0"),
+            dict(contig="c", type="exon", start=100, end=200000, strand="+", gene_id="G0", exon_id="E0"),
+            dict(contig="c", type="gene", start=150, end=190000, strand="-", gene_id="G1"),
+            dict(contig="c", type="exon", start=150, end=190000, strand="-", gene_id="G1", exon_id="E1")]
+    ann = Annotation.from_rows(["c"], rows)
+    M, N = abi.CIG_M, abi.CIG_N
+    for four, n in ((True, 4000), (False, 1500)):
+        recs = []
+        for i in range(n):
+            # (second input: a wave's ring holds 63 three-block records when a tile of 64 more arrives -- 21 fit, the rest is surplus)
+            three = [(M, 30), (N, 5), (M, 30), (N, 7), (M, 30)] if (i >= 192 or (i < 189 and i % 3 == 0)) else [(M, 90)]
+            cig = [(M, 20), (N, 5), (M, 20), (N, 5), (M, 20), (N, 7), (M, 20)] if four else three
+            recs.append(dict(qname="q%d" % (i // 2), tid=0, pos=300 + 20 * i, cigar=cig, flag=99 if i % 2 == 0 else 147, mapq=255, nm=0,
+                             mpos=300 + 20 * (i ^ 1), mtid=0))
+        b = Batch.from_records(recs)
+        p = abi.default_params()
+        r = oracle_lib.run_oracle(p, ann, [b])
+        assert int(r.gene_reads.sum()) == 2 * n                       # every record is counted to both genes: two pairs each
+        o = hostemu.run_k1(p, ann, b, grid=3 if four else 1)
+        _compare(o, r)
+        assert (o.n_deferred == n) if four else (0 < o.n_deferred < n)
+
+
 def test_many_small_contigs_in_one_tile(oracle_lib):
     """Several contigs inside one 64-record tile: the records beyond the tile's first contig take the general code and find their
     contig themselves; for one with a long CIGAR the general code also counts "Alignment Blocks" and checks the operations
