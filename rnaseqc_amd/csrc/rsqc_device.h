@@ -148,7 +148,8 @@ struct GeneCovArgs {
     unsigned long long *bias3, *bias5;
     int *error;
 };
-void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge);
+void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge,
+                          uint32_t n_le6144 = 0, uint32_t n_le3072 = 0, uint32_t n_le2048 = 0, uint32_t n_le1024 = 0);
 
 void launch_reduce_add(hipStream_t s, unsigned long long *du, const unsigned long long *su, size_t nu, double *df, const double *sf, size_t nf,
                        uint8_t *db, const uint8_t *sb, size_t nb);

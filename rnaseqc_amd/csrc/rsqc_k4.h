@@ -130,6 +130,11 @@ constexpr int k4l_log2(unsigned v) { return v <= 1 ? 0 : 1 + k4l_log2(v >> 1); }
 #ifndef RSQC_K4L_WIN
 #define RSQC_K4L_WIN 2048
 #endif
+#ifndef RSQC_K4L_CHUNKS
+#define RSQC_K4L_CHUNKS 2                        /* pair chunks a workgroup of frag_local_kernel takes as one run (A/B: 1) */
+#endif
+// workgroups of frag_local_kernel that take chunks (the launch adds the sharers of the dense region behind them)
+inline uint32_t frag_local_chunk_wgs(uint32_t n_chunks) { return (n_chunks + RSQC_K4L_CHUNKS - 1u) / RSQC_K4L_CHUNKS; }
 struct K4LocalShared {
     uint32_t gkey[RSQC_K4L_GSLOTS], gcnt[RSQC_K4L_GSLOTS];      // keyed by partition id: pairs of the pass, then their first list slot
     unsigned long long win[RSQC_K4L_WIN];       // direct-mapped window of the chunk's recent (gene, key) words: see the kernel
@@ -146,39 +151,61 @@ frag_local_kernel(const PairRec *pairs, uint32_t chunk_cap,
                   const uint32_t *chunk_count, uint32_t n_chunks, uint32_t slow_base, uint32_t slow_cap,
                   const uint4 *ginfo, uint32_t *cursor, FragKey *list, int *error) {
     __shared__ K4LocalShared S;
-    uint32_t base, count, piece0 = 0; constexpr uint32_t piece_step = 1;
-    if (blockIdx.x < n_chunks) {
-        base = blockIdx.x * chunk_cap;
-        count = chunk_count[blockIdx.x] < chunk_cap ? chunk_count[blockIdx.x] : chunk_cap;
+    // A workgroup takes RSQC_K4L_CHUNKS neighbouring chunks as ONE run of pairs (round 6: K1 runs 5120 workgroups + 1024 of the long
+    // kernel -- one workgroup of this kernel per chunk cost 0.03 ms per thousand chunks in launches, window clears and tails; neighbouring
+    // chunks are neighbouring genomic ranges, so the window de-dup carries over).
+    constexpr int CH = RSQC_K4L_CHUNKS;
+    const uint32_t n_cwg = (n_chunks + (uint32_t)CH - 1u) / (uint32_t)CH;      // workgroups that take chunks; the rest share the dense region
+    uint32_t cbase[CH], cend[CH];                                              // first pair of chunk k, end of chunk k in the run
+    uint32_t count, piece0 = 0; constexpr uint32_t piece_step = 1;
+    if (blockIdx.x < n_cwg) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const uint32_t c = blockIdx.x * (uint32_t)CH + (uint32_t)k;
+            const uint32_t n = c < n_chunks ? (chunk_count[c] < chunk_cap ? chunk_count[c] : chunk_cap) : 0u;
+            cbase[k] = c * chunk_cap; run += n; cend[k] = run;
+        }
+        count = run;
     } else {
-        base = slow_base;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { cbase[k] = slow_base; cend[k] = 0u; }
         count = chunk_count[n_chunks] < slow_cap ? chunk_count[n_chunks] : slow_cap;
+        cend[CH - 1] = count;
+#pragma unroll
+        for (int k = 0; k < CH - 1; ++k) cend[k] = 0u;
     }
-    if (count == 0u) return;                                               // (an empty chunk: a sparse stretch, an idle workgroup of classify_long_kernel)
+    if (count == 0u) return;                                               // (empty chunks: a sparse stretch, idle workgroups of classify_long_kernel)
     constexpr int U = RSQC_K4L_PIECE / RSQC_K4L_THREADS;
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t n_pieces = (count + RSQC_K4L_PIECE - 1) / RSQC_K4L_PIECE;
-    if (blockIdx.x >= n_chunks) {
+    if (blockIdx.x >= n_cwg) {
         // a dense region shared by several workgroups (a batch's slow-path region, the arena of retired batches): each takes a
         // CONTIGUOUS run of passes, so that its window sees neighbouring records
-        const uint32_t sharers = gridDim.x - n_chunks, me = blockIdx.x - n_chunks;
+        const uint32_t sharers = gridDim.x - n_cwg, me = blockIdx.x - n_cwg;
         const uint32_t per = (n_pieces + sharers - 1) / sharers;
         piece0 = me * per < n_pieces ? me * per : n_pieces;
         n_pieces = piece0 + per < n_pieces ? piece0 + per : n_pieces;
     }
+    auto pair_at = [&](uint32_t j) -> uint32_t {                           // pair j of the run -> its index in the pair buffer
+        uint32_t at = cbase[CH - 1] + (j - (CH > 1 ? cend[CH - 2] : 0u));
+#pragma unroll
+        for (int k = CH - 2; k >= 0; --k) if (j < cend[k]) at = cbase[k] + (j - (k > 0 ? cend[k - 1] : 0u));
+        return at;
+    };
     auto load_piece = [&](uint32_t piece, uint32_t (&g)[U], uint64_t (&key)[U], uint32_t (&h2)[U]) {      // one 16-byte load per pair
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t j = piece * RSQC_K4L_PIECE + (uint32_t)u * RSQC_K4L_THREADS + threadIdx.x;
             const bool ok = piece < n_pieces && j < count;
             PairRec r{NONE, 0u, 0ull};
-            if (ok) r = pairs[base + j];
+            if (ok) r = pairs[pair_at(j)];
             g[u] = r.gene; key[u] = r.hash; h2[u] = r.h2;
         }
     };
 #ifdef RSQC_K1_PROF
     if (blockIdx.x == 1000 && n_chunks > 1000) {                           // (diagnostic: one chunk, as K1 wrote it)
-        for (uint32_t i = threadIdx.x; i < count && i < 32768u; i += blockDim.x) { g_dbg_pair_hash[i] = pairs[base + i].hash; g_dbg_pair_gene[i] = pairs[base + i].gene; }
+        for (uint32_t i = threadIdx.x; i < count && i < 32768u; i += blockDim.x) { g_dbg_pair_hash[i] = pairs[pair_at(i)].hash; g_dbg_pair_gene[i] = pairs[pair_at(i)].gene; }
         if (threadIdx.x == 0) g_dbg_pair_count = count;
     }
 #endif

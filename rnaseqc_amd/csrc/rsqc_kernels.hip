@@ -506,7 +506,7 @@ void launch_frag_layout(hipStream_t s, const unsigned long long *gene_reads, uin
 }
 // list_blocks: workgroups that share the dense region behind the chunks (0 = the default for a batch's slow-path region)
 void launch_frag_local(hipStream_t s, const DevAccum &acc, uint32_t n_chunks, const FragPlan &P, uint32_t list_blocks) {
-    hipLaunchKernelGGL(frag_local_kernel, dim3(n_chunks + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pairs, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
+    hipLaunchKernelGGL(frag_local_kernel, dim3(frag_local_chunk_wgs(n_chunks) + (list_blocks ? list_blocks : RSQC_K4_SLOW_BLOCKS)), dim3(RSQC_K4L_THREADS), 0, s, acc.pairs, acc.pair_chunk_cap, acc.pair_chunk_count, n_chunks, acc.pair_slow_base, acc.pair_slow_cap,
                        P.ginfo, P.cursor, P.list, acc.error);
 }
 void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint32_t parts_bound, unsigned long long *gene_frag, int *error) {
@@ -523,7 +523,8 @@ void launch_frag_count(hipStream_t s, uint32_t n_genes, const FragPlan &P, uint3
 #ifndef RSQC_K3_SMALL_T
 #define RSQC_K3_SMALL_T uint32_t
 #endif
-void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge) {
+void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const GeneCovArgs &A, uint32_t n_large, uint32_t n_medium, uint32_t n_xlarge,
+                          uint32_t n_le6144, uint32_t n_le3072, uint32_t n_le2048, uint32_t n_le1024) {
     if (A.n_listed <= 0) return;
     // gene_order is sorted by coding length, longest first: [0, n_large) x 1024 threads,
     // [n_large, n_large + n_medium) x 256 threads, the rest one wave each; the launches are independent
@@ -537,11 +538,30 @@ void launch_gene_coverage(hipStream_t s, hipStream_t s2, hipStream_t s3, const G
     }
     // the 1024-thread class in two LDS sizes: a workgroup that holds 146 KB keeps its CU to itself, one that holds 64 KB leaves
     // room for the fragment workgroups running beside it.  (The runtime maps streams onto four hardware queues: with K4 on the
-    // context's stream there are three for K3; the 64 KB class goes in front of the one-wave class.)
+    // context's stream there are three for K3; the 64 KB class goes in front of the one-wave classes.)
+    // The other classes in several LDS sizes too (round 6): a workgroup's LDS is its gene's coverage vector, and sized for the LONGEST gene of
+    // a class it limits the workgroups a CU holds -- 8 one-wave workgroups (16 KB each: a quarter of the CU's wave slots) for the 53 k genes
+    // of up to 4 096 bases, of which 38 k have at most 1 024 -- and takes the LDS the fragment kernels beside them need.  gene_order is sorted
+    // by coding length, longest first, so a class is a range of it; the counts of genes of up to 6 144 / 3 072 / 2 048 / 1 024 bases come
+    // from the host (end-of-file kernels 1.57 -> 1.46 ms with the one-wave class in three sizes, call r6j).
+#ifndef RSQC_K3_SMALL_SPLIT
+#define RSQC_K3_SMALL_SPLIT 1
+#endif
+    static_assert(RSQC_K3_SMALL_MAX == 4096 && RSQC_K3_MEDIUM_MAX == 12288, "the split points below sit inside these classes");
+    if (!RSQC_K3_SMALL_SPLIT || n_le3072 > n_small || n_le6144 < n_small || n_le6144 > n_small + n_medium) { n_le6144 = n_small; n_le3072 = 0; n_le2048 = 0; n_le1024 = 0; }
+    if (n_le2048 > n_le3072) n_le2048 = n_le3072;
+    if (n_le1024 > n_le2048) n_le1024 = n_le2048;
+    const uint32_t n_med_short = n_le6144 - n_small;                       // genes of 4 097 .. 6 144 bases: the end of the medium class
     RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE_LDS16, n_xlarge, 0u, s)
-    RSQC_K3_LAUNCH(256, RSQC_K3_MEDIUM_T, RSQC_K3_MEDIUM_MAX, n_medium, n_large, s2)
+    RSQC_K3_LAUNCH(256, RSQC_K3_MEDIUM_T, RSQC_K3_MEDIUM_MAX, n_medium - n_med_short, n_large, s2)
+    RSQC_K3_LAUNCH(256, RSQC_K3_MEDIUM_T, 6144, n_med_short, n_large + n_medium - n_med_short, s2)
     RSQC_K3_LAUNCH(1024, uint16_t, RSQC_K3_LARGE2_LDS16, n_large - n_xlarge, n_xlarge, s3)
-    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_T, RSQC_K3_SMALL_MAX, n_small, n_large + n_medium, s3)
+    // the one-wave classes behind the 256-thread ones (0.3 + 0.2 ms), NOT behind the 64 KB class: beside the fragment kernels that one takes
+    // 0.8 ms, and queued behind it the one-wave classes ended after the fragment count -- the stage's last kernel (timeline of call r6k)
+    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_T, RSQC_K3_SMALL_MAX, n_small - n_le3072, n_large + n_medium, s2)
+    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_T, 3072, n_le3072 - n_le2048, n - n_le3072, s2)
+    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_T, 2048, n_le2048 - n_le1024, n - n_le2048, s2)
+    RSQC_K3_LAUNCH(64, RSQC_K3_SMALL_T, 1024, n_le1024, n - n_le1024, s2)
 #undef RSQC_K3_LAUNCH
 }
 

@@ -249,7 +249,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         for (uint32_t k = 0; k < lay_blocks; ++k) { wavemu::block_idx().x = k; wavemu::run_block(1024, [&]() { frag_layout_kernel(acc.gene_reads, (uint32_t)G, blk_space.data(), blk_parts.data(), part_first.data(), ginfo.data(), cursor.data(), part_info.data(), &full_n); }); }
         if (error) return error;
         if (part_first[G] > parts_bound) return 1010;
-        const uint32_t fgrid = (uint32_t)n_chunks + 4u;
+        const uint32_t fgrid = frag_local_chunk_wgs((uint32_t)n_chunks) + 4u;
         wavemu::grid_dim().x = fgrid;
         for (uint32_t k = 0; k < fgrid; ++k) {
             wavemu::block_idx().x = k;

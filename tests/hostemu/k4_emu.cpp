@@ -108,7 +108,7 @@ int k4emu_run(uint64_t seed, int n_genes, int n_chunks, int n_names, int hot_rea
         }
         counts[nch] = (uint32_t)slow_n;
         for (size_t i = 0; i < slow_n; ++i) pairs[slow_base + i] = PairRec{stream[body + i].g, stream[body + i].h2, stream[body + i].key};
-        grid = nch + 32u;
+        grid = frag_local_chunk_wgs(nch) + 32u;
     } else {
         nch = 0; chunk_cap = 0; slow_base = 0; slow_cap = (uint32_t)n_pairs;
         pairs.resize(n_pairs); counts.assign(1, (uint32_t)n_pairs);
