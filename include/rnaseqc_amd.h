@@ -325,7 +325,7 @@ typedef struct rsqc_batch {
        file index of record i of segment s is seg_file_index[s] + (i - seg_start[s]) and file_index_base is ignored.  A GPU
        that owns a set of NON-ADJACENT contigs of a sorted file (a contig-sharded run) submits them as ONE batch and
        one kernel launch; the order-dependent outputs are then kept per segment (rsqc_shard_summary lists one entry per segment
-       instead of one per batch) and the context's own "Read Length" is composed from them in file order.  ABI version 4.      */
+       instead of one per batch) and the context's own "Read Length" is composed from them in file order.  Since ABI version 4.  */
     const uint64_t *seg_file_index;    /* [n_seg]                              */
 } rsqc_batch;
 

@@ -397,6 +397,38 @@ def test_fragment_sizes_with_bed(oracle_lib, samples):
     assert_results_match(engine.run_engine(p, ann, parts, bed=bed), want)
 
 
+def test_bed_zero_length_first_block_at_an_interval_end(oracle_lib):
+    """the wave-level BED cursor of classify_ei_kernel<true> ("is any interval near this tile's candidates?") must not skip a
+    record whose ZERO-LENGTH aligned block sits one position behind the end of an interval -- fragmentSizeMetrics' block test
+    (src/Expression.cpp:490-507) accepts it: start <= bs and end >= be - 1 with be = bs.  Records of one zero-length block only (clips around
+    it), placed exactly at, one before and one behind the ends of BED intervals, beside ordinary pairs; device = oracle in full."""
+    rows = [dict(contig="c", type="gene", start=1000, end=90000, strand="+", gene_id="G"),
+            dict(contig="c", type="exon", start=1000, end=90000, strand="+", gene_id="G", exon_id="E")]
+    ann = Annotation.from_rows(["c"], rows)
+    from rnaseqc_amd.model import Bed
+    starts = [2000 + 3000 * k for k in range(20)]
+    bed = Bed.from_intervals([0] * 20, starts, [x + 1500 for x in starts])
+    M, S = abi.CIG_M, abi.CIG_S
+    recs = []
+    for k, x in enumerate(starts):
+        end = x + 1500
+        for d in (-2, -1, 0, 1, 2):                           # the zero-length block around the interval's end (1-based block start = pos + 1)
+            q = "z%d_%d" % (k, d)                             # first mate an ordinary read inside the interval, second mate the zero-length record
+            recs.append(dict(qname=q, tid=0, pos=x + 1300 + d, cigar=[(M, 100)], flag=99, mapq=255, nm=0, mpos=end + d, mtid=0, isize=300 + k))
+            recs.append(dict(qname=q, tid=0, pos=end + d, cigar=[(S, 60), (M, 0), (S, 40)], flag=147, mapq=255, nm=0, mpos=x + 1300 + d, mtid=0, isize=-(300 + k)))
+        q = "p%d" % k                                         # an ordinary pair inside the interval
+        recs.append(dict(qname=q, tid=0, pos=x + 100, cigar=[(M, 100)], flag=99, mapq=255, nm=0, mpos=x + 400, mtid=0, isize=400))
+        recs.append(dict(qname=q, tid=0, pos=x + 400, cigar=[(M, 100)], flag=147, mapq=255, nm=0, mpos=x + 100, mtid=0, isize=-400))
+    recs.sort(key=lambda r: r["pos"])
+    b = Batch.from_records(recs)
+    p = abi.default_params()
+    want = oracle_lib.run_oracle(p, ann, [b], bed=bed)
+    assert want.fragment_count.sum() > 20                      # (the ordinary pairs give 20: some zero-length mates are sampled too)
+    got = engine.run_engine(p, ann, [b], bed=bed)
+    assert_results_match(got, want)
+    assert got.fragment_samples_remaining == want.fragment_samples_remaining
+
+
 def test_fragment_sizes_duplicate_qnames(oracle_lib):
     # hand-made QNAME groups: a third record after a completed pair starts a new pending entry; a
     # failing second mate leaves the entry in place (src/Expression.cpp:528)
