@@ -99,29 +99,40 @@ def merge_order_dependent(shard: ShardInfo, dist=None, device=None, fragment_sam
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
 
-    # Seven 1-D arrays of different lengths per rank travel as ONE packed int64 buffer: a gather of the 7 lengths, then a gather
-    # of the concatenated payload padded to the longest rank (two collectives and two host copies per step; one gather per array
-    # was fourteen collectives with a device-to-host copy behind each).  uint32 / uint64 travel as int64: gloo and RCCL both carry
-    # it, values are far below 2^63.
+    # Seven 1-D arrays of different lengths per rank travel as ONE packed int64 buffer [7 lengths | payload] of a fixed width, so that the
+    # usual step costs ONE collective and one host copy (round 6; round 5: a gather of the lengths, then a gather of the payload padded to
+    # the longest rank: two latency-bound collectives with a device-to-host copy behind each, most of `collective_host_merge_ms`).  A
+    # rank whose payload does not fit the fixed width (a --bed run's kept samples) makes every rank take a second, exactly sized gather.
+    # uint32 / uint64 travel as int64: gloo and RCCL both carry it, values are far below 2^63.
     fields = [np.ascontiguousarray(x).astype(np.int64).ravel() for x in
               (shard.batch_file_index, shard.batch_records, shard.rl_offset, shard.rl_span, shard.rl_state, shard.sample_file_index, shard.sample_size)]
     if dist is None:
         cols = [[f] for f in fields]
     else:
-        lens = torch.tensor([len(f) for f in fields], dtype=torch.int64, device=device)
-        all_lens = [torch.empty_like(lens) for _ in range(world)]
-        dist.all_gather(all_lens, lens)
-        all_lens = np.stack([t.cpu().numpy() for t in all_lens])                      # [world, 7]
-        width = max(int(all_lens.sum(axis=1).max()), 1)
-        mine = np.zeros(width, np.int64)
-        cat = np.concatenate(fields) if sum(len(f) for f in fields) else np.zeros(0, np.int64)
-        mine[:len(cat)] = cat
+        W0 = 8192                                                                     # int64 words of payload in the first gather (64 KB per rank)
+        lens = np.array([len(f) for f in fields], np.int64)
+        cat = np.concatenate(fields) if int(lens.sum()) else np.zeros(0, np.int64)
+        mine = np.zeros(7 + W0, np.int64)
+        mine[:7] = lens
+        if len(cat) <= W0:
+            mine[7:7 + len(cat)] = cat
         buf = torch.from_numpy(mine).to(device)
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
+        flats = [o.cpu().numpy() for o in out]
+        all_lens = np.stack([f[:7] for f in flats])                                   # [world, 7]
+        payload = [f[7:] for f in flats]
+        width = int(all_lens.sum(axis=1).max())
+        if width > W0:                                                                # (every rank sees the same lengths: the same decision everywhere)
+            mine2 = np.zeros(width, np.int64)
+            mine2[:len(cat)] = cat
+            buf2 = torch.from_numpy(mine2).to(device)
+            out2 = [torch.empty_like(buf2) for _ in range(world)]
+            dist.all_gather(out2, buf2)
+            payload = [o.cpu().numpy() for o in out2]
         cols = [[] for _ in fields]
-        for k, o in enumerate(out):
-            flat = o.cpu().numpy()
+        for k in range(world):
+            flat = payload[k]
             at = 0
             for j in range(len(fields)):
                 n = int(all_lens[k, j]); cols[j].append(flat[at:at + n].copy()); at += n

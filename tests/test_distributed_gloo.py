@@ -181,3 +181,34 @@ def test_lpt_assignment():
     r = distributed.assign_contigs([100, 10, 90, 20, 80], 2)
     loads = [sum(x for x, k in zip([100, 10, 90, 20, 80], r) if k == j) for j in range(2)]
     assert abs(loads[0] - loads[1]) <= 40 and set(r) == {0, 1}   # LPT: 130 vs 170
+
+
+def _merge_worker(rank, port, out):
+    """One packed gather for the usual step, a second exactly sized one when a rank's payload exceeds the fixed width (a --bed run's
+    kept samples): both forms must hand every rank every shard's arrays unchanged."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from rnaseqc_amd import distributed
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        for big in (5, 20000):                                          # below / above the first gather's 8192 words
+            n = big if rank == 1 else 5
+            sh = distributed.ShardInfo(np.array([rank * 100], np.uint64), np.array([50], np.uint64), np.array([0, 1], np.uint32), np.array([151], np.uint32),
+                                       np.array([150], np.int32), np.arange(n, dtype=np.uint64) * 2 + rank, (np.arange(n) % 500 + 100).astype(np.int64))
+            rl, sizes, counts, rem, infos = distributed.merge_order_dependent(sh, dist, torch.device("cpu"), 1000000)
+            assert rl == 150 and len(infos) == 2
+            assert len(infos[0].sample_size) == 5 and len(infos[1].sample_size) == big
+            assert (infos[1].sample_file_index == np.arange(big) * 2 + 1).all() and (infos[0].batch_file_index == [0]).all() and (infos[1].batch_file_index == [100]).all()
+            assert int(np.asarray(counts).sum()) == 5 + big and rem == 1000000 - 5 - big
+        if rank == 0:
+            open(os.path.join(out, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_order_dependent_merge_one_or_two_gathers(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_merge_worker, args=(_free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
