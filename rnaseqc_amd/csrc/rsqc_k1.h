@@ -980,6 +980,8 @@ classify_ei_kernel(K1Args A) {
                     int32_t *const bc = S.T.bedc[wave];
                     int32_t bed_cur = (int32_t)__builtin_amdgcn_readfirstlane(bc[1]), bed_nxt = (int32_t)__builtin_amdgcn_readfirstlane(bc[2]), bed_pm = (int32_t)__builtin_amdgcn_readfirstlane(bc[3]);
                     const bool fresh = (uint32_t)__builtin_amdgcn_readfirstlane(bc[0]) != seg;        // first candidate tile on this contig
+                    __builtin_amdgcn_wave_barrier();             // every lane has read the cursor before the first lane may rewrite it (no instruction:
+                                                                 // an ordering point for the compiler -- and where the host emulation's lanes, which run one after the other, line up)
                     if (fresh || (int32_t)t_hi >= bed_nxt || (int32_t)t_hi < bed_cur) {   // ... or the tile's end passed the next row's start (or the stream went backwards)
                         const K1Args *q = k1e_lazy_args();
                         uint32_t bed_lo = 0u, bed_hi = 0u;

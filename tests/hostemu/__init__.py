@@ -67,7 +67,7 @@ def build_k1(coarse=True):
     return so
 
 
-def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=True):
+def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=True, bed=None):
     """The per-record KERNELS (rsqc_k1.h) on the 64-lane fiber emulation of wavemu.h, `grid` workgroups of 256 lanes."""
     lib = C.CDLL(build_k1(coarse))
     a, b = ann.to_struct(), batch.to_struct()
@@ -81,13 +81,14 @@ def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=
     if want_cov:
         total = int(sum(int(ann.exon_row_end[i]) - int(ann.exon_row_start[i]) + 1 for i in range(E))) + ann.n_genes + 8
         o.cov = np.zeros(total, np.uint32)
-    rc = lib.k1emu_run(C.byref(params), C.byref(a), C.byref(b), C.c_int(grid), C.c_int(1 if slow_kernel else 0), abi.ptr(o.counters), abi.ptr(o.gene_reads),
-                       abi.ptr(o.gene_unique), abi.ptr(o.gene_fragments), abi.ptr(o.exon_reads), C.byref(rl),
-                       abi.ptr(o.cov) if want_cov else None, abi.ptr(stats))
+    bs = bed.to_struct() if bed is not None else None           # (with a BED: the --bed instance classify_ei_kernel<true>, candidates checked)
+    rc = lib.k1emu_run_bed(C.byref(params), C.byref(a), C.byref(b), C.byref(bs) if bs is not None else None, C.c_int(grid), C.c_int(1 if slow_kernel else 0),
+                           abi.ptr(o.counters), abi.ptr(o.gene_reads), abi.ptr(o.gene_unique), abi.ptr(o.gene_fragments), abi.ptr(o.exon_reads), C.byref(rl),
+                           abi.ptr(o.cov) if want_cov else None, abi.ptr(stats))
     if rc:
         raise RuntimeError("k1emu rc=%d" % rc)
     o.read_length = rl.value
-    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]) & 0xFFFFFFFF; o.n_deferred = int(stats[1]) >> 32; o.n_pairs = int(stats[2]); o.n_coarse = int(stats[3])
+    o.n_overflow = int(stats[0]); o.n_listed = int(stats[1]) & 0xFFFFFFFF; o.n_deferred = int(stats[1]) >> 32; o.n_pairs = int(stats[2]); o.n_coarse = int(stats[3]) if bed is None else 0; o.n_candidates = int(stats[3]) if bed is not None else 0
     lib.k1emu_uniform_calls.restype = C.c_ulonglong
     o.n_uniform = int(lib.k1emu_uniform_calls())
     lib.k1emu_ucache_hits.restype = C.c_ulonglong

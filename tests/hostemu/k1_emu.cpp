@@ -44,7 +44,20 @@ extern "C" __attribute__((visibility("default"))) unsigned long long k1emu_ucach
 
 // returns 0, an RSQC_ERR_* code, or 1000 + k for a failed internal check k
 extern "C" __attribute__((visibility("default")))
+int k1emu_run_bed(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, const rsqc_bed *bed, int grid, int slow_kernel,
+                  uint64_t *counters, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag, double *exon_reads,
+                  int32_t *read_length, uint32_t *cov_out, uint64_t *stats);
+extern "C" __attribute__((visibility("default")))
 int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, int grid, int slow_kernel,
+              uint64_t *counters, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag, double *exon_reads /*by exon id*/,
+              int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/, uint64_t *stats /*[4]: overflow, listed | deferred << 32, pairs, coarse-table hits*/) {
+    return k1emu_run_bed(p, a, b, nullptr, grid, slow_kernel, counters, gene_reads, gene_unique, gene_frag, exon_reads, read_length, cov_out, stats);
+}
+// `bed` (may be NULL): with it the --bed instance classify_ei_kernel<true> runs, and the fragment-size candidates it leaves in the workgroups'
+// regions must be EXACTLY the records that pass src/RNASeQC.cpp:372 and the block tests of bed_interval_of, computed here record by record
+// without the kernel's wave-level cursor shortcut (that path had no emulation coverage); stats[3] then = candidates
+extern "C" __attribute__((visibility("default")))
+int k1emu_run_bed(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *b, const rsqc_bed *bed, int grid, int slow_kernel,
               uint64_t *counters, uint64_t *gene_reads, uint64_t *gene_unique, uint64_t *gene_frag, double *exon_reads /*by exon id*/,
               int32_t *read_length, uint32_t *cov_out /*cov_entries or NULL*/, uint64_t *stats /*[4]: overflow, listed | deferred << 32, pairs, coarse-table hits*/) {
     HostIndex hx; std::string err;
@@ -65,6 +78,20 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     d.ex_id = ex_id.data();
     std::vector<uint32_t> zero_range((size_t)a->n_contigs + 1, 0);
     d.bed_range = zero_range.data(); d.have_bed = 0;
+    std::vector<int32_t> bed_pmax;
+    if (bed) {                                                             // as rsqc_set_bed builds them (no bin table: bed_interval_of searches)
+        for (int i = 0; i < bed->n_intervals; ++i) {
+            if (bed->contig[i] < 0 || bed->contig[i] >= a->n_contigs) return RSQC_ERR_ARG;
+            zero_range[(size_t)bed->contig[i] + 1]++;
+        }
+        for (int k = 0; k < a->n_contigs; ++k) zero_range[(size_t)k + 1] += zero_range[(size_t)k];
+        bed_pmax.resize((size_t)std::max(bed->n_intervals, 1));
+        for (int k = 0; k < a->n_contigs; ++k) {
+            int32_t m = INT32_MIN;
+            for (uint32_t i = zero_range[(size_t)k]; i < zero_range[(size_t)k + 1]; ++i) { m = std::max(m, bed->end[i]); bed_pmax[i] = m; }
+        }
+        d.bed_start = bed->start; d.bed_end = bed->end; d.bed_pmax = bed_pmax.data(); d.bed_binhi = nullptr; d.bed_bin_base = nullptr; d.have_bed = 1;
+    }
     DevParams dp{p->mapq_threshold, p->base_mismatch, p->chimeric_distance, p->stranded, p->unpaired, p->exclude_chimeric, p->n_filter_tags, 0};
 
     // the batch with the slack the device buffers carry (kernels read a few entries past the end with ignored loads)
@@ -106,6 +133,12 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     acc.pair_slow_base = chunk_cap * (uint32_t)n_chunks; acc.pair_slow_cap = slow_cap; acc.pair_slow_count = chunk_count.data() + n_chunks;
     acc.ovf_count = ovf_count.data(); acc.ovf_index = (uint64_t *)ovf_index.data(); acc.ovf_cap = (uint32_t)ovf_index.size();
     acc.defer_index = defer_index.data(); acc.defer_list = defer_list.data(); acc.defer_total = &defer_total;
+    // --bed: the workgroups' candidate regions (a slot per record) and their counts
+    std::vector<uint64_t> fr_file((size_t)n + 64), fr_qhash((size_t)n + 64);
+    std::vector<int32_t> fr_name((size_t)n + 64), fr_end((size_t)n + 64);
+    std::vector<uint32_t> fr_fs((size_t)n + 64), fr_h2((size_t)n + 64), fr_counts((size_t)grid + 1, 0xDEADu);
+    acc.frag.file_index = fr_file.data(); acc.frag.qhash = fr_qhash.data(); acc.frag.name = fr_name.data(); acc.frag.endpos = fr_end.data();
+    acc.frag.flag_size = fr_fs.data(); acc.frag.h2 = fr_h2.data(); acc.frag.chunk_count = fr_counts.data(); acc.frag.count = nullptr; acc.frag.cap = (uint32_t)n;
     acc.tile_span = tile_span.data();
     acc.rl_stats = rl_stats.data(); acc.read_length = &rl_state; acc.error = &error;
 
@@ -114,7 +147,8 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     wavemu::grid_dim().x = (uint32_t)grid;
     for (int k = 0; k < grid; ++k) {
         wavemu::block_idx().x = (uint32_t)k;
-        wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel<false>(A); });      // (the instance of runs without a BED)
+        if (bed) wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel<true>(A); });
+        else wavemu::run_block(RSQC_K1_THREADS, [&]() { classify_ei_kernel<false>(A); });      // (the instance of runs without a BED)
     }
     uint64_t n_deferred = 0;
     for (uint32_t k = 0; k < defer_total; ++k) { ++n_deferred; if ((defer_list[k] & 0x7FFFFFFFu) >= n) return 1013; }
@@ -126,6 +160,7 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
         }
         wavemu::grid_dim().x = (uint32_t)grid;
     }
+    if (getenv("K1EMU_TRACE")) fprintf(stderr, "k1emu: per-record kernels done, error %d\n", error);
     uint64_t listed = 0;
     if (error) return error;
 
@@ -274,6 +309,36 @@ int k1emu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch *
     for (int e = 0; e < a->n_exons; ++e) exon_reads[a->exon_row_id[e]] = exon_rows[(size_t)e] + exon_acc[a->exon_row_id[e]];
     *read_length = (int32_t)rl;
     if (cov_out) memcpy(cov_out, cov.data(), hx.cov_entries * 4);
-    stats[0] = n_overflow; stats[1] = listed | (n_deferred << 32); stats[2] = n_pairs; stats[3] = g_k1e_coarse_hits;
+    uint64_t n_cand = 0;
+    if (getenv("K1EMU_TRACE")) fprintf(stderr, "k1emu: reached the candidate check\n");
+    if (bed) {                                                             // the kernel's candidates against the per-record rule, no shortcut
+        std::map<uint64_t, size_t> got;                                    // record index -> slot
+        for (int k = 0; k < grid; ++k) {
+            uint32_t beg, end;
+            k1e_wg_range((uint32_t)n, (uint32_t)grid, (uint32_t)k, beg, end);
+            if (fr_counts[(size_t)k] > end - beg) return 1020;
+            for (uint32_t j = 0; j < fr_counts[(size_t)k]; ++j) {
+                const uint64_t idx = fr_file[(size_t)beg + j] - b->file_index_base;
+                if (idx >= n || idx < beg || idx >= end || !got.emplace(idx, (size_t)beg + j).second) return 1021;
+            }
+        }
+        for (uint64_t i = 0; i < n; ++i) {
+            Record r;
+            if (!load(i, r)) return RSQC_ERR_ARG;
+            RecordCounters rc2; bool hq; uint32_t aligned; Blocks B;
+            gate_cascade(d, dp, r, rc2, hq, aligned, B);
+            const int32_t name = (rc2.frag_candidate && r.tid >= 0 && r.tid < a->n_contigs) ? bed_interval_of(d, r) : -1;
+            const auto it = got.find(i);
+            if ((name >= 0) != (it != got.end())) return name >= 0 ? 1022 : 1023;      // 1022: the kernel skipped a candidate (the cursor shortcut)
+            if (name < 0) continue;
+            ++n_cand;
+            const size_t sl = it->second;
+            const bool fok = !(r.flag & RSQC_FMREVERSE) && (r.flag & RSQC_FREVERSE) && r.pos != r.mpos;
+            const uint32_t sz = (uint32_t)(r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize);
+            if (fr_name[sl] != name || fr_end[sl] != rc2.endpos || fr_qhash[sl] != r.qhash || fr_fs[sl] != ((sz & 0x7FFFFFFFu) | (fok ? 0x80000000u : 0u)) ||
+                fr_h2[sl] != (b->qhash2 ? b->qhash2[i] : 0u)) return 1024;
+        }
+    }
+    stats[0] = n_overflow; stats[1] = listed | (n_deferred << 32); stats[2] = n_pairs; stats[3] = bed ? n_cand : g_k1e_coarse_hits;
     return 0;
 }

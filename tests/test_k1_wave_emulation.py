@@ -157,6 +157,40 @@ def test_every_record_deferred_fills_the_long_kernels_chunks(oracle_lib):
         assert (o.n_deferred == n) if four else (0 < o.n_deferred < n)
 
 
+def test_bed_instance_candidates(oracle_lib):
+    """The --bed instance classify_ei_kernel<true> under emulation (its wave-level cursor into the BED rows and the scalar
+    interval look-up had none): the fragment-size candidates it leaves must be exactly the records that pass the per-record rule
+    (gate cascade + bed_interval_of, no shortcut) -- a synthetic BED over three contigs, and zero-length first blocks around interval ends."""
+    from rnaseqc_amd.model import Bed
+    ann = synth.make_annotation(seed=8, contigs=[("chrA", 600_000, 60), ("chrB", 300_000, 30), ("chrC", 100_000, 0)])
+    bed = synth.make_bed(ann, min_len=250)
+    batch = synth.make_reads(ann, 5000, seed=10, frac=(0.9, 0.04, 0.03, 0.03), expr_sigma=1.0, contig_lengths=np.array([600_000, 300_000, 100_000]))
+    p = abi.default_params()
+    r = oracle_lib.run_oracle(p, ann, [batch])
+    for grid in (1, 3):
+        o = hostemu.run_k1(p, ann, batch, grid=grid, bed=bed)
+        _compare(o, r)
+        assert o.n_candidates > 300
+    rows = [dict(contig="c", type="gene", start=1000, end=90000, strand="+", gene_id="G"),
+            dict(contig="c", type="exon", start=1000, end=90000, strand="+", gene_id="G", exon_id="E")]
+    ann2 = Annotation.from_rows(["c"], rows)
+    starts = [2000 + 3000 * k for k in range(20)]
+    bed2 = Bed.from_intervals([0] * 20, starts, [x + 1500 for x in starts])
+    M, S = abi.CIG_M, abi.CIG_S
+    recs = []
+    for k, x in enumerate(starts):
+        end = x + 1500
+        for dd in (-2, -1, 0, 1, 2):
+            q = "z%d_%d" % (k, dd)
+            recs.append(dict(qname=q, tid=0, pos=x + 1300 + dd, cigar=[(M, 100)], flag=99, mapq=255, nm=0, mpos=end + dd, mtid=0, isize=300 + k))
+            recs.append(dict(qname=q, tid=0, pos=end + dd, cigar=[(S, 60), (M, 0), (S, 40)], flag=147, mapq=255, nm=0, mpos=x + 1300 + dd, mtid=0, isize=-(300 + k)))
+    recs.sort(key=lambda t: t["pos"])
+    b2 = Batch.from_records(recs)
+    o = hostemu.run_k1(p, ann2, b2, grid=2, bed=bed2)
+    _compare(o, oracle_lib.run_oracle(p, ann2, [b2]))
+    assert o.n_candidates >= 20 * 3 * 2 - 20                       # (first mates at three of the five offsets, and the zero-length mates beside them)
+
+
 def test_many_small_contigs_in_one_tile(oracle_lib):
     """Several contigs inside one 64-record tile: the records beyond the tile's first contig take the general code and find their
     contig themselves; for one with a long CIGAR the general code also counts "Alignment Blocks" and checks the operations
