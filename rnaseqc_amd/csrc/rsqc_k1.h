@@ -112,6 +112,11 @@ template <class... T> __device__ __forceinline__ void k1e_sink_s(T... x) { const
 #else
 #define K1E_STOP(n, V, S)
 #endif
+#if defined(K1E_STAGE_MARKS)
+#define K1E_AMARK(sec)                             /* (phase A's marks off: its time lands in [8], or in [0] for a tile without a stage call) */
+#else
+#define K1E_AMARK(sec) RSQC_MARK(sec)
+#endif
 constexpr int K1E_WAVES = RSQC_K1_THREADS / 64;
 #ifndef K1E_PIECE_RECORDS
 #define K1E_PIECE_RECORDS 256
@@ -133,6 +138,9 @@ constexpr uint32_t K1E_HQ = 1u << 16;         // item word `flhq`: the record's 
 //  8 no pairs, 16 no long-CIGAR kernel -- wrong results by design; the product build has K1E_ABL == 0 and none of it)
 #ifndef K1E_ABL
 #define K1E_ABL 0
+#endif
+#ifndef K1E_WALK_SKIP
+#define K1E_WALK_SKIP 1       /* operations 5-7 of the staged eight are walked only by tiles in which some record has more than five (call r6o: K1 2.27 -> 2.18 ms; 0: rounds 6a-6n) */
 #endif
 #ifndef K1E_EXON_RUNSUM
 #define K1E_EXON_RUNSUM 1     /* 0: exon fractions of multi-block records lane by lane (rounds 3-5), for an A/B */
@@ -620,17 +628,20 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     if (pre0) ++g_k1e_coarse_hits;                 // (test harness: records answered by the coarse table)
 #endif
     // the name hash is only needed by records that are counted to a gene: it comes back from the record array (the lines
-    // were streamed through this CU's caches a few tiles ago) instead of riding through the queue
+    // were streamed through this CU's caches a few tiles ago) instead of riding through the queue.
+    // (Call r6o: issued BEHIND the entry loads of the two- and three-block stages instead -- loads return in order, so in front of the rank words
+    //  these gathers are waited for by the first look-up round -- K1 2.27 -> 2.30 ms: their latency is then exposed at the pair stores.)
     const uint2 qh = ld32(reinterpret_cast<const uint2 *>(aux), idx * 2u);
     const uint32_t qh2 = qh2col ? ld32(qh2col, idx) : 0u;        // (uniform branch: the batch carries second name hashes or it does not)
+    K1E_SMARK(1);                                          // [1] queue entries read
     WaveSink cnt;
-    const uint64_t qhash = (uint64_t)qh.x | ((uint64_t)qh.y << 32);
-    if (NB != 1 || !K1E_UNIFORM1 || !k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, qhash, qh2, n >= 64u ? ~0ull : (1ull << n) - 1ull, cnt, held, wave)) {
+    if (NB != 1 || !K1E_UNIFORM1 || !k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, n >= 64u ? ~0ull : (1ull << n) - 1ull, cnt, held, wave)) {
         EiOut eo; bool over = false;
         exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
         k1e_overflow(on && over, (uint64_t)idx);
-        k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, qhash, qh2, held, blockIdx.x);
-    }
+        k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, held, blockIdx.x);
+        K1E_SMARK(6);                                      // [6] commit (LDS tables, coverage atomics, pairs)
+    } else { K1E_SMARK(7); }                               // [7] a one-block call answered by the wave-uniform path, whole
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 
@@ -647,8 +658,7 @@ __device__ __forceinline__ void k1e_walk3(int32_t pos, uint32_t n, const uint32_
     uint32_t cur = (uint32_t)pos + 1u;                                     // 1-based position of the next reference base
     uint32_t b0 = 0u, b1 = 0u, b2 = 0u, l0 = 0u, l1 = 0u, l2 = 0u, nbneg = 0u, bad = 0u;
     const uint32_t live = n >= 8u ? 0xFFu : ((1u << n) - 1u);              // bit k: operation k exists
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    auto op = [&](int k) {
         const uint32_t ck = bfi(bfe_m(live, (uint32_t)k), c[k], 5u);       // past the end: a hard clip of length 0 (no block, no reference, legal)
         const uint32_t len = ck >> 4, blk = bfe_m(K1E_TAB_BLOCK3, ck);
         bad |= bfe_u(K1E_TAB_BAD3, ck, 1u);                                // Expression.cpp:61-63
@@ -657,7 +667,20 @@ __device__ __forceinline__ void k1e_walk3(int32_t pos, uint32_t n, const uint32_
         b1 = bfi(blk, b0, b1); l1 = bfi(blk, l0, l1);
         b0 = bfi(blk, cur, b0); l0 = bfi(blk, len, l0);
         cur += len & bfe_m(K1E_TAB_REF3, ck);
+    };
+#if K1E_WALK_SKIP
+    // operations 5, 6, 7 exist in few records (four blocks, three blocks with clips or an indel): a tile without one skips them (a scalar
+    // branch; for the lanes of a tile that takes them the masked operations are the same no-ops as before)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) op(k);
+    if (__ballot(n > 5u) != 0ull) {
+#pragma unroll
+        for (int k = 5; k < 8; ++k) op(k);
     }
+#else
+#pragma unroll
+    for (int k = 0; k < 8; ++k) op(k);
+#endif
     if (__ballot(n > 8) != 0ull) {
         for (uint32_t i = 8; i < n; ++i) { const uint32_t cx = cigar[i]; cur += (cx >> 4) & bfe_m(K1E_TAB_REF3, cx); }
         K1E_LANDED(cur);
@@ -912,7 +935,7 @@ classify_ei_kernel(K1Args A) {
         { const uint32_t wb = tile_base(w2); n_co = ld32(core1 + 4 * (size_t)wb, 4u * lane_off(wb) + 3u); }
         WaveSink cnt;
         // ---- phase A: record words, CIGAR, gate cascade ----------------------------------------------------------
-        RSQC_MARK(1);
+        K1E_AMARK(1);
         // The run's switches (--unpaired, chimeric exclusion, configured tag filters) are the same for every tile: the conditions the
         // cascade derives from them are 64-bit lane masks that the compiler computes ONCE, keeps in scalar register pairs across
         // the tile loop, spills to VGPR lanes under the cascade's pressure and reloads with two v_readlane each, every tile.
@@ -948,18 +971,18 @@ classify_ei_kernel(K1Args A) {
         if (bad_wide) atomicExch(k1e_lazy_args()->acc.error, RSQC_ERR_ARG);
         const WB lane_on = WS::prim(valid) && !WS::prim(bad_wide != 0u);
         if (!WS::lane(lane_on)) r.n_cigar = 0;
-        RSQC_MARK(2);
+        K1E_AMARK(2);
         K1E_STOP(2, (r.pos, r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off), (lane_on.m))
         Walk3 w2;                                             // all eight staged operations, up to three blocks captured (last block first)
         k1e_walk3(r.pos, r.n_cigar, cg, r.cigar, w2);
-        RSQC_MARK(3);
+        K1E_AMARK(3);
         K1E_STOP(3, (r.mpos, r.isize, r.flag, r.l_qseq, r.mapq, r.nm, r.tagbits, r.n_cigar, cur_cigar_off, w2.ref_len, w2.nb, w2.bad, w2.b0, w2.b1, w2.b2, w2.l0, w2.l1, w2.l2), (lane_on.m))
         const bool shortc = r.n_cigar <= 8;                    // blocks and legality are known here; longer CIGARs: classify_long_kernel
         CigarWalk cw;
         cw.ref_len = w2.ref_len; cw.nblocks = shortc ? w2.nb : 0u; cw.aligned = 0; cw.bad = shortc && w2.bad != 0u;
         RecordCounters rc; WB hq = lane_on;
         const WB go = gate_cascade_b<false, WaveSink, true>(a, pt, r, cw, rc, hq, cnt, lane_on);    // (a lane without a record leaves with every output 0)
-        RSQC_MARK(4);
+        K1E_AMARK(4);
         K1E_STOP(4, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.b0, w2.b1, w2.b2, w2.l0, w2.l1, w2.l2, rc.e1_mm, rc.e1_bases, rc.e2_mm, rc.e2_bases, rc.mm, rc.bases, rc.blocks, rc.rl_span, rc.rl_lqseq, rc.rl_eligible, rc.error, rc.frag_candidate, cnt.vec), (go.m, hq.m))
         // --bed (src/RNASeQC.cpp:372): the block tests of fragmentSizeMetrics walk the CIGAR again and chase the BED rows per lane --
         // divergent code with dependent loads, and as soon as ONE lane of the tile takes it the wave does (round 4: 4.2 instead of
@@ -1042,7 +1065,7 @@ classify_ei_kernel(K1Args A) {
             l_span = sp > l_span ? sp : l_span;
             l_lmin = (elig && lq < l_lmin) ? lq : l_lmin; l_lmax = lq > l_lmax ? lq : l_lmax;    // (rl_lqseq is 0 for the others)
         }
-        RSQC_MARK(5);
+        K1E_AMARK(5);
         K1E_STOP(5, (r.flag, r.n_cigar, cur_cigar_off, w2.nb, w2.b0, w2.b1, w2.b2, w2.l0, w2.l1, w2.l2, cnt.vec), (go.m, hq.m, big_any.m))
         const uint32_t flhq = r.flag | (WS::lane(hq) ? K1E_HQ : 0u);
         // ---- sort by shape ------------------------------------------------------------------------------------------
@@ -1063,7 +1086,7 @@ classify_ei_kernel(K1Args A) {
             const WB none = simple && nb0;
             RSQC_COUNT(cnt, RSQC_C_INTERGENIC_READS, none); RSQC_COUNT(cnt, RSQC_C_HQ_INTERGENIC_READS, none && hq);
         }
-        RSQC_MARK(6);
+        K1E_AMARK(6);
         // ---- the staged words have landed (see above).  In the -DK1E_COARSE build the wait sits HERE, in front of the queue writes:
         //      the coarse word of this tile's records (loaded a tile ago, i.e. older than the staged words) is then complete without
         //      a wait of its own -- a wait anywhere earlier in phase A would also wait for the previous feature stage's atomics.
@@ -1105,7 +1128,7 @@ classify_ei_kernel(K1Args A) {
         if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
         if (++pending == 31 || WS::any(big_any)) flush_counts();
         } while (0);
-        RSQC_MARK(7);
+        K1E_AMARK(7);
 #if !defined(K1E_COARSE)                              /* the landing wait behind the queue writes and the counters: 2.59 -> 2.52 ms (profiles/r4_k1_variants.txt) */
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("; K1E staged words landed" :: "v"(n_cv.x), "v"(n_cv.y), "v"(n_cv.z), "v"(n_cv.w), "v"(n_av.x), "v"(n_av.y), "v"(n_av.z), "v"(n_av.w), "v"(n_co));

@@ -27,6 +27,13 @@
 #ifndef RSQC_MARK
 #define RSQC_MARK(sec)
 #endif
+// (-DK1E_STAGE_MARKS, profiling build only: the marks sit INSIDE the feature stage -- queue read, rank words, entries, flags, commit -- and
+//  phase A's own marks are off, see rsqc_k1.h)
+#if defined(K1E_STAGE_MARKS)
+#define K1E_SMARK(sec) RSQC_MARK(sec)
+#else
+#define K1E_SMARK(sec)
+#endif
 #ifndef RSQC_EVENT
 #define RSQC_EVENT(id, cond)          // profiling build: counts the tiles in which some lane takes a slow branch
 #endif
@@ -900,10 +907,13 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
         EiProbe pr[G]; EiFetch fe[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_probe(a, ci, bs[b0 + j], len[b0 + j], lane_on && (uint32_t)(b0 + j) < nbv, pr[j], (b0 + j == 0) ? pre0 : 0u);
+        K1E_SMARK(2);                                      // [2] rank words issued
 #pragma unroll
         for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_fetch(a, ci, pr[j], fe[j]);
+        K1E_SMARK(3);                                      // [3] rank words landed, entries issued
 #pragma unroll
         for (int j = 0; j < G; ++j) if (b0 + j < NB) ei_resolve(a, pr[j], fe[j], rstrand, qb[b0 + j]);
+        K1E_SMARK(4);                                      // [4] entries landed, blocks resolved
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -945,6 +955,7 @@ RSQC_HD void exon_metrics_ei(const DevAnnotation &a, const DevParams &p, const C
         if (aligned > 0) { out.hit[0] = va ? la : lb; out.hit[1] = lb; out.n_hit = nlast; }
     }
     class_counts_cf(cnt, p, fl, ei_class_flags(mask, rstrand), any_gene, hqb, keep);
+    K1E_SMARK(5);                                          // [5] gene sets, class flags, counters
 }
 
 // ---- stage 2: exonAlignmentMetrics, src/Expression.cpp:308-458 ---------------------------

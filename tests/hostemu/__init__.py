@@ -61,9 +61,10 @@ def build_k1(coarse=True):
     srcs = [os.path.join(_HERE, "k1_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
            [os.path.join(csrc, f) for f in ("rsqc_read.h", "rsqc_index.h", "rsqc_k1.h", "rsqc_k1s.h", "rsqc_kr.h", "rsqc_k4.h", "rsqc_wave.h", "rsqc_device.h")] + \
            [os.path.join(_ROOT, "include", "rnaseqc_amd.h")]
+    # (RSQC_EMU_DEFS="-DK1E_..." : the emulation of an A/B build of the kernel; remove the .so files before and after)
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
-                               "-Wno-unused-variable"] + (["-DK1E_COARSE"] if coarse else []) + [srcs[0], "-o", so])
+                               "-Wno-unused-variable"] + (["-DK1E_COARSE"] if coarse else []) + os.environ.get("RSQC_EMU_DEFS", "").split() + [srcs[0], "-o", so])
     return so
 
 

@@ -17,6 +17,10 @@ lib = engine.load_library()
 names = ["loop tail (prev. tile)", "segments + issue next loads", "unpack", "CIGAR walk", "gate cascade", "sums + Read-Length (+BED)",
          "sort by shape + queues", "landing wait", "(before a feature stage)", "one-block tiles", "two-block tiles", "long-CIGAR tiles",
          "tail flush", "wg epilogue", "", ""]
+if os.environ.get("K1_STAGE_MARKS"):             # a -DK1E_STAGE_MARKS build: the marks sit inside the feature stage
+    names = ["loop tail + phase A of tiles without a call", "queue entries read (+ name-hash gathers issued)", "rank words issued", "rank words landed, entries issued",
+             "entries landed, blocks resolved", "gene sets, class flags, counters", "commit: LDS tables, coverage atomics, pairs", "one-block call on the wave-uniform path (whole)",
+             "phase A (+ tail of the call before)", "one-block call: counters to LDS, exit", "two-block call: exit", "three-block call: park / unpark, exit", "tail flush", "wg epilogue", "", ""]
 for rep in range(2):
     e.reset(); lib.rsqc_debug_k1_prof(None, 1); e.submit_resident(h); e.wait()
 out = (C.c_ulonglong * 48)(); lib.rsqc_debug_k1_prof(out, 0)
