@@ -1223,8 +1223,21 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         // ---- K5: fragment-size sampler (BED runs) ---------------------------------------------------
         if (c->have_bed) {
-            // the batches still in flight join the retired ones in the candidate arena (file order), then one pairing pass
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            // the batches still in flight join the retired ones in the candidate arena (file order), then one pairing pass.
+            // K5 depends on the per-record kernels only (their candidates, and the counts copied behind them), not on K3 / K4: it runs BESIDE the
+            // end-of-file kernels, on the side stream whose coverage class ends first (the 64 KB class: ~0.5 ms), from the moment the fork event
+            // has fired -- rounds 4-6 waited for the whole stage here and ran it behind (1.3 ms of every --bed pass).  Only when the arena must
+            // grow while it holds retired batches (its old columns are copied on the main stream) does the old order apply.
+            uint64_t incoming = 0;
+            bool beside = true;
+#ifdef RSQC_K5_SERIAL
+            beside = false;                                   // (A/B build: the order of rounds 4-6)
+#endif
+            HIP_TRY(c, hipEventSynchronize(c->ev_fork));      // every batch's kernels are done, the mirrors of the candidate counts are valid
+            for (size_t k = 0; k < c->frags_in_flight.size(); ++k) incoming += *c->frag_pool[c->frags_in_flight[k]].h_count;
+            if (c->frag_arena.used && c->frag_arena.used + incoming > c->frag_arena.cap) beside = false;
+            hipStream_t ks = beside ? c->stream4 : c->stream;
+            if (!beside) HIP_TRY(c, hipStreamSynchronize(c->stream));
             for (size_t k = 0; k < c->frags_in_flight.size(); ++k) {
                 FragBuf &fb = c->frag_pool[c->frags_in_flight[k]];
                 const uint32_t n = *fb.h_count;               // (copied when the batch was submitted; the stream has been synchronised)
@@ -1233,7 +1246,7 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
                 const void *src[6] = {fb.file.p, fb.qhash.p, fb.name.p, fb.endpos.p, fb.fs.p, fb.h2.p};
                 for (int f = 0; f < 6 && n; ++f)
                     HIP_TRY(c, hipMemcpyAsync((char *)c->frag_arena.col[f].p + c->frag_arena.used * c->frag_arena.width[f], src[f],
-                                              (size_t)n * c->frag_arena.width[f], hipMemcpyDeviceToDevice, c->stream));
+                                              (size_t)n * c->frag_arena.width[f], hipMemcpyDeviceToDevice, ks));
                 c->frag_arena.used += n;
                 fb.used = false;
             }
@@ -1243,8 +1256,9 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
             FragCandidates fc{(uint64_t *)c->frag_arena.col[0].p, (uint64_t *)c->frag_arena.col[1].p, (int32_t *)c->frag_arena.col[2].p,
                               (int32_t *)c->frag_arena.col[3].p, (uint32_t *)c->frag_arena.col[4].p, nullptr, (uint32_t)total, nullptr, (uint32_t *)c->frag_arena.col[5].p};
             const auto tf0 = std::chrono::steady_clock::now();
-            rc = run_fragment_sizes(c->stream, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
+            rc = run_fragment_sizes(ks, fc, (uint32_t)total, c->params.fragment_samples, c->h_fsize, c->h_fcount,
                                     c->frag_remaining, c->frag_scratch, c->frag_kept, c->acc.error);
+            if (beside && !rc) HIP_TRY(c, hipStreamSynchronize(ks));      // (run_fragment_sizes returns without a wait when it keeps no samples)
             c->timing.fragment_sizes_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
             if (rc) return fail(c, rc, "fragment-size stage failed");
         }
