@@ -63,6 +63,7 @@ static const K1Args *g_k1e_args = nullptr;       // (host emulation: set by the 
 static unsigned long long g_k1e_coarse_hits = 0;
 static unsigned long long g_k1e_ucache_hits = 0;     // (test harness: ... of which the interval came from the wave's one-entry cache)
 static unsigned long long g_k1e_uniform_calls = 0;   // (test harness: one-block feature-stage calls answered by the wave-uniform path)
+static unsigned long long g_k1e_uniform2_calls = 0;  // (test harness: two-block calls answered by k1e_uniform2)
 static inline const K1Args *k1e_lazy_args() { return g_k1e_args; }
 #endif
 
@@ -499,6 +500,27 @@ __device__ __forceinline__ K1eInterval k1e_interval_of(const DevAnnotation &a, c
 __device__ __forceinline__ void k1e_count_at(WaveSink &cnt, int counter, uint32_t n) {
     cnt.vec = lane_id() == counter ? n : cnt.vec;
 }
+// class_counts_b (src/Expression.cpp:407-457) of a call whose class flags `cf` and gene set (`any_gene`: it is not empty) are the WAVE's:
+// one class for all of its records -- the counters are popcounts of the lanes' quality / flag masks
+__device__ __forceinline__ void k1e_uniform_class_counts(const DevParams &p, uint32_t cf, bool any_gene, uint32_t flhq, uint64_t onm,
+                                                         uint32_t n_on, uint32_t n_hq, WaveSink &cnt) {
+    typedef WaveSink WS;
+    const bool exonic = (cf & CF_EXONIC) != 0, intragenic = (cf & CF_INTRAGENIC) != 0;
+    const int cls = !exonic ? (intragenic ? RSQC_C_INTRONIC_READS : RSQC_C_INTERGENIC_READS) : (any_gene ? RSQC_C_EXONIC_READS : RSQC_C_AMBIGUOUS_READS);
+    static_assert(RSQC_C_HQ_INTRONIC_READS == RSQC_C_INTRONIC_READS + 2 && RSQC_C_HQ_INTERGENIC_READS == RSQC_C_INTERGENIC_READS + 1 &&
+                  RSQC_C_HQ_EXONIC_READS == RSQC_C_EXONIC_READS + 1 && RSQC_C_HQ_AMBIGUOUS_READS == RSQC_C_AMBIGUOUS_READS + 1, "counter order");
+    k1e_count_at(cnt, cls, n_on); k1e_count_at(cnt, cls + (cls == RSQC_C_INTRONIC_READS ? 2 : 1), n_hq);
+    if ((!exonic && intragenic) || (exonic && any_gene)) { k1e_count_at(cnt, RSQC_C_INTRAGENIC_READS, n_on); k1e_count_at(cnt, RSQC_C_HQ_INTRAGENIC_READS, n_hq); }
+    if (cf & CF_RIBOSOMAL) k1e_count_at(cnt, RSQC_C_RRNA_READS, n_on);
+    const bool plus = (cf & CF_PLUS) != 0, minus = (cf & CF_MINUS) != 0;
+    if (plus != minus) {                                                                        // :445-457
+        const uint64_t one = p.unpaired ? onm : (onm & WS::prim((flhq & RSQC_FPAIRED) != 0).m);
+        const uint64_t revm = WS::prim((flhq & RSQC_FREVERSE) != 0).m, sense = minus ? revm : ~revm;
+        const uint64_t end1 = p.unpaired ? ~0ull : WS::prim((flhq & RSQC_FREAD1) != 0).m;
+        RSQC_COUNT(cnt, RSQC_C_END1_SENSE, LaneMask{one & end1 & sense}); RSQC_COUNT(cnt, RSQC_C_END1_ANTISENSE, LaneMask{one & end1 & ~sense});
+        RSQC_COUNT(cnt, RSQC_C_END2_SENSE, LaneMask{one & ~end1 & sense}); RSQC_COUNT(cnt, RSQC_C_END2_ANTISENSE, LaneMask{one & ~end1 & ~sense});
+    }
+}
 // true: the call was handled here.  `onm`: lanes that hold a record (the low n lanes).
 __device__ __forceinline__ bool k1e_uniform1(const DevAnnotation &a, const DevParams &p, uint32_t *cov_diff, const ContigInfo &ci, K1eTables &T,
                                              int32_t bs, uint32_t len, uint32_t flhq, uint64_t qhash, uint32_t qh2, uint64_t onm,
@@ -552,24 +574,7 @@ __device__ __forceinline__ bool k1e_uniform1(const DevAnnotation &a, const DevPa
     if (!globin) {                                                                              // :363,395-404
         RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, LaneMask{onm}); RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, LaneMask{onm & dupm});
     }
-    {   // class_counts_b with uniform class flags: one class for the whole call (:407-457)
-        const uint32_t cf = ei_class_flags(S.mask, RSQC_STRAND_UNKNOWN);
-        const bool exonic = (cf & CF_EXONIC) != 0, intragenic = (cf & CF_INTRAGENIC) != 0;
-        const int cls = !exonic ? (intragenic ? RSQC_C_INTRONIC_READS : RSQC_C_INTERGENIC_READS) : (va ? RSQC_C_EXONIC_READS : RSQC_C_AMBIGUOUS_READS);
-        static_assert(RSQC_C_HQ_INTRONIC_READS == RSQC_C_INTRONIC_READS + 2 && RSQC_C_HQ_INTERGENIC_READS == RSQC_C_INTERGENIC_READS + 1 &&
-                      RSQC_C_HQ_EXONIC_READS == RSQC_C_EXONIC_READS + 1 && RSQC_C_HQ_AMBIGUOUS_READS == RSQC_C_AMBIGUOUS_READS + 1, "counter order");
-        k1e_count_at(cnt, cls, n_on); k1e_count_at(cnt, cls + (cls == RSQC_C_INTRONIC_READS ? 2 : 1), n_hq);
-        if ((!exonic && intragenic) || (exonic && va)) { k1e_count_at(cnt, RSQC_C_INTRAGENIC_READS, n_on); k1e_count_at(cnt, RSQC_C_HQ_INTRAGENIC_READS, n_hq); }
-        if (cf & CF_RIBOSOMAL) k1e_count_at(cnt, RSQC_C_RRNA_READS, n_on);
-        const bool plus = (cf & CF_PLUS) != 0, minus = (cf & CF_MINUS) != 0;
-        if (plus != minus) {                                                                    // :445-457
-            const uint64_t one = p.unpaired ? onm : (onm & WS::prim((flhq & RSQC_FPAIRED) != 0).m);
-            const uint64_t revm = WS::prim((flhq & RSQC_FREVERSE) != 0).m, sense = minus ? revm : ~revm;
-            const uint64_t end1 = p.unpaired ? ~0ull : WS::prim((flhq & RSQC_FREAD1) != 0).m;
-            RSQC_COUNT(cnt, RSQC_C_END1_SENSE, LaneMask{one & end1 & sense}); RSQC_COUNT(cnt, RSQC_C_END1_ANTISENSE, LaneMask{one & end1 & ~sense});
-            RSQC_COUNT(cnt, RSQC_C_END2_SENSE, LaneMask{one & ~end1 & sense}); RSQC_COUNT(cnt, RSQC_C_END2_ANTISENSE, LaneMask{one & ~end1 & ~sense});
-        }
-    }
+    k1e_uniform_class_counts(p, ei_class_flags(S.mask, RSQC_STRAND_UNKNOWN), va, flhq, onm, n_on, n_hq, cnt);
     // ---- k1e_commit<1>: high-quality records of a call that has a gene (:377-392) -------------------------------------------------
     if (!va || hqm == 0ull) return true;
     const uint64_t hvm = hqm & WS::prim(len > 0).m;                                              // (a zero-length block commits nothing)
@@ -590,6 +595,158 @@ __device__ __forceinline__ bool k1e_uniform1(const DevAnnotation &a, const DevPa
     if (!(K1E_ABL & 8)) {
         k1e_emit_pairs(T, hvm, gX, qhash, qh2, pd, blockIdx.x);
         if (vb) k1e_emit_pairs(T, hvm, g1, qhash, qh2, pd, blockIdx.x);
+    }
+    return true;
+}
+
+// ---- two-block calls whose 64 records cross ONE junction (round 6, third session) ---------------------------------------------------
+// The analogue of k1e_uniform1 for the two-block queue.  Its records are neighbours in the sorted stream of a spliced gene: on the contract
+// workload 70 % of the two-block calls have every first block inside ONE elementary interval (the exon in front of the junction) and every
+// second block inside ONE other (the exon behind it).  Two scalar look-ups (both rank words in flight together, then both entries) and four
+// compares per lane decide that; then exon_metrics_ei<2> is a computation on SCALARS -- containing exons, the intersection of the two gene
+// sets, class flags, globin, the commit slots -- and k1e_commit<2> shrinks to one exon add per block and slot (the sum of the lanes' block
+// lengths times 1 / aligned when the lanes share one aligned length -- reads of one length; lane by lane otherwise), one gene add per gene,
+// and the per-lane coverage slots and (gene, name) pairs.
+// A block that ENDS on its interval's last base has be = bs + len on the next interval's first position (blocks are [bs, bs + len], both
+// ends inclusive: src/Expression.cpp:111) -- every first block of a spliced read does.  Such a block takes the next interval's class bits
+// too (ei_resolve: m_je), its containing exons stay the first interval's (find(max(bs, be - 1)), src/GTF.cpp:181-186): the call stays
+// uniform when ALL of its lanes touch the next interval or none does.
+// MEASURED AND LEFT OFF (call r6x, profiles/r6_k1_variants.txt): K1 2.231 / 2.244 ms with the path, 2.203 without, same box.  The path trades
+// ~150 vector instructions of a general two-block call for ~400 SCALAR ones (the gene-set logic and the commit's bookkeeping on SGPRs), and
+// the CU's one scalar port is the kernel's tighter floor (1.17 ms against 0.73 ms for the vector pipes) -- the same reason
+// k1e_uniform1 measures +-0.  Opt-in build (-DK1E_UNIFORM2=1); the host emulation's superset build runs it (tests/hostemu, build_k1).
+#ifndef K1E_UNIFORM2
+#define K1E_UNIFORM2 0
+#endif
+struct K1eInterval2 { EiEntry S[2]; int32_t next_pos[2]; uint32_t next_mask[2]; };          // (wave-uniform)
+__device__ __forceinline__ K1eInterval2 k1e_intervals_of(const DevAnnotation &a, const ContigInfo &ci, int32_t x0, int32_t x1) {
+    const int32_t top = (int32_t)(ci.rk_words << 6) - 1;
+    const int32_t xc0 = x0 < 0 ? 0 : (x0 > top ? top : x0), xc1 = x1 < 0 ? 0 : (x1 > top ? top : x1);
+    const uint32_t word0 = ci.rk_base + ((uint32_t)xc0 >> 6), word1 = ci.rk_base + ((uint32_t)xc1 >> 6);
+    K1eInterval2 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x4 w0, w1;
+    asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(w0), "=&s"(w1) : "s"(a.ei_rank), "s"(word0 * 16u), "s"(word1 * 16u));
+    const uint64_t t0 = (((uint64_t)w0.y << 32) | (uint64_t)w0.x) << (63u - ((uint32_t)xc0 & 63u));
+    const uint64_t t1 = (((uint64_t)w1.y << 32) | (uint64_t)w1.x) << (63u - ((uint32_t)xc1 & 63u));
+    const uint32_t j0 = w0.z + (uint32_t)__popcll(t0) - 1u, j1 = w1.z + (uint32_t)__popcll(t1) - 1u;
+    u32x16 e0, e1;                                              // entry j and the first words of entry j + 1 (the table ends with a terminator entry)
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(e0), "=&s"(e1) : "s"(a.ei), "s"(j0 * 32u), "s"(j1 * 32u));
+    r.S[0] = EiEntry{(int32_t)e0.s0, e0.s1, e0.s2, e0.s3, e0.s4, e0.s5, e0.s6, e0.s7}; r.next_pos[0] = (int32_t)e0.s8; r.next_mask[0] = e0.s9;
+    r.S[1] = EiEntry{(int32_t)e1.s0, e1.s1, e1.s2, e1.s3, e1.s4, e1.s5, e1.s6, e1.s7}; r.next_pos[1] = (int32_t)e1.s8; r.next_mask[1] = e1.s9;
+#else
+    const int32_t xc[2] = {xc0, xc1}; const uint32_t word[2] = {word0, word1};
+    for (int b = 0; b < 2; ++b) {
+        const EiRank w = a.ei_rank[word[b]];
+        const uint64_t t = (((uint64_t)w.hi << 32) | (uint64_t)w.lo) << (63u - ((uint32_t)xc[b] & 63u));
+        const uint32_t j = w.rank + (uint32_t)__builtin_popcountll(t) - 1u;
+        r.S[b] = a.ei[j]; r.next_pos[b] = a.ei[j + 1].pos; r.next_mask[b] = a.ei[j + 1].mask;
+    }
+#endif
+    return r;
+}
+// true: the call was handled here.  `onm`: lanes that hold a record (the low n lanes).
+__device__ __forceinline__ bool k1e_uniform2(const DevAnnotation &a, const DevParams &p, uint32_t *cov_diff, const ContigInfo &ci, K1eTables &T,
+                                             const int32_t (&bs)[2], const uint32_t (&len)[2], uint32_t flhq, uint64_t qhash, uint32_t qh2,
+                                             uint64_t onm, WaveSink &cnt, const K1ePairDst &held) {
+    typedef WaveSink WS;
+    if (p.stranded != RSQC_STRAND_UNKNOWN || ci.rk_words == 0u) return false;
+    const K1eInterval2 iv = k1e_intervals_of(a, ci, (int32_t)lane_value((uint32_t)bs[0], 0), (int32_t)lane_value((uint32_t)bs[1], 0));   // (lane 0 holds a record: n >= 1)
+    if ((iv.S[0].mask | iv.S[1].mask) & EIM_DEEP) return false;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int32_t lo = iv.S[b].pos, hi = iv.next_pos[b] > iv.S[b].pos ? iv.next_pos[b] : 0x7FFFFFFF;    // (next_pos <= pos: the contig's last interval)
+        const int32_t be = bs[b] + (int32_t)len[b];
+        if ((WS::prim(bs[b] < lo || bs[b] >= hi || be > hi).m & onm) != 0ull) return false;
+        const uint64_t touch = WS::prim(be == hi).m & onm;
+        if (touch != 0ull && touch != onm) return false;
+        mask |= iv.S[b].mask | (touch != 0ull ? iv.next_mask[b] & ~EIM_DEEP : 0u);
+    }
+#if defined(RSQC_WAVE_EMU)
+    if (lane_id() == 0) ++g_k1e_uniform2_calls;
+#endif
+    // ---- exon_metrics_ei<2> with js == j1 the looked-up interval of each block in every lane: every value below is wave-uniform ---------
+    uint32_t eid[4], cd[4], con = 0, ma = 0, mb = 0, la = 0, lb = 0;
+    bool va = false, vb = false, ga = false, gb = false;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const EiEntry &S = iv.S[b];
+        const bool cA = S.eidA != EI_NONE, cB = S.eidB != EI_NONE, c0 = cA || cB, c1 = cA && cB;
+        const uint32_t g0 = S.gfA & ROW_GENE_MASK, g1 = S.gfB & ROW_GENE_MASK;
+        const uint32_t gX = cA ? g0 : g1, gfX = cA ? S.gfA : S.gfB;
+        eid[2 * b] = cA ? S.eidA : S.eidB; cd[2 * b] = cA ? S.cdA : S.cdB; eid[2 * b + 1] = S.eidB; cd[2 * b + 1] = S.cdB;
+        con |= (c0 ? 1u : 0u) << (2 * b) | (c1 ? 1u : 0u) << (2 * b + 1);
+        if (b == 0) {                                                                           // genes.front(), :363-367
+            la = gX; va = c0; ga = c0 && ((gfX >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+            lb = g1; vb = c1 && g1 != gX; gb = vb && ((S.gfB >> ROW_FLAG_SHIFT) & ROWF_GLOBIN) != 0;
+            ma = (c0 ? 1u : 0u) | ((c1 && g1 == gX) ? 2u : 0u); mb = vb ? 2u : 0u;
+        } else {                                                                                // set_intersection, :368-374
+            const bool a_in = (c0 && la == gX) || (c1 && la == g1), b_in = (c0 && lb == gX) || (c1 && lb == g1);
+            va = va && a_in; vb = vb && b_in;
+            ma |= ((c0 && la == gX) ? 1u : 0u) << 2 | ((c1 && la == g1) ? 1u : 0u) << 3;
+            mb |= ((c0 && lb == gX) ? 1u : 0u) << 2 | ((c1 && lb == g1) ? 1u : 0u) << 3;
+        }
+    }
+    ga = ga && va; gb = gb && vb;
+    const bool any_gene = va || vb;
+    const uint64_t hqm = WS::prim((flhq & K1E_HQ) != 0).m & onm, dupm = WS::prim((flhq & RSQC_FDUP) != 0).m;
+    const uint32_t n_on = (uint32_t)__popcll(onm), n_hq = (uint32_t)__popcll(hqm);
+    if (!(ga || gb)) {                                                                          // :363,395-404
+        RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_READS, LaneMask{onm}); RSQC_COUNT(cnt, RSQC_C_NON_GLOBIN_DUPLICATE_READS, LaneMask{onm & dupm});
+    }
+    k1e_uniform_class_counts(p, ei_class_flags(mask, RSQC_STRAND_UNKNOWN), any_gene, flhq, onm, n_on, n_hq, cnt);
+    // ---- k1e_commit<2>: high-quality records of a call that has a gene (:377-392) -------------------------------------------------
+    if (!any_gene || hqm == 0ull) return true;
+    const uint32_t cmask = con & ((va ? ma : 0u) | (vb ? mb : 0u));
+    const K1ePairDst pd = K1E_LAZYPAIR ? k1e_pair_dst() : held;
+    const uint32_t aligned = len[0] + len[1];
+    const bool first = k1e_first_lane();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const uint32_t bits = (cmask >> (2 * b)) & 3u;                                          // (bit 1 only with bit 0: con, and B is the same gene's or the second gene's)
+        if (bits == 0u) continue;
+        const uint32_t ln = len[b];
+        const uint64_t hvm = hqm & WS::prim(ln > 0).m;                                          // (a zero-length block commits nothing)
+        if (hvm == 0ull) continue;
+        const bool hv = WS::lane(LaneMask{hvm});
+        if (!(K1E_ABL & 2)) {
+            // exonCounts[eid] += len / aligned (src/Expression.cpp:345): the lanes share the exon; when they also share the aligned length
+            // (the first committing lane's) the call adds (sum of their block lengths) * (1 / aligned) once, as k1e_commit does per run
+            const uint32_t al0 = lane_value(aligned, __ffsll((unsigned long long)hvm) - 1);
+            if ((hvm & WS::prim(aligned != al0).m) == 0ull) {
+                const uint32_t tot = wave_sum_u32_full(hv ? ln : 0u);
+                const double frac = (double)tot * (1.0 / (double)al0);
+                if (first && (bits & 1u)) T.exon_add(eid[2 * b], frac);
+                if (first && (bits & 2u)) T.exon_add(eid[2 * b + 1], frac);
+            } else if (hv) {
+                const double frac = (double)ln * (1.0 / (double)aligned);
+                if (bits & 1u) T.exon_add(eid[2 * b], frac);
+                if (bits & 2u) T.exon_add(eid[2 * b + 1], frac);
+            }
+        }
+        if (!(K1E_ABL & 4)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (bits & (1u << j)) {
+                    const uint32_t base = cd[2 * b + j] + (uint32_t)bs[b];
+                    cov_add_merged(cov_diff, hvm, base, 1u); cov_add_merged(cov_diff, hvm, base + ln, 0xFFFFFFFFu);
+                }
+        }
+    }
+    const uint64_t m = hqm & WS::prim(aligned > 0).m;                                           // (exon_metrics_ei: hits only with aligned > 0)
+    if (m == 0ull) return true;
+    const uint32_t n0 = (uint32_t)__popcll(m), nd0 = (uint32_t)__popcll(m & ~dupm);
+    const uint32_t hit0 = va ? la : lb;
+    if (!(K1E_ABL & 8)) k1e_emit_pairs(T, m, hit0, qhash, qh2, pd, blockIdx.x);
+    if (first && !(K1E_ABL & 2)) T.gene_add(hit0, n0, nd0);
+    if (va && vb) {
+        if (!(K1E_ABL & 8)) k1e_emit_pairs(T, m, lb, qhash, qh2, pd, blockIdx.x);
+        if (first && !(K1E_ABL & 2)) T.gene_add(lb, n0, nd0);
     }
     return true;
 }
@@ -635,13 +792,20 @@ __device__ __forceinline__ void k1e_process(const DevAnnotation &a, const DevPar
     const uint32_t qh2 = qh2col ? ld32(qh2col, idx) : 0u;        // (uniform branch: the batch carries second name hashes or it does not)
     K1E_SMARK(1);                                          // [1] queue entries read
     WaveSink cnt;
-    if (NB != 1 || !K1E_UNIFORM1 || !k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, n >= 64u ? ~0ull : (1ull << n) - 1ull, cnt, held, wave)) {
+    const uint64_t onm = n >= 64u ? ~0ull : (1ull << n) - 1ull;
+    bool done = false;
+    if (NB == 1 && K1E_UNIFORM1) done = k1e_uniform1(a, p, cov_diff, ci, S.T, bs[0], len[0], flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, onm, cnt, held, wave);
+    if (NB == 2 && K1E_UNIFORM2) {
+        const int32_t b2[2] = {bs[0], bs[NB - 1]}; const uint32_t l2[2] = {len[0], len[NB - 1]};
+        done = k1e_uniform2(a, p, cov_diff, ci, S.T, b2, l2, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, onm, cnt, held);
+    }
+    if (!done) {
         EiOut eo; bool over = false;
         exon_metrics_ei<NB, WaveSink>(a, p, ci, flhq & 0xFFFFu, bs, len, (flhq & K1E_HQ) != 0, eo, over, cnt, on, (uint32_t)NB, pre0);
         k1e_overflow(on && over, (uint64_t)idx);
         k1e_commit<NB>(cov_diff, S.T, eo, len, flhq, (uint64_t)qh.x | ((uint64_t)qh.y << 32), qh2, held, blockIdx.x);
         K1E_SMARK(6);                                      // [6] commit (LDS tables, coverage atomics, pairs)
-    } else { K1E_SMARK(7); }                               // [7] a one-block call answered by the wave-uniform path, whole
+    } else { K1E_SMARK(7); }                               // [7] a one- or two-block call answered by a wave-uniform path, whole
     if (k1e_lane_below<RSQC_N_COUNTERS>() && cnt.vec) atomicAdd(&S.T.cnt32[l], cnt.vec);
 }
 

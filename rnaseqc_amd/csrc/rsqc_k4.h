@@ -142,7 +142,10 @@ struct K4LocalShared {
 };
 
 #ifdef __HIPCC__
-#define RSQC_K4L_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))   // three workgroups per CU (<= 80 VGPRs): at 90 two fit, +20 % time
+#ifndef RSQC_K4L_WAVES
+#define RSQC_K4L_WAVES 6
+#endif
+#define RSQC_K4L_OCC __attribute__((amdgpu_waves_per_eu(RSQC_K4L_WAVES, RSQC_K4L_WAVES)))   // three workgroups per CU (<= 80 VGPRs): at 90 two fit, +20 % time
 #else
 #define RSQC_K4L_OCC
 #endif

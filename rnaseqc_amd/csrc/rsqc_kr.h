@@ -82,7 +82,11 @@ read_length_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc, uint3
                     vmin = wave_min_u32(lm);
                     from = w + 1;
                 }
-                need &= __ballot(S > (cur_max < vmin ? cur_max : vmin));
+                // the tiles of this group still to look at, against the thresholds as they are NOW: a walk's state can go DOWN (a spliced
+                // record's span fires it and leaves its shorter l_qseq), and a later tile whose largest span lies between the new state and
+                // the old one then counts again -- narrowing the first ballot's mask missed it (found by the round-6 junction test of
+                // tests/test_k1_wave_emulation.py: reads of mixed lengths in fewer than 64 tiles)
+                need = __ballot(S > (cur_max < vmin ? cur_max : vmin)) & (tl == 63 ? 0ull : ~((2ull << tl) - 1ull));
             }
         }
     }

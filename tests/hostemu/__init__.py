@@ -54,8 +54,8 @@ _K1SO_DEFAULT = os.path.join(_HERE, "libk1emu_default.so")
 
 
 def build_k1(coarse=True):
-    """coarse=True: the kernel with its opt-in coarse-table path compiled in (-DK1E_COARSE: a superset of the default code, so the
-    suite exercises both look-up paths); coarse=False: the product's default configuration."""
+    """coarse=True: the kernel with its opt-in paths compiled in (-DK1E_COARSE, the coarse table; -DK1E_UNIFORM2=1, the wave-uniform
+    two-block path: a superset of the default code, so the suite exercises all look-up paths); coarse=False: the product's default configuration."""
     csrc = os.path.join(_ROOT, "rnaseqc_amd", "csrc")
     so = _K1SO if coarse else _K1SO_DEFAULT
     srcs = [os.path.join(_HERE, "k1_emu.cpp"), os.path.join(_HERE, "wavemu.h")] + \
@@ -64,7 +64,7 @@ def build_k1(coarse=True):
     # (RSQC_EMU_DEFS="-DK1E_..." : the emulation of an A/B build of the kernel; remove the .so files before and after)
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
-                               "-Wno-unused-variable"] + (["-DK1E_COARSE"] if coarse else []) + os.environ.get("RSQC_EMU_DEFS", "").split() + [srcs[0], "-o", so])
+                               "-Wno-unused-variable"] + (["-DK1E_COARSE", "-DK1E_UNIFORM2=1"] if coarse else []) + os.environ.get("RSQC_EMU_DEFS", "").split() + [srcs[0], "-o", so])
     return so
 
 
@@ -94,6 +94,8 @@ def run_k1(params, ann, batch, grid=2, want_cov=False, slow_kernel=True, coarse=
     o.n_uniform = int(lib.k1emu_uniform_calls())
     lib.k1emu_ucache_hits.restype = C.c_ulonglong
     o.n_ucache_hits = int(lib.k1emu_ucache_hits())
+    lib.k1emu_uniform2_calls.restype = C.c_ulonglong
+    o.n_uniform2 = int(lib.k1emu_uniform2_calls())
     return o
 
 

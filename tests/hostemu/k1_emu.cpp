@@ -41,6 +41,7 @@ struct SlowAccH {
 
 extern "C" __attribute__((visibility("default"))) unsigned long long k1emu_uniform_calls() { return g_k1e_uniform_calls; }
 extern "C" __attribute__((visibility("default"))) unsigned long long k1emu_ucache_hits() { return g_k1e_ucache_hits; }
+extern "C" __attribute__((visibility("default"))) unsigned long long k1emu_uniform2_calls() { return g_k1e_uniform2_calls; }
 
 // returns 0, an RSQC_ERR_* code, or 1000 + k for a failed internal check k
 extern "C" __attribute__((visibility("default")))
@@ -143,7 +144,7 @@ int k1emu_run_bed(const rsqc_params *p, const rsqc_annotation *a, const rsqc_bat
     acc.rl_stats = rl_stats.data(); acc.read_length = &rl_state; acc.error = &error;
 
     const K1Args A{d, dp, db, acc};
-    g_k1e_args = &A; g_k1e_coarse_hits = 0; g_k1e_uniform_calls = 0; g_k1e_ucache_hits = 0;
+    g_k1e_args = &A; g_k1e_coarse_hits = 0; g_k1e_uniform_calls = 0; g_k1e_ucache_hits = 0; g_k1e_uniform2_calls = 0;
     wavemu::grid_dim().x = (uint32_t)grid;
     for (int k = 0; k < grid; ++k) {
         wavemu::block_idx().x = (uint32_t)k;

@@ -690,3 +690,21 @@ def test_names_sharing_one_64_bit_hash_boundary(oracle_lib, n_names, ok):
         with pytest.raises(engine.EngineError) as e:
             engine.run_engine(p, ann, [b])
         assert e.value.code == abi.ERR_CAPACITY
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_spliced_reads_on_shared_junctions(oracle_lib, seed):
+    """The two-block calls of one junction's reads (classify_ei_kernel's wave-uniform two-block path, rsqc_k1.h k1e_uniform2) beside calls
+    that splice elsewhere (general path): two genes sharing an exon, an exon under a second exon of its gene, a globin, an rRNA gene, soft
+    clips / insertions (mixed aligned lengths), zero-length blocks -- device = oracle in full, unstranded (uniform path on) and stranded (off).
+    The reads have MIXED lengths in fewer than 64 tiles: the case in which read_length_kernel's tile gate must re-open tiles when a
+    spliced record lowers the state (src/RNASeQC.cpp:275-278; the gate was only ever narrowed before round 6's third session)."""
+    from tests.test_k1_wave_emulation import junction_case
+    ann, batch = junction_case(900 + seed, n_per_junction=2500)
+    for kw in (dict(), dict(unpaired=1, mapq_threshold=3), dict(stranded=abi.STRAND_FORWARD)):
+        p = abi.default_params(**kw)
+        want = oracle_lib.run_oracle(p, ann, [batch])
+        assert want.gene_reads.sum() > 3000
+        assert_results_match(engine.run_engine(p, ann, [batch]), want)
+        parts = [batch.slice(0, 4001), batch.slice(4001, batch.n)]
+        assert_results_match(engine.run_engine(p, ann, parts), want)

@@ -324,3 +324,78 @@ def test_dense_one_block_tiles_take_the_uniform_path(oracle_lib, seed):
             else:
                 assert o.n_uniform == 0 and o.n_ucache_hits == 0     # --stranded: the containing exons are a per-lane property
     assert want.gene_reads.sum() > 300 and want.counters[abi.COUNTER_NAMES.index("rRNA Reads")] > 0
+
+
+def junction_case(seed, n_per_junction=420):
+    """Spliced reads packed onto the junctions of a few genes: two genes that share an exon stretch (two-gene sets, the intersection over
+    the blocks drops one of them), a globin, an rRNA gene on the other strand, an exon under a second exon of its own gene.  Most reads
+    end their first block ON the last base of an exon and start the second on the first base of the next (the rule for a spliced
+    alignment); some splice inside the exons, some carry soft clips / insertions (another aligned length), a zero-length block, low
+    MAPQ, the duplicate flag.  The 64-record calls of the two-block queue are then mostly ONE junction's reads: k1e_uniform2."""
+    from rnaseqc_amd.abi import CIG_M as M, CIG_S as S, CIG_N as N, CIG_I as I
+    rng = np.random.default_rng(seed)
+    rows = []
+    def gene(gid, name, strand, ttype, exons, extra=()):
+        gs, ge = min(e[0] for e in exons), max(e[1] for e in exons)
+        rows.append(dict(contig="c", type="gene", start=gs, end=ge, strand=strand, gene_id=gid, gene_name=name, transcript_type=ttype))
+        for k, (es, ee) in enumerate(list(exons) + list(extra)):
+            rows.append(dict(contig="c", type="exon", start=es, end=ee, strand=strand, gene_id=gid, exon_id="%s_e%d" % (gid, k), gene_name=name, transcript_type=ttype))
+    g1 = [(1000, 1120), (1400, 1490), (1800, 1950)]
+    gene("G1", "N1", "+", "protein_coding", g1)
+    gene("G2", "N2", "+", "protein_coding", [(1400, 1490), (2300, 2380)])            # shares G1's middle exon, then leaves it
+    g3 = [(3000, 3100), (3300, 3420), (3700, 3800)]
+    gene("G3", "HBB", "-", "protein_coding", g3, extra=[(3320, 3400)])               # an exon under a second exon of its own gene
+    g4 = [(5000, 5090), (5200, 5300)]
+    gene("G4", "N4", "-", "rRNA", g4)
+    ann = Annotation.from_rows(["c"], rows)
+    junctions = [(g1[0][1], g1[1][0]), (g1[1][1], g1[2][0]), (1490, 2300), (g3[0][1], g3[1][0]), (g3[1][1], g3[2][0]), (g4[0][1], g4[1][0])]
+    recs = []
+    for jn, (e_end, s_next) in enumerate(junctions):                               # 1-based closed exon end / next exon start
+        noise = 0.003 if jn % 2 == 0 else 0.15                                     # every other junction: many reads spliced somewhere else
+        for _ in range(n_per_junction):
+            l0, l1 = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+            shift = 0 if rng.random() >= noise else int(rng.integers(-6, 7))        # ... into the intron or inside the exon
+            pos = e_end - l0 + shift                                               # 0-based start: the block's last base is e_end + shift
+            gap = (s_next - 1) - (pos + l0)
+            if rng.random() < noise:
+                gap += int(rng.integers(-4, 5))
+            if gap < 1:
+                gap = 1
+            cig = [(M, l0), (N, gap), (M, 0 if rng.random() < 0.01 else l1)]
+            v = rng.random()
+            if v < 0.12:
+                cig = [(S, 4)] + cig
+            elif v < 0.2:
+                cig = cig + [(I, 3)]
+            flag = (0x1 if rng.random() < 0.9 else 0) | (0x2 if rng.random() < 0.9 else 0) | (0x10 if rng.random() < 0.5 else 0) | \
+                   (0x40 if rng.random() < 0.5 else 0x80) | (0x400 if rng.random() < 0.1 else 0)
+            recs.append(dict(qname="q%d" % int(rng.integers(0, n_per_junction * 3)), tid=0, pos=int(pos), cigar=cig, flag=flag,
+                             mapq=int(rng.choice([0, 3, 60, 255, 255, 255, 255])), nm=int(rng.integers(0, 7)) if rng.random() < 0.9 else None,
+                             mpos=int(pos) + int(rng.integers(0, 300)), mtid=0))
+    for pos in rng.integers(900, 5400, 600):                                       # one-block reads between them
+        recs.append(dict(qname="s%d" % len(recs), tid=0, pos=int(pos), cigar=[(M, int(rng.integers(5, 40)))], flag=0x1 | 0x2 | 0x40, mapq=255, nm=0,
+                         mpos=int(pos) + 100, mtid=0))
+    recs.sort(key=lambda r: r["pos"])
+    return ann, Batch.from_records(recs)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_spliced_tiles_take_the_two_block_uniform_path(oracle_lib, seed):
+    ann, batch = junction_case(900 + seed)
+    for kw in (dict(), dict(unpaired=1, mapq_threshold=3), dict(stranded=abi.STRAND_REVERSE)):
+        p = abi.default_params(**kw)
+        want = oracle_lib.run_oracle(p, ann, [batch])
+        ref = hostemu.run(p, ann, batch, mode=1, want_cov=True)
+        for grid in (1, 3):
+            o = hostemu.run_k1(p, ann, batch, grid=grid, want_cov=True, coarse=False)     # the product's configuration: general path only
+            _compare(o, want, ref.cov)
+            assert o.n_uniform2 == 0
+            o = hostemu.run_k1(p, ann, batch, grid=grid, want_cov=True, coarse=True)      # the superset build: -DK1E_UNIFORM2=1
+            _compare(o, want, ref.cov)
+            if "stranded" not in kw:
+                assert o.n_uniform2 >= 8, o.n_uniform2           # (of ~40 two-block calls; the calls with a read spliced elsewhere take the general path)
+            else:
+                assert o.n_uniform2 == 0                         # --stranded: the containing exons are a per-lane property
+    names = list(ann.gene_ids[:ann.n_genes_listed]) if hasattr(ann, "gene_ids") else []
+    assert want.gene_reads.sum() > 300 and want.counters[abi.COUNTER_NAMES.index("rRNA Reads")] > 0
+    assert int((want.gene_reads > 0).sum()) >= 4, names
