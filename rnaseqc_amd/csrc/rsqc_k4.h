@@ -343,6 +343,32 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
     if (threadIdx.x < 2) s_fresh[threadIdx.x] = 0u;
     if (threadIdx.x == 0) s_ovn = 0u;
     uint32_t round = 0;
+    // Two barriers per partition (round 6, third session; rounds 2-6: four).  What the workgroup owes a partition AFTER its inserts -- the sum of the
+    // waves' fresh keys, the distinct set-aside entries, the one add to the gene -- is settled by thread 0 behind the NEXT partition's barrier B
+    // (every wave is past the previous partition's second-hash checks when it arrives there), while the other threads insert:
+    //     clear s_keys | B | insert (thread 0 first settles the partition before) | C | second-hash checks, fresh keys into s_fresh[round & 1]
+    // No barrier is needed in front of the clear: the checks behind C read s_h2 and the set-aside list only, s_h2 is written again behind the
+    // next B, and a wave clears s_keys only after every wave has passed C, i.e. has finished its inserts.
+    bool owe = false; uint32_t owe_gene = 0u;                               // (uniform) a partition waits to be settled
+    auto settle = [&]() {                                                   // thread 0, behind a barrier that follows the partition's checks
+        const uint32_t cell = (round - 1u) & 1u;
+        uint32_t t = s_fresh[cell]; s_fresh[cell] = 0u;
+        if (s_ovn) {
+            const uint32_t m = s_ovn < OVF ? s_ovn : OVF;
+            for (uint32_t a = 0; a < m; ++a) {
+                bool first = true;
+                for (uint32_t b2 = 0; b2 < a; ++b2) if (s_ovk[b2] == s_ovk[a] && s_ov2[b2] == s_ov2[a]) first = false;
+                if (first) ++t;
+            }
+            s_ovn = 0u;                                                     // (the current partition's entries come behind its barrier C)
+        }
+        if (t) atomicAdd(&gene_frag[owe_gene], (unsigned long long)t);
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define K4_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))     /* a value every thread loaded from one address: kept in a scalar register */
+#else
+#define K4_UNI(x) ((uint32_t)(x))
+#endif
     RSQC_FIN_BEGIN
     while (w < n_parts) {
         RSQC_FIN_SECT(48, 0);
@@ -350,15 +376,15 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
         keys_of(nxt, kvn, k2n);
         if (!LISTED && cur.fuller && threadIdx.x == 0) full_list[atomicAdd(full_n, 1u)] = w;
         if (cur.fill != 0u) {                                               // (uniform)
-            const uint32_t gene = cur.info.x, cap = cur.info.y;
-            const uint32_t n = cur.fill < cap ? cur.fill : cap;
-            // the set is sized to the partition: the smallest power of two >= 2 n (most partitions hold a few hundred keys)
+            const uint32_t gene = K4_UNI(cur.info.x), cap = K4_UNI(cur.info.y), fill = K4_UNI(cur.fill);
+            const uint32_t n = fill < cap ? fill : cap;
+            // the set is sized to the partition: the smallest power of two >= 2 n, at least 64 (most partitions hold a few hundred keys)
             uint32_t slots = 64;
             while (slots < 2 * n && slots < (uint32_t)SLOTS) slots <<= 1;
             const uint32_t smask = slots - 1;
-            __syncthreads();                                                // (the previous partition's set is done with)
             for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) s_keys[i] = 0ull;
-            __syncthreads();
+            __syncthreads();                                                // B
+            if (owe && threadIdx.x == 0) settle();
             RSQC_FIN_SECT(48, 1);
             uint32_t fresh = 0;
             constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
@@ -384,8 +410,8 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
             static_assert(RSQC_K4_SUB_CAP <= RSQC_K4_PART_SLOTS / 2 && RSQC_K4_PART_READS <= RSQC_K4_PART_SLOTS / 2, "a list fits the registers of its instance");
             if (n > (uint32_t)KPT * RSQC_K4_COUNT_THREADS) atomicExch(error, RSQC_ERR_CAPACITY);   // (cannot happen: capacities are <= SUB_CAP)
             // second hashes of the entries whose 64-bit key was there already (the owner's is in s_h2 once every wave is past its
-            // inserts): an entry that differs is set aside; thread 0 counts the distinct ones behind the barrier of the total
-            __syncthreads();
+            // inserts): an entry that differs is set aside; thread 0 counts the distinct ones when it settles the partition
+            __syncthreads();                                                // C
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
                 if (same[j] != NO_SLOT && s_h2[same[j]] != k2[j]) {
@@ -393,24 +419,11 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
                     if (at < OVF) { s_ovk[at] = kv[j]; s_ov2[at] = k2[j]; } else atomicExch(error, RSQC_ERR_CAPACITY);
                 }
             RSQC_FIN_SECT(48, 2);
-            fresh = wave_sum(fresh);
-            // the per-partition total alternates between two LDS cells: one barrier separates "all waves have added" from
-            // "thread 0 reads and clears"
+            fresh = wave_sum_u32_full(fresh);                               // (every lane is here: the branch above is uniform)
+            // the per-partition total alternates between two LDS cells: the partition after this one adds to the other cell, and this
+            // one's is read and cleared behind that partition's barrier B
             if (lane_id() == 0 && fresh) atomicAdd(&s_fresh[round & 1], fresh);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t t = s_fresh[round & 1]; s_fresh[round & 1] = 0u;
-                if (s_ovn) {
-                    const uint32_t m = s_ovn < OVF ? s_ovn : OVF;
-                    for (uint32_t a = 0; a < m; ++a) {
-                        bool first = true;
-                        for (uint32_t b2 = 0; b2 < a; ++b2) if (s_ovk[b2] == s_ovk[a] && s_ov2[b2] == s_ov2[a]) first = false;
-                        if (first) ++t;
-                    }
-                    s_ovn = 0u;                                             // (the next partition's entries come behind its two barriers)
-                }
-                if (t) atomicAdd(&gene_frag[gene], (unsigned long long)t);
-            }
+            owe = true; owe_gene = gene;
             ++round;
             RSQC_FIN_SECT(48, 3);
 #ifdef RSQC_K1_PROF
@@ -421,6 +434,11 @@ frag_count_kernel(const uint32_t *n_parts_at, const uint32_t *cursor, const uint
 #pragma unroll
         for (int j = 0; j < KPT; ++j) { kv[j] = kvn[j]; k2[j] = k2n[j]; }
     }
+    if (owe) {                                                              // (uniform) the last partition of the workgroup
+        __syncthreads();
+        if (threadIdx.x == 0) settle();
+    }
+#undef K4_UNI
 }
 
 }  // namespace rsqc
