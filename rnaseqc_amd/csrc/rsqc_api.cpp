@@ -540,7 +540,7 @@ int run_batch(rsqc_ctx *c, UploadedBatch *u) {
     const uint64_t chunk_cap = per_wave * (RSQC_K1_THREADS / 64) * FAST_SET;
     // --legacy: every pair comes from the general kernel (one per gene a record is counted to; 4 per record is far
     // above what annotations produce -- beyond it the run fails with RSQC_ERR_CAPACITY)
-    const uint64_t slow_cap = c->dparams.legacy ? std::max<uint64_t>(1ull << 20, 4ull * u->n) : 1ull << 20;
+    const uint64_t slow_cap = c->dparams.legacy ? std::max<uint64_t>(1ull << 20, 4ull * u->n) + (uint64_t)RSQC_SLOW_LEGACY_GRID * RSQC_SLOW_RES : 1ull << 20;
     // chunks: one per K1 workgroup, then one per workgroup of classify_long_kernel (the records K1 defers; none under --legacy)
     const int n_chunks = grid + (c->dparams.legacy ? 0 : rsqc_long_grid(grid));
     const uint64_t want = chunk_cap * (uint64_t)n_chunks + slow_cap;
@@ -1182,7 +1182,9 @@ static int run_finalize_kernels(rsqc_ctx *c, bool early_readback = false) {
                 acc.pair_chunk_cap = pb.chunk_cap; acc.pair_chunk_count = (uint32_t *)pb.counts.p;
                 acc.pair_slow_base = pb.slow_base; acc.pair_slow_cap = pb.slow_cap;
                 acc.pair_slow_count = (uint32_t *)pb.counts.p + pb.n_chunks;
-                launch_frag_local(c->stream, acc, pb.n_chunks, P, 0);
+                // (--legacy: all the batch's pairs sit in its dense region -- shared by as many workgroups as a list of that size gets below,
+                //  not by the 32 that serve the default rules' few thousand slow-path pairs: 9.3 -> ~1 ms per 100 M records)
+                launch_frag_local(c->stream, acc, pb.n_chunks, P, c->dparams.legacy ? (uint32_t)std::min<uint64_t>(4096, pb.slow_cap / 8192 + 32) : 0u);
             }
             if (!RSQC_DIAG("RSQC_DIAG_SKIP_K4")) launch_frag_count(c->stream, (uint32_t)G, P, (uint32_t)parts_bound, c->acc.gene_frag, c->acc.error);
         }

@@ -170,6 +170,11 @@ void launch_read_length(hipStream_t s, const DevAnnotation &a, const DevParams &
 // K4, streaming form (rsqc_kernels.hip): partition tables laid out on the device from the final geneCounts
 // fragment partitions (rsqc_kernels.hip, K4): a gene with n counted records owns ceil(n / PART_READS) partitions of capacity
 // SUB_CAP keys each (or one partition of capacity n); a partition's keys are counted by one workgroup in an LDS set of PART_SLOTS
+// --legacy: every record goes through classify_slow_kernel<true>, whose workgroups (at most RSQC_SLOW_LEGACY_GRID) reserve RSQC_SLOW_RES slots
+// of the batch's dense pair region at a time (one returning memory atomic; >= the pairs of one pass of a workgroup) and fill what is left of
+// their last block with empty entries: the region is sized for those too (rsqc_api.cpp), and frag_local_kernel shares it among enough workgroups
+#define RSQC_SLOW_RES 2048u
+#define RSQC_SLOW_LEGACY_GRID 4096u
 #ifndef RSQC_K4_PART_READS
 #define RSQC_K4_PART_READS 1024
 #endif

@@ -360,7 +360,11 @@ void launch_exon_gc(hipStream_t s, const DevAnnotation &a, const DevReference &R
 // that lies inside exactly ONE exon row (then exonic, alignedExons.size() == 1 and doExonMetrics hold), and
 // 100 < |InsertSize| < 1000.  A separate pass over the batch, launched only when a reference is set: the per-read
 // kernel of runs without --fasta is untouched.
-__global__ void __launch_bounds__(256)
+// 1 024 threads per workgroup: a pass reserves its candidates' slots with ONE returning atomic on the list's counter, and one address
+// completes about 88 of those per microsecond chip-wide -- with 256-record passes the 400 k reservations of 100 M records were the
+// kernel's 3.1 ms (profiles/r6_kernel_stats_fasta.txt).
+constexpr int GC_CAND_THREADS = 1024;
+__global__ void __launch_bounds__(GC_CAND_THREADS)
 gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, GcCandidates out, int *error) {
     __shared__ uint32_t s_base, s_count;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -371,7 +375,7 @@ gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, G
         bool emit = false; uint32_t row_hit = 0; int32_t endpos = 0, tid = 0; uint32_t flag_lq = 0; uint64_t qhash = 0;
         if (i < b.n) {
             Record r;
-            if (load_record(b, i, find_segment(b, i), r)) {
+            if (load_record(b, i, find_segment(b, i0), r)) {               // (the pass's first record: a wave-uniform hint, scalar loads; load_record advances from it)
                 RecordCounters rc; bool hq; uint32_t aligned; Blocks B;
                 const bool go = gate_cascade(a, p, r, rc, hq, aligned, B);
                 const int64_t isz = r.isize < 0 ? -(int64_t)r.isize : (int64_t)r.isize;
@@ -395,7 +399,9 @@ gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, G
         if (emit) {
             const uint32_t slot = s_base + my;
             if (slot < out.cap) {
-                out.file_index[slot] = batch_file_index(b, find_segment(b, i), i); out.qhash[slot] = qhash; out.row[slot] = row_hit;
+                uint32_t seg = find_segment(b, i0);
+                while (seg + 1 < b.n_seg && b.seg_start[seg + 1] <= i) ++seg;
+                out.file_index[slot] = batch_file_index(b, seg, i); out.qhash[slot] = qhash; out.row[slot] = row_hit;
                 out.h2[slot] = b.qhash2 ? b.qhash2[i] : 0u;
                 out.endpos[slot] = endpos; out.flag_lq[slot] = flag_lq; out.tid[slot] = tid;
             } else atomicExch(error, RSQC_ERR_CAPACITY);
@@ -406,8 +412,8 @@ gc_candidates_kernel(DevAnnotation a, DevParams p, DevBatch b, DevReference R, G
 void launch_gc_candidates(hipStream_t s, const DevAnnotation &a, const DevParams &p, const DevBatch &b, const DevReference &R,
                           const GcCandidates &out, int *error) {
     if (!b.n) return;
-    const uint64_t blocks = (b.n + 255) / 256;
-    hipLaunchKernelGGL(gc_candidates_kernel, dim3((unsigned)std::min<uint64_t>(blocks, 8192)), dim3(256), 0, s, a, p, b, R, out, error);
+    const uint64_t blocks = (b.n + GC_CAND_THREADS - 1) / GC_CAND_THREADS;
+    hipLaunchKernelGGL(gc_candidates_kernel, dim3((unsigned)std::min<uint64_t>(blocks, 4096)), dim3(GC_CAND_THREADS), 0, s, a, p, b, R, out, error);
 }
 
 
@@ -485,7 +491,7 @@ void launch_classify_slow(hipStream_t s, const DevAnnotation &a, const DevParams
                           const DevAccum &acc) {
     if (p.legacy) {
         const uint64_t blocks = (b.n + RSQC_SLOW_THREADS - 1) / RSQC_SLOW_THREADS;
-        hipLaunchKernelGGL(classify_slow_kernel<true>, dim3((unsigned)std::min<uint64_t>(blocks ? blocks : 1, 4096)), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
+        hipLaunchKernelGGL(classify_slow_kernel<true>, dim3((unsigned)std::min<uint64_t>(blocks ? blocks : 1, RSQC_SLOW_LEGACY_GRID)), dim3(RSQC_SLOW_THREADS), 0, s, a, p, b, acc);
     } else {
         // the number of listed records is only known on the device: enough workgroups for 1 record in 200 to take ONE record per
         // thread (the code is a chain of dependent loads: parallelism, not iterations); workgroups beyond the list leave at once
