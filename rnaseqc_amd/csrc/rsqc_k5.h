@@ -5,7 +5,7 @@
 
 namespace rsqc {
 
-constexpr uint32_t PB_MEAN = 512;            // candidates per bucket on average (the name hashes are fmix64 outputs: Poisson)
+constexpr uint32_t PB_MEAN = 384;            // candidates per bucket on average (the name hashes are fmix64 outputs: Poisson; <= 512, the hashed pairing's limit, in all but one bucket in 10^9)
 constexpr uint32_t PB_CAP = 2048;            // LDS slots of the per-bucket sort; a fuller bucket is listed and sorted in memory (pair_bucket_big_*)
 constexpr int PB_THREADS = 256;
 constexpr uint32_t SIZE_TABLE = 1u << 20;    // direct histogram of |isize| below this; larger values are listed
@@ -77,6 +77,63 @@ __device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint
             __syncthreads();
         }
     return m;
+}
+
+// The same grouping WITHOUT the sort, for the bucket every real file produces (round 6, third session): a name has one or two candidates --
+// a read and its mate -- and then "the records of a name in file order" is a comparison of two file indices.  The bucket's candidates go
+// through an LDS set keyed by a 64-bit mix of the 96-bit name; a slot counts its members and keeps the first two; `pair(first, second)`
+// (file order) is then called once per two-member slot by one thread.  The bitonic network above is 55 barrier-separated stages for
+// 1 024 slots (58 us per bucket: gc_replay_kernel 5.9 ms per 40 M candidates); this is three barriers.
+// EXACT, or not taken: a slot with a third member (a name with three or more candidates, two names whose mixes collide with a third record),
+// two members whose second hashes differ (a collision of the mix), or a bucket beyond half the set make the function return false BEFORE any call of
+// `pair`, and the caller sorts the bucket as before.
+constexpr uint32_t PH_SLOTS = 1024;
+// (the members' second hashes and file indices ride in LDS beside their candidate numbers: two members of a slot share the 64-bit mix, so equal
+//  second hashes make them one name in all 96 bits, and their order needs no gather -- going back to the candidate arrays for either made the
+//  GC statistics' replay slower than the sort, call r6ag)
+struct PairHash { unsigned long long key[PH_SLOTS]; uint32_t cnt[PH_SLOTS]; uint32_t mem[PH_SLOTS][2], mh[PH_SLOTS][2]; unsigned long long mf[PH_SLOTS][2]; uint32_t fail; };
+union PairScratch { PairBucket S; PairHash H; };
+// pair(slot, first, second): the slot's members 0 / 1 in file order (H.mem[slot][first] is the candidate seen first in the file)
+template <class F>
+__device__ __forceinline__ bool pair_bucket_hashed(PairHash &H, const uint64_t *qhash, const uint32_t *h2, const uint64_t *file_index, const uint32_t *off,
+                                                   const uint32_t *perm, F &&pair) {
+    const uint32_t lo = off[blockIdx.x], m = off[blockIdx.x + 1] - lo;
+    if (m == 0) return true;
+    if (m > PH_SLOTS / 2) return false;
+    uint32_t slots = 64;
+    while (slots < 2 * m) slots <<= 1;
+    const uint32_t mask = slots - 1;
+    for (uint32_t i = threadIdx.x; i < slots; i += PB_THREADS) { H.key[i] = 0ull; H.cnt[i] = 0u; }
+    if (threadIdx.x == 0) H.fail = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += PB_THREADS) {
+        const uint32_t c = perm[lo + i];
+        const uint32_t h = h2 ? h2[c] : 0u;
+        const unsigned long long f = file_index[c];
+        unsigned long long k = qhash[c] ^ ((unsigned long long)h * 0x9E3779B97F4A7C15ull);
+        if (k == 0ull) k = 1ull;
+        uint32_t slot = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+        bool placed = false;
+        for (uint32_t probe = 0; probe < slots; ++probe) {
+            const unsigned long long old = atomicCAS(&H.key[slot], 0ull, k);
+            if (old == 0ull || old == k) {
+                const uint32_t r = atomicAdd(&H.cnt[slot], 1u);
+                if (r < 2u) { H.mem[slot][r] = c; H.mh[slot][r] = h; H.mf[slot][r] = f; } else H.fail = 1u;
+                placed = true;
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+        if (!placed) H.fail = 1u;                                          // (cannot happen at load <= 0.5)
+    }
+    __syncthreads();
+    for (uint32_t sl = threadIdx.x; sl < slots; sl += PB_THREADS)
+        if (H.cnt[sl] == 2u && H.mh[sl][0] != H.mh[sl][1]) H.fail = 1u;   // one mix, two second hashes: two names (never seen outside crafted input)
+    __syncthreads();
+    if (H.fail) return false;                                              // (uniform: read behind the barrier)
+    for (uint32_t sl = threadIdx.x; sl < slots; sl += PB_THREADS)
+        if (H.cnt[sl] == 2u) { const uint32_t first = H.mf[sl][0] < H.mf[sl][1] ? 0u : 1u; pair(sl, first, 1u - first); }
+    return true;
 }
 
 // A listed (oversize) bucket, by ONE workgroup of 1024: its candidate indices are sorted in memory by (name hash, second hash, file
@@ -156,9 +213,30 @@ frag_replay_big_kernel(const FragCandidates c, const uint32_t *off, const uint32
 // sample: millions of atomics on one address).
 __global__ void __launch_bounds__(PB_THREADS)
 frag_replay_kernel(const FragCandidates c, const uint32_t *off, const uint32_t *perm, uint64_t *sample_file, uint32_t *sample_size, uint32_t *n_samples) {
-    __shared__ PairBucket S;
+    __shared__ PairScratch U;
+    PairBucket &S = U.S;
     __shared__ uint32_t s_n, s_base;
+    __shared__ uint32_t s_stash[PH_SLOTS / 4];                         // (hashed path) slot * 2 + member of the second records that yield a sample
     if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    // the bucket of a real file -- one or two candidates per name -- is paired by hashing (pair_bucket_hashed); anything else is sorted
+    if (pair_bucket_hashed(U.H, c.qhash, c.h2, c.file_index, off, perm, [&](uint32_t sl, uint32_t i1, uint32_t i2) {
+            const uint32_t first = U.H.mem[sl][i1], second = U.H.mem[sl][i2];
+            if (c.name[second] != c.name[first]) return;                                // :517
+            const uint32_t fs = c.flag_size[second];
+            if (!(fs >> 31) || c.endpos[second] <= c.endpos[first]) return;             // :528
+            s_stash[atomicAdd(&s_n, 1u)] = sl * 2u + i2;                                // :530 (at most one sample per two candidates: <= PH_SLOTS / 4)
+        })) {
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_samples, s_n);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < s_n; k += PB_THREADS) {
+            const uint32_t sl = s_stash[k] >> 1, i2 = s_stash[k] & 1u;
+            sample_file[s_base + k] = U.H.mf[sl][i2]; sample_size[s_base + k] = c.flag_size[U.H.mem[sl][i2]] & 0x7FFFFFFFu;
+        }
+        return;
+    }
+    __syncthreads();
     const uint32_t m = pair_bucket_sorted(S, c.qhash, c.h2, c.file_index, off, perm);
     __syncthreads();
     uint64_t my_file[2]; uint32_t my_size[2]; uint32_t mine = 0;       // a thread owns the names that START at its slots j, j + 256, ...: a handful of samples
@@ -191,9 +269,33 @@ frag_replay_kernel(const FragCandidates c, const uint32_t *off, const uint32_t *
 // cache lines: memory-side atomics on them serialise; the histogram is kept per workgroup in LDS and flushed once.
 __global__ void __launch_bounds__(PB_THREADS)
 gc_replay_kernel(const GcCandidates c, const uint32_t *off, const uint32_t *perm, const DevReference R, unsigned long long *bins) {
-    __shared__ PairBucket S;
+    __shared__ PairScratch U;
+    PairBucket &S = U.S;
     __shared__ uint32_t hist[RSQC_GC_BINS + 1];
     for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += PB_THREADS) hist[i] = 0u;
+    __syncthreads();
+    // the bucket of a real file -- one or two candidates per name -- is paired by hashing (pair_bucket_hashed); anything else is sorted
+    if (pair_bucket_hashed(U.H, c.qhash, c.h2, c.file_index, off, perm, [&](uint32_t sl, uint32_t i1, uint32_t i2) {
+            const uint32_t first = U.H.mem[sl][i1], second = U.H.mem[sl][i2];
+            if (c.row[second] != c.row[first]) return;                                  // :467
+            const uint32_t fl = c.flag_lq[second];
+            const int32_t p_end = c.endpos[first], endpos = c.endpos[second];
+            if (endpos <= p_end || !(fl >> 31)) return;                                 // :471
+            const int tid = c.tid[second];
+            const int64_t L = (int64_t)R.length[tid];
+            int64_t s0 = (int64_t)p_end - (int64_t)(fl & 0x7FFFFFFFu), en = endpos;     // :473
+            if (s0 < 0 || s0 >= L) return;
+            if (en > L) en = L;
+            if (en <= s0) return;
+            const double v = gc_value(gc_count(R, tid, s0, en), (uint64_t)(en - s0));
+            const unsigned int bin = (unsigned int)(v * 100.0);                         // src/RNASeQC.cpp:368
+            atomicAdd(&hist[bin < RSQC_GC_BINS ? bin : RSQC_GC_BINS], 1u);
+        })) {
+        __syncthreads();
+        for (int i = threadIdx.x; i <= RSQC_GC_BINS; i += PB_THREADS) if (hist[i]) atomicAdd(&bins[i], (unsigned long long)hist[i]);
+        return;
+    }
+    __syncthreads();
     const uint32_t m = pair_bucket_sorted(S, c.qhash, c.h2, c.file_index, off, perm);  // (ends with a barrier when m > 0)
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < m; j += PB_THREADS) {
