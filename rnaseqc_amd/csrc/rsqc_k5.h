@@ -87,6 +87,9 @@ __device__ __forceinline__ uint32_t pair_bucket_sorted(PairBucket &S, const uint
 // EXACT, or not taken: a slot with a third member (a name with three or more candidates, two names whose mixes collide with a third record),
 // two members whose second hashes differ (a collision of the mix), or a bucket beyond half the set make the function return false BEFORE any call of
 // `pair`, and the caller sorts the bucket as before.
+#if defined(RSQC_WAVE_EMU)
+static unsigned long long g_k5_hashed_buckets = 0, g_k5_sorted_buckets = 0;   // (test harness: buckets paired through the set / handed to the sort)
+#endif
 constexpr uint32_t PH_SLOTS = 1024;
 // (the members' second hashes and file indices ride in LDS beside their candidate numbers: two members of a slot share the 64-bit mix, so equal
 //  second hashes make them one name in all 96 bits, and their order needs no gather -- going back to the candidate arrays for either made the
@@ -99,6 +102,9 @@ __device__ __forceinline__ bool pair_bucket_hashed(PairHash &H, const uint64_t *
                                                    const uint32_t *perm, F &&pair) {
     const uint32_t lo = off[blockIdx.x], m = off[blockIdx.x + 1] - lo;
     if (m == 0) return true;
+#if defined(RSQC_WAVE_EMU)
+    if (threadIdx.x == 0 && m > PH_SLOTS / 2) ++g_k5_sorted_buckets;
+#endif
     if (m > PH_SLOTS / 2) return false;
     uint32_t slots = 64;
     while (slots < 2 * m) slots <<= 1;
@@ -130,6 +136,9 @@ __device__ __forceinline__ bool pair_bucket_hashed(PairHash &H, const uint64_t *
     for (uint32_t sl = threadIdx.x; sl < slots; sl += PB_THREADS)
         if (H.cnt[sl] == 2u && H.mh[sl][0] != H.mh[sl][1]) H.fail = 1u;   // one mix, two second hashes: two names (never seen outside crafted input)
     __syncthreads();
+#if defined(RSQC_WAVE_EMU)
+    if (threadIdx.x == 0) { if (H.fail) ++g_k5_sorted_buckets; else ++g_k5_hashed_buckets; }
+#endif
     if (H.fail) return false;                                              // (uniform: read behind the barrier)
     for (uint32_t sl = threadIdx.x; sl < slots; sl += PB_THREADS)
         if (H.cnt[sl] == 2u) { const uint32_t first = H.mf[sl][0] < H.mf[sl][1] ? 0u : 1u; pair(sl, first, 1u - first); }

@@ -170,9 +170,10 @@ def build_k5():
 
 def run_k5(seed, n_names, max_samples, hot=0):
     """The fragment-size KERNELS (rsqc_k5.h) on the 64-lane fiber emulation against a literal std::map walk in file order.
-    hot: records of one extra name (a bucket beyond the LDS sort).  Returns (rc, candidates, samples, kept, distinct sizes, listed buckets)."""
+    hot: records of one extra name (a bucket beyond the LDS sort); -1: one or two candidates per name + crafted collisions of the set's mix.  Returns (rc, candidates, samples, kept, distinct sizes, listed buckets)."""
     lib = C.CDLL(build_k5())
     lib.k5emu_run.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
-    stats = np.zeros(5, np.uint64)
+    stats = np.zeros(7, np.uint64)
     rc = lib.k5emu_run(seed, n_names, max_samples, hot, stats.ctypes.data)
-    return (rc,) + tuple(int(x) for x in stats)
+    run_k5.last_paths = (int(stats[5]), int(stats[6]))          # buckets paired through the LDS set / handed to the sort (pair_bucket_hashed)
+    return (rc,) + tuple(int(x) for x in stats[:5])

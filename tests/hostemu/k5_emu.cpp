@@ -30,8 +30,12 @@ template <class F> void launch(uint32_t grid, int threads, F &&body) {
 // direct table), emitted in a shuffled order like K1's atomic slots.  Returns 0 when samples kept, their (size, count) pairs and
 // the kept (file index, size) set equal the literal walk; 1000 + k for check k; -code for a device error.
 extern "C" __attribute__((visibility("default")))
-int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, int hot /* records of ONE extra name: a bucket beyond the LDS sort */, uint64_t *stats /*[5]: candidates, samples, kept, distinct sizes, listed buckets*/) {
+int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, int hot /* records of ONE extra name: a bucket beyond the LDS sort; -1: a file as sequencers write
+                 them -- one or two candidates per name -- plus, one name in 997, a DIFFERENT name crafted to share the 64-bit mix of the pairing set (rsqc_k5.h,
+                 pair_bucket_hashed) with an earlier one */, uint64_t *stats /*[7]: candidates, samples, kept, distinct sizes, listed buckets, buckets paired through the set, buckets sorted*/) {
     Rng R{seed};
+    const bool pairs_only = hot < 0; if (pairs_only) hot = 0;
+    g_k5_hashed_buckets = 0; g_k5_sorted_buckets = 0;
     struct Cand { uint64_t file, q; uint32_t h2; int32_t name, endpos; uint32_t flag_size; };
     std::vector<Cand> cands;
     uint64_t file = 1000;
@@ -39,6 +43,24 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, int hot /* recor
         uint64_t q = R.next();
         if (i % 311 == 0) q = ~0ull;                                  // (the padding key of the LDS sort, as a real name)
         uint32_t h2 = (uint32_t)R.next();
+        if (pairs_only) {
+            if (i % 997 == 996 && !cands.empty()) {        // another name on an earlier name's mix: q' ^ h2' K = q ^ h2 K (the set must hand the bucket to the sort)
+                const Cand &o = cands[R.below((uint32_t)cands.size())];
+                // (... AND its bucket: the buckets are cut on the high bits of q, so the two mixes' difference must leave them alone)
+                uint64_t d = 0;
+                do { h2 = (uint32_t)R.next(); d = ((uint64_t)o.h2 * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)h2 * 0x9E3779B97F4A7C15ull); } while (h2 == o.h2 || (d >> 50) != 0);
+                q = o.q ^ d;
+            }
+            const int k2 = 1 + (int)R.below(2);
+            const int32_t iv2 = (int32_t)R.below(50);
+            for (int j = 0; j < k2; ++j) {
+                Cand c;
+                c.q = q; c.h2 = h2; c.name = R.below(5) == 0 ? iv2 + 1 : iv2; c.endpos = 1000 + (int32_t)R.below(400);
+                c.flag_size = (80u + R.below(700)) | (R.below(4) ? 0x80000000u : 0u);
+                c.file = 0; cands.push_back(c);
+            }
+            continue;
+        }
         if (i % 313 == 0 && !cands.empty()) { const Cand &o = cands[R.below((uint32_t)cands.size())]; q = o.q; h2 = o.h2; }   // a name that comes back much later
         if (i % 47 == 0 && !cands.empty()) { q = cands[R.below((uint32_t)cands.size())].q; h2 = (uint32_t)R.next() | 1u; }  // ANOTHER name with the same 64-bit hash (differs in the second hash)
         const int k = 1 + (int)R.below(R.below(8) == 0 ? 4 : 2);
@@ -130,6 +152,6 @@ int k5emu_run(uint64_t seed, int n_names, uint32_t max_samples, int hot /* recor
     if (got_hist.size() != want_hist.size()) return 1005;
     size_t at = 0;
     for (auto &kv : want_hist) { if (got_hist[at].first != kv.first || got_hist[at].second != kv.second) return 1006; ++at; }
-    stats[0] = n; stats[1] = ns; stats[2] = n_kept; stats[3] = got_hist.size(); stats[4] = big_list[0];
+    stats[0] = n; stats[1] = ns; stats[2] = n_kept; stats[3] = got_hist.size(); stats[4] = big_list[0]; stats[5] = g_k5_hashed_buckets; stats[6] = g_k5_sorted_buckets;
     return 0;
 }

@@ -26,3 +26,17 @@ def test_one_name_with_thousands_of_records(seed, n_names, hot, max_samples):
     assert rc == 0, rc
     assert listed == 1 and n >= hot
     assert kept == min(ns, max_samples) and ns > 100
+
+
+@pytest.mark.parametrize("seed,n_names,max_samples", [(21, 6000, 1_000_000), (22, 6000, 900), (23, 120, 1_000_000), (24, 40000, 1_000_000)])
+def test_pairs_go_through_the_set_and_collisions_of_its_mix_through_the_sort(seed, n_names, max_samples):
+    """A file as sequencers write them -- one or two candidates per name -- is paired by pair_bucket_hashed (an LDS set keyed by a 64-bit mix of
+    the 96-bit name, three barriers) instead of the bitonic sort; one name in 997 is a DIFFERENT name crafted onto an earlier name's mix (and into its bucket): a slot
+    then holds two second hashes (or a third member) and the bucket must take the sort BEFORE anything is written.  Same literal walk as above."""
+    rc, n, ns, kept, distinct, _listed = hostemu.run_k5(seed, n_names, max_samples, hot=-1)
+    assert rc == 0, rc
+    hashed, sorted_ = hostemu.run_k5.last_paths
+    assert kept == min(ns, max_samples) and ns > 10
+    assert hashed + sorted_ >= 1 and (n_names < 6000 or (hashed >= 1 and sorted_ >= 1)), (hashed, sorted_)
+    if n_names >= 40000:
+        assert hashed > sorted_, (hashed, sorted_)         # most buckets hold no crafted name
