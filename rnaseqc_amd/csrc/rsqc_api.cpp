@@ -799,7 +799,7 @@ int rsqc_set_annotation(rsqc_ctx *c, const rsqc_annotation *a, const uint8_t *ow
     d.legacy = nullptr;
     if (c->params.legacy) {                       // tables of the --legacy rules (rsqc_read.h: LegacyTables)
         LegacyTables lt{};
-        UPV(lt.gr, hx.gr_rows); UPV(lt.gr_pmax, hx.g_pmax); UPV(lt.gr_range, hx.g_range); UPV(lt.ex_ord, hx.ex_ord);
+        UPV(lt.gr, hx.gr_rows); UPV(lt.gr_pmax, hx.g_pmax); UPV(lt.gr_range, hx.g_range); UPV(lt.ex_ord, hx.ex_ord); UPV(lt.gr_binhi, hx.gr_binhi);
         std::vector<LegacyTables> one(1, lt);
         UPV(d.legacy, one);
     }

@@ -34,6 +34,7 @@ struct HostIndex {
     std::vector<uint32_t> ei_coarse;
     std::vector<GeneRow> gr_rows;                     // --legacy tables (LegacyTables)
     std::vector<uint32_t> ex_ord;
+    std::vector<uint32_t> gr_binhi;                   // ... per bin of the exon bin table: first gene row with start >= (b + 1) << shift
     std::vector<ContigInfo> contig;
     std::vector<uint8_t> gene_flags, gene_owned;     // by listed gene id
     uint64_t cov_entries = 0;
@@ -295,6 +296,18 @@ struct HostIndex {
         // already in that order among themselves, so the list is their merge; without GTF positions a gene row goes
         // before the exon rows of the same start.
         gr_rows.resize((size_t)L); ex_ord.assign((size_t)E, 0);
+        // (round 6: the gene rows under the contig's bins, like the exon rows -- legacy_metrics found "the first gene row that starts behind
+        //  the read's span" by a binary search over the contig's rows: eleven dependent loads in front of every record)
+        gr_binhi.assign(ex_binhi.size(), 0);
+        for (int k = 0; k < nc; ++k) {
+            const ContigInfo &ci = contig[(size_t)k];
+            uint32_t row = g_range[(size_t)k];
+            for (uint32_t b = 0; b < ci.n_bins; ++b) {
+                const int64_t lim = ((int64_t)b + 1) << kBinShift;
+                while (row < g_range[(size_t)k + 1] && (int64_t)a->gene_row_start[row] < lim) ++row;
+                gr_binhi[(size_t)ci.bin_base + b] = row;
+            }
+        }
         const bool have_order = a->gene_row_order && a->exon_row_order;
         for (int k = 0; k < nc; ++k) {
             uint32_t gi = g_range[(size_t)k], ei = ex_range[(size_t)k], rank = 0;

@@ -120,6 +120,7 @@ struct LegacyTables {
     const int32_t *gr_pmax;            // running max of end per contig
     const uint32_t *gr_range;          // [n_contigs + 1]
     const uint32_t *ex_ord;            // per exon row: rank in the combined list
+    const uint32_t *gr_binhi;          // per bin (ContigInfo::bin_base / n_bins, DevAnnotation::bin_shift): first gene row with start >= (b + 1) << shift
 };
 
 struct DevAnnotation {
@@ -1145,8 +1146,13 @@ RSQC_HD void legacy_metrics(const DevAnnotation &a, const DevParams &p, const Re
     uint32_t last_ord = 0; bool have_last = false, last_not_split = false;   // the final value of legacyNotSplit (:159) is
                                                                              // the one of the LAST row of the result list
     const uint32_t glo = T.gr_range[r.tid], ghi = T.gr_range[r.tid + 1];
-    uint32_t lo = glo, hi = ghi;                                             // first gene row with start > se
-    while (lo < hi) { const uint32_t m = lo + ((hi - lo) >> 1); if (T.gr[m].start <= se) lo = m + 1; else hi = m; }
+    uint32_t lo = glo;                                                       // first gene row with start > se: from the bin of se, then down
+    if (ci.n_bins != 0 && se >= 0 && ghi > glo) {
+        uint32_t b = (uint32_t)se >> a.bin_shift;
+        if (b >= ci.n_bins) b = ci.n_bins - 1;
+        lo = T.gr_binhi[ci.bin_base + b];                                    // (every row from here on starts behind the bin, i.e. behind se -- or the contig's rows end)
+        while (lo > glo && T.gr[lo - 1].start > se) --lo;
+    }
     for (uint32_t gi = lo; gi > glo;) {
         --gi;
         if (T.gr_pmax[gi] < ss) break;

@@ -83,7 +83,8 @@ int hostemu_run(const rsqc_params *p, const rsqc_annotation *a, const rsqc_batch
     if (hx.gr_rows.empty()) hx.gr_rows.push_back(GeneRow{0, 0, 0, 0});
     if (hx.g_pmax.empty()) hx.g_pmax.push_back(0);
     if (hx.ex_ord.empty()) hx.ex_ord.push_back(0);
-    const LegacyTables lt{hx.gr_rows.data(), hx.g_pmax.data(), hx.g_range.data(), hx.ex_ord.data()};
+    if (hx.gr_binhi.empty()) hx.gr_binhi.push_back(0);
+    const LegacyTables lt{hx.gr_rows.data(), hx.g_pmax.data(), hx.g_range.data(), hx.ex_ord.data(), hx.gr_binhi.data()};
     d.legacy = &lt;
     std::vector<uint64_t> reads((size_t)a->n_genes, 0), unique((size_t)a->n_genes, 0);
     std::vector<double> exon_rows((size_t)a->n_exons, 0.0);
