@@ -86,6 +86,9 @@ template <class SHARED>
 struct SlowAccT {
     SHARED *S; const DevAccum *acc; const uint32_t *ex_id;
     __device__ __forceinline__ void exon_add(uint32_t row, double frac) {
+#ifdef RSQC_SLOW_ABL                                                     /* (timing-only ablation builds: 1 exon adds, 2 coverage events, 4 gene counts off) */
+        if (RSQC_SLOW_ABL & 1) return;
+#endif
         uint32_t slot = (row * 2654435761u) >> 22;                      // 10 bits
         for (int probe = 0; probe < 16; ++probe) {
             const uint32_t old = atomicCAS(&S->key[slot], 0xFFFFFFFFu, row);
@@ -95,6 +98,9 @@ struct SlowAccT {
         atomicAdd(&acc->exon_acc[ex_id[row]], frac);                    // table crowded: straight to memory
     }
     __device__ __forceinline__ void cov_add(uint32_t idx, uint32_t delta) {
+#ifdef RSQC_SLOW_ABL
+        if (RSQC_SLOW_ABL & 2) return;
+#endif
         if (SHARED::CSLOTS > 1) {
             static_assert(SHARED::CSLOTS == 1 || SHARED::CSLOTS == 8192, "13 bits of the hash");
             uint32_t slot = (idx * 2654435761u) >> 19;                  // 13 bits
@@ -106,9 +112,33 @@ struct SlowAccT {
         }
         atomicAdd(&acc->cov_diff[idx], delta);
     }
+    // --legacy (no coverage table): the +1 / -1 events of a record's blocks are HELD here, up to SLOW_EV per lane, and go out behind
+    // legacy_metrics, where the wave is converged, with identical neighbouring slots merged into one atomic (cov_add_merged, as in
+    // classify_ei_kernel): the lanes of a pass are neighbours in the sorted file, so the reads of a deeply covered exon start on the same
+    // few bases -- as plain per-lane atomics those same-address events were 9 of the kernel's 17.9 ms (call r6ak: 20.3 -> 11.4 ms per step
+    // with the events compiled out).  A record with more blocks than slots sends the surplus straight to memory.
+    static constexpr int SLOW_EV = 3;
+    uint32_t n_ev = 0, ev_idx[SLOW_EV] = {0u, 0u, 0u}, ev_len[SLOW_EV] = {0u, 0u, 0u};
     __device__ __forceinline__ void cov_range(uint32_t cidx, uint32_t len) {
         if (len == 0) return;
+        if (SHARED::CSLOTS <= 1 && n_ev < (uint32_t)SLOW_EV) { set_put<SLOW_EV>(ev_idx, (int)n_ev, cidx); set_put<SLOW_EV>(ev_len, (int)n_ev, len); ++n_ev; return; }
         cov_add(cidx, 1u); cov_add(cidx + len, 0xFFFFFFFFu);
+    }
+    // (all lanes of the wave, converged)
+    __device__ __forceinline__ void flush_events() {
+#ifdef RSQC_SLOW_ABL
+        if (RSQC_SLOW_ABL & 2) { n_ev = 0; return; }
+#endif
+#pragma unroll
+        for (int e = 0; e < SLOW_EV; ++e) {
+            const bool v = n_ev > (uint32_t)e;
+            const uint64_t m = WaveSink::prim(v).m;
+            if (m == 0ull) break;
+            const uint32_t at = v ? ev_idx[e] : 0u, ln = v ? ev_len[e] : 0u;
+            cov_add_merged(acc->cov_diff, m, at, 1u);
+            cov_add_merged(acc->cov_diff, m, at + ln, 0xFFFFFFFFu);
+        }
+        n_ev = 0;
     }
     uint32_t qh2 = 0;            // second name hash of the record being counted (0 without rsqc_batch.qhash2)
     __device__ __forceinline__ void gene_hit(uint32_t g, bool notdup, uint64_t qhash) {   // genes beyond the wave-aggregated ones
@@ -216,6 +246,7 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                 }
             }
         }
+        if (LEGACY) sacc.flush_events();                 // (the held coverage events of legacy_metrics, neighbours merged)
         // ---- scatter of the first-tier results: few records, so exon fractions and coverage go out as
         //      plain atomics; gene counts and pair slots are aggregated per wave (same-address traffic)
         for (int j = 0; j < fm.n_commit; ++j) {
@@ -282,6 +313,9 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                     }
                 }
                 wave_by_key(has, g, [&](int lead, uint32_t gg, bool, uint64_t same) {
+#ifdef RSQC_SLOW_ABL
+                    if (RSQC_SLOW_ABL & 4) return;
+#endif
                     if (l == lead) {
                         atomicAdd(&acc.gene_reads[gg], (unsigned long long)__popcll(same));
                         const uint32_t nd = (uint32_t)__popcll(same & nd_mask);
