@@ -319,6 +319,9 @@ classify_slow_kernel(DevAnnotation a, DevParams p, DevBatch b, DevAccum acc) {
                     if (l == lead) {
                         atomicAdd(&acc.gene_reads[gg], (unsigned long long)__popcll(same));
                         const uint32_t nd = (uint32_t)__popcll(same & nd_mask);
+#ifdef RSQC_SLOW_ABL
+                        if (RSQC_SLOW_ABL & 16) return;
+#endif
                         if (nd) atomicAdd(&acc.gene_unique[gg], (unsigned long long)nd);
                     }
                 });
